@@ -1,0 +1,210 @@
+/* custrings_amd.h -- C ABI of the MI355X-native columnar string engine.
+ *
+ * This is the drop-in boundary for the hot path of rapidsai/custrings: the
+ * entry points below are what the reference's host classes (NVStrings /
+ * NVCategory / NVText, /root/reference/cpp/include/) need from a device
+ * back-end for split / find / contains / replace / strip / lower,
+ * contains_re / replace_re, the category key build and tokenize / ngrams.
+ * Each function cites the reference interface it stands in for.
+ *
+ * Conventions
+ *  - Strings live in an Arrow-style device column: chars (u8), offsets
+ *    (int64, rows+1 entries), validity bitmask (LSB-first, bit=1 valid,
+ *    NULL pointer = all valid).  Columns are immutable and reference counted
+ *    internally; every producing call returns a new handle the caller must
+ *    release with cs_column_destroy (the reference's "new instance, caller
+ *    destroys" rule, NVStrings.h:52-57,156).
+ *  - Scalars (patterns, delimiters, replacement text) are host NUL-terminated
+ *    UTF-8, exactly as in the reference.
+ *  - Array arguments carry an `on_device` flag like the reference's trailing
+ *    `bool devmem` (NVStrings.h:861,907,963): non-zero = device pointer.
+ *  - Every call returns a cs_status; no C++ exception crosses the boundary.
+ *    cs_last_error() returns the thread-local message of the last failure.
+ *  - `stream` is a hipStream_t passed as void* (NULL = default stream).  Calls
+ *    that return host-visible values synchronise that stream before returning.
+ *  - There is no CPU fallback: without a usable gfx950 device every compute
+ *    call fails with CS_ERR_NO_DEVICE.
+ */
+#ifndef CUSTRINGS_AMD_H
+#define CUSTRINGS_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct cs_column cs_column;     /* device strings column            */
+typedef struct cs_regex cs_regex;       /* compiled pattern (host + device) */
+typedef struct cs_category cs_category; /* sorted unique keys + int32 codes */
+typedef void* cs_stream;                /* hipStream_t                      */
+
+typedef enum cs_status {
+  CS_OK = 0,
+  CS_ERR_INVALID_ARG = 1, /* std::invalid_argument in the reference */
+  CS_ERR_ALLOC = 2,       /* std::runtime_error("allocate error")   */
+  CS_ERR_HIP = 3,
+  CS_ERR_NO_DEVICE = 4,
+  CS_ERR_RANGE = 5, /* column does not fit an int32-offset export */
+  CS_ERR_INTERNAL = 6
+} cs_status;
+
+/* Borrowed, read-only view of a column's device buffers. */
+typedef struct cs_column_view {
+  const uint8_t* chars;
+  const int64_t* offsets; /* rows + 1 entries, offsets[0] == 0 */
+  const uint8_t* validity; /* may be NULL */
+  int64_t rows;
+  int64_t nbytes;
+  int64_t null_count;
+} cs_column_view;
+
+/* ---- library ----------------------------------------------------------- */
+int cs_version(void);
+const char* cs_last_error(void);
+int cs_device_count(void);
+/* Binds the calling thread to `device`, creates the stream-ordered memory
+ * pool and uploads the unicode tables (reference: lazy get_unicode_flags /
+ * get_charcases, NVStringsImpl.cu:69-91). Idempotent. */
+int cs_init(int device);
+/* Bytes currently held by live columns/categories on this device. */
+int64_t cs_device_bytes_in_use(void);
+
+/* ---- column construction / export -------------------------------------- */
+/* NVStrings::create_from_array (NVStrings.h:86): NULL entry = null row. */
+int cs_column_from_host_strings(const char* const* strs, int64_t rows, cs_stream stream,
+                                cs_column** out);
+/* NVStrings::create_from_offsets (NVStrings.h:116): int32 Arrow offsets,
+ * optional validity bitmask; buffers are copied. */
+int cs_column_from_offsets32(const char* chars, int64_t rows, const int32_t* offsets,
+                             const uint8_t* validity, int on_device, cs_stream stream,
+                             cs_column** out);
+/* Native ingest: int64 offsets. copy=0 wraps caller-owned DEVICE buffers that
+ * must outlive the handle (zero-copy); copy=1 copies (host or device). */
+int cs_column_from_offsets64(const uint8_t* chars, int64_t rows, const int64_t* offsets,
+                             const uint8_t* validity, int on_device, int copy,
+                             cs_stream stream, cs_column** out);
+/* NVStrings::destroy (NVStrings.h:156). NULL is ignored. */
+int cs_column_destroy(cs_column* col);
+/* NVStrings::size (NVStrings.h:167) and friends. */
+int64_t cs_column_rows(const cs_column* col);
+int64_t cs_column_nbytes(const cs_column* col);
+int64_t cs_column_null_count(const cs_column* col);
+int cs_column_get_view(const cs_column* col, cs_column_view* view);
+/* NVStrings::create_offsets (NVStrings.h:207): int32 offsets (rows+1), chars,
+ * optional bitmask.  CS_ERR_RANGE when nbytes >= 2^31. */
+int cs_column_export_offsets32(const cs_column* col, char* chars, int32_t* offsets,
+                               uint8_t* validity, int on_device, cs_stream stream);
+/* Native egress, int64 offsets. */
+int cs_column_export_offsets64(const cs_column* col, uint8_t* chars, int64_t* offsets,
+                               uint8_t* validity, int on_device, cs_stream stream);
+/* NVStrings::byte_count (NVStrings.h:354): bytes per row, -1 for null rows;
+ * *total receives the sum over non-null rows. */
+int cs_column_byte_count(const cs_column* col, int32_t* lengths, int on_device,
+                         cs_stream stream, int64_t* total);
+/* NVStrings::set_null_bitarray (NVStrings.h:225): bit=1 valid, LSB first;
+ * *null_count receives the number of cleared bits. */
+int cs_column_null_bitarray(const cs_column* col, uint8_t* bitarray, int empty_is_null,
+                            int on_device, cs_stream stream, int64_t* null_count);
+
+/* ---- per-row string ops ------------------------------------------------ */
+/* NVStrings::lower / upper (NVStrings.h:815,822; case.cu:31-97,100-170). */
+int cs_lower(const cs_column* col, cs_stream stream, cs_column** out);
+int cs_upper(const cs_column* col, cs_stream stream, cs_column** out);
+/* NVStrings::lstrip / strip / rstrip (NVStrings.h:796-808; strip.cu:30-199).
+ * to_strip NULL = " \n\t".  side: 0 both, 1 left, 2 right. */
+int cs_strip(const cs_column* col, const char* to_strip, int side, cs_stream stream,
+             cs_column** out);
+/* NVStrings::find (NVStrings.h:861; find.cu:75-120): char position of the
+ * first occurrence in [start,end), -1 not found, -2 null row.
+ * *found = number of rows with result != -1 (null rows included, as in the
+ * reference). */
+int cs_find(const cs_column* col, const char* str, int start, int end, int32_t* results,
+            int on_device, cs_stream stream, int64_t* found);
+/* NVStrings::contains (NVStrings.h:907; find.cu:237-272): 1 byte per row. */
+int cs_contains(const cs_column* col, const char* str, uint8_t* results, int on_device,
+                cs_stream stream, int64_t* found);
+/* NVStrings::replace (NVStrings.h:714; modify.cu:109-192). str NULL/empty ->
+ * CS_ERR_INVALID_ARG. */
+int cs_replace(const cs_column* col, const char* str, const char* repl, int maxrepl,
+               cs_stream stream, cs_column** out);
+/* NVStrings::split(delimiter,maxsplit,results) and split(maxsplit,results)
+ * (NVStrings.h:504,524; split.cu:734-956). delimiter NULL = whitespace.
+ * Column-major result: *out_cols is a malloc'd array of *ncols handles
+ * (release each handle, then cs_free the array). */
+int cs_split(const cs_column* col, const char* delimiter, int maxsplit, cs_stream stream,
+             cs_column*** out_cols, int* ncols);
+void cs_free(void* p);
+
+/* ---- regex -------------------------------------------------------------- */
+/* Reprog::create_from + dreprog::create_from (regcomp.cpp:954-960,
+ * regexec.cpp:12-73). Host-only compile; usable without a GPU. */
+int cs_regex_compile(const char* pattern, cs_regex** out);
+int cs_regex_destroy(cs_regex* re);
+int cs_regex_inst_count(const cs_regex* re);
+/* Flat int32 program image (layout: custrings_amd/csrc/regex_program.h). */
+int cs_regex_blob(const cs_regex* re, const int32_t** words, int* nwords);
+/* NVStrings::contains_re / match / count_re (NVStrings.h:963,975,988;
+ * count.cu:59-250). */
+int cs_contains_re(const cs_column* col, const cs_regex* re, uint8_t* results, int on_device,
+                   cs_stream stream, int64_t* found);
+int cs_match_re(const cs_column* col, const cs_regex* re, uint8_t* results, int on_device,
+                cs_stream stream, int64_t* found);
+int cs_count_re(const cs_column* col, const cs_regex* re, int32_t* results, int on_device,
+                cs_stream stream, int64_t* found);
+/* NVStrings::replace_re (NVStrings.h:766; replace.cu:110-189). */
+int cs_replace_re(const cs_column* col, const cs_regex* re, const char* repl, int maxrepl,
+                  cs_stream stream, cs_column** out);
+
+/* ---- category (dictionary encoding) ------------------------------------ */
+/* NVCategory::create_from_strings (NVCategory.h:107; NVCategory.cu:220-304):
+ * keys = sorted unique rows (null first, then unsigned bytewise order,
+ * custring.inl:240-261), codes[r] = index of row r's key. */
+int cs_category_build(const cs_column* col, cs_stream stream, cs_category** out);
+/* NVCategory::create_from_categories (NVCategory.h:121; NVCategory.cu:430-514):
+ * merged sorted-unique key set, concatenated remapped codes. */
+int cs_category_merge(const cs_category* const* cats, int ncats, cs_stream stream,
+                      cs_category** out);
+int cs_category_destroy(cs_category* cat);
+int64_t cs_category_size(const cs_category* cat);      /* NVCategory::size      */
+int64_t cs_category_keys_size(const cs_category* cat); /* NVCategory::keys_size */
+/* NVCategory::get_keys (new handle on the shared key column). */
+int cs_category_keys(const cs_category* cat, cs_column** out);
+/* NVCategory::values_cptr: borrowed device pointer to the int32 codes. */
+const int32_t* cs_category_values_ptr(const cs_category* cat);
+/* NVCategory::get_values (NVCategory.h:225). */
+int cs_category_get_values(const cs_category* cat, int32_t* out, int on_device,
+                           cs_stream stream);
+/* Multi-GPU key-set merge helper: out[i] = table[codes[i]] (codes < 0 kept). */
+int cs_remap_codes(const int32_t* codes, int64_t n, const int32_t* table, int32_t* out,
+                   cs_stream stream);
+
+/* ---- text --------------------------------------------------------------- */
+/* NVText::tokenize(strs, delimiter) (NVText.h:40; tokens.cu:123-155):
+ * delimiter NULL = whitespace (char <= ' '), else any char of `delimiter`. */
+int cs_tokenize(const cs_column* col, const char* delimiter, cs_stream stream,
+                cs_column** out);
+/* NVText::create_ngrams (NVText.h:153; ngram.cu:32-110). */
+int cs_ngrams(const cs_column* tokens, unsigned ngrams, const char* separator,
+              cs_stream stream, cs_column** out);
+
+/* ---- synthetic workloads (bench / parity inputs) -- */
+/* kind: 2 = C2 word rows, 3 = C3 log lines, 4 = C4 16-char tokens,
+ * 5 = C5 tweet-like text.  Row r is a pure function of (seed, first_row + r). */
+int cs_synth_column(int kind, int64_t first_row, int64_t rows, uint64_t seed,
+                    int64_t param, cs_stream stream, cs_column** out);
+/* Order-sensitive 64-bit digest of a column (offsets, chars, validity);
+ * used for full-size parity ("checksum of checksums"). */
+int cs_column_digest(const cs_column* col, cs_stream stream, uint64_t* digest);
+
+/* ---- measurement -------------------------------------------------------- */
+/* Device time (ms, HIP events on `stream`) and launch count of the dominant
+ * kernel accumulated since the last reset; see bench.py "roofline". */
+int cs_prof_reset(void);
+int cs_prof_enable(int on);
+int cs_prof_get(const char* kernel, double* total_ms, int64_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CUSTRINGS_AMD_H */

@@ -1,0 +1,302 @@
+"""ctypes wrappers for the two CPU-side test libraries:
+
+  * oracle/liboracle.so      -- the oracle (reference-formulation restatement)
+  * tests/rowemu/librowemu.so -- the product's per-row device logic run on the host
+
+Both expose the same tiny API (prefix `orc_` / `emu_`), wrapped here by `CpuLib`
+working on `Col` values (python lists of bytes / None).  Test infrastructure only.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _build(target_dir):
+    subprocess.run(["make", "-s", "-C", target_dir], check=True)
+
+
+class Col:
+    """Host-side strings column: numpy chars/offsets + validity bitmask (or None)."""
+
+    def __init__(self, chars, offsets, validity=None):
+        self.chars = np.ascontiguousarray(chars, dtype=np.uint8)
+        self.offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        self.rows = len(self.offsets) - 1
+        if validity is not None:
+            validity = np.ascontiguousarray(validity, dtype=np.uint8)
+            if validity.size and np.all(np.unpackbits(validity, bitorder="little")[: self.rows] == 1):
+                validity = None
+        self.validity = validity
+
+    @staticmethod
+    def from_list(items):
+        """items: list of str | bytes | None"""
+        bs = [None if x is None else (x.encode("utf8") if isinstance(x, str) else bytes(x)) for x in items]
+        lens = np.array([0 if b is None else len(b) for b in bs], dtype=np.int64)
+        offsets = np.zeros(len(bs) + 1, dtype=np.int64)
+        np.cumsum(lens, out=offsets[1:])
+        chars = np.frombuffer(b"".join(b for b in bs if b is not None), dtype=np.uint8)
+        validity = None
+        if any(b is None for b in bs):
+            bits = np.array([0 if b is None else 1 for b in bs], dtype=np.uint8)
+            validity = np.packbits(bits, bitorder="little")
+        return Col(chars, offsets, validity)
+
+    def valid_bits(self):
+        if self.validity is None:
+            return np.ones(self.rows, dtype=bool)
+        return np.unpackbits(self.validity, bitorder="little")[: self.rows].astype(bool)
+
+    def bitmask(self):
+        return np.packbits(self.valid_bits().astype(np.uint8), bitorder="little")
+
+    def to_bytes_list(self):
+        v = self.valid_bits()
+        data = self.chars.tobytes()
+        o = self.offsets
+        return [data[o[i] : o[i + 1]] if v[i] else None for i in range(self.rows)]
+
+    def to_list(self):
+        return [None if b is None else b.decode("utf8", "surrogateescape") for b in self.to_bytes_list()]
+
+    def same_as(self, other):
+        return (
+            self.rows == other.rows
+            and np.array_equal(self.offsets, other.offsets)
+            and np.array_equal(self.chars, other.chars)
+            and np.array_equal(self.bitmask(), other.bitmask())
+        )
+
+
+class CpuLib:
+    def __init__(self, path, prefix):
+        self.lib = C.CDLL(path)
+        self.p = prefix
+        L = self.lib
+        vp = C.c_void_p
+        self._f("col_create", vp, [C.c_int64, vp, vp, vp])
+        self._f("col_free", None, [vp])
+        self._f("col_rows", C.c_int64, [vp])
+        self._f("col_nbytes", C.c_int64, [vp])
+        self._f("col_offsets", vp, [vp])
+        self._f("col_chars", vp, [vp])
+        self._f("col_bitmask", None, [vp, vp])
+        self._f("free", None, [vp])
+        self._f("lower", vp, [vp])
+        self._f("upper", vp, [vp])
+        self._f("strip", vp, [vp, C.c_char_p, C.c_int])
+        self._f("find", C.c_int64, [vp, C.c_char_p, C.c_int, C.c_int, vp])
+        self._f("contains", C.c_int64, [vp, C.c_char_p, vp])
+        self._f("replace", vp, [vp, C.c_char_p, C.c_char_p, C.c_int])
+        self._f("split", C.c_int, [vp, C.c_char_p, C.c_int, C.POINTER(C.POINTER(vp))])
+        self._f("tokenize", vp, [vp, C.c_char_p])
+        del L
+
+    def _f(self, name, res, args):
+        fn = getattr(self.lib, self.p + name)
+        fn.restype = res
+        fn.argtypes = args
+        setattr(self, "_" + name, fn)
+
+    # -- marshalling
+    def put(self, col):
+        v = col.validity
+        return self._col_create(
+            col.rows,
+            col.offsets.ctypes.data,
+            col.chars.ctypes.data if col.chars.size else None,
+            v.ctypes.data if v is not None else None,
+        )
+
+    def take(self, h):
+        rows = self._col_rows(h)
+        nbytes = self._col_nbytes(h)
+        off = np.ctypeslib.as_array(C.cast(self._col_offsets(h), C.POINTER(C.c_int64)), shape=(rows + 1,)).copy()
+        if nbytes:
+            chars = np.ctypeslib.as_array(C.cast(self._col_chars(h), C.POINTER(C.c_uint8)), shape=(nbytes,)).copy()
+        else:
+            chars = np.zeros(0, dtype=np.uint8)
+        bm = np.zeros((rows + 7) // 8, dtype=np.uint8)
+        if rows:
+            self._col_bitmask(h, bm.ctypes.data)
+        self._col_free(h)
+        return Col(chars, off, bm)
+
+    def _unary(self, fn, col, *args):
+        h = self.put(col)
+        try:
+            o = fn(h, *args)
+            if not o:
+                raise ValueError("invalid argument")
+            return self.take(o)
+        finally:
+            self._col_free(h)
+
+    @staticmethod
+    def _b(s):
+        return None if s is None else (s.encode("utf8") if isinstance(s, str) else s)
+
+    # -- ops
+    def lower(self, col):
+        return self._unary(self._lower, col)
+
+    def upper(self, col):
+        return self._unary(self._upper, col)
+
+    def strip(self, col, to_strip=None, side=0):
+        return self._unary(self._strip, col, self._b(to_strip), side)
+
+    def replace(self, col, s, repl, maxrepl=-1):
+        return self._unary(self._replace, col, self._b(s), self._b(repl), maxrepl)
+
+    def tokenize(self, col, delim=None):
+        return self._unary(self._tokenize, col, self._b(delim))
+
+    def find(self, col, s, start=0, end=-1):
+        h = self.put(col)
+        out = np.zeros(col.rows, dtype=np.int32)
+        n = self._find(h, self._b(s), start, end, out.ctypes.data)
+        self._col_free(h)
+        return out, n
+
+    def contains(self, col, s):
+        h = self.put(col)
+        out = np.zeros(col.rows, dtype=np.uint8)
+        n = self._contains(h, self._b(s), out.ctypes.data)
+        self._col_free(h)
+        return out, n
+
+    def split(self, col, delim=None, maxsplit=-1):
+        h = self.put(col)
+        arr = C.POINTER(C.c_void_p)()
+        n = self._split(h, self._b(delim), maxsplit, C.byref(arr))
+        cols = [self.take(arr[i]) for i in range(n)]
+        self._free(arr)
+        self._col_free(h)
+        return cols
+
+
+class Oracle(CpuLib):
+    def __init__(self):
+        _build(os.path.join(ROOT, "oracle"))
+        super().__init__(os.path.join(ROOT, "oracle", "liboracle.so"), "orc_")
+        vp = C.c_void_p
+        self._f("contains_re", C.c_int64, [vp, vp, C.c_int, vp])
+        self._f("count_re", C.c_int64, [vp, vp, vp])
+        self._f("replace_re", vp, [vp, vp, C.c_char_p, C.c_int])
+        self._f("category", vp, [vp, vp])
+        self._f("ngrams", vp, [vp, C.c_uint, C.c_char_p])
+        self._f("synth", vp, [C.c_int, C.c_int64, C.c_int64, C.c_uint64, C.c_int64])
+
+    # regex entry points take a compiled program blob (int32 numpy array)
+    def contains_re(self, col, blob, mode=0):
+        h = self.put(col)
+        out = np.zeros(col.rows, dtype=np.uint8)
+        n = self._contains_re(h, blob.ctypes.data, mode, out.ctypes.data)
+        self._col_free(h)
+        return out, n
+
+    def count_re(self, col, blob):
+        h = self.put(col)
+        out = np.zeros(col.rows, dtype=np.int32)
+        n = self._count_re(h, blob.ctypes.data, out.ctypes.data)
+        self._col_free(h)
+        return out, n
+
+    def replace_re(self, col, blob, repl, maxrepl=-1):
+        return self._unary(self._replace_re, col, blob.ctypes.data, self._b(repl), maxrepl)
+
+    def category(self, col):
+        h = self.put(col)
+        vals = np.zeros(col.rows, dtype=np.int32)
+        k = self._category(h, vals.ctypes.data)
+        self._col_free(h)
+        return self.take(k), vals
+
+    def ngrams(self, col, n=2, sep="_"):
+        return self._unary(self._ngrams, col, n, self._b(sep))
+
+    def synth(self, kind, first_row, rows, seed=20240607, param=0):
+        return self.take(self._synth(kind, first_row, rows, seed, param))
+
+
+class RowEmu(CpuLib):
+    def __init__(self):
+        _build(os.path.join(ROOT, "oracle"))  # generated unicode tables
+        _build(os.path.join(ROOT, "tests", "rowemu"))
+        super().__init__(os.path.join(ROOT, "tests", "rowemu", "librowemu.so"), "emu_")
+        vp = C.c_void_p
+        self._f("regex_compile", vp, [C.c_char_p])
+        self._f("regex_free", None, [vp])
+        self._f("regex_blob", C.c_int, [vp, C.POINTER(vp)])
+        self._f("contains_re", C.c_int64, [vp, vp, C.c_int, vp])
+        self._f("count_re", C.c_int64, [vp, vp, vp])
+        self._f("replace_re", vp, [vp, vp, C.c_char_p, C.c_int])
+
+    def compile(self, pattern):
+        return self._regex_compile(self._b(pattern))
+
+    def blob(self, re):
+        p = C.c_void_p()
+        n = self._regex_blob(re, C.byref(p))
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_int32)), shape=(n,)).copy()
+
+    def contains_re(self, col, re, mode=0):
+        h = self.put(col)
+        out = np.zeros(col.rows, dtype=np.uint8)
+        n = self._contains_re(h, re, mode, out.ctypes.data)
+        self._col_free(h)
+        return out, n
+
+    def count_re(self, col, re):
+        h = self.put(col)
+        out = np.zeros(col.rows, dtype=np.int32)
+        n = self._count_re(h, re, out.ctypes.data)
+        self._col_free(h)
+        return out, n
+
+    def replace_re(self, col, re, repl, maxrepl=-1):
+        return self._unary(self._replace_re, col, re, self._b(repl), maxrepl)
+
+
+_REF = None
+
+
+def ref_regcomp():
+    """The real reference regex compiler (oracle/_ref), or None when not built."""
+    global _REF
+    if _REF is None:
+        path = os.path.join(ROOT, "oracle", "_ref", "libref_regcomp.so")
+        if not os.path.exists(path) and os.path.isdir("/root/reference"):
+            subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "ref"], check=False)
+        _REF = C.CDLL(path) if os.path.exists(path) else False
+    return _REF or None
+
+
+def pack_pattern(s):
+    b = s.encode("utf8") if isinstance(s, str) else s
+    out, i = [], 0
+    while i < len(b):
+        c = b[i]
+        w = 1 + ((c & 0xF0) == 0xF0) + ((c & 0xE0) == 0xE0) + ((c & 0xC0) == 0xC0) - ((c & 0xC0) == 0x80)
+        w = max(w, 1)
+        v = 0
+        for k in range(w):
+            v = (v << 8) | (b[i + k] if i + k < len(b) else 0)
+        out.append(v)
+        i += w
+    out.append(0)
+    return (C.c_uint32 * len(out))(*out)
+
+
+def ref_blob(pattern):
+    lib = ref_regcomp()
+    p = C.POINTER(C.c_int32)()
+    n = lib.ref_regcomp_blob(pack_pattern(pattern), C.byref(p))
+    arr = np.array(p[:n], dtype=np.int32)
+    lib.ref_free(p)
+    return arr

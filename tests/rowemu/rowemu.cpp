@@ -1,0 +1,296 @@
+// TEST HARNESS (CPU): runs the product's per-row `__host__ __device__` logic
+// (custrings_amd/csrc/row_ops.h, regex_vm.h, regex_compile.cpp) serially on the
+// host with the same size-pass / scan / write-pass structure the HIP kernels
+// use, so the row logic can be checked against oracle/ in a container without a
+// GPU.  It is NOT a CPU fallback of the product: nothing in custrings_amd/
+// links it, and the shipped library has no host execution path.
+#include <algorithm>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../custrings_amd/csrc/regex_program.h"
+#include "../../custrings_amd/csrc/regex_vm.h"
+#include "../../custrings_amd/csrc/row_ops.h"
+#include "../../oracle/unicode_tables_gen.h"  // same generated tables the product embeds
+
+using namespace csrow;
+
+struct emu_col {
+  int64_t rows = 0;
+  std::vector<int64_t> off;
+  std::vector<uint8_t> chars;
+  std::vector<uint8_t> valid;  // empty = all valid
+  bool ok(int64_t r) const { return valid.empty() || ((valid[r >> 3] >> (r & 7)) & 1); }
+  const uint8_t* row(int64_t r) const { return chars.data() + off[r]; }
+  int len(int64_t r) const { return (int)(off[r + 1] - off[r]); }
+};
+
+// sizes (-1 = null) -> column skeleton; then fill(r, dst)
+template <class Size, class Fill>
+static emu_col* two_pass(int64_t rows, Size size, Fill fill) {
+  emu_col* o = new emu_col;
+  o->rows = rows;
+  o->off.assign(rows + 1, 0);
+  std::vector<int> sz(rows);
+  bool any_null = false;
+  for (int64_t r = 0; r < rows; ++r) {
+    sz[r] = size(r);
+    any_null |= sz[r] < 0;
+    o->off[r + 1] = o->off[r] + (sz[r] < 0 ? 0 : sz[r]);
+  }
+  o->chars.assign((size_t)o->off[rows] + 16, 0);
+  if (any_null) {
+    o->valid.assign((rows + 7) / 8, 0);
+    for (int64_t r = 0; r < rows; ++r)
+      if (sz[r] >= 0) o->valid[r >> 3] |= (uint8_t)(1u << (r & 7));
+  }
+  for (int64_t r = 0; r < rows; ++r)
+    if (sz[r] >= 0) fill(r, o->chars.data() + o->off[r]);
+  o->chars.resize((size_t)o->off[rows]);
+  return o;
+}
+
+static CharSet make_set(const char* s) {
+  CharSet cs;
+  cs.n = 0;
+  int n = (int)strlen(s), i = 0;
+  while (i < n && cs.n < 64) {
+    Char c;
+    unsigned w = decode_at((const uint8_t*)s, i, n, c);
+    cs.c[cs.n++] = c;
+    i += w ? (int)w : 1;
+  }
+  return cs;
+}
+
+extern "C" {
+
+emu_col* emu_col_create(int64_t rows, const int64_t* off, const uint8_t* chars, const uint8_t* valid) {
+  emu_col* c = new emu_col;
+  c->rows = rows;
+  c->off.assign(off, off + rows + 1);
+  c->chars.assign(chars, chars + off[rows]);
+  if (valid) c->valid.assign(valid, valid + (rows + 7) / 8);
+  return c;
+}
+void emu_col_free(emu_col* c) { delete c; }
+int64_t emu_col_rows(const emu_col* c) { return c->rows; }
+int64_t emu_col_nbytes(const emu_col* c) { return (int64_t)c->chars.size(); }
+const int64_t* emu_col_offsets(const emu_col* c) { return c->off.data(); }
+const uint8_t* emu_col_chars(const emu_col* c) { return c->chars.data(); }
+void emu_col_bitmask(const emu_col* c, uint8_t* out) {
+  memset(out, 0, (size_t)((c->rows + 7) / 8));
+  for (int64_t r = 0; r < c->rows; ++r)
+    if (c->ok(r)) out[r >> 3] |= (uint8_t)(1u << (r & 7));
+}
+void emu_free(void* p) { free(p); }
+
+static emu_col* change_case(const emu_col* c, unsigned bit) {
+  return two_pass(
+      c->rows,
+      [&](int64_t r) {
+        return c->ok(r) ? row_case_size(c->row(r), c->len(r), orc_unicode_flags, orc_charcases, bit) : -1;
+      },
+      [&](int64_t r, uint8_t* o) {
+        row_case_write(c->row(r), c->len(r), orc_unicode_flags, orc_charcases, bit, o);
+      });
+}
+emu_col* emu_lower(const emu_col* c) { return change_case(c, 32); }
+emu_col* emu_upper(const emu_col* c) { return change_case(c, 64); }
+
+emu_col* emu_strip(const emu_col* c, const char* to_strip, int side) {
+  CharSet set = make_set(to_strip ? to_strip : " \n\t");
+  return two_pass(
+      c->rows,
+      [&](int64_t r) {
+        if (!c->ok(r)) return -1;
+        int lo, hi;
+        row_strip(c->row(r), c->len(r), set, side, lo, hi);
+        return hi - lo;
+      },
+      [&](int64_t r, uint8_t* o) {
+        int lo, hi;
+        row_strip(c->row(r), c->len(r), set, side, lo, hi);
+        memcpy(o, c->row(r) + lo, (size_t)(hi - lo));
+      });
+}
+
+int64_t emu_find(const emu_col* c, const char* str, int start, int end, int32_t* out) {
+  int nb = (int)strlen(str);
+  int64_t n = 0;
+  for (int64_t r = 0; r < c->rows; ++r) {
+    out[r] = c->ok(r) ? row_find(c->row(r), c->len(r), (const uint8_t*)str, nb, start, end) : -2;
+    n += out[r] != -1;
+  }
+  return n;
+}
+int64_t emu_contains(const emu_col* c, const char* str, uint8_t* out) {
+  int nb = (int)strlen(str);
+  int64_t n = 0;
+  for (int64_t r = 0; r < c->rows; ++r) {
+    out[r] = c->ok(r) && nb > 0 && find_bytes(c->row(r), 0, c->len(r), (const uint8_t*)str, nb) >= 0;
+    n += out[r];
+  }
+  return n;
+}
+emu_col* emu_replace(const emu_col* c, const char* str, const char* repl, int maxrepl) {
+  if (!str || !*str) return nullptr;
+  if (!repl) repl = "";
+  int nb = (int)strlen(str), rb = (int)strlen(repl);
+  return two_pass(
+      c->rows,
+      [&](int64_t r) {
+        return c->ok(r) ? row_replace_size(c->row(r), c->len(r), (const uint8_t*)str, nb, rb, maxrepl) : -1;
+      },
+      [&](int64_t r, uint8_t* o) {
+        row_replace_write(c->row(r), c->len(r), (const uint8_t*)str, nb, (const uint8_t*)repl, rb, maxrepl, o);
+      });
+}
+
+int emu_split(const emu_col* c, const char* delim, int maxsplit, emu_col*** cols_out) {
+  int tokens = maxsplit > 0 ? maxsplit + 1 : 0;
+  int nb = delim ? (int)strlen(delim) : 0;
+  std::vector<int> counts(c->rows, 0);
+  int ncols = 0;
+  for (int64_t r = 0; r < c->rows; ++r) {
+    if (!c->ok(r)) continue;
+    counts[r] = delim ? row_split_count(c->row(r), c->len(r), (const uint8_t*)delim, nb, tokens)
+                      : row_wssplit_count(c->row(r), c->len(r), tokens);
+    ncols = std::max(ncols, counts[r]);
+  }
+  int nout = ncols ? ncols : 1;
+  // all columns in one walk per row: token spans[col][row]
+  std::vector<std::vector<int>> lo(nout, std::vector<int>(c->rows, -1)), hi(nout, std::vector<int>(c->rows, -1));
+  for (int64_t r = 0; r < c->rows; ++r) {
+    if (!c->ok(r)) continue;
+    auto emit = [&](int k, int a, int b) {
+      if (k < nout) {
+        lo[k][r] = a;
+        hi[k][r] = b;
+      }
+    };
+    if (delim)
+      row_split_tokens(c->row(r), c->len(r), (const uint8_t*)delim, nb, counts[r], emit);
+    else
+      row_ws_tokens(c->row(r), c->len(r), tokens, emit);
+  }
+  emu_col** cols = (emu_col**)malloc(sizeof(emu_col*) * nout);
+  for (int k = 0; k < nout; ++k)
+    cols[k] = two_pass(
+        c->rows, [&](int64_t r) { return lo[k][r] < 0 ? -1 : hi[k][r] - lo[k][r]; },
+        [&](int64_t r, uint8_t* o) { memcpy(o, c->row(r) + lo[k][r], (size_t)(hi[k][r] - lo[k][r])); });
+  *cols_out = cols;
+  return nout;
+}
+
+// ---- regex ----
+struct emu_regex {
+  std::vector<int32_t> blob, image;
+};
+emu_regex* emu_regex_compile(const char* pattern) {
+  emu_regex* re = new emu_regex;
+  csrx::Program p = csrx::compile(pattern);
+  re->blob = p.to_blob();
+  re->image = p.to_device_image(orc_unicode_flags);
+  return re;
+}
+// adopt a program blob produced elsewhere (e.g. by the real reference compiler)
+emu_regex* emu_regex_from_blob(const int32_t* words, int n) {
+  emu_regex* re = new emu_regex;
+  re->blob.assign(words, words + n);
+  return re;
+}
+void emu_regex_free(emu_regex* re) { delete re; }
+int emu_regex_blob(const emu_regex* re, const int32_t** words) {
+  *words = re->blob.data();
+  return (int)re->blob.size();
+}
+
+}  // extern "C"
+template <class F>
+static void with_vm(const emu_regex* re, const uint8_t* row, int len, F f) {
+  csvm::ProgView P = csvm::make_view(re->image.data(), orc_unicode_flags);
+  std::vector<uint32_t> mem((size_t)csvm::vm_slots(P.ninst) + 1);
+  if (P.ninst <= 64) {
+    csvm::Vm<true> vm(P, mem.data(), 1, row, len);
+    f(vm);
+  } else {
+    csvm::Vm<false> vm(P, mem.data(), 1, row, len);
+    f(vm);
+  }
+}
+extern "C" {
+int64_t emu_contains_re(const emu_col* c, const emu_regex* re, int mode, uint8_t* out) {
+  int64_t n = 0;
+  for (int64_t r = 0; r < c->rows; ++r) {
+    out[r] = 0;
+    if (c->ok(r)) with_vm(re, c->row(r), c->len(r), [&](auto& vm) { out[r] = (uint8_t)csvm::row_contains_re(vm, mode != 0); });
+    n += out[r];
+  }
+  return n;
+}
+int64_t emu_count_re(const emu_col* c, const emu_regex* re, int32_t* out) {
+  int64_t n = 0;
+  for (int64_t r = 0; r < c->rows; ++r) {
+    out[r] = 0;
+    if (c->ok(r)) with_vm(re, c->row(r), c->len(r), [&](auto& vm) { out[r] = csvm::row_count_re(vm); });
+    n += out[r] > 0;
+  }
+  return n;
+}
+emu_col* emu_replace_re(const emu_col* c, const emu_regex* re, const char* repl, int maxrepl) {
+  if (!repl) repl = "";
+  int rb = (int)strlen(repl);
+  return two_pass(
+      c->rows,
+      [&](int64_t r) {
+        if (!c->ok(r)) return -1;
+        int out = c->len(r);
+        with_vm(re, c->row(r), c->len(r), [&](auto& vm) {
+          csvm::row_replace_matches(vm, maxrepl, [&](int mb, int me, int reps) { out += reps * rb - (me - mb); });
+        });
+        return out;
+      },
+      [&](int64_t r, uint8_t* o) {
+        const uint8_t* p = c->row(r);
+        int copied = 0;
+        with_vm(re, p, c->len(r), [&](auto& vm) {
+          csvm::row_replace_matches(vm, maxrepl, [&](int mb, int me, int reps) {
+            memcpy(o, p + copied, (size_t)(mb - copied));
+            o += mb - copied;
+            for (int k = 0; k < reps; ++k) {
+              memcpy(o, repl, (size_t)rb);
+              o += rb;
+            }
+            copied = me;
+          });
+        });
+        memcpy(o, p + copied, (size_t)(c->len(r) - copied));
+      });
+}
+
+// ---- tokenize ----
+emu_col* emu_tokenize(const emu_col* c, const char* delim) {
+  CharSet set = make_set(delim ? delim : "");
+  std::vector<int64_t> src;
+  std::vector<int> lo, hi;
+  for (int64_t r = 0; r < c->rows; ++r) {
+    if (!c->ok(r)) continue;
+    auto emit = [&](int, int a, int b) {
+      src.push_back(r);
+      lo.push_back(a);
+      hi.push_back(b);
+    };
+    if (delim)
+      row_set_tokens(c->row(r), c->len(r), set, emit);
+    else
+      row_ws_tokens(c->row(r), c->len(r), 0, emit);
+  }
+  return two_pass(
+      (int64_t)src.size(), [&](int64_t t) { return hi[t] - lo[t]; },
+      [&](int64_t t, uint8_t* o) { memcpy(o, c->row(src[t]) + lo[t], (size_t)(hi[t] - lo[t])); });
+}
+
+}  // extern "C"
