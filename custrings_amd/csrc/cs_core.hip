@@ -1,0 +1,871 @@
+// Library core: error reporting, device buffer cache, unicode tables, column
+// construction / export (NVStrings.cu:74-153,402-544; NVStringsImpl.cu:126-444;
+// attrs.cu:72-112), the lengths->offsets scan and measurement hooks.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <unordered_map>
+
+#include "_gen/unicode_tables.inc"  // cs_unicode_flags[65536], cs_charcases[65536]
+#include "cs_internal.h"
+#include "cs_synth_spec.h"
+#include "device_utils.h"
+
+using namespace csdev;
+
+namespace cs {
+
+// ---------------------------------------------------------------- errors ----
+static thread_local std::string g_last_error;
+void set_last_error(const std::string& msg) { g_last_error = msg; }
+void fail(int code, const std::string& msg) { throw Error{code, msg}; }
+
+// ------------------------------------------------------------ device state --
+static std::mutex g_mu;
+static int g_device = -1;
+static uint8_t* g_d_flags = nullptr;
+static uint16_t* g_d_cases = nullptr;
+static int64_t g_in_use = 0;
+static std::multimap<size_t, std::pair<void*, hipStream_t>> g_cache;  // capacity -> block
+
+void require_device() {
+  if (g_device < 0) fail(CS_ERR_NO_DEVICE, "cs_init has not succeeded: no usable gfx950 device (there is no CPU fallback)");
+}
+const uint8_t* d_unicode_flags() { return g_d_flags; }
+const uint16_t* d_charcases() { return g_d_cases; }
+const uint8_t* h_unicode_flags() { return cs_unicode_flags; }
+int64_t dev_bytes_in_use() { return g_in_use; }
+
+static void release_cache_locked() {
+  for (auto& kv : g_cache) (void)hipFree(kv.second.first);
+  g_cache.clear();
+}
+
+DevBuf::~DevBuf() {
+  if (!capacity || !p) return;
+  std::lock_guard<std::mutex> lk(g_mu);
+  g_in_use -= (int64_t)capacity;
+  g_cache.emplace(capacity, std::make_pair(p, stream));
+}
+
+Buf dev_alloc(size_t bytes, hipStream_t stream) {
+  require_device();
+  size_t want = ((bytes + 64 + 511) / 512) * 512;
+  auto b = std::make_shared<DevBuf>();
+  b->bytes = bytes;
+  b->stream = stream;
+  {
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = g_cache.lower_bound(want);
+    if (it != g_cache.end() && it->first <= want + want / 4 + 4096) {
+      b->p = it->second.first;
+      b->capacity = it->first;
+      hipStream_t prev = it->second.second;
+      g_cache.erase(it);
+      g_in_use += (int64_t)b->capacity;
+      // a block last used on another stream may still be in flight there
+      if (prev != stream) (void)hipStreamSynchronize(prev);
+      return b;
+    }
+  }
+  void* p = nullptr;
+  hipError_t e = hipMalloc(&p, want);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    {
+      std::lock_guard<std::mutex> lk(g_mu);
+      (void)hipDeviceSynchronize();
+      release_cache_locked();
+    }
+    e = hipMalloc(&p, want);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      fail(CS_ERR_ALLOC, "allocate error: " + std::to_string(want) + " bytes (" + hipGetErrorString(e) + ")");
+    }
+  }
+  b->p = p;
+  b->capacity = want;
+  std::lock_guard<std::mutex> lk(g_mu);
+  g_in_use += (int64_t)want;
+  return b;
+}
+
+Buf dev_wrap(const void* p, size_t bytes) {
+  auto b = std::make_shared<DevBuf>();
+  b->p = const_cast<void*>(p);
+  b->bytes = bytes;
+  b->capacity = 0;
+  return b;
+}
+
+void* pinned_scratch(size_t bytes) {
+  static thread_local void* p = nullptr;
+  static thread_local size_t cap = 0;
+  if (bytes > cap) {
+    if (p) (void)hipHostFree(p);
+    size_t want = bytes < 4096 ? 4096 : bytes;
+    CS_HIP(hipHostMalloc(&p, want, hipHostMallocDefault));
+    cap = want;
+  }
+  return p;
+}
+
+// ------------------------------------------------------------- profiling ----
+struct ProfEntry {
+  double ms = 0;
+  int64_t launches = 0;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+};
+static bool g_prof_on = false;
+static std::unordered_map<std::string, ProfEntry> g_prof;
+
+ProfScope::ProfScope(const char* nm, hipStream_t st) : name(nm), s(st) {
+  if (!g_prof_on) return;
+  (void)hipEventCreate(&a);
+  (void)hipEventCreate(&b);
+  (void)hipEventRecord(a, s);
+}
+ProfScope::~ProfScope() {
+  if (!a) return;
+  (void)hipEventRecord(b, s);
+  std::lock_guard<std::mutex> lk(g_mu);
+  g_prof[name].pending.emplace_back(a, b);
+}
+static void prof_collect(ProfEntry& e) {
+  for (auto& pr : e.pending) {
+    (void)hipEventSynchronize(pr.second);
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) {
+      e.ms += ms;
+      e.launches += 1;
+    }
+    (void)hipEventDestroy(pr.first);
+    (void)hipEventDestroy(pr.second);
+  }
+  e.pending.clear();
+}
+
+// ------------------------------------------------------------ scan kernels --
+// block sums of 256 lengths (negative = null -> 0)
+__global__ void k_block_sums(const int32_t* __restrict__ lens, int64_t n, int64_t* __restrict__ sums) {
+  int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  int v = (i < n) ? lens[i] : 0;
+  if (v < 0) v = 0;
+  long long t = block_reduce_sum(v);
+  if (threadIdx.x == 0) sums[blockIdx.x] = t;
+}
+// One workgroup per segment scans `nb` int64 block sums in place (exclusive),
+// 8 per thread per sweep, and publishes the segment total.
+__global__ void __launch_bounds__(1024) k_scan_block_sums(int64_t* __restrict__ sums, int64_t nb,
+                                                          int64_t* __restrict__ totals) {
+  __shared__ long long wave_tot[16];
+  __shared__ long long carry_s;
+  int64_t* seg = sums + (int64_t)blockIdx.x * nb;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  for (int64_t base = 0; base < nb; base += 8192) {
+    long long v[8], run = 0;
+    int64_t i0 = base + (int64_t)threadIdx.x * 8;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      v[k] = (i0 + k < nb) ? seg[i0 + k] : 0;
+      run += v[k];
+    }
+    long long incl = wave_inclusive_scan(run);
+    if (lane == 63) wave_tot[wv] = incl;
+    __syncthreads();
+    long long before = carry_s, all = 0;
+    for (int k = 0; k < 16; ++k) {
+      long long t = wave_tot[k];
+      if (k < wv) before += t;
+      all += t;
+    }
+    long long ex = before + incl - run;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      if (i0 + k < nb) seg[i0 + k] = ex;
+      ex += v[k];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) carry_s += all;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) totals[blockIdx.x] = carry_s;
+}
+// offsets[i] = block_base[b] + in-block exclusive prefix; offsets[n] = total
+__global__ void k_write_offsets(const int32_t* __restrict__ lens, int64_t n,
+                                const int64_t* __restrict__ block_base, int64_t nb,
+                                int64_t* __restrict__ offsets) {
+  // grid.y = segment
+  const int32_t* sl = lens + (int64_t)blockIdx.y * n;
+  const int64_t* sb = block_base + (int64_t)blockIdx.y * nb;
+  int64_t* so = offsets + (int64_t)blockIdx.y * (n + 1);
+  int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  int v = (i < n) ? sl[i] : 0;
+  if (v < 0) v = 0;
+  long long ex = block_exclusive_scan(v, nullptr) + sb[blockIdx.x];
+  if (i < n) so[i] = ex;
+  if (i == n - 1) so[n] = ex + v;
+}
+__global__ void k_block_sums_seg(const int32_t* __restrict__ lens, int64_t n, int64_t nb,
+                                 int64_t* __restrict__ sums) {
+  const int32_t* sl = lens + (int64_t)blockIdx.y * n;
+  int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  int v = (i < n) ? sl[i] : 0;
+  if (v < 0) v = 0;
+  long long t = block_reduce_sum(v);
+  if (threadIdx.x == 0) sums[(int64_t)blockIdx.y * nb + blockIdx.x] = t;
+}
+
+void offsets_from_lengths_segmented(const int32_t* lens, int64_t n, int segs, int64_t* offsets,
+                                    int64_t* totals_host, hipStream_t s) {
+  if (n == 0) {
+    CS_HIP(hipMemsetAsync(offsets, 0, sizeof(int64_t) * segs, s));
+    for (int k = 0; k < segs; ++k) totals_host[k] = 0;
+    return;
+  }
+  int64_t nb = (n + kBlock - 1) / kBlock;
+  Buf sums = dev_alloc(sizeof(int64_t) * nb * segs, s);
+  Buf totals = dev_alloc(sizeof(int64_t) * segs, s);
+  hipLaunchKernelGGL(k_block_sums_seg, dim3((unsigned)nb, segs), dim3(kBlock), 0, s, lens, n, nb,
+                     ptr<int64_t>(sums));
+  hipLaunchKernelGGL(k_scan_block_sums, dim3(segs), dim3(1024), 0, s, ptr<int64_t>(sums), nb,
+                     ptr<int64_t>(totals));
+  hipLaunchKernelGGL(k_write_offsets, dim3((unsigned)nb, segs), dim3(kBlock), 0, s, lens, n,
+                     ptr<int64_t>(sums), nb, offsets);
+  int64_t* host = (int64_t*)pinned_scratch(sizeof(int64_t) * segs);
+  CS_HIP(hipMemcpyAsync(host, ptr<int64_t>(totals), sizeof(int64_t) * segs, hipMemcpyDeviceToHost, s));
+  CS_HIP(hipStreamSynchronize(s));
+  for (int k = 0; k < segs; ++k) totals_host[k] = host[k];
+}
+
+int64_t offsets_from_lengths(const int32_t* lens, int64_t n, int64_t* offsets, hipStream_t s,
+                             Buf block_sums) {
+  if (n == 0) {
+    CS_HIP(hipMemsetAsync(offsets, 0, sizeof(int64_t), s));
+    return 0;
+  }
+  int64_t nb = (n + kBlock - 1) / kBlock;
+  Buf sums = block_sums;
+  if (!sums) {
+    sums = dev_alloc(sizeof(int64_t) * nb, s);
+    hipLaunchKernelGGL(k_block_sums, dim3((unsigned)nb), dim3(kBlock), 0, s, lens, n, ptr<int64_t>(sums));
+  }
+  Buf total = dev_alloc(sizeof(int64_t), s);
+  hipLaunchKernelGGL(k_scan_block_sums, dim3(1), dim3(1024), 0, s, ptr<int64_t>(sums), nb,
+                     ptr<int64_t>(total));
+  {
+    ProfScope ps("k_write_offsets", s);
+    hipLaunchKernelGGL(k_write_offsets, dim3((unsigned)nb, 1), dim3(kBlock), 0, s, lens, n,
+                       ptr<int64_t>(sums), nb, offsets);
+  }
+  int64_t* host = (int64_t*)pinned_scratch(sizeof(int64_t));
+  CS_HIP(hipMemcpyAsync(host, ptr<int64_t>(total), sizeof(int64_t), hipMemcpyDeviceToHost, s));
+  CS_HIP(hipStreamSynchronize(s));
+  return host[0];
+}
+
+__global__ void k_validity_from_lengths(const int32_t* __restrict__ lens, int64_t n,
+                                        uint8_t* __restrict__ validity) {
+  int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  bool ok = i < n && lens[i] >= 0;
+  store_validity_word(validity, i - (threadIdx.x & 63), ok, n);
+}
+Buf validity_from_lengths(const int32_t* lens, int64_t n, hipStream_t s) {
+  Buf v = dev_alloc(validity_bytes(n), s);
+  if (n)
+    hipLaunchKernelGGL(k_validity_from_lengths, dim3(blocks_for(n)), dim3(kBlock), 0, s, lens, n,
+                       ptr<uint8_t>(v));
+  return v;
+}
+
+__global__ void k_count_valid(const uint8_t* __restrict__ validity, int64_t rows,
+                              unsigned long long* __restrict__ out) {
+  int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  int v = (i < rows) ? ((validity[i >> 3] >> (i & 7)) & 1) : 0;
+  long long t = block_reduce_sum(v);
+  if (threadIdx.x == 0 && t) atomicAdd(out, (unsigned long long)t);
+}
+int64_t count_nulls(const cs_column* c, hipStream_t s) {
+  if (c->null_count >= 0) return c->null_count;
+  if (!c->validity || c->rows == 0) return c->null_count = 0;
+  Buf cnt = dev_alloc(8, s);
+  CS_HIP(hipMemsetAsync(cnt->p, 0, 8, s));
+  hipLaunchKernelGGL(k_count_valid, dim3(blocks_for(c->rows)), dim3(kBlock), 0, s, c->d_validity(),
+                     c->rows, ptr<unsigned long long>(cnt));
+  int64_t* host = (int64_t*)pinned_scratch(8);
+  CS_HIP(hipMemcpyAsync(host, cnt->p, 8, hipMemcpyDeviceToHost, s));
+  CS_HIP(hipStreamSynchronize(s));
+  return c->null_count = c->rows - host[0];
+}
+
+cs_column* make_all_null(int64_t rows, hipStream_t s) {
+  auto* c = new cs_column;
+  c->rows = rows;
+  c->nbytes = 0;
+  c->null_count = rows;
+  c->chars = dev_alloc(0, s);
+  c->offsets = dev_alloc(sizeof(int64_t) * (rows + 1), s);
+  CS_HIP(hipMemsetAsync(c->offsets->p, 0, sizeof(int64_t) * (rows + 1), s));
+  if (rows) {
+    c->validity = dev_alloc(validity_bytes(rows), s);
+    CS_HIP(hipMemsetAsync(c->validity->p, 0, validity_bytes(rows), s));
+  }
+  return c;
+}
+
+// ------------------------------------------------------- ingest / export ----
+__global__ void k_widen_offsets(const int32_t* __restrict__ in, int64_t n, int64_t* __restrict__ out) {
+  int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i < n) out[i] = in[i];
+}
+__global__ void k_narrow_offsets(const int64_t* __restrict__ in, int64_t n, int32_t* __restrict__ out) {
+  int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i < n) out[i] = (int32_t)in[i];
+}
+// a null row contributes no bytes: clamp its extent to zero while copying
+// (NVStringsImpl.cu:408-432 skips rows whose validity bit is clear)
+__global__ void k_lengths_from_offsets(cs::ColView in, int32_t* __restrict__ lens) {
+  int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (r >= in.rows) return;
+  lens[r] = row_is_valid(in.validity, r) ? (int32_t)(in.offsets[r + 1] - in.offsets[r]) : -1;
+}
+__global__ void k_gather_rows(cs::ColView in, const int64_t* __restrict__ out_off,
+                              uint8_t* __restrict__ out_chars) {
+  int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (r >= in.rows || !row_is_valid(in.validity, r)) return;
+  const uint8_t* src = in.chars + in.offsets[r];
+  uint8_t* dst = out_chars + out_off[r];
+  int n = (int)(in.offsets[r + 1] - in.offsets[r]);
+  for (int i = 0; i < n; ++i) dst[i] = src[i];
+}
+__global__ void k_byte_count(cs::ColView in, int32_t* __restrict__ out,
+                             unsigned long long* __restrict__ total) {
+  int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  int v = 0;
+  if (r < in.rows) {
+    bool ok = row_is_valid(in.validity, r);
+    v = ok ? (int)(in.offsets[r + 1] - in.offsets[r]) : 0;
+    out[r] = ok ? v : -1;
+  }
+  long long t = block_reduce_sum(v);
+  if (threadIdx.x == 0 && t) atomicAdd(total, (unsigned long long)t);
+}
+__global__ void k_null_bitarray(cs::ColView in, int empty_is_null, uint8_t* __restrict__ bits,
+                                unsigned long long* __restrict__ nulls) {
+  // one thread per output byte (NVStrings.cu:512-527)
+  int64_t b = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  int64_t nb = (in.rows + 7) / 8;
+  int cleared = 0;
+  if (b < nb) {
+    unsigned byte = 0;
+    for (int i = 0; i < 8; ++i) {
+      int64_t r = b * 8 + i;
+      if (r >= in.rows) break;
+      bool ok = row_is_valid(in.validity, r);
+      if (ok && empty_is_null) ok = in.offsets[r + 1] > in.offsets[r];
+      if (ok) byte |= 1u << i;
+      else ++cleared;
+    }
+    bits[b] = (uint8_t)byte;
+  }
+  long long t = block_reduce_sum(cleared);
+  if (threadIdx.x == 0 && t) atomicAdd(nulls, (unsigned long long)t);
+}
+__global__ void k_digest(cs::ColView in, unsigned long long* __restrict__ out) {
+  int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  unsigned long long h = 0;
+  if (r < in.rows) {
+    bool ok = row_is_valid(in.validity, r);
+    int n = ok ? (int)(in.offsets[r + 1] - in.offsets[r]) : 0;
+    h = cs_digest_row((uint64_t)r, ok ? in.chars + in.offsets[r] : nullptr, n, ok);
+  }
+  for (int d = 32; d > 0; d >>= 1) h += __shfl_xor(h, d, 64);
+  if ((threadIdx.x & 63) == 0 && h) atomicAdd(out, h);
+}
+
+__global__ void k_slice(cs::ColView in, int64_t first, int64_t rows, int64_t* __restrict__ out_off,
+                        uint8_t* __restrict__ out_valid) {
+  int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int64_t base = in.offsets[first];
+  if (i <= rows) out_off[i] = in.offsets[first + i] - base;
+  if (out_valid) {
+    bool ok = i < rows && row_is_valid(in.validity, first + i);
+    store_validity_word(out_valid, i - (threadIdx.x & 63), ok, rows);
+  }
+}
+
+static void copy_in(void* dst, const void* src, size_t bytes, int on_device, hipStream_t s) {
+  if (!bytes) return;
+  CS_HIP(hipMemcpyAsync(dst, src, bytes, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
+}
+static void copy_out(void* dst, const void* src, size_t bytes, int on_device, hipStream_t s) {
+  if (!bytes) return;
+  CS_HIP(hipMemcpyAsync(dst, src, bytes, on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s));
+}
+
+// Turns an ingested (chars, offsets, validity) triple into a canonical column:
+// offsets[0] == 0, null rows have zero extent, chars packed.
+static cs_column* canonicalise(Buf chars, Buf offs, Buf validity, int64_t rows, int64_t span_bytes,
+                               bool has_validity, hipStream_t s) {
+  auto* c = new cs_column;
+  std::unique_ptr<cs_column> guard_c(c);
+  c->rows = rows;
+  if (!has_validity) {
+    // offsets may start at a non-zero base: rebase by gathering only when needed
+    int64_t first = 0;
+    int64_t* host = (int64_t*)pinned_scratch(16);
+    CS_HIP(hipMemcpyAsync(host, offs->p, 8, hipMemcpyDeviceToHost, s));
+    CS_HIP(hipMemcpyAsync(host + 1, ptr<int64_t>(offs) + rows, 8, hipMemcpyDeviceToHost, s));
+    CS_HIP(hipStreamSynchronize(s));
+    first = host[0];
+    if (first == 0) {
+      c->chars = chars;
+      c->offsets = offs;
+      c->nbytes = host[1];
+      c->null_count = 0;
+      (void)span_bytes;
+      return guard_c.release();
+    }
+  }
+  ColView in{ptr<const uint8_t>(chars), ptr<const int64_t>(offs), ptr<const uint8_t>(validity), rows};
+  Buf lens = dev_alloc(sizeof(int32_t) * rows, s);
+  hipLaunchKernelGGL(k_lengths_from_offsets, dim3(blocks_for(rows)), dim3(kBlock), 0, s, in,
+                     ptr<int32_t>(lens));
+  c->offsets = dev_alloc(sizeof(int64_t) * (rows + 1), s);
+  c->nbytes = offsets_from_lengths(ptr<int32_t>(lens), rows, ptr<int64_t>(c->offsets), s);
+  c->chars = dev_alloc((size_t)c->nbytes, s);
+  hipLaunchKernelGGL(k_gather_rows, dim3(blocks_for(rows)), dim3(kBlock), 0, s, in,
+                     c->d_offsets(), ptr<uint8_t>(c->chars));
+  c->validity = validity;
+  return guard_c.release();
+}
+
+__global__ void k_gather_rows_at(cs::ColView in, const int64_t* __restrict__ out_off,
+                                 uint8_t* __restrict__ out_chars) {
+  // out_off is already advanced to this input's first output row
+  int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (r >= in.rows || !row_is_valid(in.validity, r)) return;
+  const uint8_t* src = in.chars + in.offsets[r];
+  uint8_t* dst = out_chars + out_off[r];
+  int n = (int)(in.offsets[r + 1] - in.offsets[r]);
+  for (int i = 0; i < n; ++i) dst[i] = src[i];
+}
+cs_column* concat_columns(const std::vector<const cs_column*>& cols, hipStream_t s) {
+  int64_t rows = 0;
+  bool any_mask = false;
+  for (auto* c : cols) {
+    rows += c->rows;
+    any_mask |= c->validity != nullptr;
+  }
+  if (rows == 0) return make_all_null(0, s);
+  auto out = std::make_unique<cs_column>();
+  out->rows = rows;
+  Buf lens = dev_alloc(sizeof(int32_t) * rows, s);
+  int64_t base = 0;
+  for (auto* c : cols) {
+    if (c->rows)
+      hipLaunchKernelGGL(k_lengths_from_offsets, dim3(blocks_for(c->rows)), dim3(kBlock), 0, s, view_of(c),
+                         ptr<int32_t>(lens) + base);
+    base += c->rows;
+  }
+  out->offsets = dev_alloc(sizeof(int64_t) * (rows + 1), s);
+  out->nbytes = offsets_from_lengths(ptr<int32_t>(lens), rows, ptr<int64_t>(out->offsets), s);
+  out->chars = dev_alloc((size_t)out->nbytes, s);
+  if (any_mask) out->validity = validity_from_lengths(ptr<int32_t>(lens), rows, s);
+  else out->null_count = 0;
+  base = 0;
+  for (auto* c : cols) {
+    if (c->rows)
+      hipLaunchKernelGGL(k_gather_rows_at, dim3(blocks_for(c->rows)), dim3(kBlock), 0, s, view_of(c),
+                         out->d_offsets() + base, ptr<uint8_t>(out->chars));
+    base += c->rows;
+  }
+  CS_HIP(hipStreamSynchronize(s));
+  return out.release();
+}
+
+}  // namespace cs
+
+using namespace cs;
+
+// =============================================================== public ABI ==
+extern "C" {
+
+int cs_version(void) { return 100; }
+const char* cs_last_error(void) { return g_last_error.c_str(); }
+
+int cs_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return n;
+}
+
+int cs_init(int device) {
+  return guard([&] {
+    int n = cs_device_count();
+    if (n <= 0) fail(CS_ERR_NO_DEVICE, "no HIP device visible (there is no CPU fallback)");
+    if (device < 0 || device >= n) fail(CS_ERR_INVALID_ARG, "device index out of range");
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (g_device == device) {
+      CS_HIP(hipSetDevice(device));
+      return;
+    }
+    if (g_device >= 0) fail(CS_ERR_INVALID_ARG, "this process is already bound to another device (one process per GPU)");
+    CS_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    CS_HIP(hipGetDeviceProperties(&prop, device));
+    if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
+      fail(CS_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
+    CS_HIP(hipMalloc((void**)&g_d_flags, 65536));
+    CS_HIP(hipMalloc((void**)&g_d_cases, 65536 * 2));
+    CS_HIP(hipMemcpy(g_d_flags, cs_unicode_flags, 65536, hipMemcpyHostToDevice));
+    CS_HIP(hipMemcpy(g_d_cases, cs_charcases, 65536 * 2, hipMemcpyHostToDevice));
+    g_device = device;
+  });
+}
+
+int64_t cs_device_bytes_in_use(void) { return dev_bytes_in_use(); }
+void cs_free(void* p) { free(p); }
+
+int cs_column_from_host_strings(const char* const* strs, int64_t rows, cs_stream stream, cs_column** out) {
+  return guard([&] {
+    if (!out || (rows > 0 && !strs) || rows < 0) fail(CS_ERR_INVALID_ARG, "create_from_array: bad arguments");
+    require_device();
+    hipStream_t s = S(stream);
+    // one staging buffer, one H2D copy (NVStringsImpl.cu:126-206)
+    std::vector<int64_t> off((size_t)rows + 1, 0);
+    bool any_null = false;
+    for (int64_t r = 0; r < rows; ++r) {
+      size_t n = strs[r] ? strlen(strs[r]) : 0;
+      any_null |= strs[r] == nullptr;
+      off[r + 1] = off[r] + (int64_t)n;
+    }
+    std::vector<uint8_t> chars((size_t)off[rows]);
+    std::vector<uint8_t> valid;
+    if (any_null) valid.assign(validity_bytes(rows), 0);
+    for (int64_t r = 0; r < rows; ++r) {
+      if (!strs[r]) continue;
+      memcpy(chars.data() + off[r], strs[r], (size_t)(off[r + 1] - off[r]));
+      if (any_null) valid[r >> 3] |= (uint8_t)(1u << (r & 7));
+    }
+    auto* c = new cs_column;
+    std::unique_ptr<cs_column> holder(c);
+    c->rows = rows;
+    c->nbytes = off[rows];
+    c->chars = dev_alloc(chars.size(), s);
+    c->offsets = dev_alloc(sizeof(int64_t) * (rows + 1), s);
+    copy_in(c->chars->p, chars.data(), chars.size(), 0, s);
+    copy_in(c->offsets->p, off.data(), sizeof(int64_t) * (rows + 1), 0, s);
+    if (any_null) {
+      c->validity = dev_alloc(valid.size(), s);
+      copy_in(c->validity->p, valid.data(), valid.size(), 0, s);
+    } else {
+      c->null_count = 0;
+    }
+    CS_HIP(hipStreamSynchronize(s));  // staging vectors die here
+    *out = holder.release();
+  });
+}
+
+int cs_column_from_offsets32(const char* chars, int64_t rows, const int32_t* offsets,
+                             const uint8_t* validity, int on_device, cs_stream stream, cs_column** out) {
+  return guard([&] {
+    if (!out || rows < 0 || (rows > 0 && (!offsets))) fail(CS_ERR_INVALID_ARG, "create_from_offsets: bad arguments");
+    require_device();
+    hipStream_t s = S(stream);
+    if (rows == 0) {
+      *out = make_all_null(0, s);
+      return;
+    }
+    Buf o32 = dev_alloc(sizeof(int32_t) * (rows + 1), s);
+    copy_in(o32->p, offsets, sizeof(int32_t) * (rows + 1), on_device, s);
+    int32_t ends[2];
+    CS_HIP(hipMemcpyAsync(&ends[0], ptr<int32_t>(o32), 4, hipMemcpyDeviceToHost, s));
+    CS_HIP(hipMemcpyAsync(&ends[1], ptr<int32_t>(o32) + rows, 4, hipMemcpyDeviceToHost, s));
+    CS_HIP(hipStreamSynchronize(s));
+    if (ends[1] < ends[0] || ends[0] < 0) fail(CS_ERR_INVALID_ARG, "create_from_offsets: offsets are not ascending");
+    int64_t span = ends[1];
+    if (span > 0 && !chars) fail(CS_ERR_INVALID_ARG, "create_from_offsets: chars is null");
+    Buf o64 = dev_alloc(sizeof(int64_t) * (rows + 1), s);
+    hipLaunchKernelGGL(k_widen_offsets, dim3(blocks_for(rows + 1)), dim3(kBlock), 0, s,
+                       ptr<int32_t>(o32), rows + 1, ptr<int64_t>(o64));
+    Buf ch = dev_alloc((size_t)span, s);
+    copy_in(ch->p, chars, (size_t)span, on_device, s);
+    Buf v;
+    if (validity) {
+      v = dev_alloc(validity_bytes(rows), s);
+      CS_HIP(hipMemsetAsync(v->p, 0, validity_bytes(rows), s));
+      copy_in(v->p, validity, (size_t)((rows + 7) / 8), on_device, s);
+    }
+    *out = canonicalise(ch, o64, v, rows, span, validity != nullptr, s);
+  });
+}
+
+int cs_column_from_offsets64(const uint8_t* chars, int64_t rows, const int64_t* offsets,
+                             const uint8_t* validity, int on_device, int copy, cs_stream stream,
+                             cs_column** out) {
+  return guard([&] {
+    if (!out || rows < 0 || (rows > 0 && !offsets)) fail(CS_ERR_INVALID_ARG, "from_offsets64: bad arguments");
+    if (!copy && !on_device) fail(CS_ERR_INVALID_ARG, "from_offsets64: zero-copy needs device buffers");
+    require_device();
+    hipStream_t s = S(stream);
+    if (rows == 0) {
+      *out = make_all_null(0, s);
+      return;
+    }
+    int64_t ends[2];
+    if (on_device) {
+      CS_HIP(hipMemcpyAsync(&ends[0], offsets, 8, hipMemcpyDeviceToHost, s));
+      CS_HIP(hipMemcpyAsync(&ends[1], offsets + rows, 8, hipMemcpyDeviceToHost, s));
+      CS_HIP(hipStreamSynchronize(s));
+    } else {
+      ends[0] = offsets[0];
+      ends[1] = offsets[rows];
+    }
+    if (ends[1] < ends[0] || ends[0] < 0) fail(CS_ERR_INVALID_ARG, "from_offsets64: offsets are not ascending");
+    if (!copy) {
+      // borrowed buffers must already be canonical (offsets[0]==0; null rows empty)
+      if (ends[0] != 0) fail(CS_ERR_INVALID_ARG, "from_offsets64: zero-copy needs offsets[0]==0");
+      auto* c = new cs_column;
+      c->rows = rows;
+      c->nbytes = ends[1];
+      c->chars = dev_wrap(chars, (size_t)ends[1]);
+      c->offsets = dev_wrap(offsets, sizeof(int64_t) * (rows + 1));
+      if (validity) {
+        // the engine writes/reads validity in 8-byte words: copy the small mask
+        c->validity = dev_alloc(validity_bytes(rows), s);
+        CS_HIP(hipMemsetAsync(c->validity->p, 0, validity_bytes(rows), s));
+        copy_in(c->validity->p, validity, (size_t)((rows + 7) / 8), 1, s);
+      } else {
+        c->null_count = 0;
+      }
+      *out = c;
+      return;
+    }
+    Buf o64 = dev_alloc(sizeof(int64_t) * (rows + 1), s);
+    copy_in(o64->p, offsets, sizeof(int64_t) * (rows + 1), on_device, s);
+    Buf ch = dev_alloc((size_t)ends[1], s);
+    copy_in(ch->p, chars, (size_t)ends[1], on_device, s);
+    Buf v;
+    if (validity) {
+      v = dev_alloc(validity_bytes(rows), s);
+      CS_HIP(hipMemsetAsync(v->p, 0, validity_bytes(rows), s));
+      copy_in(v->p, validity, (size_t)((rows + 7) / 8), on_device, s);
+    }
+    cs_column* c = canonicalise(ch, o64, v, rows, ends[1], validity != nullptr, s);
+    if (!on_device) CS_HIP(hipStreamSynchronize(s));
+    *out = c;
+  });
+}
+
+int cs_column_concat(const cs_column* const* cols, int n, cs_stream stream, cs_column** out) {
+  return guard([&] {
+    if (!out || n < 0 || (n > 0 && !cols)) fail(CS_ERR_INVALID_ARG, "create_from_strings: bad arguments");
+    require_device();
+    std::vector<const cs_column*> v;
+    for (int i = 0; i < n; ++i) {
+      if (!cols[i]) fail(CS_ERR_INVALID_ARG, "create_from_strings: null column");
+      v.push_back(cols[i]);
+    }
+    *out = concat_columns(v, S(stream));
+  });
+}
+
+int cs_column_slice(const cs_column* col, int64_t first, int64_t rows, cs_stream stream, cs_column** out) {
+  return guard([&] {
+    if (!col || !out || first < 0 || rows < 0 || first + rows > col->rows)
+      fail(CS_ERR_INVALID_ARG, "sublist: row range out of bounds");
+    require_device();
+    hipStream_t s = S(stream);
+    if (rows == 0) {
+      *out = make_all_null(0, s);
+      return;
+    }
+    auto c = std::make_unique<cs_column>();
+    c->rows = rows;
+    c->offsets = dev_alloc(sizeof(int64_t) * (rows + 1), s);
+    if (col->validity) c->validity = dev_alloc(validity_bytes(rows), s);
+    else c->null_count = 0;
+    hipLaunchKernelGGL(k_slice, dim3(blocks_for(rows + 1)), dim3(kBlock), 0, s, view_of(col), first, rows,
+                       ptr<int64_t>(c->offsets), ptr<uint8_t>(c->validity));
+    int64_t* host = (int64_t*)pinned_scratch(16);
+    CS_HIP(hipMemcpyAsync(host, col->d_offsets() + first, 8, hipMemcpyDeviceToHost, s));
+    CS_HIP(hipMemcpyAsync(host + 1, col->d_offsets() + first + rows, 8, hipMemcpyDeviceToHost, s));
+    CS_HIP(hipStreamSynchronize(s));
+    c->nbytes = host[1] - host[0];
+    c->chars = dev_alloc((size_t)c->nbytes, s);
+    if (c->nbytes)
+      CS_HIP(hipMemcpyAsync(c->chars->p, col->d_chars() + host[0], (size_t)c->nbytes, hipMemcpyDeviceToDevice, s));
+    *out = c.release();
+  });
+}
+
+int cs_column_destroy(cs_column* col) {
+  return guard([&] { delete col; });
+}
+int64_t cs_column_rows(const cs_column* col) { return col ? col->rows : 0; }
+int64_t cs_column_nbytes(const cs_column* col) { return col ? col->nbytes : 0; }
+int64_t cs_column_null_count(const cs_column* col) {
+  int64_t n = -1;
+  int st = guard([&] {
+    if (!col) fail(CS_ERR_INVALID_ARG, "null column");
+    n = count_nulls(col, nullptr);
+  });
+  return st == CS_OK ? n : -1;
+}
+int cs_column_get_view(const cs_column* col, cs_column_view* view) {
+  return guard([&] {
+    if (!col || !view) fail(CS_ERR_INVALID_ARG, "null argument");
+    view->chars = col->d_chars();
+    view->offsets = col->d_offsets();
+    view->validity = col->d_validity();
+    view->rows = col->rows;
+    view->nbytes = col->nbytes;
+    view->null_count = col->null_count;
+  });
+}
+
+int cs_column_export_offsets64(const cs_column* col, uint8_t* chars, int64_t* offsets, uint8_t* validity,
+                               int on_device, cs_stream stream) {
+  return guard([&] {
+    if (!col) fail(CS_ERR_INVALID_ARG, "null column");
+    hipStream_t s = S(stream);
+    if (col->rows == 0) return;
+    if (chars) copy_out(chars, col->d_chars(), (size_t)col->nbytes, on_device, s);
+    if (offsets) copy_out(offsets, col->d_offsets(), sizeof(int64_t) * (col->rows + 1), on_device, s);
+    if (validity) {
+      int64_t nulls = 0;
+      // materialise (rows+7)/8 bytes even when the column has no mask
+      Buf bits = dev_alloc((size_t)((col->rows + 7) / 8) + 8, s);
+      Buf cnt = dev_alloc(8, s);
+      CS_HIP(hipMemsetAsync(cnt->p, 0, 8, s));
+      hipLaunchKernelGGL(k_null_bitarray, dim3(blocks_for((col->rows + 7) / 8)), dim3(kBlock), 0, s,
+                         view_of(col), 0, ptr<uint8_t>(bits), ptr<unsigned long long>(cnt));
+      copy_out(validity, bits->p, (size_t)((col->rows + 7) / 8), on_device, s);
+      CS_HIP(hipStreamSynchronize(s));
+      (void)nulls;
+    }
+    if (!on_device) CS_HIP(hipStreamSynchronize(s));
+  });
+}
+
+int cs_column_export_offsets32(const cs_column* col, char* chars, int32_t* offsets, uint8_t* validity,
+                               int on_device, cs_stream stream) {
+  return guard([&] {
+    if (!col) fail(CS_ERR_INVALID_ARG, "null column");
+    if (col->rows == 0) return;
+    if (!chars || !offsets) return;  // the reference returns 0 without doing anything (NVStrings.cu:406-407)
+    if (col->nbytes >= (1LL << 31)) fail(CS_ERR_RANGE, "create_offsets: column holds >= 2 GiB of chars; int32 offsets cannot address it");
+    hipStream_t s = S(stream);
+    Buf o32 = dev_alloc(sizeof(int32_t) * (col->rows + 1), s);
+    hipLaunchKernelGGL(k_narrow_offsets, dim3(blocks_for(col->rows + 1)), dim3(kBlock), 0, s,
+                       col->d_offsets(), col->rows + 1, ptr<int32_t>(o32));
+    copy_out(offsets, o32->p, sizeof(int32_t) * (col->rows + 1), on_device, s);
+    CS_HIP(hipStreamSynchronize(s));
+    int st = cs_column_export_offsets64(col, (uint8_t*)chars, nullptr, validity, on_device, stream);
+    if (st != CS_OK) fail(st, g_last_error);
+  });
+}
+
+int cs_column_byte_count(const cs_column* col, int32_t* lengths, int on_device, cs_stream stream,
+                         int64_t* total) {
+  return guard([&] {
+    if (!col) fail(CS_ERR_INVALID_ARG, "null column");
+    hipStream_t s = S(stream);
+    if (total) *total = 0;
+    if (col->rows == 0) return;
+    Buf tmp;
+    int32_t* d_out = lengths;
+    if (!on_device || !lengths) {
+      tmp = dev_alloc(sizeof(int32_t) * col->rows, s);
+      d_out = ptr<int32_t>(tmp);
+    }
+    Buf tot = dev_alloc(8, s);
+    CS_HIP(hipMemsetAsync(tot->p, 0, 8, s));
+    hipLaunchKernelGGL(k_byte_count, dim3(blocks_for(col->rows)), dim3(kBlock), 0, s, view_of(col), d_out,
+                       ptr<unsigned long long>(tot));
+    if (lengths && !on_device) copy_out(lengths, d_out, sizeof(int32_t) * col->rows, 0, s);
+    int64_t* host = (int64_t*)pinned_scratch(8);
+    CS_HIP(hipMemcpyAsync(host, tot->p, 8, hipMemcpyDeviceToHost, s));
+    CS_HIP(hipStreamSynchronize(s));
+    if (total) *total = host[0];
+  });
+}
+
+int cs_column_null_bitarray(const cs_column* col, uint8_t* bitarray, int empty_is_null, int on_device,
+                            cs_stream stream, int64_t* null_count) {
+  return guard([&] {
+    if (!col || !bitarray) fail(CS_ERR_INVALID_ARG, "null argument");
+    hipStream_t s = S(stream);
+    if (null_count) *null_count = 0;
+    if (col->rows == 0) return;
+    size_t nb = (size_t)((col->rows + 7) / 8);
+    Buf tmp;
+    uint8_t* d_bits = bitarray;
+    if (!on_device) {
+      tmp = dev_alloc(nb, s);
+      d_bits = ptr<uint8_t>(tmp);
+    }
+    Buf cnt = dev_alloc(8, s);
+    CS_HIP(hipMemsetAsync(cnt->p, 0, 8, s));
+    hipLaunchKernelGGL(k_null_bitarray, dim3(blocks_for((int64_t)nb)), dim3(kBlock), 0, s, view_of(col),
+                       empty_is_null, d_bits, ptr<unsigned long long>(cnt));
+    if (!on_device) copy_out(bitarray, d_bits, nb, 0, s);
+    int64_t* host = (int64_t*)pinned_scratch(8);
+    CS_HIP(hipMemcpyAsync(host, cnt->p, 8, hipMemcpyDeviceToHost, s));
+    CS_HIP(hipStreamSynchronize(s));
+    if (null_count) *null_count = host[0];
+  });
+}
+
+int cs_column_digest(const cs_column* col, cs_stream stream, uint64_t* digest) {
+  return guard([&] {
+    if (!col || !digest) fail(CS_ERR_INVALID_ARG, "null argument");
+    hipStream_t s = S(stream);
+    *digest = 0;
+    if (col->rows == 0) return;
+    Buf acc = dev_alloc(8, s);
+    CS_HIP(hipMemsetAsync(acc->p, 0, 8, s));
+    hipLaunchKernelGGL(k_digest, dim3(blocks_for(col->rows)), dim3(kBlock), 0, s, view_of(col),
+                       ptr<unsigned long long>(acc));
+    uint64_t* host = (uint64_t*)pinned_scratch(8);
+    CS_HIP(hipMemcpyAsync(host, acc->p, 8, hipMemcpyDeviceToHost, s));
+    CS_HIP(hipStreamSynchronize(s));
+    *digest = host[0];
+  });
+}
+
+int cs_prof_reset(void) {
+  return guard([&] {
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (auto& kv : g_prof) prof_collect(kv.second);
+    g_prof.clear();
+  });
+}
+int cs_prof_enable(int on) {
+  g_prof_on = on != 0;
+  return CS_OK;
+}
+int cs_prof_get(const char* kernel, double* total_ms, int64_t* launches) {
+  return guard([&] {
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = g_prof.find(kernel ? kernel : "");
+    if (it == g_prof.end()) {
+      if (total_ms) *total_ms = 0;
+      if (launches) *launches = 0;
+      return;
+    }
+    prof_collect(it->second);
+    if (total_ms) *total_ms = it->second.ms;
+    if (launches) *launches = it->second.launches;
+  });
+}
+
+}  // extern "C"

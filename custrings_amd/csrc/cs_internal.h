@@ -1,0 +1,134 @@
+// Internal host-side plumbing shared by the library's translation units:
+// error handling, the device buffer cache, the column object and the
+// lengths -> offsets scan.  Not part of the public ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/custrings_amd.h"
+
+namespace cs {
+
+struct Error {
+  int code;
+  std::string msg;
+};
+[[noreturn]] void fail(int code, const std::string& msg);
+void set_last_error(const std::string& msg);
+
+#define CS_HIP(expr)                                                                      \
+  do {                                                                                    \
+    hipError_t e_ = (expr);                                                               \
+    if (e_ != hipSuccess)                                                                 \
+      ::cs::fail(CS_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));          \
+  } while (0)
+
+// Runs `f`, mapping exceptions to status codes (nothing throws across the ABI).
+template <class F>
+int guard(F&& f) {
+  try {
+    f();
+    return CS_OK;
+  } catch (const Error& e) {
+    set_last_error(e.msg);
+    return e.code;
+  } catch (const std::bad_alloc&) {
+    set_last_error("host allocation failed");
+    return CS_ERR_ALLOC;
+  } catch (const std::exception& e) {
+    set_last_error(e.what());
+    return CS_ERR_INTERNAL;
+  }
+}
+
+void require_device();  // throws CS_ERR_NO_DEVICE unless cs_init succeeded on this thread's device
+
+// ---- device memory ----------------------------------------------------------
+// Buffers come from a size-bucketed cache over hipMalloc (one output allocation
+// per produced buffer, no allocation inside kernels).  Every buffer carries 64
+// bytes of slack so 16-byte vector loads may run past the logical end.
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;     // usable bytes requested
+  size_t capacity = 0;  // bytes actually held (0 for wrapped buffers)
+  hipStream_t stream = nullptr;
+  ~DevBuf();
+};
+using Buf = std::shared_ptr<DevBuf>;
+Buf dev_alloc(size_t bytes, hipStream_t stream);
+Buf dev_wrap(const void* p, size_t bytes);  // caller-owned, never freed
+template <class T>
+T* ptr(const Buf& b) {
+  return b ? static_cast<T*>(b->p) : nullptr;
+}
+int64_t dev_bytes_in_use();
+
+// pinned host scratch for small device->host results (per thread)
+void* pinned_scratch(size_t bytes);
+
+// unicode tables on the device (uploaded by cs_init)
+const uint8_t* d_unicode_flags();
+const uint16_t* d_charcases();
+const uint8_t* h_unicode_flags();
+
+}  // namespace cs
+
+// ---- the column ---------------------------------------------------------------
+struct cs_column {
+  int64_t rows = 0;
+  int64_t nbytes = 0;
+  mutable int64_t null_count = -1;  // -1 = not counted yet
+  cs::Buf chars, offsets, validity;  // validity may be null (all valid)
+  const uint8_t* d_chars() const { return cs::ptr<const uint8_t>(chars); }
+  const int64_t* d_offsets() const { return cs::ptr<const int64_t>(offsets); }
+  const uint8_t* d_validity() const { return cs::ptr<const uint8_t>(validity); }
+};
+
+namespace cs {
+
+struct ColView {  // passed to kernels by value
+  const uint8_t* chars;
+  const int64_t* offsets;
+  const uint8_t* validity;
+  int64_t rows;
+};
+inline ColView view_of(const cs_column* c) {
+  return ColView{c->d_chars(), c->d_offsets(), c->d_validity(), c->rows};
+}
+inline hipStream_t S(cs_stream s) { return static_cast<hipStream_t>(s); }
+inline unsigned blocks_for(int64_t rows) { return (unsigned)((rows + 255) / 256); }
+inline size_t validity_bytes(int64_t rows) { return (size_t)((rows + 63) / 64) * 8; }
+
+// Empty column with `rows` rows, all null (NVStrings(count)) or zero rows.
+cs_column* make_all_null(int64_t rows, hipStream_t s);
+
+// Exclusive scan of int32 lengths (negative = null row, counts as 0) into int64
+// offsets[n+1]; returns the total (synchronises `s`).  When `block_sums` is
+// given it must hold the per-256-row sums already (fused into the caller's size
+// kernel) and the lengths are read only once.
+int64_t offsets_from_lengths(const int32_t* lens, int64_t n, int64_t* offsets, hipStream_t s,
+                             Buf block_sums = nullptr);
+// Segmented variant: `segs` independent arrays of n lengths laid out back to
+// back (lens[seg * n + i]); offsets[seg * (n + 1) + i]; totals[seg] on the host.
+void offsets_from_lengths_segmented(const int32_t* lens, int64_t n, int segs, int64_t* offsets,
+                                    int64_t* totals_host, hipStream_t s);
+// Validity bitmask from int32 lengths (bit set when len >= 0).
+Buf validity_from_lengths(const int32_t* lens, int64_t n, hipStream_t s);
+int64_t count_nulls(const cs_column* c, hipStream_t s);
+// Row-wise concatenation of columns into one new column.
+cs_column* concat_columns(const std::vector<const cs_column*>& cols, hipStream_t s);
+
+// profiling hooks (cs_prof_*): time a named kernel launch with HIP events
+struct ProfScope {
+  const char* name;
+  hipStream_t s;
+  hipEvent_t a = nullptr, b = nullptr;
+  ProfScope(const char* name, hipStream_t s);
+  ~ProfScope();
+};
+
+}  // namespace cs

@@ -1,0 +1,655 @@
+// Row-parallel string ops: lower/upper, strip, find, contains, replace, split,
+// tokenize, ngrams.  One thread per row (256 rows per workgroup), every op is
+//   size kernel (+ fused block sums) -> block-sum scan -> offsets -> write kernel
+// with the per-row logic in row_ops.h.  Reference call sites are cited at each
+// entry point.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+
+#include "cs_internal.h"
+#include "device_utils.h"
+#include "row_ops.h"
+
+using namespace cs;
+using namespace csdev;
+using namespace csrow;
+
+namespace {
+
+struct Needle {  // small host string copied to the device
+  Buf buf;
+  int n = 0;
+  const uint8_t* d() const { return ptr<const uint8_t>(buf); }
+};
+Needle upload(const char* s, hipStream_t st) {
+  Needle nd;
+  nd.n = (int)strlen(s);
+  nd.buf = dev_alloc((size_t)nd.n + 1, st);
+  CS_HIP(hipMemcpyAsync(nd.buf->p, s, (size_t)nd.n + 1, hipMemcpyHostToDevice, st));
+  return nd;
+}
+CharSet make_set(const char* s, const char* what) {
+  CharSet cs;
+  cs.n = 0;
+  int n = (int)strlen(s), i = 0;
+  while (i < n) {
+    if (cs.n == 64) fail(CS_ERR_INVALID_ARG, std::string(what) + ": more than 64 characters in the character set");
+    Char c;
+    unsigned w = decode_at((const uint8_t*)s, i, n, c);
+    cs.c[cs.n++] = c;
+    i += w ? (int)w : 1;
+  }
+  return cs;
+}
+
+// ---- generic two-pass driver -------------------------------------------------
+// SizeFn:  int  operator()(const uint8_t* row, int len, int64_t r) const
+// WriteFn: void operator()(const uint8_t* row, int len, int64_t r, uint8_t* dst) const
+template <class SizeFn>
+__global__ void k_row_sizes(ColView in, SizeFn f, int32_t* __restrict__ lens,
+                            int64_t* __restrict__ block_sums) {
+  int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  int len = -1;
+  if (r < in.rows && row_is_valid(in.validity, r)) {
+    int64_t b = in.offsets[r];
+    len = f(in.chars + b, (int)(in.offsets[r + 1] - b), r);
+  }
+  if (r < in.rows) lens[r] = len;
+  long long t = block_reduce_sum(len < 0 ? 0 : len);
+  if (threadIdx.x == 0) block_sums[blockIdx.x] = t;
+}
+template <class WriteFn>
+__global__ void k_row_write(ColView in, WriteFn f, const int64_t* __restrict__ out_off,
+                            uint8_t* __restrict__ out_chars) {
+  int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (r >= in.rows || !row_is_valid(in.validity, r)) return;
+  int64_t b = in.offsets[r];
+  f(in.chars + b, (int)(in.offsets[r + 1] - b), r, out_chars + out_off[r]);
+}
+
+template <class SizeFn, class WriteFn>
+cs_column* two_pass(const cs_column* in, SizeFn sf, WriteFn wf, hipStream_t s, const char* size_name,
+                    const char* write_name) {
+  if (in->rows == 0) return make_all_null(0, s);
+  auto* out = new cs_column;
+  std::unique_ptr<cs_column> holder(out);
+  out->rows = in->rows;
+  out->validity = in->validity;  // null rows stay null; columns are immutable, so share
+  out->null_count = in->null_count;
+  unsigned nb = blocks_for(in->rows);
+  Buf lens = dev_alloc(sizeof(int32_t) * in->rows, s);
+  Buf sums = dev_alloc(sizeof(int64_t) * nb, s);
+  {
+    ProfScope ps(size_name, s);
+    hipLaunchKernelGGL(k_row_sizes<SizeFn>, dim3(nb), dim3(kBlock), 0, s, view_of(in), sf,
+                       ptr<int32_t>(lens), ptr<int64_t>(sums));
+  }
+  out->offsets = dev_alloc(sizeof(int64_t) * (in->rows + 1), s);
+  out->nbytes = offsets_from_lengths(ptr<int32_t>(lens), in->rows, ptr<int64_t>(out->offsets), s, sums);
+  out->chars = dev_alloc((size_t)out->nbytes, s);
+  {
+    ProfScope ps(write_name, s);
+    hipLaunchKernelGGL(k_row_write<WriteFn>, dim3(nb), dim3(kBlock), 0, s, view_of(in), wf,
+                       out->d_offsets(), ptr<uint8_t>(out->chars));
+  }
+  return holder.release();
+}
+
+// ---- functors ---------------------------------------------------------------------
+struct CaseSize {
+  const uint8_t* flags;
+  const uint16_t* cases;
+  unsigned bit;
+  __device__ int operator()(const uint8_t* p, int n, int64_t) const { return row_case_size(p, n, flags, cases, bit); }
+};
+struct CaseWrite {
+  const uint8_t* flags;
+  const uint16_t* cases;
+  unsigned bit;
+  __device__ void operator()(const uint8_t* p, int n, int64_t, uint8_t* o) const { row_case_write(p, n, flags, cases, bit, o); }
+};
+struct StripSize {
+  CharSet set;
+  int side;
+  __device__ int operator()(const uint8_t* p, int n, int64_t) const {
+    int lo, hi;
+    row_strip(p, n, set, side, lo, hi);
+    return hi - lo;
+  }
+};
+struct StripWrite {
+  CharSet set;
+  int side;
+  __device__ void operator()(const uint8_t* p, int n, int64_t, uint8_t* o) const {
+    int lo, hi;
+    row_strip(p, n, set, side, lo, hi);
+    for (int i = lo; i < hi; ++i) *o++ = p[i];
+  }
+};
+struct ReplaceSize {
+  const uint8_t* needle;
+  int nb, rb, maxrepl;
+  __device__ int operator()(const uint8_t* p, int n, int64_t) const { return row_replace_size(p, n, needle, nb, rb, maxrepl); }
+};
+struct ReplaceWrite {
+  const uint8_t* needle;
+  const uint8_t* repl;
+  int nb, rb, maxrepl;
+  __device__ void operator()(const uint8_t* p, int n, int64_t, uint8_t* o) const { row_replace_write(p, n, needle, nb, repl, rb, maxrepl, o); }
+};
+
+// ---- find / contains ------------------------------------------------------------------
+__global__ void k_find(ColView in, const uint8_t* __restrict__ needle, int nb, int start, int end,
+                       int32_t* __restrict__ out, unsigned long long* __restrict__ found) {
+  int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  int hit = 0;
+  if (r < in.rows) {
+    int v = -2;  // null row (find.cu:108)
+    if (row_is_valid(in.validity, r)) {
+      int64_t b = in.offsets[r];
+      v = row_find(in.chars + b, (int)(in.offsets[r + 1] - b), needle, nb, start, end);
+    }
+    out[r] = v;
+    hit = v != -1;  // null rows are counted too (find.cu:112)
+  }
+  long long t = block_reduce_sum(hit);
+  if (threadIdx.x == 0 && t) atomicAdd(found, (unsigned long long)t);
+}
+__global__ void k_contains(ColView in, const uint8_t* __restrict__ needle, int nb,
+                           uint8_t* __restrict__ out, unsigned long long* __restrict__ found) {
+  int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  int hit = 0;
+  if (r < in.rows) {
+    if (nb > 0 && row_is_valid(in.validity, r)) {
+      int64_t b = in.offsets[r];
+      hit = find_bytes(in.chars + b, 0, (int)(in.offsets[r + 1] - b), needle, nb) >= 0;
+    }
+    out[r] = (uint8_t)hit;
+  }
+  long long t = block_reduce_sum(hit);
+  if (threadIdx.x == 0 && t) atomicAdd(found, (unsigned long long)t);
+}
+
+// ---- split ---------------------------------------------------------------------------------
+struct SplitArgs {
+  const uint8_t* delim;  // nullptr = whitespace
+  int nb;
+  int tokens;
+};
+__global__ void k_split_count(ColView in, SplitArgs a, int32_t* __restrict__ counts, int* __restrict__ max_out) {
+  int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  int c = 0;
+  if (r < in.rows) {
+    if (row_is_valid(in.validity, r)) {
+      int64_t b = in.offsets[r];
+      int n = (int)(in.offsets[r + 1] - b);
+      c = a.delim ? row_split_count(in.chars + b, n, a.delim, a.nb, a.tokens)
+                  : row_wssplit_count(in.chars + b, n, a.tokens);
+    }
+    counts[r] = c;
+  }
+  int m = block_reduce_max(c);
+  if (threadIdx.x == 0 && m) atomicMax(max_out, m);
+}
+// lens[k * rows + r] = byte length of token k of row r, -1 when the row has no
+// such token (null in that column); block sums per column are fused in.
+__global__ void k_split_sizes(ColView in, SplitArgs a, const int32_t* __restrict__ counts, int ncols,
+                              int32_t* __restrict__ lens, int64_t* __restrict__ block_sums) {
+  int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int64_t rows = in.rows;
+  if (r < rows) {
+    for (int k = 0; k < ncols; ++k) lens[(int64_t)k * rows + r] = -1;
+    int c = counts[r];
+    if (c > 0) {
+      int64_t b = in.offsets[r];
+      int n = (int)(in.offsets[r + 1] - b);
+      auto emit = [&](int k, int lo, int hi) {
+        if (k < ncols) lens[(int64_t)k * rows + r] = hi - lo;
+      };
+      if (a.delim) row_split_tokens(in.chars + b, n, a.delim, a.nb, c, emit);
+      else row_ws_tokens(in.chars + b, n, a.tokens, emit);
+    }
+  }
+  for (int k = 0; k < ncols; ++k) {
+    int v = (r < rows) ? lens[(int64_t)k * rows + r] : 0;
+    long long t = block_reduce_sum(v < 0 ? 0 : v);
+    if (threadIdx.x == 0) block_sums[(int64_t)k * gridDim.x + blockIdx.x] = t;
+  }
+}
+struct SplitOut {
+  uint8_t* chars;
+  const int64_t* offsets;
+};
+__global__ void k_split_write(ColView in, SplitArgs a, const int32_t* __restrict__ counts, int ncols,
+                              const SplitOut* __restrict__ outs) {
+  int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (r >= in.rows) return;
+  int c = counts[r];
+  if (c <= 0) return;
+  int64_t b = in.offsets[r];
+  int n = (int)(in.offsets[r + 1] - b);
+  const uint8_t* p = in.chars + b;
+  auto emit = [&](int k, int lo, int hi) {
+    if (k >= ncols) return;
+    uint8_t* o = outs[k].chars + outs[k].offsets[r];
+    for (int i = lo; i < hi; ++i) *o++ = p[i];
+  };
+  if (a.delim) row_split_tokens(p, n, a.delim, a.nb, c, emit);
+  else row_ws_tokens(p, n, a.tokens, emit);
+}
+
+// ---- tokenize --------------------------------------------------------------------------------
+struct TokArgs {
+  CharSet set;
+  int use_set;  // 0 = whitespace
+};
+__global__ void k_tok_count(ColView in, TokArgs a, int32_t* __restrict__ counts,
+                            int64_t* __restrict__ block_sums) {
+  int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  int c = 0;
+  if (r < in.rows && row_is_valid(in.validity, r)) {
+    int64_t b = in.offsets[r];
+    int n = (int)(in.offsets[r + 1] - b);
+    if (a.use_set) c = row_set_tokens(in.chars + b, n, a.set, [](int, int, int) {});
+    else c = row_ws_count(in.chars + b, n);
+  }
+  if (r < in.rows) counts[r] = c;
+  long long t = block_reduce_sum(c);
+  if (threadIdx.x == 0) block_sums[blockIdx.x] = t;
+}
+// phase 0: token lengths into tok_lens[tok_base[r] + k]; phase 1: copy bytes
+template <int PHASE>
+__global__ void k_tok_emit(ColView in, TokArgs a, const int64_t* __restrict__ tok_base,
+                           int32_t* __restrict__ tok_lens, const int64_t* __restrict__ out_off,
+                           uint8_t* __restrict__ out_chars) {
+  int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (r >= in.rows || !row_is_valid(in.validity, r)) return;
+  int64_t t0 = tok_base[r];
+  if (tok_base[r + 1] == t0) return;
+  int64_t b = in.offsets[r];
+  int n = (int)(in.offsets[r + 1] - b);
+  const uint8_t* p = in.chars + b;
+  auto emit = [&](int k, int lo, int hi) {
+    if (PHASE == 0) {
+      tok_lens[t0 + k] = hi - lo;
+    } else {
+      uint8_t* o = out_chars + out_off[t0 + k];
+      for (int i = lo; i < hi; ++i) *o++ = p[i];
+    }
+  };
+  if (a.use_set) row_set_tokens(p, n, a.set, emit);
+  else row_ws_tokens(p, n, 0, emit);
+}
+
+// ---- ngrams -----------------------------------------------------------------------------------
+__global__ void k_keep_flags(ColView in, int32_t* __restrict__ flags) {
+  int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (r < in.rows) flags[r] = row_is_valid(in.validity, r) && in.offsets[r + 1] > in.offsets[r];
+}
+__global__ void k_keep_scatter(const int32_t* __restrict__ flags, const int64_t* __restrict__ pos,
+                               int64_t rows, int32_t* __restrict__ kept) {
+  int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (r < rows && flags[r]) kept[pos[r]] = (int32_t)r;
+}
+__global__ void k_ngram_sizes(ColView in, const int32_t* __restrict__ kept, int64_t count, int n,
+                              int sep, int32_t* __restrict__ lens) {
+  int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (g >= count) return;
+  int sz = (n - 1) * sep;
+  for (int k = 0; k < n; ++k) {
+    int64_t r = kept[g + k];
+    sz += (int)(in.offsets[r + 1] - in.offsets[r]);
+  }
+  lens[g] = sz;
+}
+__global__ void k_ngram_write(ColView in, const int32_t* __restrict__ kept, int64_t count, int n,
+                              const uint8_t* __restrict__ sep, int sepn,
+                              const int64_t* __restrict__ out_off, uint8_t* __restrict__ out_chars) {
+  int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (g >= count) return;
+  uint8_t* o = out_chars + out_off[g];
+  for (int k = 0; k < n; ++k) {
+    int64_t r = kept[g + k];
+    const uint8_t* p = in.chars + in.offsets[r];
+    int len = (int)(in.offsets[r + 1] - in.offsets[r]);
+    for (int i = 0; i < len; ++i) *o++ = p[i];
+    if (k + 1 < n)
+      for (int i = 0; i < sepn; ++i) *o++ = sep[i];
+  }
+}
+// join(sep, narep="") of every row into one string (combine.cu:291-420 as used by ngram.cu:51-52)
+__global__ void k_join_sizes(ColView in, int sepn, int32_t* __restrict__ lens) {
+  int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (r >= in.rows) return;
+  int len = row_is_valid(in.validity, r) ? (int)(in.offsets[r + 1] - in.offsets[r]) : 0;
+  lens[r] = len + (r + 1 < in.rows ? sepn : 0);
+}
+__global__ void k_join_write(ColView in, const uint8_t* __restrict__ sep, int sepn,
+                             const int64_t* __restrict__ pos, uint8_t* __restrict__ out) {
+  int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (r >= in.rows) return;
+  uint8_t* o = out + pos[r];
+  if (row_is_valid(in.validity, r)) {
+    const uint8_t* p = in.chars + in.offsets[r];
+    int len = (int)(in.offsets[r + 1] - in.offsets[r]);
+    for (int i = 0; i < len; ++i) *o++ = p[i];
+  }
+  if (r + 1 < in.rows)
+    for (int i = 0; i < sepn; ++i) *o++ = sep[i];
+}
+
+cs_column* share(const cs_column* in) { return new cs_column(*in); }
+
+template <class T>
+T read_back(const Buf& b, hipStream_t s) {
+  T* host = (T*)pinned_scratch(sizeof(T));
+  CS_HIP(hipMemcpyAsync(host, b->p, sizeof(T), hipMemcpyDeviceToHost, s));
+  CS_HIP(hipStreamSynchronize(s));
+  return *host;
+}
+
+}  // namespace
+
+extern "C" {
+
+// NVStrings::lower / upper -- case.cu:31-97 / :100-170
+static int change_case(const cs_column* col, unsigned bit, cs_stream stream, cs_column** out, const char* nm) {
+  return guard([&] {
+    if (!col || !out) fail(CS_ERR_INVALID_ARG, "null argument");
+    require_device();
+    *out = two_pass(col, CaseSize{d_unicode_flags(), d_charcases(), bit},
+                    CaseWrite{d_unicode_flags(), d_charcases(), bit}, S(stream),
+                    bit == 32 ? "k_lower_size" : "k_upper_size", nm);
+  });
+}
+int cs_lower(const cs_column* col, cs_stream stream, cs_column** out) { return change_case(col, 32, stream, out, "k_lower_write"); }
+int cs_upper(const cs_column* col, cs_stream stream, cs_column** out) { return change_case(col, 64, stream, out, "k_upper_write"); }
+
+// NVStrings::strip family -- strip.cu:30-199
+int cs_strip(const cs_column* col, const char* to_strip, int side, cs_stream stream, cs_column** out) {
+  return guard([&] {
+    if (!col || !out || side < 0 || side > 2) fail(CS_ERR_INVALID_ARG, "strip: bad arguments");
+    require_device();
+    CharSet set = make_set(to_strip ? to_strip : " \n\t", "strip");
+    *out = two_pass(col, StripSize{set, side}, StripWrite{set, side}, S(stream), "k_strip_size", "k_strip_write");
+  });
+}
+
+// NVStrings::find -- find.cu:75-120
+int cs_find(const cs_column* col, const char* str, int start, int end, int32_t* results, int on_device,
+            cs_stream stream, int64_t* found) {
+  return guard([&] {
+    if (found) *found = 0;
+    if (!col || !str || !results || col->rows == 0) return;  // reference returns 0 (find.cu:78-79)
+    require_device();
+    hipStream_t s = S(stream);
+    Needle nd = upload(str, s);
+    Buf tmp, cnt = dev_alloc(8, s);
+    CS_HIP(hipMemsetAsync(cnt->p, 0, 8, s));
+    int32_t* d_out = results;
+    if (!on_device) {
+      tmp = dev_alloc(sizeof(int32_t) * col->rows, s);
+      d_out = ptr<int32_t>(tmp);
+    }
+    {
+      ProfScope ps("k_find", s);
+      hipLaunchKernelGGL(k_find, dim3(blocks_for(col->rows)), dim3(kBlock), 0, s, view_of(col), nd.d(),
+                         nd.n, start, end, d_out, ptr<unsigned long long>(cnt));
+    }
+    if (!on_device)
+      CS_HIP(hipMemcpyAsync(results, d_out, sizeof(int32_t) * col->rows, hipMemcpyDeviceToHost, s));
+    int64_t n = read_back<int64_t>(cnt, s);
+    if (found) *found = n;
+  });
+}
+
+// NVStrings::contains -- find.cu:237-272
+int cs_contains(const cs_column* col, const char* str, uint8_t* results, int on_device, cs_stream stream,
+                int64_t* found) {
+  return guard([&] {
+    if (found) *found = -1;
+    if (!col || !str || !results) fail(CS_ERR_INVALID_ARG, "contains: null argument");  // reference returns -1
+    if (found) *found = 0;
+    if (col->rows == 0) return;
+    require_device();
+    hipStream_t s = S(stream);
+    Needle nd = upload(str, s);
+    Buf tmp, cnt = dev_alloc(8, s);
+    CS_HIP(hipMemsetAsync(cnt->p, 0, 8, s));
+    uint8_t* d_out = results;
+    if (!on_device) {
+      tmp = dev_alloc((size_t)col->rows, s);
+      d_out = ptr<uint8_t>(tmp);
+    }
+    {
+      ProfScope ps("k_contains", s);
+      hipLaunchKernelGGL(k_contains, dim3(blocks_for(col->rows)), dim3(kBlock), 0, s, view_of(col), nd.d(),
+                         nd.n, d_out, ptr<unsigned long long>(cnt));
+    }
+    if (!on_device) CS_HIP(hipMemcpyAsync(results, d_out, (size_t)col->rows, hipMemcpyDeviceToHost, s));
+    int64_t n = read_back<int64_t>(cnt, s);
+    if (found) *found = n;
+  });
+}
+
+// NVStrings::replace -- modify.cu:109-192
+int cs_replace(const cs_column* col, const char* str, const char* repl, int maxrepl, cs_stream stream,
+               cs_column** out) {
+  return guard([&] {
+    if (!col || !out) fail(CS_ERR_INVALID_ARG, "null argument");
+    if (!str || !*str) fail(CS_ERR_INVALID_ARG, "replace parameter cannot be null or empty");
+    require_device();
+    hipStream_t s = S(stream);
+    if (!repl) repl = "";
+    Needle nd = upload(str, s), rp = upload(repl, s);
+    *out = two_pass(col, ReplaceSize{nd.d(), nd.n, rp.n, maxrepl},
+                    ReplaceWrite{nd.d(), rp.d(), nd.n, rp.n, maxrepl}, s, "k_replace_size", "k_replace_write");
+  });
+}
+
+// NVStrings::split(delimiter,maxsplit,results) / split(maxsplit,results) -- split.cu:734-956
+int cs_split(const cs_column* col, const char* delimiter, int maxsplit, cs_stream stream,
+             cs_column*** out_cols, int* ncols_out) {
+  return guard([&] {
+    if (!col || !out_cols || !ncols_out) fail(CS_ERR_INVALID_ARG, "null argument");
+    require_device();
+    hipStream_t s = S(stream);
+    const int64_t rows = col->rows;
+    SplitArgs a{nullptr, 0, maxsplit > 0 ? maxsplit + 1 : 0};
+    Needle nd;
+    if (delimiter) {
+      nd = upload(delimiter, s);
+      a.delim = nd.d();
+      a.nb = nd.n;
+    }
+    int ncols = 0;
+    Buf counts;
+    const unsigned nb = blocks_for(rows);
+    if (rows) {
+      counts = dev_alloc(sizeof(int32_t) * rows, s);
+      Buf mx = dev_alloc(sizeof(int), s);
+      CS_HIP(hipMemsetAsync(mx->p, 0, sizeof(int), s));
+      {
+        ProfScope ps("k_split_count", s);
+        hipLaunchKernelGGL(k_split_count, dim3(nb), dim3(kBlock), 0, s, view_of(col), a,
+                           ptr<int32_t>(counts), ptr<int>(mx));
+      }
+      ncols = read_back<int>(mx, s);
+    }
+    std::vector<std::unique_ptr<cs_column>> cols;
+    if (ncols == 0) {
+      // no columns: one all-null column (split.cu:756-757)
+      cols.emplace_back(make_all_null(rows, s));
+    } else {
+      Buf lens = dev_alloc(sizeof(int32_t) * rows * ncols, s);
+      Buf sums = dev_alloc(sizeof(int64_t) * (size_t)nb * ncols, s);
+      {
+        ProfScope ps("k_split_sizes", s);
+        hipLaunchKernelGGL(k_split_sizes, dim3(nb), dim3(kBlock), 0, s, view_of(col), a,
+                           ptr<int32_t>(counts), ncols, ptr<int32_t>(lens), ptr<int64_t>(sums));
+      }
+      // per-column offsets: one segmented scan over the fused block sums
+      Buf offs = dev_alloc(sizeof(int64_t) * (rows + 1) * ncols, s);
+      std::vector<int64_t> totals(ncols);
+      offsets_from_lengths_segmented(ptr<int32_t>(lens), rows, ncols, ptr<int64_t>(offs), totals.data(), s);
+      std::vector<SplitOut> outs(ncols);
+      for (int k = 0; k < ncols; ++k) {
+        auto* c = new cs_column;
+        cols.emplace_back(c);
+        c->rows = rows;
+        c->nbytes = totals[k];
+        c->chars = dev_alloc((size_t)totals[k], s);
+        // each column owns its offsets: copy its segment out of the scan buffer
+        c->offsets = dev_alloc(sizeof(int64_t) * (rows + 1), s);
+        CS_HIP(hipMemcpyAsync(c->offsets->p, ptr<int64_t>(offs) + (int64_t)k * (rows + 1),
+                              sizeof(int64_t) * (rows + 1), hipMemcpyDeviceToDevice, s));
+        c->validity = validity_from_lengths(ptr<int32_t>(lens) + (int64_t)k * rows, rows, s);
+        outs[k] = SplitOut{ptr<uint8_t>(c->chars), c->d_offsets()};
+      }
+      Buf d_outs = dev_alloc(sizeof(SplitOut) * ncols, s);
+      CS_HIP(hipMemcpyAsync(d_outs->p, outs.data(), sizeof(SplitOut) * ncols, hipMemcpyHostToDevice, s));
+      {
+        ProfScope ps("k_split_write", s);
+        hipLaunchKernelGGL(k_split_write, dim3(nb), dim3(kBlock), 0, s, view_of(col), a,
+                           ptr<int32_t>(counts), ncols, ptr<const SplitOut>(d_outs));
+      }
+      CS_HIP(hipStreamSynchronize(s));  // `outs` staging is on the host stack
+    }
+    cs_column** arr = (cs_column**)malloc(sizeof(cs_column*) * cols.size());
+    if (!arr) fail(CS_ERR_ALLOC, "host allocation failed");
+    for (size_t k = 0; k < cols.size(); ++k) arr[k] = cols[k].release();
+    *out_cols = arr;
+    *ncols_out = (int)cols.size();
+  });
+}
+
+// NVText::tokenize(strs, delimiter) -- tokens.cu:123-155
+int cs_tokenize(const cs_column* col, const char* delimiter, cs_stream stream, cs_column** out) {
+  return guard([&] {
+    if (!col || !out) fail(CS_ERR_INVALID_ARG, "null argument");
+    require_device();
+    hipStream_t s = S(stream);
+    const int64_t rows = col->rows;
+    if (rows == 0) {
+      *out = make_all_null(0, s);
+      return;
+    }
+    TokArgs a;
+    a.use_set = delimiter != nullptr;
+    a.set = make_set(delimiter ? delimiter : "", "tokenize");
+    const unsigned nb = blocks_for(rows);
+    Buf counts = dev_alloc(sizeof(int32_t) * rows, s);
+    Buf sums = dev_alloc(sizeof(int64_t) * nb, s);
+    {
+      ProfScope ps("k_tok_count", s);
+      hipLaunchKernelGGL(k_tok_count, dim3(nb), dim3(kBlock), 0, s, view_of(col), a, ptr<int32_t>(counts),
+                         ptr<int64_t>(sums));
+    }
+    Buf tok_base = dev_alloc(sizeof(int64_t) * (rows + 1), s);
+    int64_t ntok = offsets_from_lengths(ptr<int32_t>(counts), rows, ptr<int64_t>(tok_base), s, sums);
+    auto* c = new cs_column;
+    std::unique_ptr<cs_column> holder(c);
+    c->rows = ntok;
+    c->null_count = 0;
+    c->offsets = dev_alloc(sizeof(int64_t) * (ntok + 1), s);
+    if (ntok == 0) {
+      CS_HIP(hipMemsetAsync(c->offsets->p, 0, sizeof(int64_t), s));
+      c->chars = dev_alloc(0, s);
+      *out = holder.release();
+      return;
+    }
+    Buf tok_lens = dev_alloc(sizeof(int32_t) * ntok, s);
+    {
+      ProfScope ps("k_tok_sizes", s);
+      hipLaunchKernelGGL(k_tok_emit<0>, dim3(nb), dim3(kBlock), 0, s, view_of(col), a,
+                         ptr<const int64_t>(tok_base), ptr<int32_t>(tok_lens), (const int64_t*)nullptr,
+                         (uint8_t*)nullptr);
+    }
+    c->nbytes = offsets_from_lengths(ptr<int32_t>(tok_lens), ntok, ptr<int64_t>(c->offsets), s);
+    c->chars = dev_alloc((size_t)c->nbytes, s);
+    {
+      ProfScope ps("k_tok_write", s);
+      hipLaunchKernelGGL(k_tok_emit<1>, dim3(nb), dim3(kBlock), 0, s, view_of(col), a,
+                         ptr<const int64_t>(tok_base), (int32_t*)nullptr, c->d_offsets(),
+                         ptr<uint8_t>(c->chars));
+    }
+    *out = holder.release();
+  });
+}
+
+// NVText::create_ngrams -- ngram.cu:32-110
+int cs_ngrams(const cs_column* tokens, unsigned ngrams, const char* separator, cs_stream stream,
+              cs_column** out) {
+  return guard([&] {
+    if (!tokens || !out) fail(CS_ERR_INVALID_ARG, "null argument");
+    require_device();
+    hipStream_t s = S(stream);
+    if (ngrams == 0) ngrams = 2;
+    if (!separator) separator = "";
+    const int64_t rows = tokens->rows;
+    if (rows == 0) {
+      *out = share(tokens);
+      return;
+    }
+    Needle sep = upload(separator, s);
+    // drop null and empty rows (ngram.cu:48-50)
+    Buf flags = dev_alloc(sizeof(int32_t) * rows, s);
+    hipLaunchKernelGGL(k_keep_flags, dim3(blocks_for(rows)), dim3(kBlock), 0, s, view_of(tokens),
+                       ptr<int32_t>(flags));
+    Buf pos = dev_alloc(sizeof(int64_t) * (rows + 1), s);
+    int64_t count = offsets_from_lengths(ptr<int32_t>(flags), rows, ptr<int64_t>(pos), s);
+    if (count <= (int64_t)ngrams) {
+      // join(separator, "") over ALL rows, nulls contributing "" (ngram.cu:51-52)
+      Buf lens = dev_alloc(sizeof(int32_t) * rows, s);
+      hipLaunchKernelGGL(k_join_sizes, dim3(blocks_for(rows)), dim3(kBlock), 0, s, view_of(tokens), sep.n,
+                         ptr<int32_t>(lens));
+      Buf jpos = dev_alloc(sizeof(int64_t) * (rows + 1), s);
+      int64_t total = offsets_from_lengths(ptr<int32_t>(lens), rows, ptr<int64_t>(jpos), s);
+      auto* c = new cs_column;
+      std::unique_ptr<cs_column> holder(c);
+      c->rows = 1;
+      c->nbytes = total;
+      c->null_count = 0;
+      c->chars = dev_alloc((size_t)total, s);
+      c->offsets = dev_alloc(sizeof(int64_t) * 2, s);
+      int64_t two[2] = {0, total};
+      CS_HIP(hipMemcpyAsync(c->offsets->p, two, sizeof(two), hipMemcpyHostToDevice, s));
+      hipLaunchKernelGGL(k_join_write, dim3(blocks_for(rows)), dim3(kBlock), 0, s, view_of(tokens), sep.d(),
+                         sep.n, ptr<const int64_t>(jpos), ptr<uint8_t>(c->chars));
+      CS_HIP(hipStreamSynchronize(s));
+      *out = holder.release();
+      return;
+    }
+    if (ngrams == 1) {
+      *out = share(tokens);
+      return;
+    }
+    Buf kept = dev_alloc(sizeof(int32_t) * count, s);
+    hipLaunchKernelGGL(k_keep_scatter, dim3(blocks_for(rows)), dim3(kBlock), 0, s, ptr<const int32_t>(flags),
+                       ptr<const int64_t>(pos), rows, ptr<int32_t>(kept));
+    const int64_t ng = count - ngrams + 1;
+    Buf lens = dev_alloc(sizeof(int32_t) * ng, s);
+    {
+      ProfScope ps("k_ngram_sizes", s);
+      hipLaunchKernelGGL(k_ngram_sizes, dim3(blocks_for(ng)), dim3(kBlock), 0, s, view_of(tokens),
+                         ptr<const int32_t>(kept), ng, (int)ngrams, sep.n, ptr<int32_t>(lens));
+    }
+    auto* c = new cs_column;
+    std::unique_ptr<cs_column> holder(c);
+    c->rows = ng;
+    c->null_count = 0;
+    c->offsets = dev_alloc(sizeof(int64_t) * (ng + 1), s);
+    c->nbytes = offsets_from_lengths(ptr<int32_t>(lens), ng, ptr<int64_t>(c->offsets), s);
+    c->chars = dev_alloc((size_t)c->nbytes, s);
+    {
+      ProfScope ps("k_ngram_write", s);
+      hipLaunchKernelGGL(k_ngram_write, dim3(blocks_for(ng)), dim3(kBlock), 0, s, view_of(tokens),
+                         ptr<const int32_t>(kept), ng, (int)ngrams, sep.d(), sep.n, c->d_offsets(),
+                         ptr<uint8_t>(c->chars));
+    }
+    *out = holder.release();
+  });
+}
+
+}  // extern "C"

@@ -1,0 +1,144 @@
+"""`nvcategory` -- host-side mirror of /root/reference/python/nvcategory.py for the
+hot path (dictionary encoding: sorted unique keys + int32 values), over the C ABI.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from . import nvstrings as _nvs
+from ._lib import lib, check
+
+__all__ = ["to_device", "from_offsets", "from_strings", "from_strings_list", "bind_cpointer", "nvcategory"]
+
+
+def _build(col_ptr):
+    out = C.c_void_p()
+    check(lib.cs_category_build(col_ptr, None, C.byref(out)))
+    return nvcategory(out.value)
+
+
+def to_device(strs):
+    """nvcategory.py:5-25 -- category straight from a host list."""
+    s = _nvs.to_device(strs)
+    return _build(s.m_cptr)
+
+
+def from_offsets(sbuf, obuf, scount, nbuf=None, ncount=0, bdevmem=False):
+    """nvcategory.py:28-75 (NVCategory::create_from_offsets, NVCategory.h:101)."""
+    s = _nvs.from_offsets(sbuf, obuf, scount, nbuf, ncount, bdevmem)
+    return _build(s.m_cptr)
+
+
+def from_strings(*args):
+    """nvcategory.py:78-103 -- one category over the rows of 1..n nvstrings, in order
+    (NVCategory::create_from_strings, NVCategory.h:107,114)."""
+    return from_strings_list(list(args))
+
+
+def from_strings_list(list):
+    """nvcategory.py:106-128."""
+    _lib.ensure_init()
+    if len(list) == 1:
+        return _build(list[0].m_cptr)
+    arr = (C.c_void_p * max(len(list), 1))(*[s.m_cptr for s in list])
+    out = C.c_void_p()
+    check(lib.cs_column_concat(arr, len(list), None, C.byref(out)))
+    allrows = _nvs.nvstrings(out.value)
+    return _build(allrows.m_cptr)
+
+
+def from_categories(cats):
+    """NVCategory::create_from_categories (NVCategory.h:121; NVCategory.cu:430-514):
+    merged key set, concatenated remapped values."""
+    arr = (C.c_void_p * max(len(cats), 1))(*[c.m_cptr for c in cats])
+    out = C.c_void_p()
+    check(lib.cs_category_merge(arr, len(cats), None, C.byref(out)))
+    return nvcategory(out.value)
+
+
+def bind_cpointer(cptr, own=True):
+    """nvcategory.py:157-163."""
+    if not cptr:
+        return None
+    return nvcategory(cptr, own)
+
+
+_NOT_BUILT = (
+    "keys_type indexes_for_key add_strings remove_strings to_strings to_numbers gather_strings gather_numbers "
+    "gather_and_remap gather merge_and_remap add_keys remove_keys remove_unused_keys set_keys"
+).split()
+
+
+class nvcategory:
+    """Reference class: nvcategory.py:166-192."""
+
+    def __init__(self, cptr, own=True):
+        self.m_cptr = cptr
+        self._own = own
+
+    def __del__(self):
+        try:
+            if self.m_cptr and self._own:
+                lib.cs_category_destroy(self.m_cptr)
+            self.m_cptr = 0
+        except Exception:
+            pass
+
+    def __getattr__(self, name):
+        if name in _NOT_BUILT:
+            raise NotImplementedError("nvcategory.%s is outside the accelerated hot path (SURVEY.md section 8)" % name)
+        raise AttributeError(name)
+
+    def __str__(self):
+        return "keys: " + str(self.keys()) + "\nvalues: " + str(self.values())
+
+    def __repr__(self):
+        return "<nvcategory keys={},values={}>".format(self.keys_size(), self.size())
+
+    def get_cpointer(self):
+        return self.m_cptr
+
+    def size(self):
+        """nvcategory.py:200-219."""
+        return int(lib.cs_category_size(self.m_cptr))
+
+    def keys_size(self):
+        """nvcategory.py:221-240."""
+        return int(lib.cs_category_keys_size(self.m_cptr))
+
+    def keys(self, narr=None):
+        """nvcategory.py:242-274 -- the sorted unique keys as an nvstrings."""
+        out = C.c_void_p()
+        check(lib.cs_category_keys(self.m_cptr, C.byref(out)))
+        return _nvs.nvstrings(out.value)
+
+    def values(self, devptr=0):
+        """nvcategory.py:364-389 -- int32 key index per row."""
+        if devptr:
+            p, keep = _lib.addr(devptr)
+            on_device = 0 if keep is not None else 1
+            check(lib.cs_category_get_values(self.m_cptr, p, on_device, None))
+            return devptr
+        n = self.size()
+        res = np.zeros(max(n, 1), dtype=np.int32)
+        if n:
+            check(lib.cs_category_get_values(self.m_cptr, res.ctypes.data, 0, None))
+        return res[:n].tolist()
+
+    def values_cpointer(self):
+        """nvcategory.py:391-396."""
+        return lib.cs_category_values_ptr(self.m_cptr)
+
+    def value_for_index(self, idx):
+        """nvcategory.py:324-341."""
+        return self.values()[idx]
+
+    def value(self, str):
+        """nvcategory.py:343-362 -- index of a key, -1 when absent."""
+        k = self.keys().to_host()
+        return k.index(str) if str in k else -1
+
+    def merge_category(self, nvcat):
+        """nvcategory.py:669-685 (NVCategory::merge_category == create_from_categories of the two)."""
+        return from_categories([self, nvcat])

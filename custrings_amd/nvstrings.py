@@ -1,0 +1,354 @@
+"""`nvstrings` -- host-side mirror of the reference's Python module for the hot path.
+
+Same function / method names, argument defaults and None<->null mapping as
+/root/reference/python/nvstrings.py (cited per method), implemented over the
+C ABI in include/custrings_amd.h via ctypes.  Every method is one C call on the
+MI355X back-end; there is no Python or CPU implementation of any string op
+here.  Reference methods outside the hot path raise NotImplementedError.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import lib, check, b, addr
+
+__all__ = ["to_device", "from_strings", "from_offsets", "free", "bind_cpointer", "nvstrings"]
+
+
+def to_device(strs):
+    """nvstrings.py:4-24 -- list of str/None -> device column (NVStrings::create_from_array)."""
+    _lib.ensure_init()
+    if isinstance(strs, str) or strs is None:
+        strs = [strs]
+    strs = list(strs)
+    n = len(strs)
+    enc = [None if s is None else (s.encode("utf8") if isinstance(s, str) else bytes(s)) for s in strs]
+    for e in enc:
+        if e is not None and b"\0" in e:
+            raise ValueError("embedded NUL: use from_offsets for binary-safe ingest")
+    arr = (C.c_char_p * max(n, 1))(*enc)
+    out = C.c_void_p()
+    check(lib.cs_column_from_host_strings(arr, n, None, C.byref(out)))
+    return nvstrings(out.value)
+
+
+def from_strings(*args):
+    """nvstrings.py:27-56 -- concatenate instances / lists of instances into one (row-wise)."""
+    cols = []
+    for a in args:
+        if isinstance(a, (list, tuple)):
+            cols.extend(a)
+        else:
+            cols.append(a)
+    hosts = []
+    for c in cols:
+        hosts.extend(c.to_host())
+    return to_device(hosts)
+
+
+def from_offsets(sbuf, obuf, scount, nbuf=None, ncount=0, bdevmem=False):
+    """nvstrings.py:103-150 -- Arrow chars + int32 offsets (+ bitmask) -> instance
+    (NVStrings::create_from_offsets, NVStrings.h:116)."""
+    _lib.ensure_init()
+    pc, k1 = addr(sbuf)
+    po, k2 = addr(obuf)
+    pn, k3 = addr(nbuf)
+    out = C.c_void_p()
+    check(lib.cs_column_from_offsets32(pc, int(scount), po, pn, 1 if bdevmem else 0, None, C.byref(out)))
+    del k1, k2, k3
+    return nvstrings(out.value)
+
+
+def from_offsets64(chars, offsets, rows, validity=None, bdevmem=False, copy=True):
+    """Native ingest (int64 offsets); copy=False wraps caller-owned device buffers."""
+    _lib.ensure_init()
+    pc, k1 = addr(chars)
+    po, k2 = addr(offsets)
+    pn, k3 = addr(validity)
+    out = C.c_void_p()
+    check(lib.cs_column_from_offsets64(pc, int(rows), po, pn, 1 if bdevmem else 0, 1 if copy else 0, None, C.byref(out)))
+    r = nvstrings(out.value)
+    if not copy:
+        r._keep = (k1, k2, k3, chars, offsets)
+    return r
+
+
+def free(dstrs):
+    """nvstrings.py:363-367."""
+    if dstrs is not None:
+        dstrs._destroy()
+
+
+def bind_cpointer(cptr, own=True):
+    """nvstrings.py:370-377 -- wrap an existing cs_column* handle."""
+    if cptr == 0 or cptr is None:
+        return None
+    return nvstrings(cptr, own)
+
+
+_NOT_BUILT = (
+    "len compare hash stoi stol stof stod htoi to_booleans ip2int timestamp2int cat join split_record "
+    "rsplit_record partition rpartition rsplit get repeat pad ljust center rjust zfill wrap slice slice_from "
+    "slice_replace insert replace_multi replace_with_backrefs fillna capitalize swapcase title index rindex "
+    "find_from rfind findall_record findall match_strings startswith endswith extract_record extract isalnum "
+    "isalpha isdigit isspace isdecimal isnumeric islower isupper is_empty translate sort order gather "
+    "scatter scalar_scatter remove_strings add_strings copy find_multiple url_encode url_decode get_ipc_data"
+).split()
+
+
+class nvstrings:
+    """Immutable device strings column (reference class: nvstrings.py:380-402).
+
+    Holds a `cs_column*`; every transforming method returns a new instance.
+    """
+
+    def __init__(self, cptr, own=True):
+        self.m_cptr = cptr
+        self._own = own
+        self._keep = None
+
+    def _destroy(self):
+        if getattr(self, "m_cptr", None) and self._own:
+            lib.cs_column_destroy(self.m_cptr)
+        self.m_cptr = 0
+
+    def __del__(self):
+        try:
+            self._destroy()
+        except Exception:
+            pass
+
+    def __getattr__(self, name):
+        if name in _NOT_BUILT:
+            raise NotImplementedError("nvstrings.%s is outside the accelerated hot path (SURVEY.md section 8)" % name)
+        raise AttributeError(name)
+
+    def __str__(self):
+        return str(self.to_host())
+
+    def __repr__(self):
+        return "<nvstrings count={}>".format(self.size())
+
+    def __len__(self):
+        return self.size()
+
+    def __iter__(self):
+        raise TypeError("iterable not supported by nvstrings")
+
+    def get_cpointer(self):
+        return self.m_cptr
+
+    # ---- egress -------------------------------------------------------------
+    def _export64(self):
+        rows = self.size()
+        nbytes = lib.cs_column_nbytes(self.m_cptr)
+        chars = np.empty(max(nbytes, 1), dtype=np.uint8)
+        offs = np.zeros(rows + 1, dtype=np.int64)
+        valid = np.zeros((rows + 7) // 8 + 1, dtype=np.uint8)
+        if rows:
+            check(lib.cs_column_export_offsets64(self.m_cptr, chars.ctypes.data, offs.ctypes.data, valid.ctypes.data, 0, None))
+        return chars[:nbytes], offs, valid[: (rows + 7) // 8]
+
+    def to_host(self):
+        """nvstrings.py:464-482 -- list of str, None for null rows."""
+        chars, offs, valid = self._export64()
+        rows = len(offs) - 1
+        bits = np.unpackbits(valid, bitorder="little")[:rows] if rows else np.zeros(0, dtype=np.uint8)
+        data = chars.tobytes()
+        o = offs.tolist()
+        return [data[o[i] : o[i + 1]].decode("utf8", "surrogateescape") if bits[i] else None for i in range(rows)]
+
+    def to_offsets(self, sbuf, obuf, nbuf=0, bdevmem=False):
+        """nvstrings.py:484-517 -- NVStrings::create_offsets (int32 offsets, LSB-first bitmask)."""
+        pc, k1 = addr(sbuf)
+        po, k2 = addr(obuf)
+        pn, k3 = addr(nbuf)
+        check(lib.cs_column_export_offsets32(self.m_cptr, pc, po, pn, 1 if bdevmem else 0, None))
+        del k1, k2, k3
+
+    def sublist(self, start, end, step=0):
+        """nvstrings.py:2390 / NVStrings::sublist (NVStrings.h:261), step 1 only: rows [start, end)."""
+        if step not in (0, 1):
+            raise NotImplementedError("sublist with a step is outside the accelerated hot path")
+        out = C.c_void_p()
+        check(lib.cs_column_slice(self.m_cptr, int(start), int(end) - int(start), None, C.byref(out)))
+        return nvstrings(out.value)
+
+    def _export_window(self, first, rows):
+        return self.sublist(first, first + rows)._export64()
+
+    def size(self):
+        """nvstrings.py:519-536."""
+        return int(lib.cs_column_rows(self.m_cptr))
+
+    def byte_count(self, vals=0, bdevmem=False):
+        """nvstrings.py:567-596 -- per-row byte length (-1 null); returns the total."""
+        pv, k = addr(vals)
+        total = C.c_int64()
+        check(lib.cs_column_byte_count(self.m_cptr, pv, 1 if bdevmem else 0, None, C.byref(total)))
+        del k
+        return total.value
+
+    def set_null_bitmask(self, nbuf, bdevmem=False):
+        """nvstrings.py:598-620 -- returns the number of nulls."""
+        pn, k = addr(nbuf)
+        cnt = C.c_int64()
+        check(lib.cs_column_null_bitarray(self.m_cptr, pn, 0, 1 if bdevmem else 0, None, C.byref(cnt)))
+        del k
+        return cnt.value
+
+    def null_count(self, emptyisnull=False):
+        """nvstrings.py:622-645."""
+        rows = self.size()
+        tmp = np.zeros((rows + 7) // 8 + 1, dtype=np.uint8)
+        cnt = C.c_int64()
+        if rows == 0:
+            return 0
+        check(lib.cs_column_null_bitarray(self.m_cptr, tmp.ctypes.data, 1 if emptyisnull else 0, 0, None, C.byref(cnt)))
+        return cnt.value
+
+    def _null_flags(self):
+        rows = self.size()
+        tmp = np.zeros((rows + 7) // 8 + 1, dtype=np.uint8)
+        cnt = C.c_int64()
+        if rows:
+            check(lib.cs_column_null_bitarray(self.m_cptr, tmp.ctypes.data, 0, 0, None, C.byref(cnt)))
+        return np.unpackbits(tmp, bitorder="little")[:rows] == 0
+
+    def device_memory(self):
+        """nvstrings.py:2628 -- bytes of device memory held by this column."""
+        rows = self.size()
+        return int(lib.cs_column_nbytes(self.m_cptr)) + 8 * (rows + 1) + (rows + 7) // 8
+
+    # ---- split ----------------------------------------------------------------
+    def split(self, delimiter=None, n=-1):
+        """nvstrings.py:1069-1097 -- column-major split; list of nvstrings."""
+        arr = C.POINTER(C.c_void_p)()
+        ncols = C.c_int()
+        check(lib.cs_split(self.m_cptr, b(delimiter), int(n), None, C.byref(arr), C.byref(ncols)))
+        out = [nvstrings(arr[i]) for i in range(ncols.value)]
+        lib.cs_free(arr)
+        return out
+
+    # ---- replace ----------------------------------------------------------------
+    def replace(self, pat, repl, n=-1, regex=True):
+        """nvstrings.py:1460-1485 -- replace_re when regex (default) else literal replace."""
+        out = C.c_void_p()
+        if regex:
+            re = _compile(pat)
+            try:
+                check(lib.cs_replace_re(self.m_cptr, re, b(repl), int(n), None, C.byref(out)))
+            finally:
+                lib.cs_regex_destroy(re)
+        else:
+            check(lib.cs_replace(self.m_cptr, b(pat), b(repl), int(n), None, C.byref(out)))
+        return nvstrings(out.value)
+
+    # ---- strip --------------------------------------------------------------------
+    def _strip(self, to_strip, side):
+        out = C.c_void_p()
+        check(lib.cs_strip(self.m_cptr, b(to_strip), side, None, C.byref(out)))
+        return nvstrings(out.value)
+
+    def lstrip(self, to_strip=None):
+        """nvstrings.py:1583-1603."""
+        return self._strip(to_strip, 1)
+
+    def strip(self, to_strip=None):
+        """nvstrings.py:1605-1625."""
+        return self._strip(to_strip, 0)
+
+    def rstrip(self, to_strip=None):
+        """nvstrings.py:1627-1647."""
+        return self._strip(to_strip, 2)
+
+    # ---- case -----------------------------------------------------------------------
+    def lower(self):
+        """nvstrings.py:1649-1665."""
+        out = C.c_void_p()
+        check(lib.cs_lower(self.m_cptr, None, C.byref(out)))
+        return nvstrings(out.value)
+
+    def upper(self):
+        """nvstrings.py:1667-1683."""
+        out = C.c_void_p()
+        check(lib.cs_upper(self.m_cptr, None, C.byref(out)))
+        return nvstrings(out.value)
+
+    # ---- find / contains ----------------------------------------------------------------
+    def find(self, sub, start=0, end=None, devptr=0):
+        """nvstrings.py:1796-1823 -- char position, -1 miss; host list has None for null rows
+        (pystrings.cpp n_find: values < -1 become None)."""
+        rows = self.size()
+        end = -1 if end is None else int(end)
+        found = C.c_int64()
+        if devptr:
+            check(lib.cs_find(self.m_cptr, b(sub), int(start), end, devptr, 1, None, C.byref(found)))
+            return devptr
+        res = np.zeros(max(rows, 1), dtype=np.int32)
+        check(lib.cs_find(self.m_cptr, b(sub), int(start), end, res.ctypes.data, 0, None, C.byref(found)))
+        return [None if v < -1 else int(v) for v in res[:rows]]
+
+    def _bools(self, call, devptr):
+        rows = self.size()
+        found = C.c_int64()
+        if devptr:
+            check(call(devptr, 1, C.byref(found)))
+            return devptr
+        if rows == 0:
+            return []
+        res = np.zeros(rows, dtype=np.uint8)
+        check(call(res.ctypes.data, 0, C.byref(found)))
+        nulls = self._null_flags()
+        return [None if nulls[i] else bool(res[i]) for i in range(rows)]
+
+    def contains(self, pat, regex=True, devptr=0):
+        """nvstrings.py:1951-1978; null rows -> None in the host list (pystrings.cpp:2654-2662)."""
+        if regex:
+            re = _compile(pat)
+            try:
+                return self._bools(lambda p, d, f: lib.cs_contains_re(self.m_cptr, re, p, d, None, f), devptr)
+            finally:
+                lib.cs_regex_destroy(re)
+        return self._bools(lambda p, d, f: lib.cs_contains(self.m_cptr, b(pat), p, d, None, f), devptr)
+
+    def match(self, pat, devptr=0):
+        """nvstrings.py:1980-2003."""
+        re = _compile(pat)
+        try:
+            return self._bools(lambda p, d, f: lib.cs_match_re(self.m_cptr, re, p, d, None, f), devptr)
+        finally:
+            lib.cs_regex_destroy(re)
+
+    def count(self, pat, devptr=0):
+        """nvstrings.py:2033-2047 -- occurrences of the pattern per row."""
+        rows = self.size()
+        found = C.c_int64()
+        re = _compile(pat)
+        try:
+            if devptr:
+                check(lib.cs_count_re(self.m_cptr, re, devptr, 1, None, C.byref(found)))
+                return devptr
+            if rows == 0:
+                return []
+            res = np.zeros(rows, dtype=np.int32)
+            check(lib.cs_count_re(self.m_cptr, re, res.ctypes.data, 0, None, C.byref(found)))
+        finally:
+            lib.cs_regex_destroy(re)
+        nulls = self._null_flags()
+        return [None if nulls[i] else int(res[i]) for i in range(rows)]
+
+    # ---- parity helper ---------------------------------------------------------------------
+    def digest(self):
+        d = C.c_uint64()
+        check(lib.cs_column_digest(self.m_cptr, None, C.byref(d)))
+        return d.value
+
+
+def _compile(pat):
+    if pat is None:
+        raise ValueError("pattern cannot be null")
+    re = C.c_void_p()
+    check(lib.cs_regex_compile(b(pat), C.byref(re)))
+    return re

@@ -1,7 +1,7 @@
 /* cs_synth_spec.h -- definition of the synthetic benchmark columns
  * (BASELINE.md section 3).  Row r of a column is a pure function of
  * (kind, seed, r, param); integer arithmetic only, so the device generator
- * (custrings_amd/csrc/kernels.hip) and the CPU generator (oracle/) produce
+ * (custrings_amd/csrc/cs_synth.hip) and the CPU generator (oracle/) produce
  * identical bytes.  This header is a workload SPECIFICATION shared by both; it
  * contains no string-op logic.
  *
@@ -37,9 +37,17 @@ CS_SYNTH_HD uint64_t cs_rng_next(cs_rng* r) { /* splitmix64 */
   z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
   return z ^ (z >> 31);
 }
+CS_SYNTH_HD uint64_t cs_mix64(uint64_t z) {
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+/* The row index is hashed (not just scaled) so that neighbouring rows do not
+ * get shifted copies of one splitmix64 stream. */
 CS_SYNTH_HD cs_rng cs_rng_for_row(uint64_t seed, int64_t row, int kind) {
   cs_rng r;
-  r.s = seed * 0xD1342543DE82EF95ull + (uint64_t)row * 0x9E3779B97F4A7C15ull + (uint64_t)kind;
+  r.s = cs_mix64(seed * 0xD1342543DE82EF95ull + (uint64_t)kind) ^
+        cs_mix64((uint64_t)row * 0xD6E8FEB86659FD93ull + 0x2545F4914F6CDD1Dull);
   cs_rng_next(&r);
   return r;
 }
@@ -193,6 +201,19 @@ CS_SYNTH_HD int cs_synth_row(int kind, uint64_t seed, int64_t row, int64_t param
     return s.n;
   }
   return 0;
+}
+
+/* ---- column digest (full-size parity: "checksum of checksums") ---------------
+ * digest(column) = sum over rows (mod 2^64) of cs_digest_row(r, bytes, n, valid):
+ * FNV-1a of the row bytes, mixed with the row index and length, so it is
+ * sensitive to content, order, offsets and validity, and can be accumulated in
+ * any order (device atomics). */
+CS_SYNTH_HD uint64_t cs_digest_row(uint64_t row, const uint8_t* p, int n, int valid) {
+  uint64_t h = 0xcbf29ce484222325ull;
+  for (int i = 0; i < n; ++i) h = (h ^ p[i]) * 0x100000001b3ull;
+  h ^= (uint64_t)n * 0x9E3779B97F4A7C15ull;
+  if (!valid) h = 0x6c6c756e5f5f5f5full;
+  return cs_mix64(h + cs_mix64(row + 1));
 }
 
 #endif /* CS_SYNTH_SPEC_H */

@@ -84,6 +84,14 @@ int cs_column_from_offsets32(const char* chars, int64_t rows, const int32_t* off
 int cs_column_from_offsets64(const uint8_t* chars, int64_t rows, const int64_t* offsets,
                              const uint8_t* validity, int on_device, int copy,
                              cs_stream stream, cs_column** out);
+/* NVStrings::create_from_strings(std::vector<NVStrings*>) (NVStrings.h:125):
+ * row-wise concatenation of `n` columns into a new column. */
+int cs_column_concat(const cs_column* const* cols, int n, cs_stream stream, cs_column** out);
+/* NVStrings::sublist(start, end) with step 1 (NVStrings.h:261): rows
+ * [first, first + rows) as a new column (offsets rebased to 0).  This is also
+ * how a column is cut into row-range shards for the multi-GPU path. */
+int cs_column_slice(const cs_column* col, int64_t first, int64_t rows, cs_stream stream,
+                    cs_column** out);
 /* NVStrings::destroy (NVStrings.h:156). NULL is ignored. */
 int cs_column_destroy(cs_column* col);
 /* NVStrings::size (NVStrings.h:167) and friends. */

@@ -876,3 +876,12 @@ extern "C" orc_col* orc_synth(int kind, int64_t first_row, int64_t rows, uint64_
   }
   return b.finish();
 }
+extern "C" uint64_t orc_digest(const orc_col* c) {
+  uint64_t d = 0;
+  for (int64_t r = 0; r < c->rows; ++r) {
+    bool ok = c->is_valid(r);
+    d += cs_digest_row((uint64_t)r, ok ? c->chars.data() + c->off[r] : nullptr,
+                       ok ? (int)(c->off[r + 1] - c->off[r]) : 0, ok);
+  }
+  return d;
+}

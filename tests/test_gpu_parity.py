@@ -1,0 +1,278 @@
+"""-m gpu: the HIP path, called through the C ABI (libcustrings_amd.so), against
+(1) the committed golden vectors, (2) the oracle on seeded random columns,
+(3) the oracle on the synthetic benchmark columns, and (4) size-independent
+properties at BASELINE.json's full sizes.  Bit-exact: offsets, chars, validity,
+bools, ints."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import cpulibs
+import engines
+import fuzzdata
+import gpuutil
+
+pytestmark = pytest.mark.gpu
+
+REF = engines.load_cases("reference_tests.json")
+APX = engines.load_cases("survey_appendix_a.json")
+IPV4 = r"\d+\.\d+\.\d+\.\d+"
+IPV4B = r"\b\d{1,3}\.\d{1,3}\.\d{1,3}\.\d{1,3}\b"
+
+
+@pytest.fixture(scope="module")
+def orc():
+    return cpulibs.Oracle()
+
+
+def test_native_library_is_loaded_and_on_gfx950():
+    L = gpuutil.lib()
+    assert L.lib.cs_device_count() >= 1
+    import os
+
+    maps = open("/proc/self/maps").read()
+    assert "libcustrings_amd.so" in maps
+    assert os.path.exists(L._PATH)
+
+
+@pytest.mark.parametrize("case", REF + APX, ids=[c["id"] for c in REF + APX])
+def test_gpu_golden(gpu_engine, case):
+    assert engines.run_case(gpu_engine, case) == case["expect"], case["src"]
+
+
+def test_gpu_replace_re_rejects_empty_pattern(gpu_engine):
+    with pytest.raises(ValueError):
+        gpu_engine.replace_re(["a"], "", "x")
+    with pytest.raises(ValueError):
+        gpu_engine.replace(["a"], "", "x")
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_gpu_vs_oracle_string_ops(gpu_engine, oracle_engine, seed):
+    s = fuzzdata.rows(seed, 1500, max_len=40)
+    o, g = oracle_engine, gpu_engine
+    assert g.lower(s) == o.lower(s)
+    assert g.upper(s) == o.upper(s)
+    for ts in (None, " ", "ab ", "é ", "\n\t x"):
+        for side in (0, 1, 2):
+            assert g.strip(s, ts, side) == o.strip(s, ts, side)
+    for sub in ("a", "é", "ab", " ", "", "bc", "😀"):
+        for st, en in ((0, -1), (1, 5), (3, 2), (2, 100)):
+            assert g.find(s, sub, st, en) == o.find(s, sub, st, en), (sub, st, en)
+        assert g.contains(s, sub) == o.contains(s, sub)
+    for pat, repl in (("a", "xx"), ("é", ""), ("ab", "é"), (" ", "__")):
+        for n in (-1, 0, 1, 2):
+            assert g.replace(s, pat, repl, n) == o.replace(s, pat, repl, n), (pat, repl, n)
+    for d in (None, " ", "a", "é", "ab", ","):
+        for n in (-1, 1, 2):
+            assert g.split(s, d, n) == o.split(s, d, n), (d, n)
+    for d in (None, " ", "_-", "é "):
+        assert g.tokenize(s, d) == o.tokenize(s, d)
+        toks = o.tokenize(s, d)
+        for N in (1, 2, 3):
+            assert g.ngrams(toks, N, "_") == o.ngrams(toks, N, "_")
+    assert g.category(s) == o.category(s)
+
+
+PATTERNS = [IPV4, IPV4B, r"a*", r"x*", r"a|aa", r"aa|a", r"a+?", r"\w+", r"\W", r"[\W]", r"\s+", r"^a", r"a$", r"\bc",
+            r"\B", r"[a-c]+[x-z]?", r"[^a-c ]+", r"é+", r"[é-ü]", r"(a|b)*c", r".*", r"^$", r"(ab|a)(bc|c)?",
+            r"a{2,3}", r"(a|b|c){3}", "a" * 70, r"(a|b|c|d|e|f|g|h){8}"]
+
+
+@pytest.mark.parametrize("pat", PATTERNS, ids=[repr(p)[:30] for p in PATTERNS])
+def test_gpu_vs_oracle_regex(gpu_engine, oracle_engine, pat):
+    s = fuzzdata.rows(11, 700, alphabet=list("aabbc xyz_.\n019") + ["é", "ü", "😀"]) + fuzzdata.log_rows(5, 700)
+    s += ["a" * 80, "ab" * 50, "abcdefgh" * 3]
+    o, g = oracle_engine, gpu_engine
+    assert g.contains_re(s, pat) == o.contains_re(s, pat)
+    assert g.match(s, pat) == o.match(s, pat)
+    assert g.count_re(s, pat) == o.count_re(s, pat)
+    for n in (-1, 1, 2):
+        assert g.replace_re(s, pat, "<é>", n) == o.replace_re(s, pat, "<é>", n), n
+
+
+def test_gpu_long_and_ragged_rows(gpu_engine, oracle_engine):
+    s = ["", None, "x" * 5000 + " 1.2.3.4 " + "y" * 3000, " ".join(["tok"] * 700), "é" * 2000, None, "", "a b"]
+    o, g = oracle_engine, gpu_engine
+    assert g.lower(s) == o.lower(s)
+    assert g.split(s, " ", -1) == o.split(s, " ", -1)
+    assert g.split(s, None, 3) == o.split(s, None, 3)
+    assert g.replace_re(s, IPV4, "<IP>", -1) == o.replace_re(s, IPV4, "<IP>", -1)
+    assert g.tokenize(s, None) == o.tokenize(s, None)
+    assert g.category(s) == o.category(s)
+
+
+def test_gpu_empty_column(gpu_engine):
+    g = gpu_engine
+    assert g.lower([]) == [] and g.strip([]) == [] and g.replace_re([], "a", "b") == []
+    assert g.tokenize([], None) == []
+    assert [c for c in g.split([], " ")] == [[]]
+    k, v = g.category([])
+    assert k == [] and v == []
+
+
+def test_gpu_arrow_roundtrip_int32():
+    from custrings_amd import nvstrings
+
+    gpuutil.lib()
+    values = np.array([97, 112, 112, 108, 101, 112, 101, 97, 114], dtype=np.int8)
+    offsets = np.array([0, 5, 5, 9], dtype=np.int32)
+    bitmask = np.array([5], dtype=np.int8)
+    s = nvstrings.from_offsets(values, offsets, 3, bitmask, 1)  # python/tests/test_offsets.py:36-47
+    assert s.to_host() == ["apple", None, "pear"]
+    s = nvstrings.from_offsets(values, offsets, 3)  # :18-24
+    assert s.to_host() == ["apple", "", "pear"]
+    s = nvstrings.to_device(["a", "p", "p", "l", "e"])  # :67-82
+    v = np.empty(5, dtype=np.int8)
+    o = np.empty(6, dtype=np.int32)
+    n = np.empty(1, dtype=np.int8)
+    s.to_offsets(v, o, n)
+    assert v.tolist() == [97, 112, 112, 108, 101] and o.tolist() == [0, 1, 2, 3, 4, 5] and n.tolist() == [31]
+    s = nvstrings.to_device(["a", None, "p", "l", "e"])
+    nulls = np.zeros(1, dtype=np.uint8)
+    assert s.set_null_bitmask(nulls) == 1 and nulls[0] == 0x1D  # nvstrings.py:611-616
+    assert s.null_count() == 1
+    assert nvstrings.to_device(["abc", "", None]).null_count(True) == 2
+    lens = np.zeros(5, dtype=np.int32)
+    assert s.byte_count(lens) == 4 and lens.tolist() == [1, -1, 1, 1, 1]
+
+
+# ---- synthetic benchmark columns: generator and ops vs the oracle ----------------------
+@pytest.mark.parametrize("kind,param", [(2, 0), (3, 0), (4, 1000), (4, 1 << 20), (5, 0)])
+@pytest.mark.parametrize("first", [0, 99_000_000])
+def test_gpu_synth_matches_spec(orc, kind, param, first):
+    rows = 30_000
+    gpuutil.assert_same(gpuutil.synth(kind, first, rows, param), orc.synth(kind, first, rows, param=param), "synth")
+
+
+def test_gpu_c2_lower_strip_split(orc):
+    rows = 200_000
+    g, o = gpuutil.synth(2, 0, rows), orc.synth(2, 0, rows)
+    gl, ol = g.lower(), orc.lower(o)
+    gpuutil.assert_same(gl, ol, "lower")
+    gs, os_ = gl.strip(), orc.strip(ol)
+    gpuutil.assert_same(gs, os_, "strip")
+    gc, oc = gs.split(" "), orc.split(os_, " ")
+    assert len(gc) == len(oc)
+    for k, (a, b) in enumerate(zip(gc, oc)):
+        gpuutil.assert_same(a, b, "split col %d" % k)
+    gw, ow = g.split(None, 4), orc.split(o, None, 4)
+    assert len(gw) == len(ow)
+    for k, (a, b) in enumerate(zip(gw, ow)):
+        gpuutil.assert_same(a, b, "wssplit col %d" % k)
+    gpuutil.assert_same(g.upper(), orc.upper(o), "upper")
+    f_g = np.zeros(rows, dtype=np.int32)
+    L = gpuutil.lib()
+    found = C.c_int64()
+    L.check(L.lib.cs_find(g.m_cptr, "é".encode(), 0, -1, f_g.ctypes.data, 0, None, C.byref(found)))
+    f_o, n_o = orc.find(o, "é", 0, -1)
+    assert np.array_equal(f_g, f_o) and found.value == n_o
+
+
+@pytest.mark.parametrize("pat", [IPV4, IPV4B])
+@pytest.mark.parametrize("first", [0, 73_000_000])
+def test_gpu_c3_regex_and_split(orc, pat, first):
+    rows = 200_000
+    g, o = gpuutil.synth(3, first, rows), orc.synth(3, first, rows)
+    blob = np.ascontiguousarray(engines.reference_blob(pat))
+    gpuutil.assert_same(g.replace(pat, "<IP>"), orc.replace_re(o, blob, "<IP>"), "replace_re")
+    gpuutil.assert_same(g.replace(pat, "", 1), orc.replace_re(o, blob, "", 1), "replace_re n=1")
+    re = gpuutil.compile_re(pat)
+    got, n = gpuutil.bools(g, "cs_contains_re", re)
+    exp, n_o = orc.contains_re(o, blob, 0)
+    assert np.array_equal(got, exp) and n == n_o
+    if pat == IPV4:
+        gc, oc = g.split(" "), orc.split(o, " ")
+        assert len(gc) == len(oc)
+        for k, (a, b) in enumerate(zip(gc, oc)):
+            gpuutil.assert_same(a, b, "split col %d" % k)
+        gpuutil.assert_same(g.replace("0.", "#", regex=False), orc.replace(o, "0.", "#"), "replace")
+
+
+@pytest.mark.parametrize("K", [1000, 1 << 20])
+def test_gpu_c4_category(orc, K):
+    from custrings_amd import nvcategory
+
+    rows = 300_000
+    g, o = gpuutil.synth(4, 0, rows, K), orc.synth(4, 0, rows, param=K)
+    cat = nvcategory.from_strings(g)
+    ok, ov = orc.category(o)
+    gpuutil.assert_same(cat.keys(), ok, "keys")
+    vals = np.zeros(rows, dtype=np.int32)
+    cat.values(vals)
+    assert np.array_equal(vals, ov)
+    # merge of two shard categories == category of the concatenation (NVCategory.cu:430-514)
+    g1, g2 = gpuutil.synth(4, 0, rows // 2, K), gpuutil.synth(4, rows // 2, rows - rows // 2, K)
+    m = nvcategory.from_categories([nvcategory.from_strings(g1), nvcategory.from_strings(g2)])
+    gpuutil.assert_same(m.keys(), ok, "merged keys")
+    m.values(vals)
+    assert np.array_equal(vals, ov)
+
+
+def test_gpu_c5_tokenize_ngrams(orc):
+    from custrings_amd import nvtext
+
+    rows = 100_000
+    g, o = gpuutil.synth(5, 0, rows), orc.synth(5, 0, rows)
+    gt, ot = nvtext.tokenize(g), orc.tokenize(o)
+    gpuutil.assert_same(gt, ot, "tokenize")
+    gpuutil.assert_same(nvtext.ngrams(gt, 2, "_"), orc.ngrams(ot, 2, "_"), "bigrams")
+
+
+# ---- full-size properties (BASELINE.json configs 2 and 3) -----------------------------------
+def test_gpu_full_size_c2_properties():
+    rows = 10_000_000
+    g = gpuutil.synth(2, 0, rows)
+    low = g.lower()
+    assert low.lower().digest() == low.digest()  # idempotent
+    st = low.strip()
+    assert st.strip().digest() == st.digest()
+    cols = st.split(" ")
+    # every byte of a row is either in a token or one of the (tokens-1) delimiters
+    tok_bytes = sum(int(gpuutil.lib().lib.cs_column_nbytes(c.m_cptr)) for c in cols)
+    tokens = sum(rows - c.null_count() for c in cols)
+    nonnull_rows = rows - cols[0].null_count()
+    assert tok_bytes + (tokens - nonnull_rows) == int(gpuutil.lib().lib.cs_column_nbytes(st.m_cptr))
+    assert g.null_count() == st.null_count() == cols[0].null_count()
+
+
+def test_gpu_full_size_c3_properties(orc):
+    rows = 100_000_000
+    g = gpuutil.synth(3, 0, rows)
+    L = gpuutil.lib()
+    re = gpuutil.compile_re(IPV4)
+    found = C.c_int64()
+    flags = None
+    import torch
+
+    flags = torch.empty(rows, dtype=torch.uint8, device="cuda")
+    L.check(L.lib.cs_contains_re(g.m_cptr, re, flags.data_ptr(), 1, None, C.byref(found)))
+    n_hit = found.value
+    assert int(flags.sum(dtype=torch.int64)) == n_hit
+    assert abs(n_hit / rows - 0.55) < 0.01  # 50 % one quad + 5 % two (cs_synth_spec.h)
+    rep = g.replace(IPV4, "<IP>")
+    L.check(L.lib.cs_contains_re(rep.m_cptr, re, flags.data_ptr(), 1, None, C.byref(found)))
+    assert found.value == 0  # nothing left to replace
+    # replacing again changes nothing (idempotence, checked by digest)
+    assert rep.replace(IPV4, "<IP>").digest() == rep.digest()
+    # the literal "<IP>" now appears once per replaced quad: 0.5 + 2*0.05 per row
+    cnt = torch.empty(rows, dtype=torch.int32, device="cuda")
+    re2 = gpuutil.compile_re("<IP>")
+    L.check(L.lib.cs_count_re(rep.m_cptr, re2, cnt.data_ptr(), 1, None, C.byref(found)))
+    assert abs(int(cnt.sum(dtype=torch.int64)) / rows - 0.60) < 0.01
+    del flags, cnt
+    # sampled windows of the full column agree with the oracle bit for bit
+    blob = np.ascontiguousarray(engines.reference_blob(IPV4))
+    for first in (0, 31_415_926, 99_950_000):
+        w = 50_000
+        o = orc.synth(3, first, w)
+        exp = orc.replace_re(o, blob, "<IP>")
+        chars, offs, valid = rep._export_window(first, w)
+        got = cpulibs.Col(chars, offs, valid)
+        assert got.same_as(exp), first
+    # split: bytes are conserved (tokens + single-space delimiters)
+    cols = g.split(" ")
+    tok_bytes = sum(int(L.lib.cs_column_nbytes(c.m_cptr)) for c in cols)
+    tokens = sum(rows - c.null_count() for c in cols)
+    assert tok_bytes + (tokens - rows) == int(L.lib.cs_column_nbytes(g.m_cptr))

@@ -1,0 +1,335 @@
+#!/usr/bin/env python3
+"""Writes the committed golden fixtures under tests/golden/ (run in the build
+container; the GPU box only reads the JSON).
+
+  reference_tests.json   known answers held by the reference's own gtests /
+                         pytest files for the hot path.  Inputs and expected
+                         outputs are DATA transcribed from the cited test; where
+                         the reference test compares against pandas the expected
+                         values are computed here with pandas and recorded.
+  survey_appendix_a.json vectors recorded from the reference during the survey
+                         (SURVEY.md Appendix A), including its quirks.
+  regex_programs.json    instruction streams produced by the REAL reference regex
+                         compiler (oracle/_ref, built in place from
+                         /root/reference/cpp/src/regex/regcomp.cpp) for a list of
+                         patterns; pins the product compiler and the oracle VM's
+                         input on boxes without /root/reference.
+
+Case format: {"id", "src", "op", "input": [str|None...], "args": {...}, "expect": ...}
+  "level": "c"  -> expectation at the C++ API level (bools: null -> false,
+                   find: null -> -2);  "py" -> python-list level (null -> None)
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+OUT = os.path.join(ROOT, "tests", "golden")
+
+CASES = []
+
+
+def case(id, src, op, input, expect, level="c", **args):
+    CASES.append({"id": id, "src": src, "op": op, "input": input, "args": args, "expect": expect, "level": level})
+
+
+# ---------------------------------------------------------------- C++ gtests --
+S = ["Héllo thesé", None, "are some", "tést String", ""]
+case("cpp_split_ws", "cpp/tests/test_split.cpp:13-23", "split", S,
+     [["Héllo", None, "are", "tést", None], ["thesé", None, "some", "String", None]], delimiter=None, n=-1)
+case("cpp_split_s", "cpp/tests/test_split.cpp:36-45", "split", S,
+     [["Héllo the", None, "are ", "té", ""], ["é", None, "ome", "t String", None]], delimiter="s", n=-1)
+
+R = ["the quick brown fox jumps over the lazy dog",
+     "the fat cat lays next to the other accénted cat",
+     "a slow moving turtlé cannot catch the bird",
+     "which can be composéd together to form a more complete",
+     "thé result does not include the value in the sum in",
+     "", "absent stop words"]
+case("cpp_replace", "cpp/tests/test_replace.cpp:16-33", "replace", R,
+     ["++++ quick brown fox jumps over ++++ lazy dog",
+      "++++ fat cat lays next to ++++ other accénted cat",
+      "a slow moving turtlé cannot catch ++++ bird",
+      "which can be composéd together to form a more complete",
+      "thé result does not include ++++ value in ++++ sum in",
+      "", "absent stop words"], pat="the ", repl="++++ ", n=-1)
+case("cpp_replace_re", "cpp/tests/test_replace.cpp:35-52", "replace_re", R,
+     ["= quick brown fox jumps over = lazy dog",
+      "= fat cat lays next to = other accénted cat",
+      "= slow moving turtlé cannot catch = bird",
+      "which can be composéd together to form = more complete",
+      "thé result does not include = value = = sum =",
+      "", "absent stop words"], pat="(\\bin\\b)|(\\ba\\b)|(\\bthe\\b)", repl="=", n=-1)
+
+Cn = ["The quick brown @fox jumps", "ovér the", "lazy @dog", "1234", "00:0:00", None, ""]
+case("cpp_contains", "cpp/tests/test_count.cu:17-22", "contains", Cn,
+     [False, True, False, False, False, False, False], pat="é")
+case("cpp_contains_re_d", "cpp/tests/test_count.cu:24-29", "contains_re", Cn,
+     [False, False, False, True, True, False, False], pat="\\d+")
+case("cpp_contains_re_at", "cpp/tests/test_count.cu:31-36", "contains_re", Cn,
+     [True, False, True, False, False, False, False], pat="@\\w+")
+case("cpp_match_over", "cpp/tests/test_count.cu:47-52", "match", Cn,
+     [False, True, False, False, False, False, False], pat="ov[eé]r")
+case("cpp_match_the", "cpp/tests/test_count.cu:54-59", "match", Cn,
+     [True, False, False, False, False, False, False], pat="[tT]he")
+case("cpp_match_d", "cpp/tests/test_count.cu:61-66", "match", Cn,
+     [False, False, False, True, True, False, False], pat="\\d+")
+case("cpp_count_the", "cpp/tests/test_count.cu:79-84", "count_re", Cn, [1, 1, 0, 0, 0, 0, 0], pat="[tT]he")
+case("cpp_count_at", "cpp/tests/test_count.cu:86-91", "count_re", Cn, [1, 0, 1, 0, 0, 0, 0], pat="@\\w+")
+case("cpp_count_colon", "cpp/tests/test_count.cu:93-98", "count_re", Cn, [0, 0, 0, 0, 1, 0, 0], pat="\\d+:\\d+")
+
+St = [" hello  ", "   thesé ", None, "ARE THE", " tést  strings ", ""]
+case("cpp_lstrip", "cpp/tests/test_strip.cpp:12-17", "lstrip", St,
+     ["hello  ", "thesé ", None, "ARE THE", "tést  strings ", ""], to_strip=" ")
+case("cpp_rstrip", "cpp/tests/test_strip.cpp:18-23", "rstrip", St,
+     [" hello", "   thesé", None, "ARE THE", " tést  strings", ""], to_strip=" ")
+case("cpp_strip", "cpp/tests/test_strip.cpp:24-29", "strip", St,
+     ["hello", "thesé", None, "ARE THE", "tést  strings", ""], to_strip=" ")
+
+Ca = ["Examples aBc", "thesé", None, "ARE THE", "tést strings", ""]
+case("cpp_lower", "cpp/tests/test_case.cpp:9-17", "lower", Ca,
+     ["examples abc", "thesé", None, "are the", "tést strings", ""])
+case("cpp_upper", "cpp/tests/test_case.cpp:19-27", "upper", Ca,
+     ["EXAMPLES ABC", "THESÉ", None, "ARE THE", "TÉST STRINGS", ""])
+
+F = ["Héllo", "thesé", None, "ARE THE", "tést strings", ""]
+case("cpp_find", "cpp/tests/test_find.cu:25-36", "find", F, [1, 4, -2, -1, 1, -1], sub="é", start=0, end=-1)
+case("cpp_find_contains", "cpp/tests/test_find.cu:64-76", "contains", F,
+     [False, True, False, False, True, False], pat="s")
+
+T = ["the fox jumped over the dog", "the dog chased the cat", "the cat chased the mouse", None, "",
+     "the mouse ate the cheese"]
+case("cpp_tokenize", "cpp/tests/test_text.cu:15-26", "tokenize", T,
+     ["the", "fox", "jumped", "over", "the", "dog", "the", "dog", "chased", "the", "cat",
+      "the", "cat", "chased", "the", "mouse", "the", "mouse", "ate", "the", "cheese"], delimiter=None)
+
+# ------------------------------------------------------------- python tests --
+case("py_split_us", "python/tests/test_split.py:35-55", "split",
+     ["héllo", None, "a_bc_déf", "a__bc", "_ab_cd", "ab_cd_", "", " a b ", " a  bbb   c"],
+     [["héllo", None, "a", "a", "", "ab", "", " a b ", " a  bbb   c"],
+      [None, None, "bc", "", "ab", "cd", None, None, None],
+      [None, None, "déf", "bc", "cd", "", None, None, None]], level="py", delimiter="_", n=-1)
+case("py_lower", "python/tests/test_case.py:7-12", "lower", ["abc", "Def", None, "jLl"],
+     ["abc", "def", None, "jll"], level="py")
+case("py_upper", "python/tests/test_case.py:14-19", "upper", ["abc", "Def", None, "jLl"],
+     ["ABC", "DEF", None, "JLL"], level="py")
+for f in ("lower", "upper", "strip"):
+    case("py_allnulls_" + f, "python/tests/test_allnulls.py:9-16", f, [None, None, None], [None, None, None],
+         level="py", **({"to_strip": None} if f == "strip" else {}))
+Pc = ["hello", "there", "world", "accéntéd", None, ""]
+case("py_find", "python/tests/test_compare.py:27-33", "find", Pc, [4, -1, 1, -1, None, -1], level="py",
+     sub="o", start=0, end=-1)
+case("py_match", "python/tests/test_compare.py:88-92", "match", ["tempo", "there", "this", "ether", None, ""],
+     [False, True, True, False, None, False], level="py", pat="th")
+case("py_contains", "python/tests/test_compare.py:123-129", "contains",
+     ["he-llo", "-there-", "world-", "accént-éd", None, "-"],
+     [True, False, True, False, None, False], level="py", pat="l")
+
+E = ["eee", "aaa", "eee", "ddd", "ccc", "ccc", "ccc", "eee", "aaa"]
+case("py_cat_keys", "python/tests/test_category.py:19-24", "category", ["a", "b", "b", "f", "c", "f"],
+     {"keys": ["a", "b", "c", "f"], "values": [0, 1, 1, 3, 2, 3]}, level="py")
+case("py_cat_values", "python/tests/test_category.py:34-41", "category", E,
+     {"keys": ["aaa", "ccc", "ddd", "eee"], "values": [3, 0, 3, 2, 1, 1, 1, 3, 0]}, level="py")
+case("py_cat_from_strings", "python/tests/test_category.py:137-149", "category",
+     E + ["ggg", "fff", "hhh", "aaa", "fff", "fff", "ggg", "hhh", "bbb"],
+     {"keys": ["aaa", "bbb", "ccc", "ddd", "eee", "fff", "ggg", "hhh"],
+      "values": [4, 0, 4, 3, 2, 2, 2, 4, 0, 6, 5, 7, 0, 5, 5, 6, 7, 1]}, level="py")
+case("py_cat_to_device", "python/tests/test_category.py:262-267", "category",
+     ["apple", "pear", "banana", "orange", "pear"],
+     {"keys": ["apple", "banana", "orange", "pear"], "values": [0, 3, 1, 2, 3]}, level="py")
+case("py_cat_from_offsets", "python/tests/test_category.py:241-248", "category", ["a", "p", "p", "l", "e"],
+     {"keys": ["a", "e", "l", "p"], "values": [0, 3, 3, 2, 1]}, level="py")
+
+case("py_tokenize", "python/tests/test_text.py:10-38", "tokenize",
+     ["the quick fox jumped over the lazy dog", "the siamésé cat jumped under the sofa", None, ""],
+     ["the", "quick", "fox", "jumped", "over", "the", "lazy", "dog", "the", "siamésé", "cat", "jumped",
+      "under", "the", "sofa"], level="py", delimiter=None)
+case("py_bigrams", "python/tests/test_text.py:227-241", "tokenize_ngrams",
+     ["this is my favorite", "book on my bookshelf"],
+     ["this_is", "is_my", "my_favorite", "favorite_book", "book_on", "on_my", "my_bookshelf"], level="py",
+     N=2, sep="_")
+case("py_trigrams", "python/tests/test_text.py:243-257", "tokenize_ngrams",
+     ["this is my favorite", "book on my bookshelf"],
+     ["this-is-my", "is-my-favorite", "my-favorite-book", "favorite-book-on", "book-on-my", "on-my-bookshelf"],
+     level="py", N=3, sep="-")
+
+# pandas-compared reference tests: expectation = pandas output on the same input
+import pandas as pd  # noqa: E402
+
+
+def none_if_nan(v):
+    return None if (v is None or (isinstance(v, float) and np.isnan(v)) or v is pd.NA) else v
+
+
+REGEX_STRS = ["5", "hej", "\t \n", "12345", "\\", "d", "c:\\Tools", "+27", "1c2", "1C2", "0:00:0", "0:0:00",
+              "00:0:0", "00:00:0", "00:0:00", "0:00:00", "00:00:00", "Hello world !", "Hello world!   ",
+              "Hello worldcup  !", "0123456789", "1C2", "Xaa", "abcdefghxxx", "ABCDEFGH", "abcdefgh", "abc def",
+              "abc\ndef", "aa\r\nbb\r\ncc\r\n\r\n", "abcabc"]
+REGEX_PATS = ["\\d", "\\w+", "\\s", "\\S", "^.*\\\\.*$", "[1-5]+", "[a-h]+", "[A-H]+", "\n", "b.\\s*\n", ".*c",
+              "\\d\\d:\\d\\d:\\d\\d", "\\d\\d?:\\d\\d?:\\d\\d?", "[Hh]ello [Ww]orld", "\\bworld\\b"]
+for i, p in enumerate(REGEX_PATS):
+    exp = [bool(x) for x in pd.Series(REGEX_STRS).str.contains(p).values]
+    case("py_regex_contains_%02d" % i, "python/tests/test_regex.py:11-68 (pandas)", "contains_re", REGEX_STRS, exp,
+         level="py", pat=p)
+RS = ["hello @abc @def world", "The quick brown @fox jumps", "over the", "lazy @dog",
+      "hello http://www.world.com I'm here @home"]
+for i, fnd in enumerate(["@\\S+", "(?:@|https?://)\\S+"]):
+    for j, rep in enumerate(["***", ""]):
+        exp = list(pd.Series(RS).str.replace(fnd, rep, regex=True).values)
+        case("py_regex_replace_%d%d" % (i, j), "python/tests/test_regex.py:71-86 (pandas)", "replace_re", RS, exp,
+             level="py", pat=fnd, repl=rep, n=-1)
+RM = ["xxx 1281151 xxxxxx xxxxxxx xxxx xxxx - xxxxx xxxx xx 24",
+      "2-xxxx xxxxxxxxxxx xxxxxxxxxx xxx26x4xxx xxxxxxxxxxxx xxxxx xxxxx"]
+case("py_regex_replace_b", "python/tests/test_regex.py:89-98 (pandas)", "replace_re", RM,
+     list(pd.Series(RM).str.replace(r"\b\d+\b", "*****", regex=True).values), level="py", pat=r"\b\d+\b", repl="*****", n=-1)
+for i, p in enumerate(["[hH]", "[bB][aA]"]):
+    s = ["hello", "and héllo", None, ""]
+    exp = [none_if_nan(v) for v in pd.Series(s).str.match(p).values]
+    exp = [None if v is None else bool(v) for v in exp]
+    case("py_regex_match_%d" % i, "python/tests/test_regex.py:101-107 (pandas)", "match", s, exp, level="py", pat=p)
+for i, p in enumerate(["a", "[aA]"]):
+    s = ["hello", "and héllo", "this was empty", ""]
+    case("py_regex_count_%d" % i, "python/tests/test_regex.py:110-117 (pandas)", "count_re", s,
+         [int(v) for v in pd.Series(s).str.count(p).values], level="py", pat=p)
+LARGE_S = [
+    "hello @abc @def world The quick brown @fox jumps over the lazy @dog hello http://www.world.com I'm here @home",
+    "12345678901234567890123456789012345678901234567890123456789012345678901234567890123456789012345678901234567890",
+    "abcdefghijklmnopqrstuvwxyz" * 6,
+]
+for i, p in enumerate([LARGE_S[0], LARGE_S[0] + " zzzz"]):
+    case("py_regex_large_%d" % i, "python/tests/test_regex.py:256-273 (pandas)", "contains_re", LARGE_S,
+         [bool(v) for v in pd.Series(LARGE_S).str.contains(p).values], level="py", pat=p)
+SS = ["  hello  ", "  there  ", "  world  ", None, "  accénté  ", ""]
+ps = pd.Series(SS)
+case("py_strip", "python/tests/test_strip.py:9-15 (pandas)", "strip", SS, [none_if_nan(v) for v in ps.str.strip()],
+     level="py", to_strip=None)
+case("py_strip_e", "python/tests/test_strip.py:21-23 (pandas)", "strip", SS,
+     [none_if_nan(v) for v in ps.str.strip(" e")], level="py", to_strip=" e")
+stripped = [none_if_nan(v) for v in ps.str.strip()]
+case("py_strip_accent", "python/tests/test_strip.py:17-19 (pandas)", "strip", stripped,
+     [none_if_nan(v) for v in pd.Series(stripped).str.strip("é")], level="py", to_strip="é")
+case("py_lstrip", "python/tests/test_strip.py:26-32 (pandas)", "lstrip", SS, [none_if_nan(v) for v in ps.str.lstrip()],
+     level="py", to_strip=None)
+case("py_rstrip", "python/tests/test_strip.py:35-41 (pandas)", "rstrip", SS, [none_if_nan(v) for v in ps.str.rstrip()],
+     level="py", to_strip=None)
+
+# ------------------------------------------------------- SURVEY.md Appendix A --
+A = []
+
+
+def acase(id, op, input, expect, **args):
+    A.append({"id": id, "src": "SURVEY.md Appendix A (recorded from the reference)", "op": op, "input": input,
+              "args": args, "expect": expect, "level": "c"})
+
+
+X = ["aébéc", "éé", "", None, "é", "abc", "aéé"]
+acase("a1_split_e", "split", X, [["a", "", "", None, "", "abc", "a"], ["b", "é", None, None, "", None, "é"],
+                                 ["c", None, None, None, None, None, None]], delimiter="é", n=-1)
+acase("a1_split_e_1", "split", X, [["a", "", "", None, "", "abc", "a"], ["béc", "é", None, None, "", None, "é"]],
+      delimiter="é", n=1)
+Y = ["a,b,,c", ",", ",,", "x", None, ""]
+acase("a1_split_comma", "split", Y, [["a", "", "", "x", None, ""], ["b", "", "", None, None, None],
+                                     ["", None, "", None, None, None], ["c", None, None, None, None, None]],
+      delimiter=",", n=-1)
+W = ["", "   ", " a b ", "a", None, "\ta\nb  c", "a  b   c d"]
+acase("a1_split_ws", "split", W, [[None, None, "a", "a", None, "a", "a"], [None, None, "b", None, None, "b", "b"],
+                                  [None, None, None, None, None, "c", "c"], [None, None, None, None, None, None, "d"]],
+      delimiter=None, n=-1)
+acase("a1_split_ws_1", "split", W, [[None, None, "a", "a", None, "a", "a"],
+                                    [None, None, "b ", None, None, "b  c", "b   c d"]], delimiter=None, n=1)
+Z = ["baaac", "abc", "", None, "aaa"]
+acase("a2_re_astar", "replace_re", Z, ["XXXXXbaaac", "XXXbc", "", None, "X"], pat="a*", repl="X", n=-1)
+acase("a2_re_astar_1", "replace_re", Z, ["Xbaaac", "Xbc", "", None, "X"], pat="a*", repl="X", n=1)
+acase("a2_re_xstar", "replace_re", Z, ["-----baaac", "---abc", "", None, "---aaa"], pat="x*", repl="-", n=-1)
+acase("a2_re_aplus", "replace_re", Z, ["bc", "bc", "", None, ""], pat="a+", repl="", n=-1)
+acase("a2_re_a_or_aa", "replace_re", Z, ["b<><><>c", "<>bc", "", None, "<><><>"], pat="a|aa", repl="<>", n=-1)
+acase("a2_re_aa_or_a", "replace_re", Z, ["b<><>c", "<>bc", "", None, "<><>"], pat="aa|a", repl="<>", n=-1)
+acase("a2_re_lazy", "replace_re", Z, ["b...c", ".bc", "", None, "..."], pat="a+?", repl=".", n=-1)
+IP = ["10.0.0.1", "999.999.999.9999", "1.2.3", "a1.2.3.4b 5.6.7.8", "1..2.3.4"]
+acase("a2_ip", "replace_re", IP, ["<IP>", "<IP>", "1.2.3", "a<IP>b <IP>", "1..2.3.4"],
+      pat="\\d+\\.\\d+\\.\\d+\\.\\d+", repl="<IP>", n=-1)
+acase("a2_ip_1", "replace_re", IP, ["<IP>", "<IP>", "1.2.3", "a<IP>b 5.6.7.8", "1..2.3.4"],
+      pat="\\d+\\.\\d+\\.\\d+\\.\\d+", repl="<IP>", n=1)
+acase("a2_ip_b", "replace_re", IP, ["<IP>", "999.999.999.9999", "1.2.3", "a1.2.3.4b <IP>", "1..2.3.4"],
+      pat="\\b\\d{1,3}\\.\\d{1,3}\\.\\d{1,3}\\.\\d{1,3}\\b", repl="<IP>", n=-1)
+L = ["a\nb", "ba", "ab", "\nb", "b\n"]
+
+
+def bits(s):
+    return [c == "1" for c in s.replace(" ", "")]
+
+
+for pid, pat, exp in [("bol_a", "^a", "10100"), ("a_eol", "a$", "11000"), ("bol_b", "^b", "11011"),
+                      ("b_eol", "b$", "10111"), ("Ab", "\\Ab", "01001"), ("bZ", "b\\Z", "10110"),
+                      ("adotb", "a.b", "00000"), ("anxb", "a[^x]b", "00000"), ("bb", "\\bb", "11011")]:
+    acase("a2_anchor_" + pid, "contains_re", L, bits(exp), pat=pat)
+U = ["é", "_", "٣", "\u00a0", "a b", "x y", "été 42", "E", "😀", None, ""]
+acase("a2_w", "contains_re", U, bits("1 1 1 0 1 1 1 1 0 0 0"), pat="\\w")
+acase("a2_W", "contains_re", U, bits("0 0 0 1 1 1 1 0 1 0 0"), pat="\\W")
+acase("a2_cls_W", "contains_re", U, bits("0 0 0 1 1 1 1 0 0 0 0"), pat="[\\W]")
+acase("a2_count_xstar", "count_re", U, [1, 1, 1, 1, 3, 3, 6, 1, 1, 0, 0], pat="x*")
+acase("a2_empty_never", "contains_re", ["", None], [False, False], pat="^$")
+BIG = "a" * 120
+acase("a2_large_contains", "contains_re", [BIG, "aaa", None], [True, False, False], pat=BIG)
+acase("a2_large_replace", "replace_re", [BIG, "aaa", None], ["#", "aaa", None], pat=BIG, repl="#", n=-1)
+SP = ["\r hello\t\n", "  x  ", "\n\n", "éaé", ""]
+acase("a3_strip_default", "strip", SP, ["\r hello", "x", "", "éaé", ""], to_strip=None)
+acase("a3_strip_e", "strip", SP, ["\r hello\t\n", "  x  ", "\n\n", "a", ""], to_strip="é")
+acase("a3_lstrip_sp", "lstrip", SP, ["\r hello\t\n", "x  ", "\n\n", "éaé", ""], to_strip=" ")
+acase("a3_rstrip_default", "rstrip", SP, ["\r hello", "  x", "", "éaé", ""], to_strip=None)
+LC = ["ÀÉÎ ß İ Ǆ ǅ Σ Ω", "ABC xyz 123", "ẞ", "Ａ"]
+acase("a3_lower", "lower", LC, ["àéî ß i ǆ ǅ σ ω", "abc xyz 123", "ß", "ａ"])
+acase("a3_upper", "upper", LC, ["ÀÉÎ S İ Ǆ ǅ Σ Ω", "ABC XYZ 123", "ẞ", "Ａ"])
+acase("a3_find_e", "find", X, [1, 0, -1, -2, 0, -1, 1], sub="é", start=0, end=-1)
+acase("a3_find_empty", "find", X, [-1, -1, -1, -2, -1, -1, -1], sub="", start=0, end=-1)
+acase("a3_find_c_1_3", "find", X, [-1, -1, -1, -2, -1, 2, -1], sub="c", start=1, end=3)
+acase("a3_replace_e", "replace", X, ["aeebeec", "eeee", "", None, "ee", "abc", "aeeee"], pat="é", repl="ee", n=-1)
+acase("a3_replace_e_1", "replace", X, ["abéc", "é", "", None, "", "abc", "aé"], pat="é", repl="", n=1)
+acase("a4_cat_mixed", "category", ["b", "", None, "a", "É", "é", "a", "Z", ""],
+      {"keys": [None, "", "Z", "a", "b", "É", "é"], "values": [4, 1, 0, 3, 5, 6, 3, 2, 1]})
+acase("a4_cat_null", "category", E + [None], {"keys": [None, "aaa", "ccc", "ddd", "eee"],
+                                              "values": [4, 1, 4, 3, 2, 2, 2, 4, 1, 0]})
+TK = ["a_b-c", "__a", "", None, "-_-", "abc"]
+acase("a4_tokenize_set", "tokenize", TK, ["a", "b", "c", "a", "abc"], delimiter="_-")
+acase("a4_tokenize_ws", "tokenize", TK, ["a_b-c", "__a", "-_-", "abc"], delimiter=None)
+acase("a4_bigrams_rows", "tokenize_ngrams",
+      ["the fox jumped over the dog", "the dog chased the cat", None, "", "the mouse ate the cheese"],
+      ["the_fox", "fox_jumped", "jumped_over", "over_the", "the_dog", "dog_the", "the_dog", "dog_chased",
+       "chased_the", "the_cat", "cat_the", "the_mouse", "mouse_ate", "ate_the", "the_cheese"], N=2, sep="_")
+acase("a4_ngrams_short2", "ngrams", ["a", "b"], ["a_b"], N=2, sep="_")
+acase("a4_ngrams_short3", "ngrams", ["a", "b"], ["a_b"], N=3, sep="_")
+
+# ------------------------------------------------- reference regex compiler --
+PATTERNS = sorted(set(
+    [c["args"]["pat"] for c in CASES + A if c["op"] in ("contains_re", "match", "count_re", "replace_re")]
+    + ["a", "abc", "a|b", "(a|b)*c", "a?b+c*", "a{3}", "a{2,4}", "a{2,}", "(ab){2,3}", "[a-z]", "[^a-z]", "[a-zA-Z0-9_]",
+       "[\\d\\s]", "[^\\w]", "\\A\\w+\\Z", "^$", ".", ".*", ".+?x", "(?:ab)+", "a\\.b", "\\\\", "\\n\\t", "[é-ü]", "é+",
+       "\\bété\\b", "\\B", "\\S+@\\S+", "(\\d+)-(\\d+)", "x|", "|x", "()", "a||b", "[abc", "a{", "a{1", "\\101bc", "x\\60y\\x41z",
+       "[\\]]", "[a\\-z]", "\\d{1,3}\\.\\d{1,3}\\.\\d{1,3}\\.\\d{1,3}", "(https?|ftp)://[^\\s/$.?#].[^\\s]*",
+       "[A-Za-z0-9._%+-]+@[A-Za-z0-9.-]+\\.[A-Za-z]{2,}", "^(GET|POST|PUT|DELETE|HEAD) ", " (200|301|304|404|500|503) ",
+       "a" * 70, "(a|b|c|d|e|f|g|h){8}"]))
+
+
+def main():
+    import cpulibs
+
+    os.makedirs(OUT, exist_ok=True)
+    with open(os.path.join(OUT, "reference_tests.json"), "w") as f:
+        json.dump(CASES, f, ensure_ascii=False, indent=0)
+    with open(os.path.join(OUT, "survey_appendix_a.json"), "w") as f:
+        json.dump(A, f, ensure_ascii=False, indent=0)
+    if cpulibs.ref_regcomp() is None:
+        raise SystemExit("oracle/_ref is not built (needs /root/reference): `make -C oracle ref`")
+    progs = {p: [int(x) for x in cpulibs.ref_blob(p)] for p in PATTERNS}
+    with open(os.path.join(OUT, "regex_programs.json"), "w") as f:
+        json.dump({"note": "int32 program blobs (layout: custrings_amd/csrc/regex_program.h) emitted by the "
+                           "reference's own regcomp.cpp via oracle/ref_regcomp_wrap.cpp", "programs": progs},
+                  f, ensure_ascii=False)
+    print("wrote %d reference cases, %d appendix cases, %d regex programs" % (len(CASES), len(A), len(progs)))
+
+
+if __name__ == "__main__":
+    main()
