@@ -1,0 +1,209 @@
+#!/usr/bin/env python3
+"""Headline benchmark: split(' ') + replace_re(IPv4 -> "<IP>") over the C3 log-line
+column (BASELINE.json: "GB/s input chars + Mstrings/s, split+replace_re on 100M
+rows"), one process per GPU, rows sharded by range, no data-path collective.
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of the hot path (split + replace_re) over this rank's
+100M-row shard, inputs already resident in HBM.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import torch  # noqa: E402  (first: the process must use ONE HIP runtime, see custrings_amd/__init__.py)
+import torch.distributed as dist  # noqa: E402
+
+IPV4 = r"\d+\.\d+\.\d+\.\d+"
+REPL = "<IP>"
+SEED = 20240607
+KERNELS = ["k_split_scan", "k_split_write", "k_replace_re", "k_replace_re_size", "k_replace_re_write",
+           "k_split_count", "k_split_sizes", "k_write_offsets", "k_scan_lookback"]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--rows", type=int, default=100_000_000, help="rows per GPU (weak scaling)")
+    ap.add_argument("--cpu-rows", type=int, default=3_000_000, help="rows of the same workload timed on the CPU oracle")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--pmc-traffic", type=float, default=None, help="HBM bytes/launch of the dominant kernel from a separate rocprofv3 --pmc run")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    from custrings_amd import _lib, nvstrings
+
+    L = _lib.lib
+    _lib.ensure_init(local)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- this rank's shard: rows [rank*rows, (rank+1)*rows) of the C3 column
+    out = C.c_void_p()
+    _lib.check(L.cs_synth_column(3, rank * args.rows, args.rows, SEED, 0, None, C.byref(out)))
+    col = nvstrings.nvstrings(out.value)
+    in_bytes = int(L.cs_column_nbytes(col.m_cptr))
+    re = nvstrings._compile(IPV4)
+    stats = {}
+
+    def step(record=False):
+        arr = C.POINTER(C.c_void_p)()
+        ncols = C.c_int()
+        _lib.check(L.cs_split(col.m_cptr, b" ", -1, None, C.byref(arr), C.byref(ncols)))
+        if record:
+            stats["split_cols"] = ncols.value
+            stats["split_out_bytes"] = sum(int(L.cs_column_nbytes(arr[i])) for i in range(ncols.value))
+        for i in range(ncols.value):
+            L.cs_column_destroy(arr[i])
+        L.cs_free(arr)
+        o = C.c_void_p()
+        _lib.check(L.cs_replace_re(col.m_cptr, re, REPL.encode(), -1, None, C.byref(o)))
+        if record:
+            stats["replace_out_bytes"] = int(L.cs_column_nbytes(o))
+        L.cs_column_destroy(o)
+
+    step(record=True)
+    for _ in range(max(args.warmup - 1, 0)):
+        step()
+    L.cs_prof_reset()
+    L.cs_prof_enable(1)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    L.cs_prof_enable(0)
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    tot = torch.tensor([float(in_bytes), float(args.rows)], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+    elapsed = float(t.item())
+    total_bytes, total_rows = float(tot[0].item()), float(tot[1].item())
+
+    if rank == 0:
+        # ---- per-kernel device time from HIP events recorded on the launch stream
+        prof = {}
+        for k in KERNELS:
+            ms, n = C.c_double(), C.c_int64()
+            L.cs_prof_get(k.encode(), C.byref(ms), C.byref(n))
+            if n.value:
+                prof[k] = {"avg_ms": ms.value / n.value, "launches": n.value}
+        rows = args.rows
+        Lb = in_bytes / rows
+        Ccols = stats["split_cols"]
+        split_out = stats["split_out_bytes"] / rows
+        repl_out = stats["replace_out_bytes"] / rows
+        # algorithmic bytes per row (SURVEY.md section 8d / BASELINE.md section 2)
+        alg_replace = (Lb + 8.125) + (repl_out + 8.125)
+        alg_split = (Lb + 8.125) + split_out + Ccols * 8.125
+        # per-kernel share: what that kernel must read and write given its role
+        alg_kernel = {
+            "k_replace_re": alg_replace,
+            "k_split_scan": Lb + 8.125 + Ccols * 8.125,
+            "k_split_write": Lb + 8.125 + split_out + Ccols * 8,
+            "k_replace_re_size": Lb + 8.125 + 4,
+            "k_replace_re_write": Lb + 16 + repl_out,
+            "k_split_count": Lb + 8.125 + 4,
+            "k_split_sizes": Lb + 8.125 + 4 + 4 * Ccols,
+            "k_write_offsets": 12,
+        }
+        dom = max(prof, key=lambda k: prof[k]["avg_ms"] * prof[k]["launches"]) if prof else None
+        roofline = None
+        if dom:
+            a = alg_kernel.get(dom, 0) * rows / (prof[dom]["avg_ms"] * 1e-3) / 1e9
+            roofline = {"bound": "hbm", "kernel": dom, "achieved": round(a, 1), "peak": 8000.0, "unit": "GB/s",
+                        "frac": round(a / 8000.0, 4), "traffic": args.pmc_traffic,
+                        "avg_ms": round(prof[dom]["avg_ms"], 3),
+                        "alg_bytes_per_row": round(alg_kernel.get(dom, 0), 2)}
+        ms_step = elapsed / args.steps * 1e3
+        pipeline = (alg_replace + alg_split) * total_rows / (elapsed / args.steps) / 1e9
+        result = {
+            "metric": "GB/s input chars, split(' ') + replace_re(IPv4) on 100M log-line rows per GPU",
+            "value": round(total_bytes / (elapsed / args.steps) / 1e9, 2),
+            "unit": "GB/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_step, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8",
+            "data": "synthetic",
+            "config": {"workload": "C3 headline: 100M log-line rows (48-80 B, mean %.1f) per GPU, split(' ') -> %d columns"
+                                   " + replace_re('%s','%s')" % (Lb, Ccols, IPV4, REPL),
+                       "rows_per_gpu": rows, "seed": SEED, "sharding": "row ranges, no data-path collective"},
+            "mstrings_per_s": round(total_rows / (elapsed / args.steps) / 1e6, 1),
+            "roofline": roofline,
+            "roofline_pipeline": {"alg_bytes_per_row": round(alg_replace + alg_split, 1), "achieved": round(pipeline, 1),
+                                  "peak": 8000.0 * world, "unit": "GB/s", "frac": round(pipeline / (8000.0 * world), 4)},
+            "kernels": {k: {"avg_ms": round(v["avg_ms"], 3), "launches": v["launches"]} for k, v in prof.items()},
+        }
+        if not args.no_cpu:
+            result["cpu_baseline"] = cpu_baseline(args.cpu_rows)
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(rows):
+    """The oracle (scalar C++ port of the reference algorithm, 1 thread) on a bounded
+    sample of the same workload; plus pandas.Series.str on a smaller sample, as
+    BASELINE.json's north_star asks."""
+    import numpy as np
+
+    import cpulibs
+    import engines
+
+    orc = cpulibs.Oracle()
+    c = orc.synth(3, 0, rows)
+    blob = np.ascontiguousarray(engines.product_blob(IPV4))
+    t0 = time.perf_counter()
+    orc.split(c, " ")
+    orc.replace_re(c, blob, REPL)
+    dt = time.perf_counter() - t0
+    res = {"value": round(c.chars.size / dt / 1e9, 5), "unit": "GB/s", "cores": 1, "kind": "port",
+           "sample": "first %d rows of the same C3 column, split(' ') + replace_re, oracle/liboracle.so, %.1f s" % (rows, dt)}
+    try:
+        import pandas as pd
+
+        n = min(rows, 300_000)
+        s = pd.Series(orc.synth(3, 0, n).to_list())
+        t0 = time.perf_counter()
+        s.str.split(" ", expand=True)
+        s.str.replace(IPV4, REPL, regex=True)
+        dtp = time.perf_counter() - t0
+        nbytes = int(s.str.len().sum())
+        res["pandas"] = {"value": round(nbytes / dtp / 1e9, 5), "unit": "GB/s", "cores": 1, "rows": n,
+                         "host_cpus": os.cpu_count(), "version": pd.__version__}
+    except Exception as e:  # pandas is a courtesy figure, never fatal
+        res["pandas"] = {"error": str(e)}
+    return res
+
+
+if __name__ == "__main__":
+    main()

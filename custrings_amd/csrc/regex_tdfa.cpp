@@ -1,0 +1,392 @@
+// Host-side construction of the tagged DFA (layout and semantics: regex_tdfa.h).
+// Pure host C++; compiled into the library and into tests/rowemu.
+#include "regex_tdfa.h"
+
+#include <algorithm>
+#include <map>
+#include <vector>
+
+#include "regex_program.h"
+
+namespace csrx {
+namespace {
+
+using cstd::kMaxSlots;
+using csrow::Char;
+
+struct Atom {
+  uint64_t sig = 0;  // predicate truth bits
+  bool eot = false, nul = false;
+  bool isnl = false, isword = false;
+};
+
+struct State {
+  std::vector<int> kernel;  // ordered, de-duplicated instruction ids
+  int cat;                  // bit0 word, bit1 newline, bit2 row start (masked by use)
+  int mode;
+  bool operator<(const State& o) const {
+    if (mode != o.mode) return mode < o.mode;
+    if (cat != o.cat) return cat < o.cat;
+    return kernel < o.kernel;
+  }
+};
+
+unsigned cp_next_valid(unsigned cp) {
+  ++cp;
+  if (cp >= 0xD800 && cp <= 0xDFFF) cp = 0xE000;
+  return cp;
+}
+
+struct Builder {
+  const Program& P;
+  csvm::ProgView V;
+  std::vector<int> pred_type, pred_arg;
+  std::vector<int> inst_pred;  // per instruction: predicate index or -1
+  int p_isnl = -1, p_isword = -1;
+  bool use_word = false, use_line = false;
+  std::vector<Atom> atoms;
+  int ascii_atom[128];
+  std::vector<std::pair<uint64_t, int>> na_atoms;  // signature -> atom id, non-ASCII chars
+
+  Builder(const Program& p, const std::vector<int32_t>& image, const uint8_t* flags)
+      : P(p), V(csvm::make_view(image.data(), flags)) {}
+
+  int add_pred(int type, int arg) {
+    for (size_t i = 0; i < pred_type.size(); ++i)
+      if (pred_type[i] == type && pred_arg[i] == arg) return (int)i;
+    pred_type.push_back(type);
+    pred_arg.push_back(arg);
+    return (int)pred_type.size() - 1;
+  }
+  bool eval(int i, Char c) const {
+    switch (pred_type[i]) {
+      case cstd::P_CHAR: return c == (Char)pred_arg[i];
+      case cstd::P_ANY: return c != '\n';
+      case cstd::P_ANYNL: return true;
+      case cstd::P_CCLASS: return csvm::class_match(V, pred_arg[i], c);
+      case cstd::P_NCCLASS: return !csvm::class_match(V, pred_arg[i], c);
+      case cstd::P_ISNL: return c == '\n';
+      case cstd::P_ISWORD: return csvm::is_word(V, c);
+    }
+    return false;
+  }
+  uint64_t signature(Char c) const {
+    uint64_t s = 0;
+    for (size_t i = 0; i < pred_type.size(); ++i)
+      if (eval((int)i, c)) s |= 1ull << i;
+    return s;
+  }
+  int atom_for(uint64_t sig, bool create) {
+    for (size_t k = cstd::ATOM_FIRST_CLASS; k < atoms.size(); ++k)
+      if (atoms[k].sig == sig) return (int)k;
+    if (!create) return -1;
+    Atom a;
+    a.sig = sig;
+    a.isnl = p_isnl >= 0 && ((sig >> p_isnl) & 1);
+    a.isword = p_isword >= 0 && ((sig >> p_isword) & 1);
+    atoms.push_back(a);
+    return (int)atoms.size() - 1;
+  }
+
+  bool collect_predicates() {
+    const int n = (int)P.insts.size();
+    inst_pred.assign(n, -1);
+    bool has_big = false;  // a literal or range end among the 4-byte characters
+    for (int i = 0; i < n; ++i) {
+      const Inst& in = P.insts[i];
+      switch (in.type) {
+        case OP_CHAR:
+          inst_pred[i] = add_pred(cstd::P_CHAR, in.u1);
+          has_big |= (uint32_t)in.u1 >= 0xF0000000u;
+          break;
+        case OP_ANY: inst_pred[i] = add_pred(cstd::P_ANY, 0); break;
+        case OP_ANYNL: inst_pred[i] = add_pred(cstd::P_ANYNL, 0); break;
+        case OP_CCLASS:
+        case OP_NCCLASS:
+          if (in.u1 < 0 || in.u1 >= (int)P.classes.size()) return false;
+          inst_pred[i] = add_pred(in.type == OP_CCLASS ? cstd::P_CCLASS : cstd::P_NCCLASS, in.u1);
+          for (uint32_t r : P.classes[in.u1].ranges) has_big |= r >= 0xF0000000u;
+          break;
+        case OP_BOL: use_line = true; break;
+        case OP_EOL: use_line = true; break;
+        case OP_BOW:
+        case OP_NBOW: use_word = true; break;
+        default: break;
+      }
+    }
+    // '$' needs "next char is a newline", '^' needs "previous char was a newline"
+    if (use_line) p_isnl = add_pred(cstd::P_ISNL, 0);
+    if (use_word) p_isword = add_pred(cstd::P_ISWORD, 0);
+    if (pred_type.size() > 62) return false;
+    // atoms
+    atoms.resize(2);
+    atoms[cstd::ATOM_EOT].eot = true;
+    atoms[cstd::ATOM_NUL].eot = true;
+    atoms[cstd::ATOM_NUL].nul = true;
+    ascii_atom[0] = cstd::ATOM_NUL;
+    for (unsigned c = 1; c < 128; ++c) ascii_atom[c] = atom_for(signature(c), true);
+    auto add_na = [&](unsigned cp) {
+      uint64_t s = signature(csrow::cp_to_packed(cp));
+      for (auto& kv : na_atoms)
+        if (kv.first == s) return;
+      na_atoms.emplace_back(s, atom_for(s, true));
+    };
+    for (unsigned cp = 0x80; cp < 0x10000; cp = cp_next_valid(cp)) add_na(cp);
+    if (has_big) {
+      for (unsigned cp = 0x10000; cp < 0x110000; ++cp) add_na(cp);
+    } else {
+      add_na(0x1F600);
+    }
+    return atoms.size() <= 250;
+  }
+
+  // ---- one step of the list simulator, symbolically --------------------------
+  struct Step {
+    State next;
+    bool stop = false;
+    int match = -1;  // -1 none, 0..7 old slot, 15 new
+    std::vector<int> origins;
+  };
+  bool step(const State& S, int atom_id, Step& out) const {
+    const Atom& a = atoms[atom_id];
+    const bool at0 = (S.cat & 4) != 0, pc_nl = (S.cat & 2) != 0, pc_word = (S.cat & 1) != 0;
+    const bool cc_zero = a.eot, cc_nl = a.isnl, cc_word = a.isword;
+    const int n = (int)P.insts.size();
+    std::vector<char> seen(n, 0);
+    std::vector<std::pair<int, int>> L;  // (inst, origin)
+    std::vector<int> stk;
+    auto closure = [&](int inst, int origin) {
+      stk.clear();
+      stk.push_back(inst);
+      while (!stk.empty()) {
+        int id = stk.back();
+        stk.pop_back();
+        if (id < 0 || id >= n) continue;  // malformed program: thread vanishes
+        if (seen[id]) continue;
+        seen[id] = 1;
+        const Inst& in = P.insts[id];
+        switch (in.type) {
+          case OP_OR:
+            stk.push_back(in.u2);
+            stk.push_back(in.u1);
+            break;
+          case OP_LBRA:
+          case OP_RBRA: stk.push_back(in.u2); break;
+          case OP_BOL:
+            if (at0 || ((Char)in.u1 == '^' && pc_nl)) stk.push_back(in.u2);
+            break;
+          case OP_EOL:
+            if (cc_zero || ((Char)in.u1 == '$' && cc_nl)) stk.push_back(in.u2);
+            break;
+          case OP_BOW:
+          case OP_NBOW:
+            if ((cc_word != pc_word) == (in.type == OP_BOW)) stk.push_back(in.u2);
+            break;
+          default: L.emplace_back(id, origin); break;
+        }
+      }
+    };
+    for (size_t i = 0; i < S.kernel.size(); ++i) closure(S.kernel[i], (int)i);
+    const bool seed = (S.mode == cstd::MODE_RESTART && !(a.eot && !a.nul)) || S.mode == cstd::MODE_SEED_ONCE;
+    if (seed)
+      for (int32_t s : P.starts) {
+        if (s < 0) break;
+        closure(s, 15);
+      }
+    out = Step();
+    std::vector<std::pair<int, int>> nk;
+    for (auto& t : L) {
+      const Inst& in = P.insts[t.first];
+      if (in.type == OP_END) {
+        out.match = t.second;
+        break;
+      }
+      int pi = inst_pred[t.first];
+      if (pi < 0 || a.eot) continue;  // unknown opcode never advances; nothing advances past the end
+      if ((a.sig >> pi) & 1) {
+        bool dup = false;
+        for (auto& q : nk) dup |= q.first == in.u2;
+        if (!dup) nk.emplace_back(in.u2, t.second);
+      }
+    }
+    if ((int)nk.size() > kMaxSlots) return false;
+    out.next.mode = (S.mode == cstd::MODE_RESTART && out.match < 0) ? cstd::MODE_RESTART : cstd::MODE_NORESTART;
+    out.next.cat = (use_word && a.isword ? 1 : 0) | (use_line && a.isnl ? 2 : 0);
+    for (auto& q : nk) {
+      out.next.kernel.push_back(q.first);
+      out.origins.push_back(q.second);
+    }
+    out.stop = a.eot || (nk.empty() && out.next.mode == cstd::MODE_NORESTART);
+    return true;
+  }
+
+  int min_match_chars() const {
+    // shortest number of consumed characters from any start to END (BFS, 0-1 weights)
+    const int n = (int)P.insts.size();
+    std::vector<int> dist(n, 1 << 28);
+    std::vector<int> q;
+    for (int32_t s : P.starts) {
+      if (s < 0) break;
+      if (s < n) {
+        dist[s] = 0;
+        q.push_back(s);
+      }
+    }
+    int best = 1 << 28;
+    for (size_t h = 0; h < q.size(); ++h) {  // Bellman-Ford style relaxation (tiny graphs)
+      int id = q[h];
+      const Inst& in = P.insts[id];
+      auto relax = [&](int to, int w) {
+        if (to < 0 || to >= n) return;
+        if (dist[id] + w < dist[to]) {
+          dist[to] = dist[id] + w;
+          q.push_back(to);
+        }
+      };
+      switch (in.type) {
+        case OP_END: best = std::min(best, dist[id]); break;
+        case OP_OR:
+          relax(in.u1, 0);
+          relax(in.u2, 0);
+          break;
+        case OP_LBRA:
+        case OP_RBRA:
+        case OP_BOL:
+        case OP_EOL:
+        case OP_BOW:
+        case OP_NBOW: relax(in.u2, 0); break;
+        case OP_CHAR:
+        case OP_ANY:
+        case OP_ANYNL:
+        case OP_CCLASS:
+        case OP_NCCLASS: relax(in.u2, 1); break;
+        default: break;
+      }
+      if (q.size() > (size_t)n * n * 4 + 64) break;
+    }
+    return best >= (1 << 28) ? 0 : best;
+  }
+};
+
+}  // namespace
+
+std::vector<int32_t> build_tdfa(const Program& prog, const std::vector<int32_t>& image, const uint8_t* flags) {
+  std::vector<int32_t> none;
+  if (prog.insts.empty() || prog.insts.size() > 4096) return none;
+  Builder B(prog, image, flags);
+  if (!B.collect_predicates()) return none;
+  const int natoms = (int)B.atoms.size();
+
+  std::map<State, int> ids;
+  std::vector<State> states;
+  auto intern = [&](const State& s) {
+    auto it = ids.find(s);
+    if (it != ids.end()) return it->second;
+    int id = (int)states.size();
+    ids.emplace(s, id);
+    states.push_back(s);
+    return id;
+  };
+  // initial states: empty kernel, every (mode, category) the executor can start in
+  std::vector<uint32_t> init(3 * 8, 0);
+  for (int mode = 0; mode < 3; ++mode)
+    for (int cat = 0; cat < 8; ++cat) {
+      State s;
+      s.mode = mode;
+      int c = 0;
+      if (cat & 4) c = B.use_line ? 4 : 0;  // row start: previous char is "nothing" (not word, not newline)
+      else c = (B.use_word ? (cat & 1) : 0) | (B.use_line ? (cat & 2) : 0);
+      s.cat = c;
+      init[mode * 8 + cat] = (uint32_t)intern(s);
+    }
+  std::vector<uint32_t> t2;          // nstates x natoms
+  std::vector<uint32_t> act;         // complex origin words
+  for (size_t si = 0; si < states.size(); ++si) {
+    if (states.size() > (size_t)cstd::kMaxStates) return none;
+    t2.resize((si + 1) * natoms, 0);
+    for (int a = 0; a < natoms; ++a) {
+      Builder::Step st;
+      State cur = states[si];  // copy: `states` may grow
+      if (!B.step(cur, a, st)) return none;
+      uint32_t e = 0;
+      if (st.stop) {
+        e |= cstd::E_STOP;
+      } else {
+        e |= (uint32_t)intern(st.next);
+      }
+      if (st.match >= 0) e |= cstd::E_MATCH | ((uint32_t)st.match << 12);
+      // origins: identity prefix + new tail, or complex
+      const int m = (int)st.origins.size();
+      int k = 0;
+      while (k < m && st.origins[k] == k) ++k;
+      bool tail_new = true;
+      for (int j = k; j < m; ++j) tail_new &= st.origins[j] == 15;
+      if (st.stop || m == 0 || k == m) {
+        e |= 15u << 16;
+      } else if (tail_new) {
+        e |= (uint32_t)k << 16;
+      } else {
+        uint32_t og = 0;
+        for (int j = 0; j < kMaxSlots; ++j) og |= (uint32_t)(j < m ? st.origins[j] : 15) << (4 * j);
+        size_t idx = std::find(act.begin(), act.end(), og) - act.begin();
+        if (idx == act.size()) act.push_back(og);
+        if (idx >= 2048) return none;
+        e |= cstd::E_COMPLEX | (15u << 16) | ((uint32_t)idx << 21);
+      }
+      t2[si * natoms + a] = e;
+    }
+  }
+  const int nstates = (int)states.size();
+  if (nstates > cstd::kMaxStates) return none;
+
+  std::vector<int32_t> img(cstd::kHeaderWords, 0);
+  auto append = [&](const void* p, size_t words) {
+    size_t off = img.size();
+    const int32_t* w = (const int32_t*)p;
+    img.insert(img.end(), w, w + words);
+    return (int32_t)off;
+  };
+  img[0] = cstd::kMagic;
+  img[1] = nstates;
+  img[2] = natoms;
+  img[3] = (int32_t)B.pred_type.size();
+  img[4] = (int32_t)B.na_atoms.size();
+  img[5] = (B.use_word ? 1 : 0) | (B.use_line ? 2 : 0);
+  img[6] = append(init.data(), init.size());
+  std::vector<uint32_t> t1((size_t)nstates * 128);
+  for (int s = 0; s < nstates; ++s)
+    for (int c = 0; c < 128; ++c) t1[(size_t)s * 128 + c] = t2[(size_t)s * natoms + B.ascii_atom[c]];
+  img[7] = append(t1.data(), t1.size());
+  img[8] = append(t2.data(), t2.size());
+  std::vector<int32_t> preds;
+  for (size_t i = 0; i < B.pred_type.size(); ++i) {
+    preds.push_back(B.pred_type[i]);
+    preds.push_back(B.pred_arg[i]);
+  }
+  if (preds.empty()) preds.push_back(0);
+  img[9] = append(preds.data(), preds.size());
+  std::vector<uint32_t> sig;
+  for (auto& kv : B.na_atoms) {
+    sig.push_back((uint32_t)kv.first);
+    sig.push_back((uint32_t)(kv.first >> 32));
+    sig.push_back((uint32_t)kv.second);
+  }
+  img[10] = append(sig.data(), sig.size());
+  if (act.empty()) act.push_back(0);
+  img[11] = append(act.data(), act.size());
+  int maxslots = 0;
+  for (auto& s : states) maxslots = std::max(maxslots, (int)s.kernel.size());
+  img[12] = maxslots;
+  img[13] = B.min_match_chars();
+  uint32_t cat[32] = {0};
+  for (unsigned c = 1; c < 128; ++c) {
+    const Atom& a = B.atoms[B.ascii_atom[c]];
+    unsigned v = (B.use_word && a.isword ? 1u : 0u) | (B.use_line && a.isnl ? 2u : 0u);
+    cat[c >> 2] |= v << (8 * (c & 3));
+  }
+  img[14] = append(cat, 32);
+  img[15] = (int32_t)img.size();
+  return img;
+}
+
+}  // namespace csrx

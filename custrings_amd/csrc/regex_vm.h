@@ -268,14 +268,14 @@ struct Vm {
 };
 
 // ---- row-level drivers (count.cu:36-56,168-196 ; replace.cu:39-107) -----------
-template <bool SMALL>
-CS_HD int row_contains_re(Vm<SMALL>& vm, bool anchored) {
+template <class VM>
+CS_HD int row_contains_re(VM& vm, bool anchored) {
   int mb, me;
   // match(): start window is [0,1) even for an empty row (count.cu:51)
   return vm.find(0, anchored ? 1 : vm.n, mb, me);
 }
-template <bool SMALL>
-CS_HD int row_count_re(Vm<SMALL>& vm) {
+template <class VM>
+CS_HD int row_count_re(VM& vm) {
   int k = 0, from = 0;
   while (from <= vm.n) {
     int mb, me;
@@ -293,8 +293,8 @@ CS_HD int row_count_re(Vm<SMALL>& vm) {
 }
 // Walks the successive matches exactly as replace_re does; emit(mb, me) per
 // replacement, `reps` identical zero-length replacements are reported at once.
-template <bool SMALL, class Emit>
-CS_HD void row_replace_matches(Vm<SMALL>& vm, int maxrepl, Emit&& emit) {
+template <class VM, class Emit>
+CS_HD void row_replace_matches(VM& vm, int maxrepl, Emit&& emit) {
   int left = maxrepl < 0 ? csrow::count_chars(vm.s, vm.n) : maxrepl;
   int from = 0;
   while (left > 0) {

@@ -236,6 +236,17 @@ class RowEmu(CpuLib):
         self._f("contains_re", C.c_int64, [vp, vp, C.c_int, vp])
         self._f("count_re", C.c_int64, [vp, vp, vp])
         self._f("replace_re", vp, [vp, vp, C.c_char_p, C.c_int])
+        self._f("set_engine", None, [C.c_int])
+        self._f("regex_tdfa_info", None, [vp, C.POINTER(C.c_int)])
+
+    def set_engine(self, e):
+        """0 = list simulator (Pike VM) only, 1 = tagged DFA when the program converts"""
+        self._set_engine(e)
+
+    def tdfa_info(self, re):
+        out = (C.c_int * 5)()
+        self._regex_tdfa_info(re, out)
+        return list(out)
 
     def compile(self, pattern):
         return self._regex_compile(self._b(pattern))

@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "../../custrings_amd/csrc/regex_program.h"
+#include "../../custrings_amd/csrc/regex_tdfa.h"
 #include "../../custrings_amd/csrc/regex_vm.h"
 #include "../../custrings_amd/csrc/row_ops.h"
 #include "../../oracle/unicode_tables_gen.h"  // same generated tables the product embeds
@@ -187,14 +188,27 @@ int emu_split(const emu_col* c, const char* delim, int maxsplit, emu_col*** cols
 
 // ---- regex ----
 struct emu_regex {
-  std::vector<int32_t> blob, image;
+  std::vector<int32_t> blob, image, tdfa;
 };
+static int g_engine = 1;  // 0 = list simulator only, 1 = tagged DFA when the program converts
+void emu_set_engine(int e) { g_engine = e; }
 emu_regex* emu_regex_compile(const char* pattern) {
   emu_regex* re = new emu_regex;
   csrx::Program p = csrx::compile(pattern);
   re->blob = p.to_blob();
   re->image = p.to_device_image(orc_unicode_flags);
+  re->tdfa = csrx::build_tdfa(p, re->image, orc_unicode_flags);
   return re;
+}
+// [states, atoms, max slots, min match chars, image words] of the tagged DFA; 0 states = not convertible
+void emu_regex_tdfa_info(const emu_regex* re, int* out) {
+  for (int i = 0; i < 5; ++i) out[i] = 0;
+  if (re->tdfa.empty()) return;
+  out[0] = re->tdfa[1];
+  out[1] = re->tdfa[2];
+  out[2] = re->tdfa[12];
+  out[3] = re->tdfa[13];
+  out[4] = (int)re->tdfa.size();
 }
 // adopt a program blob produced elsewhere (e.g. by the real reference compiler)
 emu_regex* emu_regex_from_blob(const int32_t* words, int n) {
@@ -212,6 +226,12 @@ int emu_regex_blob(const emu_regex* re, const int32_t** words) {
 template <class F>
 static void with_vm(const emu_regex* re, const uint8_t* row, int len, F f) {
   csvm::ProgView P = csvm::make_view(re->image.data(), orc_unicode_flags);
+  if (g_engine == 1 && !re->tdfa.empty()) {
+    cstd::View D = cstd::make_view(re->tdfa.data());
+    cstd::Tdfa vm(D, P, row, len);
+    f(vm);
+    return;
+  }
   std::vector<uint32_t> mem((size_t)csvm::vm_slots(P.ninst) + 1);
   if (P.ninst <= 64) {
     csvm::Vm<true> vm(P, mem.data(), 1, row, len);

@@ -11,12 +11,15 @@ REF = [c for c in engines.load_cases("reference_tests.json") if c["op"] not in (
 APX = [c for c in engines.load_cases("survey_appendix_a.json") if c["op"] not in ("category", "ngrams", "tokenize_ngrams")]
 
 
+@pytest.mark.parametrize("engine", [0, 1], ids=["pike", "tdfa"])
 @pytest.mark.parametrize("case", REF + APX, ids=[c["id"] for c in REF + APX])
-def test_rowemu_golden(emu_engine, case):
+def test_rowemu_golden(emu_engine, case, engine):
+    emu_engine.e.set_engine(engine)
     assert engines.run_case(emu_engine, case) == case["expect"], case["src"]
 
 
-PATTERNS = [r"\d+\.\d+\.\d+\.\d+", r"\b\d{1,3}\.\d{1,3}\.\d{1,3}\.\d{1,3}\b", r"a*", r"x*", r"a|aa", r"aa|a", r"a+?",
+PATTERNS = [r"\w+@\w+", r"(\bin\b)|(\ba\b)|(\bthe\b)", r"ab|b", r"(a|ab)(c|bcd)", r"\s\S+\s", r"[^\W\d]+", r"^\w+|\w+$",
+            r"(a|b|c){2,}x", r"\d+\.\d+\.\d+\.\d+", r"\b\d{1,3}\.\d{1,3}\.\d{1,3}\.\d{1,3}\b", r"a*", r"x*", r"a|aa", r"aa|a", r"a+?",
             r"\w+", r"\W", r"[\W]", r"\s+", r"^a", r"a$", r"\bc", r"c\b", r"\B", r"[a-c]+[x-z]?", r"[^a-c ]+", r"é+",
             r"[é-ü]", r"(a|b)*c", r".", r".*", r"^$", r"\Aa", r"z\Z", r"(ab|a)(bc|c)?", r"a{2,3}", r"(a|b|c){3}"]
 
@@ -44,8 +47,10 @@ def test_rowemu_vs_oracle_string_ops(emu_engine, oracle_engine, seed):
         assert e.tokenize(s, d) == o.tokenize(s, d)
 
 
+@pytest.mark.parametrize("engine", [0, 1], ids=["pike", "tdfa"])
 @pytest.mark.parametrize("pat", PATTERNS)
-def test_rowemu_vs_oracle_regex(emu_engine, oracle_engine, pat):
+def test_rowemu_vs_oracle_regex(emu_engine, oracle_engine, pat, engine):
+    emu_engine.e.set_engine(engine)
     s = fuzzdata.rows(11, 300, alphabet=list("aabbc xyz_.\n019") + ["é", "ü", "😀"]) + fuzzdata.log_rows(5, 300)
     o, e = oracle_engine, emu_engine
     assert e.contains_re(s, pat) == o.contains_re(s, pat)
@@ -53,3 +58,35 @@ def test_rowemu_vs_oracle_regex(emu_engine, oracle_engine, pat):
     assert e.count_re(s, pat) == o.count_re(s, pat)
     for n in (-1, 1, 2):
         assert e.replace_re(s, pat, "<é>", n) == o.replace_re(s, pat, "<é>", n), n
+
+
+def test_tdfa_vs_oracle_on_generated_patterns(emu_engine, oracle_engine):
+    """Random programs: the tagged DFA (when the program converts) and the list
+    simulator must both reproduce the oracle's match spans."""
+    import random
+
+    rnd = random.Random(99)
+    atoms = ["a", "b", "c", "é", ".", "\\d", "\\w", "\\s", "\\W", "[a-c]", "[^x ]", "[\\d_]", "(ab)", "(a|b)", "(?:c)", "\\b",
+             "^", "$", "\\.", "x", "\\B", " "]
+    quants = ["", "", "", "*", "+", "?", "*?", "+?", "{2}", "{1,3}"]
+    s = fuzzdata.rows(21, 150, alphabet=list("aabbcc xx_.\n01") + ["é", "😀"]) + fuzzdata.log_rows(6, 60)
+    converted = 0
+    for _ in range(150):
+        pat = ""
+        n = rnd.randint(1, 5)
+        for i in range(n):
+            pat += rnd.choice(atoms) + rnd.choice(quants)
+            if rnd.random() < 0.15 and i + 1 < n:
+                pat += "|"
+        want = (oracle_engine.contains_re(s, pat), oracle_engine.count_re(s, pat), oracle_engine.replace_re(s, pat, "<>", -1),
+                oracle_engine.match(s, pat), oracle_engine.replace_re(s, pat, "#", 2))
+        for engine in (0, 1):
+            emu_engine.e.set_engine(engine)
+            got = (emu_engine.contains_re(s, pat), emu_engine.count_re(s, pat), emu_engine.replace_re(s, pat, "<>", -1),
+                   emu_engine.match(s, pat), emu_engine.replace_re(s, pat, "#", 2))
+            assert got == want, (pat, engine)
+        re = emu_engine.e.compile(pat)
+        converted += emu_engine.e.tdfa_info(re)[0] > 0
+        emu_engine.e._regex_free(re)
+    emu_engine.e.set_engine(1)
+    assert converted > 100
