@@ -302,6 +302,31 @@ int64_t count_nulls(const cs_column* c, hipStream_t s) {
   return c->null_count = c->rows - host[0];
 }
 
+__global__ void k_max_span64(const int64_t* __restrict__ offsets, int64_t rows, unsigned long long* __restrict__ out) {
+  int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  int64_t r0 = t * 64;
+  int v = 0;
+  if (r0 < rows) {
+    int64_t r1 = r0 + 64 < rows ? r0 + 64 : rows;
+    v = (int)(offsets[r1] - offsets[r0] > 0x7fffffff ? 0x7fffffff : offsets[r1] - offsets[r0]);
+  }
+  int m = block_reduce_max(v);
+  if (threadIdx.x == 0 && m) atomicMax(out, (unsigned long long)m);
+}
+int64_t max_span64(const cs_column* c, hipStream_t s) {
+  if (c->max_span64 >= 0) return c->max_span64;
+  if (c->rows == 0) return c->max_span64 = 0;
+  Buf acc = dev_alloc(8, s);
+  CS_HIP(hipMemsetAsync(acc->p, 0, 8, s));
+  int64_t nsub = (c->rows + 63) / 64;
+  hipLaunchKernelGGL(k_max_span64, dim3(blocks_for(nsub)), dim3(kBlock), 0, s, c->d_offsets(), c->rows,
+                     ptr<unsigned long long>(acc));
+  int64_t* host = (int64_t*)pinned_scratch(8);
+  CS_HIP(hipMemcpyAsync(host, acc->p, 8, hipMemcpyDeviceToHost, s));
+  CS_HIP(hipStreamSynchronize(s));
+  return c->max_span64 = host[0];
+}
+
 cs_column* make_all_null(int64_t rows, hipStream_t s) {
   auto* c = new cs_column;
   c->rows = rows;

@@ -82,6 +82,7 @@ struct cs_column {
   int64_t rows = 0;
   int64_t nbytes = 0;
   mutable int64_t null_count = -1;  // -1 = not counted yet
+  mutable int64_t max_span64 = -1;  // max bytes spanned by 64 consecutive rows (tile kernels); -1 = unknown
   cs::Buf chars, offsets, validity;  // validity may be null (all valid)
   const uint8_t* d_chars() const { return cs::ptr<const uint8_t>(chars); }
   const int64_t* d_offsets() const { return cs::ptr<const int64_t>(offsets); }
@@ -119,6 +120,9 @@ void offsets_from_lengths_segmented(const int32_t* lens, int64_t n, int segs, in
 // Validity bitmask from int32 lengths (bit set when len >= 0).
 Buf validity_from_lengths(const int32_t* lens, int64_t n, hipStream_t s);
 int64_t count_nulls(const cs_column* c, hipStream_t s);
+// Largest byte span of 64 consecutive rows starting at a multiple of 64 (cached
+// in the column; sizes the LDS staging buffers of the tile kernels).
+int64_t max_span64(const cs_column* c, hipStream_t s);
 // Row-wise concatenation of columns into one new column.
 cs_column* concat_columns(const std::vector<const cs_column*>& cols, hipStream_t s);
 

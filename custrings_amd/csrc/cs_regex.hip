@@ -15,7 +15,9 @@
 #include "cs_internal.h"
 #include "device_utils.h"
 #include "regex_program.h"
+#include "regex_tdfa.h"
 #include "regex_vm.h"
+#include "tile_utils.h"
 
 using namespace cs;
 using namespace csdev;
@@ -24,7 +26,9 @@ struct cs_regex {
   csrx::Program prog;
   std::vector<int32_t> blob;   // program only (ABI: cs_regex_blob)
   std::vector<int32_t> image;  // blob + executor extras
+  std::vector<int32_t> tdfa;   // tagged DFA image (empty = not convertible)
   Buf d_image;                 // uploaded lazily
+  Buf d_tdfa;
   bool empty_pattern = false;
 };
 
@@ -154,13 +158,288 @@ __global__ void k_replace_re_write(RowSrc src, Launch L, const uint8_t* __restri
   }
 }
 
-Plan plan(cs_regex* re, int64_t rows, hipStream_t s) {
-  require_device();
+// ---- tagged-DFA kernels (regex_tdfa.h): tables staged in LDS, no per-thread lists ----
+struct TLaunch {
+  const int32_t* tdfa;   // device image
+  int tdfa_words;
+  int in_lds;
+  const int32_t* image;  // list-simulator image (global; consulted for non-ASCII chars only)
+};
+struct TCtx {
+  cstd::View D;
+  csvm::ProgView P;
+};
+template <bool IN_LDS>
+__device__ __forceinline__ TCtx tsetup(const TLaunch& L, const uint8_t* flags, uint32_t* smem) {
+  TCtx c;
+  if (IN_LDS) {
+    for (int i = threadIdx.x; i < L.tdfa_words; i += blockDim.x) smem[i] = (uint32_t)L.tdfa[i];
+    __syncthreads();
+    c.D = cstd::make_view((const int32_t*)smem);
+  } else {
+    c.D = cstd::make_view(L.tdfa);
+  }
+  c.P = csvm::make_view(L.image, flags);
+  return c;
+}
+template <int MODE, bool IN_LDS>
+__global__ void __launch_bounds__(256) k_tdfa_scan(RowSrc src, TLaunch L, uint8_t* __restrict__ out8,
+                                                   int32_t* __restrict__ out32,
+                                                   unsigned long long* __restrict__ found) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  TCtx c = tsetup<IN_LDS>(L, src.flags, smem);
+  const ColView& in = src.in;
+  const int64_t nblk = (in.rows + blockDim.x - 1) / blockDim.x;
+  int hits = 0;
+  for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+    int64_t r = blk * blockDim.x + threadIdx.x;
+    if (r >= in.rows) continue;
+    int v = 0;
+    if (row_is_valid(in.validity, r)) {
+      int64_t b = in.offsets[r];
+      cstd::Tdfa vm(c.D, c.P, in.chars + b, (int)(in.offsets[r + 1] - b));
+      if (MODE == 2) v = csvm::row_count_re(vm);
+      else v = csvm::row_contains_re(vm, MODE == 1);
+    }
+    if (MODE == 2) out32[r] = v;
+    else out8[r] = (uint8_t)v;
+    hits += v > 0;
+  }
+  long long t = block_reduce_sum(hits);
+  if (threadIdx.x == 0 && t) atomicAdd(found, (unsigned long long)t);
+}
+template <bool IN_LDS>
+__global__ void __launch_bounds__(256) k_tdfa_replace_size(RowSrc src, TLaunch L, int rb, int maxrepl,
+                                                           int32_t* __restrict__ lens) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  TCtx c = tsetup<IN_LDS>(L, src.flags, smem);
+  const ColView& in = src.in;
+  const int64_t nblk = (in.rows + blockDim.x - 1) / blockDim.x;
+  for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+    int64_t r = blk * blockDim.x + threadIdx.x;
+    if (r >= in.rows) continue;
+    int len = -1;
+    if (row_is_valid(in.validity, r)) {
+      int64_t b = in.offsets[r];
+      int n = (int)(in.offsets[r + 1] - b);
+      cstd::Tdfa vm(c.D, c.P, in.chars + b, n);
+      len = n;
+      csvm::row_replace_matches(vm, maxrepl, [&](int mb, int me, int reps) { len += reps * rb - (me - mb); });
+    }
+    lens[r] = len;
+  }
+}
+template <bool IN_LDS>
+__global__ void __launch_bounds__(256) k_tdfa_replace_write(RowSrc src, TLaunch L, const uint8_t* __restrict__ repl,
+                                                            int rb, int maxrepl, const int64_t* __restrict__ out_off,
+                                                            uint8_t* __restrict__ out_chars) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  TCtx c = tsetup<IN_LDS>(L, src.flags, smem);
+  const ColView& in = src.in;
+  const int64_t nblk = (in.rows + blockDim.x - 1) / blockDim.x;
+  for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+    int64_t r = blk * blockDim.x + threadIdx.x;
+    if (r >= in.rows || !row_is_valid(in.validity, r)) continue;
+    int64_t b = in.offsets[r];
+    int n = (int)(in.offsets[r + 1] - b);
+    const uint8_t* p = in.chars + b;
+    uint8_t* o = out_chars + out_off[r];
+    int copied = 0;
+    cstd::Tdfa vm(c.D, c.P, p, n);
+    csvm::row_replace_matches(vm, maxrepl, [&](int mb, int me, int reps) {
+      for (int i = copied; i < mb; ++i) *o++ = p[i];
+      for (int k = 0; k < reps; ++k)
+        for (int i = 0; i < rb; ++i) *o++ = repl[i];
+      copied = me;
+    });
+    for (int i = copied; i < n; ++i) *o++ = p[i];
+  }
+}
+
+// ---- single-pass replace_re over row tiles (tile_utils.h) -----------------------------
+// Used when the output is known not to outgrow the input (replacement no longer
+// than the shortest possible match): the output buffer is allocated at the input
+// size, every input byte is read once, the automaton runs once per row, and
+// offsets come from a look-back scan inside the same kernel.
+struct TileArgs {
+  ColView in;
+  const uint8_t* flags;
+  TLaunch L;
+  const uint8_t* repl;
+  int rb, maxrepl;
+  int64_t* out_off;
+  uint8_t* out_chars;
+  cstile::u64* status;
+  unsigned* error;  // set non-zero when the single pass could not complete
+  long long ntiles;
+  int cap_in, cap_out, tbl_bytes;
+  int debug;  // CS_TILE_DEBUG bit mask: skip phases (measurement only, results are wrong)
+};
+constexpr int kMaxRec = 4;  // matches per row kept in registers between the size and write phases
+
+template <class VM, class Rec>
+__device__ __forceinline__ int tile_row_size(VM& vm, int n, int rb, int maxrepl, Rec&& rec) {
+  int len = n;
+  csvm::row_replace_matches(vm, maxrepl, [&](int mb, int me, int reps) {
+    len += reps * rb - (me - mb);
+    rec(mb, me, reps);
+  });
+  return len;
+}
+
+// One wave = one sub-tile of 64 consecutive rows (workgroup = 4 sub-tiles, tile id =
+// blockIdx: nothing persistent, the hardware scheduler overlaps as many workgroups
+// as LDS allows).  Each wave stages its rows' contiguous span of the chars buffer
+// into its private LDS region with coalesced 16-byte loads, runs the automaton per
+// lane, turns the output sizes into offsets with a wave scan + decoupled look-back
+// (sub-tile granularity), assembles the output rows in LDS and flushes them with
+// coalesced 16-byte stores.  The transition tables are read through the vector
+// cache (they are consulted only on the few bytes that leave the idle state).
+// A sub-tile that does not fit the staging buffers, or a look-back that times out,
+// raises *a.error: the host then recomputes the column with the two-pass kernels.
+template <bool IN_LDS>
+__global__ void __launch_bounds__(256) k_tdfa_replace_tile(TileArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  uint8_t* base = reinterpret_cast<uint8_t*>(smem);
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  uint8_t* lds_in = base + a.tbl_bytes + (size_t)wv * (a.cap_in + a.cap_out + 64);
+  uint8_t* lds_out = lds_in + a.cap_in + 32;
+  const TCtx c = tsetup<IN_LDS>(a.L, a.flags, smem);  // (block barrier inside when staging)
+  const cstd::View& D = c.D;
+  const csvm::ProgView& P = c.P;
+  const ColView& in = a.in;
+  const int rb = a.rb;
+  constexpr int kSub = 64;
+  const long long sub = (long long)blockIdx.x * 4 + wv;
+  const long long r0 = sub * kSub;
+  if (r0 >= in.rows) return;
+  const int nrows = (int)min((long long)kSub, in.rows - r0);
+  const long long o0 = in.offsets[r0 + min(lane, nrows)];
+  const long long o1 = in.offsets[r0 + min(lane + 1, nrows)];
+  const long long g0 = __shfl(o0, 0, 64), g1 = __shfl(o1, 63, 64);
+  const bool live = lane < nrows && row_is_valid(in.validity, r0 + lane);
+  const int rbeg = (int)(o0 - g0);
+  const int n = live ? (int)(o1 - o0) : 0;
+  bool bad = (g1 - g0) + 16 > a.cap_in;
+  int lead = 0;
+  if (!bad && !(a.debug & 16)) {
+    lead = (int)((uintptr_t)(in.chars + g0) & 15);
+    const uint8_t* src = in.chars + (g0 - lead);  // 16-byte aligned
+    const int span = (int)(g1 - g0) + lead;
+    for (int i = lane * 16; i < span; i += 64 * 16)
+      *reinterpret_cast<uint4*>(lds_in + i) = *reinterpret_cast<const uint4*>(src + i);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+  int rec_mb[kMaxRec], rec_me[kMaxRec], rec_reps[kMaxRec];
+  int nm = 0;
+  int out_len = 0;
+  if (live && !bad) {
+    if (a.debug & 1) {
+      out_len = n;
+    } else {
+      cstd::Tdfa vm(D, P, lds_in + lead + rbeg, n, (lead + rbeg) & 3);
+      out_len = tile_row_size(vm, n, rb, a.maxrepl, [&](int mb, int me, int reps) {
+#pragma unroll
+        for (int j = 0; j < kMaxRec; ++j)
+          if (nm == j) {
+            rec_mb[j] = mb;
+            rec_me[j] = me;
+            rec_reps[j] = reps;
+          }
+        ++nm;
+      });
+    }
+  }
+  bad |= __any(nm > kMaxRec);
+  // sub-tile scan (wave-wide) and look-back
+  const int incl = csdev::wave_inclusive_scan(out_len);
+  const int lo = incl - out_len;
+  const int total = __builtin_amdgcn_readlane(incl, 63);
+  bad |= total + 32 > a.cap_out;
+  long long gb = (a.debug & 8) ? sub * 4096 : cstile::lookback(a.status, 1, sub, total);
+  if (gb < 0) {
+    bad = true;
+    gb = 0;
+  }
+  if (bad) {
+    if (lane == 0) atomicOr(a.error, 1u);
+    return;
+  }
+  if (lane < nrows) a.out_off[r0 + lane] = gb + lo;
+  if (lane == nrows - 1 && r0 + nrows == in.rows) a.out_off[in.rows] = gb + lo + out_len;
+  uint8_t* gdst = a.out_chars + gb;
+  const int olead = (int)((uintptr_t)gdst & 15);
+  if (live && !(a.debug & 2)) {
+    int oi = olead + lo;         // byte index into lds_out
+    const int pi = lead + rbeg;  // byte index of the row in lds_in
+    int copied = 0;
+#pragma unroll
+    for (int j = 0; j < kMaxRec; ++j)
+      if (j < nm) {
+        cstile::lds_copy(lds_out, oi, lds_in, pi + copied, rec_mb[j] - copied);
+        oi += rec_mb[j] - copied;
+        for (int k = 0; k < rec_reps[j]; ++k)
+          for (int i = 0; i < rb; ++i) lds_out[oi++] = a.repl[i];
+        copied = rec_me[j];
+      }
+    cstile::lds_copy(lds_out, oi, lds_in, pi + copied, n - copied);
+  }
+  if (!(a.debug & 4)) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    uint8_t* a0 = gdst - olead;
+    const int end = olead + total;
+    for (int i = lane * 16; i < end; i += 64 * 16) {
+      if (i >= olead && i + 16 <= end) {
+        *reinterpret_cast<uint4*>(a0 + i) = *reinterpret_cast<const uint4*>(lds_out + i);
+      } else {
+        for (int k = 0; k < 16; ++k) {
+          int j = i + k;
+          if (j >= olead && j < end) a0[j] = lds_out[j];
+        }
+      }
+    }
+  }
+}
+
+struct TPlan {
+  TLaunch d;
+  size_t lds_bytes;
+  unsigned grid;
+};
+bool use_tdfa(const cs_regex* re) { return !re->tdfa.empty() && !getenv("CS_REGEX_NO_TDFA"); }
+void upload(cs_regex* re, hipStream_t s) {
   if (!re->d_image) {
     re->d_image = dev_alloc(re->image.size() * 4, s);
     CS_HIP(hipMemcpyAsync(re->d_image->p, re->image.data(), re->image.size() * 4, hipMemcpyHostToDevice, s));
+    if (!re->tdfa.empty()) {
+      re->d_tdfa = dev_alloc(re->tdfa.size() * 4, s);
+      CS_HIP(hipMemcpyAsync(re->d_tdfa->p, re->tdfa.data(), re->tdfa.size() * 4, hipMemcpyHostToDevice, s));
+    }
     CS_HIP(hipStreamSynchronize(s));
   }
+}
+TPlan tplan(cs_regex* re, int64_t rows, hipStream_t s) {
+  require_device();
+  upload(re, s);
+  TPlan pl{};
+  pl.d.tdfa = ptr<const int32_t>(re->d_tdfa);
+  pl.d.tdfa_words = (int)re->tdfa.size();
+  pl.d.image = ptr<const int32_t>(re->d_image);
+  pl.d.in_lds = re->tdfa.size() * 4 <= kLdsBudget;
+  pl.lds_bytes = pl.d.in_lds ? ((re->tdfa.size() * 4 + 15) & ~size_t(15)) : 0;
+  int64_t nblk = (rows + 255) / 256;
+  pl.grid = (unsigned)std::min<int64_t>(std::max<int64_t>(nblk, 1), 256 * 8);
+  return pl;
+}
+
+Plan plan(cs_regex* re, int64_t rows, hipStream_t s) {
+  require_device();
+  upload(re, s);
   Plan pl{};
   Launch& L = pl.d;
   L.image = ptr<const int32_t>(re->d_image);
@@ -203,7 +482,11 @@ void scan(const cs_column* col, cs_regex* re, uint8_t* out8, int32_t* out32, int
           int64_t* found, const char* name) {
   if (found) *found = 0;
   if (col->rows == 0) return;
-  Plan pl = plan(re, col->rows, s);
+  const bool tdfa = use_tdfa(re);
+  Plan pl{};
+  TPlan tp{};
+  if (tdfa) tp = tplan(re, col->rows, s);
+  else pl = plan(re, col->rows, s);
   const size_t esz = MODE == 2 ? 4 : 1;
   void* host_out = MODE == 2 ? (void*)out32 : (void*)out8;
   Buf tmp;
@@ -217,7 +500,14 @@ void scan(const cs_column* col, cs_regex* re, uint8_t* out8, int32_t* out32, int
   RowSrc src{view_of(col), d_unicode_flags()};
   {
     ProfScope ps(name, s);
-    if (pl.small)
+    if (tdfa)
+      if (tp.d.in_lds)
+        hipLaunchKernelGGL((k_tdfa_scan<MODE, true>), dim3(tp.grid), dim3(256), tp.lds_bytes, s, src, tp.d, out8, out32,
+                           ptr<unsigned long long>(cnt));
+      else
+        hipLaunchKernelGGL((k_tdfa_scan<MODE, false>), dim3(tp.grid), dim3(256), 0, s, src, tp.d, out8, out32,
+                           ptr<unsigned long long>(cnt));
+    else if (pl.small)
       hipLaunchKernelGGL((k_regex_scan<true, MODE>), dim3(pl.grid), dim3(pl.threads), pl.lds_bytes, s, src, pl.d, out8,
                          out32, ptr<unsigned long long>(cnt));
     else
@@ -246,6 +536,7 @@ int cs_regex_compile(const char* pattern, cs_regex** out) {
     re->prog = csrx::compile(pattern);
     re->blob = re->prog.to_blob();
     re->image = re->prog.to_device_image(h_unicode_flags());
+    re->tdfa = csrx::build_tdfa(re->prog, re->image, h_unicode_flags());
     *out = re;
   });
 }
@@ -307,17 +598,82 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
     const int rb = (int)strlen(repl);
     Buf d_repl = dev_alloc((size_t)rb + 1, s);
     CS_HIP(hipMemcpyAsync(d_repl->p, repl, (size_t)rb + 1, hipMemcpyHostToDevice, s));
-    Plan pl = plan(re, col->rows, s);
+    const bool tdfa = use_tdfa(re);
+    Plan pl{};
+    TPlan tp{};
+    if (tdfa) tp = tplan(re, col->rows, s);
+    else pl = plan(re, col->rows, s);
     RowSrc src{view_of(col), d_unicode_flags()};
     auto* o = new cs_column;
     std::unique_ptr<cs_column> holder(o);
     o->rows = col->rows;
     o->validity = col->validity;
     o->null_count = col->null_count;
+    const int minlen = tdfa ? re->tdfa[13] : 0;
+    if (tdfa && rb <= minlen && !getenv("CS_REGEX_TWO_PASS")) {
+      // single pass: the output cannot outgrow the input (each match is at least
+      // `minlen` bytes, the replacement at most that) -> allocate at the input size
+      const int64_t rows = col->rows;
+      const int64_t ntiles = (rows + cstile::kTileRows - 1) / cstile::kTileRows;
+      const int64_t nsub = ntiles * 4;
+      const int64_t span = max_span64(col, s);
+      const int cap = (int)((span + 15 + 32 + 127) & ~(int64_t)127);
+      const size_t tbl = tp.d.in_lds ? tp.lds_bytes : 0;
+      const size_t lds = tbl + (size_t)(2 * cap + 64) * 4 + 16;
+      if (lds <= 150 * 1024) {
+        TileArgs ta{};
+        ta.in = view_of(col);
+        ta.flags = d_unicode_flags();
+        ta.L = tp.d;
+        ta.repl = ptr<const uint8_t>(d_repl);
+        ta.rb = rb;
+        ta.maxrepl = maxrepl;
+        Buf out_off = dev_alloc(sizeof(int64_t) * (rows + 1), s);
+        Buf out_chars = dev_alloc((size_t)col->nbytes + 64, s);
+        ta.out_off = ptr<int64_t>(out_off);
+        ta.out_chars = ptr<uint8_t>(out_chars);
+        Buf status = dev_alloc(sizeof(cstile::u64) * nsub + 16, s);
+        CS_HIP(hipMemsetAsync(status->p, 0, sizeof(cstile::u64) * nsub + 16, s));
+        ta.status = ptr<cstile::u64>(status);
+        ta.error = reinterpret_cast<unsigned*>(ptr<cstile::u64>(status) + nsub);
+        ta.ntiles = ntiles;
+        ta.cap_in = cap;
+        ta.cap_out = cap;
+        ta.tbl_bytes = (int)tbl;
+        ta.debug = getenv("CS_TILE_DEBUG") ? atoi(getenv("CS_TILE_DEBUG")) : 0;
+        auto kern = tp.d.in_lds ? &k_tdfa_replace_tile<true> : &k_tdfa_replace_tile<false>;
+        if (lds > 48 * 1024)
+          CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)lds));
+        {
+          ProfScope ps("k_replace_re", s);
+          hipLaunchKernelGGL(kern, dim3((unsigned)ntiles), dim3(256), lds, s, ta);
+        }
+        CS_HIP(hipGetLastError());
+        int64_t* host = (int64_t*)pinned_scratch(16);
+        CS_HIP(hipMemcpyAsync(host, ptr<int64_t>(out_off) + rows, 8, hipMemcpyDeviceToHost, s));
+        CS_HIP(hipMemcpyAsync(host + 1, ta.error, 4, hipMemcpyDeviceToHost, s));
+        CS_HIP(hipStreamSynchronize(s));
+        if ((uint32_t)host[1] == 0 || ta.debug) {
+          o->offsets = out_off;
+          o->chars = out_chars;
+          o->nbytes = host[0];
+          *out = holder.release();
+          return;
+        }
+      }
+      // an oversize sub-tile or a look-back timeout: fall through to the two-pass kernels
+    }
     Buf lens = dev_alloc(sizeof(int32_t) * col->rows, s);
     {
       ProfScope ps("k_replace_re_size", s);
-      if (pl.small)
+      if (tdfa && tp.d.in_lds)
+        hipLaunchKernelGGL(k_tdfa_replace_size<true>, dim3(tp.grid), dim3(256), tp.lds_bytes, s, src, tp.d, rb, maxrepl,
+                           ptr<int32_t>(lens));
+      else if (tdfa)
+        hipLaunchKernelGGL(k_tdfa_replace_size<false>, dim3(tp.grid), dim3(256), 0, s, src, tp.d, rb, maxrepl,
+                           ptr<int32_t>(lens));
+      else if (pl.small)
         hipLaunchKernelGGL((k_replace_re_size<true>), dim3(pl.grid), dim3(pl.threads), pl.lds_bytes, s, src, pl.d, rb,
                            maxrepl, ptr<int32_t>(lens));
       else
@@ -330,7 +686,13 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
     o->chars = dev_alloc((size_t)o->nbytes, s);
     {
       ProfScope ps("k_replace_re_write", s);
-      if (pl.small)
+      if (tdfa && tp.d.in_lds)
+        hipLaunchKernelGGL(k_tdfa_replace_write<true>, dim3(tp.grid), dim3(256), tp.lds_bytes, s, src, tp.d,
+                           ptr<const uint8_t>(d_repl), rb, maxrepl, o->d_offsets(), ptr<uint8_t>(o->chars));
+      else if (tdfa)
+        hipLaunchKernelGGL(k_tdfa_replace_write<false>, dim3(tp.grid), dim3(256), 0, s, src, tp.d,
+                           ptr<const uint8_t>(d_repl), rb, maxrepl, o->d_offsets(), ptr<uint8_t>(o->chars));
+      else if (pl.small)
         hipLaunchKernelGGL((k_replace_re_write<true>), dim3(pl.grid), dim3(pl.threads), pl.lds_bytes, s, src, pl.d,
                            ptr<const uint8_t>(d_repl), rb, maxrepl, o->d_offsets(), ptr<uint8_t>(o->chars));
       else

@@ -385,6 +385,58 @@ std::vector<int32_t> build_tdfa(const Program& prog, const std::vector<int32_t>&
     cat[c >> 2] |= v << (8 * (c & 3));
   }
   img[14] = append(cat, 32);
+  // idle-state skip data (regex_tdfa.h header words 16..28)
+  {
+    // INIT[RESTART][*] were interned first: ids 0..nskip-1
+    uint32_t nskip = 0;
+    for (int c = 0; c < 8; ++c) nskip = std::max(nskip, init[cstd::MODE_RESTART * 8 + c] + 1);
+    bool ok = true;
+    for (uint32_t s = 0; s < nskip; ++s) ok &= states[s].kernel.empty() && states[s].mode == cstd::MODE_RESTART;
+    if (!ok) nskip = 0;
+    img[16] = (int32_t)nskip;
+    for (int c = 0; c < 4; ++c) img[17 + c] = (int32_t)init[cstd::MODE_RESTART * 8 + c];
+    uint32_t cand[4] = {~0u, ~0u, ~0u, ~0u}, wordbm[4] = {0, 0, 0, 0};
+    for (unsigned c = 1; c < 128; ++c) {
+      const Atom& a = B.atoms[B.ascii_atom[c]];
+      const unsigned catc = (B.use_word && a.isword ? 1u : 0u) | (B.use_line && a.isnl ? 2u : 0u);
+      if (B.use_word && a.isword) wordbm[c >> 5] |= 1u << (c & 31);
+      bool skippable = nskip > 0;
+      for (uint32_t s = 0; s < nskip && skippable; ++s) {
+        uint32_t e = t1[(size_t)s * 128 + c];
+        skippable = !(e & (cstd::E_STOP | cstd::E_MATCH | cstd::E_COMPLEX)) && cstd::e_keep(e) == 15u &&
+                    (e & cstd::E_STATE) == init[cstd::MODE_RESTART * 8 + catc];
+      }
+      if (skippable) cand[c >> 5] &= ~(1u << (c & 31));
+    }
+    for (int k = 0; k < 4; ++k) {
+      img[21 + k] = (int32_t)cand[k];
+      img[25 + k] = (int32_t)wordbm[k];
+    }
+    // two ranges covering the candidate bytes 1..127: split at the widest gap
+    std::vector<int> cs;
+    for (int c = 1; c < 128; ++c)
+      if ((cand[c >> 5] >> (c & 31)) & 1u) cs.push_back(c);
+    int lo1 = 1, hi1 = 0, lo2 = 1, hi2 = 0;  // empty ranges
+    if (!cs.empty()) {
+      size_t cut = 0;
+      int gap = 0;
+      for (size_t i = 0; i + 1 < cs.size(); ++i)
+        if (cs[i + 1] - cs[i] > gap) {
+          gap = cs[i + 1] - cs[i];
+          cut = i;
+        }
+      lo1 = cs.front();
+      if (gap > 1) {
+        hi1 = cs[cut];
+        lo2 = cs[cut + 1];
+        hi2 = cs.back();
+      } else {
+        hi1 = cs.back();
+      }
+    }
+    img[29] = lo1 | (hi1 << 8);
+    img[30] = lo2 | (hi2 << 8);
+  }
   img[15] = (int32_t)img.size();
   return img;
 }

@@ -10,7 +10,7 @@
 // lower-priority threads on END and the stop of start-seeding after the first
 // match.  Each transition also says where every surviving thread came from
 // (an old slot or "new thread at this position"), which lets the executor carry
-// the threads' START offsets in up to 8 registers: match spans come out
+// the threads' START offsets in up to 4 registers: match spans come out
 // identical to the list simulation.  Programs that need more than kMaxSlots
 // simultaneous threads, more than kMaxStates states or more than 62 distinct
 // character predicates are not converted (the caller keeps the list simulator).
@@ -20,6 +20,12 @@
 //   [5] uses (bit0 word-category, bit1 line-category) [6] off INIT [7] off T1
 //   [8] off T2 [9] off preds [10] off atomsig [11] off ACT [12] max slots
 //   [13] min match chars [14] off CAT [15] total words
+//   [16] nskip: states 0..nskip-1 are "idle" (no live thread, seeding on)
+//   [17..20] idle state to continue in after skipping a byte of category c (0..3)
+//   [21..24] candidate bitmap: ASCII bytes that must go through the table when idle
+//   [25..28] word-character bitmap of the ASCII bytes (category bit 0)
+//   [29] [30] two byte ranges (lo | hi << 8) that cover every candidate ASCII byte
+//        (a superset is fine: extra candidates just take the table path)
 //   INIT   : 3 modes x 8 categories state ids
 //   T1     : nstates x 128 entries (ASCII byte -> transition; byte 0 = embedded NUL)
 //   T2     : nstates x natoms entries (atom 0 = end of row, 1 = embedded NUL,
@@ -32,6 +38,7 @@
 //   [9:0] next state  [10] STOP  [11] MATCH  [15:12] match origin (0-7 slot, 15 = new)
 //   [19:16] keep (slots j >= keep start at this position; 15 = unchanged)
 //   [20] COMPLEX (origins in ACT[entry >> 21], 4 bits per slot, 15 = new)
+// (slot fields are 4 bits wide although kMaxSlots is 4: room to grow)
 #pragma once
 #include <stdint.h>
 
@@ -42,9 +49,9 @@
 namespace cstd {
 
 constexpr int32_t kMagic = 0x44545343;  // "CSTD"
-constexpr int kMaxSlots = 8;
+constexpr int kMaxSlots = 4;
 constexpr int kMaxStates = 512;
-constexpr int kHeaderWords = 16;
+constexpr int kHeaderWords = 32;
 enum { MODE_RESTART = 0, MODE_NORESTART = 1, MODE_SEED_ONCE = 2 };
 enum { ATOM_EOT = 0, ATOM_NUL = 1, ATOM_FIRST_CLASS = 2 };
 enum { P_CHAR = 0, P_ANY = 1, P_ANYNL = 2, P_CCLASS = 3, P_NCCLASS = 4, P_ISNL = 5, P_ISWORD = 6 };
@@ -64,6 +71,10 @@ struct View {
   const uint32_t* atomsig;
   const uint32_t* act;
   int nstates, natoms, npreds, nna, uses;
+  uint32_t nskip;
+  // scalars, not arrays: an array member would force the whole view into memory
+  uint32_t r1lo, r1hi, r2lo, r2hi;  // SWAR constants of the two candidate ranges
+  uint32_t skippack, cand0, cand1, cand2, cand3, word0, word1, word2, word3;
 };
 CS_HD View make_view(const int32_t* img) {
   View v;
@@ -80,6 +91,26 @@ CS_HD View make_view(const int32_t* img) {
   v.atomsig = (const uint32_t*)(img + img[10]);
   v.act = (const uint32_t*)(img + img[11]);
   v.cat = (const uint32_t*)(img + img[14]);
+  v.nskip = (uint32_t)img[16];
+  // idle state per category, 8 bits each (idle states have ids < 8)
+  v.skippack = ((uint32_t)img[17] & 255u) | (((uint32_t)img[18] & 255u) << 8) | (((uint32_t)img[19] & 255u) << 16) |
+               (((uint32_t)img[20] & 255u) << 24);
+  v.cand0 = (uint32_t)img[21];
+  v.cand1 = (uint32_t)img[22];
+  v.cand2 = (uint32_t)img[23];
+  v.cand3 = (uint32_t)img[24];
+  v.word0 = (uint32_t)img[25];
+  v.word1 = (uint32_t)img[26];
+  v.word2 = (uint32_t)img[27];
+  v.word3 = (uint32_t)img[28];
+  {
+    const uint32_t lo1 = (uint32_t)img[29] & 255u, hi1 = ((uint32_t)img[29] >> 8) & 255u;
+    const uint32_t lo2 = (uint32_t)img[30] & 255u, hi2 = ((uint32_t)img[30] >> 8) & 255u;
+    v.r1lo = (0x80u - lo1) * 0x01010101u;
+    v.r1hi = (0x7Fu - hi1) * 0x01010101u;
+    v.r2lo = (0x80u - lo2) * 0x01010101u;
+    v.r2hi = (0x7Fu - hi2) * 0x01010101u;
+  }
   return v;
 }
 
@@ -91,8 +122,10 @@ struct Tdfa {
   const csvm::ProgView& P;
   const uint8_t* s;
   int n;
+  int sa;  // (address of s) & 3: lets byte_at() use aligned 32-bit loads without pointer<->integer casts
 
-  CS_HD Tdfa(const View& d, const csvm::ProgView& p, const uint8_t* row, int bytes) : D(d), P(p), s(row), n(bytes) {}
+  CS_HD Tdfa(const View& d, const csvm::ProgView& p, const uint8_t* row, int bytes, int align_phase = -1)
+      : D(d), P(p), s(row), n(bytes), sa(align_phase < 0 ? (int)((uintptr_t)row & 3) : align_phase) {}
 
   CS_HD csrow::Char char_at(int i, unsigned& w) const {
     if (i >= n) {
@@ -142,32 +175,22 @@ struct Tdfa {
     return (int)D.atomsig[2];  // unreachable for a complete atom table
   }
 
+  static CS_HD uint32_t bm128(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, unsigned b) {
+    uint32_t lo = (b & 32u) ? w1 : w0, hi = (b & 32u) ? w3 : w2;
+    return (((b & 64u) ? hi : lo) >> (b & 31u)) & 1u;
+  }
   // Leftmost-first match whose start lies in [from, win_end); win_end is either
   // the row length (search) or from + 1 (anchored), as in the row drivers.
   CS_HD int find(int from, int win_end, int& mb, int& me) {
     const int mode = (win_end == from + 1) ? MODE_SEED_ONCE : MODE_RESTART;
-    uint32_t state = D.init[mode * 8 + prev_cat(from)];
+    uint32_t state = D.init[mode * 8 + (D.uses ? prev_cat(from) : 0u)];
     int st[kMaxSlots];
 #pragma unroll
     for (int j = 0; j < kMaxSlots; ++j) st[j] = from;
     int matched = 0;
     int pos = from;
-    for (;;) {
-      uint32_t e;
-      int w = 1;
-      if (pos >= n) {
-        e = D.t2[state * D.natoms + ATOM_EOT];
-      } else {
-        uint8_t b = s[pos];
-        if (b < 128) {
-          e = D.t1[state * 128 + b];
-        } else {
-          unsigned uw;
-          csrow::Char c = char_at(pos, uw);
-          w = (int)uw;
-          e = D.t2[state * D.natoms + nonascii_atom(c)];
-        }
-      }
+    // applies transition `e` taken at `pos`; returns true when the automaton stops
+    auto apply = [&](uint32_t e) -> bool {
       if (e & E_MATCH) {
         uint32_t o = e_match_origin(e);
         int v = pos;
@@ -200,15 +223,243 @@ struct Tdfa {
             if ((uint32_t)j >= keep) st[j] = pos;
         }
       }
-      if (e & E_STOP) break;
       state = e & E_STATE;
+      return (e & E_STOP) != 0;
+    };
+    // one input byte at `pos` (< n); returns true when the automaton stops
+    auto feed = [&](uint8_t b) -> bool {
+      if (state < D.nskip && b < 128 && !bm128(D.cand0, D.cand1, D.cand2, D.cand3, b)) {
+        // idle and this byte cannot start a match: stay idle, no table access
+        unsigned cat = 0;
+        if (D.uses & 1) cat |= bm128(D.word0, D.word1, D.word2, D.word3, b);
+        if (D.uses & 2) cat |= (b == '\n') ? 2u : 0u;
+        state = (D.skippack >> (8 * cat)) & 255u;
+        ++pos;
+        return false;
+      }
+      int w = 1;
+      uint32_t e;
+      if (b < 128) {
+        e = D.t1[state * 128 + b];
+      } else {
+        unsigned uw;
+        csrow::Char c = char_at(pos, uw);
+        w = (int)uw;
+        e = D.t2[state * D.natoms + nonascii_atom(c)];
+      }
+      if (apply(e)) return true;
       pos += w;
+      return false;
+    };
+#if defined(__HIP_DEVICE_COMPILE__)
+    // the row is read through aligned 32-bit words; the word is re-read only when
+    // the scan crosses into the next one
+    const uint32_t* words = reinterpret_cast<const uint32_t*>(s - sa);
+    bool stop = false;
+    int widx = -1;
+    uint32_t word = 0;
+    while (!stop && pos < n) {
+      const int j = pos + sa;
+      if ((j >> 2) != widx) {
+        widx = j >> 2;
+        word = words[widx];
+      }
+      stop = feed((uint8_t)(word >> (8 * (j & 3))));
     }
+    if (!stop) apply(D.t2[state * D.natoms + ATOM_EOT]);
+#else
+    bool stop = false;
+    while (!stop && pos < n) stop = feed(s[pos]);
+    if (!stop) apply(D.t2[state * D.natoms + ATOM_EOT]);
+#endif
     return matched;
+  }
+
+  // ---- flat scan: all successive matches of a row in ONE loop ------------------
+  // (the SIMT-friendly form of the row drivers in regex_vm.h: lanes that are in
+  // different find() rounds still share the loop body, and idle stretches are
+  // skipped a 32-bit word at a time)
+  enum { K_CONTAINS = 0, K_MATCH = 1, K_COUNT = 2, K_REPLACE = 3 };
+
+  // aligned 32-bit word `widx` of the row's storage; bytes outside the row may be anything
+  CS_HD uint32_t load_word(int widx) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return reinterpret_cast<const uint32_t*>(s - sa)[widx];
+#else
+    uint32_t w = 0;
+    for (int k = 0; k < 4; ++k) {
+      int i = widx * 4 + k - sa;
+      w |= (uint32_t)((i >= 0 && i < n) ? s[i] : 0xFFu) << (8 * k);
+    }
+    return w;
+#endif
+  }
+  // bit 7 of each byte lane set when that byte may leave the idle state
+  CS_HD uint32_t cand_mask(uint32_t w) const {
+    const uint32_t x = w & 0x7F7F7F7Fu;
+    uint32_t m = w | ((w - 0x01010101u) & ~w);                 // non-ASCII, NUL (conservative)
+    m |= (x + D.r1lo) & ~(x + D.r1hi);
+    m |= (x + D.r2lo) & ~(x + D.r2hi);
+    return m & 0x80808080u;
+  }
+  static CS_HD int ctz32(uint32_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_ctz(v);
+#else
+    int k = 0;
+    while (!(v & 1u)) {
+      v >>= 1;
+      ++k;
+    }
+    return k;
+#endif
+  }
+
+  // emit(mb, me, reps) per match (K_REPLACE: reps > 1 for the zero-length repeat);
+  // returns the number of matches (K_CONTAINS / K_MATCH: 0 or 1).
+  template <int KIND, class Emit>
+  CS_HD int scan(int maxrepl, Emit&& emit) {
+    int from = 0, pos = 0, done = 0;
+    int mb = 0, me = 0, matched = 0;
+    int st[kMaxSlots];
+#pragma unroll
+    for (int j = 0; j < kMaxSlots; ++j) st[j] = 0;
+    uint32_t state = D.init[(KIND == K_MATCH ? MODE_SEED_ONCE : MODE_RESTART) * 8 + 4];  // row start
+    for (;;) {
+      // ---- idle: jump to the next candidate byte
+      if (state < D.nskip && pos < n) {
+        const int entry = pos;
+        do {
+          const int j = pos + sa;
+          const uint32_t m = cand_mask(load_word(j >> 2)) & (0xFFFFFFFFu << (8 * (j & 3)));
+          if (m) {
+            pos = (j & ~3) - sa + (ctz32(m) >> 3);
+            break;
+          }
+          pos = (j & ~3) + 4 - sa;
+        } while (pos < n);
+        if (pos > n) pos = n;
+        if (D.uses && pos > entry) {
+          const int j = pos - 1 + sa;
+          const unsigned b = (load_word(j >> 2) >> (8 * (j & 3))) & 255u;
+          unsigned cat = 0;
+          if (b < 128) {
+            if (D.uses & 1) cat |= bm128(D.word0, D.word1, D.word2, D.word3, b);
+            if (D.uses & 2) cat |= (b == '\n') ? 2u : 0u;
+          } else {
+            cat = prev_cat(pos) & 3u;  // multi-byte character before pos
+          }
+          state = (D.skippack >> (8 * cat)) & 255u;
+        }
+      }
+      // ---- one transition at pos
+      uint32_t e;
+      int w = 1;
+      if (pos >= n) {
+        e = D.t2[state * D.natoms + ATOM_EOT];
+      } else {
+        const int j = pos + sa;
+        const unsigned b = (load_word(j >> 2) >> (8 * (j & 3))) & 255u;
+        if (b < 128) {
+          e = D.t1[state * 128 + b];
+        } else {
+          unsigned uw;
+          csrow::Char c = char_at(pos, uw);
+          w = (int)uw;
+          e = D.t2[state * D.natoms + nonascii_atom(c)];
+        }
+      }
+      if (e & E_MATCH) {
+        const uint32_t o = e_match_origin(e);
+        int v = pos;
+#pragma unroll
+        for (int j = 0; j < kMaxSlots; ++j)
+          if (o == (uint32_t)j) v = st[j];
+        mb = v;
+        me = pos;
+        matched = 1;
+      }
+      if (e & E_COMPLEX) {
+        const uint32_t og = D.act[e >> 21];
+        int nst[kMaxSlots];
+#pragma unroll
+        for (int j = 0; j < kMaxSlots; ++j) {
+          const uint32_t o = (og >> (4 * j)) & 15u;
+          int v = pos;
+#pragma unroll
+          for (int i = 0; i < kMaxSlots; ++i)
+            if (o == (uint32_t)i) v = st[i];
+          nst[j] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < kMaxSlots; ++j) st[j] = nst[j];
+      } else {
+        const uint32_t keep = e_keep(e);
+        if (keep != 15u) {
+#pragma unroll
+          for (int j = 0; j < kMaxSlots; ++j)
+            if ((uint32_t)j >= keep) st[j] = pos;
+        }
+      }
+      if (!(e & E_STOP)) {
+        state = e & E_STATE;
+        pos += w;
+        continue;
+      }
+      // ---- this find() round is over
+      if (!matched) return done;
+      if (KIND == K_CONTAINS || KIND == K_MATCH) return 1;
+      if (KIND == K_COUNT) {
+        ++done;
+        if (me > mb) {
+          from = me;
+        } else {  // empty match: step one character (count.cu:190-196)
+          unsigned uw;
+          char_at(mb, uw);
+          from = mb + (int)uw;
+        }
+        if (from > n) return done;
+      } else {
+        if (me == mb && mb == from) {
+          // a zero-length match does not advance the search (replace.cu:91-93):
+          // the same match repeats until the budget is spent
+          const int left = (maxrepl < 0 ? csrow::count_chars(s, n) : maxrepl) - done;
+          if (left > 0) emit(mb, me, left);
+          return done + (left > 0 ? left : 0);
+        }
+        emit(mb, me, 1);
+        ++done;
+        if (maxrepl >= 0 && done >= maxrepl) return done;
+        from = me;
+      }
+      // next round starts at `from`
+      pos = from;
+      matched = 0;
+#pragma unroll
+      for (int j = 0; j < kMaxSlots; ++j) st[j] = from;
+      state = D.init[MODE_RESTART * 8 + (D.uses ? prev_cat(from) : 0u)];
+    }
   }
 };
 
 }  // namespace cstd
+
+// Row drivers for the tagged DFA: same contracts as the templates in regex_vm.h
+// (overloads, so call sites are engine-agnostic).
+namespace csvm {
+CS_HD int row_contains_re(cstd::Tdfa& vm, bool anchored) {
+  auto none = [](int, int, int) {};
+  return anchored ? vm.scan<cstd::Tdfa::K_MATCH>(0, none) : vm.scan<cstd::Tdfa::K_CONTAINS>(0, none);
+}
+CS_HD int row_count_re(cstd::Tdfa& vm) {
+  return vm.scan<cstd::Tdfa::K_COUNT>(0, [](int, int, int) {});
+}
+template <class Emit>
+CS_HD void row_replace_matches(cstd::Tdfa& vm, int maxrepl, Emit&& emit) {
+  if (maxrepl == 0) return;
+  vm.scan<cstd::Tdfa::K_REPLACE>(maxrepl, emit);
+}
+}  // namespace csvm
 
 namespace csrx {
 struct Program;

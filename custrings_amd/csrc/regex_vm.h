@@ -295,20 +295,26 @@ CS_HD int row_count_re(VM& vm) {
 // replacement, `reps` identical zero-length replacements are reported at once.
 template <class VM, class Emit>
 CS_HD void row_replace_matches(VM& vm, int maxrepl, Emit&& emit) {
-  int left = maxrepl < 0 ? csrow::count_chars(vm.s, vm.n) : maxrepl;
+  // maxrepl < 0 means "up to nchars replacements" (replace.cu:66-67).  Every
+  // non-empty match consumes at least one character, so that budget can only
+  // bind on a zero-length match (after nchars advancing matches the row is used
+  // up and find() fails by itself); the character count is therefore taken lazily.
+  int done = 0;
   int from = 0;
-  while (left > 0) {
+  for (;;) {
+    if (maxrepl >= 0 && done >= maxrepl) break;
     int mb, me;
     if (!vm.find(from, vm.n, mb, me)) break;
     if (me == mb && mb == from) {
       // a zero-length match does not advance the search (replace.cu:91-93):
       // the same match repeats until the budget is spent
-      emit(mb, me, left);
+      int left = (maxrepl < 0 ? csrow::count_chars(vm.s, vm.n) : maxrepl) - done;
+      if (left > 0) emit(mb, me, left);
       return;
     }
     emit(mb, me, 1);
     from = me;
-    --left;
+    ++done;
   }
 }
 

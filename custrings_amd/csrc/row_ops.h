@@ -19,6 +19,7 @@
 #include <stdint.h>
 
 #if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
 #define CS_HD __host__ __device__ __forceinline__
 #else
 #define CS_HD inline

@@ -1,0 +1,141 @@
+// Row-tile machinery shared by the single-pass kernels (device only).
+//
+// A workgroup of 256 threads owns a TILE of 256 consecutive rows at a time:
+//   1. the tile's contiguous span of the chars buffer is staged into LDS with
+//      coalesced 16-byte loads (every input byte crosses HBM once);
+//   2. each thread runs the per-row logic on its row out of LDS;
+//   3. output sizes become offsets by a workgroup scan + a decoupled look-back
+//      across tiles (one pass over the data, no separate size kernel);
+//   4. the rows' outputs -- contiguous in the output buffer, because the rows
+//      are consecutive -- are assembled in LDS and flushed with coalesced
+//      16-byte stores.
+// Tiles are handed out by an atomic ticket, so a tile only ever waits for tiles
+// that have already started (forward progress without assuming dispatch order).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "device_utils.h"
+
+namespace cstile {
+
+constexpr int kTileRows = 256;
+constexpr unsigned long long kFlagAgg = 1ull << 62, kFlagInc = 2ull << 62, kValMask = (1ull << 62) - 1;
+
+typedef unsigned long long u64;
+
+__device__ __forceinline__ u64 status_load(const u64* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void status_store(u64* p, u64 v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Decoupled look-back, run by ONE wave (all 64 lanes).  `status` has one word
+// per tile (stride `stride` words between consecutive tiles), zeroed before the
+// launch.  Publishes this tile's aggregate, then its inclusive prefix; returns
+// the exclusive prefix (sum of the aggregates of all earlier tiles).
+// Spins are bounded: after ~kSpinLimit polls without progress the function gives
+// up and returns -1 (the caller raises an error flag; the host then recomputes
+// the column with the two-pass kernels).
+constexpr int kSpinLimit = 1 << 22;
+__device__ __forceinline__ long long lookback(u64* status, long long stride, long long tile, long long aggregate) {
+  const int lane = threadIdx.x & 63;
+  u64* mine = status + tile * stride;
+  if (tile == 0) {
+    if (lane == 0) status_store(mine, kFlagInc | ((u64)aggregate & kValMask));
+    return 0;
+  }
+  if (lane == 0) status_store(mine, kFlagAgg | ((u64)aggregate & kValMask));
+  long long excl = 0;
+  long long t = tile - 1;
+  int spins = 0;
+  for (;;) {
+    long long idx = t - lane;
+    u64 v = idx >= 0 ? status_load(status + idx * stride) : kFlagInc;
+    unsigned flag = (unsigned)(v >> 62);
+    u64 not_ready = __ballot(flag == 0);
+    u64 inc = __ballot(flag == 2);
+    int first_inc = inc ? __builtin_ctzll(inc) : 64;
+    u64 needed = first_inc < 63 ? ((2ull << first_inc) - 1) : ~0ull;
+    if (not_ready & needed) {
+      if (++spins > kSpinLimit) return -1;
+      __builtin_amdgcn_s_sleep(1);
+      continue;
+    }
+    long long part = (lane <= first_inc) ? (long long)(v & kValMask) : 0;
+    for (int d = 32; d > 0; d >>= 1) part += __shfl_xor(part, d, 64);
+    excl += part;
+    if (first_inc < 64) break;
+    t -= 64;
+  }
+  if (lane == 0) status_store(mine, kFlagInc | ((u64)(excl + aggregate) & kValMask));
+  return excl;
+}
+
+// Stages bytes [g0, g1) of `chars` into `lds` (16-byte aligned LDS buffer) so
+// that LDS index i holds the byte at absolute address (A0 + i), A0 = address of
+// chars[g0] rounded down to 16.  Returns the LDS index of chars[g0].
+__device__ __forceinline__ int stage_in(const uint8_t* chars, long long g0, long long g1, uint8_t* lds) {
+  const uintptr_t first = (uintptr_t)(chars + g0);
+  const uintptr_t a0 = first & ~(uintptr_t)15;
+  const int span = (int)((uintptr_t)(chars + g1) - a0);
+  for (int i = threadIdx.x * 16; i < span; i += blockDim.x * 16) {
+    uint4 v = *reinterpret_cast<const uint4*>(a0 + i);
+    *reinterpret_cast<uint4*>(lds + i) = v;
+  }
+  return (int)(first - a0);
+}
+
+// Flushes `total` bytes assembled in `lds` to global memory at `dst`; the
+// caller placed byte k of the output at LDS index ((uintptr_t)dst & 15) + k, so
+// whole 16-byte chunks line up in both address spaces.
+__device__ __forceinline__ void flush_out(uint8_t* dst, int total, const uint8_t* lds) {
+  const int lead = (int)((uintptr_t)dst & 15);
+  uint8_t* a0 = dst - lead;  // 16-aligned
+  const int end = lead + total;
+  for (int i = threadIdx.x * 16; i < end; i += blockDim.x * 16) {
+    if (i >= lead && i + 16 <= end) {
+      *reinterpret_cast<uint4*>(a0 + i) = *reinterpret_cast<const uint4*>(lds + i);
+    } else {
+      for (int k = 0; k < 16; ++k) {
+        int j = i + k;
+        if (j >= lead && j < end) a0[j] = lds[j];
+      }
+    }
+  }
+}
+
+// Per-thread copy inside LDS, dword-wide in the middle.  Both buffers are given
+// as (4-byte aligned base, byte index) so that no pointer is ever turned into an
+// integer (which would demote the LDS accesses to flat ones).  Neighbouring rows
+// may share boundary dwords, so only dwords lying entirely inside
+// [di, di + n) are written as dwords.
+__device__ __forceinline__ void lds_copy(uint8_t* dbase, int di, const uint8_t* sbase, int si, int n) {
+  int i = 0;
+  while (i < n && ((di + i) & 3)) {
+    dbase[di + i] = sbase[si + i];
+    ++i;
+  }
+  if (i + 4 <= n) {
+    const unsigned sh = (unsigned)((si + i) & 3);
+    const uint32_t* sp = reinterpret_cast<const uint32_t*>(sbase) + ((si + i) >> 2);
+    uint32_t* dp = reinterpret_cast<uint32_t*>(dbase) + ((di + i) >> 2);
+    uint32_t lo = *sp++;
+    if (sh == 0) {
+      for (; i + 4 <= n; i += 4) {
+        *dp++ = lo;
+        lo = *sp++;
+      }
+    } else {
+      for (; i + 4 <= n; i += 4) {
+        uint32_t hi = *sp++;
+        *dp++ = __builtin_amdgcn_alignbyte(hi, lo, sh);
+        lo = hi;
+      }
+    }
+  }
+  for (; i < n; ++i) dbase[di + i] = sbase[si + i];
+}
+
+}  // namespace cstile

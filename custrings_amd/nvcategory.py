@@ -115,7 +115,7 @@ class nvcategory:
 
     def values(self, devptr=0):
         """nvcategory.py:364-389 -- int32 key index per row."""
-        if devptr:
+        if devptr is not None and not (isinstance(devptr, int) and devptr == 0):
             p, keep = _lib.addr(devptr)
             on_device = 0 if keep is not None else 1
             check(lib.cs_category_get_values(self.m_cptr, p, on_device, None))
