@@ -26,7 +26,7 @@ import torch.distributed as dist  # noqa: E402
 IPV4 = r"\d+\.\d+\.\d+\.\d+"
 REPL = "<IP>"
 SEED = 20240607
-KERNELS = ["k_split_scan", "k_split_write", "k_replace_re", "k_replace_re_size", "k_replace_re_write",
+KERNELS = ["k_split_measure", "k_split_emit", "k_split_write", "k_replace_re", "k_replace_re_size", "k_replace_re_write",
            "k_split_count", "k_split_sizes", "k_write_offsets", "k_scan_lookback"]
 
 
@@ -122,7 +122,8 @@ def main():
         # per-kernel share: what that kernel must read and write given its role
         alg_kernel = {
             "k_replace_re": alg_replace,
-            "k_split_scan": Lb + 8.125 + Ccols * 8.125,
+            "k_split_measure": Lb + 8.125,
+            "k_split_emit": Lb + 8.125 + split_out + Ccols * 8.125,
             "k_split_write": Lb + 8.125 + split_out + Ccols * 8,
             "k_replace_re_size": Lb + 8.125 + 4,
             "k_replace_re_write": Lb + 16 + repl_out,

@@ -15,6 +15,12 @@ using namespace cs;
 using namespace csdev;
 using namespace csrow;
 
+namespace cs {
+// cs_split.hip: tile kernels for a single-byte delimiter; false = not applicable
+bool split_fast(const cs_column* col, unsigned char delim, int tokens, hipStream_t s,
+                std::vector<std::unique_ptr<cs_column>>& cols);
+}
+
 namespace {
 
 struct Needle {  // small host string copied to the device
@@ -462,6 +468,17 @@ int cs_split(const cs_column* col, const char* delimiter, int maxsplit, cs_strea
       nd = upload(delimiter, s);
       a.delim = nd.d();
       a.nb = nd.n;
+    }
+    if (delimiter && nd.n == 1 && (unsigned char)delimiter[0] < 128) {
+      std::vector<std::unique_ptr<cs_column>> fast;
+      if (split_fast(col, (unsigned char)delimiter[0], a.tokens, s, fast)) {
+        cs_column** arr = (cs_column**)malloc(sizeof(cs_column*) * fast.size());
+        if (!arr) fail(CS_ERR_ALLOC, "host allocation failed");
+        for (size_t k = 0; k < fast.size(); ++k) arr[k] = fast[k].release();
+        *out_cols = arr;
+        *ncols_out = (int)fast.size();
+        return;
+      }
     }
     int ncols = 0;
     Buf counts;

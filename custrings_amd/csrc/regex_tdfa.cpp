@@ -322,16 +322,16 @@ std::vector<int32_t> build_tdfa(const Program& prog, const std::vector<int32_t>&
       bool tail_new = true;
       for (int j = k; j < m; ++j) tail_new &= st.origins[j] == 15;
       if (st.stop || m == 0 || k == m) {
-        e |= 15u << 16;
+        e |= cstd::e_keep_field(15u);
       } else if (tail_new) {
-        e |= (uint32_t)k << 16;
+        e |= cstd::e_keep_field((uint32_t)k);
       } else {
         uint32_t og = 0;
         for (int j = 0; j < kMaxSlots; ++j) og |= (uint32_t)(j < m ? st.origins[j] : 15) << (4 * j);
         size_t idx = std::find(act.begin(), act.end(), og) - act.begin();
         if (idx == act.size()) act.push_back(og);
         if (idx >= 2048) return none;
-        e |= cstd::E_COMPLEX | (15u << 16) | ((uint32_t)idx << 21);
+        e |= cstd::E_COMPLEX | cstd::e_keep_field(15u) | ((uint32_t)idx << 21);
       }
       t2[si * natoms + a] = e;
     }

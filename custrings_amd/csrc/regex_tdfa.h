@@ -36,7 +36,8 @@
 //   ACT    : origin words of the "complex" transitions
 // Transition entry (uint32):
 //   [9:0] next state  [10] STOP  [11] MATCH  [15:12] match origin (0-7 slot, 15 = new)
-//   [19:16] keep (slots j >= keep start at this position; 15 = unchanged)
+//   [19:16] keep ^ 15 (slots j >= keep start at this position; keep 15 = unchanged), so
+//           that a transition with no side effect at all is just its next-state id (< 1024)
 //   [20] COMPLEX (origins in ACT[entry >> 21], 4 bits per slot, 15 = new)
 // (slot fields are 4 bits wide although kMaxSlots is 4: room to grow)
 #pragma once
@@ -58,7 +59,8 @@ enum { P_CHAR = 0, P_ANY = 1, P_ANYNL = 2, P_CCLASS = 3, P_NCCLASS = 4, P_ISNL =
 
 constexpr uint32_t E_STATE = 0x3FFu, E_STOP = 1u << 10, E_MATCH = 1u << 11, E_COMPLEX = 1u << 20;
 CS_HD uint32_t e_match_origin(uint32_t e) { return (e >> 12) & 15u; }
-CS_HD uint32_t e_keep(uint32_t e) { return (e >> 16) & 15u; }
+CS_HD uint32_t e_keep(uint32_t e) { return ((e >> 16) & 15u) ^ 15u; }
+CS_HD uint32_t e_keep_field(uint32_t keep) { return ((keep ^ 15u) & 15u) << 16; }
 constexpr uint32_t E_ACTION = E_MATCH | E_COMPLEX | (15u << 16);  // any bit set / keep != 15 handled below
 
 struct View {
@@ -325,13 +327,23 @@ struct Tdfa {
 #pragma unroll
     for (int j = 0; j < kMaxSlots; ++j) st[j] = 0;
     uint32_t state = D.init[(KIND == K_MATCH ? MODE_SEED_ONCE : MODE_RESTART) * 8 + 4];  // row start
+    // one-word cache of the row storage: consecutive positions share a word
+    int cwi = -(1 << 30);
+    uint32_t cw = 0;
+    auto word_at = [&](int widx) -> uint32_t {
+      if (widx != cwi) {
+        cwi = widx;
+        cw = load_word(widx);
+      }
+      return cw;
+    };
     for (;;) {
       // ---- idle: jump to the next candidate byte
       if (state < D.nskip && pos < n) {
         const int entry = pos;
         do {
           const int j = pos + sa;
-          const uint32_t m = cand_mask(load_word(j >> 2)) & (0xFFFFFFFFu << (8 * (j & 3)));
+          const uint32_t m = cand_mask(word_at(j >> 2)) & (0xFFFFFFFFu << (8 * (j & 3)));
           if (m) {
             pos = (j & ~3) - sa + (ctz32(m) >> 3);
             break;
@@ -341,7 +353,7 @@ struct Tdfa {
         if (pos > n) pos = n;
         if (D.uses && pos > entry) {
           const int j = pos - 1 + sa;
-          const unsigned b = (load_word(j >> 2) >> (8 * (j & 3))) & 255u;
+          const unsigned b = (word_at(j >> 2) >> (8 * (j & 3))) & 255u;
           unsigned cat = 0;
           if (b < 128) {
             if (D.uses & 1) cat |= bm128(D.word0, D.word1, D.word2, D.word3, b);
@@ -352,16 +364,28 @@ struct Tdfa {
           state = (D.skippack >> (8 * cat)) & 255u;
         }
       }
-      // ---- one transition at pos
+      // ---- one transition at pos; transitions without side effects are taken in a
+      // tight inner loop (an entry below 1024 is just the next state)
       uint32_t e;
       int w = 1;
       if (pos >= n) {
         e = D.t2[state * D.natoms + ATOM_EOT];
       } else {
-        const int j = pos + sa;
-        const unsigned b = (load_word(j >> 2) >> (8 * (j & 3))) & 255u;
+        int j = pos + sa;
+        unsigned b = (word_at(j >> 2) >> (8 * (j & 3))) & 255u;
         if (b < 128) {
           e = D.t1[state * 128 + b];
+          while (e < 1024u && e >= D.nskip && pos + 1 < n) {
+            state = e;
+            ++pos;
+            ++j;
+            b = (word_at(j >> 2) >> (8 * (j & 3))) & 255u;
+            if (b >= 128) break;
+            e = D.t1[state * 128 + b];
+          }
+        }
+        if (b < 128) {
+          // e is the pending transition of (state, byte at pos)
         } else {
           unsigned uw;
           csrow::Char c = char_at(pos, uw);
