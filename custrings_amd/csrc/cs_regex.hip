@@ -391,18 +391,7 @@ __global__ void __launch_bounds__(256) k_tdfa_replace_tile(TileArgs a) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    uint8_t* a0 = gdst - olead;
-    const int end = olead + total;
-    for (int i = lane * 16; i < end; i += 64 * 16) {
-      if (i >= olead && i + 16 <= end) {
-        *reinterpret_cast<uint4*>(a0 + i) = *reinterpret_cast<const uint4*>(lds_out + i);
-      } else {
-        for (int k = 0; k < 16; ++k) {
-          int j = i + k;
-          if (j >= olead && j < end) a0[j] = lds_out[j];
-        }
-      }
-    }
+    cstile::wave_flush(gdst, total, lds_out, olead, lane);
   }
 }
 

@@ -68,6 +68,13 @@ struct RowWords {  // a row inside an LDS buffer, read through aligned 32-bit wo
   }
 };
 
+__device__ __forceinline__ int rl(int v, int k) { return __builtin_amdgcn_readlane(v, k); }
+__device__ __forceinline__ long long rl64(long long v, int k) {
+  const int lo = __builtin_amdgcn_readlane((int)(v & 0xffffffffll), k);
+  const int hi = __builtin_amdgcn_readlane((int)(v >> 32), k);
+  return ((long long)hi << 32) | (unsigned int)lo;
+}
+
 struct SubTile {
   long long r0, g0;
   int nrows, rbeg, n, lead;
@@ -80,8 +87,8 @@ __device__ __forceinline__ SubTile load_subtile(const ColView& in, long long sub
   t.nrows = (int)min((long long)kSub, in.rows - t.r0);
   const long long o0 = in.offsets[t.r0 + min(lane, t.nrows)];
   const long long o1 = in.offsets[t.r0 + min(lane + 1, t.nrows)];
-  t.g0 = __shfl(o0, 0, 64);
-  const long long g1 = __shfl(o1, 63, 64);
+  t.g0 = rl64(o0, 0);
+  const long long g1 = rl64(o1, 63);
   t.live = lane < t.nrows && row_is_valid(in.validity, t.r0 + lane);
   t.rbeg = (int)(o0 - t.g0);
   t.n = t.live ? (int)(o1 - o0) : 0;
@@ -148,7 +155,9 @@ __global__ void __launch_bounds__(256) k_split_measure(MeasureArgs a) {
     }
   }
   const int m = wave_reduce_max(count);
-  if (lane == 0 && m) atomicMax(a.max_count, m);
+  // same-address atomics serialise in L2 (about 10 ns each): only waves that would
+  // raise the maximum issue one; a stale (smaller) read merely costs an extra atomic
+  if (lane == 0 && m > __hip_atomic_load(a.max_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(a.max_count, m);
 }
 
 struct ColOut {
@@ -200,10 +209,10 @@ __global__ void __launch_bounds__(256) k_split_emit(EmitArgs a) {
     const int len = has ? hi - lo : 0;
     const int incl = wave_inclusive_scan(len);
     const int pre = incl - len;
-    const long long cbase = __shfl(my_base, k, 64);
-    int64_t* coff = reinterpret_cast<int64_t*>(__shfl((long long)(uintptr_t)my_off, k, 64));
-    uint8_t* cvalid = reinterpret_cast<uint8_t*>(__shfl((long long)(uintptr_t)my_valid, k, 64));
-    const int cstart = __shfl(region, k, 64) + __shfl(my_lead, k, 64);
+    const long long cbase = rl64(my_base, k);
+    int64_t* coff = reinterpret_cast<int64_t*>(rl64((long long)(uintptr_t)my_off, k));
+    uint8_t* cvalid = reinterpret_cast<uint8_t*>(rl64((long long)(uintptr_t)my_valid, k));
+    const int cstart = rl(region, k) + rl(my_lead, k);
     if (lane < t.nrows) coff[t.r0 + lane] = cbase + pre;
     if (last_tile && lane == t.nrows - 1) coff[a.in.rows] = cbase + incl;
     const unsigned long long vmask = __ballot(has);
@@ -214,20 +223,11 @@ __global__ void __launch_bounds__(256) k_split_emit(EmitArgs a) {
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   for (int k = 0; k < a.ncols; ++k) {
-    const int rstart = __shfl(region, k, 64);
-    const int lead = __shfl(my_lead, k, 64);
-    const int end = lead + __shfl(my_sum, k, 64);
-    uint8_t* dst = reinterpret_cast<uint8_t*>(__shfl((long long)(uintptr_t)my_chars, k, 64)) + __shfl(my_base, k, 64) - lead;
-    for (int i = lane * 16; i < end; i += 64 * 16) {
-      if (i >= lead && i + 16 <= end) {
-        *reinterpret_cast<uint4*>(dst + i) = *reinterpret_cast<const uint4*>(lds_out + rstart + i);
-      } else {
-        for (int q = 0; q < 16; ++q) {
-          const int j = i + q;
-          if (j >= lead && j < end) dst[j] = lds_out[rstart + j];
-        }
-      }
-    }
+    const int rstart = rl(region, k);
+    const int lead = rl(my_lead, k);
+    const int end = lead + rl(my_sum, k);
+    uint8_t* dst = reinterpret_cast<uint8_t*>(rl64((long long)(uintptr_t)my_chars, k)) + rl64(my_base, k);
+    cstile::wave_flush(dst, end - lead, lds_out + rstart, lead, lane);
   }
 }
 

@@ -106,6 +106,26 @@ __device__ __forceinline__ void flush_out(uint8_t* dst, int total, const uint8_t
   }
 }
 
+// Wave-cooperative flush of `total` bytes from an LDS region to global memory.
+// `lds` points at the region's 16-byte aligned start; the caller placed output
+// byte k at lds[lead + k] with lead = (address of dst) & 15, so whole 16-byte
+// chunks line up in both address spaces.  Head and tail bytes (up to 15 each) are
+// stored one byte per LANE (two store instructions), never in a per-lane loop.
+__device__ __forceinline__ void wave_flush(uint8_t* dst, int total, const uint8_t* lds, int lead, int lane) {
+  uint8_t* a0 = dst - lead;  // 16-byte aligned
+  const int end = lead + total;
+  const int first_full = (lead + 15) & ~15;       // first chunk boundary at or after the start
+  const int last_full = end & ~15;                // end of the last whole chunk
+  if (first_full >= last_full) {                  // no whole chunk: bytes only
+    for (int j = lead + lane; j < end; j += 64) a0[j] = lds[j];
+    return;
+  }
+  if (lead + lane < first_full) a0[lead + lane] = lds[lead + lane];
+  for (int i = first_full + lane * 16; i < last_full; i += 64 * 16)
+    *reinterpret_cast<uint4*>(a0 + i) = *reinterpret_cast<const uint4*>(lds + i);
+  if (last_full + lane < end) a0[last_full + lane] = lds[last_full + lane];
+}
+
 // Per-thread copy inside LDS, dword-wide in the middle.  Both buffers are given
 // as (4-byte aligned base, byte index) so that no pointer is ever turned into an
 // integer (which would demote the LDS accesses to flat ones).  Neighbouring rows
