@@ -132,11 +132,22 @@ def main():
             "k_write_offsets": 12,
         }
         dom = max(prof, key=lambda k: prof[k]["avg_ms"] * prof[k]["launches"]) if prof else None
+        traffic = args.pmc_traffic
+        if traffic is None and dom:
+            # HBM bytes per launch measured in separate rocprofv3 --pmc passes (profiles/<round>/traffic.json)
+            try:
+                rounds = sorted(d for d in os.listdir(os.path.join(ROOT, "profiles")) if os.path.exists(os.path.join(ROOT, "profiles", d, "traffic.json")))
+                with open(os.path.join(ROOT, "profiles", rounds[-1], "traffic.json")) as f:
+                    tj = json.load(f)
+                if tj.get("rows") == rows and dom in tj["kernels"]:
+                    traffic = float(tj["kernels"][dom]["hbm_bytes"])
+            except Exception:
+                traffic = None
         roofline = None
         if dom:
             a = alg_kernel.get(dom, 0) * rows / (prof[dom]["avg_ms"] * 1e-3) / 1e9
             roofline = {"bound": "hbm", "kernel": dom, "achieved": round(a, 1), "peak": 8000.0, "unit": "GB/s",
-                        "frac": round(a / 8000.0, 4), "traffic": args.pmc_traffic,
+                        "frac": round(a / 8000.0, 4), "traffic": traffic,
                         "avg_ms": round(prof[dom]["avg_ms"], 3),
                         "alg_bytes_per_row": round(alg_kernel.get(dom, 0), 2)}
         ms_step = elapsed / args.steps * 1e3

@@ -1,0 +1,189 @@
+// Mirrors the reference's gtests for the hot path against the C++ host classes
+// (include/nvstrings/*.h): cpp/tests/test_split.cpp:10-46, test_replace.cpp:16-52,
+// test_count.cu:11-101, test_strip.cpp:8-32, test_case.cpp:9-27, test_find.cu:25-76,
+// test_text.cu:15-26, python/tests/test_category.py:33-45.
+//   test_hostapi nogpu  -> checks the no-device error path only
+//   test_hostapi        -> runs the known-answer tests on the GPU
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "nvstrings/NVCategory.h"
+#include "nvstrings/NVStrings.h"
+#include "nvstrings/NVText.h"
+
+static int failures = 0;
+#define EXPECT(c)                                                   \
+  do {                                                              \
+    if (!(c)) {                                                     \
+      ++failures;                                                   \
+      printf("FAILED %s:%d  %s\n", __FILE__, __LINE__, #c);         \
+    }                                                               \
+  } while (0)
+
+// cpp/tests/utils.h:7-45 (verify_strings): byte_count + to_host, null <=> nullptr
+static bool verify_strings(NVStrings* d, const std::vector<const char*>& expected) {
+  unsigned count = d->size();
+  if (count != expected.size()) return false;
+  std::vector<int> lengths(count);
+  d->byte_count(lengths.data(), false);
+  std::vector<std::string> bufs(count);
+  std::vector<char*> ptrs(count);
+  for (unsigned i = 0; i < count; ++i) {
+    bufs[i].assign(lengths[i] > 0 ? (size_t)lengths[i] : 0, '\0');
+    ptrs[i] = lengths[i] < 0 ? nullptr : (bufs[i].empty() ? (char*)"" : &bufs[i][0]);
+    if (lengths[i] == 0) ptrs[i] = nullptr;  // nothing to copy
+  }
+  d->to_host(ptrs.data(), 0, (int)count);
+  for (unsigned i = 0; i < count; ++i) {
+    if ((lengths[i] < 0) != (expected[i] == nullptr)) return false;
+    if (expected[i] && bufs[i] != expected[i]) return false;
+  }
+  return true;
+}
+
+int main(int argc, char** argv) {
+  if (argc > 1 && !strcmp(argv[1], "nogpu")) {
+    const char* one[] = {"a"};
+    try {
+      NVStrings::create_from_array(one, 1);
+      if (cs_device_count() == 0) {
+        printf("expected std::runtime_error without a device\n");
+        return 1;
+      }
+    } catch (const std::runtime_error& e) {
+      printf("ok: %s\n", e.what());
+    }
+    return 0;
+  }
+  {  // split
+    std::vector<const char*> h{"Héllo thesé", nullptr, "are some", "tést String", ""};
+    NVStrings* strs = NVStrings::create_from_array(h.data(), h.size());
+    std::vector<NVStrings*> r;
+    EXPECT(strs->split(-1, r) == 2);
+    EXPECT(verify_strings(r[0], {"Héllo", nullptr, "are", "tést", nullptr}));
+    EXPECT(verify_strings(r[1], {"thesé", nullptr, "some", "String", nullptr}));
+    for (auto* p : r) NVStrings::destroy(p);
+    r.clear();
+    EXPECT(strs->split("s", -1, r) == 2);
+    EXPECT(verify_strings(r[0], {"Héllo the", nullptr, "are ", "té", ""}));
+    EXPECT(verify_strings(r[1], {"é", nullptr, "ome", "t String", nullptr}));
+    for (auto* p : r) NVStrings::destroy(p);
+    NVStrings::destroy(strs);
+  }
+  {  // replace / replace_re
+    std::vector<const char*> h{"the quick brown fox jumps over the lazy dog",
+                               "the fat cat lays next to the other accénted cat",
+                               "a slow moving turtlé cannot catch the bird",
+                               "which can be composéd together to form a more complete",
+                               "thé result does not include the value in the sum in",
+                               "", "absent stop words"};
+    NVStrings* strs = NVStrings::create_from_array(h.data(), h.size());
+    NVStrings* got = strs->replace("the ", "++++ ");
+    EXPECT(verify_strings(got, {"++++ quick brown fox jumps over ++++ lazy dog",
+                                "++++ fat cat lays next to ++++ other accénted cat",
+                                "a slow moving turtlé cannot catch ++++ bird",
+                                "which can be composéd together to form a more complete",
+                                "thé result does not include ++++ value in ++++ sum in", "", "absent stop words"}));
+    NVStrings::destroy(got);
+    got = strs->replace_re("(\\bin\\b)|(\\ba\\b)|(\\bthe\\b)", "=");
+    EXPECT(verify_strings(got, {"= quick brown fox jumps over = lazy dog",
+                                "= fat cat lays next to = other accénted cat",
+                                "= slow moving turtlé cannot catch = bird",
+                                "which can be composéd together to form = more complete",
+                                "thé result does not include = value = = sum =", "", "absent stop words"}));
+    NVStrings::destroy(got);
+    bool threw = false;
+    try {
+      strs->replace_re("", "x");
+    } catch (const std::invalid_argument&) {
+      threw = true;
+    }
+    EXPECT(threw);
+    NVStrings::destroy(strs);
+  }
+  {  // contains / contains_re / match / count_re
+    std::vector<const char*> h{"The quick brown @fox jumps", "ovér the", "lazy @dog", "1234", "00:0:00", nullptr, ""};
+    NVStrings* strs = NVStrings::create_from_array(h.data(), h.size());
+    bool res[7];
+    auto same = [&](std::initializer_list<bool> e) {
+      int i = 0;
+      for (bool b : e)
+        if (res[i++] != b) return false;
+      return true;
+    };
+    strs->contains("é", res, false);
+    EXPECT(same({false, true, false, false, false, false, false}));
+    strs->contains_re("\\d+", res, false);
+    EXPECT(same({false, false, false, true, true, false, false}));
+    strs->contains_re("@\\w+", res, false);
+    EXPECT(same({true, false, true, false, false, false, false}));
+    strs->match("ov[eé]r", res, false);
+    EXPECT(same({false, true, false, false, false, false, false}));
+    strs->match("[tT]he", res, false);
+    EXPECT(same({true, false, false, false, false, false, false}));
+    int cnt[7];
+    strs->count_re("\\d+:\\d+", cnt, false);
+    EXPECT(cnt[4] == 1 && cnt[0] == 0 && cnt[3] == 0 && cnt[5] == 0);
+    EXPECT(strs->contains_re(nullptr, res, false) == -1);
+    NVStrings::destroy(strs);
+  }
+  {  // strip, case, find
+    std::vector<const char*> h{" hello  ", "   thesé ", nullptr, "ARE THE", " tést  strings ", ""};
+    NVStrings* strs = NVStrings::create_from_array(h.data(), h.size());
+    NVStrings* got = strs->lstrip(" ");
+    EXPECT(verify_strings(got, {"hello  ", "thesé ", nullptr, "ARE THE", "tést  strings ", ""}));
+    NVStrings::destroy(got);
+    got = strs->rstrip(" ");
+    EXPECT(verify_strings(got, {" hello", "   thesé", nullptr, "ARE THE", " tést  strings", ""}));
+    NVStrings::destroy(got);
+    got = strs->strip(" ");
+    EXPECT(verify_strings(got, {"hello", "thesé", nullptr, "ARE THE", "tést  strings", ""}));
+    NVStrings::destroy(got);
+    NVStrings::destroy(strs);
+    std::vector<const char*> c{"Examples aBc", "thesé", nullptr, "ARE THE", "tést strings", ""};
+    strs = NVStrings::create_from_array(c.data(), c.size());
+    got = strs->lower();
+    EXPECT(verify_strings(got, {"examples abc", "thesé", nullptr, "are the", "tést strings", ""}));
+    NVStrings::destroy(got);
+    got = strs->upper();
+    EXPECT(verify_strings(got, {"EXAMPLES ABC", "THESÉ", nullptr, "ARE THE", "TÉST STRINGS", ""}));
+    NVStrings::destroy(got);
+    NVStrings::destroy(strs);
+    std::vector<const char*> f{"Héllo", "thesé", nullptr, "ARE THE", "tést strings", ""};
+    strs = NVStrings::create_from_array(f.data(), f.size());
+    int pos[6];
+    strs->find("é", 0, -1, pos, false);
+    int e[] = {1, 4, -2, -1, 1, -1};
+    for (int i = 0; i < 6; ++i) EXPECT(pos[i] == e[i]);
+    NVStrings::destroy(strs);
+  }
+  {  // tokenize, ngrams, category
+    std::vector<const char*> t{"the fox jumped over the dog", "the dog chased the cat", "the cat chased the mouse",
+                               nullptr, "", "the mouse ate the cheese"};
+    NVStrings* strs = NVStrings::create_from_array(t.data(), t.size());
+    NVStrings* tok = NVText::tokenize(*strs);
+    EXPECT(verify_strings(tok, {"the", "fox", "jumped", "over", "the", "dog", "the", "dog", "chased", "the", "cat",
+                                "the", "cat", "chased", "the", "mouse", "the", "mouse", "ate", "the", "cheese"}));
+    NVStrings* bi = NVText::create_ngrams(*tok, 2, "_");
+    EXPECT(bi->size() == 20);
+    NVStrings::destroy(bi);
+    NVStrings::destroy(tok);
+    NVStrings::destroy(strs);
+    std::vector<const char*> e{"eee", "aaa", "eee", "ddd", "ccc", "ccc", "ccc", "eee", "aaa"};
+    strs = NVStrings::create_from_array(e.data(), e.size());
+    NVCategory* cat = NVCategory::create_from_strings(*strs);
+    EXPECT(cat->size() == 9 && cat->keys_size() == 4);
+    NVStrings* keys = cat->get_keys();
+    EXPECT(verify_strings(keys, {"aaa", "ccc", "ddd", "eee"}));
+    int vals[9], ev[] = {3, 0, 3, 2, 1, 1, 1, 3, 0};
+    cat->get_values(vals, false);
+    for (int i = 0; i < 9; ++i) EXPECT(vals[i] == ev[i]);
+    NVStrings::destroy(keys);
+    NVCategory::destroy(cat);
+    NVStrings::destroy(strs);
+  }
+  printf(failures ? "%d FAILURES\n" : "all host-API tests passed\n", failures);
+  return failures ? 1 : 0;
+}

@@ -273,3 +273,24 @@ def test_gpu_full_size_c3_properties(orc):
     tok_bytes = sum(int(L.lib.cs_column_nbytes(c.m_cptr)) for c in cols)
     tokens = sum(rows - c.null_count() for c in cols)
     assert tok_bytes + (tokens - rows) == int(L.lib.cs_column_nbytes(g.m_cptr))
+
+
+def test_gpu_global_category_single_rank(orc):
+    """dist.global_category with GpuOps on one rank == the plain category build."""
+    from custrings_amd import dist as csd
+
+    g, o = gpuutil.synth(4, 0, 50_000, 500), orc.synth(4, 0, 50_000, param=500)
+    keys, values = csd.global_category(g)
+    ok, ov = orc.category(o)
+    gpuutil.assert_same(keys, ok, "keys")
+    assert np.array_equal(values.cpu().numpy(), ov)
+    # the merge path itself: two shards merged on one rank through GpuOps
+    ops = csd.GpuOps()
+    a, b = gpuutil.synth(4, 0, 25_000, 500), gpuutil.synth(4, 25_000, 25_000, 500)
+    ca, (cha, ofa, na) = ops.category(a)
+    cb, (chb, ofb, nb) = ops.category(b)
+    mk, codes = ops.concat_category([ops.column(cha, ofa, na), ops.column(chb, ofb, nb)])
+    gpuutil.assert_same(mk, ok, "merged keys")
+    va = ops.remap(ca, codes[: ca.keys_size()].contiguous())
+    vb = ops.remap(cb, codes[ca.keys_size() :].contiguous())
+    assert np.array_equal(np.concatenate([va.cpu().numpy(), vb.cpu().numpy()]), ov)
