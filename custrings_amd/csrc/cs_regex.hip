@@ -55,6 +55,7 @@ struct Plan {
 struct RowSrc {
   ColView in;
   const uint8_t* flags;
+  int64_t safe_end;  // chars bytes that may be read (logical size + allocation slack)
 };
 
 // common prologue: stage the image, carve per-thread scratch
@@ -198,6 +199,7 @@ __global__ void __launch_bounds__(256) k_tdfa_scan(RowSrc src, TLaunch L, uint8_
     if (row_is_valid(in.validity, r)) {
       int64_t b = in.offsets[r];
       cstd::Tdfa vm(c.D, c.P, in.chars + b, (int)(in.offsets[r + 1] - b));
+      vm.wide_ok = (b & ~(int64_t)3) + cstd::Tdfa::kMaskBytes <= src.safe_end;
       if (MODE == 2) v = csvm::row_count_re(vm);
       else v = csvm::row_contains_re(vm, MODE == 1);
     }
@@ -223,6 +225,7 @@ __global__ void __launch_bounds__(256) k_tdfa_replace_size(RowSrc src, TLaunch L
       int64_t b = in.offsets[r];
       int n = (int)(in.offsets[r + 1] - b);
       cstd::Tdfa vm(c.D, c.P, in.chars + b, n);
+      vm.wide_ok = (b & ~(int64_t)3) + cstd::Tdfa::kMaskBytes <= src.safe_end;
       len = n;
       csvm::row_replace_matches(vm, maxrepl, [&](int mb, int me, int reps) { len += reps * rb - (me - mb); });
     }
@@ -246,6 +249,7 @@ __global__ void __launch_bounds__(256) k_tdfa_replace_write(RowSrc src, TLaunch 
     uint8_t* o = out_chars + out_off[r];
     int copied = 0;
     cstd::Tdfa vm(c.D, c.P, p, n);
+    vm.wide_ok = (b & ~(int64_t)3) + cstd::Tdfa::kMaskBytes <= src.safe_end;
     csvm::row_replace_matches(vm, maxrepl, [&](int mb, int me, int reps) {
       for (int i = copied; i < mb; ++i) *o++ = p[i];
       for (int k = 0; k < reps; ++k)
@@ -486,7 +490,7 @@ void scan(const cs_column* col, cs_regex* re, uint8_t* out8, int32_t* out32, int
   }
   Buf cnt = dev_alloc(8, s);
   CS_HIP(hipMemsetAsync(cnt->p, 0, 8, s));
-  RowSrc src{view_of(col), d_unicode_flags()};
+  RowSrc src{view_of(col), d_unicode_flags(), col->nbytes + (col->chars && col->chars->capacity ? 64 : 0)};
   {
     ProfScope ps(name, s);
     if (tdfa)
@@ -592,7 +596,7 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
     TPlan tp{};
     if (tdfa) tp = tplan(re, col->rows, s);
     else pl = plan(re, col->rows, s);
-    RowSrc src{view_of(col), d_unicode_flags()};
+    RowSrc src{view_of(col), d_unicode_flags(), col->nbytes + (col->chars && col->chars->capacity ? 64 : 0)};
     auto* o = new cs_column;
     std::unique_ptr<cs_column> holder(o);
     o->rows = col->rows;

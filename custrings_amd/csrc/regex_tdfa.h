@@ -124,7 +124,8 @@ struct Tdfa {
   const csvm::ProgView& P;
   const uint8_t* s;
   int n;
-  int sa;  // (address of s) & 3: lets byte_at() use aligned 32-bit loads without pointer<->integer casts
+  int sa;  // (address of s) & 3: lets the row be read through aligned 32-bit loads without pointer<->integer casts
+  bool wide_ok = true;  // 96 bytes from the row's aligned start are readable (LDS tiles; buffer slack in HBM)
 
   CS_HD Tdfa(const View& d, const csvm::ProgView& p, const uint8_t* row, int bytes, int align_phase = -1)
       : D(d), P(p), s(row), n(bytes), sa(align_phase < 0 ? (int)((uintptr_t)row & 3) : align_phase) {}
@@ -317,6 +318,47 @@ struct Tdfa {
 #endif
   }
 
+  // ---- candidate bitmask of a short row, held in three registers ---------------
+  // Bit q = "the byte at row offset q - sa may leave the idle state", q < 96.  Built
+  // in straight-line code from 24 aligned words (no loop, no waits between the
+  // loads), after which "next candidate" is a couple of bit operations.
+  static constexpr int kMaskBytes = 96;
+  CS_HD bool masks_fit() const { return wide_ok && n + sa <= kMaskBytes; }
+  CS_HD void build_masks(uint32_t& m0, uint32_t& m1, uint32_t& m2) const {
+    uint32_t r[3] = {0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 24; ++k) {
+      const uint32_t c = cand_mask(load_word(k));
+      // gather bits 7,15,23,31 into a nibble (bit i = byte i)
+      const uint32_t nib = ((((c >> 7) & 0x01010101u) * 0x01020408u) >> 24) & 15u;
+      r[k >> 3] |= nib << (4 * (k & 7));
+    }
+    // keep bits sa .. sa + n - 1
+    const int lo = sa, hi = sa + n;
+    r[0] &= 0xFFFFFFFFu << lo;
+    r[0] &= hi >= 32 ? 0xFFFFFFFFu : ~(0xFFFFFFFFu << (hi & 31));
+    r[1] &= hi >= 64 ? 0xFFFFFFFFu : (hi <= 32 ? 0u : ~(0xFFFFFFFFu << (hi & 31)));
+    r[2] &= hi >= 96 ? 0xFFFFFFFFu : (hi <= 64 ? 0u : ~(0xFFFFFFFFu << (hi & 31)));
+    m0 = r[0];
+    m1 = r[1];
+    m2 = r[2];
+  }
+  // first candidate position >= pos (row offsets), or n
+  CS_HD int next_candidate(uint32_t m0, uint32_t m1, uint32_t m2, int pos) const {
+    const int q = pos + sa;
+    uint32_t a = m0, b = m1, c = m2;
+    if (q >= 32) a = 0;
+    if (q >= 64) b = 0;
+    const uint32_t cut = 0xFFFFFFFFu << (q & 31);
+    if (q < 32) a &= cut;
+    else if (q < 64) b &= cut;
+    else c &= cut;
+    if (a) return ctz32(a) - sa;
+    if (b) return 32 + ctz32(b) - sa;
+    if (c) return 64 + ctz32(c) - sa;
+    return n;
+  }
+
   // emit(mb, me, reps) per match (K_REPLACE: reps > 1 for the zero-length repeat);
   // returns the number of matches (K_CONTAINS / K_MATCH: 0 or 1).
   template <int KIND, class Emit>
@@ -337,19 +379,26 @@ struct Tdfa {
       }
       return cw;
     };
+    const bool masked = D.nskip > 0 && masks_fit();
+    uint32_t cm0 = 0, cm1 = 0, cm2 = 0;
+    if (masked) build_masks(cm0, cm1, cm2);
     for (;;) {
       // ---- idle: jump to the next candidate byte
       if (state < D.nskip && pos < n) {
         const int entry = pos;
-        do {
-          const int j = pos + sa;
-          const uint32_t m = cand_mask(word_at(j >> 2)) & (0xFFFFFFFFu << (8 * (j & 3)));
-          if (m) {
-            pos = (j & ~3) - sa + (ctz32(m) >> 3);
-            break;
-          }
-          pos = (j & ~3) + 4 - sa;
-        } while (pos < n);
+        if (masked) {
+          pos = next_candidate(cm0, cm1, cm2, pos);
+        } else {
+          do {
+            const int j = pos + sa;
+            const uint32_t m = cand_mask(word_at(j >> 2)) & (0xFFFFFFFFu << (8 * (j & 3)));
+            if (m) {
+              pos = (j & ~3) - sa + (ctz32(m) >> 3);
+              break;
+            }
+            pos = (j & ~3) + 4 - sa;
+          } while (pos < n);
+        }
         if (pos > n) pos = n;
         if (D.uses && pos > entry) {
           const int j = pos - 1 + sa;
