@@ -103,14 +103,55 @@ __device__ __forceinline__ SubTile load_subtile(const ColView& in, long long sub
   return t;
 }
 
-// token walker: next() yields [lo, hi) of the row's next token, or false
+// token walker: next() yields [lo, hi) of the row's next token, or false.
+// Rows of up to 96 bytes (from their aligned start) get the positions of all their
+// delimiters as a 96-bit mask held in registers, built in straight-line code from
+// 24 aligned words; the walk is then ctz + clear-lowest-bit per token.  Longer rows
+// search word by word.
 struct Tokens {
   RowWords w;
   uint32_t dpat;
   int cursor, k, limit;  // limit: token index that swallows the rest (maxsplit), or -1
-  bool more;
+  bool more, masked;
+  unsigned long long m_lo;  // delimiter bits 0..63 (bit q = byte at row offset q - sa)
+  uint32_t m_hi;            // bits 64..95
+  int sa;
   __device__ __forceinline__ Tokens(const uint8_t* base, int beg, int n, bool live, uint32_t d, int tokens)
-      : w(base, beg, n), dpat(d), cursor(0), k(0), limit(tokens > 0 ? tokens - 1 : -1), more(live) {}
+      : w(base, beg, n), dpat(d), cursor(0), k(0), limit(tokens > 0 ? tokens - 1 : -1), more(live), masked(false),
+        m_lo(0), m_hi(0), sa(beg & 3) {
+    if (__all(!live || n + sa <= 96)) {  // wave-uniform choice keeps the unrolled build convergent
+      masked = true;
+      const uint32_t* words = reinterpret_cast<const uint32_t*>(base) + (beg >> 2);
+      uint32_t r[3] = {0, 0, 0};
+#pragma unroll
+      for (int i = 0; i < 24; ++i) {
+        const uint32_t x = words[i] ^ d;
+        const uint32_t z = ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u;
+        const uint32_t nib = ((((z >> 7) & 0x01010101u) * 0x01020408u) >> 24) & 15u;
+        r[i >> 3] |= nib << (4 * (i & 7));
+      }
+      const int hi = sa + n;  // keep bits sa .. hi - 1
+      r[0] &= 0xFFFFFFFFu << sa;
+      r[0] &= hi >= 32 ? 0xFFFFFFFFu : ~(0xFFFFFFFFu << (hi & 31));
+      r[1] &= hi >= 64 ? 0xFFFFFFFFu : (hi <= 32 ? 0u : ~(0xFFFFFFFFu << (hi & 31)));
+      r[2] &= hi >= 96 ? 0xFFFFFFFFu : (hi <= 64 ? 0u : ~(0xFFFFFFFFu << (hi & 31)));
+      m_lo = ((unsigned long long)r[1] << 32) | r[0];
+      m_hi = r[2];
+    }
+  }
+  __device__ __forceinline__ int next_delim() {  // masked: position of the next delimiter, or n
+    if (m_lo) {
+      const int q = __builtin_ctzll(m_lo);
+      m_lo &= m_lo - 1;
+      return q - sa;
+    }
+    if (m_hi) {
+      const int q = 64 + __builtin_ctz(m_hi);
+      m_hi &= m_hi - 1;
+      return q - sa;
+    }
+    return w.n;
+  }
   __device__ __forceinline__ bool next(int& lo, int& hi) {
     if (!more) return false;
     lo = cursor;
@@ -118,7 +159,7 @@ struct Tokens {
       hi = w.n;
       more = false;
     } else {
-      hi = w.find(cursor, dpat);
+      hi = masked ? next_delim() : w.find(cursor, dpat);
       if (hi >= w.n) more = false;
       else cursor = hi + 1;
     }
@@ -217,7 +258,7 @@ __global__ void __launch_bounds__(256) k_split_emit(EmitArgs a) {
     if (last_tile && lane == t.nrows - 1) coff[a.in.rows] = cbase + incl;
     const unsigned long long vmask = __ballot(has);
     if (lane == 0) *reinterpret_cast<unsigned long long*>(cvalid + sub * 8) = vmask;
-    if (has) cstile::lds_copy(lds_out, cstart + pre, lds_in, t.lead + t.rbeg + lo, len);
+    if (has) cstile::lds_copy_short(lds_out, cstart + pre, lds_in, t.lead + t.rbeg + lo, len);
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();

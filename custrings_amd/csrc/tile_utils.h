@@ -158,4 +158,23 @@ __device__ __forceinline__ void lds_copy(uint8_t* dbase, int di, const uint8_t* 
   for (; i < n; ++i) dbase[di + i] = sbase[si + i];
 }
 
+// Copy of a SHORT run (tokens, replacement text): the first 8 bytes go through two
+// funnel-shifted source dwords and straight-line predicated byte stores, longer
+// runs fall back to lds_copy for the rest.
+__device__ __forceinline__ void lds_copy_short(uint8_t* dbase, int di, const uint8_t* sbase, int si, int n) {
+  if (n <= 0) return;
+  const uint32_t* sp = reinterpret_cast<const uint32_t*>(sbase) + (si >> 2);
+  const unsigned sh = (unsigned)(si & 3);
+  const uint32_t w0 = sp[0], w1 = sp[1], w2 = sp[2];
+  const uint32_t a = sh ? __builtin_amdgcn_alignbyte(w1, w0, sh) : w0;  // source bytes 0..3
+  const uint32_t b = sh ? __builtin_amdgcn_alignbyte(w2, w1, sh) : w1;  // source bytes 4..7
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    if (j < n) dbase[di + j] = (uint8_t)(a >> (8 * j));
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    if (4 + j < n) dbase[di + 4 + j] = (uint8_t)(b >> (8 * j));
+  if (n > 8) lds_copy(dbase, di + 8, sbase, si + 8, n - 8);
+}
+
 }  // namespace cstile
