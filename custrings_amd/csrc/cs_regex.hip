@@ -399,6 +399,191 @@ __global__ void __launch_bounds__(256) k_tdfa_replace_tile(TileArgs a) {
   }
 }
 
+
+// ---- persistent single-pass replace_re (tile_utils.h: sub-tile stream) ----------------
+// Same contract as k_tdfa_replace_tile, restructured for latency: the grid is sized to
+// the device's residency, wave `wid` of W walks sub-tiles wid, wid + W, ...; the chars of
+// the next sub-tile are prefetched into registers while the current one is scanned, the
+// look-back poll is issued before the output rows are assembled and consumed after, and
+// the flush takes the destination alignment as it comes (no dependence of the assembly
+// on the global position).
+struct StreamArgs {
+  ColView in;
+  const uint8_t* flags;
+  TLaunch L;
+  const uint8_t* repl;
+  int rb, maxrepl;
+  int64_t* out_off;
+  uint8_t* out_chars;
+  cstile::u64* status;
+  unsigned* error;
+  long long nsub;
+  int cap_in, cap_out, tbl_bytes;
+  int debug;
+};
+template <bool IN_LDS>
+__global__ void __launch_bounds__(256, 3) k_tdfa_replace_stream(StreamArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  uint8_t* base = reinterpret_cast<uint8_t*>(smem);
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  uint8_t* lds_in = base + a.tbl_bytes + (size_t)wv * (a.cap_in + a.cap_out + 64);
+  uint8_t* lds_out = lds_in + a.cap_in + 32;
+  const TCtx c = tsetup<IN_LDS>(a.L, a.flags, smem);  // (block barrier inside when staging)
+  const cstd::View& D = c.D;
+  const csvm::ProgView& P = c.P;
+  const ColView& in = a.in;
+  const int rb = a.rb;
+  const long long W = (long long)gridDim.x * 4;
+  long long tile = (long long)blockIdx.x * 4 + wv;
+  if (tile >= a.nsub) return;
+  // replacement text in a register pair (the single pass is only taken for rb <= 8)
+  uint32_t rep0 = 0, rep1 = 0;
+  for (int i = 0; i < rb && i < 8; ++i) {
+    const uint32_t b = a.repl[i];
+    if (i < 4) rep0 |= b << (8 * i);
+    else rep1 |= b << (8 * (i - 4));
+  }
+  cstile::TileOffs cur = cstile::load_tile_offsets(in.offsets, in.rows, tile, lane);
+  cstile::TileOffs nxt = cur;
+  if (tile + W < a.nsub) nxt = cstile::load_tile_offsets(in.offsets, in.rows, tile + W, lane);
+  cstile::TileChars pf;
+#pragma unroll
+  for (int j = 0; j < cstile::kPfChunks; ++j) pf.v[j] = make_uint4(0, 0, 0, 0);
+  cstile::issue_chars(in.chars, cstile::rl64(cur.o0, 0), cstile::rl64(cur.o1, 63), lane, pf);
+  for (;;) {
+    const long long r0 = tile * 64;
+    const int nrows = (int)min(64ll, in.rows - r0);
+    const long long g0 = cstile::rl64(cur.o0, 0), g1 = cstile::rl64(cur.o1, 63);
+    const bool live = lane < nrows && row_is_valid(in.validity, r0 + lane);
+    const int rbeg = (int)(cur.o0 - g0);
+    const int n = live ? (int)(cur.o1 - cur.o0) : 0;
+    const int lead = (int)((uintptr_t)(in.chars + g0) & 15);
+    const long long want = g1 - g0 + lead;
+    bool bad = want + 16 > a.cap_in || want > cstile::kPfBytes;
+    if (!bad) cstile::stage_chars(lds_in, (int)want, lane, pf);
+    // bytes that the lean scan does not take (non-ASCII, NUL) anywhere in the staged span
+    uint32_t odd = 0;
+#pragma unroll
+    for (int j = 0; j < cstile::kPfChunks; ++j)
+      if (j * 1024 + lane * 16 < (int)want) {
+        const uint4 q = pf.v[j];
+        odd |= q.x | ((q.x - 0x01010101u) & ~q.x);
+        odd |= q.y | ((q.y - 0x01010101u) & ~q.y);
+        odd |= q.z | ((q.z - 0x01010101u) & ~q.z);
+        odd |= q.w | ((q.w - 0x01010101u) & ~q.w);
+      }
+    // keep the memory pipe busy: next sub-tile's chars, and the offsets of the one after
+    const bool has_next = tile + W < a.nsub;
+    if (has_next) {
+      cur = nxt;
+      cstile::issue_chars(in.chars, cstile::rl64(cur.o0, 0), cstile::rl64(cur.o1, 63), lane, pf);
+      if (tile + 2 * W < a.nsub) nxt = cstile::load_tile_offsets(in.offsets, in.rows, tile + 2 * W, lane);
+    }
+    cstile::wave_lds_fence();
+
+    int rec_mb[kMaxRec], rec_me[kMaxRec], rec_reps[kMaxRec];
+    int nm = 0;
+    int out_len = 0;
+    if (live && !bad) out_len = n;
+    if (!bad && !(a.debug & 1)) {
+      cstd::Tdfa vm(D, P, lds_in + lead + rbeg, n, (lead + rbeg) & 3);
+      auto rec = [&](int mb, int me, int reps) {
+        out_len += reps * rb - (me - mb);
+#pragma unroll
+        for (int j = 0; j < kMaxRec; ++j)
+          if (nm == j) {
+            rec_mb[j] = mb;
+            rec_me[j] = me;
+            rec_reps[j] = reps;
+          }
+        ++nm;
+      };
+      // wave-uniform choice: the lean scan when every row of the sub-tile qualifies
+      const bool lean = D.nskip > 0 && !(a.debug & 32) && !__any((odd & 0x80808080u) != 0) &&
+                        !__any(live && !vm.masks_fit());
+      bool redo = live && !lean;
+      if (lean && live && a.maxrepl != 0) {
+        out_len = n;
+        bool bail = false;
+        vm.scan_lean_dispatch(a.maxrepl, rec, bail);
+        redo = bail;
+      }
+      if (__any(redo)) {
+        if (redo) {
+          out_len = n;
+          nm = 0;
+          csvm::row_replace_matches(vm, a.maxrepl, rec);
+        }
+      }
+    }
+    bad |= __any(nm > kMaxRec);
+    const int incl = csdev::wave_inclusive_scan(out_len);
+    const int lo = incl - out_len;
+    const int total = __builtin_amdgcn_readlane(incl, 63);
+    bad |= total + 32 > a.cap_out;
+    if (bad) {
+      // the host discards this launch's output; publish something so successors do not spin
+      if (lane == 0) {
+        atomicOr(a.error, 1u);
+        cstile::status_store(a.status + tile, cstile::kFlagInc);
+      }
+    } else {
+      cstile::u64 first = (a.debug & 8) ? 0 : cstile::lookback_begin(a.status, tile, total, lane);
+      if (live && !(a.debug & 2)) {
+        int oi = lo;                 // byte index into lds_out
+        const int pi = lead + rbeg;  // byte index of the row in lds_in
+        int copied = 0;
+#pragma unroll
+        for (int j = 0; j < kMaxRec; ++j)
+          if (j < nm) {
+            cstile::lds_copy(lds_out, oi, lds_in, pi + copied, rec_mb[j] - copied);
+            oi += rec_mb[j] - copied;
+            for (int k = 0; k < rec_reps[j]; ++k)
+              for (int i = 0; i < rb; ++i) lds_out[oi++] = (uint8_t)((i < 4 ? rep0 >> (8 * i) : rep1 >> (8 * (i - 4))));
+            copied = rec_me[j];
+          }
+        cstile::lds_copy(lds_out, oi, lds_in, pi + copied, n - copied);
+      }
+      long long gb = (a.debug & 8) ? tile * 4096 : cstile::lookback_end(a.status, tile, total, first, lane);
+      if (gb < 0) {
+        if (lane == 0) atomicOr(a.error, 1u);
+        gb = 0;
+      }
+      if (lane < nrows) a.out_off[r0 + lane] = gb + lo;
+      if (lane == nrows - 1 && r0 + nrows == in.rows) a.out_off[in.rows] = gb + lo + out_len;
+      if (!(a.debug & 4)) {
+        cstile::wave_lds_fence();
+        cstile::wave_flush_shift(a.out_chars + gb, total, lds_out, lane);
+      }
+    }
+    if (!has_next) break;
+    tile += W;
+  }
+}
+
+
+// Number of 256-thread workgroups of `kern` that are resident at once on this device
+// (capped by `wanted`): the persistent kernels' look-back needs every wave of the grid
+// to be running.
+unsigned resident_grid(const void* kern, size_t lds, int64_t wanted) {
+  static const void* c_kern = nullptr;
+  static size_t c_lds = 0;
+  static int c_cus = 0, c_per = 0;
+  if (c_kern != kern || c_lds != lds) {  // the occupancy query costs about a millisecond
+    int dev = 0;
+    CS_HIP(hipGetDevice(&dev));
+    CS_HIP(hipDeviceGetAttribute(&c_cus, hipDeviceAttributeMultiprocessorCount, dev));
+    CS_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&c_per, kern, 256, lds));
+    c_kern = kern;
+    c_lds = lds;
+  }
+  int cus = c_cus, per = c_per;
+  if (per < 1) per = 1;
+  if (const char* e = getenv("CS_STREAM_BLOCKS_PER_CU")) per = std::max(1, std::min(per, atoi(e)));
+  const int64_t cap = (int64_t)cus * per;
+  return (unsigned)std::max<int64_t>(1, std::min<int64_t>(cap, wanted));
+}
+
 struct TPlan {
   TLaunch d;
   size_t lds_bytes;
@@ -613,7 +798,51 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
       const int cap = (int)((span + 15 + 32 + 127) & ~(int64_t)127);
       const size_t tbl = tp.d.in_lds ? tp.lds_bytes : 0;
       const size_t lds = tbl + (size_t)(2 * cap + 64) * 4 + 16;
-      if (lds <= 150 * 1024) {
+      if (lds <= 150 * 1024 && rb <= 8 && cap <= cstile::kPfBytes && !getenv("CS_TILE_OLD")) {
+        // persistent stream kernel: grid = what is resident at once
+        StreamArgs sa{};
+        sa.in = view_of(col);
+        sa.flags = d_unicode_flags();
+        sa.L = tp.d;
+        sa.repl = ptr<const uint8_t>(d_repl);
+        sa.rb = rb;
+        sa.maxrepl = maxrepl;
+        Buf out_off = dev_alloc(sizeof(int64_t) * (rows + 1), s);
+        Buf out_chars = dev_alloc((size_t)col->nbytes + 64, s);
+        sa.out_off = ptr<int64_t>(out_off);
+        sa.out_chars = ptr<uint8_t>(out_chars);
+        const int64_t nsub1 = (rows + 63) / 64;
+        Buf status = dev_alloc(sizeof(cstile::u64) * nsub1 + 16, s);
+        CS_HIP(hipMemsetAsync(status->p, 0, sizeof(cstile::u64) * nsub1 + 16, s));
+        sa.status = ptr<cstile::u64>(status);
+        sa.error = reinterpret_cast<unsigned*>(ptr<cstile::u64>(status) + nsub1);
+        sa.nsub = nsub1;
+        sa.cap_in = cap;
+        sa.cap_out = cap;
+        sa.tbl_bytes = (int)tbl;
+        sa.debug = getenv("CS_TILE_DEBUG") ? atoi(getenv("CS_TILE_DEBUG")) : 0;
+        auto kern = tp.d.in_lds ? &k_tdfa_replace_stream<true> : &k_tdfa_replace_stream<false>;
+        if (lds > 48 * 1024)
+          CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)lds));
+        const unsigned grid = resident_grid(reinterpret_cast<const void*>(kern), lds, (nsub1 + 3) / 4);
+        {
+          ProfScope ps("k_replace_re", s);
+          hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, sa);
+        }
+        CS_HIP(hipGetLastError());
+        int64_t* host = (int64_t*)pinned_scratch(16);
+        CS_HIP(hipMemcpyAsync(host, ptr<int64_t>(out_off) + rows, 8, hipMemcpyDeviceToHost, s));
+        CS_HIP(hipMemcpyAsync(host + 1, sa.error, 4, hipMemcpyDeviceToHost, s));
+        CS_HIP(hipStreamSynchronize(s));
+        if ((uint32_t)host[1] == 0 || sa.debug) {
+          o->offsets = out_off;
+          o->chars = out_chars;
+          o->nbytes = host[0];
+          *out = holder.release();
+          return;
+        }
+      } else if (lds <= 150 * 1024) {
         TileArgs ta{};
         ta.in = view_of(col);
         ta.flags = d_unicode_flags();

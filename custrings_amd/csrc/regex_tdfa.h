@@ -359,6 +359,130 @@ struct Tdfa {
     return n;
   }
 
+
+  // ---- lean replace scan: ASCII-only rows, candidate masks in registers ------------
+  // Preconditions (the caller checks them): every byte of the row is 1..127,
+  // D.nskip > 0, masks_fit(), and the automaton uses at most NS thread slots.  On
+  // such rows the result equals scan<K_REPLACE>.  Two levels so that a wave spends its
+  // lock-step iterations on byte steps, not on bookkeeping: the inner loop takes every
+  // transition that neither stops the automaton nor returns it to the idle state
+  // (recording MATCH / thread-start side effects on the way); idle jumps, the end of
+  // the row and the end of a find() round are handled once per outer iteration.
+  // COMPLEX transitions and zero-length matches set `bail`: the caller re-runs the row
+  // with scan<>.
+  CS_HD uint8_t byte_at(int i) const { return s[i]; }
+  template <bool USES, int NS, class Emit>
+  CS_HD int scan_lean_replace(int maxrepl, Emit&& emit, bool& bail) {
+    uint32_t cm0, cm1, cm2;
+    build_masks(cm0, cm1, cm2);
+    int from = 0, pos = 0, done = 0, mb = 0, me = 0, matched = 0;
+    int st[NS];
+#pragma unroll
+    for (int j = 0; j < NS; ++j) st[j] = 0;
+    uint32_t state = D.init[MODE_RESTART * 8 + 4];
+    // side effects of a transition that carries no COMPLEX origin word
+    auto effects = [&](uint32_t e) {
+      if (e & E_MATCH) {
+        const uint32_t o = e_match_origin(e);
+        int v = pos;
+#pragma unroll
+        for (int j = 0; j < NS; ++j)
+          if (o == (uint32_t)j) v = st[j];
+        mb = v;
+        me = pos;
+        matched = 1;
+      }
+      const uint32_t kf = (e >> 16) & 15u;  // keep ^ 15: 0 = nothing to do
+      if (kf) {
+        const uint32_t keep = kf ^ 15u;
+#pragma unroll
+        for (int j = 0; j < NS; ++j)
+          if ((uint32_t)j >= keep) st[j] = pos;
+      }
+    };
+    for (;;) {
+      if (state < D.nskip && pos < n) {  // idle: jump to the next candidate byte
+        const int entry = pos;
+        pos = next_candidate(cm0, cm1, cm2, pos);
+        if (pos > n) pos = n;
+        if (USES && pos > entry) {
+          const unsigned b = byte_at(pos - 1);
+          unsigned cat = 0;
+          if (D.uses & 1) cat |= bm128(D.word0, D.word1, D.word2, D.word3, b);
+          if (D.uses & 2) cat |= (b == '\n') ? 2u : 0u;
+          state = (D.skippack >> (8 * cat)) & 255u;
+        }
+      }
+      uint32_t e;
+      if (pos >= n) {
+        e = D.t2[state * D.natoms + ATOM_EOT];
+      } else {
+        unsigned b = byte_at(pos);
+        for (;;) {
+#if defined(__HIP_DEVICE_COMPILE__)
+          const unsigned bn = byte_at(pos + 1);  // next byte in flight together with the table lookup
+#endif
+          e = D.t1[state * 128 + b];
+          if ((e & (E_STOP | E_COMPLEX)) || (e & E_STATE) < D.nskip || pos + 1 >= n) break;
+          effects(e);
+          state = e & E_STATE;
+          ++pos;
+#if defined(__HIP_DEVICE_COMPILE__)
+          b = bn;
+#else
+          b = byte_at(pos);
+#endif
+        }
+      }
+      if (e & E_COMPLEX) {
+        bail = true;
+        return done;
+      }
+      effects(e);
+      if (!(e & E_STOP)) {
+        state = e & E_STATE;
+        pos += 1;
+        continue;
+      }
+      // ---- this find() round is over
+      if (!matched) return done;
+      if (me == mb && mb == from) {  // zero-length repeat rule (replace.cu:91-93): generic path
+        bail = true;
+        return done;
+      }
+      emit(mb, me, 1);
+      ++done;
+      if (maxrepl >= 0 && done >= maxrepl) return done;
+      from = me;
+      pos = from;
+      matched = 0;
+#pragma unroll
+      for (int j = 0; j < NS; ++j) st[j] = from;
+      unsigned pc = 0;
+      if (USES) pc = from <= 0 ? 4u : cat_of_ascii(byte_at(from - 1));
+      state = D.init[MODE_RESTART * 8 + pc];
+    }
+  }
+  // true when the row can take scan_lean_replace (host-side check; kernels decide per tile)
+  CS_HD bool lean_ok() const {
+    if (D.nskip == 0 || !masks_fit()) return false;
+    for (int i = 0; i < n; ++i)
+      if (s[i] == 0 || s[i] >= 128) return false;
+    return true;
+  }
+  template <class Emit>
+  CS_HD int scan_lean_dispatch(int maxrepl, Emit&& emit, bool& bail) {
+    const int ns = D.img[12];
+    if (D.uses) {
+      if (ns <= 1) return scan_lean_replace<true, 1>(maxrepl, emit, bail);
+      if (ns <= 2) return scan_lean_replace<true, 2>(maxrepl, emit, bail);
+      return scan_lean_replace<true, kMaxSlots>(maxrepl, emit, bail);
+    }
+    if (ns <= 1) return scan_lean_replace<false, 1>(maxrepl, emit, bail);
+    if (ns <= 2) return scan_lean_replace<false, 2>(maxrepl, emit, bail);
+    return scan_lean_replace<false, kMaxSlots>(maxrepl, emit, bail);
+  }
+
   // emit(mb, me, reps) per match (K_REPLACE: reps > 1 for the zero-length repeat);
   // returns the number of matches (K_CONTAINS / K_MATCH: 0 or 1).
   template <int KIND, class Emit>
@@ -530,6 +654,30 @@ CS_HD int row_count_re(cstd::Tdfa& vm) {
 template <class Emit>
 CS_HD void row_replace_matches(cstd::Tdfa& vm, int maxrepl, Emit&& emit) {
   if (maxrepl == 0) return;
+#if !defined(__HIP_DEVICE_COMPILE__)
+  // host builds (tests/rowemu) route qualifying rows through the lean scan so that it is
+  // checked against the oracle with the same fuzz corpus; matches are buffered because
+  // a bail-out must leave no trace
+  if (vm.lean_ok()) {
+    int buf[3 * 64];
+    int cnt = 0;
+    bool bail = false, overflow = false;
+    vm.scan_lean_dispatch(maxrepl, [&](int mb, int me, int reps) {
+      if (cnt < 64) {
+        buf[3 * cnt] = mb;
+        buf[3 * cnt + 1] = me;
+        buf[3 * cnt + 2] = reps;
+        ++cnt;
+      } else {
+        overflow = true;
+      }
+    }, bail);
+    if (!bail && !overflow) {
+      for (int i = 0; i < cnt; ++i) emit(buf[3 * i], buf[3 * i + 1], buf[3 * i + 2]);
+      return;
+    }
+  }
+#endif
   vm.scan<cstd::Tdfa::K_REPLACE>(maxrepl, emit);
 }
 }  // namespace csvm

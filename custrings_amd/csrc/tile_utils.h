@@ -177,4 +177,133 @@ __device__ __forceinline__ void lds_copy_short(uint8_t* dbase, int di, const uin
   if (n > 8) lds_copy(dbase, di + 8, sbase, si + 8, n - 8);
 }
 
+
+// ---- persistent sub-tile stream with register prefetch ------------------------------
+// A persistent wave walks sub-tiles wid, wid + W, wid + 2W, ... (W = waves in the
+// grid, all co-resident).  While it works on one sub-tile out of LDS, the chars of
+// its next sub-tile are already in flight into registers (kPfChunks x 16 bytes per
+// lane) and the offsets of the one after that are being fetched, so every wave
+// keeps several KB of HBM reads outstanding at all times instead of starting each
+// sub-tile with two dependent round trips.
+constexpr int kPfChunks = 6;
+constexpr int kPfBytes = kPfChunks * 1024;  // largest (lead + span) one prefetch can hold
+
+struct TileOffs {
+  long long o0, o1;  // offsets[r0 + lane], offsets[r0 + lane + 1] (clamped to the sub-tile)
+};
+struct TileChars {
+  uint4 v[kPfChunks];
+};
+__device__ __forceinline__ long long rl64(long long v, int k) {
+  const int lo = __builtin_amdgcn_readlane((int)(v & 0xffffffffll), k);
+  const int hi = __builtin_amdgcn_readlane((int)(v >> 32), k);
+  return ((long long)hi << 32) | (unsigned int)lo;
+}
+__device__ __forceinline__ TileOffs load_tile_offsets(const int64_t* offsets, long long rows, long long sub, int lane) {
+  const long long r0 = sub * 64;
+  const int nrows = (int)min(64ll, rows - r0);
+  TileOffs t;
+  t.o0 = offsets[r0 + min(lane, nrows)];
+  t.o1 = offsets[r0 + min(lane + 1, nrows)];
+  return t;
+}
+// issues the loads of bytes [g0 - lead, g1) of `chars` (lead = distance to the previous
+// 16-byte boundary); nothing waits on them here
+__device__ __forceinline__ void issue_chars(const uint8_t* chars, long long g0, long long g1, int lane, TileChars& c) {
+  const int lead = (int)((uintptr_t)(chars + g0) & 15);
+  const uint8_t* src = chars + (g0 - lead);
+  const long long want = g1 - g0 + lead;
+  const int span = (int)(want < (long long)kPfBytes ? want : (long long)kPfBytes);
+#pragma unroll
+  for (int j = 0; j < kPfChunks; ++j) {
+    const int i = j * 1024 + lane * 16;
+    if (i < span) c.v[j] = *reinterpret_cast<const uint4*>(src + i);
+  }
+}
+__device__ __forceinline__ void stage_chars(uint8_t* lds_in, int span, int lane, const TileChars& c) {
+#pragma unroll
+  for (int j = 0; j < kPfChunks; ++j) {
+    const int i = j * 1024 + lane * 16;
+    if (i < span) *reinterpret_cast<uint4*>(lds_in + i) = c.v[j];
+  }
+}
+__device__ __forceinline__ void wave_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Decoupled look-back in two halves so that independent work (assembling the output
+// rows in LDS) runs between publishing this sub-tile's aggregate and needing the
+// predecessors': lookback_begin publishes and issues the first poll, lookback_end
+// consumes it (re-polling only if some predecessor had not published yet).
+__device__ __forceinline__ u64 lookback_begin(u64* status, long long tile, long long aggregate, int lane) {
+  u64* mine = status + tile;
+  if (lane == 0) status_store(mine, (tile == 0 ? kFlagInc : kFlagAgg) | ((u64)aggregate & kValMask));
+  const long long idx = tile - 1 - lane;
+  return idx >= 0 ? status_load(status + idx) : kFlagInc;
+}
+__device__ __forceinline__ long long lookback_end(u64* status, long long tile, long long aggregate, u64 first, int lane) {
+  if (tile == 0) return 0;
+  long long excl = 0;
+  long long t = tile - 1;
+  int spins = 0;
+  u64 v = first;
+  for (;;) {
+    const unsigned flag = (unsigned)(v >> 62);
+    const u64 not_ready = __ballot(flag == 0);
+    const u64 inc = __ballot(flag == 2);
+    const int first_inc = inc ? __builtin_ctzll(inc) : 64;
+    const u64 needed = first_inc < 63 ? ((2ull << first_inc) - 1) : ~0ull;
+    if (not_ready & needed) {
+      if (++spins > kSpinLimit) return -1;
+      __builtin_amdgcn_s_sleep(2);
+      const long long idx = t - lane;
+      v = idx >= 0 ? status_load(status + idx) : kFlagInc;
+      continue;
+    }
+    long long partw = (lane <= first_inc) ? (long long)(v & kValMask) : 0;
+    for (int d = 32; d > 0; d >>= 1) partw += __shfl_xor(partw, d, 64);
+    excl += partw;
+    if (first_inc < 64) break;
+    t -= 64;
+    const long long idx = t - lane;
+    v = idx >= 0 ? status_load(status + idx) : kFlagInc;
+  }
+  if (lane == 0) status_store(status + tile, kFlagInc | ((u64)(excl + aggregate) & kValMask));
+  return excl;
+}
+
+// Wave-cooperative flush of `total` bytes assembled at lds[0 ..) (lds 4-byte aligned) to
+// the arbitrarily aligned global address `dst`: whole 16-byte destination chunks are
+// composed from five aligned LDS dwords and a wave-uniform funnel shift; the up to 15
+// head and tail bytes go out one byte per lane.
+__device__ __forceinline__ void wave_flush_shift(uint8_t* dst, int total, const uint8_t* lds, int lane) {
+  const int olead = (int)((uintptr_t)dst & 15);
+  uint8_t* a0 = dst - olead;                        // 16-byte aligned
+  const int end = olead + total;                     // positions relative to a0
+  const int first_full = (olead + 15) & ~15;         // 0 or 16
+  const int last_full = end & ~15;
+  if (first_full >= last_full) {
+    for (int j = lane; j < total; j += 64) dst[j] = lds[j];
+    return;
+  }
+  const int head = first_full - olead;               // bytes before the first whole chunk
+  if (lane < head) dst[lane] = lds[lane];
+  const unsigned sh = (unsigned)(head & 3);
+  const uint32_t* w = reinterpret_cast<const uint32_t*>(lds) + (head >> 2);
+  for (int i = first_full + lane * 16; i < last_full; i += 64 * 16) {
+    const uint32_t* q = w + ((i - first_full) >> 2);
+    const uint32_t w0 = q[0], w1 = q[1], w2 = q[2], w3 = q[3], w4 = q[4];
+    uint4 o;
+    o.x = __builtin_amdgcn_alignbyte(w1, w0, sh);
+    o.y = __builtin_amdgcn_alignbyte(w2, w1, sh);
+    o.z = __builtin_amdgcn_alignbyte(w3, w2, sh);
+    o.w = __builtin_amdgcn_alignbyte(w4, w3, sh);
+    *reinterpret_cast<uint4*>(a0 + i) = o;
+  }
+  const int tail0 = last_full - olead;               // output index of the first tail byte
+  if (tail0 + lane < total) dst[tail0 + lane] = lds[tail0 + lane];
+}
+
 }  // namespace cstile
