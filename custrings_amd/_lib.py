@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_PATH = os.path.join(_HERE, "libcustrings_amd.so")
+_PATH = os.environ.get("CS_LIB_PATH") or os.path.join(_HERE, "libcustrings_amd.so")  # CS_LIB_PATH: instrumented dev builds
 
 if not os.path.exists(_PATH):
     raise ImportError(

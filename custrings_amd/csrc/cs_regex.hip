@@ -421,6 +421,18 @@ struct StreamArgs {
   int cap_in, cap_out, tbl_bytes;
   int debug;
 };
+#if defined(CS_PHASE_PROF)
+#define CS_PHASE_MARK(k)                                  \
+  do {                                                    \
+    const unsigned long long t_ = __builtin_readcyclecounter(); \
+    phase_acc[k] += t_ - phase_t;                         \
+    phase_t = t_;                                         \
+  } while (0)
+#else
+#define CS_PHASE_MARK(k) \
+  do {                   \
+  } while (0)
+#endif
 template <bool IN_LDS>
 __global__ void __launch_bounds__(256, 3) k_tdfa_replace_stream(StreamArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
@@ -450,11 +462,34 @@ __global__ void __launch_bounds__(256, 3) k_tdfa_replace_stream(StreamArgs a) {
 #pragma unroll
   for (int j = 0; j < cstile::kPfChunks; ++j) pf.v[j] = make_uint4(0, 0, 0, 0);
   cstile::issue_chars(in.chars, cstile::rl64(cur.o0, 0), cstile::rl64(cur.o1, 63), lane, pf);
+  // The previous sub-tile's output stays assembled in lds_out while this one is scanned;
+  // its look-back completes afterwards, when every predecessor's aggregate has long been
+  // published, so waves do not wait on each other's scans.
+  long long p_tile = -1;
+  int p_total = 0, p_lo = 0, p_len = 0;
+#if defined(CS_PHASE_PROF)
+  unsigned long long phase_acc[6] = {0, 0, 0, 0, 0, 0};
+  unsigned long long phase_t = __builtin_readcyclecounter();
+#endif
+  auto finish_pending = [&](cstile::u64 first) {
+    long long gb = (a.debug & 8) ? p_tile * 4096 : cstile::lookback_end(a.status, p_tile, p_total, first, lane);
+    if (gb < 0) {
+      if (lane == 0) atomicOr(a.error, 1u);
+      gb = 0;
+    }
+    const long long pr0 = p_tile * 64;
+    const int pn = (int)min(64ll, in.rows - pr0);
+    if (lane < pn) a.out_off[pr0 + lane] = gb + p_lo;
+    if (lane == pn - 1 && pr0 + pn == in.rows) a.out_off[in.rows] = gb + p_lo + p_len;
+    if (!(a.debug & 4)) cstile::wave_flush_shift(a.out_chars + gb, p_total, lds_out, lane);
+  };
   for (;;) {
     const long long r0 = tile * 64;
     const int nrows = (int)min(64ll, in.rows - r0);
     const long long g0 = cstile::rl64(cur.o0, 0), g1 = cstile::rl64(cur.o1, 63);
     const bool live = lane < nrows && row_is_valid(in.validity, r0 + lane);
+    cstile::u64 p_first = 0;
+    if (p_tile >= 0 && !(a.debug & (8 | 64))) p_first = cstile::lookback_poll(a.status, p_tile, lane);
     const int rbeg = (int)(cur.o0 - g0);
     const int n = live ? (int)(cur.o1 - cur.o0) : 0;
     const int lead = (int)((uintptr_t)(in.chars + g0) & 15);
@@ -480,6 +515,7 @@ __global__ void __launch_bounds__(256, 3) k_tdfa_replace_stream(StreamArgs a) {
       if (tile + 2 * W < a.nsub) nxt = cstile::load_tile_offsets(in.offsets, in.rows, tile + 2 * W, lane);
     }
     cstile::wave_lds_fence();
+    CS_PHASE_MARK(0);
 
     int rec_mb[kMaxRec], rec_me[kMaxRec], rec_reps[kMaxRec];
     int nm = 0;
@@ -516,6 +552,7 @@ __global__ void __launch_bounds__(256, 3) k_tdfa_replace_stream(StreamArgs a) {
         }
       }
     }
+    CS_PHASE_MARK(1);
     bad |= __any(nm > kMaxRec);
     const int incl = csdev::wave_inclusive_scan(out_len);
     const int lo = incl - out_len;
@@ -527,8 +564,13 @@ __global__ void __launch_bounds__(256, 3) k_tdfa_replace_stream(StreamArgs a) {
         atomicOr(a.error, 1u);
         cstile::status_store(a.status + tile, cstile::kFlagInc);
       }
+      if (p_tile >= 0) finish_pending(p_first);
+      p_tile = -1;
     } else {
-      cstile::u64 first = (a.debug & 8) ? 0 : cstile::lookback_begin(a.status, tile, total, lane);
+      if (!(a.debug & 8)) cstile::lookback_publish(a.status, tile, total, lane);
+      CS_PHASE_MARK(2);
+      if (p_tile >= 0) finish_pending((a.debug & 64) ? cstile::lookback_poll(a.status, p_tile, lane) : p_first);
+      CS_PHASE_MARK(3);
       if (live && !(a.debug & 2)) {
         int oi = lo;                 // byte index into lds_out
         const int pi = lead + rbeg;  // byte index of the row in lds_in
@@ -544,21 +586,22 @@ __global__ void __launch_bounds__(256, 3) k_tdfa_replace_stream(StreamArgs a) {
           }
         cstile::lds_copy(lds_out, oi, lds_in, pi + copied, n - copied);
       }
-      long long gb = (a.debug & 8) ? tile * 4096 : cstile::lookback_end(a.status, tile, total, first, lane);
-      if (gb < 0) {
-        if (lane == 0) atomicOr(a.error, 1u);
-        gb = 0;
-      }
-      if (lane < nrows) a.out_off[r0 + lane] = gb + lo;
-      if (lane == nrows - 1 && r0 + nrows == in.rows) a.out_off[in.rows] = gb + lo + out_len;
-      if (!(a.debug & 4)) {
-        cstile::wave_lds_fence();
-        cstile::wave_flush_shift(a.out_chars + gb, total, lds_out, lane);
-      }
+      cstile::wave_lds_fence();
+      CS_PHASE_MARK(4);
+      p_tile = tile;
+      p_total = total;
+      p_lo = lo;
+      p_len = out_len;
     }
     if (!has_next) break;
     tile += W;
   }
+  if (p_tile >= 0) finish_pending((a.debug & 8) ? 0 : cstile::lookback_poll(a.status, p_tile, lane));
+#if defined(CS_PHASE_PROF)
+  CS_PHASE_MARK(5);
+  if (lane == 0)
+    for (int k = 0; k < 6; ++k) atomicAdd(reinterpret_cast<unsigned long long*>(a.error) + 1 + k, phase_acc[k]);
+#endif
 }
 
 
@@ -812,8 +855,8 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
         sa.out_off = ptr<int64_t>(out_off);
         sa.out_chars = ptr<uint8_t>(out_chars);
         const int64_t nsub1 = (rows + 63) / 64;
-        Buf status = dev_alloc(sizeof(cstile::u64) * nsub1 + 16, s);
-        CS_HIP(hipMemsetAsync(status->p, 0, sizeof(cstile::u64) * nsub1 + 16, s));
+        Buf status = dev_alloc(sizeof(cstile::u64) * nsub1 + 128, s);
+        CS_HIP(hipMemsetAsync(status->p, 0, sizeof(cstile::u64) * nsub1 + 128, s));
         sa.status = ptr<cstile::u64>(status);
         sa.error = reinterpret_cast<unsigned*>(ptr<cstile::u64>(status) + nsub1);
         sa.nsub = nsub1;
@@ -835,6 +878,16 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
         CS_HIP(hipMemcpyAsync(host, ptr<int64_t>(out_off) + rows, 8, hipMemcpyDeviceToHost, s));
         CS_HIP(hipMemcpyAsync(host + 1, sa.error, 4, hipMemcpyDeviceToHost, s));
         CS_HIP(hipStreamSynchronize(s));
+#if defined(CS_PHASE_PROF)
+        {
+          unsigned long long ph[6];
+          CS_HIP(hipMemcpy(ph, reinterpret_cast<unsigned long long*>(sa.error) + 1, sizeof(ph), hipMemcpyDeviceToHost));
+          const double waves = (double)grid * 4;
+          fprintf(stderr, "phase cycles/wave-iteration: stage %.0f scan %.0f wscan+publish %.0f finish_prev %.0f assemble %.0f tail %.0f (iters/wave %.1f)\n",
+                  ph[0] / waves / (nsub1 / waves), ph[1] / waves / (nsub1 / waves), ph[2] / waves / (nsub1 / waves),
+                  ph[3] / waves / (nsub1 / waves), ph[4] / waves / (nsub1 / waves), ph[5] / waves / (nsub1 / waves), nsub1 / waves);
+        }
+#endif
         if ((uint32_t)host[1] == 0 || sa.debug) {
           o->offsets = out_off;
           o->chars = out_chars;

@@ -237,11 +237,16 @@ __device__ __forceinline__ void wave_lds_fence() {
 // rows in LDS) runs between publishing this sub-tile's aggregate and needing the
 // predecessors': lookback_begin publishes and issues the first poll, lookback_end
 // consumes it (re-polling only if some predecessor had not published yet).
-__device__ __forceinline__ u64 lookback_begin(u64* status, long long tile, long long aggregate, int lane) {
-  u64* mine = status + tile;
-  if (lane == 0) status_store(mine, (tile == 0 ? kFlagInc : kFlagAgg) | ((u64)aggregate & kValMask));
+__device__ __forceinline__ void lookback_publish(u64* status, long long tile, long long aggregate, int lane) {
+  if (lane == 0) status_store(status + tile, (tile == 0 ? kFlagInc : kFlagAgg) | ((u64)aggregate & kValMask));
+}
+__device__ __forceinline__ u64 lookback_poll(const u64* status, long long tile, int lane) {
   const long long idx = tile - 1 - lane;
   return idx >= 0 ? status_load(status + idx) : kFlagInc;
+}
+__device__ __forceinline__ u64 lookback_begin(u64* status, long long tile, long long aggregate, int lane) {
+  lookback_publish(status, tile, aggregate, lane);
+  return lookback_poll(status, tile, lane);
 }
 __device__ __forceinline__ long long lookback_end(u64* status, long long tile, long long aggregate, u64 first, int lane) {
   if (tile == 0) return 0;
