@@ -313,6 +313,34 @@ __global__ void k_max_span64(const int64_t* __restrict__ offsets, int64_t rows, 
   int m = block_reduce_max(v);
   if (threadIdx.x == 0 && m) atomicMax(out, (unsigned long long)m);
 }
+// Number of 256-thread workgroups of `kern` that are resident at once on this device
+// (capped by `wanted`): the persistent kernels' look-back needs every wave of the grid
+// to be running.
+unsigned resident_grid(const void* kern, size_t lds, int64_t wanted) {
+  // the occupancy query costs about a millisecond: remember the answers
+  static std::mutex mu;
+  static std::map<std::pair<const void*, size_t>, std::pair<int, int>> cache;
+  int cus = 0, per = 0;
+  {
+    std::lock_guard<std::mutex> g(mu);
+    auto it = cache.find({kern, lds});
+    if (it == cache.end()) {
+      int dev = 0;
+      CS_HIP(hipGetDevice(&dev));
+      CS_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+      CS_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, kern, 256, lds));
+      cache[{kern, lds}] = {cus, per};
+    } else {
+      cus = it->second.first;
+      per = it->second.second;
+    }
+  }
+  if (per < 1) per = 1;
+  if (const char* e = getenv("CS_STREAM_BLOCKS_PER_CU")) per = std::max(1, std::min(per, atoi(e)));
+  const int64_t cap = (int64_t)cus * per;
+  return (unsigned)std::max<int64_t>(1, std::min<int64_t>(cap, wanted));
+}
+
 int64_t max_span64(const cs_column* c, hipStream_t s) {
   if (c->max_span64 >= 0) return c->max_span64;
   if (c->rows == 0) return c->max_span64 = 0;

@@ -123,6 +123,9 @@ int64_t count_nulls(const cs_column* c, hipStream_t s);
 // Largest byte span of 64 consecutive rows starting at a multiple of 64 (cached
 // in the column; sizes the LDS staging buffers of the tile kernels).
 int64_t max_span64(const cs_column* c, hipStream_t s);
+// Workgroups (256 threads, `lds` dynamic bytes) of `kern` resident at once on the device,
+// capped by `wanted`: grid size of the persistent tile kernels.
+unsigned resident_grid(const void* kern, size_t lds, int64_t wanted);
 // Row-wise concatenation of columns into one new column.
 cs_column* concat_columns(const std::vector<const cs_column*>& cols, hipStream_t s);
 

@@ -421,18 +421,6 @@ struct StreamArgs {
   int cap_in, cap_out, tbl_bytes;
   int debug;
 };
-#if defined(CS_PHASE_PROF)
-#define CS_PHASE_MARK(k)                                  \
-  do {                                                    \
-    const unsigned long long t_ = __builtin_readcyclecounter(); \
-    phase_acc[k] += t_ - phase_t;                         \
-    phase_t = t_;                                         \
-  } while (0)
-#else
-#define CS_PHASE_MARK(k) \
-  do {                   \
-  } while (0)
-#endif
 template <bool IN_LDS>
 __global__ void __launch_bounds__(256, 3) k_tdfa_replace_stream(StreamArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
@@ -605,27 +593,6 @@ __global__ void __launch_bounds__(256, 3) k_tdfa_replace_stream(StreamArgs a) {
 }
 
 
-// Number of 256-thread workgroups of `kern` that are resident at once on this device
-// (capped by `wanted`): the persistent kernels' look-back needs every wave of the grid
-// to be running.
-unsigned resident_grid(const void* kern, size_t lds, int64_t wanted) {
-  static const void* c_kern = nullptr;
-  static size_t c_lds = 0;
-  static int c_cus = 0, c_per = 0;
-  if (c_kern != kern || c_lds != lds) {  // the occupancy query costs about a millisecond
-    int dev = 0;
-    CS_HIP(hipGetDevice(&dev));
-    CS_HIP(hipDeviceGetAttribute(&c_cus, hipDeviceAttributeMultiprocessorCount, dev));
-    CS_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&c_per, kern, 256, lds));
-    c_kern = kern;
-    c_lds = lds;
-  }
-  int cus = c_cus, per = c_per;
-  if (per < 1) per = 1;
-  if (const char* e = getenv("CS_STREAM_BLOCKS_PER_CU")) per = std::max(1, std::min(per, atoi(e)));
-  const int64_t cap = (int64_t)cus * per;
-  return (unsigned)std::max<int64_t>(1, std::min<int64_t>(cap, wanted));
-}
 
 struct TPlan {
   TLaunch d;

@@ -108,7 +108,8 @@ __device__ __forceinline__ SubTile load_subtile(const ColView& in, long long sub
 // delimiters as a 96-bit mask held in registers, built in straight-line code from
 // 24 aligned words; the walk is then ctz + clear-lowest-bit per token.  Longer rows
 // search word by word.
-struct Tokens {
+template <bool MASKED_ONLY>
+struct TokensT {
   RowWords w;
   uint32_t dpat;
   int cursor, k, limit;  // limit: token index that swallows the rest (maxsplit), or -1
@@ -116,10 +117,11 @@ struct Tokens {
   unsigned long long m_lo;  // delimiter bits 0..63 (bit q = byte at row offset q - sa)
   uint32_t m_hi;            // bits 64..95
   int sa;
-  __device__ __forceinline__ Tokens(const uint8_t* base, int beg, int n, bool live, uint32_t d, int tokens)
+  __device__ __forceinline__ TokensT(const uint8_t* base, int beg, int n, bool live, uint32_t d, int tokens)
       : w(base, beg, n), dpat(d), cursor(0), k(0), limit(tokens > 0 ? tokens - 1 : -1), more(live), masked(false),
         m_lo(0), m_hi(0), sa(beg & 3) {
-    if (__all(!live || n + sa <= 96)) {  // wave-uniform choice keeps the unrolled build convergent
+    // (MASKED_ONLY: the caller guarantees that every row fits the 96-bit mask)
+    if (MASKED_ONLY || __all(!live || n + sa <= 96)) {  // wave-uniform choice keeps the unrolled build convergent
       masked = true;
       const uint32_t* words = reinterpret_cast<const uint32_t*>(base) + (beg >> 2);
       uint32_t r[3] = {0, 0, 0};
@@ -159,7 +161,7 @@ struct Tokens {
       hi = w.n;
       more = false;
     } else {
-      hi = masked ? next_delim() : w.find(cursor, dpat);
+      hi = (MASKED_ONLY || masked) ? next_delim() : w.find(cursor, dpat);
       if (hi >= w.n) more = false;
       else cursor = hi + 1;
     }
@@ -167,6 +169,7 @@ struct Tokens {
     return true;
   }
 };
+using Tokens = TokensT<false>;
 
 struct MeasureArgs {
   ColView in;
@@ -174,7 +177,7 @@ struct MeasureArgs {
   int tokens, cap;
   long long nsub;
   int32_t* colsum;  // [kMaxCols][nsub]
-  int* max_count;
+  int* max_count;   // [0] most tokens in a row, [1] most bytes one column receives from one sub-tile, [2] longest row
 };
 __global__ void __launch_bounds__(256) k_split_measure(MeasureArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
@@ -184,7 +187,7 @@ __global__ void __launch_bounds__(256) k_split_measure(MeasureArgs a) {
   if (sub >= a.nsub) return;
   SubTile t = load_subtile(a.in, sub, lds_in, lane);
   Tokens tk(lds_in, t.lead + t.rbeg, t.n, t.live, a.dpat, a.tokens);
-  int count = 0;
+  int count = 0, widest = 0;
   for (int k = 0;; ++k) {
     int lo, hi;
     const bool has = tk.next(lo, hi);
@@ -193,8 +196,14 @@ __global__ void __launch_bounds__(256) k_split_measure(MeasureArgs a) {
     if (k < kMaxCols) {
       const int sum = wave_reduce_sum(has ? hi - lo : 0);
       if (lane == 0) a.colsum[(long long)k * a.nsub + sub] = sum;
+      widest = max(widest, sum);
     }
   }
+  if (lane == 0 && widest > __hip_atomic_load(a.max_count + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+    atomicMax(a.max_count + 1, widest);
+  const int longest = wave_reduce_max(t.n);
+  if (lane == 0 && longest > __hip_atomic_load(a.max_count + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+    atomicMax(a.max_count + 2, longest);
   const int m = wave_reduce_max(count);
   // same-address atomics serialise in L2 (about 10 ns each): only waves that would
   // raise the maximum issue one; a stale (smaller) read merely costs an extra atomic
@@ -272,6 +281,176 @@ __global__ void __launch_bounds__(256) k_split_emit(EmitArgs a) {
   }
 }
 
+
+// ---- persistent emit (tile_utils.h: sub-tile stream) ------------------------------------
+// Same outputs as k_split_emit.  Differences: persistent waves with the next sub-tile's chars
+// and column positions prefetched; one column at a time is assembled in a small LDS region
+// (sized by the largest per-sub-tile column contribution the measure pass saw) and flushed
+// right away, two regions alternating, so a wave needs cap_in + 2 * cap_col bytes of LDS
+// instead of 2 * cap_in + 1 KB and twice as many waves are resident; short tokens reach the
+// region as three ds_or_b32 of the funnel-shifted token instead of byte stores.
+struct Emit2Args {
+  ColView in;
+  uint32_t dpat;
+  int tokens, cap_in, cap_col, ncols;
+  long long nsub;
+  const ColOut* cols;
+  unsigned long long* prof;  // instrumented builds: 6 cycle counters
+};
+__device__ __forceinline__ void lds_or(uint32_t* p, uint32_t v) {
+  __hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+}
+#ifndef CS_EMIT2_WAVES
+#define CS_EMIT2_WAVES 4
+#endif
+__global__ void __launch_bounds__(256, CS_EMIT2_WAVES) k_split_emit2(Emit2Args a) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  uint8_t* lds_in = reinterpret_cast<uint8_t*>(smem) + (size_t)wv * (a.cap_in + 32 + 2 * a.cap_col);
+  uint8_t* region0 = lds_in + a.cap_in + 32;
+  // each wave owns a contiguous run of sub-tiles: its pieces of every output column are
+  // contiguous too, so the cache lines that two neighbouring sub-tiles share are completed in
+  // one L2 instead of being written half-filled from two XCDs
+  const long long waves = (long long)gridDim.x * 4;
+  const long long per = (a.nsub + waves - 1) / waves;
+  constexpr long long W = 1;
+  long long tile = ((long long)blockIdx.x * 4 + wv) * per;
+  const long long tile_end = min(a.nsub, tile + per);
+  if (tile >= tile_end) return;
+  const ColView& in = a.in;
+  // lane k keeps column k's destination
+  uint8_t* my_chars = nullptr;
+  int64_t* my_off = nullptr;
+  uint8_t* my_valid = nullptr;
+  const int64_t* my_basep = nullptr;
+  if (lane < a.ncols) {
+    const ColOut c = a.cols[lane];
+    my_chars = c.chars;
+    my_off = c.offsets;
+    my_valid = c.validity;
+    my_basep = c.base;
+  }
+  cstile::TileOffs cur = cstile::load_tile_offsets(in.offsets, in.rows, tile, lane);
+  cstile::TileOffs nxt = cur;
+  if (tile + W < tile_end) nxt = cstile::load_tile_offsets(in.offsets, in.rows, tile + W, lane);
+  long long cb0 = 0, cb1 = 0;  // this column's byte position before / after the current sub-tile
+  if (lane < a.ncols) {
+    cb0 = my_basep[tile];
+    cb1 = my_basep[tile + 1];
+  }
+  cstile::TileChars pf;
+#pragma unroll
+  for (int j = 0; j < cstile::kPfChunks; ++j) pf.v[j] = make_uint4(0, 0, 0, 0);
+  cstile::issue_chars(in.chars, cstile::rl64(cur.o0, 0), cstile::rl64(cur.o1, 63), lane, pf);
+#if defined(CS_PHASE_PROF)
+  unsigned long long phase_acc[6] = {0, 0, 0, 0, 0, 0};
+  unsigned long long phase_t = __builtin_readcyclecounter();
+#endif
+  for (;;) {
+    const long long r0 = tile * 64;
+    const int nrows = (int)min(64ll, in.rows - r0);
+    const long long g0 = cstile::rl64(cur.o0, 0), g1 = cstile::rl64(cur.o1, 63);
+    const bool live = lane < nrows && row_is_valid(in.validity, r0 + lane);
+    const int rbeg = (int)(cur.o0 - g0);
+    const int n = live ? (int)(cur.o1 - cur.o0) : 0;
+    const int lead = (int)((uintptr_t)(in.chars + g0) & 15);
+    const int want = (int)(g1 - g0) + lead;
+    cstile::stage_chars(lds_in, want, lane, pf);
+    const long long my_base = cb0;
+    const int my_sum = (int)(cb1 - cb0);
+    const int my_lead = (int)((uintptr_t)(my_chars + my_base) & 15);
+    const bool has_next = tile + W < tile_end;
+    if (has_next) {
+      cur = nxt;
+      cstile::issue_chars(in.chars, cstile::rl64(cur.o0, 0), cstile::rl64(cur.o1, 63), lane, pf);
+      if (lane < a.ncols) {
+        cb0 = my_basep[tile + W];
+        cb1 = my_basep[tile + W + 1];
+      }
+      if (tile + 2 * W < tile_end) nxt = cstile::load_tile_offsets(in.offsets, in.rows, tile + 2 * W, lane);
+    }
+    cstile::wave_lds_fence();
+    CS_PHASE_MARK(0);
+
+    TokensT<true> tk(lds_in, lead + rbeg, n, live, a.dpat, a.tokens);
+    CS_PHASE_MARK(1);
+    const bool last_tile = r0 + nrows == in.rows;
+    unsigned long long my_vmask = 0;
+    for (int k = 0; k < a.ncols; ++k) {
+      uint8_t* region = region0 + (k & 1) * a.cap_col;
+      int lo = 0, hi = 0;
+      const bool has = tk.next(lo, hi);
+      const int len = has ? hi - lo : 0;
+      const int incl = wave_inclusive_scan(len);
+      const int pre = incl - len;
+      const long long cbase = cstile::rl64(my_base, k);
+      cstile::gptr<int64_t> coff = cstile::as_global(reinterpret_cast<int64_t*>(cstile::rl64((long long)(uintptr_t)my_off, k)));
+      const int clead = rl(my_lead, k);
+      const int csum = rl(my_sum, k);
+      if (lane < nrows) coff[r0 + lane] = cbase + pre;
+      if (last_tile && lane == nrows - 1) coff[in.rows] = cbase + incl;
+      const unsigned long long vmask = __ballot(has);
+      if (lane == k) my_vmask = vmask;
+      CS_PHASE_MARK(2);
+      // zero the region (16-byte chunks covering lead + bytes + 8 of slack for the last token's third dword)
+      const int zend = clead + csum + 20;
+      for (int i = lane * 16; i < zend; i += 64 * 16) *reinterpret_cast<uint4*>(region + i) = make_uint4(0, 0, 0, 0);
+      if (has) {
+        // first 16 bytes of the token, cut to its length and funnel-shifted to the destination's
+        // byte phase: five dwords OR-ed into the zeroed region (longer tokens copy the rest)
+        const int ti = lead + rbeg + lo;
+        const uint32_t* sp = reinterpret_cast<const uint32_t*>(lds_in) + (ti >> 2);
+        const unsigned sh = (unsigned)(ti & 3);
+        const uint32_t w0 = sp[0], w1 = sp[1], w2 = sp[2], w3 = sp[3], w4 = sp[4];
+        unsigned long long tlo = ((unsigned long long)__builtin_amdgcn_alignbyte(w2, w1, sh) << 32) |
+                                 __builtin_amdgcn_alignbyte(w1, w0, sh);  // (alignbyte with shift 0 returns the low word)
+        unsigned long long thi = ((unsigned long long)__builtin_amdgcn_alignbyte(w4, w3, sh) << 32) |
+                                 __builtin_amdgcn_alignbyte(w3, w2, sh);
+        if (len < 8) {
+          tlo &= ~(~0ull << (8 * len));
+          thi = 0;
+        } else if (len < 16) {
+          thi &= ~(~0ull << (8 * (len - 8)));
+        }
+        const uint32_t t0 = (uint32_t)tlo, t1 = (uint32_t)(tlo >> 32), t2 = (uint32_t)thi, t3 = (uint32_t)(thi >> 32);
+        const int di = clead + pre;
+        const unsigned sd = (unsigned)(di & 3);
+        uint32_t* dp = reinterpret_cast<uint32_t*>(region) + (di >> 2);
+        uint32_t d0 = t0, d1 = t1, d2 = t2, d3 = t3, d4 = 0;
+        if (sd) {
+          const unsigned up = 4 - sd;  // (hi:lo) >> 8 * up == lo's top sd bytes below hi's low bytes
+          d0 = t0 << (8 * sd);
+          d1 = __builtin_amdgcn_alignbyte(t1, t0, up);
+          d2 = __builtin_amdgcn_alignbyte(t2, t1, up);
+          d3 = __builtin_amdgcn_alignbyte(t3, t2, up);
+          d4 = t3 >> (8 * up);
+        }
+        lds_or(dp, d0);
+        lds_or(dp + 1, d1);
+        if (__any(len + (int)sd > 8)) {
+          lds_or(dp + 2, d2);
+          lds_or(dp + 3, d3);
+          lds_or(dp + 4, d4);
+        }
+        if (len > 16) cstile::lds_copy(region, di + 16, lds_in, ti + 16, len - 16);
+      }
+      cstile::wave_lds_fence();
+      CS_PHASE_MARK(3);
+      uint8_t* dst = reinterpret_cast<uint8_t*>(cstile::rl64((long long)(uintptr_t)my_chars, k)) + cbase;
+      cstile::wave_flush(dst, csum, region, clead, lane);
+      CS_PHASE_MARK(4);
+    }
+    if (lane < a.ncols) *cstile::as_global(reinterpret_cast<unsigned long long*>(my_valid + tile * 8)) = my_vmask;
+    if (!has_next) break;
+    tile += W;
+  }
+#if defined(CS_PHASE_PROF)
+  CS_PHASE_MARK(5);
+  if (lane == 0 && a.prof)
+    for (int k = 0; k < 6; ++k) atomicAdd(a.prof + k, phase_acc[k]);
+#endif
+}
+
 }  // namespace
 
 namespace cs {
@@ -290,18 +469,20 @@ bool split_fast(const cs_column* col, unsigned char delim, int tokens, hipStream
 
   Buf colsum = dev_alloc(sizeof(int32_t) * nsub * kMaxCols, s);
   CS_HIP(hipMemsetAsync(colsum->p, 0, sizeof(int32_t) * nsub * kMaxCols, s));  // columns a sub-tile never reaches
-  Buf mx = dev_alloc(sizeof(int), s);
-  CS_HIP(hipMemsetAsync(mx->p, 0, sizeof(int), s));
+  Buf mx = dev_alloc(4 * sizeof(int), s);
+  CS_HIP(hipMemsetAsync(mx->p, 0, 4 * sizeof(int), s));
   MeasureArgs ma{view_of(col), dpat, tokens, cap_in, nsub, ptr<int32_t>(colsum), ptr<int>(mx)};
   {
     ProfScope ps("k_split_measure", s);
     hipLaunchKernelGGL(k_split_measure, dim3(grid), dim3(256), (size_t)(cap_in + 32) * 4, s, ma);
   }
   CS_HIP(hipGetLastError());
-  int* hmx = (int*)pinned_scratch(sizeof(int));
-  CS_HIP(hipMemcpyAsync(hmx, mx->p, sizeof(int), hipMemcpyDeviceToHost, s));
+  int* hmx = (int*)pinned_scratch(4 * sizeof(int));
+  CS_HIP(hipMemcpyAsync(hmx, mx->p, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
   CS_HIP(hipStreamSynchronize(s));
-  const int ncols = *hmx;
+  const int ncols = hmx[0];
+  const int widest = hmx[1];
+  const int longest_row = hmx[2];
   if (ncols == 0 || ncols > kMaxCols) return false;  // all-null column / too many columns: generic path
 
   // per column: position of every sub-tile in the column's chars buffer
@@ -323,6 +504,38 @@ bool split_fast(const cs_column* col, unsigned char delim, int tokens, hipStream
   }
   Buf d_outs = dev_alloc(sizeof(ColOut) * ncols, s);
   CS_HIP(hipMemcpyAsync(d_outs->p, outs.data(), sizeof(ColOut) * ncols, hipMemcpyHostToDevice, s));
+  const int cap_col = (widest + 64 + 15) & ~15;
+  if (cap_in <= cstile::kPfBytes && longest_row + 3 <= 96 && !getenv("CS_SPLIT_OLD_EMIT")) {
+    Emit2Args e2{view_of(col), dpat, tokens, cap_in, cap_col, ncols, nsub, ptr<const ColOut>(d_outs), nullptr};
+#if defined(CS_PHASE_PROF)
+    Buf profbuf = dev_alloc(64, s);
+    CS_HIP(hipMemsetAsync(profbuf->p, 0, 64, s));
+    e2.prof = ptr<unsigned long long>(profbuf);
+#endif
+    const size_t lds2 = (size_t)(cap_in + 32 + 2 * cap_col) * 4;
+    if (lds2 <= 150 * 1024) {
+      if (lds2 > 48 * 1024)
+        CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_split_emit2),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+      const unsigned g2 = resident_grid(reinterpret_cast<const void*>(&k_split_emit2), lds2, (nsub + 3) / 4);
+      {
+        ProfScope ps("k_split_emit", s);
+        hipLaunchKernelGGL(k_split_emit2, dim3(g2), dim3(256), lds2, s, e2);
+      }
+      CS_HIP(hipGetLastError());
+      CS_HIP(hipStreamSynchronize(s));  // `outs` / `base` lifetime
+#if defined(CS_PHASE_PROF)
+      {
+        unsigned long long ph[6];
+        CS_HIP(hipMemcpy(ph, e2.prof, sizeof(ph), hipMemcpyDeviceToHost));
+        const double it = (double)nsub;
+        fprintf(stderr, "emit2 cycles/wave-iteration: stage %.0f masks %.0f col-walk+scan+offsets %.0f col-assemble %.0f col-flush %.0f tail %.0f | grid %u lds %zu cap_col %d\n",
+                ph[0] / it, ph[1] / it, ph[2] / it, ph[3] / it, ph[4] / it, ph[5] / it, g2, lds2, cap_col);
+      }
+#endif
+      return true;
+    }
+  }
   EmitArgs ea{view_of(col), dpat, tokens, cap_in, cap_out, ncols, nsub, ptr<const ColOut>(d_outs)};
   const size_t lds = (size_t)(cap_in + cap_out + 64) * 4;
   if (lds > 48 * 1024)

@@ -17,7 +17,31 @@
 
 #include "device_utils.h"
 
+// per-phase cycle accounting of the persistent kernels (instrumented builds only: make prof)
+#if defined(CS_PHASE_PROF)
+#define CS_PHASE_MARK(k)                                  \
+  do {                                                    \
+    const unsigned long long t_ = __builtin_readcyclecounter(); \
+    phase_acc[k] += t_ - phase_t;                         \
+    phase_t = t_;                                         \
+  } while (0)
+#else
+#define CS_PHASE_MARK(k) \
+  do {                   \
+  } while (0)
+#endif
+
 namespace cstile {
+
+// Pointers that went through readlane / integer arithmetic lose their address space and
+// would be accessed with flat instructions; these casts put them back in global memory.
+template <class T>
+using gptr = __attribute__((address_space(1))) T*;
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));  // plain vector: assignable through any address space
+template <class T>
+__device__ __forceinline__ gptr<T> as_global(T* p) {
+  return (gptr<T>)p;
+}
 
 constexpr int kTileRows = 256;
 constexpr unsigned long long kFlagAgg = 1ull << 62, kFlagInc = 2ull << 62, kValMask = (1ull << 62) - 1;
@@ -112,7 +136,7 @@ __device__ __forceinline__ void flush_out(uint8_t* dst, int total, const uint8_t
 // chunks line up in both address spaces.  Head and tail bytes (up to 15 each) are
 // stored one byte per LANE (two store instructions), never in a per-lane loop.
 __device__ __forceinline__ void wave_flush(uint8_t* dst, int total, const uint8_t* lds, int lead, int lane) {
-  uint8_t* a0 = dst - lead;  // 16-byte aligned
+  gptr<uint8_t> a0 = as_global(dst - lead);  // 16-byte aligned
   const int end = lead + total;
   const int first_full = (lead + 15) & ~15;       // first chunk boundary at or after the start
   const int last_full = end & ~15;                // end of the last whole chunk
@@ -122,7 +146,7 @@ __device__ __forceinline__ void wave_flush(uint8_t* dst, int total, const uint8_
   }
   if (lead + lane < first_full) a0[lead + lane] = lds[lead + lane];
   for (int i = first_full + lane * 16; i < last_full; i += 64 * 16)
-    *reinterpret_cast<uint4*>(a0 + i) = *reinterpret_cast<const uint4*>(lds + i);
+    *(gptr<u32x4>)(a0 + i) = *reinterpret_cast<const u32x4*>(lds + i);
   if (last_full + lane < end) a0[last_full + lane] = lds[last_full + lane];
 }
 
@@ -285,30 +309,31 @@ __device__ __forceinline__ long long lookback_end(u64* status, long long tile, l
 // head and tail bytes go out one byte per lane.
 __device__ __forceinline__ void wave_flush_shift(uint8_t* dst, int total, const uint8_t* lds, int lane) {
   const int olead = (int)((uintptr_t)dst & 15);
-  uint8_t* a0 = dst - olead;                        // 16-byte aligned
+  gptr<uint8_t> a0 = as_global(dst - olead);         // 16-byte aligned
+  gptr<uint8_t> gdst = as_global(dst);
   const int end = olead + total;                     // positions relative to a0
   const int first_full = (olead + 15) & ~15;         // 0 or 16
   const int last_full = end & ~15;
   if (first_full >= last_full) {
-    for (int j = lane; j < total; j += 64) dst[j] = lds[j];
+    for (int j = lane; j < total; j += 64) gdst[j] = lds[j];
     return;
   }
   const int head = first_full - olead;               // bytes before the first whole chunk
-  if (lane < head) dst[lane] = lds[lane];
+  if (lane < head) gdst[lane] = lds[lane];
   const unsigned sh = (unsigned)(head & 3);
   const uint32_t* w = reinterpret_cast<const uint32_t*>(lds) + (head >> 2);
   for (int i = first_full + lane * 16; i < last_full; i += 64 * 16) {
     const uint32_t* q = w + ((i - first_full) >> 2);
     const uint32_t w0 = q[0], w1 = q[1], w2 = q[2], w3 = q[3], w4 = q[4];
-    uint4 o;
+    u32x4 o;
     o.x = __builtin_amdgcn_alignbyte(w1, w0, sh);
     o.y = __builtin_amdgcn_alignbyte(w2, w1, sh);
     o.z = __builtin_amdgcn_alignbyte(w3, w2, sh);
     o.w = __builtin_amdgcn_alignbyte(w4, w3, sh);
-    *reinterpret_cast<uint4*>(a0 + i) = o;
+    *(gptr<u32x4>)(a0 + i) = o;
   }
   const int tail0 = last_full - olead;               // output index of the first tail byte
-  if (tail0 + lane < total) dst[tail0 + lane] = lds[tail0 + lane];
+  if (tail0 + lane < total) gdst[tail0 + lane] = lds[tail0 + lane];
 }
 
 }  // namespace cstile
