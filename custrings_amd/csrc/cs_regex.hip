@@ -456,7 +456,7 @@ __global__ void __launch_bounds__(256, 3) k_tdfa_replace_stream(StreamArgs a) {
   long long p_tile = -1;
   int p_total = 0, p_lo = 0, p_len = 0;
 #if defined(CS_PHASE_PROF)
-  unsigned long long phase_acc[6] = {0, 0, 0, 0, 0, 0};
+  unsigned long long phase_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long phase_t = __builtin_readcyclecounter();
 #endif
   auto finish_pending = [&](cstile::u64 first) {
@@ -465,6 +465,7 @@ __global__ void __launch_bounds__(256, 3) k_tdfa_replace_stream(StreamArgs a) {
       if (lane == 0) atomicOr(a.error, 1u);
       gb = 0;
     }
+    CS_PHASE_MARK(6);
     const long long pr0 = p_tile * 64;
     const int pn = (int)min(64ll, in.rows - pr0);
     if (lane < pn) a.out_off[pr0 + lane] = gb + p_lo;
@@ -588,7 +589,7 @@ __global__ void __launch_bounds__(256, 3) k_tdfa_replace_stream(StreamArgs a) {
 #if defined(CS_PHASE_PROF)
   CS_PHASE_MARK(5);
   if (lane == 0)
-    for (int k = 0; k < 6; ++k) atomicAdd(reinterpret_cast<unsigned long long*>(a.error) + 1 + k, phase_acc[k]);
+    for (int k = 0; k < 8; ++k) atomicAdd(reinterpret_cast<unsigned long long*>(a.error) + 1 + k, phase_acc[k]);
 #endif
 }
 
@@ -847,12 +848,12 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
         CS_HIP(hipStreamSynchronize(s));
 #if defined(CS_PHASE_PROF)
         {
-          unsigned long long ph[6];
+          unsigned long long ph[8];
           CS_HIP(hipMemcpy(ph, reinterpret_cast<unsigned long long*>(sa.error) + 1, sizeof(ph), hipMemcpyDeviceToHost));
           const double waves = (double)grid * 4;
-          fprintf(stderr, "phase cycles/wave-iteration: stage %.0f scan %.0f wscan+publish %.0f finish_prev %.0f assemble %.0f tail %.0f (iters/wave %.1f)\n",
+          fprintf(stderr, "phase cycles/wave-iteration: stage %.0f scan %.0f wscan+publish %.0f finish_prev(offsets+flush) %.0f assemble %.0f tail %.0f lookback %.0f (iters/wave %.1f)\n",
                   ph[0] / waves / (nsub1 / waves), ph[1] / waves / (nsub1 / waves), ph[2] / waves / (nsub1 / waves),
-                  ph[3] / waves / (nsub1 / waves), ph[4] / waves / (nsub1 / waves), ph[5] / waves / (nsub1 / waves), nsub1 / waves);
+                  ph[3] / waves / (nsub1 / waves), ph[4] / waves / (nsub1 / waves), ph[5] / waves / (nsub1 / waves), ph[6] / waves / (nsub1 / waves), nsub1 / waves);
         }
 #endif
         if ((uint32_t)host[1] == 0 || sa.debug) {

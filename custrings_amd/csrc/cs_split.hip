@@ -306,8 +306,9 @@ __device__ __forceinline__ void lds_or(uint32_t* p, uint32_t v) {
 __global__ void __launch_bounds__(256, CS_EMIT2_WAVES) k_split_emit2(Emit2Args a) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  uint8_t* lds_in = reinterpret_cast<uint8_t*>(smem) + (size_t)wv * (a.cap_in + 32 + 2 * a.cap_col);
+  uint8_t* lds_in = reinterpret_cast<uint8_t*>(smem) + (size_t)wv * (a.cap_in + 32 + 2 * a.cap_col + a.ncols * 64);
   uint8_t* region0 = lds_in + a.cap_in + 32;
+  uint8_t* dpos = region0 + 2 * a.cap_col;  // dpos[j * 64 + lane] = row offset of the lane's j-th delimiter
   // each wave owns a contiguous run of sub-tiles: its pieces of every output column are
   // contiguous too, so the cache lines that two neighbouring sub-tiles share are completed in
   // one L2 instead of being written half-filled from two XCDs
@@ -373,14 +374,28 @@ __global__ void __launch_bounds__(256, CS_EMIT2_WAVES) k_split_emit2(Emit2Args a
     CS_PHASE_MARK(0);
 
     TokensT<true> tk(lds_in, lead + rbeg, n, live, a.dpat, a.tokens);
+    // every row's delimiter positions go to LDS once, in a loop that does nothing else; the
+    // column loop then needs one byte load per token instead of the bit-mask walk
+    const int nd = __builtin_popcountll(tk.m_lo) + __builtin_popcount(tk.m_hi);
+    for (int j = 0; j < a.ncols - 1; ++j) {
+      const bool some = tk.m_lo != 0 || tk.m_hi != 0;
+      if (!__any(some)) break;
+      if (some) dpos[j * 64 + lane] = (uint8_t)tk.next_delim();
+    }
+    const int ntok = live ? min(nd, a.tokens > 0 ? a.tokens - 1 : 1 << 20) + 1 : 0;
+    cstile::wave_lds_fence();
     CS_PHASE_MARK(1);
     const bool last_tile = r0 + nrows == in.rows;
     unsigned long long my_vmask = 0;
+    int cursor = 0;
     for (int k = 0; k < a.ncols; ++k) {
       uint8_t* region = region0 + (k & 1) * a.cap_col;
-      int lo = 0, hi = 0;
-      const bool has = tk.next(lo, hi);
+      const int dk = dpos[k * 64 + lane];
+      const bool has = k < ntok;
+      const int lo = cursor;
+      const int hi = k == ntok - 1 ? n : dk;
       const int len = has ? hi - lo : 0;
+      cursor = hi + 1;
       const int incl = wave_inclusive_scan(len);
       const int pre = incl - len;
       const long long cbase = cstile::rl64(my_base, k);
@@ -512,7 +527,7 @@ bool split_fast(const cs_column* col, unsigned char delim, int tokens, hipStream
     CS_HIP(hipMemsetAsync(profbuf->p, 0, 64, s));
     e2.prof = ptr<unsigned long long>(profbuf);
 #endif
-    const size_t lds2 = (size_t)(cap_in + 32 + 2 * cap_col) * 4;
+    const size_t lds2 = (size_t)(cap_in + 32 + 2 * cap_col + ncols * 64) * 4;
     if (lds2 <= 150 * 1024) {
       if (lds2 > 48 * 1024)
         CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_split_emit2),

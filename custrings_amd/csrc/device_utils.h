@@ -13,9 +13,9 @@ constexpr int kMaxWaves = 16;  // workgroups of up to 1024 threads
 // ---- DPP building blocks --------------------------------------------------
 // v_mov_b32 with a DPP control; lanes whose source is out of range (or masked
 // off by row_mask/bank_mask) receive `old`.
-template <int CTRL, int ROW_MASK = 0xF, int BANK_MASK = 0xF>
+template <int CTRL, int ROW_MASK = 0xF, int BANK_MASK = 0xF, bool BOUND_CTRL = false>
 __device__ __forceinline__ int dpp_mov(int old, int src) {
-  return __builtin_amdgcn_update_dpp(old, src, CTRL, ROW_MASK, BANK_MASK, false);
+  return __builtin_amdgcn_update_dpp(old, src, CTRL, ROW_MASK, BANK_MASK, BOUND_CTRL);
 }
 constexpr int DPP_ROW_SHR1 = 0x111, DPP_ROW_SHR2 = 0x112, DPP_ROW_SHR4 = 0x114,
               DPP_ROW_SHR8 = 0x118, DPP_ROW_BCAST15 = 0x142, DPP_ROW_BCAST31 = 0x143;
@@ -23,10 +23,11 @@ constexpr int DPP_ROW_SHR1 = 0x111, DPP_ROW_SHR2 = 0x112, DPP_ROW_SHR4 = 0x114,
 // Inclusive prefix sum across the 64 lanes of a wave: 4 row_shr steps scan each
 // 16-lane row, row_bcast:15 / row_bcast:31 carry the row totals across rows.
 __device__ __forceinline__ int wave_inclusive_scan(int v) {
-  v += dpp_mov<DPP_ROW_SHR1>(0, v);
-  v += dpp_mov<DPP_ROW_SHR2>(0, v);
-  v += dpp_mov<DPP_ROW_SHR4>(0, v);
-  v += dpp_mov<DPP_ROW_SHR8>(0, v);
+  // (old = 0 with bound_ctrl lets the compiler fold each move into a v_add_u32_dpp: 6 VALU in all)
+  v += dpp_mov<DPP_ROW_SHR1, 0xF, 0xF, true>(0, v);
+  v += dpp_mov<DPP_ROW_SHR2, 0xF, 0xF, true>(0, v);
+  v += dpp_mov<DPP_ROW_SHR4, 0xF, 0xF, true>(0, v);
+  v += dpp_mov<DPP_ROW_SHR8, 0xF, 0xF, true>(0, v);
   v += dpp_mov<DPP_ROW_BCAST15, 0xA>(0, v);  // rows 1 and 3 += last lane of rows 0 and 2
   v += dpp_mov<DPP_ROW_BCAST31, 0xC>(0, v);  // rows 2,3 += lane 31
   return v;

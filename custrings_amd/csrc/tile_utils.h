@@ -144,10 +144,12 @@ __device__ __forceinline__ void wave_flush(uint8_t* dst, int total, const uint8_
     for (int j = lead + lane; j < end; j += 64) a0[j] = lds[j];
     return;
   }
-  if (lead + lane < first_full) a0[lead + lane] = lds[lead + lane];
   for (int i = first_full + lane * 16; i < last_full; i += 64 * 16)
     *(gptr<u32x4>)(a0 + i) = *reinterpret_cast<const u32x4*>(lds + i);
-  if (last_full + lane < end) a0[last_full + lane] = lds[last_full + lane];
+  // head bytes on lanes 0..15, tail bytes on lanes 16..31: one predicated byte store for both
+  const int j = lane < 16 ? lead + lane : last_full + lane - 16;
+  const bool ok = lane < 16 ? j < first_full : (lane < 32 && j < end);
+  if (ok) a0[j] = lds[j];
 }
 
 // Per-thread copy inside LDS, dword-wide in the middle.  Both buffers are given
@@ -166,17 +168,22 @@ __device__ __forceinline__ void lds_copy(uint8_t* dbase, int di, const uint8_t* 
     const uint32_t* sp = reinterpret_cast<const uint32_t*>(sbase) + ((si + i) >> 2);
     uint32_t* dp = reinterpret_cast<uint32_t*>(dbase) + ((di + i) >> 2);
     uint32_t lo = *sp++;
-    if (sh == 0) {
-      for (; i + 4 <= n; i += 4) {
-        *dp++ = lo;
-        lo = *sp++;
-      }
-    } else {
-      for (; i + 4 <= n; i += 4) {
-        uint32_t hi = *sp++;
-        *dp++ = __builtin_amdgcn_alignbyte(hi, lo, sh);
-        lo = hi;
-      }
+    // four dwords per trip: the loads are issued together, so a row pays the LDS latency
+    // once per 16 bytes instead of once per dword (alignbyte with shift 0 returns `lo`)
+    for (; i + 16 <= n; i += 16) {
+      const uint32_t a = sp[0], b = sp[1], c = sp[2], d = sp[3];
+      sp += 4;
+      dp[0] = __builtin_amdgcn_alignbyte(a, lo, sh);
+      dp[1] = __builtin_amdgcn_alignbyte(b, a, sh);
+      dp[2] = __builtin_amdgcn_alignbyte(c, b, sh);
+      dp[3] = __builtin_amdgcn_alignbyte(d, c, sh);
+      dp += 4;
+      lo = d;
+    }
+    for (; i + 4 <= n; i += 4) {
+      const uint32_t hi = *sp++;
+      *dp++ = __builtin_amdgcn_alignbyte(hi, lo, sh);
+      lo = hi;
     }
   }
   for (; i < n; ++i) dbase[di + i] = sbase[si + i];
@@ -291,10 +298,14 @@ __device__ __forceinline__ long long lookback_end(u64* status, long long tile, l
       v = idx >= 0 ? status_load(status + idx) : kFlagInc;
       continue;
     }
-    long long partw = (lane <= first_inc) ? (long long)(v & kValMask) : 0;
-    for (int d = 32; d > 0; d >>= 1) partw += __shfl_xor(partw, d, 64);
-    excl += partw;
-    if (first_inc < 64) break;
+    // aggregates of 64-row sub-tiles fit 32 bits: sum them with DPP adds; the one inclusive
+    // prefix that ends the window is 64 bits wide and is read from its lane directly
+    const int part = (lane < first_inc) ? (int)(unsigned)(v & 0xffffffffull) : 0;
+    excl += (unsigned)csdev::wave_reduce_sum(part);
+    if (first_inc < 64) {
+      excl += rl64((long long)(v & kValMask), first_inc);
+      break;
+    }
     t -= 64;
     const long long idx = t - lane;
     v = idx >= 0 ? status_load(status + idx) : kFlagInc;
@@ -302,6 +313,7 @@ __device__ __forceinline__ long long lookback_end(u64* status, long long tile, l
   if (lane == 0) status_store(status + tile, kFlagInc | ((u64)(excl + aggregate) & kValMask));
   return excl;
 }
+
 
 // Wave-cooperative flush of `total` bytes assembled at lds[0 ..) (lds 4-byte aligned) to
 // the arbitrarily aligned global address `dst`: whole 16-byte destination chunks are
