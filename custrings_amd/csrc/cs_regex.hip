@@ -524,13 +524,19 @@ __global__ void __launch_bounds__(256, 3) k_tdfa_replace_stream(StreamArgs a) {
         ++nm;
       };
       // wave-uniform choice: the lean scan when every row of the sub-tile qualifies
-      const bool lean = D.nskip > 0 && !(a.debug & 32) && !__any((odd & 0x80808080u) != 0) &&
+      const bool lean = D.nskip > 0 && D.img[12] <= 4 && !(a.debug & 32) && !__any((odd & 0x80808080u) != 0) &&
                         !__any(live && !vm.masks_fit());
       bool redo = live && !lean;
       if (lean && live && a.maxrepl != 0) {
         out_len = n;
         bool bail = false;
-        vm.scan_lean_dispatch(a.maxrepl, rec, bail);
+        uint32_t q0, q1, q2;  // candidate bits counted from the row's aligned start ...
+        vm.build_masks(q0, q1, q2);
+        const unsigned sa = (unsigned)vm.sa;  // ... shifted down to the row's first byte
+        const uint32_t m0 = sa ? (q0 >> sa) | (q1 << (32 - sa)) : q0;
+        const uint32_t m1 = sa ? (q1 >> sa) | (q2 << (32 - sa)) : q1;
+        const uint32_t m2 = q2 >> sa;
+        vm.scan_lean_dispatch(a.maxrepl, m0, m1, m2, rec, bail);
         redo = bail;
       }
       if (__any(redo)) {

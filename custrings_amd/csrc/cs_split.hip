@@ -210,6 +210,7 @@ __global__ void __launch_bounds__(256) k_split_measure(MeasureArgs a) {
   if (lane == 0 && m > __hip_atomic_load(a.max_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(a.max_count, m);
 }
 
+
 struct ColOut {
   uint8_t* chars;
   int64_t* offsets;
@@ -489,6 +490,8 @@ bool split_fast(const cs_column* col, unsigned char delim, int tokens, hipStream
   MeasureArgs ma{view_of(col), dpat, tokens, cap_in, nsub, ptr<int32_t>(colsum), ptr<int>(mx)};
   {
     ProfScope ps("k_split_measure", s);
+    // (a persistent, prefetching form of this kernel measured slower: it is bound by its
+    // instruction count, not by memory latency, at 28 resident waves per CU)
     hipLaunchKernelGGL(k_split_measure, dim3(grid), dim3(256), (size_t)(cap_in + 32) * 4, s, ma);
   }
   CS_HIP(hipGetLastError());

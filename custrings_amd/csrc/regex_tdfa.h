@@ -362,48 +362,67 @@ struct Tdfa {
 
   // ---- lean replace scan: ASCII-only rows, candidate masks in registers ------------
   // Preconditions (the caller checks them): every byte of the row is 1..127,
-  // D.nskip > 0, masks_fit(), and the automaton uses at most NS thread slots.  On
-  // such rows the result equals scan<K_REPLACE>.  Two levels so that a wave spends its
-  // lock-step iterations on byte steps, not on bookkeeping: the inner loop takes every
-  // transition that neither stops the automaton nor returns it to the idle state
-  // (recording MATCH / thread-start side effects on the way); idle jumps, the end of
-  // the row and the end of a find() round are handled once per outer iteration.
+  // D.nskip > 0, n <= kMaskBytes.  (m0, m1, m2) hold the row's candidate bits, bit i =
+  // "byte i may leave the idle state".  On such rows the result equals scan<K_REPLACE>.
+  // Two levels so that a wave spends its lock-step iterations on byte steps, not on
+  // bookkeeping: the inner loop takes every transition that neither stops the automaton
+  // nor returns it to the idle state, applying MATCH / thread-start side effects without
+  // branches; idle jumps, the end of the row and the end of a find() round are handled
+  // once per outer iteration.  The (up to four) thread start offsets live in ONE register,
+  // a byte each (row offsets are below 256): "slots j >= keep start here" is a single
+  // bit-field insert and a match origin a single bit-field extract.
   // COMPLEX transitions and zero-length matches set `bail`: the caller re-runs the row
   // with scan<>.
   CS_HD uint8_t byte_at(int i) const { return s[i]; }
-  template <bool USES, int NS, class Emit>
-  CS_HD int scan_lean_replace(int maxrepl, Emit&& emit, bool& bail) {
-    uint32_t cm0, cm1, cm2;
-    build_masks(cm0, cm1, cm2);
-    int from = 0, pos = 0, done = 0, mb = 0, me = 0, matched = 0;
-    int st[NS];
-#pragma unroll
-    for (int j = 0; j < NS; ++j) st[j] = 0;
+  static CS_HD int first_candidate(uint32_t m0, uint32_t m1, uint32_t m2, int pos, int n) {
+    uint32_t a = m0, b = m1, c = m2;
+    if (pos >= 32) a = 0;
+    if (pos >= 64) b = 0;
+    const uint32_t cut = 0xFFFFFFFFu << (pos & 31);
+    if (pos < 32) a &= cut;
+    else if (pos < 64) b &= cut;
+    else c &= cut;
+    if (a) return ctz32(a);
+    if (b) return 32 + ctz32(b);
+    if (c) return 64 + ctz32(c);
+    return n;
+  }
+  // row-relative candidate bits from the bytes themselves (host checks; the tile kernels
+  // build them cooperatively while staging)
+  CS_HD void build_masks_rel(uint32_t& m0, uint32_t& m1, uint32_t& m2) const {
+    uint32_t r[3] = {0, 0, 0};
+    for (int i = 0; i < n && i < kMaskBytes; ++i) {
+      const unsigned b = s[i];
+      if (b >= 128 || b == 0 || bm128(D.cand0, D.cand1, D.cand2, D.cand3, b)) r[i >> 5] |= 1u << (i & 31);
+    }
+    m0 = r[0];
+    m1 = r[1];
+    m2 = r[2];
+  }
+  template <bool USES, class Emit>
+  CS_HD int scan_lean_replace(int maxrepl, uint32_t cm0, uint32_t cm1, uint32_t cm2, Emit&& emit, bool& bail) {
+    int from = 0, pos = 0, done = 0, mb = 0, me = 0;
+    uint32_t matched = 0;
+    uint32_t slots = 0;  // byte j = start offset of thread slot j
     uint32_t state = D.init[MODE_RESTART * 8 + 4];
-    // side effects of a transition that carries no COMPLEX origin word
+    // side effects of a transition without a COMPLEX origin word, branch-free
     auto effects = [&](uint32_t e) {
-      if (e & E_MATCH) {
-        const uint32_t o = e_match_origin(e);
-        int v = pos;
-#pragma unroll
-        for (int j = 0; j < NS; ++j)
-          if (o == (uint32_t)j) v = st[j];
-        mb = v;
-        me = pos;
-        matched = 1;
-      }
+      const uint32_t is_m = (e >> 11) & 1u;
+      const uint32_t o = (e >> 12) & 15u;
+      const uint32_t from_slot = (slots >> (8u * (o & 3u))) & 255u;
+      const int v = (o & 8u) ? pos : (int)from_slot;  // origin 15 = thread born here
+      mb = is_m ? v : mb;
+      me = is_m ? pos : me;
+      matched |= is_m;
       const uint32_t kf = (e >> 16) & 15u;  // keep ^ 15: 0 = nothing to do
-      if (kf) {
-        const uint32_t keep = kf ^ 15u;
-#pragma unroll
-        for (int j = 0; j < NS; ++j)
-          if ((uint32_t)j >= keep) st[j] = pos;
-      }
+      const uint32_t keep = kf ^ 15u;
+      const uint32_t low = keep >= 4u ? 0xFFFFFFFFu : ~(0xFFFFFFFFu << (8u * keep));  // bytes below `keep` stay
+      slots = (slots & low) | (((uint32_t)pos * 0x01010101u) & ~low);
     };
     for (;;) {
       if (state < D.nskip && pos < n) {  // idle: jump to the next candidate byte
         const int entry = pos;
-        pos = next_candidate(cm0, cm1, cm2, pos);
+        pos = first_candidate(cm0, cm1, cm2, pos, n);
         if (pos > n) pos = n;
         if (USES && pos > entry) {
           const unsigned b = byte_at(pos - 1);
@@ -456,8 +475,7 @@ struct Tdfa {
       from = me;
       pos = from;
       matched = 0;
-#pragma unroll
-      for (int j = 0; j < NS; ++j) st[j] = from;
+      slots = (uint32_t)from * 0x01010101u;
       unsigned pc = 0;
       if (USES) pc = from <= 0 ? 4u : cat_of_ascii(byte_at(from - 1));
       state = D.init[MODE_RESTART * 8 + pc];
@@ -465,22 +483,15 @@ struct Tdfa {
   }
   // true when the row can take scan_lean_replace (host-side check; kernels decide per tile)
   CS_HD bool lean_ok() const {
-    if (D.nskip == 0 || !masks_fit()) return false;
+    if (D.nskip == 0 || n > kMaskBytes || D.img[12] > 4) return false;
     for (int i = 0; i < n; ++i)
       if (s[i] == 0 || s[i] >= 128) return false;
     return true;
   }
   template <class Emit>
-  CS_HD int scan_lean_dispatch(int maxrepl, Emit&& emit, bool& bail) {
-    const int ns = D.img[12];
-    if (D.uses) {
-      if (ns <= 1) return scan_lean_replace<true, 1>(maxrepl, emit, bail);
-      if (ns <= 2) return scan_lean_replace<true, 2>(maxrepl, emit, bail);
-      return scan_lean_replace<true, kMaxSlots>(maxrepl, emit, bail);
-    }
-    if (ns <= 1) return scan_lean_replace<false, 1>(maxrepl, emit, bail);
-    if (ns <= 2) return scan_lean_replace<false, 2>(maxrepl, emit, bail);
-    return scan_lean_replace<false, kMaxSlots>(maxrepl, emit, bail);
+  CS_HD int scan_lean_dispatch(int maxrepl, uint32_t m0, uint32_t m1, uint32_t m2, Emit&& emit, bool& bail) {
+    if (D.uses) return scan_lean_replace<true>(maxrepl, m0, m1, m2, emit, bail);
+    return scan_lean_replace<false>(maxrepl, m0, m1, m2, emit, bail);
   }
 
   // emit(mb, me, reps) per match (K_REPLACE: reps > 1 for the zero-length repeat);
@@ -662,7 +673,9 @@ CS_HD void row_replace_matches(cstd::Tdfa& vm, int maxrepl, Emit&& emit) {
     int buf[3 * 64];
     int cnt = 0;
     bool bail = false, overflow = false;
-    vm.scan_lean_dispatch(maxrepl, [&](int mb, int me, int reps) {
+    uint32_t lm0, lm1, lm2;
+    vm.build_masks_rel(lm0, lm1, lm2);
+    vm.scan_lean_dispatch(maxrepl, lm0, lm1, lm2, [&](int mb, int me, int reps) {
       if (cnt < 64) {
         buf[3 * cnt] = mb;
         buf[3 * cnt + 1] = me;
