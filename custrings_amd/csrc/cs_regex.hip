@@ -422,7 +422,10 @@ struct StreamArgs {
   int debug;
 };
 template <bool IN_LDS>
-__global__ void __launch_bounds__(256, 3) k_tdfa_replace_stream(StreamArgs a) {
+#ifndef CS_STREAM_WAVES
+#define CS_STREAM_WAVES 3
+#endif
+__global__ void __launch_bounds__(256, CS_STREAM_WAVES) k_tdfa_replace_stream(StreamArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   uint8_t* base = reinterpret_cast<uint8_t*>(smem);
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -625,7 +628,7 @@ TPlan tplan(cs_regex* re, int64_t rows, hipStream_t s) {
   pl.d.tdfa = ptr<const int32_t>(re->d_tdfa);
   pl.d.tdfa_words = (int)re->tdfa.size();
   pl.d.image = ptr<const int32_t>(re->d_image);
-  pl.d.in_lds = re->tdfa.size() * 4 <= kLdsBudget;
+  pl.d.in_lds = re->tdfa.size() * 4 <= kLdsBudget && !getenv("CS_TDFA_GLOBAL_TABLE");
   pl.lds_bytes = pl.d.in_lds ? ((re->tdfa.size() * 4 + 15) & ~size_t(15)) : 0;
   int64_t nblk = (rows + 255) / 256;
   pl.grid = (unsigned)std::min<int64_t>(std::max<int64_t>(nblk, 1), 256 * 8);

@@ -294,3 +294,63 @@ def test_gpu_global_category_single_rank(orc):
     va = ops.remap(ca, codes[: ca.keys_size()].contiguous())
     vb = ops.remap(cb, codes[ca.keys_size() :].contiguous())
     assert np.array_equal(np.concatenate([va.cpu().numpy(), vb.cpu().numpy()]), ov)
+
+
+# ---- code paths of the persistent tile kernels (stream replace_re, emit2) -------------------
+def _log_like(rnd, lo, hi, nonascii_every=0, idx=0):
+    words = []
+    total = 0
+    target = rnd.randint(lo, hi)
+    while total < target:
+        k = rnd.random()
+        if k < 0.15:
+            w = ".".join(str(rnd.randint(0, 255)) for _ in range(rnd.choice([3, 4, 4, 4, 5])))
+        elif k < 0.25:
+            w = str(rnd.randint(0, 99999))
+        elif k < 0.30:
+            w = "x" * rnd.randint(17, 40)  # tokens longer than the 16-byte assembly path
+        else:
+            w = "".join(rnd.choice("abcdefgh/") for _ in range(rnd.randint(1, 9)))
+        words.append(w)
+        total += len(w) + 1
+    s = " ".join(words)[:hi]
+    if nonascii_every and idx % nonascii_every == 0:
+        s = s[: len(s) // 2] + "é" + s[len(s) // 2 :]
+    return s
+
+
+@pytest.mark.parametrize("rows", [1, 63, 64, 65, 257, 4097, 20000])
+def test_gpu_tile_kernels_row_counts(gpu_engine, oracle_engine, rows):
+    import random
+
+    rnd = random.Random(rows)
+    s = [_log_like(rnd, 30, 90) for _ in range(rows)]
+    for i in range(0, rows, 97):
+        s[i] = None if i % 2 else ""
+    o, g = oracle_engine, gpu_engine
+    assert g.replace_re(s, IPV4, "<IP>", -1) == o.replace_re(s, IPV4, "<IP>", -1)
+    assert g.split(s, " ", -1) == o.split(s, " ", -1)
+
+
+@pytest.mark.parametrize("shape", ["fits", "nonascii", "long_rows", "wide_tiles"])
+def test_gpu_tile_kernels_fallback_paths(gpu_engine, oracle_engine, shape):
+    """fits: every sub-tile takes the lean scan / emit2; nonascii: some sub-tiles hold a
+    non-ASCII row (generic scan inside the stream kernel); long_rows: rows beyond the 96-byte
+    register masks; wide_tiles: 64-row spans beyond the prefetch registers (older kernels)."""
+    import random
+
+    rnd = random.Random(len(shape))
+    if shape == "fits":
+        s = [_log_like(rnd, 20, 93) for _ in range(6000)]
+    elif shape == "nonascii":
+        s = [_log_like(rnd, 20, 90, nonascii_every=150, idx=i) for i in range(6000)]
+    elif shape == "long_rows":
+        s = [_log_like(rnd, 20, 90) if i % 40 else _log_like(rnd, 100, 260) for i in range(6000)]
+    else:
+        s = [_log_like(rnd, 100, 300) for _ in range(3000)]
+    o, g = oracle_engine, gpu_engine
+    for pat, repl, n in ((IPV4, "<IP>", -1), (IPV4, "", 1), (IPV4B, "#", -1), (r"x*", "", -1), (r"\d+", "9", 2), (r"[a-c]+", "<long>", -1)):
+        assert g.replace_re(s, pat, repl, n) == o.replace_re(s, pat, repl, n), (shape, pat, repl, n)
+    for n in (-1, 1, 3):
+        assert g.split(s, " ", n) == o.split(s, " ", n), (shape, n)
+    assert g.split(s, ".", -1) == o.split(s, ".", -1)
