@@ -533,12 +533,9 @@ __global__ void __launch_bounds__(256, CS_STREAM_WAVES) k_tdfa_replace_stream(St
       if (lean && live && a.maxrepl != 0) {
         out_len = n;
         bool bail = false;
-        uint32_t q0, q1, q2;  // candidate bits counted from the row's aligned start ...
-        vm.build_masks(q0, q1, q2);
-        const unsigned sa = (unsigned)vm.sa;  // ... shifted down to the row's first byte
-        const uint32_t m0 = sa ? (q0 >> sa) | (q1 << (32 - sa)) : q0;
-        const uint32_t m1 = sa ? (q1 >> sa) | (q2 << (32 - sa)) : q1;
-        const uint32_t m2 = q2 >> sa;
+        uint32_t m0, m1, m2;  // candidate bits, bit i = byte i of the row
+        if (vm.has_range2()) vm.build_masks_lean<true>(m0, m1, m2);
+        else vm.build_masks_lean<false>(m0, m1, m2);
         vm.scan_lean_dispatch(a.maxrepl, m0, m1, m2, rec, bail);
         redo = bail;
       }

@@ -437,6 +437,18 @@ std::vector<int32_t> build_tdfa(const Program& prog, const std::vector<int32_t>&
     img[29] = lo1 | (hi1 << 8);
     img[30] = lo2 | (hi2 << 8);
   }
+  // EXIT marks (regex_tdfa.h): non-COMPLEX transitions into an idle state, in T1 and T2
+  {
+    const uint32_t nskip = (uint32_t)img[16];
+    auto mark = [&](int32_t off, size_t count) {
+      for (size_t i = 0; i < count; ++i) {
+        uint32_t e = (uint32_t)img[off + i];
+        if (!(e & (cstd::E_COMPLEX | cstd::E_STOP)) && (e & cstd::E_STATE) < nskip) img[off + i] = (int32_t)(e | cstd::E_EXIT);
+      }
+    };
+    mark(img[7], (size_t)nstates * 128);
+    mark(img[8], (size_t)nstates * natoms);
+  }
   img[15] = (int32_t)img.size();
   return img;
 }

@@ -39,6 +39,7 @@
 //   [19:16] keep ^ 15 (slots j >= keep start at this position; keep 15 = unchanged), so
 //           that a transition with no side effect at all is just its next-state id (< 1024)
 //   [20] COMPLEX (origins in ACT[entry >> 21], 4 bits per slot, 15 = new)
+//   [21] (entries without COMPLEX only) EXIT: the next state is an idle state
 // (slot fields are 4 bits wide although kMaxSlots is 4: room to grow)
 #pragma once
 #include <stdint.h>
@@ -58,6 +59,9 @@ enum { ATOM_EOT = 0, ATOM_NUL = 1, ATOM_FIRST_CLASS = 2 };
 enum { P_CHAR = 0, P_ANY = 1, P_ANYNL = 2, P_CCLASS = 3, P_NCCLASS = 4, P_ISNL = 5, P_ISWORD = 6 };
 
 constexpr uint32_t E_STATE = 0x3FFu, E_STOP = 1u << 10, E_MATCH = 1u << 11, E_COMPLEX = 1u << 20;
+// bit 21 of an entry WITHOUT E_COMPLEX (whose bits 31:21 are otherwise zero): the next state is
+// an idle one -- lets the lean scan test "leave the inner loop" with a single mask
+constexpr uint32_t E_EXIT = 1u << 21;
 CS_HD uint32_t e_match_origin(uint32_t e) { return (e >> 12) & 15u; }
 CS_HD uint32_t e_keep(uint32_t e) { return ((e >> 16) & 15u) ^ 15u; }
 CS_HD uint32_t e_keep_field(uint32_t keep) { return ((keep ^ 15u) & 15u) << 16; }
@@ -343,6 +347,35 @@ struct Tdfa {
     m1 = r[1];
     m2 = r[2];
   }
+  // Row-relative candidate bits for the lean scan: the caller guarantees that every byte the
+  // 24 words hold inside the sub-tile is 1..127 (no non-ASCII / NUL terms needed) and
+  // HAS_R2 says whether the second byte range is in use.
+  template <bool HAS_R2>
+  CS_HD void build_masks_lean(uint32_t& m0, uint32_t& m1, uint32_t& m2) const {
+    uint32_t r[3] = {0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 24; ++k) {
+      const uint32_t x = load_word(k) & 0x7F7F7F7Fu;
+      uint32_t c = (x + D.r1lo) & ~(x + D.r1hi);
+      if (HAS_R2) c |= (x + D.r2lo) & ~(x + D.r2hi);
+      c &= 0x80808080u;
+      const uint32_t nib = ((((c >> 7)) * 0x01020408u) >> 24) & 15u;  // bits 7,15,23,31 -> nibble
+      r[k >> 3] |= nib << (4 * (k & 7));
+    }
+    // shift the aligned-start masks down to the row's first byte and cut at its length
+    const unsigned a = (unsigned)sa;
+    uint32_t q0 = a ? (r[0] >> a) | (r[1] << (32 - a)) : r[0];
+    uint32_t q1 = a ? (r[1] >> a) | (r[2] << (32 - a)) : r[1];
+    uint32_t q2 = r[2] >> a;
+    const int hi = n;
+    q0 &= hi >= 32 ? 0xFFFFFFFFu : ~(0xFFFFFFFFu << (hi & 31));
+    q1 &= hi >= 64 ? 0xFFFFFFFFu : (hi <= 32 ? 0u : ~(0xFFFFFFFFu << (hi & 31)));
+    q2 &= hi >= 96 ? 0xFFFFFFFFu : (hi <= 64 ? 0u : ~(0xFFFFFFFFu << (hi & 31)));
+    m0 = q0;
+    m1 = q1;
+    m2 = q2;
+  }
+  CS_HD bool has_range2() const { return ((uint32_t)D.img[30] & 255u) <= (((uint32_t)D.img[30] >> 8) & 255u); }
   // first candidate position >= pos (row offsets), or n
   CS_HD int next_candidate(uint32_t m0, uint32_t m1, uint32_t m2, int pos) const {
     const int q = pos + sa;
@@ -387,18 +420,6 @@ struct Tdfa {
     if (c) return 64 + ctz32(c);
     return n;
   }
-  // row-relative candidate bits from the bytes themselves (host checks; the tile kernels
-  // build them cooperatively while staging)
-  CS_HD void build_masks_rel(uint32_t& m0, uint32_t& m1, uint32_t& m2) const {
-    uint32_t r[3] = {0, 0, 0};
-    for (int i = 0; i < n && i < kMaskBytes; ++i) {
-      const unsigned b = s[i];
-      if (b >= 128 || b == 0 || bm128(D.cand0, D.cand1, D.cand2, D.cand3, b)) r[i >> 5] |= 1u << (i & 31);
-    }
-    m0 = r[0];
-    m1 = r[1];
-    m2 = r[2];
-  }
   template <bool USES, class Emit>
   CS_HD int scan_lean_replace(int maxrepl, uint32_t cm0, uint32_t cm1, uint32_t cm2, Emit&& emit, bool& bail) {
     int from = 0, pos = 0, done = 0, mb = 0, me = 0;
@@ -406,6 +427,7 @@ struct Tdfa {
     uint32_t slots = 0;  // byte j = start offset of thread slot j
     uint32_t state = D.init[MODE_RESTART * 8 + 4];
     // side effects of a transition without a COMPLEX origin word, branch-free
+    uint32_t posb = 0;  // pos in every byte lane (kept in step with pos: no multiply in the inner loop)
     auto effects = [&](uint32_t e) {
       const uint32_t is_m = (e >> 11) & 1u;
       const uint32_t o = (e >> 12) & 15u;
@@ -417,13 +439,14 @@ struct Tdfa {
       const uint32_t kf = (e >> 16) & 15u;  // keep ^ 15: 0 = nothing to do
       const uint32_t keep = kf ^ 15u;
       const uint32_t low = keep >= 4u ? 0xFFFFFFFFu : ~(0xFFFFFFFFu << (8u * keep));  // bytes below `keep` stay
-      slots = (slots & low) | (((uint32_t)pos * 0x01010101u) & ~low);
+      slots = (slots & low) | (posb & ~low);
     };
     for (;;) {
       if (state < D.nskip && pos < n) {  // idle: jump to the next candidate byte
         const int entry = pos;
         pos = first_candidate(cm0, cm1, cm2, pos, n);
         if (pos > n) pos = n;
+        posb = (uint32_t)pos * 0x01010101u;
         if (USES && pos > entry) {
           const unsigned b = byte_at(pos - 1);
           unsigned cat = 0;
@@ -442,10 +465,11 @@ struct Tdfa {
           const unsigned bn = byte_at(pos + 1);  // next byte in flight together with the table lookup
 #endif
           e = D.t1[state * 128 + b];
-          if ((e & (E_STOP | E_COMPLEX)) || (e & E_STATE) < D.nskip || pos + 1 >= n) break;
+          if ((e & (E_STOP | E_COMPLEX | E_EXIT)) || pos + 1 >= n) break;
           effects(e);
           state = e & E_STATE;
           ++pos;
+          posb += 0x01010101u;
 #if defined(__HIP_DEVICE_COMPILE__)
           b = bn;
 #else
@@ -461,6 +485,7 @@ struct Tdfa {
       if (!(e & E_STOP)) {
         state = e & E_STATE;
         pos += 1;
+        posb += 0x01010101u;
         continue;
       }
       // ---- this find() round is over
@@ -475,7 +500,8 @@ struct Tdfa {
       from = me;
       pos = from;
       matched = 0;
-      slots = (uint32_t)from * 0x01010101u;
+      posb = (uint32_t)from * 0x01010101u;
+      slots = posb;
       unsigned pc = 0;
       if (USES) pc = from <= 0 ? 4u : cat_of_ascii(byte_at(from - 1));
       state = D.init[MODE_RESTART * 8 + pc];
@@ -483,7 +509,7 @@ struct Tdfa {
   }
   // true when the row can take scan_lean_replace (host-side check; kernels decide per tile)
   CS_HD bool lean_ok() const {
-    if (D.nskip == 0 || n > kMaskBytes || D.img[12] > 4) return false;
+    if (D.nskip == 0 || !masks_fit() || D.img[12] > 4) return false;
     for (int i = 0; i < n; ++i)
       if (s[i] == 0 || s[i] >= 128) return false;
     return true;
@@ -674,7 +700,8 @@ CS_HD void row_replace_matches(cstd::Tdfa& vm, int maxrepl, Emit&& emit) {
     int cnt = 0;
     bool bail = false, overflow = false;
     uint32_t lm0, lm1, lm2;
-    vm.build_masks_rel(lm0, lm1, lm2);
+    if (vm.has_range2()) vm.build_masks_lean<true>(lm0, lm1, lm2);
+    else vm.build_masks_lean<false>(lm0, lm1, lm2);
     vm.scan_lean_dispatch(maxrepl, lm0, lm1, lm2, [&](int mb, int me, int reps) {
       if (cnt < 64) {
         buf[3 * cnt] = mb;
