@@ -378,10 +378,23 @@ __global__ void __launch_bounds__(256, CS_EMIT2_WAVES) k_split_emit2(Emit2Args a
     // every row's delimiter positions go to LDS once, in a loop that does nothing else; the
     // column loop then needs one byte load per token instead of the bit-mask walk
     const int nd = __builtin_popcountll(tk.m_lo) + __builtin_popcount(tk.m_hi);
-    for (int j = 0; j < a.ncols - 1; ++j) {
-      const bool some = tk.m_lo != 0 || tk.m_hi != 0;
-      if (!__any(some)) break;
-      if (some) dpos[j * 64 + lane] = (uint8_t)tk.next_delim();
+    {
+      // word by word, lowest set bit first: ffbl, clear, one byte store per delimiter
+      uint32_t w[3] = {(uint32_t)tk.m_lo, (uint32_t)(tk.m_lo >> 32), tk.m_hi};
+      uint8_t* slot = dpos + lane;  // advances one dpos row (64 bytes) per delimiter found
+      const uint8_t* last = dpos + (a.ncols - 1) * 64;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        uint32_t v = w[i];
+        while (__any(v != 0)) {
+          if (v != 0) {
+            const int q = 32 * i + __builtin_ctz(v) - tk.sa;
+            v &= v - 1;
+            if (slot < last) *slot = (uint8_t)q;
+            slot += 64;
+          }
+        }
+      }
     }
     const int ntok = live ? min(nd, a.tokens > 0 ? a.tokens - 1 : 1 << 20) + 1 : 0;
     cstile::wave_lds_fence();
