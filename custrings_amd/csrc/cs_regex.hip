@@ -463,7 +463,15 @@ __global__ void __launch_bounds__(256, CS_STREAM_WAVES) k_tdfa_replace_stream(St
   unsigned long long phase_t = __builtin_readcyclecounter();
 #endif
   auto finish_pending = [&](cstile::u64 first) {
-    long long gb = (a.debug & 8) ? p_tile * 4096 : cstile::lookback_end(a.status, p_tile, p_total, first, lane);
+    long long gb;
+    if (a.debug & 128) {  // measurement only: one late poll, no chase for an inclusive prefix
+      const cstile::u64 v = cstile::lookback_poll(a.status, p_tile, lane);
+      const int part = (int)(unsigned)(v & 0xffffffffull);
+      gb = p_tile * 4096 + (csdev::wave_reduce_sum(part) & 0) + (long long)(first & 0);
+      if (lane == 0) cstile::status_store(a.status + p_tile, cstile::kFlagInc | 1);
+    } else {
+      gb = (a.debug & 8) ? p_tile * 4096 : cstile::lookback_end(a.status, p_tile, p_total, first, lane);
+    }
     if (gb < 0) {
       if (lane == 0) atomicOr(a.error, 1u);
       gb = 0;
@@ -480,8 +488,6 @@ __global__ void __launch_bounds__(256, CS_STREAM_WAVES) k_tdfa_replace_stream(St
     const int nrows = (int)min(64ll, in.rows - r0);
     const long long g0 = cstile::rl64(cur.o0, 0), g1 = cstile::rl64(cur.o1, 63);
     const bool live = lane < nrows && row_is_valid(in.validity, r0 + lane);
-    cstile::u64 p_first = 0;
-    if (p_tile >= 0 && !(a.debug & (8 | 64))) p_first = cstile::lookback_poll(a.status, p_tile, lane);
     const int rbeg = (int)(cur.o0 - g0);
     const int n = live ? (int)(cur.o1 - cur.o0) : 0;
     const int lead = (int)((uintptr_t)(in.chars + g0) & 15);
@@ -499,6 +505,10 @@ __global__ void __launch_bounds__(256, CS_STREAM_WAVES) k_tdfa_replace_stream(St
         odd |= q.z | ((q.z - 0x01010101u) & ~q.z);
         odd |= q.w | ((q.w - 0x01010101u) & ~q.w);
       }
+    // first look-back poll for the previous sub-tile: issued only now, after the staging above has
+    // waited for its own data (vmcnt is in order: a poll issued earlier would sit in front of it)
+    cstile::u64 p_first = 0;
+    if (p_tile >= 0 && !(a.debug & (8 | 64))) p_first = cstile::lookback_poll(a.status, p_tile, lane);
     // keep the memory pipe busy: next sub-tile's chars, and the offsets of the one after
     const bool has_next = tile + W < a.nsub;
     if (has_next) {
