@@ -1,0 +1,141 @@
+#!/usr/bin/env python3
+"""Per-operation throughput of every SURVEY section-8(a) row on the synthetic configs of
+BASELINE.json (C2-C5), one GPU, inputs resident in HBM.  Secondary to bench.py (which is the
+headline metric): this prints one JSON line per op with wall time per call (device
+synchronised), input GB/s and the fraction of the 8 TB/s HBM roofline over the op's
+ALGORITHMIC bytes (SURVEY.md 8d formulas).  Usage: python tools/bench_ops.py [--scale 1.0]
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402,F401  (one HIP runtime per process)
+
+from custrings_amd import _lib, nvcategory, nvstrings, nvtext  # noqa: E402
+
+L = _lib.lib
+_lib.ensure_init(0)
+SEED = 20240607
+IPV4 = r"\d+\.\d+\.\d+\.\d+"
+
+
+def synth(kind, rows, param=0):
+    out = C.c_void_p()
+    _lib.check(L.cs_synth_column(kind, 0, rows, SEED, param, None, C.byref(out)))
+    return nvstrings.nvstrings(out.value)
+
+
+def nbytes(col):
+    return int(L.cs_column_nbytes(col.m_cptr))
+
+
+def timed(fn, reps=3):
+    fn()  # warm-up (allocator cache, kernel load)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        r = fn()
+        del r
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps
+
+
+def report(config, op, rows, in_bytes, alg_bytes, dt):
+    print(json.dumps({"config": config, "op": op, "rows": rows, "ms": round(dt * 1e3, 3),
+                      "input_GBps": round(in_bytes / dt / 1e9, 1), "alg_bytes_per_row": round(alg_bytes / rows, 1),
+                      "alg_GBps": round(alg_bytes / dt / 1e9, 1), "frac_of_8TBps": round(alg_bytes / dt / 8e12, 4)}), flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--scale", type=float, default=1.0, help="row-count multiplier (1.0 = BASELINE.json single-GPU sizes)")
+    ap.add_argument("--only", default="C2,C3,C4,C5", help="comma-separated configs to run")
+    a = ap.parse_args()
+    only = set(a.only.split(","))
+    ov = 8.125  # native offset + validity bytes per row
+
+    if "C2" in only:
+        run_c2(a, ov)
+    if "C3" in only:
+        run_c3(a, ov)
+    if "C4" in only:
+        run_c4(a, ov)
+    if "C5" in only:
+        run_c5(a, ov)
+
+
+def run_c2(a, ov):
+    # ---- C2: 10M x 64 chars, lower + strip + split(' ')
+    rows = int(10_000_000 * a.scale)
+    c2 = synth(2, rows)
+    b = nbytes(c2)
+    low = c2.lower()
+    report("C2", "lower", rows, b, 2 * b + 2 * ov * rows, timed(lambda: c2.lower()))
+    st = low.strip()
+    report("C2", "strip", rows, nbytes(low), nbytes(low) + nbytes(st) + 2 * ov * rows, timed(lambda: low.strip()))
+    cols = st.split(" ")
+    out_b = sum(nbytes(c) for c in cols)
+    report("C2", "split(' ')", rows, nbytes(st), nbytes(st) + ov * rows + out_b + len(cols) * ov * rows, timed(lambda: st.split(" ")))
+    report("C2", "upper", rows, b, 2 * b + 2 * ov * rows, timed(lambda: c2.upper()))
+    res = torch.empty(rows, dtype=torch.int32, device="cuda")
+    report("C2", "find('é')", rows, b, b + ov * rows + 4 * rows, timed(lambda: c2.find("é", devptr=res.data_ptr())))
+    resb = torch.empty(rows, dtype=torch.uint8, device="cuda")
+    report("C2", "contains('ab', regex=False)", rows, b, b + ov * rows + rows, timed(lambda: c2.contains("ab", regex=False, devptr=resb.data_ptr())))
+    rl = c2.replace("a", "xx", regex=False)
+    report("C2", "replace('a','xx') literal", rows, b, b + nbytes(rl) + 2 * ov * rows, timed(lambda: c2.replace("a", "xx", regex=False)))
+    del c2, low, st, cols, rl
+
+
+
+def run_c3(a, ov):
+    # ---- C3: 100M log lines, contains_re + replace_re + split
+    rows = int(100_000_000 * a.scale)
+    c3 = synth(3, rows)
+    b = nbytes(c3)
+    resb = torch.empty(rows, dtype=torch.uint8, device="cuda")
+    report("C3", "contains_re(IPv4)", rows, b, b + ov * rows + rows, timed(lambda: c3.contains(IPV4, devptr=resb.data_ptr())))
+    resi = torch.empty(rows, dtype=torch.int32, device="cuda")
+    report("C3", "count_re(IPv4)", rows, b, b + ov * rows + 4 * rows, timed(lambda: c3.count(IPV4, devptr=resi.data_ptr())))
+    rep = c3.replace(IPV4, "<IP>")
+    report("C3", "replace_re(IPv4,'<IP>')", rows, b, b + nbytes(rep) + 2 * ov * rows, timed(lambda: c3.replace(IPV4, "<IP>")))
+    del rep
+    cols = c3.split(" ")
+    out_b = sum(nbytes(c) for c in cols)
+    ncols = len(cols)
+    del cols
+    report("C3", "split(' ')", rows, b, b + ov * rows + out_b + ncols * ov * rows, timed(lambda: c3.split(" ")))
+    del c3, resb, resi
+
+
+
+def run_c4(a, ov):
+    # ---- C4: 16-char tokens, category build (per-GPU shard of the 1B-row config: 125M rows)
+    rows = int(125_000_000 * a.scale)
+    for K in (1000, 1 << 20):
+        c4 = synth(4, rows, K)
+        b = nbytes(c4)
+        report("C4", "category build K=%d" % K, rows, b, b + ov * rows + 4 * rows, timed(lambda: nvcategory.from_strings(c4), reps=2))
+        del c4
+
+
+
+def run_c5(a, ov):
+    # ---- C5: tweet-like rows, tokenize + bigrams (per-GPU shard: 62.5M rows)
+    rows = int(62_500_000 * a.scale)
+    c5 = synth(5, rows)
+    b = nbytes(c5)
+    tok = nvtext.tokenize(c5)
+    t = tok.size()
+    report("C5", "tokenize", rows, b, b + ov * rows + nbytes(tok) + ov * t, timed(lambda: nvtext.tokenize(c5), reps=2))
+    del c5
+    ng = nvtext.ngrams(tok, 2, "_")
+    report("C5", "ngrams(2)", t, nbytes(tok), nbytes(tok) + ov * t + nbytes(ng) + ov * ng.size(), timed(lambda: nvtext.ngrams(tok, 2, "_"), reps=2))
+
+
+if __name__ == "__main__":
+    main()
