@@ -341,6 +341,31 @@ unsigned resident_grid(const void* kern, size_t lds, int64_t wanted) {
   return (unsigned)std::max<int64_t>(1, std::min<int64_t>(cap, wanted));
 }
 
+__global__ void k_max_span_rows(const int64_t* __restrict__ offsets, int64_t rows, int per,
+                                unsigned long long* __restrict__ out) {
+  int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  int64_t r0 = t * per;
+  int v = 0;
+  if (r0 < rows) {
+    int64_t r1 = r0 + per < rows ? r0 + per : rows;
+    v = (int)(offsets[r1] - offsets[r0] > 0x7fffffff ? 0x7fffffff : offsets[r1] - offsets[r0]);
+  }
+  int m = block_reduce_max(v);
+  if (threadIdx.x == 0 && m) atomicMax(out, (unsigned long long)m);
+}
+int64_t max_span_rows(const cs_column* c, int per, hipStream_t s) {
+  if (per == 64) return max_span64(c, s);
+  if (c->rows == 0) return 0;
+  Buf acc = dev_alloc(8, s);
+  CS_HIP(hipMemsetAsync(acc->p, 0, 8, s));
+  int64_t n = (c->rows + per - 1) / per;
+  hipLaunchKernelGGL(k_max_span_rows, dim3(blocks_for(n)), dim3(kBlock), 0, s, c->d_offsets(), c->rows, per,
+                     ptr<unsigned long long>(acc));
+  int64_t* host = (int64_t*)pinned_scratch(8);
+  CS_HIP(hipMemcpyAsync(host, acc->p, 8, hipMemcpyDeviceToHost, s));
+  CS_HIP(hipStreamSynchronize(s));
+  return host[0];
+}
 int64_t max_span64(const cs_column* c, hipStream_t s) {
   if (c->max_span64 >= 0) return c->max_span64;
   if (c->rows == 0) return c->max_span64 = 0;

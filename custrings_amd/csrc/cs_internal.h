@@ -123,6 +123,8 @@ int64_t count_nulls(const cs_column* c, hipStream_t s);
 // Largest byte span of 64 consecutive rows starting at a multiple of 64 (cached
 // in the column; sizes the LDS staging buffers of the tile kernels).
 int64_t max_span64(const cs_column* c, hipStream_t s);
+// Same for tiles of `per` consecutive rows (per = 64 is the cached one).
+int64_t max_span_rows(const cs_column* c, int per, hipStream_t s);
 // Workgroups (256 threads, `lds` dynamic bytes) of `kern` resident at once on the device,
 // capped by `wanted`: grid size of the persistent tile kernels.
 unsigned resident_grid(const void* kern, size_t lds, int64_t wanted);

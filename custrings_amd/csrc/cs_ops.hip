@@ -13,6 +13,10 @@
 
 using namespace cs;
 using namespace csdev;
+
+namespace cs {
+bool tokenize_fast(const cs_column* col, const unsigned char* delims, int ndel, hipStream_t s, cs_column** out);
+}
 using namespace csrow;
 
 namespace cs {
@@ -551,6 +555,11 @@ int cs_tokenize(const cs_column* col, const char* delimiter, cs_stream stream, c
     if (rows == 0) {
       *out = make_all_null(0, s);
       return;
+    }
+    // byte-parallel tile kernels (cs_tokenize.hip) for whitespace or a few ASCII delimiters
+    if (!delimiter || (*delimiter && strlen(delimiter) <= 4)) {
+      const unsigned char* d = reinterpret_cast<const unsigned char*>(delimiter ? delimiter : "");
+      if (tokenize_fast(col, d, (int)strlen(reinterpret_cast<const char*>(d)), s, out)) return;
     }
     TokArgs a;
     a.use_set = delimiter != nullptr;

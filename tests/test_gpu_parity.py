@@ -354,3 +354,32 @@ def test_gpu_tile_kernels_fallback_paths(gpu_engine, oracle_engine, shape):
     for n in (-1, 1, 3):
         assert g.split(s, " ", n) == o.split(s, " ", n), (shape, n)
     assert g.split(s, ".", -1) == o.split(s, ".", -1)
+
+
+@pytest.mark.parametrize("shape", ["short", "medium", "long", "huge"])
+def test_gpu_tokenize_tile_kernels(gpu_engine, oracle_engine, shape):
+    """Byte-parallel tokenize (cs_tokenize.hip): tiles of 64 / 32 / 16 rows by row length, the
+    per-row fallback beyond that, whitespace and small ASCII delimiter sets, non-ASCII text,
+    empty / null / all-delimiter rows, tokens across piece and tile boundaries."""
+    import random
+
+    rnd = random.Random(len(shape) * 7)
+    lo, hi = {"short": (0, 30), "medium": (60, 150), "long": (200, 330), "huge": (500, 900)}[shape]
+    words = ["a", "bc", "déf", "x" * 17, "12.5", "😀", "tab\tbed", "q" * 40]
+    s = []
+    for i in range(5000 if shape != "huge" else 600):
+        if i % 53 == 0:
+            s.append(None)
+        elif i % 41 == 0:
+            s.append("")
+        elif i % 37 == 0:
+            s.append(" \t  \n ")
+        else:
+            target = rnd.randint(lo, hi)
+            t = rnd.choice(["", " ", "  "])
+            while len(t) < target:
+                t += rnd.choice(words) + rnd.choice([" ", "  ", "\n", "_", "-", " \t "])
+            s.append(t[: max(target, 1)])
+    o, g = oracle_engine, gpu_engine
+    for d in (None, " ", "_-", " _-\n", "é ", "abcde"):
+        assert g.tokenize(s, d) == o.tokenize(s, d), (shape, d)
