@@ -1,0 +1,202 @@
+// NVStrings::lower / upper over row tiles (case.cu:31-170).
+//
+// Case mapping almost never changes a character's UTF-8 width, and ASCII text needs no
+// table at all, so the common case is a streaming pass: a wave takes a tile of R consecutive
+// rows (their chars are one contiguous span), every lane flips the ASCII letters of the
+// 16-byte pieces it loaded with SWAR arithmetic and writes them to the output tile in LDS,
+// and only rows that contain non-ASCII bytes (found through a per-byte bitmap the piece
+// lanes leave in LDS) are redone by their row lane with the same per-character routine the
+// row-wise kernels use (row_ops.h: decode, flag/case tables, re-encode) -- LDS to LDS.  The
+// tile is then flushed with 16-byte stores to the same positions it came from: the output
+// shares the input's offsets and validity buffers.  A row whose mapped size differs from its
+// input size raises a flag and the host recomputes the column with the two-pass row kernels.
+#include <hip/hip_runtime.h>
+
+#include "cs_internal.h"
+#include "device_utils.h"
+#include "row_ops.h"
+#include "tile_utils.h"
+
+using namespace cs;
+using namespace csdev;
+using namespace csrow;
+
+namespace cs {
+bool change_case_fast(const cs_column* col, unsigned bit, bool ascii_rule_ok, hipStream_t s, cs_column** out);
+}
+
+namespace {
+
+struct CaseTileArgs {
+  ColView in;
+  int rows_per_tile;
+  long long ntiles;
+  unsigned bit;  // 32: to lower, 64: to upper (flag bit of the characters to change)
+  const uint8_t* flags;
+  const uint16_t* cases;
+  uint8_t* out_chars;
+  unsigned* changed;  // set when a row's size would change
+  int cap;            // LDS bytes per tile buffer
+};
+
+// ASCII letters of the other case, flipped (bit 5 toggled); other bytes untouched
+__device__ __forceinline__ uint32_t flip_ascii(uint32_t w, unsigned bit) {
+  const uint32_t x = w & 0x7F7F7F7Fu;
+  // to lower: bytes 0x41..0x5A; to upper: 0x61..0x7A
+  const uint32_t lo = bit == 32 ? 0x3F3F3F3Fu : 0x1F1F1F1Fu;  // 0x80 - first letter
+  const uint32_t hi = bit == 32 ? 0x25252525u : 0x05050505u;  // 0x7F - last letter
+  const uint32_t m = (x + lo) & ~(x + hi) & ~w & 0x80808080u;
+  return w ^ (m >> 2);
+}
+
+__global__ void __launch_bounds__(256) k_case_tile(CaseTileArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  constexpr int kBitmapBytes = cstile::kPfBytes / 8 + 32;
+  uint8_t* base = reinterpret_cast<uint8_t*>(smem) + (size_t)wv * (2 * a.cap + kBitmapBytes);
+  uint8_t* lds_in = base;
+  uint8_t* lds_out = base + a.cap;
+  uint32_t* bitmap = reinterpret_cast<uint32_t*>(base + 2 * a.cap);  // bit i: byte i of the tile is >= 0x80
+  const ColView& in = a.in;
+  const int R = a.rows_per_tile;
+  const long long waves = (long long)gridDim.x * 4;
+  const long long per = (a.ntiles + waves - 1) / waves;
+  long long tile = ((long long)blockIdx.x * 4 + wv) * per;
+  const long long tile_end = min(a.ntiles, tile + per);
+  if (tile >= tile_end) return;
+  auto load_offs = [&](long long t) {
+    const long long r0 = t * R;
+    const int nrows = (int)min((long long)R, in.rows - r0);
+    cstile::TileOffs o;
+    o.o0 = in.offsets[r0 + min(lane, nrows)];
+    o.o1 = in.offsets[r0 + min(lane + 1, nrows)];
+    return o;
+  };
+  cstile::TileOffs cur = load_offs(tile);
+  cstile::TileOffs nxt = cur;
+  if (tile + 1 < tile_end) nxt = load_offs(tile + 1);
+  cstile::TileChars pf;
+#pragma unroll
+  for (int j = 0; j < cstile::kPfChunks; ++j) pf.v[j] = make_uint4(0, 0, 0, 0);
+  cstile::issue_chars(in.chars, cstile::rl64(cur.o0, 0), cstile::rl64(cur.o1, 63), lane, pf);
+  for (;;) {
+    const long long r0 = tile * R;
+    const int nrows = (int)min((long long)R, in.rows - r0);
+    const long long g0 = cstile::rl64(cur.o0, 0), g1 = cstile::rl64(cur.o1, 63);
+    const bool live = lane < nrows && row_is_valid(in.validity, r0 + lane);
+    const int rbeg = (int)(cur.o0 - g0);
+    const int n = live ? (int)(cur.o1 - cur.o0) : 0;
+    const int lead = (int)((uintptr_t)(in.chars + g0) & 15);
+    const int want = (int)(g1 - g0) + lead;
+    // pieces: keep the input in LDS for the row lanes, ASCII-flipped copy in the output tile,
+    // one "byte >= 0x80" bit per byte in the bitmap
+    uint32_t any_high = 0;
+#pragma unroll
+    for (int j = 0; j < cstile::kPfChunks; ++j) {
+      const int i = j * 1024 + lane * 16;
+      if (i < want) {
+        const uint4 q = pf.v[j];
+        *reinterpret_cast<uint4*>(lds_in + i) = q;
+        uint4 o;
+        o.x = flip_ascii(q.x, a.bit);
+        o.y = flip_ascii(q.y, a.bit);
+        o.z = flip_ascii(q.z, a.bit);
+        o.w = flip_ascii(q.w, a.bit);
+        *reinterpret_cast<uint4*>(lds_out + i) = o;
+        const uint32_t hx = q.x & 0x80808080u, hy = q.y & 0x80808080u, hz = q.z & 0x80808080u, hw = q.w & 0x80808080u;
+        any_high |= hx | hy | hz | hw;
+        const uint32_t bits = ((((hx >> 7) * 0x01020408u) >> 24) & 15u) | (((((hy >> 7) * 0x01020408u) >> 24) & 15u) << 4) |
+                              (((((hz >> 7) * 0x01020408u) >> 24) & 15u) << 8) | (((((hw >> 7) * 0x01020408u) >> 24) & 15u) << 12);
+        reinterpret_cast<uint16_t*>(bitmap)[i >> 4] = (uint16_t)bits;
+      }
+    }
+    const bool has_next = tile + 1 < tile_end;
+    if (has_next) {
+      cur = nxt;
+      cstile::issue_chars(in.chars, cstile::rl64(cur.o0, 0), cstile::rl64(cur.o1, 63), lane, pf);
+      if (tile + 2 < tile_end) nxt = load_offs(tile + 2);
+    }
+    cstile::wave_lds_fence();
+    if (__any(any_high != 0)) {  // some row of the tile holds non-ASCII characters
+      bool mine = false;
+      if (n > 0) {
+        const int p0 = lead + rbeg, p1 = p0 + n;  // this row's bits [p0, p1)
+        for (int w = p0 >> 5; w <= (p1 - 1) >> 5 && !mine; ++w) {
+          uint32_t m = bitmap[w];
+          if (w == (p0 >> 5)) m &= 0xFFFFFFFFu << (p0 & 31);
+          if (w == ((p1 - 1) >> 5) && (p1 & 31)) m &= ~(0xFFFFFFFFu << (p1 & 31));
+          mine = m != 0;
+        }
+      }
+      if (mine) {
+        const uint8_t* p = lds_in + lead + rbeg;
+        if (row_case_size(p, n, a.flags, a.cases, a.bit) != n) atomicOr(a.changed, 1u);
+        else row_case_write(p, n, a.flags, a.cases, a.bit, lds_out + lead + rbeg);
+      }
+      cstile::wave_lds_fence();
+    }
+    cstile::wave_flush(a.out_chars + g0, (int)(g1 - g0), lds_out, lead, lane);
+    cstile::wave_lds_fence();
+    if (!has_next) break;
+    ++tile;
+  }
+}
+
+}  // namespace
+
+namespace cs {
+
+bool change_case_fast(const cs_column* col, unsigned bit, bool ascii_rule_ok, hipStream_t s, cs_column** out) {
+  const int64_t rows = col->rows;
+  if (rows == 0 || !ascii_rule_ok || col->nbytes == 0 || getenv("CS_CASE_ROWWISE")) return false;
+  int R = 0;
+  for (int r : {64, 32, 16}) {
+    if (max_span_rows(col, r, s) + 32 <= cstile::kPfBytes) {
+      R = r;
+      break;
+    }
+  }
+  if (!R) return false;
+  const int64_t span = max_span_rows(col, R, s);
+  CaseTileArgs a{};
+  a.in = view_of(col);
+  a.rows_per_tile = R;
+  a.ntiles = (rows + R - 1) / R;
+  a.bit = bit;
+  a.flags = d_unicode_flags();
+  a.cases = d_charcases();
+  a.cap = (int)((span + 32 + 15) & ~(int64_t)15);
+  Buf chars = dev_alloc((size_t)col->nbytes, s);
+  Buf flag = dev_alloc(sizeof(unsigned), s);
+  CS_HIP(hipMemsetAsync(flag->p, 0, sizeof(unsigned), s));
+  a.out_chars = ptr<uint8_t>(chars);
+  a.changed = ptr<unsigned>(flag);
+  constexpr size_t kBitmapBytes = cstile::kPfBytes / 8 + 32;
+  const size_t lds = (2 * (size_t)a.cap + kBitmapBytes) * 4;
+  if (lds > 150 * 1024) return false;
+  if (lds > 48 * 1024)
+    CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_case_tile), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)lds));
+  {
+    const unsigned g = resident_grid(reinterpret_cast<const void*>(&k_case_tile), lds, (a.ntiles + 3) / 4);
+    ProfScope ps(bit == 32 ? "k_lower_write" : "k_upper_write", s);
+    hipLaunchKernelGGL(k_case_tile, dim3(g), dim3(256), lds, s, a);
+  }
+  CS_HIP(hipGetLastError());
+  unsigned* h = (unsigned*)pinned_scratch(sizeof(unsigned));
+  CS_HIP(hipMemcpyAsync(h, flag->p, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+  CS_HIP(hipStreamSynchronize(s));
+  if (*h) return false;  // some row changes size: the two-pass row kernels recompute the column
+  auto* o = new cs_column;
+  o->rows = rows;
+  o->nbytes = col->nbytes;
+  o->null_count = col->null_count;
+  o->max_span64 = col->max_span64;
+  o->offsets = col->offsets;    // same row extents: share the immutable buffers
+  o->validity = col->validity;
+  o->chars = chars;
+  *out = o;
+  return true;
+}
+
+}  // namespace cs

@@ -36,6 +36,7 @@ void require_device() {
 const uint8_t* d_unicode_flags() { return g_d_flags; }
 const uint16_t* d_charcases() { return g_d_cases; }
 const uint8_t* h_unicode_flags() { return cs_unicode_flags; }
+const uint16_t* h_charcases() { return cs_charcases; }
 int64_t dev_bytes_in_use() { return g_in_use; }
 
 static void release_cache_locked() {

@@ -74,6 +74,7 @@ void* pinned_scratch(size_t bytes);
 const uint8_t* d_unicode_flags();
 const uint16_t* d_charcases();
 const uint8_t* h_unicode_flags();
+const uint16_t* h_charcases();
 
 }  // namespace cs
 

@@ -16,6 +16,7 @@ using namespace csdev;
 
 namespace cs {
 bool tokenize_fast(const cs_column* col, const unsigned char* delims, int ndel, hipStream_t s, cs_column** out);
+bool change_case_fast(const cs_column* col, unsigned bit, bool ascii_rule_ok, hipStream_t s, cs_column** out);
 }
 using namespace csrow;
 
@@ -368,6 +369,17 @@ static int change_case(const cs_column* col, unsigned bit, cs_stream stream, cs_
   return guard([&] {
     if (!col || !out) fail(CS_ERR_INVALID_ARG, "null argument");
     require_device();
+    // tile kernel (cs_case.hip) when the tables map ASCII the plain way (A-Z <-> a-z only)
+    static const bool ascii_rule_ok = [] {
+      const uint8_t* f = h_unicode_flags();
+      const uint16_t* c = h_charcases();
+      for (unsigned b = 0; b < 128; ++b) {
+        const unsigned lower = (b >= 'A' && b <= 'Z') ? b + 32 : b, upper = (b >= 'a' && b <= 'z') ? b - 32 : b;
+        if (((f[b] & 32) ? c[b] : b) != lower || ((f[b] & 64) ? c[b] : b) != upper) return false;
+      }
+      return true;
+    }();
+    if (change_case_fast(col, bit, ascii_rule_ok, S(stream), out)) return;
     *out = two_pass(col, CaseSize{d_unicode_flags(), d_charcases(), bit},
                     CaseWrite{d_unicode_flags(), d_charcases(), bit}, S(stream),
                     bit == 32 ? "k_lower_size" : "k_upper_size", nm);
