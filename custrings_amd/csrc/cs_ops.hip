@@ -17,6 +17,7 @@ using namespace csdev;
 namespace cs {
 bool tokenize_fast(const cs_column* col, const unsigned char* delims, int ndel, hipStream_t s, cs_column** out);
 bool change_case_fast(const cs_column* col, unsigned bit, bool ascii_rule_ok, hipStream_t s, cs_column** out);
+bool ngrams_fast(const cs_column* tokens, int n, const unsigned char* sep, int sepn, hipStream_t s, cs_column** out);
 }
 using namespace csrow;
 
@@ -630,6 +631,9 @@ int cs_ngrams(const cs_column* tokens, unsigned ngrams, const char* separator, c
       *out = share(tokens);
       return;
     }
+    // tile kernel with closed-form offsets when no row is dropped (cs_ngram.hip)
+    if (ngrams_fast(tokens, (int)ngrams, reinterpret_cast<const unsigned char*>(separator), (int)strlen(separator), s, out))
+      return;
     Needle sep = upload(separator, s);
     // drop null and empty rows (ngram.cu:48-50)
     Buf flags = dev_alloc(sizeof(int32_t) * rows, s);

@@ -383,3 +383,20 @@ def test_gpu_tokenize_tile_kernels(gpu_engine, oracle_engine, shape):
     o, g = oracle_engine, gpu_engine
     for d in (None, " ", "_-", " _-\n", "é ", "abcde"):
         assert g.tokenize(s, d) == o.tokenize(s, d), (shape, d)
+
+
+@pytest.mark.parametrize("count", [3, 64, 65, 700, 9000])
+def test_gpu_ngrams_tile_kernel(gpu_engine, oracle_engine, count):
+    """cs_ngram.hip (no dropped rows: closed-form offsets) and the row-wise path (nulls / empties)."""
+    import random
+
+    rnd = random.Random(count)
+    toks = ["".join(rnd.choice("abcdé😀xyz") for _ in range(rnd.choice([1, 2, 3, 5, 8, 15, 16, 17, 33]))) for _ in range(count)]
+    o, g = oracle_engine, gpu_engine
+    for N in (2, 3, 5):
+        for sep in ("_", "", " - ", "12345678", "123456789"):
+            assert g.ngrams(toks, N, sep) == o.ngrams(toks, N, sep), (count, N, sep)
+    holes = list(toks)
+    for i in range(0, count, 7):
+        holes[i] = None if i % 2 else ""
+    assert g.ngrams(holes, 2, "_") == o.ngrams(holes, 2, "_")
