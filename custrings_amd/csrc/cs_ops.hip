@@ -465,6 +465,27 @@ int cs_replace(const cs_column* col, const char* str, const char* repl, int maxr
     require_device();
     hipStream_t s = S(stream);
     if (!repl) repl = "";
+    // A needle without regex metacharacters whose replacement is no longer than itself runs on
+    // the persistent single-pass replace_re kernel (same leftmost, non-overlapping semantics;
+    // modify.cu:109-192 restarts at pos + nchars(str), replace.cu:91-92 at the match end).
+    {
+      bool plain = true;
+      for (const char* p = str; *p && plain; ++p) {
+        const unsigned char c = (unsigned char)*p;
+        plain = (c >= '0' && c <= '9') || (c >= 'A' && c <= 'Z') || (c >= 'a' && c <= 'z') || c == ' ' || c == '_' ||
+                c == ',' || c == ';' || c == ':' || c == '=' || c == '@' || c == '#' || c == '%' || c == '&' || c == '~' ||
+                c == '<' || c == '>' || c == '/' || c == '!' || c == '-' || c == '"' || c == '\'';
+      }
+      const size_t nb = strlen(str), rb = strlen(repl);
+      if (plain && rb <= nb && rb <= 8 && col->rows > 0 && !getenv("CS_REPLACE_ROWWISE")) {
+        cs_regex* re = nullptr;
+        if (cs_regex_compile(str, &re) == CS_OK) {
+          const int rc = cs_replace_re(col, re, repl, maxrepl, stream, out);
+          cs_regex_destroy(re);
+          if (rc == CS_OK) return;
+        }
+      }
+    }
     Needle nd = upload(str, s), rp = upload(repl, s);
     *out = two_pass(col, ReplaceSize{nd.d(), nd.n, rp.n, maxrepl},
                     ReplaceWrite{nd.d(), rp.d(), nd.n, rp.n, maxrepl}, s, "k_replace_size", "k_replace_write");

@@ -400,3 +400,17 @@ def test_gpu_ngrams_tile_kernel(gpu_engine, oracle_engine, count):
     for i in range(0, count, 7):
         holes[i] = None if i % 2 else ""
     assert g.ngrams(holes, 2, "_") == o.ngrams(holes, 2, "_")
+
+
+def test_gpu_literal_replace_on_stream_kernel(gpu_engine, oracle_engine, orc):
+    """Literal needles without metacharacters and a replacement no longer than the needle take
+    the single-pass replace_re kernel; results must equal the literal replace of the oracle."""
+    s = fuzzdata.rows(3, 3000, max_len=60) + fuzzdata.log_rows(9, 2000) + ["aaaa", "aaa", "abab ab", "", None]
+    o, g = oracle_engine, gpu_engine
+    for pat, repl in (("a", "b"), ("aa", "a"), ("ab", ""), ("b c", "_"), ("1", "#"), ("abc", "abc"), ("a", "")):
+        for n in (-1, 0, 1, 2):
+            assert g.replace(s, pat, repl, n) == o.replace(s, pat, repl, n), (pat, repl, n)
+    rows = 100_000
+    gc, oc = gpuutil.synth(3, 0, rows), orc.synth(3, 0, rows)
+    for pat, repl in (("GET", "G"), ("POST ", "P"), ("200", "OK"), ("e", "")):
+        gpuutil.assert_same(gc.replace(pat, repl, regex=False), orc.replace(oc, pat, repl), "literal %r" % pat)

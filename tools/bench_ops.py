@@ -88,7 +88,9 @@ def run_c2(a, ov):
     report("C2", "contains('ab', regex=False)", rows, b, b + ov * rows + rows, timed(lambda: c2.contains("ab", regex=False, devptr=resb.data_ptr())))
     rl = c2.replace("a", "xx", regex=False)
     report("C2", "replace('a','xx') literal", rows, b, b + nbytes(rl) + 2 * ov * rows, timed(lambda: c2.replace("a", "xx", regex=False)))
-    del c2, low, st, cols, rl
+    rs = c2.replace("ab", "x", regex=False)
+    report("C2", "replace('ab','x') literal", rows, b, b + nbytes(rs) + 2 * ov * rows, timed(lambda: c2.replace("ab", "x", regex=False)))
+    del c2, low, st, cols, rl, rs
 
 
 
