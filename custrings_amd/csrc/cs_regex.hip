@@ -611,6 +611,100 @@ __global__ void __launch_bounds__(256, CS_STREAM_WAVES) k_tdfa_replace_stream(St
 
 
 
+
+// ---- persistent contains_re / count_re over row tiles -----------------------------------
+// Same staging as the replace kernel (contiguous tile runs per wave, next tile's chars in
+// flight), no output assembly: LDS holds the DFA table and one input tile per wave, so seven
+// workgroups fit a CU.  MODE 0 contains_re, 2 count_re.
+struct ScanStreamArgs {
+  ColView in;
+  const uint8_t* flags;
+  TLaunch L;
+  uint8_t* out8;
+  int32_t* out32;
+  unsigned long long* found;
+  long long nsub;
+  int cap_in, tbl_bytes;
+};
+template <int MODE, bool IN_LDS>
+__global__ void __launch_bounds__(256) k_tdfa_scan_stream(ScanStreamArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  uint8_t* base = reinterpret_cast<uint8_t*>(smem);
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  uint8_t* lds_in = base + a.tbl_bytes + (size_t)wv * (a.cap_in + 32);
+  const TCtx c = tsetup<IN_LDS>(a.L, a.flags, smem);
+  const cstd::View& D = c.D;
+  const csvm::ProgView& P = c.P;
+  const ColView& in = a.in;
+  const long long waves = (long long)gridDim.x * 4;
+  const long long per = (a.nsub + waves - 1) / waves;
+  long long tile = ((long long)blockIdx.x * 4 + wv) * per;
+  const long long tile_end = min(a.nsub, tile + per);
+  if (tile >= tile_end) return;
+  cstile::TileOffs cur = cstile::load_tile_offsets(in.offsets, in.rows, tile, lane);
+  cstile::TileOffs nxt = cur;
+  if (tile + 1 < tile_end) nxt = cstile::load_tile_offsets(in.offsets, in.rows, tile + 1, lane);
+  cstile::TileChars pf;
+#pragma unroll
+  for (int j = 0; j < cstile::kPfChunks; ++j) pf.v[j] = make_uint4(0, 0, 0, 0);
+  cstile::issue_chars(in.chars, cstile::rl64(cur.o0, 0), cstile::rl64(cur.o1, 63), lane, pf);
+  int hits = 0;
+  for (;;) {
+    const long long r0 = tile * 64;
+    const int nrows = (int)min(64ll, in.rows - r0);
+    const long long g0 = cstile::rl64(cur.o0, 0), g1 = cstile::rl64(cur.o1, 63);
+    const bool live = lane < nrows && row_is_valid(in.validity, r0 + lane);
+    const int rbeg = (int)(cur.o0 - g0);
+    const int n = live ? (int)(cur.o1 - cur.o0) : 0;
+    const int lead = (int)((uintptr_t)(in.chars + g0) & 15);
+    const int want = (int)(g1 - g0) + lead;
+    cstile::stage_chars(lds_in, want, lane, pf);
+    uint32_t odd = 0;
+#pragma unroll
+    for (int j = 0; j < cstile::kPfChunks; ++j)
+      if (j * 1024 + lane * 16 < want) {
+        const uint4 q = pf.v[j];
+        odd |= q.x | ((q.x - 0x01010101u) & ~q.x);
+        odd |= q.y | ((q.y - 0x01010101u) & ~q.y);
+        odd |= q.z | ((q.z - 0x01010101u) & ~q.z);
+        odd |= q.w | ((q.w - 0x01010101u) & ~q.w);
+      }
+    const bool has_next = tile + 1 < tile_end;
+    if (has_next) {
+      cur = nxt;
+      cstile::issue_chars(in.chars, cstile::rl64(cur.o0, 0), cstile::rl64(cur.o1, 63), lane, pf);
+      if (tile + 2 < tile_end) nxt = cstile::load_tile_offsets(in.offsets, in.rows, tile + 2, lane);
+    }
+    cstile::wave_lds_fence();
+    int v = 0;
+    {
+      cstd::Tdfa vm(D, P, lds_in + lead + rbeg, n, (lead + rbeg) & 3);
+      const bool lean = D.nskip > 0 && D.img[12] <= 4 && !__any((odd & 0x80808080u) != 0) && !__any(live && !vm.masks_fit());
+      bool redo = live && !lean;
+      if (lean && live) {
+        uint32_t m0, m1, m2;
+        if (vm.has_range2()) vm.build_masks_lean<true>(m0, m1, m2);
+        else vm.build_masks_lean<false>(m0, m1, m2);
+        v = vm.scan_lean_count<MODE == 2 ? cstd::Tdfa::K_COUNT : cstd::Tdfa::K_CONTAINS>(m0, m1, m2);
+        redo = v < 0;
+      }
+      if (__any(redo)) {
+        if (redo) v = MODE == 2 ? csvm::row_count_re(vm) : csvm::row_contains_re(vm, false);
+      }
+    }
+    if (lane < nrows) {
+      if (MODE == 2) a.out32[r0 + lane] = v;
+      else a.out8[r0 + lane] = (uint8_t)v;
+    }
+    hits += v > 0;
+    cstile::wave_lds_fence();  // the next tile overwrites lds_in
+    if (!has_next) break;
+    ++tile;
+  }
+  const int t = wave_reduce_sum(hits);
+  if (lane == 0 && t) atomicAdd(a.found, (unsigned long long)t);
+}
+
 struct TPlan {
   TLaunch d;
   size_t lds_bytes;
@@ -703,7 +797,32 @@ void scan(const cs_column* col, cs_regex* re, uint8_t* out8, int32_t* out32, int
   Buf cnt = dev_alloc(8, s);
   CS_HIP(hipMemsetAsync(cnt->p, 0, 8, s));
   RowSrc src{view_of(col), d_unicode_flags(), col->nbytes + (col->chars && col->chars->capacity ? 64 : 0)};
-  {
+  bool streamed = false;
+  if (tdfa && tp.d.in_lds && MODE != 1 && !getenv("CS_REGEX_ROWWISE")) {
+    const int64_t span = max_span64(col, s);
+    const int cap = (int)((span + 15 + 32 + 127) & ~(int64_t)127);
+    const size_t lds = tp.lds_bytes + (size_t)(cap + 32) * 4;
+    if (cap <= cstile::kPfBytes && lds <= 150 * 1024) {
+      ScanStreamArgs sa{};
+      sa.in = view_of(col);
+      sa.flags = d_unicode_flags();
+      sa.L = tp.d;
+      sa.out8 = out8;
+      sa.out32 = out32;
+      sa.found = ptr<unsigned long long>(cnt);
+      sa.nsub = (col->rows + 63) / 64;
+      sa.cap_in = cap;
+      sa.tbl_bytes = (int)tp.lds_bytes;
+      auto kern = &k_tdfa_scan_stream<MODE == 2 ? 2 : 0, true>;
+      if (lds > 48 * 1024)
+        CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      const unsigned grid = resident_grid(reinterpret_cast<const void*>(kern), lds, (sa.nsub + 3) / 4);
+      ProfScope ps(name, s);
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, sa);
+      streamed = true;
+    }
+  }
+  if (!streamed) {
     ProfScope ps(name, s);
     if (tdfa)
       if (tp.d.in_lds)

@@ -420,8 +420,8 @@ struct Tdfa {
     if (c) return 64 + ctz32(c);
     return n;
   }
-  template <bool USES, class Emit>
-  CS_HD int scan_lean_replace(int maxrepl, uint32_t cm0, uint32_t cm1, uint32_t cm2, Emit&& emit, bool& bail) {
+  template <int KIND, bool USES, class Emit>
+  CS_HD int scan_lean(int maxrepl, uint32_t cm0, uint32_t cm1, uint32_t cm2, Emit&& emit, bool& bail) {
     int from = 0, pos = 0, done = 0, mb = 0, me = 0;
     uint32_t matched = 0;
     uint32_t slots = 0;  // byte j = start offset of thread slot j
@@ -490,14 +490,21 @@ struct Tdfa {
       }
       // ---- this find() round is over
       if (!matched) return done;
-      if (me == mb && mb == from) {  // zero-length repeat rule (replace.cu:91-93): generic path
-        bail = true;
-        return done;
+      if (KIND == K_CONTAINS) return 1;
+      if (KIND == K_COUNT) {
+        ++done;
+        from = me > mb ? me : mb + 1;  // empty match: step one (ASCII) character (count.cu:190-196)
+        if (from > n) return done;
+      } else {
+        if (me == mb && mb == from) {  // zero-length repeat rule (replace.cu:91-93): generic path
+          bail = true;
+          return done;
+        }
+        emit(mb, me, 1);
+        ++done;
+        if (maxrepl >= 0 && done >= maxrepl) return done;
+        from = me;
       }
-      emit(mb, me, 1);
-      ++done;
-      if (maxrepl >= 0 && done >= maxrepl) return done;
-      from = me;
       pos = from;
       matched = 0;
       posb = (uint32_t)from * 0x01010101u;
@@ -516,8 +523,17 @@ struct Tdfa {
   }
   template <class Emit>
   CS_HD int scan_lean_dispatch(int maxrepl, uint32_t m0, uint32_t m1, uint32_t m2, Emit&& emit, bool& bail) {
-    if (D.uses) return scan_lean_replace<true>(maxrepl, m0, m1, m2, emit, bail);
-    return scan_lean_replace<false>(maxrepl, m0, m1, m2, emit, bail);
+    if (D.uses) return scan_lean<K_REPLACE, true>(maxrepl, m0, m1, m2, emit, bail);
+    return scan_lean<K_REPLACE, false>(maxrepl, m0, m1, m2, emit, bail);
+  }
+  // contains_re (KIND = K_CONTAINS) / count_re (K_COUNT) on a qualifying row; -1 = the row needs
+  // the generic scan (a COMPLEX transition was met)
+  template <int KIND>
+  CS_HD int scan_lean_count(uint32_t m0, uint32_t m1, uint32_t m2) {
+    bool bail = false;
+    auto none = [](int, int, int) {};
+    const int r = D.uses ? scan_lean<KIND, true>(0, m0, m1, m2, none, bail) : scan_lean<KIND, false>(0, m0, m1, m2, none, bail);
+    return bail ? -1 : r;
   }
 
   // emit(mb, me, reps) per match (K_REPLACE: reps > 1 for the zero-length repeat);
@@ -683,9 +699,27 @@ struct Tdfa {
 namespace csvm {
 CS_HD int row_contains_re(cstd::Tdfa& vm, bool anchored) {
   auto none = [](int, int, int) {};
+#if !defined(__HIP_DEVICE_COMPILE__)
+  if (!anchored && vm.lean_ok()) {  // host builds check the lean scan against the oracle (tests/rowemu)
+    uint32_t m0, m1, m2;
+    if (vm.has_range2()) vm.build_masks_lean<true>(m0, m1, m2);
+    else vm.build_masks_lean<false>(m0, m1, m2);
+    const int r = vm.scan_lean_count<cstd::Tdfa::K_CONTAINS>(m0, m1, m2);
+    if (r >= 0) return r;
+  }
+#endif
   return anchored ? vm.scan<cstd::Tdfa::K_MATCH>(0, none) : vm.scan<cstd::Tdfa::K_CONTAINS>(0, none);
 }
 CS_HD int row_count_re(cstd::Tdfa& vm) {
+#if !defined(__HIP_DEVICE_COMPILE__)
+  if (vm.lean_ok()) {
+    uint32_t m0, m1, m2;
+    if (vm.has_range2()) vm.build_masks_lean<true>(m0, m1, m2);
+    else vm.build_masks_lean<false>(m0, m1, m2);
+    const int r = vm.scan_lean_count<cstd::Tdfa::K_COUNT>(m0, m1, m2);
+    if (r >= 0) return r;
+  }
+#endif
   return vm.scan<cstd::Tdfa::K_COUNT>(0, [](int, int, int) {});
 }
 template <class Emit>
