@@ -25,14 +25,40 @@ struct cs_category {
 
 namespace {
 
-__device__ __forceinline__ uint64_t hash_bytes(const uint8_t* p, int n) {
-  uint64_t h = 0xcbf29ce484222325ull;
-  for (int i = 0; i < n; ++i) h = (h ^ p[i]) * 0x100000001b3ull;
-  h ^= h >> 32;
-  h *= 0x9E3779B97F4A7C15ull;
-  return h ^ (h >> 29);
+// little-endian dword k of a row, zero beyond its end (aligned rows load whole dwords)
+__device__ __forceinline__ uint32_t row_word(const uint8_t* p, int n, int k, bool aligned) {
+  const int i = 4 * k;
+  if (aligned && i + 4 <= n) return *reinterpret_cast<const uint32_t*>(p + i);
+  uint32_t w = 0;
+  for (int j = 0; j < 4; ++j)
+    if (i + j < n) w |= (uint32_t)p[i + j] << (8 * j);
+  return w;
+}
+// Any well-mixed hash will do: keys and codes depend only on the sorted key set.
+__device__ __forceinline__ uint32_t hash_bytes(const uint8_t* p, int n) {
+  const bool aligned = ((uintptr_t)p & 3) == 0;
+  uint32_t h = 0x9E3779B9u ^ (uint32_t)n;
+  for (int k = 0; 4 * k < n; ++k) {
+    uint32_t w = row_word(p, n, k, aligned) * 0xCC9E2D51u;
+    w = (w << 15) | (w >> 17);
+    h ^= w * 0x1B873593u;
+    h = ((h << 13) | (h >> 19)) * 5u + 0xE6546B64u;
+  }
+  h ^= h >> 16;
+  h *= 0x85EBCA6Bu;
+  h ^= h >> 13;
+  h *= 0xC2B2AE35u;
+  return h ^ (h >> 16);
 }
 __device__ __forceinline__ bool same_bytes(const uint8_t* a, const uint8_t* b, int n) {
+  if ((((uintptr_t)a | (uintptr_t)b) & 3) == 0) {
+    int i = 0;
+    for (; i + 4 <= n; i += 4)
+      if (*reinterpret_cast<const uint32_t*>(a + i) != *reinterpret_cast<const uint32_t*>(b + i)) return false;
+    for (; i < n; ++i)
+      if (a[i] != b[i]) return false;
+    return true;
+  }
   for (int i = 0; i < n; ++i)
     if (a[i] != b[i]) return false;
   return true;
@@ -48,8 +74,10 @@ __device__ __forceinline__ int compare_rows(const ColView& in, int64_t ra, int64
   return la - lb;
 }
 
+constexpr int kProbeLimit = 128;  // longer probe runs mean the table is too small: the host retries with a bigger one
 __global__ void k_cat_insert(ColView in, int32_t* __restrict__ table, uint32_t mask,
-                             int32_t* __restrict__ slot_of_row, int* __restrict__ has_null) {
+                             int32_t* __restrict__ slot_of_row, int* __restrict__ has_null, int* __restrict__ overflow,
+                             int probe_limit) {
   int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (r >= in.rows) return;
   if (!row_is_valid(in.validity, r)) {
@@ -60,7 +88,8 @@ __global__ void k_cat_insert(ColView in, int32_t* __restrict__ table, uint32_t m
   int64_t b = in.offsets[r];
   int n = (int)(in.offsets[r + 1] - b);
   const uint8_t* p = in.chars + b;
-  uint32_t slot = (uint32_t)hash_bytes(p, n) & mask;
+  uint32_t slot = hash_bytes(p, n) & mask;
+  int probes = 0;
   for (;;) {
     // Look before the CAS: a slot only ever changes from -1 to its final row, so a non-empty
     // value read here is final and the common case (key already present) needs no atomic at
@@ -72,6 +101,10 @@ __global__ void k_cat_insert(ColView in, int32_t* __restrict__ table, uint32_t m
     int64_t cb = in.offsets[cur];
     if ((int)(in.offsets[cur + 1] - cb) == n && same_bytes(in.chars + cb, p, n)) break;
     slot = (slot + 1) & mask;
+    if (++probes > probe_limit) {
+      *overflow = 1;
+      return;
+    }
   }
   slot_of_row[r] = (int32_t)slot;
 }
@@ -179,19 +212,36 @@ cs_category* build(const cs_column* col, hipStream_t s) {
     return cat.release();
   }
   if (rows >= (1LL << 31) - 1) fail(CS_ERR_RANGE, "category: more than 2^31 rows in one column");
-  int64_t cap = 256;
-  while (cap < 2 * rows) cap <<= 1;
+  // Table capacity: most columns have far fewer distinct keys than rows, and a table that stays
+  // in the caches makes every probe and every later pass over it cheap -- start with 4M slots
+  // and retry with room for all-distinct rows only if a probe run gets long.
+  int64_t full = 256;
+  while (full < 2 * rows) full <<= 1;
   ColView in = view_of(col);
-  Buf table = dev_alloc(sizeof(int32_t) * cap, s);
-  CS_HIP(hipMemsetAsync(table->p, 0xFF, sizeof(int32_t) * cap, s));
   Buf slot_of_row = dev_alloc(sizeof(int32_t) * rows, s);
-  Buf has_null_d = dev_alloc(sizeof(int), s);
-  CS_HIP(hipMemsetAsync(has_null_d->p, 0, sizeof(int), s));
-  {
-    ProfScope ps("k_cat_insert", s);
-    hipLaunchKernelGGL(k_cat_insert, dim3(blocks_for(rows)), dim3(kBlock), 0, s, in, ptr<int32_t>(table),
-                       (uint32_t)(cap - 1), ptr<int32_t>(slot_of_row), ptr<int>(has_null_d));
+  Buf flags_d = dev_alloc(2 * sizeof(int), s);  // [0] has_null, [1] overflow
+  Buf table;
+  int first_log2 = 22;
+  if (const char* e = getenv("CS_CAT_FIRST_LOG2")) first_log2 = std::max(4, std::min(30, atoi(e)));  // tests: force retries
+  int64_t cap = std::min<int64_t>(full, getenv("CS_CAT_FULL_TABLE") ? full : (int64_t)1 << first_log2);
+  for (;;) {
+    table = dev_alloc(sizeof(int32_t) * cap, s);
+    CS_HIP(hipMemsetAsync(table->p, 0xFF, sizeof(int32_t) * cap, s));
+    CS_HIP(hipMemsetAsync(flags_d->p, 0, 2 * sizeof(int), s));
+    {
+      ProfScope ps("k_cat_insert", s);
+      hipLaunchKernelGGL(k_cat_insert, dim3(blocks_for(rows)), dim3(kBlock), 0, s, in, ptr<int32_t>(table),
+                         (uint32_t)(cap - 1), ptr<int32_t>(slot_of_row), ptr<int>(flags_d), ptr<int>(flags_d) + 1,
+                         cap == full ? 0x7fffffff : kProbeLimit);
+    }
+    if (cap == full) break;  // room for all-distinct rows: no limit applied, nothing to retry
+    int* h = (int*)pinned_scratch(2 * sizeof(int));
+    CS_HIP(hipMemcpyAsync(h, flags_d->p, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
+    CS_HIP(hipStreamSynchronize(s));
+    if (!h[1]) break;
+    cap = std::min<int64_t>(full, cap * 16);
   }
+  Buf has_null_d = flags_d;
   // compact the occupied slots
   Buf flags = dev_alloc(sizeof(int32_t) * cap, s);
   hipLaunchKernelGGL(k_cat_flags, dim3(blocks_for(cap)), dim3(kBlock), 0, s, ptr<const int32_t>(table), cap,

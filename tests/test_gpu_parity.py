@@ -414,3 +414,20 @@ def test_gpu_literal_replace_on_stream_kernel(gpu_engine, oracle_engine, orc):
     gc, oc = gpuutil.synth(3, 0, rows), orc.synth(3, 0, rows)
     for pat, repl in (("GET", "G"), ("POST ", "P"), ("200", "OK"), ("e", "")):
         gpuutil.assert_same(gc.replace(pat, repl, regex=False), orc.replace(oc, pat, repl), "literal %r" % pat)
+
+
+def test_gpu_category_table_growth(orc, monkeypatch):
+    """The category build starts with a small hash table and retries with a larger one when a
+    probe run gets long: force the retries with a tiny first table."""
+    from custrings_amd import nvcategory
+
+    rows = 200_000
+    g, o = gpuutil.synth(4, 0, rows, 1 << 20), orc.synth(4, 0, rows, param=1 << 20)
+    ok, ov = orc.category(o)
+    for first in ("6", "12", "30"):
+        monkeypatch.setenv("CS_CAT_FIRST_LOG2", first)
+        cat = nvcategory.from_strings(g)
+        gpuutil.assert_same(cat.keys(), ok, "keys (first table 2^%s)" % first)
+        vals = np.zeros(rows, dtype=np.int32)
+        cat.values(vals)
+        assert np.array_equal(vals, ov)
