@@ -118,20 +118,54 @@ __global__ void __launch_bounds__(256) k_case_tile(CaseTileArgs a) {
     }
     cstile::wave_lds_fence();
     if (__any(any_high != 0)) {  // some row of the tile holds non-ASCII characters
-      bool mine = false;
+      // Row lanes visit only the non-ASCII bytes of their row (bitmap bits), in order: a lead byte
+      // followed by exactly its continuation bytes is mapped through the tables and patched into
+      // the output tile; anything else (stray or missing continuation bytes) sends the row through
+      // the sequential routines of row_ops.h, which define the behaviour for malformed input.
       if (n > 0) {
         const int p0 = lead + rbeg, p1 = p0 + n;  // this row's bits [p0, p1)
-        for (int w = p0 >> 5; w <= (p1 - 1) >> 5 && !mine; ++w) {
+        const uint8_t* p = lds_in + p0;
+        uint8_t* o = lds_out + p0;
+        bool any = false, malformed = false, resized = false;
+        int expect = 0, last = -2;
+        for (int w = p0 >> 5; w <= (p1 - 1) >> 5; ++w) {
           uint32_t m = bitmap[w];
           if (w == (p0 >> 5)) m &= 0xFFFFFFFFu << (p0 & 31);
           if (w == ((p1 - 1) >> 5) && (p1 & 31)) m &= ~(0xFFFFFFFFu << (p1 & 31));
-          mine = m != 0;
+          while (m) {
+            const int i = (w << 5) + __builtin_ctz(m) - p0;  // row offset of this non-ASCII byte
+            m &= m - 1;
+            any = true;
+            const uint8_t b = p[i];
+            if (expect > 0) {
+              malformed |= !is_cont(b) || i != last + 1;
+              --expect;
+            } else {
+              const unsigned w8 = lead_width(b);
+              malformed |= w8 < 2 || i + (int)w8 > n;
+              expect = (int)w8 - 1;
+              if (!malformed) {
+                Char ch;
+                decode_at(p, i, n, ch);
+                const unsigned u = packed_to_cp(ch);
+                const unsigned f = u <= 0xFFFF ? a.flags[u] : 0;
+                if (f & a.bit) {
+                  const Char nc = cp_to_packed(a.cases[u]);
+                  if (packed_width(nc) != w8) resized = true;
+                  else
+                    for (unsigned k = 0; k < w8; ++k) o[i + (int)k] = (uint8_t)(nc >> (8 * (w8 - 1 - k)));
+                }
+              }
+            }
+            last = i;
+          }
         }
-      }
-      if (mine) {
-        const uint8_t* p = lds_in + lead + rbeg;
-        if (row_case_size(p, n, a.flags, a.cases, a.bit) != n) atomicOr(a.changed, 1u);
-        else row_case_write(p, n, a.flags, a.cases, a.bit, lds_out + lead + rbeg);
+        malformed |= expect != 0;
+        if (any && malformed) {
+          if (row_case_size(p, n, a.flags, a.cases, a.bit) != n) resized = true;
+          else row_case_write(p, n, a.flags, a.cases, a.bit, o);
+        }
+        if (resized) atomicOr(a.changed, 1u);
       }
       cstile::wave_lds_fence();
     }

@@ -431,3 +431,22 @@ def test_gpu_category_table_growth(orc, monkeypatch):
         vals = np.zeros(rows, dtype=np.int32)
         cat.values(vals)
         assert np.array_equal(vals, ov)
+
+
+def test_gpu_case_tile_kernel_on_arbitrary_bytes(monkeypatch):
+    """lower()/upper() tile kernel against the row-wise kernels on rows of ARBITRARY bytes
+    (stray / missing continuation bytes, truncated sequences at row ends): the fast path must
+    hand every malformed row to the sequential routine, so both routes agree bit for bit."""
+    rng = np.random.default_rng(5)
+    rows = 20_000
+    lens = rng.integers(0, 90, rows)
+    offs = np.zeros(rows + 1, dtype=np.int64)
+    np.cumsum(lens, out=offs[1:])
+    pool = np.array(list(b"abcXYZ 09.") + [0xC3, 0xA9, 0x89, 0xE2, 0x82, 0xAC, 0xF0, 0x9F, 0x98, 0x80, 0xC4, 0xB0, 0xFF, 0x80], dtype=np.uint8)
+    chars = pool[rng.integers(0, len(pool), int(offs[-1]))]
+    col = cpulibs.Col(chars, offs, None)
+    g = gpuutil.from_col(col)
+    fast_l, fast_u = gpuutil.to_col(g.lower()), gpuutil.to_col(g.upper())
+    monkeypatch.setenv("CS_CASE_ROWWISE", "1")
+    slow_l, slow_u = gpuutil.to_col(g.lower()), gpuutil.to_col(g.upper())
+    assert fast_l.same_as(slow_l) and fast_u.same_as(slow_u)
