@@ -19,6 +19,13 @@ bool tokenize_fast(const cs_column* col, const unsigned char* delims, int ndel, 
 bool change_case_fast(const cs_column* col, unsigned bit, bool ascii_rule_ok, hipStream_t s, cs_column** out);
 bool ngrams_fast(const cs_column* tokens, int n, const unsigned char* sep, int sepn, hipStream_t s, cs_column** out);
 }
+namespace csrow {
+struct CharSet;
+}
+namespace cs {
+bool strip_write_tiles(const cs_column* in, const csrow::CharSet& set, int side, const int64_t* out_off, uint8_t* out_chars,
+                       hipStream_t s);
+}
 using namespace csrow;
 
 namespace cs {
@@ -395,6 +402,36 @@ int cs_strip(const cs_column* col, const char* to_strip, int side, cs_stream str
     if (!col || !out || side < 0 || side > 2) fail(CS_ERR_INVALID_ARG, "strip: bad arguments");
     require_device();
     CharSet set = make_set(to_strip ? to_strip : " \n\t", "strip");
+    hipStream_t s = S(stream);
+    // size pass + scan as for every row-wise op; the write pass runs on row tiles (cs_rows.hip)
+    if (col->rows > 0 && !getenv("CS_STRIP_ROWWISE")) {
+      auto o = std::make_unique<cs_column>();
+      o->rows = col->rows;
+      o->validity = col->validity;
+      o->null_count = col->null_count;
+      const unsigned nb = blocks_for(col->rows);
+      Buf lens = dev_alloc(sizeof(int32_t) * col->rows, s);
+      Buf sums = dev_alloc(sizeof(int64_t) * nb, s);
+      {
+        ProfScope ps("k_strip_size", s);
+        hipLaunchKernelGGL(k_row_sizes<StripSize>, dim3(nb), dim3(kBlock), 0, s, view_of(col), StripSize{set, side},
+                           ptr<int32_t>(lens), ptr<int64_t>(sums));
+      }
+      o->offsets = dev_alloc(sizeof(int64_t) * (col->rows + 1), s);
+      o->nbytes = offsets_from_lengths(ptr<int32_t>(lens), col->rows, ptr<int64_t>(o->offsets), s, sums);
+      o->chars = dev_alloc((size_t)o->nbytes, s);
+      if (strip_write_tiles(col, set, side, o->d_offsets(), ptr<uint8_t>(o->chars), s)) {
+        *out = o.release();
+        return;
+      }
+      {
+        ProfScope ps("k_strip_write", s);
+        hipLaunchKernelGGL(k_row_write<StripWrite>, dim3(nb), dim3(kBlock), 0, s, view_of(col), StripWrite{set, side},
+                           o->d_offsets(), ptr<uint8_t>(o->chars));
+      }
+      *out = o.release();
+      return;
+    }
     *out = two_pass(col, StripSize{set, side}, StripWrite{set, side}, S(stream), "k_strip_size", "k_strip_write");
   });
 }

@@ -1,0 +1,131 @@
+// Tile form of the write pass of strip (strip.cu:30-199): the output row is a sub-range of the
+// input row, so with the output offsets known (size pass + scan) a wave stages a tile of R
+// consecutive rows in LDS, every row lane finds its kept range again on the LDS copy (it only
+// touches the row's ends), copies it to its place in the output tile (4 dwords per trip) and
+// the tile leaves with 16-byte stores.  Replaces the per-byte global-to-global copy of the
+// row-wise write kernel.
+#include <hip/hip_runtime.h>
+
+#include "cs_internal.h"
+#include "device_utils.h"
+#include "row_ops.h"
+#include "tile_utils.h"
+
+using namespace cs;
+using namespace csdev;
+using namespace csrow;
+
+namespace cs {
+bool strip_write_tiles(const cs_column* in, const CharSet& set, int side, const int64_t* out_off, uint8_t* out_chars,
+                       hipStream_t s);
+}
+
+namespace {
+
+struct StripTileArgs {
+  ColView in;
+  CharSet set;
+  int side, rows_per_tile, cap;
+  long long ntiles;
+  const int64_t* out_off;
+  uint8_t* out_chars;
+};
+
+__global__ void __launch_bounds__(256) k_strip_tile(StripTileArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  uint8_t* lds_in = reinterpret_cast<uint8_t*>(smem) + (size_t)wv * 2 * a.cap;
+  uint8_t* lds_out = lds_in + a.cap;
+  const ColView& in = a.in;
+  const int R = a.rows_per_tile;
+  const long long waves = (long long)gridDim.x * 4;
+  const long long per = (a.ntiles + waves - 1) / waves;
+  long long tile = ((long long)blockIdx.x * 4 + wv) * per;
+  const long long tile_end = min(a.ntiles, tile + per);
+  if (tile >= tile_end) return;
+  auto load_offs = [&](long long t) {
+    const long long r0 = t * R;
+    const int nrows = (int)min((long long)R, in.rows - r0);
+    cstile::TileOffs o;
+    o.o0 = in.offsets[r0 + min(lane, nrows)];
+    o.o1 = in.offsets[r0 + min(lane + 1, nrows)];
+    return o;
+  };
+  cstile::TileOffs cur = load_offs(tile);
+  cstile::TileOffs nxt = cur;
+  if (tile + 1 < tile_end) nxt = load_offs(tile + 1);
+  cstile::TileChars pf;
+#pragma unroll
+  for (int j = 0; j < cstile::kPfChunks; ++j) pf.v[j] = make_uint4(0, 0, 0, 0);
+  cstile::issue_chars(in.chars, cstile::rl64(cur.o0, 0), cstile::rl64(cur.o1, 63), lane, pf);
+  for (;;) {
+    const long long r0 = tile * R;
+    const int nrows = (int)min((long long)R, in.rows - r0);
+    const long long g0 = cstile::rl64(cur.o0, 0), g1 = cstile::rl64(cur.o1, 63);
+    const bool live = lane < nrows && row_is_valid(in.validity, r0 + lane);
+    const int rbeg = (int)(cur.o0 - g0);
+    const int n = live ? (int)(cur.o1 - cur.o0) : 0;
+    const int lead = (int)((uintptr_t)(in.chars + g0) & 15);
+    const int want = (int)(g1 - g0) + lead;
+    cstile::stage_chars(lds_in, want, lane, pf);
+    // output extents of the tile's rows (the size pass and the scan already ran)
+    const long long oo0 = a.out_off[r0 + min(lane, nrows)];
+    const long long oo1 = a.out_off[r0 + min(lane + 1, nrows)];
+    const bool has_next = tile + 1 < tile_end;
+    if (has_next) {
+      cur = nxt;
+      cstile::issue_chars(in.chars, cstile::rl64(cur.o0, 0), cstile::rl64(cur.o1, 63), lane, pf);
+      if (tile + 2 < tile_end) nxt = load_offs(tile + 2);
+    }
+    cstile::wave_lds_fence();
+    const long long ob = cstile::rl64(oo0, 0), oe = cstile::rl64(oo1, 63);
+    if (live && n > 0) {
+      int lo, hi;
+      row_strip(lds_in + lead + rbeg, n, a.set, a.side, lo, hi);
+      cstile::lds_copy(lds_out, (int)(oo0 - ob), lds_in, lead + rbeg + lo, hi - lo);
+    }
+    cstile::wave_lds_fence();
+    cstile::wave_flush_shift(a.out_chars + ob, (int)(oe - ob), lds_out, lane);
+    cstile::wave_lds_fence();
+    if (!has_next) break;
+    ++tile;
+  }
+}
+
+}  // namespace
+
+namespace cs {
+
+bool strip_write_tiles(const cs_column* in, const CharSet& set, int side, const int64_t* out_off, uint8_t* out_chars,
+                       hipStream_t s) {
+  if (in->rows == 0 || getenv("CS_STRIP_ROWWISE")) return false;
+  int R = 0;
+  for (int r : {64, 32, 16}) {
+    if (max_span_rows(in, r, s) + 32 <= cstile::kPfBytes) {
+      R = r;
+      break;
+    }
+  }
+  if (!R) return false;
+  StripTileArgs a{};
+  a.in = view_of(in);
+  a.set = set;
+  a.side = side;
+  a.rows_per_tile = R;
+  a.cap = (int)((max_span_rows(in, R, s) + 48 + 15) & ~(int64_t)15);
+  a.ntiles = (in->rows + R - 1) / R;
+  a.out_off = out_off;
+  a.out_chars = out_chars;
+  const size_t lds = (size_t)a.cap * 2 * 4;
+  if (lds > 150 * 1024) return false;
+  if (lds > 48 * 1024)
+    CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_strip_tile), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)lds));
+  const unsigned g = resident_grid(reinterpret_cast<const void*>(&k_strip_tile), lds, (a.ntiles + 3) / 4);
+  ProfScope ps("k_strip_write", s);
+  hipLaunchKernelGGL(k_strip_tile, dim3(g), dim3(256), lds, s, a);
+  CS_HIP(hipGetLastError());
+  return true;
+}
+
+}  // namespace cs
