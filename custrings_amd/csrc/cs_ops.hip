@@ -25,6 +25,8 @@ struct CharSet;
 namespace cs {
 bool strip_write_tiles(const cs_column* in, const csrow::CharSet& set, int side, const int64_t* out_off, uint8_t* out_chars,
                        hipStream_t s);
+bool find_tiles(const cs_column* in, const unsigned char* needle, int nb, int mode, int start, int end, int32_t* out32,
+                uint8_t* out8, unsigned long long* found, hipStream_t s);
 }
 using namespace csrow;
 
@@ -454,8 +456,10 @@ int cs_find(const cs_column* col, const char* str, int start, int end, int32_t* 
     }
     {
       ProfScope ps("k_find", s);
-      hipLaunchKernelGGL(k_find, dim3(blocks_for(col->rows)), dim3(kBlock), 0, s, view_of(col), nd.d(),
-                         nd.n, start, end, d_out, ptr<unsigned long long>(cnt));
+      if (!find_tiles(col, reinterpret_cast<const unsigned char*>(str), nd.n, 0, start, end, d_out, nullptr,
+                      ptr<unsigned long long>(cnt), s))
+        hipLaunchKernelGGL(k_find, dim3(blocks_for(col->rows)), dim3(kBlock), 0, s, view_of(col), nd.d(),
+                           nd.n, start, end, d_out, ptr<unsigned long long>(cnt));
     }
     if (!on_device)
       CS_HIP(hipMemcpyAsync(results, d_out, sizeof(int32_t) * col->rows, hipMemcpyDeviceToHost, s));
@@ -484,8 +488,10 @@ int cs_contains(const cs_column* col, const char* str, uint8_t* results, int on_
     }
     {
       ProfScope ps("k_contains", s);
-      hipLaunchKernelGGL(k_contains, dim3(blocks_for(col->rows)), dim3(kBlock), 0, s, view_of(col), nd.d(),
-                         nd.n, d_out, ptr<unsigned long long>(cnt));
+      if (!find_tiles(col, reinterpret_cast<const unsigned char*>(str), nd.n, 1, 0, 0, nullptr, d_out,
+                      ptr<unsigned long long>(cnt), s))
+        hipLaunchKernelGGL(k_contains, dim3(blocks_for(col->rows)), dim3(kBlock), 0, s, view_of(col), nd.d(),
+                           nd.n, d_out, ptr<unsigned long long>(cnt));
     }
     if (!on_device) CS_HIP(hipMemcpyAsync(results, d_out, (size_t)col->rows, hipMemcpyDeviceToHost, s));
     int64_t n = read_back<int64_t>(cnt, s);

@@ -16,6 +16,8 @@ using namespace csdev;
 using namespace csrow;
 
 namespace cs {
+bool find_tiles(const cs_column* in, const unsigned char* needle, int nb, int mode, int start, int end, int32_t* out32,
+                uint8_t* out8, unsigned long long* found, hipStream_t s);
 bool strip_write_tiles(const cs_column* in, const CharSet& set, int side, const int64_t* out_off, uint8_t* out_chars,
                        hipStream_t s);
 }
@@ -92,9 +94,129 @@ __global__ void __launch_bounds__(256) k_strip_tile(StripTileArgs a) {
   }
 }
 
+
+// find (MODE 0: char position or -1, -2 for null rows) / contains (MODE 1) over row tiles:
+// same staging; every row lane searches its row in LDS (find.cu:75-120,237-272).
+struct FindTileArgs {
+  ColView in;
+  uint8_t needle[64];
+  int nb, start, end, rows_per_tile, cap;
+  long long ntiles;
+  int32_t* out32;
+  uint8_t* out8;
+  unsigned long long* found;
+};
+template <int MODE>
+__global__ void __launch_bounds__(256) k_find_tile(FindTileArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  __shared__ uint8_t s_needle[64];
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (threadIdx.x < 64) s_needle[threadIdx.x] = a.needle[threadIdx.x];
+  __syncthreads();
+  uint8_t* lds_in = reinterpret_cast<uint8_t*>(smem) + (size_t)wv * a.cap;
+  const ColView& in = a.in;
+  const int R = a.rows_per_tile;
+  const long long waves = (long long)gridDim.x * 4;
+  const long long per = (a.ntiles + waves - 1) / waves;
+  long long tile = ((long long)blockIdx.x * 4 + wv) * per;
+  const long long tile_end = min(a.ntiles, tile + per);
+  if (tile >= tile_end) return;
+  auto load_offs = [&](long long t) {
+    const long long r0 = t * R;
+    const int nrows = (int)min((long long)R, in.rows - r0);
+    cstile::TileOffs o;
+    o.o0 = in.offsets[r0 + min(lane, nrows)];
+    o.o1 = in.offsets[r0 + min(lane + 1, nrows)];
+    return o;
+  };
+  cstile::TileOffs cur = load_offs(tile);
+  cstile::TileOffs nxt = cur;
+  if (tile + 1 < tile_end) nxt = load_offs(tile + 1);
+  cstile::TileChars pf;
+#pragma unroll
+  for (int j = 0; j < cstile::kPfChunks; ++j) pf.v[j] = make_uint4(0, 0, 0, 0);
+  cstile::issue_chars(in.chars, cstile::rl64(cur.o0, 0), cstile::rl64(cur.o1, 63), lane, pf);
+  int hits = 0;
+  for (;;) {
+    const long long r0 = tile * R;
+    const int nrows = (int)min((long long)R, in.rows - r0);
+    const long long g0 = cstile::rl64(cur.o0, 0), g1 = cstile::rl64(cur.o1, 63);
+    const bool in_tile = lane < nrows;
+    const bool live = in_tile && row_is_valid(in.validity, r0 + lane);
+    const int rbeg = (int)(cur.o0 - g0);
+    const int n = live ? (int)(cur.o1 - cur.o0) : 0;
+    const int lead = (int)((uintptr_t)(in.chars + g0) & 15);
+    cstile::stage_chars(lds_in, (int)(g1 - g0) + lead, lane, pf);
+    const bool has_next = tile + 1 < tile_end;
+    if (has_next) {
+      cur = nxt;
+      cstile::issue_chars(in.chars, cstile::rl64(cur.o0, 0), cstile::rl64(cur.o1, 63), lane, pf);
+      if (tile + 2 < tile_end) nxt = load_offs(tile + 2);
+    }
+    cstile::wave_lds_fence();
+    const uint8_t* p = lds_in + lead + rbeg;
+    if (MODE == 0) {
+      int v = -2;  // null row (find.cu:108)
+      if (live) v = row_find(p, n, s_needle, a.nb, a.start, a.end);
+      if (in_tile) {
+        a.out32[r0 + lane] = v;
+        hits += v != -1;  // null rows are counted too (find.cu:112)
+      }
+    } else {
+      int hit = 0;
+      if (live && a.nb > 0) hit = find_bytes(p, 0, n, s_needle, a.nb) >= 0;
+      if (in_tile) a.out8[r0 + lane] = (uint8_t)hit;
+      hits += hit;
+    }
+    cstile::wave_lds_fence();
+    if (!has_next) break;
+    ++tile;
+  }
+  const int t = wave_reduce_sum(hits);
+  if (lane == 0 && t) atomicAdd(a.found, (unsigned long long)t);
+}
+
 }  // namespace
 
 namespace cs {
+
+
+bool find_tiles(const cs_column* in, const unsigned char* needle, int nb, int mode, int start, int end, int32_t* out32,
+                uint8_t* out8, unsigned long long* found, hipStream_t s) {
+  if (in->rows == 0 || nb > 64 || getenv("CS_FIND_ROWWISE")) return false;
+  int R = 0;
+  for (int r : {64, 32, 16}) {
+    if (max_span_rows(in, r, s) + 32 <= cstile::kPfBytes) {
+      R = r;
+      break;
+    }
+  }
+  if (!R) return false;
+  FindTileArgs a{};
+  a.in = view_of(in);
+  for (int i = 0; i < nb; ++i) a.needle[i] = needle[i];
+  a.nb = nb;
+  a.start = start;
+  a.end = end;
+  a.rows_per_tile = R;
+  a.cap = (int)((max_span_rows(in, R, s) + 48 + 15) & ~(int64_t)15);
+  a.ntiles = (in->rows + R - 1) / R;
+  a.out32 = out32;
+  a.out8 = out8;
+  a.found = found;
+  const size_t lds = (size_t)a.cap * 4;
+  if (lds > 150 * 1024) return false;
+  auto launch = [&](auto kern) {
+    if (lds > 48 * 1024)
+      CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const unsigned g = resident_grid(reinterpret_cast<const void*>(kern), lds, (a.ntiles + 3) / 4);
+    hipLaunchKernelGGL(kern, dim3(g), dim3(256), lds, s, a);
+  };
+  if (mode == 0) launch(&k_find_tile<0>);
+  else launch(&k_find_tile<1>);
+  CS_HIP(hipGetLastError());
+  return true;
+}
 
 bool strip_write_tiles(const cs_column* in, const CharSet& set, int side, const int64_t* out_off, uint8_t* out_chars,
                        hipStream_t s) {
