@@ -508,8 +508,8 @@ int cs_replace(const cs_column* col, const char* str, const char* repl, int maxr
     require_device();
     hipStream_t s = S(stream);
     if (!repl) repl = "";
-    // A needle without regex metacharacters whose replacement is no longer than itself runs on
-    // the persistent single-pass replace_re kernel (same leftmost, non-overlapping semantics;
+    // A needle without regex metacharacters and a replacement of at most 16 bytes run on the
+    // persistent single-pass replace_re kernel (same leftmost, non-overlapping semantics;
     // modify.cu:109-192 restarts at pos + nchars(str), replace.cu:91-92 at the match end).
     {
       bool plain = true;
@@ -520,7 +520,7 @@ int cs_replace(const cs_column* col, const char* str, const char* repl, int maxr
                 c == '<' || c == '>' || c == '/' || c == '!' || c == '-' || c == '"' || c == '\'';
       }
       const size_t nb = strlen(str), rb = strlen(repl);
-      if (plain && rb <= nb && rb <= 8 && col->rows > 0 && !getenv("CS_REPLACE_ROWWISE")) {
+      if (plain && rb <= 16 && col->rows > 0 && !getenv("CS_REPLACE_ROWWISE")) {
         cs_regex* re = nullptr;
         if (cs_regex_compile(str, &re) == CS_OK) {
           const int rc = cs_replace_re(col, re, repl, maxrepl, stream, out);

@@ -439,13 +439,11 @@ __global__ void __launch_bounds__(256, CS_STREAM_WAVES) k_tdfa_replace_stream(St
   const long long W = (long long)gridDim.x * 4;
   long long tile = (long long)blockIdx.x * 4 + wv;
   if (tile >= a.nsub) return;
-  // replacement text in a register pair (the single pass is only taken for rb <= 8)
-  uint32_t rep0 = 0, rep1 = 0;
-  for (int i = 0; i < rb && i < 8; ++i) {
-    const uint32_t b = a.repl[i];
-    if (i < 4) rep0 |= b << (8 * i);
-    else rep1 |= b << (8 * (i - 4));
-  }
+  // replacement text in four registers (this kernel is only taken for rb <= 16)
+  uint32_t rep[4] = {0, 0, 0, 0};
+#pragma unroll
+  for (int i = 0; i < 16; ++i)
+    if (i < rb) rep[i >> 2] |= (uint32_t)a.repl[i] << (8 * (i & 3));
   cstile::TileOffs cur = cstile::load_tile_offsets(in.offsets, in.rows, tile, lane);
   cstile::TileOffs nxt = cur;
   if (tile + W < a.nsub) nxt = cstile::load_tile_offsets(in.offsets, in.rows, tile + W, lane);
@@ -586,7 +584,10 @@ __global__ void __launch_bounds__(256, CS_STREAM_WAVES) k_tdfa_replace_stream(St
             cstile::lds_copy(lds_out, oi, lds_in, pi + copied, rec_mb[j] - copied);
             oi += rec_mb[j] - copied;
             for (int k = 0; k < rec_reps[j]; ++k)
-              for (int i = 0; i < rb; ++i) lds_out[oi++] = (uint8_t)((i < 4 ? rep0 >> (8 * i) : rep1 >> (8 * (i - 4))));
+#pragma unroll
+              for (int i = 0; i < 16; ++i)
+                if (i < rb) lds_out[oi + i] = (uint8_t)(rep[i >> 2] >> (8 * (i & 3)));
+              oi += rb;
             copied = rec_me[j];
           }
         cstile::lds_copy(lds_out, oi, lds_in, pi + copied, n - copied);
@@ -934,17 +935,23 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
     o->validity = col->validity;
     o->null_count = col->null_count;
     const int minlen = tdfa ? re->tdfa[13] : 0;
-    if (tdfa && rb <= minlen && !getenv("CS_REGEX_TWO_PASS")) {
-      // single pass: the output cannot outgrow the input (each match is at least
-      // `minlen` bytes, the replacement at most that) -> allocate at the input size
+    // Single pass when the output size is bounded up front: a match is at least `minlen` bytes,
+    // so a row grows by at most kMaxRec * (rb - minlen) bytes (rows with more matches than the
+    // kernel keeps in registers raise its error word); rb <= minlen means "never grows".  A
+    // pattern that matches the empty string with a non-empty replacement is unbounded (the
+    // zero-length repeat rule) and takes the two-pass kernels.
+    const int growth = rb > minlen ? rb - minlen : 0;
+    const bool bounded = growth == 0 || (minlen >= 1 && (int64_t)col->rows * kMaxRec * growth <= col->nbytes + (1ll << 30));
+    if (tdfa && bounded && !getenv("CS_REGEX_TWO_PASS")) {
       const int64_t rows = col->rows;
       const int64_t ntiles = (rows + cstile::kTileRows - 1) / cstile::kTileRows;
       const int64_t nsub = ntiles * 4;
       const int64_t span = max_span64(col, s);
       const int cap = (int)((span + 15 + 32 + 127) & ~(int64_t)127);
+      const int cap_out = cap + ((64 * kMaxRec * growth + 127) & ~127);
       const size_t tbl = tp.d.in_lds ? tp.lds_bytes : 0;
-      const size_t lds = tbl + (size_t)(2 * cap + 64) * 4 + 16;
-      if (lds <= 150 * 1024 && rb <= 8 && cap <= cstile::kPfBytes && !getenv("CS_TILE_OLD")) {
+      const size_t lds = tbl + (size_t)(cap + cap_out + 64) * 4 + 16;
+      if (lds <= 150 * 1024 && rb <= 16 && cap <= cstile::kPfBytes && !getenv("CS_TILE_OLD")) {
         // persistent stream kernel: grid = what is resident at once
         StreamArgs sa{};
         sa.in = view_of(col);
@@ -954,7 +961,7 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
         sa.rb = rb;
         sa.maxrepl = maxrepl;
         Buf out_off = dev_alloc(sizeof(int64_t) * (rows + 1), s);
-        Buf out_chars = dev_alloc((size_t)col->nbytes + 64, s);
+        Buf out_chars = dev_alloc((size_t)col->nbytes + (size_t)rows * kMaxRec * growth + 64, s);
         sa.out_off = ptr<int64_t>(out_off);
         sa.out_chars = ptr<uint8_t>(out_chars);
         const int64_t nsub1 = (rows + 63) / 64;
@@ -964,7 +971,7 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
         sa.error = reinterpret_cast<unsigned*>(ptr<cstile::u64>(status) + nsub1);
         sa.nsub = nsub1;
         sa.cap_in = cap;
-        sa.cap_out = cap;
+        sa.cap_out = cap_out;
         sa.tbl_bytes = (int)tbl;
         sa.debug = getenv("CS_TILE_DEBUG") ? atoi(getenv("CS_TILE_DEBUG")) : 0;
         auto kern = tp.d.in_lds ? &k_tdfa_replace_stream<true> : &k_tdfa_replace_stream<false>;
@@ -998,7 +1005,7 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
           *out = holder.release();
           return;
         }
-      } else if (lds <= 150 * 1024) {
+      } else if (lds <= 150 * 1024 && growth == 0) {
         TileArgs ta{};
         ta.in = view_of(col);
         ta.flags = d_unicode_flags();
