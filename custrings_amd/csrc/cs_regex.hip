@@ -421,10 +421,11 @@ struct StreamArgs {
   int cap_in, cap_out, tbl_bytes;
   int debug;
 };
-template <bool IN_LDS>
 #ifndef CS_STREAM_WAVES
 #define CS_STREAM_WAVES 3
 #endif
+// REP16: replacement of 9..16 bytes (four registers); the common short replacement keeps two
+template <bool IN_LDS, bool REP16>
 __global__ void __launch_bounds__(256, CS_STREAM_WAVES) k_tdfa_replace_stream(StreamArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   uint8_t* base = reinterpret_cast<uint8_t*>(smem);
@@ -439,10 +440,13 @@ __global__ void __launch_bounds__(256, CS_STREAM_WAVES) k_tdfa_replace_stream(St
   const long long W = (long long)gridDim.x * 4;
   long long tile = (long long)blockIdx.x * 4 + wv;
   if (tile >= a.nsub) return;
-  // replacement text in four registers (this kernel is only taken for rb <= 16)
-  uint32_t rep[4] = {0, 0, 0, 0};
+  // replacement text in registers (this kernel is only taken for rb <= 8, or <= 16 with REP16)
+  constexpr int kRepRegs = REP16 ? 4 : 2;
+  uint32_t rep[kRepRegs];
 #pragma unroll
-  for (int i = 0; i < 16; ++i)
+  for (int i = 0; i < kRepRegs; ++i) rep[i] = 0;
+#pragma unroll
+  for (int i = 0; i < 4 * kRepRegs; ++i)
     if (i < rb) rep[i >> 2] |= (uint32_t)a.repl[i] << (8 * (i & 3));
   cstile::TileOffs cur = cstile::load_tile_offsets(in.offsets, in.rows, tile, lane);
   cstile::TileOffs nxt = cur;
@@ -583,11 +587,16 @@ __global__ void __launch_bounds__(256, CS_STREAM_WAVES) k_tdfa_replace_stream(St
           if (j < nm) {
             cstile::lds_copy(lds_out, oi, lds_in, pi + copied, rec_mb[j] - copied);
             oi += rec_mb[j] - copied;
-            for (int k = 0; k < rec_reps[j]; ++k)
+            for (int k = 0; k < rec_reps[j]; ++k) {
+              if (REP16) {
 #pragma unroll
-              for (int i = 0; i < 16; ++i)
-                if (i < rb) lds_out[oi + i] = (uint8_t)(rep[i >> 2] >> (8 * (i & 3)));
-              oi += rb;
+                for (int i = 0; i < 16; ++i)
+                  if (i < rb) lds_out[oi + i] = (uint8_t)(rep[i >> 2] >> (8 * (i & 3)));
+                oi += rb;
+              } else {
+                for (int i = 0; i < rb; ++i) lds_out[oi++] = (uint8_t)((i < 4 ? rep[0] >> (8 * i) : rep[1] >> (8 * (i - 4))));
+              }
+            }
             copied = rec_me[j];
           }
         cstile::lds_copy(lds_out, oi, lds_in, pi + copied, n - copied);
@@ -974,7 +983,8 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
         sa.cap_out = cap_out;
         sa.tbl_bytes = (int)tbl;
         sa.debug = getenv("CS_TILE_DEBUG") ? atoi(getenv("CS_TILE_DEBUG")) : 0;
-        auto kern = tp.d.in_lds ? &k_tdfa_replace_stream<true> : &k_tdfa_replace_stream<false>;
+        auto kern = rb > 8 ? (tp.d.in_lds ? &k_tdfa_replace_stream<true, true> : &k_tdfa_replace_stream<false, true>)
+                           : (tp.d.in_lds ? &k_tdfa_replace_stream<true, false> : &k_tdfa_replace_stream<false, false>);
         if (lds > 48 * 1024)
           CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)lds));
