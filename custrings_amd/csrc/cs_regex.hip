@@ -430,13 +430,16 @@ __global__ void __launch_bounds__(256, CS_STREAM_WAVES) k_tdfa_replace_stream(St
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   uint8_t* base = reinterpret_cast<uint8_t*>(smem);
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  uint8_t* lds_in = base + a.tbl_bytes + (size_t)wv * (a.cap_in + a.cap_out + 64);
+  const int bm_bytes = (a.cap_in >> 3) + 32;  // one candidate bit per staged byte
+  uint8_t* lds_in = base + a.tbl_bytes + (size_t)wv * (a.cap_in + a.cap_out + 64 + bm_bytes);
   uint8_t* lds_out = lds_in + a.cap_in + 32;
+  uint32_t* bitmap = reinterpret_cast<uint32_t*>(lds_out + a.cap_out + 32);
   const TCtx c = tsetup<IN_LDS>(a.L, a.flags, smem);  // (block barrier inside when staging)
   const cstd::View& D = c.D;
   const csvm::ProgView& P = c.P;
   const ColView& in = a.in;
   const int rb = a.rb;
+  const bool has_r2 = (((uint32_t)D.img[30] & 255u) <= (((uint32_t)D.img[30] >> 8) & 255u));
   const long long W = (long long)gridDim.x * 4;
   long long tile = (long long)blockIdx.x * 4 + wv;
   if (tile >= a.nsub) return;
@@ -496,7 +499,8 @@ __global__ void __launch_bounds__(256, CS_STREAM_WAVES) k_tdfa_replace_stream(St
     const long long want = g1 - g0 + lead;
     bool bad = want + 16 > a.cap_in || want > cstile::kPfBytes;
     if (!bad) cstile::stage_chars(lds_in, (int)want, lane, pf);
-    // bytes that the lean scan does not take (non-ASCII, NUL) anywhere in the staged span
+    // bytes that the lean scan does not take (non-ASCII, NUL) anywhere in the staged span, and one
+    // candidate bit per byte for the row lanes (classified here, out of the prefetch registers)
     uint32_t odd = 0;
 #pragma unroll
     for (int j = 0; j < cstile::kPfChunks; ++j)
@@ -506,6 +510,14 @@ __global__ void __launch_bounds__(256, CS_STREAM_WAVES) k_tdfa_replace_stream(St
         odd |= q.y | ((q.y - 0x01010101u) & ~q.y);
         odd |= q.z | ((q.z - 0x01010101u) & ~q.z);
         odd |= q.w | ((q.w - 0x01010101u) & ~q.w);
+        uint32_t bits;
+        if (has_r2)
+          bits = cstile::gather_bit7(cstd::Tdfa::cand_bits_ascii<true>(D, q.x)) | (cstile::gather_bit7(cstd::Tdfa::cand_bits_ascii<true>(D, q.y)) << 4) |
+                 (cstile::gather_bit7(cstd::Tdfa::cand_bits_ascii<true>(D, q.z)) << 8) | (cstile::gather_bit7(cstd::Tdfa::cand_bits_ascii<true>(D, q.w)) << 12);
+        else
+          bits = cstile::gather_bit7(cstd::Tdfa::cand_bits_ascii<false>(D, q.x)) | (cstile::gather_bit7(cstd::Tdfa::cand_bits_ascii<false>(D, q.y)) << 4) |
+                 (cstile::gather_bit7(cstd::Tdfa::cand_bits_ascii<false>(D, q.z)) << 8) | (cstile::gather_bit7(cstd::Tdfa::cand_bits_ascii<false>(D, q.w)) << 12);
+        if (!bad) cstile::put_bits16(bitmap, j * 1024 + lane * 16, bits);
       }
     // first look-back poll for the previous sub-tile: issued only now, after the staging above has
     // waited for its own data (vmcnt is in order: a poll issued earlier would sit in front of it)
@@ -546,8 +558,7 @@ __global__ void __launch_bounds__(256, CS_STREAM_WAVES) k_tdfa_replace_stream(St
         out_len = n;
         bool bail = false;
         uint32_t m0, m1, m2;  // candidate bits, bit i = byte i of the row
-        if (vm.has_range2()) vm.build_masks_lean<true>(m0, m1, m2);
-        else vm.build_masks_lean<false>(m0, m1, m2);
+        cstile::row_bits96(bitmap, lead + rbeg, n, m0, m1, m2);
         vm.scan_lean_dispatch(a.maxrepl, m0, m1, m2, rec, bail);
         redo = bail;
       }
@@ -641,11 +652,14 @@ __global__ void __launch_bounds__(256) k_tdfa_scan_stream(ScanStreamArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   uint8_t* base = reinterpret_cast<uint8_t*>(smem);
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  uint8_t* lds_in = base + a.tbl_bytes + (size_t)wv * (a.cap_in + 32);
+  const int bm_bytes = (a.cap_in >> 3) + 32;
+  uint8_t* lds_in = base + a.tbl_bytes + (size_t)wv * (a.cap_in + 32 + bm_bytes);
+  uint32_t* bitmap = reinterpret_cast<uint32_t*>(lds_in + a.cap_in + 32);
   const TCtx c = tsetup<IN_LDS>(a.L, a.flags, smem);
   const cstd::View& D = c.D;
   const csvm::ProgView& P = c.P;
   const ColView& in = a.in;
+  const bool has_r2 = (((uint32_t)D.img[30] & 255u) <= (((uint32_t)D.img[30] >> 8) & 255u));
   const long long waves = (long long)gridDim.x * 4;
   const long long per = (a.nsub + waves - 1) / waves;
   long long tile = ((long long)blockIdx.x * 4 + wv) * per;
@@ -678,6 +692,14 @@ __global__ void __launch_bounds__(256) k_tdfa_scan_stream(ScanStreamArgs a) {
         odd |= q.y | ((q.y - 0x01010101u) & ~q.y);
         odd |= q.z | ((q.z - 0x01010101u) & ~q.z);
         odd |= q.w | ((q.w - 0x01010101u) & ~q.w);
+        uint32_t bits;
+        if (has_r2)
+          bits = cstile::gather_bit7(cstd::Tdfa::cand_bits_ascii<true>(D, q.x)) | (cstile::gather_bit7(cstd::Tdfa::cand_bits_ascii<true>(D, q.y)) << 4) |
+                 (cstile::gather_bit7(cstd::Tdfa::cand_bits_ascii<true>(D, q.z)) << 8) | (cstile::gather_bit7(cstd::Tdfa::cand_bits_ascii<true>(D, q.w)) << 12);
+        else
+          bits = cstile::gather_bit7(cstd::Tdfa::cand_bits_ascii<false>(D, q.x)) | (cstile::gather_bit7(cstd::Tdfa::cand_bits_ascii<false>(D, q.y)) << 4) |
+                 (cstile::gather_bit7(cstd::Tdfa::cand_bits_ascii<false>(D, q.z)) << 8) | (cstile::gather_bit7(cstd::Tdfa::cand_bits_ascii<false>(D, q.w)) << 12);
+        cstile::put_bits16(bitmap, j * 1024 + lane * 16, bits);
       }
     const bool has_next = tile + 1 < tile_end;
     if (has_next) {
@@ -693,8 +715,7 @@ __global__ void __launch_bounds__(256) k_tdfa_scan_stream(ScanStreamArgs a) {
       bool redo = live && !lean;
       if (lean && live) {
         uint32_t m0, m1, m2;
-        if (vm.has_range2()) vm.build_masks_lean<true>(m0, m1, m2);
-        else vm.build_masks_lean<false>(m0, m1, m2);
+        cstile::row_bits96(bitmap, lead + rbeg, n, m0, m1, m2);
         v = vm.scan_lean_count<MODE == 2 ? cstd::Tdfa::K_COUNT : cstd::Tdfa::K_CONTAINS>(m0, m1, m2);
         redo = v < 0;
       }
@@ -811,7 +832,7 @@ void scan(const cs_column* col, cs_regex* re, uint8_t* out8, int32_t* out32, int
   if (tdfa && tp.d.in_lds && MODE != 1 && !getenv("CS_REGEX_ROWWISE")) {
     const int64_t span = max_span64(col, s);
     const int cap = (int)((span + 15 + 32 + 127) & ~(int64_t)127);
-    const size_t lds = tp.lds_bytes + (size_t)(cap + 32) * 4;
+    const size_t lds = tp.lds_bytes + (size_t)(cap + 32 + (cap >> 3) + 32) * 4;
     if (cap <= cstile::kPfBytes && lds <= 150 * 1024) {
       ScanStreamArgs sa{};
       sa.in = view_of(col);
@@ -959,7 +980,7 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
       const int cap = (int)((span + 15 + 32 + 127) & ~(int64_t)127);
       const int cap_out = cap + ((64 * kMaxRec * growth + 127) & ~127);
       const size_t tbl = tp.d.in_lds ? tp.lds_bytes : 0;
-      const size_t lds = tbl + (size_t)(cap + cap_out + 64) * 4 + 16;
+      const size_t lds = tbl + (size_t)(cap + cap_out + 64 + (cap >> 3) + 32) * 4 + 16;
       if (lds <= 150 * 1024 && rb <= 16 && cap <= cstile::kPfBytes && !getenv("CS_TILE_OLD")) {
         // persistent stream kernel: grid = what is resident at once
         StreamArgs sa{};

@@ -375,6 +375,14 @@ struct Tdfa {
     m1 = q1;
     m2 = q2;
   }
+  // bit 7 of each byte lane: the (ASCII, non-NUL) byte is a candidate
+  template <bool HAS_R2>
+  static CS_HD uint32_t cand_bits_ascii(const View& V, uint32_t w) {
+    const uint32_t x = w & 0x7F7F7F7Fu;
+    uint32_t c = (x + V.r1lo) & ~(x + V.r1hi);
+    if (HAS_R2) c |= (x + V.r2lo) & ~(x + V.r2hi);
+    return c & 0x80808080u;
+  }
   CS_HD bool has_range2() const { return ((uint32_t)D.img[30] & 255u) <= (((uint32_t)D.img[30] >> 8) & 255u); }
   // first candidate position >= pos (row offsets), or n
   CS_HD int next_candidate(uint32_t m0, uint32_t m1, uint32_t m2, int pos) const {

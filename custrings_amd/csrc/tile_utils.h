@@ -315,6 +315,33 @@ __device__ __forceinline__ long long lookback_end(u64* status, long long tile, l
 }
 
 
+
+// ---- per-byte bitmaps shared between piece lanes and row lanes -------------------------------
+// While a tile's 16-byte pieces are still in the lanes' prefetch registers, each lane can
+// classify its own bytes (SWAR, 4 words) and leave one bit per byte in an LDS bitmap; a row
+// lane then picks up the up to 96 bits of its row with four dword reads and a funnel shift,
+// instead of re-reading and re-classifying 24 words of LDS itself.
+// gathers bit 7 of the four byte lanes of `c` (which must have no other bits set) into bits 0..3
+__device__ __forceinline__ uint32_t gather_bit7(uint32_t c) { return (((c >> 7) * 0x01020408u) >> 24) & 15u; }
+__device__ __forceinline__ void put_bits16(uint32_t* bitmap, int byte_index, uint32_t bits16) {
+  reinterpret_cast<uint16_t*>(bitmap)[byte_index >> 4] = (uint16_t)bits16;
+}
+// bits [p0, p0 + n) of the bitmap, n <= 96, as three words (bit i of m0 = bit p0 + i)
+__device__ __forceinline__ void row_bits96(const uint32_t* bitmap, int p0, int n, uint32_t& m0, uint32_t& m1, uint32_t& m2) {
+  const uint32_t* w = bitmap + (p0 >> 5);
+  const unsigned sh = (unsigned)(p0 & 31);
+  const uint32_t a = w[0], b = w[1], c = w[2], d = w[3];
+  uint32_t q0 = sh ? (a >> sh) | (b << (32 - sh)) : a;
+  uint32_t q1 = sh ? (b >> sh) | (c << (32 - sh)) : b;
+  uint32_t q2 = sh ? (c >> sh) | (d << (32 - sh)) : c;
+  q0 &= n >= 32 ? 0xFFFFFFFFu : ~(0xFFFFFFFFu << (n & 31));
+  q1 &= n >= 64 ? 0xFFFFFFFFu : (n <= 32 ? 0u : ~(0xFFFFFFFFu << (n & 31)));
+  q2 &= n >= 96 ? 0xFFFFFFFFu : (n <= 64 ? 0u : ~(0xFFFFFFFFu << (n & 31)));
+  m0 = q0;
+  m1 = q1;
+  m2 = q2;
+}
+
 // Wave-cooperative flush of `total` bytes assembled at lds[0 ..) (lds 4-byte aligned) to
 // the arbitrarily aligned global address `dst`: whole 16-byte destination chunks are
 // composed from five aligned LDS dwords and a wave-uniform funnel shift; the up to 15
