@@ -421,6 +421,7 @@ __global__ void __launch_bounds__(256, CS_EMIT2_WAVES) k_split_emit2(Emit2Args a
       const unsigned long long vmask = __ballot(has);
       if (lane == k) my_vmask = vmask;
       CS_PHASE_MARK(2);
+      if (csum == 0) continue;  // no row of this sub-tile reaches column k (or all its tokens are empty): offsets only
       // zero the region (16-byte chunks covering lead + bytes + 8 of slack for the last token's third dword)
       const int zend = clead + csum + 20;
       for (int i = lane * 16; i < zend; i += 64 * 16) *reinterpret_cast<uint4*>(region + i) = make_uint4(0, 0, 0, 0);
