@@ -424,8 +424,13 @@ struct StreamArgs {
 #ifndef CS_STREAM_WAVES
 #define CS_STREAM_WAVES 3
 #endif
-// REP16: replacement of 9..16 bytes (four registers); the common short replacement keeps two
-template <bool IN_LDS, bool REP16>
+// REP16: replacement of 9..16 bytes (four registers); the common short replacement keeps two.
+// INPLACE (the output cannot outgrow the input): every row is compacted inside its own extent of
+// the input tile while it is scanned -- the bytes before a match move down to the write cursor,
+// the replacement follows -- so any number of matches per row costs no registers and the
+// assembly is one contiguous copy per row.  Otherwise (bounded growth) up to kMaxRec matches per
+// row are kept in registers and the rows are assembled piecewise.
+template <bool IN_LDS, bool REP16, bool INPLACE>
 __global__ void __launch_bounds__(256, CS_STREAM_WAVES) k_tdfa_replace_stream(StreamArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   uint8_t* base = reinterpret_cast<uint8_t*>(smem);
@@ -539,39 +544,67 @@ __global__ void __launch_bounds__(256, CS_STREAM_WAVES) k_tdfa_replace_stream(St
     if (live && !bad) out_len = n;
     if (!bad && !(a.debug & 1)) {
       cstd::Tdfa vm(D, P, lds_in + lead + rbeg, n, (lead + rbeg) & 3);
-      auto rec = [&](int mb, int me, int reps) {
-        out_len += reps * rb - (me - mb);
+      const int pi = lead + rbeg;          // byte index of the row in lds_in
+      int wr = 0, copied = 0, pend = -1;   // INPLACE: write cursor, input consumed, replacement not yet written
+      auto put_repl_at = [&](int at) {
+        if (REP16) {
 #pragma unroll
-        for (int j = 0; j < kMaxRec; ++j)
-          if (nm == j) {
-            rec_mb[j] = mb;
-            rec_me[j] = me;
-            rec_reps[j] = reps;
-          }
+          for (int i = 0; i < 16; ++i)
+            if (i < rb) lds_in[pi + at + i] = (uint8_t)(rep[i >> 2] >> (8 * (i & 3)));
+        } else {
+          for (int i = 0; i < rb; ++i) lds_in[pi + at + i] = (uint8_t)((i < 4 ? rep[0] >> (8 * i) : rep[1] >> (8 * (i - 4))));
+        }
+      };
+      auto rec = [&](int mb, int me, int reps) {
+        if (INPLACE) {
+          // the previous match's replacement is written only now: until the next round has started the
+          // scan may still look at the byte in front of that match's end (word / line context)
+          if (pend >= 0) put_repl_at(pend);
+          if (wr != copied) cstile::lds_copy(lds_in, pi + wr, lds_in, pi + copied, mb - copied);  // moves down: ascending copy is safe
+          wr += mb - copied;
+          pend = wr;
+          wr += reps * rb;  // (reps > 1 only for patterns that match the empty string, where rb == 0)
+          copied = me;
+        } else {
+          out_len += reps * rb - (me - mb);
+#pragma unroll
+          for (int j = 0; j < kMaxRec; ++j)
+            if (nm == j) {
+              rec_mb[j] = mb;
+              rec_me[j] = me;
+              rec_reps[j] = reps;
+            }
+        }
         ++nm;
       };
       // wave-uniform choice: the lean scan when every row of the sub-tile qualifies
       const bool lean = D.nskip > 0 && D.img[12] <= 4 && !(a.debug & 32) && !__any((odd & 0x80808080u) != 0) &&
                         !__any(live && !vm.masks_fit());
-      bool redo = live && !lean;
+      bool redo = live && !lean && a.maxrepl != 0;
+      int resume = 0;
       if (lean && live && a.maxrepl != 0) {
-        out_len = n;
         bool bail = false;
         uint32_t m0, m1, m2;  // candidate bits, bit i = byte i of the row
         cstile::row_bits96(bitmap, lead + rbeg, n, m0, m1, m2);
         vm.scan_lean_dispatch(a.maxrepl, m0, m1, m2, rec, bail);
         redo = bail;
+        resume = vm.lean_resume_from;
       }
       if (__any(redo)) {
-        if (redo) {
-          out_len = n;
-          nm = 0;
-          csvm::row_replace_matches(vm, a.maxrepl, rec);
+        // rows the lean scan handed over continue with the generic scan in the round they stopped in
+        // (the matches reported so far are final)
+        if (redo) vm.template scan<cstd::Tdfa::K_REPLACE>(a.maxrepl, rec, resume, nm);
+      }
+      if (INPLACE && live) {
+        if (pend >= 0) put_repl_at(pend);
+        if (nm > 0) {
+          if (wr != copied) cstile::lds_copy(lds_in, pi + wr, lds_in, pi + copied, n - copied);
+          out_len = wr + (n - copied);
         }
       }
     }
     CS_PHASE_MARK(1);
-    bad |= __any(nm > kMaxRec);
+    if (!INPLACE) bad |= __any(nm > kMaxRec);
     const int incl = csdev::wave_inclusive_scan(out_len);
     const int lo = incl - out_len;
     const int total = __builtin_amdgcn_readlane(incl, 63);
@@ -589,7 +622,9 @@ __global__ void __launch_bounds__(256, CS_STREAM_WAVES) k_tdfa_replace_stream(St
       CS_PHASE_MARK(2);
       if (p_tile >= 0) finish_pending((a.debug & 64) ? cstile::lookback_poll(a.status, p_tile, lane) : p_first);
       CS_PHASE_MARK(3);
-      if (live && !(a.debug & 2)) {
+      if (INPLACE) {
+        if (live && !(a.debug & 2)) cstile::lds_copy(lds_out, lo, lds_in, lead + rbeg, out_len);
+      } else if (live && !(a.debug & 2)) {
         int oi = lo;                 // byte index into lds_out
         const int pi = lead + rbeg;  // byte index of the row in lds_in
         int copied = 0;
@@ -1004,8 +1039,12 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
         sa.cap_out = cap_out;
         sa.tbl_bytes = (int)tbl;
         sa.debug = getenv("CS_TILE_DEBUG") ? atoi(getenv("CS_TILE_DEBUG")) : 0;
-        auto kern = rb > 8 ? (tp.d.in_lds ? &k_tdfa_replace_stream<true, true> : &k_tdfa_replace_stream<false, true>)
-                           : (tp.d.in_lds ? &k_tdfa_replace_stream<true, false> : &k_tdfa_replace_stream<false, false>);
+        auto pick = [&](auto inplace) {
+          constexpr bool IP = decltype(inplace)::value;
+          return rb > 8 ? (tp.d.in_lds ? &k_tdfa_replace_stream<true, true, IP> : &k_tdfa_replace_stream<false, true, IP>)
+                        : (tp.d.in_lds ? &k_tdfa_replace_stream<true, false, IP> : &k_tdfa_replace_stream<false, false, IP>);
+        };
+        auto kern = growth == 0 ? pick(std::true_type{}) : pick(std::false_type{});
         if (lds > 48 * 1024)
           CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)lds));

@@ -428,6 +428,7 @@ struct Tdfa {
     if (c) return 64 + ctz32(c);
     return n;
   }
+  int lean_resume_from = 0;  // set with `bail`: the find() round that has to be redone starts here
   template <int KIND, bool USES, class Emit>
   CS_HD int scan_lean(int maxrepl, uint32_t cm0, uint32_t cm1, uint32_t cm2, Emit&& emit, bool& bail) {
     int from = 0, pos = 0, done = 0, mb = 0, me = 0;
@@ -487,6 +488,7 @@ struct Tdfa {
       }
       if (e & E_COMPLEX) {
         bail = true;
+        lean_resume_from = from;
         return done;
       }
       effects(e);
@@ -506,6 +508,7 @@ struct Tdfa {
       } else {
         if (me == mb && mb == from) {  // zero-length repeat rule (replace.cu:91-93): generic path
           bail = true;
+          lean_resume_from = from;
           return done;
         }
         emit(mb, me, 1);
@@ -547,13 +550,17 @@ struct Tdfa {
   // emit(mb, me, reps) per match (K_REPLACE: reps > 1 for the zero-length repeat);
   // returns the number of matches (K_CONTAINS / K_MATCH: 0 or 1).
   template <int KIND, class Emit>
-  CS_HD int scan(int maxrepl, Emit&& emit) {
-    int from = 0, pos = 0, done = 0;
+  CS_HD int scan(int maxrepl, Emit&& emit, int from0 = 0, int done0 = 0) {
+    // (from0, done0): resume a K_REPLACE / K_COUNT scan at the start of a find() round -- the
+    // state every round starts in depends only on the position (used when the lean scan hands a
+    // row over in the middle)
+    int from = from0, pos = from0, done = done0;
     int mb = 0, me = 0, matched = 0;
     int st[kMaxSlots];
 #pragma unroll
-    for (int j = 0; j < kMaxSlots; ++j) st[j] = 0;
-    uint32_t state = D.init[(KIND == K_MATCH ? MODE_SEED_ONCE : MODE_RESTART) * 8 + 4];  // row start
+    for (int j = 0; j < kMaxSlots; ++j) st[j] = from0;
+    uint32_t state = from0 == 0 ? D.init[(KIND == K_MATCH ? MODE_SEED_ONCE : MODE_RESTART) * 8 + 4]  // row start
+                                : D.init[MODE_RESTART * 8 + (D.uses ? prev_cat(from0) : 0u)];
     // one-word cache of the row storage: consecutive positions share a word
     int cwi = -(1 << 30);
     uint32_t cw = 0;
@@ -754,8 +761,11 @@ CS_HD void row_replace_matches(cstd::Tdfa& vm, int maxrepl, Emit&& emit) {
         overflow = true;
       }
     }, bail);
-    if (!bail && !overflow) {
+    if (!overflow) {
+      // the matches found so far are final; a bail-out resumes the generic scan at the round it
+      // happened in (the tile kernels do the same)
       for (int i = 0; i < cnt; ++i) emit(buf[3 * i], buf[3 * i + 1], buf[3 * i + 2]);
+      if (bail) vm.scan<cstd::Tdfa::K_REPLACE>(maxrepl, emit, vm.lean_resume_from, cnt);
       return;
     }
   }
