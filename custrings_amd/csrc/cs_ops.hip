@@ -19,6 +19,9 @@ bool tokenize_fast(const cs_column* col, const unsigned char* delims, int ndel, 
 bool change_case_fast(const cs_column* col, unsigned bit, bool ascii_rule_ok, hipStream_t s, cs_column** out);
 bool ngrams_fast(const cs_column* tokens, int n, const unsigned char* sep, int sepn, hipStream_t s, cs_column** out);
 }
+namespace cs {
+extern thread_local int g_replace_plain_only;
+}
 namespace csrow {
 struct CharSet;
 }
@@ -523,7 +526,9 @@ int cs_replace(const cs_column* col, const char* str, const char* repl, int maxr
       if (plain && rb <= 16 && col->rows > 0 && !getenv("CS_REPLACE_ROWWISE")) {
         cs_regex* re = nullptr;
         if (cs_regex_compile(str, &re) == CS_OK) {
+          cs::g_replace_plain_only = 1;  // equivalent only on plain bytes: the kernel gives up on NUL / non-ASCII tiles
           const int rc = cs_replace_re(col, re, repl, maxrepl, stream, out);
+          cs::g_replace_plain_only = 0;
           cs_regex_destroy(re);
           if (rc == CS_OK) return;
         }

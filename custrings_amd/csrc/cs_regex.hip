@@ -32,6 +32,10 @@ struct cs_regex {
   bool empty_pattern = false;
 };
 
+namespace cs {
+thread_local int g_replace_plain_only = 0;  // set by cs_replace around its call of cs_replace_re
+}
+
 namespace {
 
 constexpr size_t kLdsBudget = 64 * 1024;
@@ -419,6 +423,7 @@ struct StreamArgs {
   unsigned* error;
   long long nsub;
   int cap_in, cap_out, tbl_bytes;
+  int plain_only;  // literal replace routed here: give up on sub-tiles holding NUL or non-ASCII bytes
   int debug;
 };
 #ifndef CS_STREAM_WAVES
@@ -524,6 +529,9 @@ __global__ void __launch_bounds__(256, CS_STREAM_WAVES) k_tdfa_replace_stream(St
                  (cstile::gather_bit7(cstd::Tdfa::cand_bits_ascii<false>(D, q.z)) << 8) | (cstile::gather_bit7(cstd::Tdfa::cand_bits_ascii<false>(D, q.w)) << 12);
         if (!bad) cstile::put_bits16(bitmap, j * 1024 + lane * 16, bits);
       }
+    // (a literal needle is only equivalent to its regex on plain bytes: the regex engine stops at an
+    // embedded NUL and consumes malformed multi-byte sequences as characters)
+    bad |= a.plain_only && __any((odd & 0x80808080u) != 0);
     // first look-back poll for the previous sub-tile: issued only now, after the staging above has
     // waited for its own data (vmcnt is in order: a poll issued earlier would sit in front of it)
     cstile::u64 p_first = 0;
@@ -1038,6 +1046,7 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
         sa.cap_in = cap;
         sa.cap_out = cap_out;
         sa.tbl_bytes = (int)tbl;
+        sa.plain_only = cs::g_replace_plain_only;
         sa.debug = getenv("CS_TILE_DEBUG") ? atoi(getenv("CS_TILE_DEBUG")) : 0;
         auto pick = [&](auto inplace) {
           constexpr bool IP = decltype(inplace)::value;
@@ -1119,6 +1128,7 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
       }
       // an oversize sub-tile or a look-back timeout: fall through to the two-pass kernels
     }
+    if (cs::g_replace_plain_only) fail(CS_ERR_INTERNAL, "literal replace: single-pass kernel not applicable");  // cs_replace falls back to its own kernels
     Buf lens = dev_alloc(sizeof(int32_t) * col->rows, s);
     {
       ProfScope ps("k_replace_re_size", s);

@@ -38,7 +38,7 @@ struct TokTileArgs {
   // pass 0
   int32_t* tile_bytes;   // [ntiles]
   int32_t* tile_tokens;  // [ntiles]
-  int* maxima;           // [0] most kept bytes in a tile, [1] most tokens in a tile
+  int* maxima;           // [0] most kept bytes in a tile, [1] most tokens in a tile, [2] malformed UTF-8 seen (set mode)
   // pass 1
   const int64_t* byte_base;  // [ntiles + 1]
   const int64_t* tok_base;   // [ntiles + 1]
@@ -66,6 +66,11 @@ __device__ __forceinline__ uint32_t nibble(uint32_t c) {  // bits 7,15,23,31 -> 
 __device__ __forceinline__ uint32_t keep16_of(const uint4& q, const TokTileArgs& a) {
   return nibble(keep_bits(q.x, a)) | (nibble(keep_bits(q.y, a)) << 4) | (nibble(keep_bits(q.z, a)) << 8) |
          (nibble(keep_bits(q.w, a)) << 12);
+}
+// bit `bit` of each of the 16 bytes of the piece, as a 16-bit mask
+__device__ __forceinline__ uint32_t bit16_of(const uint4& q, int bit) {
+  auto g = [&](uint32_t w) { return nibble((w << (7 - bit)) & 0x80808080u); };
+  return g(q.x) | (g(q.y) << 4) | (g(q.z) << 8) | (g(q.w) << 12);
 }
 __device__ __forceinline__ uint32_t byte_of(const uint4& q, int b) {
   const uint32_t w = b < 8 ? (b < 4 ? q.x : q.y) : (b < 12 ? q.z : q.w);
@@ -106,6 +111,7 @@ __global__ void __launch_bounds__(256) k_tok_tile(TokTileArgs a) {
   for (int j = 0; j < cstile::kPfChunks; ++j) pf.v[j] = make_uint4(0, 0, 0, 0);
   cstile::issue_chars(in.chars, cstile::rl64(cur.o0, 0), cstile::rl64(cur.o1, 63), lane, pf);
   int most_bytes = 0, most_tokens = 0;
+  bool malformed = false;
   for (;;) {
     const long long r0 = tile * R;
     const int nrows = (int)min((long long)R, in.rows - r0);
@@ -134,6 +140,7 @@ __global__ void __launch_bounds__(256) k_tok_tile(TokTileArgs a) {
 
     int carry_bytes = 0, carry_tokens = 0;  // totals of the pieces before this chunk row (wave-uniform)
     uint32_t carry_keep = 0;                // was the last byte of the previous chunk row kept?
+    uint32_t carry_expect = 0;              // continuation bytes announced into the next chunk row (set mode check)
 #pragma unroll
     for (int j = 0; j < cstile::kPfChunks; ++j) {
       if (j * 1024 < want) {  // wave-uniform
@@ -147,6 +154,25 @@ __global__ void __launch_bounds__(256) k_tok_tile(TokTileArgs a) {
         if (lane == 0) prev = carry_keep;
         const uint32_t before = ((keep << 1) | prev) & 0xFFFFu;  // bit b = byte b - 1 was kept
         const uint32_t starts = keep & (rs | ~before) & 0xFFFFu;
+        if (PASS == 0 && a.ndel > 0) {
+          // Delimiter SETS are matched per character by the row-wise routine (row_ops.h), which
+          // swallows the bytes a lead byte announces; that equals this per-byte classification only
+          // on well-formed UTF-8.  Check it: the continuation bytes must sit exactly where the lead
+          // bytes announce them, inside the lead's own row and inside the tile.
+          const uint32_t high = bit16_of(q.v[j], 7) & valid;
+          uint32_t cont = 0, expect = 0;
+          if (__any(high != 0)) {
+            const uint32_t b6 = bit16_of(q.v[j], 6), b5 = bit16_of(q.v[j], 5), b4 = bit16_of(q.v[j], 4);
+            const uint32_t lead2 = high & b6, lead3 = lead2 & b5, lead4 = lead3 & b4;
+            cont = high & ~b6;
+            expect = (lead2 << 1) | (lead3 << 2) | (lead4 << 3);  // bits 16..18 fall into the next piece
+          }
+          uint32_t carry = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(expect >> 16), 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
+          if (lane == 0) carry = carry_expect;
+          const uint32_t announced = (expect & 0xFFFFu) | carry;
+          malformed |= (announced & valid) != cont || (announced & rs) != 0 || (announced & ~valid & 0xFFFFu) != 0;
+          carry_expect = (uint32_t)__builtin_amdgcn_readlane((int)(expect >> 16), 63);
+        }
         const int nk = __builtin_popcount(keep), nt = __builtin_popcount(starts);
         const int packed = nk | (nt << 16);
         const int incl = wave_inclusive_scan(packed);
@@ -176,6 +202,7 @@ __global__ void __launch_bounds__(256) k_tok_tile(TokTileArgs a) {
       }
     }
     if (PASS == 0) {
+      malformed |= carry_expect != 0;  // a sequence cut off by the end of the tile's last row
       if (lane == 0) {
         a.tile_bytes[tile] = carry_bytes;
         a.tile_tokens[tile] = carry_tokens;
@@ -193,6 +220,7 @@ __global__ void __launch_bounds__(256) k_tok_tile(TokTileArgs a) {
     if (!has_next) break;
     ++tile;
   }
+  if (PASS == 0 && __any(malformed) && lane == 0) atomicOr(reinterpret_cast<unsigned*>(a.maxima + 2), 1u);
   if (PASS == 0 && lane == 0) {
     if (most_bytes > __hip_atomic_load(a.maxima, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(a.maxima, most_bytes);
     if (most_tokens > __hip_atomic_load(a.maxima + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(a.maxima + 1, most_tokens);
@@ -224,8 +252,8 @@ bool tokenize_fast(const cs_column* col, const unsigned char* delims, int ndel, 
   a.ndel = ndel;
   for (int k = 0; k < ndel; ++k) a.dpat[k] = 0x01010101u * delims[k];
   Buf counts = dev_alloc(sizeof(int32_t) * 2 * a.ntiles, s);
-  Buf maxima = dev_alloc(2 * sizeof(int), s);
-  CS_HIP(hipMemsetAsync(maxima->p, 0, 2 * sizeof(int), s));
+  Buf maxima = dev_alloc(4 * sizeof(int), s);
+  CS_HIP(hipMemsetAsync(maxima->p, 0, 4 * sizeof(int), s));
   a.tile_bytes = ptr<int32_t>(counts);
   a.tile_tokens = ptr<int32_t>(counts) + a.ntiles;
   a.maxima = ptr<int>(maxima);
@@ -241,9 +269,10 @@ bool tokenize_fast(const cs_column* col, const unsigned char* delims, int ndel, 
   Buf bases = dev_alloc(sizeof(int64_t) * 2 * (a.ntiles + 1), s);
   int64_t totals[2];
   offsets_from_lengths_segmented(ptr<int32_t>(counts), a.ntiles, 2, ptr<int64_t>(bases), totals, s);
-  int* hmax = (int*)pinned_scratch(2 * sizeof(int));
-  CS_HIP(hipMemcpyAsync(hmax, maxima->p, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
+  int* hmax = (int*)pinned_scratch(4 * sizeof(int));
+  CS_HIP(hipMemcpyAsync(hmax, maxima->p, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
   CS_HIP(hipStreamSynchronize(s));
+  if (hmax[2]) return false;  // malformed UTF-8 with a delimiter set: the row-wise routine defines the result
   const int64_t nbytes = totals[0], ntok = totals[1];
   auto c = std::make_unique<cs_column>();
   c->rows = ntok;

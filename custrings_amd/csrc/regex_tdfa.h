@@ -142,6 +142,10 @@ struct Tdfa {
     csrow::Char c;
     w = csrow::decode_at(s, i, n, c);
     if (w == 0) w = 1;
+    // a multi-byte sequence cut off by the end of the row (malformed input) must not carry the
+    // scan position past the row: match spans stay inside [0, n], so the size pass and the
+    // write pass of every replace kernel agree byte for byte
+    if (i + (int)w > n) w = (unsigned)(n - i);
     return c;
   }
   CS_HD unsigned cat_of_ascii(unsigned b) const { return (D.cat[b >> 2] >> (8 * (b & 3))) & 3u; }

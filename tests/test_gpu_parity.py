@@ -450,3 +450,57 @@ def test_gpu_case_tile_kernel_on_arbitrary_bytes(monkeypatch):
     monkeypatch.setenv("CS_CASE_ROWWISE", "1")
     slow_l, slow_u = gpuutil.to_col(g.lower()), gpuutil.to_col(g.upper())
     assert fast_l.same_as(slow_l) and fast_u.same_as(slow_u)
+
+
+def test_gpu_tile_kernels_on_arbitrary_bytes(monkeypatch):
+    """Tile kernels against the row-wise kernels on rows of ARBITRARY bytes (NUL, invalid UTF-8,
+    control characters): every fast path must either handle such bytes or hand the tile to the
+    sequential code, so the two routes agree bit for bit."""
+    rng = np.random.default_rng(11)
+    rows = 30_000
+    lens = rng.integers(0, 95, rows)
+    offs = np.zeros(rows + 1, dtype=np.int64)
+    np.cumsum(lens, out=offs[1:])
+    pool = np.array(list(b"ab1.2 3.4.5.6 x9_\t\n") + [0, 0xC3, 0xA9, 0xE2, 0x82, 0xFF, 0x80, 0x1F], dtype=np.uint8)
+    chars = pool[rng.integers(0, len(pool), int(offs[-1]))]
+    valid = np.packbits(rng.random(rows) > 0.02, bitorder="little")
+    col = cpulibs.Col(chars, offs, valid)
+    g = gpuutil.from_col(col)
+    L = gpuutil.lib()
+
+    def snapshot():
+        out = {}
+        out["replace"] = gpuutil.to_col(g.replace(IPV4, "<IP>"))
+        out["replace1"] = gpuutil.to_col(g.replace(r"\d", "#", 2))
+        out["lit"] = gpuutil.to_col(g.replace("a", "b", regex=False))
+        out["split"] = [gpuutil.to_col(c) for c in g.split(" ")]
+        out["split2"] = [gpuutil.to_col(c) for c in g.split(".", 2)]
+        from custrings_amd import nvtext
+        out["tok"] = gpuutil.to_col(nvtext.tokenize(g))
+        out["tok2"] = gpuutil.to_col(nvtext.tokenize(g, " ."))
+        out["strip"] = gpuutil.to_col(g.strip())
+        re = gpuutil.compile_re(IPV4)
+        out["contains"] = gpuutil.bools(g, "cs_contains_re", re)
+        cnt = np.zeros(rows, dtype=np.int32)
+        found = C.c_int64()
+        L.check(L.lib.cs_count_re(g.m_cptr, re, cnt.ctypes.data, 0, None, C.byref(found)))
+        out["count"] = (cnt, found.value)
+        f = np.zeros(rows, dtype=np.int32)
+        L.check(L.lib.cs_find(g.m_cptr, b"3.4", 0, -1, f.ctypes.data, 0, None, C.byref(found)))
+        out["find"] = (f, found.value)
+        return out
+
+    fast = snapshot()
+    for var in ("CS_REGEX_TWO_PASS", "CS_REGEX_ROWWISE", "CS_SPLIT_GENERIC", "CS_TOKENIZE_ROWWISE", "CS_STRIP_ROWWISE",
+                "CS_FIND_ROWWISE", "CS_REPLACE_ROWWISE"):
+        monkeypatch.setenv(var, "1")
+    slow = snapshot()
+    for k in fast:
+        a, b = fast[k], slow[k]
+        if isinstance(a, list):
+            assert len(a) == len(b), k
+            assert all(x.same_as(y) for x, y in zip(a, b)), k
+        elif isinstance(a, tuple):
+            assert np.array_equal(a[0], b[0]) and a[1] == b[1], k
+        else:
+            assert a.same_as(b), k
