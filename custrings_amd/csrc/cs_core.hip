@@ -381,6 +381,58 @@ int64_t max_span64(const cs_column* c, hipStream_t s) {
   return c->max_span64 = host[0];
 }
 
+// One streaming pass over the chars buffer, remembered on the (immutable) column: true when
+// the bytes hold no NUL and no UTF-8 lead byte whose announced continuation positions hold an
+// ASCII byte.  On such a column a per-character scan and a per-byte scan see every ASCII byte
+// at a character boundary, so an ASCII needle may be searched either way (cs_replace routes a
+// literal needle through the regex stream kernel on the strength of this).
+__global__ void __launch_bounds__(256) k_bytes_plain(const uint8_t* __restrict__ chars, int64_t nbytes, unsigned* __restrict__ flag) {
+  const int64_t pieces = (nbytes + 15) / 16;
+  uint32_t hit = 0;
+  for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < pieces; p += (int64_t)gridDim.x * 256) {
+    uint32_t w[5];
+    w[0] = p > 0 ? *reinterpret_cast<const uint32_t*>(chars + 16 * p - 4) : 0x20202020u;
+    if (16 * p + 16 <= nbytes) {
+      const uint4 q = *reinterpret_cast<const uint4*>(chars + 16 * p);
+      w[1] = q.x, w[2] = q.y, w[3] = q.z, w[4] = q.w;
+    } else {
+      for (int k = 1; k < 5; ++k) w[k] = 0x20202020u;
+      for (int64_t i = 16 * p; i < nbytes; ++i) {
+        const int j = (int)(i - 16 * p);
+        w[1 + (j >> 2)] = (w[1 + (j >> 2)] & ~(0xFFu << (8 * (j & 3)))) | ((uint32_t)chars[i] << (8 * (j & 3)));
+      }
+    }
+    uint32_t l2[5], l3[5], l4[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      l2[k] = w[k] & (w[k] << 1) & 0x80808080u;  // bytes >= 0xC0
+      l3[k] = l2[k] & (w[k] << 2);               // >= 0xE0
+      l4[k] = l3[k] & (w[k] << 3);               // >= 0xF0
+    }
+#pragma unroll
+    for (int k = 1; k < 5; ++k) {
+      const uint32_t announced = __funnelshift_l(l2[k - 1], l2[k], 8) | __funnelshift_l(l3[k - 1], l3[k], 16) |
+                                 __funnelshift_l(l4[k - 1], l4[k], 24);
+      hit |= (announced | (w[k] - 0x01010101u)) & ~w[k] & 0x80808080u;
+    }
+  }
+  if (__any(hit != 0) && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
+}
+bool bytes_plain(const cs_column* c, hipStream_t s) {
+  if (c->plain_bytes >= 0) return c->plain_bytes != 0;
+  if (c->nbytes == 0) return (c->plain_bytes = 1) != 0;
+  Buf acc = dev_alloc(8, s);
+  CS_HIP(hipMemsetAsync(acc->p, 0, 8, s));
+  const int64_t pieces = (c->nbytes + 15) / 16;
+  const unsigned grid = (unsigned)std::min<int64_t>((pieces + 255) / 256, 256 * 16);
+  hipLaunchKernelGGL(k_bytes_plain, dim3(grid), dim3(256), 0, s, c->d_chars(), c->nbytes, ptr<unsigned>(acc));
+  CS_HIP(hipGetLastError());
+  unsigned* host = (unsigned*)pinned_scratch(8);
+  CS_HIP(hipMemcpyAsync(host, acc->p, 4, hipMemcpyDeviceToHost, s));
+  CS_HIP(hipStreamSynchronize(s));
+  return (c->plain_bytes = host[0] ? 0 : 1) != 0;
+}
+
 cs_column* make_all_null(int64_t rows, hipStream_t s) {
   auto* c = new cs_column;
   c->rows = rows;

@@ -84,6 +84,7 @@ struct cs_column {
   int64_t nbytes = 0;
   mutable int64_t null_count = -1;  // -1 = not counted yet
   mutable int64_t max_span64 = -1;  // max bytes spanned by 64 consecutive rows (tile kernels); -1 = unknown
+  mutable int plain_bytes = -1;     // 1: no NUL byte and no lead byte announcing over an ASCII byte; -1 = unknown
   cs::Buf chars, offsets, validity;  // validity may be null (all valid)
   const uint8_t* d_chars() const { return cs::ptr<const uint8_t>(chars); }
   const int64_t* d_offsets() const { return cs::ptr<const int64_t>(offsets); }
@@ -124,6 +125,7 @@ int64_t count_nulls(const cs_column* c, hipStream_t s);
 // Largest byte span of 64 consecutive rows starting at a multiple of 64 (cached
 // in the column; sizes the LDS staging buffers of the tile kernels).
 int64_t max_span64(const cs_column* c, hipStream_t s);
+bool bytes_plain(const cs_column* c, hipStream_t s);
 // Same for tiles of `per` consecutive rows (per = 64 is the cached one).
 int64_t max_span_rows(const cs_column* c, int per, hipStream_t s);
 // Workgroups (256 threads, `lds` dynamic bytes) of `kern` resident at once on the device,

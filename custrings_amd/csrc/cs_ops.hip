@@ -522,11 +522,11 @@ int cs_replace(const cs_column* col, const char* str, const char* repl, int maxr
                 c == ',' || c == ';' || c == ':' || c == '=' || c == '@' || c == '#' || c == '%' || c == '&' || c == '~' ||
                 c == '<' || c == '>' || c == '/' || c == '!' || c == '-' || c == '"' || c == '\'';
       }
-      const size_t nb = strlen(str), rb = strlen(repl);
-      if (plain && rb <= 16 && col->rows > 0 && !getenv("CS_REPLACE_ROWWISE")) {
+      const size_t rb = strlen(repl);
+      if (plain && rb <= 16 && col->rows > 0 && !getenv("CS_REPLACE_ROWWISE") && bytes_plain(col, S(stream))) {
         cs_regex* re = nullptr;
         if (cs_regex_compile(str, &re) == CS_OK) {
-          cs::g_replace_plain_only = 1;  // equivalent only on plain bytes: the kernel gives up on NUL / non-ASCII tiles
+          cs::g_replace_plain_only = 1;  // the single-pass kernel or nothing: this function's own kernels are the fallback
           const int rc = cs_replace_re(col, re, repl, maxrepl, stream, out);
           cs::g_replace_plain_only = 0;
           cs_regex_destroy(re);

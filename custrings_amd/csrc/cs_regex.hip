@@ -33,7 +33,7 @@ struct cs_regex {
 };
 
 namespace cs {
-thread_local int g_replace_plain_only = 0;  // set by cs_replace around its call of cs_replace_re
+thread_local int g_replace_plain_only = 0;  // set by cs_replace around its call of cs_replace_re: single-pass kernel or nothing
 }
 
 namespace {
@@ -423,8 +423,8 @@ struct StreamArgs {
   unsigned* error;
   long long nsub;
   int cap_in, cap_out, tbl_bytes;
-  int plain_only;  // literal replace routed here: give up on sub-tiles holding NUL or non-ASCII bytes
   int debug;
+  long long out_cap;  // bytes provisioned at out_chars (growing replacements)
 };
 #ifndef CS_STREAM_WAVES
 #define CS_STREAM_WAVES 3
@@ -433,9 +433,11 @@ struct StreamArgs {
 // INPLACE (the output cannot outgrow the input): every row is compacted inside its own extent of
 // the input tile while it is scanned -- the bytes before a match move down to the write cursor,
 // the replacement follows -- so any number of matches per row costs no registers and the
-// assembly is one contiguous copy per row.  Otherwise (bounded growth) up to kMaxRec matches per
-// row are kept in registers and the rows are assembled piecewise.
-template <bool IN_LDS, bool REP16, bool INPLACE>
+// assembly is one contiguous copy per row.  Otherwise (growing replacement) up to kMaxRec matches
+// per row are kept in registers and the rows are assembled piecewise; with RESCAN a row with more
+// matches is scanned a second time during assembly (its size is known from the first scan),
+// without it such a row fails the launch and the host repeats it with the RESCAN variant.
+template <bool IN_LDS, bool REP16, bool INPLACE, bool RESCAN = false>
 __global__ void __launch_bounds__(256, CS_STREAM_WAVES) k_tdfa_replace_stream(StreamArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   uint8_t* base = reinterpret_cast<uint8_t*>(smem);
@@ -496,6 +498,10 @@ __global__ void __launch_bounds__(256, CS_STREAM_WAVES) k_tdfa_replace_stream(St
     const int pn = (int)min(64ll, in.rows - pr0);
     if (lane < pn) a.out_off[pr0 + lane] = gb + p_lo;
     if (lane == pn - 1 && pr0 + pn == in.rows) a.out_off[in.rows] = gb + p_lo + p_len;
+    if (!INPLACE && gb + p_total > a.out_cap) {  // more growth than the host provisioned for
+      if (lane == 0) atomicOr(a.error, 2u);
+      return;
+    }
     if (!(a.debug & 4)) cstile::wave_flush_shift(a.out_chars + gb, p_total, lds_out, lane);
   };
   for (;;) {
@@ -529,9 +535,6 @@ __global__ void __launch_bounds__(256, CS_STREAM_WAVES) k_tdfa_replace_stream(St
                  (cstile::gather_bit7(cstd::Tdfa::cand_bits_ascii<false>(D, q.z)) << 8) | (cstile::gather_bit7(cstd::Tdfa::cand_bits_ascii<false>(D, q.w)) << 12);
         if (!bad) cstile::put_bits16(bitmap, j * 1024 + lane * 16, bits);
       }
-    // (a literal needle is only equivalent to its regex on plain bytes: the regex engine stops at an
-    // embedded NUL and consumes malformed multi-byte sequences as characters)
-    bad |= a.plain_only && __any((odd & 0x80808080u) != 0);
     // first look-back poll for the previous sub-tile: issued only now, after the staging above has
     // waited for its own data (vmcnt is in order: a poll issued earlier would sit in front of it)
     cstile::u64 p_first = 0;
@@ -612,15 +615,18 @@ __global__ void __launch_bounds__(256, CS_STREAM_WAVES) k_tdfa_replace_stream(St
       }
     }
     CS_PHASE_MARK(1);
-    if (!INPLACE) bad |= __any(nm > kMaxRec);
     const int incl = csdev::wave_inclusive_scan(out_len);
     const int lo = incl - out_len;
     const int total = __builtin_amdgcn_readlane(incl, 63);
+    // (error bit 1: a roomier launch, which also takes rows with many matches, can succeed)
+    bool grew = false;
+    if (!INPLACE) grew = !bad && (total + 32 > a.cap_out || (!RESCAN && __any(nm > kMaxRec)));
     bad |= total + 32 > a.cap_out;
+    if (!INPLACE) bad |= grew;
     if (bad) {
       // the host discards this launch's output; publish something so successors do not spin
       if (lane == 0) {
-        atomicOr(a.error, 1u);
+        atomicOr(a.error, !INPLACE && grew ? 2u : 1u);
         cstile::status_store(a.status + tile, cstile::kFlagInc);
       }
       if (p_tile >= 0) finish_pending(p_first);
@@ -636,23 +642,37 @@ __global__ void __launch_bounds__(256, CS_STREAM_WAVES) k_tdfa_replace_stream(St
         int oi = lo;                 // byte index into lds_out
         const int pi = lead + rbeg;  // byte index of the row in lds_in
         int copied = 0;
+        if (!RESCAN || nm <= kMaxRec) {
 #pragma unroll
-        for (int j = 0; j < kMaxRec; ++j)
-          if (j < nm) {
-            cstile::lds_copy(lds_out, oi, lds_in, pi + copied, rec_mb[j] - copied);
-            oi += rec_mb[j] - copied;
-            for (int k = 0; k < rec_reps[j]; ++k) {
-              if (REP16) {
+          for (int j = 0; j < kMaxRec; ++j)
+            if (j < nm) {
+              cstile::lds_copy(lds_out, oi, lds_in, pi + copied, rec_mb[j] - copied);
+              oi += rec_mb[j] - copied;
+              for (int k = 0; k < rec_reps[j]; ++k) {
+                if (REP16) {
 #pragma unroll
-                for (int i = 0; i < 16; ++i)
-                  if (i < rb) lds_out[oi + i] = (uint8_t)(rep[i >> 2] >> (8 * (i & 3)));
-                oi += rb;
-              } else {
-                for (int i = 0; i < rb; ++i) lds_out[oi++] = (uint8_t)((i < 4 ? rep[0] >> (8 * i) : rep[1] >> (8 * (i - 4))));
+                  for (int i = 0; i < 16; ++i)
+                    if (i < rb) lds_out[oi + i] = (uint8_t)(rep[i >> 2] >> (8 * (i & 3)));
+                  oi += rb;
+                } else {
+                  for (int i = 0; i < rb; ++i) lds_out[oi++] = (uint8_t)((i < 4 ? rep[0] >> (8 * i) : rep[1] >> (8 * (i - 4))));
+                }
               }
+              copied = rec_me[j];
             }
-            copied = rec_me[j];
-          }
+        } else {
+          // more matches than the registers keep: the row's size is known from the first scan, so
+          // scan it again and assemble as the matches are reported
+          auto piece2 = [&](int mb, int me, int reps) {
+            cstile::lds_copy(lds_out, oi, lds_in, pi + copied, mb - copied);
+            oi += mb - copied;
+            for (int k = 0; k < reps; ++k)
+              for (int i = 0; i < rb; ++i) lds_out[oi++] = a.repl[i];
+            copied = me;
+          };
+          cstd::Tdfa vm2(D, P, lds_in + pi, n, pi & 3);
+          vm2.template scan<cstd::Tdfa::K_REPLACE>(a.maxrepl, piece2, 0, 0);
+        }
         cstile::lds_copy(lds_out, oi, lds_in, pi + copied, n - copied);
       }
       cstile::wave_lds_fence();
@@ -1008,24 +1028,37 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
     o->validity = col->validity;
     o->null_count = col->null_count;
     const int minlen = tdfa ? re->tdfa[13] : 0;
-    // Single pass when the output size is bounded up front: a match is at least `minlen` bytes,
-    // so a row grows by at most kMaxRec * (rb - minlen) bytes (rows with more matches than the
-    // kernel keeps in registers raise its error word); rb <= minlen means "never grows".  A
-    // pattern that matches the empty string with a non-empty replacement is unbounded (the
-    // zero-length repeat rule) and takes the two-pass kernels.
+    // Single pass when a match cannot be empty: a match is at least `minlen` bytes, so a row grows
+    // by at most (rb - minlen) bytes per match; rb <= minlen means "never grows" and the rows are
+    // rewritten in place.  A growing replacement is provisioned for kMaxRec matches per row first
+    // (or, for one- and two-byte patterns, which tend to match often, for up to the worst case);
+    // a launch that runs out of room says so in its error word and is repeated once with the
+    // roomier sizing.  A pattern that matches the empty string with a non-empty replacement is
+    // unbounded (the zero-length repeat rule) and takes the two-pass kernels.
     const int growth = rb > minlen ? rb - minlen : 0;
-    const bool bounded = growth == 0 || (minlen >= 1 && (int64_t)col->rows * kMaxRec * growth <= col->nbytes + (1ll << 30));
+    const bool bounded = growth == 0 || minlen >= 1;
     if (tdfa && bounded && !getenv("CS_REGEX_TWO_PASS")) {
       const int64_t rows = col->rows;
       const int64_t ntiles = (rows + cstile::kTileRows - 1) / cstile::kTileRows;
       const int64_t nsub = ntiles * 4;
       const int64_t span = max_span64(col, s);
       const int cap = (int)((span + 15 + 32 + 127) & ~(int64_t)127);
-      const int cap_out = cap + ((64 * kMaxRec * growth + 127) & ~127);
       const size_t tbl = tp.d.in_lds ? tp.lds_bytes : 0;
-      const size_t lds = tbl + (size_t)(cap + cap_out + 64 + (cap >> 3) + 32) * 4 + 16;
-      if (lds <= 150 * 1024 && rb <= 16 && cap <= cstile::kPfBytes && !getenv("CS_TILE_OLD")) {
-        // persistent stream kernel: grid = what is resident at once
+      size_t lds = tbl + (size_t)(cap + cap + 64 + (cap >> 3) + 32) * 4 + 16;
+      // persistent stream kernel (grid = what is resident at once); returns its error word, or -1
+      // when the sizing does not fit
+      auto stream_attempt = [&](bool roomy) -> int {
+        const int64_t few = (int64_t)rows * kMaxRec * growth;  // extra bytes if no row has more than kMaxRec matches
+        int cap_out = cap + ((64 * kMaxRec * growth + 127) & ~127);
+        int64_t extra = std::min<int64_t>(few, col->nbytes + (1ll << 30));
+        if (roomy) {
+          const int64_t worst = ((int64_t)cap * rb + minlen - 1) / minlen;
+          cap_out = std::max(cap_out, (int)((std::min<int64_t>(worst, 3ll * cap) + 127) & ~(int64_t)127));
+          const int64_t worst_extra = (col->nbytes * growth + minlen - 1) / minlen;
+          extra = std::min(worst_extra, std::max<int64_t>(extra, col->nbytes));
+        }
+        const size_t lds1 = tbl + (size_t)(cap + cap_out + 64 + (cap >> 3) + 32) * 4 + 16;
+        if (lds1 > 150 * 1024) return -1;
         StreamArgs sa{};
         sa.in = view_of(col);
         sa.flags = d_unicode_flags();
@@ -1034,9 +1067,10 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
         sa.rb = rb;
         sa.maxrepl = maxrepl;
         Buf out_off = dev_alloc(sizeof(int64_t) * (rows + 1), s);
-        Buf out_chars = dev_alloc((size_t)col->nbytes + (size_t)rows * kMaxRec * growth + 64, s);
+        Buf out_chars = dev_alloc((size_t)col->nbytes + (size_t)extra + 64, s);
         sa.out_off = ptr<int64_t>(out_off);
         sa.out_chars = ptr<uint8_t>(out_chars);
+        sa.out_cap = col->nbytes + extra;
         const int64_t nsub1 = (rows + 63) / 64;
         Buf status = dev_alloc(sizeof(cstile::u64) * nsub1 + 128, s);
         CS_HIP(hipMemsetAsync(status->p, 0, sizeof(cstile::u64) * nsub1 + 128, s));
@@ -1046,21 +1080,21 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
         sa.cap_in = cap;
         sa.cap_out = cap_out;
         sa.tbl_bytes = (int)tbl;
-        sa.plain_only = cs::g_replace_plain_only;
         sa.debug = getenv("CS_TILE_DEBUG") ? atoi(getenv("CS_TILE_DEBUG")) : 0;
-        auto pick = [&](auto inplace) {
-          constexpr bool IP = decltype(inplace)::value;
-          return rb > 8 ? (tp.d.in_lds ? &k_tdfa_replace_stream<true, true, IP> : &k_tdfa_replace_stream<false, true, IP>)
-                        : (tp.d.in_lds ? &k_tdfa_replace_stream<true, false, IP> : &k_tdfa_replace_stream<false, false, IP>);
+        auto pick = [&](auto inplace, auto rescan) {
+          constexpr bool IP = decltype(inplace)::value, RS = decltype(rescan)::value;
+          return rb > 8 ? (tp.d.in_lds ? &k_tdfa_replace_stream<true, true, IP, RS> : &k_tdfa_replace_stream<false, true, IP, RS>)
+                        : (tp.d.in_lds ? &k_tdfa_replace_stream<true, false, IP, RS> : &k_tdfa_replace_stream<false, false, IP, RS>);
         };
-        auto kern = growth == 0 ? pick(std::true_type{}) : pick(std::false_type{});
-        if (lds > 48 * 1024)
+        auto kern = growth == 0 ? pick(std::true_type{}, std::false_type{})
+                                : roomy ? pick(std::false_type{}, std::true_type{}) : pick(std::false_type{}, std::false_type{});
+        if (lds1 > 48 * 1024)
           CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)lds));
-        const unsigned grid = resident_grid(reinterpret_cast<const void*>(kern), lds, (nsub1 + 3) / 4);
+                                     (int)lds1));
+        const unsigned grid = resident_grid(reinterpret_cast<const void*>(kern), lds1, (nsub1 + 3) / 4);
         {
           ProfScope ps("k_replace_re", s);
-          hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, sa);
+          hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds1, s, sa);
         }
         CS_HIP(hipGetLastError());
         int64_t* host = (int64_t*)pinned_scratch(16);
@@ -1077,13 +1111,21 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
                   ph[3] / waves / (nsub1 / waves), ph[4] / waves / (nsub1 / waves), ph[5] / waves / (nsub1 / waves), ph[6] / waves / (nsub1 / waves), nsub1 / waves);
         }
 #endif
-        if ((uint32_t)host[1] == 0 || sa.debug) {
+        const int err = (int)(uint32_t)host[1];
+        if (err == 0 || sa.debug) {
           o->offsets = out_off;
           o->chars = out_chars;
           o->nbytes = host[0];
           *out = holder.release();
-          return;
+          return 0;
         }
+        return err;
+      };
+      if (lds <= 150 * 1024 && rb <= 16 && cap <= cstile::kPfBytes && !getenv("CS_TILE_OLD")) {
+        const bool roomy_first = growth > 0 && (minlen <= 2 || getenv("CS_REPLACE_ROOMY"));
+        int err = stream_attempt(roomy_first);
+        if (err == 2 && !roomy_first) err = stream_attempt(true);  // only ran out of room: once more, roomier
+        if (err == 0) return;
       } else if (lds <= 150 * 1024 && growth == 0) {
         TileArgs ta{};
         ta.in = view_of(col);

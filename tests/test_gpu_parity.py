@@ -416,6 +416,49 @@ def test_gpu_literal_replace_on_stream_kernel(gpu_engine, oracle_engine, orc):
         gpuutil.assert_same(gc.replace(pat, repl, regex=False), orc.replace(oc, pat, repl), "literal %r" % pat)
 
 
+def test_gpu_growing_replace_with_many_matches(gpu_engine, oracle_engine, orc):
+    """A replacement longer than the match, on rows with more matches than the single-pass kernel
+    keeps in registers: the roomier launch rescans such rows while it assembles them."""
+    s = fuzzdata.rows(4, 3000, max_len=70) + fuzzdata.log_rows(10, 2000) + ["aaaaaaaaaaaaaaaaaaaaaaaa", "a" * 90, "", None, "é" * 20 + "a"]
+    o, g = oracle_engine, gpu_engine
+    for pat, repl in (("a", "xx"), ("a", "xyz12"), (" ", "    "), ("ab", "abab"), ("1", "0123456789abcdef")):
+        for n in (-1, 1, 5, 7):
+            assert g.replace(s, pat, repl, n) == o.replace(s, pat, repl, n), (pat, repl, n)
+    for pat, repl in ((r"\d", "<d>"), (r"[aeiou]", "<v>"), (r"\s", "__"), (r"\w+", "<word>"), (r"\d+", "<number-here>"), (r"[a-c]", "é")):
+        for n in (-1, 6):
+            assert g.replace_re(s, pat, repl, n) == o.replace_re(s, pat, repl, n), (pat, repl, n)
+    rows = 100_000
+    gc, oc = gpuutil.synth(3, 0, rows), orc.synth(3, 0, rows)
+    gpuutil.assert_same(gc.replace(" ", "  ", regex=False), orc.replace(oc, " ", "  "), "literal ' ' -> '  '")
+    for pat, repl in ((r"\d", "##"), (r"[aeiou]", "<v>")):
+        blob = np.ascontiguousarray(engines.reference_blob(pat))
+        gpuutil.assert_same(gc.replace(pat, repl), orc.replace_re(oc, blob, repl), "%s -> %s" % (pat, repl))
+
+
+def test_gpu_literal_replace_routing_on_odd_bytes(monkeypatch):
+    """A literal needle is routed through the regex stream kernel only when a per-character scan
+    and a per-byte scan agree on the column's bytes (no NUL, no lead byte announcing over an ASCII
+    byte).  Columns built from valid sequences, stray continuation bytes and rows cut in the
+    middle of a sequence qualify; a lead byte in front of ASCII does not.  Either way the result
+    must equal the row-wise literal kernels."""
+    rng = np.random.default_rng(21)
+    tokens = [bytes([c]) for c in b"abab 12.x"] + ["é".encode(), "€".encode(), "😀".encode(), b"\x80", b"\xbf", b"\xf0\xe2\x80\x80"]
+    for extra in ([], [b"\xe2"], [b"\x00"]):
+        pool = tokens + extra
+        data = b"".join(pool[i] for i in rng.integers(0, len(pool), 400_000))
+        chars = np.frombuffer(data, dtype=np.uint8)
+        rows = 12_000
+        cuts = np.sort(rng.integers(0, len(chars), rows - 1))
+        offs = np.concatenate([[0], cuts, [len(chars)]]).astype(np.int64)
+        col = cpulibs.Col(chars, offs, None)
+        g = gpuutil.from_col(col)
+        fast = [gpuutil.to_col(g.replace(p, r, regex=False)) for p, r in (("ab", "x"), ("a", "xx"), (" ", ""), ("b", "b"))]
+        monkeypatch.setenv("CS_REPLACE_ROWWISE", "1")
+        slow = [gpuutil.to_col(g.replace(p, r, regex=False)) for p, r in (("ab", "x"), ("a", "xx"), (" ", ""), ("b", "b"))]
+        monkeypatch.delenv("CS_REPLACE_ROWWISE")
+        assert all(a.same_as(b) for a, b in zip(fast, slow)), extra
+
+
 def test_gpu_category_table_growth(orc, monkeypatch):
     """The category build starts with a small hash table and retries with a larger one when a
     probe run gets long: force the retries with a tiny first table."""
