@@ -6,7 +6,7 @@
 // reference gets there by comparator-sorting every row; the outputs depend only
 // on the sorted set of distinct keys and each row's rank in it, so here rows are
 // first de-duplicated through an open-addressing hash table in HBM (one CAS per
-// row, full byte compare on every hit, so there are no false merges), and only
+// new key, full byte compare on every hit, so there are no false merges), and only
 // the U distinct representatives are sorted (bitonic network on an 8-byte
 // big-endian prefix with a full-compare tie break).
 #include <hip/hip_runtime.h>
@@ -25,49 +25,99 @@ struct cs_category {
 
 namespace {
 
-// little-endian dword k of a row, zero beyond its end (aligned rows load whole dwords)
-__device__ __forceinline__ uint32_t row_word(const uint8_t* p, int n, int k, bool aligned) {
-  const int i = 4 * k;
-  if (aligned && i + 4 <= n) return *reinterpret_cast<const uint32_t*>(p + i);
-  uint32_t w = 0;
-  for (int j = 0; j < 4; ++j)
-    if (i + j < n) w |= (uint32_t)p[i + j] << (8 * j);
-  return w;
+// A table entry names a key by where its bytes are: (byte offset into chars) << 24 | length.
+// The probe then goes table -> key bytes, without a detour through the offsets array.
+typedef unsigned long long Entry;
+constexpr Entry kEmpty = ~0ull;
+constexpr int kMaxKeyLen = (1 << 24) - 2;
+__device__ __forceinline__ Entry make_entry(int64_t off, int n) { return ((Entry)off << 24) | (Entry)(unsigned)n; }
+__device__ __forceinline__ int64_t entry_off(Entry e) { return (int64_t)(e >> 24); }
+__device__ __forceinline__ int entry_len(Entry e) { return (int)(e & 0xFFFFFFu); }
+
+// Bytes [i, i + 32) of the row at `p` (n bytes) as eight little-endian dwords, zero beyond the
+// row's end.  Read as the 16-byte-aligned pieces that cover them (three loads at most) and
+// shifted into place: the memory pipe sees a few wide requests per row instead of one per
+// byte, which is what bounds this kernel (every lane of a probe touches a different line).
+// Reads stay inside the aligned pieces that hold at least one byte of the row.
+__device__ __forceinline__ void row_block32(const uint8_t* p, int n, int i, uint32_t w[8]) {
+  const int rem = n - i;  // > 0
+  const uint8_t* q = p + i;
+  const int sh = (int)((uintptr_t)q & 15);
+  const uint4* a = reinterpret_cast<const uint4*>(q - sh);
+  const int last = (sh + (rem < 32 ? rem : 32) - 1) >> 4;  // index of the last aligned piece in use: 0..2
+  // (wave-uniform branches; a lane that does not need the piece re-reads one it does need)
+  const uint4 x = a[0];
+  uint4 y = x, z = x;
+  if (__any(last >= 1)) y = a[last >= 1 ? 1 : 0];
+  if (__any(last >= 2)) z = a[last >= 2 ? 2 : 0];
+  // shift right by sh bytes, one binary digit of sh at a time (selects, then a funnel shift).  Written
+  // out on scalars: with arrays indexed in an unrolled loop the optimizer turns the selects into a
+  // dynamically indexed private array, i.e. a round trip through scratch memory.
+  const bool by8 = (sh & 8) != 0, by4 = (sh & 4) != 0;
+  const int bits = (sh & 3) * 8;
+  const uint32_t u0 = by8 ? x.z : x.x;
+  const uint32_t u1 = by8 ? x.w : x.y;
+  const uint32_t u2 = by8 ? y.x : x.z;
+  const uint32_t u3 = by8 ? y.y : x.w;
+  const uint32_t u4 = by8 ? y.z : y.x;
+  const uint32_t u5 = by8 ? y.w : y.y;
+  const uint32_t u6 = by8 ? z.x : y.z;
+  const uint32_t u7 = by8 ? z.y : y.w;
+  const uint32_t u8 = by8 ? z.z : z.x;
+  const uint32_t u9 = by8 ? z.w : z.y;
+  const uint32_t t0 = by4 ? u1 : u0;
+  const uint32_t t1 = by4 ? u2 : u1;
+  const uint32_t t2 = by4 ? u3 : u2;
+  const uint32_t t3 = by4 ? u4 : u3;
+  const uint32_t t4 = by4 ? u5 : u4;
+  const uint32_t t5 = by4 ? u6 : u5;
+  const uint32_t t6 = by4 ? u7 : u6;
+  const uint32_t t7 = by4 ? u8 : u7;
+  const uint32_t t8 = by4 ? u9 : u8;
+  auto keep = [&](int k, uint32_t d) {  // zero beyond the row's end
+    const int left = rem - 4 * k;
+    return d & (left >= 4 ? 0xFFFFFFFFu : (left <= 0 ? 0u : (1u << (8 * left)) - 1u));
+  };
+  w[0] = keep(0, __funnelshift_r(t0, t1, bits));
+  w[1] = keep(1, __funnelshift_r(t1, t2, bits));
+  w[2] = keep(2, __funnelshift_r(t2, t3, bits));
+  w[3] = keep(3, __funnelshift_r(t3, t4, bits));
+  w[4] = keep(4, __funnelshift_r(t4, t5, bits));
+  w[5] = keep(5, __funnelshift_r(t5, t6, bits));
+  w[6] = keep(6, __funnelshift_r(t6, t7, bits));
+  w[7] = keep(7, __funnelshift_r(t7, t8, bits));
 }
 // Any well-mixed hash will do: keys and codes depend only on the sorted key set.
-__device__ __forceinline__ uint32_t hash_bytes(const uint8_t* p, int n) {
-  const bool aligned = ((uintptr_t)p & 3) == 0;
-  uint32_t h = 0x9E3779B9u ^ (uint32_t)n;
-  for (int k = 0; 4 * k < n; ++k) {
-    uint32_t w = row_word(p, n, k, aligned) * 0xCC9E2D51u;
-    w = (w << 15) | (w >> 17);
-    h ^= w * 0x1B873593u;
-    h = ((h << 13) | (h >> 19)) * 5u + 0xE6546B64u;
-  }
+__device__ __forceinline__ uint32_t hash_mix(uint32_t h, uint32_t w) {
+  w *= 0xCC9E2D51u;
+  w = (w << 15) | (w >> 17);
+  h ^= w * 0x1B873593u;
+  return ((h << 13) | (h >> 19)) * 5u + 0xE6546B64u;
+}
+__device__ __forceinline__ uint32_t hash_final(uint32_t h) {
   h ^= h >> 16;
   h *= 0x85EBCA6Bu;
   h ^= h >> 13;
   h *= 0xC2B2AE35u;
   return h ^ (h >> 16);
 }
-__device__ __forceinline__ bool same_bytes(const uint8_t* a, const uint8_t* b, int n) {
-  if ((((uintptr_t)a | (uintptr_t)b) & 3) == 0) {
-    int i = 0;
-    for (; i + 4 <= n; i += 4)
-      if (*reinterpret_cast<const uint32_t*>(a + i) != *reinterpret_cast<const uint32_t*>(b + i)) return false;
-    for (; i < n; ++i)
-      if (a[i] != b[i]) return false;
-    return true;
+// are the n bytes at a and b equal?  (rows longer than the 32 bytes the caller holds in registers)
+__device__ __forceinline__ bool same_tail(const uint8_t* a, const uint8_t* b, int n) {
+  for (int i = 32; i < n; i += 32) {
+    uint32_t x[8], y[8];
+    row_block32(a, n, i, x);
+    row_block32(b, n, i, y);
+    uint32_t d = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) d |= x[k] ^ y[k];
+    if (d) return false;
   }
-  for (int i = 0; i < n; ++i)
-    if (a[i] != b[i]) return false;
   return true;
 }
 // custr::compare: unsigned bytewise, shorter is less
-__device__ __forceinline__ int compare_rows(const ColView& in, int64_t ra, int64_t rb) {
-  int64_t oa = in.offsets[ra], ob = in.offsets[rb];
-  int la = (int)(in.offsets[ra + 1] - oa), lb = (int)(in.offsets[rb + 1] - ob);
-  const uint8_t *pa = in.chars + oa, *pb = in.chars + ob;
+__device__ __forceinline__ int compare_keys(const uint8_t* chars, Entry ea, Entry eb) {
+  const uint8_t *pa = chars + entry_off(ea), *pb = chars + entry_off(eb);
+  const int la = entry_len(ea), lb = entry_len(eb);
   int m = la < lb ? la : lb;
   for (int i = 0; i < m; ++i)
     if (pa[i] != pb[i]) return (int)pa[i] - (int)pb[i];
@@ -75,9 +125,10 @@ __device__ __forceinline__ int compare_rows(const ColView& in, int64_t ra, int64
 }
 
 constexpr int kProbeLimit = 128;  // longer probe runs mean the table is too small: the host retries with a bigger one
-__global__ void k_cat_insert(ColView in, int32_t* __restrict__ table, uint32_t mask,
-                             int32_t* __restrict__ slot_of_row, int* __restrict__ has_null, int* __restrict__ overflow,
-                             int probe_limit) {
+// `dbg` (CS_CAT_DEBUG, measurement only -- wrong results): 1 skips the byte compare, 2 the table.
+__global__ void __launch_bounds__(256) k_cat_insert(ColView in, Entry* table, uint32_t mask,
+                                                    int32_t* __restrict__ slot_of_row, int* __restrict__ has_null,
+                                                    int* __restrict__ overflow, int probe_limit, int dbg) {
   int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (r >= in.rows) return;
   if (!row_is_valid(in.validity, r)) {
@@ -85,43 +136,79 @@ __global__ void k_cat_insert(ColView in, int32_t* __restrict__ table, uint32_t m
     *has_null = 1;
     return;
   }
-  int64_t b = in.offsets[r];
-  int n = (int)(in.offsets[r + 1] - b);
+  const int64_t b = in.offsets[r];
+  const int n = (int)min(in.offsets[r + 1] - b, (int64_t)kMaxKeyLen + 1);
+  if (n > kMaxKeyLen) {
+    atomicOr(overflow, 2);  // a key the table entry cannot name
+    return;
+  }
   const uint8_t* p = in.chars + b;
-  uint32_t slot = hash_bytes(p, n) & mask;
+  // the first 32 bytes stay in registers for the probe's compare; longer rows hash the rest from memory
+  uint32_t w[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) w[k] = 0;
+  if (n > 0) row_block32(p, n, 0, w);
+  uint32_t h = 0x9E3779B9u ^ (uint32_t)n;
+#pragma unroll
+  for (int k = 0; k < 8; ++k)
+    if (4 * k < n) h = hash_mix(h, w[k]);
+  for (int i = 32; i < n; i += 32) {
+    uint32_t x[8];
+    row_block32(p, n, i, x);
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (i + 4 * k < n) h = hash_mix(h, x[k]);
+  }
+  uint32_t slot = hash_final(h) & mask;
+  const Entry mine = make_entry(b, n);
   int probes = 0;
+  if (dbg & 2) {  // measurement only: no table
+    slot_of_row[r] = (int32_t)slot;
+    return;
+  }
   for (;;) {
-    // Look before the CAS: a slot only ever changes from -1 to its final row, so a non-empty
+    // Look before the CAS: a slot only ever changes from empty to its final key, so a non-empty
     // value read here is final and the common case (key already present) needs no atomic at
     // all -- with a skewed key distribution the CASes of a hot key would otherwise queue on one
     // address (about 10 ns each: 100 ms for a key that 7 % of 125M rows share).
-    int32_t cur = __hip_atomic_load(&table[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (cur == -1) cur = atomicCAS(&table[slot], -1, (int32_t)r);
-    if (cur == -1 || cur == (int32_t)r) break;  // this row represents the key
-    int64_t cb = in.offsets[cur];
-    if ((int)(in.offsets[cur + 1] - cb) == n && same_bytes(in.chars + cb, p, n)) break;
+    Entry cur = __hip_atomic_load(&table[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (cur == kEmpty) cur = atomicCAS(&table[slot], kEmpty, mine);
+    if (cur == kEmpty || cur == mine) break;  // this row represents the key
+    if (entry_len(cur) == n) {
+      bool same = true;
+      if (n > 0 && !(dbg & 1)) {
+        const uint8_t* q = in.chars + entry_off(cur);
+        uint32_t y[8];
+        row_block32(q, n, 0, y);
+        uint32_t d = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) d |= w[k] ^ y[k];
+        same = d == 0 && (n <= 32 || same_tail(p, q, n));
+      }
+      if (same) break;
+    }
     slot = (slot + 1) & mask;
     if (++probes > probe_limit) {
-      *overflow = 1;
+      atomicOr(overflow, 1);
       return;
     }
   }
   slot_of_row[r] = (int32_t)slot;
 }
-__global__ void k_cat_flags(const int32_t* __restrict__ table, int64_t cap, int32_t* __restrict__ flags) {
+__global__ void k_cat_flags(const Entry* __restrict__ table, int64_t cap, int32_t* __restrict__ flags) {
   int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (i < cap) flags[i] = table[i] >= 0;
+  if (i < cap) flags[i] = table[i] != kEmpty;
 }
 // sort records: prefix[i] = first 8 key bytes big-endian, item[i] = slot id;
 // padding up to the power of two sorts last
-__global__ void k_cat_records(ColView in, const int32_t* __restrict__ table, const int32_t* __restrict__ flags,
+__global__ void k_cat_records(ColView in, const Entry* __restrict__ table, const int32_t* __restrict__ flags,
                               const int64_t* __restrict__ pos, int64_t cap, int64_t padded, int64_t uniq,
                               uint64_t* __restrict__ prefix, int32_t* __restrict__ item) {
   int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i < cap && flags[i]) {
-    int64_t row = table[i];
-    int64_t b = in.offsets[row];
-    int n = (int)(in.offsets[row + 1] - b);
+    const Entry e = table[i];
+    int64_t b = entry_off(e);
+    int n = entry_len(e);
     uint64_t k = 0;
     for (int j = 0; j < 8; ++j) k = (k << 8) | (j < n ? in.chars[b + j] : 0);
     prefix[pos[i]] = k;
@@ -132,7 +219,7 @@ __global__ void k_cat_records(ColView in, const int32_t* __restrict__ table, con
     item[i] = -1;
   }
 }
-__global__ void k_bitonic_step(ColView in, const int32_t* __restrict__ table, uint64_t* __restrict__ prefix,
+__global__ void k_bitonic_step(ColView in, const Entry* __restrict__ table, uint64_t* __restrict__ prefix,
                                int32_t* __restrict__ item, int64_t padded, int64_t j, int64_t k) {
   int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= padded) return;
@@ -143,13 +230,56 @@ __global__ void k_bitonic_step(ColView in, const int32_t* __restrict__ table, ui
   int cmp;
   if (ia < 0 || ib < 0) cmp = (ia < 0) - (ib < 0);  // padding is greatest
   else if (pa != pb) cmp = pa < pb ? -1 : 1;
-  else cmp = compare_rows(in, table[ia], table[ib]);
+  else cmp = compare_keys(in.chars, table[ia], table[ib]);
   bool ascending = (i & k) == 0;
   if ((cmp > 0) == ascending && cmp != 0) {
     prefix[i] = pb;
     prefix[l] = pa;
     item[i] = ib;
     item[l] = ia;
+  }
+}
+// The steps of the network whose partners lie inside one chunk of kSortChunk records, run out
+// of LDS in a single launch: every j < kSortChunk of the stages k_first..k_last (the whole
+// network for the first kSortChunk-sized stages, the tail of each later stage).  Directions
+// depend on the global index, so chunks sort independently.
+constexpr int kSortChunk = 2048;
+__global__ void __launch_bounds__(256) k_bitonic_local(ColView in, const Entry* __restrict__ table,
+                                                       uint64_t* __restrict__ prefix, int32_t* __restrict__ item,
+                                                       int64_t padded, int64_t k_first, int64_t k_last) {
+  __shared__ uint64_t s_prefix[kSortChunk];
+  __shared__ int32_t s_item[kSortChunk];
+  const int n = (int)(padded < kSortChunk ? padded : kSortChunk);
+  const int64_t base = (int64_t)blockIdx.x * n;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    s_prefix[i] = prefix[base + i];
+    s_item[i] = item[base + i];
+  }
+  __syncthreads();
+  for (int64_t k = k_first; k <= k_last; k <<= 1) {
+    for (int j = (int)(k / 2 < n / 2 ? k / 2 : n / 2); j > 0; j >>= 1) {
+      for (int t = threadIdx.x; t < n / 2; t += 256) {
+        const int i = ((t / j) * 2 * j) + (t % j), l = i + j;
+        const uint64_t pa = s_prefix[i], pb = s_prefix[l];
+        const int32_t ia = s_item[i], ib = s_item[l];
+        int cmp;
+        if (ia < 0 || ib < 0) cmp = (ia < 0) - (ib < 0);  // padding is greatest
+        else if (pa != pb) cmp = pa < pb ? -1 : 1;
+        else cmp = compare_keys(in.chars, table[ia], table[ib]);
+        const bool ascending = ((base + i) & k) == 0;
+        if ((cmp > 0) == ascending && cmp != 0) {
+          s_prefix[i] = pb;
+          s_prefix[l] = pa;
+          s_item[i] = ib;
+          s_item[l] = ia;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  for (int i = threadIdx.x; i < n; i += 256) {
+    prefix[base + i] = s_prefix[i];
+    item[base + i] = s_item[i];
   }
 }
 __global__ void k_cat_ranks(const int32_t* __restrict__ item, int64_t uniq, int shift,
@@ -164,7 +294,7 @@ __global__ void k_cat_values(const int32_t* __restrict__ slot_of_row, const int3
   int32_t s = slot_of_row[r];
   values[r] = s < 0 ? 0 : rank_of_slot[s];  // a null row maps to key 0 (the null key)
 }
-__global__ void k_key_sizes(ColView in, const int32_t* __restrict__ table, const int32_t* __restrict__ item,
+__global__ void k_key_sizes(ColView in, const Entry* __restrict__ table, const int32_t* __restrict__ item,
                             int64_t nkeys, int shift, int32_t* __restrict__ lens) {
   int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= nkeys) return;
@@ -172,17 +302,16 @@ __global__ void k_key_sizes(ColView in, const int32_t* __restrict__ table, const
     lens[i] = -1;  // the null key
     return;
   }
-  int64_t row = table[item[i - shift]];
-  lens[i] = (int32_t)(in.offsets[row + 1] - in.offsets[row]);
+  lens[i] = entry_len(table[item[i - shift]]);
 }
-__global__ void k_key_copy(ColView in, const int32_t* __restrict__ table, const int32_t* __restrict__ item,
+__global__ void k_key_copy(ColView in, const Entry* __restrict__ table, const int32_t* __restrict__ item,
                            int64_t nkeys, int shift, const int64_t* __restrict__ out_off,
                            uint8_t* __restrict__ out_chars) {
   int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= nkeys || i < shift) return;
-  int64_t row = table[item[i - shift]];
-  const uint8_t* p = in.chars + in.offsets[row];
-  int n = (int)(in.offsets[row + 1] - in.offsets[row]);
+  const Entry e = table[item[i - shift]];
+  const uint8_t* p = in.chars + entry_off(e);
+  int n = entry_len(e);
   uint8_t* o = out_chars + out_off[i];
   for (int k = 0; k < n; ++k) o[k] = p[k];
 }
@@ -225,26 +354,28 @@ cs_category* build(const cs_column* col, hipStream_t s) {
   if (const char* e = getenv("CS_CAT_FIRST_LOG2")) first_log2 = std::max(4, std::min(30, atoi(e)));  // tests: force retries
   int64_t cap = std::min<int64_t>(full, getenv("CS_CAT_FULL_TABLE") ? full : (int64_t)1 << first_log2);
   for (;;) {
-    table = dev_alloc(sizeof(int32_t) * cap, s);
-    CS_HIP(hipMemsetAsync(table->p, 0xFF, sizeof(int32_t) * cap, s));
+    table = dev_alloc(sizeof(Entry) * cap, s);
+    CS_HIP(hipMemsetAsync(table->p, 0xFF, sizeof(Entry) * cap, s));
     CS_HIP(hipMemsetAsync(flags_d->p, 0, 2 * sizeof(int), s));
     {
       ProfScope ps("k_cat_insert", s);
-      hipLaunchKernelGGL(k_cat_insert, dim3(blocks_for(rows)), dim3(kBlock), 0, s, in, ptr<int32_t>(table),
-                         (uint32_t)(cap - 1), ptr<int32_t>(slot_of_row), ptr<int>(flags_d), ptr<int>(flags_d) + 1,
-                         cap == full ? 0x7fffffff : kProbeLimit);
+      const int limit = cap == full ? 0x7fffffff : kProbeLimit;
+      const int dbg = getenv("CS_CAT_DEBUG") ? atoi(getenv("CS_CAT_DEBUG")) : 0;
+      hipLaunchKernelGGL(k_cat_insert, dim3(blocks_for(rows)), dim3(kBlock), 0, s, in, ptr<Entry>(table),
+                         (uint32_t)(cap - 1), ptr<int32_t>(slot_of_row), ptr<int>(flags_d), ptr<int>(flags_d) + 1, limit,
+                         dbg);
     }
-    if (cap == full) break;  // room for all-distinct rows: no limit applied, nothing to retry
     int* h = (int*)pinned_scratch(2 * sizeof(int));
     CS_HIP(hipMemcpyAsync(h, flags_d->p, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
     CS_HIP(hipStreamSynchronize(s));
-    if (!h[1]) break;
+    if (h[1] & 2) fail(CS_ERR_RANGE, "category: a key of 16 MiB or more");
+    if (cap == full || !h[1]) break;  // (room for all-distinct rows: no limit applied, nothing to retry)
     cap = std::min<int64_t>(full, cap * 16);
   }
   Buf has_null_d = flags_d;
   // compact the occupied slots
   Buf flags = dev_alloc(sizeof(int32_t) * cap, s);
-  hipLaunchKernelGGL(k_cat_flags, dim3(blocks_for(cap)), dim3(kBlock), 0, s, ptr<const int32_t>(table), cap,
+  hipLaunchKernelGGL(k_cat_flags, dim3(blocks_for(cap)), dim3(kBlock), 0, s, ptr<const Entry>(table), cap,
                      ptr<int32_t>(flags));
   Buf pos = dev_alloc(sizeof(int64_t) * (cap + 1), s);
   const int64_t uniq = offsets_from_lengths(ptr<int32_t>(flags), cap, ptr<int64_t>(pos), s);
@@ -254,14 +385,24 @@ cs_category* build(const cs_column* col, hipStream_t s) {
   Buf prefix = dev_alloc(sizeof(uint64_t) * padded, s);
   Buf item = dev_alloc(sizeof(int32_t) * padded, s);
   hipLaunchKernelGGL(k_cat_records, dim3(blocks_for(std::max(cap, padded))), dim3(kBlock), 0, s, in,
-                     ptr<const int32_t>(table), ptr<const int32_t>(flags), ptr<const int64_t>(pos), cap, padded,
+                     ptr<const Entry>(table), ptr<const int32_t>(flags), ptr<const int64_t>(pos), cap, padded,
                      uniq, ptr<uint64_t>(prefix), ptr<int32_t>(item));
   {
     ProfScope ps("k_cat_sort", s);
-    for (int64_t k = 2; k <= padded; k <<= 1)
-      for (int64_t j = k >> 1; j > 0; j >>= 1)
+    // stages that fit a chunk run in LDS in one launch; a later stage takes its long-distance
+    // steps one launch each and finishes in LDS
+    const int64_t chunk = std::min<int64_t>(padded, kSortChunk);
+    const unsigned nchunks = (unsigned)(padded / chunk);
+    if (padded >= 2)
+      hipLaunchKernelGGL(k_bitonic_local, dim3(nchunks), dim3(256), 0, s, in, ptr<const Entry>(table),
+                         ptr<uint64_t>(prefix), ptr<int32_t>(item), padded, (int64_t)2, chunk);
+    for (int64_t k = 2 * chunk; k <= padded; k <<= 1) {
+      for (int64_t j = k >> 1; j >= chunk; j >>= 1)
         hipLaunchKernelGGL(k_bitonic_step, dim3(blocks_for(padded)), dim3(kBlock), 0, s, in,
-                           ptr<const int32_t>(table), ptr<uint64_t>(prefix), ptr<int32_t>(item), padded, j, k);
+                           ptr<const Entry>(table), ptr<uint64_t>(prefix), ptr<int32_t>(item), padded, j, k);
+      hipLaunchKernelGGL(k_bitonic_local, dim3(nchunks), dim3(256), 0, s, in, ptr<const Entry>(table),
+                         ptr<uint64_t>(prefix), ptr<int32_t>(item), padded, k, k);
+    }
   }
   Buf rank_of_slot = dev_alloc(sizeof(int32_t) * cap, s);
   if (uniq)
@@ -279,13 +420,13 @@ cs_category* build(const cs_column* col, hipStream_t s) {
   keys->rows = nkeys;
   keys->null_count = shift;
   Buf lens = dev_alloc(sizeof(int32_t) * nkeys, s);
-  hipLaunchKernelGGL(k_key_sizes, dim3(blocks_for(nkeys)), dim3(kBlock), 0, s, in, ptr<const int32_t>(table),
+  hipLaunchKernelGGL(k_key_sizes, dim3(blocks_for(nkeys)), dim3(kBlock), 0, s, in, ptr<const Entry>(table),
                      ptr<const int32_t>(item), nkeys, shift, ptr<int32_t>(lens));
   keys->offsets = dev_alloc(sizeof(int64_t) * (nkeys + 1), s);
   keys->nbytes = offsets_from_lengths(ptr<int32_t>(lens), nkeys, ptr<int64_t>(keys->offsets), s);
   keys->chars = dev_alloc((size_t)keys->nbytes, s);
   if (shift) keys->validity = validity_from_lengths(ptr<int32_t>(lens), nkeys, s);
-  hipLaunchKernelGGL(k_key_copy, dim3(blocks_for(nkeys)), dim3(kBlock), 0, s, in, ptr<const int32_t>(table),
+  hipLaunchKernelGGL(k_key_copy, dim3(blocks_for(nkeys)), dim3(kBlock), 0, s, in, ptr<const Entry>(table),
                      ptr<const int32_t>(item), nkeys, shift, keys->d_offsets(), ptr<uint8_t>(keys->chars));
   CS_HIP(hipStreamSynchronize(s));
   cat->keys = std::move(keys);
