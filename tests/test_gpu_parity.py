@@ -459,6 +459,28 @@ def test_gpu_literal_replace_routing_on_odd_bytes(monkeypatch):
         assert all(a.same_as(b) for a, b in zip(fast, slow)), extra
 
 
+def test_gpu_category_long_keys_at_every_alignment(gpu_engine, oracle_engine):
+    """Keys longer than the 32 bytes the probe keeps in registers, equal up to their last bytes
+    or up to byte 31 / 32 / 33 / 63 / 64, of every length around the 16- and 32-byte piece
+    boundaries, starting at every byte alignment (a filler row of 0..16 bytes in front)."""
+    import random
+
+    rnd = random.Random(8)
+    stem = "".join(rnd.choice("abcdefgh") for _ in range(300))
+    keys = []
+    for n in list(range(0, 70)) + [95, 96, 97, 127, 128, 129, 200, 300]:
+        keys.append(stem[:n])
+        for cut in (0, 15, 16, 17, 31, 32, 33, 63, 64, n - 1):
+            if 0 <= cut < n:
+                keys.append(stem[:cut] + "Z" + stem[cut + 1:n])
+    keys += ["é" * 17, "é" * 16 + "e", "", None]
+    s = []
+    for _ in range(6000):
+        s.append("f" * rnd.randint(0, 16))  # shifts the alignment of the next row
+        s.append(rnd.choice(keys))
+    assert gpu_engine.category(s) == oracle_engine.category(s)
+
+
 def test_gpu_category_table_growth(orc, monkeypatch):
     """The category build starts with a small hash table and retries with a larger one when a
     probe run gets long: force the retries with a tiny first table."""
