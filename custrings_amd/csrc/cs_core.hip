@@ -421,6 +421,8 @@ __global__ void __launch_bounds__(256) k_bytes_plain(const uint8_t* __restrict__
 bool bytes_plain(const cs_column* c, hipStream_t s) {
   if (c->plain_bytes >= 0) return c->plain_bytes != 0;
   if (c->nbytes == 0) return (c->plain_bytes = 1) != 0;
+  // (a wrapped caller buffer at an odd address: the check reads aligned 16-byte pieces -- decline)
+  if ((uintptr_t)c->d_chars() & 15) return (c->plain_bytes = 0) != 0;
   Buf acc = dev_alloc(8, s);
   CS_HIP(hipMemsetAsync(acc->p, 0, 8, s));
   const int64_t pieces = (c->nbytes + 15) / 16;

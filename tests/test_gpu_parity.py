@@ -481,6 +481,46 @@ def test_gpu_category_long_keys_at_every_alignment(gpu_engine, oracle_engine):
     assert gpu_engine.category(s) == oracle_engine.category(s)
 
 
+@pytest.mark.parametrize("shift", [0, 1, 7, 13])
+def test_gpu_zero_copy_column_at_odd_address(orc, shift):
+    """A borrowed (zero-copy) column whose chars start at an arbitrary byte address inside the
+    caller's allocation: every tile kernel derives its 16-byte pieces from the absolute address,
+    so the results must equal those of the copied column."""
+    import torch
+    from custrings_amd import nvstrings, nvtext, nvcategory
+
+    rows = 50_000
+    o = orc.synth(3, 0, rows)
+    dev = torch.device("cuda:0")
+    backing = torch.zeros(len(o.chars) + 64, dtype=torch.uint8, device=dev)
+    backing[shift:shift + len(o.chars)] = torch.from_numpy(o.chars).to(dev)
+    offs = torch.from_numpy(o.offsets.astype(np.int64)).to(dev)
+    chars = backing[shift:shift + len(o.chars)]
+    assert chars.data_ptr() % 16 == (backing.data_ptr() + shift) % 16
+    g = nvstrings.from_offsets64(chars, offs, rows, None, bdevmem=True, copy=False)
+    ref = gpuutil.from_col(o)
+
+    def same(a, b, what):
+        assert gpuutil.to_col(a).same_as(gpuutil.to_col(b)), what
+
+    same(g.replace(IPV4, "<IP>"), ref.replace(IPV4, "<IP>"), "replace_re")
+    same(g.replace(IPV4, "<redacted-ip>"), ref.replace(IPV4, "<redacted-ip>"), "growing replace_re")
+    same(g.replace("e", "EE", regex=False), ref.replace("e", "EE", regex=False), "literal replace")
+    for a, b in zip(g.split(" "), ref.split(" ")):
+        same(a, b, "split")
+    same(g.upper(), ref.upper(), "upper")
+    same(g.strip("GETPOS "), ref.strip("GETPOS "), "strip")
+    same(nvtext.tokenize(g), nvtext.tokenize(ref), "tokenize")
+    same(nvtext.ngrams(nvtext.tokenize(g), 2, "_"), nvtext.ngrams(nvtext.tokenize(ref), 2, "_"), "ngrams")
+    assert g.contains(IPV4) == ref.contains(IPV4)
+    assert g.find("200") == ref.find("200")
+    ca, cb = nvcategory.from_strings(g), nvcategory.from_strings(ref)
+    same(ca.keys(), cb.keys(), "category keys")
+    va, vb = np.zeros(rows, dtype=np.int32), np.zeros(rows, dtype=np.int32)
+    ca.values(va), cb.values(vb)
+    assert np.array_equal(va, vb)
+
+
 def test_gpu_category_table_growth(orc, monkeypatch):
     """The category build starts with a small hash table and retries with a larger one when a
     probe run gets long: force the retries with a tiny first table."""
