@@ -84,6 +84,7 @@ struct cs_column {
   int64_t nbytes = 0;
   mutable int64_t null_count = -1;  // -1 = not counted yet
   mutable int64_t max_span64 = -1;  // max bytes spanned by 64 consecutive rows (tile kernels); -1 = unknown
+  mutable int drops = -1;           // 1: some row is null or empty (rows create_ngrams drops), 0: none; -1 = unknown
   mutable int plain_bytes = -1;     // 1: no NUL byte and no lead byte announcing over an ASCII byte; -1 = unknown
   cs::Buf chars, offsets, validity;  // validity may be null (all valid)
   const uint8_t* d_chars() const { return cs::ptr<const uint8_t>(chars); }

@@ -216,15 +216,16 @@ namespace cs {
 bool ngrams_fast(const cs_column* tokens, int n, const unsigned char* sep, int sepn, hipStream_t s, cs_column** out) {
   const int64_t rows = tokens->rows;
   if (n < 2 || n > 8 || sepn > 8 || rows <= n || getenv("CS_NGRAM_ROWWISE")) return false;
-  {
+  if (tokens->drops < 0) {  // remembered on the immutable column (the tokenizer's output is born with the answer)
     Buf drop = dev_alloc(sizeof(unsigned), s);
     CS_HIP(hipMemsetAsync(drop->p, 0, sizeof(unsigned), s));
     hipLaunchKernelGGL(k_ngram_check, dim3(blocks_for(rows)), dim3(kBlock), 0, s, view_of(tokens), ptr<unsigned>(drop));
     unsigned* h = (unsigned*)pinned_scratch(sizeof(unsigned));
     CS_HIP(hipMemcpyAsync(h, drop->p, sizeof(unsigned), hipMemcpyDeviceToHost, s));
     CS_HIP(hipStreamSynchronize(s));
-    if (*h) return false;  // some rows are dropped: the closed-form offsets do not apply
+    tokens->drops = *h ? 1 : 0;
   }
+  if (tokens->drops) return false;  // some rows are dropped: the closed-form offsets do not apply
   const int64_t ng = rows - n + 1;
   const long long step = (long long)(n - 1) * sepn;
   // n-grams per lane per tile: the largest M whose widest tile fits the staging buffers

@@ -277,6 +277,7 @@ bool tokenize_fast(const cs_column* col, const unsigned char* delims, int ndel, 
   auto c = std::make_unique<cs_column>();
   c->rows = ntok;
   c->null_count = 0;
+  c->drops = 0;  // a token is never empty and never null
   c->nbytes = nbytes;
   c->offsets = dev_alloc(sizeof(int64_t) * (ntok + 1), s);
   c->chars = dev_alloc((size_t)nbytes, s);
