@@ -1,0 +1,227 @@
+#!/usr/bin/env python3
+"""Soak (GPU box): every tile kernel against the row-wise kernels on randomly shaped columns of
+random bytes / text, many seeds.  usage: python tools/soak_gpu.py [seconds] [first_seed]
+Prints one line per failing (seed, op); exit status 1 if any."""
+import ctypes as C
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import cpulibs  # noqa: E402
+import gpuutil  # noqa: E402
+from custrings_amd import nvtext, nvcategory  # noqa: E402
+
+TOGGLES = ("CS_REGEX_TWO_PASS", "CS_REGEX_ROWWISE", "CS_SPLIT_GENERIC", "CS_TOKENIZE_ROWWISE", "CS_STRIP_ROWWISE",
+           "CS_FIND_ROWWISE", "CS_REPLACE_ROWWISE", "CS_CASE_ROWWISE", "CS_NGRAM_ROWWISE")
+PATS = [(r"\d+\.\d+\.\d+\.\d+", "<IP>"), (r"\d", "#"), (r"[a-c]+", "xyz__"), (r"\s+", " "), (r"\w+", "<w>"), (r"b|ab", ""),
+        (r"\bx", "YY"), (r"[0-9]+", "<number-here>"), (r"a", "aa"), (r"(a|b)c", "-")]
+
+
+def make_column(seed):
+    rng = np.random.default_rng(seed)
+    kind = seed % 6
+    rows = int(rng.integers(1, 40_000))
+    if kind == 0:
+        lens = rng.integers(0, 95, rows)
+    elif kind == 1:
+        lens = rng.integers(0, 20, rows)
+    elif kind == 2:
+        lens = np.full(rows, int(rng.integers(1, 90)))
+    elif kind == 3:
+        lens = rng.integers(0, 400, rows)
+    elif kind == 4:
+        lens = (rng.pareto(1.5, rows) * 20).astype(np.int64) % 7000
+    else:
+        lens = rng.integers(0, 64, rows) * (rng.random(rows) < 0.5)
+    offs = np.zeros(rows + 1, dtype=np.int64)
+    np.cumsum(lens, out=offs[1:])
+    flavour = (seed // 6) % 4
+    if flavour == 0:  # arbitrary bytes
+        pool = np.array(list(b"ab1.2 3.4.5.6 x9_\t\nABc") + [0, 0xC3, 0xA9, 0xE2, 0x82, 0xAC, 0xFF, 0x80, 0x1F, 0xF0, 0x9F], dtype=np.uint8)
+        chars = pool[rng.integers(0, len(pool), int(offs[-1]))]
+    elif flavour == 1:  # ASCII text
+        pool = np.array(list(b"abcxyzABC 0123456789..  __\t"), dtype=np.uint8)
+        chars = pool[rng.integers(0, len(pool), int(offs[-1]))]
+    elif flavour == 3:  # valid UTF-8 rows (the reference's contract): these are also checked against the oracle
+        toks = [bytes([c]) for c in b"abcab 12.3 XY  .7"] + ["é".encode(), "É".encode(), "€".encode(), "😀".encode(), "İ".encode(), "ß".encode()]
+        tl = np.array([len(t) for t in toks])
+        pick = rng.integers(0, len(toks), int(offs[-1]) + 1)
+        # row r takes lens[r] tokens
+        starts = offs.copy()
+        data = b"".join(toks[i] for i in pick[:int(offs[-1])])
+        bl = np.concatenate([[0], np.cumsum(tl[pick[:int(offs[-1])]])])
+        offs = bl[starts].astype(np.int64)
+        chars = np.frombuffer(data, dtype=np.uint8).copy()
+    else:  # valid UTF-8 text cut at arbitrary places
+        toks = [bytes([c]) for c in b"abcab 12.3 XY"] + ["é".encode(), "É".encode(), "€".encode(), "😀".encode(), "İ".encode(), "ß".encode()]
+        data = b"".join(toks[i] for i in rng.integers(0, len(toks), int(offs[-1]) + 4))
+        chars = np.frombuffer(data[:int(offs[-1])], dtype=np.uint8).copy()
+    valid = np.packbits(rng.random(rows) > 0.03, bitorder="little") if seed % 4 else None
+    return cpulibs.Col(chars, offs, valid), flavour
+
+
+def snapshot(g, rows, rng_seed):
+    L = gpuutil.lib()
+    rng = np.random.default_rng(rng_seed)
+    out = {}
+    for i in rng.choice(len(PATS), 4, replace=False):
+        pat, repl = PATS[i]
+        n = int(rng.choice([-1, -1, 1, 3]))
+        out["replace_re %r %r %d" % (pat, repl, n)] = gpuutil.to_col(g.replace(pat, repl, n))
+        re = gpuutil.compile_re(pat)
+        out["contains_re %r" % pat] = gpuutil.bools(g, "cs_contains_re", re)
+        cnt = np.zeros(max(rows, 1), dtype=np.int32)
+        found = C.c_int64()
+        L.check(L.lib.cs_count_re(g.m_cptr, re, cnt.ctypes.data, 0, None, C.byref(found)))
+        out["count_re %r" % pat] = (cnt, found.value)
+    for pat, repl in (("a", "b"), ("ab", "x"), (" ", "  "), ("1", "one")):
+        out["replace %r %r" % (pat, repl)] = gpuutil.to_col(g.replace(pat, repl, regex=False))
+    for d, n in ((" ", -1), (".", 2), (None, -1), (None, 2), ("ab", -1)):
+        out["split %r %d" % (d, n)] = [gpuutil.to_col(c) for c in g.split(d, n)]
+    tok = nvtext.tokenize(g)
+    out["tokenize"] = gpuutil.to_col(tok)
+    out["tokenize set"] = gpuutil.to_col(nvtext.tokenize(g, " ."))
+    for N, sep in ((2, "_"), (3, ""), (2, "<sep>")):
+        out["ngrams %d %r" % (N, sep)] = gpuutil.to_col(nvtext.ngrams(tok, N, sep))
+    out["strip"] = gpuutil.to_col(g.strip())
+    out["strip set"] = gpuutil.to_col(g.strip("ab é"))
+    out["lower"] = gpuutil.to_col(g.lower())
+    out["upper"] = gpuutil.to_col(g.upper())
+    for sub in ("3.4", "é", "ab"):
+        f = np.zeros(max(rows, 1), dtype=np.int32)
+        found = C.c_int64()
+        L.check(L.lib.cs_find(g.m_cptr, sub.encode(), 0, -1, f.ctypes.data, 0, None, C.byref(found)))
+        out["find %r" % sub] = (f, found.value)
+    return out
+
+
+try:
+    import engines  # noqa: E402
+    ORC = cpulibs.Oracle()
+except Exception as e:  # the oracle library is test infrastructure: absent -> fast-vs-rowwise only
+    print("oracle leg off:", e)
+    ORC = None
+
+
+def oracle_leg(col, fast, seed):
+    """The fast paths' results against the CPU oracle (valid UTF-8 columns only)."""
+    bad = 0
+    want = {}
+    for k in fast:
+        op, _, rest = k.partition(" ")
+        try:
+            if op == "replace_re":
+                pat, repl, n = _parse3(rest)
+                want[k] = ORC.replace_re(col, np.ascontiguousarray(engines.reference_blob(pat)), repl, n)
+            elif op == "replace":
+                pat, repl = _split_reprs(rest)
+                want[k] = ORC.replace(col, pat, repl)
+            elif op == "split":
+                d, n = _parse2(rest)
+                want[k] = ORC.split(col, d, n)
+            elif k == "tokenize":
+                want[k] = ORC.tokenize(col)
+            elif k == "tokenize set":
+                want[k] = ORC.tokenize(col, " .")
+            elif k == "strip":
+                want[k] = ORC.strip(col)
+            elif k == "strip set":
+                want[k] = ORC.strip(col, "ab é")
+            elif k == "lower":
+                want[k] = ORC.lower(col)
+            elif k == "upper":
+                want[k] = ORC.upper(col)
+        except Exception as e:
+            print("oracle error seed=%d op=%s: %s" % (seed, k, e), flush=True)
+            bad += 1
+    for k, w in want.items():
+        if not same(fast[k], w):
+            bad += 1
+            print("ORACLE MISMATCH seed=%d rows=%d op=%s" % (seed, col.rows, k), flush=True)
+    return bad
+
+
+def _parse2(rest):
+    import ast
+    i = rest.rindex(" ")
+    return ast.literal_eval(rest[:i]), ast.literal_eval(rest[i + 1:])
+
+
+def _parse3(rest):
+    import ast
+    i = rest.rindex(" ")
+    n = ast.literal_eval(rest[i + 1:])
+    a, b = _split_reprs(rest[:i])
+    return a, b, n
+
+
+def _split_reprs(s):
+    """two python reprs of str separated by one space"""
+    import ast
+    for i in range(1, len(s)):
+        if s[i] == " ":
+            try:
+                return ast.literal_eval(s[:i]), ast.literal_eval(s[i + 1:])
+            except Exception:
+                continue
+    raise ValueError(s)
+
+
+def same(a, b):
+    if isinstance(a, list):
+        return len(a) == len(b) and all(x.same_as(y) for x, y in zip(a, b))
+    if isinstance(a, tuple):
+        return np.array_equal(a[0], b[0]) and a[1] == b[1]
+    return a.same_as(b)
+
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+    t0 = time.time()
+    bad = done = 0
+    while time.time() - t0 < budget:
+        col, flavour = make_column(seed)
+        g = gpuutil.from_col(col)
+        for v in TOGGLES:
+            os.environ.pop(v, None)
+        fast = snapshot(g, col.rows, seed)
+        cat_f = nvcategory.from_strings(g)
+        for v in TOGGLES:
+            os.environ[v] = "1"
+        slow = snapshot(g, col.rows, seed)
+        for k in fast:
+            if not same(fast[k], slow[k]):
+                bad += 1
+                print("MISMATCH seed=%d rows=%d op=%s" % (seed, col.rows, k), flush=True)
+        if flavour in (1, 3) and ORC is not None:
+            bad += oracle_leg(col, fast, seed)
+        # category against numpy's view of the same bytes
+        keys = gpuutil.to_col(cat_f.keys())
+        vals = np.zeros(max(col.rows, 1), dtype=np.int32)
+        cat_f.values(vals)
+        rows_b = col.to_bytes_list()
+        uniq = sorted({x for x in rows_b if x is not None})
+        want_keys = ([None] if any(x is None for x in rows_b) else []) + uniq
+        got_keys = keys.to_bytes_list()
+        if got_keys != want_keys:
+            bad += 1
+            print("MISMATCH seed=%d category keys" % seed, flush=True)
+        else:
+            idx = {k: i for i, k in enumerate(want_keys)}
+            want_vals = np.array([idx[x] for x in rows_b], dtype=np.int32)
+            if not np.array_equal(vals[:col.rows], want_vals):
+                bad += 1
+                print("MISMATCH seed=%d category values" % seed, flush=True)
+        done += 1
+        seed += 1
+    print("soak: %d columns, %d mismatches, %.0f s" % (done, bad, time.time() - t0))
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
