@@ -95,12 +95,19 @@ __global__ void __launch_bounds__(256) k_strip_tile(StripTileArgs a) {
 }
 
 
-// find (MODE 0: char position or -1, -2 for null rows) / contains (MODE 1) over row tiles:
-// same staging; every row lane searches its row in LDS (find.cu:75-120,237-272).
+// find (MODE 0: char position or -1, -2 for null rows) / contains (MODE 1) over row tiles
+// (find.cu:75-120,237-272): same staging.  Whole-row searches are byte-parallel: while the
+// tile's 16-byte pieces are still in the prefetch registers their lanes compare every byte with
+// the needle's first byte (SWAR) and leave one candidate bit per byte in LDS -- for find also
+// one "continuation byte" bit per byte -- so a row lane only takes its row's bits (rows up to
+// 96 bytes), verifies the few candidates against the rest of the needle, and turns the byte
+// position into a character position with a population count.  Tiles with longer rows and
+// searches over a character window walk the row in LDS instead.
 struct FindTileArgs {
   ColView in;
   uint8_t needle[64];
   int nb, start, end, rows_per_tile, cap;
+  int whole;  // the search covers the whole row (find's default window; contains always)
   long long ntiles;
   int32_t* out32;
   uint8_t* out8;
@@ -113,7 +120,10 @@ __global__ void __launch_bounds__(256) k_find_tile(FindTileArgs a) {
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
   if (threadIdx.x < 64) s_needle[threadIdx.x] = a.needle[threadIdx.x];
   __syncthreads();
-  uint8_t* lds_in = reinterpret_cast<uint8_t*>(smem) + (size_t)wv * a.cap;
+  constexpr int kBitmapBytes = cstile::kPfBytes / 8 + 32;
+  uint8_t* lds_in = reinterpret_cast<uint8_t*>(smem) + (size_t)wv * (a.cap + 2 * kBitmapBytes);
+  uint32_t* bm_first = reinterpret_cast<uint32_t*>(lds_in + a.cap);                 // byte == needle[0]
+  uint32_t* bm_cont = reinterpret_cast<uint32_t*>(lds_in + a.cap + kBitmapBytes);   // byte is 10xxxxxx
   const ColView& in = a.in;
   const int R = a.rows_per_tile;
   const long long waves = (long long)gridDim.x * 4;
@@ -136,6 +146,10 @@ __global__ void __launch_bounds__(256) k_find_tile(FindTileArgs a) {
 #pragma unroll
   for (int j = 0; j < cstile::kPfChunks; ++j) pf.v[j] = make_uint4(0, 0, 0, 0);
   cstile::issue_chars(in.chars, cstile::rl64(cur.o0, 0), cstile::rl64(cur.o1, 63), lane, pf);
+  const uint32_t first4 = (uint32_t)a.needle[0] * 0x01010101u;
+  // bits 0..3: which bytes of w are zero (exact, no borrow between bytes)
+  auto zero4 = [](uint32_t w) { return cstile::gather_bit7(~(((w & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | w) & 0x80808080u); };
+  auto cont4 = [](uint32_t w) { return cstile::gather_bit7(w & ~(w << 1) & 0x80808080u); };
   int hits = 0;
   for (;;) {
     const long long r0 = tile * R;
@@ -146,7 +160,26 @@ __global__ void __launch_bounds__(256) k_find_tile(FindTileArgs a) {
     const int rbeg = (int)(cur.o0 - g0);
     const int n = live ? (int)(cur.o1 - cur.o0) : 0;
     const int lead = (int)((uintptr_t)(in.chars + g0) & 15);
-    cstile::stage_chars(lds_in, (int)(g1 - g0) + lead, lane, pf);
+    const int want = (int)(g1 - g0) + lead;
+    cstile::stage_chars(lds_in, want, lane, pf);
+    const bool by_bits = a.whole && a.nb > 0 && !__any(n > 96);
+    if (by_bits) {
+#pragma unroll
+      for (int j = 0; j < cstile::kPfChunks; ++j)
+        if (j * 1024 < want) {  // wave-uniform
+          const int i = j * 1024 + lane * 16;
+          const uint4 q = pf.v[j];
+          if (i < want)
+            cstile::put_bits16(bm_first, i, zero4(q.x ^ first4) | (zero4(q.y ^ first4) << 4) | (zero4(q.z ^ first4) << 8) |
+                                                (zero4(q.w ^ first4) << 12));
+          if (MODE == 0) {
+            const bool high = i < want && ((q.x | q.y | q.z | q.w) & 0x80808080u) != 0;
+            uint32_t cb = 0;
+            if (__any(high)) cb = cont4(q.x) | (cont4(q.y) << 4) | (cont4(q.z) << 8) | (cont4(q.w) << 12);
+            if (i < want) cstile::put_bits16(bm_cont, i, cb);
+          }
+        }
+    }
     const bool has_next = tile + 1 < tile_end;
     if (has_next) {
       cur = nxt;
@@ -155,16 +188,45 @@ __global__ void __launch_bounds__(256) k_find_tile(FindTileArgs a) {
     }
     cstile::wave_lds_fence();
     const uint8_t* p = lds_in + lead + rbeg;
+    int at = -1;  // byte offset of the first occurrence (by_bits)
+    if (by_bits && live && n >= a.nb) {
+      uint32_t m0, m1, m2;  // candidate starts that leave room for the needle
+      cstile::row_bits96(bm_first, lead + rbeg, n - a.nb + 1, m0, m1, m2);
+      while ((m0 | m1 | m2) != 0) {
+        const int pos = m0 ? __builtin_ctz(m0) : (m1 ? 32 + __builtin_ctz(m1) : 64 + __builtin_ctz(m2));
+        if (m0) m0 &= m0 - 1;
+        else if (m1) m1 &= m1 - 1;
+        else m2 &= m2 - 1;
+        int j = 1;
+        while (j < a.nb && p[pos + j] == s_needle[j]) ++j;
+        if (j >= a.nb) {
+          at = pos;
+          break;
+        }
+      }
+    }
     if (MODE == 0) {
       int v = -2;  // null row (find.cu:108)
-      if (live) v = row_find(p, n, s_needle, a.nb, a.start, a.end);
+      if (live) {
+        if (by_bits) {
+          v = at;
+          if (at > 0) {  // character position = bytes before the hit that are not continuation bytes
+            uint32_t c0, c1, c2;
+            cstile::row_bits96(bm_cont, lead + rbeg, at, c0, c1, c2);
+            v = at - (__builtin_popcount(c0) + __builtin_popcount(c1) + __builtin_popcount(c2));
+          }
+        } else {
+          v = row_find(p, n, s_needle, a.nb, a.start, a.end);
+        }
+      }
       if (in_tile) {
         a.out32[r0 + lane] = v;
         hits += v != -1;  // null rows are counted too (find.cu:112)
       }
     } else {
       int hit = 0;
-      if (live && a.nb > 0) hit = find_bytes(p, 0, n, s_needle, a.nb) >= 0;
+      if (by_bits) hit = at >= 0;
+      else if (live && a.nb > 0) hit = find_bytes(p, 0, n, s_needle, a.nb) >= 0;
       if (in_tile) a.out8[r0 + lane] = (uint8_t)hit;
       hits += hit;
     }
@@ -204,7 +266,8 @@ bool find_tiles(const cs_column* in, const unsigned char* needle, int nb, int mo
   a.out32 = out32;
   a.out8 = out8;
   a.found = found;
-  const size_t lds = (size_t)a.cap * 4;
+  a.whole = mode != 0 || (start <= 0 && end - (start < 0 ? 0 : start) < 0);
+  const size_t lds = ((size_t)a.cap + 2 * (cstile::kPfBytes / 8 + 32)) * 4;
   if (lds > 150 * 1024) return false;
   auto launch = [&](auto kern) {
     if (lds > 48 * 1024)
