@@ -477,6 +477,7 @@ __global__ void __launch_bounds__(256, CS_STREAM_WAVES) k_tdfa_replace_stream(St
   int p_total = 0, p_lo = 0, p_len = 0;
 #if defined(CS_PHASE_PROF)
   unsigned long long phase_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long lb_acc[3] = {0, 0, 0};
   unsigned long long phase_t = __builtin_readcyclecounter();
 #endif
   auto finish_pending = [&](cstile::u64 first) {
@@ -487,7 +488,11 @@ __global__ void __launch_bounds__(256, CS_STREAM_WAVES) k_tdfa_replace_stream(St
       gb = p_tile * 4096 + (csdev::wave_reduce_sum(part) & 0) + (long long)(first & 0);
       if (lane == 0) cstile::status_store(a.status + p_tile, cstile::kFlagInc | 1);
     } else {
+#if defined(CS_PHASE_PROF)
+      gb = (a.debug & 8) ? p_tile * 4096 : cstile::lookback_end(a.status, p_tile, p_total, first, lane, lb_acc);
+#else
       gb = (a.debug & 8) ? p_tile * 4096 : cstile::lookback_end(a.status, p_tile, p_total, first, lane);
+#endif
     }
     if (gb < 0) {
       if (lane == 0) atomicOr(a.error, 1u);
@@ -690,6 +695,8 @@ __global__ void __launch_bounds__(256, CS_STREAM_WAVES) k_tdfa_replace_stream(St
   CS_PHASE_MARK(5);
   if (lane == 0)
     for (int k = 0; k < 8; ++k) atomicAdd(reinterpret_cast<unsigned long long*>(a.error) + 1 + k, phase_acc[k]);
+  if (lane == 0)
+    for (int k = 0; k < 3; ++k) atomicAdd(&cstile::g_lb_stats[k], lb_acc[k]);
 #endif
 }
 
@@ -1105,6 +1112,10 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
         {
           unsigned long long ph[8];
           CS_HIP(hipMemcpy(ph, reinterpret_cast<unsigned long long*>(sa.error) + 1, sizeof(ph), hipMemcpyDeviceToHost));
+          unsigned long long lb[4] = {0, 0, 0, 0};
+          CS_HIP(hipMemcpyFromSymbol(lb, HIP_SYMBOL(cstile::g_lb_stats), sizeof(lb)));
+          fprintf(stderr, "look-back (cumulative): %llu calls, %.2f windows per call, %.2f re-polls per call\n", lb[0], (double)lb[1] / (double)(lb[0] ? lb[0] : 1),
+                  (double)lb[2] / (double)(lb[0] ? lb[0] : 1));
           const double waves = (double)grid * 4;
           fprintf(stderr, "phase cycles/wave-iteration: stage %.0f scan %.0f wscan+publish %.0f finish_prev(offsets+flush) %.0f assemble %.0f tail %.0f lookback %.0f (iters/wave %.1f)\n",
                   ph[0] / waves / (nsub1 / waves), ph[1] / waves / (nsub1 / waves), ph[2] / waves / (nsub1 / waves),

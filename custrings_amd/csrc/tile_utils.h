@@ -279,12 +279,19 @@ __device__ __forceinline__ u64 lookback_begin(u64* status, long long tile, long 
   lookback_publish(status, tile, aggregate, lane);
   return lookback_poll(status, tile, lane);
 }
-__device__ __forceinline__ long long lookback_end(u64* status, long long tile, long long aggregate, u64 first, int lane) {
+#if defined(CS_PHASE_PROF)
+static __device__ unsigned long long g_lb_stats[4];  // calls, windows walked, re-polls of a window, -
+#endif
+__device__ __forceinline__ long long lookback_end(u64* status, long long tile, long long aggregate, u64 first, int lane,
+                                                  unsigned long long* acc = nullptr) {
   if (tile == 0) return 0;
   long long excl = 0;
   long long t = tile - 1;
   int spins = 0;
   u64 v = first;
+#if defined(CS_PHASE_PROF)
+  int windows = 1;
+#endif
   for (;;) {
     const unsigned flag = (unsigned)(v >> 62);
     const u64 not_ready = __ballot(flag == 0);
@@ -307,10 +314,20 @@ __device__ __forceinline__ long long lookback_end(u64* status, long long tile, l
       break;
     }
     t -= 64;
+#if defined(CS_PHASE_PROF)
+    ++windows;
+#endif
     const long long idx = t - lane;
     v = idx >= 0 ? status_load(status + idx) : kFlagInc;
   }
   if (lane == 0) status_store(status + tile, kFlagInc | ((u64)(excl + aggregate) & kValMask));
+#if defined(CS_PHASE_PROF)
+  if (acc) {
+    acc[0] += 1;
+    acc[1] += (unsigned long long)windows;
+    acc[2] += (unsigned long long)spins;
+  }
+#endif
   return excl;
 }
 
