@@ -288,6 +288,7 @@ __device__ __forceinline__ long long lookback_end(u64* status, long long tile, l
   long long excl = 0;
   long long t = tile - 1;
   int spins = 0;
+  unsigned part = 0;
   u64 v = first;
 #if defined(CS_PHASE_PROF)
   int windows = 1;
@@ -305,12 +306,13 @@ __device__ __forceinline__ long long lookback_end(u64* status, long long tile, l
       v = idx >= 0 ? status_load(status + idx) : kFlagInc;
       continue;
     }
-    // aggregates of 64-row sub-tiles fit 32 bits: sum them with DPP adds; the one inclusive
-    // prefix that ends the window is 64 bits wide and is read from its lane directly
-    const int part = (lane < first_inc) ? (int)(unsigned)(v & 0xffffffffull) : 0;
-    excl += (unsigned)csdev::wave_reduce_sum(part);
+    // aggregates of 64-row sub-tiles fit 32 bits: every lane keeps the sum of its column of the
+    // windows walked and ONE reduction follows the walk (the kernel is bound by its instruction
+    // count, and the walk covers four windows on average); the one inclusive prefix that ends
+    // the walk is 64 bits wide and is read from its lane directly
+    part += (lane < first_inc) ? (unsigned)(v & 0xffffffffull) : 0u;
     if (first_inc < 64) {
-      excl += rl64((long long)(v & kValMask), first_inc);
+      excl = rl64((long long)(v & kValMask), first_inc);
       break;
     }
     t -= 64;
@@ -320,6 +322,7 @@ __device__ __forceinline__ long long lookback_end(u64* status, long long tile, l
     const long long idx = t - lane;
     v = idx >= 0 ? status_load(status + idx) : kFlagInc;
   }
+  excl += (unsigned)csdev::wave_reduce_sum((int)part);
   if (lane == 0) status_store(status + tile, kFlagInc | ((u64)(excl + aggregate) & kValMask));
 #if defined(CS_PHASE_PROF)
   if (acc) {
