@@ -475,18 +475,6 @@ __global__ void k_gather_rows(cs::ColView in, const int64_t* __restrict__ out_of
   int n = (int)(in.offsets[r + 1] - in.offsets[r]);
   for (int i = 0; i < n; ++i) dst[i] = src[i];
 }
-__global__ void k_byte_count(cs::ColView in, int32_t* __restrict__ out,
-                             unsigned long long* __restrict__ total) {
-  int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  int v = 0;
-  if (r < in.rows) {
-    bool ok = row_is_valid(in.validity, r);
-    v = ok ? (int)(in.offsets[r + 1] - in.offsets[r]) : 0;
-    out[r] = ok ? v : -1;
-  }
-  long long t = block_reduce_sum(v);
-  if (threadIdx.x == 0 && t) atomicAdd(total, (unsigned long long)t);
-}
 __global__ void k_null_bitarray(cs::ColView in, int empty_is_null, uint8_t* __restrict__ bits,
                                 unsigned long long* __restrict__ nulls) {
   // one thread per output byte (NVStrings.cu:512-527)
@@ -540,6 +528,13 @@ static void copy_out(void* dst, const void* src, size_t bytes, int on_device, hi
   CS_HIP(hipMemcpyAsync(dst, src, bytes, on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s));
 }
 
+// sets *flag when a null row has a non-empty extent
+__global__ void k_null_rows_hold_bytes(cs::ColView in, unsigned* __restrict__ flag) {
+  const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  bool bad = false;
+  if (r < in.rows) bad = !row_is_valid(in.validity, r) && in.offsets[r + 1] != in.offsets[r];
+  if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
+}
 // Turns an ingested (chars, offsets, validity) triple into a canonical column:
 // offsets[0] == 0, null rows have zero extent, chars packed.
 static cs_column* canonicalise(Buf chars, Buf offs, Buf validity, int64_t rows, int64_t span_bytes,
@@ -565,6 +560,25 @@ static cs_column* canonicalise(Buf chars, Buf offs, Buf validity, int64_t rows, 
     }
   }
   ColView in{ptr<const uint8_t>(chars), ptr<const int64_t>(offs), ptr<const uint8_t>(validity), rows};
+  if (has_validity) {
+    // The usual Arrow column is canonical already (offsets from 0, nothing stored under a null):
+    // one pass over offsets + bitmask decides, and the ingested buffers are then used as they are.
+    Buf flag = dev_alloc(sizeof(unsigned), s);
+    CS_HIP(hipMemsetAsync(flag->p, 0, sizeof(unsigned), s));
+    hipLaunchKernelGGL(k_null_rows_hold_bytes, dim3(blocks_for(rows)), dim3(kBlock), 0, s, in, ptr<unsigned>(flag));
+    int64_t* host = (int64_t*)pinned_scratch(24);
+    CS_HIP(hipMemcpyAsync(host, offs->p, 8, hipMemcpyDeviceToHost, s));
+    CS_HIP(hipMemcpyAsync(host + 1, ptr<int64_t>(offs) + rows, 8, hipMemcpyDeviceToHost, s));
+    CS_HIP(hipMemcpyAsync(host + 2, flag->p, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+    CS_HIP(hipStreamSynchronize(s));
+    if (host[0] == 0 && (unsigned)host[2] == 0) {
+      c->chars = chars;
+      c->offsets = offs;
+      c->validity = validity;
+      c->nbytes = host[1];
+      return guard_c.release();
+    }
+  }
   Buf lens = dev_alloc(sizeof(int32_t) * rows, s);
   hipLaunchKernelGGL(k_lengths_from_offsets, dim3(blocks_for(rows)), dim3(kBlock), 0, s, in,
                      ptr<int32_t>(lens));
@@ -920,15 +934,13 @@ int cs_column_byte_count(const cs_column* col, int32_t* lengths, int on_device, 
       tmp = dev_alloc(sizeof(int32_t) * col->rows, s);
       d_out = ptr<int32_t>(tmp);
     }
-    Buf tot = dev_alloc(8, s);
-    CS_HIP(hipMemsetAsync(tot->p, 0, 8, s));
-    hipLaunchKernelGGL(k_byte_count, dim3(blocks_for(col->rows)), dim3(kBlock), 0, s, view_of(col), d_out,
-                       ptr<unsigned long long>(tot));
-    if (lengths && !on_device) copy_out(lengths, d_out, sizeof(int32_t) * col->rows, 0, s);
-    int64_t* host = (int64_t*)pinned_scratch(8);
-    CS_HIP(hipMemcpyAsync(host, tot->p, 8, hipMemcpyDeviceToHost, s));
-    CS_HIP(hipStreamSynchronize(s));
-    if (total) *total = host[0];
+    // (null rows have zero extent, so the total is the column's byte count: no reduction)
+    if (lengths) {
+      hipLaunchKernelGGL(k_lengths_from_offsets, dim3(blocks_for(col->rows)), dim3(kBlock), 0, s, view_of(col), d_out);
+      if (!on_device) copy_out(lengths, d_out, sizeof(int32_t) * col->rows, 0, s);
+      CS_HIP(hipStreamSynchronize(s));
+    }
+    if (total) *total = col->nbytes;
   });
 }
 

@@ -521,6 +521,48 @@ def test_gpu_zero_copy_column_at_odd_address(orc, shift):
     assert np.array_equal(va, vb)
 
 
+@pytest.mark.parametrize("base", [0, 5])
+@pytest.mark.parametrize("nulls", ["none", "empty", "holding_bytes"])
+@pytest.mark.parametrize("width", [32, 64])
+def test_gpu_ingest_makes_columns_canonical(base, nulls, width):
+    """create_from_offsets (NVStringsImpl.cu:399-444): offsets may start above zero and Arrow allows
+    bytes under a null row; the native column always has offsets[0] == 0 and empty null rows.  The
+    already-canonical case keeps the ingested buffers, the others are re-packed: both must export
+    the same rows."""
+    import torch
+    from custrings_amd import nvstrings
+
+    rng = np.random.default_rng(3)
+    rows = 5000
+    lens = rng.integers(0, 40, rows)
+    valid_bits = np.ones(rows, dtype=bool) if nulls == "none" else rng.random(rows) > 0.2
+    if nulls == "empty":
+        lens[~valid_bits] = 0
+    offs = np.zeros(rows + 1, dtype=np.int64)
+    np.cumsum(lens, out=offs[1:])
+    chars = rng.integers(97, 123, int(offs[-1]) + base, dtype=np.uint8)
+    offs += base
+    mask = None if nulls == "none" else np.packbits(valid_bits, bitorder="little")
+    want = [chars[offs[i]:offs[i + 1]].tobytes().decode() if valid_bits[i] else None for i in range(rows)]
+    dev = torch.device("cuda:0")
+    for on_device in (False, True):
+        c = torch.from_numpy(chars).to(dev) if on_device else chars
+        o = offs.astype(np.int32) if width == 32 else offs
+        o = torch.from_numpy(o).to(dev) if on_device else o
+        m = None if mask is None else (torch.from_numpy(mask).to(dev) if on_device else mask)
+        if width == 32:
+            g = nvstrings.from_offsets(c, o, rows, m, 0, bdevmem=on_device)
+        else:
+            g = nvstrings.from_offsets64(c, o, rows, m, bdevmem=on_device)
+        assert g.to_host() == want, (on_device,)
+        ch, of, va = g._export64()
+        assert of[0] == 0 and of[-1] == sum(len(w) for w in want if w is not None)
+        assert g.byte_count() == of[-1]
+        lens_out = np.zeros(rows, dtype=np.int32)
+        g.byte_count(lens_out)
+        assert lens_out.tolist() == [len(w) if w is not None else -1 for w in want]
+
+
 def test_gpu_category_table_growth(orc, monkeypatch):
     """The category build starts with a small hash table and retries with a larger one when a
     probe run gets long: force the retries with a tiny first table."""

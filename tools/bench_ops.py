@@ -90,7 +90,18 @@ def run_c2(a, ov):
     report("C2", "replace('a','xx') literal", rows, b, b + nbytes(rl) + 2 * ov * rows, timed(lambda: c2.replace("a", "xx", regex=False)))
     rs = c2.replace("ab", "x", regex=False)
     report("C2", "replace('ab','x') literal", rows, b, b + nbytes(rs) + 2 * ov * rows, timed(lambda: c2.replace("ab", "x", regex=False)))
-    del c2, low, st, cols, rl, rs
+    # ingest / egress through the reference's Arrow boundary (int32 offsets + bitmask, device buffers):
+    # create_offsets (NVStrings.cu:402-482), create_from_offsets (NVStringsImpl.cu:399-444), byte_count
+    chars = torch.empty(b + 64, dtype=torch.uint8, device="cuda")
+    offs = torch.empty(rows + 1, dtype=torch.int32, device="cuda")
+    mask = torch.empty((rows + 7) // 8 + 8, dtype=torch.uint8, device="cuda")
+    report("C2", "egress to_offsets (device, int32)", rows, b, 2 * b + (ov + 4.125) * rows,
+           timed(lambda: c2.to_offsets(chars.data_ptr(), offs.data_ptr(), mask.data_ptr(), bdevmem=True)))
+    report("C2", "ingest from_offsets (device, int32)", rows, b, 2 * b + (ov + 4.125) * rows,
+           timed(lambda: nvstrings.from_offsets(chars.data_ptr(), offs.data_ptr(), rows, mask.data_ptr(), 0, bdevmem=True)))
+    lens = torch.empty(rows, dtype=torch.int32, device="cuda")
+    report("C2", "byte_count (device)", rows, b, (ov + 4) * rows, timed(lambda: c2.byte_count(lens.data_ptr(), bdevmem=True)))
+    del c2, low, st, cols, rl, rs, chars, offs, mask, lens
 
 
 
