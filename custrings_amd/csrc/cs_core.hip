@@ -283,10 +283,17 @@ Buf validity_from_lengths(const int32_t* lens, int64_t n, hipStream_t s) {
   return v;
 }
 
+// one thread per 64-row validity word (the bits past `rows` in the last word are zero)
 __global__ void k_count_valid(const uint8_t* __restrict__ validity, int64_t rows,
                               unsigned long long* __restrict__ out) {
-  int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  int v = (i < rows) ? ((validity[i >> 3] >> (i & 7)) & 1) : 0;
+  const int64_t w = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  int v = 0;
+  if (w * 64 < rows) {
+    unsigned long long bits = reinterpret_cast<const unsigned long long*>(validity)[w];
+    const int64_t left = rows - w * 64;
+    if (left < 64) bits &= (1ull << left) - 1ull;
+    v = __builtin_popcountll(bits);
+  }
   long long t = block_reduce_sum(v);
   if (threadIdx.x == 0 && t) atomicAdd(out, (unsigned long long)t);
 }
@@ -295,7 +302,7 @@ int64_t count_nulls(const cs_column* c, hipStream_t s) {
   if (!c->validity || c->rows == 0) return c->null_count = 0;
   Buf cnt = dev_alloc(8, s);
   CS_HIP(hipMemsetAsync(cnt->p, 0, 8, s));
-  hipLaunchKernelGGL(k_count_valid, dim3(blocks_for(c->rows)), dim3(kBlock), 0, s, c->d_validity(),
+  hipLaunchKernelGGL(k_count_valid, dim3(blocks_for((c->rows + 63) / 64)), dim3(kBlock), 0, s, c->d_validity(),
                      c->rows, ptr<unsigned long long>(cnt));
   int64_t* host = (int64_t*)pinned_scratch(8);
   CS_HIP(hipMemcpyAsync(host, cnt->p, 8, hipMemcpyDeviceToHost, s));

@@ -166,32 +166,33 @@ struct ReplaceWrite {
 // ---- find / contains ------------------------------------------------------------------
 __global__ void k_find(ColView in, const uint8_t* __restrict__ needle, int nb, int start, int end,
                        int32_t* __restrict__ out, unsigned long long* __restrict__ found) {
-  int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  // (grid-stride: one same-address atomic per workgroup of a capped grid, not per 256 rows)
   int hit = 0;
-  if (r < in.rows) {
+  for (int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x; r < in.rows; r += (int64_t)gridDim.x * kBlock) {
     int v = -2;  // null row (find.cu:108)
     if (row_is_valid(in.validity, r)) {
       int64_t b = in.offsets[r];
       v = row_find(in.chars + b, (int)(in.offsets[r + 1] - b), needle, nb, start, end);
     }
     out[r] = v;
-    hit = v != -1;  // null rows are counted too (find.cu:112)
+    hit += v != -1;  // null rows are counted too (find.cu:112)
   }
   long long t = block_reduce_sum(hit);
   if (threadIdx.x == 0 && t) atomicAdd(found, (unsigned long long)t);
 }
 __global__ void k_contains(ColView in, const uint8_t* __restrict__ needle, int nb,
                            uint8_t* __restrict__ out, unsigned long long* __restrict__ found) {
-  int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  int hit = 0;
-  if (r < in.rows) {
+  int hits = 0;
+  for (int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x; r < in.rows; r += (int64_t)gridDim.x * kBlock) {
+    int hit = 0;
     if (nb > 0 && row_is_valid(in.validity, r)) {
       int64_t b = in.offsets[r];
       hit = find_bytes(in.chars + b, 0, (int)(in.offsets[r + 1] - b), needle, nb) >= 0;
     }
     out[r] = (uint8_t)hit;
+    hits += hit;
   }
-  long long t = block_reduce_sum(hit);
+  long long t = block_reduce_sum(hits);
   if (threadIdx.x == 0 && t) atomicAdd(found, (unsigned long long)t);
 }
 
@@ -214,7 +215,8 @@ __global__ void k_split_count(ColView in, SplitArgs a, int32_t* __restrict__ cou
     counts[r] = c;
   }
   int m = block_reduce_max(c);
-  if (threadIdx.x == 0 && m) atomicMax(max_out, m);
+  // (only a workgroup that would raise the maximum issues the same-address atomic)
+  if (threadIdx.x == 0 && m > __hip_atomic_load(max_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(max_out, m);
 }
 // lens[k * rows + r] = byte length of token k of row r, -1 when the row has no
 // such token (null in that column); block sums per column are fused in.
@@ -461,7 +463,7 @@ int cs_find(const cs_column* col, const char* str, int start, int end, int32_t* 
       ProfScope ps("k_find", s);
       if (!find_tiles(col, reinterpret_cast<const unsigned char*>(str), nd.n, 0, start, end, d_out, nullptr,
                       ptr<unsigned long long>(cnt), s))
-        hipLaunchKernelGGL(k_find, dim3(blocks_for(col->rows)), dim3(kBlock), 0, s, view_of(col), nd.d(),
+        hipLaunchKernelGGL(k_find, dim3(std::min(blocks_for(col->rows), 8192u)), dim3(kBlock), 0, s, view_of(col), nd.d(),
                            nd.n, start, end, d_out, ptr<unsigned long long>(cnt));
     }
     if (!on_device)
@@ -493,7 +495,7 @@ int cs_contains(const cs_column* col, const char* str, uint8_t* results, int on_
       ProfScope ps("k_contains", s);
       if (!find_tiles(col, reinterpret_cast<const unsigned char*>(str), nd.n, 1, 0, 0, nullptr, d_out,
                       ptr<unsigned long long>(cnt), s))
-        hipLaunchKernelGGL(k_contains, dim3(blocks_for(col->rows)), dim3(kBlock), 0, s, view_of(col), nd.d(),
+        hipLaunchKernelGGL(k_contains, dim3(std::min(blocks_for(col->rows), 8192u)), dim3(kBlock), 0, s, view_of(col), nd.d(),
                            nd.n, d_out, ptr<unsigned long long>(cnt));
     }
     if (!on_device) CS_HIP(hipMemcpyAsync(results, d_out, (size_t)col->rows, hipMemcpyDeviceToHost, s));

@@ -122,6 +122,11 @@ def run_c3(a, ov):
     ncols = len(cols)
     del cols
     report("C3", "split(' ')", rows, b, b + ov * rows + out_b + ncols * ov * rows, timed(lambda: c3.split(" ")))
+    cols = c3.split()
+    out_b = sum(nbytes(c) for c in cols)
+    ncols = len(cols)
+    del cols
+    report("C3", "split() whitespace", rows, b, b + ov * rows + out_b + ncols * ov * rows, timed(lambda: c3.split(), reps=2))
     del c3, resb, resi
 
 
