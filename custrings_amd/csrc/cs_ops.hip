@@ -36,7 +36,7 @@ using namespace csrow;
 namespace cs {
 // cs_split.hip: tile kernels for a single-byte delimiter; false = not applicable
 bool split_fast(const cs_column* col, unsigned char delim, int tokens, hipStream_t s,
-                std::vector<std::unique_ptr<cs_column>>& cols);
+                std::vector<std::unique_ptr<cs_column>>& cols, bool ws);
 }
 
 namespace {
@@ -557,9 +557,9 @@ int cs_split(const cs_column* col, const char* delimiter, int maxsplit, cs_strea
       a.delim = nd.d();
       a.nb = nd.n;
     }
-    if (delimiter && nd.n == 1 && (unsigned char)delimiter[0] < 128) {
+    if (!delimiter || (nd.n == 1 && (unsigned char)delimiter[0] < 128)) {
       std::vector<std::unique_ptr<cs_column>> fast;
-      if (split_fast(col, (unsigned char)delimiter[0], a.tokens, s, fast)) {
+      if (split_fast(col, delimiter ? (unsigned char)delimiter[0] : 0, a.tokens, s, fast, delimiter == nullptr)) {
         cs_column** arr = (cs_column**)malloc(sizeof(cs_column*) * fast.size());
         if (!arr) fail(CS_ERR_ALLOC, "host allocation failed");
         for (size_t k = 0; k < fast.size(); ++k) arr[k] = fast[k].release();

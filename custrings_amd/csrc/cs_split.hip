@@ -28,7 +28,7 @@ using namespace csdev;
 
 namespace cs {
 bool split_fast(const cs_column* col, unsigned char delim, int tokens, hipStream_t s,
-                std::vector<std::unique_ptr<cs_column>>& cols);
+                std::vector<std::unique_ptr<cs_column>>& cols, bool ws);
 }
 
 namespace {
@@ -108,18 +108,24 @@ __device__ __forceinline__ SubTile load_subtile(const ColView& in, long long sub
 // delimiters as a 96-bit mask held in registers, built in straight-line code from
 // 24 aligned words; the walk is then ctz + clear-lowest-bit per token.  Longer rows
 // search word by word.
-template <bool MASKED_ONLY>
+// WS (whitespace splitting, split.cu:863-956): a token is a maximal run of bytes above ' '
+// (every byte <= ' ' separates, no non-ASCII byte does); runs of separators collapse, there are
+// no empty tokens, and the token that exhausts maxsplit takes the rest of the row as it is.
+// The masks then hold token STARTS (m_*) and token ENDS (e_*); only the masked form exists.
+template <bool MASKED_ONLY, bool WS = false>
 struct TokensT {
   RowWords w;
   uint32_t dpat;
   int cursor, k, limit;  // limit: token index that swallows the rest (maxsplit), or -1
   bool more, masked;
-  unsigned long long m_lo;  // delimiter bits 0..63 (bit q = byte at row offset q - sa)
+  unsigned long long m_lo;  // delimiter bits 0..63 (bit q = byte at row offset q - sa); WS: token starts
   uint32_t m_hi;            // bits 64..95
+  unsigned long long e_lo;  // WS: last byte of each token
+  uint32_t e_hi;
   int sa;
   __device__ __forceinline__ TokensT(const uint8_t* base, int beg, int n, bool live, uint32_t d, int tokens)
       : w(base, beg, n), dpat(d), cursor(0), k(0), limit(tokens > 0 ? tokens - 1 : -1), more(live), masked(false),
-        m_lo(0), m_hi(0), sa(beg & 3) {
+        m_lo(0), m_hi(0), e_lo(0), e_hi(0), sa(beg & 3) {
     // (MASKED_ONLY: the caller guarantees that every row fits the 96-bit mask)
     if (MASKED_ONLY || __all(!live || n + sa <= 96)) {  // wave-uniform choice keeps the unrolled build convergent
       masked = true;
@@ -127,18 +133,36 @@ struct TokensT {
       uint32_t r[3] = {0, 0, 0};
 #pragma unroll
       for (int i = 0; i < 24; ++i) {
-        const uint32_t x = words[i] ^ d;
-        const uint32_t z = ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u;
+        uint32_t z;
+        if (WS) {
+          const uint32_t x = words[i];  // byte <= 0x20: bit 7 clear and the low seven bits below 0x21
+          z = ~(((x & 0x7F7F7F7Fu) + 0x5F5F5F5Fu) | x) & 0x80808080u;
+        } else {
+          const uint32_t x = words[i] ^ d;
+          z = ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u;
+        }
         const uint32_t nib = ((((z >> 7) & 0x01010101u) * 0x01020408u) >> 24) & 15u;
         r[i >> 3] |= nib << (4 * (i & 7));
       }
       const int hi = sa + n;  // keep bits sa .. hi - 1
-      r[0] &= 0xFFFFFFFFu << sa;
-      r[0] &= hi >= 32 ? 0xFFFFFFFFu : ~(0xFFFFFFFFu << (hi & 31));
-      r[1] &= hi >= 64 ? 0xFFFFFFFFu : (hi <= 32 ? 0u : ~(0xFFFFFFFFu << (hi & 31)));
-      r[2] &= hi >= 96 ? 0xFFFFFFFFu : (hi <= 64 ? 0u : ~(0xFFFFFFFFu << (hi & 31)));
-      m_lo = ((unsigned long long)r[1] << 32) | r[0];
-      m_hi = r[2];
+      uint32_t in0 = 0xFFFFFFFFu << sa;
+      in0 &= hi >= 32 ? 0xFFFFFFFFu : ~(0xFFFFFFFFu << (hi & 31));
+      const uint32_t in1 = hi >= 64 ? 0xFFFFFFFFu : (hi <= 32 ? 0u : ~(0xFFFFFFFFu << (hi & 31)));
+      const uint32_t in2 = hi >= 96 ? 0xFFFFFFFFu : (hi <= 64 ? 0u : ~(0xFFFFFFFFu << (hi & 31)));
+      if (WS) {
+        // token bytes of the row, then starts (byte before is not a token byte) and ends (byte after)
+        const uint32_t t0 = ~r[0] & in0, t1 = ~r[1] & in1, t2 = ~r[2] & in2;
+        const uint32_t up0 = t0 << 1, up1 = (t1 << 1) | (t0 >> 31), up2 = (t2 << 1) | (t1 >> 31);
+        const uint32_t dn0 = (t0 >> 1) | (t1 << 31), dn1 = (t1 >> 1) | (t2 << 31), dn2 = t2 >> 1;
+        m_lo = ((unsigned long long)(t1 & ~up1) << 32) | (t0 & ~up0);
+        m_hi = t2 & ~up2;
+        e_lo = ((unsigned long long)(t1 & ~dn1) << 32) | (t0 & ~dn0);
+        e_hi = t2 & ~dn2;
+        more = live && (m_lo != 0 || m_hi != 0);
+      } else {
+        m_lo = ((unsigned long long)(r[1] & in1) << 32) | (r[0] & in0);
+        m_hi = r[2] & in2;
+      }
     }
   }
   __device__ __forceinline__ int next_delim() {  // masked: position of the next delimiter, or n
@@ -154,8 +178,30 @@ struct TokensT {
     }
     return w.n;
   }
+  __device__ __forceinline__ int next_end() {  // WS: position of the last byte of the next token
+    if (e_lo) {
+      const int q = __builtin_ctzll(e_lo);
+      e_lo &= e_lo - 1;
+      return q - sa;
+    }
+    const int q = 64 + __builtin_ctz(e_hi);
+    e_hi &= e_hi - 1;
+    return q - sa;
+  }
   __device__ __forceinline__ bool next(int& lo, int& hi) {
     if (!more) return false;
+    if (WS) {
+      lo = next_delim();  // (the next token start)
+      if (k == limit) {
+        hi = w.n;
+        more = false;
+      } else {
+        hi = next_end() + 1;
+        more = m_lo != 0 || m_hi != 0;
+      }
+      ++k;
+      return true;
+    }
     lo = cursor;
     if (k == limit) {
       hi = w.n;
@@ -177,8 +223,10 @@ struct MeasureArgs {
   int tokens, cap;
   long long nsub;
   int32_t* colsum;  // [kMaxCols][nsub]
-  int* max_count;   // [0] most tokens in a row, [1] most bytes one column receives from one sub-tile, [2] longest row
+  int* max_count;   // [0] most tokens in a row, [1] most bytes one column receives from one sub-tile, [2] longest row,
+                    // [3] set when a sub-tile needs the generic kernels (whitespace mode: a row beyond the 96-bit masks)
 };
+template <bool WS>
 __global__ void __launch_bounds__(256) k_split_measure(MeasureArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -186,7 +234,11 @@ __global__ void __launch_bounds__(256) k_split_measure(MeasureArgs a) {
   const long long sub = (long long)blockIdx.x * 4 + wv;
   if (sub >= a.nsub) return;
   SubTile t = load_subtile(a.in, sub, lds_in, lane);
-  Tokens tk(lds_in, t.lead + t.rbeg, t.n, t.live, a.dpat, a.tokens);
+  TokensT<false, WS> tk(lds_in, t.lead + t.rbeg, t.n, t.live, a.dpat, a.tokens);
+  if (WS && !tk.masked) {
+    if (lane == 0) atomicMax(a.max_count + 3, 1);
+    return;
+  }
   int count = 0, widest = 0;
   for (int k = 0;; ++k) {
     int lo, hi;
@@ -304,12 +356,14 @@ __device__ __forceinline__ void lds_or(uint32_t* p, uint32_t v) {
 #ifndef CS_EMIT2_WAVES
 #define CS_EMIT2_WAVES 4
 #endif
+template <bool WS>
 __global__ void __launch_bounds__(256, CS_EMIT2_WAVES) k_split_emit2(Emit2Args a) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  uint8_t* lds_in = reinterpret_cast<uint8_t*>(smem) + (size_t)wv * (a.cap_in + 32 + 2 * a.cap_col + a.ncols * 64);
+  uint8_t* lds_in = reinterpret_cast<uint8_t*>(smem) + (size_t)wv * (a.cap_in + 32 + 2 * a.cap_col + (WS ? 2 : 1) * a.ncols * 64);
   uint8_t* region0 = lds_in + a.cap_in + 32;
-  uint8_t* dpos = region0 + 2 * a.cap_col;  // dpos[j * 64 + lane] = row offset of the lane's j-th delimiter
+  uint8_t* dpos = region0 + 2 * a.cap_col;  // dpos[j * 64 + lane] = row offset of the lane's j-th delimiter (WS: j-th token start)
+  uint8_t* epos = dpos + a.ncols * 64;      // WS: last byte of the lane's j-th token
   // each wave owns a contiguous run of sub-tiles: its pieces of every output column are
   // contiguous too, so the cache lines that two neighbouring sub-tiles share are completed in
   // one L2 instead of being written half-filled from two XCDs
@@ -374,15 +428,15 @@ __global__ void __launch_bounds__(256, CS_EMIT2_WAVES) k_split_emit2(Emit2Args a
     cstile::wave_lds_fence();
     CS_PHASE_MARK(0);
 
-    TokensT<true> tk(lds_in, lead + rbeg, n, live, a.dpat, a.tokens);
+    TokensT<true, WS> tk(lds_in, lead + rbeg, n, live, a.dpat, a.tokens);
     // every row's delimiter positions go to LDS once, in a loop that does nothing else; the
     // column loop then needs one byte load per token instead of the bit-mask walk
     const int nd = __builtin_popcountll(tk.m_lo) + __builtin_popcount(tk.m_hi);
-    {
-      // word by word, lowest set bit first: ffbl, clear, one byte store per delimiter
-      uint32_t w[3] = {(uint32_t)tk.m_lo, (uint32_t)(tk.m_lo >> 32), tk.m_hi};
-      uint8_t* slot = dpos + lane;  // advances one dpos row (64 bytes) per delimiter found
-      const uint8_t* last = dpos + (a.ncols - 1) * 64;
+    auto fill = [&](unsigned long long lo64, uint32_t hi32, uint8_t* table, int entries) {
+      // word by word, lowest set bit first: ffbl, clear, one byte store per position
+      uint32_t w[3] = {(uint32_t)lo64, (uint32_t)(lo64 >> 32), hi32};
+      uint8_t* slot = table + lane;  // advances one table row (64 bytes) per position found
+      const uint8_t* last = table + entries * 64;
 #pragma unroll
       for (int i = 0; i < 3; ++i) {
         uint32_t v = w[i];
@@ -395,8 +449,14 @@ __global__ void __launch_bounds__(256, CS_EMIT2_WAVES) k_split_emit2(Emit2Args a
           }
         }
       }
+    };
+    if (WS) {
+      fill(tk.m_lo, tk.m_hi, dpos, a.ncols);
+      fill(tk.e_lo, tk.e_hi, epos, a.ncols);
+    } else {
+      fill(tk.m_lo, tk.m_hi, dpos, a.ncols - 1);
     }
-    const int ntok = live ? min(nd, a.tokens > 0 ? a.tokens - 1 : 1 << 20) + 1 : 0;
+    const int ntok = !live ? 0 : WS ? min(nd, a.tokens > 0 ? a.tokens : 1 << 20) : min(nd, a.tokens > 0 ? a.tokens - 1 : 1 << 20) + 1;
     cstile::wave_lds_fence();
     CS_PHASE_MARK(1);
     const bool last_tile = r0 + nrows == in.rows;
@@ -406,10 +466,16 @@ __global__ void __launch_bounds__(256, CS_EMIT2_WAVES) k_split_emit2(Emit2Args a
       uint8_t* region = region0 + (k & 1) * a.cap_col;
       const int dk = dpos[k * 64 + lane];
       const bool has = k < ntok;
-      const int lo = cursor;
-      const int hi = k == ntok - 1 ? n : dk;
+      int lo, hi;
+      if (WS) {  // the token that exhausts maxsplit keeps the rest of the row
+        lo = dk;
+        hi = (a.tokens > 0 && k == a.tokens - 1) ? n : epos[k * 64 + lane] + 1;
+      } else {
+        lo = cursor;
+        hi = k == ntok - 1 ? n : dk;
+        cursor = hi + 1;
+      }
       const int len = has ? hi - lo : 0;
-      cursor = hi + 1;
       const int incl = wave_inclusive_scan(len);
       const int pre = incl - len;
       const long long cbase = cstile::rl64(my_base, k);
@@ -485,8 +551,9 @@ __global__ void __launch_bounds__(256, CS_EMIT2_WAVES) k_split_emit2(Emit2Args a
 
 namespace cs {
 
+// `ws`: whitespace splitting (delimiter == nullptr in the API); `delim` is then unused.
 bool split_fast(const cs_column* col, unsigned char delim, int tokens, hipStream_t s,
-                std::vector<std::unique_ptr<cs_column>>& cols) {
+                std::vector<std::unique_ptr<cs_column>>& cols, bool ws) {
   const int64_t rows = col->rows;
   if (rows == 0 || getenv("CS_SPLIT_GENERIC")) return false;
   const int64_t span = max_span64(col, s);
@@ -506,7 +573,8 @@ bool split_fast(const cs_column* col, unsigned char delim, int tokens, hipStream
     ProfScope ps("k_split_measure", s);
     // (a persistent, prefetching form of this kernel measured slower: it is bound by its
     // instruction count, not by memory latency, at 28 resident waves per CU)
-    hipLaunchKernelGGL(k_split_measure, dim3(grid), dim3(256), (size_t)(cap_in + 32) * 4, s, ma);
+    if (ws) hipLaunchKernelGGL(k_split_measure<true>, dim3(grid), dim3(256), (size_t)(cap_in + 32) * 4, s, ma);
+    else hipLaunchKernelGGL(k_split_measure<false>, dim3(grid), dim3(256), (size_t)(cap_in + 32) * 4, s, ma);
   }
   CS_HIP(hipGetLastError());
   int* hmx = (int*)pinned_scratch(4 * sizeof(int));
@@ -516,6 +584,8 @@ bool split_fast(const cs_column* col, unsigned char delim, int tokens, hipStream
   const int widest = hmx[1];
   const int longest_row = hmx[2];
   if (ncols == 0 || ncols > kMaxCols) return false;  // all-null column / too many columns: generic path
+  const bool emit2_ok = cap_in <= cstile::kPfBytes && longest_row + 3 <= 96 && !getenv("CS_SPLIT_OLD_EMIT");
+  if (ws && (hmx[3] || !emit2_ok)) return false;  // whitespace mode exists in the masked kernels only
 
   // per column: position of every sub-tile in the column's chars buffer
   Buf base = dev_alloc(sizeof(int64_t) * (nsub + 1) * ncols, s);
@@ -537,22 +607,23 @@ bool split_fast(const cs_column* col, unsigned char delim, int tokens, hipStream
   Buf d_outs = dev_alloc(sizeof(ColOut) * ncols, s);
   CS_HIP(hipMemcpyAsync(d_outs->p, outs.data(), sizeof(ColOut) * ncols, hipMemcpyHostToDevice, s));
   const int cap_col = (widest + 64 + 15) & ~15;
-  if (cap_in <= cstile::kPfBytes && longest_row + 3 <= 96 && !getenv("CS_SPLIT_OLD_EMIT")) {
+  if (emit2_ok) {
     Emit2Args e2{view_of(col), dpat, tokens, cap_in, cap_col, ncols, nsub, ptr<const ColOut>(d_outs), nullptr};
 #if defined(CS_PHASE_PROF)
     Buf profbuf = dev_alloc(64, s);
     CS_HIP(hipMemsetAsync(profbuf->p, 0, 64, s));
     e2.prof = ptr<unsigned long long>(profbuf);
 #endif
-    const size_t lds2 = (size_t)(cap_in + 32 + 2 * cap_col + ncols * 64) * 4;
+    const size_t lds2 = (size_t)(cap_in + 32 + 2 * cap_col + (ws ? 2 : 1) * ncols * 64) * 4;
     if (lds2 <= 150 * 1024) {
       if (lds2 > 48 * 1024)
-        CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_split_emit2),
+        CS_HIP(hipFuncSetAttribute(ws ? reinterpret_cast<const void*>(&k_split_emit2<true>) : reinterpret_cast<const void*>(&k_split_emit2<false>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
-      const unsigned g2 = resident_grid(reinterpret_cast<const void*>(&k_split_emit2), lds2, (nsub + 3) / 4);
+      const unsigned g2 = resident_grid(ws ? reinterpret_cast<const void*>(&k_split_emit2<true>) : reinterpret_cast<const void*>(&k_split_emit2<false>), lds2, (nsub + 3) / 4);
       {
         ProfScope ps("k_split_emit", s);
-        hipLaunchKernelGGL(k_split_emit2, dim3(g2), dim3(256), lds2, s, e2);
+        if (ws) hipLaunchKernelGGL(k_split_emit2<true>, dim3(g2), dim3(256), lds2, s, e2);
+        else hipLaunchKernelGGL(k_split_emit2<false>, dim3(g2), dim3(256), lds2, s, e2);
       }
       CS_HIP(hipGetLastError());
       CS_HIP(hipStreamSynchronize(s));  // `outs` / `base` lifetime

@@ -563,6 +563,26 @@ def test_gpu_ingest_makes_columns_canonical(base, nulls, width):
         assert lens_out.tolist() == [len(w) if w is not None else -1 for w in want]
 
 
+@pytest.mark.parametrize("long_rows", [False, True])
+def test_gpu_whitespace_split_tile_kernels(gpu_engine, oracle_engine, long_rows):
+    """split(None, n) (split.cu:863-956) on the tile kernels: runs of spaces, tabs, newlines and
+    other control bytes separate, non-ASCII bytes never do, the token that exhausts maxsplit keeps
+    the rest of the row; with a row beyond the 96-bit masks the column takes the generic kernels."""
+    import random
+
+    rnd = random.Random(17)
+    alphabet = list("abcXYZ09_.") + [" ", " ", "  ", "\t", "\n", "\x01", "\x1f", "é", "\u00a0", "\u2003", "😀"]
+    s = []
+    for _ in range(4000):
+        s.append("".join(rnd.choice(alphabet) for _ in range(rnd.randint(0, 30))))
+    s += ["", " ", "   ", "a", " a", "a ", " a b ", "\ta\nb  c", "a  b   c d", None, "é é"]
+    if long_rows:
+        s += ["w " * 80, "x" * 200]
+    o, g = oracle_engine, gpu_engine
+    for n in (-1, 0, 1, 2, 3, 7):
+        assert g.split(s, None, n) == o.split(s, None, n), n
+
+
 def test_gpu_category_table_growth(orc, monkeypatch):
     """The category build starts with a small hash table and retries with a larger one when a
     probe run gets long: force the retries with a tiny first table."""
