@@ -513,21 +513,24 @@ int cs_replace(const cs_column* col, const char* str, const char* repl, int maxr
     require_device();
     hipStream_t s = S(stream);
     if (!repl) repl = "";
-    // A needle without regex metacharacters and a replacement of at most 16 bytes run on the
-    // persistent single-pass replace_re kernel (same leftmost, non-overlapping semantics;
-    // modify.cu:109-192 restarts at pos + nchars(str), replace.cu:91-92 at the match end).
+    // An ASCII needle and a replacement of at most 16 bytes run on the persistent single-pass
+    // replace_re kernel (same leftmost, non-overlapping semantics; modify.cu:109-192 restarts at
+    // pos + nchars(str), replace.cu:91-92 at the match end): the needle becomes a pattern with
+    // its regex metacharacters escaped.
     {
       bool plain = true;
+      std::string pattern;
       for (const char* p = str; *p && plain; ++p) {
         const unsigned char c = (unsigned char)*p;
-        plain = (c >= '0' && c <= '9') || (c >= 'A' && c <= 'Z') || (c >= 'a' && c <= 'z') || c == ' ' || c == '_' ||
-                c == ',' || c == ';' || c == ':' || c == '=' || c == '@' || c == '#' || c == '%' || c == '&' || c == '~' ||
-                c == '<' || c == '>' || c == '/' || c == '!' || c == '-' || c == '"' || c == '\'';
+        plain = c >= 0x20 && c < 0x7F;
+        if (strchr(".*+?{|()^$[\\", c)) pattern.push_back('\\');
+        pattern.push_back((char)c);
       }
+      plain = plain && pattern.size() <= 128;
       const size_t rb = strlen(repl);
       if (plain && rb <= 16 && col->rows > 0 && !getenv("CS_REPLACE_ROWWISE") && bytes_plain(col, S(stream))) {
         cs_regex* re = nullptr;
-        if (cs_regex_compile(str, &re) == CS_OK) {
+        if (cs_regex_compile(pattern.c_str(), &re) == CS_OK) {
           cs::g_replace_plain_only = 1;  // the single-pass kernel or nothing: this function's own kernels are the fallback
           const int rc = cs_replace_re(col, re, repl, maxrepl, stream, out);
           cs::g_replace_plain_only = 0;

@@ -162,7 +162,15 @@ __global__ void __launch_bounds__(256) k_find_tile(FindTileArgs a) {
     const int lead = (int)((uintptr_t)(in.chars + g0) & 15);
     const int want = (int)(g1 - g0) + lead;
     cstile::stage_chars(lds_in, want, lane, pf);
-    const bool by_bits = a.whole && a.nb > 0 && !__any(n > 96);
+    // (a search over a character window is a search over a byte window when the tile is ASCII)
+    bool by_bits = a.nb > 0 && !__any(n > 96);
+    if (by_bits && !a.whole) {
+      uint32_t high = 0;
+#pragma unroll
+      for (int j = 0; j < cstile::kPfChunks; ++j)
+        if (j * 1024 + lane * 16 < want) high |= pf.v[j].x | pf.v[j].y | pf.v[j].z | pf.v[j].w;
+      by_bits = !__any((high & 0x80808080u) != 0);
+    }
     if (by_bits) {
 #pragma unroll
       for (int j = 0; j < cstile::kPfChunks; ++j)
@@ -191,7 +199,18 @@ __global__ void __launch_bounds__(256) k_find_tile(FindTileArgs a) {
     int at = -1;  // byte offset of the first occurrence (by_bits)
     if (by_bits && live && n >= a.nb) {
       uint32_t m0, m1, m2;  // candidate starts that leave room for the needle
-      cstile::row_bits96(bm_first, lead + rbeg, n - a.nb + 1, m0, m1, m2);
+      int from = 0, to = n;  // the byte window (find.cu:75-120: start, then a count of end - start characters)
+      if (!a.whole) {
+        const int st = a.start < 0 ? 0 : a.start;
+        from = st < n ? st : n;
+        if (a.end - st >= 0) to = min(n, from + (a.end - st));
+      }
+      cstile::row_bits96(bm_first, lead + rbeg, max(0, to - a.nb + 1), m0, m1, m2);
+      if (from > 0) {  // drop the candidates before the window
+        if (from >= 64) m0 = 0, m1 = 0, m2 &= from >= 96 ? 0u : 0xFFFFFFFFu << (from - 64);
+        else if (from >= 32) m0 = 0, m1 &= 0xFFFFFFFFu << (from - 32);
+        else m0 &= 0xFFFFFFFFu << from;
+      }
       while ((m0 | m1 | m2) != 0) {
         const int pos = m0 ? __builtin_ctz(m0) : (m1 ? 32 + __builtin_ctz(m1) : 64 + __builtin_ctz(m2));
         if (m0) m0 &= m0 - 1;

@@ -583,6 +583,31 @@ def test_gpu_whitespace_split_tile_kernels(gpu_engine, oracle_engine, long_rows)
         assert g.split(s, None, n) == o.split(s, None, n), n
 
 
+def test_gpu_find_windows_and_escaped_literal_replace(orc):
+    """find(sub, start, end) on ASCII tiles takes the candidate bitmap with the window applied as a
+    byte range; a literal needle made of regex metacharacters rides the stream kernel escaped."""
+    rows = 100_000
+    g, o = gpuutil.synth(3, 0, rows), orc.synth(3, 0, rows)
+    L = gpuutil.lib()
+    for sub in ("200", " ", "GET /", "e"):
+        for st, en in ((0, -1), (10, 60), (5, 5), (40, 20), (-3, 30), (70, 200), (0, 1), (47, 49)):
+            f = np.zeros(rows, dtype=np.int32)
+            found = C.c_int64()
+            L.check(L.lib.cs_find(g.m_cptr, sub.encode(), st, en, f.ctypes.data, 0, None, C.byref(found)))
+            f_o, n_o = orc.find(o, sub, st, en)
+            assert np.array_equal(f, f_o) and found.value == n_o, (sub, st, en)
+    for pat, repl in ((".", "_"), ("/", "//"), (". ", ""), ("(", "["), ("a.b", "x"), ("\\", "/"), ("$", "USD"), ("[", "]"), ("*", "")):
+        gpuutil.assert_same(g.replace(pat, repl, regex=False), orc.replace(o, pat, repl), "literal %r" % pat)
+    s = ["a.b.c", "..", "x*y+z?", "(a|b)", "^$", "[x]{2}", "back\\slash", "", None, "3.14"]
+    from custrings_amd import nvstrings
+
+    d = nvstrings.to_device(s)
+    for pat, repl in ((".", "-"), ("*", "S"), ("+", "P"), ("?", "Q"), ("(", "<"), (")", ">"), ("|", "I"), ("^", "C"), ("$", "D"),
+                      ("[", "L"), ("]", "R"), ("{", "B"), ("}", "E"), ("\\", "/"), ("a.b", "AB"), ("..", ":")):
+        want = [None if x is None else x.replace(pat, repl) for x in s]
+        assert d.replace(pat, repl, regex=False).to_host() == want, (pat, repl)
+
+
 def test_gpu_category_table_growth(orc, monkeypatch):
     """The category build starts with a small hash table and retries with a larger one when a
     probe run gets long: force the retries with a tiny first table."""
