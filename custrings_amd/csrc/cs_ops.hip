@@ -35,8 +35,8 @@ using namespace csrow;
 
 namespace cs {
 // cs_split.hip: tile kernels for a single-byte delimiter; false = not applicable
-bool split_fast(const cs_column* col, unsigned char delim, int tokens, hipStream_t s,
-                std::vector<std::unique_ptr<cs_column>>& cols, bool ws);
+bool split_fast(const cs_column* col, const unsigned char* delim, int dlen, int tokens, hipStream_t s,
+                std::vector<std::unique_ptr<cs_column>>& cols);
 }
 
 namespace {
@@ -560,9 +560,11 @@ int cs_split(const cs_column* col, const char* delimiter, int maxsplit, cs_strea
       a.delim = nd.d();
       a.nb = nd.n;
     }
-    if (!delimiter || (nd.n == 1 && (unsigned char)delimiter[0] < 128)) {
+    bool ascii_delim = delimiter && nd.n >= 1 && nd.n <= 8;
+    for (int i = 0; ascii_delim && i < nd.n; ++i) ascii_delim = (unsigned char)delimiter[i] < 128;
+    if (!delimiter || ascii_delim) {
       std::vector<std::unique_ptr<cs_column>> fast;
-      if (split_fast(col, delimiter ? (unsigned char)delimiter[0] : 0, a.tokens, s, fast, delimiter == nullptr)) {
+      if (split_fast(col, reinterpret_cast<const unsigned char*>(delimiter), delimiter ? nd.n : 0, a.tokens, s, fast)) {
         cs_column** arr = (cs_column**)malloc(sizeof(cs_column*) * fast.size());
         if (!arr) fail(CS_ERR_ALLOC, "host allocation failed");
         for (size_t k = 0; k < fast.size(); ++k) arr[k] = fast[k].release();

@@ -27,8 +27,8 @@ using namespace cs;
 using namespace csdev;
 
 namespace cs {
-bool split_fast(const cs_column* col, unsigned char delim, int tokens, hipStream_t s,
-                std::vector<std::unique_ptr<cs_column>>& cols, bool ws);
+bool split_fast(const cs_column* col, const unsigned char* delim, int dlen, int tokens, hipStream_t s,
+                std::vector<std::unique_ptr<cs_column>>& cols);
 }
 
 namespace {
@@ -112,7 +112,11 @@ __device__ __forceinline__ SubTile load_subtile(const ColView& in, long long sub
 // (every byte <= ' ' separates, no non-ASCII byte does); runs of separators collapse, there are
 // no empty tokens, and the token that exhausts maxsplit takes the rest of the row as it is.
 // The masks then hold token STARTS (m_*) and token ENDS (e_*); only the masked form exists.
-template <bool MASKED_ONLY, bool WS = false>
+// MULTI (a delimiter of 2..8 ASCII bytes): the mask first holds the positions of the delimiter's
+// first byte; each row lane then keeps those where the whole delimiter stands and that do not
+// overlap the previous occurrence (the search continues after an occurrence, custring_view.inl:
+// 1223-1279), and a token ends where the next kept position begins.  Masked form only.
+template <bool MASKED_ONLY, bool WS = false, bool MULTI = false>
 struct TokensT {
   RowWords w;
   uint32_t dpat;
@@ -123,9 +127,11 @@ struct TokensT {
   unsigned long long e_lo;  // WS: last byte of each token
   uint32_t e_hi;
   int sa;
-  __device__ __forceinline__ TokensT(const uint8_t* base, int beg, int n, bool live, uint32_t d, int tokens)
+  int dlen;  // delimiter bytes (1 unless MULTI)
+  __device__ __forceinline__ TokensT(const uint8_t* base, int beg, int n, bool live, uint32_t d, int tokens,
+                                     unsigned long long d64 = 0, int delim_len = 1)
       : w(base, beg, n), dpat(d), cursor(0), k(0), limit(tokens > 0 ? tokens - 1 : -1), more(live), masked(false),
-        m_lo(0), m_hi(0), e_lo(0), e_hi(0), sa(beg & 3) {
+        m_lo(0), m_hi(0), e_lo(0), e_hi(0), sa(beg & 3), dlen(MULTI ? delim_len : 1) {
     // (MASKED_ONLY: the caller guarantees that every row fits the 96-bit mask)
     if (MASKED_ONLY || __all(!live || n + sa <= 96)) {  // wave-uniform choice keeps the unrolled build convergent
       masked = true;
@@ -162,6 +168,32 @@ struct TokensT {
       } else {
         m_lo = ((unsigned long long)(r[1] & in1) << 32) | (r[0] & in0);
         m_hi = r[2] & in2;
+        if (MULTI) {
+          unsigned long long c_lo = m_lo, k_lo = 0;
+          uint32_t c_hi = m_hi, k_hi = 0;
+          int free_from = 0;  // row offset where the next occurrence may begin
+          const uint8_t* row = base + beg;
+          while (c_lo != 0 || c_hi != 0) {
+            int q;
+            if (c_lo) {
+              q = __builtin_ctzll(c_lo);
+              c_lo &= c_lo - 1;
+            } else {
+              q = 64 + __builtin_ctz(c_hi);
+              c_hi &= c_hi - 1;
+            }
+            const int pos = q - sa;
+            if (pos < free_from || pos + dlen > n) continue;
+            int j = 1;
+            while (j < dlen && row[pos + j] == (uint8_t)(d64 >> (8 * j))) ++j;
+            if (j < dlen) continue;
+            if (q < 64) k_lo |= 1ull << q;
+            else k_hi |= 1u << (q - 64);
+            free_from = pos + dlen;
+          }
+          m_lo = k_lo;
+          m_hi = k_hi;
+        }
       }
     }
   }
@@ -209,7 +241,7 @@ struct TokensT {
     } else {
       hi = (MASKED_ONLY || masked) ? next_delim() : w.find(cursor, dpat);
       if (hi >= w.n) more = false;
-      else cursor = hi + 1;
+      else cursor = hi + dlen;
     }
     ++k;
     return true;
@@ -220,22 +252,26 @@ using Tokens = TokensT<false>;
 struct MeasureArgs {
   ColView in;
   uint32_t dpat;
+  unsigned long long d64;  // the delimiter's bytes, first byte lowest (multi-byte delimiters)
+  int dlen;
   int tokens, cap;
   long long nsub;
   int32_t* colsum;  // [kMaxCols][nsub]
   int* max_count;   // [0] most tokens in a row, [1] most bytes one column receives from one sub-tile, [2] longest row,
                     // [3] set when a sub-tile needs the generic kernels (whitespace mode: a row beyond the 96-bit masks)
 };
-template <bool WS>
+// MODE 0: one-byte delimiter, 1: whitespace, 2: delimiter of 2..8 ASCII bytes
+template <int MODE>
 __global__ void __launch_bounds__(256) k_split_measure(MeasureArgs a) {
+  constexpr bool WS = MODE == 1, MULTI = MODE == 2;
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
   uint8_t* lds_in = reinterpret_cast<uint8_t*>(smem) + (size_t)wv * (a.cap + 32);
   const long long sub = (long long)blockIdx.x * 4 + wv;
   if (sub >= a.nsub) return;
   SubTile t = load_subtile(a.in, sub, lds_in, lane);
-  TokensT<false, WS> tk(lds_in, t.lead + t.rbeg, t.n, t.live, a.dpat, a.tokens);
-  if (WS && !tk.masked) {
+  TokensT<false, WS, MULTI> tk(lds_in, t.lead + t.rbeg, t.n, t.live, a.dpat, a.tokens, a.d64, a.dlen);
+  if ((WS || MULTI) && !tk.masked) {
     if (lane == 0) atomicMax(a.max_count + 3, 1);
     return;
   }
@@ -345,6 +381,8 @@ __global__ void __launch_bounds__(256) k_split_emit(EmitArgs a) {
 struct Emit2Args {
   ColView in;
   uint32_t dpat;
+  unsigned long long d64;
+  int dlen;
   int tokens, cap_in, cap_col, ncols;
   long long nsub;
   const ColOut* cols;
@@ -356,8 +394,9 @@ __device__ __forceinline__ void lds_or(uint32_t* p, uint32_t v) {
 #ifndef CS_EMIT2_WAVES
 #define CS_EMIT2_WAVES 4
 #endif
-template <bool WS>
+template <int MODE>
 __global__ void __launch_bounds__(256, CS_EMIT2_WAVES) k_split_emit2(Emit2Args a) {
+  constexpr bool WS = MODE == 1, MULTI = MODE == 2;
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
   uint8_t* lds_in = reinterpret_cast<uint8_t*>(smem) + (size_t)wv * (a.cap_in + 32 + 2 * a.cap_col + (WS ? 2 : 1) * a.ncols * 64);
@@ -428,7 +467,7 @@ __global__ void __launch_bounds__(256, CS_EMIT2_WAVES) k_split_emit2(Emit2Args a
     cstile::wave_lds_fence();
     CS_PHASE_MARK(0);
 
-    TokensT<true, WS> tk(lds_in, lead + rbeg, n, live, a.dpat, a.tokens);
+    TokensT<true, WS, MULTI> tk(lds_in, lead + rbeg, n, live, a.dpat, a.tokens, a.d64, a.dlen);
     // every row's delimiter positions go to LDS once, in a loop that does nothing else; the
     // column loop then needs one byte load per token instead of the bit-mask walk
     const int nd = __builtin_popcountll(tk.m_lo) + __builtin_popcount(tk.m_hi);
@@ -473,7 +512,7 @@ __global__ void __launch_bounds__(256, CS_EMIT2_WAVES) k_split_emit2(Emit2Args a
       } else {
         lo = cursor;
         hi = k == ntok - 1 ? n : dk;
-        cursor = hi + 1;
+        cursor = hi + (MULTI ? a.dlen : 1);
       }
       const int len = has ? hi - lo : 0;
       const int incl = wave_inclusive_scan(len);
@@ -551,9 +590,13 @@ __global__ void __launch_bounds__(256, CS_EMIT2_WAVES) k_split_emit2(Emit2Args a
 
 namespace cs {
 
-// `ws`: whitespace splitting (delimiter == nullptr in the API); `delim` is then unused.
-bool split_fast(const cs_column* col, unsigned char delim, int tokens, hipStream_t s,
-                std::vector<std::unique_ptr<cs_column>>& cols, bool ws) {
+// `delim`: 1..8 ASCII bytes, or nullptr for whitespace splitting.
+bool split_fast(const cs_column* col, const unsigned char* delim, int dlen, int tokens, hipStream_t s,
+                std::vector<std::unique_ptr<cs_column>>& cols) {
+  const bool ws = delim == nullptr;
+  const int mode = ws ? 1 : (dlen > 1 ? 2 : 0);
+  unsigned long long d64 = 0;
+  for (int i = 0; !ws && i < dlen; ++i) d64 |= (unsigned long long)delim[i] << (8 * i);
   const int64_t rows = col->rows;
   if (rows == 0 || getenv("CS_SPLIT_GENERIC")) return false;
   const int64_t span = max_span64(col, s);
@@ -562,19 +605,20 @@ bool split_fast(const cs_column* col, unsigned char delim, int tokens, hipStream
   if ((size_t)(cap_in + cap_out + 64) * 4 > 150 * 1024) return false;
   const int64_t nsub = (rows + kSub - 1) / kSub;
   const unsigned grid = (unsigned)((nsub + 3) / 4);
-  const uint32_t dpat = 0x01010101u * delim;
+  const uint32_t dpat = 0x01010101u * (ws ? 0u : (uint32_t)delim[0]);
 
   Buf colsum = dev_alloc(sizeof(int32_t) * nsub * kMaxCols, s);
   CS_HIP(hipMemsetAsync(colsum->p, 0, sizeof(int32_t) * nsub * kMaxCols, s));  // columns a sub-tile never reaches
   Buf mx = dev_alloc(4 * sizeof(int), s);
   CS_HIP(hipMemsetAsync(mx->p, 0, 4 * sizeof(int), s));
-  MeasureArgs ma{view_of(col), dpat, tokens, cap_in, nsub, ptr<int32_t>(colsum), ptr<int>(mx)};
+  MeasureArgs ma{view_of(col), dpat, d64, dlen, tokens, cap_in, nsub, ptr<int32_t>(colsum), ptr<int>(mx)};
   {
     ProfScope ps("k_split_measure", s);
     // (a persistent, prefetching form of this kernel measured slower: it is bound by its
     // instruction count, not by memory latency, at 28 resident waves per CU)
-    if (ws) hipLaunchKernelGGL(k_split_measure<true>, dim3(grid), dim3(256), (size_t)(cap_in + 32) * 4, s, ma);
-    else hipLaunchKernelGGL(k_split_measure<false>, dim3(grid), dim3(256), (size_t)(cap_in + 32) * 4, s, ma);
+    if (mode == 1) hipLaunchKernelGGL(k_split_measure<1>, dim3(grid), dim3(256), (size_t)(cap_in + 32) * 4, s, ma);
+    else if (mode == 2) hipLaunchKernelGGL(k_split_measure<2>, dim3(grid), dim3(256), (size_t)(cap_in + 32) * 4, s, ma);
+    else hipLaunchKernelGGL(k_split_measure<0>, dim3(grid), dim3(256), (size_t)(cap_in + 32) * 4, s, ma);
   }
   CS_HIP(hipGetLastError());
   int* hmx = (int*)pinned_scratch(4 * sizeof(int));
@@ -585,7 +629,7 @@ bool split_fast(const cs_column* col, unsigned char delim, int tokens, hipStream
   const int longest_row = hmx[2];
   if (ncols == 0 || ncols > kMaxCols) return false;  // all-null column / too many columns: generic path
   const bool emit2_ok = cap_in <= cstile::kPfBytes && longest_row + 3 <= 96 && !getenv("CS_SPLIT_OLD_EMIT");
-  if (ws && (hmx[3] || !emit2_ok)) return false;  // whitespace mode exists in the masked kernels only
+  if (mode != 0 && (hmx[3] || !emit2_ok)) return false;  // whitespace and multi-byte delimiters exist in the masked kernels only
 
   // per column: position of every sub-tile in the column's chars buffer
   Buf base = dev_alloc(sizeof(int64_t) * (nsub + 1) * ncols, s);
@@ -608,7 +652,7 @@ bool split_fast(const cs_column* col, unsigned char delim, int tokens, hipStream
   CS_HIP(hipMemcpyAsync(d_outs->p, outs.data(), sizeof(ColOut) * ncols, hipMemcpyHostToDevice, s));
   const int cap_col = (widest + 64 + 15) & ~15;
   if (emit2_ok) {
-    Emit2Args e2{view_of(col), dpat, tokens, cap_in, cap_col, ncols, nsub, ptr<const ColOut>(d_outs), nullptr};
+    Emit2Args e2{view_of(col), dpat, d64, dlen, tokens, cap_in, cap_col, ncols, nsub, ptr<const ColOut>(d_outs), nullptr};
 #if defined(CS_PHASE_PROF)
     Buf profbuf = dev_alloc(64, s);
     CS_HIP(hipMemsetAsync(profbuf->p, 0, 64, s));
@@ -616,14 +660,15 @@ bool split_fast(const cs_column* col, unsigned char delim, int tokens, hipStream
 #endif
     const size_t lds2 = (size_t)(cap_in + 32 + 2 * cap_col + (ws ? 2 : 1) * ncols * 64) * 4;
     if (lds2 <= 150 * 1024) {
-      if (lds2 > 48 * 1024)
-        CS_HIP(hipFuncSetAttribute(ws ? reinterpret_cast<const void*>(&k_split_emit2<true>) : reinterpret_cast<const void*>(&k_split_emit2<false>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
-      const unsigned g2 = resident_grid(ws ? reinterpret_cast<const void*>(&k_split_emit2<true>) : reinterpret_cast<const void*>(&k_split_emit2<false>), lds2, (nsub + 3) / 4);
+      const void* kern = mode == 1 ? reinterpret_cast<const void*>(&k_split_emit2<1>)
+                         : mode == 2 ? reinterpret_cast<const void*>(&k_split_emit2<2>) : reinterpret_cast<const void*>(&k_split_emit2<0>);
+      if (lds2 > 48 * 1024) CS_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+      const unsigned g2 = resident_grid(kern, lds2, (nsub + 3) / 4);
       {
         ProfScope ps("k_split_emit", s);
-        if (ws) hipLaunchKernelGGL(k_split_emit2<true>, dim3(g2), dim3(256), lds2, s, e2);
-        else hipLaunchKernelGGL(k_split_emit2<false>, dim3(g2), dim3(256), lds2, s, e2);
+        if (mode == 1) hipLaunchKernelGGL(k_split_emit2<1>, dim3(g2), dim3(256), lds2, s, e2);
+        else if (mode == 2) hipLaunchKernelGGL(k_split_emit2<2>, dim3(g2), dim3(256), lds2, s, e2);
+        else hipLaunchKernelGGL(k_split_emit2<0>, dim3(g2), dim3(256), lds2, s, e2);
       }
       CS_HIP(hipGetLastError());
       CS_HIP(hipStreamSynchronize(s));  // `outs` / `base` lifetime

@@ -608,6 +608,28 @@ def test_gpu_find_windows_and_escaped_literal_replace(orc):
         assert d.replace(pat, repl, regex=False).to_host() == want, (pat, repl)
 
 
+def test_gpu_multibyte_delimiter_split_tile_kernels(gpu_engine, oracle_engine, orc):
+    """split on a delimiter of 2..8 ASCII bytes: occurrences are taken left to right without
+    overlap (custring_view.inl:1223-1279), also when the delimiter overlaps itself."""
+    import random
+
+    rnd = random.Random(23)
+    alphabet = list("aab.,;  x") + ["é", "ab", ", ", "aa"]
+    s = ["".join(rnd.choice(alphabet) for _ in range(rnd.randint(0, 28))) for _ in range(4000)]
+    s += ["", "aa", "aaa", "aaaa", "aaaaa", ", ", "a, ", ", a", "a, , b", None, "ab" * 30, ", " * 20 + "x"]
+    o, g = oracle_engine, gpu_engine
+    for d in ("aa", ", ", "ab", "a, ", ". ", "aaa", "b.,;", ";  x", "abababab"):
+        for n in (-1, 1, 2, 5):
+            assert g.split(s, d, n) == o.split(s, d, n), (d, n)
+    rows = 100_000
+    gc, oc = gpuutil.synth(3, 0, rows), orc.synth(3, 0, rows)
+    for d in (". ", " /", "00 "):
+        got, want = gc.split(d), orc.split(oc, d)
+        assert len(got) == len(want), d
+        for a, b in zip(got, want):
+            gpuutil.assert_same(a, b, "split %r" % d)
+
+
 def test_gpu_category_table_growth(orc, monkeypatch):
     """The category build starts with a small hash table and retries with a larger one when a
     probe run gets long: force the retries with a tiny first table."""
