@@ -26,6 +26,16 @@ cases = [
  ("contains_re('\\\\bGET\\\\b')", lambda: c3.contains(r"\bGET\b", devptr=resb.data_ptr())),
  ("contains_re('[45]0[0-9] ')", lambda: c3.contains(r"[45]0[0-9] ", devptr=resb.data_ptr())),
  ("count_re('\\\\d+')", lambda: c3.count(r"\d+", devptr=resi.data_ptr())),
+ ("contains_re(GET|POST|PUT|DELETE|HEAD)", lambda: c3.contains(r"GET|POST|PUT|DELETE|HEAD", devptr=resb.data_ptr())),
+ ("contains_re('\\w+@\\w+\\.\\w+')", lambda: c3.contains(r"\w+@\w+\.\w+", devptr=resb.data_ptr())),
+ ("contains_re('\\d{4}-\\d{2}-\\d{2}')", lambda: c3.contains(r"\d{4}-\d{2}-\d{2}", devptr=resb.data_ptr())),
+ ("contains_re('/[a-z]+/[a-z]+')", lambda: c3.contains(r"/[a-z]+/[a-z]+", devptr=resb.data_ptr())),
+ ("contains_re('^(GET|POST) /a')", lambda: c3.contains(r"^(GET|POST) /a", devptr=resb.data_ptr())),
+ ("contains_re(' (4|5)\\d\\d( |$)')", lambda: c3.contains(r" (4|5)\d\d( |$)", devptr=resb.data_ptr())),
+ ("replace_re('\\s+', ' ')", lambda: c3.replace(r"\s+", " ")),
+ ("replace_re('[aeiou]', '')", lambda: c3.replace(r"[aeiou]", "")),
+ ("replace_re('(GET|POST) ', 'M ')", lambda: c3.replace(r"(GET|POST) ", "M ")),
+ ("replace_re('\\b\\d{1,3}(\\.\\d{1,3}){3}\\b','<IP>')", lambda: c3.replace(r"\b\d{1,3}(\.\d{1,3}){3}\b", "<IP>")),
  ("split(' ')", lambda: c3.split(" ")),
  ("split(' ', 2)", lambda: c3.split(" ", 2)),
  ("split()", lambda: c3.split()),
