@@ -374,6 +374,10 @@ int64_t max_span_rows(const cs_column* c, int per, hipStream_t s) {
   CS_HIP(hipStreamSynchronize(s));
   return host[0];
 }
+int64_t max_row_bytes(const cs_column* c, hipStream_t s) {
+  if (c->max_row >= 0) return c->max_row;
+  return c->max_row = max_span_rows(c, 1, s);
+}
 int64_t max_span64(const cs_column* c, hipStream_t s) {
   if (c->max_span64 >= 0) return c->max_span64;
   if (c->rows == 0) return c->max_span64 = 0;

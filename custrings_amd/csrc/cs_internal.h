@@ -84,6 +84,7 @@ struct cs_column {
   int64_t nbytes = 0;
   mutable int64_t null_count = -1;  // -1 = not counted yet
   mutable int64_t max_span64 = -1;  // max bytes spanned by 64 consecutive rows (tile kernels); -1 = unknown
+  mutable int64_t max_row = -1;     // longest row in bytes; -1 = unknown
   mutable int drops = -1;           // 1: some row is null or empty (rows create_ngrams drops), 0: none; -1 = unknown
   mutable int plain_bytes = -1;     // 1: no NUL byte and no lead byte announcing over an ASCII byte; -1 = unknown
   cs::Buf chars, offsets, validity;  // validity may be null (all valid)
@@ -126,6 +127,7 @@ int64_t count_nulls(const cs_column* c, hipStream_t s);
 // Largest byte span of 64 consecutive rows starting at a multiple of 64 (cached
 // in the column; sizes the LDS staging buffers of the tile kernels).
 int64_t max_span64(const cs_column* c, hipStream_t s);
+int64_t max_row_bytes(const cs_column* c, hipStream_t s);
 bool bytes_plain(const cs_column* c, hipStream_t s);
 // Same for tiles of `per` consecutive rows (per = 64 is the cached one).
 int64_t max_span_rows(const cs_column* c, int per, hipStream_t s);

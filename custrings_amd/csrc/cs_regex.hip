@@ -425,6 +425,7 @@ struct StreamArgs {
   int cap_in, cap_out, tbl_bytes;
   int debug;
   long long out_cap;  // bytes provisioned at out_chars (growing replacements)
+  int rows_per_tile;  // LONG variants: 64, 32 or 16
 };
 #ifndef CS_STREAM_WAVES
 #define CS_STREAM_WAVES 3
@@ -437,7 +438,8 @@ struct StreamArgs {
 // per row are kept in registers and the rows are assembled piecewise; with RESCAN a row with more
 // matches is scanned a second time during assembly (its size is known from the first scan),
 // without it such a row fails the launch and the host repeats it with the RESCAN variant.
-template <bool IN_LDS, bool REP16, bool INPLACE, bool RESCAN = false>
+// LONG: rows of up to 255 bytes keep the lean scan (a sliding 96-byte window of candidate bits).
+template <bool IN_LDS, bool REP16, bool INPLACE, bool RESCAN = false, bool LONG = false>
 __global__ void __launch_bounds__(256, CS_STREAM_WAVES) k_tdfa_replace_stream(StreamArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   uint8_t* base = reinterpret_cast<uint8_t*>(smem);
@@ -452,6 +454,8 @@ __global__ void __launch_bounds__(256, CS_STREAM_WAVES) k_tdfa_replace_stream(St
   const ColView& in = a.in;
   const int rb = a.rb;
   const bool has_r2 = (((uint32_t)D.img[30] & 255u) <= (((uint32_t)D.img[30] >> 8) & 255u));
+  // rows per tile: 64, or fewer for the long-row variants (so that the tile fits the prefetch registers)
+  const int R = LONG ? a.rows_per_tile : 64;
   const long long W = (long long)gridDim.x * 4;
   long long tile = (long long)blockIdx.x * 4 + wv;
   if (tile >= a.nsub) return;
@@ -463,9 +467,9 @@ __global__ void __launch_bounds__(256, CS_STREAM_WAVES) k_tdfa_replace_stream(St
 #pragma unroll
   for (int i = 0; i < 4 * kRepRegs; ++i)
     if (i < rb) rep[i >> 2] |= (uint32_t)a.repl[i] << (8 * (i & 3));
-  cstile::TileOffs cur = cstile::load_tile_offsets(in.offsets, in.rows, tile, lane);
+  cstile::TileOffs cur = cstile::load_tile_offsets_r(in.offsets, in.rows, tile, R, lane);
   cstile::TileOffs nxt = cur;
-  if (tile + W < a.nsub) nxt = cstile::load_tile_offsets(in.offsets, in.rows, tile + W, lane);
+  if (tile + W < a.nsub) nxt = cstile::load_tile_offsets_r(in.offsets, in.rows, tile + W, R, lane);
   cstile::TileChars pf;
 #pragma unroll
   for (int j = 0; j < cstile::kPfChunks; ++j) pf.v[j] = make_uint4(0, 0, 0, 0);
@@ -499,8 +503,8 @@ __global__ void __launch_bounds__(256, CS_STREAM_WAVES) k_tdfa_replace_stream(St
       gb = 0;
     }
     CS_PHASE_MARK(6);
-    const long long pr0 = p_tile * 64;
-    const int pn = (int)min(64ll, in.rows - pr0);
+    const long long pr0 = p_tile * R;
+    const int pn = (int)min((long long)R, in.rows - pr0);
     if (lane < pn) a.out_off[pr0 + lane] = gb + p_lo;
     if (lane == pn - 1 && pr0 + pn == in.rows) a.out_off[in.rows] = gb + p_lo + p_len;
     if (!INPLACE && gb + p_total > a.out_cap) {  // more growth than the host provisioned for
@@ -510,8 +514,8 @@ __global__ void __launch_bounds__(256, CS_STREAM_WAVES) k_tdfa_replace_stream(St
     if (!(a.debug & 4)) cstile::wave_flush_shift(a.out_chars + gb, p_total, lds_out, lane);
   };
   for (;;) {
-    const long long r0 = tile * 64;
-    const int nrows = (int)min(64ll, in.rows - r0);
+    const long long r0 = tile * R;
+    const int nrows = (int)min((long long)R, in.rows - r0);
     const long long g0 = cstile::rl64(cur.o0, 0), g1 = cstile::rl64(cur.o1, 63);
     const bool live = lane < nrows && row_is_valid(in.validity, r0 + lane);
     const int rbeg = (int)(cur.o0 - g0);
@@ -549,7 +553,7 @@ __global__ void __launch_bounds__(256, CS_STREAM_WAVES) k_tdfa_replace_stream(St
     if (has_next) {
       cur = nxt;
       cstile::issue_chars(in.chars, cstile::rl64(cur.o0, 0), cstile::rl64(cur.o1, 63), lane, pf);
-      if (tile + 2 * W < a.nsub) nxt = cstile::load_tile_offsets(in.offsets, in.rows, tile + 2 * W, lane);
+      if (tile + 2 * W < a.nsub) nxt = cstile::load_tile_offsets_r(in.offsets, in.rows, tile + 2 * W, R, lane);
     }
     cstile::wave_lds_fence();
     CS_PHASE_MARK(0);
@@ -595,14 +599,23 @@ __global__ void __launch_bounds__(256, CS_STREAM_WAVES) k_tdfa_replace_stream(St
       };
       // wave-uniform choice: the lean scan when every row of the sub-tile qualifies
       const bool lean = D.nskip > 0 && D.img[12] <= 4 && !(a.debug & 32) && !__any((odd & 0x80808080u) != 0) &&
-                        !__any(live && !vm.masks_fit());
+                        !__any(live && (LONG ? n > cstd::Tdfa::kLongBytes : !vm.masks_fit()));
       bool redo = live && !lean && a.maxrepl != 0;
       int resume = 0;
       if (lean && live && a.maxrepl != 0) {
         bool bail = false;
         uint32_t m0, m1, m2;  // candidate bits, bit i = byte i of the row
-        cstile::row_bits96(bitmap, lead + rbeg, n, m0, m1, m2);
-        vm.scan_lean_dispatch(a.maxrepl, m0, m1, m2, rec, bail);
+        if (LONG) {
+          const int p0 = lead + rbeg;
+          cstile::row_bits96(bitmap, p0, min(n, 96), m0, m1, m2);
+          auto refill = [&](int wb, uint32_t& x0, uint32_t& x1, uint32_t& x2) {
+            cstile::row_bits96(bitmap, p0 + wb, min(n - wb, 96), x0, x1, x2);
+          };
+          vm.scan_lean_dispatch_long(a.maxrepl, m0, m1, m2, rec, bail, refill);
+        } else {
+          cstile::row_bits96(bitmap, lead + rbeg, n, m0, m1, m2);
+          vm.scan_lean_dispatch(a.maxrepl, m0, m1, m2, rec, bail);
+        }
         redo = bail;
         resume = vm.lean_resume_from;
       }
@@ -716,8 +729,9 @@ struct ScanStreamArgs {
   unsigned long long* found;
   long long nsub;
   int cap_in, tbl_bytes;
+  int rows_per_tile;  // LONG variant: 64, 32 or 16
 };
-template <int MODE, bool IN_LDS>
+template <int MODE, bool IN_LDS, bool LONG = false>
 __global__ void __launch_bounds__(256) k_tdfa_scan_stream(ScanStreamArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   uint8_t* base = reinterpret_cast<uint8_t*>(smem);
@@ -730,22 +744,23 @@ __global__ void __launch_bounds__(256) k_tdfa_scan_stream(ScanStreamArgs a) {
   const csvm::ProgView& P = c.P;
   const ColView& in = a.in;
   const bool has_r2 = (((uint32_t)D.img[30] & 255u) <= (((uint32_t)D.img[30] >> 8) & 255u));
+  const int R = LONG ? a.rows_per_tile : 64;
   const long long waves = (long long)gridDim.x * 4;
   const long long per = (a.nsub + waves - 1) / waves;
   long long tile = ((long long)blockIdx.x * 4 + wv) * per;
   const long long tile_end = min(a.nsub, tile + per);
   if (tile >= tile_end) return;
-  cstile::TileOffs cur = cstile::load_tile_offsets(in.offsets, in.rows, tile, lane);
+  cstile::TileOffs cur = cstile::load_tile_offsets_r(in.offsets, in.rows, tile, R, lane);
   cstile::TileOffs nxt = cur;
-  if (tile + 1 < tile_end) nxt = cstile::load_tile_offsets(in.offsets, in.rows, tile + 1, lane);
+  if (tile + 1 < tile_end) nxt = cstile::load_tile_offsets_r(in.offsets, in.rows, tile + 1, R, lane);
   cstile::TileChars pf;
 #pragma unroll
   for (int j = 0; j < cstile::kPfChunks; ++j) pf.v[j] = make_uint4(0, 0, 0, 0);
   cstile::issue_chars(in.chars, cstile::rl64(cur.o0, 0), cstile::rl64(cur.o1, 63), lane, pf);
   int hits = 0;
   for (;;) {
-    const long long r0 = tile * 64;
-    const int nrows = (int)min(64ll, in.rows - r0);
+    const long long r0 = tile * R;
+    const int nrows = (int)min((long long)R, in.rows - r0);
     const long long g0 = cstile::rl64(cur.o0, 0), g1 = cstile::rl64(cur.o1, 63);
     const bool live = lane < nrows && row_is_valid(in.validity, r0 + lane);
     const int rbeg = (int)(cur.o0 - g0);
@@ -775,18 +790,29 @@ __global__ void __launch_bounds__(256) k_tdfa_scan_stream(ScanStreamArgs a) {
     if (has_next) {
       cur = nxt;
       cstile::issue_chars(in.chars, cstile::rl64(cur.o0, 0), cstile::rl64(cur.o1, 63), lane, pf);
-      if (tile + 2 < tile_end) nxt = cstile::load_tile_offsets(in.offsets, in.rows, tile + 2, lane);
+      if (tile + 2 < tile_end) nxt = cstile::load_tile_offsets_r(in.offsets, in.rows, tile + 2, R, lane);
     }
     cstile::wave_lds_fence();
     int v = 0;
     {
       cstd::Tdfa vm(D, P, lds_in + lead + rbeg, n, (lead + rbeg) & 3);
-      const bool lean = D.nskip > 0 && D.img[12] <= 4 && !__any((odd & 0x80808080u) != 0) && !__any(live && !vm.masks_fit());
+      const bool lean = D.nskip > 0 && D.img[12] <= 4 && !__any((odd & 0x80808080u) != 0) &&
+                        !__any(live && (LONG ? n > cstd::Tdfa::kLongBytes : !vm.masks_fit()));
       bool redo = live && !lean;
       if (lean && live) {
         uint32_t m0, m1, m2;
-        cstile::row_bits96(bitmap, lead + rbeg, n, m0, m1, m2);
-        v = vm.scan_lean_count<MODE == 2 ? cstd::Tdfa::K_COUNT : cstd::Tdfa::K_CONTAINS>(m0, m1, m2);
+        constexpr int KIND = MODE == 2 ? cstd::Tdfa::K_COUNT : cstd::Tdfa::K_CONTAINS;
+        if (LONG) {
+          const int p0 = lead + rbeg;
+          cstile::row_bits96(bitmap, p0, min(n, 96), m0, m1, m2);
+          auto refill = [&](int wb, uint32_t& x0, uint32_t& x1, uint32_t& x2) {
+            cstile::row_bits96(bitmap, p0 + wb, min(n - wb, 96), x0, x1, x2);
+          };
+          v = vm.template scan_lean_count_long<KIND>(m0, m1, m2, refill);
+        } else {
+          cstile::row_bits96(bitmap, lead + rbeg, n, m0, m1, m2);
+          v = vm.scan_lean_count<KIND>(m0, m1, m2);
+        }
         redo = v < 0;
       }
       if (__any(redo)) {
@@ -877,6 +903,28 @@ Plan plan(cs_regex* re, int64_t rows, hipStream_t s) {
   return pl;
 }
 
+// Rows per tile and staging capacity for the stream kernels: 64 rows when their widest span fits
+// the prefetch registers and no row outgrows the 96-byte candidate masks; otherwise the long-row
+// variants (rows up to 255 bytes) with 64, 32 or 16 rows per tile.  R == 0: no stream kernel.
+struct TileChoice {
+  int R, cap;
+  bool lng;
+};
+TileChoice choose_tile(const cs_column* col, hipStream_t s) {
+  const int64_t longest = max_row_bytes(col, s);
+  auto cap_of = [](int64_t span) { return (int64_t)((span + 15 + 32 + 127) & ~(int64_t)127); };
+  const int64_t cap64 = cap_of(max_span64(col, s));
+  const bool fits64 = cap64 <= cstile::kPfBytes;
+  if (fits64 && longest + 3 <= cstd::Tdfa::kMaskBytes) return {64, (int)cap64, false};
+  if (longest > cstd::Tdfa::kLongBytes) return {fits64 ? 64 : 0, (int)cap64, false};  // (such tiles scan generically)
+  if (fits64) return {64, (int)cap64, true};
+  for (int r : {32, 16}) {
+    const int64_t c = cap_of(max_span_rows(col, r, s));
+    if (c <= cstile::kPfBytes) return {r, (int)c, true};
+  }
+  return {0, (int)cap64, false};
+}
+
 template <int MODE>
 void scan(const cs_column* col, cs_regex* re, uint8_t* out8, int32_t* out32, int on_device, hipStream_t s,
           int64_t* found, const char* name) {
@@ -900,10 +948,10 @@ void scan(const cs_column* col, cs_regex* re, uint8_t* out8, int32_t* out32, int
   RowSrc src{view_of(col), d_unicode_flags(), col->nbytes + (col->chars && col->chars->capacity ? 64 : 0)};
   bool streamed = false;
   if (tdfa && tp.d.in_lds && MODE != 1 && !getenv("CS_REGEX_ROWWISE")) {
-    const int64_t span = max_span64(col, s);
-    const int cap = (int)((span + 15 + 32 + 127) & ~(int64_t)127);
+    const TileChoice tc = choose_tile(col, s);
+    const int cap = tc.cap;
     const size_t lds = tp.lds_bytes + (size_t)(cap + 32 + (cap >> 3) + 32) * 4;
-    if (cap <= cstile::kPfBytes && lds <= 150 * 1024) {
+    if (tc.R && lds <= 150 * 1024) {
       ScanStreamArgs sa{};
       sa.in = view_of(col);
       sa.flags = d_unicode_flags();
@@ -911,10 +959,11 @@ void scan(const cs_column* col, cs_regex* re, uint8_t* out8, int32_t* out32, int
       sa.out8 = out8;
       sa.out32 = out32;
       sa.found = ptr<unsigned long long>(cnt);
-      sa.nsub = (col->rows + 63) / 64;
+      sa.nsub = (col->rows + tc.R - 1) / tc.R;
+      sa.rows_per_tile = tc.R;
       sa.cap_in = cap;
       sa.tbl_bytes = (int)tp.lds_bytes;
-      auto kern = &k_tdfa_scan_stream<MODE == 2 ? 2 : 0, true>;
+      auto kern = tc.lng ? &k_tdfa_scan_stream<MODE == 2 ? 2 : 0, true, true> : &k_tdfa_scan_stream<MODE == 2 ? 2 : 0, true, false>;
       if (lds > 48 * 1024)
         CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       const unsigned grid = resident_grid(reinterpret_cast<const void*>(kern), lds, (sa.nsub + 3) / 4);
@@ -1048,8 +1097,8 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
       const int64_t rows = col->rows;
       const int64_t ntiles = (rows + cstile::kTileRows - 1) / cstile::kTileRows;
       const int64_t nsub = ntiles * 4;
-      const int64_t span = max_span64(col, s);
-      const int cap = (int)((span + 15 + 32 + 127) & ~(int64_t)127);
+      const TileChoice tc = choose_tile(col, s);
+      const int cap = tc.cap;
       const size_t tbl = tp.d.in_lds ? tp.lds_bytes : 0;
       size_t lds = tbl + (size_t)(cap + cap + 64 + (cap >> 3) + 32) * 4 + 16;
       // persistent stream kernel (grid = what is resident at once); returns its error word, or -1
@@ -1078,7 +1127,8 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
         sa.out_off = ptr<int64_t>(out_off);
         sa.out_chars = ptr<uint8_t>(out_chars);
         sa.out_cap = col->nbytes + extra;
-        const int64_t nsub1 = (rows + 63) / 64;
+        const int64_t nsub1 = (rows + tc.R - 1) / tc.R;
+        sa.rows_per_tile = tc.R;
         Buf status = dev_alloc(sizeof(cstile::u64) * nsub1 + 128, s);
         CS_HIP(hipMemsetAsync(status->p, 0, sizeof(cstile::u64) * nsub1 + 128, s));
         sa.status = ptr<cstile::u64>(status);
@@ -1088,10 +1138,15 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
         sa.cap_out = cap_out;
         sa.tbl_bytes = (int)tbl;
         sa.debug = getenv("CS_TILE_DEBUG") ? atoi(getenv("CS_TILE_DEBUG")) : 0;
+        auto pick2 = [&](auto inplace, auto rescan, auto lng) {
+          constexpr bool IP = decltype(inplace)::value, RS = decltype(rescan)::value, LG = decltype(lng)::value;
+          return rb > 8 ? (tp.d.in_lds ? &k_tdfa_replace_stream<true, true, IP, RS, LG> : &k_tdfa_replace_stream<false, true, IP, RS, LG>)
+                        : (tp.d.in_lds ? &k_tdfa_replace_stream<true, false, IP, RS, LG> : &k_tdfa_replace_stream<false, false, IP, RS, LG>);
+        };
+        // rows beyond the 96-byte candidate masks (and up to 255 bytes) take the sliding-window form
+        const bool lng = tc.lng;
         auto pick = [&](auto inplace, auto rescan) {
-          constexpr bool IP = decltype(inplace)::value, RS = decltype(rescan)::value;
-          return rb > 8 ? (tp.d.in_lds ? &k_tdfa_replace_stream<true, true, IP, RS> : &k_tdfa_replace_stream<false, true, IP, RS>)
-                        : (tp.d.in_lds ? &k_tdfa_replace_stream<true, false, IP, RS> : &k_tdfa_replace_stream<false, false, IP, RS>);
+          return lng ? pick2(inplace, rescan, std::true_type{}) : pick2(inplace, rescan, std::false_type{});
         };
         auto kern = growth == 0 ? pick(std::true_type{}, std::false_type{})
                                 : roomy ? pick(std::false_type{}, std::true_type{}) : pick(std::false_type{}, std::false_type{});
@@ -1132,12 +1187,12 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
         }
         return err;
       };
-      if (lds <= 150 * 1024 && rb <= 16 && cap <= cstile::kPfBytes && !getenv("CS_TILE_OLD")) {
+      if (lds <= 150 * 1024 && rb <= 16 && tc.R && !getenv("CS_TILE_OLD")) {
         const bool roomy_first = growth > 0 && (minlen <= 2 || getenv("CS_REPLACE_ROOMY"));
         int err = stream_attempt(roomy_first);
         if (err == 2 && !roomy_first) err = stream_attempt(true);  // only ran out of room: once more, roomier
         if (err == 0) return;
-      } else if (lds <= 150 * 1024 && growth == 0) {
+      } else if (lds <= 150 * 1024 && growth == 0 && (tc.R == 64 || tc.R == 0)) {  // (cap is the 64-row capacity then)
         TileArgs ta{};
         ta.in = view_of(col);
         ta.flags = d_unicode_flags();

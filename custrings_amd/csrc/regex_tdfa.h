@@ -433,8 +433,16 @@ struct Tdfa {
     return n;
   }
   int lean_resume_from = 0;  // set with `bail`: the find() round that has to be redone starts here
-  template <int KIND, bool USES, class Emit>
-  CS_HD int scan_lean(int maxrepl, uint32_t cm0, uint32_t cm1, uint32_t cm2, Emit&& emit, bool& bail) {
+  struct NoRefill {
+    CS_HD void operator()(int, uint32_t&, uint32_t&, uint32_t&) const {}
+  };
+  // LONG: rows of up to kLongBytes bytes.  (cm0, cm1, cm2) are then a 96-byte WINDOW of the
+  // row's candidate bits starting at row offset `wb`; refill(wb, m0, m1, m2) fetches the window
+  // at a new base (the kernels keep the whole tile's bits in an LDS bitmap).
+  static constexpr int kLongBytes = 255;  // thread start offsets are kept one byte each
+  template <int KIND, bool USES, class Emit, bool LONG = false, class Refill = NoRefill>
+  CS_HD int scan_lean(int maxrepl, uint32_t cm0, uint32_t cm1, uint32_t cm2, Emit&& emit, bool& bail, Refill refill = Refill()) {
+    int wb = 0;  // LONG: row offset of bit 0 of the candidate window
     int from = 0, pos = 0, done = 0, mb = 0, me = 0;
     uint32_t matched = 0;
     uint32_t slots = 0;  // byte j = start offset of thread slot j
@@ -457,7 +465,20 @@ struct Tdfa {
     for (;;) {
       if (state < D.nskip && pos < n) {  // idle: jump to the next candidate byte
         const int entry = pos;
-        pos = first_candidate(cm0, cm1, cm2, pos, n);
+        if (LONG) {
+          for (;;) {
+            if (pos < wb || pos - wb >= 96) {  // the window does not cover pos (a new round may step back)
+              wb = pos;
+              refill(wb, cm0, cm1, cm2);
+            }
+            const int lim = n - wb < 96 ? n - wb : 96;
+            const int c = first_candidate(cm0, cm1, cm2, pos - wb, lim);
+            pos = wb + (c < lim ? c : lim);
+            if (c < lim || pos >= n) break;
+          }
+        } else {
+          pos = first_candidate(cm0, cm1, cm2, pos, n);
+        }
         if (pos > n) pos = n;
         posb = (uint32_t)pos * 0x01010101u;
         if (USES && pos > entry) {
@@ -540,6 +561,19 @@ struct Tdfa {
   CS_HD int scan_lean_dispatch(int maxrepl, uint32_t m0, uint32_t m1, uint32_t m2, Emit&& emit, bool& bail) {
     if (D.uses) return scan_lean<K_REPLACE, true>(maxrepl, m0, m1, m2, emit, bail);
     return scan_lean<K_REPLACE, false>(maxrepl, m0, m1, m2, emit, bail);
+  }
+  template <class Emit, class Refill>
+  CS_HD int scan_lean_dispatch_long(int maxrepl, uint32_t m0, uint32_t m1, uint32_t m2, Emit&& emit, bool& bail, Refill refill) {
+    if (D.uses) return scan_lean<K_REPLACE, true, Emit&, true, Refill>(maxrepl, m0, m1, m2, emit, bail, refill);
+    return scan_lean<K_REPLACE, false, Emit&, true, Refill>(maxrepl, m0, m1, m2, emit, bail, refill);
+  }
+  template <int KIND, class Refill>
+  CS_HD int scan_lean_count_long(uint32_t m0, uint32_t m1, uint32_t m2, Refill refill) {
+    bool bail = false;
+    auto none = [](int, int, int) {};
+    const int r = D.uses ? scan_lean<KIND, true, decltype(none)&, true, Refill>(0, m0, m1, m2, none, bail, refill)
+                         : scan_lean<KIND, false, decltype(none)&, true, Refill>(0, m0, m1, m2, none, bail, refill);
+    return bail ? -1 : r;
   }
   // contains_re (KIND = K_CONTAINS) / count_re (K_COUNT) on a qualifying row; -1 = the row needs
   // the generic scan (a COMPLEX transition was met)

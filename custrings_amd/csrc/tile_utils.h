@@ -238,6 +238,15 @@ __device__ __forceinline__ TileOffs load_tile_offsets(const int64_t* offsets, lo
   t.o1 = offsets[r0 + min(lane + 1, nrows)];
   return t;
 }
+// the same for tiles of R <= 64 rows (lanes beyond the tile's rows repeat its end offset)
+__device__ __forceinline__ TileOffs load_tile_offsets_r(const int64_t* offsets, long long rows, long long tile, int R, int lane) {
+  const long long r0 = tile * R;
+  const int nrows = (int)min((long long)R, rows - r0);
+  TileOffs t;
+  t.o0 = offsets[r0 + min(lane, nrows)];
+  t.o1 = offsets[r0 + min(lane + 1, nrows)];
+  return t;
+}
 // issues the loads of bytes [g0 - lead, g1) of `chars` (lead = distance to the previous
 // 16-byte boundary); nothing waits on them here
 __device__ __forceinline__ void issue_chars(const uint8_t* chars, long long g0, long long g1, int lane, TileChars& c) {

@@ -23,7 +23,7 @@ PATS = [(r"\d+\.\d+\.\d+\.\d+", "<IP>"), (r"\d", "#"), (r"[a-c]+", "xyz__"), (r"
 
 def make_column(seed):
     rng = np.random.default_rng(seed)
-    kind = seed % 6
+    kind = seed % 7
     rows = int(rng.integers(1, 40_000))
     if kind == 0:
         lens = rng.integers(0, 95, rows)
@@ -35,11 +35,13 @@ def make_column(seed):
         lens = rng.integers(0, 400, rows)
     elif kind == 4:
         lens = (rng.pareto(1.5, rows) * 20).astype(np.int64) % 7000
-    else:
+    elif kind == 5:
         lens = rng.integers(0, 64, rows) * (rng.random(rows) < 0.5)
+    else:  # rows beyond the 96-byte masks but within the long-row variants
+        lens = rng.integers(0, 250, rows)
     offs = np.zeros(rows + 1, dtype=np.int64)
     np.cumsum(lens, out=offs[1:])
-    flavour = (seed // 6) % 4
+    flavour = (seed // 7) % 4
     if flavour == 0:  # arbitrary bytes
         pool = np.array(list(b"ab1.2 3.4.5.6 x9_\t\nABc") + [0, 0xC3, 0xA9, 0xE2, 0x82, 0xAC, 0xFF, 0x80, 0x1F, 0xF0, 0x9F], dtype=np.uint8)
         chars = pool[rng.integers(0, len(pool), int(offs[-1]))]
