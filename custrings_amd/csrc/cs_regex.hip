@@ -163,6 +163,61 @@ __global__ void k_replace_re_write(RowSrc src, Launch L, const uint8_t* __restri
   }
 }
 
+// ---- extract (extract.cu:36-151): capture-group spans ------------------------------------
+// One thread per row: find() the leftmost match (list simulator), then one anchored run per
+// capture group with that group's ranges tracked (csvm::GroupVm).  The spans go to
+// begins / lens [group * rows + row] (len -1 = null row); a second kernel copies the bytes.
+// The thread lists live in a global arena (12 slots per instruction per thread), interleaved
+// across the lanes of a workgroup so the list walks coalesce.
+constexpr int kMaxGroups = 32;
+template <bool SMALL>
+__global__ void __launch_bounds__(256) k_extract_spans(RowSrc src, Launch L, int groups, int32_t* __restrict__ begins,
+                                                       int32_t* __restrict__ lens) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  Ctx c = setup(L, src.flags, smem);
+  const ColView& in = src.in;
+  const int64_t nblk = (in.rows + blockDim.x - 1) / blockDim.x;
+  for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+    const int64_t r = blk * blockDim.x + threadIdx.x;
+    if (r >= in.rows) continue;
+    int mb = 0, me = 0;
+    bool hit = false;
+    const int64_t b = in.offsets[r];
+    const int n = (int)(in.offsets[r + 1] - b);
+    if (row_is_valid(in.validity, r)) {
+      csvm::Vm<SMALL> vm(c.P, c.mem, c.stride, in.chars + b, n);
+      hit = vm.find(0, n, mb, me) > 0;
+    }
+    for (int g = 0; g < groups; ++g) {
+      int x = 0, y = -1;
+      if (hit) {
+        csvm::GroupVm<SMALL> gv(c.P, c.mem, c.stride, in.chars + b, n);
+        if (!csvm::row_group_span(gv, mb, g + 1, x, y)) y = -1;
+      }
+      begins[(int64_t)g * in.rows + r] = x;
+      lens[(int64_t)g * in.rows + r] = y < 0 ? -1 : y - x;
+    }
+  }
+}
+struct ExtractOut {
+  const int64_t* off[kMaxGroups];
+  uint8_t* chars[kMaxGroups];
+};
+// thread per row: every group's span is copied by the row's thread (spans are short)
+__global__ void __launch_bounds__(256) k_extract_write(ColView in, int groups, const int32_t* __restrict__ begins,
+                                                       const int32_t* __restrict__ lens, ExtractOut out) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= in.rows) return;
+  const uint8_t* p = in.chars + in.offsets[r];
+  for (int g = 0; g < groups; ++g) {
+    const int len = lens[(int64_t)g * in.rows + r];
+    if (len <= 0) continue;
+    const uint8_t* q = p + begins[(int64_t)g * in.rows + r];
+    uint8_t* o = out.chars[g] + out.off[g][r];
+    for (int i = 0; i < len; ++i) o[i] = q[i];
+  }
+}
+
 // ---- tagged-DFA kernels (regex_tdfa.h): tables staged in LDS, no per-thread lists ----
 struct TLaunch {
   const int32_t* tdfa;   // device image
@@ -1275,6 +1330,73 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
     CS_HIP(hipGetLastError());
     CS_HIP(hipStreamSynchronize(s));  // d_repl / arena lifetime
     *out = holder.release();
+  });
+}
+
+// NVStrings::extract(pattern, results) (NVStrings.h:682; extract.cu:69-151): one column per
+// capture group; a pattern without groups, or an empty column, yields no columns.
+int cs_extract(const cs_column* col, const cs_regex* cre, cs_stream stream, cs_column*** out_cols, int* ncols_out) {
+  return guard([&] {
+    if (!col || !cre || !out_cols || !ncols_out) fail(CS_ERR_INVALID_ARG, "null argument");
+    require_device();
+    hipStream_t s = S(stream);
+    cs_regex* re = const_cast<cs_regex*>(cre);
+    *out_cols = nullptr;
+    *ncols_out = 0;
+    const int groups = re->prog.num_groups;
+    const int64_t rows = col->rows;
+    if (groups <= 0 || rows == 0) return;
+    if (groups > kMaxGroups) fail(CS_ERR_RANGE, "extract: more than 32 capture groups");
+    upload(re, s);
+    const int ninst = (int)re->prog.insts.size();
+    Launch L{};
+    L.image = ptr<const int32_t>(re->d_image);
+    L.image_words = (int)re->image.size();
+    L.slots = csvm::gvm_slots(ninst);
+    const size_t img_bytes = (((size_t)L.image_words + 3) & ~size_t(3)) * 4;
+    L.image_in_lds = img_bytes <= kLdsBudget / 2;
+    const unsigned grid = (unsigned)std::min<int64_t>((rows + 255) / 256, 256 * 4);
+    Buf arena = dev_alloc((size_t)grid * 256 * L.slots * 4, s);
+    L.arena = ptr<uint32_t>(arena);
+    RowSrc src{view_of(col), d_unicode_flags(), col->nbytes + (col->chars && col->chars->capacity ? 64 : 0)};
+    Buf begins = dev_alloc(sizeof(int32_t) * rows * groups, s);
+    Buf lens = dev_alloc(sizeof(int32_t) * rows * groups, s);
+    {
+      ProfScope ps("k_extract_spans", s);
+      if (ninst <= 64)
+        hipLaunchKernelGGL((k_extract_spans<true>), dim3(grid), dim3(256), L.image_in_lds ? img_bytes : 0, s, src, L, groups,
+                           ptr<int32_t>(begins), ptr<int32_t>(lens));
+      else
+        hipLaunchKernelGGL((k_extract_spans<false>), dim3(grid), dim3(256), L.image_in_lds ? img_bytes : 0, s, src, L, groups,
+                           ptr<int32_t>(begins), ptr<int32_t>(lens));
+    }
+    CS_HIP(hipGetLastError());
+    std::vector<std::unique_ptr<cs_column>> cols;
+    ExtractOut eo{};
+    for (int g = 0; g < groups; ++g) {
+      auto o = std::make_unique<cs_column>();
+      o->rows = rows;
+      const int32_t* gl = ptr<int32_t>(lens) + (size_t)g * rows;
+      o->offsets = dev_alloc(sizeof(int64_t) * (rows + 1), s);
+      o->nbytes = offsets_from_lengths(gl, rows, ptr<int64_t>(o->offsets), s);
+      o->chars = dev_alloc((size_t)o->nbytes, s);
+      o->validity = validity_from_lengths(gl, rows, s);
+      eo.off[g] = o->d_offsets();
+      eo.chars[g] = ptr<uint8_t>(o->chars);
+      cols.push_back(std::move(o));
+    }
+    {
+      ProfScope ps("k_extract_write", s);
+      hipLaunchKernelGGL(k_extract_write, dim3(blocks_for(rows)), dim3(256), 0, s, view_of(col), groups, ptr<int32_t>(begins),
+                         ptr<int32_t>(lens), eo);
+    }
+    CS_HIP(hipGetLastError());
+    CS_HIP(hipStreamSynchronize(s));  // arena / span buffers
+    cs_column** arr = (cs_column**)malloc(sizeof(cs_column*) * groups);
+    if (!arr) fail(CS_ERR_ALLOC, "host allocation failed");
+    for (int g = 0; g < groups; ++g) arr[g] = cols[g].release();
+    *out_cols = arr;
+    *ncols_out = groups;
   });
 }
 

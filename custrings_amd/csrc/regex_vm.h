@@ -271,6 +271,154 @@ struct Vm {
   }
 };
 
+// ---- capture groups (regexec.inl:204-442 with groupId != 0) -------------------------------
+// The same ordered simulation with a (begin, end) range per thread instead of a start offset:
+// a thread is born with (-1, -1), LBRA / RBRA of the wanted group set begin / end to the
+// position they are expanded at (regexec.inl:296-307), END reports the range of the first
+// thread in list order (regexec.inl:425-428).  Only used anchored at a known match start
+// (dreprog::extract, regexec.inl:465-469: start window [begin, begin + 1)).
+// Scratch: 12*ninst (+ mask words) 32-bit slots per thread, interleaved like Vm's.
+CS_HD int gvm_slots(int ninst) { return 12 * ninst + (ninst > 64 ? (ninst + 31) / 32 : 0); }
+
+template <bool SMALL>
+struct GroupVm {
+  const ProgView& P;
+  uint32_t* mem;
+  int stride;
+  const uint8_t* s;
+  int n;
+  int N;
+  uint64_t seen;
+  int lst, cnt;
+  Vm<true> text;  // character decoding only (no scratch touched)
+
+  CS_HD GroupVm(const ProgView& p, uint32_t* m, int st, const uint8_t* row, int bytes)
+      : P(p), mem(m), stride(st), s(row), n(bytes), N(p.ninst), seen(0), lst(0), cnt(0), text(p, nullptr, 0, row, bytes) {}
+
+  // lists: id | begin | end, two lists each; closure stack: id | begin | end, 2*ninst deep
+  CS_HD uint32_t& id_at(int l, int k) { return mem[(l * N + k) * stride]; }
+  CS_HD uint32_t& bx_at(int l, int k) { return mem[(2 * N + l * N + k) * stride]; }
+  CS_HD uint32_t& by_at(int l, int k) { return mem[(4 * N + l * N + k) * stride]; }
+  CS_HD uint32_t& stk(int f, int k) { return mem[(6 * N + f * 2 * N + k) * stride]; }
+  CS_HD uint32_t& mask_word(int k) { return mem[(12 * N + k) * stride]; }
+
+  CS_HD void begin_list(int l) {
+    lst = l;
+    cnt = 0;
+    if (SMALL) {
+      seen = 0;
+    } else {
+      for (int k = 0; k < (N + 31) / 32; ++k) mask_word(k) = 0;
+    }
+  }
+  CS_HD bool test_and_set(int id) {
+    if (SMALL) {
+      uint64_t b = 1ull << id;
+      bool was = (seen & b) != 0;
+      seen |= b;
+      return was;
+    } else {
+      uint32_t& w = mask_word(id >> 5);
+      uint32_t b = 1u << (id & 31);
+      bool was = (w & b) != 0;
+      w |= b;
+      return was;
+    }
+  }
+  CS_HD void closure(int inst, int group, int bx, int by, int at, Char pc, Char cc) {
+    int sp = 0;
+    auto push = [&](int id, int x, int y) {
+      stk(0, sp) = (uint32_t)id;
+      stk(1, sp) = (uint32_t)x;
+      stk(2, sp) = (uint32_t)y;
+      ++sp;
+    };
+    push(inst, bx, by);
+    while (sp > 0) {
+      --sp;
+      const int id = (int)stk(0, sp), x = (int)stk(1, sp), y = (int)stk(2, sp);
+      if (test_and_set(id)) continue;
+      const int32_t* in = P.insts + 4 * id;
+      const int type = in[0];
+      switch (type) {
+        case I_OR:
+          push(in[2], x, y);  // left: lower priority, visited second
+          push(in[1], x, y);  // right: preferred
+          break;
+        case I_LBRA:
+          push(in[2], in[1] == group ? at : x, y);
+          break;
+        case I_RBRA:
+          push(in[2], x, in[1] == group ? at : y);
+          break;
+        case I_BOL:
+          if (at == 0 || ((Char)in[1] == '^' && pc == '\n')) push(in[2], x, y);
+          break;
+        case I_EOL:
+          if (cc == 0 || ((Char)in[1] == '$' && cc == '\n')) push(in[2], x, y);
+          break;
+        case I_BOW:
+        case I_NBOW:
+          if ((is_word(P, cc) != is_word(P, pc)) == (type == I_BOW)) push(in[2], x, y);
+          break;
+        default:
+          id_at(lst, cnt) = (uint32_t)id;
+          bx_at(lst, cnt) = (uint32_t)x;
+          by_at(lst, cnt) = (uint32_t)y;
+          ++cnt;
+          break;
+      }
+    }
+  }
+  // The program run from byte offset `from` only (threads are born there and nowhere else);
+  // on a match (gb, ge) is the range recorded for `group` (>= 1), byte offsets or -1.
+  CS_HD int run(int from, int group, int& gb, int& ge) {
+    int match = 0;
+    int pos = from;
+    unsigned w = 1, wn = 1;
+    Char pc = text.char_before(pos);
+    Char c = text.char_at(pos, w);
+    Char cn = c ? text.char_at(pos + (int)w, wn) : 0;
+    int cur = 0;
+    begin_list(cur);
+    for (int i = 0; P.starts[i] >= 0; ++i) closure(P.starts[i], group, -1, -1, pos, pc, c);
+    for (;;) {
+      const int ncur = cnt;
+      if (ncur == 0) break;
+      const int nxt = cur ^ 1;
+      const int npos = pos + (int)w;
+      begin_list(nxt);
+      for (int k = 0; k < ncur; ++k) {
+        const int id = (int)id_at(cur, k);
+        const int x = (int)bx_at(cur, k), y = (int)by_at(cur, k);
+        const int32_t* in = P.insts + 4 * id;
+        bool go = false;
+        const int type = in[0];
+        if (type == I_CHAR) go = (Char)in[1] == c;
+        else if (type == I_ANY) go = c != '\n';
+        else if (type == I_ANYNL) go = true;
+        else if (type == I_CCLASS) go = class_match(P, in[1], c);
+        else if (type == I_NCCLASS) go = !class_match(P, in[1], c);
+        else if (type == I_END) {
+          match = 1;
+          gb = x;
+          ge = y;
+          break;
+        }
+        if (go) closure(in[2], group, x, y, npos, c, cn);
+      }
+      if (c == 0) break;
+      pos = npos;
+      pc = c;
+      c = cn;
+      w = wn;
+      cn = c ? text.char_at(pos + (int)w, wn) : 0;
+      cur = nxt;
+    }
+    return match;
+  }
+};
+
 // ---- row-level drivers (count.cu:36-56,168-196 ; replace.cu:39-107) -----------
 template <class VM>
 CS_HD int row_contains_re(VM& vm, bool anchored) {
@@ -320,6 +468,19 @@ CS_HD void row_replace_matches(VM& vm, int maxrepl, Emit&& emit) {
     from = me;
     ++done;
   }
+}
+
+// extract.cu:36-66,139-146: the byte span [x, y) of capture group `group` (1-based) in the match
+// that starts at byte offset `mb` (found by find()); false = the row's result is null (the group
+// took no part in the match, or matched the empty string: extract.cu:144-145).
+template <class GVM>
+CS_HD bool row_group_span(GVM& g, int mb, int group, int& x, int& y) {
+  int gb = -1, ge = -1;
+  if (!g.run(mb, group, gb, ge)) return false;
+  if (gb < 0 || ge <= gb) return false;
+  x = gb;
+  y = ge;
+  return true;
 }
 
 }  // namespace csvm

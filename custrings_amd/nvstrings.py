@@ -91,7 +91,7 @@ _NOT_BUILT = (
     "len compare hash stoi stol stof stod htoi to_booleans ip2int timestamp2int cat join split_record "
     "rsplit_record partition rpartition rsplit get repeat pad ljust center rjust zfill wrap slice slice_from "
     "slice_replace insert replace_multi replace_with_backrefs fillna capitalize swapcase title index rindex "
-    "find_from rfind findall_record findall match_strings startswith endswith extract_record extract isalnum "
+    "find_from rfind findall_record findall match_strings startswith endswith extract_record isalnum "
     "isalpha isdigit isspace isdecimal isnumeric islower isupper is_empty translate sort order gather "
     "scatter scalar_scatter remove_strings add_strings copy find_multiple url_encode url_decode get_ipc_data"
 ).split()
@@ -244,6 +244,21 @@ class nvstrings:
         else:
             check(lib.cs_replace(self.m_cptr, b(pat), b(repl), int(n), None, C.byref(out)))
         return nvstrings(out.value)
+
+    # ---- extract ------------------------------------------------------------------
+    def extract(self, pat):
+        """nvstrings.py:2127-2157 -- one nvstrings per capture group (column-major)."""
+        re = _compile(pat)
+        arr = C.POINTER(C.c_void_p)()
+        ncols = C.c_int()
+        try:
+            check(lib.cs_extract(self.m_cptr, re, None, C.byref(arr), C.byref(ncols)))
+        finally:
+            lib.cs_regex_destroy(re)
+        out = [nvstrings(arr[i]) for i in range(ncols.value)]
+        if ncols.value:
+            lib.cs_free(arr)
+        return out
 
     # ---- strip --------------------------------------------------------------------
     def _strip(self, to_strip, side):

@@ -163,6 +163,13 @@ int cs_count_re(const cs_column* col, const cs_regex* re, int32_t* results, int 
 /* NVStrings::replace_re (NVStrings.h:766; replace.cu:110-189). */
 int cs_replace_re(const cs_column* col, const cs_regex* re, const char* repl, int maxrepl,
                   cs_stream stream, cs_column** out);
+/* NVStrings::extract(pattern, results) (NVStrings.h:682; extract.cu:69-151):
+ * column-major, one column per capture group; a row is null unless the
+ * pattern matches and the group's span is non-empty.  *out_cols is a malloc'd
+ * array of *ncols handles (release each, then cs_free the array); a pattern
+ * without capture groups or a column of zero rows yields *ncols = 0. */
+int cs_extract(const cs_column* col, const cs_regex* re, cs_stream stream,
+               cs_column*** out_cols, int* ncols);
 
 /* ---- category (dictionary encoding) ------------------------------------ */
 /* NVCategory::create_from_strings (NVCategory.h:107; NVCategory.cu:220-304):

@@ -136,6 +136,17 @@ class NVStrings {
     check(cs_replace_re(m_col, re.h, repl, maxrepl, nullptr, &c));
     return new NVStrings(c);
   }
+  /* NVStrings.h:682 -- one instance per capture group; returns the group count (-1: null pattern) */
+  int extract(const char* pattern, std::vector<NVStrings*>& results) {
+    if (!pattern) return -1;
+    Regex re(pattern);
+    cs_column** cols = nullptr;
+    int n = 0;
+    check(cs_extract(m_col, re.h, nullptr, &cols, &n));
+    for (int i = 0; i < n; ++i) results.push_back(new NVStrings(cols[i]));
+    if (n) cs_free(cols);
+    return n;
+  }
   /* NVStrings.h:796-808 */
   NVStrings* lstrip(const char* to_strip) { return strip_side(to_strip, 1); }
   NVStrings* strip(const char* to_strip) { return strip_side(to_strip, 0); }

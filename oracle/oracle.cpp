@@ -282,9 +282,11 @@ static bool is_word(Char c) {
   return u < 0x10000 && fl_alnum(orc_unicode_flags[u]);
 }
 
-// regexec.inl:204-442 (group id 0).  [begin,end) on entry is the window of
-// allowed START positions; on success they become the match span.
-static int nfa_run(const Prog& p, const View& v, int& begin, int& end) {
+// regexec.inl:204-442.  [begin,end) on entry is the window of allowed START
+// positions; on success they become the match span (group id 0) or the range
+// the highest-priority thread recorded for capture group `group_id`
+// (regexec.inl:268,296-307,425-428; -1 where that group took no part).
+static int nfa_run(const Prog& p, const View& v, int& begin, int& end, int group_id = 0) {
   int match = 0;
   int first_type = p.type(p.start);
   int fast = (first_type == CHAR || first_type == BOL) ? first_type : 0;
@@ -311,7 +313,7 @@ static int nfa_run(const Prog& p, const View& v, int& begin, int& end) {
       }
     }
     if ((eos < 0 || pos < eos) && match == 0)
-      for (int i = 0; p.starts[i] >= 0; ++i) cur->activate(p.starts[i], pos, -1);
+      for (int i = 0; p.starts[i] >= 0; ++i) cur->activate(p.starts[i], group_id == 0 ? pos : -1, -1);
     c = pos >= txtlen ? 0 : char_at(v, (unsigned)pos);
     // expand the non-consuming instructions until a fixed point
     bool expanded;
@@ -327,12 +329,12 @@ static int nfa_run(const Prog& p, const View& v, int& begin, int& end) {
             go = id;
             break;
           case LBRA:
-            if (p.u1(id) == 0) x = pos;
+            if (p.u1(id) == group_id) x = pos;
             go = p.u2(id);
             expanded = true;
             break;
           case RBRA:
-            if (p.u1(id) == 0) y = pos;
+            if (p.u1(id) == group_id) y = pos;
             go = p.u2(id);
             expanded = true;
             break;
@@ -384,7 +386,7 @@ static int nfa_run(const Prog& p, const View& v, int& begin, int& end) {
         case END:
           match = 1;
           begin = x;
-          end = pos;
+          end = group_id == 0 ? pos : y;
           stop = true;  // lower-priority threads are cut off
           break;
       }
@@ -739,6 +741,44 @@ orc_col* orc_replace_re(const orc_col* c, const int32_t* prog, const char* repl,
     b.close_row();
   }
   return b.finish();
+}
+
+// extract.cu:36-151 (column-major extract): one column per capture group.  Per row:
+// find() the leftmost match, then run the program again from the match start with
+// that group's id (regexec.inl:465-469: start window [begin, begin+1)); the row is
+// null unless the recorded range is non-empty (extract.cu:144-145).
+// Returns the number of groups; a pattern without groups yields no columns (extract.cu:95-100).
+int orc_extract(const orc_col* c, const int32_t* prog, orc_col*** cols_out) {
+  Prog p(prog);
+  int groups = prog[2];
+  *cols_out = nullptr;
+  if (groups <= 0 || c->rows == 0) return 0;
+  orc_col** cols = (orc_col**)malloc(sizeof(orc_col*) * groups);
+  for (int g = 0; g < groups; ++g) {
+    Builder b;
+    for (int64_t r = 0; r < c->rows; ++r) {
+      if (!c->is_valid(r)) {
+        b.add_null();
+        continue;
+      }
+      View v = make_view(*c, r);
+      int begin = 0, end = (int)v.nchars;
+      int res = re_find(p, v, begin, end);
+      if (res > 0) {
+        end = begin + 1;
+        res = nfa_run(p, v, begin, end, g + 1);
+      }
+      if (res > 0 && begin >= 0 && end > begin) {
+        unsigned s = byte_pos(v, (unsigned)begin), e = byte_pos(v, (unsigned)end);
+        b.add(v.d + s, e - s);
+      } else {
+        b.add_null();
+      }
+    }
+    cols[g] = b.finish();
+  }
+  *cols_out = cols;
+  return groups;
 }
 
 // NVCategory.cu:220-304: sort (null first, bytewise, shorter-is-less), unique, rank

@@ -1,5 +1,5 @@
 // Mirrors the reference's gtests for the hot path against the C++ host classes
-// (include/nvstrings/*.h): cpp/tests/test_split.cpp:10-46, test_replace.cpp:16-52,
+// (include/nvstrings/*.h): cpp/tests/test_split.cpp:10-46, test_extract.cpp:10-25, test_replace.cpp:16-52,
 // test_count.cu:11-101, test_strip.cpp:8-32, test_case.cpp:9-27, test_find.cu:25-76,
 // test_text.cu:15-26, python/tests/test_category.py:33-45.
 //   test_hostapi nogpu  -> checks the no-device error path only
@@ -69,6 +69,19 @@ int main(int argc, char** argv) {
     EXPECT(strs->split("s", -1, r) == 2);
     EXPECT(verify_strings(r[0], {"Héllo the", nullptr, "are ", "té", ""}));
     EXPECT(verify_strings(r[1], {"é", nullptr, "ome", "t String", nullptr}));
+    for (auto* p : r) NVStrings::destroy(p);
+    NVStrings::destroy(strs);
+  }
+  {  // extract (cpp/tests/test_extract.cpp:10-25)
+    std::vector<const char*> h{"First Last", "Joe Schmoe", "John Smith", "Jane Smith", "Beyonce", "Sting", nullptr, ""};
+    NVStrings* strs = NVStrings::create_from_array(h.data(), h.size());
+    std::vector<NVStrings*> r;
+    EXPECT(strs->extract("(\\w+) (\\w+)", r) == 2);
+    EXPECT(r.size() == 2);
+    if (r.size() == 2) {
+      EXPECT(verify_strings(r[0], {"First", "Joe", "John", "Jane", nullptr, nullptr, nullptr, nullptr}));
+      EXPECT(verify_strings(r[1], {"Last", "Schmoe", "Smith", "Smith", nullptr, nullptr, nullptr, nullptr}));
+    }
     for (auto* p : r) NVStrings::destroy(p);
     NVStrings::destroy(strs);
   }

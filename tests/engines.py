@@ -108,6 +108,9 @@ class OracleEngine:
             raise ValueError("empty pattern")
         return self.o.replace_re(Col.from_list(s), self._blob(pat), repl, n).to_list()
 
+    def extract(self, s, pat):
+        return [c.to_list() for c in self.o.extract(Col.from_list(s), self._blob(pat))]
+
     def category(self, s):
         k, v = self.o.category(Col.from_list(s))
         return k.to_list(), v.tolist()
@@ -175,6 +178,13 @@ class EmuEngine:
         re = self._re(pat)
         try:
             return self.e.replace_re(Col.from_list(s), re, repl, n).to_list()
+        finally:
+            self.e._regex_free(re)
+
+    def extract(self, s, pat):
+        re = self._re(pat)
+        try:
+            return [c.to_list() for c in self.e.extract(Col.from_list(s), re)]
         finally:
             self.e._regex_free(re)
 
@@ -265,6 +275,9 @@ class GpuEngine:
     def split(self, s, delimiter=None, n=-1):
         return [c.to_host() for c in self.col(s).split(delimiter, n)]
 
+    def extract(self, s, pat):
+        return [c.to_host() for c in self.col(s).extract(pat)]
+
     def category(self, s):
         cat = self.nvc.from_strings(self.col(s))
         return cat.keys().to_host(), cat.values()
@@ -308,6 +321,8 @@ def run_case(eng, case):
         return eng.replace_re(s, a["pat"], a["repl"], a["n"])
     if op == "split":
         return eng.split(s, a["delimiter"], a["n"])
+    if op == "extract":
+        return eng.extract(s, a["pat"])
     if op == "category":
         k, v = eng.category(s)
         return {"keys": k, "values": v}

@@ -291,6 +291,45 @@ emu_col* emu_replace_re(const emu_col* c, const emu_regex* re, const char* repl,
       });
 }
 
+// ---- extract (one column per capture group; the kernel's per-row logic) ----
+int emu_extract(const emu_col* c, const emu_regex* re, emu_col*** cols_out) {
+  csvm::ProgView P = csvm::make_view(re->image.data(), orc_unicode_flags);
+  const int groups = re->image[2];
+  *cols_out = nullptr;
+  if (groups <= 0 || c->rows == 0) return 0;
+  std::vector<uint32_t> mem((size_t)csvm::gvm_slots(P.ninst) + 1);
+  std::vector<std::vector<int>> lo(groups, std::vector<int>(c->rows, 0)), len(groups, std::vector<int>(c->rows, -1));
+  for (int64_t r = 0; r < c->rows; ++r) {
+    if (!c->ok(r)) continue;
+    int mb = 0, me = 0;
+    bool hit = false;
+    with_vm(re, c->row(r), c->len(r), [&](auto& vm) { hit = vm.find(0, vm.n, mb, me) > 0; });
+    if (!hit) continue;
+    for (int g = 0; g < groups; ++g) {
+      int x = 0, y = -1;
+      bool ok;
+      if (P.ninst <= 64) {
+        csvm::GroupVm<true> gv(P, mem.data(), 1, c->row(r), c->len(r));
+        ok = csvm::row_group_span(gv, mb, g + 1, x, y);
+      } else {
+        csvm::GroupVm<false> gv(P, mem.data(), 1, c->row(r), c->len(r));
+        ok = csvm::row_group_span(gv, mb, g + 1, x, y);
+      }
+      if (ok) {
+        lo[g][r] = x;
+        len[g][r] = y - x;
+      }
+    }
+  }
+  emu_col** cols = (emu_col**)malloc(sizeof(emu_col*) * groups);
+  for (int g = 0; g < groups; ++g)
+    cols[g] = two_pass(
+        c->rows, [&](int64_t r) { return len[g][r]; },
+        [&](int64_t r, uint8_t* o) { memcpy(o, c->row(r) + lo[g][r], (size_t)len[g][r]); });
+  *cols_out = cols;
+  return groups;
+}
+
 // ---- tokenize ----
 emu_col* emu_tokenize(const emu_col* c, const char* delim) {
   CharSet set = make_set(delim ? delim : "");

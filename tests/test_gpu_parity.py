@@ -718,3 +718,41 @@ def test_gpu_tile_kernels_on_arbitrary_bytes(monkeypatch):
             assert np.array_equal(a[0], b[0]) and a[1] == b[1], k
         else:
             assert a.same_as(b), k
+
+
+# ---- extract: capture groups through cs_extract ----------------------
+GROUP_PATTERNS = [r"(\w+) (\w+)", r"(a|ab)(c|bcd)", r"(a|b)*c", r"((a)|(b))+", r"(\d+)\.(\d+)\.(\d+)\.(\d+)", r"(a*)(b*)", r"(a+?)(a*)",
+                  r"(?:x)(y)?z", r"^(\w)(\w*)$", r"(é+)|(a)", r"((\w)\w*) ", r"(x?)(y?)(z?)", r"(.)(.)", r"(GET|POST) (/\S*)", r"(b)?a",
+                  r"no_groups", r"()a", r"(a|b|c|d|e|f|g|h){8}(x)?", "(" + "a" * 70 + ")|(b)"]
+
+
+@pytest.mark.parametrize("pat", GROUP_PATTERNS, ids=[repr(p)[:30] for p in GROUP_PATTERNS])
+def test_gpu_vs_oracle_extract(gpu_engine, oracle_engine, pat):
+    s = fuzzdata.rows(12, 700, alphabet=list("aabbc xyz_.\n019") + ["é", "ü", "😀"]) + fuzzdata.log_rows(7, 700)
+    s += ["a" * 80, "ab" * 50, "abcdefgh" * 3, None, ""]
+    assert gpu_engine.extract(s, pat) == oracle_engine.extract(s, pat)
+
+
+@pytest.mark.parametrize("rows", [1, 63, 64, 65, 257, 4097])
+def test_gpu_extract_row_counts(gpu_engine, oracle_engine, rows):
+    s = fuzzdata.log_rows(40 + rows, rows)
+    pat = r"(\w+) (/\S*) (\d+\.\d+\.\d+\.\d+)?"
+    assert gpu_engine.extract(s, pat) == oracle_engine.extract(s, pat)
+
+
+def test_gpu_extract_empty_column_and_no_groups(gpu_engine):
+    assert gpu_engine.extract([], r"(a)") == []
+    assert gpu_engine.extract(["a", None], r"a") == []
+    assert gpu_engine.extract([None, None], r"(a)(b)") == [[None, None], [None, None]]
+
+
+@pytest.mark.parametrize("first", [0, 73_000_000])
+def test_gpu_c3_extract(orc, first):
+    rows = 200_000
+    g, o = gpuutil.synth(3, first, rows), orc.synth(3, first, rows)
+    pat = r"(\d+)\.(\d+)\.\d+\.(\d+) "
+    blob = np.ascontiguousarray(engines.reference_blob(pat))
+    gc, oc = g.extract(pat), orc.extract(o, blob)
+    assert len(gc) == len(oc) == 3
+    for k, (a, b) in enumerate(zip(gc, oc)):
+        gpuutil.assert_same(a, b, "extract group %d" % (k + 1))

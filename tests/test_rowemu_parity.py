@@ -90,3 +90,42 @@ def test_tdfa_vs_oracle_on_generated_patterns(emu_engine, oracle_engine):
         emu_engine.e._regex_free(re)
     emu_engine.e.set_engine(1)
     assert converted > 100
+
+
+GROUP_PATTERNS = [r"(\w+) (\w+)", r"(a|ab)(c|bcd)", r"(a|b)*c", r"((a)|(b))+", r"(\d+)\.(\d+)\.(\d+)\.(\d+)", r"(a*)(b*)", r"(a+?)(a*)",
+                  r"(?:x)(y)?z", r"^(\w)(\w*)$", r"(é+)|(a)", r"(\bin\b)|(\ba\b)", r"((\w)\w*) ", r"(a)|(b)|(c)", r"(x?)(y?)(z?)",
+                  r"(.)(.)", r"([^ ]+) ([^ ]+) ", r"(GET|POST) (/\S*)", r"(b)?a", r"((a|b)(c|x))+", r"no_groups", r"()a"]
+
+
+@pytest.mark.parametrize("engine", [0, 1], ids=["pike", "tdfa"])
+@pytest.mark.parametrize("pat", GROUP_PATTERNS)
+def test_rowemu_vs_oracle_extract(emu_engine, oracle_engine, pat, engine):
+    """extract: the product's per-row logic (find + one anchored GroupVm run per group) vs the oracle."""
+    emu_engine.e.set_engine(engine)
+    s = fuzzdata.rows(12, 300, alphabet=list("aabbc xyz_.\n019") + ["é", "ü", "😀"]) + fuzzdata.log_rows(7, 200)
+    assert emu_engine.extract(s, pat) == oracle_engine.extract(s, pat)
+
+
+def test_rowemu_vs_oracle_extract_generated_patterns(emu_engine, oracle_engine):
+    import random
+
+    rnd = random.Random(314)
+    atoms = ["a", "b", "c", "é", ".", "\\d", "\\w", "\\s", "[a-c]", "[^x ]", "(ab)", "(a|b)", "(?:c)", "\\b", "^", "$", "x", " ",
+             "(a)", "(\\w)", "(b|)", "((a)b)", "(\\d+)"]
+    quants = ["", "", "", "*", "+", "?", "*?", "+?", "{2}", "{1,3}"]
+    s = fuzzdata.rows(22, 120, alphabet=list("aabbcc xx_.\n01") + ["é", "😀"]) + fuzzdata.log_rows(8, 40)
+    with_groups = 0
+    for _ in range(120):
+        pat = ""
+        n = rnd.randint(1, 5)
+        for i in range(n):
+            pat += rnd.choice(atoms) + rnd.choice(quants)
+            if rnd.random() < 0.15 and i + 1 < n:
+                pat += "|"
+        want = oracle_engine.extract(s, pat)
+        with_groups += len(want) > 0
+        for engine in (0, 1):
+            emu_engine.e.set_engine(engine)
+            assert emu_engine.extract(s, pat) == want, (pat, engine)
+    emu_engine.e.set_engine(1)
+    assert with_groups > 60
