@@ -319,6 +319,49 @@ __global__ void __launch_bounds__(256) k_tdfa_replace_write(RowSrc src, TLaunch 
   }
 }
 
+// extract with the leftmost match found by the tagged DFA (table in LDS); only rows that hold a
+// match run the list simulation, and only from the match start
+template <bool IN_LDS, bool SMALL>
+__global__ void __launch_bounds__(256) k_extract_spans_tdfa(RowSrc src, TLaunch TL, Launch L, int groups, int use_fast,
+                                                            int32_t* __restrict__ begins, int32_t* __restrict__ lens) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  TCtx c = tsetup<IN_LDS>(TL, src.flags, smem);
+  uint32_t* mem = L.arena + (size_t)blockIdx.x * blockDim.x * L.slots + threadIdx.x;
+  // the head of every thread's lists and closure stack in LDS, behind the DFA table
+  uint32_t* region = smem + (IN_LDS ? ((TL.tdfa_words + 3) & ~3) : 0);
+  uint32_t* fast = use_fast ? region + threadIdx.x : nullptr;
+  if (L.image_in_lds) {  // the program image behind the fast region: the list simulation fetches an instruction per step
+    uint32_t* img = region + (use_fast ? 256 * csvm::GroupVm<true>::kFastSlots : 0);
+    for (int i = threadIdx.x; i < L.image_words; i += blockDim.x) img[i] = (uint32_t)L.image[i];
+    __syncthreads();
+    c.P = csvm::make_view((const int32_t*)img, src.flags);
+  }
+  const ColView& in = src.in;
+  const int64_t nblk = (in.rows + blockDim.x - 1) / blockDim.x;
+  for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+    const int64_t r = blk * blockDim.x + threadIdx.x;
+    if (r >= in.rows) continue;
+    int mb = 0, me = 0;
+    bool hit = false;
+    const int64_t b = in.offsets[r];
+    const int n = (int)(in.offsets[r + 1] - b);
+    if (row_is_valid(in.validity, r)) {
+      cstd::Tdfa vm(c.D, c.P, in.chars + b, n);
+      vm.wide_ok = (b & ~(int64_t)3) + cstd::Tdfa::kMaskBytes <= src.safe_end;
+      hit = vm.find(0, n, mb, me) > 0;
+    }
+    for (int g = 0; g < groups; ++g) {
+      int x = 0, y = -1;
+      if (hit) {
+        csvm::GroupVm<SMALL> gv(c.P, mem, blockDim.x, in.chars + b, n, fast, blockDim.x);
+        if (!csvm::row_group_span(gv, mb, g + 1, x, y)) y = -1;
+      }
+      begins[(int64_t)g * in.rows + r] = x;
+      lens[(int64_t)g * in.rows + r] = y < 0 ? -1 : y - x;
+    }
+  }
+}
+
 // ---- single-pass replace_re over row tiles (tile_utils.h) -----------------------------
 // Used when the output is known not to outgrow the input (replacement no longer
 // than the shortest possible match): the output buffer is allocated at the input
@@ -1361,7 +1404,28 @@ int cs_extract(const cs_column* col, const cs_regex* cre, cs_stream stream, cs_c
     RowSrc src{view_of(col), d_unicode_flags(), col->nbytes + (col->chars && col->chars->capacity ? 64 : 0)};
     Buf begins = dev_alloc(sizeof(int32_t) * rows * groups, s);
     Buf lens = dev_alloc(sizeof(int32_t) * rows * groups, s);
-    {
+    const bool tdfa = use_tdfa(re);
+    if (tdfa) {
+      TPlan tp = tplan(re, rows, s);
+      size_t fast_bytes = (size_t)256 * csvm::GroupVm<true>::kFastSlots * 4;
+      const int use_fast = tp.lds_bytes + fast_bytes <= kLdsBudget;
+      if (!use_fast) fast_bytes = 0;
+      L.image_in_lds = tp.lds_bytes + fast_bytes + img_bytes <= kLdsBudget;
+      const size_t lds = tp.lds_bytes + fast_bytes + (L.image_in_lds ? img_bytes : 0);
+      ProfScope ps("k_extract_spans", s);
+      if (tp.d.in_lds && ninst <= 64)
+        hipLaunchKernelGGL((k_extract_spans_tdfa<true, true>), dim3(grid), dim3(256), lds, s, src, tp.d, L, groups, use_fast,
+                           ptr<int32_t>(begins), ptr<int32_t>(lens));
+      else if (tp.d.in_lds)
+        hipLaunchKernelGGL((k_extract_spans_tdfa<true, false>), dim3(grid), dim3(256), lds, s, src, tp.d, L, groups, use_fast,
+                           ptr<int32_t>(begins), ptr<int32_t>(lens));
+      else if (ninst <= 64)
+        hipLaunchKernelGGL((k_extract_spans_tdfa<false, true>), dim3(grid), dim3(256), lds, s, src, tp.d, L, groups, use_fast,
+                           ptr<int32_t>(begins), ptr<int32_t>(lens));
+      else
+        hipLaunchKernelGGL((k_extract_spans_tdfa<false, false>), dim3(grid), dim3(256), lds, s, src, tp.d, L, groups, use_fast,
+                           ptr<int32_t>(begins), ptr<int32_t>(lens));
+    } else {
       ProfScope ps("k_extract_spans", s);
       if (ninst <= 64)
         hipLaunchKernelGGL((k_extract_spans<true>), dim3(grid), dim3(256), L.image_in_lds ? img_bytes : 0, s, src, L, groups,

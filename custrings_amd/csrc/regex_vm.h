@@ -292,14 +292,30 @@ struct GroupVm {
   int lst, cnt;
   Vm<true> text;  // character decoding only (no scratch touched)
 
-  CS_HD GroupVm(const ProgView& p, uint32_t* m, int st, const uint8_t* row, int bytes)
-      : P(p), mem(m), stride(st), s(row), n(bytes), N(p.ninst), seen(0), lst(0), cnt(0), text(p, nullptr, 0, row, bytes) {}
+  // Optional fast region (LDS on the device): the first kFastList entries of either list and the
+  // first kFastStack stack entries live there, the rest in `mem`.  An anchored run keeps a handful
+  // of threads alive, so the global arena is touched only by unusual programs.
+  static constexpr int kFastList = 4, kFastStack = 6;
+  static constexpr int kFastSlots = 3 * (2 * kFastList + kFastStack);
+  uint32_t* fast = nullptr;
+  int fstride = 0;
+
+  CS_HD GroupVm(const ProgView& p, uint32_t* m, int st, const uint8_t* row, int bytes, uint32_t* fast_mem = nullptr, int fast_stride = 0)
+      : P(p), mem(m), stride(st), s(row), n(bytes), N(p.ninst), seen(0), lst(0), cnt(0), text(p, nullptr, 0, row, bytes),
+        fast(fast_mem), fstride(fast_stride) {}
 
   // lists: id | begin | end, two lists each; closure stack: id | begin | end, 2*ninst deep
-  CS_HD uint32_t& id_at(int l, int k) { return mem[(l * N + k) * stride]; }
-  CS_HD uint32_t& bx_at(int l, int k) { return mem[(2 * N + l * N + k) * stride]; }
-  CS_HD uint32_t& by_at(int l, int k) { return mem[(4 * N + l * N + k) * stride]; }
-  CS_HD uint32_t& stk(int f, int k) { return mem[(6 * N + f * 2 * N + k) * stride]; }
+  CS_HD uint32_t& list_at(int f, int l, int k) {
+    if (fast && k < kFastList) return fast[((f * 2 + l) * kFastList + k) * fstride];
+    return mem[(2 * f * N + l * N + k) * stride];
+  }
+  CS_HD uint32_t& id_at(int l, int k) { return list_at(0, l, k); }
+  CS_HD uint32_t& bx_at(int l, int k) { return list_at(1, l, k); }
+  CS_HD uint32_t& by_at(int l, int k) { return list_at(2, l, k); }
+  CS_HD uint32_t& stk(int f, int k) {
+    if (fast && k < kFastStack) return fast[(6 * kFastList + f * kFastStack + k) * fstride];
+    return mem[(6 * N + f * 2 * N + k) * stride];
+  }
   CS_HD uint32_t& mask_word(int k) { return mem[(12 * N + k) * stride]; }
 
   CS_HD void begin_list(int l) {
