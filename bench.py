@@ -200,6 +200,37 @@ def cpu_baseline(rows):
     dt = time.perf_counter() - t0
     res = {"value": round(c.chars.size / dt / 1e9, 5), "unit": "GB/s", "cores": 1, "kind": "port",
            "sample": "first %d rows of the same C3 column, split(' ') + replace_re, oracle/liboracle.so, %.1f s" % (rows, dt)}
+    # the same port on all host cores: one worker process per core (tests/cpu_worker.py), each on
+    # its own row range of the same column; all start together, aggregate bytes / wall time
+    try:
+        import subprocess
+
+        cores = len(os.sched_getaffinity(0))
+        per = max(50_000, min(250_000, rows))
+        worker = os.path.join(ROOT, "tests", "cpu_worker.py")
+        import tempfile
+
+        prog = os.path.join(tempfile.mkdtemp(prefix="cs_bench_"), "ipv4_program.npy")
+        np.save(prog, blob)
+        procs = [subprocess.Popen([sys.executable, worker, str(i * per), str(per), prog], stdin=subprocess.PIPE, stdout=subprocess.PIPE,
+                                  text=True, env=dict(os.environ, CS_CPULIBS_PREBUILT="1")) for i in range(cores)]
+        for p in procs:
+            if p.stdout.readline().strip() != "ready":
+                raise RuntimeError("cpu worker failed to start")
+        t0 = time.perf_counter()
+        for p in procs:
+            p.stdin.write("go\n")
+            p.stdin.flush()
+        total = 0
+        for p in procs:
+            total += int(p.stdout.readline().split()[1])
+        dta = time.perf_counter() - t0
+        for p in procs:
+            p.wait()
+        res["all_cores"] = {"value": round(total / dta / 1e9, 4), "unit": "GB/s", "cores": cores, "rows": per * cores,
+                            "seconds": round(dta, 1)}
+    except Exception as e:
+        res["all_cores"] = {"error": str(e)}
     try:
         import pandas as pd
 

@@ -16,6 +16,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _build(target_dir):
+    if os.environ.get("CS_CPULIBS_PREBUILT"):  # bench.py's worker processes: the parent built it already
+        return
     subprocess.run(["make", "-s", "-C", target_dir], check=True)
 
 
