@@ -362,6 +362,65 @@ __global__ void __launch_bounds__(256) k_extract_spans_tdfa(RowSrc src, TLaunch 
   }
 }
 
+// ---- findall (findall.cu:39-179): column k = every row's k-th match ------------------------
+// The per-row match counts come from the count_re kernels; this pass walks the matches again
+// (tagged DFA, or the list simulator) and leaves the first `ncols` spans in begins / lens
+// [k * rows + row]  (len -1: the row has no k-th match).  k_extract_write copies the bytes.
+__global__ void __launch_bounds__(256) k_max_i32(const int32_t* __restrict__ v, int64_t n, int* __restrict__ out) {
+  int m = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) m = max(m, v[i]);
+  for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0 && m > 0) atomicMax(out, m);
+}
+template <class VM>
+__device__ __forceinline__ void findall_row(VM& vm, int64_t r, int64_t rows, int ncols, int32_t* __restrict__ begins,
+                                            int32_t* __restrict__ lens) {
+  const int k = csvm::row_findall(vm, [&](int j, int mb, int me) {
+    begins[(int64_t)j * rows + r] = mb;
+    lens[(int64_t)j * rows + r] = me - mb;
+    return j + 1 < ncols;
+  });
+  for (int j = k; j < ncols; ++j) lens[(int64_t)j * rows + r] = -1;
+}
+template <bool IN_LDS>
+__global__ void __launch_bounds__(256) k_findall_spans_tdfa(RowSrc src, TLaunch L, int ncols, int32_t* __restrict__ begins,
+                                                            int32_t* __restrict__ lens) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  TCtx c = tsetup<IN_LDS>(L, src.flags, smem);
+  const ColView& in = src.in;
+  const int64_t nblk = (in.rows + blockDim.x - 1) / blockDim.x;
+  for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+    const int64_t r = blk * blockDim.x + threadIdx.x;
+    if (r >= in.rows) continue;
+    if (!row_is_valid(in.validity, r)) {
+      for (int j = 0; j < ncols; ++j) lens[(int64_t)j * in.rows + r] = -1;
+      continue;
+    }
+    const int64_t b = in.offsets[r];
+    cstd::Tdfa vm(c.D, c.P, in.chars + b, (int)(in.offsets[r + 1] - b));
+    vm.wide_ok = (b & ~(int64_t)3) + cstd::Tdfa::kMaskBytes <= src.safe_end;
+    findall_row(vm, r, in.rows, ncols, begins, lens);
+  }
+}
+template <bool SMALL>
+__global__ void k_findall_spans(RowSrc src, Launch L, int ncols, int32_t* __restrict__ begins, int32_t* __restrict__ lens) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  Ctx c = setup(L, src.flags, smem);
+  const ColView& in = src.in;
+  const int64_t nblk = (in.rows + blockDim.x - 1) / blockDim.x;
+  for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+    const int64_t r = blk * blockDim.x + threadIdx.x;
+    if (r >= in.rows) continue;
+    if (!row_is_valid(in.validity, r)) {
+      for (int j = 0; j < ncols; ++j) lens[(int64_t)j * in.rows + r] = -1;
+      continue;
+    }
+    const int64_t b = in.offsets[r];
+    csvm::Vm<SMALL> vm(c.P, c.mem, c.stride, in.chars + b, (int)(in.offsets[r + 1] - b));
+    findall_row(vm, r, in.rows, ncols, begins, lens);
+  }
+}
+
 // ---- single-pass replace_re over row tiles (tile_utils.h) -----------------------------
 // Used when the output is known not to outgrow the input (replacement no longer
 // than the shortest possible match): the output buffer is allocated at the input
@@ -1461,6 +1520,94 @@ int cs_extract(const cs_column* col, const cs_regex* cre, cs_stream stream, cs_c
     for (int g = 0; g < groups; ++g) arr[g] = cols[g].release();
     *out_cols = arr;
     *ncols_out = groups;
+  });
+}
+
+// NVStrings::findall(pattern, results) (NVStrings.h:943; findall.cu:99-179): column k holds each
+// row's k-th match (null where the row has fewer); no match in any row -> one all-null column.
+int cs_findall(const cs_column* col, const cs_regex* cre, cs_stream stream, cs_column*** out_cols, int* ncols_out) {
+  return guard([&] {
+    if (!col || !cre || !out_cols || !ncols_out) fail(CS_ERR_INVALID_ARG, "null argument");
+    require_device();
+    hipStream_t s = S(stream);
+    cs_regex* re = const_cast<cs_regex*>(cre);
+    *out_cols = nullptr;
+    *ncols_out = 0;
+    const int64_t rows = col->rows;
+    if (rows == 0) return;
+    // matches per row (the count_re kernels), their maximum = number of columns
+    Buf counts = dev_alloc(sizeof(int32_t) * rows, s);
+    scan<2>(col, re, nullptr, ptr<int32_t>(counts), 1, s, nullptr, "k_count_re");
+    Buf dmax = dev_alloc(8, s);
+    CS_HIP(hipMemsetAsync(dmax->p, 0, 8, s));
+    hipLaunchKernelGGL(k_max_i32, dim3((unsigned)std::min<int64_t>((rows + 255) / 256, 2048)), dim3(256), 0, s, ptr<int32_t>(counts), rows,
+                       ptr<int>(dmax));
+    int* hmax = (int*)pinned_scratch(8);
+    CS_HIP(hipMemcpyAsync(hmax, dmax->p, 4, hipMemcpyDeviceToHost, s));
+    CS_HIP(hipStreamSynchronize(s));
+    const int ncols = hmax[0];
+    counts.reset();
+    auto finish = [&](std::vector<std::unique_ptr<cs_column>>& cols) {
+      cs_column** arr = (cs_column**)malloc(sizeof(cs_column*) * cols.size());
+      if (!arr) fail(CS_ERR_ALLOC, "host allocation failed");
+      for (size_t k = 0; k < cols.size(); ++k) arr[k] = cols[k].release();
+      *out_cols = arr;
+      *ncols_out = (int)cols.size();
+    };
+    std::vector<std::unique_ptr<cs_column>> cols;
+    if (ncols == 0) {  // findall.cu:149-151
+      cols.emplace_back(make_all_null(rows, s));
+      finish(cols);
+      return;
+    }
+    RowSrc src{view_of(col), d_unicode_flags(), col->nbytes + (col->chars && col->chars->capacity ? 64 : 0)};
+    Buf begins = dev_alloc(sizeof(int32_t) * rows * ncols, s);
+    Buf lens = dev_alloc(sizeof(int32_t) * rows * ncols, s);
+    Plan pl{};
+    {
+      ProfScope ps("k_findall_spans", s);
+      if (use_tdfa(re)) {
+        TPlan tp = tplan(re, rows, s);
+        if (tp.d.in_lds)
+          hipLaunchKernelGGL(k_findall_spans_tdfa<true>, dim3(tp.grid), dim3(256), tp.lds_bytes, s, src, tp.d, ncols, ptr<int32_t>(begins),
+                             ptr<int32_t>(lens));
+        else
+          hipLaunchKernelGGL(k_findall_spans_tdfa<false>, dim3(tp.grid), dim3(256), 0, s, src, tp.d, ncols, ptr<int32_t>(begins),
+                             ptr<int32_t>(lens));
+      } else {
+        pl = plan(re, rows, s);
+        if (pl.small)
+          hipLaunchKernelGGL((k_findall_spans<true>), dim3(pl.grid), dim3(pl.threads), pl.lds_bytes, s, src, pl.d, ncols,
+                             ptr<int32_t>(begins), ptr<int32_t>(lens));
+        else
+          hipLaunchKernelGGL((k_findall_spans<false>), dim3(pl.grid), dim3(pl.threads), pl.lds_bytes, s, src, pl.d, ncols,
+                             ptr<int32_t>(begins), ptr<int32_t>(lens));
+      }
+    }
+    CS_HIP(hipGetLastError());
+    // columns, kMaxGroups at a time through the shared write kernel
+    for (int k0 = 0; k0 < ncols; k0 += kMaxGroups) {
+      const int nk = std::min(kMaxGroups, ncols - k0);
+      ExtractOut eo{};
+      for (int k = 0; k < nk; ++k) {
+        auto o = std::make_unique<cs_column>();
+        o->rows = rows;
+        const int32_t* gl = ptr<int32_t>(lens) + (size_t)(k0 + k) * rows;
+        o->offsets = dev_alloc(sizeof(int64_t) * (rows + 1), s);
+        o->nbytes = offsets_from_lengths(gl, rows, ptr<int64_t>(o->offsets), s);
+        o->chars = dev_alloc((size_t)o->nbytes, s);
+        o->validity = validity_from_lengths(gl, rows, s);
+        eo.off[k] = o->d_offsets();
+        eo.chars[k] = ptr<uint8_t>(o->chars);
+        cols.push_back(std::move(o));
+      }
+      ProfScope ps("k_extract_write", s);
+      hipLaunchKernelGGL(k_extract_write, dim3(blocks_for(rows)), dim3(256), 0, s, view_of(col), nk,
+                         ptr<int32_t>(begins) + (size_t)k0 * rows, ptr<int32_t>(lens) + (size_t)k0 * rows, eo);
+    }
+    CS_HIP(hipGetLastError());
+    CS_HIP(hipStreamSynchronize(s));
+    finish(cols);
   });
 }
 

@@ -459,6 +459,25 @@ CS_HD int row_count_re(VM& vm) {
   }
   return k;
 }
+// findall.cu:61-77: the count_re walk reporting every match span; emit(k, mb, me) returns false to stop.
+template <class VM, class Emit>
+CS_HD int row_findall(VM& vm, Emit&& emit) {
+  int k = 0, from = 0;
+  while (from <= vm.n) {
+    int mb, me;
+    if (!vm.find(from, vm.n, mb, me)) break;
+    if (!emit(k, mb, me)) return k + 1;
+    ++k;
+    if (me > mb) {
+      from = me;
+    } else {  // empty match: step one character
+      unsigned w;
+      vm.char_at(mb, w);
+      from = mb + (int)w;
+    }
+  }
+  return k;
+}
 // Walks the successive matches exactly as replace_re does; emit(mb, me) per
 // replacement, `reps` identical zero-length replacements are reported at once.
 template <class VM, class Emit>

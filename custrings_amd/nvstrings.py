@@ -91,7 +91,7 @@ _NOT_BUILT = (
     "len compare hash stoi stol stof stod htoi to_booleans ip2int timestamp2int cat join split_record "
     "rsplit_record partition rpartition rsplit get repeat pad ljust center rjust zfill wrap slice slice_from "
     "slice_replace insert replace_multi replace_with_backrefs fillna capitalize swapcase title index rindex "
-    "find_from rfind findall_record findall match_strings startswith endswith extract_record isalnum "
+    "find_from rfind findall_record match_strings startswith endswith extract_record isalnum "
     "isalpha isdigit isspace isdecimal isnumeric islower isupper is_empty translate sort order gather "
     "scatter scalar_scatter remove_strings add_strings copy find_multiple url_encode url_decode get_ipc_data"
 ).split()
@@ -253,6 +253,20 @@ class nvstrings:
         ncols = C.c_int()
         try:
             check(lib.cs_extract(self.m_cptr, re, None, C.byref(arr), C.byref(ncols)))
+        finally:
+            lib.cs_regex_destroy(re)
+        out = [nvstrings(arr[i]) for i in range(ncols.value)]
+        if ncols.value:
+            lib.cs_free(arr)
+        return out
+
+    def findall(self, pat):
+        """nvstrings.py:1921-1948 -- column k holds every row's k-th match (column-major)."""
+        re = _compile(pat)
+        arr = C.POINTER(C.c_void_p)()
+        ncols = C.c_int()
+        try:
+            check(lib.cs_findall(self.m_cptr, re, None, C.byref(arr), C.byref(ncols)))
         finally:
             lib.cs_regex_destroy(re)
         out = [nvstrings(arr[i]) for i in range(ncols.value)]

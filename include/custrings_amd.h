@@ -170,6 +170,13 @@ int cs_replace_re(const cs_column* col, const cs_regex* re, const char* repl, in
  * without capture groups or a column of zero rows yields *ncols = 0. */
 int cs_extract(const cs_column* col, const cs_regex* re, cs_stream stream,
                cs_column*** out_cols, int* ncols);
+/* NVStrings::findall(pattern, results) (NVStrings.h:943; findall.cu:99-179):
+ * column-major, column k holds every row's k-th match in count_re order; rows
+ * with fewer matches (and null rows) are null, an empty match is an empty
+ * string.  No match in any row yields one all-null column; a column of zero
+ * rows yields *ncols = 0.  Same ownership as cs_extract. */
+int cs_findall(const cs_column* col, const cs_regex* re, cs_stream stream,
+               cs_column*** out_cols, int* ncols);
 
 /* ---- category (dictionary encoding) ------------------------------------ */
 /* NVCategory::create_from_strings (NVCategory.h:107; NVCategory.cu:220-304):

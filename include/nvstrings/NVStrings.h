@@ -147,6 +147,17 @@ class NVStrings {
     if (n) cs_free(cols);
     return n;
   }
+  /* NVStrings.h:943 -- column k = every row's k-th match; returns the column count (-1: null pattern) */
+  int findall(const char* pattern, std::vector<NVStrings*>& results) {
+    if (!pattern) return -1;
+    Regex re(pattern);
+    cs_column** cols = nullptr;
+    int n = 0;
+    check(cs_findall(m_col, re.h, nullptr, &cols, &n));
+    for (int i = 0; i < n; ++i) results.push_back(new NVStrings(cols[i]));
+    if (n) cs_free(cols);
+    return n;
+  }
   /* NVStrings.h:796-808 */
   NVStrings* lstrip(const char* to_strip) { return strip_side(to_strip, 1); }
   NVStrings* strip(const char* to_strip) { return strip_side(to_strip, 0); }

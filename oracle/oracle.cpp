@@ -781,6 +781,46 @@ int orc_extract(const orc_col* c, const int32_t* prog, orc_col*** cols_out) {
   return groups;
 }
 
+// findall.cu:39-96,99-179 (column-major findall): column k holds every row's k-th match, found by
+// the count_re walk (an empty match advances one character); rows with fewer matches and null
+// rows are null, an empty match is an empty string; no match anywhere -> one all-null column.
+int orc_findall(const orc_col* c, const int32_t* prog, orc_col*** cols_out) {
+  Prog p(prog);
+  *cols_out = nullptr;
+  if (c->rows == 0) return 0;
+  std::vector<std::vector<std::pair<int, int>>> spans(c->rows);  // char positions
+  int ncols = 0;
+  for (int64_t r = 0; r < c->rows; ++r) {
+    if (!c->is_valid(r)) continue;
+    View v = make_view(*c, r);
+    int nchars = (int)v.nchars, spos = 0, epos = nchars;
+    while (spos <= nchars) {
+      if (re_find(p, v, spos, epos) <= 0) break;
+      spans[r].push_back({spos, epos});
+      spos = epos > spos ? epos : spos + 1;
+      epos = nchars;
+    }
+    ncols = std::max(ncols, (int)spans[r].size());
+  }
+  int nout = ncols ? ncols : 1;
+  orc_col** cols = (orc_col**)malloc(sizeof(orc_col*) * nout);
+  for (int k = 0; k < nout; ++k) {
+    Builder b;
+    for (int64_t r = 0; r < c->rows; ++r) {
+      if (!c->is_valid(r) || k >= (int)spans[r].size()) {
+        b.add_null();
+        continue;
+      }
+      View v = make_view(*c, r);
+      unsigned s = byte_pos(v, (unsigned)spans[r][k].first), e = byte_pos(v, (unsigned)spans[r][k].second);
+      b.add(v.d + s, e > s ? e - s : 0);
+    }
+    cols[k] = b.finish();
+  }
+  *cols_out = cols;
+  return nout;
+}
+
 // NVCategory.cu:220-304: sort (null first, bytewise, shorter-is-less), unique, rank
 static int key_cmp(const orc_col* c, int64_t a, int64_t b) {  // custring.inl:240-261
   const uint8_t *pa = c->chars.data() + c->off[a], *pb = c->chars.data() + c->off[b];

@@ -191,6 +191,7 @@ class Oracle(CpuLib):
         self._f("count_re", C.c_int64, [vp, vp, vp])
         self._f("replace_re", vp, [vp, vp, C.c_char_p, C.c_int])
         self._f("extract", C.c_int, [vp, vp, C.POINTER(C.POINTER(vp))])
+        self._f("findall", C.c_int, [vp, vp, C.POINTER(C.POINTER(vp))])
         self._f("category", vp, [vp, vp])
         self._f("ngrams", vp, [vp, C.c_uint, C.c_char_p])
         self._f("synth", vp, [C.c_int, C.c_int64, C.c_int64, C.c_uint64, C.c_int64])
@@ -213,15 +214,21 @@ class Oracle(CpuLib):
     def replace_re(self, col, blob, repl, maxrepl=-1):
         return self._unary(self._replace_re, col, blob.ctypes.data, self._b(repl), maxrepl)
 
-    def extract(self, col, blob):
+    def _columns(self, fn, col, blob):
         h = self.put(col)
         arr = C.POINTER(C.c_void_p)()
-        n = self._extract(h, blob.ctypes.data_as(C.c_void_p), C.byref(arr))
+        n = fn(h, blob.ctypes.data_as(C.c_void_p), C.byref(arr))
         cols = [self.take(arr[i]) for i in range(n)]
         if n:
             self._free(arr)
         self._col_free(h)
         return cols
+
+    def extract(self, col, blob):
+        return self._columns(self._extract, col, blob)
+
+    def findall(self, col, blob):
+        return self._columns(self._findall, col, blob)
 
     def category(self, col):
         h = self.put(col)
@@ -250,6 +257,7 @@ class RowEmu(CpuLib):
         self._f("count_re", C.c_int64, [vp, vp, vp])
         self._f("replace_re", vp, [vp, vp, C.c_char_p, C.c_int])
         self._f("extract", C.c_int, [vp, vp, C.POINTER(C.POINTER(vp))])
+        self._f("findall", C.c_int, [vp, vp, C.POINTER(C.POINTER(vp))])
         self._f("set_engine", None, [C.c_int])
         self._f("regex_tdfa_info", None, [vp, C.POINTER(C.c_int)])
 
@@ -287,15 +295,21 @@ class RowEmu(CpuLib):
     def replace_re(self, col, re, repl, maxrepl=-1):
         return self._unary(self._replace_re, col, re, self._b(repl), maxrepl)
 
-    def extract(self, col, re):
+    def _columns(self, fn, col, re):
         h = self.put(col)
         arr = C.POINTER(C.c_void_p)()
-        n = self._extract(h, re, C.byref(arr))
+        n = fn(h, re, C.byref(arr))
         cols = [self.take(arr[i]) for i in range(n)]
         if n:
             self._free(arr)
         self._col_free(h)
         return cols
+
+    def extract(self, col, re):
+        return self._columns(self._extract, col, re)
+
+    def findall(self, col, re):
+        return self._columns(self._findall, col, re)
 
 
 _REF = None

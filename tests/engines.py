@@ -111,6 +111,9 @@ class OracleEngine:
     def extract(self, s, pat):
         return [c.to_list() for c in self.o.extract(Col.from_list(s), self._blob(pat))]
 
+    def findall(self, s, pat):
+        return [c.to_list() for c in self.o.findall(Col.from_list(s), self._blob(pat))]
+
     def category(self, s):
         k, v = self.o.category(Col.from_list(s))
         return k.to_list(), v.tolist()
@@ -185,6 +188,13 @@ class EmuEngine:
         re = self._re(pat)
         try:
             return [c.to_list() for c in self.e.extract(Col.from_list(s), re)]
+        finally:
+            self.e._regex_free(re)
+
+    def findall(self, s, pat):
+        re = self._re(pat)
+        try:
+            return [c.to_list() for c in self.e.findall(Col.from_list(s), re)]
         finally:
             self.e._regex_free(re)
 
@@ -278,6 +288,9 @@ class GpuEngine:
     def extract(self, s, pat):
         return [c.to_host() for c in self.col(s).extract(pat)]
 
+    def findall(self, s, pat):
+        return [c.to_host() for c in self.col(s).findall(pat)]
+
     def category(self, s):
         cat = self.nvc.from_strings(self.col(s))
         return cat.keys().to_host(), cat.values()
@@ -323,6 +336,8 @@ def run_case(eng, case):
         return eng.split(s, a["delimiter"], a["n"])
     if op == "extract":
         return eng.extract(s, a["pat"])
+    if op == "findall":
+        return eng.findall(s, a["pat"])
     if op == "category":
         k, v = eng.category(s)
         return {"keys": k, "values": v}

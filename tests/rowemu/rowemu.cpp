@@ -330,6 +330,32 @@ int emu_extract(const emu_col* c, const emu_regex* re, emu_col*** cols_out) {
   return groups;
 }
 
+// ---- findall (column k = every row's k-th match) ----
+int emu_findall(const emu_col* c, const emu_regex* re, emu_col*** cols_out) {
+  *cols_out = nullptr;
+  if (c->rows == 0) return 0;
+  std::vector<std::vector<std::pair<int, int>>> spans(c->rows);
+  int ncols = 0;
+  for (int64_t r = 0; r < c->rows; ++r) {
+    if (!c->ok(r)) continue;
+    with_vm(re, c->row(r), c->len(r), [&](auto& vm) {
+      csvm::row_findall(vm, [&](int, int mb, int me) {
+        spans[r].push_back({mb, me});
+        return true;
+      });
+    });
+    ncols = std::max(ncols, (int)spans[r].size());
+  }
+  int nout = ncols ? ncols : 1;
+  emu_col** cols = (emu_col**)malloc(sizeof(emu_col*) * nout);
+  for (int k = 0; k < nout; ++k)
+    cols[k] = two_pass(
+        c->rows, [&](int64_t r) { return k < (int)spans[r].size() ? spans[r][k].second - spans[r][k].first : -1; },
+        [&](int64_t r, uint8_t* o) { memcpy(o, c->row(r) + spans[r][k].first, (size_t)(spans[r][k].second - spans[r][k].first)); });
+  *cols_out = cols;
+  return nout;
+}
+
 // ---- tokenize ----
 emu_col* emu_tokenize(const emu_col* c, const char* delim) {
   CharSet set = make_set(delim ? delim : "");

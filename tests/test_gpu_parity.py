@@ -756,3 +756,28 @@ def test_gpu_c3_extract(orc, first):
     assert len(gc) == len(oc) == 3
     for k, (a, b) in enumerate(zip(gc, oc)):
         gpuutil.assert_same(a, b, "extract group %d" % (k + 1))
+
+
+# ---- findall -------------------------------------------------------
+@pytest.mark.parametrize("pat", PATTERNS, ids=[repr(p)[:30] for p in PATTERNS])
+def test_gpu_vs_oracle_findall(gpu_engine, oracle_engine, pat):
+    s = fuzzdata.rows(13, 500, alphabet=list("aabbc xyz_.\n019") + ["é", "ü", "😀"]) + fuzzdata.log_rows(9, 500)
+    s += ["a" * 80, "ab" * 50, None, ""]
+    assert gpu_engine.findall(s, pat) == oracle_engine.findall(s, pat)
+
+
+def test_gpu_findall_edges(gpu_engine):
+    assert gpu_engine.findall([], "a") == []
+    assert gpu_engine.findall(["xyz", None, ""], "a") == [[None, None, None]]
+    assert gpu_engine.findall(["a1b22", None, "", "333"], r"\d+") == [["1", None, None, "333"], ["22", None, None, None]]
+
+
+@pytest.mark.parametrize("first", [0, 73_000_000])
+def test_gpu_c3_findall(orc, first):
+    rows = 200_000
+    g, o = gpuutil.synth(3, first, rows), orc.synth(3, first, rows)
+    blob = np.ascontiguousarray(engines.reference_blob(IPV4))
+    gc, oc = g.findall(IPV4), orc.findall(o, blob)
+    assert len(gc) == len(oc) == 2
+    for k, (a, b) in enumerate(zip(gc, oc)):
+        gpuutil.assert_same(a, b, "findall column %d" % k)

@@ -129,3 +129,11 @@ def test_rowemu_vs_oracle_extract_generated_patterns(emu_engine, oracle_engine):
             assert emu_engine.extract(s, pat) == want, (pat, engine)
     emu_engine.e.set_engine(1)
     assert with_groups > 60
+
+
+@pytest.mark.parametrize("engine", [0, 1], ids=["pike", "tdfa"])
+@pytest.mark.parametrize("pat", PATTERNS)
+def test_rowemu_vs_oracle_findall(emu_engine, oracle_engine, pat, engine):
+    emu_engine.e.set_engine(engine)
+    s = fuzzdata.rows(13, 200, alphabet=list("aabbc xyz_.\n019") + ["é", "ü", "😀"]) + fuzzdata.log_rows(9, 150)
+    assert emu_engine.findall(s, pat) == oracle_engine.findall(s, pat)

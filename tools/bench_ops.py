@@ -114,6 +114,10 @@ def run_c3(a, ov):
     report("C3", "contains_re(IPv4)", rows, b, b + ov * rows + rows, timed(lambda: c3.contains(IPV4, devptr=resb.data_ptr())))
     resi = torch.empty(rows, dtype=torch.int32, device="cuda")
     report("C3", "count_re(IPv4)", rows, b, b + ov * rows + 4 * rows, timed(lambda: c3.count(IPV4, devptr=resi.data_ptr())))
+    fa = c3.findall(IPV4)
+    report("C3", "findall(IPv4) -> %d columns" % len(fa), rows, b, b + ov * rows + sum(nbytes(c) for c in fa) + len(fa) * ov * rows,
+           timed(lambda: c3.findall(IPV4)))
+    del fa
     report("C3", "extract((\\d+)\\.(\\d+)\\.\\d+\\.(\\d+) ), 3 groups", rows, b, b + ov * rows + 3 * (ov * rows) + 6 * rows,
            timed(lambda: c3.extract(r"(\d+)\.(\d+)\.\d+\.(\d+) "), reps=2))
     rep = c3.replace(IPV4, "<IP>")
