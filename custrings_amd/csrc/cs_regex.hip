@@ -376,8 +376,10 @@ template <class VM>
 __device__ __forceinline__ void findall_row(VM& vm, int64_t r, int64_t rows, int ncols, int32_t* __restrict__ begins,
                                             int32_t* __restrict__ lens) {
   const int k = csvm::row_findall(vm, [&](int j, int mb, int me) {
-    begins[(int64_t)j * rows + r] = mb;
-    lens[(int64_t)j * rows + r] = me - mb;
+    if (j < ncols) {
+      begins[(int64_t)j * rows + r] = mb;
+      lens[(int64_t)j * rows + r] = me - mb;
+    }
     return j + 1 < ncols;
   });
   for (int j = k; j < ncols; ++j) lens[(int64_t)j * rows + r] = -1;
@@ -876,7 +878,7 @@ __global__ void __launch_bounds__(256, CS_STREAM_WAVES) k_tdfa_replace_stream(St
 // ---- persistent contains_re / count_re over row tiles -----------------------------------
 // Same staging as the replace kernel (contiguous tile runs per wave, next tile's chars in
 // flight), no output assembly: LDS holds the DFA table and one input tile per wave, so seven
-// workgroups fit a CU.  MODE 0 contains_re, 2 count_re.
+// workgroups fit a CU.  MODE 0 contains_re, 2 count_re, 3 findall spans (begins / lens [k * rows + row]).
 struct ScanStreamArgs {
   ColView in;
   const uint8_t* flags;
@@ -887,6 +889,9 @@ struct ScanStreamArgs {
   long long nsub;
   int cap_in, tbl_bytes;
   int rows_per_tile;  // LONG variant: 64, 32 or 16
+  int32_t* begins;    // MODE 3
+  int32_t* lens;
+  int ncols;
 };
 template <int MODE, bool IN_LDS, bool LONG = false>
 __global__ void __launch_bounds__(256) k_tdfa_scan_stream(ScanStreamArgs a) {
@@ -956,29 +961,51 @@ __global__ void __launch_bounds__(256) k_tdfa_scan_stream(ScanStreamArgs a) {
       const bool lean = D.nskip > 0 && D.img[12] <= 4 && !__any((odd & 0x80808080u) != 0) &&
                         !__any(live && (LONG ? n > cstd::Tdfa::kLongBytes : !vm.masks_fit()));
       bool redo = live && !lean;
+      int k = 0;  // MODE 3: matches reported so far
+      auto span = [&](int mb, int me, int) {
+        if (k < a.ncols) {
+          a.begins[(long long)k * in.rows + r0 + lane] = mb;
+          a.lens[(long long)k * in.rows + r0 + lane] = me - mb;
+        }
+        ++k;
+      };
       if (lean && live) {
         uint32_t m0, m1, m2;
-        constexpr int KIND = MODE == 2 ? cstd::Tdfa::K_COUNT : cstd::Tdfa::K_CONTAINS;
+        constexpr int KIND = MODE == 0 ? cstd::Tdfa::K_CONTAINS : cstd::Tdfa::K_COUNT;
         if (LONG) {
           const int p0 = lead + rbeg;
           cstile::row_bits96(bitmap, p0, min(n, 96), m0, m1, m2);
           auto refill = [&](int wb, uint32_t& x0, uint32_t& x1, uint32_t& x2) {
             cstile::row_bits96(bitmap, p0 + wb, min(n - wb, 96), x0, x1, x2);
           };
-          v = vm.template scan_lean_count_long<KIND>(m0, m1, m2, refill);
+          if (MODE == 3) v = vm.scan_lean_spans_long(m0, m1, m2, span, refill);
+          else v = vm.template scan_lean_count_long<KIND>(m0, m1, m2, refill);
         } else {
           cstile::row_bits96(bitmap, lead + rbeg, n, m0, m1, m2);
-          v = vm.scan_lean_count<KIND>(m0, m1, m2);
+          if (MODE == 3) v = vm.scan_lean_spans(m0, m1, m2, span);
+          else v = vm.template scan_lean_count<KIND>(m0, m1, m2);
         }
         redo = v < 0;
       }
       if (__any(redo)) {
-        if (redo) v = MODE == 2 ? csvm::row_count_re(vm) : csvm::row_contains_re(vm, false);
+        if (redo) {
+          if (MODE == 3) {
+            k = 0;  // (the spans reported so far are written again, identically)
+            v = csvm::row_findall(vm, [&](int, int mb, int me) {
+              span(mb, me, 1);
+              return true;
+            });
+          } else {
+            v = MODE == 2 ? csvm::row_count_re(vm) : csvm::row_contains_re(vm, false);
+          }
+        }
       }
+      if (MODE == 3 && lane < nrows)
+        for (int j = live ? k : 0; j < a.ncols; ++j) a.lens[(long long)j * in.rows + r0 + lane] = -1;
     }
     if (lane < nrows) {
       if (MODE == 2) a.out32[r0 + lane] = v;
-      else a.out8[r0 + lane] = (uint8_t)v;
+      else if (MODE == 0) a.out8[r0 + lane] = (uint8_t)v;
     }
     hits += v > 0;
     cstile::wave_lds_fence();  // the next tile overwrites lds_in
@@ -1564,7 +1591,35 @@ int cs_findall(const cs_column* col, const cs_regex* cre, cs_stream stream, cs_c
     Buf begins = dev_alloc(sizeof(int32_t) * rows * ncols, s);
     Buf lens = dev_alloc(sizeof(int32_t) * rows * ncols, s);
     Plan pl{};
-    {
+    bool streamed = false;
+    if (use_tdfa(re) && !getenv("CS_REGEX_ROWWISE")) {  // the count_re stream kernel, reporting spans
+      TPlan tp = tplan(re, rows, s);
+      const TileChoice tc = choose_tile(col, s);
+      const int cap = tc.cap;
+      const size_t lds = tp.lds_bytes + (size_t)(cap + 32 + (cap >> 3) + 32) * 4;
+      if (tp.d.in_lds && tc.R && lds <= 150 * 1024) {
+        ScanStreamArgs sa{};
+        sa.in = view_of(col);
+        sa.flags = d_unicode_flags();
+        sa.L = tp.d;
+        sa.found = ptr<unsigned long long>(dmax);  // (hit counter: not used here)
+        sa.nsub = (rows + tc.R - 1) / tc.R;
+        sa.rows_per_tile = tc.R;
+        sa.cap_in = cap;
+        sa.tbl_bytes = (int)tp.lds_bytes;
+        sa.begins = ptr<int32_t>(begins);
+        sa.lens = ptr<int32_t>(lens);
+        sa.ncols = ncols;
+        auto kern = tc.lng ? &k_tdfa_scan_stream<3, true, true> : &k_tdfa_scan_stream<3, true, false>;
+        if (lds > 48 * 1024)
+          CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        const unsigned grid = resident_grid(reinterpret_cast<const void*>(kern), lds, (sa.nsub + 3) / 4);
+        ProfScope ps("k_findall_spans", s);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, sa);
+        streamed = true;
+      }
+    }
+    if (!streamed) {
       ProfScope ps("k_findall_spans", s);
       if (use_tdfa(re)) {
         TPlan tp = tplan(re, rows, s);

@@ -527,6 +527,7 @@ struct Tdfa {
       if (!matched) return done;
       if (KIND == K_CONTAINS) return 1;
       if (KIND == K_COUNT) {
+        emit(mb, me, 1);  // (findall; count_re passes a no-op)
         ++done;
         from = me > mb ? me : mb + 1;  // empty match: step one (ASCII) character (count.cu:190-196)
         if (from > n) return done;
@@ -573,6 +574,20 @@ struct Tdfa {
     auto none = [](int, int, int) {};
     const int r = D.uses ? scan_lean<KIND, true, decltype(none)&, true, Refill>(0, m0, m1, m2, none, bail, refill)
                          : scan_lean<KIND, false, decltype(none)&, true, Refill>(0, m0, m1, m2, none, bail, refill);
+    return bail ? -1 : r;
+  }
+  // findall: the count_re walk with emit(mb, me, 1) per match; -1 = the row needs the generic scan
+  template <class Emit>
+  CS_HD int scan_lean_spans(uint32_t m0, uint32_t m1, uint32_t m2, Emit&& emit) {
+    bool bail = false;
+    const int r = D.uses ? scan_lean<K_COUNT, true>(0, m0, m1, m2, emit, bail) : scan_lean<K_COUNT, false>(0, m0, m1, m2, emit, bail);
+    return bail ? -1 : r;
+  }
+  template <class Emit, class Refill>
+  CS_HD int scan_lean_spans_long(uint32_t m0, uint32_t m1, uint32_t m2, Emit&& emit, Refill refill) {
+    bool bail = false;
+    const int r = D.uses ? scan_lean<K_COUNT, true, Emit&, true, Refill>(0, m0, m1, m2, emit, bail, refill)
+                         : scan_lean<K_COUNT, false, Emit&, true, Refill>(0, m0, m1, m2, emit, bail, refill);
     return bail ? -1 : r;
   }
   // contains_re (KIND = K_CONTAINS) / count_re (K_COUNT) on a qualifying row; -1 = the row needs
@@ -713,6 +728,7 @@ struct Tdfa {
       if (!matched) return done;
       if (KIND == K_CONTAINS || KIND == K_MATCH) return 1;
       if (KIND == K_COUNT) {
+        emit(mb, me, 1);  // (findall; count_re passes a no-op)
         ++done;
         if (me > mb) {
           from = me;
@@ -774,6 +790,35 @@ CS_HD int row_count_re(cstd::Tdfa& vm) {
   }
 #endif
   return vm.scan<cstd::Tdfa::K_COUNT>(0, [](int, int, int) {});
+}
+// findall on the flat scan loop; emit(k, mb, me) as csvm::row_findall's (its return value is not consulted:
+// the callers bound k themselves)
+template <class Emit>
+CS_HD int row_findall(cstd::Tdfa& vm, Emit&& emit) {
+#if !defined(__HIP_DEVICE_COMPILE__)
+  if (vm.lean_ok()) {  // host builds check the lean span scan against the oracle (tests/rowemu)
+    uint32_t m0, m1, m2;
+    if (vm.has_range2()) vm.build_masks_lean<true>(m0, m1, m2);
+    else vm.build_masks_lean<false>(m0, m1, m2);
+    int sb[128], se[128], k = 0;
+    const int r = vm.scan_lean_spans(m0, m1, m2, [&](int mb, int me, int) {
+      if (k < 128) {
+        sb[k] = mb;
+        se[k] = me;
+      }
+      ++k;
+    });
+    if (r >= 0 && k <= 128) {
+      for (int j = 0; j < k; ++j) emit(j, sb[j], se[j]);
+      return k;
+    }
+  }
+#endif
+  int k = 0;
+  return vm.scan<cstd::Tdfa::K_COUNT>(0, [&](int mb, int me, int) {
+    emit(k, mb, me);
+    ++k;
+  });
 }
 template <class Emit>
 CS_HD void row_replace_matches(cstd::Tdfa& vm, int maxrepl, Emit&& emit) {
