@@ -61,6 +61,7 @@ _PROTOS = {
     "cs_contains": (i32, [vp, cp, vp, i32, vp, P(i64)]),
     "cs_replace": (i32, [vp, cp, cp, i32, vp, P(vp)]),
     "cs_split": (i32, [vp, cp, i32, vp, P(P(vp)), P(i32)]),
+    "cs_rsplit": (i32, [vp, cp, i32, vp, P(P(vp)), P(i32)]),
     "cs_regex_compile": (i32, [cp, P(vp)]),
     "cs_regex_destroy": (i32, [vp]),
     "cs_regex_inst_count": (i32, [vp]),

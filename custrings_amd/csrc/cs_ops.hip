@@ -201,7 +201,24 @@ struct SplitArgs {
   const uint8_t* delim;  // nullptr = whitespace
   int nb;
   int tokens;
+  int reverse;  // rsplit: tokens located from the right
+  int ncols;    // rsplit on whitespace: the column count of the whole call (known after k_split_count)
 };
+// the row's tokens through emit(k, lo, hi), forward or (rsplit) from the right
+template <class Emit>
+__device__ __forceinline__ void split_row_tokens(const SplitArgs& a, const uint8_t* p, int n, int c, Emit&& emit) {
+  if (!a.reverse) {
+    if (a.delim) row_split_tokens(p, n, a.delim, a.nb, c, emit);
+    else row_ws_tokens(p, n, a.tokens, emit);
+  } else if (a.delim) {
+    row_rsplit_tokens(p, n, a.delim, a.nb, c, emit);
+  } else {
+    for (int k = 0; k < c; ++k) {
+      int lo, hi;
+      if (row_ws_rtoken(p, n, a.tokens, c, a.ncols, k, lo, hi)) emit(k, lo, hi);
+    }
+  }
+}
 __global__ void k_split_count(ColView in, SplitArgs a, int32_t* __restrict__ counts, int* __restrict__ max_out) {
   int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   int c = 0;
@@ -233,8 +250,7 @@ __global__ void k_split_sizes(ColView in, SplitArgs a, const int32_t* __restrict
       auto emit = [&](int k, int lo, int hi) {
         if (k < ncols) lens[(int64_t)k * rows + r] = hi - lo;
       };
-      if (a.delim) row_split_tokens(in.chars + b, n, a.delim, a.nb, c, emit);
-      else row_ws_tokens(in.chars + b, n, a.tokens, emit);
+      split_row_tokens(a, in.chars + b, n, c, emit);
     }
   }
   for (int k = 0; k < ncols; ++k) {
@@ -261,8 +277,7 @@ __global__ void k_split_write(ColView in, SplitArgs a, const int32_t* __restrict
     uint8_t* o = outs[k].chars + outs[k].offsets[r];
     for (int i = lo; i < hi; ++i) *o++ = p[i];
   };
-  if (a.delim) row_split_tokens(p, n, a.delim, a.nb, c, emit);
-  else row_ws_tokens(p, n, a.tokens, emit);
+  split_row_tokens(a, p, n, c, emit);
 }
 
 // ---- tokenize --------------------------------------------------------------------------------
@@ -546,14 +561,30 @@ int cs_replace(const cs_column* col, const char* str, const char* repl, int maxr
 }
 
 // NVStrings::split(delimiter,maxsplit,results) / split(maxsplit,results) -- split.cu:734-956
-int cs_split(const cs_column* col, const char* delimiter, int maxsplit, cs_stream stream,
-             cs_column*** out_cols, int* ncols_out) {
+static int split_impl(const cs_column* col, const char* delimiter, int maxsplit, cs_stream stream, cs_column*** out_cols,
+                      int* ncols_out, bool reverse) {
   return guard([&] {
     if (!col || !out_cols || !ncols_out) fail(CS_ERR_INVALID_ARG, "null argument");
     require_device();
     hipStream_t s = S(stream);
     const int64_t rows = col->rows;
-    SplitArgs a{nullptr, 0, maxsplit > 0 ? maxsplit + 1 : 0};
+    SplitArgs a{nullptr, 0, maxsplit > 0 ? maxsplit + 1 : 0, 0, 0};
+    if (reverse) {
+      // Without a split limit the walk from the right meets the same tokens as the walk from the left
+      // when the delimiter is whitespace, or ASCII and border-free (no proper prefix that is also a
+      // suffix: occurrences cannot overlap, and the character/byte quirk of the token count
+      // (row_ops.h) does not arise): those calls take the split kernels.  Everything else -- a
+      // limit, a delimiter that can overlap itself, a multi-byte delimiter -- is located from the
+      // right by the row-wise kernels below.
+      bool same = maxsplit <= 0;
+      if (same && delimiter) {
+        const int n = (int)strlen(delimiter);
+        same = n > 0;
+        for (int i = 0; same && i < n; ++i) same = (unsigned char)delimiter[i] < 128;
+        for (int b = 1; same && b < n; ++b) same = memcmp(delimiter, delimiter + n - b, (size_t)b) != 0;
+      }
+      a.reverse = same ? 0 : 1;
+    }
     Needle nd;
     if (delimiter) {
       nd = upload(delimiter, s);
@@ -562,7 +593,7 @@ int cs_split(const cs_column* col, const char* delimiter, int maxsplit, cs_strea
     }
     bool ascii_delim = delimiter && nd.n >= 1 && nd.n <= 8;
     for (int i = 0; ascii_delim && i < nd.n; ++i) ascii_delim = (unsigned char)delimiter[i] < 128;
-    if (!delimiter || ascii_delim) {
+    if (!a.reverse && (!delimiter || ascii_delim)) {
       std::vector<std::unique_ptr<cs_column>> fast;
       if (split_fast(col, reinterpret_cast<const unsigned char*>(delimiter), delimiter ? nd.n : 0, a.tokens, s, fast)) {
         cs_column** arr = (cs_column**)malloc(sizeof(cs_column*) * fast.size());
@@ -586,6 +617,7 @@ int cs_split(const cs_column* col, const char* delimiter, int maxsplit, cs_strea
                            ptr<int32_t>(counts), ptr<int>(mx));
       }
       ncols = read_back<int>(mx, s);
+      a.ncols = ncols;
     }
     std::vector<std::unique_ptr<cs_column>> cols;
     if (ncols == 0) {
@@ -632,6 +664,16 @@ int cs_split(const cs_column* col, const char* delimiter, int maxsplit, cs_strea
     *out_cols = arr;
     *ncols_out = (int)cols.size();
   });
+}
+
+int cs_split(const cs_column* col, const char* delimiter, int maxsplit, cs_stream stream, cs_column*** out_cols,
+             int* ncols_out) {
+  return split_impl(col, delimiter, maxsplit, stream, out_cols, ncols_out, false);
+}
+// NVStrings::rsplit(delimiter, maxsplit, results) / rsplit(maxsplit, results) -- split.cu:960-1148
+int cs_rsplit(const cs_column* col, const char* delimiter, int maxsplit, cs_stream stream, cs_column*** out_cols,
+              int* ncols_out) {
+  return split_impl(col, delimiter, maxsplit, stream, out_cols, ncols_out, true);
 }
 
 // NVText::tokenize(strs, delimiter) -- tokens.cu:123-155

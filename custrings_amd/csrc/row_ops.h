@@ -291,6 +291,61 @@ CS_HD void row_ws_tokens(const uint8_t* p, int n, int tokens, Emit&& emit) {
   }
 }
 
+// ---- rsplit (split.cu:960-1148): the forward token COUNT, tokens located from the right ----
+CS_HD int rfind_bytes(const uint8_t* p, int to, const uint8_t* needle, int nb) {  // last occurrence inside [0, to)
+  for (int m = to - nb; m >= 0; --m) {
+    int j = 0;
+    while (j < nb && p[m + j] == needle[j]) ++j;
+    if (j == nb) return m;
+  }
+  return -1;
+}
+// emit(k, lo, hi) for every column k < cnt (empty tokens included); one walk from the right:
+// token k runs from behind the k-th delimiter found from the right to the previous one; when
+// the delimiters run out early every remaining column repeats [0, hi) (split.cu:1006-1021)
+template <class Emit>
+CS_HD void row_rsplit_tokens(const uint8_t* p, int n, const uint8_t* d, int nb, int cnt, Emit&& emit) {
+  int hi = n;
+  for (int k = cnt - 1; k > 0; --k) {
+    const int m = rfind_bytes(p, hi, d, nb);
+    if (m < 0) {
+      for (int j = k; j > 0; --j) emit(j, 0, hi);
+      break;
+    }
+    emit(k, m + nb, m + nb < hi ? hi : m + nb);
+    hi = m;
+  }
+  emit(0, 0, hi);
+}
+// Whitespace rsplit, column `col` of a row holding `cnt` columns (split.cu:1098-1124 restated on
+// bytes: every byte of a multi-byte character is above ' ').  `ncols` is the column count of the
+// whole call, which the reference compares with `tokens`.  false = null in this column.
+CS_HD bool row_ws_rtoken(const uint8_t* p, int n, int tokens, int cnt, int ncols, int col, int& lo, int& hi) {
+  int c = cnt - 1, spos = 0, epos = n;
+  bool spaces = true;
+  for (int pos = n; pos > 0; --pos) {
+    const bool sp = p[pos - 1] <= 0x20;
+    if (spaces == sp) {
+      if (spaces) epos = pos - 1;
+      else spos = pos - 1;
+      continue;
+    }
+    if (!spaces) {
+      spos = 0;
+      if (ncols - c == tokens) break;
+      spos = pos;
+      if (c == col) break;
+      epos = pos - 1;
+      spos = 0;
+      --c;
+    }
+    spaces = !spaces;
+  }
+  lo = spos;
+  hi = epos;
+  return spos < epos;
+}
+
 // ---- tokenize on a set of delimiter characters -------------------------------------
 template <class Emit>
 CS_HD int row_set_tokens(const uint8_t* p, int n, const CharSet& set, Emit&& emit) {

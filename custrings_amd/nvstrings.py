@@ -89,7 +89,7 @@ def bind_cpointer(cptr, own=True):
 
 _NOT_BUILT = (
     "len compare hash stoi stol stof stod htoi to_booleans ip2int timestamp2int cat join split_record "
-    "rsplit_record partition rpartition rsplit get repeat pad ljust center rjust zfill wrap slice slice_from "
+    "rsplit_record partition rpartition get repeat pad ljust center rjust zfill wrap slice slice_from "
     "slice_replace insert replace_multi replace_with_backrefs fillna capitalize swapcase title index rindex "
     "find_from rfind findall_record match_strings startswith endswith extract_record isalnum "
     "isalpha isdigit isspace isdecimal isnumeric islower isupper is_empty translate sort order gather "
@@ -227,6 +227,15 @@ class nvstrings:
         arr = C.POINTER(C.c_void_p)()
         ncols = C.c_int()
         check(lib.cs_split(self.m_cptr, b(delimiter), int(n), None, C.byref(arr), C.byref(ncols)))
+        out = [nvstrings(arr[i]) for i in range(ncols.value)]
+        lib.cs_free(arr)
+        return out
+
+    def rsplit(self, delimiter=None, n=-1):
+        """nvstrings.py:1099-1127 -- column-major split with the tokens located from the right."""
+        arr = C.POINTER(C.c_void_p)()
+        ncols = C.c_int()
+        check(lib.cs_rsplit(self.m_cptr, b(delimiter), int(n), None, C.byref(arr), C.byref(ncols)))
         out = [nvstrings(arr[i]) for i in range(ncols.value)]
         lib.cs_free(arr)
         return out

@@ -142,6 +142,12 @@ int cs_replace(const cs_column* col, const char* str, const char* repl, int maxr
  * (release each handle, then cs_free the array). */
 int cs_split(const cs_column* col, const char* delimiter, int maxsplit, cs_stream stream,
              cs_column*** out_cols, int* ncols);
+/* NVStrings::rsplit(delimiter,maxsplit,results) and rsplit(maxsplit,results)
+ * (NVStrings.h:514,534; split.cu:960-1148): as cs_split with the tokens
+ * located from the right (the per-row token count is split's).  Same
+ * ownership of *out_cols. */
+int cs_rsplit(const cs_column* col, const char* delimiter, int maxsplit, cs_stream stream,
+              cs_column*** out_cols, int* ncols);
 void cs_free(void* p);
 
 /* ---- regex -------------------------------------------------------------- */

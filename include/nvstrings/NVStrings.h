@@ -122,6 +122,17 @@ class NVStrings {
   /* NVStrings.h:524 -- whitespace split */
   unsigned int split(int maxsplit, std::vector<NVStrings*>& results) { return split(nullptr, maxsplit, results); }
 
+  /* NVStrings.h:514,534 -- column-major split with the tokens located from the right */
+  unsigned int rsplit(const char* delimiter, int maxsplit, std::vector<NVStrings*>& results) {
+    cs_column** cols = nullptr;
+    int n = 0;
+    check(cs_rsplit(m_col, delimiter, maxsplit, nullptr, &cols, &n));
+    for (int i = 0; i < n; ++i) results.push_back(new NVStrings(cols[i]));
+    cs_free(cols);
+    return (unsigned int)n;
+  }
+  unsigned int rsplit(int maxsplit, std::vector<NVStrings*>& results) { return rsplit(nullptr, maxsplit, results); }
+
   /* NVStrings.h:714 */
   NVStrings* replace(const char* str, const char* repl, int maxrepl = -1) {
     cs_column* c = nullptr;

@@ -676,6 +676,100 @@ int orc_split(const orc_col* c, const char* delim, int maxsplit, orc_col*** cols
   *cols_out = cols;
   return nout;
 }
+// custring_view.inl:550-582 rfind(str, bytes, pos, count): last occurrence lying inside the
+// character window [pos, pos+count); -1 when there is none
+static int rfind_str(const View& v, const uint8_t* s, unsigned sbytes, unsigned pos, int count) {
+  if (!s || !sbytes) return -1;
+  int nchars = (int)v.nchars;
+  int end = (int)pos + count;
+  if (end < 0 || end > nchars) end = nchars;
+  int spos = (int)byte_pos(v, pos);
+  int epos = (int)byte_pos(v, (unsigned)end);
+  int span = (epos - spos) - (int)sbytes + 1;
+  for (int i = 0; i < span; ++i)
+    if (memcmp(v.d + epos - (int)sbytes - i, s, sbytes) == 0) return (int)char_pos(v, (unsigned)(epos - (int)sbytes - i));
+  return -1;
+}
+// split.cu:960-1053 (delimiter) and :1055-1148 (whitespace): column-major rsplit.  The token
+// COUNT is the forward one of split (same token_counter); the tokens are located from the right.
+int orc_rsplit(const orc_col* c, const char* delim, int maxsplit, orc_col*** cols_out) {
+  int tokens = maxsplit > 0 ? maxsplit + 1 : 0;
+  unsigned dbytes = delim ? (unsigned)strlen(delim) : 0;
+  int dchars = delim ? (int)count_chars((const uint8_t*)delim, dbytes) : 0;
+  std::vector<int> counts(c->rows, 0);
+  int ncols = 0;
+  for (int64_t r = 0; r < c->rows; ++r) {
+    if (!c->is_valid(r)) continue;
+    View v = make_view(*c, r);
+    counts[r] = delim ? count_delim_tokens(v, (const uint8_t*)delim, dbytes, tokens) : count_ws_tokens(v, tokens);
+    ncols = std::max(ncols, counts[r]);
+  }
+  int nout = ncols ? ncols : 1;  // split.cu:980-982
+  orc_col** cols = (orc_col**)malloc(sizeof(orc_col*) * nout);
+  for (int col = 0; col < nout; ++col) {
+    Builder b;
+    for (int64_t r = 0; r < c->rows; ++r) {
+      if (!c->is_valid(r) || col >= counts[r]) {
+        b.add_null();
+        continue;
+      }
+      View v = make_view(*c, r);
+      int dcount = counts[r];
+      int nchars = (int)v.nchars, spos = 0, epos = nchars;
+      if (delim) {
+        for (int k = dcount - 1; k > 0; --k) {  // split.cu:1006-1021
+          spos = rfind_str(v, (const uint8_t*)delim, dbytes, 0, epos);
+          if (spos < 0) {
+            spos = 0;
+            break;
+          }
+          if (k == col) {
+            spos += dchars;
+            break;
+          }
+          epos = spos;
+          spos = 0;
+        }
+        if (spos < epos) {
+          unsigned s = byte_pos(v, (unsigned)spos), e = byte_pos(v, (unsigned)epos);
+          b.add(v.d + s, e - s);
+        } else {
+          b.add(v.d, 0);  // empty, not null (split.cu:1031-1034)
+        }
+      } else {
+        int k = dcount - 1;  // split.cu:1098-1124
+        bool spaces = true;
+        for (int pos = nchars; pos > 0; --pos) {
+          Char ch = char_at(v, (unsigned)pos - 1);
+          if (spaces == (ch <= ' ')) {
+            if (spaces) epos = pos - 1;
+            else spos = pos - 1;
+            continue;
+          }
+          if (!spaces) {
+            spos = 0;
+            if ((ncols - k) == tokens) break;  // (the COLUMN count of the whole call, as the reference has it)
+            spos = pos;
+            if (k == col) break;
+            epos = pos - 1;
+            spos = 0;
+            --k;
+          }
+          spaces = !spaces;
+        }
+        if (spos < epos) {
+          unsigned s = byte_pos(v, (unsigned)spos), e = byte_pos(v, (unsigned)epos);
+          b.add(v.d + s, e - s);
+        } else {
+          b.add_null();
+        }
+      }
+    }
+    cols[col] = b.finish();
+  }
+  *cols_out = cols;
+  return nout;
+}
 void orc_free(void* p) { free(p); }
 
 // count.cu:36-56,59-110: mode 0 contains_re, 1 match (start window = [0,1))

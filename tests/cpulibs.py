@@ -95,6 +95,7 @@ class CpuLib:
         self._f("contains", C.c_int64, [vp, C.c_char_p, vp])
         self._f("replace", vp, [vp, C.c_char_p, C.c_char_p, C.c_int])
         self._f("split", C.c_int, [vp, C.c_char_p, C.c_int, C.POINTER(C.POINTER(vp))])
+        self._f("rsplit", C.c_int, [vp, C.c_char_p, C.c_int, C.POINTER(C.POINTER(vp))])
         self._f("tokenize", vp, [vp, C.c_char_p])
         del L
 
@@ -172,10 +173,13 @@ class CpuLib:
         self._col_free(h)
         return out, n
 
-    def split(self, col, delim=None, maxsplit=-1):
+    def rsplit(self, col, delim=None, maxsplit=-1):
+        return self.split(col, delim, maxsplit, fn=self._rsplit)
+
+    def split(self, col, delim=None, maxsplit=-1, fn=None):
         h = self.put(col)
         arr = C.POINTER(C.c_void_p)()
-        n = self._split(h, self._b(delim), maxsplit, C.byref(arr))
+        n = (fn or self._split)(h, self._b(delim), maxsplit, C.byref(arr))
         cols = [self.take(arr[i]) for i in range(n)]
         self._free(arr)
         self._col_free(h)

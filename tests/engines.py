@@ -91,6 +91,9 @@ class OracleEngine:
     def split(self, s, delimiter=None, n=-1):
         return [c.to_list() for c in self.o.split(Col.from_list(s), delimiter, n)]
 
+    def rsplit(self, s, delimiter=None, n=-1):
+        return [c.to_list() for c in self.o.rsplit(Col.from_list(s), delimiter, n)]
+
     def contains_re(self, s, pat):
         out, n = self.o.contains_re(Col.from_list(s), self._blob(pat), 0)
         return [bool(x) for x in out], n
@@ -155,6 +158,9 @@ class EmuEngine:
 
     def split(self, s, delimiter=None, n=-1):
         return [c.to_list() for c in self.e.split(Col.from_list(s), delimiter, n)]
+
+    def rsplit(self, s, delimiter=None, n=-1):
+        return [c.to_list() for c in self.e.rsplit(Col.from_list(s), delimiter, n)]
 
     def _re(self, pat):
         return self.e.compile(pat)
@@ -285,6 +291,9 @@ class GpuEngine:
     def split(self, s, delimiter=None, n=-1):
         return [c.to_host() for c in self.col(s).split(delimiter, n)]
 
+    def rsplit(self, s, delimiter=None, n=-1):
+        return [c.to_host() for c in self.col(s).rsplit(delimiter, n)]
+
     def extract(self, s, pat):
         return [c.to_host() for c in self.col(s).extract(pat)]
 
@@ -334,6 +343,8 @@ def run_case(eng, case):
         return eng.replace_re(s, a["pat"], a["repl"], a["n"])
     if op == "split":
         return eng.split(s, a["delimiter"], a["n"])
+    if op == "rsplit":
+        return eng.rsplit(s, a["delimiter"], a["n"])
     if op == "extract":
         return eng.extract(s, a["pat"])
     if op == "findall":

@@ -150,7 +150,15 @@ emu_col* emu_replace(const emu_col* c, const char* str, const char* repl, int ma
       });
 }
 
+static int split_any(const emu_col* c, const char* delim, int maxsplit, emu_col*** cols_out, bool reverse);
 int emu_split(const emu_col* c, const char* delim, int maxsplit, emu_col*** cols_out) {
+  return split_any(c, delim, maxsplit, cols_out, false);
+}
+// the row-wise rsplit kernels' logic (the product routes the cases that equal split to the split kernels)
+int emu_rsplit(const emu_col* c, const char* delim, int maxsplit, emu_col*** cols_out) {
+  return split_any(c, delim, maxsplit, cols_out, true);
+}
+static int split_any(const emu_col* c, const char* delim, int maxsplit, emu_col*** cols_out, bool reverse) {
   int tokens = maxsplit > 0 ? maxsplit + 1 : 0;
   int nb = delim ? (int)strlen(delim) : 0;
   std::vector<int> counts(c->rows, 0);
@@ -172,7 +180,14 @@ int emu_split(const emu_col* c, const char* delim, int maxsplit, emu_col*** cols
         hi[k][r] = b;
       }
     };
-    if (delim)
+    if (reverse && delim) {
+      row_rsplit_tokens(c->row(r), c->len(r), (const uint8_t*)delim, nb, counts[r], emit);
+    } else if (reverse) {
+      for (int k = 0; k < counts[r]; ++k) {
+        int a, b;
+        if (row_ws_rtoken(c->row(r), c->len(r), tokens, counts[r], ncols, k, a, b)) emit(k, a, b);
+      }
+    } else if (delim)
       row_split_tokens(c->row(r), c->len(r), (const uint8_t*)delim, nb, counts[r], emit);
     else
       row_ws_tokens(c->row(r), c->len(r), tokens, emit);

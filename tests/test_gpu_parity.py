@@ -781,3 +781,23 @@ def test_gpu_c3_findall(orc, first):
     assert len(gc) == len(oc) == 2
     for k, (a, b) in enumerate(zip(gc, oc)):
         gpuutil.assert_same(a, b, "findall column %d" % k)
+
+
+# ---- rsplit ---------------------------------------------------------
+@pytest.mark.parametrize("seed", [1, 2])
+def test_gpu_vs_oracle_rsplit(gpu_engine, oracle_engine, seed):
+    s = fuzzdata.rows(seed, 900) + ["a_b_c_d", "  a b  c ", "aaa", "_a_", "aaaa", "a  b", "  ", "x", None, ""]
+    o, g = oracle_engine, gpu_engine
+    for d in (None, " ", "a", "é", "ab", "éa", ",", "aa", "  ", "aba", "_"):
+        for n in (-1, 0, 1, 2, 5):
+            assert g.rsplit(s, d, n) == o.rsplit(s, d, n), (d, n)
+
+
+def test_gpu_c3_rsplit(orc):
+    rows = 200_000
+    g, o = gpuutil.synth(3, 5_000_000, rows), orc.synth(3, 5_000_000, rows)
+    for d, n in ((" ", -1), (" ", 3), (None, 2), (". ", -1)):
+        gc, oc = g.rsplit(d, n), orc.rsplit(o, d, n)
+        assert len(gc) == len(oc)
+        for k, (a, b) in enumerate(zip(gc, oc)):
+            gpuutil.assert_same(a, b, "rsplit(%r,%d) col %d" % (d, n, k))

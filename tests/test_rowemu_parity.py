@@ -137,3 +137,17 @@ def test_rowemu_vs_oracle_findall(emu_engine, oracle_engine, pat, engine):
     emu_engine.e.set_engine(engine)
     s = fuzzdata.rows(13, 200, alphabet=list("aabbc xyz_.\n019") + ["é", "ü", "😀"]) + fuzzdata.log_rows(9, 150)
     assert emu_engine.findall(s, pat) == oracle_engine.findall(s, pat)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_rowemu_vs_oracle_rsplit(emu_engine, oracle_engine, seed):
+    """rsplit: the row-wise kernels' logic against the oracle, and the routing claim of cs_rsplit
+    (no limit + whitespace or an ASCII border-free delimiter == split) on the oracle itself."""
+    s = fuzzdata.rows(seed, 600) + ["a_b_c_d", "  a b  c ", "aaa", "_a_", "aaaa", "a  b", "  ", "x"]
+    o, e = oracle_engine, emu_engine
+    for d in (None, " ", "a", "é", "ab", "éa", ",", "aa", "  ", "aba", "_"):
+        for n in (-1, 0, 1, 2, 5):
+            assert e.rsplit(s, d, n) == o.rsplit(s, d, n), (d, n)
+    for d in (None, " ", "a", "ab", ",", "_-", "abc", "xay"):
+        for n in (-1, 0):
+            assert o.rsplit(s, d, n) == o.split(s, d, n), (d, n)

@@ -123,6 +123,14 @@ def run_c3(a, ov):
     rep = c3.replace(IPV4, "<IP>")
     report("C3", "replace_re(IPv4,'<IP>')", rows, b, b + nbytes(rep) + 2 * ov * rows, timed(lambda: c3.replace(IPV4, "<IP>")))
     del rep
+    rc = c3.rsplit(" ")
+    report("C3", "rsplit(' ') (no limit: the split kernels)", rows, b, b + sum(nbytes(c) for c in rc) + (len(rc) + 1) * ov * rows,
+           timed(lambda: c3.rsplit(" ")))
+    del rc
+    rc = c3.rsplit(" ", 3)
+    report("C3", "rsplit(' ', 3) (row-wise, from the right)", rows, b, b + sum(nbytes(c) for c in rc) + (len(rc) + 1) * ov * rows,
+           timed(lambda: c3.rsplit(" ", 3), reps=2))
+    del rc
     cols = c3.split(" ")
     out_b = sum(nbytes(c) for c in cols)
     ncols = len(cols)
