@@ -27,8 +27,10 @@ struct cs_regex {
   std::vector<int32_t> blob;   // program only (ABI: cs_regex_blob)
   std::vector<int32_t> image;  // blob + executor extras
   std::vector<int32_t> tdfa;   // tagged DFA image (empty = not convertible)
+  std::vector<int32_t> gtags;  // capture-group tag image of the tagged DFA (empty = no groups / not convertible)
   Buf d_image;                 // uploaded lazily
   Buf d_tdfa;
+  Buf d_gtags;
   bool empty_pattern = false;
 };
 
@@ -358,6 +360,34 @@ __global__ void __launch_bounds__(256) k_extract_spans_tdfa(RowSrc src, TLaunch 
       }
       begins[(int64_t)g * in.rows + r] = x;
       lens[(int64_t)g * in.rows + r] = y < 0 ? -1 : y - x;
+    }
+  }
+}
+
+// extract with the group ranges carried by the tagged DFA (Tdfa::group_find): the leftmost match, then
+// one anchored DFA run per capture group -- no thread lists, no scratch memory
+template <bool IN_LDS>
+__global__ void __launch_bounds__(256) k_extract_spans_dfa(RowSrc src, TLaunch TL, const int32_t* __restrict__ gtags, int groups,
+                                                           int32_t* __restrict__ begins, int32_t* __restrict__ lens) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  TCtx c = tsetup<IN_LDS>(TL, src.flags, smem);
+  const ColView& in = src.in;
+  const int64_t nblk = (in.rows + blockDim.x - 1) / blockDim.x;
+  for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+    const int64_t r = blk * blockDim.x + threadIdx.x;
+    if (r >= in.rows) continue;
+    int mb = 0, me = 0;
+    bool hit = false;
+    const int64_t b = in.offsets[r];
+    const int n = (int)(in.offsets[r + 1] - b);
+    cstd::Tdfa vm(c.D, c.P, in.chars + b, n);
+    vm.wide_ok = (b & ~(int64_t)3) + cstd::Tdfa::kMaskBytes <= src.safe_end;
+    if (row_is_valid(in.validity, r)) hit = vm.find(0, n, mb, me) > 0;
+    for (int g = 0; g < groups; ++g) {
+      int x = -1, y = -1;
+      const bool ok = hit && vm.group_find(mb, gtags, g + 1, x, y) && x >= 0 && y > x;
+      begins[(int64_t)g * in.rows + r] = ok ? x : 0;
+      lens[(int64_t)g * in.rows + r] = ok ? y - x : -1;
     }
   }
 }
@@ -1029,6 +1059,10 @@ void upload(cs_regex* re, hipStream_t s) {
     if (!re->tdfa.empty()) {
       re->d_tdfa = dev_alloc(re->tdfa.size() * 4, s);
       CS_HIP(hipMemcpyAsync(re->d_tdfa->p, re->tdfa.data(), re->tdfa.size() * 4, hipMemcpyHostToDevice, s));
+      if (!re->gtags.empty()) {
+        re->d_gtags = dev_alloc(re->gtags.size() * 4, s);
+        CS_HIP(hipMemcpyAsync(re->d_gtags->p, re->gtags.data(), re->gtags.size() * 4, hipMemcpyHostToDevice, s));
+      }
     }
     CS_HIP(hipStreamSynchronize(s));
   }
@@ -1194,7 +1228,7 @@ int cs_regex_compile(const char* pattern, cs_regex** out) {
     re->prog = csrx::compile(pattern);
     re->blob = re->prog.to_blob();
     re->image = re->prog.to_device_image(h_unicode_flags());
-    re->tdfa = csrx::build_tdfa(re->prog, re->image, h_unicode_flags());
+    re->tdfa = csrx::build_tdfa(re->prog, re->image, h_unicode_flags(), &re->gtags);
     *out = re;
   });
 }
@@ -1485,13 +1519,26 @@ int cs_extract(const cs_column* col, const cs_regex* cre, cs_stream stream, cs_c
     const size_t img_bytes = (((size_t)L.image_words + 3) & ~size_t(3)) * 4;
     L.image_in_lds = img_bytes <= kLdsBudget / 2;
     const unsigned grid = (unsigned)std::min<int64_t>((rows + 255) / 256, 256 * 4);
-    Buf arena = dev_alloc((size_t)grid * 256 * L.slots * 4, s);
-    L.arena = ptr<uint32_t>(arena);
+    const bool dfa_groups = use_tdfa(re) && re->d_gtags && !getenv("CS_EXTRACT_LISTS");
+    Buf arena;  // thread lists of the list simulation (not needed when the DFA carries the group ranges)
+    if (!dfa_groups) {
+      arena = dev_alloc((size_t)grid * 256 * L.slots * 4, s);
+      L.arena = ptr<uint32_t>(arena);
+    }
     RowSrc src{view_of(col), d_unicode_flags(), col->nbytes + (col->chars && col->chars->capacity ? 64 : 0)};
     Buf begins = dev_alloc(sizeof(int32_t) * rows * groups, s);
     Buf lens = dev_alloc(sizeof(int32_t) * rows * groups, s);
     const bool tdfa = use_tdfa(re);
-    if (tdfa) {
+    if (dfa_groups) {
+      TPlan tp = tplan(re, rows, s);
+      ProfScope ps("k_extract_spans", s);
+      if (tp.d.in_lds)
+        hipLaunchKernelGGL(k_extract_spans_dfa<true>, dim3(tp.grid), dim3(256), tp.lds_bytes, s, src, tp.d, ptr<const int32_t>(re->d_gtags),
+                           groups, ptr<int32_t>(begins), ptr<int32_t>(lens));
+      else
+        hipLaunchKernelGGL(k_extract_spans_dfa<false>, dim3(tp.grid), dim3(256), 0, s, src, tp.d, ptr<const int32_t>(re->d_gtags), groups,
+                           ptr<int32_t>(begins), ptr<int32_t>(lens));
+    } else if (tdfa) {
       TPlan tp = tplan(re, rows, s);
       size_t fast_bytes = (size_t)256 * csvm::GroupVm<true>::kFastSlots * 4;
       const int use_fast = tp.lds_bytes + fast_bytes <= kLdsBudget;

@@ -146,6 +146,10 @@ struct Builder {
     bool stop = false;
     int match = -1;  // -1 none, 0..7 old slot, 15 new
     std::vector<int> origins;
+    // capture groups whose LBRA / RBRA lies on the closure path into each surviving thread (bit g-1 = group g),
+    // and into the matching thread: the simulator sets that group's begin / end to the current position there
+    std::vector<uint32_t> tag_b, tag_e;
+    uint32_t match_b = 0, match_e = 0;
   };
   bool step(const State& S, int atom_id, Step& out) const {
     const Atom& a = atoms[atom_id];
@@ -153,13 +157,19 @@ struct Builder {
     const bool cc_zero = a.eot, cc_nl = a.isnl, cc_word = a.isword;
     const int n = (int)P.insts.size();
     std::vector<char> seen(n, 0);
-    std::vector<std::pair<int, int>> L;  // (inst, origin)
-    std::vector<int> stk;
+    struct Thr {
+      int first, second;  // (inst, origin)
+      uint32_t tb, te;    // group tags collected on the closure path
+    };
+    std::vector<Thr> L;
+    std::vector<Thr> stk;  // (inst, -, tags)
+    auto gbit = [](int subid) -> uint32_t { return subid >= 1 && subid <= 32 ? 1u << (subid - 1) : 0u; };
     auto closure = [&](int inst, int origin) {
       stk.clear();
-      stk.push_back(inst);
+      stk.push_back(Thr{inst, 0, 0, 0});
       while (!stk.empty()) {
-        int id = stk.back();
+        const Thr t = stk.back();
+        const int id = t.first;
         stk.pop_back();
         if (id < 0 || id >= n) continue;  // malformed program: thread vanishes
         if (seen[id]) continue;
@@ -167,22 +177,22 @@ struct Builder {
         const Inst& in = P.insts[id];
         switch (in.type) {
           case OP_OR:
-            stk.push_back(in.u2);
-            stk.push_back(in.u1);
+            stk.push_back(Thr{in.u2, 0, t.tb, t.te});
+            stk.push_back(Thr{in.u1, 0, t.tb, t.te});
             break;
-          case OP_LBRA:
-          case OP_RBRA: stk.push_back(in.u2); break;
+          case OP_LBRA: stk.push_back(Thr{in.u2, 0, t.tb | gbit(in.u1), t.te}); break;
+          case OP_RBRA: stk.push_back(Thr{in.u2, 0, t.tb, t.te | gbit(in.u1)}); break;
           case OP_BOL:
-            if (at0 || ((Char)in.u1 == '^' && pc_nl)) stk.push_back(in.u2);
+            if (at0 || ((Char)in.u1 == '^' && pc_nl)) stk.push_back(Thr{in.u2, 0, t.tb, t.te});
             break;
           case OP_EOL:
-            if (cc_zero || ((Char)in.u1 == '$' && cc_nl)) stk.push_back(in.u2);
+            if (cc_zero || ((Char)in.u1 == '$' && cc_nl)) stk.push_back(Thr{in.u2, 0, t.tb, t.te});
             break;
           case OP_BOW:
           case OP_NBOW:
-            if ((cc_word != pc_word) == (in.type == OP_BOW)) stk.push_back(in.u2);
+            if ((cc_word != pc_word) == (in.type == OP_BOW)) stk.push_back(Thr{in.u2, 0, t.tb, t.te});
             break;
-          default: L.emplace_back(id, origin); break;
+          default: L.push_back(Thr{id, origin, t.tb, t.te}); break;
         }
       }
     };
@@ -194,11 +204,13 @@ struct Builder {
         closure(s, 15);
       }
     out = Step();
-    std::vector<std::pair<int, int>> nk;
+    std::vector<Thr> nk;
     for (auto& t : L) {
       const Inst& in = P.insts[t.first];
       if (in.type == OP_END) {
         out.match = t.second;
+        out.match_b = t.tb;
+        out.match_e = t.te;
         break;
       }
       int pi = inst_pred[t.first];
@@ -206,7 +218,7 @@ struct Builder {
       if ((a.sig >> pi) & 1) {
         bool dup = false;
         for (auto& q : nk) dup |= q.first == in.u2;
-        if (!dup) nk.emplace_back(in.u2, t.second);
+        if (!dup) nk.push_back(Thr{in.u2, t.second, t.tb, t.te});
       }
     }
     if ((int)nk.size() > kMaxSlots) return false;
@@ -215,6 +227,8 @@ struct Builder {
     for (auto& q : nk) {
       out.next.kernel.push_back(q.first);
       out.origins.push_back(q.second);
+      out.tag_b.push_back(q.tb);
+      out.tag_e.push_back(q.te);
     }
     out.stop = a.eot || (nk.empty() && out.next.mode == cstd::MODE_NORESTART);
     return true;
@@ -270,8 +284,12 @@ struct Builder {
 
 }  // namespace
 
-std::vector<int32_t> build_tdfa(const Program& prog, const std::vector<int32_t>& image, const uint8_t* flags) {
+std::vector<int32_t> build_tdfa(const Program& prog, const std::vector<int32_t>& image, const uint8_t* flags,
+                                std::vector<int32_t>* groups_out) {
   std::vector<int32_t> none;
+  if (groups_out) groups_out->clear();
+  const int ngroups = std::max(0, std::min(prog.num_groups, 32));
+  std::vector<std::vector<uint32_t>> gt(ngroups);  // per group: nstates x natoms tag words (regex_tdfa.h: group_find)
   if (prog.insts.empty() || prog.insts.size() > 4096) return none;
   Builder B(prog, image, flags);
   if (!B.collect_predicates()) return none;
@@ -304,6 +322,7 @@ std::vector<int32_t> build_tdfa(const Program& prog, const std::vector<int32_t>&
   for (size_t si = 0; si < states.size(); ++si) {
     if (states.size() > (size_t)cstd::kMaxStates) return none;
     t2.resize((si + 1) * natoms, 0);
+    for (auto& g : gt) g.resize((si + 1) * natoms, 0);
     for (int a = 0; a < natoms; ++a) {
       Builder::Step st;
       State cur = states[si];  // copy: `states` may grow
@@ -334,6 +353,11 @@ std::vector<int32_t> build_tdfa(const Program& prog, const std::vector<int32_t>&
         e |= cstd::E_COMPLEX | cstd::e_keep_field(15u) | ((uint32_t)idx << 21);
       }
       t2[si * natoms + a] = e;
+      for (int g = 0; g < ngroups; ++g) {
+        uint32_t w = (((st.match_b >> g) & 1u) << 8) | (((st.match_e >> g) & 1u) << 9);
+        for (int j = 0; j < m && j < kMaxSlots; ++j) w |= (((st.tag_b[j] >> g) & 1u) << (2 * j)) | (((st.tag_e[j] >> g) & 1u) << (2 * j + 1));
+        gt[g][si * natoms + a] = w;
+      }
     }
   }
   const int nstates = (int)states.size();
@@ -450,6 +474,18 @@ std::vector<int32_t> build_tdfa(const Program& prog, const std::vector<int32_t>&
     mark(img[8], (size_t)nstates * natoms);
   }
   img[15] = (int32_t)img.size();
+  if (groups_out && ngroups > 0) {
+    // group-tag image: [0] groups [1] nstates [2] natoms [3] words per table, [4..35] the atom of each ASCII byte
+    // (four per word), then one nstates x natoms table per group
+    std::vector<int32_t>& G = *groups_out;
+    G.assign(4 + 32, 0);
+    G[0] = ngroups;
+    G[1] = nstates;
+    G[2] = natoms;
+    G[3] = nstates * natoms;
+    for (unsigned c = 0; c < 128; ++c) G[4 + (c >> 2)] |= (int32_t)((uint32_t)(B.ascii_atom[c] & 255) << (8 * (c & 3)));
+    for (int g = 0; g < ngroups; ++g) G.insert(G.end(), gt[g].begin(), gt[g].begin() + (size_t)nstates * natoms);
+  }
   return img;
 }
 

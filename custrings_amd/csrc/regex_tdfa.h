@@ -286,6 +286,81 @@ struct Tdfa {
     return matched;
   }
 
+  // ---- capture groups (regexec.inl:204-442 with groupId != 0; dreprog::extract, regexec.inl:465-469) ----
+  // The program run from byte offset `from` only (MODE_SEED_ONCE), every thread slot carrying the
+  // (begin, end) range of ONE capture group instead of its start offset.  `G` is the group-tag image
+  // of build_tdfa and `group` is 1-based: per (state, atom) a word says which surviving slots -- and the
+  // matching thread -- passed that group's LBRA / RBRA in the closure at this position (bits 2j / 2j+1
+  // for slot j, bits 8 / 9 for the match), where the simulator sets begin / end to the position.
+  // Returns 1 and the range (byte offsets, -1 = never set) of the thread whose END wins, or 0.
+  CS_HD int group_find(int from, const int32_t* G, int group, int& gb, int& ge) {
+    const uint32_t* tags = (const uint32_t*)(G + 36) + (long long)(group - 1) * (long long)G[3];
+    const uint32_t* amap = (const uint32_t*)(G + 4);
+    uint32_t state = D.init[MODE_SEED_ONCE * 8 + (D.uses ? prev_cat(from) : 0u)];
+    int bx[kMaxSlots], by[kMaxSlots];
+#pragma unroll
+    for (int j = 0; j < kMaxSlots; ++j) bx[j] = by[j] = -1;
+    int matched = 0;
+    int pos = from;
+    auto pick = [&](const int* v, uint32_t o) -> int {
+      int r = -1;
+#pragma unroll
+      for (int j = 0; j < kMaxSlots; ++j)
+        if (o == (uint32_t)j) r = v[j];
+      return r;
+    };
+    auto apply = [&](uint32_t e, uint32_t tg) -> bool {
+      if (e & E_MATCH) {
+        const uint32_t o = e_match_origin(e);
+        const int mx = pick(bx, o), my = pick(by, o);
+        gb = (tg & 0x100u) ? pos : mx;
+        ge = (tg & 0x200u) ? pos : my;
+        matched = 1;
+      }
+      uint32_t og = 0x3210u;  // identity
+      if (e & E_COMPLEX) {
+        og = D.act[e >> 21];
+      } else {
+        const uint32_t keep = e_keep(e);
+        if (keep != 15u) og = (0x3210u & ~(0xFFFFu << (4 * keep))) | (0xFFFFu << (4 * keep));
+      }
+      int nx[kMaxSlots], ny[kMaxSlots];
+#pragma unroll
+      for (int j = 0; j < kMaxSlots; ++j) {
+        const uint32_t o = (og >> (4 * j)) & 15u;
+        nx[j] = ((tg >> (2 * j)) & 1u) ? pos : pick(bx, o);
+        ny[j] = ((tg >> (2 * j + 1)) & 1u) ? pos : pick(by, o);
+      }
+#pragma unroll
+      for (int j = 0; j < kMaxSlots; ++j) {
+        bx[j] = nx[j];
+        by[j] = ny[j];
+      }
+      state = e & E_STATE;
+      return (e & E_STOP) != 0;
+    };
+    bool stop = false;
+    while (!stop && pos < n) {
+      const uint8_t b = byte_at(pos);
+      int w = 1;
+      uint32_t e, atom;
+      if (b < 128) {
+        e = D.t1[state * 128 + b];
+        atom = (amap[b >> 2] >> (8 * (b & 3))) & 255u;
+      } else {
+        unsigned uw;
+        const csrow::Char c = char_at(pos, uw);
+        w = (int)uw;
+        atom = (uint32_t)nonascii_atom(c);
+        e = D.t2[state * D.natoms + atom];
+      }
+      stop = apply(e, tags[state * D.natoms + atom]);
+      if (!stop) pos += w;
+    }
+    if (!stop) apply(D.t2[state * D.natoms + ATOM_EOT], tags[state * D.natoms + ATOM_EOT]);
+    return matched;
+  }
+
   // ---- flat scan: all successive matches of a row in ONE loop ------------------
   // (the SIMT-friendly form of the row drivers in regex_vm.h: lanes that are in
   // different find() rounds still share the loop body, and idle stretches are
@@ -862,5 +937,8 @@ struct Program;
 // Host: builds the image; returns an empty vector when the program is not
 // convertible within the limits above.  `image` is the list simulator's device
 // image of the same program (Program::to_device_image), `flags` the unicode table.
-std::vector<int32_t> build_tdfa(const Program& prog, const std::vector<int32_t>& image, const uint8_t* flags);
+// `groups_out` (optional) receives the capture-group tag image consumed by cstd::Tdfa::group_find
+// (empty when the program has no groups).
+std::vector<int32_t> build_tdfa(const Program& prog, const std::vector<int32_t>& image, const uint8_t* flags,
+                                std::vector<int32_t>* groups_out = nullptr);
 }  // namespace csrx

@@ -270,7 +270,7 @@ class RowEmu(CpuLib):
         self._set_engine(e)
 
     def tdfa_info(self, re):
-        out = (C.c_int * 5)()
+        out = (C.c_int * 6)()
         self._regex_tdfa_info(re, out)
         return list(out)
 

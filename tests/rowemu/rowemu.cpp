@@ -203,7 +203,7 @@ static int split_any(const emu_col* c, const char* delim, int maxsplit, emu_col*
 
 // ---- regex ----
 struct emu_regex {
-  std::vector<int32_t> blob, image, tdfa;
+  std::vector<int32_t> blob, image, tdfa, gtags;
 };
 static int g_engine = 1;  // 0 = list simulator only, 1 = tagged DFA when the program converts
 void emu_set_engine(int e) { g_engine = e; }
@@ -212,12 +212,13 @@ emu_regex* emu_regex_compile(const char* pattern) {
   csrx::Program p = csrx::compile(pattern);
   re->blob = p.to_blob();
   re->image = p.to_device_image(orc_unicode_flags);
-  re->tdfa = csrx::build_tdfa(p, re->image, orc_unicode_flags);
+  re->tdfa = csrx::build_tdfa(p, re->image, orc_unicode_flags, &re->gtags);
   return re;
 }
 // [states, atoms, max slots, min match chars, image words] of the tagged DFA; 0 states = not convertible
 void emu_regex_tdfa_info(const emu_regex* re, int* out) {
-  for (int i = 0; i < 5; ++i) out[i] = 0;
+  for (int i = 0; i < 6; ++i) out[i] = 0;
+  out[5] = (int)re->gtags.size();  // capture-group tag image (0: no groups, or not convertible)
   if (re->tdfa.empty()) return;
   out[0] = re->tdfa[1];
   out[1] = re->tdfa[2];
@@ -323,7 +324,14 @@ int emu_extract(const emu_col* c, const emu_regex* re, emu_col*** cols_out) {
     for (int g = 0; g < groups; ++g) {
       int x = 0, y = -1;
       bool ok;
-      if (P.ninst <= 64) {
+      if (g_engine == 1 && !re->tdfa.empty() && !re->gtags.empty()) {  // group ranges carried by the tagged DFA
+        cstd::View D = cstd::make_view(re->tdfa.data());
+        cstd::Tdfa vm(D, P, c->row(r), c->len(r));
+        int gb = -1, ge = -1;
+        ok = vm.group_find(mb, re->gtags.data(), g + 1, gb, ge) && gb >= 0 && ge > gb;
+        x = gb;
+        y = ge;
+      } else if (P.ninst <= 64) {
         csvm::GroupVm<true> gv(P, mem.data(), 1, c->row(r), c->len(r));
         ok = csvm::row_group_span(gv, mb, g + 1, x, y);
       } else {

@@ -726,8 +726,13 @@ GROUP_PATTERNS = [r"(\w+) (\w+)", r"(a|ab)(c|bcd)", r"(a|b)*c", r"((a)|(b))+", r
                   r"no_groups", r"()a", r"(a|b|c|d|e|f|g|h){8}(x)?", "(" + "a" * 70 + ")|(b)"]
 
 
+@pytest.mark.parametrize("route", ["dfa", "lists"])
 @pytest.mark.parametrize("pat", GROUP_PATTERNS, ids=[repr(p)[:30] for p in GROUP_PATTERNS])
-def test_gpu_vs_oracle_extract(gpu_engine, oracle_engine, pat):
+def test_gpu_vs_oracle_extract(gpu_engine, oracle_engine, pat, route, monkeypatch):
+    """route dfa: group ranges carried by the tagged DFA (k_extract_spans_dfa) where the program converts;
+    route lists: the anchored list simulation (GroupVm) for every program."""
+    if route == "lists":
+        monkeypatch.setenv("CS_EXTRACT_LISTS", "1")
     s = fuzzdata.rows(12, 700, alphabet=list("aabbc xyz_.\n019") + ["é", "ü", "😀"]) + fuzzdata.log_rows(7, 700)
     s += ["a" * 80, "ab" * 50, "abcdefgh" * 3, None, ""]
     assert gpu_engine.extract(s, pat) == oracle_engine.extract(s, pat)

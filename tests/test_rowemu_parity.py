@@ -114,7 +114,7 @@ def test_rowemu_vs_oracle_extract_generated_patterns(emu_engine, oracle_engine):
              "(a)", "(\\w)", "(b|)", "((a)b)", "(\\d+)"]
     quants = ["", "", "", "*", "+", "?", "*?", "+?", "{2}", "{1,3}"]
     s = fuzzdata.rows(22, 120, alphabet=list("aabbcc xx_.\n01") + ["é", "😀"]) + fuzzdata.log_rows(8, 40)
-    with_groups = 0
+    with_groups = tagged = 0
     for _ in range(120):
         pat = ""
         n = rnd.randint(1, 5)
@@ -124,11 +124,14 @@ def test_rowemu_vs_oracle_extract_generated_patterns(emu_engine, oracle_engine):
                 pat += "|"
         want = oracle_engine.extract(s, pat)
         with_groups += len(want) > 0
+        re = emu_engine.e.compile(pat)
+        tagged += len(want) > 0 and emu_engine.e.tdfa_info(re)[5] > 0  # group ranges carried by the tagged DFA
+        emu_engine.e._regex_free(re)
         for engine in (0, 1):
             emu_engine.e.set_engine(engine)
             assert emu_engine.extract(s, pat) == want, (pat, engine)
     emu_engine.e.set_engine(1)
-    assert with_groups > 60
+    assert with_groups > 60 and tagged > 50
 
 
 @pytest.mark.parametrize("engine", [0, 1], ids=["pike", "tdfa"])
