@@ -908,7 +908,8 @@ __global__ void __launch_bounds__(256, CS_STREAM_WAVES) k_tdfa_replace_stream(St
 // ---- persistent contains_re / count_re over row tiles -----------------------------------
 // Same staging as the replace kernel (contiguous tile runs per wave, next tile's chars in
 // flight), no output assembly: LDS holds the DFA table and one input tile per wave, so seven
-// workgroups fit a CU.  MODE 0 contains_re, 2 count_re, 3 findall spans (begins / lens [k * rows + row]).
+// workgroups fit a CU.  MODE 0 contains_re, 2 count_re, 3 findall spans (begins / lens [k * rows + row]),
+// 4 extract spans (leftmost match, then Tdfa::group_find per capture group, all on the staged row).
 struct ScanStreamArgs {
   ColView in;
   const uint8_t* flags;
@@ -919,9 +920,10 @@ struct ScanStreamArgs {
   long long nsub;
   int cap_in, tbl_bytes;
   int rows_per_tile;  // LONG variant: 64, 32 or 16
-  int32_t* begins;    // MODE 3
+  int32_t* begins;    // MODE 3, 4
   int32_t* lens;
   int ncols;
+  const int32_t* gtags;  // MODE 4: capture-group tag image
 };
 template <int MODE, bool IN_LDS, bool LONG = false>
 __global__ void __launch_bounds__(256) k_tdfa_scan_stream(ScanStreamArgs a) {
@@ -986,7 +988,31 @@ __global__ void __launch_bounds__(256) k_tdfa_scan_stream(ScanStreamArgs a) {
     }
     cstile::wave_lds_fence();
     int v = 0;
-    {
+    if (MODE == 4) {
+      cstd::Tdfa vm(D, P, lds_in + lead + rbeg, n, (lead + rbeg) & 3);
+      int mb = 0, me = 0;
+      // leftmost match: the lean scan on ASCII tiles of short rows (as contains_re), else the generic find
+      const bool lean = !LONG && D.nskip > 0 && D.img[12] <= 4 && !__any((odd & 0x80808080u) != 0) && !__any(live && !vm.masks_fit());
+      int f = -1;
+      if (lean && live) {
+        uint32_t m0, m1, m2;
+        cstile::row_bits96(bitmap, lead + rbeg, n, m0, m1, m2);
+        f = vm.scan_lean_first(m0, m1, m2, [&](int b0, int e0, int) {
+          mb = b0;
+          me = e0;
+        });
+      }
+      if (live && f < 0) f = vm.find(0, n, mb, me);
+      const bool hit = live && f > 0;
+      v = hit;
+      if (lane < nrows)
+        for (int g = 0; g < a.ncols; ++g) {
+          int x = -1, y = -1;
+          const bool ok = hit && vm.group_find(mb, a.gtags, g + 1, x, y) && x >= 0 && y > x;
+          a.begins[(long long)g * in.rows + r0 + lane] = ok ? x : 0;
+          a.lens[(long long)g * in.rows + r0 + lane] = ok ? y - x : -1;
+        }
+    } else {
       cstd::Tdfa vm(D, P, lds_in + lead + rbeg, n, (lead + rbeg) & 3);
       const bool lean = D.nskip > 0 && D.img[12] <= 4 && !__any((odd & 0x80808080u) != 0) &&
                         !__any(live && (LONG ? n > cstd::Tdfa::kLongBytes : !vm.masks_fit()));
@@ -1529,7 +1555,39 @@ int cs_extract(const cs_column* col, const cs_regex* cre, cs_stream stream, cs_c
     Buf begins = dev_alloc(sizeof(int32_t) * rows * groups, s);
     Buf lens = dev_alloc(sizeof(int32_t) * rows * groups, s);
     const bool tdfa = use_tdfa(re);
-    if (dfa_groups) {
+    bool streamed = false;
+    if (dfa_groups && !getenv("CS_REGEX_ROWWISE")) {  // rows staged through LDS tiles by the scan stream kernel
+      TPlan tp = tplan(re, rows, s);
+      const TileChoice tc = choose_tile(col, s);
+      const int cap = tc.cap;
+      const size_t lds = tp.lds_bytes + (size_t)(cap + 32 + (cap >> 3) + 32) * 4;
+      if (tp.d.in_lds && tc.R && lds <= 150 * 1024) {
+        Buf cnt = dev_alloc(8, s);
+        CS_HIP(hipMemsetAsync(cnt->p, 0, 8, s));
+        ScanStreamArgs sa{};
+        sa.in = view_of(col);
+        sa.flags = d_unicode_flags();
+        sa.L = tp.d;
+        sa.found = ptr<unsigned long long>(cnt);
+        sa.nsub = (rows + tc.R - 1) / tc.R;
+        sa.rows_per_tile = tc.R;
+        sa.cap_in = cap;
+        sa.tbl_bytes = (int)tp.lds_bytes;
+        sa.begins = ptr<int32_t>(begins);
+        sa.lens = ptr<int32_t>(lens);
+        sa.ncols = groups;
+        sa.gtags = ptr<const int32_t>(re->d_gtags);
+        auto kern = tc.lng ? &k_tdfa_scan_stream<4, true, true> : &k_tdfa_scan_stream<4, true, false>;
+        if (lds > 48 * 1024)
+          CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        const unsigned sgrid = resident_grid(reinterpret_cast<const void*>(kern), lds, (sa.nsub + 3) / 4);
+        ProfScope ps("k_extract_spans", s);
+        hipLaunchKernelGGL(kern, dim3(sgrid), dim3(256), lds, s, sa);
+        streamed = true;
+      }
+    }
+    if (streamed) {
+    } else if (dfa_groups) {
       TPlan tp = tplan(re, rows, s);
       ProfScope ps("k_extract_spans", s);
       if (tp.d.in_lds)

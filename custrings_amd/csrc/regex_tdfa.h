@@ -310,6 +310,11 @@ struct Tdfa {
       return r;
     };
     auto apply = [&](uint32_t e, uint32_t tg) -> bool {
+      // most transitions inside a match keep every slot where it is and pass no bracket of the group
+      if (tg == 0 && (e & (E_MATCH | E_COMPLEX | (15u << 16))) == 0) {
+        state = e & E_STATE;
+        return (e & E_STOP) != 0;
+      }
       if (e & E_MATCH) {
         const uint32_t o = e_match_origin(e);
         const int mx = pick(bx, o), my = pick(by, o);
@@ -600,7 +605,10 @@ struct Tdfa {
       }
       // ---- this find() round is over
       if (!matched) return done;
-      if (KIND == K_CONTAINS) return 1;
+      if (KIND == K_CONTAINS) {
+        emit(mb, me, 1);  // (extract: the leftmost match; contains_re passes a no-op)
+        return 1;
+      }
       if (KIND == K_COUNT) {
         emit(mb, me, 1);  // (findall; count_re passes a no-op)
         ++done;
@@ -649,6 +657,13 @@ struct Tdfa {
     auto none = [](int, int, int) {};
     const int r = D.uses ? scan_lean<KIND, true, decltype(none)&, true, Refill>(0, m0, m1, m2, none, bail, refill)
                          : scan_lean<KIND, false, decltype(none)&, true, Refill>(0, m0, m1, m2, none, bail, refill);
+    return bail ? -1 : r;
+  }
+  // extract: the leftmost match through emit(mb, me, 1); 1 / 0 = match / none, -1 = the row needs the generic scan
+  template <class Emit>
+  CS_HD int scan_lean_first(uint32_t m0, uint32_t m1, uint32_t m2, Emit&& emit) {
+    bool bail = false;
+    const int r = D.uses ? scan_lean<K_CONTAINS, true>(0, m0, m1, m2, emit, bail) : scan_lean<K_CONTAINS, false>(0, m0, m1, m2, emit, bail);
     return bail ? -1 : r;
   }
   // findall: the count_re walk with emit(mb, me, 1) per match; -1 = the row needs the generic scan
