@@ -70,6 +70,7 @@ _PROTOS = {
     "cs_match_re": (i32, [vp, vp, vp, i32, vp, P(i64)]),
     "cs_count_re": (i32, [vp, vp, vp, i32, vp, P(i64)]),
     "cs_replace_re": (i32, [vp, vp, cp, i32, vp, P(vp)]),
+    "cs_replace_with_backrefs": (i32, [vp, vp, cp, vp, P(vp)]),
     "cs_extract": (i32, [vp, vp, vp, P(P(vp)), P(i32)]),
     "cs_findall": (i32, [vp, vp, vp, P(P(vp)), P(i32)]),
     "cs_category_build": (i32, [vp, vp, P(vp)]),

@@ -392,6 +392,82 @@ __global__ void __launch_bounds__(256) k_extract_spans_dfa(RowSrc src, TLaunch T
   }
 }
 
+// ---- replace_with_backrefs (replace_backref.cu:36-207) ---------------------------------------
+// Two passes, one thread per row (csvm::row_backrefs): sizes, then the bytes.  DFA: matches and group
+// ranges by the tagged DFA (Tdfa::find / group_find); otherwise the list simulators over a global arena.
+template <bool DFA, bool IN_LDS, bool SMALL, class Out>
+__device__ __forceinline__ void backrefs_for_row(const TCtx& c, const csvm::ProgView& P, uint32_t* mem, int stride, const RowSrc& src,
+                                                 const int32_t* gtags, const csvm::BackrefTemplate& t, int64_t r, Out&& out) {
+  const ColView& in = src.in;
+  const int64_t b = in.offsets[r];
+  const int n = (int)(in.offsets[r + 1] - b);
+  const uint8_t* p = in.chars + b;
+  if constexpr (DFA) {
+    cstd::Tdfa vm(c.D, c.P, p, n);
+    vm.wide_ok = (b & ~(int64_t)3) + cstd::Tdfa::kMaskBytes <= src.safe_end;
+    csvm::row_backrefs(
+        p, n, t, [&](int from, int& mb, int& me) { return vm.find(from, n, mb, me) > 0; },
+        [&](int mb, int g, int& x, int& y) { return g == 0 ? vm.find(mb, mb + 1, x, y) > 0 : vm.group_find(mb, gtags, g, x, y) > 0; }, out);
+  } else {
+    csvm::row_backrefs(
+        p, n, t,
+        [&](int from, int& mb, int& me) {
+          csvm::Vm<SMALL> vm(P, mem, stride, p, n);
+          return vm.find(from, n, mb, me) > 0;
+        },
+        [&](int mb, int g, int& x, int& y) {
+          if (g == 0) {
+            csvm::Vm<SMALL> vm(P, mem, stride, p, n);
+            return vm.find(mb, mb + 1, x, y) > 0;
+          }
+          csvm::GroupVm<SMALL> gv(P, mem, stride, p, n);
+          return gv.run(mb, g, x, y) > 0;
+        },
+        out);
+  }
+}
+struct BackrefArgs {
+  RowSrc src;
+  TLaunch TL;
+  Launch L;
+  const int32_t* gtags;
+  csvm::BackrefTemplate t;
+};
+template <bool DFA, bool IN_LDS, bool SMALL, bool WRITE>
+__global__ void __launch_bounds__(256) k_backrefs(BackrefArgs a, int32_t* __restrict__ lens, const int64_t* __restrict__ out_off,
+                                                  uint8_t* __restrict__ out_chars) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  TCtx c{};
+  csvm::ProgView P{};
+  uint32_t* mem = nullptr;
+  if (DFA) {
+    c = tsetup<IN_LDS>(a.TL, a.src.flags, smem);
+  } else {
+    P = csvm::make_view(a.L.image, a.src.flags);
+    mem = a.L.arena + (size_t)blockIdx.x * blockDim.x * a.L.slots + threadIdx.x;
+  }
+  const ColView& in = a.src.in;
+  const int64_t nblk = (in.rows + blockDim.x - 1) / blockDim.x;
+  for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+    const int64_t r = blk * blockDim.x + threadIdx.x;
+    if (r >= in.rows) continue;
+    const bool valid = row_is_valid(in.validity, r);
+    if (!WRITE) {
+      int len = -1;
+      if (valid) {
+        len = 0;
+        backrefs_for_row<DFA, IN_LDS, SMALL>(c, P, mem, blockDim.x, a.src, a.gtags, a.t, r, [&](const uint8_t*, int k) { len += k; });
+      }
+      lens[r] = len;
+    } else if (valid) {
+      uint8_t* o = out_chars + out_off[r];
+      backrefs_for_row<DFA, IN_LDS, SMALL>(c, P, mem, blockDim.x, a.src, a.gtags, a.t, r, [&](const uint8_t* q, int k) {
+        for (int i = 0; i < k; ++i) *o++ = q[i];
+      });
+    }
+  }
+}
+
 // ---- findall (findall.cu:39-179): column k = every row's k-th match ------------------------
 // The per-row match counts come from the count_re kernels; this pass walks the matches again
 // (tagged DFA, or the list simulator) and leaves the first `ncols` spans in begins / lens
@@ -1768,6 +1844,101 @@ int cs_findall(const cs_column* col, const cs_regex* cre, cs_stream stream, cs_c
     CS_HIP(hipGetLastError());
     CS_HIP(hipStreamSynchronize(s));
     finish(cols);
+  });
+}
+
+// NVStrings::replace_with_backrefs(pattern, repl) (NVStrings.h:788; replace_backref.cu:128-207).
+// repl NULL -> a column of all nulls, as the reference returns.  A pattern that can match the empty
+// string is refused (CS_ERR_INVALID_ARG): the reference does not terminate on it (replace_backref.cu:112).
+int cs_replace_with_backrefs(const cs_column* col, const cs_regex* cre, const char* repl, cs_stream stream, cs_column** out) {
+  return guard([&] {
+    if (!col || !cre || !out) fail(CS_ERR_INVALID_ARG, "null argument");
+    require_device();
+    hipStream_t s = S(stream);
+    cs_regex* re = const_cast<cs_regex*>(cre);
+    if (re->empty_pattern) fail(CS_ERR_INVALID_ARG, "nvstrings::replace_with_backrefs parameter cannot be null or empty");
+    const int64_t rows = col->rows;
+    if (rows == 0 || !repl) {
+      *out = make_all_null(rows, s);
+      return;
+    }
+    // backref.h:31-57: a backslash followed by digits is a reference
+    std::string text;
+    csvm::BackrefTemplate t{};
+    for (const char* p = repl; *p;) {
+      if (*p == '\\' && p[1] >= '0' && p[1] <= '9') {
+        const char* q = p + 1;
+        while (*q >= '0' && *q <= '9') ++q;
+        if (t.nrefs == csvm::BackrefTemplate::kMaxRefs) fail(CS_ERR_RANGE, "replace_with_backrefs: more than 16 references in the template");
+        t.idx[t.nrefs] = atoi(p + 1);
+        t.pos[t.nrefs] = (int)text.size();
+        ++t.nrefs;
+        p = q;
+      } else {
+        text.push_back(*p++);
+      }
+    }
+    t.bytes = (int)text.size();
+    t.groups = re->prog.num_groups;
+    upload(re, s);
+    const bool dfa = use_tdfa(re) && (re->d_gtags || re->prog.num_groups == 0);
+    if (dfa ? re->tdfa[13] == 0 : false) fail(CS_ERR_INVALID_ARG, "replace_with_backrefs: the pattern matches the empty string");
+    Buf d_text = dev_alloc(text.size() + 1, s);
+    CS_HIP(hipMemcpyAsync(d_text->p, text.c_str(), text.size() + 1, hipMemcpyHostToDevice, s));
+    t.text = ptr<const uint8_t>(d_text);
+    BackrefArgs a{};
+    a.src = RowSrc{view_of(col), d_unicode_flags(), col->nbytes + (col->chars && col->chars->capacity ? 64 : 0)};
+    a.gtags = ptr<const int32_t>(re->d_gtags);
+    a.t = t;
+    const int ninst = (int)re->prog.insts.size();
+    unsigned grid = (unsigned)std::min<int64_t>((rows + 255) / 256, 256 * 8);
+    size_t lds = 0;
+    Buf arena;
+    if (dfa) {
+      TPlan tp = tplan(re, rows, s);
+      a.TL = tp.d;
+      lds = tp.lds_bytes;
+    } else {
+      // (no minimum match length without the DFA: the row walk stops at an empty match)
+      a.L.image = ptr<const int32_t>(re->d_image);
+      a.L.image_words = (int)re->image.size();
+      a.L.slots = csvm::gvm_slots(ninst);
+      grid = std::min(grid, 1024u);
+      arena = dev_alloc((size_t)grid * 256 * a.L.slots * 4, s);
+      a.L.arena = ptr<uint32_t>(arena);
+    }
+    auto launch = [&](bool write, int32_t* lens, const int64_t* off, uint8_t* chars) {
+      const bool small = ninst <= 64;
+#define CS_BR(D_, I_, S_)                                                                                        \
+  do {                                                                                                           \
+    if (write) hipLaunchKernelGGL((k_backrefs<D_, I_, S_, true>), dim3(grid), dim3(256), lds, s, a, lens, off, chars);  \
+    else hipLaunchKernelGGL((k_backrefs<D_, I_, S_, false>), dim3(grid), dim3(256), lds, s, a, lens, off, chars);       \
+  } while (0)
+      if (dfa && a.TL.in_lds) CS_BR(true, true, true);
+      else if (dfa) CS_BR(true, false, true);
+      else if (small) CS_BR(false, false, true);
+      else CS_BR(false, false, false);
+#undef CS_BR
+      CS_HIP(hipGetLastError());
+    };
+    auto o = std::make_unique<cs_column>();
+    o->rows = rows;
+    o->validity = col->validity;
+    o->null_count = col->null_count;
+    Buf lens = dev_alloc(sizeof(int32_t) * rows, s);
+    {
+      ProfScope ps("k_backrefs_size", s);
+      launch(false, ptr<int32_t>(lens), nullptr, nullptr);
+    }
+    o->offsets = dev_alloc(sizeof(int64_t) * (rows + 1), s);
+    o->nbytes = offsets_from_lengths(ptr<int32_t>(lens), rows, ptr<int64_t>(o->offsets), s);
+    o->chars = dev_alloc((size_t)o->nbytes, s);
+    {
+      ProfScope ps("k_backrefs_write", s);
+      launch(true, nullptr, o->d_offsets(), ptr<uint8_t>(o->chars));
+    }
+    CS_HIP(hipStreamSynchronize(s));
+    *out = o.release();
   });
 }
 

@@ -459,6 +459,41 @@ CS_HD int row_count_re(VM& vm) {
   }
   return k;
 }
+// replace_backref.cu:36-125: walks the matches of a row and sends the output through out(ptr, len):
+// the text before each match, then the template with the capture groups of that match filled in.
+// find(from, mb, me): leftmost match starting in [from, n); group(mb, g, x, y): the range of group g
+// (0 = whole match) in the program run anchored at mb.  Matches are never empty (the host rejects
+// patterns that can match the empty string: the reference would not terminate on them).
+struct BackrefTemplate {
+  static constexpr int kMaxRefs = 16;
+  const uint8_t* text;  // template without the references
+  int bytes;
+  int nrefs;
+  int idx[kMaxRefs];  // reference number
+  int pos[kMaxRefs];  // byte position in `text`
+  int groups;         // capture groups of the program
+};
+template <class Find, class Group, class Out>
+CS_HD void row_backrefs(const uint8_t* p, int n, const BackrefTemplate& t, Find&& find, Group&& group, Out&& out) {
+  int lpos = 0, from = 0;
+  for (;;) {
+    int mb = 0, me = 0;
+    if (!find(from, mb, me)) break;
+    out(p + lpos, mb - lpos);
+    int il = 0;
+    for (int j = 0; j < t.nrefs; ++j) {
+      out(t.text + il, t.pos[j] - il);
+      il = t.pos[j];
+      int x = -1, y = -1;
+      if (t.idx[j] <= t.groups && group(mb, t.idx[j], x, y) && x >= 0 && y > x) out(p + x, y - x);
+    }
+    out(t.text + il, t.bytes - il);
+    lpos = me;
+    if (me <= mb) break;
+    from = me;
+  }
+  out(p + lpos, n - lpos);
+}
 // findall.cu:61-77: the count_re walk reporting every match span; emit(k, mb, me) returns false to stop.
 template <class VM, class Emit>
 CS_HD int row_findall(VM& vm, Emit&& emit) {

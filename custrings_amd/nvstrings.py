@@ -90,7 +90,7 @@ def bind_cpointer(cptr, own=True):
 _NOT_BUILT = (
     "len compare hash stoi stol stof stod htoi to_booleans ip2int timestamp2int cat join split_record "
     "rsplit_record partition rpartition get repeat pad ljust center rjust zfill wrap slice slice_from "
-    "slice_replace insert replace_multi replace_with_backrefs fillna capitalize swapcase title index rindex "
+    "slice_replace insert replace_multi fillna capitalize swapcase title index rindex "
     "find_from rfind findall_record match_strings startswith endswith extract_record isalnum "
     "isalpha isdigit isspace isdecimal isnumeric islower isupper is_empty translate sort order gather "
     "scatter scalar_scatter remove_strings add_strings copy find_multiple url_encode url_decode get_ipc_data"
@@ -252,6 +252,18 @@ class nvstrings:
                 lib.cs_regex_destroy(re)
         else:
             check(lib.cs_replace(self.m_cptr, b(pat), b(repl), int(n), None, C.byref(out)))
+        return nvstrings(out.value)
+
+    def replace_with_backrefs(self, pat, repl):
+        """nvstrings.py:1532-1557 -- regex replace with \\N in repl standing for capture group N of the match."""
+        if not pat:
+            raise ValueError("nvstrings::replace_with_backrefs parameter cannot be null or empty")
+        re = _compile(pat)
+        out = C.c_void_p()
+        try:
+            check(lib.cs_replace_with_backrefs(self.m_cptr, re, b(repl), None, C.byref(out)))
+        finally:
+            lib.cs_regex_destroy(re)
         return nvstrings(out.value)
 
     # ---- extract ------------------------------------------------------------------

@@ -169,6 +169,15 @@ int cs_count_re(const cs_column* col, const cs_regex* re, int32_t* results, int 
 /* NVStrings::replace_re (NVStrings.h:766; replace.cu:110-189). */
 int cs_replace_re(const cs_column* col, const cs_regex* re, const char* repl, int maxrepl,
                   cs_stream stream, cs_column** out);
+/* NVStrings::replace_with_backrefs(pattern, repl) (NVStrings.h:788;
+ * replace_backref.cu:36-207): every match is replaced by `repl` with \N
+ * (backslash + digits) standing for capture group N of that match (0 = the
+ * whole match; a group that took no part contributes nothing).  repl NULL ->
+ * all rows null.  At most 16 references.  A pattern that can match the empty
+ * string is refused with CS_ERR_INVALID_ARG (the reference does not terminate
+ * on it). */
+int cs_replace_with_backrefs(const cs_column* col, const cs_regex* re, const char* repl,
+                             cs_stream stream, cs_column** out);
 /* NVStrings::extract(pattern, results) (NVStrings.h:682; extract.cu:69-151):
  * column-major, one column per capture group; a row is null unless the
  * pattern matches and the group's span is non-empty.  *out_cols is a malloc'd

@@ -169,6 +169,14 @@ class NVStrings {
     if (n) cs_free(cols);
     return n;
   }
+  /* NVStrings.h:788 */
+  NVStrings* replace_with_backrefs(const char* pattern, const char* repl) {
+    if (!pattern || !*pattern) throw std::invalid_argument("nvstrings::replace_with_backrefs parameter cannot be null or empty");
+    Regex re(pattern);
+    cs_column* c = nullptr;
+    check(cs_replace_with_backrefs(m_col, re.h, repl, nullptr, &c));
+    return new NVStrings(c);
+  }
   /* NVStrings.h:796-808 */
   NVStrings* lstrip(const char* to_strip) { return strip_side(to_strip, 1); }
   NVStrings* strip(const char* to_strip) { return strip_side(to_strip, 0); }

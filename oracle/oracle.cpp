@@ -915,6 +915,64 @@ int orc_findall(const orc_col* c, const int32_t* prog, orc_col*** cols_out) {
   return nout;
 }
 
+// backref.h:31-57 parse_backrefs: every backslash followed by digits is a reference; returns the
+// template without them and (index, byte position in the stripped template) per reference
+static std::string parse_backrefs(const char* repl, std::vector<std::pair<int, int>>& refs) {
+  std::string out;
+  for (const char* p = repl; *p;) {
+    if (*p == '\\' && p[1] >= '0' && p[1] <= '9') {
+      const char* q = p + 1;
+      while (*q >= '0' && *q <= '9') ++q;
+      refs.push_back({atoi(p + 1), (int)out.size()});
+      p = q;
+    } else {
+      out.push_back(*p++);
+    }
+  }
+  return out;
+}
+// replace_backref.cu:36-125,128-207: every match is replaced by the template with the capture
+// groups of THAT match filled in (each by a program run anchored at the match start, group id =
+// reference number; 0 = the whole anchored match).  A match of length zero would repeat forever
+// in the reference (begin = end, replace_backref.cu:112); the walk stops there (the product
+// rejects such patterns).
+orc_col* orc_replace_with_backrefs(const orc_col* c, const int32_t* prog, const char* repl) {
+  Prog p(prog);
+  std::vector<std::pair<int, int>> refs;
+  std::string tmpl = parse_backrefs(repl, refs);
+  Builder b;
+  for (int64_t r = 0; r < c->rows; ++r) {
+    if (!c->is_valid(r)) {
+      b.add_null();
+      continue;
+    }
+    View v = make_view(*c, r);
+    int nchars = (int)v.nchars, begin = 0, end = nchars;
+    unsigned lpos = 0;
+    while (re_find(p, v, begin, end) > 0) {
+      unsigned mb = byte_pos(v, (unsigned)begin);
+      b.chars.insert(b.chars.end(), v.d + lpos, v.d + mb);
+      int il = 0;
+      for (auto& ref : refs) {
+        b.chars.insert(b.chars.end(), tmpl.begin() + il, tmpl.begin() + ref.second);
+        il = ref.second;
+        int spos = begin, epos = begin + 1;
+        if (nfa_run(p, v, spos, epos, ref.first) <= 0 || spos < 0 || epos <= spos) continue;
+        unsigned x = byte_pos(v, (unsigned)spos), y = byte_pos(v, (unsigned)epos);
+        b.chars.insert(b.chars.end(), v.d + x, v.d + y);
+      }
+      b.chars.insert(b.chars.end(), tmpl.begin() + il, tmpl.end());
+      lpos = byte_pos(v, (unsigned)end);
+      if (end == begin) break;
+      begin = end;
+      end = nchars;
+    }
+    b.chars.insert(b.chars.end(), v.d + lpos, v.d + v.bytes);
+    b.close_row();
+  }
+  return b.finish();
+}
+
 // NVCategory.cu:220-304: sort (null first, bytewise, shorter-is-less), unique, rank
 static int key_cmp(const orc_col* c, int64_t a, int64_t b) {  // custring.inl:240-261
   const uint8_t *pa = c->chars.data() + c->off[a], *pb = c->chars.data() + c->off[b];

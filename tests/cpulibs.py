@@ -196,6 +196,7 @@ class Oracle(CpuLib):
         self._f("replace_re", vp, [vp, vp, C.c_char_p, C.c_int])
         self._f("extract", C.c_int, [vp, vp, C.POINTER(C.POINTER(vp))])
         self._f("findall", C.c_int, [vp, vp, C.POINTER(C.POINTER(vp))])
+        self._f("replace_with_backrefs", vp, [vp, vp, C.c_char_p])
         self._f("category", vp, [vp, vp])
         self._f("ngrams", vp, [vp, C.c_uint, C.c_char_p])
         self._f("synth", vp, [C.c_int, C.c_int64, C.c_int64, C.c_uint64, C.c_int64])
@@ -217,6 +218,9 @@ class Oracle(CpuLib):
 
     def replace_re(self, col, blob, repl, maxrepl=-1):
         return self._unary(self._replace_re, col, blob.ctypes.data, self._b(repl), maxrepl)
+
+    def replace_with_backrefs(self, col, blob, repl):
+        return self._unary(self._replace_with_backrefs, col, blob.ctypes.data, self._b(repl))
 
     def _columns(self, fn, col, blob):
         h = self.put(col)
@@ -262,6 +266,7 @@ class RowEmu(CpuLib):
         self._f("replace_re", vp, [vp, vp, C.c_char_p, C.c_int])
         self._f("extract", C.c_int, [vp, vp, C.POINTER(C.POINTER(vp))])
         self._f("findall", C.c_int, [vp, vp, C.POINTER(C.POINTER(vp))])
+        self._f("replace_with_backrefs", vp, [vp, vp, C.c_char_p])
         self._f("set_engine", None, [C.c_int])
         self._f("regex_tdfa_info", None, [vp, C.POINTER(C.c_int)])
 
@@ -298,6 +303,9 @@ class RowEmu(CpuLib):
 
     def replace_re(self, col, re, repl, maxrepl=-1):
         return self._unary(self._replace_re, col, re, self._b(repl), maxrepl)
+
+    def replace_with_backrefs(self, col, re, repl):
+        return self._unary(self._replace_with_backrefs, col, re, self._b(repl))
 
     def _columns(self, fn, col, re):
         h = self.put(col)

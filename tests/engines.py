@@ -111,6 +111,9 @@ class OracleEngine:
             raise ValueError("empty pattern")
         return self.o.replace_re(Col.from_list(s), self._blob(pat), repl, n).to_list()
 
+    def replace_with_backrefs(self, s, pat, repl):
+        return self.o.replace_with_backrefs(Col.from_list(s), self._blob(pat), repl).to_list()
+
     def extract(self, s, pat):
         return [c.to_list() for c in self.o.extract(Col.from_list(s), self._blob(pat))]
 
@@ -187,6 +190,13 @@ class EmuEngine:
         re = self._re(pat)
         try:
             return self.e.replace_re(Col.from_list(s), re, repl, n).to_list()
+        finally:
+            self.e._regex_free(re)
+
+    def replace_with_backrefs(self, s, pat, repl):
+        re = self._re(pat)
+        try:
+            return self.e.replace_with_backrefs(Col.from_list(s), re, repl).to_list()
         finally:
             self.e._regex_free(re)
 
@@ -294,6 +304,9 @@ class GpuEngine:
     def rsplit(self, s, delimiter=None, n=-1):
         return [c.to_host() for c in self.col(s).rsplit(delimiter, n)]
 
+    def replace_with_backrefs(self, s, pat, repl):
+        return self.col(s).replace_with_backrefs(pat, repl).to_host()
+
     def extract(self, s, pat):
         return [c.to_host() for c in self.col(s).extract(pat)]
 
@@ -347,6 +360,8 @@ def run_case(eng, case):
         return eng.rsplit(s, a["delimiter"], a["n"])
     if op == "extract":
         return eng.extract(s, a["pat"])
+    if op == "replace_with_backrefs":
+        return eng.replace_with_backrefs(s, a["pat"], a["repl"])
     if op == "findall":
         return eng.findall(s, a["pat"])
     if op == "category":

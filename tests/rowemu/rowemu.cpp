@@ -8,6 +8,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <string>
 #include <vector>
 
 #include "../../custrings_amd/csrc/regex_program.h"
@@ -351,6 +352,74 @@ int emu_extract(const emu_col* c, const emu_regex* re, emu_col*** cols_out) {
         [&](int64_t r, uint8_t* o) { memcpy(o, c->row(r) + lo[g][r], (size_t)len[g][r]); });
   *cols_out = cols;
   return groups;
+}
+
+// ---- replace_with_backrefs (the kernels' per-row logic; template parsed as the product's host code does) ----
+emu_col* emu_replace_with_backrefs(const emu_col* c, const emu_regex* re, const char* repl) {
+  csvm::ProgView P = csvm::make_view(re->image.data(), orc_unicode_flags);
+  std::string text;
+  csvm::BackrefTemplate t{};
+  for (const char* p = repl; *p;) {
+    if (*p == '\\' && p[1] >= '0' && p[1] <= '9' && t.nrefs < csvm::BackrefTemplate::kMaxRefs) {
+      const char* q = p + 1;
+      while (*q >= '0' && *q <= '9') ++q;
+      t.idx[t.nrefs] = atoi(p + 1);
+      t.pos[t.nrefs] = (int)text.size();
+      ++t.nrefs;
+      p = q;
+    } else {
+      text.push_back(*p++);
+    }
+  }
+  t.text = (const uint8_t*)text.data();
+  t.bytes = (int)text.size();
+  t.groups = re->image[2];
+  const bool dfa = g_engine == 1 && !re->tdfa.empty() && (!re->gtags.empty() || t.groups == 0);
+  std::vector<uint32_t> mem((size_t)csvm::gvm_slots(P.ninst) + 1);
+  auto run = [&](int64_t r, auto&& out) {
+    const uint8_t* p = c->row(r);
+    const int n = c->len(r);
+    if (dfa) {
+      cstd::View D = cstd::make_view(re->tdfa.data());
+      cstd::Tdfa vm(D, P, p, n);
+      csvm::row_backrefs(
+          p, n, t, [&](int from, int& mb, int& me) { return vm.find(from, n, mb, me) > 0; },
+          [&](int mb, int g, int& x, int& y) {
+            return g == 0 ? vm.find(mb, mb + 1, x, y) > 0 : vm.group_find(mb, re->gtags.data(), g, x, y) > 0;
+          },
+          out);
+    } else {
+      csvm::row_backrefs(
+          p, n, t,
+          [&](int from, int& mb, int& me) {
+            csvm::Vm<false> vm(P, mem.data(), 1, p, n);
+            return vm.find(from, n, mb, me) > 0;
+          },
+          [&](int mb, int g, int& x, int& y) {
+            if (g == 0) {
+              csvm::Vm<false> vm(P, mem.data(), 1, p, n);
+              return vm.find(mb, mb + 1, x, y) > 0;
+            }
+            csvm::GroupVm<false> gv(P, mem.data(), 1, p, n);
+            return gv.run(mb, g, x, y) > 0;
+          },
+          out);
+    }
+  };
+  return two_pass(
+      c->rows,
+      [&](int64_t r) {
+        if (!c->ok(r)) return -1;
+        int len = 0;
+        run(r, [&](const uint8_t*, int k) { len += k; });
+        return len;
+      },
+      [&](int64_t r, uint8_t* o) {
+        run(r, [&](const uint8_t* q, int k) {
+          memcpy(o, q, (size_t)k);
+          o += k;
+        });
+      });
 }
 
 // ---- findall (column k = every row's k-th match) ----

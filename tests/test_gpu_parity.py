@@ -806,3 +806,37 @@ def test_gpu_c3_rsplit(orc):
         assert len(gc) == len(oc)
         for k, (a, b) in enumerate(zip(gc, oc)):
             gpuutil.assert_same(a, b, "rsplit(%r,%d) col %d" % (d, n, k))
+
+
+# ---- replace_with_backrefs -----------------------------------------
+BACKREF_CASES = [(r"(\w) (\w)", r"\1-\2"), (r"(\d+)\.(\d+)", r"<\2.\1>"), (r"(a|ab)(c|bcd)", r"[\2|\1|\0]"), (r"(a)|(b)", r"\1x\2"),
+                 (r"(é+)", r"\1\1"), (r"b", r"\0\0"), (r"(a)(b)?", r"\2\9_"), (r"(GET|POST) (/\S*)", r"\2 \1"), (r"((a|b)(c|x))+", r"\3\2\1"),
+                 (r"\b(\w)(\w*)", r"\2\1"), (r"x(?:y)(z)", r"\1"), (r"(.)", r"\1,"), (r"(a|b|c|d|e|f|g|h){8}(x)?", r"<\1\2>")]
+
+
+@pytest.mark.parametrize("route", ["dfa", "lists"])
+@pytest.mark.parametrize("pat,repl", BACKREF_CASES, ids=[repr(p)[:24] for p, _ in BACKREF_CASES])
+def test_gpu_vs_oracle_replace_with_backrefs(gpu_engine, oracle_engine, pat, repl, route, monkeypatch):
+    if route == "lists":
+        monkeypatch.setenv("CS_REGEX_NO_TDFA", "1")
+    s = fuzzdata.rows(14, 600, alphabet=list("aabbc xyz_.\n019") + ["é", "ü", "😀"]) + fuzzdata.log_rows(11, 600)
+    s += ["a" * 80, "ab" * 50, "abcdefgh" * 3, None, ""]
+    assert gpu_engine.replace_with_backrefs(s, pat, repl) == oracle_engine.replace_with_backrefs(s, pat, repl)
+
+
+def test_gpu_replace_with_backrefs_edges(gpu_engine):
+    col = gpu_engine.col(["a1", None, ""])
+    assert col.replace_with_backrefs(r"(\d)", None).to_host() == [None, None, None]
+    with pytest.raises(ValueError):
+        col.replace_with_backrefs("", "x")
+    with pytest.raises(ValueError):
+        col.replace_with_backrefs(r"(a*)", r"\1")  # matches the empty string: the reference would not terminate
+    assert gpu_engine.col([]).replace_with_backrefs(r"(a)", r"\1").to_host() == []
+
+
+def test_gpu_c3_replace_with_backrefs(orc):
+    rows = 200_000
+    g, o = gpuutil.synth(3, 9_000_000, rows), orc.synth(3, 9_000_000, rows)
+    pat, repl = r"(\d+)\.(\d+)\.(\d+)\.(\d+)", r"\4.\3.\2.\1"
+    blob = np.ascontiguousarray(engines.reference_blob(pat))
+    gpuutil.assert_same(g.replace_with_backrefs(pat, repl), orc.replace_with_backrefs(o, blob, repl), "replace_with_backrefs")

@@ -154,3 +154,16 @@ def test_rowemu_vs_oracle_rsplit(emu_engine, oracle_engine, seed):
     for d in (None, " ", "a", "ab", ",", "_-", "abc", "xay"):
         for n in (-1, 0):
             assert o.rsplit(s, d, n) == o.split(s, d, n), (d, n)
+
+
+BACKREF_CASES = [(r"(\w) (\w)", r"\1-\2"), (r"(\d+)\.(\d+)", r"<\2.\1>"), (r"(a|ab)(c|bcd)", r"[\2|\1|\0]"), (r"(a)|(b)", r"\1x\2"),
+                 (r"(é+)", r"\1\1"), (r"b", r"\0\0"), (r"(a)(b)?", r"\2\9_"), (r"(GET|POST) (/\S*)", r"\2 \1"), (r"((a|b)(c|x))+", r"\3\2\1"),
+                 (r"\b(\w)(\w*)", r"\2\1"), (r"x(?:y)(z)", r"\1"), (r"(.)", r"\1,")]
+
+
+@pytest.mark.parametrize("engine", [0, 1], ids=["lists", "dfa"])
+@pytest.mark.parametrize("pat,repl", BACKREF_CASES)
+def test_rowemu_vs_oracle_replace_with_backrefs(emu_engine, oracle_engine, pat, repl, engine):
+    emu_engine.e.set_engine(engine)
+    s = fuzzdata.rows(14, 300, alphabet=list("aabbc xyz_.\n019") + ["é", "ü", "😀"]) + fuzzdata.log_rows(11, 200)
+    assert emu_engine.replace_with_backrefs(s, pat, repl) == oracle_engine.replace_with_backrefs(s, pat, repl)

@@ -120,6 +120,10 @@ def run_c3(a, ov):
     del fa
     report("C3", "extract((\\d+)\\.(\\d+)\\.\\d+\\.(\\d+) ), 3 groups", rows, b, b + ov * rows + 3 * (ov * rows) + 6 * rows,
            timed(lambda: c3.extract(r"(\d+)\.(\d+)\.\d+\.(\d+) "), reps=2))
+    bk = c3.replace_with_backrefs(r"(\d+)\.(\d+)\.(\d+)\.(\d+)", r"\4.\3.\2.\1")
+    report("C3", "replace_with_backrefs(IPv4 octets reversed)", rows, b, b + nbytes(bk) + 2 * ov * rows,
+           timed(lambda: c3.replace_with_backrefs(r"(\d+)\.(\d+)\.(\d+)\.(\d+)", r"\4.\3.\2.\1"), reps=2))
+    del bk
     rep = c3.replace(IPV4, "<IP>")
     report("C3", "replace_re(IPv4,'<IP>')", rows, b, b + nbytes(rep) + 2 * ov * rows, timed(lambda: c3.replace(IPV4, "<IP>")))
     del rep
