@@ -985,7 +985,8 @@ __global__ void __launch_bounds__(256, CS_STREAM_WAVES) k_tdfa_replace_stream(St
 // Same staging as the replace kernel (contiguous tile runs per wave, next tile's chars in
 // flight), no output assembly: LDS holds the DFA table and one input tile per wave, so seven
 // workgroups fit a CU.  MODE 0 contains_re, 2 count_re, 3 findall spans (begins / lens [k * rows + row]),
-// 4 extract spans (leftmost match, then Tdfa::group_find per capture group, all on the staged row).
+// 4 extract spans (leftmost match, then Tdfa::group_find per capture group, all on the staged row),
+// 5 / 6 replace_with_backrefs sizes / bytes (csvm::row_backrefs on the staged row; the bytes go out per row lane).
 struct ScanStreamArgs {
   ColView in;
   const uint8_t* flags;
@@ -999,7 +1000,11 @@ struct ScanStreamArgs {
   int32_t* begins;    // MODE 3, 4
   int32_t* lens;
   int ncols;
-  const int32_t* gtags;  // MODE 4: capture-group tag image
+  const int32_t* gtags;  // MODE 4, 5, 6: capture-group tag image
+  int gt_off, gt_words;  // when gt_words > 0 the image is staged into LDS at byte offset gt_off (inside tbl_bytes)
+  const csvm::BackrefTemplate* tmpl;  // MODE 5, 6 (device memory: indexed per reference, must not live in the kernel arguments)
+  const int64_t* out_off;      // MODE 6
+  uint8_t* out_chars;
 };
 template <int MODE, bool IN_LDS, bool LONG = false>
 __global__ void __launch_bounds__(256) k_tdfa_scan_stream(ScanStreamArgs a) {
@@ -1013,6 +1018,12 @@ __global__ void __launch_bounds__(256) k_tdfa_scan_stream(ScanStreamArgs a) {
   const cstd::View& D = c.D;
   const csvm::ProgView& P = c.P;
   const ColView& in = a.in;
+  if (MODE >= 4 && a.gt_words > 0) {  // the group-tag tables are read once per DFA step: keep them next to the DFA table
+    int32_t* g = reinterpret_cast<int32_t*>(base + a.gt_off);
+    for (int i = threadIdx.x; i < a.gt_words; i += blockDim.x) g[i] = a.gtags[i];
+    __syncthreads();
+    a.gtags = g;
+  }
   const bool has_r2 = (((uint32_t)D.img[30] & 255u) <= (((uint32_t)D.img[30] >> 8) & 255u));
   const int R = LONG ? a.rows_per_tile : 64;
   const long long waves = (long long)gridDim.x * 4;
@@ -1064,7 +1075,27 @@ __global__ void __launch_bounds__(256) k_tdfa_scan_stream(ScanStreamArgs a) {
     }
     cstile::wave_lds_fence();
     int v = 0;
-    if (MODE == 4) {
+    if (MODE == 5 || MODE == 6) {
+      const uint8_t* p = lds_in + lead + rbeg;
+      cstd::Tdfa vm(D, P, p, n, (lead + rbeg) & 3);
+      auto find = [&](int from, int& mb, int& me) { return vm.find(from, n, mb, me) > 0; };
+      auto group = [&](int mb, int g, int& x, int& y) {
+        return g == 0 ? vm.find(mb, mb + 1, x, y) > 0 : vm.group_find(mb, a.gtags, g, x, y) > 0;
+      };
+      if (MODE == 5) {
+        int len = -1;
+        if (live) {
+          len = 0;
+          csvm::row_backrefs(p, n, *a.tmpl, find, group, [&](const uint8_t*, int k) { len += k; });
+        }
+        if (lane < nrows) a.out32[r0 + lane] = len;
+      } else if (live) {
+        uint8_t* o = a.out_chars + a.out_off[r0 + lane];
+        csvm::row_backrefs(p, n, *a.tmpl, find, group, [&](const uint8_t* q, int k) {
+          for (int i = 0; i < k; ++i) *o++ = q[i];
+        });
+      }
+    } else if (MODE == 4) {
       cstd::Tdfa vm(D, P, lds_in + lead + rbeg, n, (lead + rbeg) & 3);
       int mb = 0, me = 0;
       // leftmost match: the lean scan on ASCII tiles of short rows (as contains_re), else the generic find
@@ -1636,7 +1667,8 @@ int cs_extract(const cs_column* col, const cs_regex* cre, cs_stream stream, cs_c
       TPlan tp = tplan(re, rows, s);
       const TileChoice tc = choose_tile(col, s);
       const int cap = tc.cap;
-      const size_t lds = tp.lds_bytes + (size_t)(cap + 32 + (cap >> 3) + 32) * 4;
+      const size_t gt_bytes = re->gtags.size() * 4 <= 16 * 1024 ? ((re->gtags.size() * 4 + 15) & ~size_t(15)) : 0;
+      const size_t lds = tp.lds_bytes + gt_bytes + (size_t)(cap + 32 + (cap >> 3) + 32) * 4;
       if (tp.d.in_lds && tc.R && lds <= 150 * 1024) {
         Buf cnt = dev_alloc(8, s);
         CS_HIP(hipMemsetAsync(cnt->p, 0, 8, s));
@@ -1648,7 +1680,9 @@ int cs_extract(const cs_column* col, const cs_regex* cre, cs_stream stream, cs_c
         sa.nsub = (rows + tc.R - 1) / tc.R;
         sa.rows_per_tile = tc.R;
         sa.cap_in = cap;
-        sa.tbl_bytes = (int)tp.lds_bytes;
+        sa.tbl_bytes = (int)(tp.lds_bytes + gt_bytes);
+        sa.gt_off = (int)tp.lds_bytes;
+        sa.gt_words = gt_bytes ? (int)re->gtags.size() : 0;
         sa.begins = ptr<int32_t>(begins);
         sa.lens = ptr<int32_t>(lens);
         sa.ncols = groups;
@@ -1921,6 +1955,50 @@ int cs_replace_with_backrefs(const cs_column* col, const cs_regex* cre, const ch
 #undef CS_BR
       CS_HIP(hipGetLastError());
     };
+    // rows staged through LDS tiles by the scan stream kernel when the DFA carries the groups and the tiles fit
+    ScanStreamArgs sa{};
+    Buf d_tmpl;
+    size_t slds = 0;
+    unsigned sgrid = 0;
+    bool lng = false, stream = false;
+    // (measured on the 100M-row C3 column: 180 ms against 162 ms for the row-wise kernels below -- the per-lane work
+    // is too long for the few resident waves of the persistent kernel -- so the tile route is opt-in for now)
+    if (dfa && a.TL.in_lds && getenv("CS_BACKREFS_STREAM")) {
+      const TileChoice tc = choose_tile(col, s);
+      const size_t gt_bytes = (!re->gtags.empty() && re->gtags.size() * 4 <= 16 * 1024) ? ((re->gtags.size() * 4 + 15) & ~size_t(15)) : 0;
+      slds = lds + gt_bytes + (size_t)(tc.cap + 32 + (tc.cap >> 3) + 32) * 4;
+      if (tc.R && slds <= 150 * 1024) {
+        sa.gt_off = (int)lds;
+        sa.gt_words = gt_bytes ? (int)re->gtags.size() : 0;
+        stream = true;
+        lng = tc.lng;
+        sa.in = view_of(col);
+        sa.flags = d_unicode_flags();
+        sa.L = a.TL;
+        sa.nsub = (rows + tc.R - 1) / tc.R;
+        sa.rows_per_tile = tc.R;
+        sa.cap_in = tc.cap;
+        sa.tbl_bytes = (int)(lds + gt_bytes);
+        sa.gtags = a.gtags;
+        d_tmpl = dev_alloc(sizeof(csvm::BackrefTemplate), s);
+        CS_HIP(hipMemcpyAsync(d_tmpl->p, &t, sizeof(t), hipMemcpyHostToDevice, s));
+        sa.tmpl = ptr<const csvm::BackrefTemplate>(d_tmpl);
+      }
+    }
+    Buf scnt;
+    auto launch_stream = [&](bool write) {
+      if (!scnt) {
+        scnt = dev_alloc(8, s);
+        CS_HIP(hipMemsetAsync(scnt->p, 0, 8, s));
+        sa.found = ptr<unsigned long long>(scnt);
+      }
+      const void* kern = write ? (lng ? (const void*)&k_tdfa_scan_stream<6, true, true> : (const void*)&k_tdfa_scan_stream<6, true, false>)
+                               : (lng ? (const void*)&k_tdfa_scan_stream<5, true, true> : (const void*)&k_tdfa_scan_stream<5, true, false>);
+      if (slds > 48 * 1024) CS_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)slds));
+      sgrid = resident_grid(kern, slds, (sa.nsub + 3) / 4);
+      void* args[] = {&sa};
+      CS_HIP(hipLaunchKernel(kern, dim3(sgrid), dim3(256), args, slds, s));
+    };
     auto o = std::make_unique<cs_column>();
     o->rows = rows;
     o->validity = col->validity;
@@ -1928,14 +2006,25 @@ int cs_replace_with_backrefs(const cs_column* col, const cs_regex* cre, const ch
     Buf lens = dev_alloc(sizeof(int32_t) * rows, s);
     {
       ProfScope ps("k_backrefs_size", s);
-      launch(false, ptr<int32_t>(lens), nullptr, nullptr);
+      if (stream) {
+        sa.out32 = ptr<int32_t>(lens);
+        launch_stream(false);
+      } else {
+        launch(false, ptr<int32_t>(lens), nullptr, nullptr);
+      }
     }
     o->offsets = dev_alloc(sizeof(int64_t) * (rows + 1), s);
     o->nbytes = offsets_from_lengths(ptr<int32_t>(lens), rows, ptr<int64_t>(o->offsets), s);
     o->chars = dev_alloc((size_t)o->nbytes, s);
     {
       ProfScope ps("k_backrefs_write", s);
-      launch(true, nullptr, o->d_offsets(), ptr<uint8_t>(o->chars));
+      if (stream) {
+        sa.out_off = o->d_offsets();
+        sa.out_chars = ptr<uint8_t>(o->chars);
+        launch_stream(true);
+      } else {
+        launch(true, nullptr, o->d_offsets(), ptr<uint8_t>(o->chars));
+      }
     }
     CS_HIP(hipStreamSynchronize(s));
     *out = o.release();
