@@ -73,6 +73,7 @@ _PROTOS = {
     "cs_replace_with_backrefs": (i32, [vp, vp, cp, vp, P(vp)]),
     "cs_extract": (i32, [vp, vp, vp, P(P(vp)), P(i32)]),
     "cs_findall": (i32, [vp, vp, vp, P(P(vp)), P(i32)]),
+    "cs_records_from_columns": (i32, [P(vp), i32, i32, vp, i32, vp, P(vp)]),
     "cs_category_build": (i32, [vp, vp, P(vp)]),
     "cs_category_merge": (i32, [P(vp), i32, vp, P(vp)]),
     "cs_category_destroy": (i32, [vp]),

@@ -612,6 +612,58 @@ __global__ void k_gather_rows_at(cs::ColView in, const int64_t* __restrict__ out
   int n = (int)(in.offsets[r + 1] - in.offsets[r]);
   for (int i = 0; i < n; ++i) dst[i] = src[i];
 }
+// ---- record (row-major) forms: columns -> one flat column + list offsets ---------------------------
+// The reference's *_record methods return one NVStrings instance per row (extract_record.cu:146-152,
+// findall_record.cu:144-151: a device allocation per row).  Natively a record result is ONE column whose rows are
+// the records' strings in row-major order plus rows+1 list offsets: record r = flat rows [list[r], list[r+1]).
+struct RecordCols {
+  static constexpr int kMax = 64;
+  cs::ColView col[kMax];
+};
+// (the columns go through the kernels kMax at a time: c.col[j] is column k0 + j)
+// entries per record: all columns (fixed) or the row's leading non-null columns (ragged)
+__global__ void k_record_counts(RecordCols c, int k0, int nb, int ncols, int ragged, int64_t rows, int32_t* __restrict__ counts) {
+  int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (r >= rows) return;
+  if (!ragged) {
+    counts[r] = ncols;
+    return;
+  }
+  int n = k0 ? counts[r] : 0;
+  if (n == k0) {  // every earlier column was non-null for this row
+    int j = 0;
+    while (j < nb && row_is_valid(c.col[j].validity, r)) ++j;
+    n += j;
+  }
+  counts[r] = n;
+}
+__global__ void k_record_lengths(RecordCols c, int k0, int nb, int64_t rows, const int64_t* __restrict__ list,
+                                 int32_t* __restrict__ lens) {
+  int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (r >= rows) return;
+  const int64_t e0 = list[r];
+  const int n = (int)(list[r + 1] - e0);
+  for (int j = 0; j < nb && k0 + j < n; ++j) {
+    const cs::ColView& v = c.col[j];
+    lens[e0 + k0 + j] = row_is_valid(v.validity, r) ? (int32_t)(v.offsets[r + 1] - v.offsets[r]) : -1;
+  }
+}
+__global__ void k_record_copy(RecordCols c, int k0, int nb, int64_t rows, const int64_t* __restrict__ list,
+                              const int64_t* __restrict__ out_off, uint8_t* __restrict__ out_chars) {
+  int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (r >= rows) return;
+  const int64_t e0 = list[r];
+  const int n = (int)(list[r + 1] - e0);
+  for (int j = 0; j < nb && k0 + j < n; ++j) {
+    const cs::ColView& v = c.col[j];
+    if (!row_is_valid(v.validity, r)) continue;
+    const uint8_t* src = v.chars + v.offsets[r];
+    uint8_t* dst = out_chars + out_off[e0 + k0 + j];
+    const int len = (int)(v.offsets[r + 1] - v.offsets[r]);
+    for (int i = 0; i < len; ++i) dst[i] = src[i];
+  }
+}
+
 cs_column* concat_columns(const std::vector<const cs_column*>& cols, hipStream_t s) {
   int64_t rows = 0;
   bool any_mask = false;
@@ -1021,6 +1073,66 @@ int cs_prof_get(const char* kernel, double* total_ms, int64_t* launches) {
     prof_collect(it->second);
     if (total_ms) *total_ms = it->second.ms;
     if (launches) *launches = it->second.launches;
+  });
+}
+
+// Row-major ("record") view of a column-major result (cs_split / cs_rsplit / cs_extract / cs_findall).
+int cs_records_from_columns(const cs_column* const* cols, int ncols, int ragged, int64_t* list_offsets, int on_device,
+                            cs_stream stream, cs_column** out) {
+  return guard([&] {
+    if (!out || !list_offsets || ncols < 0 || (ncols > 0 && !cols)) fail(CS_ERR_INVALID_ARG, "records: bad arguments");
+    require_device();
+    hipStream_t s = S(stream);
+    const int64_t rows = ncols ? cols[0]->rows : 0;
+    for (int k = 0; k < ncols; ++k)
+      if (!cols[k] || cols[k]->rows != rows) fail(CS_ERR_INVALID_ARG, "records: columns of different row counts");
+    auto batch = [&](int k0, RecordCols& rc) {
+      const int nb = std::min(RecordCols::kMax, ncols - k0);
+      for (int j = 0; j < nb; ++j) rc.col[j] = view_of(cols[k0 + j]);
+      return nb;
+    };
+    Buf list = dev_alloc(sizeof(int64_t) * (rows + 1), s);
+    int64_t total = 0;
+    if (rows && ncols) {
+      Buf counts = dev_alloc(sizeof(int32_t) * rows, s);
+      for (int k0 = 0; k0 < ncols; k0 += RecordCols::kMax) {
+        RecordCols rc{};
+        const int nb = batch(k0, rc);
+        hipLaunchKernelGGL(k_record_counts, dim3(blocks_for(rows)), dim3(kBlock), 0, s, rc, k0, nb, ncols, ragged, rows, ptr<int32_t>(counts));
+      }
+      total = offsets_from_lengths(ptr<int32_t>(counts), rows, ptr<int64_t>(list), s);
+    } else {
+      CS_HIP(hipMemsetAsync(list->p, 0, sizeof(int64_t) * (rows + 1), s));
+    }
+    if (total >= (int64_t)1 << 31) fail(CS_ERR_RANGE, "records: more than 2^31 strings");
+    auto o = std::make_unique<cs_column>();
+    o->rows = total;
+    o->offsets = dev_alloc(sizeof(int64_t) * (total + 1), s);
+    if (total) {
+      Buf lens = dev_alloc(sizeof(int32_t) * total, s);
+      for (int k0 = 0; k0 < ncols; k0 += RecordCols::kMax) {
+        RecordCols rc{};
+        const int nb = batch(k0, rc);
+        hipLaunchKernelGGL(k_record_lengths, dim3(blocks_for(rows)), dim3(kBlock), 0, s, rc, k0, nb, rows, ptr<int64_t>(list), ptr<int32_t>(lens));
+      }
+      o->nbytes = offsets_from_lengths(ptr<int32_t>(lens), total, ptr<int64_t>(o->offsets), s);
+      o->chars = dev_alloc((size_t)o->nbytes, s);
+      o->validity = validity_from_lengths(ptr<int32_t>(lens), total, s);
+      for (int k0 = 0; k0 < ncols; k0 += RecordCols::kMax) {
+        RecordCols rc{};
+        const int nb = batch(k0, rc);
+        hipLaunchKernelGGL(k_record_copy, dim3(blocks_for(rows)), dim3(kBlock), 0, s, rc, k0, nb, rows, ptr<int64_t>(list), o->d_offsets(),
+                           ptr<uint8_t>(o->chars));
+      }
+      CS_HIP(hipGetLastError());
+    } else {
+      CS_HIP(hipMemsetAsync(o->offsets->p, 0, sizeof(int64_t), s));
+      o->chars = dev_alloc(0, s);
+      o->nbytes = 0;
+    }
+    CS_HIP(hipMemcpyAsync(list_offsets, list->p, sizeof(int64_t) * (rows + 1), on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s));
+    CS_HIP(hipStreamSynchronize(s));
+    *out = o.release();
   });
 }
 

@@ -91,7 +91,7 @@ _NOT_BUILT = (
     "len compare hash stoi stol stof stod htoi to_booleans ip2int timestamp2int cat join split_record "
     "rsplit_record partition rpartition get repeat pad ljust center rjust zfill wrap slice slice_from "
     "slice_replace insert replace_multi fillna capitalize swapcase title index rindex "
-    "find_from rfind findall_record match_strings startswith endswith extract_record isalnum "
+    "find_from rfind match_strings startswith endswith isalnum "
     "isalpha isdigit isspace isdecimal isnumeric islower isupper is_empty translate sort order gather "
     "scatter scalar_scatter remove_strings add_strings copy find_multiple url_encode url_decode get_ipc_data"
 ).split()
@@ -294,6 +294,38 @@ class nvstrings:
         if ncols.value:
             lib.cs_free(arr)
         return out
+
+    # ---- record (row-major) forms ---------------------------------------------------
+    @staticmethod
+    def _records(cols, ragged):
+        """Column-major result -> (flat nvstrings in row-major order, list offsets as a host numpy int64 array):
+        the native record form (cs_records_from_columns)."""
+        import numpy as np
+
+        rows = cols[0].size() if cols else 0
+        arr = (C.c_void_p * max(len(cols), 1))(*[c.m_cptr for c in cols])
+        loff = np.zeros(rows + 1, dtype=np.int64)
+        out = C.c_void_p()
+        check(lib.cs_records_from_columns(arr, len(cols), int(ragged), loff.ctypes.data, 0, None, C.byref(out)))
+        return nvstrings(out.value), loff
+
+    @staticmethod
+    def _rows_of(flat, loff):
+        return [flat.sublist(int(loff[r]), int(loff[r + 1])) for r in range(len(loff) - 1)]
+
+    def extract_record(self, pat, flat=False):
+        """nvstrings.py:2097-2125 -- per row the capture groups of its first match (null where there is none).
+        flat=True returns the native form instead: (one nvstrings in row-major order, list offsets)."""
+        cols = self.extract(pat)
+        if not cols:
+            return []
+        f, loff = self._records(cols, False)
+        return (f, loff) if flat else self._rows_of(f, loff)
+
+    def findall_record(self, pat, flat=False):
+        """nvstrings.py:1891-1919 -- per row all its matches (an empty instance where there is none)."""
+        f, loff = self._records(self.findall(pat), True)
+        return (f, loff) if flat else self._rows_of(f, loff)
 
     # ---- strip --------------------------------------------------------------------
     def _strip(self, to_strip, side):

@@ -193,6 +193,21 @@ int cs_extract(const cs_column* col, const cs_regex* re, cs_stream stream,
 int cs_findall(const cs_column* col, const cs_regex* re, cs_stream stream,
                cs_column*** out_cols, int* ncols);
 
+/* Record (row-major) forms -- NVStrings::split_record / rsplit_record /
+ * extract_record / findall_record (NVStrings.h:443-494,693,952;
+ * extract_record.cu:146-152, findall_record.cu:144-151) return one instance
+ * per row.  Natively a record result is ONE column holding the records'
+ * strings in row-major order plus rows+1 list offsets (record r = flat rows
+ * [list_offsets[r], list_offsets[r+1])).  This call transposes a column-major
+ * result (`ncols` columns of equal row count): ragged = 0 keeps
+ * every column per record, nulls included (extract_record); ragged = 1 keeps
+ * each row's leading non-null columns (findall_record, split_record: a null
+ * row or a row without matches has an empty record).  list_offsets: rows+1
+ * int64, device memory when on_device. */
+int cs_records_from_columns(const cs_column* const* cols, int ncols, int ragged,
+                            int64_t* list_offsets, int on_device, cs_stream stream,
+                            cs_column** out);
+
 /* ---- category (dictionary encoding) ------------------------------------ */
 /* NVCategory::create_from_strings (NVCategory.h:107; NVCategory.cu:220-304):
  * keys = sorted unique rows (null first, then unsigned bytewise order,

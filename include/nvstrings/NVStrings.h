@@ -110,6 +110,23 @@ class NVStrings {
     return 0;
   }
 
+  /* columns -> one NVStrings per row (ragged: each row's leading non-null columns) */
+  static void records(const std::vector<NVStrings*>& cols, int ragged, std::vector<NVStrings*>& results) {
+    if (cols.empty()) return;
+    std::vector<const cs_column*> h;
+    for (auto* c : cols) h.push_back(c->m_col);
+    const int64_t rows = (int64_t)cols[0]->size();
+    std::vector<int64_t> list((size_t)rows + 1, 0);
+    cs_column* flat = nullptr;
+    check(cs_records_from_columns(h.data(), (int)h.size(), ragged, list.data(), 0, nullptr, &flat));
+    for (int64_t r = 0; r < rows; ++r) {
+      cs_column* row = nullptr;
+      check(cs_column_slice(flat, list[(size_t)r], list[(size_t)r + 1] - list[(size_t)r], nullptr, &row));
+      results.push_back(new NVStrings(row));
+    }
+    cs_column_destroy(flat);
+  }
+
   /* NVStrings.h:504 -- column-major split on a delimiter; returns the column count */
   unsigned int split(const char* delimiter, int maxsplit, std::vector<NVStrings*>& results) {
     cs_column** cols = nullptr;
@@ -168,6 +185,22 @@ class NVStrings {
     for (int i = 0; i < n; ++i) results.push_back(new NVStrings(cols[i]));
     if (n) cs_free(cols);
     return n;
+  }
+  /* NVStrings.h:693,952 -- row-major forms: one instance per row, cut out of the native record column
+   * (cs_records_from_columns: one flat column + list offsets) */
+  int extract_record(const char* pattern, std::vector<NVStrings*>& results) {
+    std::vector<NVStrings*> cols;
+    const int n = extract(pattern, cols);
+    if (n > 0) records(cols, 0, results);
+    for (auto* c : cols) destroy(c);
+    return n < 0 ? n : (int)results.size();
+  }
+  int findall_record(const char* pattern, std::vector<NVStrings*>& results) {
+    std::vector<NVStrings*> cols;
+    const int n = findall(pattern, cols);
+    if (n > 0) records(cols, 1, results);
+    for (auto* c : cols) destroy(c);
+    return n < 0 ? n : (int)results.size();
   }
   /* NVStrings.h:788 */
   NVStrings* replace_with_backrefs(const char* pattern, const char* repl) {

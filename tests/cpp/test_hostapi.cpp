@@ -83,6 +83,15 @@ int main(int argc, char** argv) {
       EXPECT(verify_strings(r[1], {"Last", "Schmoe", "Smith", "Smith", nullptr, nullptr, nullptr, nullptr}));
     }
     for (auto* p : r) NVStrings::destroy(p);
+    r.clear();
+    EXPECT(strs->extract_record("(\\w+) (\\w+)", r) == 8);  // cpp/tests/test_extract.cpp:27-52
+    if (r.size() == 8) {
+      EXPECT(verify_strings(r[0], {"First", "Last"}));
+      EXPECT(verify_strings(r[3], {"Jane", "Smith"}));
+      EXPECT(verify_strings(r[4], {nullptr, nullptr}));
+      EXPECT(verify_strings(r[6], {nullptr, nullptr}));
+    }
+    for (auto* p : r) NVStrings::destroy(p);
     NVStrings::destroy(strs);
   }
   {  // replace / replace_re

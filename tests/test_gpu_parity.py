@@ -842,3 +842,48 @@ def test_gpu_c3_replace_with_backrefs(orc):
     pat, repl = r"(\d+)\.(\d+)\.(\d+)\.(\d+)", r"\4.\3.\2.\1"
     blob = np.ascontiguousarray(engines.reference_blob(pat))
     gpuutil.assert_same(g.replace_with_backrefs(pat, repl), orc.replace_with_backrefs(o, blob, repl), "replace_with_backrefs")
+
+
+# ---- record (row-major) forms of extract / findall --------------------------------------------------
+def _transpose(cols, ragged):
+    rows = len(cols[0]) if cols else 0
+    out = []
+    for r in range(rows):
+        rec = [c[r] for c in cols]
+        if ragged:
+            n = 0
+            while n < len(rec) and rec[n] is not None:
+                n += 1
+            rec = rec[:n]
+        out.append(rec)
+    return out
+
+
+def test_gpu_record_forms_reference_vectors(gpu_engine):
+    # cpp/tests/test_extract.cpp:27-52
+    s = ["First Last", "Joe Schmoe", "John Smith", "Jane Smith", "Beyonce", "Sting", None, ""]
+    got = [r.to_host() for r in gpu_engine.col(s).extract_record(r"(\w+) (\w+)")]
+    assert got == [["First", "Last"], ["Joe", "Schmoe"], ["John", "Smith"], ["Jane", "Smith"]] + [[None, None]] * 4
+    # python/tests/test_regex.py:129-136
+    s = ["hello", "and héllo", "this was empty", "", "another"]
+    got = [r.to_host() for r in gpu_engine.col(s).findall_record("[aA]")]
+    assert got == [[], ["a"], ["a"], [], ["a"]]
+
+
+@pytest.mark.parametrize("pat", [r"(\w+) (\w+)", r"(a)|(b)", r"(\d+)\.(\d+)", r"(x?)(y?)(z?)", r"\d+", r"a|b", r"\w+"])
+def test_gpu_record_forms_vs_oracle(gpu_engine, oracle_engine, pat):
+    s = fuzzdata.rows(15, 400, alphabet=list("aabbc xyz_.\n019") + ["é", "ü", "😀"]) + fuzzdata.log_rows(12, 300) + [None, ""]
+    col = gpu_engine.col(s)
+    want = oracle_engine.findall(s, pat)
+    flat, loff = col.findall_record(pat, flat=True)
+    recs = _transpose(want, True)
+    assert flat.to_host() == [x for rec in recs for x in rec]
+    assert loff.tolist() == [0] + list(np.cumsum([len(rec) for rec in recs]))
+    want = oracle_engine.extract(s, pat)
+    if want:
+        flat, loff = col.extract_record(pat, flat=True)
+        recs = _transpose(want, False)
+        assert flat.to_host() == [x for rec in recs for x in rec]
+        assert loff.tolist() == list(range(0, len(s) * len(want) + 1, len(want)))
+    else:
+        assert col.extract_record(pat) == []
