@@ -294,10 +294,16 @@ struct Tdfa {
   // for slot j, bits 8 / 9 for the match), where the simulator sets begin / end to the position.
   // Returns 1 and the range (byte offsets, -1 = never set) of the thread whose END wins, or 0.
   CS_HD int group_find(int from, const int32_t* G, int group, int& gb, int& ge) {
+    // rows below 255 bytes keep the four (begin, end) pairs in two registers, a byte per slot (255 = never set)
+    return n < 255 ? group_find_impl<true>(from, G, group, gb, ge) : group_find_impl<false>(from, G, group, gb, ge);
+  }
+  template <bool PACKED>
+  CS_HD int group_find_impl(int from, const int32_t* G, int group, int& gb, int& ge) {
     const uint32_t* tags = (const uint32_t*)(G + 36) + (long long)(group - 1) * (long long)G[3];
     const uint32_t* amap = (const uint32_t*)(G + 4);
     uint32_t state = D.init[MODE_SEED_ONCE * 8 + (D.uses ? prev_cat(from) : 0u)];
     int bx[kMaxSlots], by[kMaxSlots];
+    uint32_t px = 0xFFFFFFFFu, py = 0xFFFFFFFFu;  // PACKED
 #pragma unroll
     for (int j = 0; j < kMaxSlots; ++j) bx[j] = by[j] = -1;
     int matched = 0;
@@ -309,6 +315,7 @@ struct Tdfa {
         if (o == (uint32_t)j) r = v[j];
       return r;
     };
+    auto pick8 = [](uint32_t p, uint32_t o) -> uint32_t { return o > 3u ? 255u : (p >> (8u * o)) & 255u; };
     auto apply = [&](uint32_t e, uint32_t tg) -> bool {
       // most transitions inside a match keep every slot where it is and pass no bracket of the group
       if (tg == 0 && (e & (E_MATCH | E_COMPLEX | (15u << 16))) == 0) {
@@ -317,9 +324,15 @@ struct Tdfa {
       }
       if (e & E_MATCH) {
         const uint32_t o = e_match_origin(e);
-        const int mx = pick(bx, o), my = pick(by, o);
-        gb = (tg & 0x100u) ? pos : mx;
-        ge = (tg & 0x200u) ? pos : my;
+        if (PACKED) {
+          const uint32_t mx = (tg & 0x100u) ? (uint32_t)pos : pick8(px, o), my = (tg & 0x200u) ? (uint32_t)pos : pick8(py, o);
+          gb = mx == 255u ? -1 : (int)mx;
+          ge = my == 255u ? -1 : (int)my;
+        } else {
+          const int mx = pick(bx, o), my = pick(by, o);
+          gb = (tg & 0x100u) ? pos : mx;
+          ge = (tg & 0x200u) ? pos : my;
+        }
         matched = 1;
       }
       uint32_t og = 0x3210u;  // identity
@@ -329,17 +342,29 @@ struct Tdfa {
         const uint32_t keep = e_keep(e);
         if (keep != 15u) og = (0x3210u & ~(0xFFFFu << (4 * keep))) | (0xFFFFu << (4 * keep));
       }
-      int nx[kMaxSlots], ny[kMaxSlots];
+      if (PACKED) {
+        uint32_t nx = 0, ny = 0;
 #pragma unroll
-      for (int j = 0; j < kMaxSlots; ++j) {
-        const uint32_t o = (og >> (4 * j)) & 15u;
-        nx[j] = ((tg >> (2 * j)) & 1u) ? pos : pick(bx, o);
-        ny[j] = ((tg >> (2 * j + 1)) & 1u) ? pos : pick(by, o);
-      }
+        for (int j = 0; j < kMaxSlots; ++j) {
+          const uint32_t o = (og >> (4 * j)) & 15u;
+          nx |= (((tg >> (2 * j)) & 1u) ? (uint32_t)pos : pick8(px, o)) << (8 * j);
+          ny |= (((tg >> (2 * j + 1)) & 1u) ? (uint32_t)pos : pick8(py, o)) << (8 * j);
+        }
+        px = nx;
+        py = ny;
+      } else {
+        int nx[kMaxSlots], ny[kMaxSlots];
 #pragma unroll
-      for (int j = 0; j < kMaxSlots; ++j) {
-        bx[j] = nx[j];
-        by[j] = ny[j];
+        for (int j = 0; j < kMaxSlots; ++j) {
+          const uint32_t o = (og >> (4 * j)) & 15u;
+          nx[j] = ((tg >> (2 * j)) & 1u) ? pos : pick(bx, o);
+          ny[j] = ((tg >> (2 * j + 1)) & 1u) ? pos : pick(by, o);
+        }
+#pragma unroll
+        for (int j = 0; j < kMaxSlots; ++j) {
+          bx[j] = nx[j];
+          by[j] = ny[j];
+        }
       }
       state = e & E_STATE;
       return (e & E_STOP) != 0;

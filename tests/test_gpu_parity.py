@@ -735,6 +735,7 @@ def test_gpu_vs_oracle_extract(gpu_engine, oracle_engine, pat, route, monkeypatc
         monkeypatch.setenv("CS_EXTRACT_LISTS", "1")
     s = fuzzdata.rows(12, 700, alphabet=list("aabbc xyz_.\n019") + ["é", "ü", "😀"]) + fuzzdata.log_rows(7, 700)
     s += ["a" * 80, "ab" * 50, "abcdefgh" * 3, None, ""]
+    s += ["z" * 260 + " First Last 10.2.3.4 ab abcd xyz", "ab" * 150 + "c", "é" * 130 + " a b "]  # rows beyond the packed slots (255 bytes)
     assert gpu_engine.extract(s, pat) == oracle_engine.extract(s, pat)
 
 

@@ -103,6 +103,7 @@ def test_rowemu_vs_oracle_extract(emu_engine, oracle_engine, pat, engine):
     """extract: the product's per-row logic (find + one anchored GroupVm run per group) vs the oracle."""
     emu_engine.e.set_engine(engine)
     s = fuzzdata.rows(12, 300, alphabet=list("aabbc xyz_.\n019") + ["é", "ü", "😀"]) + fuzzdata.log_rows(7, 200)
+    s += ["z" * 260 + " First Last 10.2.3.4 ab abcd xyz", "ab" * 150 + "c", "é" * 130 + " a b "]  # rows beyond the packed slots (255 bytes)
     assert emu_engine.extract(s, pat) == oracle_engine.extract(s, pat)
 
 
