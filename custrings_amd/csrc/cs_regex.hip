@@ -405,15 +405,20 @@ __device__ __forceinline__ void backrefs_for_row(const TCtx& c, const csvm::Prog
   if constexpr (DFA) {
     cstd::Tdfa vm(c.D, c.P, p, n);
     vm.wide_ok = (b & ~(int64_t)3) + cstd::Tdfa::kMaskBytes <= src.safe_end;
+    // the matches by the flat scan loop of replace_re (word-wise idle skipping), not by one find() per match
     csvm::row_backrefs(
-        p, n, t, [&](int from, int& mb, int& me) { return vm.find(from, n, mb, me) > 0; },
+        p, n, t, [&](auto&& f) { csvm::walk_matches(vm, f); },
         [&](int mb, int g, int& x, int& y) { return g == 0 ? vm.find(mb, mb + 1, x, y) > 0 : vm.group_find(mb, gtags, g, x, y) > 0; }, out);
   } else {
     csvm::row_backrefs(
         p, n, t,
-        [&](int from, int& mb, int& me) {
-          csvm::Vm<SMALL> vm(P, mem, stride, p, n);
-          return vm.find(from, n, mb, me) > 0;
+        [&](auto&& f) {
+          csvm::walk_matches_by_find(
+              [&](int from, int& mb, int& me) {
+                csvm::Vm<SMALL> vm(P, mem, stride, p, n);
+                return vm.find(from, n, mb, me) > 0;
+              },
+              f);
         },
         [&](int mb, int g, int& x, int& y) {
           if (g == 0) {
@@ -1078,7 +1083,7 @@ __global__ void __launch_bounds__(256) k_tdfa_scan_stream(ScanStreamArgs a) {
     if (MODE == 5 || MODE == 6) {
       const uint8_t* p = lds_in + lead + rbeg;
       cstd::Tdfa vm(D, P, p, n, (lead + rbeg) & 3);
-      auto find = [&](int from, int& mb, int& me) { return vm.find(from, n, mb, me) > 0; };
+      auto find = [&](auto&& f) { csvm::walk_matches(vm, f); };
       auto group = [&](int mb, int g, int& x, int& y) {
         return g == 0 ? vm.find(mb, mb + 1, x, y) > 0 : vm.group_find(mb, a.gtags, g, x, y) > 0;
       };
@@ -1961,9 +1966,7 @@ int cs_replace_with_backrefs(const cs_column* col, const cs_regex* cre, const ch
     size_t slds = 0;
     unsigned sgrid = 0;
     bool lng = false, stream = false;
-    // (measured on the 100M-row C3 column: 180 ms against 162 ms for the row-wise kernels below -- the per-lane work
-    // is too long for the few resident waves of the persistent kernel -- so the tile route is opt-in for now)
-    if (dfa && a.TL.in_lds && getenv("CS_BACKREFS_STREAM")) {
+    if (dfa && a.TL.in_lds && !getenv("CS_REGEX_ROWWISE")) {
       const TileChoice tc = choose_tile(col, s);
       const size_t gt_bytes = (!re->gtags.empty() && re->gtags.size() * 4 <= 16 * 1024) ? ((re->gtags.size() * 4 + 15) & ~size_t(15)) : 0;
       slds = lds + gt_bytes + (size_t)(tc.cap + 32 + (tc.cap >> 3) + 32) * 4;

@@ -970,6 +970,32 @@ CS_HD void row_replace_matches(cstd::Tdfa& vm, int maxrepl, Emit&& emit) {
 #endif
   vm.scan<cstd::Tdfa::K_REPLACE>(maxrepl, emit);
 }
+// The match walk of replace_with_backrefs on the DFA: the first matches of the row by the flat scan loop (word-wise
+// idle skipping), kept in registers and handed to f(mb, me) only after the scan -- f runs whole DFA passes of its
+// own (group_find), which must not sit inside the scan loop -- the rare rest by one find() per match.
+template <class F>
+CS_HD void walk_matches(cstd::Tdfa& vm, F&& f) {
+  constexpr int kKeep = 4;
+  int mbs[kKeep], mes[kKeep], cnt = 0;
+  row_replace_matches(vm, kKeep, [&](int mb, int me, int) {
+#pragma unroll
+    for (int j = 0; j < kKeep; ++j)
+      if (cnt == j) {
+        mbs[j] = mb;
+        mes[j] = me;
+      }
+    ++cnt;
+  });
+  int last = 0;
+#pragma unroll
+  for (int j = 0; j < kKeep; ++j)
+    if (j < cnt) {
+      f(mbs[j], mes[j]);
+      last = mes[j];
+    }
+  if (cnt >= kKeep && mes[kKeep - 1] > mbs[kKeep - 1])
+    walk_matches_by_find([&](int from, int& mb, int& me) { return vm.find(from, vm.n, mb, me) > 0; }, f, last);
+}
 }  // namespace csvm
 
 namespace csrx {

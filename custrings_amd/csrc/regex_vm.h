@@ -461,9 +461,8 @@ CS_HD int row_count_re(VM& vm) {
 }
 // replace_backref.cu:36-125: walks the matches of a row and sends the output through out(ptr, len):
 // the text before each match, then the template with the capture groups of that match filled in.
-// find(from, mb, me): leftmost match starting in [from, n); group(mb, g, x, y): the range of group g
-// (0 = whole match) in the program run anchored at mb.  Matches are never empty (the host rejects
-// patterns that can match the empty string: the reference would not terminate on them).
+// Matches are never empty where it matters (the host rejects patterns that can match the empty string
+// when the DFA knows: the reference would not terminate on them).
 struct BackrefTemplate {
   static constexpr int kMaxRefs = 16;
   const uint8_t* text;  // template without the references
@@ -473,12 +472,12 @@ struct BackrefTemplate {
   int pos[kMaxRefs];  // byte position in `text`
   int groups;         // capture groups of the program
 };
-template <class Find, class Group, class Out>
-CS_HD void row_backrefs(const uint8_t* p, int n, const BackrefTemplate& t, Find&& find, Group&& group, Out&& out) {
-  int lpos = 0, from = 0;
-  for (;;) {
-    int mb = 0, me = 0;
-    if (!find(from, mb, me)) break;
+// walk(f): calls f(mb, me) for every match of the row in replace order (non-empty matches: the next search
+// starts at me); group(mb, g, x, y): the range of group g (0 = whole match) in the program run anchored at mb.
+template <class Walk, class Group, class Out>
+CS_HD void row_backrefs(const uint8_t* p, int n, const BackrefTemplate& t, Walk&& walk, Group&& group, Out&& out) {
+  int lpos = 0;
+  walk([&](int mb, int me) {
     out(p + lpos, mb - lpos);
     int il = 0;
     for (int j = 0; j < t.nrefs; ++j) {
@@ -489,10 +488,19 @@ CS_HD void row_backrefs(const uint8_t* p, int n, const BackrefTemplate& t, Find&
     }
     out(t.text + il, t.bytes - il);
     lpos = me;
+  });
+  out(p + lpos, n - lpos);
+}
+// the match walk on successive find() calls (list simulators); stops at an empty match
+template <class Find, class F>
+CS_HD void walk_matches_by_find(Find&& find, F&& f, int from = 0) {
+  for (;;) {
+    int mb = 0, me = 0;
+    if (!find(from, mb, me)) break;
+    f(mb, me);
     if (me <= mb) break;
     from = me;
   }
-  out(p + lpos, n - lpos);
 }
 // findall.cu:61-77: the count_re walk reporting every match span; emit(k, mb, me) returns false to stop.
 template <class VM, class Emit>

@@ -383,7 +383,7 @@ emu_col* emu_replace_with_backrefs(const emu_col* c, const emu_regex* re, const 
       cstd::View D = cstd::make_view(re->tdfa.data());
       cstd::Tdfa vm(D, P, p, n);
       csvm::row_backrefs(
-          p, n, t, [&](int from, int& mb, int& me) { return vm.find(from, n, mb, me) > 0; },
+          p, n, t, [&](auto&& f) { csvm::walk_matches(vm, f); },
           [&](int mb, int g, int& x, int& y) {
             return g == 0 ? vm.find(mb, mb + 1, x, y) > 0 : vm.group_find(mb, re->gtags.data(), g, x, y) > 0;
           },
@@ -391,9 +391,13 @@ emu_col* emu_replace_with_backrefs(const emu_col* c, const emu_regex* re, const 
     } else {
       csvm::row_backrefs(
           p, n, t,
-          [&](int from, int& mb, int& me) {
-            csvm::Vm<false> vm(P, mem.data(), 1, p, n);
-            return vm.find(from, n, mb, me) > 0;
+          [&](auto&& f) {
+            csvm::walk_matches_by_find(
+                [&](int from, int& mb, int& me) {
+                  csvm::Vm<false> vm(P, mem.data(), 1, p, n);
+                  return vm.find(from, n, mb, me) > 0;
+                },
+                f);
           },
           [&](int mb, int g, int& x, int& y) {
             if (g == 0) {

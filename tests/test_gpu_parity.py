@@ -815,13 +815,13 @@ BACKREF_CASES = [(r"(\w) (\w)", r"\1-\2"), (r"(\d+)\.(\d+)", r"<\2.\1>"), (r"(a|
                  (r"\b(\w)(\w*)", r"\2\1"), (r"x(?:y)(z)", r"\1"), (r"(.)", r"\1,"), (r"(a|b|c|d|e|f|g|h){8}(x)?", r"<\1\2>")]
 
 
-@pytest.mark.parametrize("route", ["dfa", "lists", "tiles"])
+@pytest.mark.parametrize("route", ["tiles", "lists", "rowwise"])
 @pytest.mark.parametrize("pat,repl", BACKREF_CASES, ids=[repr(p)[:24] for p, _ in BACKREF_CASES])
 def test_gpu_vs_oracle_replace_with_backrefs(gpu_engine, oracle_engine, pat, repl, route, monkeypatch):
     if route == "lists":
         monkeypatch.setenv("CS_REGEX_NO_TDFA", "1")
-    if route == "tiles":
-        monkeypatch.setenv("CS_BACKREFS_STREAM", "1")
+    if route == "rowwise":
+        monkeypatch.setenv("CS_REGEX_ROWWISE", "1")
     s = fuzzdata.rows(14, 600, alphabet=list("aabbc xyz_.\n019") + ["é", "ü", "😀"]) + fuzzdata.log_rows(11, 600)
     s += ["a" * 80, "ab" * 50, "abcdefgh" * 3, None, ""]
     assert gpu_engine.replace_with_backrefs(s, pat, repl) == oracle_engine.replace_with_backrefs(s, pat, repl)
