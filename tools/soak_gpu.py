@@ -84,6 +84,14 @@ def snapshot(g, rows, rng_seed):
         out["replace %r %r" % (pat, repl)] = gpuutil.to_col(g.replace(pat, repl, regex=False))
     for d, n in ((" ", -1), (".", 2), (None, -1), (None, 2), ("ab", -1)):
         out["split %r %d" % (d, n)] = [gpuutil.to_col(c) for c in g.split(d, n)]
+    for d, n in ((" ", 2), (None, 1), ("ab", -1), ("aa", -1)):
+        out["rsplit %r %d" % (d, n)] = [gpuutil.to_col(c) for c in g.rsplit(d, n)]
+    for pat in (r"(\d+)\.(\d+)", r"(a|b)(c)?", r"(\w+) (\w+)"):
+        out["extract %r" % pat] = [gpuutil.to_col(c) for c in g.extract(pat)]
+    for pat in (r"\d+", r"[a-c]+"):
+        out["findall %r" % pat] = [gpuutil.to_col(c) for c in g.findall(pat)]
+    for pat, repl in ((r"(\d+)\.(\d+)", r"\2.\1"), (r"(a|b)(c)?", r"<\2\1\0>")):
+        out["backrefs %r %r" % (pat, repl)] = gpuutil.to_col(g.replace_with_backrefs(pat, repl))
     tok = nvtext.tokenize(g)
     out["tokenize"] = gpuutil.to_col(tok)
     out["tokenize set"] = gpuutil.to_col(nvtext.tokenize(g, " ."))
@@ -125,6 +133,18 @@ def oracle_leg(col, fast, seed):
             elif op == "split":
                 d, n = _parse2(rest)
                 want[k] = ORC.split(col, d, n)
+            elif op == "rsplit":
+                d, n = _parse2(rest)
+                want[k] = ORC.rsplit(col, d, n)
+            elif op == "extract":
+                import ast
+                want[k] = ORC.extract(col, np.ascontiguousarray(engines.reference_blob(ast.literal_eval(rest))))
+            elif op == "findall":
+                import ast
+                want[k] = ORC.findall(col, np.ascontiguousarray(engines.reference_blob(ast.literal_eval(rest))))
+            elif op == "backrefs":
+                pat, repl = _split_reprs(rest)
+                want[k] = ORC.replace_with_backrefs(col, np.ascontiguousarray(engines.reference_blob(pat)), repl)
             elif k == "tokenize":
                 want[k] = ORC.tokenize(col)
             elif k == "tokenize set":
