@@ -1005,6 +1005,7 @@ struct ScanStreamArgs {
   int32_t* begins;    // MODE 3, 4
   int32_t* lens;
   int ncols;
+  int* maxp;             // MODE 3 (optional): receives the largest match count of a row
   const int32_t* gtags;  // MODE 4, 5, 6: capture-group tag image
   int gt_off, gt_words;  // when gt_words > 0 the image is staged into LDS at byte offset gt_off (inside tbl_bytes)
   const csvm::BackrefTemplate* tmpl;  // MODE 5, 6 (device memory: indexed per reference, must not live in the kernel arguments)
@@ -1170,6 +1171,12 @@ __global__ void __launch_bounds__(256) k_tdfa_scan_stream(ScanStreamArgs a) {
       }
       if (MODE == 3 && lane < nrows)
         for (int j = live ? k : 0; j < a.ncols; ++j) a.lens[(long long)j * in.rows + r0 + lane] = -1;
+      if (MODE == 3 && a.maxp) {
+        int m = live ? k : 0;
+        for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o));
+        // (only a wave that would raise the maximum issues the same-address atomic)
+        if (lane == 0 && m > __hip_atomic_load(a.maxp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(a.maxp, m);
+      }
     }
     if (lane < nrows) {
       if (MODE == 2) a.out32[r0 + lane] = v;
@@ -1782,18 +1789,6 @@ int cs_findall(const cs_column* col, const cs_regex* cre, cs_stream stream, cs_c
     *ncols_out = 0;
     const int64_t rows = col->rows;
     if (rows == 0) return;
-    // matches per row (the count_re kernels), their maximum = number of columns
-    Buf counts = dev_alloc(sizeof(int32_t) * rows, s);
-    scan<2>(col, re, nullptr, ptr<int32_t>(counts), 1, s, nullptr, "k_count_re");
-    Buf dmax = dev_alloc(8, s);
-    CS_HIP(hipMemsetAsync(dmax->p, 0, 8, s));
-    hipLaunchKernelGGL(k_max_i32, dim3((unsigned)std::min<int64_t>((rows + 255) / 256, 2048)), dim3(256), 0, s, ptr<int32_t>(counts), rows,
-                       ptr<int>(dmax));
-    int* hmax = (int*)pinned_scratch(8);
-    CS_HIP(hipMemcpyAsync(hmax, dmax->p, 4, hipMemcpyDeviceToHost, s));
-    CS_HIP(hipStreamSynchronize(s));
-    const int ncols = hmax[0];
-    counts.reset();
     auto finish = [&](std::vector<std::unique_ptr<cs_column>>& cols) {
       cs_column** arr = (cs_column**)malloc(sizeof(cs_column*) * cols.size());
       if (!arr) fail(CS_ERR_ALLOC, "host allocation failed");
@@ -1802,42 +1797,81 @@ int cs_findall(const cs_column* col, const cs_regex* cre, cs_stream stream, cs_c
       *ncols_out = (int)cols.size();
     };
     std::vector<std::unique_ptr<cs_column>> cols;
-    if (ncols == 0) {  // findall.cu:149-151
-      cols.emplace_back(make_all_null(rows, s));
-      finish(cols);
-      return;
-    }
+    Buf dmax = dev_alloc(8, s);
+    int* hmax = (int*)pinned_scratch(8);
+    auto read_max = [&]() {
+      CS_HIP(hipMemcpyAsync(hmax, dmax->p, 4, hipMemcpyDeviceToHost, s));
+      CS_HIP(hipStreamSynchronize(s));
+      return hmax[0];
+    };
     RowSrc src{view_of(col), d_unicode_flags(), col->nbytes + (col->chars && col->chars->capacity ? 64 : 0)};
-    Buf begins = dev_alloc(sizeof(int32_t) * rows * ncols, s);
-    Buf lens = dev_alloc(sizeof(int32_t) * rows * ncols, s);
+    Buf begins, lens;
     Plan pl{};
+    int ncols = -1;  // unknown
     bool streamed = false;
-    if (use_tdfa(re) && !getenv("CS_REGEX_ROWWISE")) {  // the count_re stream kernel, reporting spans
+    // The scan stream kernel reports spans and the largest match count in ONE pass when the rows hold at most
+    // kProvisional matches (the span arrays are laid out [k * rows + row], so unused columns cost only memory);
+    // a column with busier rows is scanned a second time with the exact column count.
+    constexpr int kProvisional = 4;
+    if (use_tdfa(re) && !getenv("CS_REGEX_ROWWISE")) {
       TPlan tp = tplan(re, rows, s);
       const TileChoice tc = choose_tile(col, s);
       const int cap = tc.cap;
       const size_t lds = tp.lds_bytes + (size_t)(cap + 32 + (cap >> 3) + 32) * 4;
       if (tp.d.in_lds && tc.R && lds <= 150 * 1024) {
+        Buf hits = dev_alloc(8, s);
+        CS_HIP(hipMemsetAsync(hits->p, 0, 8, s));
         ScanStreamArgs sa{};
         sa.in = view_of(col);
         sa.flags = d_unicode_flags();
         sa.L = tp.d;
-        sa.found = ptr<unsigned long long>(dmax);  // (hit counter: not used here)
+        sa.found = ptr<unsigned long long>(hits);  // (hit counter: not used here)
         sa.nsub = (rows + tc.R - 1) / tc.R;
         sa.rows_per_tile = tc.R;
         sa.cap_in = cap;
         sa.tbl_bytes = (int)tp.lds_bytes;
-        sa.begins = ptr<int32_t>(begins);
-        sa.lens = ptr<int32_t>(lens);
-        sa.ncols = ncols;
+        sa.maxp = ptr<int>(dmax);
         auto kern = tc.lng ? &k_tdfa_scan_stream<3, true, true> : &k_tdfa_scan_stream<3, true, false>;
         if (lds > 48 * 1024)
           CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         const unsigned grid = resident_grid(reinterpret_cast<const void*>(kern), lds, (sa.nsub + 3) / 4);
-        ProfScope ps("k_findall_spans", s);
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, sa);
+        int width = kProvisional;
+        for (int pass = 0; pass < 2; ++pass) {
+          begins = dev_alloc(sizeof(int32_t) * rows * width, s);
+          lens = dev_alloc(sizeof(int32_t) * rows * width, s);
+          CS_HIP(hipMemsetAsync(dmax->p, 0, 8, s));
+          sa.begins = ptr<int32_t>(begins);
+          sa.lens = ptr<int32_t>(lens);
+          sa.ncols = width;
+          {
+            ProfScope ps("k_findall_spans", s);
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, sa);
+          }
+          CS_HIP(hipGetLastError());
+          ncols = read_max();
+          if (ncols <= width) break;
+          width = ncols;  // busier rows than provisioned for: once more, exactly
+        }
         streamed = true;
       }
+    }
+    if (!streamed) {
+      // matches per row (the count_re kernels), their maximum = number of columns
+      Buf counts = dev_alloc(sizeof(int32_t) * rows, s);
+      scan<2>(col, re, nullptr, ptr<int32_t>(counts), 1, s, nullptr, "k_count_re");
+      CS_HIP(hipMemsetAsync(dmax->p, 0, 8, s));
+      hipLaunchKernelGGL(k_max_i32, dim3((unsigned)std::min<int64_t>((rows + 255) / 256, 2048)), dim3(256), 0, s, ptr<int32_t>(counts), rows,
+                         ptr<int>(dmax));
+      ncols = read_max();
+    }
+    if (ncols == 0) {  // findall.cu:149-151
+      cols.emplace_back(make_all_null(rows, s));
+      finish(cols);
+      return;
+    }
+    if (!streamed) {
+      begins = dev_alloc(sizeof(int32_t) * rows * ncols, s);
+      lens = dev_alloc(sizeof(int32_t) * rows * ncols, s);
     }
     if (!streamed) {
       ProfScope ps("k_findall_spans", s);
