@@ -147,7 +147,7 @@ def main():
         if dom:
             a = alg_kernel.get(dom, 0) * rows / (prof[dom]["avg_ms"] * 1e-3) / 1e9
             roofline = {"bound": "hbm", "kernel": dom, "achieved": round(a, 1), "peak": 8000.0, "unit": "GB/s",
-                        "frac": round(a / 8000.0, 4), "traffic": traffic,
+                        "frac": round(a / 8000.0, 4), "frac_of_achievable_6300": round(a / 6300.0, 4), "traffic": traffic,
                         "avg_ms": round(prof[dom]["avg_ms"], 3),
                         "alg_bytes_per_row": round(alg_kernel.get(dom, 0), 2)}
         ms_step = elapsed / args.steps * 1e3
