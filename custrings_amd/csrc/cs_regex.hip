@@ -1955,7 +1955,7 @@ int cs_replace_with_backrefs(const cs_column* col, const cs_regex* cre, const ch
     t.groups = re->prog.num_groups;
     upload(re, s);
     const bool dfa = use_tdfa(re) && (re->d_gtags || re->prog.num_groups == 0);
-    if (dfa ? re->tdfa[13] == 0 : false) fail(CS_ERR_INVALID_ARG, "replace_with_backrefs: the pattern matches the empty string");
+    if (csrx::min_match_chars(re->prog) == 0) fail(CS_ERR_INVALID_ARG, "replace_with_backrefs: the pattern matches the empty string");
     Buf d_text = dev_alloc(text.size() + 1, s);
     CS_HIP(hipMemcpyAsync(d_text->p, text.c_str(), text.size() + 1, hipMemcpyHostToDevice, s));
     t.text = ptr<const uint8_t>(d_text);
@@ -1972,7 +1972,6 @@ int cs_replace_with_backrefs(const cs_column* col, const cs_regex* cre, const ch
       a.TL = tp.d;
       lds = tp.lds_bytes;
     } else {
-      // (no minimum match length without the DFA: the row walk stops at an empty match)
       a.L.image = ptr<const int32_t>(re->d_image);
       a.L.image_words = (int)re->image.size();
       a.L.slots = csvm::gvm_slots(ninst);

@@ -9,6 +9,56 @@
 #include "regex_program.h"
 
 namespace csrx {
+// shortest number of characters a match consumes (0: the pattern matches the empty string)
+int min_match_chars(const Program& P) {
+  // shortest number of consumed characters from any start to END (BFS, 0-1 weights)
+  const int n = (int)P.insts.size();
+  std::vector<int> dist(n, 1 << 28);
+  std::vector<int> q;
+  for (int32_t s : P.starts) {
+    if (s < 0) break;
+    if (s < n) {
+      dist[s] = 0;
+      q.push_back(s);
+    }
+  }
+  int best = 1 << 28;
+  for (size_t h = 0; h < q.size(); ++h) {  // Bellman-Ford style relaxation (tiny graphs)
+    int id = q[h];
+    const Inst& in = P.insts[id];
+    auto relax = [&](int to, int w) {
+      if (to < 0 || to >= n) return;
+      if (dist[id] + w < dist[to]) {
+        dist[to] = dist[id] + w;
+        q.push_back(to);
+      }
+    };
+    switch (in.type) {
+      case OP_END: best = std::min(best, dist[id]); break;
+      case OP_OR:
+        relax(in.u1, 0);
+        relax(in.u2, 0);
+        break;
+      case OP_LBRA:
+      case OP_RBRA:
+      case OP_BOL:
+      case OP_EOL:
+      case OP_BOW:
+      case OP_NBOW: relax(in.u2, 0); break;
+      case OP_CHAR:
+      case OP_ANY:
+      case OP_ANYNL:
+      case OP_CCLASS:
+      case OP_NCCLASS: relax(in.u2, 1); break;
+      default: break;
+    }
+    if (q.size() > (size_t)n * n * 4 + 64) break;
+  }
+  return best >= (1 << 28) ? 0 : best;
+}
+}  // namespace csrx
+
+namespace csrx {
 namespace {
 
 using cstd::kMaxSlots;
@@ -234,52 +284,7 @@ struct Builder {
     return true;
   }
 
-  int min_match_chars() const {
-    // shortest number of consumed characters from any start to END (BFS, 0-1 weights)
-    const int n = (int)P.insts.size();
-    std::vector<int> dist(n, 1 << 28);
-    std::vector<int> q;
-    for (int32_t s : P.starts) {
-      if (s < 0) break;
-      if (s < n) {
-        dist[s] = 0;
-        q.push_back(s);
-      }
-    }
-    int best = 1 << 28;
-    for (size_t h = 0; h < q.size(); ++h) {  // Bellman-Ford style relaxation (tiny graphs)
-      int id = q[h];
-      const Inst& in = P.insts[id];
-      auto relax = [&](int to, int w) {
-        if (to < 0 || to >= n) return;
-        if (dist[id] + w < dist[to]) {
-          dist[to] = dist[id] + w;
-          q.push_back(to);
-        }
-      };
-      switch (in.type) {
-        case OP_END: best = std::min(best, dist[id]); break;
-        case OP_OR:
-          relax(in.u1, 0);
-          relax(in.u2, 0);
-          break;
-        case OP_LBRA:
-        case OP_RBRA:
-        case OP_BOL:
-        case OP_EOL:
-        case OP_BOW:
-        case OP_NBOW: relax(in.u2, 0); break;
-        case OP_CHAR:
-        case OP_ANY:
-        case OP_ANYNL:
-        case OP_CCLASS:
-        case OP_NCCLASS: relax(in.u2, 1); break;
-        default: break;
-      }
-      if (q.size() > (size_t)n * n * 4 + 64) break;
-    }
-    return best >= (1 << 28) ? 0 : best;
-  }
+  int min_match_chars() const { return csrx::min_match_chars(P); }
 };
 
 }  // namespace

@@ -1003,6 +1003,8 @@ struct Program;
 // Host: builds the image; returns an empty vector when the program is not
 // convertible within the limits above.  `image` is the list simulator's device
 // image of the same program (Program::to_device_image), `flags` the unicode table.
+// Shortest number of characters a match of the program consumes (0 = it matches the empty string).
+int min_match_chars(const Program& prog);
 // `groups_out` (optional) receives the capture-group tag image consumed by cstd::Tdfa::group_find
 // (empty when the program has no groups).
 std::vector<int32_t> build_tdfa(const Program& prog, const std::vector<int32_t>& image, const uint8_t* flags,

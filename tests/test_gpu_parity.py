@@ -827,7 +827,10 @@ def test_gpu_vs_oracle_replace_with_backrefs(gpu_engine, oracle_engine, pat, rep
     assert gpu_engine.replace_with_backrefs(s, pat, repl) == oracle_engine.replace_with_backrefs(s, pat, repl)
 
 
-def test_gpu_replace_with_backrefs_edges(gpu_engine):
+@pytest.mark.parametrize("route", ["dfa", "lists"])
+def test_gpu_replace_with_backrefs_edges(gpu_engine, route, monkeypatch):
+    if route == "lists":
+        monkeypatch.setenv("CS_REGEX_NO_TDFA", "1")
     col = gpu_engine.col(["a1", None, ""])
     assert col.replace_with_backrefs(r"(\d)", None).to_host() == [None, None, None]
     with pytest.raises(ValueError):
