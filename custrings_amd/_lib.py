@@ -38,6 +38,8 @@ _PROTOS = {
     "cs_last_error": (cp, []),
     "cs_device_count": (i32, []),
     "cs_init": (i32, [i32]),
+    "cs_current_device": (i32, []),
+    "cs_fallback_count": (i64, []),
     "cs_device_bytes_in_use": (i64, []),
     "cs_free": (None, [vp]),
     "cs_column_from_host_strings": (i32, [P(cp), i64, vp, P(vp)]),

@@ -3,9 +3,11 @@
 // attrs.cu:72-112), the lengths->offsets scan and measurement hooks.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <set>
 #include <unordered_map>
 
 #include "_gen/unicode_tables.inc"  // cs_unicode_flags[65536], cs_charcases[65536]
@@ -29,9 +31,28 @@ static uint8_t* g_d_flags = nullptr;
 static uint16_t* g_d_cases = nullptr;
 static int64_t g_in_use = 0;
 static std::multimap<size_t, std::pair<void*, hipStream_t>> g_cache;  // capacity -> block
+// Streams that have asked for buffers.  While there is one (the usual case) stream order alone
+// makes the reuse of a released block safe.  With more, a block may still be read by a kernel on
+// a stream other than the one it was allocated on when its last handle goes away, so a release
+// then waits for the device before the block returns to the cache.
+static std::set<hipStream_t> g_streams;
+static std::atomic<bool> g_multi_stream{false};
+static std::atomic<long long> g_fallbacks{0};
 
 void require_device() {
   if (g_device < 0) fail(CS_ERR_NO_DEVICE, "cs_init has not succeeded: no usable gfx950 device (there is no CPU fallback)");
+  // hipSetDevice is per thread: a host thread other than the one that ran cs_init would launch on device 0
+  static thread_local int bound = -1;
+  if (bound != g_device) {
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess || cur != g_device) CS_HIP(hipSetDevice(g_device));
+    bound = g_device;
+  }
+}
+int bound_device() { return g_device; }
+void note_fallback(const char* what) {
+  if (g_fallbacks.fetch_add(1) == 0 || getenv("CS_LOG_FALLBACKS"))
+    fprintf(stderr, "custrings_amd: %s: the single-pass kernel gave up, recomputing with the two-pass kernels\n", what);
 }
 const uint8_t* d_unicode_flags() { return g_d_flags; }
 const uint16_t* d_charcases() { return g_d_cases; }
@@ -46,6 +67,7 @@ static void release_cache_locked() {
 
 DevBuf::~DevBuf() {
   if (!capacity || !p) return;
+  if (g_multi_stream.load(std::memory_order_relaxed)) (void)hipDeviceSynchronize();  // (see g_streams)
   std::lock_guard<std::mutex> lk(g_mu);
   g_in_use -= (int64_t)capacity;
   g_cache.emplace(capacity, std::make_pair(p, stream));
@@ -57,19 +79,25 @@ Buf dev_alloc(size_t bytes, hipStream_t stream) {
   auto b = std::make_shared<DevBuf>();
   b->bytes = bytes;
   b->stream = stream;
+  bool reused = false;
+  hipStream_t prev = nullptr;
   {
     std::lock_guard<std::mutex> lk(g_mu);
+    if (g_streams.insert(stream).second && g_streams.size() > 1) g_multi_stream.store(true);
     auto it = g_cache.lower_bound(want);
     if (it != g_cache.end() && it->first <= want + want / 4 + 4096) {
       b->p = it->second.first;
       b->capacity = it->first;
-      hipStream_t prev = it->second.second;
+      prev = it->second.second;
       g_cache.erase(it);
       g_in_use += (int64_t)b->capacity;
-      // a block last used on another stream may still be in flight there
-      if (prev != stream) (void)hipStreamSynchronize(prev);
-      return b;
+      reused = true;
     }
+  }
+  if (reused) {
+    // a block last used on another stream may still be in flight there (waited for outside the lock)
+    if (prev != stream) CS_HIP(hipStreamSynchronize(prev));
+    return b;
   }
   void* p = nullptr;
   hipError_t e = hipMalloc(&p, want);
@@ -470,6 +498,27 @@ __global__ void k_narrow_offsets(const int64_t* __restrict__ in, int64_t n, int3
   int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i < n) out[i] = (int32_t)in[i];
 }
+}  // namespace cs
+// int64 form of a column born with int32 offsets, built once (any thread) and kept
+static std::mutex g_widen_mu;
+const int64_t* cs_column::d_offsets() const {
+  std::lock_guard<std::mutex> lk(g_widen_mu);
+  if (!offsets && offsets32) {
+    cs::Buf o64 = cs::dev_alloc(sizeof(int64_t) * (rows + 1), nullptr);
+    hipLaunchKernelGGL(cs::k_widen_offsets, dim3(cs::blocks_for(rows + 1)), dim3(kBlock), 0, nullptr, d_offsets32(), rows + 1,
+                       cs::ptr<int64_t>(o64));
+    CS_HIP(hipGetLastError());
+    CS_HIP(hipStreamSynchronize(nullptr));
+    offsets = o64;
+  }
+  return cs::ptr<const int64_t>(offsets);
+}
+void cs_column::share_extents_with(cs_column* o) const {
+  std::lock_guard<std::mutex> lk(g_widen_mu);
+  o->offsets = offsets;
+  o->offsets32 = offsets32;
+}
+namespace cs {
 // a null row contributes no bytes: clamp its extent to zero while copying
 // (NVStringsImpl.cu:408-432 skips rows whose validity bit is clear)
 __global__ void k_lengths_from_offsets(cs::ColView in, int32_t* __restrict__ lens) {
@@ -741,6 +790,8 @@ int cs_init(int device) {
   });
 }
 
+int cs_current_device(void) { return g_device; }
+int64_t cs_fallback_count(void) { return (int64_t)g_fallbacks.load(); }
 int64_t cs_device_bytes_in_use(void) { return dev_bytes_in_use(); }
 void cs_free(void* p) { free(p); }
 
@@ -974,10 +1025,14 @@ int cs_column_export_offsets32(const cs_column* col, char* chars, int32_t* offse
     if (!chars || !offsets) return;  // the reference returns 0 without doing anything (NVStrings.cu:406-407)
     if (col->nbytes >= (1LL << 31)) fail(CS_ERR_RANGE, "create_offsets: column holds >= 2 GiB of chars; int32 offsets cannot address it");
     hipStream_t s = S(stream);
-    Buf o32 = dev_alloc(sizeof(int32_t) * (col->rows + 1), s);
-    hipLaunchKernelGGL(k_narrow_offsets, dim3(blocks_for(col->rows + 1)), dim3(kBlock), 0, s,
-                       col->d_offsets(), col->rows + 1, ptr<int32_t>(o32));
-    copy_out(offsets, o32->p, sizeof(int32_t) * (col->rows + 1), on_device, s);
+    if (col->offsets32) {  // born with int32 offsets: they go out as they are
+      copy_out(offsets, col->d_offsets32(), sizeof(int32_t) * (col->rows + 1), on_device, s);
+    } else {
+      Buf o32 = dev_alloc(sizeof(int32_t) * (col->rows + 1), s);
+      hipLaunchKernelGGL(k_narrow_offsets, dim3(blocks_for(col->rows + 1)), dim3(kBlock), 0, s,
+                         col->d_offsets(), col->rows + 1, ptr<int32_t>(o32));
+      copy_out(offsets, o32->p, sizeof(int32_t) * (col->rows + 1), on_device, s);
+    }
     CS_HIP(hipStreamSynchronize(s));
     int st = cs_column_export_offsets64(col, (uint8_t*)chars, nullptr, validity, on_device, stream);
     if (st != CS_OK) fail(st, g_last_error);

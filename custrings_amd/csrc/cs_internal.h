@@ -45,7 +45,13 @@ int guard(F&& f) {
   }
 }
 
-void require_device();  // throws CS_ERR_NO_DEVICE unless cs_init succeeded on this thread's device
+// Throws CS_ERR_NO_DEVICE unless cs_init succeeded; binds the calling thread to the library's
+// device when its current device differs (hipSetDevice is per thread).
+void require_device();
+int bound_device();  // -1 before cs_init
+// One message per process on stderr and a counter (cs_fallback_count): a persistent single-pass
+// kernel gave up and the host recomputed the column with the two-pass kernels.
+void note_fallback(const char* what);
 
 // ---- device memory ----------------------------------------------------------
 // Buffers come from a size-bucketed cache over hipMalloc (one output allocation
@@ -87,10 +93,19 @@ struct cs_column {
   mutable int64_t max_row = -1;     // longest row in bytes; -1 = unknown
   mutable int drops = -1;           // 1: some row is null or empty (rows create_ngrams drops), 0: none; -1 = unknown
   mutable int plain_bytes = -1;     // 1: no NUL byte and no lead byte announcing over an ASCII byte; -1 = unknown
-  cs::Buf chars, offsets, validity;  // validity may be null (all valid)
+  cs::Buf chars, validity;  // validity may be null (all valid)
+  // Row extents: int64 offsets (`offsets`) and / or int32 offsets (`offsets32`, columns whose
+  // chars stay below 2 GiB -- what split produces: half the bytes written per output row).  A
+  // column born with int32 offsets gets its int64 form on first use by a kernel that reads
+  // int64 (d_offsets(), under a lock; the widened buffer is kept).
+  mutable cs::Buf offsets;
+  cs::Buf offsets32;
   const uint8_t* d_chars() const { return cs::ptr<const uint8_t>(chars); }
-  const int64_t* d_offsets() const { return cs::ptr<const int64_t>(offsets); }
+  const int64_t* d_offsets() const;
+  const int32_t* d_offsets32() const { return cs::ptr<const int32_t>(offsets32); }
   const uint8_t* d_validity() const { return cs::ptr<const uint8_t>(validity); }
+  // the other column gets the same (immutable) extents
+  void share_extents_with(cs_column* o) const;
 };
 
 namespace cs {

@@ -4,19 +4,28 @@
 // Two passes over the chars buffer, both one wave per sub-tile of 64 consecutive
 // rows with the sub-tile's contiguous chars span staged in LDS by coalesced
 // 16-byte loads:
-//   pass 1  k_split_measure: tokens per row (SWAR delimiter search), the global
-//           maximum (= number of output columns) and, per sub-tile and column,
-//           the bytes that column receives.  A segmented scan of those sums
-//           gives every (sub-tile, column) its position in the column's chars.
-//   pass 2  k_split_emit: walks the tokens again; column k's tokens of the 64
-//           rows are contiguous in column k's chars buffer, so they are
-//           assembled in LDS and flushed with 16-byte stores; offsets (one wave
-//           scan per column) and validity words (one ballot per column) are
-//           written coalesced.  All columns come out of this single pass.
+//   pass 1  k_split_measure2: tokens per row (SWAR delimiter search), the global
+//           maximum (= number of output columns) and, per SEGMENT of consecutive
+//           sub-tiles and column, the bytes that column receives (every row lane
+//           keeps its own sum per column; one reduction per column per segment).
+//           A small scan over the segments gives every emit wave the position of
+//           its run of sub-tiles in every column's chars.
+//   pass 2  k_split_emit2: walks the tokens again; each wave owns a contiguous run
+//           of sub-tiles and carries its position in every column along; column
+//           k's tokens of the 64 rows are contiguous in column k's chars buffer,
+//           so they are assembled in LDS and flushed with 16-byte stores; offsets
+//           (one wave scan per column; int32 when every column stays below 2 GiB,
+//           which halves the bytes written per output row) and validity words
+//           (one ballot per column) are written coalesced.  All columns come out
+//           of this single pass.
+//   (k_split_measure / k_split_emit: the first tile generation, one sub-tile per
+//   wave with per-sub-tile column sums; kept for rows beyond 93 bytes.)
 // Rows with more than kMaxCols tokens, multi-byte delimiters and whitespace
 // splitting use the generic kernels in cs_ops.hip.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <type_traits>
 #include <vector>
 
 #include "cs_internal.h"
@@ -299,6 +308,90 @@ __global__ void __launch_bounds__(256) k_split_measure(MeasureArgs a) {
 }
 
 
+// ---- measure, second generation: per-segment column sums ----------------------------------
+// A wave walks a SEGMENT of consecutive sub-tiles (a fixed fraction of an emit wave's run); every
+// row lane keeps the bytes its rows give to each column in registers and the 64 partial sums
+// are reduced once per segment, so the per-sub-tile work is the token walk alone.
+struct Measure2Args {
+  ColView in;
+  uint32_t dpat;
+  unsigned long long d64;
+  int dlen;
+  int tokens, cap;
+  long long nsub, per, seg, nseg;  // emit run length, segment length (sub-tiles), segments
+  int segs_per_run;
+  int32_t* colsum;  // [kMaxCols][nseg], zeroed by the host
+  int* max_count;   // [0] most tokens in a row, [1] bound on the bytes one column receives from one sub-tile
+                    // (sum over its rows of the row's longest token), [2] longest row, [3] a sub-tile needs the generic kernels
+};
+template <int MODE>
+__global__ void __launch_bounds__(256) k_split_measure2(Measure2Args a) {
+  constexpr bool WS = MODE == 1, MULTI = MODE == 2;
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  uint8_t* lds_in = reinterpret_cast<uint8_t*>(smem) + (size_t)wv * (a.cap + 32);
+  const long long sid = (long long)blockIdx.x * 4 + wv;
+  if (sid >= a.nseg) return;
+  const long long run = sid / a.segs_per_run;
+  const long long t0 = run * a.per + (sid - run * a.segs_per_run) * a.seg;
+  const long long t1 = min(min(t0 + a.seg, (run + 1) * a.per), a.nsub);
+  int acc[kMaxCols];
+#pragma unroll
+  for (int k = 0; k < kMaxCols; ++k) acc[k] = 0;
+  int most = 0, widest = 0, longest = 0;
+  bool generic = false;
+  for (long long sub = t0; sub < t1; ++sub) {
+    SubTile t = load_subtile(a.in, sub, lds_in, lane);
+    TokensT<false, WS, MULTI> tk(lds_in, t.lead + t.rbeg, t.n, t.live, a.dpat, a.tokens, a.d64, a.dlen);
+    if ((WS || MULTI) && !tk.masked) {  // (wave-uniform)
+      generic = true;
+      break;
+    }
+    int count = 0, rowmax = 0;
+    bool any_more = true;
+#pragma unroll
+    for (int k = 0; k < kMaxCols; ++k) {
+      if (any_more) {
+        int lo = 0, hi = 0;
+        const bool has = tk.next(lo, hi);
+        any_more = __any(has);
+        const int len = has ? hi - lo : 0;
+        count += has;
+        acc[k] += len;
+        rowmax = max(rowmax, len);
+      }
+    }
+    while (any_more) {  // rows with more than kMaxCols tokens: the host takes the generic path
+      int lo = 0, hi = 0;
+      const bool has = tk.next(lo, hi);
+      any_more = __any(has);
+      count += has;
+    }
+    most = max(most, count);
+    longest = max(longest, t.n);
+    widest = max(widest, wave_reduce_sum(rowmax));
+    __builtin_amdgcn_wave_barrier();  // the next sub-tile overwrites the staged rows
+  }
+  if (generic) {
+    if (lane == 0) atomicMax(a.max_count + 3, 1);
+    return;
+  }
+  const int m = wave_reduce_max(most);
+#pragma unroll
+  for (int k = 0; k < kMaxCols; ++k) {
+    if (k < m) {
+      const int sum = wave_reduce_sum(acc[k]);
+      if (lane == 0) a.colsum[(long long)k * a.nseg + sid] = sum;
+    }
+  }
+  // same-address atomics serialise in L2: only waves that would raise a maximum issue one
+  if (lane == 0 && widest > __hip_atomic_load(a.max_count + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(a.max_count + 1, widest);
+  const int lg = wave_reduce_max(longest);
+  if (lane == 0 && lg > __hip_atomic_load(a.max_count + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(a.max_count + 2, lg);
+  if (lane == 0 && m > __hip_atomic_load(a.max_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(a.max_count, m);
+}
+
+
 struct ColOut {
   uint8_t* chars;
   int64_t* offsets;
@@ -378,6 +471,12 @@ __global__ void __launch_bounds__(256) k_split_emit(EmitArgs a) {
 // right away, two regions alternating, so a wave needs cap_in + 2 * cap_col bytes of LDS
 // instead of 2 * cap_in + 1 KB and twice as many waves are resident; short tokens reach the
 // region as three ds_or_b32 of the funnel-shifted token instead of byte stores.
+struct ColOut2 {
+  uint8_t* chars;
+  void* offsets;  // int32 or int64 (OFF32)
+  uint8_t* validity;
+  const int64_t* seg_base;  // seg_base[j] = bytes of this column before measure segment j
+};
 struct Emit2Args {
   ColView in;
   uint32_t dpat;
@@ -385,7 +484,9 @@ struct Emit2Args {
   int dlen;
   int tokens, cap_in, cap_col, ncols;
   long long nsub;
-  const ColOut* cols;
+  long long per;  // sub-tiles per wave (run length); wave w owns [w * per, (w + 1) * per)
+  int segs_per_run;
+  const ColOut2* cols;
   unsigned long long* prof;  // instrumented builds: 6 cycle counters
 };
 __device__ __forceinline__ void lds_or(uint32_t* p, uint32_t v) {
@@ -394,9 +495,10 @@ __device__ __forceinline__ void lds_or(uint32_t* p, uint32_t v) {
 #ifndef CS_EMIT2_WAVES
 #define CS_EMIT2_WAVES 4
 #endif
-template <int MODE>
+template <int MODE, bool OFF32>
 __global__ void __launch_bounds__(256, CS_EMIT2_WAVES) k_split_emit2(Emit2Args a) {
   constexpr bool WS = MODE == 1, MULTI = MODE == 2;
+  typedef typename std::conditional<OFF32, int32_t, int64_t>::type off_t;
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
   uint8_t* lds_in = reinterpret_cast<uint8_t*>(smem) + (size_t)wv * (a.cap_in + 32 + 2 * a.cap_col + (WS ? 2 : 1) * a.ncols * 64);
@@ -406,33 +508,28 @@ __global__ void __launch_bounds__(256, CS_EMIT2_WAVES) k_split_emit2(Emit2Args a
   // each wave owns a contiguous run of sub-tiles: its pieces of every output column are
   // contiguous too, so the cache lines that two neighbouring sub-tiles share are completed in
   // one L2 instead of being written half-filled from two XCDs
-  const long long waves = (long long)gridDim.x * 4;
-  const long long per = (a.nsub + waves - 1) / waves;
+  const long long per = a.per;
   constexpr long long W = 1;
-  long long tile = ((long long)blockIdx.x * 4 + wv) * per;
+  const long long run = (long long)blockIdx.x * 4 + wv;
+  long long tile = run * per;
   const long long tile_end = min(a.nsub, tile + per);
   if (tile >= tile_end) return;
   const ColView& in = a.in;
-  // lane k keeps column k's destination
+  // lane k keeps column k's destination and the wave's running position in column k's chars
   uint8_t* my_chars = nullptr;
-  int64_t* my_off = nullptr;
+  off_t* my_off = nullptr;
   uint8_t* my_valid = nullptr;
-  const int64_t* my_basep = nullptr;
+  long long my_pos = 0;
   if (lane < a.ncols) {
-    const ColOut c = a.cols[lane];
+    const ColOut2 c = a.cols[lane];
     my_chars = c.chars;
-    my_off = c.offsets;
+    my_off = reinterpret_cast<off_t*>(c.offsets);
     my_valid = c.validity;
-    my_basep = c.base;
+    my_pos = c.seg_base[run * a.segs_per_run];
   }
   cstile::TileOffs cur = cstile::load_tile_offsets(in.offsets, in.rows, tile, lane);
   cstile::TileOffs nxt = cur;
   if (tile + W < tile_end) nxt = cstile::load_tile_offsets(in.offsets, in.rows, tile + W, lane);
-  long long cb0 = 0, cb1 = 0;  // this column's byte position before / after the current sub-tile
-  if (lane < a.ncols) {
-    cb0 = my_basep[tile];
-    cb1 = my_basep[tile + 1];
-  }
   cstile::TileChars pf;
 #pragma unroll
   for (int j = 0; j < cstile::kPfChunks; ++j) pf.v[j] = make_uint4(0, 0, 0, 0);
@@ -451,17 +548,12 @@ __global__ void __launch_bounds__(256, CS_EMIT2_WAVES) k_split_emit2(Emit2Args a
     const int lead = (int)((uintptr_t)(in.chars + g0) & 15);
     const int want = (int)(g1 - g0) + lead;
     cstile::stage_chars(lds_in, want, lane, pf);
-    const long long my_base = cb0;
-    const int my_sum = (int)(cb1 - cb0);
+    const long long my_base = my_pos;
     const int my_lead = (int)((uintptr_t)(my_chars + my_base) & 15);
     const bool has_next = tile + W < tile_end;
     if (has_next) {
       cur = nxt;
       cstile::issue_chars(in.chars, cstile::rl64(cur.o0, 0), cstile::rl64(cur.o1, 63), lane, pf);
-      if (lane < a.ncols) {
-        cb0 = my_basep[tile + W];
-        cb1 = my_basep[tile + W + 1];
-      }
       if (tile + 2 * W < tile_end) nxt = cstile::load_tile_offsets(in.offsets, in.rows, tile + 2 * W, lane);
     }
     cstile::wave_lds_fence();
@@ -518,13 +610,16 @@ __global__ void __launch_bounds__(256, CS_EMIT2_WAVES) k_split_emit2(Emit2Args a
       const int incl = wave_inclusive_scan(len);
       const int pre = incl - len;
       const long long cbase = cstile::rl64(my_base, k);
-      cstile::gptr<int64_t> coff = cstile::as_global(reinterpret_cast<int64_t*>(cstile::rl64((long long)(uintptr_t)my_off, k)));
+      cstile::gptr<off_t> coff = cstile::as_global(reinterpret_cast<off_t*>(cstile::rl64((long long)(uintptr_t)my_off, k)));
       const int clead = rl(my_lead, k);
-      const int csum = rl(my_sum, k);
-      if (lane < nrows) coff[r0 + lane] = cbase + pre;
-      if (last_tile && lane == nrows - 1) coff[in.rows] = cbase + incl;
+      const int csum = rl(incl, 63);  // bytes this sub-tile adds to column k
+      if (lane < nrows) coff[r0 + lane] = (off_t)(cbase + pre);
+      if (last_tile && lane == nrows - 1) coff[in.rows] = (off_t)(cbase + incl);
       const unsigned long long vmask = __ballot(has);
-      if (lane == k) my_vmask = vmask;
+      if (lane == k) {
+        my_vmask = vmask;
+        my_pos += csum;
+      }
       CS_PHASE_MARK(2);
       if (csum == 0) continue;  // no row of this sub-tile reaches column k (or all its tokens are empty): offsets only
       // zero the region (16-byte chunks covering lead + bytes + 8 of slack for the last token's third dword)
@@ -604,32 +699,114 @@ bool split_fast(const cs_column* col, const unsigned char* delim, int dlen, int 
   const int cap_out = cap_in + 32 * kMaxCols;
   if ((size_t)(cap_in + cap_out + 64) * 4 > 150 * 1024) return false;
   const int64_t nsub = (rows + kSub - 1) / kSub;
-  const unsigned grid = (unsigned)((nsub + 3) / 4);
   const uint32_t dpat = 0x01010101u * (ws ? 0u : (uint32_t)delim[0]);
+  Buf mx = dev_alloc(4 * sizeof(int), s);
+  int* hmx = (int*)pinned_scratch(4 * sizeof(int));
 
+  // ---- second generation: runs of sub-tiles per wave (rows up to 93 bytes, 64-row spans up to 6 KB)
+  if (cap_in <= cstile::kPfBytes && !getenv("CS_SPLIT_OLD_EMIT")) {
+    // The run decomposition is a function of the row count alone (not of the emit kernel's
+    // residency, which depends on what the measure pass finds): emit needs no co-residency.
+    int dev = 0, cus = 0;
+    CS_HIP(hipGetDevice(&dev));
+    CS_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    int64_t runs = std::min<int64_t>(nsub, (int64_t)cus * 16);
+    const int64_t per = (nsub + runs - 1) / runs;
+    runs = (nsub + per - 1) / per;
+    const int segs_per_run = (int)std::min<int64_t>(4, per);
+    const int64_t seg = (per + segs_per_run - 1) / segs_per_run;
+    const int64_t nseg = runs * segs_per_run;
+    Buf colsum = dev_alloc(sizeof(int32_t) * nseg * kMaxCols, s);
+    CS_HIP(hipMemsetAsync(colsum->p, 0, sizeof(int32_t) * nseg * kMaxCols, s));
+    CS_HIP(hipMemsetAsync(mx->p, 0, 4 * sizeof(int), s));
+    Measure2Args ma{view_of(col), dpat, d64, dlen, tokens, cap_in, nsub, per, seg, nseg, segs_per_run, ptr<int32_t>(colsum), ptr<int>(mx)};
+    {
+      ProfScope ps("k_split_measure", s);
+      const unsigned g = (unsigned)((nseg + 3) / 4);
+      const size_t lds = (size_t)(cap_in + 32) * 4;
+      if (mode == 1) hipLaunchKernelGGL(k_split_measure2<1>, dim3(g), dim3(256), lds, s, ma);
+      else if (mode == 2) hipLaunchKernelGGL(k_split_measure2<2>, dim3(g), dim3(256), lds, s, ma);
+      else hipLaunchKernelGGL(k_split_measure2<0>, dim3(g), dim3(256), lds, s, ma);
+    }
+    CS_HIP(hipGetLastError());
+    CS_HIP(hipMemcpyAsync(hmx, mx->p, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
+    CS_HIP(hipStreamSynchronize(s));
+    const int ncols = hmx[0], bound = hmx[1], longest_row = hmx[2];
+    if (ncols == 0 || ncols > kMaxCols) return false;  // all-null column / too many columns: generic path
+    const bool emit2_ok = !hmx[3] && longest_row + 3 <= 96;
+    const int cap_col = (bound + 64 + 15) & ~15;
+    const size_t lds2 = (size_t)(cap_in + 32 + 2 * cap_col + (ws ? 2 : 1) * ncols * 64) * 4;
+    if (emit2_ok && lds2 <= 150 * 1024) {
+      // per column: position of every segment in the column's chars buffer
+      Buf base = dev_alloc(sizeof(int64_t) * (nseg + 1) * ncols, s);
+      std::vector<int64_t> totals(ncols);
+      offsets_from_lengths_segmented(ptr<int32_t>(colsum), nseg, ncols, ptr<int64_t>(base), totals.data(), s);
+      bool off32 = !getenv("CS_SPLIT_OFF64");
+      for (int k = 0; k < ncols; ++k) off32 = off32 && totals[k] < ((int64_t)1 << 31);
+      std::vector<ColOut2> outs(ncols);
+      for (int k = 0; k < ncols; ++k) {
+        auto c = std::make_unique<cs_column>();
+        c->rows = rows;
+        c->nbytes = totals[k];
+        c->chars = dev_alloc((size_t)totals[k], s);
+        if (off32) c->offsets32 = dev_alloc(sizeof(int32_t) * (rows + 1), s);
+        else c->offsets = dev_alloc(sizeof(int64_t) * (rows + 1), s);
+        c->validity = dev_alloc(validity_bytes(rows), s);
+        outs[k] = ColOut2{ptr<uint8_t>(c->chars), off32 ? c->offsets32->p : c->offsets->p, ptr<uint8_t>(c->validity),
+                          ptr<const int64_t>(base) + (int64_t)k * (nseg + 1)};
+        cols.push_back(std::move(c));
+      }
+      Buf d_outs = dev_alloc(sizeof(ColOut2) * ncols, s);
+      CS_HIP(hipMemcpyAsync(d_outs->p, outs.data(), sizeof(ColOut2) * ncols, hipMemcpyHostToDevice, s));
+      Emit2Args e2{view_of(col), dpat, d64, dlen, tokens, cap_in, cap_col, ncols, nsub, per, segs_per_run, ptr<const ColOut2>(d_outs), nullptr};
+#if defined(CS_PHASE_PROF)
+      Buf profbuf = dev_alloc(64, s);
+      CS_HIP(hipMemsetAsync(profbuf->p, 0, 64, s));
+      e2.prof = ptr<unsigned long long>(profbuf);
+#endif
+      typedef void (*EmitKernel)(Emit2Args);
+      static const EmitKernel kerns[2][3] = {{k_split_emit2<0, false>, k_split_emit2<1, false>, k_split_emit2<2, false>},
+                                             {k_split_emit2<0, true>, k_split_emit2<1, true>, k_split_emit2<2, true>}};
+      const EmitKernel kern = kerns[off32 ? 1 : 0][mode];
+      if (lds2 > 48 * 1024) CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+      const unsigned g2 = (unsigned)((runs + 3) / 4);
+      {
+        ProfScope ps("k_split_emit", s);
+        hipLaunchKernelGGL(kern, dim3(g2), dim3(256), lds2, s, e2);
+      }
+      CS_HIP(hipGetLastError());
+      CS_HIP(hipStreamSynchronize(s));  // `outs` / `base` lifetime
+#if defined(CS_PHASE_PROF)
+      {
+        unsigned long long ph[6];
+        CS_HIP(hipMemcpy(ph, e2.prof, sizeof(ph), hipMemcpyDeviceToHost));
+        const double it = (double)nsub;
+        fprintf(stderr, "emit2 cycles/wave-iteration: stage %.0f masks %.0f col-walk+scan+offsets %.0f col-assemble %.0f col-flush %.0f tail %.0f | grid %u lds %zu cap_col %d\n",
+                ph[0] / it, ph[1] / it, ph[2] / it, ph[3] / it, ph[4] / it, ph[5] / it, g2, lds2, cap_col);
+      }
+#endif
+      return true;
+    }
+    if (mode != 0) return false;  // whitespace and multi-byte delimiters exist in the masked kernels only
+  } else if (mode != 0) {
+    return false;
+  }
+
+  // ---- first generation (one-byte delimiter; rows beyond 93 bytes, wide tiles): one sub-tile per wave
+  const unsigned grid = (unsigned)((nsub + 3) / 4);
   Buf colsum = dev_alloc(sizeof(int32_t) * nsub * kMaxCols, s);
   CS_HIP(hipMemsetAsync(colsum->p, 0, sizeof(int32_t) * nsub * kMaxCols, s));  // columns a sub-tile never reaches
-  Buf mx = dev_alloc(4 * sizeof(int), s);
   CS_HIP(hipMemsetAsync(mx->p, 0, 4 * sizeof(int), s));
   MeasureArgs ma{view_of(col), dpat, d64, dlen, tokens, cap_in, nsub, ptr<int32_t>(colsum), ptr<int>(mx)};
   {
     ProfScope ps("k_split_measure", s);
-    // (a persistent, prefetching form of this kernel measured slower: it is bound by its
-    // instruction count, not by memory latency, at 28 resident waves per CU)
-    if (mode == 1) hipLaunchKernelGGL(k_split_measure<1>, dim3(grid), dim3(256), (size_t)(cap_in + 32) * 4, s, ma);
-    else if (mode == 2) hipLaunchKernelGGL(k_split_measure<2>, dim3(grid), dim3(256), (size_t)(cap_in + 32) * 4, s, ma);
-    else hipLaunchKernelGGL(k_split_measure<0>, dim3(grid), dim3(256), (size_t)(cap_in + 32) * 4, s, ma);
+    hipLaunchKernelGGL(k_split_measure<0>, dim3(grid), dim3(256), (size_t)(cap_in + 32) * 4, s, ma);
   }
   CS_HIP(hipGetLastError());
-  int* hmx = (int*)pinned_scratch(4 * sizeof(int));
   CS_HIP(hipMemcpyAsync(hmx, mx->p, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
   CS_HIP(hipStreamSynchronize(s));
   const int ncols = hmx[0];
-  const int widest = hmx[1];
-  const int longest_row = hmx[2];
   if (ncols == 0 || ncols > kMaxCols) return false;  // all-null column / too many columns: generic path
-  const bool emit2_ok = cap_in <= cstile::kPfBytes && longest_row + 3 <= 96 && !getenv("CS_SPLIT_OLD_EMIT");
-  if (mode != 0 && (hmx[3] || !emit2_ok)) return false;  // whitespace and multi-byte delimiters exist in the masked kernels only
 
   // per column: position of every sub-tile in the column's chars buffer
   Buf base = dev_alloc(sizeof(int64_t) * (nsub + 1) * ncols, s);
@@ -650,40 +827,6 @@ bool split_fast(const cs_column* col, const unsigned char* delim, int dlen, int 
   }
   Buf d_outs = dev_alloc(sizeof(ColOut) * ncols, s);
   CS_HIP(hipMemcpyAsync(d_outs->p, outs.data(), sizeof(ColOut) * ncols, hipMemcpyHostToDevice, s));
-  const int cap_col = (widest + 64 + 15) & ~15;
-  if (emit2_ok) {
-    Emit2Args e2{view_of(col), dpat, d64, dlen, tokens, cap_in, cap_col, ncols, nsub, ptr<const ColOut>(d_outs), nullptr};
-#if defined(CS_PHASE_PROF)
-    Buf profbuf = dev_alloc(64, s);
-    CS_HIP(hipMemsetAsync(profbuf->p, 0, 64, s));
-    e2.prof = ptr<unsigned long long>(profbuf);
-#endif
-    const size_t lds2 = (size_t)(cap_in + 32 + 2 * cap_col + (ws ? 2 : 1) * ncols * 64) * 4;
-    if (lds2 <= 150 * 1024) {
-      const void* kern = mode == 1 ? reinterpret_cast<const void*>(&k_split_emit2<1>)
-                         : mode == 2 ? reinterpret_cast<const void*>(&k_split_emit2<2>) : reinterpret_cast<const void*>(&k_split_emit2<0>);
-      if (lds2 > 48 * 1024) CS_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
-      const unsigned g2 = resident_grid(kern, lds2, (nsub + 3) / 4);
-      {
-        ProfScope ps("k_split_emit", s);
-        if (mode == 1) hipLaunchKernelGGL(k_split_emit2<1>, dim3(g2), dim3(256), lds2, s, e2);
-        else if (mode == 2) hipLaunchKernelGGL(k_split_emit2<2>, dim3(g2), dim3(256), lds2, s, e2);
-        else hipLaunchKernelGGL(k_split_emit2<0>, dim3(g2), dim3(256), lds2, s, e2);
-      }
-      CS_HIP(hipGetLastError());
-      CS_HIP(hipStreamSynchronize(s));  // `outs` / `base` lifetime
-#if defined(CS_PHASE_PROF)
-      {
-        unsigned long long ph[6];
-        CS_HIP(hipMemcpy(ph, e2.prof, sizeof(ph), hipMemcpyDeviceToHost));
-        const double it = (double)nsub;
-        fprintf(stderr, "emit2 cycles/wave-iteration: stage %.0f masks %.0f col-walk+scan+offsets %.0f col-assemble %.0f col-flush %.0f tail %.0f | grid %u lds %zu cap_col %d\n",
-                ph[0] / it, ph[1] / it, ph[2] / it, ph[3] / it, ph[4] / it, ph[5] / it, g2, lds2, cap_col);
-      }
-#endif
-      return true;
-    }
-  }
   EmitArgs ea{view_of(col), dpat, tokens, cap_in, cap_out, ncols, nsub, ptr<const ColOut>(d_outs)};
   const size_t lds = (size_t)(cap_in + cap_out + 64) * 4;
   if (lds > 48 * 1024)

@@ -9,7 +9,9 @@
  *
  * Conventions
  *  - Strings live in an Arrow-style device column: chars (u8), offsets
- *    (int64, rows+1 entries), validity bitmask (LSB-first, bit=1 valid,
+ *    (rows+1 entries; int64, or int32 for columns an op produced with less
+ *    than 2 GiB of chars -- cs_column_get_view always hands out int64,
+ *    widening once on demand), validity bitmask (LSB-first, bit=1 valid,
  *    NULL pointer = all valid).  Columns are immutable and reference counted
  *    internally; every producing call returns a new handle the caller must
  *    release with cs_column_destroy (the reference's "new instance, caller
@@ -67,6 +69,13 @@ int cs_device_count(void);
  * pool and uploads the unicode tables (reference: lazy get_unicode_flags /
  * get_charcases, NVStringsImpl.cu:69-91). Idempotent. */
 int cs_init(int device);
+/* Device the process is bound to (cs_init), or -1.  Compute calls from any host
+ * thread run on it (the library re-binds the calling thread when needed). */
+int cs_current_device(void);
+/* Number of times a persistent single-pass kernel gave up (its grid was not
+ * fully resident, e.g. a co-tenant on the device) and the column was recomputed
+ * with the two-pass kernels.  Correct either way; a benchmark should see 0. */
+int64_t cs_fallback_count(void);
 /* Bytes currently held by live columns/categories on this device. */
 int64_t cs_device_bytes_in_use(void);
 
