@@ -30,11 +30,44 @@ KERNELS = ["k_split_measure", "k_split_emit", "k_split_write", "k_replace_re", "
            "k_split_count", "k_split_sizes", "k_write_offsets", "k_scan_lookback"]
 
 
+def source_hash():
+    """sha256 over the kernel sources: profiles/<round>/traffic.json is stamped with it when the
+    PMC passes are taken, and bench.py reports `traffic` only while the sources are unchanged."""
+    import hashlib
+
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "custrings_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h", ".cpp")):
+            with open(os.path.join(d, name), "rb") as f:
+                h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
+
+
+def effective_cpus():
+    """CPUs this process may actually use: the affinity mask cut by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except Exception:
+            pass
+    return n
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--rows", type=int, default=100_000_000, help="rows per GPU (weak scaling)")
     ap.add_argument("--cpu-rows", type=int, default=3_000_000, help="rows of the same workload timed on the CPU oracle")
     ap.add_argument("--no-cpu", action="store_true")
@@ -73,6 +106,7 @@ def main():
         if record:
             stats["split_cols"] = ncols.value
             stats["split_out_bytes"] = sum(int(L.cs_column_nbytes(arr[i])) for i in range(ncols.value))
+            stats["split_off_bytes"] = 4 if all(int(L.cs_column_offset_width(arr[i])) == 4 for i in range(ncols.value)) else 8
         for i in range(ncols.value):
             L.cs_column_destroy(arr[i])
         L.cs_free(arr)
@@ -85,6 +119,7 @@ def main():
     step(record=True)
     for _ in range(max(args.warmup - 1, 0)):
         step()
+    fallbacks0 = int(L.cs_fallback_count())
     L.cs_prof_reset()
     L.cs_prof_enable(1)
     barrier()
@@ -116,14 +151,15 @@ def main():
         Ccols = stats["split_cols"]
         split_out = stats["split_out_bytes"] / rows
         repl_out = stats["replace_out_bytes"] / rows
-        # algorithmic bytes per row (SURVEY.md section 8d / BASELINE.md section 2)
+        ob = stats["split_off_bytes"] + 0.125  # offset + validity bytes per row of a split output column
+        # algorithmic bytes per row (SURVEY.md section 8d / BASELINE.md section 2; DESIGN.md section 4)
         alg_replace = (Lb + 8.125) + (repl_out + 8.125)
-        alg_split = (Lb + 8.125) + split_out + Ccols * 8.125
-        # per-kernel share: what that kernel must read and write given its role (DESIGN.md section 5)
+        alg_split = (Lb + 8.125) + split_out + Ccols * ob
+        # per-kernel share: what that kernel must read and write given its role
         alg_kernel = {
             "k_replace_re": alg_replace,
             "k_split_measure": Lb + 8.125,
-            "k_split_emit": Lb + 8.125 + split_out + Ccols * 8.125,
+            "k_split_emit": Lb + 8.125 + split_out + Ccols * ob,
             "k_split_write": Lb + 8.125 + split_out + Ccols * 8,
             "k_replace_re_size": Lb + 8.125 + 4,
             "k_replace_re_write": Lb + 16 + repl_out,
@@ -132,24 +168,29 @@ def main():
             "k_write_offsets": 12,
         }
         dom = max(prof, key=lambda k: prof[k]["avg_ms"] * prof[k]["launches"]) if prof else None
-        traffic = args.pmc_traffic
-        if traffic is None and dom:
-            # HBM bytes per launch measured in separate rocprofv3 --pmc passes (profiles/<round>/traffic.json)
-            try:
-                rounds = sorted(d for d in os.listdir(os.path.join(ROOT, "profiles")) if os.path.exists(os.path.join(ROOT, "profiles", d, "traffic.json")))
-                with open(os.path.join(ROOT, "profiles", rounds[-1], "traffic.json")) as f:
-                    tj = json.load(f)
-                if tj.get("rows") == rows and dom in tj["kernels"]:
-                    traffic = float(tj["kernels"][dom]["hbm_bytes"])
-            except Exception:
-                traffic = None
-        roofline = None
-        if dom:
-            a = alg_kernel.get(dom, 0) * rows / (prof[dom]["avg_ms"] * 1e-3) / 1e9
-            roofline = {"bound": "hbm", "kernel": dom, "achieved": round(a, 1), "peak": 8000.0, "unit": "GB/s",
-                        "frac": round(a / 8000.0, 4), "frac_of_achievable_6300": round(a / 6300.0, 4), "traffic": traffic,
-                        "avg_ms": round(prof[dom]["avg_ms"], 3),
-                        "alg_bytes_per_row": round(alg_kernel.get(dom, 0), 2)}
+        # HBM bytes per launch measured in separate rocprofv3 --pmc passes (profiles/<round>/traffic.json);
+        # only quoted while the kernel sources are the ones those passes ran on
+        tj = None
+        try:
+            rounds = sorted(d for d in os.listdir(os.path.join(ROOT, "profiles")) if os.path.exists(os.path.join(ROOT, "profiles", d, "traffic.json")))
+            with open(os.path.join(ROOT, "profiles", rounds[-1], "traffic.json")) as f:
+                tj = json.load(f)
+            if tj.get("rows") != rows or tj.get("source_hash") != source_hash():
+                tj = None
+        except Exception:
+            tj = None
+
+        def roof(k):
+            a = alg_kernel.get(k, 0) * rows / (prof[k]["avg_ms"] * 1e-3) / 1e9
+            tr = args.pmc_traffic if (args.pmc_traffic is not None and k == dom) else None
+            if tr is None and tj and k in tj["kernels"]:
+                tr = float(tj["kernels"][k]["hbm_bytes"])
+            return {"bound": "hbm", "kernel": k, "achieved": round(a, 1), "peak": 8000.0, "unit": "GB/s",
+                    "frac": round(a / 8000.0, 4), "frac_of_achievable_6300": round(a / 6300.0, 4), "traffic": tr,
+                    "avg_ms": round(prof[k]["avg_ms"], 3), "alg_bytes_per_row": round(alg_kernel.get(k, 0), 2)}
+
+        roofline = roof(dom) if dom else None
+        roofline_kernels = [roof(k) for k in sorted(prof, key=lambda k: -prof[k]["avg_ms"] * prof[k]["launches"])]
         ms_step = elapsed / args.steps * 1e3
         pipeline = (alg_replace + alg_split) * total_rows / (elapsed / args.steps) / 1e9
         result = {
@@ -170,6 +211,8 @@ def main():
                        "rows_per_gpu": rows, "seed": SEED, "sharding": "row ranges, no data-path collective"},
             "mstrings_per_s": round(total_rows / (elapsed / args.steps) / 1e6, 1),
             "roofline": roofline,
+            "roofline_kernels": roofline_kernels,
+            "fallbacks_in_timed_region": int(L.cs_fallback_count()) - fallbacks0,
             "roofline_pipeline": {"alg_bytes_per_row": round(alg_replace + alg_split, 1), "achieved": round(pipeline, 1),
                                   "peak": 8000.0 * world, "unit": "GB/s", "frac": round(pipeline / (8000.0 * world), 4)},
             "kernels": {k: {"avg_ms": round(v["avg_ms"], 3), "launches": v["launches"]} for k, v in prof.items()},
@@ -182,10 +225,26 @@ def main():
         dist.destroy_process_group()
 
 
+def _pandas_chunk(args):
+    first, n = args
+    import time as _t
+
+    import cpulibs
+    import pandas as pd
+
+    s = pd.Series(cpulibs.Oracle().synth(3, first, n).to_list())
+    t0 = _t.perf_counter()
+    s.str.split(" ", expand=True)
+    s.str.replace(IPV4, REPL, regex=True)
+    return int(s.str.len().sum()), _t.perf_counter() - t0
+
+
 def cpu_baseline(rows):
-    """The oracle (scalar C++ port of the reference algorithm, 1 thread) on a bounded
-    sample of the same workload; plus pandas.Series.str on a smaller sample, as
-    BASELINE.json's north_star asks."""
+    """The oracle (scalar C++ port of the reference algorithm) on a bounded sample of the same
+    workload: one thread, then one worker process per USABLE core (affinity mask cut by the cgroup
+    CPU quota -- on a box whose container is limited to a few CPUs, starting a worker per visible
+    core only measures the quota); plus pandas.Series.str, one core and a Pool over the usable
+    cores, as BASELINE.json's north_star asks."""
     import numpy as np
 
     import cpulibs
@@ -198,22 +257,23 @@ def cpu_baseline(rows):
     orc.split(c, " ")
     orc.replace_re(c, blob, REPL)
     dt = time.perf_counter() - t0
+    visible, cores = len(os.sched_getaffinity(0)), effective_cpus()
     res = {"value": round(c.chars.size / dt / 1e9, 5), "unit": "GB/s", "cores": 1, "kind": "port",
-           "sample": "first %d rows of the same C3 column, split(' ') + replace_re, oracle/liboracle.so, %.1f s" % (rows, dt)}
-    # the same port on all host cores: one worker process per core (tests/cpu_worker.py), each on
-    # its own row range of the same column; all start together, aggregate bytes / wall time
+           "sample": "first %d rows of the same C3 column, split(' ') + replace_re, oracle/liboracle.so, %.1f s" % (rows, dt),
+           "host": {"cpus_visible": visible, "cpus_usable": cores, "os_cpu_count": os.cpu_count()}}
+    # the same port on all usable cores: one worker process per core (tests/cpu_worker.py), each on
+    # its own row range of the same column (about as long as the one-thread leg); all start together
     try:
         import subprocess
-
-        cores = len(os.sched_getaffinity(0))
-        per = max(50_000, min(250_000, rows))
-        worker = os.path.join(ROOT, "tests", "cpu_worker.py")
         import tempfile
 
+        per = max(50_000, min(rows, 2_000_000))
+        worker = os.path.join(ROOT, "tests", "cpu_worker.py")
         prog = os.path.join(tempfile.mkdtemp(prefix="cs_bench_"), "ipv4_program.npy")
         np.save(prog, blob)
+        env = dict(os.environ, CS_CPULIBS_PREBUILT="1", OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1")
         procs = [subprocess.Popen([sys.executable, worker, str(i * per), str(per), prog], stdin=subprocess.PIPE, stdout=subprocess.PIPE,
-                                  text=True, env=dict(os.environ, CS_CPULIBS_PREBUILT="1")) for i in range(cores)]
+                                  text=True, env=env) for i in range(cores)]
         for p in procs:
             if p.stdout.readline().strip() != "ready":
                 raise RuntimeError("cpu worker failed to start")
@@ -228,23 +288,30 @@ def cpu_baseline(rows):
         for p in procs:
             p.wait()
         res["all_cores"] = {"value": round(total / dta / 1e9, 4), "unit": "GB/s", "cores": cores, "rows": per * cores,
-                            "seconds": round(dta, 1)}
+                            "seconds": round(dta, 1), "speedup_over_one_core": round(total / dta / (c.chars.size / dt), 1)}
     except Exception as e:
         res["all_cores"] = {"error": str(e)}
     try:
+        import multiprocessing as mp
+
         import pandas as pd
 
-        n = min(rows, 300_000)
-        s = pd.Series(orc.synth(3, 0, n).to_list())
-        t0 = time.perf_counter()
-        s.str.split(" ", expand=True)
-        s.str.replace(IPV4, REPL, regex=True)
-        dtp = time.perf_counter() - t0
-        nbytes = int(s.str.len().sum())
-        res["pandas"] = {"value": round(nbytes / dtp / 1e9, 5), "unit": "GB/s", "cores": 1, "rows": n,
-                         "host_cpus": os.cpu_count(), "version": pd.__version__}
+        n = min(rows, 1_000_000)
+        nb, dtp = _pandas_chunk((0, n))
+        res["pandas"] = {"value": round(nb / dtp / 1e9, 5), "unit": "GB/s", "cores": 1, "rows": n, "seconds": round(dtp, 1),
+                         "host_cpus": os.cpu_count(), "version": pd.__version__,
+                         "extrapolated_s_for_100M_rows": round(dtp * 1e8 / n, 0)}
+        chunk = max(50_000, n // 4)
+        with mp.get_context("spawn").Pool(cores) as pool:
+            pool.map(_pandas_chunk, [(i * 1000, 1000) for i in range(cores)])  # start the workers, import pandas
+            t0 = time.perf_counter()
+            parts = pool.map(_pandas_chunk, [(i * chunk, chunk) for i in range(cores)])
+            dtq = time.perf_counter() - t0
+        res["pandas_pool"] = {"value": round(sum(p[0] for p in parts) / dtq / 1e9, 5), "unit": "GB/s", "cores": cores,
+                              "rows": chunk * cores, "seconds": round(dtq, 1)}
     except Exception as e:  # pandas is a courtesy figure, never fatal
-        res["pandas"] = {"error": str(e)}
+        res.setdefault("pandas", {"error": str(e)})
+        res["pandas_pool"] = {"error": str(e)}
     return res
 
 

@@ -50,6 +50,7 @@ _PROTOS = {
     "cs_column_destroy": (i32, [vp]),
     "cs_column_rows": (i64, [vp]),
     "cs_column_nbytes": (i64, [vp]),
+    "cs_column_offset_width": (i32, [vp]),
     "cs_column_null_count": (i64, [vp]),
     "cs_column_get_view": (i32, [vp, P(ColumnView)]),
     "cs_column_export_offsets32": (i32, [vp, vp, vp, vp, i32, vp]),

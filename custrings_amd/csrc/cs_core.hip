@@ -973,6 +973,7 @@ int cs_column_destroy(cs_column* col) {
 }
 int64_t cs_column_rows(const cs_column* col) { return col ? col->rows : 0; }
 int64_t cs_column_nbytes(const cs_column* col) { return col ? col->nbytes : 0; }
+int cs_column_offset_width(const cs_column* col) { return !col ? 0 : (col->offsets32 ? 4 : 8); }
 int64_t cs_column_null_count(const cs_column* col) {
   int64_t n = -1;
   int st = guard([&] {

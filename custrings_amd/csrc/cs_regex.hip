@@ -696,6 +696,7 @@ struct StreamArgs {
   int debug;
   long long out_cap;  // bytes provisioned at out_chars (growing replacements)
   int rows_per_tile;  // LONG variants: 64, 32 or 16
+  unsigned long long* tickets;  // 8 tile counters, 64 bytes apart, zeroed before the launch
 };
 #ifndef CS_STREAM_WAVES
 #define CS_STREAM_WAVES 3
@@ -726,8 +727,34 @@ __global__ void __launch_bounds__(256, CS_STREAM_WAVES) k_tdfa_replace_stream(St
   const bool has_r2 = (((uint32_t)D.img[30] & 255u) <= (((uint32_t)D.img[30] >> 8) & 255u));
   // rows per tile: 64, or fewer for the long-row variants (so that the tile fits the prefetch registers)
   const int R = LONG ? a.rows_per_tile : 64;
+  // Tiles are handed out by tickets, so every tile's predecessors were started before it and a
+  // wave that meets a slow tile does not hold back the tiles it would have taken next (with a static
+  // round-robin the look-back of everybody else waits for them).  One counter per class of
+  // workgroups (blockIdx mod 8, the observed XCD placement -- for speed only): counter k hands out
+  // tiles k, k + 8, ...; a single word would saturate at the rate this kernel takes tiles.  The
+  // ticket of the tile after next is in flight while the current tile is processed.
+  const long long K = gridDim.x >= 8 ? 8 : 1;
+  const long long key = (long long)blockIdx.x % K;
+  const bool fixed = (a.debug & 256) != 0;  // measurement: the static round-robin
   const long long W = (long long)gridDim.x * 4;
-  long long tile = (long long)blockIdx.x * 4 + wv;
+  unsigned long long* my_ticket = a.tickets + key * 8;
+  auto take = [&]() -> unsigned long long {
+    unsigned long long t = 0;
+    if (lane == 0) t = __hip_atomic_fetch_add(my_ticket, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return t;
+  };
+  auto tile_of = [&](unsigned long long t) -> long long { return (long long)cstile::rl64((long long)t, 0) * K + key; };
+  long long tile, t_nxt, t_nn = 0;
+  unsigned long long pending = 0;
+  if (fixed) {
+    tile = (long long)blockIdx.x * 4 + wv;
+    t_nxt = tile + W;
+  } else {
+    const unsigned long long q0 = take(), q1 = take();
+    pending = take();
+    tile = tile_of(q0);
+    t_nxt = tile_of(q1);
+  }
   if (tile >= a.nsub) return;
   // replacement text in registers (this kernel is only taken for rb <= 8, or <= 16 with REP16)
   constexpr int kRepRegs = REP16 ? 4 : 2;
@@ -739,7 +766,7 @@ __global__ void __launch_bounds__(256, CS_STREAM_WAVES) k_tdfa_replace_stream(St
     if (i < rb) rep[i >> 2] |= (uint32_t)a.repl[i] << (8 * (i & 3));
   cstile::TileOffs cur = cstile::load_tile_offsets_r(in.offsets, in.rows, tile, R, lane);
   cstile::TileOffs nxt = cur;
-  if (tile + W < a.nsub) nxt = cstile::load_tile_offsets_r(in.offsets, in.rows, tile + W, R, lane);
+  if (t_nxt < a.nsub) nxt = cstile::load_tile_offsets_r(in.offsets, in.rows, t_nxt, R, lane);
   cstile::TileChars pf;
 #pragma unroll
   for (int j = 0; j < cstile::kPfChunks; ++j) pf.v[j] = make_uint4(0, 0, 0, 0);
@@ -819,11 +846,17 @@ __global__ void __launch_bounds__(256, CS_STREAM_WAVES) k_tdfa_replace_stream(St
     cstile::u64 p_first = 0;
     if (p_tile >= 0 && !(a.debug & (8 | 64))) p_first = cstile::lookback_poll(a.status, p_tile, lane);
     // keep the memory pipe busy: next sub-tile's chars, and the offsets of the one after
-    const bool has_next = tile + W < a.nsub;
+    const bool has_next = t_nxt < a.nsub;
     if (has_next) {
       cur = nxt;
       cstile::issue_chars(in.chars, cstile::rl64(cur.o0, 0), cstile::rl64(cur.o1, 63), lane, pf);
-      if (tile + 2 * W < a.nsub) nxt = cstile::load_tile_offsets_r(in.offsets, in.rows, tile + 2 * W, R, lane);
+      if (fixed) {
+        t_nn = t_nxt + W;
+      } else {
+        t_nn = tile_of(pending);
+        if (t_nn < a.nsub) pending = take();
+      }
+      if (t_nn < a.nsub) nxt = cstile::load_tile_offsets_r(in.offsets, in.rows, t_nn, R, lane);
     }
     cstile::wave_lds_fence();
     CS_PHASE_MARK(0);
@@ -971,7 +1004,8 @@ __global__ void __launch_bounds__(256, CS_STREAM_WAVES) k_tdfa_replace_stream(St
       p_len = out_len;
     }
     if (!has_next) break;
-    tile += W;
+    tile = t_nxt;
+    t_nxt = t_nn;
   }
   if (p_tile >= 0) finish_pending((a.debug & 8) ? 0 : cstile::lookback_poll(a.status, p_tile, lane));
 #if defined(CS_PHASE_PROF)
@@ -1492,10 +1526,11 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
         sa.out_cap = col->nbytes + extra;
         const int64_t nsub1 = (rows + tc.R - 1) / tc.R;
         sa.rows_per_tile = tc.R;
-        Buf status = dev_alloc(sizeof(cstile::u64) * nsub1 + 128, s);
-        CS_HIP(hipMemsetAsync(status->p, 0, sizeof(cstile::u64) * nsub1 + 128, s));
+        Buf status = dev_alloc(sizeof(cstile::u64) * nsub1 + 128 + 512, s);
+        CS_HIP(hipMemsetAsync(status->p, 0, sizeof(cstile::u64) * nsub1 + 128 + 512, s));
         sa.status = ptr<cstile::u64>(status);
         sa.error = reinterpret_cast<unsigned*>(ptr<cstile::u64>(status) + nsub1);
+        sa.tickets = ptr<cstile::u64>(status) + nsub1 + 16;
         sa.nsub = nsub1;
         sa.cap_in = cap;
         sa.cap_out = cap_out;

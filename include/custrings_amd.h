@@ -106,6 +106,9 @@ int cs_column_destroy(cs_column* col);
 /* NVStrings::size (NVStrings.h:167) and friends. */
 int64_t cs_column_rows(const cs_column* col);
 int64_t cs_column_nbytes(const cs_column* col);
+/* Bytes per offset the column was produced with: 4 (int32, an op's output below
+ * 2 GiB of chars) or 8.  Either way cs_column_get_view hands out int64 offsets. */
+int cs_column_offset_width(const cs_column* col);
 int64_t cs_column_null_count(const cs_column* col);
 int cs_column_get_view(const cs_column* col, cs_column_view* view);
 /* NVStrings::create_offsets (NVStrings.h:207): int32 offsets (rows+1), chars,

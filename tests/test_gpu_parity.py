@@ -275,6 +275,109 @@ def test_gpu_full_size_c3_properties(orc):
     assert tok_bytes + (tokens - rows) == int(L.lib.cs_column_nbytes(g.m_cptr))
 
 
+def test_gpu_full_size_c3_split_windows(orc):
+    """split(' ') of the 100M-row headline column: sampled row windows of every output column equal
+    the oracle's split of the same rows (columns the window's rows do not reach are all null)."""
+    rows = 100_000_000
+    g = gpuutil.synth(3, 0, rows)
+    L = gpuutil.lib()
+    cols = g.split(" ")
+    assert all(int(L.lib.cs_column_offset_width(c.m_cptr)) == 4 for c in cols)  # each column is far below 2 GiB
+    for first in (0, 27_182_818, 99_949_937):
+        w = 50_000
+        exp = orc.split(orc.synth(3, first, w), " ")
+        assert len(exp) <= len(cols)
+        for k, c in enumerate(cols):
+            chars, offs, valid = c._export_window(first, w)
+            got = cpulibs.Col(chars, offs, valid)
+            if k < len(exp):
+                assert got.same_as(exp[k]), (first, k)
+            else:
+                assert chars.size == 0 and not got.bitmask().any(), (first, k)
+    # the same call with 64-bit offsets forced gives the same columns (digest covers offsets, chars, validity)
+    import os
+
+    os.environ["CS_SPLIT_OFF64"] = "1"
+    try:
+        cols64 = g.split(" ")
+    finally:
+        del os.environ["CS_SPLIT_OFF64"]
+    assert all(int(L.lib.cs_column_offset_width(c.m_cptr)) == 8 for c in cols64)
+    assert [c.digest() for c in cols64] == [c.digest() for c in cols]
+
+
+def test_gpu_full_shard_c4_category(orc):
+    """C4 at one GPU's shard of the 1B-row config (125M rows, K = 1M tokens): the key set equals the
+    oracle's on a sample that covers it, keys are strictly ascending, and sampled windows of the values
+    point at the rows' own strings."""
+    from custrings_amd import nvcategory
+
+    rows, K = 125_000_000, 1_000_000
+    g = gpuutil.synth(4, 0, rows, K)
+    cat = nvcategory.from_strings(g)
+    assert cat.size() == rows
+    keys = cat.keys()
+    kchars, koffs, kvalid = keys._export64()
+    nk = keys.size()
+    assert keys.null_count() == 1 and not (kvalid[0] & 1)  # 0.1 % null rows: the null key sorts first
+    kb = kchars.reshape(-1, 16)  # every non-null key is 16 bytes
+    assert kb.shape[0] == nk - 1 and np.array_equal(koffs[1:], np.arange(nk) * 16)
+    as_rows = kb.view(">u8")  # bytewise order == numeric order of the two big-endian halves
+    order = np.lexsort((as_rows[:, 1], as_rows[:, 0]))
+    assert np.array_equal(order, np.arange(nk - 1)), "keys not in ascending bytewise order"
+    assert np.unique(as_rows, axis=0).shape[0] == nk - 1
+    # a small-K column of the same generator: every key occurs in a 300k-row sample -> same key set as the oracle
+    g2 = gpuutil.synth(4, 0, rows, 1000)
+    ok, _ = orc.category(orc.synth(4, 0, 300_000, param=1000))
+    cat2 = nvcategory.from_strings(g2)
+    gpuutil.assert_same(cat2.keys(), ok, "K=1000 keys at 125M rows")
+    # values: key[value[r]] is row r's string (null rows -> key 0)
+    vals = np.zeros(rows, dtype=np.int32)
+    cat.values(vals)
+    assert vals.min() == 0 and vals.max() == nk - 1
+    for first in (0, 62_500_001, 124_900_000):
+        w = 100_000
+        chars, offs, valid = g._export_window(first, w)
+        isnull = np.unpackbits(valid, bitorder="little")[:w] == 0
+        v = vals[first : first + w]
+        assert np.array_equal(v == 0, isnull)
+        rb = chars.reshape(-1, 16)
+        assert np.array_equal(kb[v[~isnull] - 1], rb), first
+    del vals
+
+
+def test_gpu_full_shard_c5_tokenize_ngrams(orc):
+    """C5 at one GPU's shard of the 500M-row config (62.5M rows): token and byte conservation over
+    the whole shard, sampled row windows of the flat token column and of its bigrams against the oracle."""
+    from custrings_amd import nvtext
+
+    rows = 62_500_000
+    g = gpuutil.synth(5, 0, rows)
+    L = gpuutil.lib()
+    toks = nvtext.tokenize(g)
+    ntok = toks.size()
+    assert toks.null_count() == 0
+    # a 64-bit-offset column: the shard's chars exceed 2 GiB
+    assert int(L.lib.cs_column_nbytes(g.m_cptr)) > (1 << 31)
+    bi = nvtext.ngrams(toks, 2, "_")
+    assert bi.size() == ntok - 1
+    # every bigram is token_i + '_' + token_i+1: bytes = 2 * token bytes - first - last + (ntok - 1)
+    tb = int(L.lib.cs_column_nbytes(toks.m_cptr))
+    first_len = toks.sublist(0, 1).byte_count()
+    last_len = toks.sublist(ntok - 1, ntok).byte_count()
+    assert int(L.lib.cs_column_nbytes(bi.m_cptr)) == 2 * tb - first_len - last_len + (ntok - 1)
+    for first in (0, 31_250_000, rows - 40_000):
+        w = 40_000
+        before = nvtext.tokenize(g.sublist(0, first)).size() if first else 0
+        o = orc.synth(5, first, w)
+        ot = orc.tokenize(o)
+        chars, offs, valid = toks._export_window(before, ot.rows)
+        assert cpulibs.Col(chars, offs, valid).same_as(ot), first
+        ob = orc.ngrams(ot, 2, "_")
+        chars, offs, valid = bi._export_window(before, ob.rows)
+        assert cpulibs.Col(chars, offs, valid).same_as(ob), first
+
+
 def test_gpu_global_category_single_rank(orc):
     """dist.global_category with GpuOps on one rank == the plain category build."""
     from custrings_amd import dist as csd

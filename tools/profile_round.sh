@@ -9,7 +9,7 @@ REPO=$PWD
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-python $REPO/bench.py --steps 5 --warmup 2 > $OUT/bench_$TAG.json 2> $OUT/bench_$TAG.err
+python $REPO/bench.py --steps 20 --warmup 5 > $OUT/bench_$TAG.json 2> $OUT/bench_$TAG.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o stats -- python $REPO/bench.py --steps 5 --warmup 2 --no-cpu > $OUT/bench_under_rocprof.log 2>&1
 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $OUT/pmc_fetch -o fetch -- python $REPO/bench.py --steps 2 --warmup 1 --no-cpu > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d $OUT/pmc_write -o write -- python $REPO/bench.py --steps 2 --warmup 1 --no-cpu > $OUT/pmc_write.log 2>&1
