@@ -57,6 +57,37 @@ _PROTOS = {
     "cs_column_export_offsets64": (i32, [vp, vp, vp, vp, i32, vp]),
     "cs_column_byte_count": (i32, [vp, vp, i32, vp, P(i64)]),
     "cs_column_null_bitarray": (i32, [vp, vp, i32, i32, vp, P(i64)]),
+    "cs_column_from_index": (i32, [vp, i64, i32, i32, vp, P(vp)]),
+    "cs_len": (i32, [vp, vp, i32, vp, P(i64)]),
+    "cs_gather": (i32, [vp, vp, i64, i32, vp, P(vp)]),
+    "cs_gather_mask": (i32, [vp, vp, i32, vp, P(vp)]),
+    "cs_sublist": (i32, [vp, i64, i64, i64, vp, P(vp)]),
+    "cs_scatter": (i32, [vp, vp, vp, i32, vp, P(vp)]),
+    "cs_scatter_scalar": (i32, [vp, cp, vp, i64, i32, vp, P(vp)]),
+    "cs_sort": (i32, [vp, i32, i32, i32, vp, P(vp)]),
+    "cs_order": (i32, [vp, i32, i32, i32, vp, i32, vp]),
+    "cs_cat": (i32, [vp, P(vp), i32, cp, cp, vp, P(vp)]),
+    "cs_join": (i32, [vp, cp, cp, vp, P(vp)]),
+    "cs_replace_re_multi": (i32, [vp, P(vp), i32, vp, vp, P(vp)]),
+    "cs_split_record": (i32, [vp, cp, i32, vp, i32, vp, P(vp)]),
+    "cs_rsplit_record": (i32, [vp, cp, i32, vp, i32, vp, P(vp)]),
+    "cs_partition": (i32, [vp, cp, i32, vp, P(vp)]),
+    "cs_category_to_strings": (i32, [vp, vp, P(vp)]),
+    "cs_category_gather_strings": (i32, [vp, vp, i64, i32, vp, P(vp)]),
+    "cs_category_gather": (i32, [vp, vp, i64, i32, vp, P(vp)]),
+    "cs_category_gather_and_remap": (i32, [vp, vp, i64, i32, vp, P(vp)]),
+    "cs_category_add_strings": (i32, [vp, vp, vp, P(vp)]),
+    "cs_category_remove_strings": (i32, [vp, vp, vp, P(vp)]),
+    "cs_category_merge_category": (i32, [vp, vp, vp, P(vp)]),
+    "cs_category_add_keys": (i32, [vp, vp, vp, P(vp)]),
+    "cs_category_remove_keys": (i32, [vp, vp, vp, P(vp)]),
+    "cs_category_remove_unused_keys": (i32, [vp, vp, P(vp)]),
+    "cs_category_set_keys": (i32, [vp, vp, vp, P(vp)]),
+    "cs_token_count": (i32, [vp, cp, vp, i32, vp]),
+    "cs_unique_tokens": (i32, [vp, cp, vp, P(vp)]),
+    "cs_tokens_counts": (i32, [vp, vp, cp, vp, i32, vp]),
+    "cs_replace_tokens": (i32, [vp, vp, vp, cp, vp, P(vp)]),
+    "cs_normalize_spaces": (i32, [vp, vp, P(vp)]),
     "cs_lower": (i32, [vp, vp, P(vp)]),
     "cs_upper": (i32, [vp, vp, P(vp)]),
     "cs_strip": (i32, [vp, cp, i32, vp, P(vp)]),

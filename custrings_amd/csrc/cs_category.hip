@@ -17,11 +17,6 @@
 using namespace cs;
 using namespace csdev;
 
-struct cs_category {
-  std::unique_ptr<cs_column> keys;
-  Buf values;  // int32[rows]
-  int64_t rows = 0;
-};
 
 namespace {
 
@@ -331,7 +326,14 @@ T read_back(const void* d, hipStream_t s) {
   return *host;
 }
 
-cs_category* build(const cs_column* col, hipStream_t s) {
+}  // namespace
+namespace cs {
+cs_category* category_build(const cs_column* col, hipStream_t s);
+}
+namespace {
+cs_category* build(const cs_column* col, hipStream_t s) { return cs::category_build(col, s); }
+}  // namespace
+cs_category* cs::category_build(const cs_column* col, hipStream_t s) {
   auto cat = std::make_unique<cs_category>();
   const int64_t rows = col->rows;
   cat->rows = rows;
@@ -371,6 +373,8 @@ cs_category* build(const cs_column* col, hipStream_t s) {
     if (h[1] & 2) fail(CS_ERR_RANGE, "category: a key of 16 MiB or more");
     if (cap == full || !h[1]) break;  // (room for all-distinct rows: no limit applied, nothing to retry)
     cap = std::min<int64_t>(full, cap * 16);
+    // slot ids travel as int32 (negative = null row): a table of 2^31 slots or more cannot be addressed
+    if (cap > ((int64_t)1 << 30)) fail(CS_ERR_RANGE, "category: more than 2^29 rows with mostly distinct keys in one column");
   }
   Buf has_null_d = flags_d;
   // compact the occupied slots
@@ -432,8 +436,6 @@ cs_category* build(const cs_column* col, hipStream_t s) {
   cat->keys = std::move(keys);
   return cat.release();
 }
-
-}  // namespace
 
 extern "C" {
 

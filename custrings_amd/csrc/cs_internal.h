@@ -108,6 +108,13 @@ struct cs_column {
   void share_extents_with(cs_column* o) const;
 };
 
+// ---- the category: sorted unique keys + one int32 code per row (-1 / key 0 conventions: cs_category.hip)
+struct cs_category {
+  std::unique_ptr<cs_column> keys;
+  cs::Buf values;  // int32[rows]
+  int64_t rows = 0;
+};
+
 namespace cs {
 
 struct ColView {  // passed to kernels by value
@@ -151,6 +158,20 @@ int64_t max_span_rows(const cs_column* c, int per, hipStream_t s);
 unsigned resident_grid(const void* kern, size_t lds, int64_t wanted);
 // Row-wise concatenation of columns into one new column.
 cs_column* concat_columns(const std::vector<const cs_column*>& cols, hipStream_t s);
+
+// cs_category.hip: keys = sorted unique rows (null first), values[r] = index of row r's key
+cs_category* category_build(const cs_column* col, hipStream_t s);
+// cs_array.hip: rows of `col` at the given device positions; with `null_when_negative` a negative
+// position yields a null row instead of CS_ERR_RANGE
+cs_column* gather_rows(const cs_column* col, const int32_t* d_pos, int64_t n, hipStream_t s, bool null_when_negative = false);
+// finishes a column from per-row lengths (-1 = null): offsets, validity, an empty chars buffer of the
+// right size; the caller's copy kernel fills the chars, then prefer_offsets32 keeps the narrow offsets
+struct Built {
+  std::unique_ptr<cs_column> col;
+  const int64_t* off;
+};
+Built column_from_lengths(const int32_t* lens, int64_t rows, bool any_null_possible, hipStream_t s);
+void prefer_offsets32(cs_column* c, hipStream_t s);
 
 // profiling hooks (cs_prof_*): time a named kernel launch with HIP events
 struct ProfScope {

@@ -17,6 +17,8 @@
 #include "regex_program.h"
 #include "regex_tdfa.h"
 #include "regex_vm.h"
+#include <mutex>
+
 #include "tile_utils.h"
 
 using namespace cs;
@@ -470,6 +472,91 @@ __global__ void __launch_bounds__(256) k_backrefs(BackrefArgs a, int32_t* __rest
         for (int i = 0; i < k; ++i) *o++ = q[i];
       });
     }
+  }
+}
+
+// ---- replace_re with several patterns (replace_multi.cu:39-189) ----------------------------
+// At every character position the patterns are tried in order, each anchored at that position
+// (regexec.inl: start window [pos, pos + 1)); the first that matches is replaced and the walk
+// continues behind the match.  Thread per row, size pass + write pass.  `first` holds, per
+// pattern, the ASCII bytes an anchored match can begin with (a superset): most (position,
+// pattern) pairs are turned away by one bit test.
+struct MultiProg {
+  const int32_t* tdfa;   // tagged DFA image (DFA variant)
+  const int32_t* image;  // list-simulator image
+  uint32_t first[4];     // ASCII bytes that can start a match; all ones when unknown
+};
+struct MultiArgs {
+  RowSrc src;
+  const MultiProg* progs;
+  int nprogs;
+  ColView repls;
+  uint32_t* arena;  // list simulator scratch (VM variant)
+  int slots;
+};
+template <bool DFA, bool WRITE>
+__global__ void __launch_bounds__(256) k_multi_replace(MultiArgs a, int32_t* __restrict__ lens, const int64_t* __restrict__ out_off,
+                                                       uint8_t* __restrict__ out_chars, unsigned* __restrict__ bad) {
+  const ColView& in = a.src.in;
+  uint32_t* mem = DFA ? nullptr : a.arena + (size_t)blockIdx.x * blockDim.x * a.slots + threadIdx.x;
+  const int64_t nblk = (in.rows + blockDim.x - 1) / blockDim.x;
+  for (int64_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+    const int64_t r = blk * blockDim.x + threadIdx.x;
+    if (r >= in.rows) continue;
+    if (!row_is_valid(in.validity, r)) {
+      if (!WRITE) lens[r] = -1;
+      continue;
+    }
+    const int64_t b = in.offsets[r];
+    const int n = (int)(in.offsets[r + 1] - b);
+    const uint8_t* p = in.chars + b;
+    uint8_t* o = WRITE ? out_chars + out_off[r] : nullptr;
+    int total = n, copied = 0, pos = 0;
+    while (pos < n) {
+      const uint8_t c0 = p[pos];
+      int mb = 0, me = 0;
+      bool hit = false;
+      int t = 0;
+      for (; t < a.nprogs && !hit; ++t) {
+        const MultiProg& mp = a.progs[t];
+        if (c0 < 128 && !((mp.first[c0 >> 5] >> (c0 & 31)) & 1u)) continue;
+        if (DFA) {
+          const cstd::View D = cstd::make_view(mp.tdfa);
+          const csvm::ProgView P = csvm::make_view(mp.image, a.src.flags);
+          cstd::Tdfa vm(D, P, p, n);
+          vm.wide_ok = false;
+          hit = vm.find(pos, pos + 1, mb, me) > 0;
+        } else {
+          const csvm::ProgView P = csvm::make_view(mp.image, a.src.flags);
+          csvm::Vm<false> vm(P, mem, blockDim.x, p, n);
+          hit = vm.find(pos, pos + 1, mb, me) > 0;
+        }
+      }
+      if (!hit) {
+        unsigned w = csrow::lead_width(c0);
+        pos += w ? (int)w : 1;
+        continue;
+      }
+      --t;  // the pattern that matched
+      if (me <= mb) {  // an empty match: the reference never leaves this position
+        atomicOr(bad, 1u);
+        break;
+      }
+      const int64_t rr = a.repls.rows == 1 ? 0 : t;
+      const bool has = row_is_valid(a.repls.validity, rr);
+      const int rn = has ? (int)(a.repls.offsets[rr + 1] - a.repls.offsets[rr]) : 0;
+      total += rn - (me - mb);
+      if (WRITE) {
+        copy_bytes(o, p + copied, mb - copied);
+        o += mb - copied;
+        if (rn) copy_bytes(o, a.repls.chars + a.repls.offsets[rr], rn);
+        o += rn;
+        copied = me;
+      }
+      pos = me;
+    }
+    if (WRITE) copy_bytes(o, p + copied, n - copied);
+    else lens[r] = total;
   }
 }
 
@@ -1232,6 +1319,9 @@ struct TPlan {
 };
 bool use_tdfa(const cs_regex* re) { return !re->tdfa.empty() && !getenv("CS_REGEX_NO_TDFA"); }
 void upload(cs_regex* re, hipStream_t s) {
+  // a compiled pattern may be shared between host threads: the device images are made once
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lk(mu);
   if (!re->d_image) {
     re->d_image = dev_alloc(re->image.size() * 4, s);
     CS_HIP(hipMemcpyAsync(re->d_image->p, re->image.data(), re->image.size() * 4, hipMemcpyHostToDevice, s));
@@ -2097,6 +2187,83 @@ int cs_replace_with_backrefs(const cs_column* col, const cs_regex* cre, const ch
         launch(true, nullptr, o->d_offsets(), ptr<uint8_t>(o->chars));
       }
     }
+    CS_HIP(hipStreamSynchronize(s));
+    *out = o.release();
+  });
+}
+
+
+// NVStrings::replace_re(patterns, repls) (NVStrings.h:777; replace_multi.cu:110-189)
+int cs_replace_re_multi(const cs_column* col, const cs_regex* const* res, int npatterns, const cs_column* repls, cs_stream stream,
+                        cs_column** out) {
+  return guard([&] {
+    if (!col || !out) fail(CS_ERR_INVALID_ARG, "null argument");
+    if (npatterns <= 0 || !res || !repls || repls->rows == 0)
+      fail(CS_ERR_INVALID_ARG, "replace_re patterns and repls parameters cannot be empty");
+    if (repls->rows > 1 && repls->rows != npatterns)
+      fail(CS_ERR_INVALID_ARG, "replace_re patterns and repls must have the same number of strings");
+    require_device();
+    hipStream_t s = S(stream);
+    const int64_t rows = col->rows;
+    if (rows == 0) {
+      *out = make_all_null(0, s);
+      return;
+    }
+    std::vector<MultiProg> progs;
+    bool all_dfa = !getenv("CS_REGEX_NO_TDFA");
+    int max_inst = 0;
+    for (int i = 0; i < npatterns; ++i) {
+      cs_regex* re = const_cast<cs_regex*>(res[i]);
+      if (!re || re->empty_pattern) continue;  // (a null pattern is skipped, replace_multi.cu:125-127)
+      upload(re, s);
+      if (csrx::min_match_chars(re->prog) == 0) fail(CS_ERR_INVALID_ARG, "replace_re: a pattern matches the empty string");
+      MultiProg mp{};
+      mp.tdfa = ptr<const int32_t>(re->d_tdfa);
+      mp.image = ptr<const int32_t>(re->d_image);
+      for (int k = 0; k < 4; ++k) mp.first[k] = 0xFFFFFFFFu;
+      if (!re->tdfa.empty() && re->tdfa[16] > 0)  // idle states exist: the candidate bitmap says which bytes leave them
+        for (int k = 0; k < 4; ++k) mp.first[k] = (uint32_t)re->tdfa[21 + k];
+      all_dfa = all_dfa && !re->tdfa.empty();
+      max_inst = std::max(max_inst, (int)re->prog.insts.size());
+      progs.push_back(mp);
+      if (repls->rows > 1 && (int)progs.size() - 1 != i) fail(CS_ERR_INVALID_ARG, "replace_re: a null pattern among several replacements");
+    }
+    if (progs.empty()) fail(CS_ERR_INVALID_ARG, "replace_re invalid patterns");
+    Buf d_progs = dev_alloc(sizeof(MultiProg) * progs.size(), s);
+    CS_HIP(hipMemcpyAsync(d_progs->p, progs.data(), sizeof(MultiProg) * progs.size(), hipMemcpyHostToDevice, s));
+    MultiArgs a{};
+    a.src = RowSrc{view_of(col), d_unicode_flags(), col->nbytes};
+    a.progs = ptr<const MultiProg>(d_progs);
+    a.nprogs = (int)progs.size();
+    a.repls = view_of(repls);
+    unsigned grid = (unsigned)std::min<int64_t>((rows + 255) / 256, 256 * 8);
+    Buf arena;
+    if (!all_dfa) {
+      a.slots = 6 * max_inst + (max_inst + 31) / 32 + 2;
+      grid = std::min(grid, 1024u);
+      arena = dev_alloc((size_t)grid * 256 * a.slots * 4, s);
+      a.arena = ptr<uint32_t>(arena);
+    }
+    Buf bad = dev_alloc(sizeof(unsigned), s);
+    CS_HIP(hipMemsetAsync(bad->p, 0, sizeof(unsigned), s));
+    Buf lens = dev_alloc(sizeof(int32_t) * rows, s);
+    if (all_dfa) hipLaunchKernelGGL((k_multi_replace<true, false>), dim3(grid), dim3(256), 0, s, a, ptr<int32_t>(lens), (const int64_t*)nullptr, (uint8_t*)nullptr, ptr<unsigned>(bad));
+    else hipLaunchKernelGGL((k_multi_replace<false, false>), dim3(grid), dim3(256), 0, s, a, ptr<int32_t>(lens), (const int64_t*)nullptr, (uint8_t*)nullptr, ptr<unsigned>(bad));
+    CS_HIP(hipGetLastError());
+    auto o = std::make_unique<cs_column>();
+    o->rows = rows;
+    o->validity = col->validity;
+    o->null_count = col->null_count;
+    o->offsets = dev_alloc(sizeof(int64_t) * (rows + 1), s);
+    o->nbytes = offsets_from_lengths(ptr<int32_t>(lens), rows, ptr<int64_t>(o->offsets), s);
+    unsigned* hb = (unsigned*)pinned_scratch(sizeof(unsigned));
+    CS_HIP(hipMemcpyAsync(hb, bad->p, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+    CS_HIP(hipStreamSynchronize(s));
+    if (*hb) fail(CS_ERR_INVALID_ARG, "replace_re: a pattern matched the empty string");
+    o->chars = dev_alloc((size_t)o->nbytes, s);
+    if (all_dfa) hipLaunchKernelGGL((k_multi_replace<true, true>), dim3(grid), dim3(256), 0, s, a, (int32_t*)nullptr, o->d_offsets(), ptr<uint8_t>(o->chars), ptr<unsigned>(bad));
+    else hipLaunchKernelGGL((k_multi_replace<false, true>), dim3(grid), dim3(256), 0, s, a, (int32_t*)nullptr, o->d_offsets(), ptr<uint8_t>(o->chars), ptr<unsigned>(bad));
+    CS_HIP(hipGetLastError());
     CS_HIP(hipStreamSynchronize(s));
     *out = o.release();
   });

@@ -112,4 +112,21 @@ __device__ __forceinline__ bool row_is_valid(const uint8_t* validity, long long 
   return validity == nullptr || ((validity[r >> 3] >> (r & 7)) & 1);
 }
 
+// copies n bytes between arbitrarily aligned global addresses, 8 bytes at a time
+__device__ __forceinline__ void copy_bytes(uint8_t* __restrict__ d, const uint8_t* __restrict__ s, int n) {
+  int i = 0;
+  for (; i + 8 <= n; i += 8) {
+    uint64_t v;
+    __builtin_memcpy(&v, s + i, 8);
+    __builtin_memcpy(d + i, &v, 8);
+  }
+  if (i + 4 <= n) {
+    uint32_t v;
+    __builtin_memcpy(&v, s + i, 4);
+    __builtin_memcpy(d + i, &v, 4);
+    i += 4;
+  }
+  for (; i < n; ++i) d[i] = s[i];
+}
+
 }  // namespace csdev

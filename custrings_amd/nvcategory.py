@@ -64,10 +64,22 @@ def bind_cpointer(cptr, own=True):
     return nvcategory(cptr, own)
 
 
-_NOT_BUILT = (
-    "keys_type indexes_for_key add_strings remove_strings to_strings to_numbers gather_strings gather_numbers "
-    "gather_and_remap gather merge_and_remap add_keys remove_keys remove_unused_keys set_keys"
-).split()
+_NOT_BUILT = "keys_type to_numbers gather_numbers".split()
+
+
+def _ints(values, count=0):
+    if isinstance(values, int):
+        return values, int(count), 1, None
+    if hasattr(values, "data_ptr"):
+        return values.data_ptr(), int(count) or values.numel(), 1, values
+    a = np.ascontiguousarray(values, dtype=np.int32)
+    return a.ctypes.data, len(a), 0, a
+
+
+def _checked(status):
+    if status == _lib.CS_ERR_RANGE:
+        raise IndexError(_lib.last_error())  # std::out_of_range in the reference
+    check(status)
 
 
 class nvcategory:
@@ -113,11 +125,14 @@ class nvcategory:
         check(lib.cs_category_keys(self.m_cptr, C.byref(out)))
         return _nvs.nvstrings(out.value)
 
-    def values(self, devptr=0):
-        """nvcategory.py:364-389 -- int32 key index per row."""
+    def values(self, devptr=0, bdevmem=None):
+        """nvcategory.py:364-389 -- int32 key index per row.  `devptr`: an int address or a tensor with
+        data_ptr() is device memory, a numpy array host memory (bdevmem overrides)."""
         if devptr is not None and not (isinstance(devptr, int) and devptr == 0):
             p, keep = _lib.addr(devptr)
-            on_device = 0 if keep is not None else 1
+            on_device = 1 if (isinstance(devptr, int) or hasattr(devptr, "data_ptr") or hasattr(devptr, "__cuda_array_interface__")) else 0
+            if bdevmem is not None:
+                on_device = 1 if bdevmem else 0
             check(lib.cs_category_get_values(self.m_cptr, p, on_device, None))
             return devptr
         n = self.size()
@@ -139,6 +154,68 @@ class nvcategory:
         k = self.keys().to_host()
         return k.index(str) if str in k else -1
 
+    def indexes_for_key(self, str, devptr=0):
+        """nvcategory.py:276-322 -- the rows whose value is the given key."""
+        k = self.value(str)
+        res = [i for i, v in enumerate(self.values()) if v == k] if k >= 0 else []
+        return res
+
+    def _cat_call(self, fn, *args):
+        out = C.c_void_p()
+        _checked(fn(self.m_cptr, *args, None, C.byref(out)))
+        return nvcategory(out.value)
+
+    def to_strings(self):
+        """nvcategory.py:419-436 -- the original strings back (NVCategory::to_strings)."""
+        out = C.c_void_p()
+        check(lib.cs_category_to_strings(self.m_cptr, None, C.byref(out)))
+        return _nvs.nvstrings(out.value) if out.value else None
+
+    def gather_strings(self, indexes, count=0):
+        """nvcategory.py:438-470 -- keys[indexes[i]] as strings; an index outside the keys raises."""
+        p, n, dev, keep = _ints(indexes, count)
+        out = C.c_void_p()
+        _checked(lib.cs_category_gather_strings(self.m_cptr, p, n, dev, None, C.byref(out)))
+        return _nvs.nvstrings(out.value)
+
+    def gather(self, indexes, count=0):
+        """nvcategory.py:510-545 -- same keys, the given indexes as values."""
+        p, n, dev, keep = _ints(indexes, count)
+        return self._cat_call(lib.cs_category_gather, p, n, dev)
+
+    def gather_and_remap(self, indexes, count=0):
+        """nvcategory.py:472-508 -- only the keys the indexes name, values renumbered."""
+        p, n, dev, keep = _ints(indexes, count)
+        return self._cat_call(lib.cs_category_gather_and_remap, p, n, dev)
+
+    def add_strings(self, nvs):
+        """nvcategory.py:547-574."""
+        return self._cat_call(lib.cs_category_add_strings, nvs.m_cptr)
+
+    def remove_strings(self, nvs):
+        """nvcategory.py:576-603."""
+        return self._cat_call(lib.cs_category_remove_strings, nvs.m_cptr)
+
     def merge_category(self, nvcat):
-        """nvcategory.py:669-685 (NVCategory::merge_category == create_from_categories of the two)."""
+        """nvcategory.py:669-685 -- the other category's new keys are appended behind these keys (NVCategory.cu:1223-1337)."""
+        return self._cat_call(lib.cs_category_merge_category, nvcat.m_cptr)
+
+    def merge_and_remap(self, nvcat):
+        """nvcategory.py:687-715 -- merged sorted key set, both value lists renumbered."""
         return from_categories([self, nvcat])
+
+    def add_keys(self, strs):
+        """nvcategory.py:605-624 (NVCategory::add_keys_and_remap)."""
+        return self._cat_call(lib.cs_category_add_keys, strs.m_cptr)
+
+    def remove_keys(self, strs):
+        """nvcategory.py:626-645 (NVCategory::remove_keys_and_remap)."""
+        return self._cat_call(lib.cs_category_remove_keys, strs.m_cptr)
+
+    def remove_unused_keys(self):
+        """nvcategory.py:717-733 (NVCategory::remove_unused_keys_and_remap)."""
+        return self._cat_call(lib.cs_category_remove_unused_keys)
+
+    def set_keys(self, strs):
+        """nvcategory.py:647-667 (NVCategory::set_keys_and_remap)."""
+        return self._cat_call(lib.cs_category_set_keys, strs.m_cptr)

@@ -88,13 +88,28 @@ def bind_cpointer(cptr, own=True):
 
 
 _NOT_BUILT = (
-    "len compare hash stoi stol stof stod htoi to_booleans ip2int timestamp2int cat join split_record "
-    "rsplit_record partition rpartition get repeat pad ljust center rjust zfill wrap slice slice_from "
-    "slice_replace insert replace_multi fillna capitalize swapcase title index rindex "
+    "compare hash stoi stol stof stod htoi to_booleans ip2int timestamp2int "
+    "get repeat pad ljust center rjust zfill wrap slice slice_from "
+    "slice_replace insert fillna capitalize swapcase title index rindex "
     "find_from rfind match_strings startswith endswith isalnum "
-    "isalpha isdigit isspace isdecimal isnumeric islower isupper is_empty translate sort order gather "
-    "scatter scalar_scatter remove_strings add_strings copy find_multiple url_encode url_decode get_ipc_data"
+    "isalpha isdigit isspace isdecimal isnumeric islower isupper is_empty translate "
+    "find_multiple url_encode url_decode get_ipc_data"
 ).split()
+
+
+def _int_array(values, count=0):
+    """list of ints | numpy array | device address (+ count) -> (address, n, on_device, keepalive)"""
+    if isinstance(values, int):
+        return values, int(count), 1, None
+    if hasattr(values, "data_ptr"):  # torch tensor on the device
+        return values.data_ptr(), int(count) or values.numel(), 1, values
+    a = np.ascontiguousarray(values, dtype=np.int32)
+    return a.ctypes.data, len(a), 0, a
+
+
+def _escape_literal(text):
+    """A literal as a pattern of the reference's regex dialect (regcomp.cpp:314-539): metacharacters quoted."""
+    return "".join("\\" + ch if ch in "\\^$.|?*+()[]{}" else ch for ch in text)
 
 
 class nvstrings:
@@ -167,12 +182,119 @@ class nvstrings:
         check(lib.cs_column_export_offsets32(self.m_cptr, pc, po, pn, 1 if bdevmem else 0, None))
         del k1, k2, k3
 
-    def sublist(self, start, end, step=0):
-        """nvstrings.py:2390 / NVStrings::sublist (NVStrings.h:261), step 1 only: rows [start, end)."""
-        if step not in (0, 1):
-            raise NotImplementedError("sublist with a step is outside the accelerated hot path")
+    def sublist(self, start, end=0, step=0):
+        """NVStrings::sublist(start, end, step) (NVStrings.h:261; array.cu:238-260): rows start, start+step, ...
+        before `end`.  A list as the first argument is the Python module's form (nvstrings.py:2390): gather."""
+        if not isinstance(start, int):
+            return self.gather(start, end)
         out = C.c_void_p()
-        check(lib.cs_column_slice(self.m_cptr, int(start), int(end) - int(start), None, C.byref(out)))
+        check(lib.cs_sublist(self.m_cptr, int(start), int(end), int(step), None, C.byref(out)))
+        return nvstrings(out.value)
+
+    # ---- re-arrangement (nvstrings.py:2326-2540; array.cu) --------------------------------------------
+    def gather(self, indexes, count=0):
+        """nvstrings.py:2394-2418 -- rows at the given positions (ints) or where the mask is true (bools)."""
+        out = C.c_void_p()
+        if not isinstance(indexes, int) and not hasattr(indexes, "data_ptr") and len(indexes) and isinstance(indexes[0], (bool, np.bool_)):
+            m = np.ascontiguousarray(indexes, dtype=np.uint8)
+            if len(m) != self.size():
+                raise ValueError("gather: the mask must have one entry per string")
+            check(lib.cs_gather_mask(self.m_cptr, m.ctypes.data, 0, None, C.byref(out)))
+            return nvstrings(out.value)
+        p, n, dev, keep = _int_array(indexes, count)
+        st = lib.cs_gather(self.m_cptr, p, n, dev, None, C.byref(out))
+        if st == _lib.CS_ERR_RANGE:
+            raise IndexError(_lib.last_error())  # std::out_of_range in the reference
+        check(st)
+        del keep
+        return nvstrings(out.value)
+
+    def scatter(self, strs, indexes):
+        """nvstrings.py:2420-2448 -- a copy with row indexes[j] replaced by row j of strs."""
+        p, n, dev, keep = _int_array(indexes, strs.size())
+        if n != strs.size():
+            raise ValueError("scatter: one index per string of strs")
+        out = C.c_void_p()
+        check(lib.cs_scatter(self.m_cptr, strs.m_cptr, p, dev, None, C.byref(out)))
+        del keep
+        return nvstrings(out.value)
+
+    def scalar_scatter(self, str, indexes, count):
+        """nvstrings.py:2450-2478 -- a copy with the given rows replaced by one string."""
+        p, n, dev, keep = _int_array(indexes, count)
+        out = C.c_void_p()
+        check(lib.cs_scatter_scalar(self.m_cptr, b(str), p, n if not dev else int(count), dev, None, C.byref(out)))
+        del keep
+        return nvstrings(out.value)
+
+    def remove_strings(self, indexes, count=0):
+        """nvstrings.py:2480-2505 -- the rows NOT named by indexes (array.cu:262-300)."""
+        p, n, dev, keep = _int_array(indexes, count)
+        if dev:
+            raise NotImplementedError("remove_strings with a device pointer")
+        mask = np.ones(self.size(), dtype=np.uint8)
+        idx = np.asarray(keep, dtype=np.int64)
+        mask[idx[(idx >= 0) & (idx < self.size())]] = 0
+        out = C.c_void_p()
+        check(lib.cs_gather_mask(self.m_cptr, mask.ctypes.data, 0, None, C.byref(out)))
+        return nvstrings(out.value)
+
+    def add_strings(self, strs):
+        """nvstrings.py:2507-2530 -- these rows followed by those of strs."""
+        arr = (C.c_void_p * 2)(self.m_cptr, strs.m_cptr)
+        out = C.c_void_p()
+        check(lib.cs_column_concat(arr, 2, None, C.byref(out)))
+        return nvstrings(out.value)
+
+    def copy(self):
+        """nvstrings.py:2532-2540."""
+        return self.sublist(0, self.size(), 1) if self.size() else to_device([])
+
+    def sort(self, stype=2, asc=True, nullfirst=True):
+        """nvstrings.py:2326-2355 -- by name (2), byte length (1) or both (3)."""
+        out = C.c_void_p()
+        check(lib.cs_sort(self.m_cptr, int(stype), 1 if asc else 0, 1 if nullfirst else 0, None, C.byref(out)))
+        return nvstrings(out.value)
+
+    def order(self, stype=2, asc=True, nullfirst=True, devptr=0):
+        """nvstrings.py:2357-2388 -- the row indexes in sorted order."""
+        rows = self.size()
+        if devptr:
+            check(lib.cs_order(self.m_cptr, int(stype), 1 if asc else 0, 1 if nullfirst else 0, devptr, 1, None))
+            return devptr
+        res = np.zeros(max(rows, 1), dtype=np.uint32)
+        check(lib.cs_order(self.m_cptr, int(stype), 1 if asc else 0, 1 if nullfirst else 0, res.ctypes.data, 0, None))
+        return [int(v) for v in res[:rows]]
+
+    def len(self, devptr=0):
+        """nvstrings.py:538-565 -- characters per row; None for null rows in the host list."""
+        rows = self.size()
+        total = C.c_int64()
+        if devptr:
+            check(lib.cs_len(self.m_cptr, devptr, 1, None, C.byref(total)))
+            return devptr
+        res = np.zeros(max(rows, 1), dtype=np.int32)
+        check(lib.cs_len(self.m_cptr, res.ctypes.data, 0, None, C.byref(total)))
+        return [None if v < 0 else int(v) for v in res[:rows]]
+
+    # ---- combine (nvstrings.py:881-934; combine.cu) ---------------------------------------------------
+    def cat(self, others=None, sep=None, na_rep=None):
+        """nvstrings.py:881-911 -- row-wise concatenation with one or several other instances; without `others`
+        all rows are joined into one string (pystrings.cpp n_cat: join(sep or "", na_rep))."""
+        out = C.c_void_p()
+        if others is None:
+            check(lib.cs_join(self.m_cptr, b(sep if sep is not None else ""), b(na_rep), None, C.byref(out)))
+            return nvstrings(out.value)
+        if not isinstance(others, (list, tuple)):
+            others = [others]
+        arr = (C.c_void_p * max(len(others), 1))(*[o.m_cptr for o in others])
+        check(lib.cs_cat(self.m_cptr, arr, len(others), b(sep), b(na_rep), None, C.byref(out)))
+        return nvstrings(out.value)
+
+    def join(self, sep=""):
+        """nvstrings.py:913-934 -- all rows joined into a single string (null rows contribute nothing)."""
+        out = C.c_void_p()
+        check(lib.cs_join(self.m_cptr, b(sep), None, None, C.byref(out)))
         return nvstrings(out.value)
 
     def _export_window(self, first, rows):
@@ -240,7 +362,69 @@ class nvstrings:
         lib.cs_free(arr)
         return out
 
+    def _record_call(self, fn, delimiter, n, flat):
+        rows = self.size()
+        loff = np.zeros(rows + 1, dtype=np.int64)
+        out = C.c_void_p()
+        check(fn(self.m_cptr, b(delimiter), int(n), loff.ctypes.data, 0, None, C.byref(out)))
+        f = nvstrings(out.value)
+        if flat:
+            return f, loff
+        nulls = self._null_flags() if rows else []
+        return [None if nulls[r] else f.sublist(int(loff[r]), int(loff[r + 1]), 1) for r in range(rows)]
+
+    def split_record(self, delimiter=None, n=-1, flat=False):
+        """nvstrings.py:936-967 -- one nvstrings per row holding that row's tokens (None for a null row).
+        flat=True returns the native form: (all tokens in row-major order, rows+1 list offsets)."""
+        return self._record_call(lib.cs_split_record, delimiter, n, flat)
+
+    def rsplit_record(self, delimiter=None, n=-1, flat=False):
+        """nvstrings.py:969-1001 -- split_record with the tokens located from the right."""
+        return self._record_call(lib.cs_rsplit_record, delimiter, n, flat)
+
+    def _partition(self, delimiter, from_right, flat):
+        out = C.c_void_p()
+        check(lib.cs_partition(self.m_cptr, b(delimiter), from_right, None, C.byref(out)))
+        if not out.value:
+            return []
+        f = nvstrings(out.value)
+        if flat:
+            return f
+        return [f.sublist(3 * r, 3 * r + 3, 1) for r in range(self.size())]
+
+    def partition(self, delimiter=" ", flat=False):
+        """nvstrings.py:1003-1034 -- per row (head, delimiter, tail) around the first occurrence."""
+        return self._partition(delimiter, 0, flat)
+
+    def rpartition(self, delimiter=" ", flat=False):
+        """nvstrings.py:1036-1067 -- per row (head, delimiter, tail) around the last occurrence."""
+        return self._partition(delimiter, 1, flat)
+
     # ---- replace ----------------------------------------------------------------
+    def replace_multi(self, pats, repls, regex=True):
+        """nvstrings.py:1487-1530 -- several patterns (list of str; regex) or literals (list / nvstrings) at once:
+        at each position the first that matches is replaced by its replacement (or the single one)."""
+        if regex:
+            if not isinstance(pats, list):
+                raise ValueError("pats must be list of str")
+            pats = list(pats)
+        else:
+            pats = [None if p is None else _escape_literal(p) for p in (pats.to_host() if isinstance(pats, nvstrings) else pats)]
+        if isinstance(repls, str):
+            repls = to_device([repls])
+        if isinstance(repls, list):
+            repls = to_device(repls)
+        res = [_compile(p) if p is not None else None for p in pats]
+        arr = (C.c_void_p * max(len(res), 1))(*[r for r in res])
+        out = C.c_void_p()
+        try:
+            check(lib.cs_replace_re_multi(self.m_cptr, arr, len(res), repls.m_cptr, None, C.byref(out)))
+        finally:
+            for r in res:
+                if r is not None:
+                    lib.cs_regex_destroy(r)
+        return nvstrings(out.value)
+
     def replace(self, pat, repl, n=-1, regex=True):
         """nvstrings.py:1460-1485 -- replace_re when regex (default) else literal replace."""
         out = C.c_void_p()

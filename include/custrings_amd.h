@@ -127,6 +127,61 @@ int cs_column_byte_count(const cs_column* col, int32_t* lengths, int on_device,
 int cs_column_null_bitarray(const cs_column* col, uint8_t* bitarray, int empty_is_null,
                             int on_device, cs_stream stream, int64_t* null_count);
 
+/* ---- re-arrangement / combination -------------- */
+/* NVStrings::create_from_index (NVStrings.h:98; NVStringsImpl.cu:209-325): `pairs`
+ * is an array of `count` std::pair<const char*, size_t> (pointer, byte length;
+ * NULL pointer = null row, zero length = empty string).  The pointers address
+ * device-visible memory; on_device says where the PAIR ARRAY lives (the
+ * reference's `devmem`).  sorttype: NVStrings::sorttype bits (0 none, 1 length,
+ * 2 name): ascending, nulls first.  An unreadable pointer surfaces as
+ * CS_ERR_INVALID_ARG ("bad_device_ptr"). */
+int cs_column_from_index(const void* pairs, int64_t count, int on_device, int sorttype,
+                         cs_stream stream, cs_column** out);
+/* NVStrings::len (NVStrings.h:343; attrs.cu:32-69): characters per row, -1 for
+ * null rows; *total = sum over non-null rows (the row count when `lengths` is
+ * NULL, as in the reference). */
+int cs_len(const cs_column* col, int32_t* lengths, int on_device, cs_stream stream,
+           int64_t* total);
+/* NVStrings::gather(pos, count) (NVStrings.h:278; array.cu:73-118): rows in the
+ * given order, repeats allowed; a position outside [0, rows) -> CS_ERR_RANGE
+ * (std::out_of_range in the reference). */
+int cs_gather(const cs_column* col, const int32_t* pos, int64_t n, int on_device,
+              cs_stream stream, cs_column** out);
+/* NVStrings::gather(mask) (NVStrings.h:288; array.cu:121-146): rows whose mask
+ * byte is non-zero. */
+int cs_gather_mask(const cs_column* col, const uint8_t* mask, int on_device,
+                   cs_stream stream, cs_column** out);
+/* NVStrings::sublist(start, end, step) (NVStrings.h:261; array.cu:238-260). */
+int cs_sublist(const cs_column* col, int64_t start, int64_t end, int64_t step,
+               cs_stream stream, cs_column** out);
+/* NVStrings::scatter(strs, pos) / scatter(str, pos, count) (NVStrings.h:302,318;
+ * array.cu:157-236): a copy of `col` with row pos[j] replaced by row j of
+ * `strs` (or by the scalar; NULL = null row).  Positions outside the column are
+ * ignored; when a row is named more than once the last entry wins. */
+int cs_scatter(const cs_column* col, const cs_column* strs, const int32_t* pos, int on_device,
+               cs_stream stream, cs_column** out);
+int cs_scatter_scalar(const cs_column* col, const char* str, const int32_t* pos, int64_t n,
+                      int on_device, cs_stream stream, cs_column** out);
+/* NVStrings::sort / order (NVStrings.h:1102,1114; array.cu:303-360): sorttype
+ * bits 1 = byte length, 2 = name (unsigned bytewise, custring.inl:240-261);
+ * nulls first or last regardless of direction.  Equal rows keep their index
+ * order (the reference's comparator sort leaves their order unspecified). */
+int cs_sort(const cs_column* col, int sorttype, int ascending, int nullfirst, cs_stream stream,
+            cs_column** out);
+int cs_order(const cs_column* col, int sorttype, int ascending, int nullfirst, uint32_t* indexes,
+             int on_device, cs_stream stream);
+/* NVStrings::cat(others, separator, narep) (NVStrings.h:384,397; combine.cu:31-291):
+ * row-wise concatenation of `col` and up to 15 other columns of the same row
+ * count; a null element is replaced by narep, or makes the row null when narep
+ * is NULL. */
+int cs_cat(const cs_column* col, const cs_column* const* others, int nothers,
+           const char* separator, const char* narep, cs_stream stream, cs_column** out);
+/* NVStrings::join(delimiter, narep) (NVStrings.h:561; combine.cu:293-420): all
+ * rows joined into a column of ONE row; a null row contributes narep, or nothing
+ * (and no delimiter) when narep is NULL.  delimiter NULL -> CS_ERR_INVALID_ARG. */
+int cs_join(const cs_column* col, const char* delimiter, const char* narep, cs_stream stream,
+            cs_column** out);
+
 /* ---- per-row string ops ------------------------------------------------ */
 /* NVStrings::lower / upper (NVStrings.h:815,822; case.cu:31-97,100-170). */
 int cs_lower(const cs_column* col, cs_stream stream, cs_column** out);
@@ -181,6 +236,14 @@ int cs_count_re(const cs_column* col, const cs_regex* re, int32_t* results, int 
 /* NVStrings::replace_re (NVStrings.h:766; replace.cu:110-189). */
 int cs_replace_re(const cs_column* col, const cs_regex* re, const char* repl, int maxrepl,
                   cs_stream stream, cs_column** out);
+/* NVStrings::replace_re(patterns, repls) (NVStrings.h:777; replace_multi.cu:110-189):
+ * at every character position the patterns are tried in order, anchored there;
+ * the first that matches is replaced by repls[its index] (or by repls[0] when
+ * `repls` holds one row; a null replacement removes the match) and the walk
+ * continues behind the match.  A pattern that can match the empty string is
+ * refused with CS_ERR_INVALID_ARG (the reference does not terminate on it). */
+int cs_replace_re_multi(const cs_column* col, const cs_regex* const* patterns, int npatterns,
+                        const cs_column* repls, cs_stream stream, cs_column** out);
 /* NVStrings::replace_with_backrefs(pattern, repl) (NVStrings.h:788;
  * replace_backref.cu:36-207): every match is replaced by `repl` with \N
  * (backslash + digits) standing for capture group N of that match (0 = the
@@ -220,6 +283,25 @@ int cs_records_from_columns(const cs_column* const* cols, int ncols, int ragged,
                             int64_t* list_offsets, int on_device, cs_stream stream,
                             cs_column** out);
 
+/* NVStrings::split_record / rsplit_record (NVStrings.h:443-494; split.cu:125-700)
+ * natively: ONE flat column of every row's tokens in row-major order plus rows+1
+ * list offsets (record r = flat rows [list_offsets[r], list_offsets[r+1]); a
+ * null row has no entries, where the reference pushes a null instance).
+ * delimiter NULL (or "") = whitespace: a valid row without tokens then yields one
+ * empty string (split.cu:393-397).  list_offsets: int64, device memory when
+ * on_device. */
+int cs_split_record(const cs_column* col, const char* delimiter, int maxsplit,
+                    int64_t* list_offsets, int on_device, cs_stream stream, cs_column** out);
+int cs_rsplit_record(const cs_column* col, const char* delimiter, int maxsplit,
+                     int64_t* list_offsets, int on_device, cs_stream stream, cs_column** out);
+/* NVStrings::partition / rpartition (NVStrings.h:537,549; split.cu:1165-1361):
+ * three strings per row -- head, delimiter, tail around the first (last)
+ * occurrence; no occurrence: (row, "", "") / ("", "", row); a null row: three
+ * nulls.  Flat column of 3 * rows entries (row r = entries 3r .. 3r+2).  A NULL
+ * or empty delimiter yields *out = NULL (the reference returns no results). */
+int cs_partition(const cs_column* col, const char* delimiter, int from_right, cs_stream stream,
+                 cs_column** out);
+
 /* ---- category (dictionary encoding) ------------------------------------ */
 /* NVCategory::create_from_strings (NVCategory.h:107; NVCategory.cu:220-304):
  * keys = sorted unique rows (null first, then unsigned bytewise order,
@@ -239,6 +321,29 @@ const int32_t* cs_category_values_ptr(const cs_category* cat);
 /* NVCategory::get_values (NVCategory.h:225). */
 int cs_category_get_values(const cs_category* cat, int32_t* out, int on_device,
                            cs_stream stream);
+/* The remap family (NVCategory.h:247-420; NVCategory.cu:926-1822).  Keys stay
+ * sorted unique (merge_category alone appends the new keys behind the old ones);
+ * values of keys that disappear become -1. */
+int cs_category_to_strings(const cs_category* cat, cs_stream stream, cs_column** out);
+int cs_category_gather_strings(const cs_category* cat, const int32_t* pos, int64_t n, int on_device,
+                               cs_stream stream, cs_column** out); /* CS_ERR_RANGE: std::out_of_range */
+int cs_category_gather(const cs_category* cat, const int32_t* pos, int64_t n, int on_device,
+                       cs_stream stream, cs_category** out);
+int cs_category_gather_and_remap(const cs_category* cat, const int32_t* pos, int64_t n, int on_device,
+                                 cs_stream stream, cs_category** out);
+int cs_category_add_strings(const cs_category* cat, const cs_column* strs, cs_stream stream,
+                            cs_category** out);
+int cs_category_remove_strings(const cs_category* cat, const cs_column* strs, cs_stream stream,
+                               cs_category** out);
+int cs_category_merge_category(const cs_category* cat, const cs_category* cat2, cs_stream stream,
+                               cs_category** out);
+int cs_category_add_keys(const cs_category* cat, const cs_column* strs, cs_stream stream,
+                         cs_category** out); /* add_keys_and_remap */
+int cs_category_remove_keys(const cs_category* cat, const cs_column* strs, cs_stream stream,
+                            cs_category** out); /* remove_keys_and_remap */
+int cs_category_remove_unused_keys(const cs_category* cat, cs_stream stream, cs_category** out);
+int cs_category_set_keys(const cs_category* cat, const cs_column* strs, cs_stream stream,
+                         cs_category** out); /* set_keys_and_remap */
 /* Multi-GPU key-set merge helper: out[i] = table[codes[i]] (codes < 0 kept). */
 int cs_remap_codes(const int32_t* codes, int64_t n, const int32_t* table, int32_t* out,
                    cs_stream stream);
@@ -251,6 +356,24 @@ int cs_tokenize(const cs_column* col, const char* delimiter, cs_stream stream,
 /* NVText::create_ngrams (NVText.h:153; ngram.cu:32-110). */
 int cs_ngrams(const cs_column* tokens, unsigned ngrams, const char* separator,
               cs_stream stream, cs_column** out);
+
+/* NVText counters (NVText.h:51-141; tokens.cu:262-716).  delimiter NULL (or "")
+ * = whitespace, else any character of the string. */
+int cs_token_count(const cs_column* col, const char* delimiter, uint32_t* results, int on_device,
+                   cs_stream stream); /* tokens per row, 0 for a null row */
+int cs_unique_tokens(const cs_column* col, const char* delimiter, cs_stream stream,
+                     cs_column** out); /* sorted distinct tokens */
+/* results[r * tokens_rows + t] = how many of row r's tokens equal tokens[t]. */
+int cs_tokens_counts(const cs_column* col, const cs_column* tokens, const char* delimiter,
+                     uint32_t* results, int on_device, cs_stream stream);
+/* Every token equal to targets[t] becomes repls[t] (repls[0] when `repls` has one
+ * row; a null replacement removes the token).  *out = NULL when the result holds
+ * no bytes at all (tokens.cu:612-613). */
+int cs_replace_tokens(const cs_column* col, const cs_column* targets, const cs_column* repls,
+                      const char* delimiter, cs_stream stream, cs_column** out);
+/* Tokens of each row joined by one space; *out = NULL when no row holds a token
+ * (tokens.cu:703-704). */
+int cs_normalize_spaces(const cs_column* col, cs_stream stream, cs_column** out);
 
 /* ---- synthetic workloads (bench / parity inputs) -- */
 /* kind: 2 = C2 word rows, 3 = C3 log lines, 4 = C4 16-char tokens,

@@ -1117,3 +1117,5 @@ extern "C" uint64_t orc_digest(const orc_col* c) {
   }
   return d;
 }
+
+#include "oracle_round2.inc"

@@ -200,6 +200,156 @@ class Oracle(CpuLib):
         self._f("category", vp, [vp, vp])
         self._f("ngrams", vp, [vp, C.c_uint, C.c_char_p])
         self._f("synth", vp, [C.c_int, C.c_int64, C.c_int64, C.c_uint64, C.c_int64])
+        # second part (oracle_round2.inc)
+        i32, i64 = C.c_int, C.c_int64
+        self._f("len", i64, [vp, vp])
+        self._f("gather", vp, [vp, vp, i64])
+        self._f("sublist", vp, [vp, C.c_uint, C.c_uint, i32])
+        self._f("order", None, [vp, i32, i32, i32, vp])
+        self._f("sort", vp, [vp, i32, i32, i32])
+        self._f("scatter", vp, [vp, vp, C.c_char_p, i32, vp, i64])
+        self._f("cat", vp, [vp, vp, i32, C.c_char_p, C.c_char_p])
+        self._f("join", vp, [vp, C.c_char_p, C.c_char_p])
+        self._f("split_record", vp, [vp, C.c_char_p, i32, vp])
+        self._f("rsplit_record", vp, [vp, C.c_char_p, i32, vp])
+        self._f("partition", vp, [vp, C.c_char_p, i32])
+        self._f("replace_multi", vp, [vp, vp, i32, vp])
+        self._f("cat_gather_strings", vp, [vp, vp, i64, i32])
+        self._f("cat_gather_and_remap", vp, [vp, vp, i64, vp])
+        self._f("cat_add_keys_and_remap", vp, [vp, vp, i64, vp, vp])
+        self._f("token_count", None, [vp, C.c_char_p, vp])
+        self._f("unique_tokens", vp, [vp, C.c_char_p])
+        self._f("tokens_counts", None, [vp, vp, C.c_char_p, vp])
+        self._f("replace_tokens", vp, [vp, vp, vp, C.c_char_p])
+        self._f("normalize_spaces", vp, [vp])
+
+    # ---- second part: array / combine / records / multi-pattern replace / category remap / text counters
+    def _call(self, fn, cols, *args, err=ValueError):
+        """fn(handles of `cols`..., *args) -> column; a NULL result is the reference's exception"""
+        hs = [self.put(c) for c in cols]
+        try:
+            o = fn(*hs, *args)
+            if not o:
+                raise err("the reference raises here")
+            return self.take(o)
+        finally:
+            for h in hs:
+                self._col_free(h)
+
+    def len(self, col):
+        h = self.put(col)
+        out = np.zeros(col.rows, dtype=np.int32)
+        total = self._len(h, out.ctypes.data)
+        self._col_free(h)
+        return out, total
+
+    def gather(self, col, pos):
+        pos = np.ascontiguousarray(pos, dtype=np.int32)
+        return self._call(self._gather, [col], pos.ctypes.data, len(pos), err=IndexError)
+
+    def sublist(self, col, start, end, step):
+        return self._call(self._sublist, [col], start, end, step)
+
+    def order(self, col, stype, ascending=True, nullfirst=True):
+        h = self.put(col)
+        out = np.zeros(col.rows, dtype=np.uint32)
+        self._order(h, stype, int(ascending), int(nullfirst), out.ctypes.data)
+        self._col_free(h)
+        return out
+
+    def sort(self, col, stype, ascending=True, nullfirst=True):
+        return self._call(self._sort, [col], stype, int(ascending), int(nullfirst))
+
+    def scatter(self, col, strs, pos):
+        pos = np.ascontiguousarray(pos, dtype=np.int32)
+        if isinstance(strs, Col):
+            hs = self.put(strs)
+            try:
+                return self._call(self._scatter, [col], hs, None, 0, pos.ctypes.data, len(pos))
+            finally:
+                self._col_free(hs)
+        return self._call(self._scatter, [col], None, self._b(strs) or b"", 1 if strs is None else 0, pos.ctypes.data, len(pos))
+
+    def cat(self, col, others, sep=None, narep=None):
+        hs = [self.put(o) for o in others]
+        arr = (C.c_void_p * max(len(hs), 1))(*hs)
+        try:
+            return self._call(self._cat, [col], arr, len(hs), self._b(sep), self._b(narep))
+        finally:
+            for h in hs:
+                self._col_free(h)
+
+    def join(self, col, delim, narep=None):
+        return self._call(self._join, [col], self._b(delim), self._b(narep))
+
+    def _records(self, fn, col, delim, maxsplit):
+        h = self.put(col)
+        lst = np.zeros(col.rows + 1, dtype=np.int64)
+        o = fn(h, self._b(delim), maxsplit, lst.ctypes.data)
+        self._col_free(h)
+        return self.take(o), lst
+
+    def split_record(self, col, delim=None, maxsplit=-1):
+        return self._records(self._split_record, col, delim, maxsplit)
+
+    def rsplit_record(self, col, delim=None, maxsplit=-1):
+        return self._records(self._rsplit_record, col, delim, maxsplit)
+
+    def partition(self, col, delim, from_right=False):
+        return self._call(self._partition, [col], self._b(delim), int(from_right))
+
+    def replace_multi(self, col, blobs, repls):
+        blobs = [np.ascontiguousarray(b, dtype=np.int32) for b in blobs]
+        arr = (C.c_void_p * len(blobs))(*[b.ctypes.data for b in blobs])
+        hr = self.put(repls)
+        try:
+            return self._call(self._replace_multi, [col], arr, len(blobs), hr)
+        finally:
+            self._col_free(hr)
+
+    def cat_gather_strings(self, keys, pos, strict=True):
+        pos = np.ascontiguousarray(pos, dtype=np.int32)
+        return self._call(self._cat_gather_strings, [keys], pos.ctypes.data, len(pos), int(strict), err=IndexError)
+
+    def cat_gather_and_remap(self, keys, pos):
+        pos = np.ascontiguousarray(pos, dtype=np.int32)
+        out = np.zeros(len(pos), dtype=np.int32)
+        k = self._call(self._cat_gather_and_remap, [keys], pos.ctypes.data, len(pos), out.ctypes.data, err=IndexError)
+        return k, out
+
+    def cat_add_keys_and_remap(self, keys, values, strs):
+        values = np.ascontiguousarray(values, dtype=np.int32)
+        out = np.zeros(len(values), dtype=np.int32)
+        hs = self.put(strs)
+        try:
+            k = self._call(self._cat_add_keys_and_remap, [keys], values.ctypes.data, len(values), hs, out.ctypes.data)
+        finally:
+            self._col_free(hs)
+        return k, out
+
+    def token_count(self, col, delim=None):
+        h = self.put(col)
+        out = np.zeros(col.rows, dtype=np.uint32)
+        self._token_count(h, self._b(delim), out.ctypes.data)
+        self._col_free(h)
+        return out
+
+    def unique_tokens(self, col, delim=None):
+        return self._call(self._unique_tokens, [col], self._b(delim))
+
+    def tokens_counts(self, col, tkns, delim=None):
+        h, ht = self.put(col), self.put(tkns)
+        out = np.zeros((col.rows, tkns.rows), dtype=np.uint32)
+        self._tokens_counts(h, ht, self._b(delim), out.ctypes.data)
+        self._col_free(h)
+        self._col_free(ht)
+        return out
+
+    def replace_tokens(self, col, tgts, repls, delim=None):
+        return self._call(self._replace_tokens, [col, tgts, repls], self._b(delim))
+
+    def normalize_spaces(self, col):
+        return self._call(self._normalize_spaces, [col])
 
     # regex entry points take a compiled program blob (int32 numpy array)
     def contains_re(self, col, blob, mode=0):

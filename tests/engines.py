@@ -131,6 +131,150 @@ class OracleEngine:
         return self.o.ngrams(Col.from_list(s), N, sep).to_list()
 
 
+
+    # ---- second part (oracle_round2.inc); category keys / values travel as python lists here ----
+    def len(self, s):
+        out, _ = self.o.len(Col.from_list(s))
+        return [None if v < 0 else int(v) for v in out]
+
+    def gather(self, s, pos):
+        return self.o.gather(Col.from_list(s), pos).to_list()
+
+    def sublist(self, s, start, end, step):
+        return self.o.sublist(Col.from_list(s), start, end, step).to_list()
+
+    def sort(self, s, stype=2, asc=True, nullfirst=True):
+        return self.o.sort(Col.from_list(s), stype, asc, nullfirst).to_list()
+
+    def order(self, s, stype=2, asc=True, nullfirst=True):
+        return self.o.order(Col.from_list(s), stype, asc, nullfirst).tolist()
+
+    def scatter(self, s, strs, pos):
+        return self.o.scatter(Col.from_list(s), Col.from_list(strs), pos).to_list()
+
+    def scalar_scatter(self, s, one, pos):
+        return self.o.scatter(Col.from_list(s), one, pos).to_list()
+
+    def cat(self, s, others, sep=None, narep=None):
+        return self.o.cat(Col.from_list(s), [Col.from_list(x) for x in others], sep, narep).to_list()
+
+    def join(self, s, sep="", narep=None):
+        return self.o.join(Col.from_list(s), sep, narep).to_list()
+
+    @staticmethod
+    def _rows_of(flat, lst, s):
+        f = flat.to_list()
+        return [None if s[r] is None else f[lst[r] : lst[r + 1]] for r in range(len(s))]
+
+    def split_record(self, s, delimiter=None, n=-1):
+        f, lst = self.o.split_record(Col.from_list(s), delimiter, n)
+        return self._rows_of(f, lst, s)
+
+    def rsplit_record(self, s, delimiter=None, n=-1):
+        f, lst = self.o.rsplit_record(Col.from_list(s), delimiter, n)
+        return self._rows_of(f, lst, s)
+
+    def partition(self, s, delimiter=" ", from_right=False):
+        f = self.o.partition(Col.from_list(s), delimiter, from_right).to_list()
+        return [f[3 * r : 3 * r + 3] for r in range(len(s))]
+
+    def replace_multi(self, s, pats, repls):
+        return self.o.replace_multi(Col.from_list(s), [self._blob(p) for p in pats], Col.from_list(repls)).to_list()
+
+    def token_count(self, s, delimiter=None):
+        return self.o.token_count(Col.from_list(s), delimiter).tolist()
+
+    def unique_tokens(self, s, delimiter=None):
+        return self.o.unique_tokens(Col.from_list(s), delimiter).to_list()
+
+    def tokens_counts(self, s, tkns, delimiter=None):
+        return self.o.tokens_counts(Col.from_list(s), Col.from_list(tkns), delimiter).tolist()
+
+    def replace_tokens(self, s, tgts, repls, delimiter=None):
+        return self.o.replace_tokens(Col.from_list(s), Col.from_list(tgts), Col.from_list(repls), delimiter).to_list()
+
+    def normalize_spaces(self, s):
+        return self.o.normalize_spaces(Col.from_list(s)).to_list()
+
+    # category family: (keys, values) of category(s), then the member function
+    def cat_to_strings(self, s):
+        k, v = self.o.category(Col.from_list(s))
+        return self.o.cat_gather_strings(k, v, strict=False).to_list()  # NVCategory.cu:977-1009
+
+    def cat_gather_strings(self, s, pos):
+        k, _ = self.o.category(Col.from_list(s))
+        return self.o.cat_gather_strings(k, pos, strict=True).to_list()
+
+    def cat_gather(self, s, pos):  # NVCategory.cu:1142-1170: same keys, the positions as values (-1 allowed)
+        k, _ = self.o.category(Col.from_list(s))
+        if any(p < -1 or p >= k.rows for p in pos):
+            raise IndexError("out of range")
+        return k.to_list(), list(pos)
+
+    def cat_gather_and_remap(self, s, pos):
+        k, _ = self.o.category(Col.from_list(s))
+        nk, v = self.o.cat_gather_and_remap(k, pos)
+        return nk.to_list(), v.tolist()
+
+    def cat_add_strings(self, s, t):  # NVCategory.cu:926-940: category of (rows ++ strs)
+        return self.category(self.cat_to_strings(s) + list(t))
+
+    def cat_remove_strings(self, s, t):  # NVCategory.cu:942-975: rows equal to any of strs (null == null) go away
+        gone = set(t)
+        return self.category([x for x in self.cat_to_strings(s) if x not in gone])
+
+    def cat_add_keys(self, s, t):
+        k, v = self.o.category(Col.from_list(s))
+        nk, nv = self.o.cat_add_keys_and_remap(k, v, Col.from_list(t))
+        return nk.to_list(), nv.tolist()
+
+    @staticmethod
+    def _sorted_keys(keys):
+        """null first, then unsigned bytewise order (custring.inl:240-261)"""
+        return sorted(keys, key=lambda x: (x is not None, b"" if x is None else x.encode("utf8")))
+
+    def _remap(self, keys, values, new_keys):
+        where = {k: i for i, k in enumerate(new_keys)}
+        return new_keys, [v if v < 0 else where.get(keys[v], -1) for v in values]
+
+    def cat_remove_keys(self, s, t):  # NVCategory.cu:1482-1565
+        keys, values = self.category(s)
+        if not keys or not t:
+            return keys, values
+        gone = set(t)
+        return self._remap(keys, values, [k for k in keys if k not in gone])
+
+    def cat_remove_unused_keys(self, keys, values):  # NVCategory.cu:1567-1706 (on a given category)
+        used = {v for v in values if v >= 0}
+        return self._remap(keys, values, [k for i, k in enumerate(keys) if i in used])
+
+    def cat_set_keys(self, s, t):  # NVCategory.cu:1708-1822
+        keys, values = self.category(s)
+        if not t:
+            return [], ([-1] * len(values) if keys else [])
+        new_keys = self._sorted_keys(set(t))
+        if not keys:
+            return new_keys, values
+        return self._remap(keys, values, new_keys)
+
+    def cat_merge_category(self, s, t):  # NVCategory.cu:1223-1337: the new keys of cat2 go behind the keys of cat1
+        k1, v1 = self.category(s)
+        k2, v2 = self.category(t)
+        if not k1 or not k2:
+            return (k2, v2) if not k1 else (k1, v1)
+        have = set(k1)
+        merged = k1 + [k for k in k2 if k not in have]
+        where = {k: i for i, k in enumerate(merged)}
+        return merged, v1 + [v if v < 0 else where[k2[v]] for v in v2]
+
+    def cat_merge_and_remap(self, s, t):  # NVCategory.cu:1339-1345 == create_from_categories
+        k1, v1 = self.category(s)
+        k2, v2 = self.category(t)
+        merged = self._sorted_keys(set(k1) | set(k2))
+        where = {k: i for i, k in enumerate(merged)}
+        return merged, [where[k1[v]] for v in v1] + [where[k2[v]] for v in v2]
+
+
 class EmuEngine:
     """Product row logic (row_ops.h / regex_vm.h / regex_compile.cpp) on the host."""
 
@@ -324,6 +468,108 @@ class GpuEngine:
         return self.nvt.ngrams(self.col(s), N, sep).to_host()
 
 
+
+    # ---- second part: array / combine / records / multi replace / category family / text counters ----
+    def len(self, s):
+        return self.col(s).len()
+
+    def gather(self, s, pos):
+        return self.col(s).gather(list(pos)).to_host()
+
+    def sublist(self, s, start, end, step):
+        return self.col(s).sublist(start, end, step).to_host()
+
+    def sort(self, s, stype=2, asc=True, nullfirst=True):
+        return self.col(s).sort(stype, asc, nullfirst).to_host()
+
+    def order(self, s, stype=2, asc=True, nullfirst=True):
+        return self.col(s).order(stype, asc, nullfirst)
+
+    def scatter(self, s, strs, pos):
+        return self.col(s).scatter(self.col(strs), list(pos)).to_host()
+
+    def scalar_scatter(self, s, one, pos):
+        return self.col(s).scalar_scatter(one, list(pos), len(pos)).to_host()
+
+    def cat(self, s, others, sep=None, narep=None):
+        return self.col(s).cat([self.col(o) for o in others], sep, narep).to_host()
+
+    def join(self, s, sep="", narep=None):
+        return self.col(s).cat(None, sep, narep).to_host()
+
+    def split_record(self, s, delimiter=None, n=-1):
+        return [None if r is None else r.to_host() for r in self.col(s).split_record(delimiter, n)]
+
+    def rsplit_record(self, s, delimiter=None, n=-1):
+        return [None if r is None else r.to_host() for r in self.col(s).rsplit_record(delimiter, n)]
+
+    def partition(self, s, delimiter=" ", from_right=False):
+        c = self.col(s)
+        return [r.to_host() for r in (c.rpartition(delimiter) if from_right else c.partition(delimiter))]
+
+    def replace_multi(self, s, pats, repls):
+        return self.col(s).replace_multi(list(pats), list(repls)).to_host()
+
+    def token_count(self, s, delimiter=None):
+        return self.nvt.token_count(self.col(s), delimiter)
+
+    def unique_tokens(self, s, delimiter=None):
+        return self.nvt.unique_tokens(self.col(s), delimiter).to_host()
+
+    def tokens_counts(self, s, tkns, delimiter=None):
+        return self.nvt.tokens_counts(self.col(s), self.col(tkns), delimiter)
+
+    def replace_tokens(self, s, tgts, repls, delimiter=None):
+        r = self.nvt.replace_tokens(self.col(s), self.col(tgts), self.col(repls), delimiter)
+        return None if r is None else r.to_host()
+
+    def normalize_spaces(self, s):
+        r = self.nvt.normalize_spaces(self.col(s))
+        return None if r is None else r.to_host()
+
+    def _kv(self, cat):
+        return cat.keys().to_host(), cat.values()
+
+    def _cat(self, s):
+        return self.nvc.from_strings(self.col(s))
+
+    def cat_to_strings(self, s):
+        return self._cat(s).to_strings().to_host()
+
+    def cat_gather_strings(self, s, pos):
+        return self._cat(s).gather_strings(list(pos)).to_host()
+
+    def cat_gather(self, s, pos):
+        return self._kv(self._cat(s).gather(list(pos)))
+
+    def cat_gather_and_remap(self, s, pos):
+        return self._kv(self._cat(s).gather_and_remap(list(pos)))
+
+    def cat_add_strings(self, s, t):
+        return self._kv(self._cat(s).add_strings(self.col(t)))
+
+    def cat_remove_strings(self, s, t):
+        return self._kv(self._cat(s).remove_strings(self.col(t)))
+
+    def cat_add_keys(self, s, t):
+        return self._kv(self._cat(s).add_keys(self.col(t)))
+
+    def cat_remove_keys(self, s, t):
+        return self._kv(self._cat(s).remove_keys(self.col(t)))
+
+    def cat_set_keys(self, s, t):
+        return self._kv(self._cat(s).set_keys(self.col(t)))
+
+    def cat_set_keys_then_remove_unused(self, s, t):
+        return self._kv(self._cat(s).set_keys(self.col(t)).remove_unused_keys())
+
+    def cat_merge_category(self, s, t):
+        return self._kv(self._cat(s).merge_category(self._cat(t)))
+
+    def cat_merge_and_remap(self, s, t):
+        return self._kv(self._cat(s).merge_and_remap(self._cat(t)))
+
+
 # ------------------------------------------------------------------ golden ----
 def load_cases(name):
     with open(os.path.join(GOLDEN, name)) as f:
@@ -373,4 +619,51 @@ def run_case(eng, case):
         return eng.ngrams(s, a["N"], a["sep"])
     if op == "tokenize_ngrams":
         return eng.ngrams(eng.tokenize(s, None), a["N"], a["sep"])
+    # second part
+    if op == "len":
+        return eng.len(s)
+    if op == "gather":
+        return eng.gather(s, a["pos"])
+    if op == "sublist":
+        return eng.sublist(s, a["start"], a["end"], a["step"])
+    if op == "sort":
+        return eng.sort(s, a["stype"], a["asc"], a["nullfirst"])
+    if op == "order":
+        return eng.order(s, a["stype"], a["asc"], a["nullfirst"])
+    if op == "scatter":
+        return eng.scatter(s, a["strs"], a["pos"])
+    if op == "scalar_scatter":
+        return eng.scalar_scatter(s, a["str"], a["pos"])
+    if op == "cat":
+        return eng.cat(s, a["others"], a["sep"], a["narep"])
+    if op == "join":
+        return eng.join(s, a["sep"], a["narep"])
+    if op == "split_record":
+        return eng.split_record(s, a["delimiter"], a["n"])
+    if op == "rsplit_record":
+        return eng.rsplit_record(s, a["delimiter"], a["n"])
+    if op == "partition":
+        return eng.partition(s, a["delimiter"], False)
+    if op == "rpartition":
+        return eng.partition(s, a["delimiter"], True)
+    if op == "replace_multi":
+        return eng.replace_multi(s, a["pats"], a["repls"])
+    if op == "token_count":
+        return eng.token_count(s, a["delimiter"])
+    if op == "unique_tokens":
+        return eng.unique_tokens(s, a["delimiter"])
+    if op == "tokens_counts":
+        return eng.tokens_counts(s, a["tokens"], a["delimiter"])
+    if op == "replace_tokens":
+        return eng.replace_tokens(s, a["tgts"], a["repls"], a["delimiter"])
+    if op == "normalize_spaces":
+        return eng.normalize_spaces(s)
+    if op.startswith("cat_"):
+        fn = getattr(eng, op)
+        if op == "cat_to_strings":
+            return fn(s)
+        res = fn(s, a["arg"])
+        if isinstance(res, tuple):
+            return {"keys": res[0], "values": list(res[1])}
+        return res
     raise KeyError(op)

@@ -1,0 +1,204 @@
+"""-m gpu: the SURVEY.md section 8(f) rows built in round 2 -- array / combine ops, record and
+partition forms of split, replace_re with several patterns, the NVCategory remap family, the
+NVText counters -- through the C ABI against the oracle on seeded random columns.  (The
+reference's own test vectors for these ops run in test_gpu_parity.py::test_gpu_golden.)"""
+import random
+
+import numpy as np
+import pytest
+
+import fuzzdata
+
+pytestmark = pytest.mark.gpu
+
+
+def _rows(seed, n, **kw):
+    return fuzzdata.rows(seed, n, **kw)
+
+
+def _same(f, g, *args):
+    """both engines give the same result, or both raise (the reference throws there)"""
+    try:
+        exp = f(*args)
+    except (ValueError, IndexError):
+        with pytest.raises((ValueError, IndexError)):
+            g(*args)
+        return
+    assert g(*args) == exp, args
+
+
+@pytest.mark.parametrize("seed", [3, 4])
+def test_gpu_array_ops(gpu_engine, oracle_engine, seed):
+    g, o = gpu_engine, oracle_engine
+    s = _rows(seed, 1200, max_len=30)
+    rnd = random.Random(seed)
+    assert g.len(s) == o.len(s)
+    pos = [rnd.randrange(len(s)) for _ in range(900)]
+    assert g.gather(s, pos) == o.gather(s, pos)
+    with pytest.raises(IndexError):
+        g.gather(s, [0, len(s)])
+    with pytest.raises(IndexError):
+        g.gather(s, [-1])
+    for start, end, step in ((0, len(s), 2), (5, 400, 3), (900, 10, -7), (len(s), 0, -1), (3, 3, 1), (7, 2, 1), (0, 10 ** 6, 5)):
+        _same(o.sublist, g.sublist, s, start, end, step)  # (start == size with a negative step: gather(size) throws)
+    for stype in (0, 1, 2, 3):
+        for asc in (True, False):
+            for nf in (True, False):
+                assert g.order(s, stype, asc, nf) == o.order(s, stype, asc, nf), (stype, asc, nf)
+                assert g.sort(s, stype, asc, nf) == o.sort(s, stype, asc, nf)
+    strs = _rows(seed + 50, 300, max_len=12)
+    p2 = [rnd.randrange(-3, len(s) + 3) for _ in range(300)]
+    assert g.scatter(s, strs, p2) == o.scatter(s, strs, p2)
+    assert g.scalar_scatter(s, "é+", p2) == o.scalar_scatter(s, "é+", p2)
+    assert g.scalar_scatter(s, None, p2[:40]) == o.scalar_scatter(s, None, p2[:40])
+
+
+def test_gpu_gather_mask_and_from_index(gpu_engine):
+    from custrings_amd import _lib, nvstrings
+    import ctypes as C
+
+    s = _rows(9, 500, max_len=20)
+    col = gpu_engine.col(s)
+    mask = [i % 3 == 0 for i in range(len(s))]
+    assert col.gather(mask).to_host() == [x for x, m in zip(s, mask) if m]
+    assert col.remove_strings([0, 2, 499, 2]).to_host() == [x for i, x in enumerate(s) if i not in (0, 2, 499)]
+    # create_from_index over the column's own device buffers: (pointer, length) pairs, null pointer = null row
+    chars, offs, valid = col._export64()
+    v = _lib.ColumnView()
+    _lib.check(_lib.lib.cs_column_get_view(col.m_cptr, C.byref(v)))
+    pairs = np.zeros((len(s), 2), dtype=np.uint64)
+    order = list(range(len(s)))[::-1]
+    for j, r in enumerate(order):
+        if s[r] is not None:
+            pairs[j, 0] = v.chars + int(offs[r]) if offs[r + 1] > offs[r] else v.chars  # (an empty string still needs a non-null pointer)
+            pairs[j, 1] = int(offs[r + 1] - offs[r])
+    out = C.c_void_p()
+    _lib.check(_lib.lib.cs_column_from_index(pairs.ctypes.data, len(s), 0, 0, None, C.byref(out)))
+    assert nvstrings.nvstrings(out.value).to_host() == [s[r] for r in order]
+    _lib.check(_lib.lib.cs_column_from_index(pairs.ctypes.data, len(s), 0, 2, None, C.byref(out)))  # sorted by name, nulls first
+    assert nvstrings.nvstrings(out.value).to_host() == col.sort(2).to_host()
+
+
+@pytest.mark.parametrize("seed", [5, 6])
+def test_gpu_combine(gpu_engine, oracle_engine, seed):
+    g, o = gpu_engine, oracle_engine
+    a, b_, c = (_rows(seed + k, 700, max_len=15) for k in (0, 10, 20))
+    for sep in (None, "", ":", "é-"):
+        for narep in (None, "", "_", "ná"):
+            assert g.cat(a, [b_], sep, narep) == o.cat(a, [b_], sep, narep), (sep, narep)
+            assert g.cat(a, [b_, c], sep, narep) == o.cat(a, [b_, c], sep, narep), (sep, narep)
+            assert g.join(a, sep or "", narep) == o.join(a, sep or "", narep), (sep, narep)
+    with pytest.raises(ValueError):
+        g.cat(a, [b_[:10]], None, None)
+    assert g.join([], ",", None) == o.join([], ",", None) == [""]
+    assert g.join([None, None], ",", None) == o.join([None, None], ",", None)
+
+
+RECORD_ROWS = ["", None, "a b", " a b ", "  aa  bb  ", " a  bbb   c", " aa b  ccc  ", "héllo", "a_bc_déf", "a__bc", "_ab_cd", "ab_cd_",
+               "_", "__", "\ta\nb  c", "x" * 70 + " y", "é é é"]
+
+
+@pytest.mark.parametrize("delim", [None, " ", "_", "b", "é"])
+@pytest.mark.parametrize("n", [-1, 1, 2, 3])
+def test_gpu_split_records(gpu_engine, oracle_engine, delim, n):
+    g, o = gpu_engine, oracle_engine
+    s = RECORD_ROWS + fuzzdata.rows(21, 400, max_len=24, alphabet=list("ab _é\t") + ["cd"])
+    assert g.split_record(s, delim, n) == o.split_record(s, delim, n)
+    assert g.rsplit_record(s, delim, n) == o.rsplit_record(s, delim, n)
+
+
+@pytest.mark.parametrize("delim", [" ", "_", "ab", "é", "é_"])
+def test_gpu_partition(gpu_engine, oracle_engine, delim):
+    g, o = gpu_engine, oracle_engine
+    s = RECORD_ROWS + fuzzdata.rows(22, 400, max_len=24, alphabet=list("ab _é"))
+    assert g.partition(s, delim, False) == o.partition(s, delim, False)
+    assert g.partition(s, delim, True) == o.partition(s, delim, True)
+    assert gpu_engine.col(s).partition("") == [] and gpu_engine.col(s).rpartition(None) == []
+
+
+def test_gpu_records_flat_form(gpu_engine):
+    """the native record form: one column + list offsets, no per-row objects"""
+    c = gpu_engine.col(["a b c", None, "", "d"])
+    flat, lst = c.split_record(" ", -1, flat=True)
+    assert flat.to_host() == ["a", "b", "c", "", "d"] and lst.tolist() == [0, 3, 3, 4, 5]
+    flat = c.partition(" ", flat=True)
+    assert flat.to_host() == ["a", " ", "b c", None, None, None, "", "", "", "d", "", ""]
+
+
+@pytest.mark.parametrize("pats,repls", [([r"\d+", "ab", r"\bc"], ["<N>", "", "C"]), (["a+", "b"], ["_"]), ([r"[aeiou]", r"\s+"], [None, " "]),
+                                        (["é", "a.c", "xyz"], ["e", "<>", ""]), (["(ab|a)(bc|c)?", "b"], ["1", "2"])])
+def test_gpu_replace_multi(gpu_engine, oracle_engine, pats, repls):
+    g, o = gpu_engine, oracle_engine
+    s = fuzzdata.rows(31, 600, alphabet=list("aabbc xyz_.019") + ["é", "ü"]) + fuzzdata.log_rows(7, 300) + ["", None, "abcabc"]
+    assert g.replace_multi(s, pats, repls) == o.replace_multi(s, pats, repls)
+
+
+def test_gpu_replace_multi_arguments(gpu_engine):
+    c = gpu_engine.col(["abc"])
+    with pytest.raises(ValueError):
+        c.replace_multi([], ["x"])
+    with pytest.raises(ValueError):
+        c.replace_multi(["a", "b"], ["1", "2", "3"])
+    with pytest.raises(ValueError):
+        c.replace_multi(["a*"], ["x"])  # matches the empty string: the reference does not terminate
+    with pytest.raises(ValueError):
+        c.replace_multi("a", ["x"])  # patterns must be a list (nvstrings.py:1516-1518)
+    assert c.replace_multi(["a.c"], "x", regex=False).to_host() == ["abc"]  # literal: '.' is not a wildcard
+    assert c.replace_multi(["b", "c"], ["1", "2"], regex=False).to_host() == ["a12"]
+    # a program the tagged DFA does not take (many simultaneous threads) runs the list simulator
+    big = "(a|b|c|d|e|f|g|h){8}"
+    d = gpu_engine.col(["abcdefgh-abcdefgh", "abc", None])
+    assert d.replace_multi([big, "-"], ["#", "+"]).to_host() == ["#+#", "abc", None]
+
+
+@pytest.mark.parametrize("seed", [41, 42])
+def test_gpu_text_counters(gpu_engine, oracle_engine, seed):
+    g, o = gpu_engine, oracle_engine
+    s = fuzzdata.rows(seed, 800, max_len=40, alphabet=list("ab cd_-é\t") + ["the", "cat"])
+    for d in (None, " ", "_-", "é "):
+        assert g.token_count(s, d) == o.token_count(s, d), d
+        assert g.unique_tokens(s, d) == o.unique_tokens(s, d), d
+        tk = o.unique_tokens(s, d)[:25] + [None, "zzz"]
+        assert g.tokens_counts(s, tk, d) == o.tokens_counts(s, tk, d), d
+        tg = ["the", "cat", "a", None, "ab"]
+        assert g.replace_tokens(s, tg, ["T", "é", "", None, "longer replacement"], d) == o.replace_tokens(s, tg, ["T", "é", "", None, "longer replacement"], d)
+        assert g.replace_tokens(s, tg, ["*"], d) == o.replace_tokens(s, tg, ["*"], d)
+    assert g.normalize_spaces(s) == o.normalize_spaces(s)
+    assert g.normalize_spaces(["", "  ", None]) is None  # nothing to hold: no instance (tokens.cu:703-704)
+
+
+@pytest.mark.parametrize("seed", [51, 52])
+def test_gpu_category_family(gpu_engine, oracle_engine, seed):
+    g, o = gpu_engine, oracle_engine
+    rnd = random.Random(seed)
+    words = ["w%d" % i for i in range(30)] + ["é", "", "zz top"]
+    s = [rnd.choice(words + [None]) for _ in range(600)]
+    t = [rnd.choice(words[10:] + ["new1", "new2", None]) for _ in range(200)]
+    nk = len(o.category(s)[0])
+    assert g.cat_to_strings(s) == o.cat_to_strings(s) == s
+    pos = [rnd.randrange(nk) for _ in range(300)]
+    assert g.cat_gather_strings(s, pos) == o.cat_gather_strings(s, pos)
+    assert g.cat_gather(s, pos + [-1]) == o.cat_gather(s, pos + [-1])
+    assert g.cat_gather_and_remap(s, pos) == o.cat_gather_and_remap(s, pos)
+    for bad in ([0, nk], [-1] if True else []):
+        with pytest.raises(IndexError):
+            g.cat_gather_strings(s, bad)
+        with pytest.raises(IndexError):
+            g.cat_gather_and_remap(s, bad)
+    with pytest.raises(IndexError):
+        g.cat_gather(s, [-2])
+    for fn in ("cat_add_strings", "cat_remove_strings", "cat_add_keys", "cat_remove_keys", "cat_set_keys", "cat_merge_category",
+               "cat_merge_and_remap"):
+        got, exp = getattr(g, fn)(s, t), getattr(o, fn)(s, t)
+        assert (list(got[0]), list(got[1])) == (list(exp[0]), list(exp[1])), fn
+    # remove_unused_keys after set_keys (python/tests/test_category.py:213-220)
+    keys, values = o.cat_set_keys(s, t)
+    exp = o.cat_remove_unused_keys(keys, values)
+    got = g.cat_set_keys_then_remove_unused(s, t)
+    assert (list(got[0]), list(got[1])) == (list(exp[0]), list(exp[1]))
+    # the key-only expectations of the reference's tests (python/tests/test_category.py:191-220)
+    k = ["a", "b", "b", "f", "c", "f"]
+    assert g.cat_add_keys(k, ["a", "b", "c", "d"])[0] == ["a", "b", "c", "d", "f"]
+    assert g.cat_remove_keys(k, ["b", "d"])[0] == ["a", "c", "f"]
+    assert g.cat_set_keys(k, ["b", "c", "e", "d"])[0] == ["b", "c", "d", "e"]
+    assert g.cat_set_keys_then_remove_unused(k, ["b", "c", "e", "d"])[0] == ["b", "c"]

@@ -216,6 +216,160 @@ case("py_lstrip", "python/tests/test_strip.py:26-32 (pandas)", "lstrip", SS, [no
 case("py_rstrip", "python/tests/test_strip.py:35-41 (pandas)", "rstrip", SS, [none_if_nan(v) for v in ps.str.rstrip()],
      level="py", to_strip=None)
 
+# ------------------------------------------- second part: SURVEY.md section 8(f) rows --
+# (data transcribed from the reference's gtests / pytest files, as above)
+AR = ["John Smith", "Joe Blow", "Jane Smith", None, ""]
+case("cpp_sublist", "cpp/tests/test_array.cu:10-21", "sublist", AR, ["Joe Blow", "Jane Smith", None], start=1, end=4, step=0)
+case("cpp_gather", "cpp/tests/test_array.cu:23-38", "gather", AR, ["Joe Blow", None, "Jane Smith"], pos=[1, 3, 2])
+case("cpp_scatter", "cpp/tests/test_array.cu:59-75", "scatter", AR, ["John Smith", "", "Jane Smith", "Joe Schmoe", ""],
+     strs=["", "Joe Schmoe"], pos=[1, 3])
+case("cpp_scatter_scalar", "cpp/tests/test_array.cu:76-81", "scalar_scatter", AR, ["John Smith", "_", "Jane Smith", "_", ""],
+     str="_", pos=[1, 3])
+case("cpp_sort_length", "cpp/tests/test_array.cu:105-115", "sort", AR, [None, "", "Joe Blow", "John Smith", "Jane Smith"],
+     stype=1, asc=True, nullfirst=True)
+case("cpp_sort_name", "cpp/tests/test_array.cu:117-127", "sort", AR, [None, "", "Jane Smith", "Joe Blow", "John Smith"],
+     stype=2, asc=True, nullfirst=True)
+case("cpp_order_length_desc", "cpp/tests/test_array.cu:129-141", "order", AR, [3, 0, 2, 1, 4], stype=1, asc=False, nullfirst=True)
+case("cpp_order_name_desc_nulls_last", "cpp/tests/test_array.cu:143-155", "order", AR, [0, 1, 2, 4, 3], stype=2, asc=False,
+     nullfirst=False)
+AT = ["Héllo", "thesé", None, "ARE THE", "tést strings", "", "1.75", "-34", "+9.8", "17¼", "x³", "2³", " 12⅝", "1234567890", "de",
+      "\t\r\n\f "]
+case("cpp_len", "cpp/tests/test_attrs.cu:11-24", "len", AT, [5, 5, None, 7, 12, 0, 4, 3, 4, 3, 2, 2, 4, 10, 2, 5], level="py")
+C1 = ["thesé", None, "are", "the", "tést", "strings", ""]
+C2 = ["1234", "accénted", "", None, "5678", "othér", "9"]
+C3 = ["abcdéf", "", None, "ghijkl", "mnop", "éach", "xyz"]
+case("cpp_cat", "cpp/tests/test_combine.cpp:18-24", "cat", C1, ["thesé1234", None, "are", None, "tést5678", "stringsothér", "9"],
+     others=[C2], sep=None, narep=None)
+case("cpp_cat_sep", "cpp/tests/test_combine.cpp:26-32", "cat", C1, ["thesé:1234", None, "are:", None, "tést:5678", "strings:othér", ":9"],
+     others=[C2], sep=":", narep=None)
+case("cpp_cat_sep_narep", "cpp/tests/test_combine.cpp:34-40", "cat", C1,
+     ["thesé:1234", "_:accénted", "are:", "the:_", "tést:5678", "strings:othér", ":9"], others=[C2], sep=":", narep="_")
+case("cpp_cat_multi", "cpp/tests/test_combine.cpp:58-64", "cat", C1,
+     ["thesé1234abcdéf", None, None, None, "tést5678mnop", "stringsothéréach", "9xyz"], others=[C2, C3], sep=None, narep=None)
+case("cpp_cat_multi_sep", "cpp/tests/test_combine.cpp:66-72", "cat", C1,
+     ["thesé:1234:abcdéf", None, None, None, "tést:5678:mnop", "strings:othér:éach", ":9:xyz"], others=[C2, C3], sep=":", narep=None)
+case("cpp_cat_multi_sep_narep", "cpp/tests/test_combine.cpp:74-80", "cat", C1,
+     ["thesé:1234:abcdéf", "_:accénted:", "are::_", "the:_:ghijkl", "tést:5678:mnop", "strings:othér:éach", ":9:xyz"],
+     others=[C2, C3], sep=":", narep="_")
+case("cpp_join", "cpp/tests/test_combine.cpp:91-96", "join", C1, ["theséarethetéststrings"], sep="", narep=None)
+case("cpp_join_sep", "cpp/tests/test_combine.cpp:98-103", "join", C1, ["thesé:are:the:tést:strings:"], sep=":", narep=None)
+case("cpp_join_sep_narep", "cpp/tests/test_combine.cpp:105-110", "join", C1, ["thesé:_:are:the:tést:strings:"], sep=":", narep="_")
+case("cpp_split_record_ws", "cpp/tests/test_split.cpp:63-84", "split_record", S,
+     [["Héllo", "thesé"], None, ["are", "some"], ["tést", "String"], [""]], delimiter=None, n=-1)
+case("cpp_rsplit_record_ws", "cpp/tests/test_split.cpp:85-105", "rsplit_record", S,
+     [["Héllo", "thesé"], None, ["are", "some"], ["tést", "String"], [""]], delimiter=None, n=-1)
+case("cpp_split_record_s", "cpp/tests/test_split.cpp:106-126", "split_record", S,
+     [["Héllo the", "é"], None, ["are ", "ome"], ["té", "t String"], [""]], delimiter="s", n=-1)
+case("cpp_split_record_s_2", "cpp/tests/test_split.cpp:127-147", "split_record", S,
+     [["Héllo the", "é"], None, ["are ", "ome"], ["té", "t String"], [""]], delimiter="s", n=2)
+case("cpp_partition", "cpp/tests/test_split.cpp:155-176", "partition", S,
+     [["Héllo", " ", "thesé"], [None, None, None], ["are", " ", "some"], ["tést", " ", "String"], ["", "", ""]], delimiter=" ")
+case("cpp_rpartition", "cpp/tests/test_split.cpp:177-198", "rpartition", S,
+     [["Héllo", " ", "thesé"], [None, None, None], ["are", " ", "some"], ["tést", " ", "String"], ["", "", ""]], delimiter=" ")
+TX = ["the fox jumped over the dog", "the dog chased the cat", "the cat chased the mouse", None, "", "the mouse ate the cheese"]
+case("cpp_token_count", "cpp/tests/test_text.cu:28-40", "token_count", TX, [6, 5, 5, 0, 0, 5], delimiter=" ")
+case("cpp_unique_tokens", "cpp/tests/test_text.cu:42-51", "unique_tokens", TX,
+     ["ate", "cat", "chased", "cheese", "dog", "fox", "jumped", "mouse", "over", "the"], delimiter=None)
+case("cpp_tokens_counts", "cpp/tests/test_text.cu:88-103", "tokens_counts", TX, [[0, 1], [1, 1], [1, 0], [0, 0], [0, 0], [0, 0]],
+     tokens=["cat", "dog"], delimiter=" ")
+case("cpp_replace_multi_literals", "cpp/tests/replace_multi.cpp:24-58 (targets , ! e as patterns; '!' and ',' are not metacharacters)",
+     "replace_multi", ["hello there, good friend!", "hi there!", None, "", "!accénted"],
+     ["h_llo th_r__ good fri_nd_", "hi th_r__", None, "", "_accént_d"], pats=[",", "!", "e"], repls=["_"])
+PA = ["abc", "defghi", None, "cat"]
+case("py_gather", "python/tests/test_array.py:6-10", "gather", PA, ["defghi", "cat", None], pos=[1, 3, 2])
+case("py_scatter", "python/tests/test_array.py:34-39", "scatter", ["a", "b", "c", "d"], ["a", "e", "c", "f"], strs=["e", "f"], pos=[1, 3])
+case("py_scalar_scatter", "python/tests/test_array.py:42-46", "scalar_scatter", ["a", "b", "c", "d"], ["a", "+", "c", "+"], str="+",
+     pos=[1, 3])
+SO = ["abc", "defghi", None, "jkl", "mno", "pqr", "stu", "dog and cat", "accénted", ""]
+case("py_sort_length", "python/tests/test_sort.py:7-36", "sort", SO,
+     [None, "", "abc", "jkl", "mno", "pqr", "stu", "defghi", "accénted", "dog and cat"], stype=1, asc=True, nullfirst=True)
+case("py_sort_name", "python/tests/test_sort.py:39-68", "sort", SO,
+     [None, "", "abc", "accénted", "defghi", "dog and cat", "jkl", "mno", "pqr", "stu"], stype=2, asc=True, nullfirst=True)
+case("py_sort_both", "python/tests/test_sort.py:71-100", "sort", SO,
+     [None, "", "abc", "jkl", "mno", "pqr", "stu", "defghi", "accénted", "dog and cat"], stype=3, asc=True, nullfirst=True)
+case("py_order_length", "python/tests/test_sort.py:103-121", "order", SO, [2, 9, 0, 3, 4, 5, 6, 1, 8, 7], stype=1, asc=True, nullfirst=True)
+case("py_order_name", "python/tests/test_sort.py:124-142", "order", SO, [2, 9, 0, 8, 1, 7, 3, 4, 5, 6], stype=2, asc=True, nullfirst=True)
+case("py_order_both", "python/tests/test_sort.py:145-163", "order", SO, [2, 9, 0, 3, 4, 5, 6, 1, 8, 7], stype=3, asc=True, nullfirst=True)
+case("py_len", "python/tests/test_length.py:6-23", "len",
+     ["abc", "Def", None, "jLl", "mnO", "PqR", "sTT", "dog and cat", "accénted", "", " 1234 ", "XYZ"],
+     [3, 3, None, 3, 3, 3, 3, 11, 8, 0, 6, 3], level="py")
+PC = ["abc", "def", None, "", "jkl", "mno", "accént"]
+case("py_cat_join", "python/tests/test_combine.py:7-13", "join", PC, ["abcdefjklmnoaccént"], sep="", narep=None)
+case("py_cat_join_sep", "python/tests/test_combine.py:15-18", "join", PC, ["abc:def::jkl:mno:accént"], sep=":", narep=None)
+case("py_cat_join_sep_narep", "python/tests/test_combine.py:20-23", "join", PC, ["abc:def:_::jkl:mno:accént"], sep=":", narep="_")
+case("py_cat_others", "python/tests/test_combine.py:25-29", "cat", PC, ["abc:1", "def:2", "_:3", ":4", "jkl:5", "mno:é", "accént:_"],
+     others=[["1", "2", "3", "4", "5", "é", None]], sep=":", narep="_")
+case("py_cat_others_nulls", "python/tests/test_combine.py:31-35", "cat", PC, ["abc1", "def2", None, None, "jkl5", "mnoé", "accént"],
+     others=[["1", "2", "3", None, "5", "é", ""]], sep=None, narep=None)
+PM = ["abc", "df", None, "", "jkl", "mn", "accént"]
+case("py_cat_multiple", "python/tests/test_combine.py:38-44", "cat", PM, ["abc11", "df22", None, None, "jkl55", "mnéé", None],
+     others=[["1", "2", "3", "4", "5", "é", None], ["1", "2", "3", None, "5", "é", ""]], sep=None, narep=None)
+case("py_cat_multiple_sep", "python/tests/test_combine.py:46-57", "cat", PM,
+     ["abc:1:1", "df:2:2", "_:3:3", ":4:_", "jkl:5:5", "mn:é:é", "accént:_:"],
+     others=[["1", "2", "3", "4", "5", "é", None], ["1", "2", "3", None, "5", "é", ""]], sep=":", narep="_")
+case("py_join", "python/tests/test_combine.py:60-64", "join", ["1", "2", "3", None, "5", "é", ""], ["1235é"], sep="", narep=None)
+case("py_join_sep", "python/tests/test_combine.py:66-69", "join", ["1", "2", "3", None, "5", "é", ""], ["1:2:3:5:é:"], sep=":", narep=None)
+PS = ["héllo", None, "a_bc_déf", "a__bc", "_ab_cd", "ab_cd_", "", " a b ", " a  bbb   c"]
+case("py_partition", "python/tests/test_split.py:98-127", "partition", PS,
+     [["héllo", "", ""], [None, None, None], ["a", "_", "bc_déf"], ["a", "_", "_bc"], ["", "_", "ab_cd"], ["ab", "_", "cd_"],
+      ["", "", ""], [" a b ", "", ""], [" a  bbb   c", "", ""]], delimiter="_")
+case("py_rpartition", "python/tests/test_split.py:130-159", "rpartition", PS,
+     [["", "", "héllo"], [None, None, None], ["a_bc", "_", "déf"], ["a_", "_", "bc"], ["_ab", "_", "cd"], ["ab_cd", "_", ""],
+      ["", "", ""], ["", "", " a b "], ["", "", " a  bbb   c"]], delimiter="_")
+CE = ["eee", "aaa", "eee", "ddd", "ccc", "ccc", "ccc", "eee", "aaa"]
+CG = ["ggg", "fff", "hhh", "aaa", "fff", "fff", "ggg", "hhh", "bbb"]
+CK = ["a", "b", "b", "f", "c", "f"]
+case("py_cat_to_strings", "python/tests/test_category.py:78-84", "cat_to_strings", CE, CE)
+case("py_cat_add_strings", "python/tests/test_category.py:87-96", "cat_add_strings", CE,
+     {"keys": ["aaa", "ccc", "ddd", "eee"], "values": [3, 0, 3, 2, 1, 1, 1, 3, 0, 3, 0, 3, 2, 1, 1, 1, 3, 0]}, arg=CE)
+case("py_cat_gather_strings", "python/tests/test_category.py:99-106", "cat_gather_strings", CE, ["aaa", "ddd", "aaa"], arg=[0, 2, 0])
+case("py_cat_remove_strings", "python/tests/test_category.py:126-137", "cat_remove_strings", CE,
+     {"keys": ["ddd", "eee"], "values": [1, 1, 0, 1]}, arg=["ccc", "aaa", "bbb"])
+case("py_cat_merge_category", "python/tests/test_category.py:157-171", "cat_merge_category", CE,
+     {"keys": ["aaa", "ccc", "ddd", "eee", "bbb", "fff", "ggg", "hhh"],
+      "values": [3, 0, 3, 2, 1, 1, 1, 3, 0, 6, 5, 7, 0, 5, 5, 6, 7, 4]}, arg=CG)
+case("py_cat_merge_and_remap", "python/tests/test_category.py:174-188", "cat_merge_and_remap", CE,
+     {"keys": ["aaa", "bbb", "ccc", "ddd", "eee", "fff", "ggg", "hhh"],
+      "values": [4, 0, 4, 3, 2, 2, 2, 4, 0, 6, 5, 7, 0, 5, 5, 6, 7, 1]}, arg=CG)
+case("py_cat_gather", "python/tests/test_category.py:226-235", "cat_gather", CK,
+     {"keys": ["a", "b", "c", "f"], "values": [1, 3, 2, 3, 1, 2]}, arg=[1, 3, 2, 3, 1, 2])
+case("py_cat_gather_and_remap", "python/tests/test_category.py:238-247", "cat_gather_and_remap", CK,
+     {"keys": ["b", "c", "f"], "values": [0, 2, 1, 2, 0, 1]}, arg=[1, 3, 2, 3, 1, 2])
+RMS = ["the quick brown fox jumps over the lazy dog", "the fat cat lays next to the other accénted cat",
+       "a slow moving turtlé cannot catch the bird", "", None]
+STOP = ("i me my myself we our ours ourselves you your yours yourself yourselves he him his himself she her hers herself it its "
+        "itself they them their theirs themselves what which who whom this that these those am is are was were be been being "
+        "have has had having do does did doing a an the and but if or because as until while of at by for with about against "
+        "between into through during before after above below to from up down in out on off over under again further then once "
+        "here there when where why how all any both each few more most other some such no nor not only own same so than too very "
+        "s t can will just don should now uses use using used one also").split()
+case("py_replace_multi_re", "python/tests/test_replace_multi.py:178-190", "replace_multi", RMS,
+     [" quick brown fox jumps   lazy dog", " fat cat lays next    accénted cat", " slow moving turtlé cannot catch  bird", "", None],
+     pats=["\\b" + w + "\\b" for w in STOP], repls=[""])
+case("py_replace_tokens", "python/tests/test_replace_multi.py:193-204", "replace_tokens", RMS,
+     [" quick brown fox jumps   lazy dog", " fat cat lays next    accénted cat", " slow moving turtlé cannot catch  bird", "", None],
+     tgts=STOP, repls=[""], delimiter=None)
+
+TC = ["the quick brown fox jumped over the lazy brown dog", "the sable siamésé cat jumped under the brown sofa", None, ""]
+case("py_token_count", "python/tests/test_text.py:40-52", "token_count", TC, [10, 9, 0, 0], delimiter=" ")
+case("py_token_count_o", "python/tests/test_text.py:54-57", "token_count", TC, [6, 3, 0, 0], delimiter="o")
+UT = ["this is my favorite book", "Your Favorite book is different", None, ""]
+case("py_unique_tokens", "python/tests/test_text.py:67-88 (the test compares sets; sorted here)", "unique_tokens", UT,
+     ["Favorite", "Your", "book", "different", "favorite", "is", "my", "this"], delimiter=" ")
+case("py_unique_tokens_my", "python/tests/test_text.py:90-95 (sorted)", "unique_tokens", UT,
+     [" favorite book", "Your Favorite book is different", "this is "], delimiter="my")
+AP = ["apples are green", "apples are a fruit", None, ""]
+case("py_tokens_counts", "python/tests/test_text.py:144-160 (query = unique_tokens(strs))", "tokens_counts", AP,
+     [[0, 1, 1, 0, 1], [1, 1, 1, 1, 0], [0, 0, 0, 0, 0], [0, 0, 0, 0, 0]], tokens=["a", "apples", "are", "fruit", "green"],
+     delimiter=" ")
+case("py_replace_tokens_3", "python/tests/test_text.py:173-191", "replace_tokens",
+     ["the quick fox jumped over the lazy dog", "the siamésé cat jumped under the sofa", None, ""],
+     ["1 quick fox jumped 2 1 lazy dog", "1 siamésé cat jumped 3 1 sofa", None, ""], tgts=["the", "over", "under"],
+     repls=["1", "2", "3"], delimiter=None)
+case("py_normalize_spaces", "python/tests/test_text.py:194-211", "normalize_spaces",
+     [" the\t quick fox  jumped over the lazy dog", "the siamésé cat\f jumped\t\tunder the sofa  ", None, ""],
+     ["the quick fox jumped over the lazy dog", "the siamésé cat jumped under the sofa", None, ""])
+
 # ------------------------------------------------------- SURVEY.md Appendix A --
 A = []
 
@@ -305,6 +459,7 @@ acase("a4_ngrams_short3", "ngrams", ["a", "b"], ["a_b"], N=3, sep="_")
 # ------------------------------------------------- reference regex compiler --
 PATTERNS = sorted(set(
     [c["args"]["pat"] for c in CASES + A if c["op"] in ("contains_re", "match", "count_re", "replace_re")]
+    + [p for c in CASES if c["op"] == "replace_multi" for p in c["args"]["pats"]]
     + ["a", "abc", "a|b", "(a|b)*c", "a?b+c*", "a{3}", "a{2,4}", "a{2,}", "(ab){2,3}", "[a-z]", "[^a-z]", "[a-zA-Z0-9_]",
        "[\\d\\s]", "[^\\w]", "\\A\\w+\\Z", "^$", ".", ".*", ".+?x", "(?:ab)+", "a\\.b", "\\\\", "\\n\\t", "[é-ü]", "é+",
        "\\bété\\b", "\\B", "\\S+@\\S+", "(\\d+)-(\\d+)", "x|", "|x", "()", "a||b", "[abc", "a{", "a{1", "\\101bc", "x\\60y\\x41z",
