@@ -58,6 +58,7 @@ _PROTOS = {
     "cs_column_byte_count": (i32, [vp, vp, i32, vp, P(i64)]),
     "cs_column_null_bitarray": (i32, [vp, vp, i32, i32, vp, P(i64)]),
     "cs_column_from_index": (i32, [vp, i64, i32, i32, vp, P(vp)]),
+    "cs_column_create_index": (i32, [vp, vp, i32, vp]),
     "cs_len": (i32, [vp, vp, i32, vp, P(i64)]),
     "cs_gather": (i32, [vp, vp, i64, i32, vp, P(vp)]),
     "cs_gather_mask": (i32, [vp, vp, i32, vp, P(vp)]),
@@ -118,6 +119,7 @@ _PROTOS = {
     "cs_category_get_values": (i32, [vp, vp, i32, vp]),
     "cs_remap_codes": (i32, [vp, i64, vp, vp, vp]),
     "cs_tokenize": (i32, [vp, cp, vp, P(vp)]),
+    "cs_tokenize_multi": (i32, [vp, vp, vp, P(vp)]),
     "cs_ngrams": (i32, [vp, C.c_uint, cp, vp, P(vp)]),
     "cs_synth_column": (i32, [i32, i64, i64, u64, i64, vp, P(vp)]),
     "cs_column_digest": (i32, [vp, vp, P(u64)]),

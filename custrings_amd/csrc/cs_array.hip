@@ -81,6 +81,14 @@ __global__ void k_index_copy(const IndexPair* __restrict__ ix, int64_t rows, con
   if (r < rows && ix[r].p) copy_bytes(out + off[r], reinterpret_cast<const uint8_t*>(ix[r].p), (int)ix[r].n);
 }
 
+__global__ void k_index_make(ColView in, IndexPair* __restrict__ ix) {
+  int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (r >= in.rows) return;
+  const bool ok = row_is_valid(in.validity, r);
+  ix[r].p = ok ? reinterpret_cast<const char*>(in.chars + in.offsets[r]) : nullptr;
+  ix[r].n = ok ? (size_t)(in.offsets[r + 1] - in.offsets[r]) : 0;
+}
+
 // ---- len ------------------------------------------------------------------------------------------
 __global__ void k_len(ColView in, int32_t* __restrict__ out, unsigned long long* __restrict__ total) {
   int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -199,6 +207,26 @@ int cs_column_from_index(const void* pairs, int64_t count, int on_device, int so
       return;
     }
     *out = b.col.release();
+  });
+}
+
+int cs_column_create_index(const cs_column* col, void* pairs, int on_device, cs_stream stream) {
+  return guard([&] {
+    if (!col || !pairs) fail(CS_ERR_INVALID_ARG, "create_index: bad arguments");
+    require_device();
+    hipStream_t s = S(stream);
+    const int64_t rows = col->rows;
+    if (rows == 0) return;
+    Buf tmp;
+    IndexPair* d = static_cast<IndexPair*>(pairs);
+    if (!on_device) {
+      tmp = dev_alloc(sizeof(IndexPair) * rows, s);
+      d = ptr<IndexPair>(tmp);
+    }
+    hipLaunchKernelGGL(k_index_make, dim3(blocks_for(rows)), dim3(kBlock), 0, s, view_of(col), d);
+    CS_HIP(hipGetLastError());
+    if (!on_device) CS_HIP(hipMemcpyAsync(pairs, d, sizeof(IndexPair) * rows, hipMemcpyDeviceToHost, s));
+    CS_HIP(hipStreamSynchronize(s));
   });
 }
 

@@ -145,6 +145,48 @@ __global__ void k_normalize_spaces(ColView in, Tokenizer t, int32_t* __restrict_
   if (!WRITE) lens[r] = total;
 }
 
+// tokenize with whole-string delimiters (NVText::tokenize(strs, delims), tokens.cu:158-260): at every byte the
+// delimiters are tried in order (null and empty ones skipped); the text between two delimiter occurrences is a
+// token, empty pieces are dropped.  Pass 0 counts the kept pieces, pass 1 leaves (pointer, length) pairs.
+struct BytePair {
+  const char* p;
+  size_t n;
+};
+template <bool WRITE>
+__global__ void k_tokenize_multi(ColView in, ColView dl, int32_t* __restrict__ counts, const int64_t* __restrict__ base, BytePair* __restrict__ pairs) {
+  int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (r >= in.rows) return;
+  int kept = 0;
+  if (row_is_valid(in.validity, r)) {
+    const int64_t b = in.offsets[r];
+    const int n = (int)(in.offsets[r + 1] - b);
+    const uint8_t* p = in.chars + b;
+    BytePair* mine = WRITE ? pairs + base[r] : nullptr;
+    int spos = 0, i = 0;
+    auto piece = [&](int lo, int hi) {
+      if (hi <= lo) return;
+      if (WRITE) mine[kept] = BytePair{reinterpret_cast<const char*>(p + lo), (size_t)(hi - lo)};
+      ++kept;
+    };
+    while (i < n) {
+      int step = 1;
+      for (int64_t k = 0; k < dl.rows; ++k) {
+        if (!row_is_valid(dl.validity, k)) continue;
+        const int64_t db = dl.offsets[k];
+        const int dn = (int)(dl.offsets[k + 1] - db);
+        if (dn == 0 || i + dn > n || !same_bytes(dl.chars + db, p + i, dn)) continue;
+        piece(spos, i);
+        step = dn;
+        spos = i + dn;
+        break;
+      }
+      i += step;
+    }
+    piece(spos, n);
+  }
+  if (!WRITE) counts[r] = kept;
+}
+
 }  // namespace
 
 extern "C" {
@@ -260,6 +302,40 @@ int cs_normalize_spaces(const cs_column* col, cs_stream stream, cs_column** out)
     CS_HIP(hipGetLastError());
     prefer_offsets32(b.col.get(), s);
     *out = b.col.release();
+  });
+}
+
+
+int cs_tokenize_multi(const cs_column* col, const cs_column* delimiters, cs_stream stream, cs_column** out) {
+  return guard([&] {
+    if (!col || !delimiters || !out) fail(CS_ERR_INVALID_ARG, "tokenize: bad arguments");
+    require_device();
+    hipStream_t s = S(stream);
+    if (delimiters->rows == 0) {  // tokens.cu:160-162: whitespace tokenize
+      int st = cs_tokenize(col, nullptr, stream, out);
+      if (st != CS_OK) fail(st, cs_last_error());
+      return;
+    }
+    const int64_t rows = col->rows;
+    if (rows == 0) {
+      *out = make_all_null(0, s);
+      return;
+    }
+    Buf counts = dev_alloc(sizeof(int32_t) * rows, s);
+    hipLaunchKernelGGL(k_tokenize_multi<false>, dim3(blocks_for(rows)), dim3(kBlock), 0, s, view_of(col), view_of(delimiters), ptr<int32_t>(counts),
+                       (const int64_t*)nullptr, (BytePair*)nullptr);
+    Buf base = dev_alloc(sizeof(int64_t) * (rows + 1), s);
+    const int64_t total = offsets_from_lengths(ptr<int32_t>(counts), rows, ptr<int64_t>(base), s);
+    if (total == 0) {
+      *out = make_all_null(0, s);
+      return;
+    }
+    Buf pairs = dev_alloc(sizeof(BytePair) * total, s);
+    hipLaunchKernelGGL(k_tokenize_multi<true>, dim3(blocks_for(rows)), dim3(kBlock), 0, s, view_of(col), view_of(delimiters), (int32_t*)nullptr,
+                       ptr<const int64_t>(base), ptr<BytePair>(pairs));
+    CS_HIP(hipGetLastError());
+    int st = cs_column_from_index(pairs->p, total, 1, 0, stream, out);
+    if (st != CS_OK) fail(st, cs_last_error());
   });
 }
 

@@ -89,8 +89,16 @@ class nvcategory:
         self.m_cptr = cptr
         self._own = own
 
+    _cs_abi = True  # m_cptr is a cs_category* (the pyni glue wraps it on demand, see host/pyni_common.h)
+    _nv_cptr = None
+
     def __del__(self):
         try:
+            if self._nv_cptr:
+                import pyniNVCategory
+
+                pyniNVCategory.n_dropWrapper(self._nv_cptr)
+                self._nv_cptr = None
             if self.m_cptr and self._own:
                 lib.cs_category_destroy(self.m_cptr)
             self.m_cptr = 0

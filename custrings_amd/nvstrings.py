@@ -123,7 +123,15 @@ class nvstrings:
         self._own = own
         self._keep = None
 
+    _cs_abi = True  # m_cptr is a cs_column* (the pyni glue wraps it on demand, see host/pyni_common.h)
+    _nv_cptr = None
+
     def _destroy(self):
+        if self._nv_cptr:  # the C++ instance the glue wrapped around this handle
+            import pyniNVStrings
+
+            pyniNVStrings.n_dropWrapper(self._nv_cptr)
+            self._nv_cptr = None
         if getattr(self, "m_cptr", None) and self._own:
             lib.cs_column_destroy(self.m_cptr)
         self.m_cptr = 0

@@ -15,6 +15,10 @@ def tokenize(strs, delimiter=None):
     delimiter None = whitespace; otherwise ANY character of `delimiter` separates
     (NVText::tokenize, NVText.h:40; tokens.cu:45-50)."""
     out = C.c_void_p()
+    if isinstance(delimiter, (list, _nvs.nvstrings)):  # nvtext.py:38-40: several whole-string delimiters
+        d = _nvs.to_device(delimiter) if isinstance(delimiter, list) else delimiter
+        check(lib.cs_tokenize_multi(strs.m_cptr, d.m_cptr, None, C.byref(out)))
+        return _nvs.nvstrings(out.value)
     check(lib.cs_tokenize(strs.m_cptr, b(delimiter), None, C.byref(out)))
     return _nvs.nvstrings(out.value)
 

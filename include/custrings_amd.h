@@ -137,6 +137,10 @@ int cs_column_null_bitarray(const cs_column* col, uint8_t* bitarray, int empty_i
  * CS_ERR_INVALID_ARG ("bad_device_ptr"). */
 int cs_column_from_index(const void* pairs, int64_t count, int on_device, int sorttype,
                          cs_stream stream, cs_column** out);
+/* NVStrings::create_index (NVStrings.h:180; NVStrings.cu:348-400): one (pointer,
+ * byte length) pair per row, the pointers addressing the column's own device
+ * chars (valid until the handle is destroyed); null row = (NULL, 0). */
+int cs_column_create_index(const cs_column* col, void* pairs, int on_device, cs_stream stream);
 /* NVStrings::len (NVStrings.h:343; attrs.cu:32-69): characters per row, -1 for
  * null rows; *total = sum over non-null rows (the row count when `lengths` is
  * NULL, as in the reference). */
@@ -353,6 +357,11 @@ int cs_remap_codes(const int32_t* codes, int64_t n, const int32_t* table, int32_
  * delimiter NULL = whitespace (char <= ' '), else any char of `delimiter`. */
 int cs_tokenize(const cs_column* col, const char* delimiter, cs_stream stream,
                 cs_column** out);
+/* NVText::tokenize(strs, delimiters) (NVText.h:48; tokens.cu:158-260): every row of
+ * `delimiters` is a whole-string delimiter (tried in order at each byte; null and
+ * empty rows skipped); empty tokens are dropped.  No delimiters = whitespace. */
+int cs_tokenize_multi(const cs_column* col, const cs_column* delimiters, cs_stream stream,
+                      cs_column** out);
 /* NVText::create_ngrams (NVText.h:153; ngram.cu:32-110). */
 int cs_ngrams(const cs_column* tokens, unsigned ngrams, const char* separator,
               cs_stream stream, cs_column** out);

@@ -222,6 +222,7 @@ class Oracle(CpuLib):
         self._f("tokens_counts", None, [vp, vp, C.c_char_p, vp])
         self._f("replace_tokens", vp, [vp, vp, vp, C.c_char_p])
         self._f("normalize_spaces", vp, [vp])
+        self._f("tokenize_multi", vp, [vp, vp])
 
     # ---- second part: array / combine / records / multi-pattern replace / category remap / text counters
     def _call(self, fn, cols, *args, err=ValueError):
@@ -350,6 +351,9 @@ class Oracle(CpuLib):
 
     def normalize_spaces(self, col):
         return self._call(self._normalize_spaces, [col])
+
+    def tokenize_multi(self, col, delims):
+        return self._call(self._tokenize_multi, [col, delims])
 
     # regex entry points take a compiled program blob (int32 numpy array)
     def contains_re(self, col, blob, mode=0):

@@ -196,6 +196,9 @@ class OracleEngine:
     def normalize_spaces(self, s):
         return self.o.normalize_spaces(Col.from_list(s)).to_list()
 
+    def tokenize_multi(self, s, delims):
+        return self.o.tokenize_multi(Col.from_list(s), Col.from_list(delims)).to_list()
+
     # category family: (keys, values) of category(s), then the member function
     def cat_to_strings(self, s):
         k, v = self.o.category(Col.from_list(s))
@@ -527,6 +530,9 @@ class GpuEngine:
         r = self.nvt.normalize_spaces(self.col(s))
         return None if r is None else r.to_host()
 
+    def tokenize_multi(self, s, delims):
+        return self.nvt.tokenize(self.col(s), list(delims)).to_host()
+
     def _kv(self, cat):
         return cat.keys().to_host(), cat.values()
 
@@ -658,6 +664,8 @@ def run_case(eng, case):
         return eng.replace_tokens(s, a["tgts"], a["repls"], a["delimiter"])
     if op == "normalize_spaces":
         return eng.normalize_spaces(s)
+    if op == "tokenize_multi":
+        return eng.tokenize_multi(s, a["delimiters"])
     if op.startswith("cat_"):
         fn = getattr(eng, op)
         if op == "cat_to_strings":

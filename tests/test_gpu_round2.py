@@ -202,3 +202,11 @@ def test_gpu_category_family(gpu_engine, oracle_engine, seed):
     assert g.cat_remove_keys(k, ["b", "d"])[0] == ["a", "c", "f"]
     assert g.cat_set_keys(k, ["b", "c", "e", "d"])[0] == ["b", "c", "d", "e"]
     assert g.cat_set_keys_then_remove_unused(k, ["b", "c", "e", "d"])[0] == ["b", "c"]
+
+
+def test_gpu_tokenize_multi(gpu_engine, oracle_engine):
+    g, o = gpu_engine, oracle_engine
+    s = fuzzdata.rows(61, 700, max_len=40, alphabet=list("ab c,.;") + ["--", "é", "the"])
+    for delims in ([" "], [",", "."], ["--", " ", "é"], ["the", "a"], [None, "", ";"], ["ab", "a"]):
+        assert g.tokenize_multi(s, delims) == o.tokenize_multi(s, delims), delims
+    assert g.tokenize_multi(s, []) == o.tokenize(s, None)
