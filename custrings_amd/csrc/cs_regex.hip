@@ -777,6 +777,7 @@ struct StreamArgs {
   int64_t* out_off;
   uint8_t* out_chars;
   cstile::u64* status;
+  cstile::u64* excl;  // exclusive prefix per tile, written by the scanner wave (tile_utils.h: prefix_scanner)
   unsigned* error;
   long long nsub;
   int cap_in, cap_out, tbl_bytes;
@@ -797,21 +798,89 @@ struct StreamArgs {
 // matches is scanned a second time during assembly (its size is known from the first scan),
 // without it such a row fails the launch and the host repeats it with the RESCAN variant.
 // LONG: rows of up to 255 bytes keep the lean scan (a sliding 96-byte window of candidate bits).
-template <bool IN_LDS, bool REP16, bool INPLACE, bool RESCAN = false, bool LONG = false>
+// ---- unit scan (regex_tdfa.cpp, header word 31): helpers shared by the stream kernels ------------------
+constexpr int kUnitQueue = 128;  // units one round of the queue holds (a busier sub-tile scans its rows whole)
+// Row lanes: the row's candidate bits (returned in m0..m2) and x bits give its units; all units of the sub-tile are
+// queued as (row | first byte << 8 | end << 16).  `between` runs once every lane holds its masks (the bitmaps may
+// be re-used from there on).  Returns the number of units, or -1 when the queue cannot hold them (nothing is
+// written then and `between` has not run).
+template <class Between>
+__device__ __forceinline__ int unit_discover(const cstd::View& D, const uint32_t* bitmap, const uint32_t* xbitmap, int p0, int n, int lane,
+                                             uint32_t* uqueue, uint32_t& m0, uint32_t& m1, uint32_t& m2, Between&& between) {
+  using namespace cstd;
+  uint32_t x0 = 0, x1 = 0, x2 = 0;
+  cstile::row_bits96(bitmap, p0, n, m0, m1, m2);
+  if ((D.units >> 8) & 127u) cstile::row_bits96(xbitmap, p0, n, x0, x1, x2);
+  const U128 C = u128(m0 | ((unsigned long long)m1 << 32), m2), X = u128(x0 | ((unsigned long long)x1 << 32), x2);
+  U128 N;
+  U128 W = unit_ends(C, X, ((D.units >> 16) & 1u) != 0, N);
+  const int cnt = u128_popc(W);
+  const int uincl = csdev::wave_inclusive_scan(cnt);
+  const int total = __builtin_amdgcn_readlane(uincl, 63);
+  if (total > kUnitQueue) return -1;
+  cstile::wave_lds_fence();
+  between();
+  int slot = uincl - cnt;
+  while (__any(u128_any(W))) {
+    if (u128_any(W)) {
+      const int q = u128_ctz(W);
+      W = u128_clear_lowest(W);
+      uqueue[slot++] = (uint32_t)lane | ((uint32_t)unit_start(N, q) << 8) | ((uint32_t)q << 16);
+    }
+  }
+  cstile::wave_lds_fence();
+  return total;
+}
+// Unit lanes: queue entry -> the unit's row (its position and length come from the row's lane) and the row's
+// candidate bits cut to the unit.  Every lane of the wave must call this (shuffles).
+__device__ __forceinline__ void unit_take(uint32_t ent, int rbeg, int n, uint32_t m0, uint32_t m1, uint32_t m2, int& r, int& rbeg_r, int& n_r,
+                                          uint32_t& c0, uint32_t& c1, uint32_t& c2) {
+  using namespace cstd;
+  r = (int)(ent & 63u);
+  const int us = (int)((ent >> 8) & 255u), uq = (int)((ent >> 16) & 255u);
+  rbeg_r = __shfl(rbeg, r, 64);
+  n_r = __shfl(n, r, 64);
+  const U128 keep = u128_andn(u128_below(uq), u128_below(us));
+  c0 = (uint32_t)__shfl((int)m0, r, 64) & (uint32_t)keep.lo;
+  c1 = (uint32_t)__shfl((int)m1, r, 64) & (uint32_t)(keep.lo >> 32);
+  c2 = (uint32_t)__shfl((int)m2, r, 64) & (uint32_t)keep.hi;
+}
+// "byte == x" bits of one 16-byte piece (staging, from the prefetch registers)
+__device__ __forceinline__ uint32_t unit_xbits16(const uint4& q, uint32_t xpat) {
+  auto eq = [&](uint32_t w) {  // bit 7 of every byte lane that equals x (exact: no borrow between lanes)
+    const uint32_t t = w ^ xpat;
+    return ~(((t & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | t) & 0x80808080u;
+  };
+  return cstile::gather_bit7(eq(q.x)) | (cstile::gather_bit7(eq(q.y)) << 4) | (cstile::gather_bit7(eq(q.z)) << 8) | (cstile::gather_bit7(eq(q.w)) << 12);
+}
+
+// UNITS (with !INPLACE, RESCAN, !LONG): the scan runs per UNIT instead of per row (regex_tdfa.cpp, header word 31).
+// Row lanes cut their rows into units with bit arithmetic on two per-byte bitmaps (candidate bytes, bytes equal
+// to x) and queue them in LDS; then every lane takes a unit -- whichever row it belongs to -- and runs the lean scan
+// over it, leaving a start bit and a last-byte bit per match in the (re-used) bitmaps, from which the row lanes
+// read their rows' matches.  A wave's lock-step scan then costs the longest UNIT (a dotted quad) instead of the
+// busiest ROW (two dotted quads and a status code), and runs that cannot hold a match are never scanned.
+template <bool IN_LDS, bool REP16, bool INPLACE, bool RESCAN = false, bool LONG = false, bool UNITS = false>
 __global__ void __launch_bounds__(256, CS_STREAM_WAVES) k_tdfa_replace_stream(StreamArgs a) {
+  static_assert(!UNITS || (!INPLACE && RESCAN && !LONG), "the unit scan builds on the register-record assembly");
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   uint8_t* base = reinterpret_cast<uint8_t*>(smem);
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int bm_bytes = (a.cap_in >> 3) + 32;  // one candidate bit per staged byte
-  uint8_t* lds_in = base + a.tbl_bytes + (size_t)wv * (a.cap_in + a.cap_out + 64 + bm_bytes);
+  const int unit_bytes = UNITS ? bm_bytes + kUnitQueue * 4 + 16 : 0;  // second bitmap, unit queue, bail word
+  uint8_t* lds_in = base + a.tbl_bytes + (size_t)wv * (a.cap_in + a.cap_out + 64 + bm_bytes + unit_bytes);
   uint8_t* lds_out = lds_in + a.cap_in + 32;
   uint32_t* bitmap = reinterpret_cast<uint32_t*>(lds_out + a.cap_out + 32);
+  uint32_t* xbitmap = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(bitmap) + bm_bytes);  // UNITS: "byte == x", later the matches' last bytes
+  uint32_t* uqueue = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(xbitmap) + bm_bytes);
+  uint32_t* bailw = uqueue + kUnitQueue;  // one bit per row: the lean scan handed a unit of the row over
   const TCtx c = tsetup<IN_LDS>(a.L, a.flags, smem);  // (block barrier inside when staging)
   const cstd::View& D = c.D;
   const csvm::ProgView& P = c.P;
   const ColView& in = a.in;
   const int rb = a.rb;
   const bool has_r2 = (((uint32_t)D.img[30] & 255u) <= (((uint32_t)D.img[30] >> 8) & 255u));
+  const uint32_t unit_x = (D.units >> 8) & 127u, unit_xpat = unit_x * 0x01010101u;
   // rows per tile: 64, or fewer for the long-row variants (so that the tile fits the prefetch registers)
   const int R = LONG ? a.rows_per_tile : 64;
   // Tiles are handed out by tickets, so every tile's predecessors were started before it and a
@@ -823,6 +892,16 @@ __global__ void __launch_bounds__(256, CS_STREAM_WAVES) k_tdfa_replace_stream(St
   const long long K = gridDim.x >= 8 ? 8 : 1;
   const long long key = (long long)blockIdx.x % K;
   const bool fixed = (a.debug & 256) != 0;  // measurement: the static round-robin
+  // Wave 0 of workgroup 0 takes no tiles: it turns the aggregates the other waves publish into each tile's
+  // exclusive prefix, in order (a tile then needs ONE load instead of a walk over its predecessors' words).
+  // (debug 512: the decoupled look-back, for comparison; it also serves tiles too small to lend the scanner its buffer)
+  const bool scanner = !fixed && !(a.debug & 512) && a.cap_in + a.cap_out + 32 >= cstile::kScanBatch * 512;
+  if (scanner && blockIdx.x == 0 && wv == 0) {
+    // (its tile buffers are free: they hold the fetched status words)
+    if (!cstile::prefix_scanner(a.status, a.excl, a.nsub, lane, reinterpret_cast<cstile::u64*>(lds_in)) && lane == 0)
+      atomicOr(a.error, 1u | 16u);  // (16: the scanner wave timed out)
+    return;
+  }
   const long long W = (long long)gridDim.x * 4;
   unsigned long long* my_ticket = a.tickets + key * 8;
   auto take = [&]() -> unsigned long long {
@@ -864,7 +943,7 @@ __global__ void __launch_bounds__(256, CS_STREAM_WAVES) k_tdfa_replace_stream(St
   long long p_tile = -1;
   int p_total = 0, p_lo = 0, p_len = 0;
 #if defined(CS_PHASE_PROF)
-  unsigned long long phase_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long phase_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long lb_acc[3] = {0, 0, 0};
   unsigned long long phase_t = __builtin_readcyclecounter();
 #endif
@@ -875,6 +954,8 @@ __global__ void __launch_bounds__(256, CS_STREAM_WAVES) k_tdfa_replace_stream(St
       const int part = (int)(unsigned)(v & 0xffffffffull);
       gb = p_tile * 4096 + (csdev::wave_reduce_sum(part) & 0) + (long long)(first & 0);
       if (lane == 0) cstile::status_store(a.status + p_tile, cstile::kFlagInc | 1);
+    } else if (scanner) {
+      gb = (a.debug & 8) ? p_tile * 4096 : cstile::prefix_wait(a.excl, p_tile, first, a.error, lane);
     } else {
 #if defined(CS_PHASE_PROF)
       gb = (a.debug & 8) ? p_tile * 4096 : cstile::lookback_end(a.status, p_tile, p_total, first, lane, lb_acc);
@@ -883,7 +964,7 @@ __global__ void __launch_bounds__(256, CS_STREAM_WAVES) k_tdfa_replace_stream(St
 #endif
     }
     if (gb < 0) {
-      if (lane == 0) atomicOr(a.error, 1u);
+      if (lane == 0) atomicOr(a.error, 1u | 8u);  // (8: no prefix for the tile)
       gb = 0;
     }
     CS_PHASE_MARK(6);
@@ -927,11 +1008,12 @@ __global__ void __launch_bounds__(256, CS_STREAM_WAVES) k_tdfa_replace_stream(St
           bits = cstile::gather_bit7(cstd::Tdfa::cand_bits_ascii<false>(D, q.x)) | (cstile::gather_bit7(cstd::Tdfa::cand_bits_ascii<false>(D, q.y)) << 4) |
                  (cstile::gather_bit7(cstd::Tdfa::cand_bits_ascii<false>(D, q.z)) << 8) | (cstile::gather_bit7(cstd::Tdfa::cand_bits_ascii<false>(D, q.w)) << 12);
         if (!bad) cstile::put_bits16(bitmap, j * 1024 + lane * 16, bits);
+        if (UNITS && unit_x != 0 && !bad) cstile::put_bits16(xbitmap, j * 1024 + lane * 16, unit_xbits16(q, unit_xpat));
       }
     // first look-back poll for the previous sub-tile: issued only now, after the staging above has
     // waited for its own data (vmcnt is in order: a poll issued earlier would sit in front of it)
     cstile::u64 p_first = 0;
-    if (p_tile >= 0 && !(a.debug & (8 | 64))) p_first = cstile::lookback_poll(a.status, p_tile, lane);
+    if (p_tile >= 0 && !(a.debug & (8 | 64))) p_first = scanner ? cstile::status_load(a.excl + p_tile) : cstile::lookback_poll(a.status, p_tile, lane);
     // keep the memory pipe busy: next sub-tile's chars, and the offsets of the one after
     const bool has_next = t_nxt < a.nsub;
     if (has_next) {
@@ -992,7 +1074,68 @@ __global__ void __launch_bounds__(256, CS_STREAM_WAVES) k_tdfa_replace_stream(St
                         !__any(live && (LONG ? n > cstd::Tdfa::kLongBytes : !vm.masks_fit()));
       bool redo = live && !lean && a.maxrepl != 0;
       int resume = 0;
-      if (lean && live && a.maxrepl != 0) {
+      bool units_done = false;
+      if (UNITS) {
+        if (lean && a.maxrepl < 0 && (D.units & 1u) && !(a.debug & 1024)) {  // (wave-uniform)
+          using namespace cstd;
+          // -- row lanes: the row's units from its candidate and x bits
+          uint32_t m0, m1, m2;
+          const int total_units = unit_discover(D, bitmap, xbitmap, lead + rbeg, n, lane, uqueue, m0, m1, m2, [&] {
+            // every lane holds its masks: both bitmaps are re-used for the matches
+            for (int i = lane * 16; i < bm_bytes; i += 64 * 16) {
+              *reinterpret_cast<uint4*>(reinterpret_cast<uint8_t*>(bitmap) + i) = make_uint4(0, 0, 0, 0);
+              *reinterpret_cast<uint4*>(reinterpret_cast<uint8_t*>(xbitmap) + i) = make_uint4(0, 0, 0, 0);
+            }
+            if (lane < 2) bailw[lane] = 0;
+          });
+          if (total_units >= 0) {
+            CS_PHASE_MARK(7);
+            // -- unit lanes: one unit each, whatever row it lies in
+            for (int u0 = 0; u0 < total_units; u0 += 64) {
+              const bool act = u0 + lane < total_units;
+              int r, rbeg_r, n_r;
+              uint32_t c0, c1, c2;
+              unit_take(act ? uqueue[u0 + lane] : 0u, rbeg, n, m0, m1, m2, r, rbeg_r, n_r, c0, c1, c2);
+              if (act) {
+                const int pu = lead + rbeg_r;
+                cstd::Tdfa vu(D, P, lds_in + pu, n_r, pu & 3);
+                bool ubail = false;
+                auto recu = [&](int mb, int me, int) {
+                  const int ps = pu + mb, pe = pu + me - 1;
+                  __hip_atomic_fetch_or(bitmap + (ps >> 5), 1u << (ps & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                  __hip_atomic_fetch_or(xbitmap + (pe >> 5), 1u << (pe & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                };
+                vu.scan_lean_dispatch(-1, c0, c1, c2, recu, ubail);
+                if (ubail) __hip_atomic_fetch_or(bailw + (r >> 5), 1u << (r & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+              }
+            }
+            cstile::wave_lds_fence();
+            CS_PHASE_MARK(8);
+            // -- row lanes again: the row's matches from the start / last-byte bits
+            uint32_t s0, s1, s2, e0, e1, e2;
+            cstile::row_bits96(bitmap, lead + rbeg, n, s0, s1, s2);
+            cstile::row_bits96(xbitmap, lead + rbeg, n, e0, e1, e2);
+            const bool rbail = ((bailw[lane >> 5] >> (lane & 31)) & 1u) != 0;
+            if (live && !rbail) {
+              U128 S = u128(s0 | ((unsigned long long)s1 << 32), s2), E = u128(e0 | ((unsigned long long)e1 << 32), e2);
+              nm = u128_popc(S);
+              out_len = n - u128_popc(u128_sub(u128_shl1(E), S)) + nm * rb;
+#pragma unroll
+              for (int j = 0; j < kMaxRec; ++j)
+                if (u128_any(S)) {
+                  rec_mb[j] = u128_ctz(S);
+                  S = u128_clear_lowest(S);
+                  rec_me[j] = u128_ctz(E) + 1;
+                  E = u128_clear_lowest(E);
+                  rec_reps[j] = 1;
+                }
+            }
+            redo = live && rbail;  // (such a row is scanned whole; nothing of it was recorded above)
+            units_done = true;
+          }
+        }
+      }
+      if (!units_done && lean && live && a.maxrepl != 0) {
         bool bail = false;
         uint32_t m0, m1, m2;  // candidate bits, bit i = byte i of the row
         if (LONG) {
@@ -1034,7 +1177,7 @@ __global__ void __launch_bounds__(256, CS_STREAM_WAVES) k_tdfa_replace_stream(St
     if (bad) {
       // the host discards this launch's output; publish something so successors do not spin
       if (lane == 0) {
-        atomicOr(a.error, !INPLACE && grew ? 2u : 1u);
+        atomicOr(a.error, !INPLACE && grew ? 2u : (1u | 4u));  // (4: a sub-tile beyond the staging capacity)
         cstile::status_store(a.status + tile, cstile::kFlagInc);
       }
       if (p_tile >= 0) finish_pending(p_first);
@@ -1042,7 +1185,7 @@ __global__ void __launch_bounds__(256, CS_STREAM_WAVES) k_tdfa_replace_stream(St
     } else {
       if (!(a.debug & 8)) cstile::lookback_publish(a.status, tile, total, lane);
       CS_PHASE_MARK(2);
-      if (p_tile >= 0) finish_pending((a.debug & 64) ? cstile::lookback_poll(a.status, p_tile, lane) : p_first);
+      if (p_tile >= 0) finish_pending((a.debug & 64) ? (scanner ? cstile::status_load(a.excl + p_tile) : cstile::lookback_poll(a.status, p_tile, lane)) : p_first);
       CS_PHASE_MARK(3);
       if (INPLACE) {
         if (live && !(a.debug & 2)) cstile::lds_copy(lds_out, lo, lds_in, lead + rbeg, out_len);
@@ -1094,11 +1237,11 @@ __global__ void __launch_bounds__(256, CS_STREAM_WAVES) k_tdfa_replace_stream(St
     tile = t_nxt;
     t_nxt = t_nn;
   }
-  if (p_tile >= 0) finish_pending((a.debug & 8) ? 0 : cstile::lookback_poll(a.status, p_tile, lane));
+  if (p_tile >= 0) finish_pending((a.debug & 8) ? 0 : (scanner ? cstile::status_load(a.excl + p_tile) : cstile::lookback_poll(a.status, p_tile, lane)));
 #if defined(CS_PHASE_PROF)
   CS_PHASE_MARK(5);
   if (lane == 0)
-    for (int k = 0; k < 8; ++k) atomicAdd(reinterpret_cast<unsigned long long*>(a.error) + 1 + k, phase_acc[k]);
+    for (int k = 0; k < 10; ++k) atomicAdd(reinterpret_cast<unsigned long long*>(a.error) + 1 + k, phase_acc[k]);
   if (lane == 0)
     for (int k = 0; k < 3; ++k) atomicAdd(&cstile::g_lb_stats[k], lb_acc[k]);
 #endif
@@ -1133,14 +1276,22 @@ struct ScanStreamArgs {
   const int64_t* out_off;      // MODE 6
   uint8_t* out_chars;
 };
-template <int MODE, bool IN_LDS, bool LONG = false>
+// UNITS (MODE 0 and 2, !LONG): the unit scan of the replace kernel -- units queued by the row lanes, one unit per lane
+// whatever its row, the per-row result summed (count_re) / OR-ed (contains_re) in LDS.
+template <int MODE, bool IN_LDS, bool LONG = false, bool UNITS = false>
 __global__ void __launch_bounds__(256) k_tdfa_scan_stream(ScanStreamArgs a) {
+  static_assert(!UNITS || ((MODE == 0 || MODE == 2) && !LONG), "unit scan: contains_re / count_re on rows within the 96-byte masks");
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   uint8_t* base = reinterpret_cast<uint8_t*>(smem);
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int bm_bytes = (a.cap_in >> 3) + 32;
-  uint8_t* lds_in = base + a.tbl_bytes + (size_t)wv * (a.cap_in + 32 + bm_bytes);
+  const int unit_bytes = UNITS ? bm_bytes + kUnitQueue * 4 + 64 * 4 + 16 : 0;  // x bitmap, unit queue, per-row results, bail word
+  uint8_t* lds_in = base + a.tbl_bytes + (size_t)wv * (a.cap_in + 32 + bm_bytes + unit_bytes);
   uint32_t* bitmap = reinterpret_cast<uint32_t*>(lds_in + a.cap_in + 32);
+  uint32_t* xbitmap = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(bitmap) + bm_bytes);
+  uint32_t* uqueue = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(xbitmap) + bm_bytes);
+  uint32_t* rowres = uqueue + kUnitQueue;
+  uint32_t* bailw = rowres + 64;
   const TCtx c = tsetup<IN_LDS>(a.L, a.flags, smem);
   const cstd::View& D = c.D;
   const csvm::ProgView& P = c.P;
@@ -1152,6 +1303,7 @@ __global__ void __launch_bounds__(256) k_tdfa_scan_stream(ScanStreamArgs a) {
     a.gtags = g;
   }
   const bool has_r2 = (((uint32_t)D.img[30] & 255u) <= (((uint32_t)D.img[30] >> 8) & 255u));
+  const uint32_t unit_x = (D.units >> 8) & 127u, unit_xpat = unit_x * 0x01010101u;
   const int R = LONG ? a.rows_per_tile : 64;
   const long long waves = (long long)gridDim.x * 4;
   const long long per = (a.nsub + waves - 1) / waves;
@@ -1193,6 +1345,7 @@ __global__ void __launch_bounds__(256) k_tdfa_scan_stream(ScanStreamArgs a) {
           bits = cstile::gather_bit7(cstd::Tdfa::cand_bits_ascii<false>(D, q.x)) | (cstile::gather_bit7(cstd::Tdfa::cand_bits_ascii<false>(D, q.y)) << 4) |
                  (cstile::gather_bit7(cstd::Tdfa::cand_bits_ascii<false>(D, q.z)) << 8) | (cstile::gather_bit7(cstd::Tdfa::cand_bits_ascii<false>(D, q.w)) << 12);
         cstile::put_bits16(bitmap, j * 1024 + lane * 16, bits);
+        if (UNITS && unit_x != 0) cstile::put_bits16(xbitmap, j * 1024 + lane * 16, unit_xbits16(q, unit_xpat));
       }
     const bool has_next = tile + 1 < tile_end;
     if (has_next) {
@@ -1259,7 +1412,38 @@ __global__ void __launch_bounds__(256) k_tdfa_scan_stream(ScanStreamArgs a) {
         }
         ++k;
       };
-      if (lean && live) {
+      bool units_done = false;
+      if (UNITS) {
+        if (lean && (D.units & 1u)) {  // (wave-uniform)
+          constexpr int KIND = MODE == 0 ? cstd::Tdfa::K_CONTAINS : cstd::Tdfa::K_COUNT;
+          uint32_t m0, m1, m2;
+          const int total_units = unit_discover(D, bitmap, xbitmap, lead + rbeg, n, lane, uqueue, m0, m1, m2, [&] {
+            rowres[lane] = 0;
+            if (lane < 2) bailw[lane] = 0;
+          });
+          if (total_units >= 0) {
+            for (int u0 = 0; u0 < total_units; u0 += 64) {
+              const bool act = u0 + lane < total_units;
+              int r, rbeg_r, n_r;
+              uint32_t c0, c1, c2;
+              unit_take(act ? uqueue[u0 + lane] : 0u, rbeg, n, m0, m1, m2, r, rbeg_r, n_r, c0, c1, c2);
+              if (act) {
+                const int pu = lead + rbeg_r;
+                cstd::Tdfa vu(D, P, lds_in + pu, n_r, pu & 3);
+                const int got = vu.template scan_lean_count<KIND>(c0, c1, c2);
+                if (got < 0) __hip_atomic_fetch_or(bailw + (r >> 5), 1u << (r & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                else if (got > 0 && MODE == 0) __hip_atomic_fetch_or(rowres + r, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                else if (got > 0) __hip_atomic_fetch_add(rowres + r, (uint32_t)got, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+              }
+            }
+            cstile::wave_lds_fence();
+            v = live ? (int)rowres[lane] : 0;
+            redo = live && ((bailw[lane >> 5] >> (lane & 31)) & 1u) != 0;  // (such a row is scanned whole)
+            units_done = true;
+          }
+        }
+      }
+      if (!units_done && lean && live) {
         uint32_t m0, m1, m2;
         constexpr int KIND = MODE == 0 ? cstd::Tdfa::K_CONTAINS : cstd::Tdfa::K_COUNT;
         if (LONG) {
@@ -1437,7 +1621,11 @@ void scan(const cs_column* col, cs_regex* re, uint8_t* out8, int32_t* out32, int
   if (tdfa && tp.d.in_lds && MODE != 1 && !getenv("CS_REGEX_ROWWISE")) {
     const TileChoice tc = choose_tile(col, s);
     const int cap = tc.cap;
-    const size_t lds = tp.lds_bytes + (size_t)(cap + 32 + (cap >> 3) + 32) * 4;
+    // the unit scan (k_tdfa_scan_stream<.., UNITS>): patterns whose tagged DFA offers the decomposition, rows within the masks
+    // (count_re only: contains_re stops at a row's first match, and scanning every unit of the row cost more than the
+    // balance won -- 3.87 against 2.66 ms on the 100M-row C3 column)
+    const bool units = MODE == 2 && (re->tdfa[31] & 1) != 0 && !tc.lng && tc.R == 64 && !getenv("CS_NO_UNITS");
+    const size_t lds = tp.lds_bytes + (size_t)(cap + 32 + (cap >> 3) + 32 + (units ? (cap >> 3) + 32 + kUnitQueue * 4 + 64 * 4 + 16 : 0)) * 4;
     if (tc.R && lds <= 150 * 1024) {
       ScanStreamArgs sa{};
       sa.in = view_of(col);
@@ -1451,6 +1639,7 @@ void scan(const cs_column* col, cs_regex* re, uint8_t* out8, int32_t* out32, int
       sa.cap_in = cap;
       sa.tbl_bytes = (int)tp.lds_bytes;
       auto kern = tc.lng ? &k_tdfa_scan_stream<MODE == 2 ? 2 : 0, true, true> : &k_tdfa_scan_stream<MODE == 2 ? 2 : 0, true, false>;
+      if (units) kern = &k_tdfa_scan_stream<MODE == 2 ? 2 : 0, true, false, true>;
       if (lds > 48 * 1024)
         CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       const unsigned grid = resident_grid(reinterpret_cast<const void*>(kern), lds, (sa.nsub + 3) / 4);
@@ -1600,7 +1789,11 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
           const int64_t worst_extra = (col->nbytes * growth + minlen - 1) / minlen;
           extra = std::min(worst_extra, std::max<int64_t>(extra, col->nbytes));
         }
-        const size_t lds1 = tbl + (size_t)(cap + cap_out + 64 + (cap >> 3) + 32) * 4 + 16;
+        // the unit scan (k_tdfa_replace_stream<.., UNITS>): patterns whose tagged DFA offers the decomposition, no limit
+        // on the number of replacements, rows within the 96-byte masks
+        const bool units = (re->tdfa[31] & 1) != 0 && maxrepl < 0 && !tc.lng && tc.R == 64 && !getenv("CS_NO_UNITS");
+        const size_t unit_bytes = units ? (size_t)((cap >> 3) + 32 + kUnitQueue * 4 + 16) : 0;
+        const size_t lds1 = tbl + (size_t)(cap + cap_out + 64 + (cap >> 3) + 32 + unit_bytes) * 4 + 16;
         if (lds1 > 150 * 1024) return -1;
         StreamArgs sa{};
         sa.in = view_of(col);
@@ -1616,11 +1809,15 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
         sa.out_cap = col->nbytes + extra;
         const int64_t nsub1 = (rows + tc.R - 1) / tc.R;
         sa.rows_per_tile = tc.R;
-        Buf status = dev_alloc(sizeof(cstile::u64) * nsub1 + 128 + 512, s);
-        CS_HIP(hipMemsetAsync(status->p, 0, sizeof(cstile::u64) * nsub1 + 128 + 512, s));
+        // [aggregates nsub1][error word + phase counters 16][tickets 64][exclusive prefixes nsub1]
+        // (+ kScanBatch windows of slack: the scanner wave fetches whole batches)
+        const size_t status_bytes = sizeof(cstile::u64) * (2 * (size_t)nsub1 + 16 + 64 + 64 * cstile::kScanBatch);
+        Buf status = dev_alloc(status_bytes, s);
+        CS_HIP(hipMemsetAsync(status->p, 0, status_bytes, s));
         sa.status = ptr<cstile::u64>(status);
         sa.error = reinterpret_cast<unsigned*>(ptr<cstile::u64>(status) + nsub1);
         sa.tickets = ptr<cstile::u64>(status) + nsub1 + 16;
+        sa.excl = ptr<cstile::u64>(status) + nsub1 + 16 + 64;
         sa.nsub = nsub1;
         sa.cap_in = cap;
         sa.cap_out = cap_out;
@@ -1638,6 +1835,9 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
         };
         auto kern = growth == 0 ? pick(std::true_type{}, std::false_type{})
                                 : roomy ? pick(std::false_type{}, std::true_type{}) : pick(std::false_type{}, std::false_type{});
+        if (units)
+          kern = rb > 8 ? (tp.d.in_lds ? &k_tdfa_replace_stream<true, true, false, true, false, true> : &k_tdfa_replace_stream<false, true, false, true, false, true>)
+                        : (tp.d.in_lds ? &k_tdfa_replace_stream<true, false, false, true, false, true> : &k_tdfa_replace_stream<false, false, false, true, false, true>);
         if (lds1 > 48 * 1024)
           CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)lds1));
@@ -1653,19 +1853,30 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
         CS_HIP(hipStreamSynchronize(s));
 #if defined(CS_PHASE_PROF)
         {
-          unsigned long long ph[8];
+          unsigned long long ph[10];
           CS_HIP(hipMemcpy(ph, reinterpret_cast<unsigned long long*>(sa.error) + 1, sizeof(ph), hipMemcpyDeviceToHost));
           unsigned long long lb[4] = {0, 0, 0, 0};
           CS_HIP(hipMemcpyFromSymbol(lb, HIP_SYMBOL(cstile::g_lb_stats), sizeof(lb)));
           fprintf(stderr, "look-back (cumulative): %llu calls, %.2f windows per call, %.2f re-polls per call\n", lb[0], (double)lb[1] / (double)(lb[0] ? lb[0] : 1),
                   (double)lb[2] / (double)(lb[0] ? lb[0] : 1));
           const double waves = (double)grid * 4;
-          fprintf(stderr, "phase cycles/wave-iteration: stage %.0f scan %.0f wscan+publish %.0f finish_prev(offsets+flush) %.0f assemble %.0f tail %.0f lookback %.0f (iters/wave %.1f)\n",
-                  ph[0] / waves / (nsub1 / waves), ph[1] / waves / (nsub1 / waves), ph[2] / waves / (nsub1 / waves),
+          fprintf(stderr, "phase cycles/wave-iteration: stage %.0f scan %.0f (units: discovery %.0f rounds %.0f) wscan+publish %.0f finish_prev(offsets+flush) %.0f assemble %.0f tail %.0f lookback %.0f (iters/wave %.1f)\n",
+                  ph[0] / waves / (nsub1 / waves), ph[1] / waves / (nsub1 / waves), ph[7] / waves / (nsub1 / waves), ph[8] / waves / (nsub1 / waves), ph[2] / waves / (nsub1 / waves),
                   ph[3] / waves / (nsub1 / waves), ph[4] / waves / (nsub1 / waves), ph[5] / waves / (nsub1 / waves), ph[6] / waves / (nsub1 / waves), nsub1 / waves);
         }
 #endif
         const int err = (int)(uint32_t)host[1];
+        if (err != 0 && getenv("CS_DUMP_STATUS")) {  // development aid: where did the prefix chain stop?
+          std::vector<cstile::u64> st((size_t)nsub1), ex((size_t)nsub1);
+          CS_HIP(hipMemcpy(st.data(), sa.status, sizeof(cstile::u64) * nsub1, hipMemcpyDeviceToHost));
+          CS_HIP(hipMemcpy(ex.data(), sa.excl, sizeof(cstile::u64) * nsub1, hipMemcpyDeviceToHost));
+          unsigned long long tk[8];
+          CS_HIP(hipMemcpy(tk, sa.tickets, sizeof(tk), hipMemcpyDeviceToHost));
+          fprintf(stderr, "status dump: err %d nsub %lld grid %u ticket0 %llu\n", err, (long long)nsub1, grid, tk[0]);
+          for (int64_t t = 0; t < nsub1 && t < 64; ++t)
+            fprintf(stderr, "  tile %lld: agg flag %u val %llu | excl flag %u val %llu\n", (long long)t, (unsigned)(st[t] >> 62), (unsigned long long)(st[t] & cstile::kValMask),
+                    (unsigned)(ex[t] >> 62), (unsigned long long)(ex[t] & cstile::kValMask));
+        }
         if (err == 0 || sa.debug) {
           o->offsets = out_off;
           o->chars = out_chars;
@@ -1680,6 +1891,11 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
         int err = stream_attempt(roomy_first);
         if (err == 2 && !roomy_first) err = stream_attempt(true);  // only ran out of room: once more, roomier
         if (err == 0) return;
+        if (err > 0) {  // (counted: cs_fallback_count)
+          char what[64];
+          snprintf(what, sizeof(what), "replace_re (error word %d)", err);
+          note_fallback(what);
+        }
       } else if (lds <= 150 * 1024 && growth == 0 && (tc.R == 64 || tc.R == 0)) {  // (cap is the 64-row capacity then)
         TileArgs ta{};
         ta.in = view_of(col);
@@ -1721,6 +1937,7 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
           *out = holder.release();
           return;
         }
+        note_fallback("replace_re (tile kernel)");
       }
       // an oversize sub-tile or a look-back timeout: fall through to the two-pass kernels
     }

@@ -488,6 +488,7 @@ struct Emit2Args {
   int segs_per_run;
   const ColOut2* cols;
   unsigned long long* prof;  // instrumented builds: 6 cycle counters
+  int debug;  // CS_SPLIT_DEBUG bit mask: 1 no offset stores, 2 no chars stores, 4 no assembly, 8 no column loop (measurement only)
 };
 __device__ __forceinline__ void lds_or(uint32_t* p, uint32_t v) {
   __hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
@@ -593,7 +594,7 @@ __global__ void __launch_bounds__(256, CS_EMIT2_WAVES) k_split_emit2(Emit2Args a
     const bool last_tile = r0 + nrows == in.rows;
     unsigned long long my_vmask = 0;
     int cursor = 0;
-    for (int k = 0; k < a.ncols; ++k) {
+    for (int k = 0; k < ((a.debug & 8) ? 0 : a.ncols); ++k) {
       uint8_t* region = region0 + (k & 1) * a.cap_col;
       const int dk = dpos[k * 64 + lane];
       const bool has = k < ntok;
@@ -613,7 +614,7 @@ __global__ void __launch_bounds__(256, CS_EMIT2_WAVES) k_split_emit2(Emit2Args a
       cstile::gptr<off_t> coff = cstile::as_global(reinterpret_cast<off_t*>(cstile::rl64((long long)(uintptr_t)my_off, k)));
       const int clead = rl(my_lead, k);
       const int csum = rl(incl, 63);  // bytes this sub-tile adds to column k
-      if (lane < nrows) coff[r0 + lane] = (off_t)(cbase + pre);
+      if (lane < nrows && !(a.debug & 1)) coff[r0 + lane] = (off_t)(cbase + pre);
       if (last_tile && lane == nrows - 1) coff[in.rows] = (off_t)(cbase + incl);
       const unsigned long long vmask = __ballot(has);
       if (lane == k) {
@@ -621,7 +622,7 @@ __global__ void __launch_bounds__(256, CS_EMIT2_WAVES) k_split_emit2(Emit2Args a
         my_pos += csum;
       }
       CS_PHASE_MARK(2);
-      if (csum == 0) continue;  // no row of this sub-tile reaches column k (or all its tokens are empty): offsets only
+      if (csum == 0 || (a.debug & 4)) continue;  // no row of this sub-tile reaches column k (or all its tokens are empty): offsets only
       // zero the region (16-byte chunks covering lead + bytes + 8 of slack for the last token's third dword)
       const int zend = clead + csum + 20;
       for (int i = lane * 16; i < zend; i += 64 * 16) *reinterpret_cast<uint4*>(region + i) = make_uint4(0, 0, 0, 0);
@@ -667,7 +668,7 @@ __global__ void __launch_bounds__(256, CS_EMIT2_WAVES) k_split_emit2(Emit2Args a
       cstile::wave_lds_fence();
       CS_PHASE_MARK(3);
       uint8_t* dst = reinterpret_cast<uint8_t*>(cstile::rl64((long long)(uintptr_t)my_chars, k)) + cbase;
-      cstile::wave_flush(dst, csum, region, clead, lane);
+      if (!(a.debug & 2)) cstile::wave_flush(dst, csum, region, clead, lane);
       CS_PHASE_MARK(4);
     }
     if (lane < a.ncols) *cstile::as_global(reinterpret_cast<unsigned long long*>(my_valid + tile * 8)) = my_vmask;
@@ -758,7 +759,8 @@ bool split_fast(const cs_column* col, const unsigned char* delim, int dlen, int 
       }
       Buf d_outs = dev_alloc(sizeof(ColOut2) * ncols, s);
       CS_HIP(hipMemcpyAsync(d_outs->p, outs.data(), sizeof(ColOut2) * ncols, hipMemcpyHostToDevice, s));
-      Emit2Args e2{view_of(col), dpat, d64, dlen, tokens, cap_in, cap_col, ncols, nsub, per, segs_per_run, ptr<const ColOut2>(d_outs), nullptr};
+      Emit2Args e2{view_of(col), dpat, d64, dlen, tokens, cap_in, cap_col, ncols, nsub, per, segs_per_run, ptr<const ColOut2>(d_outs), nullptr,
+                   getenv("CS_SPLIT_DEBUG") ? atoi(getenv("CS_SPLIT_DEBUG")) : 0};
 #if defined(CS_PHASE_PROF)
       Buf profbuf = dev_alloc(64, s);
       CS_HIP(hipMemsetAsync(profbuf->p, 0, 64, s));

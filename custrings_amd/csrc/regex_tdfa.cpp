@@ -478,6 +478,70 @@ std::vector<int32_t> build_tdfa(const Program& prog, const std::vector<int32_t>&
     mark(img[7], (size_t)nstates * 128);
     mark(img[8], (size_t)nstates * natoms);
   }
+  // Unit decomposition for the replace kernels (regex_tdfa.h header word 31).  A KILLER byte sends every state to
+  // an idle state or stops the automaton, starting nothing: whatever the scan did before it, it continues
+  // behind it exactly as a fresh scan would.  A row then falls into independent UNITS -- maximal runs of
+  // non-killer bytes that hold a candidate byte -- which any lane may scan on its own.  The device finds the
+  // runs from two per-byte bitmaps, "candidate" (the two header ranges, a superset) and "equals x", so the
+  // decomposition is offered when every non-killer byte is inside the candidate ranges or is the one byte x;
+  // when no match exists without an x, runs that hold none are not scanned at all (for the dotted-quad
+  // pattern: x = '.', and a run of digits alone, a status code say, costs nothing).
+  {
+    const uint32_t nskip = (uint32_t)img[16];
+    const uint32_t* T1 = (const uint32_t*)(img.data() + img[7]);
+    const uint32_t* T2 = (const uint32_t*)(img.data() + img[8]);
+    const int lo1 = img[29] & 255, hi1 = (img[29] >> 8) & 255, lo2 = img[30] & 255, hi2 = (img[30] >> 8) & 255;
+    auto in_ranges = [&](int c) { return (c >= lo1 && c <= hi1) || (c >= lo2 && c <= hi2); };
+    int32_t word = 0;
+    if (nskip > 0 && maxslots <= 4 && B.min_match_chars() >= 1) {
+      int extras = 0, x = 0;
+      for (int c = 1; c < 128; ++c) {
+        bool killer = true;
+        for (int st = 0; st < nstates && killer; ++st) {
+          const uint32_t e = T1[(size_t)st * 128 + c];
+          killer = !(e & cstd::E_COMPLEX) && cstd::e_keep(e) == 15u && ((e & cstd::E_STOP) || (e & cstd::E_STATE) < nskip);
+        }
+        if (!killer && !in_ranges(c)) {
+          ++extras;
+          x = c;
+        }
+      }
+      if (extras <= 1) {
+        bool required = false;
+        if (extras == 1) {
+          // is a match reachable from the start states without ever consuming x?
+          std::vector<char> seen((size_t)nstates, 0);
+          std::vector<int> todo;
+          for (int c = 0; c < 8; ++c) {
+            const int st = (int)init[cstd::MODE_RESTART * 8 + c];
+            if (!seen[(size_t)st]) {
+              seen[(size_t)st] = 1;
+              todo.push_back(st);
+            }
+          }
+          bool match = false;
+          while (!todo.empty() && !match) {
+            const int st = todo.back();
+            todo.pop_back();
+            if (T2[(size_t)st * natoms + cstd::ATOM_EOT] & cstd::E_MATCH) match = true;
+            for (int c = 1; c < 128 && !match; ++c) {
+              if (c == x) continue;
+              const uint32_t e = T1[(size_t)st * 128 + c];
+              if (e & cstd::E_MATCH) match = true;
+              const int nx = (int)(e & cstd::E_STATE);
+              if (!(e & cstd::E_STOP) && nx < nstates && !seen[(size_t)nx]) {
+                seen[(size_t)nx] = 1;
+                todo.push_back(nx);
+              }
+            }
+          }
+          required = !match;
+        }
+        word = 1 | (x << 8) | (required ? 1 << 16 : 0);
+      }
+    }
+    img[31] = word;
+  }
   img[15] = (int32_t)img.size();
   if (groups_out && ngroups > 0) {
     // group-tag image: [0] groups [1] nstates [2] natoms [3] words per table, [4..35] the atom of each ASCII byte

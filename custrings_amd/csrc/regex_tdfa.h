@@ -26,6 +26,7 @@
 //   [25..28] word-character bitmap of the ASCII bytes (category bit 0)
 //   [29] [30] two byte ranges (lo | hi << 8) that cover every candidate ASCII byte
 //        (a superset is fine: extra candidates just take the table path)
+//   [31] unit decomposition (regex_tdfa.cpp): bit 0 offered, bits 8..14 the byte x (0 = none), bit 16 = no match without an x
 //   INIT   : 3 modes x 8 categories state ids
 //   T1     : nstates x 128 entries (ASCII byte -> transition; byte 0 = embedded NUL)
 //   T2     : nstates x natoms entries (atom 0 = end of row, 1 = embedded NUL,
@@ -67,6 +68,54 @@ CS_HD uint32_t e_keep(uint32_t e) { return ((e >> 16) & 15u) ^ 15u; }
 CS_HD uint32_t e_keep_field(uint32_t keep) { return ((keep ^ 15u) & 15u) << 16; }
 constexpr uint32_t E_ACTION = E_MATCH | E_COMPLEX | (15u << 16);  // any bit set / keep != 15 handled below
 
+// 128-bit masks for the unit decomposition (rows of up to 96 bytes; bit 96 may hold a carry)
+struct U128 {
+  unsigned long long lo, hi;
+};
+CS_HD U128 u128(unsigned long long lo, unsigned long long hi) {
+  U128 r;
+  r.lo = lo;
+  r.hi = hi;
+  return r;
+}
+CS_HD U128 u128_add(U128 a, U128 b) {
+  U128 r;
+  r.lo = a.lo + b.lo;
+  r.hi = a.hi + b.hi + (r.lo < a.lo ? 1ull : 0ull);
+  return r;
+}
+CS_HD U128 u128_sub(U128 a, U128 b) {
+  U128 r;
+  r.lo = a.lo - b.lo;
+  r.hi = a.hi - b.hi - (a.lo < b.lo ? 1ull : 0ull);
+  return r;
+}
+CS_HD U128 u128_shl1(U128 a) { return u128(a.lo << 1, (a.hi << 1) | (a.lo >> 63)); }
+CS_HD U128 u128_andn(U128 a, U128 b) { return u128(a.lo & ~b.lo, a.hi & ~b.hi); }  // a & ~b
+CS_HD U128 u128_and(U128 a, U128 b) { return u128(a.lo & b.lo, a.hi & b.hi); }
+CS_HD U128 u128_or(U128 a, U128 b) { return u128(a.lo | b.lo, a.hi | b.hi); }
+CS_HD bool u128_any(U128 a) { return (a.lo | a.hi) != 0; }
+CS_HD int u128_popc(U128 a) { return __builtin_popcountll(a.lo) + __builtin_popcountll(a.hi); }
+CS_HD int u128_ctz(U128 a) { return a.lo ? __builtin_ctzll(a.lo) : 64 + __builtin_ctzll(a.hi); }  // a != 0
+CS_HD int u128_msb(U128 a) { return a.hi ? 127 - __builtin_clzll(a.hi) : (a.lo ? 63 - __builtin_clzll(a.lo) : -1); }
+CS_HD U128 u128_clear_lowest(U128 a) { return a.lo ? u128(a.lo & (a.lo - 1), a.hi) : u128(0, a.hi & (a.hi - 1)); }
+CS_HD U128 u128_below(int q) {  // bits 0 .. q-1, q in 0..128
+  if (q >= 128) return u128(~0ull, ~0ull);
+  if (q >= 64) return u128(~0ull, q == 64 ? 0ull : ~(~0ull << (q - 64)));
+  return u128(q == 0 ? 0ull : ~(~0ull << q), 0ull);
+}
+// Units of a row (see regex_tdfa.cpp): C = candidate bits, X = "byte equals x" bits, both row-relative and cut at
+// the row length.  Returns one bit per unit, at the position just behind the unit's last byte; N receives C | X.
+// (Adding a subset M of N to N carries out of exactly those runs of N that hold a bit of M, into the zero above them.)
+CS_HD U128 unit_ends(U128 C, U128 X, bool required, U128& N) {
+  N = u128_or(C, X);
+  U128 w = u128_andn(u128_add(N, C), N);
+  if (required) w = u128_and(w, u128_andn(u128_add(N, X), N));
+  return w;
+}
+// first byte of the run of N that ends just below bit q
+CS_HD int unit_start(U128 N, int q) { return u128_msb(u128_andn(u128_below(q), N)) + 1; }
+
 struct View {
   const int32_t* img;
   const uint32_t* init;
@@ -81,6 +130,7 @@ struct View {
   // scalars, not arrays: an array member would force the whole view into memory
   uint32_t r1lo, r1hi, r2lo, r2hi;  // SWAR constants of the two candidate ranges
   uint32_t skippack, cand0, cand1, cand2, cand3, word0, word1, word2, word3;
+  uint32_t units;  // header word 31
 };
 CS_HD View make_view(const int32_t* img) {
   View v;
@@ -109,6 +159,7 @@ CS_HD View make_view(const int32_t* img) {
   v.word1 = (uint32_t)img[26];
   v.word2 = (uint32_t)img[27];
   v.word3 = (uint32_t)img[28];
+  v.units = (uint32_t)img[31];
   {
     const uint32_t lo1 = (uint32_t)img[29] & 255u, hi1 = ((uint32_t)img[29] >> 8) & 255u;
     const uint32_t lo2 = (uint32_t)img[30] & 255u, hi2 = ((uint32_t)img[30] >> 8) & 255u;
@@ -942,6 +993,43 @@ CS_HD void row_replace_matches(cstd::Tdfa& vm, int maxrepl, Emit&& emit) {
   // host builds (tests/rowemu) route qualifying rows through the lean scan so that it is
   // checked against the oracle with the same fuzz corpus; matches are buffered because
   // a bail-out must leave no trace
+  // the unit decomposition of the replace kernels (regex_tdfa.cpp): every unit scanned on its own, in order
+  if (maxrepl < 0 && (vm.D.units & 1u) && vm.lean_ok()) {
+    int buf[3 * 64];
+    int cnt = 0;
+    bool bail = false, overflow = false;
+    uint32_t c0, c1, c2;
+    if (vm.has_range2()) vm.build_masks_lean<true>(c0, c1, c2);
+    else vm.build_masks_lean<false>(c0, c1, c2);
+    const unsigned x = (vm.D.units >> 8) & 127u;
+    const cstd::U128 C = cstd::u128(c0 | ((unsigned long long)c1 << 32), c2);
+    cstd::U128 X = cstd::u128(0, 0), N;
+    for (int i = 0; x && i < vm.n; ++i)
+      if (vm.s[i] == x) {
+        if (i < 64) X.lo |= 1ull << i;
+        else X.hi |= 1ull << (i - 64);
+      }
+    cstd::U128 W = cstd::unit_ends(C, X, ((vm.D.units >> 16) & 1u) != 0, N);
+    while (cstd::u128_any(W) && !bail && !overflow) {
+      const int q = cstd::u128_ctz(W);
+      W = cstd::u128_clear_lowest(W);
+      const cstd::U128 cm = cstd::u128_and(C, cstd::u128_andn(cstd::u128_below(q), cstd::u128_below(cstd::unit_start(N, q))));
+      vm.scan_lean_dispatch(-1, (uint32_t)cm.lo, (uint32_t)(cm.lo >> 32), (uint32_t)cm.hi, [&](int mb, int me, int reps) {
+        if (cnt < 64) {
+          buf[3 * cnt] = mb;
+          buf[3 * cnt + 1] = me;
+          buf[3 * cnt + 2] = reps;
+          ++cnt;
+        } else {
+          overflow = true;
+        }
+      }, bail);
+    }
+    if (!bail && !overflow) {
+      for (int i = 0; i < cnt; ++i) emit(buf[3 * i], buf[3 * i + 1], buf[3 * i + 2]);
+      return;
+    }
+  }
   if (vm.lean_ok()) {
     int buf[3 * 64];
     int cnt = 0;

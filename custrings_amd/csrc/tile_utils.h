@@ -344,6 +344,80 @@ __device__ __forceinline__ long long lookback_end(u64* status, long long tile, l
 }
 
 
+// ---- prefix resolution by a dedicated wave ---------------------------------------------------
+// The look-back above costs a tile several DEPENDENT device-scope round trips (it walks back window by
+// window until it meets an inclusive prefix: 4.3 windows per tile on the replace kernel).  Here ONE
+// wave of the persistent grid does nothing but turn the published aggregates into exclusive prefixes,
+// in tile order, several windows of 64 tiles per round trip; a tile then needs a single load of its own
+// prefix.  `status[t]` = flag | aggregate (any non-zero flag counts as published), `excl[t]` = kFlagInc |
+// sum of the aggregates of tiles 0 .. t-1; both zeroed before the launch.  Returns false on a timeout
+// (the caller raises the error word; tiles waiting for their prefix watch that word and give up).
+constexpr int kScanBatch = 16;  // windows in flight (1024 tiles per round trip: the replace kernel takes ~200 tiles per microsecond)
+// `buf`: wave-private LDS, kScanBatch x 512 bytes.  `status` must be readable for kScanBatch windows past its last
+// tile (whatever lies there is ignored).  The loop that consumes the windows is kept ROLLED (the fetched words
+// pass through `buf`) and the fetch is sixteen loads off one address: this wave runs code nobody else on its CU
+// runs, and a body of several KB was evicted from the instruction cache between trips (measured: one window per
+// trip, 15 ms instead of 8).
+__device__ __forceinline__ bool prefix_scanner(const u64* status, u64* excl, long long ntiles, int lane, u64* buf) {
+  __builtin_amdgcn_s_setprio(3);  // every tile of the launch waits for this wave: it goes first on its SIMD
+  gptr<u64> ex = as_global(excl);
+  long long base = 0;
+  long long w = 0;  // next window
+  int idle = 0;
+  while (w * 64 < ntiles) {
+    // one round trip fetches the next kScanBatch windows; the leading ones that are complete are consumed, the
+    // rest is fetched again together with what follows (at the frontier of the publishing waves this keeps
+    // pace with them instead of paying a round trip per window)
+    gptr<const u64> at = as_global(status) + (w * 64 + lane);
+    u64 v[kScanBatch];
+#pragma unroll
+    for (int j = 0; j < kScanBatch; ++j) v[j] = __hip_atomic_load(at + j * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int j = 0; j < kScanBatch; ++j) buf[j * 64 + lane] = v[j];
+    int done = 0;
+#pragma unroll 1
+    for (int j = 0; j < kScanBatch; ++j) {
+      const long long idx = (w + j) * 64 + lane;
+      if ((w + j) * 64 >= ntiles) break;
+      const u64 x = buf[j * 64 + lane];
+      const bool in = idx < ntiles;
+      // A tile's prefix needs its predecessors only: the leading published tiles of an incomplete window get
+      // theirs at once (and the first unpublished one too).  Waiting for whole windows deadlocks small grids, where
+      // one wave holds several tiles of the same window and finishes a tile only after the scan of its next.
+      const u64 missing = __ballot(in && (x >> 62) == 0);
+      const int ready = missing ? __builtin_ctzll(missing) : 64;  // lanes below are published
+      const int val = in && lane < ready ? (int)(unsigned)(x & 0xffffffffull) : 0;  // aggregates of 64-row sub-tiles fit 31 bits
+      const int inc = csdev::wave_inclusive_scan(val);
+      if (in && lane <= ready) __hip_atomic_store(ex + idx, kFlagInc | ((u64)(base + inc - val) & kValMask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (missing) break;  // (the window is visited again; what was stored is stored again, unchanged)
+      base += __builtin_amdgcn_readlane(inc, 63);
+      ++done;
+    }
+    w += done;
+    if (done == 0) {  // (an incomplete first window may still have made progress: the limit is far beyond any honest wait)
+      if (++idle > kSpinLimit) return false;
+      __builtin_amdgcn_s_sleep(1);
+    } else {
+      idle = 0;
+    }
+  }
+  return true;
+}
+// a tile's side: `first` is an early load of excl[tile]; polls until the prefix is there.  -1 = timeout / launch failed.
+__device__ __forceinline__ long long prefix_wait(const u64* excl, long long tile, u64 first, const unsigned* error, int lane) {
+  u64 v = first;
+  int spins = 0;
+  while ((v >> 62) == 0) {
+    ++spins;
+    if (spins > kSpinLimit) return -1;
+    if ((spins & 255) == 0 && __hip_atomic_load(error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return -1;
+    __builtin_amdgcn_s_sleep(2);
+    v = status_load(excl + tile);
+  }
+  return (long long)(v & kValMask);
+}
+
+
 
 // ---- per-byte bitmaps shared between piece lanes and row lanes -------------------------------
 // While a tile's 16-byte pieces are still in the lanes' prefetch registers, each lane can

@@ -423,10 +423,18 @@ class RowEmu(CpuLib):
         self._f("replace_with_backrefs", vp, [vp, vp, C.c_char_p])
         self._f("set_engine", None, [C.c_int])
         self._f("regex_tdfa_info", None, [vp, C.POINTER(C.c_int)])
+        self._f("regex_units", C.c_int, [vp])
 
     def set_engine(self, e):
         """0 = list simulator (Pike VM) only, 1 = tagged DFA when the program converts"""
         self._set_engine(e)
+
+    def units(self, pattern):
+        """(offered, x byte or None, x required) -- the unit decomposition of the replace kernels (regex_tdfa.cpp)"""
+        re = self.compile(pattern)
+        w = self._regex_units(re)
+        self._regex_free(re)
+        return bool(w & 1), (chr((w >> 8) & 127) if (w >> 8) & 127 else None), bool((w >> 16) & 1)
 
     def tdfa_info(self, re):
         out = (C.c_int * 6)()

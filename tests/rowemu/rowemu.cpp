@@ -227,6 +227,8 @@ void emu_regex_tdfa_info(const emu_regex* re, int* out) {
   out[3] = re->tdfa[13];
   out[4] = (int)re->tdfa.size();
 }
+// header word 31 of the tagged DFA: the unit decomposition offered to the replace kernels (0: none / not convertible)
+int emu_regex_units(const emu_regex* re) { return re->tdfa.empty() ? 0 : re->tdfa[31]; }
 // adopt a program blob produced elsewhere (e.g. by the real reference compiler)
 emu_regex* emu_regex_from_blob(const int32_t* words, int n) {
   emu_regex* re = new emu_regex;

@@ -210,3 +210,33 @@ def test_gpu_tokenize_multi(gpu_engine, oracle_engine):
     for delims in ([" "], [",", "."], ["--", " ", "é"], ["the", "a"], [None, "", ";"], ["ab", "a"]):
         assert g.tokenize_multi(s, delims) == o.tokenize_multi(s, delims), delims
     assert g.tokenize_multi(s, []) == o.tokenize(s, None)
+
+
+UNIT_PATS = [r"\d+\.\d+\.\d+\.\d+", r"\d+", r"[a-c]+@[a-c]+", r"a+b", r"\w+ \w+", r"\b\d{1,3}\.\d{1,3}\.\d{1,3}\.\d{1,3}\b", r"\d+$", r"[^x]+"]
+
+
+@pytest.mark.parametrize("pat", UNIT_PATS)
+def test_gpu_replace_re_unit_scan_edges(gpu_engine, oracle_engine, pat):
+    """k_tdfa_replace_stream<.., UNITS> (the scan per unit instead of per row, regex_tdfa.cpp header word 31) against the
+    oracle on columns built for its edges: sub-tiles with no unit at all, with up to 64 units (one round), 65..128
+    (two rounds) and more than the queue holds (the rows are then scanned whole), rows with more matches than the
+    register records keep, units at both ends of a row, null and empty rows in between, a non-ASCII row that sends
+    its sub-tile to the generic scan, and growing / shrinking / empty replacements."""
+    rnd = random.Random(len(pat))
+    ip = lambda: ".".join(str(rnd.randrange(256)) for _ in range(4))
+    word = lambda: "".join(rnd.choice("abcx@ ") for _ in range(rnd.randrange(1, 7)))
+    blocks = []
+    blocks.append([word() + "x" for _ in range(64)])                                   # few or no units
+    blocks.append([("%s %s" % (word(), ip())) if i % 2 else word() for i in range(64)])  # about 32 units
+    blocks.append(["%s %s x" % (ip(), ip()) for _ in range(45)] + [None, ""] * 9 + ["q"])  # 65..128 units: two rounds
+    blocks.append([" ".join(str(rnd.randrange(10)) for _ in range(30)) for _ in range(64)])  # 30 units per row: beyond the queue
+    blocks.append(["1.2.3.4 5.6.7.8 9.9.9.9 1.1.1.1 2.2.2.2 3.3.3.3 a@b c@c ab aab" for _ in range(20)] + [ip() for _ in range(44)])  # > 4 matches per row
+    blocks.append([ip()] * 30 + ["é " + ip()] + [ip()] * 33)                             # one non-ASCII row
+    blocks.append([ip() + " ", " " + ip(), ip(), "." + ip() + ".", ip() + "." + ip()] * 12 + ["12", "1.2", "", None])
+    s = [r for b in blocks for r in b] + fuzzdata.log_rows(31, 700)
+    from custrings_amd import _lib
+
+    before = _lib.lib.cs_fallback_count()
+    for repl in ("<IP>", "", "<a-much-longer-one>"):
+        assert gpu_engine.replace_re(s, pat, repl, -1) == oracle_engine.replace_re(s, pat, repl, -1), (pat, repl)
+    assert _lib.lib.cs_fallback_count() == before  # the single-pass kernel itself produced these results

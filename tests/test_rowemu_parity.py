@@ -95,6 +95,48 @@ def test_tdfa_vs_oracle_on_generated_patterns(emu_engine, oracle_engine):
     assert converted > 100
 
 
+UNIT_PATTERNS = {  # pattern -> (x byte, required) the builder must find (regex_tdfa.cpp, header word 31)
+    r"\d+\.\d+\.\d+\.\d+": (".", True), r"\d+": (None, False), r"\d+\.\d+": (".", True), r"\d+(\.\d+)?": (".", False),
+    r"[0-9]+-[0-9]+": ("-", True), r"\b\d{1,3}\.\d{1,3}\.\d{1,3}\.\d{1,3}\b": (".", True), r"[a-c]+": (None, False),
+    r"[a-c]+@[a-c]+": ("@", True), r"a+b": ("b", True), r"\d+$": (None, False), r"\w+ \w+": (" ", True), r"[^x]+": (None, False),
+    r"\s+": (None, False), r"[a-z]+\.com": (".", True),
+}
+NO_UNITS = [r"a.*b", r"x\d*", r"\d*", r"\d+\.\d+:\d+", r"GET|POST"]
+
+
+def test_unit_decomposition_is_offered_where_expected(emu_engine):
+    for pat, want in UNIT_PATTERNS.items():
+        assert emu_engine.e.units(pat) == (True,) + want, pat
+    for pat in NO_UNITS:
+        assert not emu_engine.e.units(pat)[0], pat
+
+
+def test_unit_decomposition_vs_oracle(emu_engine, oracle_engine):
+    """replace_re with no limit takes the unit route on ASCII rows (regex_tdfa.h: row_replace_matches, host build):
+    every unit scanned on its own must give the whole-row scan's matches -- listed patterns and generated ones."""
+    import random
+
+    rnd = random.Random(7)
+    emu_engine.e.set_engine(1)
+    s = fuzzdata.log_rows(17, 400) + fuzzdata.rows(23, 300, max_len=90, alphabet=list("abc@-  ..0199x\n_")) + \
+        ["1.2.3.4", "1.2.3.4.5.6.7.8", "1.2.3.4 5.6.7.8", ".1.2.3.4.", "1..2.3.4", "999.999.999.999x1.1.1.1", "1.2.3.", "12", "", None]
+    atoms = ["\\d", "[a-c]", "\\.", "-", "@", "x", "[0-9a-c]", "\\b", "$", "^", "(\\.\\d)", "_"]
+    quants = ["", "", "+", "+", "*", "?", "{1,3}", "{2}"]
+    pats = list(UNIT_PATTERNS)
+    for _ in range(200):
+        pats.append("".join(rnd.choice(atoms) + rnd.choice(quants) for _ in range(rnd.randint(1, 5))))
+    offered = 0
+    for pat in pats:
+        try:
+            want = oracle_engine.replace_re(s, pat, "<IP>", -1)
+        except Exception:
+            continue
+        offered += emu_engine.e.units(pat)[0]
+        assert emu_engine.replace_re(s, pat, "<IP>", -1) == want, pat
+        assert emu_engine.replace_re(s, pat, "", -1) == oracle_engine.replace_re(s, pat, "", -1), pat
+    assert offered > 60, offered
+
+
 GROUP_PATTERNS = [r"(\w+) (\w+)", r"(a|ab)(c|bcd)", r"(a|b)*c", r"((a)|(b))+", r"(\d+)\.(\d+)\.(\d+)\.(\d+)", r"(a*)(b*)", r"(a+?)(a*)",
                   r"(?:x)(y)?z", r"^(\w)(\w*)$", r"(é+)|(a)", r"(\bin\b)|(\ba\b)", r"((\w)\w*) ", r"(a)|(b)|(c)", r"(x?)(y?)(z?)",
                   r"(.)(.)", r"([^ ]+) ([^ ]+) ", r"(GET|POST) (/\S*)", r"(b)?a", r"((a|b)(c|x))+", r"no_groups", r"()a"]
