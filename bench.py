@@ -72,6 +72,10 @@ def main():
     ap.add_argument("--cpu-rows", type=int, default=3_000_000, help="rows of the same workload timed on the CPU oracle")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--pmc-traffic", type=float, default=None, help="HBM bytes/launch of the dominant kernel from a separate rocprofv3 --pmc run")
+    ap.add_argument("--config", default="c3", choices=["c3", "c4", "c5"],
+                    help="c3 = the headline (default); c4 = distributed NVCategory build (key-set all-gather inside the timed region); "
+                         "c5 = tokenize + n-grams(2) with the shard-boundary exchange inside the timed region")
+    ap.add_argument("--keys", type=int, default=1_000_000, help="c4: distinct tokens K")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -90,6 +94,13 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    if args.config != "c3":
+        run_other_config(args, rank, world, barrier)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     # ---- this rank's shard: rows [rank*rows, (rank+1)*rows) of the C3 column
     out = C.c_void_p()
@@ -223,6 +234,74 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def run_other_config(args, rank, world, barrier):
+    """The two BASELINE.json configs with an exchange step, one process per GPU, the collective inside the timed
+    region: c4 = NVCategory build of a 16-character token column (1B rows over 8 GPUs = 125M per GPU, Zipf over K
+    distinct tokens): local build, RCCL all-gather of the sorted key sets, merge, remap (custrings_amd/dist.py);
+    c5 = tokenize + n-grams(2) of tweet-like rows (500M over 8 GPUs = 62.5M per GPU) with the first-tokens exchange
+    across the shard boundaries.  Rank 0 prints ONE JSON line (no CPU baseline: that belongs to the headline)."""
+    from custrings_amd import _lib, nvstrings, nvtext
+    from custrings_amd import dist as csd
+
+    L = _lib.lib
+    c4 = args.config == "c4"
+    rows = args.rows if args.rows != 100_000_000 else (125_000_000 if c4 else 62_500_000)
+    out = C.c_void_p()
+    _lib.check(L.cs_synth_column(4 if c4 else 5, rank * rows, rows, SEED, args.keys if c4 else 0, None, C.byref(out)))
+    col = nvstrings.nvstrings(out.value)
+    in_bytes = int(L.cs_column_nbytes(col.m_cptr))
+    ops = csd.GpuOps()
+    info = {}
+
+    def step():
+        if c4:
+            keys, values = csd.global_category(col, ops=ops)
+            info["keys"] = keys.size()
+            info["exchange"] = dict(csd.last_category_exchange)
+        else:
+            toks = nvtext.tokenize(col)
+            grams = csd.sharded_ngrams(toks, 2, "_", ops=ops)
+            info["tokens"], info["ngrams"] = toks.size(), grams.size()
+
+    for _ in range(max(args.warmup, 1)):
+        step()
+    fallbacks0 = int(L.cs_fallback_count())
+    L.cs_prof_reset()
+    L.cs_prof_enable(1)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    L.cs_prof_enable(0)
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    tot = torch.tensor([float(in_bytes), float(rows)], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+    elapsed = float(t.item())
+    if rank != 0:
+        return
+    per = elapsed / args.steps
+    result = {
+        "metric": ("Mstrings/s, NVCategory key build incl. the all-gather of the key sets (C4)" if c4 else
+                   "GB/s input chars, tokenize + ngrams(2) incl. the shard-boundary exchange (C5)"),
+        "value": round((float(tot[1].item()) / per / 1e6) if c4 else (float(tot[0].item()) / per / 1e9), 2),
+        "unit": "Mstrings/s" if c4 else "GB/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(per * 1e3, 3), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "config": {"workload": ("C4: %d rows x 16-char tokens per GPU, Zipf(1.1) over K = %d, category build + key-set all-gather + merge + remap" % (rows, args.keys))
+                   if c4 else ("C5: %d tweet-like rows per GPU, tokenize() + ngrams(2, '_') with the first-token exchange" % rows),
+                   "rows_per_gpu": rows, "seed": SEED, "sharding": "row ranges; " + ("RCCL all-gather of the key sets" if c4 else "all-gather of each rank's first 2 tokens")},
+        "gb_per_s_input": round(float(tot[0].item()) / per / 1e9, 2),
+        "mstrings_per_s": round(float(tot[1].item()) / per / 1e6, 1),
+        "fallbacks_in_timed_region": int(L.cs_fallback_count()) - fallbacks0,
+        "rank0": info,
+    }
+    print(json.dumps(result), flush=True)
 
 
 def _pandas_chunk(args):

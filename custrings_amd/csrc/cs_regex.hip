@@ -851,7 +851,7 @@ __device__ __forceinline__ uint32_t unit_xbits16(const uint4& q, uint32_t xpat) 
     const uint32_t t = w ^ xpat;
     return ~(((t & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | t) & 0x80808080u;
   };
-  return cstile::gather_bit7(eq(q.x)) | (cstile::gather_bit7(eq(q.y)) << 4) | (cstile::gather_bit7(eq(q.z)) << 8) | (cstile::gather_bit7(eq(q.w)) << 12);
+  return cstile::gather16_bit7(eq(q.x), eq(q.y), eq(q.z), eq(q.w));
 }
 
 // UNITS (with !INPLACE, RESCAN, !LONG): the scan runs per UNIT instead of per row (regex_tdfa.cpp, header word 31).
@@ -1002,11 +1002,11 @@ __global__ void __launch_bounds__(256, CS_STREAM_WAVES) k_tdfa_replace_stream(St
         odd |= q.w | ((q.w - 0x01010101u) & ~q.w);
         uint32_t bits;
         if (has_r2)
-          bits = cstile::gather_bit7(cstd::Tdfa::cand_bits_ascii<true>(D, q.x)) | (cstile::gather_bit7(cstd::Tdfa::cand_bits_ascii<true>(D, q.y)) << 4) |
-                 (cstile::gather_bit7(cstd::Tdfa::cand_bits_ascii<true>(D, q.z)) << 8) | (cstile::gather_bit7(cstd::Tdfa::cand_bits_ascii<true>(D, q.w)) << 12);
+          bits = cstile::gather16_bit7(cstd::Tdfa::cand_bits_ascii<true>(D, q.x), cstd::Tdfa::cand_bits_ascii<true>(D, q.y), cstd::Tdfa::cand_bits_ascii<true>(D, q.z),
+                                       cstd::Tdfa::cand_bits_ascii<true>(D, q.w));
         else
-          bits = cstile::gather_bit7(cstd::Tdfa::cand_bits_ascii<false>(D, q.x)) | (cstile::gather_bit7(cstd::Tdfa::cand_bits_ascii<false>(D, q.y)) << 4) |
-                 (cstile::gather_bit7(cstd::Tdfa::cand_bits_ascii<false>(D, q.z)) << 8) | (cstile::gather_bit7(cstd::Tdfa::cand_bits_ascii<false>(D, q.w)) << 12);
+          bits = cstile::gather16_bit7(cstd::Tdfa::cand_bits_ascii<false>(D, q.x), cstd::Tdfa::cand_bits_ascii<false>(D, q.y), cstd::Tdfa::cand_bits_ascii<false>(D, q.z),
+                                       cstd::Tdfa::cand_bits_ascii<false>(D, q.w));
         if (!bad) cstile::put_bits16(bitmap, j * 1024 + lane * 16, bits);
         if (UNITS && unit_x != 0 && !bad) cstile::put_bits16(xbitmap, j * 1024 + lane * 16, unit_xbits16(q, unit_xpat));
       }
@@ -1111,6 +1111,9 @@ __global__ void __launch_bounds__(256, CS_STREAM_WAVES) k_tdfa_replace_stream(St
             }
             cstile::wave_lds_fence();
             CS_PHASE_MARK(8);
+            // the previous tile's prefix: the poll issued before the scan came too early more often than not (the
+            // scanner wave needs every earlier aggregate first); this one has the extraction below to arrive in
+            if (scanner && p_tile >= 0 && !(a.debug & (8 | 64)) && (p_first >> 62) == 0) p_first = cstile::status_load(a.excl + p_tile);
             // -- row lanes again: the row's matches from the start / last-byte bits
             uint32_t s0, s1, s2, e0, e1, e2;
             cstile::row_bits96(bitmap, lead + rbeg, n, s0, s1, s2);
@@ -1339,11 +1342,11 @@ __global__ void __launch_bounds__(256) k_tdfa_scan_stream(ScanStreamArgs a) {
         odd |= q.w | ((q.w - 0x01010101u) & ~q.w);
         uint32_t bits;
         if (has_r2)
-          bits = cstile::gather_bit7(cstd::Tdfa::cand_bits_ascii<true>(D, q.x)) | (cstile::gather_bit7(cstd::Tdfa::cand_bits_ascii<true>(D, q.y)) << 4) |
-                 (cstile::gather_bit7(cstd::Tdfa::cand_bits_ascii<true>(D, q.z)) << 8) | (cstile::gather_bit7(cstd::Tdfa::cand_bits_ascii<true>(D, q.w)) << 12);
+          bits = cstile::gather16_bit7(cstd::Tdfa::cand_bits_ascii<true>(D, q.x), cstd::Tdfa::cand_bits_ascii<true>(D, q.y), cstd::Tdfa::cand_bits_ascii<true>(D, q.z),
+                                       cstd::Tdfa::cand_bits_ascii<true>(D, q.w));
         else
-          bits = cstile::gather_bit7(cstd::Tdfa::cand_bits_ascii<false>(D, q.x)) | (cstile::gather_bit7(cstd::Tdfa::cand_bits_ascii<false>(D, q.y)) << 4) |
-                 (cstile::gather_bit7(cstd::Tdfa::cand_bits_ascii<false>(D, q.z)) << 8) | (cstile::gather_bit7(cstd::Tdfa::cand_bits_ascii<false>(D, q.w)) << 12);
+          bits = cstile::gather16_bit7(cstd::Tdfa::cand_bits_ascii<false>(D, q.x), cstd::Tdfa::cand_bits_ascii<false>(D, q.y), cstd::Tdfa::cand_bits_ascii<false>(D, q.z),
+                                       cstd::Tdfa::cand_bits_ascii<false>(D, q.w));
         cstile::put_bits16(bitmap, j * 1024 + lane * 16, bits);
         if (UNITS && unit_x != 0) cstile::put_bits16(xbitmap, j * 1024 + lane * 16, unit_xbits16(q, unit_xpat));
       }

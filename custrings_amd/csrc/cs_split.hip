@@ -146,19 +146,17 @@ struct TokensT {
       masked = true;
       const uint32_t* words = reinterpret_cast<const uint32_t*>(base) + (beg >> 2);
       uint32_t r[3] = {0, 0, 0};
-#pragma unroll
-      for (int i = 0; i < 24; ++i) {
-        uint32_t z;
+      auto flags = [&](int i) -> uint32_t {  // bit 7 of every byte lane that separates
         if (WS) {
           const uint32_t x = words[i];  // byte <= 0x20: bit 7 clear and the low seven bits below 0x21
-          z = ~(((x & 0x7F7F7F7Fu) + 0x5F5F5F5Fu) | x) & 0x80808080u;
-        } else {
-          const uint32_t x = words[i] ^ d;
-          z = ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u;
+          return ~(((x & 0x7F7F7F7Fu) + 0x5F5F5F5Fu) | x) & 0x80808080u;
         }
-        const uint32_t nib = ((((z >> 7) & 0x01010101u) * 0x01020408u) >> 24) & 15u;
-        r[i >> 3] |= nib << (4 * (i & 7));
-      }
+        const uint32_t x = words[i] ^ d;
+        return ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u;
+      };
+#pragma unroll
+      for (int i = 0; i < 24; i += 4)  // sixteen bytes -> sixteen bits (byte-wise dot products, tile_utils.h)
+        r[i >> 3] |= cstile::gather16_bit7(flags(i), flags(i + 1), flags(i + 2), flags(i + 3)) << (4 * (i & 7));
       const int hi = sa + n;  // keep bits sa .. hi - 1
       uint32_t in0 = 0xFFFFFFFFu << sa;
       in0 &= hi >= 32 ? 0xFFFFFFFFu : ~(0xFFFFFFFFu << (hi & 31));

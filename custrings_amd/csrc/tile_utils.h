@@ -152,41 +152,35 @@ __device__ __forceinline__ void wave_flush(uint8_t* dst, int total, const uint8_
   if (ok) a0[j] = lds[j];
 }
 
-// Per-thread copy inside LDS, dword-wide in the middle.  Both buffers are given
-// as (4-byte aligned base, byte index) so that no pointer is ever turned into an
-// integer (which would demote the LDS accesses to flat ones).  Neighbouring rows
-// may share boundary dwords, so only dwords lying entirely inside
-// [di, di + n) are written as dwords.
+// Per-thread copy inside LDS (ascending: a move down inside one buffer is safe).  gfx950 takes DS accesses at
+// any alignment, so the copy is 16 bytes per trip through two 8-byte accesses and a 8 / 4 / 2 / 1 tail, with no
+// alignment prologue.  Both buffers are given as (base, byte index); the pointers are never turned into integers
+// (which would demote the LDS accesses to flat ones).
+typedef unsigned long long lds_u64u __attribute__((aligned(1)));
+typedef uint32_t lds_u32u __attribute__((aligned(1)));
+typedef uint16_t lds_u16u __attribute__((aligned(1)));
 __device__ __forceinline__ void lds_copy(uint8_t* dbase, int di, const uint8_t* sbase, int si, int n) {
+  uint8_t* d = dbase + di;
+  const uint8_t* s = sbase + si;
   int i = 0;
-  while (i < n && ((di + i) & 3)) {
-    dbase[di + i] = sbase[si + i];
-    ++i;
+  for (; i + 16 <= n; i += 16) {
+    const unsigned long long a = *reinterpret_cast<const lds_u64u*>(s + i), b = *reinterpret_cast<const lds_u64u*>(s + i + 8);
+    *reinterpret_cast<lds_u64u*>(d + i) = a;
+    *reinterpret_cast<lds_u64u*>(d + i + 8) = b;
   }
-  if (i + 4 <= n) {
-    const unsigned sh = (unsigned)((si + i) & 3);
-    const uint32_t* sp = reinterpret_cast<const uint32_t*>(sbase) + ((si + i) >> 2);
-    uint32_t* dp = reinterpret_cast<uint32_t*>(dbase) + ((di + i) >> 2);
-    uint32_t lo = *sp++;
-    // four dwords per trip: the loads are issued together, so a row pays the LDS latency
-    // once per 16 bytes instead of once per dword (alignbyte with shift 0 returns `lo`)
-    for (; i + 16 <= n; i += 16) {
-      const uint32_t a = sp[0], b = sp[1], c = sp[2], d = sp[3];
-      sp += 4;
-      dp[0] = __builtin_amdgcn_alignbyte(a, lo, sh);
-      dp[1] = __builtin_amdgcn_alignbyte(b, a, sh);
-      dp[2] = __builtin_amdgcn_alignbyte(c, b, sh);
-      dp[3] = __builtin_amdgcn_alignbyte(d, c, sh);
-      dp += 4;
-      lo = d;
-    }
-    for (; i + 4 <= n; i += 4) {
-      const uint32_t hi = *sp++;
-      *dp++ = __builtin_amdgcn_alignbyte(hi, lo, sh);
-      lo = hi;
-    }
+  if (n & 8) {
+    *reinterpret_cast<lds_u64u*>(d + i) = *reinterpret_cast<const lds_u64u*>(s + i);
+    i += 8;
   }
-  for (; i < n; ++i) dbase[di + i] = sbase[si + i];
+  if (n & 4) {
+    *reinterpret_cast<lds_u32u*>(d + i) = *reinterpret_cast<const lds_u32u*>(s + i);
+    i += 4;
+  }
+  if (n & 2) {
+    *reinterpret_cast<lds_u16u*>(d + i) = *reinterpret_cast<const lds_u16u*>(s + i);
+    i += 2;
+  }
+  if (n & 1) d[i] = s[i];
 }
 
 // Copy of a SHORT run (tokens, replacement text): the first 8 bytes go through two
@@ -426,6 +420,14 @@ __device__ __forceinline__ long long prefix_wait(const u64* excl, long long tile
 // instead of re-reading and re-classifying 24 words of LDS itself.
 // gathers bit 7 of the four byte lanes of `c` (which must have no other bits set) into bits 0..3
 __device__ __forceinline__ uint32_t gather_bit7(uint32_t c) { return (((c >> 7) * 0x01020408u) >> 24) & 15u; }
+// the same for the four words of a 16-byte piece at once: bit 4j + i of the result = bit 7 of byte i of word j.
+// One byte-wise dot product per word (0x80 x weight, summed: a full-rate instruction, where the multiply above
+// is quarter rate), two words per accumulator.
+__device__ __forceinline__ uint32_t gather16_bit7(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3) {
+  const uint32_t lo = __builtin_amdgcn_udot4(c1, 0x80402010u, __builtin_amdgcn_udot4(c0, 0x08040201u, 0u, false), false);  // 128 x bits 0..7
+  const uint32_t hi = __builtin_amdgcn_udot4(c3, 0x80402010u, __builtin_amdgcn_udot4(c2, 0x08040201u, 0u, false), false);  // 128 x bits 8..15
+  return (lo >> 7) | (hi << 1);
+}
 __device__ __forceinline__ void put_bits16(uint32_t* bitmap, int byte_index, uint32_t bits16) {
   reinterpret_cast<uint16_t*>(bitmap)[byte_index >> 4] = (uint16_t)bits16;
 }

@@ -4,7 +4,9 @@
 Every hot-path op except the category key set is row-local: a rank runs it on
 its own row range and results stay sharded -- no collective on the data path.
 `split` needs one 4-byte all-reduce(max) so that every shard emits the same
-number of columns.  The category build is the one real exchange step
+number of columns.  `ngrams` runs over the token column of ALL rows (ngram.cu:32-110), so an
+n-gram may begin in one shard and end in the next: every rank receives the first n-1 tokens of
+the ranks behind it (`sharded_ngrams`, a few hundred bytes).  The category build is the one real exchange step
 (SURVEY.md section 8e): each rank dictionary-encodes its shard, the ranks
 all-gather their (small) sorted key sets, every rank merges them into the
 global key set -- the semantics of NVCategory::create_from_categories
@@ -82,6 +84,41 @@ class GpuOps:
             self._lib.check(self._lib.lib.cs_category_get_values(cat.m_cptr, codes.data_ptr(), 1, None))
         return cat.keys(), codes
 
+    # ---- token columns (sharded_ngrams) ----
+    def drop_empty(self, col):
+        """the rows create_ngrams keeps (ngram.cu:47-58): not null and not empty; `col` itself when nothing is dropped"""
+        L = self._lib
+        rows = col.size()
+        if rows == 0:
+            return col
+        lens = torch.empty(rows, dtype=torch.int32, device="cuda")
+        total = C.c_int64()
+        L.check(L.lib.cs_len(col.m_cptr, lens.data_ptr(), 1, None, C.byref(total)))  # (characters; -1 for null rows)
+        mask = lens > 0
+        if bool(mask.all()):
+            return col
+        out = C.c_void_p()
+        m8 = mask.to(torch.uint8).contiguous()
+        L.check(L.lib.cs_gather_mask(col.m_cptr, m8.data_ptr(), 1, None, C.byref(out)))
+        return self._nvs.nvstrings(out.value)
+
+    def head(self, col, k):
+        return col.sublist(0, min(k, col.size()))
+
+    def concat(self, cols):
+        cols = [c for c in cols if c.size()]
+        if len(cols) == 1:
+            return cols[0]
+        arr = (C.c_void_p * max(len(cols), 1))(*[c.m_cptr for c in cols])
+        out = C.c_void_p()
+        self._lib.check(self._lib.lib.cs_column_concat(arr, len(cols), None, C.byref(out)))
+        return self._nvs.nvstrings(out.value)
+
+    def ngrams(self, col, n, sep):
+        from . import nvtext
+
+        return nvtext.ngrams(col, n, sep)
+
     def remap(self, cat, table):
         """values of `cat` mapped through `table` (i32 device tensor) -> i32 device tensor"""
         n = cat.size()
@@ -93,19 +130,32 @@ class GpuOps:
         return out
 
 
-def _all_gather_ragged(t, group):
-    """all-gather of 1-D tensors of different lengths (padded to the max; two collectives)."""
+def _all_gather_ragged(tensors, group, scalars=()):
+    """All-gather of several 1-D tensors whose lengths differ between ranks, plus a few integers per rank.  One
+    collective carries every length and the integers (ONE host read for all of them), then one padded all-gather
+    per tensor (RCCL's all-gather wants equal counts; the padding is max - own, small for key sets of similar
+    shards).  Returns (per tensor the list of the ranks' parts, per rank the list of its integers)."""
     world = dist.get_world_size(group)
-    n = torch.tensor([t.numel()], dtype=torch.int64, device=t.device)
-    sizes = [torch.zeros_like(n) for _ in range(world)]
-    dist.all_gather(sizes, n, group=group)
-    sizes = [int(s.item()) for s in sizes]
-    m = max(max(sizes), 1)
-    pad = torch.zeros(m, dtype=t.dtype, device=t.device)
-    pad[: t.numel()] = t
-    parts = [torch.empty_like(pad) for _ in range(world)]
-    dist.all_gather(parts, pad, group=group)
-    return [p[:s] for p, s in zip(parts, sizes)]
+    dev = tensors[0].device
+    nt = len(tensors)
+    mine = torch.tensor([t.numel() for t in tensors] + [int(v) for v in scalars], dtype=torch.int64, device=dev)
+    table = torch.empty(world * mine.numel(), dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(table, mine, group=group)
+    table = table.view(world, mine.numel()).tolist()  # the one device-to-host read
+    out = []
+    for j, t in enumerate(tensors):
+        m = max(max(row[j] for row in table), 1)
+        pad = torch.zeros(m, dtype=t.dtype, device=dev)
+        pad[: t.numel()] = t
+        parts = torch.empty(world * m, dtype=t.dtype, device=dev)
+        dist.all_gather_into_tensor(parts, pad, group=group)
+        out.append([parts[r * m : r * m + table[r][j]] for r in range(world)])
+    return out, [row[nt:] for row in table]
+
+
+# Reported when the distributed category build stops paying (SURVEY.md section 8e: with K close to N every rank
+# ends up holding, and merging, almost the whole column): the exchanged key bytes against the shard's own bytes.
+last_category_exchange = {}
 
 
 def global_category(local_col, ops=None, group=None):
@@ -117,12 +167,18 @@ def global_category(local_col, ops=None, group=None):
     if world == 1:
         return cat.keys(), ops.remap(cat, torch.arange(cat.keys_size(), dtype=torch.int32, device=chars.device))
     rank = dist.get_rank(group)
-    flag = torch.tensor([1 if has_null else 0], dtype=torch.int64, device=chars.device)
-    all_chars = _all_gather_ragged(chars, group)
-    all_offs = _all_gather_ragged(offs, group)
-    flags = [torch.zeros_like(flag) for _ in range(world)]
-    dist.all_gather(flags, flag, group=group)
-    key_cols = [ops.column(c, o, bool(f.item())) for c, o, f in zip(all_chars, all_offs, flags)]
+    (all_chars, all_offs), flags = _all_gather_ragged([chars, offs], group, scalars=[1 if has_null else 0])
+    key_cols = [ops.column(c, o, bool(f[0])) for c, o, f in zip(all_chars, all_offs, flags)]
+    gathered = sum(int(c.numel()) + 8 * int(o.numel()) for c, o in zip(all_chars, all_offs))
+    local_rows = cat.size()
+    last_category_exchange.update(key_bytes_gathered=gathered, local_keys=cat.keys_size(), local_rows=local_rows,
+                                  keys_per_row=cat.keys_size() / max(local_rows, 1))
+    if local_rows and cat.keys_size() > local_rows // 2:
+        import warnings
+
+        warnings.warn("global_category: %d distinct keys in %d local rows -- the key-set all-gather (%d bytes per rank) is as "
+                      "large as the data; a hash-partitioned exchange of the rows would move less (SURVEY.md section 8e)"
+                      % (cat.keys_size(), local_rows, gathered))
     merged_keys, codes = ops.concat_category(key_cols)
     start = sum(k.size() for k in key_cols[:rank])
     table = codes[start : start + key_cols[rank].size()].contiguous()
@@ -136,3 +192,49 @@ def agree_on_columns(ncols, device="cuda", group=None):
     t = torch.tensor([ncols], dtype=torch.int32, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
     return int(t.item())
+
+
+def sharded_ngrams(local_tokens, n=2, sep="_", ops=None, group=None):
+    """NVText::create_ngrams (ngram.cu:32-110) over the token columns of all ranks taken in rank order: rank r
+    returns the n-grams that BEGIN in its shard, so the ranks' results in rank order are the single-GPU result
+    on the whole token column.  An n-gram that begins in the last n-1 tokens of a shard ends in the shards behind
+    it: the ranks all-gather their first n kept tokens (a few hundred bytes) and each appends what follows its
+    own.  `local_tokens`: this rank's tokens (e.g. tokenize() of its row range); n >= 2 (n = 1 is a row-local copy:
+    call nvtext.ngrams on the shard)."""
+    ops = ops or GpuOps()
+    n = 2 if n == 0 else int(n)
+    if n < 2:
+        raise ValueError("sharded_ngrams: n must be at least 2")
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return ops.ngrams(local_tokens, n, sep)
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    mine = ops.drop_empty(local_tokens)  # the rows create_ngrams keeps (ngram.cu:47-58)
+    chars, offs, _ = ops.export(ops.head(mine, n))
+    (all_chars, all_offs), counts = _all_gather_ragged([chars, offs], group, scalars=[mine.size()])
+    counts = [c[0] for c in counts]
+    heads = [ops.column(c, o, False) for c, o in zip(all_chars, all_offs)]
+    return _ngrams_of_shard(ops, rank, world, local_tokens, mine, heads, counts, n, sep)
+
+
+def _ngrams_of_shard(ops, rank, world, local_tokens, mine, heads, counts, n, sep):
+    """what rank `rank` returns once every rank's first n kept tokens (`heads`) and kept-token count are known"""
+    total = sum(counts)
+    if total <= n:
+        # the reference then returns ONE row, all tokens joined (ngram.cu:60-66); it lands on rank 0.  No shard
+        # holds more than n tokens here, so the gathered heads are the whole token column.  (No kept token at
+        # all: rank 0 answers for its own rows.)
+        if rank != 0:
+            return ops.head(mine, 0)
+        return ops.ngrams(ops.concat(heads), n, sep) if total else ops.ngrams(local_tokens, n, sep)
+    # tokens that follow this shard, n - 1 of them at most
+    tail, need = [], n - 1
+    for r in range(rank + 1, world):
+        take = min(need, counts[r])
+        if take:
+            tail.append(ops.head(heads[r], take))
+            need -= take
+    have = mine.size() + (n - 1 - need)
+    if mine.size() == 0 or have < n:
+        return ops.head(mine, 0)  # no n-gram begins here
+    # (have == n: create_ngrams joins all n tokens into one row -- exactly the one n-gram that begins here)
+    return ops.ngrams(ops.concat([mine] + tail), n, sep)

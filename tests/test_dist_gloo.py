@@ -74,6 +74,23 @@ class OracleOps:
         v = torch.from_numpy(np.asarray(cat.values).copy()).long()
         return table[v].to(torch.int32)
 
+    # ---- token columns (sharded_ngrams) ----
+    def drop_empty(self, colw):
+        items = [b for b in colw.col.to_bytes_list() if b]
+        return _ColWrap(cpulibs.Col.from_list(items))
+
+    def head(self, colw, k):
+        return _ColWrap(cpulibs.Col.from_list(colw.col.to_bytes_list()[:k]))
+
+    def concat(self, cols):
+        items = []
+        for c in cols:
+            items.extend(c.col.to_bytes_list())
+        return _ColWrap(cpulibs.Col.from_list(items))
+
+    def ngrams(self, colw, n, sep):
+        return _ColWrap(self.o.ngrams(colw.col, n, sep))
+
 
 def _worker(rank, world, port, rows, K, q):
     sys.path.insert(0, HERE)
@@ -125,3 +142,99 @@ def test_shard_range_covers_rows():
             assert all(edges[i][1] == edges[i + 1][0] for i in range(world - 1))
             sizes = [b - a for a, b in edges]
             assert max(sizes) - min(sizes) <= 1
+
+
+# ---- n-grams across the shard boundary, split's column agreement on a real column, the K ~ N report ----
+def _worker2(rank, world, port, case, q):
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import warnings
+
+    from custrings_amd import dist as csd
+
+    ops = OracleOps()
+    out = {}
+    if case[0] == "ngrams":
+        _, rows, n, sep, cuts = case
+        lo, hi = cuts[rank], cuts[rank + 1]
+        local = cpulibs.Col.from_list(rows[lo:hi])
+        toks = ops.o.tokenize(local)
+        out["ngrams"] = csd.sharded_ngrams(_ColWrap(toks), n, sep, ops=ops).col.to_list()
+    elif case[0] == "split":
+        _, total_rows = case
+        lo, hi = csd.shard_range(total_rows, rank, world)
+        local = ops.o.synth(3, lo, hi - lo)
+        cols = ops.o.split(local, " ", -1)
+        ncols = csd.agree_on_columns(len(cols), device="cpu")
+        # a shard with fewer columns pads with all-null columns (what split emits for rows without such a token)
+        out["split"] = [c.to_list() for c in cols] + [[None] * (hi - lo)] * (ncols - len(cols))
+        out["range"] = (lo, hi)
+    elif case[0] == "dense_keys":
+        _, total_rows = case
+        lo, hi = csd.shard_range(total_rows, rank, world)
+        local = cpulibs.Col.from_list([("key%07d" % i).encode() for i in range(lo, hi)])  # every row its own key
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            keys, values = csd.global_category(_ColWrap(local), ops=ops)
+        out["warned"] = [str(x.message) for x in w]
+        out["report"] = dict(csd.last_category_exchange)
+        out["keys"] = keys.col.rows
+        out["values"] = values.tolist()
+        out["range"] = (lo, hi)
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run2(case, world=2):
+    port = 31500 + (os.getpid() % 2000)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker2, args=(r, world, port, case, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return [got[r] for r in range(world)]
+
+
+TWEETS = [b"the quick brown fox", b"jumped", None, b"", b"over the lazy dog and", b"a", b"b c", b"d e f g h", b"  ", b"tail end here"]
+
+
+@pytest.mark.parametrize("n,sep,cuts", [(2, "_", [0, 5, 10]), (3, "-", [0, 2, 10]), (2, "", [0, 0, 10]), (4, "_", [0, 9, 10]), (3, "_", [0, 3, 4]),
+                                        (5, "+", [0, 1, 2])])
+def test_sharded_ngrams_equal_the_unsharded_result(n, sep, cuts):
+    """ngram.cu:32-110 runs over the token column of all rows: the n-grams that begin in the last n-1 tokens of a
+    shard need the next shard's first tokens (custrings_amd/dist.py: sharded_ngrams).  Cases: an ordinary cut, a cut
+    that leaves one shard with fewer than n tokens, an empty shard, a last shard of one row, and totals at or below n
+    (the reference then returns one joined row)."""
+    rows = TWEETS[: cuts[-1]]
+    got = _run2(("ngrams", rows, n, sep, cuts))
+    o = cpulibs.Oracle()
+    want = o.ngrams(o.tokenize(cpulibs.Col.from_list(rows)), n, sep).to_list()
+    assert got[0]["ngrams"] + got[1]["ngrams"] == want
+
+
+def test_sharded_split_agrees_on_the_column_count():
+    rows = 3000
+    got = _run2(("split", rows))
+    o = cpulibs.Oracle()
+    want = [c.to_list() for c in o.split(o.synth(3, 0, rows), " ", -1)]
+    assert len(got[0]["split"]) == len(got[1]["split"]) == len(want)
+    for k in range(len(want)):
+        assert got[0]["split"][k] + got[1]["split"][k] == want[k]
+
+
+def test_global_category_reports_dense_key_sets():
+    """with K close to N the key-set all-gather moves as much as the data; the build still
+    gives the right answer and says so (a warning and dist.last_category_exchange)."""
+    rows = 600
+    got = _run2(("dense_keys", rows))
+    for r in got:
+        assert r["keys"] == rows and r["values"] == list(range(*r["range"]))
+        assert r["warned"] and "hash-partitioned" in r["warned"][0]
+        assert r["report"]["keys_per_row"] == 1.0 and r["report"]["key_bytes_gathered"] > 0

@@ -240,3 +240,30 @@ def test_gpu_replace_re_unit_scan_edges(gpu_engine, oracle_engine, pat):
     for repl in ("<IP>", "", "<a-much-longer-one>"):
         assert gpu_engine.replace_re(s, pat, repl, -1) == oracle_engine.replace_re(s, pat, repl, -1), (pat, repl)
     assert _lib.lib.cs_fallback_count() == before  # the single-pass kernel itself produced these results
+
+
+@pytest.mark.parametrize("n,sep", [(2, "_"), (3, ""), (5, "--")])
+def test_gpu_sharded_ngrams_pieces(gpu_engine, n, sep):
+    """custrings_amd/dist.py sharded_ngrams on the GPU ops (drop_empty / head / export / column / concat / ngrams): the
+    per-rank step run for three shards in one process -- the exchange itself is covered by the gloo tests -- gives,
+    shard after shard, nvtext.ngrams of the whole token column."""
+    from custrings_amd import dist as csd, nvstrings, nvtext
+
+    ops = csd.GpuOps()
+    rows = fuzzdata.rows(77, 400, max_len=40, alphabet=list("ab cd  e")) + ["x"]
+    whole = nvtext.tokenize(nvstrings.to_device(rows))
+    want = nvtext.ngrams(whole, n, sep).to_host()
+    for cuts in ([0, 150, 300, 401], [0, 1, 2, 401], [0, 0, 400, 401], [0, 399, 401, 401]):
+        shards = [nvtext.tokenize(nvstrings.to_device(rows[cuts[r]:cuts[r + 1]])) for r in range(3)]
+        # (a shard with a null / empty token row in it: create_ngrams drops those rows)
+        shards[1] = ops.concat([shards[1], nvstrings.to_device(["", None])]) if shards[1].size() else shards[1]
+        mine = [ops.drop_empty(t) for t in shards]
+        heads = []
+        for m in mine:
+            chars, offs, _ = ops.export(ops.head(m, n))
+            heads.append(ops.column(chars, offs, False))
+        counts = [m.size() for m in mine]
+        got = []
+        for r in range(3):
+            got += csd._ngrams_of_shard(ops, r, 3, shards[r], mine[r], heads, counts, n, sep).to_host()
+        assert got == want, cuts
