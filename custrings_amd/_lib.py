@@ -46,6 +46,10 @@ _PROTOS = {
     "cs_column_from_offsets32": (i32, [vp, i64, vp, vp, i32, vp, P(vp)]),
     "cs_column_from_offsets64": (i32, [vp, i64, vp, vp, i32, i32, vp, P(vp)]),
     "cs_column_concat": (i32, [P(vp), i32, vp, P(vp)]),
+    "cs_column_ipc_export": (i32, [vp, vp]),
+    "cs_column_ipc_import": (i32, [vp, P(vp)]),
+    "cs_category_ipc_export": (i32, [vp, vp]),
+    "cs_category_ipc_import": (i32, [vp, P(vp)]),
     "cs_column_slice": (i32, [vp, i64, i64, vp, P(vp)]),
     "cs_column_destroy": (i32, [vp]),
     "cs_column_rows": (i64, [vp]),

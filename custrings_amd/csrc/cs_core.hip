@@ -66,6 +66,10 @@ static void release_cache_locked() {
 }
 
 DevBuf::~DevBuf() {
+  if (ipc_mapped && p) {
+    (void)hipIpcCloseMemHandle(p);
+    return;
+  }
   if (!capacity || !p) return;
   if (g_multi_stream.load(std::memory_order_relaxed)) (void)hipDeviceSynchronize();  // (see g_streams)
   std::lock_guard<std::mutex> lk(g_mu);
@@ -964,6 +968,104 @@ int cs_column_slice(const cs_column* col, int64_t first, int64_t rows, cs_stream
     c->chars = dev_alloc((size_t)c->nbytes, s);
     if (c->nbytes)
       CS_HIP(hipMemcpyAsync(c->chars->p, col->d_chars() + host[0], (size_t)c->nbytes, hipMemcpyDeviceToDevice, s));
+    *out = c.release();
+  });
+}
+
+// ---- HIP IPC (NVStrings::create_ipc_transfer / create_from_ipc; ipc_transfer.h:31-107) ----
+namespace {
+void ipc_handle_of(const Buf& b, unsigned char* out) {
+  static_assert(sizeof(hipIpcMemHandle_t) == 64, "cs_ipc_column carries 64-byte handles");
+  hipIpcMemHandle_t h;
+  CS_HIP(hipIpcGetMemHandle(&h, b->p));
+  memcpy(out, &h, sizeof(h));
+}
+Buf ipc_open(const unsigned char* handle, size_t bytes) {
+  hipIpcMemHandle_t h;
+  memcpy(&h, handle, sizeof(h));
+  void* p = nullptr;
+  CS_HIP(hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess));
+  auto b = std::make_shared<DevBuf>();
+  b->p = p;
+  b->bytes = bytes;
+  b->capacity = 0;
+  b->ipc_mapped = true;
+  return b;
+}
+void export_column(const cs_column* col, cs_ipc_column* out) {
+  memset(out, 0, sizeof(*out));
+  for (const Buf& b : {col->chars, col->offsets, col->offsets32, col->validity})
+    if (b && b->p && b->capacity == 0) fail(CS_ERR_INVALID_ARG, "ipc export: the column wraps memory it does not own (zero-copy ingest): copy it first");
+  out->rows = col->rows;
+  out->nbytes = col->nbytes;
+  out->null_count = col->null_count;
+  out->device = bound_device();
+  if (col->chars && col->chars->p) ipc_handle_of(col->chars, out->chars);
+  else out->nbytes = 0;
+  if (col->offsets32) {
+    out->offset_width = 4;
+    ipc_handle_of(col->offsets32, out->offsets);
+  } else {
+    out->offset_width = 8;
+    (void)col->d_offsets();
+    ipc_handle_of(col->offsets, out->offsets);
+  }
+  if (col->validity && col->validity->p) {
+    out->has_validity = 1;
+    ipc_handle_of(col->validity, out->validity);
+  }
+}
+cs_column* import_column(const cs_ipc_column* ipc) {
+  if (ipc->rows < 0 || ipc->nbytes < 0 || (ipc->offset_width != 4 && ipc->offset_width != 8)) fail(CS_ERR_INVALID_ARG, "ipc import: malformed transfer record");
+  auto c = std::make_unique<cs_column>();
+  c->rows = ipc->rows;
+  c->nbytes = ipc->nbytes;
+  c->null_count = ipc->null_count;
+  if (ipc->nbytes > 0) c->chars = ipc_open(ipc->chars, (size_t)ipc->nbytes);
+  if (ipc->offset_width == 4) c->offsets32 = ipc_open(ipc->offsets, sizeof(int32_t) * (size_t)(ipc->rows + 1));
+  else c->offsets = ipc_open(ipc->offsets, sizeof(int64_t) * (size_t)(ipc->rows + 1));
+  if (ipc->has_validity) c->validity = ipc_open(ipc->validity, validity_bytes(ipc->rows));
+  return c.release();
+}
+}  // namespace
+
+int cs_column_ipc_export(const cs_column* col, cs_ipc_column* out) {
+  return guard([&] {
+    if (!col || !out) fail(CS_ERR_INVALID_ARG, "ipc export: null argument");
+    require_device();
+    CS_HIP(hipDeviceSynchronize());  // the importer must find finished buffers
+    export_column(col, out);
+  });
+}
+int cs_column_ipc_import(const cs_ipc_column* ipc, cs_column** out) {
+  return guard([&] {
+    if (!ipc || !out) fail(CS_ERR_INVALID_ARG, "ipc import: null argument");
+    require_device();
+    *out = import_column(ipc);
+  });
+}
+int cs_category_ipc_export(const cs_category* cat, cs_ipc_category* out) {
+  return guard([&] {
+    if (!cat || !out) fail(CS_ERR_INVALID_ARG, "ipc export: null argument");
+    require_device();
+    CS_HIP(hipDeviceSynchronize());
+    memset(out, 0, sizeof(*out));
+    export_column(cat->keys.get(), &out->keys);
+    out->rows = cat->rows;
+    if (cat->rows > 0) {
+      if (cat->values->capacity == 0) fail(CS_ERR_INVALID_ARG, "ipc export: the category's values are not owned memory");
+      ipc_handle_of(cat->values, out->values);
+    }
+  });
+}
+int cs_category_ipc_import(const cs_ipc_category* ipc, cs_category** out) {
+  return guard([&] {
+    if (!ipc || !out) fail(CS_ERR_INVALID_ARG, "ipc import: null argument");
+    require_device();
+    auto c = std::make_unique<cs_category>();
+    c->keys.reset(import_column(&ipc->keys));
+    c->rows = ipc->rows;
+    if (ipc->rows > 0) c->values = ipc_open(ipc->values, sizeof(int32_t) * (size_t)ipc->rows);
     *out = c.release();
   });
 }

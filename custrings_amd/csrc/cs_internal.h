@@ -62,6 +62,7 @@ struct DevBuf {
   size_t bytes = 0;     // usable bytes requested
   size_t capacity = 0;  // bytes actually held (0 for wrapped buffers)
   hipStream_t stream = nullptr;
+  bool ipc_mapped = false;  // opened with hipIpcOpenMemHandle: closed, not freed (cs_column_ipc_import)
   ~DevBuf();
 };
 using Buf = std::shared_ptr<DevBuf>;

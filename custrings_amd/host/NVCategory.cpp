@@ -6,6 +6,7 @@
 
 #include "custrings_amd.h"
 #include "nvstrings/NVStrings.h"
+#include "nvstrings/ipc_transfer.h"
 
 namespace {
 void check_range(int status) {  // the gather family throws std::out_of_range (NVCategory.cu:1067,1101,1161)
@@ -23,6 +24,16 @@ NVCategory* NVCategory::adopt(cs_category* cat) {
   return c;
 }
 cs_category* NVCategory::handle() const { return m_cat; }
+NVCategory* NVCategory::create_from_ipc(nvcategory_ipc_transfer& ipc) {  // NVCategory.cu:373
+  NVStrings::ensure_device();
+  cs_category* c = nullptr;
+  NVStrings::check(cs_category_ipc_import(&ipc.category, &c));
+  return adopt(c);
+}
+int NVCategory::create_ipc_transfer(nvcategory_ipc_transfer& ipc) {  // NVCategory.cu:715
+  NVStrings::check(cs_category_ipc_export(m_cat, &ipc.category));
+  return 0;
+}
 cs_category* NVCategory::release() {
   cs_category* c = m_cat;
   m_cat = nullptr;

@@ -2,6 +2,7 @@
 // over the C ABI of libcustrings_amd.so.  Host C++ only: every member is argument checking, one or two
 // C-ABI calls and the reference's exception / return-value conventions (cited per member).
 #include "nvstrings/NVStrings.h"
+#include "nvstrings/ipc_transfer.h"
 
 #include <cstdlib>
 #include <cstring>
@@ -100,6 +101,16 @@ NVStrings* NVStrings::create_from_strings(std::vector<NVStrings*> strs) {  // NV
   cs_column* c = nullptr;
   check(cs_column_concat(cols.data(), (int)cols.size(), nullptr, &c));
   return adopt(c);
+}
+NVStrings* NVStrings::create_from_ipc(nvstrings_ipc_transfer& ipc) {  // strings/NVStrings.cu:137
+  ensure_device();
+  cs_column* c = nullptr;
+  check(cs_column_ipc_import(&ipc.column, &c));
+  return adopt(c);
+}
+int NVStrings::create_ipc_transfer(nvstrings_ipc_transfer& ipc) {  // strings/NVStrings.cu:484
+  check(cs_column_ipc_export(m_col, &ipc.column));
+  return 0;
 }
 void NVStrings::destroy(NVStrings* inst) { delete inst; }
 

@@ -1,6 +1,8 @@
 // pyniNVStrings -- CPython glue of the nvstrings Python class (python/cpp/pystrings.cpp in the reference,
 // method table :3860-3973) for the members SURVEY.md section 8 names, over libNVStrings.so.
 #include "pyni_common.h"
+#include "nvstrings/ipc_transfer.h"
+#include <cstring>
 
 using namespace pyni;
 
@@ -59,6 +61,24 @@ static PyObject* n_createFromNVStrings(PyObject*, PyObject* args) {  // one inst
       return nullptr;
     }
   return make_instance([&] { return NVStrings::create_from_strings(all); });
+}
+static PyObject* n_getIPCData(PyObject*, PyObject* args) {  // pystrings.cpp: n_getIPCData -- here the transfer record as bytes
+  NVStrings* s = SELF(args);
+  nvstrings_ipc_transfer rec;
+  if (!guarded([&] { s->create_ipc_transfer(rec); })) return nullptr;
+  return PyBytes_FromStringAndSize(reinterpret_cast<const char*>(&rec), (Py_ssize_t)sizeof(rec));
+}
+static PyObject* n_createFromIPC(PyObject*, PyObject* args) {  // pystrings.cpp: n_createFromIPC
+  PyObject* o = arg(args, 0);
+  char* data = nullptr;
+  Py_ssize_t len = 0;
+  if (!PyBytes_Check(o) || PyBytes_AsStringAndSize(o, &data, &len) != 0 || len != (Py_ssize_t)sizeof(nvstrings_ipc_transfer)) {
+    PyErr_SetString(PyExc_ValueError, "nvstrings: the bytes of get_ipc_data() are required");
+    return nullptr;
+  }
+  nvstrings_ipc_transfer rec;
+  memcpy(&rec, data, sizeof(rec));
+  return make_instance([&] { return NVStrings::create_from_ipc(rec); });
 }
 static PyObject* n_size(PyObject*, PyObject* args) { return PyLong_FromLong((long)SELF(args)->size()); }
 static PyObject* n_len(PyObject*, PyObject* args) {
@@ -369,7 +389,7 @@ static PyObject* n_dropWrapper(PyObject*, PyObject* args) { return drop_wrapper<
 
 static PyMethodDef s_Methods[] = {
 #define M(n) {#n, n, METH_VARARGS, ""}
-    M(n_dropWrapper),
+    M(n_dropWrapper), M(n_getIPCData), M(n_createFromIPC),
     M(n_createFromHostStrings), M(n_destroyStrings), M(n_createHostStrings), M(n_createFromOffsets), M(n_createFromNVStrings), M(n_create_offsets),
     M(n_size), M(n_len), M(n_byte_count), M(n_null_count), M(n_set_null_bitmask), M(n_copy), M(n_split), M(n_rsplit), M(n_split_record),
     M(n_rsplit_record), M(n_partition), M(n_rpartition), M(n_replace), M(n_replace_multi), M(n_replace_with_backrefs), M(n_lstrip), M(n_strip),

@@ -57,6 +57,19 @@ def from_categories(cats):
     return nvcategory(out.value)
 
 
+IPC_CATEGORY_BYTES = (3 * 64 + 3 * 8 + 4 * 4) + 64 + 8  # sizeof(cs_ipc_category)
+
+
+def create_from_ipc(ipc_data):
+    """A category over the buffers another process exported with get_ipc_data() (NVCategory::create_from_ipc,
+    NVCategory.h:128; the reference exposes it in C++ only)."""
+    _lib.ensure_init()
+    rec = C.create_string_buffer(bytes(ipc_data), IPC_CATEGORY_BYTES)
+    out = C.c_void_p()
+    check(lib.cs_category_ipc_import(rec, C.byref(out)))
+    return nvcategory(out.value)
+
+
 def bind_cpointer(cptr, own=True):
     """nvcategory.py:157-163."""
     if not cptr:
@@ -88,6 +101,12 @@ class nvcategory:
     def __init__(self, cptr, own=True):
         self.m_cptr = cptr
         self._own = own
+
+    def get_ipc_data(self):
+        """The record for create_from_ipc in another process (NVCategory::create_ipc_transfer, NVCategory.h:176)."""
+        rec = C.create_string_buffer(IPC_CATEGORY_BYTES)
+        check(lib.cs_category_ipc_export(self.m_cptr, rec))
+        return rec.raw
 
     _cs_abi = True  # m_cptr is a cs_category* (the pyni glue wraps it on demand, see host/pyni_common.h)
     _nv_cptr = None

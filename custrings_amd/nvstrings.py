@@ -13,7 +13,7 @@ import numpy as np
 from . import _lib
 from ._lib import lib, check, b, addr
 
-__all__ = ["to_device", "from_strings", "from_offsets", "free", "bind_cpointer", "nvstrings"]
+__all__ = ["to_device", "from_strings", "from_offsets", "free", "bind_cpointer", "create_from_ipc", "nvstrings"]
 
 
 def to_device(strs):
@@ -74,6 +74,20 @@ def from_offsets64(chars, offsets, rows, validity=None, bdevmem=False, copy=True
     return r
 
 
+IPC_COLUMN_BYTES = 3 * 64 + 3 * 8 + 4 * 4  # sizeof(cs_ipc_column), include/custrings_amd.h
+
+
+def create_from_ipc(ipc_data):
+    """nvstrings.py:348-360 -- an instance over the buffers another process of this node exported with
+    get_ipc_data() (NVStrings::create_from_ipc, NVStrings.h:132): mapped through HIP IPC, no copy.  The
+    exporting instance must stay alive while this one is in use."""
+    _lib.ensure_init()
+    rec = C.create_string_buffer(bytes(ipc_data), IPC_COLUMN_BYTES)
+    out = C.c_void_p()
+    check(lib.cs_column_ipc_import(rec, C.byref(out)))
+    return nvstrings(out.value)
+
+
 def free(dstrs):
     """nvstrings.py:363-367."""
     if dstrs is not None:
@@ -125,6 +139,13 @@ class nvstrings:
 
     _cs_abi = True  # m_cptr is a cs_column* (the pyni glue wraps it on demand, see host/pyni_common.h)
     _nv_cptr = None
+
+    def get_ipc_data(self):
+        """nvstrings.py:447-462 -- the record another process hands to create_from_ipc (NVStrings::create_ipc_transfer,
+        NVStrings.h:214): the HIP IPC handles of this column's buffers, as bytes."""
+        rec = C.create_string_buffer(IPC_COLUMN_BYTES)
+        check(lib.cs_column_ipc_export(self.m_cptr, rec))
+        return rec.raw
 
     def _destroy(self):
         if self._nv_cptr:  # the C++ instance the glue wrapped around this handle

@@ -93,6 +93,23 @@ int cs_column_from_offsets32(const char* chars, int64_t rows, const int32_t* off
 int cs_column_from_offsets64(const uint8_t* chars, int64_t rows, const int64_t* offsets,
                              const uint8_t* validity, int on_device, int copy,
                              cs_stream stream, cs_column** out);
+/* NVStrings::create_ipc_transfer / create_from_ipc (NVStrings.h:132,214; cpp/include/ipc_transfer.h:31-107):
+ * a column handed to another process of the same node without a copy.  The exporter fills a plain
+ * struct with the HIP IPC handles of the column's buffers (chars, offsets, validity) and their sizes;
+ * the struct travels by any byte channel (pipe, socket, shared memory); the importer maps the buffers
+ * and gets a read-only column over them.  The exporter's column must stay alive until every importer
+ * has destroyed its handle.  (The reference ships an array of custring_view pointers plus the memory
+ * they point into, rebased by the importer; the native layout has no pointers to rebase.) */
+typedef struct cs_ipc_column {
+  unsigned char chars[64], offsets[64], validity[64]; /* hipIpcMemHandle_t each */
+  int64_t rows, nbytes, null_count;
+  int32_t offset_width; /* 4 or 8 */
+  int32_t has_validity;
+  int32_t device;       /* the exporter's device ordinal (the importer must be able to reach it) */
+  int32_t reserved;
+} cs_ipc_column;
+int cs_column_ipc_export(const cs_column* col, cs_ipc_column* out);
+int cs_column_ipc_import(const cs_ipc_column* ipc, cs_column** out);
 /* NVStrings::create_from_strings(std::vector<NVStrings*>) (NVStrings.h:125):
  * row-wise concatenation of `n` columns into a new column. */
 int cs_column_concat(const cs_column* const* cols, int n, cs_stream stream, cs_column** out);
@@ -316,6 +333,15 @@ int cs_category_build(const cs_column* col, cs_stream stream, cs_category** out)
 int cs_category_merge(const cs_category* const* cats, int ncats, cs_stream stream,
                       cs_category** out);
 int cs_category_destroy(cs_category* cat);
+/* NVCategory::create_ipc_transfer / create_from_ipc (NVCategory.h:128,176; ipc_transfer.h:109-200): the key column
+ * as above plus the handle of the int32 values. */
+typedef struct cs_ipc_category {
+  cs_ipc_column keys;
+  unsigned char values[64]; /* hipIpcMemHandle_t */
+  int64_t rows;
+} cs_ipc_category;
+int cs_category_ipc_export(const cs_category* cat, cs_ipc_category* out);
+int cs_category_ipc_import(const cs_ipc_category* ipc, cs_category** out);
 int64_t cs_category_size(const cs_category* cat);      /* NVCategory::size      */
 int64_t cs_category_keys_size(const cs_category* cat); /* NVCategory::keys_size */
 /* NVCategory::get_keys (new handle on the shared key column). */

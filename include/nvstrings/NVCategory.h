@@ -9,6 +9,7 @@
 #include <vector>
 
 struct cs_category;
+struct nvcategory_ipc_transfer; /* nvstrings/ipc_transfer.h */
 class NVStrings;
 
 class NVCategory {
@@ -27,6 +28,8 @@ class NVCategory {
   static NVCategory* create_from_strings(NVStrings& strs);
   static NVCategory* create_from_strings(std::vector<NVStrings*>& strs);
   static NVCategory* create_from_categories(std::vector<NVCategory*>& cats);
+  static NVCategory* create_from_ipc(nvcategory_ipc_transfer& ipc); /* NVCategory.h:128 */
+  int create_ipc_transfer(nvcategory_ipc_transfer& ipc);            /* NVCategory.h:176 */
   static void destroy(NVCategory* inst);
   /* NVCategory.h:148-249 */
   unsigned int size();

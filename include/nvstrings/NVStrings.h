@@ -19,6 +19,7 @@
 #include <vector>
 
 struct cs_column;
+struct nvstrings_ipc_transfer; /* nvstrings/ipc_transfer.h */
 
 class NVStrings {
   cs_column* m_col; /* (the reference holds an NVStringsImpl* here; one pointer either way) */
@@ -40,6 +41,7 @@ class NVStrings {
   static NVStrings* create_from_offsets(const char* strs, int count, const int* offsets, const unsigned char* nullbitmask = 0, int nulls = 0,
                                         bool devmem = true);
   static NVStrings* create_from_strings(std::vector<NVStrings*> strs);
+  static NVStrings* create_from_ipc(nvstrings_ipc_transfer& ipc); /* NVStrings.h:132: maps the exporter's buffers, no copy */
   static void destroy(NVStrings* inst);
 
   /* ---- attributes / export (NVStrings.h:162-354) ---- */
@@ -47,6 +49,7 @@ class NVStrings {
   unsigned int size() const;
   int create_index(std::pair<const char*, size_t>* strs, bool devmem = true);
   int create_offsets(char* strs, int* offsets, unsigned char* nullbitmask = 0, bool devmem = true);
+  int create_ipc_transfer(nvstrings_ipc_transfer& ipc); /* NVStrings.h:214 */
   unsigned int set_null_bitarray(unsigned char* bitarray, bool emptyIsNull = false, bool devmem = true);
   NVStrings* copy();
   int to_host(char** list, int start, int end);

@@ -267,3 +267,46 @@ def test_gpu_sharded_ngrams_pieces(gpu_engine, n, sep):
         for r in range(3):
             got += csd._ngrams_of_shard(ops, r, 3, shards[r], mine[r], heads, counts, n, sep).to_host()
         assert got == want, cuts
+
+
+def _ipc_child(col_rec, cat_rec, part_rec, q):
+    import os
+    import sys
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.dirname(here))
+    try:
+        from custrings_amd import nvcategory, nvstrings
+
+        s = nvstrings.create_from_ipc(col_rec)
+        c = nvcategory.create_from_ipc(cat_rec)
+        part = nvstrings.create_from_ipc(part_rec)  # (a split output column: int32 offsets)
+        q.put(("ok", s.to_host(), s.upper().to_host(), c.keys().to_host(), c.values(), part.to_host()))
+    except Exception as e:  # the parent reports it
+        q.put(("error", repr(e)))
+
+
+def test_gpu_ipc_transfer_between_processes(gpu_engine):
+    """NVStrings / NVCategory::create_ipc_transfer + create_from_ipc (NVStrings.h:132,214; ipc_transfer.h:31-200) on HIP
+    IPC handles: a second process maps the exporter's buffers, reads them and runs an op on them, no copy in between."""
+    import multiprocessing as mp
+
+    from custrings_amd import nvcategory, nvstrings
+
+    rows = fuzzdata.rows(5, 3000, max_len=30)
+    s = nvstrings.to_device(rows)
+    cat = nvcategory.from_strings(s)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    parts = s.split(" ")
+    p = ctx.Process(target=_ipc_child, args=(s.get_ipc_data(), cat.get_ipc_data(), parts[0].get_ipc_data(), q))
+    p.start()
+    got = q.get(timeout=180)
+    p.join(timeout=60)
+    assert got[0] == "ok", got
+    assert got[1] == rows
+    assert got[2] == s.upper().to_host()
+    assert got[3] == cat.keys().to_host() and list(got[4]) == list(cat.values())
+    assert got[5] == parts[0].to_host()
+    with pytest.raises(ValueError):  # a record that is not one
+        nvstrings.create_from_ipc(b"\0" * 231 + b"\7")
