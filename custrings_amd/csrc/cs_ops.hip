@@ -36,7 +36,7 @@ using namespace csrow;
 namespace cs {
 // cs_split.hip: tile kernels for a single-byte delimiter; false = not applicable
 bool split_fast(const cs_column* col, const unsigned char* delim, int dlen, int tokens, hipStream_t s,
-                std::vector<std::unique_ptr<cs_column>>& cols);
+                std::vector<std::unique_ptr<cs_column>>& cols, bool reverse = false);
 }
 
 namespace {
@@ -593,9 +593,12 @@ static int split_impl(const cs_column* col, const char* delimiter, int maxsplit,
     }
     bool ascii_delim = delimiter && nd.n >= 1 && nd.n <= 8;
     for (int i = 0; ascii_delim && i < nd.n; ++i) ascii_delim = (unsigned char)delimiter[i] < 128;
-    if (!a.reverse && (!delimiter || ascii_delim)) {
+    // rsplit with a limit on a one-byte ASCII delimiter rides the split tile kernels too (the first delimiters of a
+    // row are struck from its mask: cs_split.hip TokensT)
+    const bool reverse_fast = a.reverse && ascii_delim && nd.n == 1 && a.tokens > 0 && !getenv("CS_RSPLIT_ROWWISE");
+    if ((!a.reverse && (!delimiter || ascii_delim)) || reverse_fast) {
       std::vector<std::unique_ptr<cs_column>> fast;
-      if (split_fast(col, reinterpret_cast<const unsigned char*>(delimiter), delimiter ? nd.n : 0, a.tokens, s, fast)) {
+      if (split_fast(col, reinterpret_cast<const unsigned char*>(delimiter), delimiter ? nd.n : 0, a.tokens, s, fast, reverse_fast)) {
         cs_column** arr = (cs_column**)malloc(sizeof(cs_column*) * fast.size());
         if (!arr) fail(CS_ERR_ALLOC, "host allocation failed");
         for (size_t k = 0; k < fast.size(); ++k) arr[k] = fast[k].release();

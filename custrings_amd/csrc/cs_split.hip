@@ -37,7 +37,7 @@ using namespace csdev;
 
 namespace cs {
 bool split_fast(const cs_column* col, const unsigned char* delim, int dlen, int tokens, hipStream_t s,
-                std::vector<std::unique_ptr<cs_column>>& cols);
+                std::vector<std::unique_ptr<cs_column>>& cols, bool reverse = false);
 }
 
 namespace {
@@ -137,8 +137,11 @@ struct TokensT {
   uint32_t e_hi;
   int sa;
   int dlen;  // delimiter bytes (1 unless MULTI)
+  // `reverse` (one-byte delimiter, a split limit, masked rows): rsplit -- the LAST `limit` delimiters of the row are the
+  // ones that split (split.cu:1006-1021 finds them from the right), so the first ones are struck from the mask and
+  // the forward walk over what is left yields rsplit's tokens, left-aligned in the columns as the reference has them.
   __device__ __forceinline__ TokensT(const uint8_t* base, int beg, int n, bool live, uint32_t d, int tokens,
-                                     unsigned long long d64 = 0, int delim_len = 1)
+                                     unsigned long long d64 = 0, int delim_len = 1, bool reverse = false)
       : w(base, beg, n), dpat(d), cursor(0), k(0), limit(tokens > 0 ? tokens - 1 : -1), more(live), masked(false),
         m_lo(0), m_hi(0), e_lo(0), e_hi(0), sa(beg & 3), dlen(MULTI ? delim_len : 1) {
     // (MASKED_ONLY: the caller guarantees that every row fits the 96-bit mask)
@@ -175,6 +178,16 @@ struct TokensT {
       } else {
         m_lo = ((unsigned long long)(r[1] & in1) << 32) | (r[0] & in0);
         m_hi = r[2] & in2;
+        if (!MULTI && reverse && limit >= 0) {
+          int drop = __builtin_popcountll(m_lo) + __builtin_popcount(m_hi) - limit;  // delimiters that do not split
+          while (__any(drop > 0)) {
+            if (drop > 0) {
+              if (m_lo) m_lo &= m_lo - 1;
+              else m_hi &= m_hi - 1;
+              --drop;
+            }
+          }
+        }
         if (MULTI) {
           unsigned long long c_lo = m_lo, k_lo = 0;
           uint32_t c_hi = m_hi, k_hi = 0;
@@ -318,6 +331,7 @@ struct Measure2Args {
   int tokens, cap;
   long long nsub, per, seg, nseg;  // emit run length, segment length (sub-tiles), segments
   int segs_per_run;
+  int reverse;  // rsplit with a limit (TokensT)
   int32_t* colsum;  // [kMaxCols][nseg], zeroed by the host
   int* max_count;   // [0] most tokens in a row, [1] bound on the bytes one column receives from one sub-tile
                     // (sum over its rows of the row's longest token), [2] longest row, [3] a sub-tile needs the generic kernels
@@ -340,8 +354,8 @@ __global__ void __launch_bounds__(256) k_split_measure2(Measure2Args a) {
   bool generic = false;
   for (long long sub = t0; sub < t1; ++sub) {
     SubTile t = load_subtile(a.in, sub, lds_in, lane);
-    TokensT<false, WS, MULTI> tk(lds_in, t.lead + t.rbeg, t.n, t.live, a.dpat, a.tokens, a.d64, a.dlen);
-    if ((WS || MULTI) && !tk.masked) {  // (wave-uniform)
+    TokensT<false, WS, MULTI> tk(lds_in, t.lead + t.rbeg, t.n, t.live, a.dpat, a.tokens, a.d64, a.dlen, a.reverse != 0);
+    if ((WS || MULTI || a.reverse) && !tk.masked) {  // (wave-uniform)
       generic = true;
       break;
     }
@@ -486,6 +500,7 @@ struct Emit2Args {
   int segs_per_run;
   const ColOut2* cols;
   unsigned long long* prof;  // instrumented builds: 6 cycle counters
+  int reverse;  // rsplit with a limit (TokensT)
   int debug;  // CS_SPLIT_DEBUG bit mask: 1 no offset stores, 2 no chars stores, 4 no assembly, 8 no column loop (measurement only)
 };
 __device__ __forceinline__ void lds_or(uint32_t* p, uint32_t v) {
@@ -558,7 +573,7 @@ __global__ void __launch_bounds__(256, CS_EMIT2_WAVES) k_split_emit2(Emit2Args a
     cstile::wave_lds_fence();
     CS_PHASE_MARK(0);
 
-    TokensT<true, WS, MULTI> tk(lds_in, lead + rbeg, n, live, a.dpat, a.tokens, a.d64, a.dlen);
+    TokensT<true, WS, MULTI> tk(lds_in, lead + rbeg, n, live, a.dpat, a.tokens, a.d64, a.dlen, a.reverse != 0);
     // every row's delimiter positions go to LDS once, in a loop that does nothing else; the
     // column loop then needs one byte load per token instead of the bit-mask walk
     const int nd = __builtin_popcountll(tk.m_lo) + __builtin_popcount(tk.m_hi);
@@ -685,10 +700,12 @@ __global__ void __launch_bounds__(256, CS_EMIT2_WAVES) k_split_emit2(Emit2Args a
 namespace cs {
 
 // `delim`: 1..8 ASCII bytes, or nullptr for whitespace splitting.
+// `reverse`: rsplit with a limit on a one-byte delimiter (the masked kernels only; anything else returns false).
 bool split_fast(const cs_column* col, const unsigned char* delim, int dlen, int tokens, hipStream_t s,
-                std::vector<std::unique_ptr<cs_column>>& cols) {
+                std::vector<std::unique_ptr<cs_column>>& cols, bool reverse) {
   const bool ws = delim == nullptr;
   const int mode = ws ? 1 : (dlen > 1 ? 2 : 0);
+  if (reverse && (mode != 0 || tokens <= 0)) return false;
   unsigned long long d64 = 0;
   for (int i = 0; !ws && i < dlen; ++i) d64 |= (unsigned long long)delim[i] << (8 * i);
   const int64_t rows = col->rows;
@@ -718,7 +735,7 @@ bool split_fast(const cs_column* col, const unsigned char* delim, int dlen, int 
     Buf colsum = dev_alloc(sizeof(int32_t) * nseg * kMaxCols, s);
     CS_HIP(hipMemsetAsync(colsum->p, 0, sizeof(int32_t) * nseg * kMaxCols, s));
     CS_HIP(hipMemsetAsync(mx->p, 0, 4 * sizeof(int), s));
-    Measure2Args ma{view_of(col), dpat, d64, dlen, tokens, cap_in, nsub, per, seg, nseg, segs_per_run, ptr<int32_t>(colsum), ptr<int>(mx)};
+    Measure2Args ma{view_of(col), dpat, d64, dlen, tokens, cap_in, nsub, per, seg, nseg, segs_per_run, reverse ? 1 : 0, ptr<int32_t>(colsum), ptr<int>(mx)};
     {
       ProfScope ps("k_split_measure", s);
       const unsigned g = (unsigned)((nseg + 3) / 4);
@@ -758,7 +775,7 @@ bool split_fast(const cs_column* col, const unsigned char* delim, int dlen, int 
       Buf d_outs = dev_alloc(sizeof(ColOut2) * ncols, s);
       CS_HIP(hipMemcpyAsync(d_outs->p, outs.data(), sizeof(ColOut2) * ncols, hipMemcpyHostToDevice, s));
       Emit2Args e2{view_of(col), dpat, d64, dlen, tokens, cap_in, cap_col, ncols, nsub, per, segs_per_run, ptr<const ColOut2>(d_outs), nullptr,
-                   getenv("CS_SPLIT_DEBUG") ? atoi(getenv("CS_SPLIT_DEBUG")) : 0};
+                   reverse ? 1 : 0, getenv("CS_SPLIT_DEBUG") ? atoi(getenv("CS_SPLIT_DEBUG")) : 0};
 #if defined(CS_PHASE_PROF)
       Buf profbuf = dev_alloc(64, s);
       CS_HIP(hipMemsetAsync(profbuf->p, 0, 64, s));
@@ -787,8 +804,8 @@ bool split_fast(const cs_column* col, const unsigned char* delim, int dlen, int 
 #endif
       return true;
     }
-    if (mode != 0) return false;  // whitespace and multi-byte delimiters exist in the masked kernels only
-  } else if (mode != 0) {
+    if (mode != 0 || reverse) return false;  // whitespace, multi-byte delimiters and rsplit exist in the masked kernels only
+  } else if (mode != 0 || reverse) {
     return false;
   }
 

@@ -132,7 +132,7 @@ def run_c3(a, ov):
            timed(lambda: c3.rsplit(" ")))
     del rc
     rc = c3.rsplit(" ", 3)
-    report("C3", "rsplit(' ', 3) (row-wise, from the right)", rows, b, b + sum(nbytes(c) for c in rc) + (len(rc) + 1) * ov * rows,
+    report("C3", "rsplit(' ', 3) (the split kernels, the row's first delimiters struck from the mask)", rows, b, b + sum(nbytes(c) for c in rc) + (len(rc) + 1) * ov * rows,
            timed(lambda: c3.rsplit(" ", 3), reps=2))
     del rc
     cols = c3.split(" ")
