@@ -1362,8 +1362,35 @@ __global__ void __launch_bounds__(256) k_tdfa_scan_stream(ScanStreamArgs a) {
       const uint8_t* p = lds_in + lead + rbeg;
       cstd::Tdfa vm(D, P, p, n, (lead + rbeg) & 3);
       auto find = [&](auto&& f) { csvm::walk_matches(vm, f); };
-      auto group = [&](int mb, int g, int& x, int& y) {
-        return g == 0 ? vm.find(mb, mb + 1, x, y) > 0 : vm.group_find(mb, a.gtags, g, x, y) > 0;
+      // the groups of a match come four at a time from ONE anchored run (regex_tdfa.h: group_find_all) and are kept
+      // until the walk moves to the next match: a template with four references costs one run, not four
+      int c_mb = -1, c_batch = -1, c_ok = 0, c_end = 0;
+      int c_gb[cstd::Tdfa::kGroupBatch], c_ge[cstd::Tdfa::kGroupBatch];
+      const int tgroups = a.tmpl->groups;
+      auto group = [&](int mb, int g, int& x, int& y) -> bool {
+        if (n >= 255 || !a.gtags) return g == 0 ? vm.find(mb, mb + 1, x, y) > 0 : vm.group_find(mb, a.gtags, g, x, y) > 0;
+        const int batch = g == 0 ? (c_mb == mb ? c_batch : 0) : (g - 1) / cstd::Tdfa::kGroupBatch;
+        if (c_mb != mb || c_batch != batch) {
+          const int first = batch * cstd::Tdfa::kGroupBatch + 1;
+          int cnt = tgroups - first + 1;
+          cnt = cnt < 0 ? 0 : (cnt > cstd::Tdfa::kGroupBatch ? cstd::Tdfa::kGroupBatch : cnt);
+          c_ok = vm.group_find_all(mb, a.gtags, first, cnt, c_gb, c_ge, c_end);
+          c_mb = mb;
+          c_batch = batch;
+        }
+        if (g == 0) {
+          x = mb;
+          y = c_end;
+        } else {
+          const int k = (g - 1) % cstd::Tdfa::kGroupBatch;
+#pragma unroll
+          for (int i = 0; i < cstd::Tdfa::kGroupBatch; ++i)
+            if (i == k) {
+              x = c_gb[i];
+              y = c_ge[i];
+            }
+        }
+        return c_ok > 0;
       };
       if (MODE == 5) {
         int len = -1;
@@ -1395,13 +1422,29 @@ __global__ void __launch_bounds__(256) k_tdfa_scan_stream(ScanStreamArgs a) {
       if (live && f < 0) f = vm.find(0, n, mb, me);
       const bool hit = live && f > 0;
       v = hit;
-      if (lane < nrows)
-        for (int g = 0; g < a.ncols; ++g) {
-          int x = -1, y = -1;
-          const bool ok = hit && vm.group_find(mb, a.gtags, g + 1, x, y) && x >= 0 && y > x;
-          a.begins[(long long)g * in.rows + r0 + lane] = ok ? x : 0;
-          a.lens[(long long)g * in.rows + r0 + lane] = ok ? y - x : -1;
+      if (lane < nrows) {
+        if (n < 255) {  // every group of the match from one anchored run, four at a time (regex_tdfa.h: group_find_all)
+          for (int g0 = 0; g0 < a.ncols; g0 += cstd::Tdfa::kGroupBatch) {
+            int gb[cstd::Tdfa::kGroupBatch], ge[cstd::Tdfa::kGroupBatch], mend = 0;
+            const int cnt = min(cstd::Tdfa::kGroupBatch, a.ncols - g0);
+            const bool found = hit && vm.group_find_all(mb, a.gtags, g0 + 1, cnt, gb, ge, mend) > 0;
+#pragma unroll
+            for (int k = 0; k < cstd::Tdfa::kGroupBatch; ++k)
+              if (k < cnt) {
+                const bool ok = found && gb[k] >= 0 && ge[k] > gb[k];
+                a.begins[(long long)(g0 + k) * in.rows + r0 + lane] = ok ? gb[k] : 0;
+                a.lens[(long long)(g0 + k) * in.rows + r0 + lane] = ok ? ge[k] - gb[k] : -1;
+              }
+          }
+        } else {
+          for (int g = 0; g < a.ncols; ++g) {
+            int x = -1, y = -1;
+            const bool ok = hit && vm.group_find(mb, a.gtags, g + 1, x, y) && x >= 0 && y > x;
+            a.begins[(long long)g * in.rows + r0 + lane] = ok ? x : 0;
+            a.lens[(long long)g * in.rows + r0 + lane] = ok ? y - x : -1;
+          }
         }
+      }
     } else {
       cstd::Tdfa vm(D, P, lds_in + lead + rbeg, n, (lead + rbeg) & 3);
       const bool lean = D.nskip > 0 && D.img[12] <= 4 && !__any((odd & 0x80808080u) != 0) &&

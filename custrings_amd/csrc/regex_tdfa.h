@@ -442,6 +442,116 @@ struct Tdfa {
     return matched;
   }
 
+  // All capture groups of a match from ONE anchored run: groups first .. first + count - 1 (count <= kGroupBatch),
+  // ranges into gb[] / ge[] (-1 = never set), `mend` = where the match ends (the range of group 0).  Same
+  // automaton, same slot shuffles as group_find; every group keeps its own (begin, end) per slot, a byte each,
+  // so rows of 255 bytes and more take group_find per group (the callers' choice).  The fast path -- a
+  // transition that moves no slot and passes no bracket of ANY tracked group -- costs one more table word per
+  // group per step; everything else is paid once instead of once per group.
+  static constexpr int kGroupBatch = 4;
+  CS_HD int group_find_all(int from, const int32_t* G, int first, int count, int* gb, int* ge, int& mend) {
+    const uint32_t* tags0 = (const uint32_t*)(G + 36) + (long long)(first - 1) * (long long)G[3];
+    const long long tstride = (long long)G[3];
+    const uint32_t* amap = (const uint32_t*)(G + 4);
+    uint32_t state = D.init[MODE_SEED_ONCE * 8 + (D.uses ? prev_cat(from) : 0u)];
+    uint32_t px[kGroupBatch], py[kGroupBatch];
+#pragma unroll
+    for (int g = 0; g < kGroupBatch; ++g) {
+      px[g] = py[g] = 0xFFFFFFFFu;
+      gb[g] = ge[g] = -1;
+    }
+    int matched = 0;
+    int pos = from;
+    mend = from;
+    auto pick8 = [](uint32_t p, uint32_t o) -> uint32_t { return o > 3u ? 255u : (p >> (8u * o)) & 255u; };
+    auto apply = [&](uint32_t e, const uint32_t* tg, uint32_t any) -> bool {
+      if (any == 0 && (e & (E_MATCH | E_COMPLEX | (15u << 16))) == 0) {
+        state = e & E_STATE;
+        return (e & E_STOP) != 0;
+      }
+      if (e & E_MATCH) {
+        const uint32_t o = e_match_origin(e);
+#pragma unroll
+        for (int g = 0; g < kGroupBatch; ++g)
+          if (g < count) {
+            const uint32_t mx = (tg[g] & 0x100u) ? (uint32_t)pos : pick8(px[g], o), my = (tg[g] & 0x200u) ? (uint32_t)pos : pick8(py[g], o);
+            gb[g] = mx == 255u ? -1 : (int)mx;
+            ge[g] = my == 255u ? -1 : (int)my;
+          }
+        mend = pos;
+        matched = 1;
+      }
+      if (!(e & E_COMPLEX) && e_keep(e) == 15u) {
+        // every slot stays where it is: only the tagged slots take the position (a byte mask per tag nibble)
+        const uint32_t posb = (uint32_t)pos * 0x01010101u;
+        auto spread = [](uint32_t x) -> uint32_t {  // bits 0, 2, 4, 6 -> bytes 0..3 all ones
+          return (((x | (x << 6) | (x << 12) | (x << 18)) & 0x01010101u)) * 255u;
+        };
+#pragma unroll
+        for (int g = 0; g < kGroupBatch; ++g)
+          if (g < count && (tg[g] & 0xFFu)) {
+            const uint32_t bm = spread(tg[g] & 0x55u), em = spread((tg[g] >> 1) & 0x55u);
+            px[g] = (px[g] & ~bm) | (posb & bm);
+            py[g] = (py[g] & ~em) | (posb & em);
+          }
+        state = e & E_STATE;
+        return (e & E_STOP) != 0;
+      }
+      uint32_t og = 0x3210u;  // identity
+      if (e & E_COMPLEX) {
+        og = D.act[e >> 21];
+      } else {
+        const uint32_t keep = e_keep(e);
+        if (keep != 15u) og = (0x3210u & ~(0xFFFFu << (4 * keep))) | (0xFFFFu << (4 * keep));
+      }
+#pragma unroll
+      for (int g = 0; g < kGroupBatch; ++g)
+        if (g < count) {
+          uint32_t nx = 0, ny = 0;
+#pragma unroll
+          for (int j = 0; j < kMaxSlots; ++j) {
+            const uint32_t o = (og >> (4 * j)) & 15u;
+            nx |= (((tg[g] >> (2 * j)) & 1u) ? (uint32_t)pos : pick8(px[g], o)) << (8 * j);
+            ny |= (((tg[g] >> (2 * j + 1)) & 1u) ? (uint32_t)pos : pick8(py[g], o)) << (8 * j);
+          }
+          px[g] = nx;
+          py[g] = ny;
+        }
+      state = e & E_STATE;
+      return (e & E_STOP) != 0;
+    };
+    auto step = [&](uint32_t e, uint32_t atom) -> bool {
+      uint32_t tg[kGroupBatch], any = 0;
+      const uint32_t* t = tags0 + state * D.natoms + atom;
+#pragma unroll
+      for (int g = 0; g < kGroupBatch; ++g) {
+        tg[g] = g < count ? t[g * tstride] : 0u;
+        any |= tg[g];
+      }
+      return apply(e, tg, any);
+    };
+    bool stop = false;
+    while (!stop && pos < n) {
+      const uint8_t b = byte_at(pos);
+      int w = 1;
+      uint32_t e, atom;
+      if (b < 128) {
+        e = D.t1[state * 128 + b];
+        atom = (amap[b >> 2] >> (8 * (b & 3))) & 255u;
+      } else {
+        unsigned uw;
+        const csrow::Char c = char_at(pos, uw);
+        w = (int)uw;
+        atom = (uint32_t)nonascii_atom(c);
+        e = D.t2[state * D.natoms + atom];
+      }
+      stop = step(e, atom);
+      if (!stop) pos += w;
+    }
+    if (!stop) step(D.t2[state * D.natoms + ATOM_EOT], (uint32_t)ATOM_EOT);
+    return matched;
+  }
+
   // ---- flat scan: all successive matches of a row in ONE loop ------------------
   // (the SIMT-friendly form of the row drivers in regex_vm.h: lanes that are in
   // different find() rounds still share the loop body, and idle stretches are
