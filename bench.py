@@ -331,7 +331,7 @@ def cpu_baseline(rows):
 
     orc = cpulibs.Oracle()
     c = orc.synth(3, 0, rows)
-    blob = np.ascontiguousarray(engines.product_blob(IPV4))
+    blob = np.ascontiguousarray(engines.reference_blob(IPV4) if engines.reference_blob(IPV4) is not None else engines.product_blob(IPV4), dtype=np.int32)
     t0 = time.perf_counter()
     orc.split(c, " ")
     orc.replace_re(c, blob, REPL)

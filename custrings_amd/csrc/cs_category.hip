@@ -348,13 +348,16 @@ cs_category* cs::category_build(const cs_column* col, hipStream_t s) {
   // and retry with room for all-distinct rows only if a probe run gets long.
   int64_t full = 256;
   while (full < 2 * rows) full <<= 1;
+  // slot ids are int32 (slot_of_row, rank_of_slot; a negative id means "null row"): a table for all-distinct rows
+  // beyond 2^30 rows would need ids from 2^31 on -- such a column is refused when (and only when) it needs that table
+  const bool full_out_of_range = full > ((int64_t)1 << 31);
   ColView in = view_of(col);
   Buf slot_of_row = dev_alloc(sizeof(int32_t) * rows, s);
   Buf flags_d = dev_alloc(2 * sizeof(int), s);  // [0] has_null, [1] overflow
   Buf table;
   int first_log2 = 22;
   if (const char* e = getenv("CS_CAT_FIRST_LOG2")) first_log2 = std::max(4, std::min(30, atoi(e)));  // tests: force retries
-  int64_t cap = std::min<int64_t>(full, getenv("CS_CAT_FULL_TABLE") ? full : (int64_t)1 << first_log2);
+  int64_t cap = std::min<int64_t>(full, getenv("CS_CAT_FULL_TABLE") && !full_out_of_range ? full : (int64_t)1 << first_log2);
   for (;;) {
     table = dev_alloc(sizeof(Entry) * cap, s);
     CS_HIP(hipMemsetAsync(table->p, 0xFF, sizeof(Entry) * cap, s));
@@ -373,6 +376,7 @@ cs_category* cs::category_build(const cs_column* col, hipStream_t s) {
     if (h[1] & 2) fail(CS_ERR_RANGE, "category: a key of 16 MiB or more");
     if (cap == full || !h[1]) break;  // (room for all-distinct rows: no limit applied, nothing to retry)
     cap = std::min<int64_t>(full, cap * 16);
+    if (cap == full && full_out_of_range) fail(CS_ERR_RANGE, "category: more than 2^30 rows with more distinct keys than a 2^31-slot table holds");
     // slot ids travel as int32 (negative = null row): a table of 2^31 slots or more cannot be addressed
     if (cap > ((int64_t)1 << 30)) fail(CS_ERR_RANGE, "category: more than 2^29 rows with mostly distinct keys in one column");
   }
