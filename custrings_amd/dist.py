@@ -119,6 +119,14 @@ class GpuOps:
 
         return nvtext.ngrams(col, n, sep)
 
+    def values(self, cat):
+        """the category's int32 codes as a device tensor (a copy: the tensor outlives the handle)"""
+        n = cat.size()
+        out = torch.empty(n, dtype=torch.int32, device="cuda")
+        if n:
+            self._lib.check(self._lib.lib.cs_category_get_values(cat.m_cptr, out.data_ptr(), 1, None))
+        return out
+
     def remap(self, cat, table):
         """values of `cat` mapped through `table` (i32 device tensor) -> i32 device tensor"""
         n = cat.size()
@@ -164,7 +172,9 @@ def global_category(local_col, ops=None, group=None):
     ops = ops or GpuOps()
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     cat, (chars, offs, has_null) = ops.category(local_col)
-    if world == 1:
+    if world == 1:  # the local codes are the global ones
+        if hasattr(ops, "values"):
+            return cat.keys(), ops.values(cat)
         return cat.keys(), ops.remap(cat, torch.arange(cat.keys_size(), dtype=torch.int32, device=chars.device))
     rank = dist.get_rank(group)
     (all_chars, all_offs), flags = _all_gather_ragged([chars, offs], group, scalars=[1 if has_null else 0])
