@@ -798,6 +798,25 @@ struct StreamArgs {
 // matches is scanned a second time during assembly (its size is known from the first scan),
 // without it such a row fails the launch and the host repeats it with the RESCAN variant.
 // LONG: rows of up to 255 bytes keep the lean scan (a sliding 96-byte window of candidate bits).
+// the replacement text (rb <= 8 bytes in two registers) to an LDS position of any alignment: one to three stores
+__device__ __forceinline__ void lds_put_short(uint8_t* at, uint32_t r0, uint32_t r1, int rb) {
+  if (rb >= 8) {
+    *reinterpret_cast<cstile::lds_u64u*>(at) = ((unsigned long long)r1 << 32) | r0;
+    return;
+  }
+  if (rb & 4) {
+    *reinterpret_cast<cstile::lds_u32u*>(at) = r0;
+    at += 4;
+    r0 = r1;
+  }
+  if (rb & 2) {
+    *reinterpret_cast<cstile::lds_u16u*>(at) = (uint16_t)r0;
+    at += 2;
+    r0 >>= 16;
+  }
+  if (rb & 1) *at = (uint8_t)r0;
+}
+
 // ---- unit scan (regex_tdfa.cpp, header word 31): helpers shared by the stream kernels ------------------
 constexpr int kUnitQueue = 128;  // units one round of the queue holds (a busier sub-tile scans its rows whole)
 // Row lanes: the row's candidate bits (returned in m0..m2) and x bits give its units; all units of the sub-tile are
@@ -1033,6 +1052,8 @@ __global__ void __launch_bounds__(256, CS_STREAM_WAVES) k_tdfa_replace_stream(St
     int rec_mb[kMaxRec], rec_me[kMaxRec], rec_reps[kMaxRec];
     int nm = 0;
     int out_len = 0;
+    cstd::U128 uS = cstd::u128(0, 0), uE = cstd::u128(0, 0);  // UNITS: the row's match starts / last bytes
+    bool from_masks = false;
     if (live && !bad) out_len = n;
     if (!bad && !(a.debug & 1)) {
       cstd::Tdfa vm(D, P, lds_in + lead + rbeg, n, (lead + rbeg) & 3);
@@ -1044,7 +1065,7 @@ __global__ void __launch_bounds__(256, CS_STREAM_WAVES) k_tdfa_replace_stream(St
           for (int i = 0; i < 16; ++i)
             if (i < rb) lds_in[pi + at + i] = (uint8_t)(rep[i >> 2] >> (8 * (i & 3)));
         } else {
-          for (int i = 0; i < rb; ++i) lds_in[pi + at + i] = (uint8_t)((i < 4 ? rep[0] >> (8 * i) : rep[1] >> (8 * (i - 4))));
+          lds_put_short(lds_in + pi + at, rep[0], rep[1], rb);
         }
       };
       auto rec = [&](int mb, int me, int reps) {
@@ -1075,6 +1096,7 @@ __global__ void __launch_bounds__(256, CS_STREAM_WAVES) k_tdfa_replace_stream(St
       bool redo = live && !lean && a.maxrepl != 0;
       int resume = 0;
       bool units_done = false;
+      from_masks = false;
       if (UNITS) {
         if (lean && a.maxrepl < 0 && (D.units & 1u) && !(a.debug & 1024)) {  // (wave-uniform)
           using namespace cstd;
@@ -1120,18 +1142,12 @@ __global__ void __launch_bounds__(256, CS_STREAM_WAVES) k_tdfa_replace_stream(St
             cstile::row_bits96(xbitmap, lead + rbeg, n, e0, e1, e2);
             const bool rbail = ((bailw[lane >> 5] >> (lane & 31)) & 1u) != 0;
             if (live && !rbail) {
-              U128 S = u128(s0 | ((unsigned long long)s1 << 32), s2), E = u128(e0 | ((unsigned long long)e1 << 32), e2);
-              nm = u128_popc(S);
-              out_len = n - u128_popc(u128_sub(u128_shl1(E), S)) + nm * rb;
-#pragma unroll
-              for (int j = 0; j < kMaxRec; ++j)
-                if (u128_any(S)) {
-                  rec_mb[j] = u128_ctz(S);
-                  S = u128_clear_lowest(S);
-                  rec_me[j] = u128_ctz(E) + 1;
-                  E = u128_clear_lowest(E);
-                  rec_reps[j] = 1;
-                }
+              // the matches stay in the two masks until the rows are assembled (any number of them per row)
+              uS = u128(s0 | ((unsigned long long)s1 << 32), s2);
+              uE = u128(e0 | ((unsigned long long)e1 << 32), e2);
+              nm = u128_popc(uS);
+              out_len = n - u128_popc(u128_sub(u128_shl1(uE), uS)) + nm * rb;
+              from_masks = true;
             }
             redo = live && rbail;  // (such a row is scanned whole; nothing of it was recorded above)
             units_done = true;
@@ -1196,7 +1212,24 @@ __global__ void __launch_bounds__(256, CS_STREAM_WAVES) k_tdfa_replace_stream(St
         int oi = lo;                 // byte index into lds_out
         const int pi = lead + rbeg;  // byte index of the row in lds_in
         int copied = 0;
-        if (!RESCAN || nm <= kMaxRec) {
+        if (UNITS && from_masks) {
+          while (cstd::u128_any(uS)) {
+            const int mb = cstd::u128_ctz(uS), me = cstd::u128_ctz(uE) + 1;
+            uS = cstd::u128_clear_lowest(uS);
+            uE = cstd::u128_clear_lowest(uE);
+            cstile::lds_copy(lds_out, oi, lds_in, pi + copied, mb - copied);
+            oi += mb - copied;
+            if (REP16) {
+#pragma unroll
+              for (int i = 0; i < 16; ++i)
+                if (i < rb) lds_out[oi + i] = (uint8_t)(rep[i >> 2] >> (8 * (i & 3)));
+              oi += rb;
+            } else {
+              for (int i = 0; i < rb; ++i) lds_out[oi++] = (uint8_t)((i < 4 ? rep[0] >> (8 * i) : rep[1] >> (8 * (i - 4))));
+            }
+            copied = me;
+          }
+        } else if (!RESCAN || nm <= kMaxRec) {
 #pragma unroll
           for (int j = 0; j < kMaxRec; ++j)
             if (j < nm) {
