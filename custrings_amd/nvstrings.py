@@ -24,9 +24,15 @@ def to_device(strs):
     strs = list(strs)
     n = len(strs)
     enc = [None if s is None else (s.encode("utf8") if isinstance(s, str) else bytes(s)) for s in strs]
-    for e in enc:
-        if e is not None and b"\0" in e:
-            raise ValueError("embedded NUL: use from_offsets for binary-safe ingest")
+    if any(e is not None and b"\0" in e for e in enc):
+        # a NUL inside a string: the C-string ingest would cut it there; the offsets ingest is binary safe
+        lens = np.array([0 if e is None else len(e) for e in enc], dtype=np.int64)
+        offs = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum(lens, out=offs[1:])
+        chars = np.frombuffer(b"".join(e for e in enc if e is not None), dtype=np.uint8)
+        valid = np.packbits(np.array([e is not None for e in enc], dtype=np.uint8), bitorder="little")
+        valid = np.concatenate([valid, np.zeros(8, dtype=np.uint8)])
+        return from_offsets64(chars if chars.size else np.zeros(1, dtype=np.uint8), offs, n, valid)
     arr = (C.c_char_p * max(n, 1))(*enc)
     out = C.c_void_p()
     check(lib.cs_column_from_host_strings(arr, n, None, C.byref(out)))

@@ -310,3 +310,15 @@ def test_gpu_ipc_transfer_between_processes(gpu_engine):
     assert got[5] == parts[0].to_host()
     with pytest.raises(ValueError):  # a record that is not one
         nvstrings.create_from_ipc(b"\0" * 231 + b"\7")
+
+
+def test_gpu_to_device_keeps_embedded_nul(gpu_engine):
+    """nvstrings.to_device with a NUL inside a string: the C-string ingest would cut the string there, so such lists take
+    the offsets ingest; the round trip and a byte-level op keep the NUL."""
+    from custrings_amd import nvstrings
+
+    rows = ["ab\0cd", None, "", "\0", "x y\0z w"]
+    s = nvstrings.to_device(rows)
+    assert s.to_host() == rows and s.len() == [5, None, 0, 1, 7]
+    assert s.upper().to_host() == ["AB\0CD", None, "", "\0", "X Y\0Z W"]
+    assert [c.to_host() for c in s.split(" ")] == [["ab\0cd", None, "", "\0", "x"], [None, None, None, None, "y\0z"], [None, None, None, None, "w"]]
