@@ -18,7 +18,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _build(target_dir):
     if os.environ.get("CS_CPULIBS_PREBUILT"):  # bench.py's worker processes: the parent built it already
         return
-    subprocess.run(["make", "-s", "-C", target_dir], check=True)
+    # one make at a time per directory (pytest-xdist workers start together; a second make would relink a library
+    # while the first worker is loading it)
+    import fcntl
+
+    with open(os.path.join(target_dir, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        subprocess.run(["make", "-s", "-C", target_dir], check=True)
 
 
 class Col:
