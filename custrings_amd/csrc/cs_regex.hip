@@ -962,7 +962,7 @@ __global__ void __launch_bounds__(256, CS_STREAM_WAVES) k_tdfa_replace_stream(St
   long long p_tile = -1;
   int p_total = 0, p_lo = 0, p_len = 0;
 #if defined(CS_PHASE_PROF)
-  unsigned long long phase_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long phase_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long lb_acc[3] = {0, 0, 0};
   unsigned long long phase_t = __builtin_readcyclecounter();
 #endif
@@ -1008,6 +1008,7 @@ __global__ void __launch_bounds__(256, CS_STREAM_WAVES) k_tdfa_replace_stream(St
     const long long want = g1 - g0 + lead;
     bool bad = want + 16 > a.cap_in || want > cstile::kPfBytes;
     if (!bad) cstile::stage_chars(lds_in, (int)want, lane, pf);
+    CS_PHASE_MARK(9);   // (wait for the prefetched chars + the LDS writes)
     // bytes that the lean scan does not take (non-ASCII, NUL) anywhere in the staged span, and one
     // candidate bit per byte for the row lanes (classified here, out of the prefetch registers)
     uint32_t odd = 0;
@@ -1031,6 +1032,7 @@ __global__ void __launch_bounds__(256, CS_STREAM_WAVES) k_tdfa_replace_stream(St
       }
     // first look-back poll for the previous sub-tile: issued only now, after the staging above has
     // waited for its own data (vmcnt is in order: a poll issued earlier would sit in front of it)
+    CS_PHASE_MARK(10);  // (classification into the bitmaps)
     cstile::u64 p_first = 0;
     if (p_tile >= 0 && !(a.debug & (8 | 64))) p_first = scanner ? cstile::status_load(a.excl + p_tile) : cstile::lookback_poll(a.status, p_tile, lane);
     // keep the memory pipe busy: next sub-tile's chars, and the offsets of the one after
@@ -1277,7 +1279,7 @@ __global__ void __launch_bounds__(256, CS_STREAM_WAVES) k_tdfa_replace_stream(St
 #if defined(CS_PHASE_PROF)
   CS_PHASE_MARK(5);
   if (lane == 0)
-    for (int k = 0; k < 10; ++k) atomicAdd(reinterpret_cast<unsigned long long*>(a.error) + 1 + k, phase_acc[k]);
+    for (int k = 0; k < 12; ++k) atomicAdd(reinterpret_cast<unsigned long long*>(a.error) + 1 + k, phase_acc[k]);
   if (lane == 0)
     for (int k = 0; k < 3; ++k) atomicAdd(&cstile::g_lb_stats[k], lb_acc[k]);
 #endif
@@ -1932,13 +1934,14 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
         CS_HIP(hipStreamSynchronize(s));
 #if defined(CS_PHASE_PROF)
         {
-          unsigned long long ph[10];
+          unsigned long long ph[12];
           CS_HIP(hipMemcpy(ph, reinterpret_cast<unsigned long long*>(sa.error) + 1, sizeof(ph), hipMemcpyDeviceToHost));
           unsigned long long lb[4] = {0, 0, 0, 0};
           CS_HIP(hipMemcpyFromSymbol(lb, HIP_SYMBOL(cstile::g_lb_stats), sizeof(lb)));
           fprintf(stderr, "look-back (cumulative): %llu calls, %.2f windows per call, %.2f re-polls per call\n", lb[0], (double)lb[1] / (double)(lb[0] ? lb[0] : 1),
                   (double)lb[2] / (double)(lb[0] ? lb[0] : 1));
           const double waves = (double)grid * 4;
+          fprintf(stderr, "stage split: wait+lds %.0f classify %.0f rest %.0f | ", ph[9] / waves / (nsub1 / waves), ph[10] / waves / (nsub1 / waves), ph[0] / waves / (nsub1 / waves));
           fprintf(stderr, "phase cycles/wave-iteration: stage %.0f scan %.0f (units: discovery %.0f rounds %.0f) wscan+publish %.0f finish_prev(offsets+flush) %.0f assemble %.0f tail %.0f lookback %.0f (iters/wave %.1f)\n",
                   ph[0] / waves / (nsub1 / waves), ph[1] / waves / (nsub1 / waves), ph[7] / waves / (nsub1 / waves), ph[8] / waves / (nsub1 / waves), ph[2] / waves / (nsub1 / waves),
                   ph[3] / waves / (nsub1 / waves), ph[4] / waves / (nsub1 / waves), ph[5] / waves / (nsub1 / waves), ph[6] / waves / (nsub1 / waves), nsub1 / waves);
