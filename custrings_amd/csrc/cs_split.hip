@@ -636,47 +636,38 @@ __global__ void __launch_bounds__(256, CS_EMIT2_WAVES) k_split_emit2(Emit2Args a
       }
       CS_PHASE_MARK(2);
       if (csum == 0 || (a.debug & 4)) continue;  // no row of this sub-tile reaches column k (or all its tokens are empty): offsets only
-      // zero the region (16-byte chunks covering lead + bytes + 8 of slack for the last token's third dword)
-      const int zend = clead + csum + 20;
-      for (int i = lane * 16; i < zend; i += 64 * 16) *reinterpret_cast<uint4*>(region + i) = make_uint4(0, 0, 0, 0);
       if (has) {
-        // first 16 bytes of the token, cut to its length and funnel-shifted to the destination's
-        // byte phase: five dwords OR-ed into the zeroed region (longer tokens copy the rest)
+        // the token goes to its place in the column's region with at most five stores of 16 / 8 / 4 / 2 / 1 bytes at
+        // whatever alignment the position has (gfx950 takes DS accesses at any alignment): one 16-byte read of the
+        // staged row, no zeroing of the region, no funnel shifts, no OR-assembly (round 1 composed the token from five
+        // aligned dwords, shifted it to the destination's byte phase and OR-ed it into a zeroed region)
         const int ti = lead + rbeg + lo;
-        const uint32_t* sp = reinterpret_cast<const uint32_t*>(lds_in) + (ti >> 2);
-        const unsigned sh = (unsigned)(ti & 3);
-        const uint32_t w0 = sp[0], w1 = sp[1], w2 = sp[2], w3 = sp[3], w4 = sp[4];
-        unsigned long long tlo = ((unsigned long long)__builtin_amdgcn_alignbyte(w2, w1, sh) << 32) |
-                                 __builtin_amdgcn_alignbyte(w1, w0, sh);  // (alignbyte with shift 0 returns the low word)
-        unsigned long long thi = ((unsigned long long)__builtin_amdgcn_alignbyte(w4, w3, sh) << 32) |
-                                 __builtin_amdgcn_alignbyte(w3, w2, sh);
-        if (len < 8) {
-          tlo &= ~(~0ull << (8 * len));
-          thi = 0;
-        } else if (len < 16) {
-          thi &= ~(~0ull << (8 * (len - 8)));
-        }
-        const uint32_t t0 = (uint32_t)tlo, t1 = (uint32_t)(tlo >> 32), t2 = (uint32_t)thi, t3 = (uint32_t)(thi >> 32);
         const int di = clead + pre;
-        const unsigned sd = (unsigned)(di & 3);
-        uint32_t* dp = reinterpret_cast<uint32_t*>(region) + (di >> 2);
-        uint32_t d0 = t0, d1 = t1, d2 = t2, d3 = t3, d4 = 0;
-        if (sd) {
-          const unsigned up = 4 - sd;  // (hi:lo) >> 8 * up == lo's top sd bytes below hi's low bytes
-          d0 = t0 << (8 * sd);
-          d1 = __builtin_amdgcn_alignbyte(t1, t0, up);
-          d2 = __builtin_amdgcn_alignbyte(t2, t1, up);
-          d3 = __builtin_amdgcn_alignbyte(t3, t2, up);
-          d4 = t3 >> (8 * up);
+        const cstile::lds_u32x4u v = *reinterpret_cast<const cstile::lds_u32x4u*>(lds_in + ti);
+        uint8_t* dp = region + di;
+        if (len >= 16) {
+          *reinterpret_cast<cstile::lds_u32x4u*>(dp) = v;
+          if (len > 16) cstile::lds_copy(region, di + 16, lds_in, ti + 16, len - 16);
+        } else {
+          uint32_t t0 = v.x, t1 = v.y;
+          if (len & 8) {
+            *reinterpret_cast<cstile::lds_u64u*>(dp) = ((unsigned long long)v.y << 32) | v.x;
+            dp += 8;
+            t0 = v.z;
+            t1 = v.w;
+          }
+          if (len & 4) {
+            *reinterpret_cast<cstile::lds_u32u*>(dp) = t0;
+            dp += 4;
+            t0 = t1;
+          }
+          if (len & 2) {
+            *reinterpret_cast<cstile::lds_u16u*>(dp) = (uint16_t)t0;
+            dp += 2;
+            t0 >>= 16;
+          }
+          if (len & 1) *dp = (uint8_t)t0;
         }
-        lds_or(dp, d0);
-        lds_or(dp + 1, d1);
-        if (__any(len + (int)sd > 8)) {
-          lds_or(dp + 2, d2);
-          lds_or(dp + 3, d3);
-          lds_or(dp + 4, d4);
-        }
-        if (len > 16) cstile::lds_copy(region, di + 16, lds_in, ti + 16, len - 16);
       }
       cstile::wave_lds_fence();
       CS_PHASE_MARK(3);

@@ -156,6 +156,7 @@ __device__ __forceinline__ void wave_flush(uint8_t* dst, int total, const uint8_
 // any alignment, so the copy is 16 bytes per trip through two 8-byte accesses and a 8 / 4 / 2 / 1 tail, with no
 // alignment prologue.  Both buffers are given as (base, byte index); the pointers are never turned into integers
 // (which would demote the LDS accesses to flat ones).
+typedef uint32_t lds_u32x4u __attribute__((ext_vector_type(4), aligned(1)));
 typedef unsigned long long lds_u64u __attribute__((aligned(1)));
 typedef uint32_t lds_u32u __attribute__((aligned(1)));
 typedef uint16_t lds_u16u __attribute__((aligned(1)));
@@ -163,11 +164,7 @@ __device__ __forceinline__ void lds_copy(uint8_t* dbase, int di, const uint8_t* 
   uint8_t* d = dbase + di;
   const uint8_t* s = sbase + si;
   int i = 0;
-  for (; i + 16 <= n; i += 16) {
-    const unsigned long long a = *reinterpret_cast<const lds_u64u*>(s + i), b = *reinterpret_cast<const lds_u64u*>(s + i + 8);
-    *reinterpret_cast<lds_u64u*>(d + i) = a;
-    *reinterpret_cast<lds_u64u*>(d + i + 8) = b;
-  }
+  for (; i + 16 <= n; i += 16) *reinterpret_cast<lds_u32x4u*>(d + i) = *reinterpret_cast<const lds_u32x4u*>(s + i);
   if (n & 8) {
     *reinterpret_cast<lds_u64u*>(d + i) = *reinterpret_cast<const lds_u64u*>(s + i);
     i += 8;
@@ -464,16 +461,11 @@ __device__ __forceinline__ void wave_flush_shift(uint8_t* dst, int total, const 
   }
   const int head = first_full - olead;               // bytes before the first whole chunk
   if (lane < head) gdst[lane] = lds[lane];
-  const unsigned sh = (unsigned)(head & 3);
-  const uint32_t* w = reinterpret_cast<const uint32_t*>(lds) + (head >> 2);
+  // (gfx950 reads LDS at any alignment: one 16-byte read per chunk, where five aligned dwords and four funnel
+  // shifts used to compose it)
   for (int i = first_full + lane * 16; i < last_full; i += 64 * 16) {
-    const uint32_t* q = w + ((i - first_full) >> 2);
-    const uint32_t w0 = q[0], w1 = q[1], w2 = q[2], w3 = q[3], w4 = q[4];
-    u32x4 o;
-    o.x = __builtin_amdgcn_alignbyte(w1, w0, sh);
-    o.y = __builtin_amdgcn_alignbyte(w2, w1, sh);
-    o.z = __builtin_amdgcn_alignbyte(w3, w2, sh);
-    o.w = __builtin_amdgcn_alignbyte(w4, w3, sh);
+    const lds_u32x4u v = *reinterpret_cast<const lds_u32x4u*>(lds + head + (i - first_full));
+    u32x4 o = {v.x, v.y, v.z, v.w};
     *(gptr<u32x4>)(a0 + i) = o;
   }
   const int tail0 = last_full - olead;               // output index of the first tail byte
