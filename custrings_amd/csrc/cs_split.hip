@@ -643,31 +643,8 @@ __global__ void __launch_bounds__(256, CS_EMIT2_WAVES) k_split_emit2(Emit2Args a
         // aligned dwords, shifted it to the destination's byte phase and OR-ed it into a zeroed region)
         const int ti = lead + rbeg + lo;
         const int di = clead + pre;
-        const cstile::lds_u32x4u v = *reinterpret_cast<const cstile::lds_u32x4u*>(lds_in + ti);
-        uint8_t* dp = region + di;
-        if (len >= 16) {
-          *reinterpret_cast<cstile::lds_u32x4u*>(dp) = v;
-          if (len > 16) cstile::lds_copy(region, di + 16, lds_in, ti + 16, len - 16);
-        } else {
-          uint32_t t0 = v.x, t1 = v.y;
-          if (len & 8) {
-            *reinterpret_cast<cstile::lds_u64u*>(dp) = ((unsigned long long)v.y << 32) | v.x;
-            dp += 8;
-            t0 = v.z;
-            t1 = v.w;
-          }
-          if (len & 4) {
-            *reinterpret_cast<cstile::lds_u32u*>(dp) = t0;
-            dp += 4;
-            t0 = t1;
-          }
-          if (len & 2) {
-            *reinterpret_cast<cstile::lds_u16u*>(dp) = (uint16_t)t0;
-            dp += 2;
-            t0 >>= 16;
-          }
-          if (len & 1) *dp = (uint8_t)t0;
-        }
+        cstile::lds_put16(region + di, *reinterpret_cast<const cstile::lds_u32x4u*>(lds_in + ti), len);
+        if (len > 16) cstile::lds_copy(region, di + 16, lds_in, ti + 16, len - 16);
       }
       cstile::wave_lds_fence();
       CS_PHASE_MARK(3);

@@ -180,6 +180,33 @@ __device__ __forceinline__ void lds_copy(uint8_t* dbase, int di, const uint8_t* 
   if (n & 1) d[i] = s[i];
 }
 
+// The first `len` (<= 16) bytes of `v` to an LDS position of any alignment: at most five stores of 16 / 8 / 4 / 2 / 1
+// bytes, exactly the bytes asked for (neighbouring lanes write the bytes next to them).
+__device__ __forceinline__ void lds_put16(uint8_t* dp, lds_u32x4u v, int len) {
+  if (len >= 16) {
+    *reinterpret_cast<lds_u32x4u*>(dp) = v;
+    return;
+  }
+  uint32_t t0 = v.x, t1 = v.y;
+  if (len & 8) {
+    *reinterpret_cast<lds_u64u*>(dp) = ((unsigned long long)v.y << 32) | v.x;
+    dp += 8;
+    t0 = v.z;
+    t1 = v.w;
+  }
+  if (len & 4) {
+    *reinterpret_cast<lds_u32u*>(dp) = t0;
+    dp += 4;
+    t0 = t1;
+  }
+  if (len & 2) {
+    *reinterpret_cast<lds_u16u*>(dp) = (uint16_t)t0;
+    dp += 2;
+    t0 >>= 16;
+  }
+  if (len & 1) *dp = (uint8_t)t0;
+}
+
 // Copy of a SHORT run (tokens, replacement text): the first 8 bytes go through two
 // funnel-shifted source dwords and straight-line predicated byte stores, longer
 // runs fall back to lds_copy for the rest.
