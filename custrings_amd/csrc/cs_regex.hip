@@ -1082,13 +1082,18 @@ __global__ void __launch_bounds__(256, CS_STREAM_WAVES) k_tdfa_replace_stream(St
           copied = me;
         } else {
           out_len += reps * rb - (me - mb);
+          // (UNITS: the rows that come through here -- non-ASCII sub-tiles, rows a unit handed over -- are only
+          // measured; the assembly scans them again.  Twelve registers less in a kernel at its VGPR limit, whose
+          // spill reloads -- VMEM operations -- otherwise wait behind the prefix poll in every iteration.)
+          if (!UNITS) {
 #pragma unroll
-          for (int j = 0; j < kMaxRec; ++j)
-            if (nm == j) {
-              rec_mb[j] = mb;
-              rec_me[j] = me;
-              rec_reps[j] = reps;
-            }
+            for (int j = 0; j < kMaxRec; ++j)
+              if (nm == j) {
+                rec_mb[j] = mb;
+                rec_me[j] = me;
+                rec_reps[j] = reps;
+              }
+          }
         }
         ++nm;
       };
@@ -1231,7 +1236,7 @@ __global__ void __launch_bounds__(256, CS_STREAM_WAVES) k_tdfa_replace_stream(St
             }
             copied = me;
           }
-        } else if (!RESCAN || nm <= kMaxRec) {
+        } else if (!UNITS && (!RESCAN || nm <= kMaxRec)) {
 #pragma unroll
           for (int j = 0; j < kMaxRec; ++j)
             if (j < nm) {
@@ -1249,9 +1254,9 @@ __global__ void __launch_bounds__(256, CS_STREAM_WAVES) k_tdfa_replace_stream(St
               }
               copied = rec_me[j];
             }
-        } else {
-          // more matches than the registers keep: the row's size is known from the first scan, so
-          // scan it again and assemble as the matches are reported
+        } else if (nm > 0) {
+          // more matches than the registers keep (UNITS: any row measured by the generic scan): the row's size is
+          // known from the first scan, so scan it again and assemble as the matches are reported
           auto piece2 = [&](int mb, int me, int reps) {
             cstile::lds_copy(lds_out, oi, lds_in, pi + copied, mb - copied);
             oi += mb - copied;
