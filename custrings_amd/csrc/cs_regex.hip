@@ -879,7 +879,9 @@ __device__ __forceinline__ uint32_t unit_xbits16(const uint4& q, uint32_t xpat) 
 // over it, leaving a start bit and a last-byte bit per match in the (re-used) bitmaps, from which the row lanes
 // read their rows' matches.  A wave's lock-step scan then costs the longest UNIT (a dotted quad) instead of the
 // busiest ROW (two dotted quads and a status code), and runs that cannot hold a match are never scanned.
-template <bool IN_LDS, bool REP16, bool INPLACE, bool RESCAN = false, bool LONG = false, bool UNITS = false>
+// PF: 16-byte chunks per lane of the register prefetch (1 KB of the sub-tile each): 6 covers every span the kernel
+// takes; the unit variant also exists with 5 (spans up to 5 KB, the usual case), four registers less where it spills.
+template <bool IN_LDS, bool REP16, bool INPLACE, bool RESCAN = false, bool LONG = false, bool UNITS = false, int PF = cstile::kPfChunks>
 __global__ void __launch_bounds__(256, CS_STREAM_WAVES) k_tdfa_replace_stream(StreamArgs a) {
   static_assert(!UNITS || (!INPLACE && RESCAN && !LONG), "the unit scan builds on the register-record assembly");
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
@@ -952,9 +954,9 @@ __global__ void __launch_bounds__(256, CS_STREAM_WAVES) k_tdfa_replace_stream(St
   cstile::TileOffs cur = cstile::load_tile_offsets_r(in.offsets, in.rows, tile, R, lane);
   cstile::TileOffs nxt = cur;
   if (t_nxt < a.nsub) nxt = cstile::load_tile_offsets_r(in.offsets, in.rows, t_nxt, R, lane);
-  cstile::TileChars pf;
+  cstile::TileCharsT<PF> pf;
 #pragma unroll
-  for (int j = 0; j < cstile::kPfChunks; ++j) pf.v[j] = make_uint4(0, 0, 0, 0);
+  for (int j = 0; j < PF; ++j) pf.v[j] = make_uint4(0, 0, 0, 0);
   cstile::issue_chars(in.chars, cstile::rl64(cur.o0, 0), cstile::rl64(cur.o1, 63), lane, pf);
   // The previous sub-tile's output stays assembled in lds_out while this one is scanned;
   // its look-back completes afterwards, when every predecessor's aggregate has long been
@@ -1006,14 +1008,14 @@ __global__ void __launch_bounds__(256, CS_STREAM_WAVES) k_tdfa_replace_stream(St
     const int n = live ? (int)(cur.o1 - cur.o0) : 0;
     const int lead = (int)((uintptr_t)(in.chars + g0) & 15);
     const long long want = g1 - g0 + lead;
-    bool bad = want + 16 > a.cap_in || want > cstile::kPfBytes;
+    bool bad = want + 16 > a.cap_in || want > PF * 1024;
     if (!bad) cstile::stage_chars(lds_in, (int)want, lane, pf);
     CS_PHASE_MARK(9);   // (wait for the prefetched chars + the LDS writes)
     // bytes that the lean scan does not take (non-ASCII, NUL) anywhere in the staged span, and one
     // candidate bit per byte for the row lanes (classified here, out of the prefetch registers)
     uint32_t odd = 0;
 #pragma unroll
-    for (int j = 0; j < cstile::kPfChunks; ++j)
+    for (int j = 0; j < PF; ++j)
       if (j * 1024 + lane * 16 < (int)want) {
         const uint4 q = pf.v[j];
         odd |= q.x | ((q.x - 0x01010101u) & ~q.x);
@@ -1921,7 +1923,10 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
         };
         auto kern = growth == 0 ? pick(std::true_type{}, std::false_type{})
                                 : roomy ? pick(std::false_type{}, std::true_type{}) : pick(std::false_type{}, std::false_type{});
-        if (units)
+        if (units && cap <= 5 * 1024)
+          kern = rb > 8 ? (tp.d.in_lds ? &k_tdfa_replace_stream<true, true, false, true, false, true, 5> : &k_tdfa_replace_stream<false, true, false, true, false, true, 5>)
+                        : (tp.d.in_lds ? &k_tdfa_replace_stream<true, false, false, true, false, true, 5> : &k_tdfa_replace_stream<false, false, false, true, false, true, 5>);
+        else if (units)
           kern = rb > 8 ? (tp.d.in_lds ? &k_tdfa_replace_stream<true, true, false, true, false, true> : &k_tdfa_replace_stream<false, true, false, true, false, true>)
                         : (tp.d.in_lds ? &k_tdfa_replace_stream<true, false, false, true, false, true> : &k_tdfa_replace_stream<false, false, false, true, false, true>);
         if (lds1 > 48 * 1024)

@@ -240,9 +240,11 @@ constexpr int kPfBytes = kPfChunks * 1024;  // largest (lead + span) one prefetc
 struct TileOffs {
   long long o0, o1;  // offsets[r0 + lane], offsets[r0 + lane + 1] (clamped to the sub-tile)
 };
-struct TileChars {
-  uint4 v[kPfChunks];
+template <int N>
+struct TileCharsT {
+  uint4 v[N];
 };
+typedef TileCharsT<kPfChunks> TileChars;
 __device__ __forceinline__ long long rl64(long long v, int k) {
   const int lo = __builtin_amdgcn_readlane((int)(v & 0xffffffffll), k);
   const int hi = __builtin_amdgcn_readlane((int)(v >> 32), k);
@@ -267,20 +269,22 @@ __device__ __forceinline__ TileOffs load_tile_offsets_r(const int64_t* offsets, 
 }
 // issues the loads of bytes [g0 - lead, g1) of `chars` (lead = distance to the previous
 // 16-byte boundary); nothing waits on them here
-__device__ __forceinline__ void issue_chars(const uint8_t* chars, long long g0, long long g1, int lane, TileChars& c) {
+template <int N>
+__device__ __forceinline__ void issue_chars(const uint8_t* chars, long long g0, long long g1, int lane, TileCharsT<N>& c) {
   const int lead = (int)((uintptr_t)(chars + g0) & 15);
   const uint8_t* src = chars + (g0 - lead);
   const long long want = g1 - g0 + lead;
-  const int span = (int)(want < (long long)kPfBytes ? want : (long long)kPfBytes);
+  const int span = (int)(want < (long long)(N * 1024) ? want : (long long)(N * 1024));
 #pragma unroll
-  for (int j = 0; j < kPfChunks; ++j) {
+  for (int j = 0; j < N; ++j) {
     const int i = j * 1024 + lane * 16;
     if (i < span) c.v[j] = *reinterpret_cast<const uint4*>(src + i);
   }
 }
-__device__ __forceinline__ void stage_chars(uint8_t* lds_in, int span, int lane, const TileChars& c) {
+template <int N>
+__device__ __forceinline__ void stage_chars(uint8_t* lds_in, int span, int lane, const TileCharsT<N>& c) {
 #pragma unroll
-  for (int j = 0; j < kPfChunks; ++j) {
+  for (int j = 0; j < N; ++j) {
     const int i = j * 1024 + lane * 16;
     if (i < span) *reinterpret_cast<uint4*>(lds_in + i) = c.v[j];
   }
