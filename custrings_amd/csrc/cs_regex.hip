@@ -1324,7 +1324,7 @@ struct ScanStreamArgs {
 // UNITS (MODE 0 and 2, !LONG): the unit scan of the replace kernel -- units queued by the row lanes, one unit per lane
 // whatever its row, the per-row result summed (count_re) / OR-ed (contains_re) in LDS.
 template <int MODE, bool IN_LDS, bool LONG = false, bool UNITS = false>
-__global__ void __launch_bounds__(256) k_tdfa_scan_stream(ScanStreamArgs a) {
+__global__ void __launch_bounds__(256, (UNITS || MODE == 3) ? 4 : 1) k_tdfa_scan_stream(ScanStreamArgs a) {
   static_assert(!UNITS || ((MODE == 0 || MODE == 2) && !LONG), "unit scan: contains_re / count_re on rows within the 96-byte masks");
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   uint8_t* base = reinterpret_cast<uint8_t*>(smem);
