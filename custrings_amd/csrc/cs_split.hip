@@ -337,7 +337,7 @@ struct Measure2Args {
                     // (sum over its rows of the row's longest token), [2] longest row, [3] a sub-tile needs the generic kernels
 };
 template <int MODE>
-__global__ void __launch_bounds__(256) k_split_measure2(Measure2Args a) {
+__global__ void __launch_bounds__(256, 8) k_split_measure2(Measure2Args a) {  // (8 waves per SIMD: 2.05 -> 1.94 ms)
   constexpr bool WS = MODE == 1, MULTI = MODE == 2;
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
