@@ -322,3 +322,27 @@ def test_gpu_to_device_keeps_embedded_nul(gpu_engine):
     assert s.to_host() == rows and s.len() == [5, None, 0, 1, 7]
     assert s.upper().to_host() == ["AB\0CD", None, "", "\0", "X Y\0Z W"]
     assert [c.to_host() for c in s.split(" ")] == [["ab\0cd", None, "", "\0", "x"], [None, None, None, None, "y\0z"], [None, None, None, None, "w"]]
+
+
+@pytest.mark.parametrize("config,extra", [("c4", ["--rows", "200000", "--keys", "500"]), ("c5", ["--rows", "50000"])])
+def test_gpu_bench_exchange_configs_run(config, extra):
+    """bench.py --config c4|c5 (the two BASELINE configs with an exchange step; at one rank the collectives are skipped):
+    one JSON line with the contract's fields, and the work it reports is plausible."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--config", config, "--steps", "2", "--warmup", "1"] + extra,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "dtype", "data", "config"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["fallbacks_in_timed_region"] == 0
+    if config == "c4":
+        assert 0 < d["rank0"]["keys"] <= 501
+    else:
+        assert d["rank0"]["ngrams"] == d["rank0"]["tokens"] - 1
