@@ -21,6 +21,8 @@ bool ngrams_fast(const cs_column* tokens, int n, const unsigned char* sep, int s
 }
 namespace cs {
 extern thread_local int g_replace_plain_only;
+extern thread_local unsigned long long g_replace_literal;
+extern thread_local int g_replace_literal_len;
 }
 namespace csrow {
 struct CharSet;
@@ -547,8 +549,17 @@ int cs_replace(const cs_column* col, const char* str, const char* repl, int maxr
         cs_regex* re = nullptr;
         if (cs_regex_compile(pattern.c_str(), &re) == CS_OK) {
           cs::g_replace_plain_only = 1;  // the single-pass kernel or nothing: this function's own kernels are the fallback
+          {  // a needle of up to eight bytes without a border is matched by byte comparison (cs_regex.hip)
+            const size_t m = strlen(str);
+            bool border_free = m >= 1 && m <= 8;
+            for (size_t b = 1; border_free && b < m; ++b) border_free = memcmp(str, str + m - b, b) != 0;
+            cs::g_replace_literal = 0;
+            cs::g_replace_literal_len = border_free ? (int)m : 0;
+            for (size_t i = 0; border_free && i < m; ++i) cs::g_replace_literal |= (unsigned long long)(unsigned char)str[i] << (8 * i);
+          }
           const int rc = cs_replace_re(col, re, repl, maxrepl, stream, out);
           cs::g_replace_plain_only = 0;
+          cs::g_replace_literal_len = 0;
           cs_regex_destroy(re);
           if (rc == CS_OK) return;
         }

@@ -38,6 +38,11 @@ struct cs_regex {
 
 namespace cs {
 thread_local int g_replace_plain_only = 0;  // set by cs_replace around its call of cs_replace_re: single-pass kernel or nothing
+// cs_replace also leaves the needle itself here when it has at most eight bytes and no border (no proper prefix that is
+// also a suffix: occurrences cannot overlap): the stream kernel then finds the matches by byte comparison, all bytes of
+// the sub-tile at once, instead of walking the DFA
+thread_local unsigned long long g_replace_literal = 0;
+thread_local int g_replace_literal_len = 0;
 }
 
 namespace {
@@ -785,6 +790,8 @@ struct StreamArgs {
   long long out_cap;  // bytes provisioned at out_chars (growing replacements)
   int rows_per_tile;  // LONG variants: 64, 32 or 16
   unsigned long long* tickets;  // 8 tile counters, 64 bytes apart, zeroed before the launch
+  unsigned long long lit;       // UNITS: a literal needle (first byte lowest), litn bytes; litn == 0: none
+  int litn;
 };
 #ifndef CS_STREAM_WAVES
 #define CS_STREAM_WAVES 3
@@ -1106,7 +1113,62 @@ __global__ void __launch_bounds__(256, CS_STREAM_WAVES) k_tdfa_replace_stream(St
       int resume = 0;
       bool units_done = false;
       from_masks = false;
-      if (UNITS) {
+      if (UNITS && a.litn > 0) {
+        // A literal needle without a border: every match of the sub-tile by byte comparison, sixteen positions per
+        // lane and step -- no automaton.  Match starts land in `bitmap`; `xbitmap` holds the row starts, so that a
+        // match never spans two rows (or the end of the staged span).  Rows of any bytes qualify (an ASCII needle
+        // never matches inside a multi-byte character), rows beyond the 96-bit masks do not.
+        if (a.maxrepl < 0 && !__any(live && !vm.masks_fit())) {  // (wave-uniform)
+          using namespace cstd;
+          const int m = a.litn;
+          for (int i = lane * 16; i < bm_bytes; i += 64 * 16) *reinterpret_cast<uint4*>(reinterpret_cast<uint8_t*>(xbitmap) + i) = make_uint4(0, 0, 0, 0);
+          cstile::wave_lds_fence();
+          {
+            const int p = lane < nrows ? lead + rbeg : (int)want;  // (every row, null or not; the others mark the end of the span)
+            __hip_atomic_fetch_or(xbitmap + (p >> 5), 1u << (p & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+          }
+          cstile::wave_lds_fence();
+#pragma unroll
+          for (int j = 0; j < PF; ++j) {
+            const int i = j * 1024 + lane * 16;
+            if (i < (int)want) {
+              const uint32_t* wp = reinterpret_cast<const uint32_t*>(lds_in + i);
+              const uint32_t w0 = wp[0], w1 = wp[1], w2 = wp[2], w3 = wp[3], w4 = wp[4], w5 = wp[5];
+              uint32_t M = 0xFFFFFFu;
+              for (int k = 0; k < m; ++k) {
+                const uint32_t cpat = (uint32_t)((a.lit >> (8 * k)) & 255u) * 0x01010101u;
+                auto eq = [&](uint32_t w) {
+                  const uint32_t t = w ^ cpat;
+                  return ~(((t & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | t) & 0x80808080u;
+                };
+                const uint32_t hi8 = __builtin_amdgcn_udot4(eq(w5), 0x80402010u, __builtin_amdgcn_udot4(eq(w4), 0x08040201u, 0u, false), false) >> 7;
+                M &= (cstile::gather16_bit7(eq(w0), eq(w1), eq(w2), eq(w3)) | (hi8 << 16)) >> k;
+              }
+              // row starts at i .. i + 23 (a row start at p + k, 0 < k < m, forbids a match at p)
+              const uint32_t* xb = xbitmap + (i >> 5);
+              const unsigned sh = (unsigned)(i & 31);
+              const uint32_t rs = sh ? (xb[0] >> sh) | (xb[1] << (32 - sh)) : xb[0];
+              for (int k = 1; k < m; ++k) M &= ~(rs >> k);
+              const int room = (int)want - i;  // positions of this piece inside the staged span
+              if (room < 16) M &= (1u << room) - 1u;
+              cstile::put_bits16(bitmap, i, M & 0xFFFFu);
+            }
+          }
+          cstile::wave_lds_fence();
+          uint32_t s0, s1, s2;
+          cstile::row_bits96(bitmap, lead + rbeg, n, s0, s1, s2);
+          if (live) {
+            uS = u128(s0 | ((unsigned long long)s1 << 32), s2);
+            const int up = m - 1;  // the match's last byte
+            uE = up ? u128(uS.lo << up, (uS.hi << up) | (uS.lo >> (64 - up))) : uS;
+            nm = u128_popc(uS);
+            out_len = n + nm * (rb - m);
+            from_masks = true;
+          }
+          redo = false;  // (no row needs the automaton)
+          units_done = true;
+        }
+      } else if (UNITS) {
         if (lean && a.maxrepl < 0 && (D.units & 1u) && !(a.debug & 1024)) {  // (wave-uniform)
           using namespace cstd;
           // -- row lanes: the row's units from its candidate and x bits
@@ -1881,7 +1943,8 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
         // on the number of replacements, rows within the 96-byte masks
         // (not for the literal needles of cs_replace: short needles match densely, and then the per-row kernel with its
         // in-place compaction is the faster one -- 'ab' -> 'x' on the C2 column: 1.25 against 1.77 ms)
-        const bool units = (re->tdfa[31] & 1) != 0 && maxrepl < 0 && !tc.lng && tc.R == 64 && !cs::g_replace_plain_only && !getenv("CS_NO_UNITS");
+        const bool literal = cs::g_replace_plain_only && cs::g_replace_literal_len > 0 && maxrepl < 0 && !tc.lng && tc.R == 64 && !getenv("CS_NO_LITERAL_SCAN");
+        const bool units = literal || ((re->tdfa[31] & 1) != 0 && maxrepl < 0 && !tc.lng && tc.R == 64 && !cs::g_replace_plain_only && !getenv("CS_NO_UNITS"));
         const size_t unit_bytes = units ? (size_t)((cap >> 3) + 32 + kUnitQueue * 4 + 16) : 0;
         const size_t lds1 = tbl + (size_t)(cap + cap_out + 64 + (cap >> 3) + 32 + unit_bytes) * 4 + 16;
         if (lds1 > 150 * 1024) return -1;
@@ -1913,6 +1976,8 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
         sa.cap_out = cap_out;
         sa.tbl_bytes = (int)tbl;
         sa.debug = getenv("CS_TILE_DEBUG") ? atoi(getenv("CS_TILE_DEBUG")) : 0;
+        sa.lit = literal ? cs::g_replace_literal : 0;
+        sa.litn = literal ? cs::g_replace_literal_len : 0;
         auto pick2 = [&](auto inplace, auto rescan, auto lng) {
           constexpr bool IP = decltype(inplace)::value, RS = decltype(rescan)::value, LG = decltype(lng)::value;
           return rb > 8 ? (tp.d.in_lds ? &k_tdfa_replace_stream<true, true, IP, RS, LG> : &k_tdfa_replace_stream<false, true, IP, RS, LG>)

@@ -346,3 +346,31 @@ def test_gpu_bench_exchange_configs_run(config, extra):
         assert 0 < d["rank0"]["keys"] <= 501
     else:
         assert d["rank0"]["ngrams"] == d["rank0"]["tokens"] - 1
+
+
+@pytest.mark.parametrize("needle", ["a", "ab", " ", "the ", "abcdefgh", "b a", ".", "aa", "aba", "abcdefghi"])
+def test_gpu_literal_replace_by_byte_comparison(gpu_engine, oracle_engine, needle):
+    """replace(str) with a needle of up to eight bytes and no border takes the byte-comparison scan of the replace stream
+    kernel (cs_regex.hip: StreamArgs::lit; 'aa', 'aba' have a border and nine bytes are too many: those stay on the
+    automaton): against the oracle on rows with non-ASCII text, nulls, empties, matches at both row ends and across what
+    would be a row boundary, with growing / shrinking / empty / 16-byte replacements, and at the row-count edges."""
+    rnd = random.Random(len(needle) * 7)
+    words = ["a", "ab", "abc", "the ", "the", " ", "  ", "é", "😀", "abcdefgh", "abcdefg", "b a", ".", "..", "aa", "aba", "x", "hab", "tha"]
+    rows = []
+    for _ in range(1500):
+        u = rnd.random()
+        if u < 0.05:
+            rows.append(None)
+        elif u < 0.1:
+            rows.append("")
+        else:
+            rows.append("".join(rnd.choice(words) for _ in range(rnd.randrange(1, 14)))[:90])
+    rows += [needle, needle * 3, needle[:-1] if len(needle) > 1 else "", needle[1:] + needle[:1], "x" + needle, needle + "x"]
+    from custrings_amd import _lib
+
+    for repl in ("", "x", "xyz", "0123456789abcdef"):
+        before = _lib.lib.cs_fallback_count()
+        for cut in (len(rows), 65, 64, 1):
+            assert gpu_engine.replace(rows[:cut], needle, repl, -1) == oracle_engine.replace(rows[:cut], needle, repl, -1), (needle, repl, cut)
+        # (a 16-byte replacement of a one-byte needle may outgrow the provisioned room: that launch is repeated two-pass)
+        assert len(repl) > 3 or _lib.lib.cs_fallback_count() == before
