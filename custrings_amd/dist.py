@@ -146,6 +146,10 @@ def _all_gather_ragged(tensors, group, scalars=()):
     world = dist.get_world_size(group)
     dev = tensors[0].device
     nt = len(tensors)
+    if dev.type == "cuda" and dist.get_backend(group) == "gloo":
+        # (several ranks on one GPU, as the two-process GPU test runs: gloo moves host memory)
+        parts, scal = _all_gather_ragged([t.cpu() for t in tensors], group, scalars)
+        return [[p.to(dev) for p in ps] for ps in parts], scal
     mine = torch.tensor([t.numel() for t in tensors] + [int(v) for v in scalars], dtype=torch.int64, device=dev)
     table = torch.empty(world * mine.numel(), dtype=torch.int64, device=dev)
     dist.all_gather_into_tensor(table, mine, group=group)

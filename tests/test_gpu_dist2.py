@@ -1,0 +1,81 @@
+"""-m gpu: the exchange paths of custrings_amd/dist.py with the real GPU ops in TWO processes.  Both ranks share the one
+GPU of the test box, so the process group is gloo (RCCL refuses two ranks on one device); dist.py moves the small
+exchanged tensors through host memory for that backend.  What is checked is the product code on both sides of the
+collective: local category build -> key-set all-gather -> merge -> remap, and tokenize -> first-tokens all-gather ->
+n-grams, each against the single-process result on the whole column."""
+import os
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _worker(rank, world, port, rows, q):
+    sys.path.insert(0, os.path.dirname(HERE))
+    sys.path.insert(0, HERE)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    try:
+        import ctypes as C
+
+        import torch
+        import torch.distributed as dist
+
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from custrings_amd import _lib, nvstrings, nvtext
+        from custrings_amd import dist as csd
+
+        _lib.ensure_init(0)
+        lo, hi = csd.shard_range(rows, rank, world)
+
+        def synth(kind, first, n, param=0):
+            out = C.c_void_p()
+            _lib.check(_lib.lib.cs_synth_column(kind, first, n, 20240607, param, None, C.byref(out)))
+            return nvstrings.nvstrings(out.value)
+
+        keys, values = csd.global_category(synth(4, lo, hi - lo, 3000))
+        grams = csd.sharded_ngrams(nvtext.tokenize(synth(5, lo, hi - lo)), 2, "_")
+        ncols = csd.agree_on_columns(len(synth(3, lo, hi - lo).split(" ")), device="cpu")
+        q.put((rank, "ok", keys.to_host(), values.cpu().tolist(), grams.to_host(), ncols))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as e:  # the parent reports it
+        import traceback
+
+        q.put((rank, "error", traceback.format_exc() + repr(e)))
+
+
+def test_gpu_two_rank_exchanges_with_the_gpu_ops(gpu_engine):
+    import ctypes as C
+
+    import torch.multiprocessing as mp
+
+    from custrings_amd import _lib, nvcategory, nvstrings, nvtext
+
+    rows, world = 40_000, 2
+    port = 33500 + (os.getpid() % 2000)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, rows, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+    assert all(g[1] == "ok" for g in got), [g[2] for g in got if g[1] != "ok"]
+
+    def synth(kind, param=0):
+        out = C.c_void_p()
+        _lib.check(_lib.lib.cs_synth_column(kind, 0, rows, 20240607, param, None, C.byref(out)))
+        return nvstrings.nvstrings(out.value)
+
+    cat = nvcategory.from_strings(synth(4, 3000))
+    want_keys, want_values = cat.keys().to_host(), cat.values()
+    want_grams = nvtext.ngrams(nvtext.tokenize(synth(5)), 2, "_").to_host()
+    want_cols = len(synth(3).split(" "))
+    assert got[0][2] == got[1][2] == want_keys                  # the same, global key set on both ranks
+    assert got[0][3] + got[1][3] == list(want_values)           # each rank the codes of its own rows
+    assert got[0][4] + got[1][4] == want_grams                  # the n-grams across the shard boundary included
+    assert got[0][5] == got[1][5] == want_cols
