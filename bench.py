@@ -76,14 +76,19 @@ def main():
                     help="c3 = the headline (default); c4 = distributed NVCategory build (key-set all-gather inside the timed region); "
                          "c5 = tokenize + n-grams(2) with the shard-boundary exchange inside the timed region")
     ap.add_argument("--keys", type=int, default=1_000_000, help="c4: distinct tokens K")
+    ap.add_argument("--backend", default="nccl", help="process-group backend (nccl = RCCL; gloo lets several ranks share one GPU for a plumbing check)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = local % max(torch.cuda.device_count(), 1)  # (more ranks than GPUs only with --backend gloo)
     torch.cuda.set_device(local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(args.backend)
 
     from custrings_amd import _lib, nvstrings
 

@@ -79,3 +79,27 @@ def test_gpu_two_rank_exchanges_with_the_gpu_ops(gpu_engine):
     assert got[0][3] + got[1][3] == list(want_values)           # each rank the codes of its own rows
     assert got[0][4] + got[1][4] == want_grams                  # the n-grams across the shard boundary included
     assert got[0][5] == got[1][5] == want_cols
+
+
+@pytest.mark.parametrize("config", ["c3", "c5"])
+def test_gpu_bench_two_ranks_on_one_gpu(config):
+    """bench.py as the driver launches it for N > 1 (torch.distributed.run, one rank per process), here with two ranks on
+    the one GPU over gloo (--backend gloo): the barrier / max-over-ranks / sum-over-ranks plumbing and rank 0's single
+    JSON line."""
+    import json
+    import subprocess
+
+    root = os.path.dirname(HERE)
+    port = 34500 + (os.getpid() % 2000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--config", config, "--rows", "300000", "--steps", "2", "--warmup", "1", "--no-cpu"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1  # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["scaling"] == "weak"
+    if config == "c5":
+        assert d["rank0"]["ngrams"] == d["rank0"]["tokens"]  # (rank 0's last token pairs with rank 1's first)
+    else:
+        assert d["config"]["rows_per_gpu"] == 300000 and abs(d["mstrings_per_s"] * d["ms_per_step"] / 1e3 - 0.6) < 0.01
