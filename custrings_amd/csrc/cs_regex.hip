@@ -43,6 +43,10 @@ thread_local int g_replace_plain_only = 0;  // set by cs_replace around its call
 // the sub-tile at once, instead of walking the DFA
 thread_local unsigned long long g_replace_literal = 0;
 thread_local int g_replace_literal_len = 0;
+// cs_replace_with_backrefs hands its template to the same single-pass kernel (the device copy of the template struct);
+// nullptr: plain replace_re
+thread_local const void* g_backrefs_dev = nullptr;
+thread_local int g_backrefs_text_bytes = 0;
 }
 
 namespace {
@@ -792,6 +796,11 @@ struct StreamArgs {
   unsigned long long* tickets;  // 8 tile counters, 64 bytes apart, zeroed before the launch
   unsigned long long lit;       // UNITS: a literal needle (first byte lowest), litn bytes; litn == 0: none
   int litn;
+  // BREFS (replace_with_backrefs on the unit scan): the template, the capture-group tag image and where both are
+  // staged in LDS (behind the DFA table, inside tbl_bytes)
+  const csvm::BackrefTemplate* tmpl;
+  const int32_t* gtags;
+  int gt_off, gt_words;
 };
 #ifndef CS_STREAM_WAVES
 #define CS_STREAM_WAVES 3
@@ -888,25 +897,46 @@ __device__ __forceinline__ uint32_t unit_xbits16(const uint4& q, uint32_t xpat) 
 // busiest ROW (two dotted quads and a status code), and runs that cannot hold a match are never scanned.
 // PF: 16-byte chunks per lane of the register prefetch (1 KB of the sub-tile each): 6 covers every span the kernel
 // takes; the unit variant also exists with 5 (spans up to 5 KB, the usual case), four registers less where it spills.
-template <bool IN_LDS, bool REP16, bool INPLACE, bool RESCAN = false, bool LONG = false, bool UNITS = false, int PF = cstile::kPfChunks>
-__global__ void __launch_bounds__(256, CS_STREAM_WAVES) k_tdfa_replace_stream(StreamArgs a) {
+// BREFS (a UNITS variant): replace_with_backrefs in the same single pass.  The matches come from the unit scan; every
+// row lane then runs ONE anchored group run per match of its row (Tdfa::group_find_all) to size the expansion of the
+// template, keeps the group ranges of its first two matches, and assembles text pieces and group substrings straight
+// from the staged row -- where the two-pass form ran the groups twice at two waves per SIMD and wrote its output a
+// byte per lane.
+template <bool IN_LDS, bool REP16, bool INPLACE, bool RESCAN = false, bool LONG = false, bool UNITS = false, int PF = cstile::kPfChunks, bool BREFS = false>
+__global__ void __launch_bounds__(256, BREFS ? 2 : CS_STREAM_WAVES) k_tdfa_replace_stream(StreamArgs a) {
   static_assert(!UNITS || (!INPLACE && RESCAN && !LONG), "the unit scan builds on the register-record assembly");
+  static_assert(!BREFS || (UNITS && IN_LDS && !REP16), "the backrefs form is a unit-scan variant");
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   uint8_t* base = reinterpret_cast<uint8_t*>(smem);
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int bm_bytes = (a.cap_in >> 3) + 32;  // one candidate bit per staged byte
-  const int unit_bytes = UNITS ? bm_bytes + kUnitQueue * 4 + 16 : 0;  // second bitmap, unit queue, bail word
+  // second bitmap, unit queue, bail word (+ BREFS: a record of three words per match, a growth counter per row)
+  const int unit_bytes = UNITS ? bm_bytes + kUnitQueue * 4 + 16 + (BREFS ? kUnitQueue * 12 + 64 * 4 : 0) : 0;
   uint8_t* lds_in = base + a.tbl_bytes + (size_t)wv * (a.cap_in + a.cap_out + 64 + bm_bytes + unit_bytes);
   uint8_t* lds_out = lds_in + a.cap_in + 32;
   uint32_t* bitmap = reinterpret_cast<uint32_t*>(lds_out + a.cap_out + 32);
   uint32_t* xbitmap = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(bitmap) + bm_bytes);  // UNITS: "byte == x", later the matches' last bytes
   uint32_t* uqueue = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(xbitmap) + bm_bytes);
   uint32_t* bailw = uqueue + kUnitQueue;  // one bit per row: the lean scan handed a unit of the row over
+  uint32_t* mrec = bailw + 4;              // BREFS: per match (group ranges of groups 1-2, of groups 3-4, match end | ok << 8)
+  uint32_t* rowgrow = mrec + kUnitQueue * 3;  // BREFS: bytes the row's expansions add
   const TCtx c = tsetup<IN_LDS>(a.L, a.flags, smem);  // (block barrier inside when staging)
   const cstd::View& D = c.D;
   const csvm::ProgView& P = c.P;
   const ColView& in = a.in;
   const int rb = a.rb;
+  const int32_t* gt = nullptr;    // BREFS: the group tags and the template text, in LDS
+  const uint8_t* ttext = nullptr;
+  if (BREFS) {
+    int32_t* g = reinterpret_cast<int32_t*>(base + a.gt_off);
+    for (int i = threadIdx.x; i < a.gt_words; i += blockDim.x) g[i] = a.gtags[i];
+    uint8_t* tt = base + a.gt_off + ((a.gt_words * 4 + 15) & ~15);
+    const int tb = a.tmpl->bytes;
+    for (int i = threadIdx.x; i < tb; i += blockDim.x) tt[i] = a.tmpl->text[i];
+    __syncthreads();
+    gt = g;
+    ttext = tt;
+  }
   const bool has_r2 = (((uint32_t)D.img[30] & 255u) <= (((uint32_t)D.img[30] >> 8) & 255u));
   const uint32_t unit_x = (D.units >> 8) & 127u, unit_xpat = unit_x * 0x01010101u;
   // rows per tile: 64, or fewer for the long-row variants (so that the tile fits the prefetch registers)
@@ -1024,7 +1054,18 @@ __global__ void __launch_bounds__(256, CS_STREAM_WAVES) k_tdfa_replace_stream(St
 #pragma unroll
     for (int j = 0; j < PF; ++j)
       if (j * 1024 + lane * 16 < (int)want) {
-        const uint4 q = pf.v[j];
+        uint4 q = pf.v[j];
+        if (tile + 1 == a.nsub && j * 1024 + lane * 16 + 16 > (int)want) {
+          // the column's last piece: what lies behind its last byte is allocation slack, not data (zeros there made the
+          // last sub-tile look as if it held NUL bytes and sent it to the generic scan)
+          const int keep = (int)want - (j * 1024 + lane * 16);  // 1..15 bytes of data
+          auto cut = [&](uint32_t w, int k) {
+            const int left = keep - 4 * k;
+            const uint32_t m = left >= 4 ? 0xFFFFFFFFu : (left <= 0 ? 0u : (1u << (8 * left)) - 1u);
+            return (w & m) | (0x20202020u & ~m);
+          };
+          q = make_uint4(cut(q.x, 0), cut(q.y, 1), cut(q.z, 2), cut(q.w, 3));
+        }
         odd |= q.x | ((q.x - 0x01010101u) & ~q.x);
         odd |= q.y | ((q.y - 0x01010101u) & ~q.y);
         odd |= q.z | ((q.z - 0x01010101u) & ~q.z);
@@ -1065,6 +1106,7 @@ __global__ void __launch_bounds__(256, CS_STREAM_WAVES) k_tdfa_replace_stream(St
     int out_len = 0;
     cstd::U128 uS = cstd::u128(0, 0), uE = cstd::u128(0, 0);  // UNITS: the row's match starts / last bytes
     bool from_masks = false;
+    int mslot = 0;  // BREFS: where the row's matches stand in the match queue / record table
     if (live && !bad) out_len = n;
     if (!bad && !(a.debug & 1)) {
       cstd::Tdfa vm(D, P, lds_in + lead + rbeg, n, (lead + rbeg) & 3);
@@ -1221,11 +1263,85 @@ __global__ void __launch_bounds__(256, CS_STREAM_WAVES) k_tdfa_replace_stream(St
               from_masks = true;
             }
             redo = live && rbail;  // (such a row is scanned whole; nothing of it was recorded above)
+            if (BREFS) {
+              if (__any(redo)) {  // (the template needs the unit route's masks: the host repeats with the two-pass form)
+                if (lane == 0) atomicOr(a.error, 1u | 32u);
+                redo = false;
+              }
+              {
+                // the matches of the sub-tile go through the queue once more, one per lane whatever its row (as the units
+                // did): ONE anchored group run per match sizes its expansion and leaves its group ranges in LDS
+                const csvm::BackrefTemplate& T = *a.tmpl;
+                const int cnt = from_masks ? nm : 0;
+                const int mincl = csdev::wave_inclusive_scan(cnt);
+                const int total_m = __builtin_amdgcn_readlane(mincl, 63);
+                mslot = mincl - cnt;
+                if (total_m > kUnitQueue) {
+                  if (lane == 0) atomicOr(a.error, 1u | 32u);
+                } else {
+                  cstile::wave_lds_fence();  // (the unit lanes are done with the queue)
+                  {
+                    U128 S = uS, E = uE;
+                    int at = mslot;
+                    while (__any(u128_any(S))) {
+                      if (u128_any(S)) {
+                        const int mb = u128_ctz(S), me = u128_ctz(E) + 1;
+                        S = u128_clear_lowest(S);
+                        E = u128_clear_lowest(E);
+                        uqueue[at++] = (uint32_t)lane | ((uint32_t)mb << 8) | ((uint32_t)me << 16);
+                      }
+                    }
+                  }
+                  rowgrow[lane] = 0;
+                  cstile::wave_lds_fence();
+                  for (int u0 = 0; u0 < total_m; u0 += 64) {
+                    const bool act = u0 + lane < total_m;
+                    const uint32_t ent = act ? uqueue[u0 + lane] : 0u;
+                    const int r = (int)(ent & 63u), mb = (int)((ent >> 8) & 255u), me = (int)((ent >> 16) & 255u);
+                    const int rbeg_r = __shfl(rbeg, r, 64), n_r = __shfl(n, r, 64);
+                    if (act) {
+                      const int pu = lead + rbeg_r;
+                      cstd::Tdfa vg(D, P, lds_in + pu, n_r, pu & 3);
+                      int gb[cstd::Tdfa::kGroupBatch], ge[cstd::Tdfa::kGroupBatch], mend = me;
+                      const bool ok = T.nrefs > 0 && vg.group_find_all(mb, gt, 1, T.groups, gb, ge, mend) > 0;
+                      int grow = T.bytes - (me - mb);
+                      for (int j = 0; j < T.nrefs; ++j) {
+                        const int g = T.idx[j];
+                        int x = -1, y = -1;
+                        if (g == 0) {
+                          x = mb;
+                          y = mend;
+                        }
+#pragma unroll
+                        for (int q = 0; q < cstd::Tdfa::kGroupBatch; ++q)
+                          if (g == q + 1 && g <= T.groups) {
+                            x = gb[q];
+                            y = ge[q];
+                          }
+                        if (ok && x >= 0 && y > x) grow += y - x;
+                      }
+                      __hip_atomic_fetch_add(rowgrow + r, (uint32_t)grow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                      auto by = [&](int v) { return (uint32_t)(ok && v >= 0 ? v : 255) & 255u; };
+                      uint32_t* rec = mrec + (u0 + lane) * 3;
+                      rec[0] = by(gb[0]) | (by(ge[0]) << 8) | (by(gb[1]) << 16) | (by(ge[1]) << 24);
+                      rec[1] = by(gb[2]) | (by(ge[2]) << 8) | (by(gb[3]) << 16) | (by(ge[3]) << 24);
+                      rec[2] = by(mend) | ((ok ? 1u : 0u) << 8);
+                    }
+                  }
+                  cstile::wave_lds_fence();
+                  if (from_masks) out_len = n + (int)rowgrow[lane];
+                }
+              }
+            }
             units_done = true;
           }
         }
       }
-      if (!units_done && lean && live && a.maxrepl != 0) {
+      if (BREFS && !units_done) {  // (only the unit route carries the template: the host repeats with the two-pass form)
+        if (lane == 0) atomicOr(a.error, 1u | 32u);
+        redo = false;
+      }
+      if (!BREFS && !units_done && lean && live && a.maxrepl != 0) {
         bool bail = false;
         uint32_t m0, m1, m2;  // candidate bits, bit i = byte i of the row
         if (LONG) {
@@ -1283,7 +1399,54 @@ __global__ void __launch_bounds__(256, CS_STREAM_WAVES) k_tdfa_replace_stream(St
         int oi = lo;                 // byte index into lds_out
         const int pi = lead + rbeg;  // byte index of the row in lds_in
         int copied = 0;
-        if (UNITS && from_masks) {
+        if (BREFS && from_masks) {
+          const csvm::BackrefTemplate& T = *a.tmpl;
+          int mi = 0;
+          while (cstd::u128_any(uS)) {
+            const int mb = cstd::u128_ctz(uS), me = cstd::u128_ctz(uE) + 1;
+            uS = cstd::u128_clear_lowest(uS);
+            uE = cstd::u128_clear_lowest(uE);
+            cstile::lds_copy(lds_out, oi, lds_in, pi + copied, mb - copied);
+            oi += mb - copied;
+            int gb[cstd::Tdfa::kGroupBatch], ge[cstd::Tdfa::kGroupBatch], mend = me;
+            bool ok;
+            {
+              const uint32_t* rec = mrec + (mslot + mi) * 3;
+              const uint32_t lo4 = rec[0], hi4 = rec[1], e4 = rec[2];
+              auto un = [](uint32_t v) { return v == 255u ? -1 : (int)v; };
+              gb[0] = un(lo4 & 255u), ge[0] = un((lo4 >> 8) & 255u), gb[1] = un((lo4 >> 16) & 255u), ge[1] = un(lo4 >> 24);
+              gb[2] = un(hi4 & 255u), ge[2] = un((hi4 >> 8) & 255u), gb[3] = un((hi4 >> 16) & 255u), ge[3] = un(hi4 >> 24);
+              mend = (int)(e4 & 255u);
+              ok = ((e4 >> 8) & 1u) != 0;
+            }
+            int il = 0;
+            for (int j = 0; j < T.nrefs; ++j) {
+              cstile::lds_copy(lds_out, oi, ttext, il, T.pos[j] - il);
+              oi += T.pos[j] - il;
+              il = T.pos[j];
+              const int g = T.idx[j];
+              int x = -1, y = -1;
+              if (g == 0) {
+                x = mb;
+                y = mend;
+              }
+#pragma unroll
+              for (int q = 0; q < cstd::Tdfa::kGroupBatch; ++q)
+                if (g == q + 1 && g <= T.groups) {
+                  x = gb[q];
+                  y = ge[q];
+                }
+              if (ok && x >= 0 && y > x) {
+                cstile::lds_copy(lds_out, oi, lds_in, pi + x, y - x);
+                oi += y - x;
+              }
+            }
+            cstile::lds_copy(lds_out, oi, ttext, il, T.bytes - il);
+            oi += T.bytes - il;
+            copied = me;
+            ++mi;
+          }
+        } else if (UNITS && from_masks) {
           while (cstd::u128_any(uS)) {
             const int mb = cstd::u128_ctz(uS), me = cstd::u128_ctz(uE) + 1;
             uS = cstd::u128_clear_lowest(uS);
@@ -1943,10 +2106,23 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
         // on the number of replacements, rows within the 96-byte masks
         // (not for the literal needles of cs_replace: short needles match densely, and then the per-row kernel with its
         // in-place compaction is the faster one -- 'ab' -> 'x' on the C2 column: 1.25 against 1.77 ms)
-        const bool literal = cs::g_replace_plain_only && cs::g_replace_literal_len > 0 && maxrepl < 0 && !tc.lng && tc.R == 64 && !getenv("CS_NO_LITERAL_SCAN");
-        const bool units = literal || ((re->tdfa[31] & 1) != 0 && maxrepl < 0 && !tc.lng && tc.R == 64 && !cs::g_replace_plain_only && !getenv("CS_NO_UNITS"));
-        const size_t unit_bytes = units ? (size_t)((cap >> 3) + 32 + kUnitQueue * 4 + 16) : 0;
-        const size_t lds1 = tbl + (size_t)(cap + cap_out + 64 + (cap >> 3) + 32 + unit_bytes) * 4 + 16;
+        // replace_with_backrefs on this kernel (cs_replace_with_backrefs left its template in g_backrefs_dev): the unit
+        // scan, groups carried by the DFA (four at most), tables in LDS
+        const bool brefs = cs::g_backrefs_dev != nullptr;
+        if (brefs && !((re->tdfa[31] & 1) != 0 && !tc.lng && tc.R == 64 && tp.d.in_lds && !re->gtags.empty() && re->prog.num_groups <= cstd::Tdfa::kGroupBatch &&
+                       re->gtags.size() * 4 <= 8 * 1024))
+          return -1;
+        const bool literal = !brefs && cs::g_replace_plain_only && cs::g_replace_literal_len > 0 && maxrepl < 0 && !tc.lng && tc.R == 64 && !getenv("CS_NO_LITERAL_SCAN");
+        const bool units = literal || brefs || ((re->tdfa[31] & 1) != 0 && maxrepl < 0 && !tc.lng && tc.R == 64 && !cs::g_replace_plain_only && !getenv("CS_NO_UNITS"));
+        const size_t unit_bytes = units ? (size_t)((cap >> 3) + 32 + kUnitQueue * 4 + 16 + (cs::g_backrefs_dev ? kUnitQueue * 12 + 64 * 4 : 0)) : 0;
+        // (backrefs: the group tags and the template text sit behind the DFA table; the template may grow a row by any
+        // amount: room for twice the input, a launch that needs more says so and the two-pass form takes over)
+        const size_t gt_bytes = brefs ? ((re->gtags.size() * 4 + 15) & ~size_t(15)) + (((size_t)cs::g_backrefs_text_bytes + 31) & ~size_t(15)) : 0;
+        if (brefs) {
+          cap_out = std::max(cap_out, 2 * cap);
+          extra = std::max<int64_t>(extra, col->nbytes);
+        }
+        const size_t lds1 = tbl + gt_bytes + (size_t)(cap + cap_out + 64 + (cap >> 3) + 32 + unit_bytes) * 4 + 16;
         if (lds1 > 150 * 1024) return -1;
         StreamArgs sa{};
         sa.in = view_of(col);
@@ -1974,7 +2150,11 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
         sa.nsub = nsub1;
         sa.cap_in = cap;
         sa.cap_out = cap_out;
-        sa.tbl_bytes = (int)tbl;
+        sa.tbl_bytes = (int)(tbl + gt_bytes);
+        sa.tmpl = static_cast<const csvm::BackrefTemplate*>(cs::g_backrefs_dev);
+        sa.gtags = brefs ? ptr<const int32_t>(re->d_gtags) : nullptr;
+        sa.gt_off = (int)tbl;
+        sa.gt_words = brefs ? (int)re->gtags.size() : 0;
         sa.debug = getenv("CS_TILE_DEBUG") ? atoi(getenv("CS_TILE_DEBUG")) : 0;
         sa.lit = literal ? cs::g_replace_literal : 0;
         sa.litn = literal ? cs::g_replace_literal_len : 0;
@@ -1990,7 +2170,9 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
         };
         auto kern = growth == 0 ? pick(std::true_type{}, std::false_type{})
                                 : roomy ? pick(std::false_type{}, std::true_type{}) : pick(std::false_type{}, std::false_type{});
-        if (units && cap <= 5 * 1024)
+        if (brefs)
+          kern = cap <= 5 * 1024 ? &k_tdfa_replace_stream<true, false, false, true, false, true, 5, true> : &k_tdfa_replace_stream<true, false, false, true, false, true, cstile::kPfChunks, true>;
+        else if (units && cap <= 5 * 1024)
           kern = rb > 8 ? (tp.d.in_lds ? &k_tdfa_replace_stream<true, true, false, true, false, true, 5> : &k_tdfa_replace_stream<false, true, false, true, false, true, 5>)
                         : (tp.d.in_lds ? &k_tdfa_replace_stream<true, false, false, true, false, true, 5> : &k_tdfa_replace_stream<false, false, false, true, false, true, 5>);
         else if (units)
@@ -2460,6 +2642,26 @@ int cs_replace_with_backrefs(const cs_column* col, const cs_regex* cre, const ch
     Buf d_text = dev_alloc(text.size() + 1, s);
     CS_HIP(hipMemcpyAsync(d_text->p, text.c_str(), text.size() + 1, hipMemcpyHostToDevice, s));
     t.text = ptr<const uint8_t>(d_text);
+    // First choice: the single-pass replace kernel in its backrefs form (unit scan, one group run per match, coalesced
+    // output).  It declines patterns without the unit decomposition, more than four groups, long rows; a launch that
+    // runs out of output room or meets a row the unit route hands over reports it, and the two-pass form below runs.
+    if (dfa && re->prog.num_groups >= 1 && !getenv("CS_BACKREFS_TWO_PASS")) {
+      Buf d_t = dev_alloc(sizeof(csvm::BackrefTemplate), s);
+      CS_HIP(hipMemcpyAsync(d_t->p, &t, sizeof(t), hipMemcpyHostToDevice, s));
+      CS_HIP(hipStreamSynchronize(s));  // (`t` lives on this stack frame)
+      cs::g_backrefs_dev = d_t->p;
+      cs::g_backrefs_text_bytes = t.bytes;
+      cs::g_replace_plain_only = 1;  // (single-pass kernel or nothing)
+      cs_column* fast = nullptr;
+      const int rc = cs_replace_re(col, re, "", -1, stream, &fast);
+      cs::g_backrefs_dev = nullptr;
+      cs::g_backrefs_text_bytes = 0;
+      cs::g_replace_plain_only = 0;
+      if (rc == CS_OK) {
+        *out = fast;
+        return;
+      }
+    }
     BackrefArgs a{};
     a.src = RowSrc{view_of(col), d_unicode_flags(), col->nbytes + (col->chars && col->chars->capacity ? 64 : 0)};
     a.gtags = ptr<const int32_t>(re->d_gtags);
