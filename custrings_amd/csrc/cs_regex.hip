@@ -1166,8 +1166,10 @@ __global__ void __launch_bounds__(256, BREFS ? 2 : CS_STREAM_WAVES) k_tdfa_repla
           for (int i = lane * 16; i < bm_bytes; i += 64 * 16) *reinterpret_cast<uint4*>(reinterpret_cast<uint8_t*>(xbitmap) + i) = make_uint4(0, 0, 0, 0);
           cstile::wave_lds_fence();
           {
-            const int p = lane < nrows ? lead + rbeg : (int)want;  // (every row, null or not; the others mark the end of the span)
+            const int p = lane < nrows ? lead + rbeg : (int)want;  // (every row, null or not)
             __hip_atomic_fetch_or(xbitmap + (p >> 5), 1u << (p & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            // and the end of the staged span: the last row's match must not run on into the next sub-tile's bytes
+            if (lane == 0) __hip_atomic_fetch_or(xbitmap + ((int)want >> 5), 1u << ((int)want & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
           }
           cstile::wave_lds_fence();
 #pragma unroll
@@ -2237,7 +2239,7 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
           snprintf(what, sizeof(what), "replace_re (error word %d)", err);
           note_fallback(what);
         }
-      } else if (lds <= 150 * 1024 && growth == 0 && (tc.R == 64 || tc.R == 0)) {  // (cap is the 64-row capacity then)
+      } else if (lds <= 150 * 1024 && growth == 0 && (tc.R == 64 || tc.R == 0) && !cs::g_backrefs_dev) {  // (cap is the 64-row capacity then)
         TileArgs ta{};
         ta.in = view_of(col);
         ta.flags = d_unicode_flags();

@@ -374,3 +374,23 @@ def test_gpu_literal_replace_by_byte_comparison(gpu_engine, oracle_engine, needl
             assert gpu_engine.replace(rows[:cut], needle, repl, -1) == oracle_engine.replace(rows[:cut], needle, repl, -1), (needle, repl, cut)
         # (a 16-byte replacement of a one-byte needle may outgrow the provisioned room: that launch is repeated two-pass)
         assert len(repl) > 3 or _lib.lib.cs_fallback_count() == before
+
+
+def test_gpu_literal_replace_does_not_match_across_sub_tiles(gpu_engine, oracle_engine):
+    """Found by tools/soak_gpu.py: with all 64 rows of a sub-tile present nobody marked the end of the staged span, so the
+    last row's 'a' and the next sub-tile's leading 'b' matched 'ab'.  Rows of equal length whose ends and starts line up."""
+    rows = ["xa", "bx"] * 3000 + ["a", "b"] * 500 + ["ab"]
+    for needle, repl in (("ab", "x"), ("ab", "12345"), ("xab", ""), ("a", "")):
+        assert gpu_engine.replace(rows, needle, repl, -1) == oracle_engine.replace(rows, needle, repl, -1), (needle, repl)
+
+
+def test_gpu_backrefs_on_columns_the_unit_kernel_declines(gpu_engine, oracle_engine):
+    """Found by tools/soak_gpu.py: a column whose 64-row spans exceed the stream kernel's staging fell through to the older
+    tile kernel, which knows nothing of the template and returned a plain replace.  Long rows, then a column with one
+    row beyond the 96-byte masks, then one with a non-ASCII row (the unit route hands those launches over)."""
+    pat, repl = r"(\d+)\.(\d+)", r"\2.\1"
+    long_rows = [("w%d 12.34 " % i) * 30 for i in range(300)]
+    mixed = ["a 1.2 b"] * 200 + ["x" * 120 + " 3.4"] + ["c 5.6"] * 200
+    accents = ["a 1.2 b"] * 100 + ["é 7.8"] + ["c 5.6"] * 100
+    for rows in (long_rows, mixed, accents):
+        assert gpu_engine.replace_with_backrefs(rows, pat, repl) == oracle_engine.replace_with_backrefs(rows, pat, repl)
