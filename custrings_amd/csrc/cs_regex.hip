@@ -1083,20 +1083,25 @@ __global__ void __launch_bounds__(256, BREFS ? 2 : CS_STREAM_WAVES) k_tdfa_repla
     // first look-back poll for the previous sub-tile: issued only now, after the staging above has
     // waited for its own data (vmcnt is in order: a poll issued earlier would sit in front of it)
     CS_PHASE_MARK(10);  // (classification into the bitmaps)
-    cstile::u64 p_first = 0;
-    if (p_tile >= 0 && !(a.debug & (8 | 64))) p_first = scanner ? cstile::status_load(a.excl + p_tile) : cstile::lookback_poll(a.status, p_tile, lane);
+    // Everything fetched here for later -- the poll, the ticket, the offsets two tiles ahead -- is assigned
+    // UNCONDITIONALLY (clamped addresses) and handed to its loop-carried variable only at the bottom of the iteration:
+    // a conditional assignment of a value that is still in flight makes the compiler copy it at the join of the branch,
+    // i.e. wait for the load right behind its issue -- s_waitcnt vmcnt(0), which drained the whole prefetch every
+    // iteration (found in the ISA of every stream kernel; the "prefetch" had never overlapped anything).
+    cstile::u64 p_first, p_second;
+    bool has_second = false;
+    {
+      const long long pt = p_tile >= 0 ? p_tile : 0;
+      p_first = scanner ? cstile::status_load(a.excl + pt) : cstile::lookback_poll(a.status, pt, lane);
+    }
     // keep the memory pipe busy: next sub-tile's chars, and the offsets of the one after
     const bool has_next = t_nxt < a.nsub;
+    t_nn = fixed ? t_nxt + W : tile_of(pending);
+    const unsigned long long pending_new = fixed ? 0ull : take();  // (tickets drawn past the end are harmless)
+    const cstile::TileOffs nn = cstile::load_tile_offsets_r(in.offsets, in.rows, t_nn < a.nsub ? t_nn : a.nsub - 1, R, lane);
     if (has_next) {
       cur = nxt;
       cstile::issue_chars(in.chars, cstile::rl64(cur.o0, 0), cstile::rl64(cur.o1, 63), lane, pf);
-      if (fixed) {
-        t_nn = t_nxt + W;
-      } else {
-        t_nn = tile_of(pending);
-        if (t_nn < a.nsub) pending = take();
-      }
-      if (t_nn < a.nsub) nxt = cstile::load_tile_offsets_r(in.offsets, in.rows, t_nn, R, lane);
     }
     cstile::wave_lds_fence();
     CS_PHASE_MARK(0);
@@ -1250,7 +1255,9 @@ __global__ void __launch_bounds__(256, BREFS ? 2 : CS_STREAM_WAVES) k_tdfa_repla
             CS_PHASE_MARK(8);
             // the previous tile's prefix: the poll issued before the scan came too early more often than not (the
             // scanner wave needs every earlier aggregate first); this one has the extraction below to arrive in
-            if (scanner && p_tile >= 0 && !(a.debug & (8 | 64)) && (p_first >> 62) == 0) p_first = cstile::status_load(a.excl + p_tile);
+            // (into its own variable, unconditionally: see the note at the first poll)
+            p_second = cstile::status_load(a.excl + (p_tile >= 0 ? p_tile : 0));
+            has_second = scanner;
             // -- row lanes again: the row's matches from the start / last-byte bits
             uint32_t s0, s1, s2, e0, e1, e2;
             cstile::row_bits96(bitmap, lead + rbeg, n, s0, s1, s2);
@@ -1393,7 +1400,9 @@ __global__ void __launch_bounds__(256, BREFS ? 2 : CS_STREAM_WAVES) k_tdfa_repla
     } else {
       if (!(a.debug & 8)) cstile::lookback_publish(a.status, tile, total, lane);
       CS_PHASE_MARK(2);
-      if (p_tile >= 0) finish_pending((a.debug & 64) ? (scanner ? cstile::status_load(a.excl + p_tile) : cstile::lookback_poll(a.status, p_tile, lane)) : p_first);
+      if (p_tile >= 0)
+        finish_pending((a.debug & 64) ? (scanner ? cstile::status_load(a.excl + p_tile) : cstile::lookback_poll(a.status, p_tile, lane))
+                                      : (has_second && (p_first >> 62) == 0 ? p_second : p_first));
       CS_PHASE_MARK(3);
       if (INPLACE) {
         if (live && !(a.debug & 2)) cstile::lds_copy(lds_out, lo, lds_in, lead + rbeg, out_len);
@@ -1508,6 +1517,8 @@ __global__ void __launch_bounds__(256, BREFS ? 2 : CS_STREAM_WAVES) k_tdfa_repla
     if (!has_next) break;
     tile = t_nxt;
     t_nxt = t_nn;
+    nxt = nn;
+    pending = pending_new;
   }
   if (p_tile >= 0) finish_pending((a.debug & 8) ? 0 : (scanner ? cstile::status_load(a.excl + p_tile) : cstile::lookback_poll(a.status, p_tile, lane)));
 #if defined(CS_PHASE_PROF)
@@ -1620,10 +1631,12 @@ __global__ void __launch_bounds__(256, (UNITS || MODE == 3) ? 4 : 1) k_tdfa_scan
         if (UNITS && unit_x != 0) cstile::put_bits16(xbitmap, j * 1024 + lane * 16, unit_xbits16(q, unit_xpat));
       }
     const bool has_next = tile + 1 < tile_end;
+    // (the offsets two tiles ahead are fetched unconditionally, at a clamped index, and become `nxt` at the bottom of
+    // the iteration: see the note in k_tdfa_replace_stream)
+    const cstile::TileOffs nn = cstile::load_tile_offsets_r(in.offsets, in.rows, tile + 2 < tile_end ? tile + 2 : tile_end - 1, R, lane);
     if (has_next) {
       cur = nxt;
       cstile::issue_chars(in.chars, cstile::rl64(cur.o0, 0), cstile::rl64(cur.o1, 63), lane, pf);
-      if (tile + 2 < tile_end) nxt = cstile::load_tile_offsets_r(in.offsets, in.rows, tile + 2, R, lane);
     }
     cstile::wave_lds_fence();
     int v = 0;
@@ -1806,6 +1819,7 @@ __global__ void __launch_bounds__(256, (UNITS || MODE == 3) ? 4 : 1) k_tdfa_scan
     cstile::wave_lds_fence();  // the next tile overwrites lds_in
     if (!has_next) break;
     ++tile;
+    nxt = nn;
   }
   const int t = wave_reduce_sum(hits);
   if (lane == 0 && t) atomicAdd(a.found, (unsigned long long)t);

@@ -565,10 +565,14 @@ __global__ void __launch_bounds__(256, CS_EMIT2_WAVES) k_split_emit2(Emit2Args a
     const long long my_base = my_pos;
     const int my_lead = (int)((uintptr_t)(my_chars + my_base) & 15);
     const bool has_next = tile + W < tile_end;
+    // The offsets two sub-tiles ahead are fetched unconditionally (clamped index) and become `nxt` only at the bottom
+    // of the iteration: assigned under a condition, a value still in flight is copied at the join of the branch, and
+    // the compiler waited for it there -- s_waitcnt vmcnt(0) right behind the issue of the whole prefetch, every
+    // iteration (the prefetch never overlapped the work it was meant to hide behind).
+    const cstile::TileOffs nn = cstile::load_tile_offsets(in.offsets, in.rows, tile + 2 * W < tile_end ? tile + 2 * W : tile_end - 1, lane);
     if (has_next) {
       cur = nxt;
       cstile::issue_chars(in.chars, cstile::rl64(cur.o0, 0), cstile::rl64(cur.o1, 63), lane, pf);
-      if (tile + 2 * W < tile_end) nxt = cstile::load_tile_offsets(in.offsets, in.rows, tile + 2 * W, lane);
     }
     cstile::wave_lds_fence();
     CS_PHASE_MARK(0);
@@ -655,6 +659,7 @@ __global__ void __launch_bounds__(256, CS_EMIT2_WAVES) k_split_emit2(Emit2Args a
     if (lane < a.ncols) *cstile::as_global(reinterpret_cast<unsigned long long*>(my_valid + tile * 8)) = my_vmask;
     if (!has_next) break;
     tile += W;
+    nxt = nn;
   }
 #if defined(CS_PHASE_PROF)
   CS_PHASE_MARK(5);
