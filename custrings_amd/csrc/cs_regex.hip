@@ -231,6 +231,55 @@ __global__ void __launch_bounds__(256) k_extract_write(ColView in, int groups, c
   }
 }
 
+// The same on 64-row sub-tiles, a wave each (columns whose sub-tiles fit the staging buffer): the sub-tile's bytes
+// arrive in LDS with whole 16-byte loads; per output column the row lanes put their span into the column's region
+// with exact-size stores at any alignment (16 / 8 / 4 / 2 / 1 bytes from unaligned 16-byte reads of the staged row)
+// and the wave flushes the region -- the 64 rows' spans are consecutive in the column's chars -- with aligned
+// 16-byte stores.  The thread-per-row kernel above reads every row byte by byte from 64 different cache lines.
+struct SpanWriteArgs {
+  ColView in;
+  int ncols;
+  const int32_t* begins;
+  const int32_t* lens;
+  ExtractOut out;
+  long long nsub;
+  int cap;
+};
+__global__ void __launch_bounds__(256) k_spans_write_tile(SpanWriteArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  uint8_t* lds_in = reinterpret_cast<uint8_t*>(smem) + (size_t)wv * (2 * a.cap + 64);
+  uint8_t* region = lds_in + a.cap + 32;
+  const ColView& in = a.in;
+  for (long long tile = (long long)blockIdx.x * 4 + wv; tile < a.nsub; tile += (long long)gridDim.x * 4) {
+    const long long r0 = tile * 64;
+    const int nrows = (int)min(64ll, in.rows - r0);
+    const cstile::TileOffs t = cstile::load_tile_offsets_r(in.offsets, in.rows, tile, 64, lane);
+    const long long g0 = cstile::rl64(t.o0, 0), g1 = cstile::rl64(t.o1, 63);
+    const int lead = (int)((uintptr_t)(in.chars + g0) & 15);
+    const int want = (int)(g1 - g0) + lead;
+    for (int i = lane * 16; i < want; i += 64 * 16) *reinterpret_cast<uint4*>(lds_in + i) = *reinterpret_cast<const uint4*>(in.chars + (g0 - lead) + i);
+    const int rpos = lead + (int)(t.o0 - g0);
+    cstile::wave_lds_fence();
+    for (int g = 0; g < a.ncols; ++g) {
+      const long long at = (long long)g * in.rows + r0 + lane;
+      int len = lane < nrows ? a.lens[at] : 0;
+      const int beg = len > 0 ? a.begins[at] : 0;
+      if (len < 0) len = 0;
+      const long long d0 = a.out.off[g][r0 + min(lane, nrows)];
+      const long long base = cstile::rl64(d0, 0);
+      const int total = (int)(cstile::rl64(d0, 63) - base) + __builtin_amdgcn_readlane(len, 63);
+      if (total == 0) continue;
+      const int di = (int)(d0 - base);
+      for (int k = 0; k < len; k += 16)
+        cstile::lds_put16(region + di + k, *reinterpret_cast<const cstile::lds_u32x4u*>(lds_in + rpos + beg + k), len - k);
+      cstile::wave_lds_fence();
+      cstile::wave_flush_shift(a.out.chars[g] + base, total, region, lane);
+      cstile::wave_lds_fence();  // the next column re-uses the region
+    }
+  }
+}
+
 // ---- tagged-DFA kernels (regex_tdfa.h): tables staged in LDS, no per-thread lists ----
 struct TLaunch {
   const int32_t* tdfa;   // device image
@@ -2340,6 +2389,31 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
   });
 }
 
+// The spans' bytes into the output columns (extract / findall): 64-row sub-tiles through LDS when the column's
+// sub-tiles fit the staging buffer, else the thread-per-row kernel.
+void write_spans(const cs_column* col, int ncols, const int32_t* begins, const int32_t* lens, const ExtractOut& eo, hipStream_t s) {
+  const int64_t rows = col->rows;
+  const TileChoice tc = choose_tile(col, s);
+  ProfScope ps("k_extract_write", s);
+  if (tc.R == 64 && !getenv("CS_SPANS_ROWWISE")) {
+    SpanWriteArgs a{};
+    a.in = view_of(col);
+    a.ncols = ncols;
+    a.begins = begins;
+    a.lens = lens;
+    a.out = eo;
+    a.nsub = (rows + 63) / 64;
+    a.cap = tc.cap;
+    const size_t lds = (size_t)4 * (2 * tc.cap + 64);
+    if (lds > 48 * 1024)
+      CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spans_write_tile), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const unsigned grid = (unsigned)std::min<long long>((a.nsub + 3) / 4, 256 * 16);
+    hipLaunchKernelGGL(k_spans_write_tile, dim3(grid), dim3(256), lds, s, a);
+  } else {
+    hipLaunchKernelGGL(k_extract_write, dim3(blocks_for(rows)), dim3(256), 0, s, view_of(col), ncols, begins, lens, eo);
+  }
+}
+
 // NVStrings::extract(pattern, results) (NVStrings.h:682; extract.cu:69-151): one column per
 // capture group; a pattern without groups, or an empty column, yields no columns.
 int cs_extract(const cs_column* col, const cs_regex* cre, cs_stream stream, cs_column*** out_cols, int* ncols_out) {
@@ -2461,11 +2535,7 @@ int cs_extract(const cs_column* col, const cs_regex* cre, cs_stream stream, cs_c
       eo.chars[g] = ptr<uint8_t>(o->chars);
       cols.push_back(std::move(o));
     }
-    {
-      ProfScope ps("k_extract_write", s);
-      hipLaunchKernelGGL(k_extract_write, dim3(blocks_for(rows)), dim3(256), 0, s, view_of(col), groups, ptr<int32_t>(begins),
-                         ptr<int32_t>(lens), eo);
-    }
+    write_spans(col, groups, ptr<int32_t>(begins), ptr<int32_t>(lens), eo, s);
     CS_HIP(hipGetLastError());
     CS_HIP(hipStreamSynchronize(s));  // arena / span buffers
     cs_column** arr = (cs_column**)malloc(sizeof(cs_column*) * groups);
@@ -2609,9 +2679,7 @@ int cs_findall(const cs_column* col, const cs_regex* cre, cs_stream stream, cs_c
         eo.chars[k] = ptr<uint8_t>(o->chars);
         cols.push_back(std::move(o));
       }
-      ProfScope ps("k_extract_write", s);
-      hipLaunchKernelGGL(k_extract_write, dim3(blocks_for(rows)), dim3(256), 0, s, view_of(col), nk,
-                         ptr<int32_t>(begins) + (size_t)k0 * rows, ptr<int32_t>(lens) + (size_t)k0 * rows, eo);
+      write_spans(col, nk, ptr<int32_t>(begins) + (size_t)k0 * rows, ptr<int32_t>(lens) + (size_t)k0 * rows, eo, s);
     }
     CS_HIP(hipGetLastError());
     CS_HIP(hipStreamSynchronize(s));
