@@ -394,3 +394,29 @@ def test_gpu_backrefs_on_columns_the_unit_kernel_declines(gpu_engine, oracle_eng
     accents = ["a 1.2 b"] * 100 + ["é 7.8"] + ["c 5.6"] * 100
     for rows in (long_rows, mixed, accents):
         assert gpu_engine.replace_with_backrefs(rows, pat, repl) == oracle_engine.replace_with_backrefs(rows, pat, repl)
+
+
+@pytest.mark.parametrize("shape", ["short", "long_spans", "beyond_staging"])
+def test_gpu_span_bytes_written_by_sub_tiles(gpu_engine, oracle_engine, shape, monkeypatch):
+    """extract / findall write the spans' bytes through 64-row sub-tiles in LDS (k_spans_write_tile) when the column's
+    sub-tiles fit the staging buffer: spans of 1 .. 90 bytes at every alignment, null and empty rows, several sub-tiles and
+    a ragged last one; a column whose sub-tiles do not fit takes the thread-per-row kernel.  Both against the oracle,
+    and against each other with the tile kernel switched off."""
+    rnd = random.Random(4242)
+    if shape == "short":
+        rows = [" ".join("%d.%d" % (rnd.randrange(300), rnd.randrange(300)) for _ in range(rnd.randrange(4))) for _ in range(1000)]
+    elif shape == "long_spans":
+        rows = ["".join(rnd.choice("abcdefgh") * rnd.randrange(1, 45) + rnd.choice([" ", "  ", ""]) for _ in range(2))[:90] for _ in range(777)]
+    else:
+        rows = [("tok%d " % i) * 40 for i in range(200)]
+    rows[5] = None
+    rows[70] = ""
+    rows[-1] = None
+    for pat in (r"\w+", r"\d+\.\d+", r"[a-h]{17,}"):
+        want = oracle_engine.findall(rows, pat)
+        assert gpu_engine.findall(rows, pat) == want, pat
+    for pat in (r"(\w+) +(\w+)", r"(\d+)\.(\d+)"):
+        want = oracle_engine.extract(rows, pat)
+        assert gpu_engine.extract(rows, pat) == want, pat
+    monkeypatch.setenv("CS_SPANS_ROWWISE", "1")
+    assert gpu_engine.findall(rows, r"\w+") == oracle_engine.findall(rows, r"\w+")
