@@ -1611,8 +1611,8 @@ struct ScanStreamArgs {
 // UNITS (MODE 0 and 2, !LONG): the unit scan of the replace kernel -- units queued by the row lanes, one unit per lane
 // whatever its row, the per-row result summed (count_re) / OR-ed (contains_re) in LDS.
 template <int MODE, bool IN_LDS, bool LONG = false, bool UNITS = false>
-__global__ void __launch_bounds__(256, (UNITS || MODE == 3) ? 4 : 1) k_tdfa_scan_stream(ScanStreamArgs a) {
-  static_assert(!UNITS || ((MODE == 0 || MODE == 2) && !LONG), "unit scan: contains_re / count_re on rows within the 96-byte masks");
+__global__ void __launch_bounds__(256, (UNITS && MODE == 3) ? 3 : (UNITS || MODE == 3) ? 4 : 1) k_tdfa_scan_stream(ScanStreamArgs a) {
+  static_assert(!UNITS || ((MODE == 0 || MODE == 2 || MODE == 3) && !LONG), "unit scan: contains_re / count_re / findall on rows within the 96-byte masks");
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   uint8_t* base = reinterpret_cast<uint8_t*>(smem);
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -1790,7 +1790,58 @@ __global__ void __launch_bounds__(256, (UNITS || MODE == 3) ? 4 : 1) k_tdfa_scan
         ++k;
       };
       bool units_done = false;
-      if (UNITS) {
+      if (UNITS && MODE == 3) {
+        // findall: the units leave each match's first and last byte in the two bitmaps (as in the replace kernel);
+        // the row lanes read their matches back in order
+        if (lean && (D.units & 1u)) {  // (wave-uniform)
+          using namespace cstd;
+          uint32_t m0, m1, m2;
+          const int total_units = unit_discover(D, bitmap, xbitmap, lead + rbeg, n, lane, uqueue, m0, m1, m2, [&] {
+            for (int i = lane * 16; i < bm_bytes; i += 64 * 16) {
+              *reinterpret_cast<uint4*>(reinterpret_cast<uint8_t*>(bitmap) + i) = make_uint4(0, 0, 0, 0);
+              *reinterpret_cast<uint4*>(reinterpret_cast<uint8_t*>(xbitmap) + i) = make_uint4(0, 0, 0, 0);
+            }
+            if (lane < 2) bailw[lane] = 0;
+          });
+          if (total_units >= 0) {
+            for (int u0 = 0; u0 < total_units; u0 += 64) {
+              const bool act = u0 + lane < total_units;
+              int r, rbeg_r, n_r;
+              uint32_t c0, c1, c2;
+              unit_take(act ? uqueue[u0 + lane] : 0u, rbeg, n, m0, m1, m2, r, rbeg_r, n_r, c0, c1, c2);
+              if (act) {
+                const int pu = lead + rbeg_r;
+                cstd::Tdfa vu(D, P, lds_in + pu, n_r, pu & 3);
+                bool ubail = false;
+                auto recu = [&](int mb, int me, int) {
+                  const int ps = pu + mb, pe = pu + me - 1;
+                  __hip_atomic_fetch_or(bitmap + (ps >> 5), 1u << (ps & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                  __hip_atomic_fetch_or(xbitmap + (pe >> 5), 1u << (pe & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                };
+                vu.scan_lean_dispatch(-1, c0, c1, c2, recu, ubail);
+                if (ubail) __hip_atomic_fetch_or(bailw + (r >> 5), 1u << (r & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+              }
+            }
+            cstile::wave_lds_fence();
+            uint32_t s0, s1, s2, e0, e1, e2;
+            cstile::row_bits96(bitmap, lead + rbeg, n, s0, s1, s2);
+            cstile::row_bits96(xbitmap, lead + rbeg, n, e0, e1, e2);
+            const bool rbail = ((bailw[lane >> 5] >> (lane & 31)) & 1u) != 0;
+            if (live && !rbail) {
+              U128 S = u128(s0 | ((unsigned long long)s1 << 32), s2), E = u128(e0 | ((unsigned long long)e1 << 32), e2);
+              while (u128_any(S)) {
+                const int mb = u128_ctz(S), me = u128_ctz(E) + 1;
+                S = u128_clear_lowest(S);
+                E = u128_clear_lowest(E);
+                span(mb, me, 0);
+              }
+              v = k;
+            }
+            redo = live && rbail;  // (such a row is scanned whole)
+            units_done = true;
+          }
+        }
+      } else if (UNITS) {
         if (lean && (D.units & 1u)) {  // (wave-uniform)
           constexpr int KIND = MODE == 0 ? cstd::Tdfa::K_CONTAINS : cstd::Tdfa::K_COUNT;
           uint32_t m0, m1, m2;
@@ -2586,7 +2637,9 @@ int cs_findall(const cs_column* col, const cs_regex* cre, cs_stream stream, cs_c
       TPlan tp = tplan(re, rows, s);
       const TileChoice tc = choose_tile(col, s);
       const int cap = tc.cap;
-      const size_t lds = tp.lds_bytes + (size_t)(cap + 32 + (cap >> 3) + 32) * 4;
+      // the unit scan where the tagged DFA offers the decomposition (as count_re)
+      const bool units = (re->tdfa[31] & 1) != 0 && !tc.lng && tc.R == 64 && !getenv("CS_NO_UNITS");
+      const size_t lds = tp.lds_bytes + (size_t)(cap + 32 + (cap >> 3) + 32 + (units ? (cap >> 3) + 32 + kUnitQueue * 4 + 64 * 4 + 16 : 0)) * 4;
       if (tp.d.in_lds && tc.R && lds <= 150 * 1024) {
         Buf hits = dev_alloc(8, s);
         CS_HIP(hipMemsetAsync(hits->p, 0, 8, s));
@@ -2601,6 +2654,7 @@ int cs_findall(const cs_column* col, const cs_regex* cre, cs_stream stream, cs_c
         sa.tbl_bytes = (int)tp.lds_bytes;
         sa.maxp = ptr<int>(dmax);
         auto kern = tc.lng ? &k_tdfa_scan_stream<3, true, true> : &k_tdfa_scan_stream<3, true, false>;
+        if (units) kern = &k_tdfa_scan_stream<3, true, false, true>;
         if (lds > 48 * 1024)
           CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         const unsigned grid = resident_grid(reinterpret_cast<const void*>(kern), lds, (sa.nsub + 3) / 4);
