@@ -449,6 +449,21 @@ struct Tdfa {
   // transition that moves no slot and passes no bracket of ANY tracked group -- costs one more table word per
   // group per step; everything else is paid once instead of once per group.
   static constexpr int kGroupBatch = 4;
+  // v_perm_b32: result byte j = byte sel[j] of {hi : lo} for sel[j] in 0..7, 0x00 for 12, 0xFF for 13 and above
+  // (the selector values 8..11 are not used here)
+  static CS_HD uint32_t perm_bytes(uint32_t hi, uint32_t lo, uint32_t sel) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_perm(hi, lo, sel);
+#else
+    uint32_t r = 0;
+    for (int j = 0; j < 4; ++j) {
+      const uint32_t c = (sel >> (8 * j)) & 255u;
+      const uint32_t b = c < 4 ? (lo >> (8 * c)) & 255u : c < 8 ? (hi >> (8 * (c - 4))) & 255u : c == 12 ? 0u : 255u;
+      r |= b << (8 * j);
+    }
+    return r;
+#endif
+  }
   CS_HD int group_find_all(int from, const int32_t* G, int first, int count, int* gb, int* ge, int& mend) {
     const uint32_t* tags0 = (const uint32_t*)(G + 36) + (long long)(first - 1) * (long long)G[3];
     const long long tstride = (long long)G[3];
@@ -504,18 +519,20 @@ struct Tdfa {
         const uint32_t keep = e_keep(e);
         if (keep != 15u) og = (0x3210u & ~(0xFFFFu << (4 * keep))) | (0xFFFFu << (4 * keep));
       }
+      // The slots move as whole bytes: ONE byte permute per group and side (v_perm_b32).  Selector byte j = the
+      // origin slot (0..3: that byte of the old word), 15 for a new thread (-> 0xFF, never set), 4 where the
+      // slot passes the group's bracket here (-> a byte of `posb`, the position).
+      const uint32_t sel = (og & 0xFu) | ((og & 0xF0u) << 4) | ((og & 0xF00u) << 8) | ((og & 0xF000u) << 12);
+      const uint32_t posb = (uint32_t)pos * 0x01010101u;
+      auto spread = [](uint32_t x) -> uint32_t {  // bits 0, 2, 4, 6 -> bytes 0..3 all ones
+        return (((x | (x << 6) | (x << 12) | (x << 18)) & 0x01010101u)) * 255u;
+      };
 #pragma unroll
       for (int g = 0; g < kGroupBatch; ++g)
         if (g < count) {
-          uint32_t nx = 0, ny = 0;
-#pragma unroll
-          for (int j = 0; j < kMaxSlots; ++j) {
-            const uint32_t o = (og >> (4 * j)) & 15u;
-            nx |= (((tg[g] >> (2 * j)) & 1u) ? (uint32_t)pos : pick8(px[g], o)) << (8 * j);
-            ny |= (((tg[g] >> (2 * j + 1)) & 1u) ? (uint32_t)pos : pick8(py[g], o)) << (8 * j);
-          }
-          px[g] = nx;
-          py[g] = ny;
+          const uint32_t bm = spread(tg[g] & 0x55u), em = spread((tg[g] >> 1) & 0x55u);
+          px[g] = perm_bytes(posb, px[g], (sel & ~bm) | (0x04040404u & bm));
+          py[g] = perm_bytes(posb, py[g], (sel & ~em) | (0x04040404u & em));
         }
       state = e & E_STATE;
       return (e & E_STOP) != 0;
