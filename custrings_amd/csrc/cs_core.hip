@@ -456,7 +456,7 @@ __global__ void k_max_span64(const int64_t* __restrict__ offsets, int64_t rows, 
     v = (int)(offsets[r1] - offsets[r0] > 0x7fffffff ? 0x7fffffff : offsets[r1] - offsets[r0]);
   }
   int m = block_reduce_max(v);
-  if (threadIdx.x == 0 && m) atomicMax(out, (unsigned long long)m);
+  if (threadIdx.x == 0 && (unsigned long long)m > __hip_atomic_load(out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(out, (unsigned long long)m);
 }
 // Number of 256-thread workgroups of `kern` that are resident at once on this device
 // (capped by `wanted`): the persistent kernels' look-back needs every wave of the grid
@@ -496,7 +496,9 @@ __global__ void k_max_span_rows(const int64_t* __restrict__ offsets, int64_t row
     v = (int)(offsets[r1] - offsets[r0] > 0x7fffffff ? 0x7fffffff : offsets[r1] - offsets[r0]);
   }
   int m = block_reduce_max(v);
-  if (threadIdx.x == 0 && m) atomicMax(out, (unsigned long long)m);
+  // (only a workgroup that would raise the maximum issues the same-address atomic: 390 K of them in a row cost
+  // 4.4 ms on a 100M-row column, more than most kernels that ask for this number)
+  if (threadIdx.x == 0 && (unsigned long long)m > __hip_atomic_load(out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(out, (unsigned long long)m);
 }
 int64_t max_span_rows(const cs_column* c, int per, hipStream_t s) {
   if (per == 64) return max_span64(c, s);

@@ -196,8 +196,9 @@ __global__ void k_ngram_spans(const int64_t* __restrict__ off, long long ng, int
   }
   const int mi = block_reduce_max(vin), mo = block_reduce_max(vout);
   if (threadIdx.x == 0) {
-    if (mi) atomicMax(maxima, (unsigned long long)mi);
-    if (mo) atomicMax(maxima + 1, (unsigned long long)mo);
+    // (only a workgroup that would raise a maximum issues the same-address atomic)
+    if ((unsigned long long)mi > __hip_atomic_load(maxima, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(maxima, (unsigned long long)mi);
+    if ((unsigned long long)mo > __hip_atomic_load(maxima + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(maxima + 1, (unsigned long long)mo);
   }
 }
 

@@ -626,7 +626,7 @@ __global__ void __launch_bounds__(256) k_max_i32(const int32_t* __restrict__ v, 
   int m = 0;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) m = max(m, v[i]);
   for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o));
-  if ((threadIdx.x & 63) == 0 && m > 0) atomicMax(out, m);
+  if ((threadIdx.x & 63) == 0 && m > __hip_atomic_load(out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(out, m);
 }
 template <class VM>
 __device__ __forceinline__ void findall_row(VM& vm, int64_t r, int64_t rows, int ncols, int32_t* __restrict__ begins,
