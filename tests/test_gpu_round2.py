@@ -420,3 +420,25 @@ def test_gpu_span_bytes_written_by_sub_tiles(gpu_engine, oracle_engine, shape, m
         assert gpu_engine.extract(rows, pat) == want, pat
     monkeypatch.setenv("CS_SPANS_ROWWISE", "1")
     assert gpu_engine.findall(rows, r"\w+") == oracle_engine.findall(rows, r"\w+")
+
+
+def test_gpu_offsets_from_lengths_beyond_32_bits(gpu_engine):
+    """The chunked lengths -> offsets scan (cs_core.hip) runs a chunk's inner sums in 32 bits only when the chunk's total
+    fits; 200 copies of a 16 MiB row put 3.1 GiB into one 2048-row chunk.  Rows gathered from both ends of the result
+    must come back whole, and the scan must also be right at sizes around a chunk (2047 .. 2049 rows) and a workgroup."""
+    from custrings_amd import nvstrings
+
+    big = "a" * (1 << 24)
+    s = nvstrings.to_device([big, "b", None, ""])
+    g = s.gather([0] * 200 + [1, 2, 3, 0])
+    assert g.size() == 204
+    lens = np.zeros(204, dtype=np.int32)
+    assert g.byte_count(lens.ctypes.data) == 201 * (1 << 24) + 1
+    assert lens[:200].tolist() == [1 << 24] * 200 and lens[200:].tolist() == [1, -1, 0, 1 << 24]
+    tail = g.sublist(199, 204).to_host()
+    assert tail[0] == big and tail[1:4] == ["b", None, ""] and tail[4] == big
+    for rows in (1, 2047, 2048, 2049, 8191, 8193, 70_001):
+        src = ["x" * (i % 7) if i % 11 else None for i in range(rows)]
+        c = nvstrings.to_device(src)
+        idx = list(range(rows - 1, -1, -1))
+        assert c.gather(idx).to_host() == src[::-1], rows
