@@ -282,6 +282,9 @@ void offsets_from_lengths_segmented(const int32_t* lens, int64_t n, int segs, in
 // the 0.3 ms the 1.6 GB of traffic needs.  A one-pass form with a decoupled look-back per 1024-length tile was
 // measured slower than either -- 1.23 ms: with thousands of small tiles in flight each walks many windows back.)
 constexpr int kChunkRounds = 8, kChunk = kChunkRounds * 256;
+// (gfx950 takes 16-byte global accesses at dword alignment: a column's lengths may start anywhere in a span array)
+typedef int int4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+typedef long long ll2_a8 __attribute__((ext_vector_type(2), aligned(8)));
 struct ChunkVals {
   int v[kChunkRounds][4];
 };
@@ -290,7 +293,7 @@ __device__ __forceinline__ void load_chunk(const int32_t* __restrict__ lens, int
   for (int j = 0; j < kChunkRounds; ++j) {
     const int64_t i = base + j * 256 + lane * 4;
     if (i + 3 < n) {
-      const int4 q = *reinterpret_cast<const int4*>(lens + i);
+      const int4_a4 q = *reinterpret_cast<const int4_a4*>(lens + i);
       c.v[j][0] = q.x;
       c.v[j][1] = q.y;
       c.v[j][2] = q.z;
@@ -349,8 +352,8 @@ __global__ void __launch_bounds__(256) k_chunk_offsets(const int32_t* __restrict
 #pragma unroll
     for (int k = 0; k < 4; ++k) o[k + 1] = o[k] + c.v[j][k];
     if (i + 3 < n) {
-      *reinterpret_cast<longlong2*>(offsets + i) = make_longlong2(o[0], o[1]);
-      *reinterpret_cast<longlong2*>(offsets + i + 2) = make_longlong2(o[2], o[3]);
+      *reinterpret_cast<ll2_a8*>(offsets + i) = ll2_a8{o[0], o[1]};
+      *reinterpret_cast<ll2_a8*>(offsets + i + 2) = ll2_a8{o[2], o[3]};
     } else {
 #pragma unroll
       for (int k = 0; k < 4; ++k)
@@ -370,7 +373,7 @@ int64_t offsets_from_lengths(const int32_t* lens, int64_t n, int64_t* offsets, h
     CS_HIP(hipMemsetAsync(offsets, 0, sizeof(int64_t), s));
     return 0;
   }
-  if (!block_sums && ((uintptr_t)lens & 15) == 0 && ((uintptr_t)offsets & 15) == 0 && !getenv("CS_SCAN_BY_WORKGROUPS")) {
+  if (!block_sums && !getenv("CS_SCAN_BY_WORKGROUPS")) {
     const int64_t nchunks = (n + kChunk - 1) / kChunk;
     Buf sums = dev_alloc(sizeof(int64_t) * nchunks, s);
     Buf total = dev_alloc(sizeof(int64_t), s);
