@@ -10,6 +10,9 @@
 // Workgroups walk the rows grid-stride so the arena is bounded by the grid.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+#include <list>
+
 #include <cstring>
 
 #include "cs_internal.h"
@@ -34,6 +37,7 @@ struct cs_regex {
   Buf d_tdfa;
   Buf d_gtags;
   bool empty_pattern = false;
+  std::atomic<int> refs{1};    // handles given out by cs_regex_compile + one for the list of kept patterns
 };
 
 namespace cs {
@@ -2110,17 +2114,47 @@ extern "C" {
 int cs_regex_compile(const char* pattern, cs_regex** out) {
   return guard([&] {
     if (!pattern || !out) fail(CS_ERR_INVALID_ARG, "regex pattern cannot be null");
-    auto* re = new cs_regex;
+    // A compiled pattern is immutable (the device images are uploaded once, under a lock) and costs 0.6 - 1.6 ms of host
+    // time to build -- a tenth of the replace_re kernel on 100M rows, more than the kernel on a few million -- while
+    // the callers above the C ABI compile per call, as the reference does.  The last 32 patterns are kept; a handle
+    // is a counted reference to the shared object.
+    static std::mutex& mu = *new std::mutex;  // (never destroyed: see the note on process exit in cs_core.hip's buffer cache)
+    static auto& kept = *new std::list<std::pair<std::string, cs_regex*>>;
+    const bool keep = !getenv("CS_REGEX_NO_CACHE");
+    if (keep) {
+      std::lock_guard<std::mutex> lk(mu);
+      for (auto it = kept.begin(); it != kept.end(); ++it)
+        if (it->first == pattern) {
+          kept.splice(kept.begin(), kept, it);
+          it->second->refs.fetch_add(1);
+          *out = it->second;
+          return;
+        }
+    }
+    std::unique_ptr<cs_regex> re(new cs_regex);
     re->empty_pattern = *pattern == 0;
     re->prog = csrx::compile(pattern);
     re->blob = re->prog.to_blob();
     re->image = re->prog.to_device_image(h_unicode_flags());
     re->tdfa = csrx::build_tdfa(re->prog, re->image, h_unicode_flags(), &re->gtags);
-    *out = re;
+    cs_regex* dropped = nullptr;
+    if (keep) {
+      std::lock_guard<std::mutex> lk(mu);
+      re->refs.store(2);
+      kept.emplace_front(pattern, re.get());
+      if (kept.size() > 32) {
+        dropped = kept.back().second;
+        kept.pop_back();
+      }
+    }
+    *out = re.release();
+    if (dropped && dropped->refs.fetch_sub(1) == 1) delete dropped;
   });
 }
 int cs_regex_destroy(cs_regex* re) {
-  return guard([&] { delete re; });
+  return guard([&] {
+    if (re && re->refs.fetch_sub(1) == 1) delete re;
+  });
 }
 int cs_regex_inst_count(const cs_regex* re) { return re ? (int)re->prog.insts.size() : 0; }
 int cs_regex_blob(const cs_regex* re, const int32_t** words, int* nwords) {

@@ -38,6 +38,35 @@ def test_regex_compile_is_host_only():
     _lib.lib.cs_regex_destroy(re_)
 
 
+def test_compiled_patterns_are_kept_and_counted(monkeypatch):
+    """cs_regex_compile keeps the last 32 compiled patterns: the same pattern gives the same (counted) object, a handle stays
+    valid after its pattern has dropped off the list, and CS_REGEX_NO_CACHE compiles afresh."""
+    from custrings_amd import _lib
+
+    L = _lib.lib
+
+    def compile_(p):
+        h = C.c_void_p()
+        assert L.cs_regex_compile(p, C.byref(h)) == 0
+        return h
+
+    a, b, c = compile_(b"ke+pt [0-9]"), compile_(b"ke+pt [0-9]"), compile_(b"other")
+    assert a.value == b.value and a.value != c.value
+    n = L.cs_regex_inst_count(a)
+    L.cs_regex_destroy(b)
+    others = [compile_(b"p%d+" % i) for i in range(40)]  # pushes the first pattern off the list
+    assert L.cs_regex_inst_count(a) == n  # (still alive: this handle holds it)
+    d = compile_(b"ke+pt [0-9]")
+    assert d.value != a.value and L.cs_regex_inst_count(d) == n
+    for h in [a, c, d] + others:
+        L.cs_regex_destroy(h)
+    monkeypatch.setenv("CS_REGEX_NO_CACHE", "1")
+    e, f = compile_(b"fresh"), compile_(b"fresh")
+    assert e.value != f.value
+    L.cs_regex_destroy(e)
+    L.cs_regex_destroy(f)
+
+
 def test_compute_fails_loudly_without_a_device():
     from custrings_amd import _lib
 
