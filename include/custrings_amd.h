@@ -240,7 +240,10 @@ void cs_free(void* p);
 
 /* ---- regex -------------------------------------------------------------- */
 /* Reprog::create_from + dreprog::create_from (regcomp.cpp:954-960,
- * regexec.cpp:12-73). Host-only compile; usable without a GPU. */
+ * regexec.cpp:12-73). Host-only compile; usable without a GPU.  The library keeps
+ * the last 32 compiled patterns: a handle is a counted reference to an immutable
+ * object that several handles (and host threads) may share; every handle is
+ * released with cs_regex_destroy.  CS_REGEX_NO_CACHE=1 compiles afresh per call. */
 int cs_regex_compile(const char* pattern, cs_regex** out);
 int cs_regex_destroy(cs_regex* re);
 int cs_regex_inst_count(const cs_regex* re);
