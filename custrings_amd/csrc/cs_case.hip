@@ -226,6 +226,7 @@ bool change_case_fast(const cs_column* col, unsigned bit, bool ascii_rule_ok, hi
   o->nbytes = col->nbytes;
   o->null_count = col->null_count;
   o->max_span64 = col->max_span64;
+  o->max_row = col->max_row;
   col->share_extents_with(o);    // same row extents: share the immutable buffers
   o->validity = col->validity;
   o->chars = chars;

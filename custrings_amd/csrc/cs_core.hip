@@ -287,6 +287,7 @@ typedef int int4_a4 __attribute__((ext_vector_type(4), aligned(4)));
 typedef long long ll2_a8 __attribute__((ext_vector_type(2), aligned(8)));
 struct ChunkVals {
   int v[kChunkRounds][4];
+  unsigned ok[kChunkRounds];  // bit k: length k of the round is not negative (a row, not a null) and lies below n
 };
 __device__ __forceinline__ void load_chunk(const int32_t* __restrict__ lens, int64_t n, int64_t base, int lane, ChunkVals& c) {
 #pragma unroll
@@ -302,8 +303,12 @@ __device__ __forceinline__ void load_chunk(const int32_t* __restrict__ lens, int
 #pragma unroll
       for (int k = 0; k < 4; ++k) c.v[j][k] = i + k < n ? lens[i + k] : 0;
     }
+    c.ok[j] = 0;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) c.v[j][k] = c.v[j][k] < 0 ? 0 : c.v[j][k];
+    for (int k = 0; k < 4; ++k) {
+      if (i + k < n && c.v[j][k] >= 0) c.ok[j] |= 1u << k;
+      c.v[j][k] = c.v[j][k] < 0 ? 0 : c.v[j][k];
+    }
   }
 }
 __device__ __forceinline__ long long chunk_total(const ChunkVals& c) {
@@ -323,7 +328,8 @@ __global__ void __launch_bounds__(256) k_chunk_sums(const int32_t* __restrict__ 
   if (lane == 0) sums[chunk] = t;
 }
 __global__ void __launch_bounds__(256) k_chunk_offsets(const int32_t* __restrict__ lens, int64_t n, int64_t nchunks,
-                                                       const int64_t* __restrict__ chunk_base, int64_t* __restrict__ offsets) {
+                                                       const int64_t* __restrict__ chunk_base, int64_t* __restrict__ offsets,
+                                                       uint8_t* __restrict__ validity, int64_t validity_len) {
   const int lane = threadIdx.x & 63;
   const int64_t chunk = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (chunk >= nchunks) return;
@@ -363,17 +369,38 @@ __global__ void __launch_bounds__(256) k_chunk_offsets(const int32_t* __restrict
 #pragma unroll
     for (int k = 0; k < 4; ++k)
       if (i + k == n - 1) offsets[n] = o[k + 1];
+    // the validity bits of the round's 256 rows: two lanes' nibbles make a byte
+    if (validity) {
+      const unsigned pair = c.ok[j] | ((unsigned)__shfl_down((int)c.ok[j], 1, 64) << 4);
+      const int64_t at = ((base + j * 256) >> 3) + (lane >> 1);
+      if (!(lane & 1) && at < validity_len) validity[at] = (uint8_t)pair;
+    }
     carry += round_total;
   }
 }
 
+static int64_t offsets_by_chunks(const int32_t* lens, int64_t n, int64_t* offsets, uint8_t* validity, hipStream_t s);
+static int64_t offsets_by_workgroups(const int32_t* lens, int64_t n, int64_t* offsets, hipStream_t s, Buf block_sums);
 int64_t offsets_from_lengths(const int32_t* lens, int64_t n, int64_t* offsets, hipStream_t s,
                              Buf block_sums) {
   if (n == 0) {
     CS_HIP(hipMemsetAsync(offsets, 0, sizeof(int64_t), s));
     return 0;
   }
-  if (!block_sums && !getenv("CS_SCAN_BY_WORKGROUPS")) {
+  if (!block_sums && !getenv("CS_SCAN_BY_WORKGROUPS")) return offsets_by_chunks(lens, n, offsets, nullptr, s);
+  return offsets_by_workgroups(lens, n, offsets, s, block_sums);
+}
+// offsets and the validity mask (length >= 0) of a column in the same pass over its lengths
+int64_t offsets_and_validity_from_lengths(const int32_t* lens, int64_t n, int64_t* offsets, Buf* validity, hipStream_t s) {
+  if (n == 0 || getenv("CS_SCAN_BY_WORKGROUPS")) {
+    *validity = validity_from_lengths(lens, n, s);
+    return offsets_from_lengths(lens, n, offsets, s);
+  }
+  *validity = dev_alloc(validity_bytes(n), s);
+  return offsets_by_chunks(lens, n, offsets, ptr<uint8_t>(*validity), s);
+}
+static int64_t offsets_by_chunks(const int32_t* lens, int64_t n, int64_t* offsets, uint8_t* validity, hipStream_t s) {
+  {
     const int64_t nchunks = (n + kChunk - 1) / kChunk;
     Buf sums = dev_alloc(sizeof(int64_t) * nchunks, s);
     Buf total = dev_alloc(sizeof(int64_t), s);
@@ -382,13 +409,16 @@ int64_t offsets_from_lengths(const int32_t* lens, int64_t n, int64_t* offsets, h
     hipLaunchKernelGGL(k_scan_block_sums, dim3(1), dim3(1024), 0, s, ptr<int64_t>(sums), nchunks, ptr<int64_t>(total));
     {
       ProfScope ps("k_write_offsets", s);
-      hipLaunchKernelGGL(k_chunk_offsets, dim3(grid), dim3(kBlock), 0, s, lens, n, nchunks, ptr<const int64_t>(sums), offsets);
+      hipLaunchKernelGGL(k_chunk_offsets, dim3(grid), dim3(kBlock), 0, s, lens, n, nchunks, ptr<const int64_t>(sums), offsets, validity,
+                         (int64_t)validity_bytes(n));
     }
     int64_t* host = (int64_t*)pinned_scratch(sizeof(int64_t));
     CS_HIP(hipMemcpyAsync(host, ptr<int64_t>(total), sizeof(int64_t), hipMemcpyDeviceToHost, s));
     CS_HIP(hipStreamSynchronize(s));
     return host[0];
   }
+}
+static int64_t offsets_by_workgroups(const int32_t* lens, int64_t n, int64_t* offsets, hipStream_t s, Buf block_sums) {
   int64_t nb = (n + kBlock - 1) / kBlock;
   Buf sums = block_sums;
   if (!sums) {

@@ -140,6 +140,8 @@ cs_column* make_all_null(int64_t rows, hipStream_t s);
 // kernel) and the lengths are read only once.
 int64_t offsets_from_lengths(const int32_t* lens, int64_t n, int64_t* offsets, hipStream_t s,
                              Buf block_sums = nullptr);
+// the same and the validity mask (length >= 0) from one pass over the lengths
+int64_t offsets_and_validity_from_lengths(const int32_t* lens, int64_t n, int64_t* offsets, Buf* validity, hipStream_t s);
 // Segmented variant: `segs` independent arrays of n lengths laid out back to
 // back (lens[seg * n + i]); offsets[seg * (n + 1) + i]; totals[seg] on the host.
 void offsets_from_lengths_segmented(const int32_t* lens, int64_t n, int segs, int64_t* offsets,

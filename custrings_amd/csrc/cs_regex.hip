@@ -2613,9 +2613,8 @@ int cs_extract(const cs_column* col, const cs_regex* cre, cs_stream stream, cs_c
       o->rows = rows;
       const int32_t* gl = ptr<int32_t>(lens) + (size_t)g * rows;
       o->offsets = dev_alloc(sizeof(int64_t) * (rows + 1), s);
-      o->nbytes = offsets_from_lengths(gl, rows, ptr<int64_t>(o->offsets), s);
+      o->nbytes = offsets_and_validity_from_lengths(gl, rows, ptr<int64_t>(o->offsets), &o->validity, s);
       o->chars = dev_alloc((size_t)o->nbytes, s);
-      o->validity = validity_from_lengths(gl, rows, s);
       eo.off[g] = o->d_offsets();
       eo.chars[g] = ptr<uint8_t>(o->chars);
       cols.push_back(std::move(o));
@@ -2760,9 +2759,8 @@ int cs_findall(const cs_column* col, const cs_regex* cre, cs_stream stream, cs_c
         o->rows = rows;
         const int32_t* gl = ptr<int32_t>(lens) + (size_t)(k0 + k) * rows;
         o->offsets = dev_alloc(sizeof(int64_t) * (rows + 1), s);
-        o->nbytes = offsets_from_lengths(gl, rows, ptr<int64_t>(o->offsets), s);
+        o->nbytes = offsets_and_validity_from_lengths(gl, rows, ptr<int64_t>(o->offsets), &o->validity, s);
         o->chars = dev_alloc((size_t)o->nbytes, s);
-        o->validity = validity_from_lengths(gl, rows, s);
         eo.off[k] = o->d_offsets();
         eo.chars[k] = ptr<uint8_t>(o->chars);
         cols.push_back(std::move(o));
