@@ -1615,13 +1615,14 @@ struct ScanStreamArgs {
 // UNITS (MODE 0 and 2, !LONG): the unit scan of the replace kernel -- units queued by the row lanes, one unit per lane
 // whatever its row, the per-row result summed (count_re) / OR-ed (contains_re) in LDS.
 template <int MODE, bool IN_LDS, bool LONG = false, bool UNITS = false>
-__global__ void __launch_bounds__(256, (UNITS && MODE == 3) ? 3 : (UNITS || MODE == 3) ? 4 : 1) k_tdfa_scan_stream(ScanStreamArgs a) {
+__global__ void __launch_bounds__(256, ((UNITS && MODE == 3) || MODE == 4) ? 3 : (UNITS || MODE == 3) ? 4 : 1) k_tdfa_scan_stream(ScanStreamArgs a) {
   static_assert(!UNITS || ((MODE == 0 || MODE == 2 || MODE == 3) && !LONG), "unit scan: contains_re / count_re / findall on rows within the 96-byte masks");
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   uint8_t* base = reinterpret_cast<uint8_t*>(smem);
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int bm_bytes = (a.cap_in >> 3) + 32;
-  const int unit_bytes = UNITS ? bm_bytes + kUnitQueue * 4 + 64 * 4 + 16 : 0;  // x bitmap, unit queue, per-row results, bail word
+  // (MODE 4 keeps a lane-private byte per step of a group run behind the bitmap: regex_tdfa.h, group_find_back)
+  const int unit_bytes = UNITS ? bm_bytes + kUnitQueue * 4 + 64 * 4 + 16 : (MODE == 4 ? cstd::Tdfa::kBackSteps * 64 : 0);  // x bitmap, unit queue, per-row results, bail word
   uint8_t* lds_in = base + a.tbl_bytes + (size_t)wv * (a.cap_in + 32 + bm_bytes + unit_bytes);
   uint32_t* bitmap = reinterpret_cast<uint32_t*>(lds_in + a.cap_in + 32);
   uint32_t* xbitmap = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(bitmap) + bm_bytes);
@@ -1762,7 +1763,11 @@ __global__ void __launch_bounds__(256, (UNITS && MODE == 3) ? 3 : (UNITS || MODE
           for (int g0 = 0; g0 < a.ncols; g0 += cstd::Tdfa::kGroupBatch) {
             int gb[cstd::Tdfa::kGroupBatch], ge[cstd::Tdfa::kGroupBatch], mend = 0;
             const int cnt = min(cstd::Tdfa::kGroupBatch, a.ncols - g0);
-            const bool found = hit && vm.group_find_all(mb, a.gtags, g0 + 1, cnt, gb, ge, mend) > 0;
+            // (backwards from the match where that applies -- short ASCII matches: regex_tdfa.h -- else the forward run)
+            int got = -1;
+            if (hit) got = vm.group_find_back(mb, a.gtags, g0 + 1, cnt, gb, ge, mend, cstd::Tdfa::HistBytes{reinterpret_cast<uint8_t*>(xbitmap) + lane, 64});
+            if (hit && got < 0) got = vm.group_find_all(mb, a.gtags, g0 + 1, cnt, gb, ge, mend);
+            const bool found = hit && got > 0;
 #pragma unroll
             for (int k = 0; k < cstd::Tdfa::kGroupBatch; ++k)
               if (k < cnt) {
@@ -2538,7 +2543,7 @@ int cs_extract(const cs_column* col, const cs_regex* cre, cs_stream stream, cs_c
       const TileChoice tc = choose_tile(col, s);
       const int cap = tc.cap;
       const size_t gt_bytes = re->gtags.size() * 4 <= 16 * 1024 ? ((re->gtags.size() * 4 + 15) & ~size_t(15)) : 0;
-      const size_t lds = tp.lds_bytes + gt_bytes + (size_t)(cap + 32 + (cap >> 3) + 32) * 4;
+      const size_t lds = tp.lds_bytes + gt_bytes + (size_t)(cap + 32 + (cap >> 3) + 32 + cstd::Tdfa::kBackSteps * 64) * 4;
       if (tp.d.in_lds && tc.R && lds <= 150 * 1024) {
         Buf cnt = dev_alloc(8, s);
         CS_HIP(hipMemsetAsync(cnt->p, 0, 8, s));

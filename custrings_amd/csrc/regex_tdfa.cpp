@@ -554,6 +554,20 @@ std::vector<int32_t> build_tdfa(const Program& prog, const std::vector<int32_t>&
     G[3] = nstates * natoms;
     for (unsigned c = 0; c < 128; ++c) G[4 + (c >> 2)] |= (int32_t)((uint32_t)(B.ascii_atom[c] & 255) << (8 * (c & 3)));
     for (int g = 0; g < ngroups; ++g) G.insert(G.end(), gt[g].begin(), gt[g].begin() + (size_t)nstates * natoms);
+    // then, for the backward resolution of a match's groups (regex_tdfa.h: group_find_back), one table per batch of
+    // four groups with the slot tags of the whole batch in ONE word: bit 8j + 2q (+1) = slot j passes the begin (end)
+    // bracket of the batch's q-th group
+    for (int g0 = 0; g0 < ngroups; g0 += 4) {
+      std::vector<int32_t> pt((size_t)nstates * natoms, 0);
+      for (int q = 0; q < 4 && g0 + q < ngroups; ++q)
+        for (size_t i = 0; i < (size_t)nstates * natoms; ++i) {
+          const uint32_t w = (uint32_t)gt[g0 + q][i];
+          uint32_t o = 0;
+          for (int j = 0; j < kMaxSlots; ++j) o |= ((w >> (2 * j)) & 3u) << (8 * j + 2 * q);
+          pt[i] = (int32_t)((uint32_t)pt[i] | o);
+        }
+      G.insert(G.end(), pt.begin(), pt.end());
+    }
   }
   return img;
 }

@@ -569,6 +569,100 @@ struct Tdfa {
     return matched;
   }
 
+  // The same result by a BACKWARD walk (matches of up to kBackSteps ASCII bytes on automata of up to 256 states;
+  // -1 = not applicable, the caller takes group_find_all).  The forward run above carries the (begin, end) of every
+  // group for every live thread through every step -- a byte permute per group and side per step.  Only ONE thread
+  // matters in the end, the one that matches: here the forward run is the plain automaton (one table word per byte,
+  // the state before each step kept in `hist`, a lane-private byte array), and the groups are read off on the way
+  // back from the match along that thread's origin slots: at step i the slot `cur` either passed a bracket (its
+  // two tag bits per group, all four groups of the batch in one word of the packed table) -- then the position of
+  // step i is that bracket's final value unless a later step already set it -- or it inherits from slot
+  // origin_i[cur] of the step before.
+  static constexpr int kBackSteps = 32;
+  struct HistBytes {  // `hist` over plain memory (LDS on the device: a lane's bytes lie `stride` apart)
+    uint8_t* p;
+    int stride;
+    CS_HD void put(int i, uint8_t v) { p[i * stride] = v; }
+    CS_HD uint32_t get(int i) const { return p[i * stride]; }
+  };
+  template <class Hist>
+  CS_HD int group_find_back(int from, const int32_t* G, int first, int count, int* gb, int* ge, int& mend, Hist hist) {
+    if (D.nstates > 256) return -1;
+    const long long tstride = (long long)G[3];
+    const uint32_t* tags0 = (const uint32_t*)(G + 36) + (long long)(first - 1) * tstride;
+    const uint32_t* packed = (const uint32_t*)(G + 36) + ((long long)G[0] + (first - 1) / kGroupBatch) * tstride;
+    const uint32_t* amap = (const uint32_t*)(G + 4);
+    uint32_t state = D.init[MODE_SEED_ONCE * 8 + (D.uses ? prev_cat(from) : 0u)];
+#pragma unroll
+    for (int g = 0; g < kGroupBatch; ++g) gb[g] = ge[g] = -1;
+    mend = from;
+    int steps = 0, m_step = -1;
+    uint32_t m_origin = 15u, m_state = 0, m_atom = 0;
+    bool stop = false;
+    int pos = from;
+    while (!stop && pos < n) {
+      const uint8_t b = byte_at(pos);
+      if (b >= 128 || steps >= kBackSteps) return -1;
+      const uint32_t e = D.t1[state * 128 + b];
+      if (e & E_MATCH) {
+        m_step = steps;
+        m_origin = e_match_origin(e);
+        m_state = state;
+        m_atom = (amap[b >> 2] >> (8 * (b & 3))) & 255u;
+        mend = pos;
+      }
+      hist.put(steps, (uint8_t)state);
+      ++steps;
+      state = e & E_STATE;
+      stop = (e & E_STOP) != 0;
+      if (!stop) ++pos;
+    }
+    if (!stop) {
+      const uint32_t e = D.t2[state * D.natoms + ATOM_EOT];
+      if (e & E_MATCH) {
+        m_step = steps;
+        m_origin = e_match_origin(e);
+        m_state = state;
+        m_atom = (uint32_t)ATOM_EOT;
+        mend = pos;
+      }
+    }
+    if (m_step < 0) return 0;
+    uint32_t open = 0;  // bit 2q / 2q + 1: begin / end of the batch's q-th group not set yet
+#pragma unroll
+    for (int g = 0; g < kGroupBatch; ++g)
+      if (g < count) {
+        const uint32_t tg = tags0[g * tstride + m_state * D.natoms + m_atom];
+        if (tg & 0x100u) gb[g] = mend;
+        else open |= 1u << (2 * g);
+        if (tg & 0x200u) ge[g] = mend;
+        else open |= 2u << (2 * g);
+      }
+    uint32_t cur = m_origin;
+    for (int i = m_step - 1; i >= 0 && cur < 4u && open; --i) {
+      const uint32_t s = hist.get(i);
+      const uint8_t b = byte_at(from + i);
+      const uint32_t e = D.t1[s * 128 + b];
+      const uint32_t atom = (amap[b >> 2] >> (8 * (b & 3))) & 255u;
+      const uint32_t hit = (packed[s * D.natoms + atom] >> (8 * cur)) & open;
+      if (hit) {
+#pragma unroll
+        for (int g = 0; g < kGroupBatch; ++g) {
+          if (hit & (1u << (2 * g))) gb[g] = from + i;
+          if (hit & (2u << (2 * g))) ge[g] = from + i;
+        }
+        open &= ~hit;
+      }
+      if (e & E_COMPLEX) {
+        cur = (D.act[e >> 21] >> (4 * cur)) & 15u;
+      } else {
+        const uint32_t keep = e_keep(e);
+        if (keep != 15u && cur >= keep) cur = 15u;
+      }
+    }
+    return 1;
+  }
+
   // ---- flat scan: all successive matches of a row in ONE loop ------------------
   // (the SIMT-friendly form of the row drivers in regex_vm.h: lanes that are in
   // different find() rounds still share the loop body, and idle stretches are

@@ -331,7 +331,29 @@ int emu_extract(const emu_col* c, const emu_regex* re, emu_col*** cols_out) {
       cstd::Tdfa vm(D, P, c->row(r), c->len(r));
       int gb[cstd::Tdfa::kGroupBatch], ge[cstd::Tdfa::kGroupBatch], mend = 0;
       const int cnt = std::min(cstd::Tdfa::kGroupBatch, groups - g0);
-      const int ok = vm.group_find_all(mb, re->gtags.data(), g0 + 1, cnt, gb, ge, mend);
+      // (the kernels try the backward resolution first; here both forms run wherever the backward one applies and
+      // must agree -- the oracle comparison above this library then checks the backward result)
+      uint8_t hist_bytes[cstd::Tdfa::kBackSteps];
+      int ok = vm.group_find_back(mb, re->gtags.data(), g0 + 1, cnt, gb, ge, mend, cstd::Tdfa::HistBytes{hist_bytes, 1});
+      static long long n_back = 0, n_all = 0;  // ROWEMU_STATS=1: how often the backward form applied
+      ++(ok < 0 ? n_all : n_back);
+      if (getenv("ROWEMU_STATS") && ((n_back + n_all) % 1000) == 0) fprintf(stderr, "rowemu: group runs backward %lld, forward only %lld\n", n_back, n_all);
+      {
+        int fb[cstd::Tdfa::kGroupBatch], fe[cstd::Tdfa::kGroupBatch], fend = 0;
+        const int fok = vm.group_find_all(mb, re->gtags.data(), g0 + 1, cnt, fb, fe, fend);
+        if (ok < 0) {
+          ok = fok;
+          mend = fend;
+          for (int k = 0; k < cnt; ++k) gb[k] = fb[k], ge[k] = fe[k];
+        } else {
+          bool same = ok == fok && (!ok || mend == fend);
+          for (int k = 0; ok && k < cnt; ++k) same = same && gb[k] == fb[k] && ge[k] == fe[k];
+          if (!same) {
+            fprintf(stderr, "rowemu: group_find_back and group_find_all disagree on row %lld\n", (long long)r);
+            abort();
+          }
+        }
+      }
       for (int k = 0; k < cnt; ++k)
         if (ok && gb[k] >= 0 && ge[k] > gb[k]) {
           lo[g0 + k][r] = gb[k];
