@@ -37,3 +37,19 @@ def log_rows(seed, n):
                 parts.append("".join(rnd.choice("abcxyz_é") for _ in range(rnd.randint(1, 6))))
         out.append(rnd.choice(["", " ", "x"]).join(parts) if rnd.random() < 0.2 else " ".join(parts))
     return out
+
+
+# matches around the limits of the backward group resolution (regex_tdfa.h: group_find_back): 31 / 32 / 33 / 60 steps,
+# matches that end with the row, non-ASCII inside or next to the match, groups that do not take part, nested and
+# repeated groups, more than four groups
+GROUP_EDGE_PATTERNS = [r"(\w+)=(\d+)(?:\.(\d+))?", r"((a+)|(x+))=(\d*)", r"(\w)(\w)(\w)(\w)(\w)(\w)?(\w)?", r"(a|b|c)+(X)?",
+                       r"(\d+)\.(\d+)\.(\d+)\.(\d+)$", r"((\w+) )?(/\S*)", r"(a(b(c)?)?)+", r"(.*)=(.*)", r"(é+)( ?)(k)?"]
+
+
+def group_edge_rows():
+    out = []
+    for k in (1, 2, 30, 31, 32, 33, 60):
+        out += ["x" * k + "=1.2", "k " + "a" * k + "=" + "9" * k + " z", "a" * k]
+    out += ["é=1.2", "ab=é1", "key=12.5é", "é" * 20 + " k=3.4", "k=3.4" + "é" * 20, None, "", "=", "a=", "=1", "a=1", "ab=12.34=56.78"]
+    out += ["GET /a/b 10.2.3.4 200", "POST / 1.2.3.4", "abcdefgh", "aXbXcXdXeXfXgXhX", "abcabcabc", "aaaa", "ab" * 20]
+    return out * 3  # several sub-tiles' worth, the same matches at different lanes

@@ -442,3 +442,13 @@ def test_gpu_offsets_from_lengths_beyond_32_bits(gpu_engine):
         c = nvstrings.to_device(src)
         idx = list(range(rows - 1, -1, -1))
         assert c.gather(idx).to_host() == src[::-1], rows
+
+
+def test_gpu_extract_groups_resolved_backwards_edges(gpu_engine, oracle_engine):
+    """The extract kernel reads a match's groups off a backward walk from the matching thread when the match is ASCII and
+    at most 32 steps long (regex_tdfa.h: group_find_back) and runs the forward form otherwise, lane by lane: matches of
+    31 / 32 / 33 / 60 bytes, matches that end with the row, a non-ASCII character inside or next to the match, groups
+    that do not take part, nested and repeated groups, more than four groups (two batches)."""
+    rows = fuzzdata.group_edge_rows()
+    for pat in fuzzdata.GROUP_EDGE_PATTERNS:
+        assert gpu_engine.extract(rows, pat) == oracle_engine.extract(rows, pat), pat

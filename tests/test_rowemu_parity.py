@@ -213,3 +213,12 @@ def test_rowemu_vs_oracle_replace_with_backrefs(emu_engine, oracle_engine, pat, 
     emu_engine.e.set_engine(engine)
     s = fuzzdata.rows(14, 300, alphabet=list("aabbc xyz_.\n019") + ["é", "ü", "😀"]) + fuzzdata.log_rows(11, 200)
     assert emu_engine.replace_with_backrefs(s, pat, repl) == oracle_engine.replace_with_backrefs(s, pat, repl)
+
+
+def test_rowemu_vs_oracle_extract_backward_edges(emu_engine, oracle_engine):
+    """The matches around the limits of the backward group resolution (the emulation also runs the forward form on
+    each and aborts on a difference)."""
+    emu_engine.e.set_engine(1)  # the tagged DFA (the kernels' route)
+    rows = fuzzdata.group_edge_rows()
+    for pat in fuzzdata.GROUP_EDGE_PATTERNS:
+        assert emu_engine.extract(rows, pat) == oracle_engine.extract(rows, pat), pat
