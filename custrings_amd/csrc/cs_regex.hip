@@ -1365,7 +1365,12 @@ __global__ void __launch_bounds__(256, BREFS ? 2 : CS_STREAM_WAVES) k_tdfa_repla
                       const int pu = lead + rbeg_r;
                       cstd::Tdfa vg(D, P, lds_in + pu, n_r, pu & 3);
                       int gb[cstd::Tdfa::kGroupBatch], ge[cstd::Tdfa::kGroupBatch], mend = me;
-                      const bool ok = T.nrefs > 0 && vg.group_find_all(mb, gt, 1, T.groups, gb, ge, mend) > 0;
+                      // backwards from the match where that applies (regex_tdfa.h: group_find_back); the history bytes
+                      // lie in the two bitmaps, whose bits every row lane has taken into its masks by now
+                      const int hsteps = min(cstd::Tdfa::kBackSteps, (2 * bm_bytes) >> 6);
+                      int got = T.nrefs > 0 ? vg.group_find_back(mb, gt, 1, T.groups, gb, ge, mend, cstd::Tdfa::HistBytes{reinterpret_cast<uint8_t*>(bitmap) + lane, 64}, hsteps) : 0;
+                      if (got < 0) got = vg.group_find_all(mb, gt, 1, T.groups, gb, ge, mend);
+                      const bool ok = got > 0;
                       int grow = T.bytes - (me - mb);
                       for (int j = 0; j < T.nrefs; ++j) {
                         const int g = T.idx[j];

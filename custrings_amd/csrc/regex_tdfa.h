@@ -586,7 +586,7 @@ struct Tdfa {
     CS_HD uint32_t get(int i) const { return p[i * stride]; }
   };
   template <class Hist>
-  CS_HD int group_find_back(int from, const int32_t* G, int first, int count, int* gb, int* ge, int& mend, Hist hist) {
+  CS_HD int group_find_back(int from, const int32_t* G, int first, int count, int* gb, int* ge, int& mend, Hist hist, int max_steps = kBackSteps) {
     if (D.nstates > 256) return -1;
     const long long tstride = (long long)G[3];
     const uint32_t* tags0 = (const uint32_t*)(G + 36) + (long long)(first - 1) * tstride;
@@ -602,7 +602,7 @@ struct Tdfa {
     int pos = from;
     while (!stop && pos < n) {
       const uint8_t b = byte_at(pos);
-      if (b >= 128 || steps >= kBackSteps) return -1;
+      if (b >= 128 || steps >= max_steps) return -1;  // (`max_steps`: what the caller's history holds)
       const uint32_t e = D.t1[state * 128 + b];
       if (e & E_MATCH) {
         m_step = steps;
