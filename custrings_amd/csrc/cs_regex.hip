@@ -1946,26 +1946,32 @@ struct TPlan {
 };
 bool use_tdfa(const cs_regex* re) { return !re->tdfa.empty() && !getenv("CS_REGEX_NO_TDFA"); }
 void upload(cs_regex* re, hipStream_t s) {
-  // a compiled pattern may be shared between host threads: the device images are made once
+  // a compiled pattern may be shared between host threads (and is kept in the process-wide pattern cache): the device
+  // images are made once.  All three are built into locals and committed together only after the copies completed --
+  // an allocation or copy that throws half way must not leave d_image set with the DFA images missing (the guard
+  // below would then skip the upload for every later caller of the cached pattern).
   static std::mutex mu;
   std::lock_guard<std::mutex> lk(mu);
-  if (!re->d_image) {
-    re->d_image = dev_alloc(re->image.size() * 4, s);
-    CS_HIP(hipMemcpyAsync(re->d_image->p, re->image.data(), re->image.size() * 4, hipMemcpyHostToDevice, s));
-    if (!re->tdfa.empty()) {
-      re->d_tdfa = dev_alloc(re->tdfa.size() * 4, s);
-      CS_HIP(hipMemcpyAsync(re->d_tdfa->p, re->tdfa.data(), re->tdfa.size() * 4, hipMemcpyHostToDevice, s));
-      if (!re->gtags.empty()) {
-        re->d_gtags = dev_alloc(re->gtags.size() * 4, s);
-        CS_HIP(hipMemcpyAsync(re->d_gtags->p, re->gtags.data(), re->gtags.size() * 4, hipMemcpyHostToDevice, s));
-      }
+  if (re->d_image) return;
+  Buf image = dev_alloc(re->image.size() * 4, s), tdfa, gtags;
+  CS_HIP(hipMemcpyAsync(image->p, re->image.data(), re->image.size() * 4, hipMemcpyHostToDevice, s));
+  if (!re->tdfa.empty()) {
+    tdfa = dev_alloc(re->tdfa.size() * 4, s);
+    CS_HIP(hipMemcpyAsync(tdfa->p, re->tdfa.data(), re->tdfa.size() * 4, hipMemcpyHostToDevice, s));
+    if (!re->gtags.empty()) {
+      gtags = dev_alloc(re->gtags.size() * 4, s);
+      CS_HIP(hipMemcpyAsync(gtags->p, re->gtags.data(), re->gtags.size() * 4, hipMemcpyHostToDevice, s));
     }
-    CS_HIP(hipStreamSynchronize(s));
   }
+  CS_HIP(hipStreamSynchronize(s));
+  re->d_tdfa = std::move(tdfa);
+  re->d_gtags = std::move(gtags);
+  re->d_image = std::move(image);  // (last: it is what the guard looks at)
 }
 TPlan tplan(cs_regex* re, int64_t rows, hipStream_t s) {
   require_device();
   upload(re, s);
+  if (!re->d_tdfa) fail(CS_ERR_INTERNAL, "regex: the tagged-DFA image is not on the device");
   TPlan pl{};
   pl.d.tdfa = ptr<const int32_t>(re->d_tdfa);
   pl.d.tdfa_words = (int)re->tdfa.size();
@@ -2378,7 +2384,7 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
             fprintf(stderr, "  tile %lld: agg flag %u val %llu | excl flag %u val %llu\n", (long long)t, (unsigned)(st[t] >> 62), (unsigned long long)(st[t] & cstile::kValMask),
                     (unsigned)(ex[t] >> 62), (unsigned long long)(ex[t] & cstile::kValMask));
         }
-        if (err == 0 || sa.debug) {
+        if (err == 0) {  // (a launch whose error word is set never yields a column, measurement switches or not)
           o->offsets = out_off;
           o->chars = out_chars;
           o->nbytes = host[0];
@@ -2431,7 +2437,7 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
         CS_HIP(hipMemcpyAsync(host, ptr<int64_t>(out_off) + rows, 8, hipMemcpyDeviceToHost, s));
         CS_HIP(hipMemcpyAsync(host + 1, ta.error, 4, hipMemcpyDeviceToHost, s));
         CS_HIP(hipStreamSynchronize(s));
-        if ((uint32_t)host[1] == 0 || ta.debug) {
+        if ((uint32_t)host[1] == 0) {
           o->offsets = out_off;
           o->chars = out_chars;
           o->nbytes = host[0];

@@ -84,6 +84,19 @@ __device__ __forceinline__ long long rl64(long long v, int k) {
   return ((long long)hi << 32) | (unsigned int)lo;
 }
 
+// lowest set bit of a 96-bit mask (m2 : m1 : m0), 0xFFFFFFFF when there is none: three v_ffbl_b32 (-1 for zero), the upper
+// two moved up with SATURATING adds so that "none" stays the largest value, one v_min3_u32
+__device__ __forceinline__ uint32_t lowest96(uint32_t m0, uint32_t m1, uint32_t m2) {
+  uint32_t f0, f1, f2, q;
+  asm("v_ffbl_b32 %0, %1" : "=v"(f0) : "v"(m0));
+  asm("v_ffbl_b32 %0, %1" : "=v"(f1) : "v"(m1));
+  asm("v_ffbl_b32 %0, %1" : "=v"(f2) : "v"(m2));
+  asm("v_add_u32_e64 %0, %1, 32 clamp" : "=v"(f1) : "v"(f1));
+  asm("v_add_u32_e64 %0, %1, 64 clamp" : "=v"(f2) : "v"(f2));
+  asm("v_min3_u32 %0, %1, %2, %3" : "=v"(q) : "v"(f0), "v"(f1), "v"(f2));
+  return q;
+}
+
 struct SubTile {
   long long r0, g0;
   int nrows, rbeg, n, lead;
@@ -336,9 +349,12 @@ struct Measure2Args {
   int* max_count;   // [0] most tokens in a row, [1] bound on the bytes one column receives from one sub-tile
                     // (sum over its rows of the row's longest token), [2] longest row, [3] a sub-tile needs the generic kernels
 };
-template <int MODE>
+// PLAIN (a one-byte delimiter, no split limit, rows of at most 92 bytes): the sentinel walk of k_split_emit3 -- three mask
+// words with a bit behind the row's last byte, lowest96 + a 96-bit clear per token.
+template <int MODE, bool PLAIN = false>
 __global__ void __launch_bounds__(256, 8) k_split_measure2(Measure2Args a) {  // (8 waves per SIMD: 2.05 -> 1.94 ms)
   constexpr bool WS = MODE == 1, MULTI = MODE == 2;
+  static_assert(!PLAIN || MODE == 0, "the sentinel walk is the one-byte delimiter's");
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
   uint8_t* lds_in = reinterpret_cast<uint8_t*>(smem) + (size_t)wv * (a.cap + 32);
@@ -361,16 +377,47 @@ __global__ void __launch_bounds__(256, 8) k_split_measure2(Measure2Args a) {  //
     }
     int count = 0, rowmax = 0;
     bool any_more = true;
+    if (PLAIN) {
+      uint32_t m0 = (uint32_t)tk.m_lo, m1 = (uint32_t)(tk.m_lo >> 32), m2 = tk.m_hi;
+      if (t.live) {  // the sentinel: bit sa + n (<= 95)
+        const int q = tk.sa + t.n;
+        const uint32_t bit = 1u << (q & 31);
+        if (q < 32) m0 |= bit;
+        else if (q < 64) m1 |= bit;
+        else m2 |= bit;
+      }
+      count = __builtin_popcount(m0) + __builtin_popcount(m1) + __builtin_popcount(m2);
+      int prev = tk.sa - 1;  // mask position of the delimiter in front of the current token
 #pragma unroll
-    for (int k = 0; k < kMaxCols; ++k) {
-      if (any_more) {
-        int lo = 0, hi = 0;
-        const bool has = tk.next(lo, hi);
-        any_more = __any(has);
-        const int len = has ? hi - lo : 0;
-        count += has;
-        acc[k] += len;
-        rowmax = max(rowmax, len);
+      for (int k = 0; k < kMaxCols; ++k) {
+        if (any_more) {
+          const bool has = (m0 | m1 | m2) != 0;
+          any_more = __any(has);
+          const int q = (int)lowest96(m0, m1, m2);
+          const int len = has ? q - prev - 1 : 0;
+          prev = q;
+          const unsigned long long l64 = ((unsigned long long)m1 << 32) | m0, d64 = l64 - 1;
+          const uint32_t d2 = m2 - (l64 == 0 ? 1u : 0u);
+          m0 &= (uint32_t)d64;
+          m1 &= (uint32_t)(d64 >> 32);
+          m2 &= d2;
+          acc[k] += len;
+          rowmax = max(rowmax, len);
+        }
+      }
+      any_more = false;  // (rows with more than kMaxCols tokens: `count` says so, the host takes the generic path)
+    } else {
+#pragma unroll
+      for (int k = 0; k < kMaxCols; ++k) {
+        if (any_more) {
+          int lo = 0, hi = 0;
+          const bool has = tk.next(lo, hi);
+          any_more = __any(has);
+          const int len = has ? hi - lo : 0;
+          count += has;
+          acc[k] += len;
+          rowmax = max(rowmax, len);
+        }
       }
     }
     while (any_more) {  // rows with more than kMaxCols tokens: the host takes the generic path
@@ -668,6 +715,298 @@ __global__ void __launch_bounds__(256, CS_EMIT2_WAVES) k_split_emit2(Emit2Args a
 #endif
 }
 
+
+// ---- byte runs into an LDS tile with ALIGNED accesses only ---------------------------------------------
+// A DS access off its natural alignment is replayed a lane at a time on gfx950: 64 LDS cycles per wave-instruction
+// for every width but one byte (128 for some stores), against 3-5 for an aligned dword (tools/ubench/lds_align.hip).
+// The exact-size stores at any alignment that the second generation assembled its columns with made the LDS pipe
+// the kernel's bound (SQ_LDS_UNALIGNED_STALL: 1.3 k cycles per sub-tile).  Here a run of up to 16 bytes is read as
+// six aligned dwords, moved to the destination's byte phase with v_alignbyte, cut to its bytes with a mask per dword
+// (a 16-entry table in LDS: byte-validity nibble -> byte mask) and OR-ed into the zeroed destination as five aligned
+// dwords.  `src` needs 4 readable bytes in front of index 0 and 24 behind the run; `dst` 20 writable bytes from di & ~3.
+__device__ __forceinline__ void lds_or16(uint8_t* dst, int di, const uint8_t* src, int ti, int len, const uint32_t* lut) {
+  const int delta = (ti & 3) - (di & 3);  // -3 .. 3: source phase minus destination phase
+  const uint32_t* w = reinterpret_cast<const uint32_t*>(src + ((ti & ~3) - (delta < 0 ? 4 : 0)));
+  const unsigned d = (unsigned)delta & 3u;
+  const uint32_t w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3], w4 = w[4], w5 = w[5];
+  const uint32_t valid = ((1u << len) - 1u) << (di & 3);  // one bit per destination byte, from the first dword's byte 0
+  // (every read before the first OR: the compiler keeps a load behind an atomic it may alias and waits for each)
+  const uint32_t m0 = lut[valid & 15u], m1 = lut[(valid >> 4) & 15u], m2 = lut[(valid >> 8) & 15u], m3 = lut[(valid >> 12) & 15u],
+                 m4 = lut[(valid >> 16) & 15u];
+  uint32_t* o = reinterpret_cast<uint32_t*>(dst + (di & ~3));
+  lds_or(o + 0, __builtin_amdgcn_alignbyte(w1, w0, d) & m0);
+  lds_or(o + 1, __builtin_amdgcn_alignbyte(w2, w1, d) & m1);
+  lds_or(o + 2, __builtin_amdgcn_alignbyte(w3, w2, d) & m2);
+  lds_or(o + 3, __builtin_amdgcn_alignbyte(w4, w3, d) & m3);
+  lds_or(o + 4, __builtin_amdgcn_alignbyte(w5, w4, d) & m4);
+}
+
+// The same with ONE read of the run at whatever alignment it has (64 LDS cycles, but the run then stands at byte 0 of
+// four registers): only its tail needs a mask (tailmask: 17 entries of four dwords, entry n = the first n bytes), the
+// shift to the destination's byte phase fills with zeros from below, and the kernel -- bound by its VALU count, with
+// LDS time to spare once the stores are aligned -- gets away with a third of the vector instructions of lds_or16.
+__device__ __forceinline__ void lds_or16u(uint8_t* dst, int di, const uint8_t* src, int ti, int len, const cstile::u32x4* tailmask) {
+  const cstile::lds_u32x4u v = *reinterpret_cast<const cstile::lds_u32x4u*>(src + ti);
+  const cstile::u32x4 m = tailmask[len];
+  const uint32_t a0 = v.x & m.x, a1 = v.y & m.y, a2 = v.z & m.z, a3 = v.w & m.w;
+  // destination dword j receives bytes of {a_j : a_(j-1)} cut at the destination's byte phase pd: alignbyte by (4 - pd) & 3,
+  // which for pd = 0 yields a_(j-1) -- so that case begins one dword earlier (its first OR adds nothing)
+  const unsigned up = (0u - (unsigned)di) & 3u;
+  uint32_t* o = reinterpret_cast<uint32_t*>(dst + (((di + 3) & ~3) - 4));
+  lds_or(o + 0, __builtin_amdgcn_alignbyte(a0, 0u, up));
+  lds_or(o + 1, __builtin_amdgcn_alignbyte(a1, a0, up));
+  lds_or(o + 2, __builtin_amdgcn_alignbyte(a2, a1, up));
+  lds_or(o + 3, __builtin_amdgcn_alignbyte(a3, a2, up));
+  lds_or(o + 4, __builtin_amdgcn_alignbyte(0u, a3, up));
+}
+
+// ---- emit, third generation: all columns assembled side by side, no fence in the column loop ------------
+// Same inputs and outputs as k_split_emit2 (runs of consecutive sub-tiles per wave, column positions from the
+// measure pass).  What changed is the shape of the column loop, whose twenty rounds of "walk, scan, assemble,
+// fence, flush head bytes / chunks / tail bytes, fence" were the kernel's latency chain, and the way bytes reach LDS:
+//   * every column gets its own REGION of one LDS out tile (regions back to back, each starting at a 16-byte
+//     boundary that corresponds to a 16-byte boundary of the column's chars); a round of the column loop is one token
+//     walk step, one wave scan, the offsets store and the tokens' OR into the (zeroed) region with ALIGNED dword
+//     accesses -- lds_or16u: the second generation's exact-size stores at any alignment were replayed a lane at a time;
+//   * the bytes of a column that do not fill a 16-byte chunk are CARRIED to the wave's next sub-tile (a register
+//     quad in the column's lane; the wave's sub-tiles are consecutive, so they continue where these left off): the
+//     chars leave as whole, aligned 16-byte chunks only -- a run's first and last chunk, shared with the
+//     neighbouring waves, are the exception and go out bytewise once per run and column;
+//   * a region LEAVES DURING THE NEXT COLUMN'S ROUND: its chunks are read at the top of that round (one aligned
+//     16-byte read per lane), stored to the column's chars at the bottom and zeroed again, so the LDS round trip
+//     hides behind the round's own work and no pass over the out tile follows the column loop;
+//   * 16 waves per CU (128 registers, 10 KB of LDS per wave): the kernel is bound by its vector instruction count
+//     (a wave64 integer instruction holds its SIMD for four cycles) and by the dependent chain of a round, not by
+//     HBM or LDS bandwidth, so resident waves are what fills the SIMDs.
+struct Emit3Args {
+  Emit2Args e;
+  int cap_in;     // bytes of the in tile (the largest 64-row span, the lead of its first 16-byte chunk, read-ahead slack)
+  int cap_out;    // bytes of the out tile (regions of all columns)
+};
+#ifndef CS_EMIT3_WAVES
+#define CS_EMIT3_WAVES 4
+#endif
+constexpr int kEmit3Threads = 128;  // two waves per workgroup: the LDS of a CU is shared out in finer grains
+// PLAIN: a one-byte delimiter without a split limit on rows of at most 92 bytes -- the token walk then runs on three
+// mask words that also hold a sentinel bit behind the row's last byte (every token ends at a set bit, the walk is over
+// when the mask is empty) instead of the general TokensT::next.
+template <int MODE, bool OFF32, bool PLAIN>
+__global__ void __launch_bounds__(kEmit3Threads, CS_EMIT3_WAVES) k_split_emit3(Emit3Args args) {
+  constexpr bool WS = MODE == 1, MULTI = MODE == 2;
+  static_assert(!PLAIN || MODE == 0, "the sentinel walk is the one-byte delimiter's");
+  typedef typename std::conditional<OFF32, int32_t, int64_t>::type off_t;
+  const Emit2Args& a = args.e;
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  // (the wave index through readfirstlane: everything derived from it -- tile, first row, addresses -- is then
+  // wave-uniform to the compiler too and lives in scalar registers)
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+  // the workgroup's mask table first (17 entries, both waves write the same values); then per wave 16 bytes of slack
+  // (a run's dwords may begin 4 bytes in front of a tile), the in tile, the out tile
+  uint8_t* lds_in = reinterpret_cast<uint8_t*>(smem) + 288 + (size_t)wv * (16 + args.cap_in + 32 + args.cap_out) + 16;
+  uint8_t* lds_out = lds_in + args.cap_in + 32;
+  // tail[n], n = 0..16: a mask of the first n bytes of sixteen (lds_or16u)
+  cstile::u32x4* tail = reinterpret_cast<cstile::u32x4*>(smem);
+  if (lane <= 16) {
+    auto first = [](int k) -> uint32_t { return k >= 4 ? 0xFFFFFFFFu : (k <= 0 ? 0u : (1u << (8 * k)) - 1u); };
+    tail[lane] = cstile::u32x4{first(lane), first(lane - 4), first(lane - 8), first(lane - 12)};
+  }
+  // the out tile is zero whenever a sub-tile begins (tokens are OR-ed in; what is flushed or carried is zeroed again)
+  const cstile::u32x4 zero4 = {0u, 0u, 0u, 0u};
+  for (int i = lane * 16; i < args.cap_out; i += 64 * 16) *reinterpret_cast<cstile::u32x4*>(lds_out + i) = zero4;
+  const long long per = a.per;
+  const long long run = (long long)blockIdx.x * (kEmit3Threads / 64) + wv;
+  long long tile = run * per;
+  const long long tile_end = min(a.nsub, tile + per);
+  if (tile >= tile_end) return;
+  const ColView& in = a.in;
+  // lane k keeps column k: destination, the wave's running position in the column's chars, the bytes carried
+  // over from the previous sub-tile (they precede `my_pos` in the same 16-byte chunk) and how many leading bytes
+  // of the next chunk to go out belong to the wave in front (non-zero until the run's first whole chunk left)
+  uint8_t* my_chars = nullptr;
+  off_t* my_off = nullptr;
+  uint8_t* my_valid = nullptr;
+  long long my_pos = 0;
+  int my_head = 0;
+  cstile::u32x4 carry = zero4;
+  if (lane < a.ncols) {
+    const ColOut2 c = a.cols[lane];
+    my_chars = c.chars;
+    my_off = reinterpret_cast<off_t*>(c.offsets);
+    my_valid = c.validity;
+    my_pos = c.seg_base[run * a.segs_per_run];
+    my_head = (int)((uintptr_t)(my_chars + my_pos) & 15);
+  }
+  cstile::TileOffs cur = cstile::load_tile_offsets(in.offsets, in.rows, tile, lane);
+  cstile::TileOffs nxt = cur;
+  if (tile + 1 < tile_end) nxt = cstile::load_tile_offsets(in.offsets, in.rows, tile + 1, lane);
+  cstile::TileChars pf;
+#pragma unroll
+  for (int j = 0; j < cstile::kPfChunks; ++j) pf.v[j] = make_uint4(0, 0, 0, 0);
+  cstile::issue_chars(in.chars, cstile::rl64(cur.o0, 0), cstile::rl64(cur.o1, 63), lane, pf);
+  for (;;) {
+    const long long r0 = tile * 64;
+    const int nrows = (int)min(64ll, in.rows - r0);
+    const long long g0 = cstile::rl64(cur.o0, 0), g1 = cstile::rl64(cur.o1, 63);
+    const bool live = lane < nrows && row_is_valid(in.validity, r0 + lane);
+    const int rbeg = (int)(cur.o0 - g0);
+    const int n = live ? (int)(cur.o1 - cur.o0) : 0;
+    const int lead = (int)((uintptr_t)(in.chars + g0) & 15);
+    const int want = (int)(g1 - g0) + lead;
+    cstile::stage_chars(lds_in, want, lane, pf);
+    const bool has_next = tile + 1 < tile_end;
+    // (fetched unconditionally, handed to `nxt` at the bottom: see k_split_emit2)
+    const cstile::TileOffs nn = cstile::load_tile_offsets(in.offsets, in.rows, tile + 2 < tile_end ? tile + 2 : tile_end - 1, lane);
+    if (has_next) {
+      cur = nxt;
+      cstile::issue_chars(in.chars, cstile::rl64(cur.o0, 0), cstile::rl64(cur.o1, 63), lane, pf);
+    }
+    cstile::wave_lds_fence();
+
+    TokensT<true, WS, MULTI> tk(lds_in, lead + rbeg, n, live, a.dpat, a.tokens, a.d64, a.dlen, a.reverse != 0);
+    // PLAIN: the delimiter bits and the sentinel behind the row (bit sa + n <= 95), the start of the next token
+    uint32_t m0 = 0, m1 = 0, m2 = 0;
+    int tcur = 0;
+    if (PLAIN) {
+      m0 = (uint32_t)tk.m_lo;
+      m1 = (uint32_t)(tk.m_lo >> 32);
+      m2 = tk.m_hi;
+      if (live) {
+        const int q = tk.sa + n;
+        const uint32_t bit = 1u << (q & 31);
+        if (q < 32) m0 |= bit;
+        else if (q < 64) m1 |= bit;
+        else m2 |= bit;
+      }
+    }
+    const bool last_tile = r0 + nrows == in.rows;
+    unsigned long long my_vmask = 0;
+    const int my_cph = (int)(((uintptr_t)my_chars + (uintptr_t)my_pos) & 15);  // bytes carried into this sub-tile
+    int rg = 0;  // where the next column's region begins in the out tile (wave-uniform)
+    // The region of the column before is flushed while this column's round runs (its chunks are read at the top of the
+    // round and stored at the bottom): p_k < 0 = nothing pending.  All wave-uniform.
+    int p_k = -1, p_rg = 0, p_nwhole = 0, p_nch = 0, p_tot = 0, p_cph = 0;
+    // (chunks of the pending region: p_nch in all, the first p_nwhole of them whole)
+    auto pending_read = [&]() -> cstile::u32x4 {  // lane i < 64 reads chunk i (aligned 16-byte reads)
+      cstile::u32x4 v = zero4;
+      if (p_k >= 0 && lane < p_nch) v = *reinterpret_cast<const cstile::u32x4*>(lds_out + p_rg + 16 * lane);
+      return v;
+    };
+    auto pending_leave = [&](cstile::u32x4 pv) {
+      if (p_k < 0) return;
+      // chunk i goes to ((chars + pos) & ~15) + 16 i, pos still being the column's position before this sub-tile
+      uint8_t* ga = reinterpret_cast<uint8_t*>(((uintptr_t)cstile::rl64((long long)(uintptr_t)my_chars, p_k) + (uintptr_t)cstile::rl64(my_pos, p_k)) & ~(uintptr_t)15);
+      const int head = rl(my_head, p_k);
+      if (lane < p_nwhole && !(lane == 0 && head != 0)) *(cstile::gptr<cstile::u32x4>)cstile::as_global(ga + 16 * lane) = pv;
+      // the bytes behind the last whole chunk become the carry of the column's lane (its own read of that quad: the LDS
+      // takes the wave's operations in order, so it comes before the zeroing below; zeros when the region ends on a
+      // chunk boundary -- the quad behind it is the next region's, still untouched, or empty)
+      if (lane == p_k) {
+        carry = *reinterpret_cast<const cstile::u32x4*>(lds_out + p_rg + 16 * p_nwhole);
+        if (p_nwhole == p_nch) carry = zero4;
+        my_pos += p_tot - p_cph;
+      }
+      if (lane < p_nch) *reinterpret_cast<cstile::u32x4*>(lds_out + p_rg + 16 * lane) = zero4;  // (zero again for the next sub-tile)
+      if (head != 0 && p_nwhole > 0) {
+        // a run's first whole chunk of a column: its leading bytes belong to the wave in front, bytes head .. 15 go out
+        // one per lane from lane 0's quad (once per run and column)
+        const int w = lane >> 2;
+        const uint32_t d0 = (uint32_t)__builtin_amdgcn_readlane((int)pv.x, 0), d1 = (uint32_t)__builtin_amdgcn_readlane((int)pv.y, 0),
+                       d2 = (uint32_t)__builtin_amdgcn_readlane((int)pv.z, 0), d3 = (uint32_t)__builtin_amdgcn_readlane((int)pv.w, 0);
+        const uint32_t dw = w == 0 ? d0 : (w == 1 ? d1 : (w == 2 ? d2 : d3));
+        if (lane >= head && lane < 16) cstile::as_global(ga)[lane] = (uint8_t)(dw >> (8 * (lane & 3)));
+        if (lane == p_k) my_head = 0;
+      }
+      if (p_nch > 64) {  // (a column that receives a KB or more from one sub-tile: the rest of its chunks)
+        for (int i = 64 + lane; i < p_nch; i += 64) {
+          const cstile::u32x4 w = *reinterpret_cast<const cstile::u32x4*>(lds_out + p_rg + 16 * i);
+          *reinterpret_cast<cstile::u32x4*>(lds_out + p_rg + 16 * i) = zero4;
+          if (i < p_nwhole) *(cstile::gptr<cstile::u32x4>)cstile::as_global(ga + 16 * i) = w;
+        }
+      }
+    };
+    bool any_more = true;
+    for (int k = 0; k < a.ncols; ++k) {
+      const long long cbase = cstile::rl64(my_pos, k);
+      cstile::gptr<off_t> coff = cstile::as_global(reinterpret_cast<off_t*>(cstile::rl64((long long)(uintptr_t)my_off, k))) + r0;
+      if (!any_more) {
+        // no row of the sub-tile reaches this column: null rows at the column's running position, the carried
+        // bytes stay where they are
+        if (lane < nrows) coff[lane] = (off_t)cbase;
+        if (last_tile && lane == nrows - 1) coff[nrows] = (off_t)cbase;
+        continue;
+      }
+      // ---- the region of the column before: its chunks are read here and leave at the bottom of the round
+      const cstile::u32x4 pv = pending_read();
+      // ---- this column's tokens
+      int lo = 0, hi = 0;
+      bool has;
+      if (PLAIN) {
+        has = (m0 | m1 | m2) != 0;
+        const uint32_t q = lowest96(m0, m1, m2);
+        lo = tcur;
+        hi = (int)q - tk.sa;
+        tcur = hi + 1;
+        const unsigned long long l64 = ((unsigned long long)m1 << 32) | m0, d64 = l64 - 1;
+        const uint32_t d2 = m2 - (l64 == 0 ? 1u : 0u);
+        m0 &= (uint32_t)d64;
+        m1 &= (uint32_t)(d64 >> 32);
+        m2 &= d2;
+      } else {
+        has = tk.next(lo, hi);
+      }
+      any_more = __any(has);
+      if (any_more) {
+        const int len = has ? hi - lo : 0;
+        const int incl = wave_inclusive_scan(len);
+        const int pre = incl - len;
+        const int csum = rl(incl, 63);  // bytes this sub-tile adds to column k
+        if (lane < nrows) coff[lane] = (off_t)(cbase + pre);
+        if (last_tile && lane == nrows - 1) coff[nrows] = (off_t)(cbase + incl);
+        const unsigned long long vmask = __ballot(has);
+        const int cph = rl(my_cph, k);  // carried bytes: they precede the column's position in its 16-byte chunk
+        if (lane == k) {
+          my_vmask = vmask;
+          // the carried bytes open the region (the LDS takes a wave's operations in order: the tokens below land
+          // behind them, over the quad's zero tail)
+          if (cph) *reinterpret_cast<cstile::u32x4*>(lds_out + rg) = carry;
+        }
+        if (has) lds_or16u(lds_out, rg + cph + pre, lds_in, lead + rbeg + lo, min(len, 16), tail);
+        if (__any(len > 16)) {  // (tokens beyond 16 bytes: the same, 16 bytes at a time)
+          for (int done = 16; __any(done < len); done += 16)
+            if (done < len) lds_or16u(lds_out, rg + cph + pre + done, lds_in, lead + rbeg + lo + done, min(len - done, 16), tail);
+        }
+        // ---- the column before leaves: whole chunks to its chars, the bytes behind them into its lane's carry quad
+        pending_leave(pv);
+        p_k = k;
+        p_rg = rg;
+        p_cph = cph;
+        p_tot = cph + csum;
+        p_nwhole = p_tot >> 4;
+        p_nch = (p_tot + 15) >> 4;
+        rg += p_nch << 4;
+      } else {
+        --k;  // (this column again, on the short path above)
+      }
+    }
+    // ---- the last column with tokens leaves (the same steps, nothing to overlap them with)
+    pending_leave(pending_read());
+    if (lane < a.ncols) *cstile::as_global(reinterpret_cast<unsigned long long*>(my_valid + tile * 8)) = my_vmask;
+    if (!has_next) break;
+    tile += 1;
+    nxt = nn;
+  }
+  // ---- the run's last bytes of every column: what is still carried goes out bytewise
+  if (lane < a.ncols) {
+    const int have = (int)((uintptr_t)(my_chars + my_pos) & 15);
+    if (have > my_head) {
+      // (the quad's bytes through the out tile: a lane's own 16 bytes, nobody else's)
+      *reinterpret_cast<cstile::u32x4*>(lds_out + 16 * lane) = carry;
+      cstile::gptr<uint8_t> d = cstile::as_global(reinterpret_cast<uint8_t*>(((uintptr_t)my_chars + (uintptr_t)my_pos) & ~(uintptr_t)15));
+      for (int j = my_head; j < have; ++j) d[j] = lds_out[16 * lane + j];
+    }
+  }
+}
+
 }  // namespace
 
 namespace cs {
@@ -699,15 +1038,20 @@ bool split_fast(const cs_column* col, const unsigned char* delim, int dlen, int 
     int dev = 0, cus = 0;
     CS_HIP(hipGetDevice(&dev));
     CS_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    int64_t runs = std::min<int64_t>(nsub, (int64_t)cus * 16);
+    // (the third-generation emit keeps 14 waves per CU resident: runs a quarter as long share the tail out evenly)
+    const bool want_emit3 = !getenv("CS_SPLIT_EMIT2");
+    int64_t runs = std::min<int64_t>(nsub, (int64_t)cus * (want_emit3 ? 128 : 16));
     const int64_t per = (nsub + runs - 1) / runs;
     runs = (nsub + per - 1) / per;
-    const int segs_per_run = (int)std::min<int64_t>(4, per);
+    const int segs_per_run = (int)std::min<int64_t>(want_emit3 ? 2 : 4, per);
     const int64_t seg = (per + segs_per_run - 1) / segs_per_run;
     const int64_t nseg = runs * segs_per_run;
     Buf colsum = dev_alloc(sizeof(int32_t) * nseg * kMaxCols, s);
     CS_HIP(hipMemsetAsync(colsum->p, 0, sizeof(int32_t) * nseg * kMaxCols, s));
     CS_HIP(hipMemsetAsync(mx->p, 0, 4 * sizeof(int), s));
+    // the sentinel walk (both passes): a one-byte delimiter, no split limit, every row's sentinel bit inside the 96-bit mask
+    // (the longest row is column metadata, kept on the immutable column like its largest 64-row span)
+    const bool plain_walk = want_emit3 && mode == 0 && tokens <= 0 && !reverse && max_row_bytes(col, s) + 3 <= 95 && !getenv("CS_SPLIT_GENERIC_WALK");
     Measure2Args ma{view_of(col), dpat, d64, dlen, tokens, cap_in, nsub, per, seg, nseg, segs_per_run, reverse ? 1 : 0, ptr<int32_t>(colsum), ptr<int>(mx)};
     {
       ProfScope ps("k_split_measure", s);
@@ -715,6 +1059,7 @@ bool split_fast(const cs_column* col, const unsigned char* delim, int dlen, int 
       const size_t lds = (size_t)(cap_in + 32) * 4;
       if (mode == 1) hipLaunchKernelGGL(k_split_measure2<1>, dim3(g), dim3(256), lds, s, ma);
       else if (mode == 2) hipLaunchKernelGGL(k_split_measure2<2>, dim3(g), dim3(256), lds, s, ma);
+      else if (plain_walk) hipLaunchKernelGGL((k_split_measure2<0, true>), dim3(g), dim3(256), lds, s, ma);
       else hipLaunchKernelGGL(k_split_measure2<0>, dim3(g), dim3(256), lds, s, ma);
     }
     CS_HIP(hipGetLastError());
@@ -754,13 +1099,32 @@ bool split_fast(const cs_column* col, const unsigned char* delim, int dlen, int 
       CS_HIP(hipMemsetAsync(profbuf->p, 0, 64, s));
       e2.prof = ptr<unsigned long long>(profbuf);
 #endif
-      typedef void (*EmitKernel)(Emit2Args);
-      static const EmitKernel kerns[2][3] = {{k_split_emit2<0, false>, k_split_emit2<1, false>, k_split_emit2<2, false>},
-                                             {k_split_emit2<0, true>, k_split_emit2<1, true>, k_split_emit2<2, true>}};
-      const EmitKernel kern = kerns[off32 ? 1 : 0][mode];
-      if (lds2 > 48 * 1024) CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
-      const unsigned g2 = (unsigned)((runs + 3) / 4);
-      {
+      // third generation (all columns side by side in one out tile, one flush per sub-tile) when its tiles fit
+      // (regions: every token byte once, up to 15 carried bytes and up to 15 bytes of padding per column, 20 bytes of OR slack)
+      const int cap_out3 = (int)((span + 31 * ncols + 48 + 15) & ~(int64_t)15);
+      const int cap_in3 = (int)((span + 15 + 32 + 15) & ~(int64_t)15);
+      const size_t lds3 = 288 + (size_t)(16 + cap_in3 + 32 + cap_out3) * (kEmit3Threads / 64);
+      unsigned g2 = 0;
+      if (want_emit3 && lds3 <= 64 * 1024) {
+        typedef void (*Emit3Kernel)(Emit3Args);
+        // the sentinel walk: a one-byte delimiter, no split limit, rows whose sentinel bit fits the 96-bit mask
+        const bool plain = plain_walk;
+        static const Emit3Kernel kerns3[2][3] = {{k_split_emit3<0, false, false>, k_split_emit3<1, false, false>, k_split_emit3<2, false, false>},
+                                                 {k_split_emit3<0, true, false>, k_split_emit3<1, true, false>, k_split_emit3<2, true, false>}};
+        const Emit3Kernel kern3 = plain ? (off32 ? k_split_emit3<0, true, true> : k_split_emit3<0, false, true>) : kerns3[off32 ? 1 : 0][mode];
+        if (lds3 > 48 * 1024) CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern3), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
+        Emit3Args e3{e2, cap_in3, cap_out3};
+        constexpr int wpg = kEmit3Threads / 64;
+        g2 = (unsigned)((runs + wpg - 1) / wpg);
+        ProfScope ps("k_split_emit", s);
+        hipLaunchKernelGGL(kern3, dim3(g2), dim3(kEmit3Threads), lds3, s, e3);
+      } else {
+        typedef void (*EmitKernel)(Emit2Args);
+        static const EmitKernel kerns[2][3] = {{k_split_emit2<0, false>, k_split_emit2<1, false>, k_split_emit2<2, false>},
+                                               {k_split_emit2<0, true>, k_split_emit2<1, true>, k_split_emit2<2, true>}};
+        const EmitKernel kern = kerns[off32 ? 1 : 0][mode];
+        if (lds2 > 48 * 1024) CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+        g2 = (unsigned)((runs + 3) / 4);
         ProfScope ps("k_split_emit", s);
         hipLaunchKernelGGL(kern, dim3(g2), dim3(256), lds2, s, e2);
       }

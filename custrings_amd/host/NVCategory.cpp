@@ -24,6 +24,7 @@ NVCategory* NVCategory::adopt(cs_category* cat) {
   return c;
 }
 cs_category* NVCategory::handle() const { return m_cat; }
+const char* NVCategory::get_type_name() { return "custring"; }  // NVCategory.cu:581 (the key function: the vtable is emitted here)
 NVCategory* NVCategory::create_from_ipc(nvcategory_ipc_transfer& ipc) {  // NVCategory.cu:373
   NVStrings::ensure_device();
   cs_category* c = nullptr;

@@ -8,11 +8,13 @@
 #include <utility>
 #include <vector>
 
+#include "base_category.h"
+
 struct cs_category;
 struct nvcategory_ipc_transfer; /* nvstrings/ipc_transfer.h */
 class NVStrings;
 
-class NVCategory {
+class NVCategory : base_category_type { /* NVCategory.h:48: the object begins with the vtable pointer */
   cs_category* m_cat;
   NVCategory();
   NVCategory(const NVCategory&);
@@ -31,6 +33,7 @@ class NVCategory {
   static NVCategory* create_from_ipc(nvcategory_ipc_transfer& ipc); /* NVCategory.h:128 */
   int create_ipc_transfer(nvcategory_ipc_transfer& ipc);            /* NVCategory.h:176 */
   static void destroy(NVCategory* inst);
+  const char* get_type_name(); /* NVCategory.h:143, NVCategory.cu:581: "custring" */
   /* NVCategory.h:148-249 */
   unsigned int size();
   unsigned int keys_size();

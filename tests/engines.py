@@ -120,6 +120,16 @@ class OracleEngine:
     def findall(self, s, pat):
         return [c.to_list() for c in self.o.findall(Col.from_list(s), self._blob(pat))]
 
+    # record forms (extract_record.cu:47-152, findall_record.cu:39-151): the same per-row find / extract as the
+    # column-major forms, one list per row -- every group of the row for extract, the row's matches for findall
+    def extract_record(self, s, pat):
+        cols = self.extract(s, pat)
+        return [[c[i] for c in cols] for i in range(len(s))]
+
+    def findall_record(self, s, pat):
+        cols = self.findall(s, pat)
+        return [[c[i] for c in cols if c[i] is not None] for i in range(len(s))]
+
     def category(self, s):
         k, v = self.o.category(Col.from_list(s))
         return k.to_list(), v.tolist()
@@ -361,6 +371,16 @@ class EmuEngine:
         finally:
             self.e._regex_free(re)
 
+    # record forms (extract_record.cu:47-152, findall_record.cu:39-151): the same per-row find / extract as the
+    # column-major forms, one list per row -- every group of the row for extract, the row's matches for findall
+    def extract_record(self, s, pat):
+        cols = self.extract(s, pat)
+        return [[c[i] for c in cols] for i in range(len(s))]
+
+    def findall_record(self, s, pat):
+        cols = self.findall(s, pat)
+        return [[c[i] for c in cols if c[i] is not None] for i in range(len(s))]
+
     def tokenize(self, s, delimiter=None):
         return self.e.tokenize(Col.from_list(s), delimiter).to_list()
 
@@ -459,6 +479,12 @@ class GpuEngine:
 
     def findall(self, s, pat):
         return [c.to_host() for c in self.col(s).findall(pat)]
+
+    def extract_record(self, s, pat):
+        return [r.to_host() for r in self.col(s).extract_record(pat)]
+
+    def findall_record(self, s, pat):
+        return [r.to_host() for r in self.col(s).findall_record(pat)]
 
     def category(self, s):
         cat = self.nvc.from_strings(self.col(s))
@@ -616,6 +642,12 @@ def run_case(eng, case):
         return eng.replace_with_backrefs(s, a["pat"], a["repl"])
     if op == "findall":
         return eng.findall(s, a["pat"])
+    if op == "findall_col0":
+        return eng.findall(s, a["pat"])[0]
+    if op == "extract_record":
+        return eng.extract_record(s, a["pat"])
+    if op == "findall_record":
+        return eng.findall_record(s, a["pat"])
     if op == "category":
         k, v = eng.category(s)
         return {"keys": k, "values": v}

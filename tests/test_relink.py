@@ -36,6 +36,7 @@ void calls(NVStrings* s, NVCategory* c, std::vector<NVStrings*>& v, std::vector<
   s->find("a", 0, -1, ip); s->contains("a", bp); s->contains_re("a", bp); s->match("a", bp); s->count_re("a", ip);
   NVCategory::create_from_array(arr, 1); NVCategory::create_from_index(ix, 1); NVCategory::create_from_offsets(cp, 1, ip);
   NVCategory::create_from_strings(*s); NVCategory::create_from_strings(v); NVCategory::create_from_categories(cv); NVCategory::destroy(c);
+  c->get_type_name(); reinterpret_cast<base_category_type*>(c)->get_type_name();
   c->size(); c->keys_size(); c->has_nulls(); c->copy(); c->get_keys(); c->get_value(0u); c->get_value("a"); c->get_values(ip); c->values_cptr();
   c->get_indexes_for(0u, ip); c->get_indexes_for("a", ip); c->add_strings(*s); c->remove_strings(*s); c->add_keys_and_remap(*s);
   c->remove_keys_and_remap(*s); c->set_keys_and_remap(*s); c->remove_unused_keys_and_remap(); c->merge_category(*c); c->merge_and_remap(*c);
@@ -64,3 +65,36 @@ def test_reference_compiled_callers_relink_against_our_libraries():
         have |= _symbols(["-D", "--defined-only", os.path.join(ROOT, "custrings_amd", lib)])
     assert len(wanted) > 90
     assert not (wanted - have), sorted(wanted - have)
+
+
+BASE_USER = r"""
+#include <cstdio>
+#include <cstring>
+#include "nvstrings/NVCategory.h"
+// what python/cpp/numeric_category.cpp:217-236 does with a category handle: cast to the base, dispatch on the name
+int main() {
+  NVCategory* c = NVCategory::adopt(nullptr);  // (an empty instance: no device needed)
+  base_category_type* b = reinterpret_cast<base_category_type*>(c);
+  const char* name = b->get_type_name();
+  std::printf("%s\n", name);
+  const bool ok = std::strcmp(name, "custring") == 0 && *reinterpret_cast<void**>(c) != nullptr;
+  NVCategory::destroy(c);
+  return ok ? 0 : 1;
+}
+"""
+
+
+def test_category_is_reachable_through_base_category_type():
+    """base_category.h:18-23 / NVCategory.h:48: the object's first word is a vtable pointer and get_type_name()
+    dispatched through the base says "custring" (NVCategory.cu:581)."""
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "custrings_amd", "host"), "libs"], check=True)
+    libdir = os.path.join(ROOT, "custrings_amd")
+    with tempfile.TemporaryDirectory() as d:
+        src, exe = os.path.join(d, "base_user.cpp"), os.path.join(d, "base_user")
+        open(src, "w").write(BASE_USER)
+        subprocess.run(["g++", "-std=c++14", "-I", os.path.join(ROOT, "include"), src, "-o", exe, "-L", libdir, "-lNVCategory", "-lNVStrings",
+                        "-Wl,-rpath," + libdir], check=True)
+        out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.strip() == "custring", (out.returncode, out.stdout, out.stderr)
+    syms = _symbols(["-D", "--defined-only", os.path.join(libdir, "libNVCategory.so")])
+    assert "_ZTV10NVCategory" in syms and "_ZN10NVCategory13get_type_nameEv" in syms
