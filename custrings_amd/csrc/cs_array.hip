@@ -10,7 +10,6 @@
 #include <hip/hip_runtime.h>
 
 #include <cstring>
-#include <rocprim/rocprim.hpp>
 
 #include "cs_internal.h"
 #include "device_utils.h"
@@ -175,6 +174,10 @@ __global__ void k_order_keys(ColView in, const int32_t* __restrict__ ranks, int 
   const unsigned long long len = by_len ? (unsigned long long)(in.offsets[r + 1] - in.offsets[r]) + 1ull : 1ull;
   const unsigned long long rk = by_name ? (unsigned long long)(uint32_t)ranks[r] : 0ull;
   keys[r] = (len << 32) | rk;  // (len >= 1 keeps valid rows above the all-zero null key and below the all-ones one)
+}
+__global__ void k_complement_keys(unsigned long long* __restrict__ keys, int64_t n) {
+  int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i < n) keys[i] = ~keys[i];
 }
 
 }  // namespace cs
@@ -346,24 +349,18 @@ int cs_order(const cs_column* col, int sorttype, int ascending, int nullfirst, u
         if (c) cs_category_destroy(c);
       }
     } cg{cat};
-    Buf keys = dev_alloc(sizeof(unsigned long long) * rows * 2, s);
-    Buf idx = dev_alloc(sizeof(uint32_t) * rows * 2, s);
+    Buf keys = dev_alloc(sizeof(unsigned long long) * rows, s);
+    Buf idx = dev_alloc(sizeof(uint32_t) * rows, s);
     unsigned long long* k0 = ptr<unsigned long long>(keys);
     uint32_t* i0 = ptr<uint32_t>(idx);
     // nulls come first (or last) whatever the direction: their key is the extreme the direction puts there
     const int nulls_low = (nullfirst != 0) == (ascending != 0);
     hipLaunchKernelGGL(k_order_keys, dim3(blocks_for(rows)), dim3(kBlock), 0, s, view_of(col), ranks, by_len, by_name, nulls_low, k0, i0);
-    size_t tmp_bytes = 0;
-    rocprim::double_buffer<unsigned long long> kb(k0, k0 + rows);
-    rocprim::double_buffer<uint32_t> vb(i0, i0 + rows);
-    hipError_t e = ascending ? rocprim::radix_sort_pairs(nullptr, tmp_bytes, kb, vb, (size_t)rows, 0, 64, s)
-                             : rocprim::radix_sort_pairs_desc(nullptr, tmp_bytes, kb, vb, (size_t)rows, 0, 64, s);
-    if (e != hipSuccess) fail(CS_ERR_HIP, std::string("order: ") + hipGetErrorString(e));
-    Buf tmp = dev_alloc(tmp_bytes, s);
-    e = ascending ? rocprim::radix_sort_pairs(tmp->p, tmp_bytes, kb, vb, (size_t)rows, 0, 64, s)
-                  : rocprim::radix_sort_pairs_desc(tmp->p, tmp_bytes, kb, vb, (size_t)rows, 0, 64, s);
-    if (e != hipSuccess) fail(CS_ERR_HIP, std::string("order: ") + hipGetErrorString(e));
-    CS_HIP(hipMemcpyAsync(indexes, vb.current(), sizeof(uint32_t) * rows, on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s));
+    // the library's own stable radix sort (cs_radix.hip); a descending order is the ascending order of the
+    // complemented keys (equal keys keep their input order either way, as a stable descending sort leaves them)
+    if (!ascending) hipLaunchKernelGGL(k_complement_keys, dim3(blocks_for(rows)), dim3(kBlock), 0, s, k0, rows);
+    radix_sort_pairs64(reinterpret_cast<uint64_t*>(k0), reinterpret_cast<int32_t*>(i0), rows, s);
+    CS_HIP(hipMemcpyAsync(indexes, i0, sizeof(uint32_t) * rows, on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s));
     CS_HIP(hipStreamSynchronize(s));
   });
 }

@@ -51,7 +51,7 @@ __device__ __forceinline__ uint32_t flip_ascii(uint32_t w, unsigned bit) {
 
 __global__ void __launch_bounds__(256) k_case_tile(CaseTileArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;  // (scalar: what derives from it stays in SGPRs)
   constexpr int kBitmapBytes = cstile::kPfBytes / 8 + 32;
   uint8_t* base = reinterpret_cast<uint8_t*>(smem) + (size_t)wv * (2 * a.cap + kBitmapBytes);
   uint8_t* lds_in = base;

@@ -126,6 +126,8 @@ __global__ void __launch_bounds__(256) k_cat_insert(ColView in, Entry* table, ui
                                                     int* __restrict__ overflow, int probe_limit, int dbg) {
   int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (r >= in.rows) return;
+  // a table that turned out too small: the launch is lost, the workgroups that have not begun yet leave at once
+  if (__hip_atomic_load(overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 1) return;
   if (!row_is_valid(in.validity, r)) {
     slot_of_row[r] = -1;
     *has_null = 1;
@@ -277,6 +279,35 @@ __global__ void __launch_bounds__(256) k_bitonic_local(ColView in, const Entry* 
     item[base + i] = s_item[i];
   }
 }
+// ---- distinct keys in order: radix sort on the 8-byte prefix, full compares only among equal prefixes ----------
+// flags[i] = 1 when record i shares its prefix with a neighbour of the prefix-sorted sequence (such records keep their
+// SET of positions; only the order among them is open)
+__global__ void k_tie_flags(const uint64_t* __restrict__ prefix, int64_t n, int32_t* __restrict__ flags) {
+  int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t p = prefix[i];
+  flags[i] = ((i > 0 && prefix[i - 1] == p) || (i + 1 < n && prefix[i + 1] == p)) ? 1 : 0;
+}
+// the tied records, in sequence order, into their own (padded) arrays; where[j] = position of the j-th of them
+__global__ void k_tie_gather(const uint64_t* __restrict__ prefix, const int32_t* __restrict__ item, const int32_t* __restrict__ flags,
+                             const int64_t* __restrict__ pos, int64_t n, int64_t tied, int64_t padded, uint64_t* __restrict__ tprefix,
+                             int32_t* __restrict__ titem, int32_t* __restrict__ where) {
+  int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i < n && flags[i]) {
+    const int64_t j = pos[i];
+    tprefix[j] = prefix[i];
+    titem[j] = item[i];
+    where[j] = (int32_t)i;
+  }
+  if (i >= tied && i < padded) {
+    tprefix[i] = ~0ull;
+    titem[i] = -1;
+  }
+}
+__global__ void k_tie_scatter(const int32_t* __restrict__ titem, const int32_t* __restrict__ where, int64_t tied, int32_t* __restrict__ item) {
+  int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (j < tied) item[where[j]] = titem[j];
+}
 __global__ void k_cat_ranks(const int32_t* __restrict__ item, int64_t uniq, int shift,
                             int32_t* __restrict__ rank_of_slot) {
   int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -358,6 +389,8 @@ cs_category* cs::category_build(const cs_column* col, hipStream_t s) {
   int first_log2 = 22;
   if (const char* e = getenv("CS_CAT_FIRST_LOG2")) first_log2 = std::max(4, std::min(30, atoi(e)));  // tests: force retries
   int64_t cap = std::min<int64_t>(full, getenv("CS_CAT_FULL_TABLE") && !full_out_of_range ? full : (int64_t)1 << first_log2);
+  constexpr int64_t kSampleRows = 1 << 21;  // (the first rows: they fit the small table whatever they hold)
+  bool sampled = getenv("CS_CAT_NO_SAMPLE") != nullptr;
   for (;;) {
     table = dev_alloc(sizeof(Entry) * cap, s);
     CS_HIP(hipMemsetAsync(table->p, 0xFF, sizeof(Entry) * cap, s));
@@ -375,7 +408,28 @@ cs_category* cs::category_build(const cs_column* col, hipStream_t s) {
     CS_HIP(hipStreamSynchronize(s));
     if (h[1] & 2) fail(CS_ERR_RANGE, "category: a key of 16 MiB or more");
     if (cap == full || !h[1]) break;  // (room for all-distinct rows: no limit applied, nothing to retry)
-    cap = std::min<int64_t>(full, cap * 16);
+    int64_t next_cap = std::min<int64_t>(full, cap * 16);
+    if (!sampled && rows > kSampleRows && cap >= 2 * kSampleRows) {
+      // The small table overflowed.  How many distinct keys is this?  The share of distinct keys among the first rows
+      // bounds the column's from above (it only falls as more rows come), so the table is sized from a sample instead of
+      // growing 16-fold per lost pass over all rows (K = 0.5 N: the 64M-slot attempt ran to 90 % before it gave up).
+      sampled = true;
+      ColView head = in;
+      head.rows = kSampleRows;
+      CS_HIP(hipMemsetAsync(table->p, 0xFF, sizeof(Entry) * cap, s));
+      CS_HIP(hipMemsetAsync(flags_d->p, 0, 2 * sizeof(int), s));
+      hipLaunchKernelGGL(k_cat_insert, dim3(blocks_for(kSampleRows)), dim3(kBlock), 0, s, head, ptr<Entry>(table), (uint32_t)(cap - 1),
+                         ptr<int32_t>(slot_of_row), ptr<int>(flags_d), ptr<int>(flags_d) + 1, 0x7fffffff, 0);
+      Buf occ = dev_alloc(sizeof(int32_t) * cap, s);
+      hipLaunchKernelGGL(k_cat_flags, dim3(blocks_for(cap)), dim3(kBlock), 0, s, ptr<const Entry>(table), cap, ptr<int32_t>(occ));
+      Buf occ_pos = dev_alloc(sizeof(int64_t) * (cap + 1), s);
+      const int64_t distinct = offsets_from_lengths(ptr<int32_t>(occ), cap, ptr<int64_t>(occ_pos), s);
+      const double share = (double)distinct / (double)kSampleRows;
+      int64_t want = 256;
+      while (want < (int64_t)(2.5 * share * (double)rows)) want <<= 1;
+      next_cap = std::min<int64_t>(full, std::max<int64_t>(next_cap, want));
+    }
+    cap = next_cap;
     if (cap == full && full_out_of_range) fail(CS_ERR_RANGE, "category: more than 2^30 rows with more distinct keys than a 2^31-slot table holds");
     // slot ids travel as int32 (negative = null row): a table of 2^31 slots or more cannot be addressed
     if (cap > ((int64_t)1 << 30)) fail(CS_ERR_RANGE, "category: more than 2^29 rows with mostly distinct keys in one column");
@@ -388,8 +442,30 @@ cs_category* cs::category_build(const cs_column* col, hipStream_t s) {
   Buf pos = dev_alloc(sizeof(int64_t) * (cap + 1), s);
   const int64_t uniq = offsets_from_lengths(ptr<int32_t>(flags), cap, ptr<int64_t>(pos), s);
   const int shift = read_back<int>(has_null_d->p, s) ? 1 : 0;
+  // Distinct keys in order.  The records (8-byte big-endian prefix, slot) are radix-sorted on the prefix -- linear in the
+  // key count, where the bitonic network this replaces took log^2 K steps over the padded records and compared whole
+  // keys through the table on every tie (K = 100M: hundreds of global steps).  Keys that share a prefix with a
+  // neighbour keep their set of positions; the order among them comes from full compares: those records alone go
+  // through the compare network (a handful for ordinary columns; every one only when all keys share 8 bytes).
+  auto bitonic = [&](uint64_t* pfx, int32_t* itm, int64_t padded) {
+    // stages that fit a chunk run in LDS in one launch; a later stage takes its long-distance
+    // steps one launch each and finishes in LDS
+    const int64_t chunk = std::min<int64_t>(padded, kSortChunk);
+    const unsigned nchunks = (unsigned)(padded / chunk);
+    if (padded >= 2)
+      hipLaunchKernelGGL(k_bitonic_local, dim3(nchunks), dim3(256), 0, s, in, ptr<const Entry>(table), pfx, itm, padded, (int64_t)2, chunk);
+    for (int64_t k = 2 * chunk; k <= padded; k <<= 1) {
+      for (int64_t j = k >> 1; j >= chunk; j >>= 1)
+        hipLaunchKernelGGL(k_bitonic_step, dim3(blocks_for(padded)), dim3(kBlock), 0, s, in, ptr<const Entry>(table), pfx, itm, padded, j, k);
+      hipLaunchKernelGGL(k_bitonic_local, dim3(nchunks), dim3(256), 0, s, in, ptr<const Entry>(table), pfx, itm, padded, k, k);
+    }
+  };
+  // (a key set that one LDS chunk holds sorts in a single launch of the compare network: the radix sort's histogram and
+  // scan round trips would cost more than they save there)
+  const bool use_radix = !getenv("CS_CAT_BITONIC") && (uniq > kSortChunk || getenv("CS_CAT_RADIX"));
   int64_t padded = 1;
   while (padded < uniq) padded <<= 1;
+  if (use_radix) padded = std::max<int64_t>(uniq, 1);
   Buf prefix = dev_alloc(sizeof(uint64_t) * padded, s);
   Buf item = dev_alloc(sizeof(int32_t) * padded, s);
   hipLaunchKernelGGL(k_cat_records, dim3(blocks_for(std::max(cap, padded))), dim3(kBlock), 0, s, in,
@@ -397,19 +473,26 @@ cs_category* cs::category_build(const cs_column* col, hipStream_t s) {
                      uniq, ptr<uint64_t>(prefix), ptr<int32_t>(item));
   {
     ProfScope ps("k_cat_sort", s);
-    // stages that fit a chunk run in LDS in one launch; a later stage takes its long-distance
-    // steps one launch each and finishes in LDS
-    const int64_t chunk = std::min<int64_t>(padded, kSortChunk);
-    const unsigned nchunks = (unsigned)(padded / chunk);
-    if (padded >= 2)
-      hipLaunchKernelGGL(k_bitonic_local, dim3(nchunks), dim3(256), 0, s, in, ptr<const Entry>(table),
-                         ptr<uint64_t>(prefix), ptr<int32_t>(item), padded, (int64_t)2, chunk);
-    for (int64_t k = 2 * chunk; k <= padded; k <<= 1) {
-      for (int64_t j = k >> 1; j >= chunk; j >>= 1)
-        hipLaunchKernelGGL(k_bitonic_step, dim3(blocks_for(padded)), dim3(kBlock), 0, s, in,
-                           ptr<const Entry>(table), ptr<uint64_t>(prefix), ptr<int32_t>(item), padded, j, k);
-      hipLaunchKernelGGL(k_bitonic_local, dim3(nchunks), dim3(256), 0, s, in, ptr<const Entry>(table),
-                         ptr<uint64_t>(prefix), ptr<int32_t>(item), padded, k, k);
+    if (!use_radix) {
+      bitonic(ptr<uint64_t>(prefix), ptr<int32_t>(item), padded);
+    } else if (uniq > 1) {
+      radix_sort_pairs64(ptr<uint64_t>(prefix), ptr<int32_t>(item), uniq, s);
+      Buf tflags = dev_alloc(sizeof(int32_t) * uniq, s);
+      hipLaunchKernelGGL(k_tie_flags, dim3(blocks_for(uniq)), dim3(kBlock), 0, s, ptr<const uint64_t>(prefix), uniq, ptr<int32_t>(tflags));
+      Buf tpos = dev_alloc(sizeof(int64_t) * (uniq + 1), s);
+      const int64_t tied = offsets_from_lengths(ptr<int32_t>(tflags), uniq, ptr<int64_t>(tpos), s);
+      if (tied > 0) {
+        int64_t tpad = 1;
+        while (tpad < tied) tpad <<= 1;
+        Buf tprefix = dev_alloc(sizeof(uint64_t) * tpad, s), titem = dev_alloc(sizeof(int32_t) * tpad, s), where = dev_alloc(sizeof(int32_t) * tied, s);
+        hipLaunchKernelGGL(k_tie_gather, dim3(blocks_for(std::max(uniq, tpad))), dim3(kBlock), 0, s, ptr<const uint64_t>(prefix), ptr<const int32_t>(item),
+                           ptr<const int32_t>(tflags), ptr<const int64_t>(tpos), uniq, tied, tpad, ptr<uint64_t>(tprefix), ptr<int32_t>(titem),
+                           ptr<int32_t>(where));
+        bitonic(ptr<uint64_t>(tprefix), ptr<int32_t>(titem), tpad);
+        hipLaunchKernelGGL(k_tie_scatter, dim3(blocks_for(tied)), dim3(kBlock), 0, s, ptr<const int32_t>(titem), ptr<const int32_t>(where), tied,
+                           ptr<int32_t>(item));
+        CS_HIP(hipStreamSynchronize(s));  // (the tie buffers' lifetime)
+      }
     }
   }
   Buf rank_of_slot = dev_alloc(sizeof(int32_t) * cap, s);

@@ -197,7 +197,7 @@ __global__ void __launch_bounds__(1024) k_scan_block_sums(int64_t* __restrict__ 
   __shared__ long long wave_tot[16];
   __shared__ long long carry_s;
   int64_t* seg = sums + (int64_t)blockIdx.x * nb;
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   if (threadIdx.x == 0) carry_s = 0;
   __syncthreads();
   for (int64_t base = 0; base < nb; base += 8192) {

@@ -162,6 +162,8 @@ unsigned resident_grid(const void* kern, size_t lds, int64_t wanted);
 // Row-wise concatenation of columns into one new column.
 cs_column* concat_columns(const std::vector<const cs_column*>& cols, hipStream_t s);
 
+// cs_radix.hip: stable LSD radix sort of n (64-bit key, 32-bit item) pairs by key, ascending, in place (synchronises `s`)
+void radix_sort_pairs64(uint64_t* keys, int32_t* items, int64_t n, hipStream_t s);
 // cs_category.hip: keys = sorted unique rows (null first), values[r] = index of row r's key
 cs_category* category_build(const cs_column* col, hipStream_t s);
 // cs_array.hip: rows of `col` at the given device positions; with `null_when_negative` a negative

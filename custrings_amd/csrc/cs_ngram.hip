@@ -72,7 +72,7 @@ __device__ __forceinline__ void or_bytes(uint8_t* region, int di, uint32_t t0, u
 
 __global__ void __launch_bounds__(256) k_ngram_tile(NgramArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;  // (scalar: what derives from it stays in SGPRs)
   const int NG = 64 * a.M;
   const int nrel = NG + a.n + 1;                       // relative offsets kept per tile
   const int rel_bytes = (nrel * 4 + 15) & ~15;

@@ -251,7 +251,7 @@ struct SpanWriteArgs {
 };
 __global__ void __launch_bounds__(256) k_spans_write_tile(SpanWriteArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;  // (scalar: what derives from it stays in SGPRs)
   uint8_t* lds_in = reinterpret_cast<uint8_t*>(smem) + (size_t)wv * (2 * a.cap + 64);
   uint8_t* region = lds_in + a.cap + 32;
   const ColView& in = a.in;
@@ -728,7 +728,7 @@ template <bool IN_LDS>
 __global__ void __launch_bounds__(256) k_tdfa_replace_tile(TileArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   uint8_t* base = reinterpret_cast<uint8_t*>(smem);
-  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;  // (scalar: what derives from it stays in SGPRs)
   uint8_t* lds_in = base + a.tbl_bytes + (size_t)wv * (a.cap_in + a.cap_out + 64);
   uint8_t* lds_out = lds_in + a.cap_in + 32;
   const TCtx c = tsetup<IN_LDS>(a.L, a.flags, smem);  // (block barrier inside when staging)
@@ -961,7 +961,7 @@ __global__ void __launch_bounds__(256, BREFS ? 2 : CS_STREAM_WAVES) k_tdfa_repla
   static_assert(!BREFS || (UNITS && IN_LDS && !REP16), "the backrefs form is a unit-scan variant");
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   uint8_t* base = reinterpret_cast<uint8_t*>(smem);
-  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;  // (scalar: what derives from it stays in SGPRs)
   const int bm_bytes = (a.cap_in >> 3) + 32;  // one candidate bit per staged byte
   // second bitmap, unit queue, bail word (+ BREFS: a record of three words per match, a growth counter per row)
   const int unit_bytes = UNITS ? bm_bytes + kUnitQueue * 4 + 16 + (BREFS ? kUnitQueue * 12 + 64 * 4 : 0) : 0;
@@ -1624,7 +1624,7 @@ __global__ void __launch_bounds__(256, ((UNITS && MODE == 3) || MODE == 4) ? 3 :
   static_assert(!UNITS || ((MODE == 0 || MODE == 2 || MODE == 3) && !LONG), "unit scan: contains_re / count_re / findall on rows within the 96-byte masks");
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   uint8_t* base = reinterpret_cast<uint8_t*>(smem);
-  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;  // (scalar: what derives from it stays in SGPRs)
   const int bm_bytes = (a.cap_in >> 3) + 32;
   // (MODE 4 keeps a lane-private byte per step of a group run behind the bitmap: regex_tdfa.h, group_find_back)
   const int unit_bytes = UNITS ? bm_bytes + kUnitQueue * 4 + 64 * 4 + 16 : (MODE == 4 ? cstd::Tdfa::kBackSteps * 64 : 0);  // x bitmap, unit queue, per-row results, bail word

@@ -35,7 +35,7 @@ struct StripTileArgs {
 
 __global__ void __launch_bounds__(256) k_strip_tile(StripTileArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;  // (scalar: what derives from it stays in SGPRs)
   uint8_t* lds_in = reinterpret_cast<uint8_t*>(smem) + (size_t)wv * 2 * a.cap;
   uint8_t* lds_out = lds_in + a.cap;
   const ColView& in = a.in;
@@ -117,7 +117,7 @@ template <int MODE>
 __global__ void __launch_bounds__(256) k_find_tile(FindTileArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   __shared__ uint8_t s_needle[64];
-  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;  // (scalar: what derives from it stays in SGPRs)
   if (threadIdx.x < 64) s_needle[threadIdx.x] = a.needle[threadIdx.x];
   __syncthreads();
   constexpr int kBitmapBytes = cstile::kPfBytes / 8 + 32;

@@ -298,7 +298,7 @@ template <int MODE>
 __global__ void __launch_bounds__(256) k_split_measure(MeasureArgs a) {
   constexpr bool WS = MODE == 1, MULTI = MODE == 2;
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;  // (scalar: what derives from it stays in SGPRs)
   uint8_t* lds_in = reinterpret_cast<uint8_t*>(smem) + (size_t)wv * (a.cap + 32);
   const long long sub = (long long)blockIdx.x * 4 + wv;
   if (sub >= a.nsub) return;
@@ -356,7 +356,7 @@ __global__ void __launch_bounds__(256, 8) k_split_measure2(Measure2Args a) {  //
   constexpr bool WS = MODE == 1, MULTI = MODE == 2;
   static_assert(!PLAIN || MODE == 0, "the sentinel walk is the one-byte delimiter's");
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;  // (scalar: what derives from it stays in SGPRs)
   uint8_t* lds_in = reinterpret_cast<uint8_t*>(smem) + (size_t)wv * (a.cap + 32);
   const long long sid = (long long)blockIdx.x * 4 + wv;
   if (sid >= a.nseg) return;
@@ -466,7 +466,7 @@ struct EmitArgs {
 };
 __global__ void __launch_bounds__(256) k_split_emit(EmitArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;  // (scalar: what derives from it stays in SGPRs)
   uint8_t* lds_in = reinterpret_cast<uint8_t*>(smem) + (size_t)wv * (a.cap_in + a.cap_out + 64);
   uint8_t* lds_out = lds_in + a.cap_in + 32;
   const long long sub = (long long)blockIdx.x * 4 + wv;
@@ -561,7 +561,7 @@ __global__ void __launch_bounds__(256, CS_EMIT2_WAVES) k_split_emit2(Emit2Args a
   constexpr bool WS = MODE == 1, MULTI = MODE == 2;
   typedef typename std::conditional<OFF32, int32_t, int64_t>::type off_t;
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;  // (scalar: what derives from it stays in SGPRs)
   uint8_t* lds_in = reinterpret_cast<uint8_t*>(smem) + (size_t)wv * (a.cap_in + 32 + 2 * a.cap_col + (WS ? 2 : 1) * a.ncols * 64);
   uint8_t* region0 = lds_in + a.cap_in + 32;
   uint8_t* dpos = region0 + 2 * a.cap_col;  // dpos[j * 64 + lane] = row offset of the lane's j-th delimiter (WS: j-th token start)

@@ -80,7 +80,7 @@ __device__ __forceinline__ uint32_t byte_of(const uint4& q, int b) {
 template <int PASS>
 __global__ void __launch_bounds__(256) k_tok_tile(TokTileArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;  // (scalar: what derives from it stays in SGPRs)
   constexpr int kBitmapBytes = cstile::kPfBytes / 8 + 32;
   const int per_wave = kBitmapBytes + (PASS ? a.cap_out + 2 * a.cap_tok : 0);
   uint8_t* base = reinterpret_cast<uint8_t*>(smem) + (size_t)wv * per_wave;

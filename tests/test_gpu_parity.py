@@ -346,6 +346,49 @@ def test_gpu_full_shard_c4_category(orc):
     del vals
 
 
+@pytest.mark.parametrize("K", [1 << 27, 1 << 40])
+def test_gpu_category_with_keys_close_to_rows(orc, K, monkeypatch):
+    """BASELINE.md section 3, C4 with K close to N (NVCategory.cu:246-304 sorts every distinct key): 60M rows of the
+    log-uniform generator over 2^27 names (about a fifth of the rows are distinct keys) and over 2^40 names (nearly every
+    row is its own key).  The distinct keys go through the radix sort on the 8-byte prefix with full compares among equal
+    prefixes: keys strictly ascending bytewise (hence distinct), sampled windows of the values point at the rows' own
+    strings, and on a prefix of the column the whole category equals the oracle's."""
+    from custrings_amd import nvcategory
+
+    rows = 60_000_000
+    g = gpuutil.synth(4, 0, rows, K)
+    cat = nvcategory.from_strings(g)
+    keys = cat.keys()
+    kchars, koffs, kvalid = keys._export64()
+    nk = keys.size()
+    assert nk > (8_000_000 if K == 1 << 27 else 20_000_000)
+    assert keys.null_count() == 1 and not (kvalid[0] & 1)
+    kb = kchars.reshape(-1, 16)
+    assert kb.shape[0] == nk - 1
+    hi, lo = kb[:, :8].copy().view(">u8").ravel(), kb[:, 8:].copy().view(">u8").ravel()
+    assert np.all((hi[1:] > hi[:-1]) | ((hi[1:] == hi[:-1]) & (lo[1:] > lo[:-1]))), "keys not strictly ascending"
+    vals = np.zeros(rows, dtype=np.int32)
+    cat.values(vals)
+    assert vals.min() == 0 and vals.max() == nk - 1
+    for first in (0, 31_000_001, rows - 100_000):
+        w = 100_000
+        chars, offs, valid = g._export_window(first, w)
+        isnull = np.unpackbits(valid, bitorder="little")[:w] == 0
+        v = vals[first : first + w]
+        assert np.array_equal(v == 0, isnull)
+        assert np.array_equal(kb[v[~isnull] - 1], chars.reshape(-1, 16)), first
+    del vals, cat, keys
+    # the whole category of a 300k-row prefix against the oracle, through the same sort (forced: the key set is small)
+    monkeypatch.setenv("CS_CAT_RADIX", "1")
+    small = gpuutil.synth(4, 0, 300_000, K)
+    ok, ov = orc.category(orc.synth(4, 0, 300_000, param=K))
+    c2 = nvcategory.from_strings(small)
+    gpuutil.assert_same(c2.keys(), ok, "keys")
+    v2 = np.zeros(300_000, dtype=np.int32)
+    c2.values(v2)
+    assert np.array_equal(v2, ov)
+
+
 def test_gpu_full_shard_c5_tokenize_ngrams(orc):
     """C5 at one GPU's shard of the 500M-row config (62.5M rows): token and byte conservation over
     the whole shard, sampled row windows of the flat token column and of its bigrams against the oracle."""
