@@ -72,8 +72,9 @@ def main():
     ap.add_argument("--cpu-rows", type=int, default=3_000_000, help="rows of the same workload timed on the CPU oracle")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--pmc-traffic", type=float, default=None, help="HBM bytes/launch of the dominant kernel from a separate rocprofv3 --pmc run")
-    ap.add_argument("--config", default="c3", choices=["c3", "c4", "c5"],
-                    help="c3 = the headline (default); c4 = distributed NVCategory build (key-set all-gather inside the timed region); "
+    ap.add_argument("--config", default="c3", choices=["c2", "c3", "c4", "c5"],
+                    help="c3 = the headline (default); c2 = lower + strip + split(' ') on 10M rows x 64 chars; "
+                         "c4 = distributed NVCategory build (key-set all-gather inside the timed region); "
                          "c5 = tokenize + n-grams(2) with the shard-boundary exchange inside the timed region")
     ap.add_argument("--keys", type=int, default=1_000_000, help="c4: distinct tokens K")
     ap.add_argument("--backend", default="nccl", help="process-group backend (nccl = RCCL; gloo lets several ranks share one GPU for a plumbing check)")
@@ -100,6 +101,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if args.config == "c2":
+        run_c2(args, rank, world, barrier)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     if args.config != "c3":
         run_other_config(args, rank, world, barrier)
         if world > 1:
@@ -239,6 +246,83 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def run_c2(args, rank, world, barrier):
+    """BASELINE.json configs[1]: 10M synthetic UTF-8 rows x 64 chars per GPU, lower() + strip() + split(' ') -- each op on
+    the result of the one before, as a caller would chain them.  One JSON line: whole-step throughput, the three ops'
+    device times (HIP events on the launch stream, recorded around each call) and their shares of the HBM roofline over
+    the ops' algorithmic bytes (output offsets counted at the width actually written)."""
+    from custrings_amd import _lib, nvstrings
+
+    L = _lib.lib
+    rows = args.rows if args.rows != 100_000_000 else 10_000_000
+    out = C.c_void_p()
+    _lib.check(L.cs_synth_column(2, rank * rows, rows, SEED, 0, None, C.byref(out)))
+    col = nvstrings.nvstrings(out.value)
+    in_bytes = int(L.cs_column_nbytes(col.m_cptr))
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
+    info = {}
+
+    def step(marks=None):
+        if marks:
+            marks[0].record()
+        low = col.lower()
+        if marks:
+            marks[1].record()
+        st = low.strip()
+        if marks:
+            marks[2].record()
+        cols = st.split(" ")
+        if marks:
+            marks[3].record()
+        if "cols" not in info:
+            info.update(cols=len(cols), lower_bytes=int(L.cs_column_nbytes(low.m_cptr)), strip_bytes=int(L.cs_column_nbytes(st.m_cptr)),
+                        split_bytes=sum(int(L.cs_column_nbytes(c.m_cptr)) for c in cols),
+                        off_bytes=4 if all(int(L.cs_column_offset_width(c.m_cptr)) == 4 for c in cols) else 8)
+
+    for _ in range(max(args.warmup, 1)):
+        step()
+    fallbacks0 = int(L.cs_fallback_count())
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(ev[i])
+    barrier()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    tot = torch.tensor([float(in_bytes), float(rows)], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+    elapsed = float(t.item())
+    if rank != 0:
+        return
+    per = elapsed / args.steps
+    ms = [sum(ev[i][k].elapsed_time(ev[i][k + 1]) for i in range(args.steps)) / args.steps for k in range(3)]
+    ov = 8.125
+    alg = {"lower": in_bytes + info["lower_bytes"] + 2 * ov * rows,
+           "strip": info["lower_bytes"] + info["strip_bytes"] + 2 * ov * rows,
+           "split": info["strip_bytes"] + ov * rows + info["split_bytes"] + info["cols"] * (info["off_bytes"] + 0.125) * rows}
+    ops = [{"op": name, "ms": round(ms[k], 3), "alg_bytes_per_row": round(alg[name] / rows, 1),
+            "achieved_GBps": round(alg[name] / (ms[k] * 1e-3) / 1e9, 1), "frac": round(alg[name] / (ms[k] * 1e-3) / 8e12, 4)}
+           for k, name in enumerate(("lower", "strip", "split"))]
+    dom = max(ops, key=lambda o: o["ms"])
+    total_alg = sum(alg.values())
+    result = {
+        "metric": "GB/s input chars, lower() + strip() + split(' ') on 10M rows x 64 chars per GPU (C2)",
+        "value": round(float(tot[0].item()) / per / 1e9, 2), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(per * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "config": {"workload": "C2: %d rows x 64 chars per GPU (5 %% rows with two-byte characters, 1 %% null, 0.5 %% empty), lower() -> strip() -> split(' ') into %d columns"
+                               % (rows, info["cols"]), "rows_per_gpu": rows, "seed": SEED, "sharding": "row ranges, no data-path collective"},
+        "mstrings_per_s": round(float(tot[1].item()) / per / 1e6, 1),
+        "roofline": {"bound": "hbm", "kernel": dom["op"], "achieved": dom["achieved_GBps"], "peak": 8000.0, "unit": "GB/s", "frac": dom["frac"], "traffic": None},
+        "roofline_ops": ops,
+        "roofline_pipeline": {"alg_bytes_per_row": round(total_alg / rows, 1), "achieved": round(total_alg * world / per / 1e9, 1), "peak": 8000.0 * world,
+                              "unit": "GB/s", "frac": round(total_alg / per / 8e12, 4)},
+        "fallbacks_in_timed_region": int(L.cs_fallback_count()) - fallbacks0,
+    }
+    print(json.dumps(result), flush=True)
 
 
 def run_other_config(args, rank, world, barrier):

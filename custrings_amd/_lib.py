@@ -104,6 +104,7 @@ _PROTOS = {
     "cs_regex_compile": (i32, [cp, P(vp)]),
     "cs_regex_destroy": (i32, [vp]),
     "cs_regex_inst_count": (i32, [vp]),
+    "cs_regex_engine": (i32, [vp]),
     "cs_regex_blob": (i32, [vp, P(P(C.c_int32)), P(i32)]),
     "cs_contains_re": (i32, [vp, vp, vp, i32, vp, P(i64)]),
     "cs_match_re": (i32, [vp, vp, vp, i32, vp, P(i64)]),
@@ -115,6 +116,7 @@ _PROTOS = {
     "cs_records_from_columns": (i32, [P(vp), i32, i32, vp, i32, vp, P(vp)]),
     "cs_category_build": (i32, [vp, vp, P(vp)]),
     "cs_category_merge": (i32, [P(vp), i32, vp, P(vp)]),
+    "cs_category_merge_gathered": (i32, [vp, P(vp), i32, i32, vp, P(vp), vp]),
     "cs_category_destroy": (i32, [vp]),
     "cs_category_size": (i64, [vp]),
     "cs_category_keys_size": (i64, [vp]),

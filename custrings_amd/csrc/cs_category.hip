@@ -571,6 +571,41 @@ int cs_category_merge(const cs_category* const* cats, int ncats, cs_stream strea
   });
 }
 
+// The step of a DISTRIBUTED category build that follows the exchange (BASELINE.json north_star: "an RCCL all-gather ...
+// only to merge NVCategory's global key set"; the reference has no multi-GPU form: this composes create_from_categories,
+// NVCategory.cu:430-514).  Every rank built the category of its own row range and all-gathered the ranks' key sets --
+// with RCCL, MPI or anything else: the transport stays with the caller, so a C++ host reaches the global category without
+// the Python layer (custrings_amd/dist.py does the same composition for torch.distributed).  `keysets[r]` = rank r's
+// sorted key set as a column (this rank's own at index `rank`, equal to local->keys).  Out: the merged key set (the same
+// on every rank) and, in `values` (device memory, local->rows int32), the local rows' codes in the merged key set.
+int cs_category_merge_gathered(const cs_category* local, const cs_column* const* keysets, int nranks, int rank, cs_stream stream,
+                               cs_column** merged_keys, int32_t* values) {
+  return guard([&] {
+    if (!local || !keysets || !merged_keys || nranks < 1 || rank < 0 || rank >= nranks) fail(CS_ERR_INVALID_ARG, "merge_gathered: bad arguments");
+    if (local->rows > 0 && !values) fail(CS_ERR_INVALID_ARG, "merge_gathered: no room for the values");
+    require_device();
+    hipStream_t s = S(stream);
+    std::vector<const cs_column*> sets;
+    int64_t before = 0;
+    for (int r = 0; r < nranks; ++r) {
+      if (!keysets[r]) fail(CS_ERR_INVALID_ARG, "merge_gathered: null key set");
+      if (r < rank) before += keysets[r]->rows;
+      sets.push_back(keysets[r]);
+    }
+    if (keysets[rank]->rows != local->keys->rows) fail(CS_ERR_INVALID_ARG, "merge_gathered: keysets[rank] is not the local key set");
+    // the category of the concatenated key sets: its keys are the merged key set, its codes the old-code -> new-code
+    // tables of the ranks, back to back
+    std::unique_ptr<cs_column> all_keys(concat_columns(sets, s));
+    std::unique_ptr<cs_category> merged(build(all_keys.get(), s));
+    if (local->rows)
+      hipLaunchKernelGGL(k_remap, dim3(blocks_for(local->rows)), dim3(kBlock), 0, s, ptr<const int32_t>(local->values), local->rows,
+                         ptr<const int32_t>(merged->values) + before, values);
+    CS_HIP(hipGetLastError());
+    CS_HIP(hipStreamSynchronize(s));
+    *merged_keys = merged->keys.release();
+  });
+}
+
 int cs_category_destroy(cs_category* cat) {
   return guard([&] { delete cat; });
 }

@@ -1408,6 +1408,47 @@ __global__ void __launch_bounds__(256, BREFS ? 2 : CS_STREAM_WAVES) k_tdfa_repla
         if (lane == 0) atomicOr(a.error, 1u | 32u);
         redo = false;
       }
+      if (UNITS && !BREFS && !units_done && lean && a.maxrepl < 0 && D.img[13] >= 1 && !(a.debug & 2048)) {  // (wave-uniform)
+        // A sub-tile the unit route did not take (more units than the queue holds: patterns whose candidate bytes are
+        // everywhere, such as alternations of word-bounded literals; or no decomposition at all): every row lane scans its
+        // own row, but the matches still go into the two bitmaps -- a start bit and a last-byte bit each, as the unit lanes
+        // leave them -- so that the rows are assembled from the masks.  Before, such rows were only MEASURED here and
+        // scanned a second time at assembly by the generic byte-at-a-time scanner: one matching row in a wave made the
+        // other 63 lanes wait for that whole scan (52 ms on the 100M-row column for (\bin\b)|(\ba\b)|(\bthe\b), which
+        // matches in 1.3 % of the rows).
+        using namespace cstd;
+        uint32_t m0, m1, m2;
+        cstile::row_bits96(bitmap, lead + rbeg, n, m0, m1, m2);
+        cstile::wave_lds_fence();
+        for (int i = lane * 16; i < bm_bytes; i += 64 * 16) {
+          *reinterpret_cast<uint4*>(reinterpret_cast<uint8_t*>(bitmap) + i) = make_uint4(0, 0, 0, 0);
+          *reinterpret_cast<uint4*>(reinterpret_cast<uint8_t*>(xbitmap) + i) = make_uint4(0, 0, 0, 0);
+        }
+        cstile::wave_lds_fence();
+        bool bail = false;
+        if (live) {
+          const int pu = lead + rbeg;
+          auto recm = [&](int mb, int me, int) {
+            const int ps = pu + mb, pe = pu + me - 1;
+            __hip_atomic_fetch_or(bitmap + (ps >> 5), 1u << (ps & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            __hip_atomic_fetch_or(xbitmap + (pe >> 5), 1u << (pe & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+          };
+          vm.scan_lean_dispatch(-1, m0, m1, m2, recm, bail);
+        }
+        cstile::wave_lds_fence();
+        uint32_t s0, s1, s2, e0, e1, e2;
+        cstile::row_bits96(bitmap, lead + rbeg, n, s0, s1, s2);
+        cstile::row_bits96(xbitmap, lead + rbeg, n, e0, e1, e2);
+        if (live && !bail) {
+          uS = u128(s0 | ((unsigned long long)s1 << 32), s2);
+          uE = u128(e0 | ((unsigned long long)e1 << 32), e2);
+          nm = u128_popc(uS);
+          out_len = n - u128_popc(u128_sub(u128_shl1(uE), uS)) + nm * rb;
+          from_masks = true;
+        }
+        redo = live && bail;  // (such a row is scanned whole by the generic scan below; nothing of it counts from above)
+        units_done = true;
+      }
       if (!BREFS && !units_done && lean && live && a.maxrepl != 0) {
         bool bail = false;
         uint32_t m0, m1, m2;  // candidate bits, bit i = byte i of the row
@@ -1746,6 +1787,11 @@ __global__ void __launch_bounds__(256, ((UNITS && MODE == 3) || MODE == 4) ? 3 :
           for (int i = 0; i < k; ++i) *o++ = q[i];
         });
       }
+    } else if (MODE == 1) {
+      // match (count.cu:113-165): the anchored run on the staged row -- the rows arrive through the same coalesced
+      // tiles as contains_re's instead of a thread per row reading its bytes from HBM
+      cstd::Tdfa vm(D, P, lds_in + lead + rbeg, n, (lead + rbeg) & 3);
+      v = live ? csvm::row_contains_re(vm, true) : 0;
     } else if (MODE == 4) {
       cstd::Tdfa vm(D, P, lds_in + lead + rbeg, n, (lead + rbeg) & 3);
       int mb = 0, me = 0;
@@ -1927,7 +1973,7 @@ __global__ void __launch_bounds__(256, ((UNITS && MODE == 3) || MODE == 4) ? 3 :
     }
     if (lane < nrows) {
       if (MODE == 2) a.out32[r0 + lane] = v;
-      else if (MODE == 0) a.out8[r0 + lane] = (uint8_t)v;
+      else if (MODE == 0 || MODE == 1) a.out8[r0 + lane] = (uint8_t)v;
     }
     hits += v > 0;
     cstile::wave_lds_fence();  // the next tile overwrites lds_in
@@ -2067,7 +2113,7 @@ void scan(const cs_column* col, cs_regex* re, uint8_t* out8, int32_t* out32, int
   CS_HIP(hipMemsetAsync(cnt->p, 0, 8, s));
   RowSrc src{view_of(col), d_unicode_flags(), col->nbytes + (col->chars && col->chars->capacity ? 64 : 0)};
   bool streamed = false;
-  if (tdfa && tp.d.in_lds && MODE != 1 && !getenv("CS_REGEX_ROWWISE")) {
+  if (tdfa && tp.d.in_lds && !getenv("CS_REGEX_ROWWISE")) {
     const TileChoice tc = choose_tile(col, s);
     const int cap = tc.cap;
     // the unit scan (k_tdfa_scan_stream<.., UNITS>): patterns whose tagged DFA offers the decomposition, rows within the masks
@@ -2087,7 +2133,7 @@ void scan(const cs_column* col, cs_regex* re, uint8_t* out8, int32_t* out32, int
       sa.rows_per_tile = tc.R;
       sa.cap_in = cap;
       sa.tbl_bytes = (int)tp.lds_bytes;
-      auto kern = tc.lng ? &k_tdfa_scan_stream<MODE == 2 ? 2 : 0, true, true> : &k_tdfa_scan_stream<MODE == 2 ? 2 : 0, true, false>;
+      auto kern = tc.lng ? &k_tdfa_scan_stream<MODE, true, true> : &k_tdfa_scan_stream<MODE, true, false>;
       if (units) kern = &k_tdfa_scan_stream<MODE == 2 ? 2 : 0, true, false, true>;
       if (lds > 48 * 1024)
         CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -2173,6 +2219,18 @@ int cs_regex_destroy(cs_regex* re) {
   });
 }
 int cs_regex_inst_count(const cs_regex* re) { return re ? (int)re->prog.insts.size() : 0; }
+int cs_regex_engine(const cs_regex* re) {
+  if (!re) return 0;
+  int e = 0;
+  if (!re->tdfa.empty()) {
+    e |= 1;                               // the tagged DFA (regex_tdfa.h) runs the pattern
+    if (re->tdfa[31] & 1) e |= 2;         // ... and offers the unit decomposition (regex_tdfa.cpp)
+    if (!re->gtags.empty()) e |= 4;       // ... and carries the capture-group tags
+    e |= (re->tdfa[12] & 15) << 8;        // live threads the automaton keeps at most
+    e |= (re->tdfa[1] & 0xFFFF) << 16;    // states
+  }
+  return e;
+}
 int cs_regex_blob(const cs_regex* re, const int32_t** words, int* nwords) {
   return guard([&] {
     if (!re || !words || !nwords) fail(CS_ERR_INVALID_ARG, "null argument");

@@ -59,10 +59,30 @@ __device__ __forceinline__ void status_store(u64* p, u64 v) {
 // per tile (stride `stride` words between consecutive tiles), zeroed before the
 // launch.  Publishes this tile's aggregate, then its inclusive prefix; returns
 // the exclusive prefix (sum of the aggregates of all earlier tiles).
-// Spins are bounded: after ~kSpinLimit polls without progress the function gives
+// Spins are bounded: after kSpinTicks without progress the function gives
 // up and returns -1 (the caller raises an error flag; the host then recomputes
 // the column with the two-pass kernels).
-constexpr int kSpinLimit = 1 << 22;
+// The bound is TIME, not a poll count (a poll's cost varies with what shares the device: a co-tenant or a CU mask made a
+// count of polls anything from a blink to minutes): kSpinTicks of the constant-rate 100 MHz counter (wall_clock64), looked
+// at every 64 polls.
+constexpr unsigned long long kSpinTicks = 200ull * 1000 * 1000;  // two seconds: far beyond any honest wait
+struct SpinClock {
+  unsigned long long t0 = 0;
+  int polls = 0;
+  __device__ __forceinline__ bool expired() {
+    if ((++polls & 63) != 0) return false;
+    const unsigned long long now = wall_clock64();
+    if (t0 == 0) {
+      t0 = now;
+      return false;
+    }
+    return now - t0 > kSpinTicks;
+  }
+  __device__ __forceinline__ void reset() {
+    t0 = 0;
+    polls = 0;
+  }
+};
 __device__ __forceinline__ long long lookback(u64* status, long long stride, long long tile, long long aggregate) {
   const int lane = threadIdx.x & 63;
   u64* mine = status + tile * stride;
@@ -73,7 +93,7 @@ __device__ __forceinline__ long long lookback(u64* status, long long stride, lon
   if (lane == 0) status_store(mine, kFlagAgg | ((u64)aggregate & kValMask));
   long long excl = 0;
   long long t = tile - 1;
-  int spins = 0;
+  SpinClock clock;
   for (;;) {
     long long idx = t - lane;
     u64 v = idx >= 0 ? status_load(status + idx * stride) : kFlagInc;
@@ -83,7 +103,7 @@ __device__ __forceinline__ long long lookback(u64* status, long long stride, lon
     int first_inc = inc ? __builtin_ctzll(inc) : 64;
     u64 needed = first_inc < 63 ? ((2ull << first_inc) - 1) : ~0ull;
     if (not_ready & needed) {
-      if (++spins > kSpinLimit) return -1;
+      if (clock.expired()) return -1;
       __builtin_amdgcn_s_sleep(1);
       continue;
     }
@@ -319,6 +339,7 @@ __device__ __forceinline__ long long lookback_end(u64* status, long long tile, l
   long long excl = 0;
   long long t = tile - 1;
   int spins = 0;
+  SpinClock clock;
   unsigned part = 0;
   u64 v = first;
 #if defined(CS_PHASE_PROF)
@@ -331,7 +352,8 @@ __device__ __forceinline__ long long lookback_end(u64* status, long long tile, l
     const int first_inc = inc ? __builtin_ctzll(inc) : 64;
     const u64 needed = first_inc < 63 ? ((2ull << first_inc) - 1) : ~0ull;
     if (not_ready & needed) {
-      if (++spins > kSpinLimit) return -1;
+      ++spins;
+      if (clock.expired()) return -1;
       __builtin_amdgcn_s_sleep(2);
       const long long idx = t - lane;
       v = idx >= 0 ? status_load(status + idx) : kFlagInc;
@@ -385,7 +407,7 @@ __device__ __forceinline__ bool prefix_scanner(const u64* status, u64* excl, lon
   gptr<u64> ex = as_global(excl);
   long long base = 0;
   long long w = 0;  // next window
-  int idle = 0;
+  SpinClock clock;
   while (w * 64 < ntiles) {
     // one round trip fetches the next kScanBatch windows; the leading ones that are complete are consumed, the
     // rest is fetched again together with what follows (at the frontier of the publishing waves this keeps
@@ -417,10 +439,10 @@ __device__ __forceinline__ bool prefix_scanner(const u64* status, u64* excl, lon
     }
     w += done;
     if (done == 0) {  // (an incomplete first window may still have made progress: the limit is far beyond any honest wait)
-      if (++idle > kSpinLimit) return false;
+      if (clock.expired()) return false;
       __builtin_amdgcn_s_sleep(1);
     } else {
-      idle = 0;
+      clock.reset();
     }
   }
   return true;
@@ -429,9 +451,10 @@ __device__ __forceinline__ bool prefix_scanner(const u64* status, u64* excl, lon
 __device__ __forceinline__ long long prefix_wait(const u64* excl, long long tile, u64 first, const unsigned* error, int lane) {
   u64 v = first;
   int spins = 0;
+  SpinClock clock;
   while ((v >> 62) == 0) {
     ++spins;
-    if (spins > kSpinLimit) return -1;
+    if (clock.expired()) return -1;
     if ((spins & 255) == 0 && __hip_atomic_load(error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return -1;
     __builtin_amdgcn_s_sleep(2);
     v = status_load(excl + tile);

@@ -127,6 +127,16 @@ class GpuOps:
             self._lib.check(self._lib.lib.cs_category_get_values(cat.m_cptr, out.data_ptr(), 1, None))
         return out
 
+    def merge_gathered(self, cat, key_cols, rank):
+        """cs_category_merge_gathered: the ranks' key sets (columns, in rank order) merged, the local codes remapped"""
+        L = self._lib
+        arr = (C.c_void_p * len(key_cols))(*[k.m_cptr for k in key_cols])
+        out = C.c_void_p()
+        n = cat.size()
+        values = torch.empty(n, dtype=torch.int32, device="cuda")
+        L.check(L.lib.cs_category_merge_gathered(cat.m_cptr, arr, len(key_cols), rank, None, C.byref(out), values.data_ptr()))
+        return self._nvs.nvstrings(out.value), values
+
     def remap(self, cat, table):
         """values of `cat` mapped through `table` (i32 device tensor) -> i32 device tensor"""
         n = cat.size()
@@ -193,6 +203,8 @@ def global_category(local_col, ops=None, group=None):
         warnings.warn("global_category: %d distinct keys in %d local rows -- the key-set all-gather (%d bytes per rank) is as "
                       "large as the data; a hash-partitioned exchange of the rows would move less (SURVEY.md section 8e)"
                       % (cat.keys_size(), local_rows, gathered))
+    if hasattr(ops, "merge_gathered"):  # the C ABI's merge step (cs_category_merge_gathered): what a C++ host would call
+        return ops.merge_gathered(cat, key_cols, rank)
     merged_keys, codes = ops.concat_category(key_cols)
     start = sum(k.size() for k in key_cols[:rank])
     table = codes[start : start + key_cols[rank].size()].contiguous()

@@ -247,6 +247,10 @@ void cs_free(void* p);
 int cs_regex_compile(const char* pattern, cs_regex** out);
 int cs_regex_destroy(cs_regex* re);
 int cs_regex_inst_count(const cs_regex* re);
+/* Which executor runs the pattern (no reference counterpart: the reference has one executor, regexec.inl:204-442).
+ * Bit 0: the tagged DFA (otherwise the ordered-list simulator); bit 1: the unit decomposition is offered; bit 2: capture
+ * groups are tracked on the DFA; bits 8..11: live threads the automaton keeps at most; bits 16..31: DFA states. */
+int cs_regex_engine(const cs_regex* re);
 /* Flat int32 program image (layout: custrings_amd/csrc/regex_program.h). */
 int cs_regex_blob(const cs_regex* re, const int32_t** words, int* nwords);
 /* NVStrings::contains_re / match / count_re (NVStrings.h:963,975,988;
@@ -335,6 +339,13 @@ int cs_category_build(const cs_column* col, cs_stream stream, cs_category** out)
  * merged sorted-unique key set, concatenated remapped codes. */
 int cs_category_merge(const cs_category* const* cats, int ncats, cs_stream stream,
                       cs_category** out);
+/* The merge step of a distributed category build (one process per GPU): after the ranks all-gathered their key sets --
+ * the transport is the caller's: RCCL, MPI, torch.distributed -- every rank merges them and maps its local codes into the
+ * merged key set.  keysets[r] = rank r's key set (this rank's own at index `rank`); *merged_keys is the same column on every
+ * rank; values = device memory for cs_category_size(local) int32 codes.  Composes NVCategory::create_from_categories
+ * (NVCategory.cu:430-514); the reference itself is single-GPU. */
+int cs_category_merge_gathered(const cs_category* local, const cs_column* const* keysets, int nranks, int rank, cs_stream stream,
+                               cs_column** merged_keys, int32_t* values);
 int cs_category_destroy(cs_category* cat);
 /* NVCategory::create_ipc_transfer / create_from_ipc (NVCategory.h:128,176; ipc_transfer.h:109-200): the key column
  * as above plus the handle of the int32 values. */

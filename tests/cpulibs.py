@@ -13,6 +13,9 @@ import subprocess
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# CS_SANITIZE=1 (tests/test_sanitizers.py, in a child interpreter with libasan preloaded): the ASan + UBSan builds
+SANITIZE = bool(os.environ.get("CS_SANITIZE"))
+_SUFFIX = "_asan.so" if SANITIZE else ".so"
 
 
 def _build(target_dir):
@@ -24,7 +27,7 @@ def _build(target_dir):
 
     with open(os.path.join(target_dir, ".build.lock"), "w") as lock:
         fcntl.flock(lock, fcntl.LOCK_EX)
-        subprocess.run(["make", "-s", "-C", target_dir], check=True)
+        subprocess.run(["make", "-s", "-C", target_dir] + (["asan"] if SANITIZE else []), check=True)
 
 
 class Col:
@@ -195,7 +198,7 @@ class CpuLib:
 class Oracle(CpuLib):
     def __init__(self):
         _build(os.path.join(ROOT, "oracle"))
-        super().__init__(os.path.join(ROOT, "oracle", "liboracle.so"), "orc_")
+        super().__init__(os.path.join(ROOT, "oracle", "liboracle" + _SUFFIX), "orc_")
         vp = C.c_void_p
         self._f("contains_re", C.c_int64, [vp, vp, C.c_int, vp])
         self._f("count_re", C.c_int64, [vp, vp, vp])
@@ -416,7 +419,7 @@ class RowEmu(CpuLib):
     def __init__(self):
         _build(os.path.join(ROOT, "oracle"))  # generated unicode tables
         _build(os.path.join(ROOT, "tests", "rowemu"))
-        super().__init__(os.path.join(ROOT, "tests", "rowemu", "librowemu.so"), "emu_")
+        super().__init__(os.path.join(ROOT, "tests", "rowemu", "librowemu" + _SUFFIX), "emu_")
         vp = C.c_void_p
         self._f("regex_compile", vp, [C.c_char_p])
         self._f("regex_free", None, [vp])

@@ -442,6 +442,30 @@ def test_gpu_global_category_single_rank(orc):
     assert np.array_equal(np.concatenate([va.cpu().numpy(), vb.cpu().numpy()]), ov)
 
 
+def test_gpu_category_merge_gathered_c_abi(orc):
+    """cs_category_merge_gathered (the merge step of the distributed build behind the C ABI): three shards of one column,
+    each "rank" merges the gathered key sets and remaps its own codes -- merged keys and the concatenated codes equal the
+    category of the whole column (oracle), for every rank; a shard that is all null and an empty shard take part."""
+    from custrings_amd import dist as csd
+
+    ops = csd.GpuOps()
+    rows = 60_000
+    ok, ov = orc.category(orc.synth(4, 0, rows, param=700))
+    cuts = [0, 25_000, 25_000, 60_000]  # (the middle shard is empty)
+    shards = [gpuutil.synth(4, cuts[i], cuts[i + 1] - cuts[i], 700) for i in range(3)]
+    cats, keysets = [], []
+    for sh in shards:
+        cat, (ch, of, nn) = ops.category(sh)
+        cats.append(cat)
+        keysets.append(ops.column(ch, of, nn))
+    got = []
+    for rank in range(3):
+        mk, vals = ops.merge_gathered(cats[rank], keysets, rank)
+        gpuutil.assert_same(mk, ok, "merged keys on rank %d" % rank)
+        got.append(vals.cpu().numpy())
+    assert np.array_equal(np.concatenate(got), ov)
+
+
 # ---- code paths of the persistent tile kernels (stream replace_re, emit2) -------------------
 def _log_like(rnd, lo, hi, nonascii_every=0, idx=0):
     words = []
