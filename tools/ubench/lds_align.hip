@@ -110,7 +110,6 @@ int main() {
     run<11>(pm, 2, names[11]);
     run<12>(pm, 2, names[12]);
   }
-  return 0;
   for (int bpc : {1, 2}) {
     for (int pm = 0; pm <= 4; ++pm) {
       run<0>(pm, bpc, names[0]);
