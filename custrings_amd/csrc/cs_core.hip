@@ -31,11 +31,21 @@ static int g_device = -1;
 static uint8_t* g_d_flags = nullptr;
 static uint16_t* g_d_cases = nullptr;
 static int64_t g_in_use = 0;
-static std::multimap<size_t, std::pair<void*, hipStream_t>> g_cache;  // capacity -> block
+// A cached block remembers the stream it was last used on and, once a second stream has been seen, an EVENT recorded on
+// that stream when the block was released: a different stream that takes the block waits for the event on the device
+// (hipStreamWaitEvent) -- the host does not wait, where a device-wide synchronisation per released block used to turn
+// every op of a multi-stream caller into dozens of full stalls.
+struct CachedBlock {
+  void* first;
+  hipStream_t second;
+  std::vector<hipEvent_t> released;  // one per stream known at the release (a column made on one stream may have been read on another)
+};
+static std::multimap<size_t, CachedBlock> g_cache;  // capacity -> block
+static std::vector<hipEvent_t> g_event_pool;
 // Streams that have asked for buffers.  While there is one (the usual case) stream order alone
 // makes the reuse of a released block safe.  With more, a block may still be read by a kernel on
 // a stream other than the one it was allocated on when its last handle goes away, so a release
-// then waits for the device before the block returns to the cache.
+// then records an event on every known stream, and whoever takes the block next waits for them on the device.
 static std::set<hipStream_t> g_streams;
 static std::atomic<bool> g_multi_stream{false};
 static std::atomic<long long> g_fallbacks{0};
@@ -62,7 +72,10 @@ const uint16_t* h_charcases() { return cs_charcases; }
 int64_t dev_bytes_in_use() { return g_in_use; }
 
 static void release_cache_locked() {
-  for (auto& kv : g_cache) (void)hipFree(kv.second.first);
+  for (auto& kv : g_cache) {
+    (void)hipFree(kv.second.first);
+    for (hipEvent_t e : kv.second.released) g_event_pool.push_back(e);
+  }
   g_cache.clear();
 }
 
@@ -72,10 +85,41 @@ DevBuf::~DevBuf() {
     return;
   }
   if (!capacity || !p) return;
-  if (g_multi_stream.load(std::memory_order_relaxed)) (void)hipDeviceSynchronize();  // (see g_streams)
+  std::vector<hipEvent_t> evs;
+  if (g_multi_stream.load(std::memory_order_relaxed)) {
+    std::vector<hipStream_t> streams;
+    {
+      std::lock_guard<std::mutex> lk(g_mu);
+      streams.assign(g_streams.begin(), g_streams.end());
+      while (evs.size() < streams.size() && !g_event_pool.empty()) {
+        evs.push_back(g_event_pool.back());
+        g_event_pool.pop_back();
+      }
+    }
+    bool ok = true;
+    while (ok && evs.size() < streams.size()) {
+      hipEvent_t e = nullptr;
+      ok = hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+      if (ok) evs.push_back(e);
+    }
+    std::vector<hipStream_t> dead;
+    for (size_t i = 0; ok && i < streams.size(); ++i)
+      if (hipEventRecord(evs[i], streams[i]) != hipSuccess) {  // (a stream its owner destroyed: forget it)
+        (void)hipGetLastError();
+        dead.push_back(streams[i]);
+        ok = false;
+      }
+    if (!ok) {
+      (void)hipDeviceSynchronize();  // (no complete set of events to wait for: the block is idle before anyone else may take it)
+      std::lock_guard<std::mutex> lk(g_mu);
+      for (hipEvent_t e : evs) g_event_pool.push_back(e);
+      for (hipStream_t d : dead) g_streams.erase(d);
+      evs.clear();
+    }
+  }
   std::lock_guard<std::mutex> lk(g_mu);
   g_in_use -= (int64_t)capacity;
-  g_cache.emplace(capacity, std::make_pair(p, stream));
+  g_cache.emplace(capacity, CachedBlock{p, stream, std::move(evs)});
 }
 
 Buf dev_alloc(size_t bytes, hipStream_t stream) {
@@ -86,6 +130,7 @@ Buf dev_alloc(size_t bytes, hipStream_t stream) {
   b->stream = stream;
   bool reused = false;
   hipStream_t prev = nullptr;
+  std::vector<hipEvent_t> released;
   {
     std::lock_guard<std::mutex> lk(g_mu);
     if (g_streams.insert(stream).second && g_streams.size() > 1) g_multi_stream.store(true);
@@ -94,14 +139,22 @@ Buf dev_alloc(size_t bytes, hipStream_t stream) {
       b->p = it->second.first;
       b->capacity = it->first;
       prev = it->second.second;
+      released = std::move(it->second.released);
       g_cache.erase(it);
       g_in_use += (int64_t)b->capacity;
       reused = true;
     }
   }
   if (reused) {
-    // a block last used on another stream may still be in flight there (waited for outside the lock)
-    if (prev != stream) CS_HIP(hipStreamSynchronize(prev));
+    // a block last used on another stream may still be in flight there: this stream waits for the release event on the
+    // device (blocks released before a second stream existed carry none: the host waits for their stream once)
+    if (!released.empty()) {
+      for (hipEvent_t e : released) CS_HIP(hipStreamWaitEvent(stream, e, 0));
+      std::lock_guard<std::mutex> lk(g_mu);
+      for (hipEvent_t e : released) g_event_pool.push_back(e);
+    } else if (prev != stream) {
+      CS_HIP(hipStreamSynchronize(prev));
+    }
     return b;
   }
   void* p = nullptr;

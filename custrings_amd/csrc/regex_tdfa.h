@@ -588,6 +588,9 @@ struct Tdfa {
   template <class Hist>
   CS_HD int group_find_back(int from, const int32_t* G, int first, int count, int* gb, int* ge, int& mend, Hist hist, int max_steps = kBackSteps) {
     if (D.nstates > 256) return -1;
+    // the packed tag table holds a BATCH of four groups per word at batch-relative bit positions: only whole batches
+    // (groups 1-4, 5-8, ...) can be resolved this way -- anything else goes to the forward run
+    if ((first - 1) % kGroupBatch != 0 || count > kGroupBatch || count < 0) return -1;
     const long long tstride = (long long)G[3];
     const uint32_t* tags0 = (const uint32_t*)(G + 36) + (long long)(first - 1) * tstride;
     const uint32_t* packed = (const uint32_t*)(G + 36) + ((long long)G[0] + (first - 1) / kGroupBatch) * tstride;

@@ -144,11 +144,36 @@ struct Array {
     } else if (PyLong_Check(o)) {
       data = reinterpret_cast<T*>(PyLong_AsVoidPtr(o));
       on_device = true;
-    } else if (PyObject_CheckBuffer(o) && PyObject_GetBuffer(o, &view, PyBUF_SIMPLE) == 0) {
+    } else if (PyObject_CheckBuffer(o) && PyObject_GetBuffer(o, &view, PyBUF_FORMAT | PyBUF_ND | PyBUF_C_CONTIGUOUS) == 0) {
+      // A typed buffer (numpy array, array.array, memoryview): its ITEM size decides how it is read -- numpy's default
+      // int64 index arrays handed to a 4-byte parameter used to be reinterpreted as pairs of int32 (twice the count, wrong
+      // rows).  Same width: taken in place; another integer width or a bool array: converted element by element (a bool
+      // array also sets all_bool, which routes gather / remove_strings to the mask overloads).
       has_view = true;
-      data = static_cast<T*>(view.buf);
-      count = (size_t)view.len / sizeof(T);
-      all_bool = view.itemsize == 1 && sizeof(T) != 1 ? false : false;
+      const size_t isz = (size_t)view.itemsize, n = isz ? (size_t)view.len / isz : 0;
+      const char f = view.format ? view.format[view.format[0] == '<' || view.format[0] == '=' || view.format[0] == '@' ? 1 : 0] : 'B';
+      const bool is_bool = f == '?', is_signed = f == 'b' || f == 'h' || f == 'i' || f == 'l' || f == 'q' || f == 'n';
+      const bool is_int = is_bool || is_signed || f == 'B' || f == 'H' || f == 'I' || f == 'L' || f == 'Q' || f == 'N';
+      if (!is_int || !(isz == 1 || isz == 2 || isz == 4 || isz == 8)) {
+        bad = true;
+      } else if (isz == sizeof(T) && !is_bool) {
+        data = static_cast<T*>(view.buf);
+        count = n;
+      } else {
+        count = n;
+        own.resize(n ? n : 1);
+        const unsigned char* p = static_cast<const unsigned char*>(view.buf);
+        for (size_t i = 0; i < n; ++i) {
+          long long v = 0;
+          if (isz == 1) v = is_signed ? (long long)*reinterpret_cast<const signed char*>(p + i) : (long long)p[i];
+          else if (isz == 2) v = is_signed ? (long long)*reinterpret_cast<const short*>(p + 2 * i) : (long long)*reinterpret_cast<const unsigned short*>(p + 2 * i);
+          else if (isz == 4) v = is_signed ? (long long)*reinterpret_cast<const int*>(p + 4 * i) : (long long)*reinterpret_cast<const unsigned int*>(p + 4 * i);
+          else v = *reinterpret_cast<const long long*>(p + 8 * i);
+          own[i] = is_bool ? T(v != 0) : T(v);
+        }
+        data = own.data();
+        all_bool = is_bool && n > 0;
+      }
     } else {
       PyErr_Clear();
       bad = true;

@@ -315,6 +315,15 @@ static PyObject* n_gather(PyObject*, PyObject* args) {  // (self, indexes: list 
     PyErr_SetString(PyExc_ValueError, "nvstrings.gather: unknown type of indexes");
     return nullptr;
   }
+  if (a.all_bool && !a.on_device) {  // (a numpy bool array: the mask form, as a list of bool)
+    if (a.count != s->size()) {
+      PyErr_SetString(PyExc_ValueError, "nvstrings.gather: the mask must have one entry per string");
+      return nullptr;
+    }
+    std::vector<unsigned char> m(a.count);
+    for (size_t i = 0; i < a.count; ++i) m[i] = a.data[i] != 0;
+    return make_instance([&] { return s->gather(reinterpret_cast<const bool*>(m.data()), false); });
+  }
   const unsigned int count = a.on_device ? (unsigned int)int_arg(args, 2, 0) : (unsigned int)a.count;
   return make_instance([&] { return s->gather(a.data, count, a.on_device); });
 }

@@ -1061,3 +1061,50 @@ def test_gpu_record_forms_vs_oracle(gpu_engine, oracle_engine, pat):
         assert loff.tolist() == list(range(0, len(s) * len(want) + 1, len(want)))
     else:
         assert col.extract_record(pat) == []
+
+
+def test_gpu_two_streams_share_the_buffer_cache(orc):
+    """Ops issued on two HIP streams in turn: blocks released on one stream are taken by the other (the cache then makes
+    the taker wait for the release EVENT on the device, cs_core.hip: CachedBlock).  Results equal the oracle's, and the
+    interleaving does not stall the host per released block (a loose bound on the wall time against one stream)."""
+    import ctypes as C
+    import time
+
+    import torch
+
+    from custrings_amd import _lib, nvstrings
+
+    L = _lib.lib
+    rows = 200_000
+    g, o = gpuutil.synth(3, 0, rows), orc.synth(3, 0, rows)
+    re = nvstrings._compile(r"\d+\.\d+\.\d+\.\d+")
+    blob = np.ascontiguousarray(engines.reference_blob(r"\d+\.\d+\.\d+\.\d+") if engines.reference_blob(r"\d+\.\d+\.\d+\.\d+") is not None
+                                else engines.product_blob(r"\d+\.\d+\.\d+\.\d+"), dtype=np.int32)
+    want_low, want_rep = orc.lower(o), orc.replace_re(o, blob, "<IP>")
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+
+    def round_on(stream):
+        h = C.c_void_p(stream.cuda_stream)
+        a, b = C.c_void_p(), C.c_void_p()
+        _lib.check(L.cs_lower(g.m_cptr, h, C.byref(a)))
+        _lib.check(L.cs_replace_re(g.m_cptr, re, b"<IP>", -1, h, C.byref(b)))
+        return nvstrings.nvstrings(a.value), nvstrings.nvstrings(b.value)
+
+    def timed(seq, n):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(n):
+            x, y = round_on(seq[i % len(seq)])
+            del x, y
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+
+    one = timed(streams[:1], 40)
+    for i in range(6):
+        low, rep = round_on(streams[i % 2])
+        gpuutil.assert_same(low, want_low, "lower on stream %d" % (i % 2))
+        gpuutil.assert_same(rep, want_rep, "replace_re on stream %d" % (i % 2))
+        del low, rep
+    two = timed(streams, 40)
+    assert two < 5 * one + 0.05, (one, two)
+    L.cs_regex_destroy(re)

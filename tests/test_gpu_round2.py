@@ -452,3 +452,4 @@ def test_gpu_extract_groups_resolved_backwards_edges(gpu_engine, oracle_engine):
     rows = fuzzdata.group_edge_rows()
     for pat in fuzzdata.GROUP_EDGE_PATTERNS:
         assert gpu_engine.extract(rows, pat) == oracle_engine.extract(rows, pat), pat
+

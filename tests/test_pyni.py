@@ -95,6 +95,14 @@ def test_gpu_pyni_strings_path():
     assert s.n_createHostStrings(s.n_strip(s.n_createFromHostStrings(["  a  ", None]), None)) == ["a", None]
     assert s.n_createHostStrings(s.n_gather(h, [3, 0], 0)) == ["tést String", "Héllo thesé"]
     assert s.n_createHostStrings(s.n_gather(h, [True, False, False, False, True], 0)) == ["Héllo thesé", ""]
+    # typed buffers are read by their item size: numpy's default int64 indexes, int16, and a bool array as a mask
+    import numpy as np
+    assert s.n_createHostStrings(s.n_gather(h, np.array([3, 0]), 0)) == ["tést String", "Héllo thesé"]
+    assert s.n_createHostStrings(s.n_gather(h, np.array([3, 0], dtype=np.int16), 0)) == ["tést String", "Héllo thesé"]
+    assert s.n_createHostStrings(s.n_gather(h, np.array([3, 0], dtype=np.int32), 0)) == ["tést String", "Héllo thesé"]
+    assert s.n_createHostStrings(s.n_gather(h, np.array([True, False, False, False, True]), 0)) == ["Héllo thesé", ""]
+    with pytest.raises(ValueError):
+        s.n_gather(h, np.array([1.5, 2.0]), 0)
     with pytest.raises(ValueError):
         s.n_gather(h, [9], 0)  # std::out_of_range
     assert s.n_order(h, 2, True, True, 0) == [1, 4, 0, 2, 3]
