@@ -545,7 +545,7 @@ int cs_replace(const cs_column* col, const char* str, const char* repl, int maxr
       }
       plain = plain && pattern.size() <= 128;
       const size_t rb = strlen(repl);
-      if (plain && rb <= 16 && col->rows > 0 && !getenv("CS_REPLACE_ROWWISE") && bytes_plain(col, S(stream))) {
+      if (plain && rb <= 64 && col->rows > 0 && !getenv("CS_REPLACE_ROWWISE") && bytes_plain(col, S(stream))) {
         cs_regex* re = nullptr;
         if (cs_regex_compile(pattern.c_str(), &re) == CS_OK) {
           cs::g_replace_plain_only = 1;  // the single-pass kernel or nothing: this function's own kernels are the fallback

@@ -858,7 +858,10 @@ struct StreamArgs {
 #ifndef CS_STREAM_WAVES
 #define CS_STREAM_WAVES 3
 #endif
-// REP16: replacement of 9..16 bytes (four registers); the common short replacement keeps two.
+// REP16: replacement of 9..16 bytes (four registers) -- and, since round 3, of up to kMaxStreamRepl bytes, whose text the
+// assembly reads from memory (a 21-byte replacement used to fall to the two-pass row kernels: 48.8 ms on the 100M-row column);
+// the common short replacement keeps two registers.
+constexpr int kMaxStreamRepl = 64;
 // INPLACE (the output cannot outgrow the input): every row is compacted inside its own extent of
 // the input tile while it is scanned -- the bytes before a match move down to the write cursor,
 // the replacement follows -- so any number of matches per row costs no registers and the
@@ -1172,9 +1175,13 @@ __global__ void __launch_bounds__(256, BREFS ? 2 : CS_STREAM_WAVES) k_tdfa_repla
       int wr = 0, copied = 0, pend = -1;   // INPLACE: write cursor, input consumed, replacement not yet written
       auto put_repl_at = [&](int at) {
         if (REP16) {
+          if (rb > 16) {  // (a long replacement: its bytes from memory, the same for every lane)
+            for (int i = 0; i < rb; ++i) lds_in[pi + at + i] = a.repl[i];
+          } else {
 #pragma unroll
-          for (int i = 0; i < 16; ++i)
-            if (i < rb) lds_in[pi + at + i] = (uint8_t)(rep[i >> 2] >> (8 * (i & 3)));
+            for (int i = 0; i < 16; ++i)
+              if (i < rb) lds_in[pi + at + i] = (uint8_t)(rep[i >> 2] >> (8 * (i & 3)));
+          }
         } else {
           lds_put_short(lds_in + pi + at, rep[0], rep[1], rb);
         }
@@ -1564,9 +1571,13 @@ __global__ void __launch_bounds__(256, BREFS ? 2 : CS_STREAM_WAVES) k_tdfa_repla
             cstile::lds_copy(lds_out, oi, lds_in, pi + copied, mb - copied);
             oi += mb - copied;
             if (REP16) {
+              if (rb > 16) {
+                for (int i = 0; i < rb; ++i) lds_out[oi + i] = a.repl[i];
+              } else {
 #pragma unroll
-              for (int i = 0; i < 16; ++i)
-                if (i < rb) lds_out[oi + i] = (uint8_t)(rep[i >> 2] >> (8 * (i & 3)));
+                for (int i = 0; i < 16; ++i)
+                  if (i < rb) lds_out[oi + i] = (uint8_t)(rep[i >> 2] >> (8 * (i & 3)));
+              }
               oi += rb;
             } else {
               for (int i = 0; i < rb; ++i) lds_out[oi++] = (uint8_t)((i < 4 ? rep[0] >> (8 * i) : rep[1] >> (8 * (i - 4))));
@@ -1581,9 +1592,13 @@ __global__ void __launch_bounds__(256, BREFS ? 2 : CS_STREAM_WAVES) k_tdfa_repla
               oi += rec_mb[j] - copied;
               for (int k = 0; k < rec_reps[j]; ++k) {
                 if (REP16) {
+                  if (rb > 16) {
+                    for (int i = 0; i < rb; ++i) lds_out[oi + i] = a.repl[i];
+                  } else {
 #pragma unroll
-                  for (int i = 0; i < 16; ++i)
-                    if (i < rb) lds_out[oi + i] = (uint8_t)(rep[i >> 2] >> (8 * (i & 3)));
+                    for (int i = 0; i < 16; ++i)
+                      if (i < rb) lds_out[oi + i] = (uint8_t)(rep[i >> 2] >> (8 * (i & 3)));
+                  }
                   oi += rb;
                 } else {
                   for (int i = 0; i < rb; ++i) lds_out[oi++] = (uint8_t)((i < 4 ? rep[0] >> (8 * i) : rep[1] >> (8 * (i - 4))));
@@ -2451,7 +2466,8 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
         }
         return err;
       };
-      if (lds <= 150 * 1024 && rb <= 16 && tc.R && !getenv("CS_TILE_OLD")) {
+      // (replacements of 17 .. kMaxStreamRepl bytes ride the four-register variants, their text read from memory at assembly)
+      if (lds <= 150 * 1024 && rb <= kMaxStreamRepl && tc.R && !getenv("CS_TILE_OLD")) {
         const bool roomy_first = growth > 0 && (minlen <= 2 || getenv("CS_REPLACE_ROOMY"));
         int err = stream_attempt(roomy_first);
         if (err == 2 && !roomy_first) err = stream_attempt(true);  // only ran out of room: once more, roomier

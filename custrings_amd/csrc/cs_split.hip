@@ -97,6 +97,27 @@ __device__ __forceinline__ uint32_t lowest96(uint32_t m0, uint32_t m1, uint32_t 
   return q;
 }
 
+// The same scan as six fused v_add_u32_dpp (the compiler splits the generic form above into v_mov_b32_dpp + v_add_u32 when
+// the partial sums have other uses: twelve vector instructions).  The s_nop cover the two wait states a DPP read of a
+// freshly written VGPR needs; they cost the wave issue slots, not the SIMD.
+__device__ __forceinline__ int wave_inclusive_scan_fused(int v) {
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_add_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "s_nop 1\n\t"
+      "v_add_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "s_nop 1\n\t"
+      "v_add_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "s_nop 1\n\t"
+      "v_add_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "s_nop 1\n\t"
+      "v_add_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_add_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+      "s_nop 1"
+      : "+v"(v));
+  return v;
+}
 struct SubTile {
   long long r0, g0;
   int nrows, rbeg, n, lead;
@@ -957,7 +978,7 @@ __global__ void __launch_bounds__(kEmit3Threads, CS_EMIT3_WAVES) k_split_emit3(E
       any_more = __any(has);
       if (any_more) {
         const int len = has ? hi - lo : 0;
-        const int incl = wave_inclusive_scan(len);
+        const int incl = wave_inclusive_scan_fused(len);
         const int pre = incl - len;
         const int csum = rl(incl, 63);  // bytes this sub-tile adds to column k
         if (lane < nrows) coff[lane] = (off_t)(cbase + pre);

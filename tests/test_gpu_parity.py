@@ -572,6 +572,37 @@ def test_gpu_ngrams_tile_kernel(gpu_engine, oracle_engine, count):
     assert g.ngrams(holes, 2, "_") == o.ngrams(holes, 2, "_")
 
 
+@pytest.mark.parametrize("rlen", [17, 21, 33, 64, 65, 200])
+def test_gpu_long_replacements_on_the_stream_kernel(gpu_engine, oracle_engine, orc, rlen):
+    """replace_re / replace with a replacement beyond the sixteen bytes the stream kernel keeps in registers: up to 64
+    bytes it still takes the single-pass kernel (the text is read from memory at assembly), beyond that the two-pass
+    kernels; either way the result is the oracle's -- rows with several matches, shrinking and growing patterns, a limit."""
+    import random
+
+    L = gpuutil.lib().lib
+    rnd = random.Random(rlen)
+    s = [_log_like(rnd, 20, 90) for _ in range(4000)]
+    for i in range(0, len(s), 101):
+        s[i] = None if i % 2 else ""
+    repl = ("[REDACTED-IP-ADDRESS]" * 12)[:rlen]
+    o, g = oracle_engine, gpu_engine
+    before = int(L.cs_fallback_count())
+    assert g.replace_re(s, IPV4, repl, -1) == o.replace_re(s, IPV4, repl, -1), rlen
+    assert int(L.cs_fallback_count()) == before  # (single pass, whatever the replacement's length)
+    # (one-byte matches with a replacement this long may outgrow what the single pass provisions: the host then repeats
+    # with the two-pass kernels, counted -- the result is what matters here)
+    for pat, n in ((r"\d+", -1), (r"[a-c]+", 2), (r"x{17,}", -1)):
+        assert g.replace_re(s, pat, repl, n) == o.replace_re(s, pat, repl, n), (pat, n, rlen)
+    assert g.replace(s, "cab", repl, -1) == o.replace(s, "cab", repl, -1)
+    assert g.replace(s, ".", repl, 1) == o.replace(s, ".", repl, 1)
+    before = int(L.cs_fallback_count())
+    # the 100k-row C3 column (many sub-tiles, the persistent grid, the scanner wave)
+    gc, oc = gpuutil.synth(3, 0, 100_000), orc.synth(3, 0, 100_000)
+    blob = np.ascontiguousarray(engines.reference_blob(IPV4) if engines.reference_blob(IPV4) is not None else engines.product_blob(IPV4), dtype=np.int32)
+    gpuutil.assert_same(gc.replace(IPV4, repl), orc.replace_re(oc, blob, repl), "C3 replace_re, %d-byte replacement" % rlen)
+    assert int(L.cs_fallback_count()) == before
+
+
 def test_gpu_literal_replace_on_stream_kernel(gpu_engine, oracle_engine, orc):
     """Literal needles without metacharacters and a replacement no longer than the needle take
     the single-pass replace_re kernel; results must equal the literal replace of the oracle."""
