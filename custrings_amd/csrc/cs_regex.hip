@@ -308,7 +308,7 @@ __device__ __forceinline__ TCtx tsetup(const TLaunch& L, const uint8_t* flags, u
   c.P = csvm::make_view(L.image, flags);
   return c;
 }
-template <int MODE, bool IN_LDS>
+template <int MODE, bool IN_LDS, bool WIDE = false>
 __global__ void __launch_bounds__(256) k_tdfa_scan(RowSrc src, TLaunch L, uint8_t* __restrict__ out8,
                                                    int32_t* __restrict__ out32,
                                                    unsigned long long* __restrict__ found) {
@@ -323,7 +323,7 @@ __global__ void __launch_bounds__(256) k_tdfa_scan(RowSrc src, TLaunch L, uint8_
     int v = 0;
     if (row_is_valid(in.validity, r)) {
       int64_t b = in.offsets[r];
-      cstd::Tdfa vm(c.D, c.P, in.chars + b, (int)(in.offsets[r + 1] - b));
+      typename std::conditional<WIDE, cstd::TdfaWide, cstd::Tdfa>::type vm(c.D, c.P, in.chars + b, (int)(in.offsets[r + 1] - b));
       vm.wide_ok = (b & ~(int64_t)3) + cstd::Tdfa::kMaskBytes <= src.safe_end;
       if (MODE == 2) v = csvm::row_count_re(vm);
       else v = csvm::row_contains_re(vm, MODE == 1);
@@ -335,7 +335,7 @@ __global__ void __launch_bounds__(256) k_tdfa_scan(RowSrc src, TLaunch L, uint8_
   long long t = block_reduce_sum(hits);
   if (threadIdx.x == 0 && t) atomicAdd(found, (unsigned long long)t);
 }
-template <bool IN_LDS>
+template <bool IN_LDS, bool WIDE = false>
 __global__ void __launch_bounds__(256) k_tdfa_replace_size(RowSrc src, TLaunch L, int rb, int maxrepl,
                                                            int32_t* __restrict__ lens) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
@@ -349,7 +349,7 @@ __global__ void __launch_bounds__(256) k_tdfa_replace_size(RowSrc src, TLaunch L
     if (row_is_valid(in.validity, r)) {
       int64_t b = in.offsets[r];
       int n = (int)(in.offsets[r + 1] - b);
-      cstd::Tdfa vm(c.D, c.P, in.chars + b, n);
+      typename std::conditional<WIDE, cstd::TdfaWide, cstd::Tdfa>::type vm(c.D, c.P, in.chars + b, n);
       vm.wide_ok = (b & ~(int64_t)3) + cstd::Tdfa::kMaskBytes <= src.safe_end;
       len = n;
       csvm::row_replace_matches(vm, maxrepl, [&](int mb, int me, int reps) { len += reps * rb - (me - mb); });
@@ -357,7 +357,7 @@ __global__ void __launch_bounds__(256) k_tdfa_replace_size(RowSrc src, TLaunch L
     lens[r] = len;
   }
 }
-template <bool IN_LDS>
+template <bool IN_LDS, bool WIDE = false>
 __global__ void __launch_bounds__(256) k_tdfa_replace_write(RowSrc src, TLaunch L, const uint8_t* __restrict__ repl,
                                                             int rb, int maxrepl, const int64_t* __restrict__ out_off,
                                                             uint8_t* __restrict__ out_chars) {
@@ -373,7 +373,7 @@ __global__ void __launch_bounds__(256) k_tdfa_replace_write(RowSrc src, TLaunch 
     const uint8_t* p = in.chars + b;
     uint8_t* o = out_chars + out_off[r];
     int copied = 0;
-    cstd::Tdfa vm(c.D, c.P, p, n);
+    typename std::conditional<WIDE, cstd::TdfaWide, cstd::Tdfa>::type vm(c.D, c.P, p, n);
     vm.wide_ok = (b & ~(int64_t)3) + cstd::Tdfa::kMaskBytes <= src.safe_end;
     csvm::row_replace_matches(vm, maxrepl, [&](int mb, int me, int reps) {
       for (int i = copied; i < mb; ++i) *o++ = p[i];
@@ -1807,6 +1807,11 @@ __global__ void __launch_bounds__(256, ((UNITS && MODE == 3) || MODE == 4) ? 3 :
       // tiles as contains_re's instead of a thread per row reading its bytes from HBM
       cstd::Tdfa vm(D, P, lds_in + lead + rbeg, n, (lead + rbeg) & 3);
       v = live ? csvm::row_contains_re(vm, true) : 0;
+    } else if (MODE >= 7) {
+      // programs of five to eight live threads (MODE 7 contains_re, 8 match, 9 count_re): the generic executor with
+      // eight start offsets on the staged row (regex_tdfa.h: TdfaWide)
+      cstd::TdfaWide vm(D, P, lds_in + lead + rbeg, n, (lead + rbeg) & 3);
+      v = !live ? 0 : (MODE == 9 ? csvm::row_count_re(vm) : csvm::row_contains_re(vm, MODE == 8));
     } else if (MODE == 4) {
       cstd::Tdfa vm(D, P, lds_in + lead + rbeg, n, (lead + rbeg) & 3);
       int mb = 0, me = 0;
@@ -1987,8 +1992,8 @@ __global__ void __launch_bounds__(256, ((UNITS && MODE == 3) || MODE == 4) ? 3 :
       }
     }
     if (lane < nrows) {
-      if (MODE == 2) a.out32[r0 + lane] = v;
-      else if (MODE == 0 || MODE == 1) a.out8[r0 + lane] = (uint8_t)v;
+      if (MODE == 2 || MODE == 9) a.out32[r0 + lane] = v;
+      else if (MODE == 0 || MODE == 1 || MODE == 7 || MODE == 8) a.out8[r0 + lane] = (uint8_t)v;
     }
     hits += v > 0;
     cstile::wave_lds_fence();  // the next tile overwrites lds_in
@@ -2005,7 +2010,11 @@ struct TPlan {
   size_t lds_bytes;
   unsigned grid;
 };
-bool use_tdfa(const cs_regex* re) { return !re->tdfa.empty() && !getenv("CS_REGEX_NO_TDFA"); }
+// the tagged DFA with at most four live threads: every DFA kernel (lean scans, unit decomposition, capture groups)
+bool use_tdfa(const cs_regex* re) { return !re->tdfa.empty() && re->tdfa[12] <= cstd::kMaxSlots && !getenv("CS_REGEX_NO_TDFA"); }
+// ... with five to eight (counted repetitions): contains_re / match / count_re and replace_re run it on the generic executor
+// with eight start offsets (regex_tdfa.h: TdfaWide); the other ops keep the list simulator for such programs
+bool use_tdfa_wide(const cs_regex* re) { return !re->tdfa.empty() && re->tdfa[12] > cstd::kMaxSlots && !getenv("CS_REGEX_NO_TDFA"); }
 void upload(cs_regex* re, hipStream_t s) {
   // a compiled pattern may be shared between host threads (and is kept in the process-wide pattern cache): the device
   // images are made once.  All three are built into locals and committed together only after the copies completed --
@@ -2111,7 +2120,8 @@ void scan(const cs_column* col, cs_regex* re, uint8_t* out8, int32_t* out32, int
           int64_t* found, const char* name) {
   if (found) *found = 0;
   if (col->rows == 0) return;
-  const bool tdfa = use_tdfa(re);
+  const bool wide = use_tdfa_wide(re);  // (five to eight live threads: TdfaWide on the same kernels' generic row path)
+  const bool tdfa = use_tdfa(re) || wide;
   Plan pl{};
   TPlan tp{};
   if (tdfa) tp = tplan(re, col->rows, s);
@@ -2134,7 +2144,7 @@ void scan(const cs_column* col, cs_regex* re, uint8_t* out8, int32_t* out32, int
     // the unit scan (k_tdfa_scan_stream<.., UNITS>): patterns whose tagged DFA offers the decomposition, rows within the masks
     // (count_re only: contains_re stops at a row's first match, and scanning every unit of the row cost more than the
     // balance won -- 3.87 against 2.66 ms on the 100M-row C3 column)
-    const bool units = MODE == 2 && (re->tdfa[31] & 1) != 0 && !tc.lng && tc.R == 64 && !getenv("CS_NO_UNITS");
+    const bool units = !wide && MODE == 2 && (re->tdfa[31] & 1) != 0 && !tc.lng && tc.R == 64 && !getenv("CS_NO_UNITS");
     const size_t lds = tp.lds_bytes + (size_t)(cap + 32 + (cap >> 3) + 32 + (units ? (cap >> 3) + 32 + kUnitQueue * 4 + 64 * 4 + 16 : 0)) * 4;
     if (tc.R && lds <= 150 * 1024) {
       ScanStreamArgs sa{};
@@ -2150,6 +2160,7 @@ void scan(const cs_column* col, cs_regex* re, uint8_t* out8, int32_t* out32, int
       sa.tbl_bytes = (int)tp.lds_bytes;
       auto kern = tc.lng ? &k_tdfa_scan_stream<MODE, true, true> : &k_tdfa_scan_stream<MODE, true, false>;
       if (units) kern = &k_tdfa_scan_stream<MODE == 2 ? 2 : 0, true, false, true>;
+      if (wide) kern = tc.lng ? &k_tdfa_scan_stream<MODE + 7, true, true> : &k_tdfa_scan_stream<MODE + 7, true, false>;
       if (lds > 48 * 1024)
         CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       const unsigned grid = resident_grid(reinterpret_cast<const void*>(kern), lds, (sa.nsub + 3) / 4);
@@ -2160,7 +2171,14 @@ void scan(const cs_column* col, cs_regex* re, uint8_t* out8, int32_t* out32, int
   }
   if (!streamed) {
     ProfScope ps(name, s);
-    if (tdfa)
+    if (wide)
+      if (tp.d.in_lds)
+        hipLaunchKernelGGL((k_tdfa_scan<MODE, true, true>), dim3(tp.grid), dim3(256), tp.lds_bytes, s, src, tp.d, out8, out32,
+                           ptr<unsigned long long>(cnt));
+      else
+        hipLaunchKernelGGL((k_tdfa_scan<MODE, false, true>), dim3(tp.grid), dim3(256), 0, s, src, tp.d, out8, out32,
+                           ptr<unsigned long long>(cnt));
+    else if (tdfa)
       if (tp.d.in_lds)
         hipLaunchKernelGGL((k_tdfa_scan<MODE, true>), dim3(tp.grid), dim3(256), tp.lds_bytes, s, src, tp.d, out8, out32,
                            ptr<unsigned long long>(cnt));
@@ -2301,9 +2319,10 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
     Buf d_repl = dev_alloc((size_t)rb + 1, s);
     CS_HIP(hipMemcpyAsync(d_repl->p, repl, (size_t)rb + 1, hipMemcpyHostToDevice, s));
     const bool tdfa = use_tdfa(re);
+    const bool wide = use_tdfa_wide(re);  // (five to eight live threads: the two-pass kernels on TdfaWide)
     Plan pl{};
     TPlan tp{};
-    if (tdfa) tp = tplan(re, col->rows, s);
+    if (tdfa || wide) tp = tplan(re, col->rows, s);
     else pl = plan(re, col->rows, s);
     RowSrc src{view_of(col), d_unicode_flags(), col->nbytes + (col->chars && col->chars->capacity ? 64 : 0)};
     auto* o = new cs_column;
@@ -2467,7 +2486,9 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
         return err;
       };
       // (replacements of 17 .. kMaxStreamRepl bytes ride the four-register variants, their text read from memory at assembly)
-      if (lds <= 150 * 1024 && rb <= kMaxStreamRepl && tc.R && !getenv("CS_TILE_OLD")) {
+      // (... where a match is long enough for the row not to outgrow the out tile: a 19-byte replacement of one-digit matches
+      // goes to the two-pass kernels at once instead of failing the single pass twice first)
+      if (lds <= 150 * 1024 && (rb <= 16 || (rb <= kMaxStreamRepl && rb <= 4 * minlen)) && tc.R && !getenv("CS_TILE_OLD")) {
         const bool roomy_first = growth > 0 && (minlen <= 2 || getenv("CS_REPLACE_ROOMY"));
         int err = stream_attempt(roomy_first);
         if (err == 2 && !roomy_first) err = stream_attempt(true);  // only ran out of room: once more, roomier
@@ -2526,7 +2547,13 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
     Buf lens = dev_alloc(sizeof(int32_t) * col->rows, s);
     {
       ProfScope ps("k_replace_re_size", s);
-      if (tdfa && tp.d.in_lds)
+      if (wide && tp.d.in_lds)
+        hipLaunchKernelGGL((k_tdfa_replace_size<true, true>), dim3(tp.grid), dim3(256), tp.lds_bytes, s, src, tp.d, rb, maxrepl,
+                           ptr<int32_t>(lens));
+      else if (wide)
+        hipLaunchKernelGGL((k_tdfa_replace_size<false, true>), dim3(tp.grid), dim3(256), 0, s, src, tp.d, rb, maxrepl,
+                           ptr<int32_t>(lens));
+      else if (tdfa && tp.d.in_lds)
         hipLaunchKernelGGL(k_tdfa_replace_size<true>, dim3(tp.grid), dim3(256), tp.lds_bytes, s, src, tp.d, rb, maxrepl,
                            ptr<int32_t>(lens));
       else if (tdfa)
@@ -2545,7 +2572,13 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
     o->chars = dev_alloc((size_t)o->nbytes, s);
     {
       ProfScope ps("k_replace_re_write", s);
-      if (tdfa && tp.d.in_lds)
+      if (wide && tp.d.in_lds)
+        hipLaunchKernelGGL((k_tdfa_replace_write<true, true>), dim3(tp.grid), dim3(256), tp.lds_bytes, s, src, tp.d,
+                           ptr<const uint8_t>(d_repl), rb, maxrepl, o->d_offsets(), ptr<uint8_t>(o->chars));
+      else if (wide)
+        hipLaunchKernelGGL((k_tdfa_replace_write<false, true>), dim3(tp.grid), dim3(256), 0, s, src, tp.d,
+                           ptr<const uint8_t>(d_repl), rb, maxrepl, o->d_offsets(), ptr<uint8_t>(o->chars));
+      else if (tdfa && tp.d.in_lds)
         hipLaunchKernelGGL(k_tdfa_replace_write<true>, dim3(tp.grid), dim3(256), tp.lds_bytes, s, src, tp.d,
                            ptr<const uint8_t>(d_repl), rb, maxrepl, o->d_offsets(), ptr<uint8_t>(o->chars));
       else if (tdfa)
@@ -3061,7 +3094,7 @@ int cs_replace_re_multi(const cs_column* col, const cs_regex* const* res, int np
       for (int k = 0; k < 4; ++k) mp.first[k] = 0xFFFFFFFFu;
       if (!re->tdfa.empty() && re->tdfa[16] > 0)  // idle states exist: the candidate bitmap says which bytes leave them
         for (int k = 0; k < 4; ++k) mp.first[k] = (uint32_t)re->tdfa[21 + k];
-      all_dfa = all_dfa && !re->tdfa.empty();
+      all_dfa = all_dfa && use_tdfa(re);  // (a program of more than four threads takes the list simulator here)
       max_inst = std::max(max_inst, (int)re->prog.insts.size());
       progs.push_back(mp);
       if (repls->rows > 1 && (int)progs.size() - 1 != i) fail(CS_ERR_INVALID_ARG, "replace_re: a null pattern among several replacements");

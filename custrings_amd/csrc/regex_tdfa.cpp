@@ -271,7 +271,7 @@ struct Builder {
         if (!dup) nk.push_back(Thr{in.u2, t.second, t.tb, t.te});
       }
     }
-    if ((int)nk.size() > kMaxSlots) return false;
+    if ((int)nk.size() > cstd::kMaxSlotsWide) return false;  // (five to eight threads: TdfaWide, regex_tdfa.h)
     out.next.mode = (S.mode == cstd::MODE_RESTART && out.match < 0) ? cstd::MODE_RESTART : cstd::MODE_NORESTART;
     out.next.cat = (use_word && a.isword ? 1 : 0) | (use_line && a.isnl ? 2 : 0);
     for (auto& q : nk) {
@@ -351,7 +351,7 @@ std::vector<int32_t> build_tdfa(const Program& prog, const std::vector<int32_t>&
         e |= cstd::e_keep_field((uint32_t)k);
       } else {
         uint32_t og = 0;
-        for (int j = 0; j < kMaxSlots; ++j) og |= (uint32_t)(j < m ? st.origins[j] : 15) << (4 * j);
+        for (int j = 0; j < cstd::kMaxSlotsWide; ++j) og |= (uint32_t)(j < m ? st.origins[j] : 15) << (4 * j);
         size_t idx = std::find(act.begin(), act.end(), og) - act.begin();
         if (idx == act.size()) act.push_back(og);
         if (idx >= 2048) return none;
@@ -543,7 +543,7 @@ std::vector<int32_t> build_tdfa(const Program& prog, const std::vector<int32_t>&
     img[31] = word;
   }
   img[15] = (int32_t)img.size();
-  if (groups_out && ngroups > 0) {
+  if (groups_out && ngroups > 0 && maxslots <= kMaxSlots) {  // (the tag words hold four slots: wider programs track no groups on the DFA)
     // group-tag image: [0] groups [1] nstates [2] natoms [3] words per table, [4..35] the atom of each ASCII byte
     // (four per word), then one nstates x natoms table per group
     std::vector<int32_t>& G = *groups_out;

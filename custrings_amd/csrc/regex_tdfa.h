@@ -53,6 +53,10 @@ namespace cstd {
 
 constexpr int32_t kMagic = 0x44545343;  // "CSTD"
 constexpr int kMaxSlots = 4;
+// Programs that keep five to eight threads alive (counted repetitions: \d{1,3}\.\d{1,3}..., \w{5}, [0-9a-f]{8}-...) convert
+// too; they run on the generic executor with eight start offsets (TdfaWide below) -- not on the lean scans, the unit
+// decomposition or the capture-group runs, all of which pack four slots into one register.
+constexpr int kMaxSlotsWide = 8;
 constexpr int kMaxStates = 512;
 constexpr int kHeaderWords = 32;
 enum { MODE_RESTART = 0, MODE_NORESTART = 1, MODE_SEED_ONCE = 2 };
@@ -243,12 +247,13 @@ struct Tdfa {
   }
   // Leftmost-first match whose start lies in [from, win_end); win_end is either
   // the row length (search) or from + 1 (anchored), as in the row drivers.
+  template <int NS = kMaxSlots>
   CS_HD int find(int from, int win_end, int& mb, int& me) {
     const int mode = (win_end == from + 1) ? MODE_SEED_ONCE : MODE_RESTART;
     uint32_t state = D.init[mode * 8 + (D.uses ? prev_cat(from) : 0u)];
-    int st[kMaxSlots];
+    int st[NS];
 #pragma unroll
-    for (int j = 0; j < kMaxSlots; ++j) st[j] = from;
+    for (int j = 0; j < NS; ++j) st[j] = from;
     int matched = 0;
     int pos = from;
     // applies transition `e` taken at `pos`; returns true when the automaton stops
@@ -257,7 +262,7 @@ struct Tdfa {
         uint32_t o = e_match_origin(e);
         int v = pos;
 #pragma unroll
-        for (int j = 0; j < kMaxSlots; ++j)
+        for (int j = 0; j < NS; ++j)
           if (o == (uint32_t)j) v = st[j];
         mb = v;
         me = pos;
@@ -265,23 +270,23 @@ struct Tdfa {
       }
       if (e & E_COMPLEX) {
         uint32_t og = D.act[e >> 21];
-        int nst[kMaxSlots];
+        int nst[NS];
 #pragma unroll
-        for (int j = 0; j < kMaxSlots; ++j) {
+        for (int j = 0; j < NS; ++j) {
           uint32_t o = (og >> (4 * j)) & 15u;
           int v = pos;
 #pragma unroll
-          for (int i = 0; i < kMaxSlots; ++i)
+          for (int i = 0; i < NS; ++i)
             if (o == (uint32_t)i) v = st[i];
           nst[j] = v;
         }
 #pragma unroll
-        for (int j = 0; j < kMaxSlots; ++j) st[j] = nst[j];
+        for (int j = 0; j < NS; ++j) st[j] = nst[j];
       } else {
         uint32_t keep = e_keep(e);
         if (keep != 15u) {
 #pragma unroll
-          for (int j = 0; j < kMaxSlots; ++j)
+          for (int j = 0; j < NS; ++j)
             if ((uint32_t)j >= keep) st[j] = pos;
         }
       }
@@ -992,16 +997,16 @@ struct Tdfa {
 
   // emit(mb, me, reps) per match (K_REPLACE: reps > 1 for the zero-length repeat);
   // returns the number of matches (K_CONTAINS / K_MATCH: 0 or 1).
-  template <int KIND, class Emit>
+  template <int KIND, class Emit, int NS = kMaxSlots>
   CS_HD int scan(int maxrepl, Emit&& emit, int from0 = 0, int done0 = 0) {
     // (from0, done0): resume a K_REPLACE / K_COUNT scan at the start of a find() round -- the
     // state every round starts in depends only on the position (used when the lean scan hands a
     // row over in the middle)
     int from = from0, pos = from0, done = done0;
     int mb = 0, me = 0, matched = 0;
-    int st[kMaxSlots];
+    int st[NS];
 #pragma unroll
-    for (int j = 0; j < kMaxSlots; ++j) st[j] = from0;
+    for (int j = 0; j < NS; ++j) st[j] = from0;
     uint32_t state = from0 == 0 ? D.init[(KIND == K_MATCH ? MODE_SEED_ONCE : MODE_RESTART) * 8 + 4]  // row start
                                 : D.init[MODE_RESTART * 8 + (D.uses ? prev_cat(from0) : 0u)];
     // one-word cache of the row storage: consecutive positions share a word
@@ -1081,7 +1086,7 @@ struct Tdfa {
         const uint32_t o = e_match_origin(e);
         int v = pos;
 #pragma unroll
-        for (int j = 0; j < kMaxSlots; ++j)
+        for (int j = 0; j < NS; ++j)
           if (o == (uint32_t)j) v = st[j];
         mb = v;
         me = pos;
@@ -1089,23 +1094,23 @@ struct Tdfa {
       }
       if (e & E_COMPLEX) {
         const uint32_t og = D.act[e >> 21];
-        int nst[kMaxSlots];
+        int nst[NS];
 #pragma unroll
-        for (int j = 0; j < kMaxSlots; ++j) {
+        for (int j = 0; j < NS; ++j) {
           const uint32_t o = (og >> (4 * j)) & 15u;
           int v = pos;
 #pragma unroll
-          for (int i = 0; i < kMaxSlots; ++i)
+          for (int i = 0; i < NS; ++i)
             if (o == (uint32_t)i) v = st[i];
           nst[j] = v;
         }
 #pragma unroll
-        for (int j = 0; j < kMaxSlots; ++j) st[j] = nst[j];
+        for (int j = 0; j < NS; ++j) st[j] = nst[j];
       } else {
         const uint32_t keep = e_keep(e);
         if (keep != 15u) {
 #pragma unroll
-          for (int j = 0; j < kMaxSlots; ++j)
+          for (int j = 0; j < NS; ++j)
             if ((uint32_t)j >= keep) st[j] = pos;
         }
       }
@@ -1145,10 +1150,16 @@ struct Tdfa {
       pos = from;
       matched = 0;
 #pragma unroll
-      for (int j = 0; j < kMaxSlots; ++j) st[j] = from;
+      for (int j = 0; j < NS; ++j) st[j] = from;
       state = D.init[MODE_RESTART * 8 + (D.uses ? prev_cat(from) : 0u)];
     }
   }
+};
+
+// The same executor for programs of five to eight live threads (header word 12): only the generic scan and find, with
+// eight start offsets.  A distinct type so that the row drivers below pick the right width by overload.
+struct TdfaWide : Tdfa {
+  using Tdfa::Tdfa;
 };
 
 }  // namespace cstd
@@ -1281,6 +1292,30 @@ CS_HD void row_replace_matches(cstd::Tdfa& vm, int maxrepl, Emit&& emit) {
   }
 #endif
   vm.scan<cstd::Tdfa::K_REPLACE>(maxrepl, emit);
+}
+// ---- the drivers for TdfaWide: the generic scan with eight thread slots (no lean scan, no unit decomposition) ----
+CS_HD int row_contains_re(cstd::TdfaWide& vm, bool anchored) {
+  auto none = [](int, int, int) {};
+  return anchored ? vm.template scan<cstd::Tdfa::K_MATCH, decltype(none)&, cstd::kMaxSlotsWide>(0, none)
+                  : vm.template scan<cstd::Tdfa::K_CONTAINS, decltype(none)&, cstd::kMaxSlotsWide>(0, none);
+}
+CS_HD int row_count_re(cstd::TdfaWide& vm) {
+  auto none = [](int, int, int) {};
+  return vm.template scan<cstd::Tdfa::K_COUNT, decltype(none)&, cstd::kMaxSlotsWide>(0, none);
+}
+template <class Emit>
+CS_HD int row_findall(cstd::TdfaWide& vm, Emit&& emit) {
+  int k = 0;
+  auto each = [&](int mb, int me, int) {
+    emit(k, mb, me);
+    ++k;
+  };
+  return vm.template scan<cstd::Tdfa::K_COUNT, decltype(each)&, cstd::kMaxSlotsWide>(0, each);
+}
+template <class Emit>
+CS_HD void row_replace_matches(cstd::TdfaWide& vm, int maxrepl, Emit&& emit) {
+  if (maxrepl == 0) return;
+  vm.template scan<cstd::Tdfa::K_REPLACE, Emit&, cstd::kMaxSlotsWide>(maxrepl, emit);
 }
 // The match walk of replace_with_backrefs on the DFA: the first matches of the row by the flat scan loop (word-wise
 // idle skipping), kept in registers and handed to f(mb, me) only after the scan -- f runs whole DFA passes of its

@@ -242,13 +242,20 @@ int emu_regex_blob(const emu_regex* re, const int32_t** words) {
 }
 
 }  // extern "C"
+// the tagged DFA with four thread slots (lean scans, unit decomposition, capture groups) / with five to eight (TdfaWide)
+static bool narrow_dfa(const emu_regex* re) { return !re->tdfa.empty() && re->tdfa[12] <= cstd::kMaxSlots; }
 template <class F>
 static void with_vm(const emu_regex* re, const uint8_t* row, int len, F f) {
   csvm::ProgView P = csvm::make_view(re->image.data(), orc_unicode_flags);
   if (g_engine == 1 && !re->tdfa.empty()) {
     cstd::View D = cstd::make_view(re->tdfa.data());
-    cstd::Tdfa vm(D, P, row, len);
-    f(vm);
+    if (narrow_dfa(re)) {
+      cstd::Tdfa vm(D, P, row, len);
+      f(vm);
+    } else {
+      cstd::TdfaWide vm(D, P, row, len);
+      f(vm);
+    }
     return;
   }
   std::vector<uint32_t> mem((size_t)csvm::vm_slots(P.ninst) + 1);
@@ -325,7 +332,7 @@ int emu_extract(const emu_col* c, const emu_regex* re, emu_col*** cols_out) {
     with_vm(re, c->row(r), c->len(r), [&](auto& vm) { hit = vm.find(0, vm.n, mb, me) > 0; });
     if (!hit) continue;
     // the kernels' route on rows below 255 bytes: every group of the match from one anchored run, four at a time
-    const bool all_at_once = g_engine == 1 && !re->tdfa.empty() && !re->gtags.empty() && c->len(r) < 255;
+    const bool all_at_once = g_engine == 1 && narrow_dfa(re) && !re->gtags.empty() && c->len(r) < 255;
     for (int g0 = 0; all_at_once && g0 < groups; g0 += cstd::Tdfa::kGroupBatch) {
       cstd::View D = cstd::make_view(re->tdfa.data());
       cstd::Tdfa vm(D, P, c->row(r), c->len(r));
@@ -363,7 +370,7 @@ int emu_extract(const emu_col* c, const emu_regex* re, emu_col*** cols_out) {
     for (int g = 0; !all_at_once && g < groups; ++g) {
       int x = 0, y = -1;
       bool ok;
-      if (g_engine == 1 && !re->tdfa.empty() && !re->gtags.empty()) {  // group ranges carried by the tagged DFA
+      if (g_engine == 1 && narrow_dfa(re) && !re->gtags.empty()) {  // group ranges carried by the tagged DFA
         cstd::View D = cstd::make_view(re->tdfa.data());
         cstd::Tdfa vm(D, P, c->row(r), c->len(r));
         int gb = -1, ge = -1;
@@ -412,7 +419,7 @@ emu_col* emu_replace_with_backrefs(const emu_col* c, const emu_regex* re, const 
   t.text = (const uint8_t*)text.data();
   t.bytes = (int)text.size();
   t.groups = re->image[2];
-  const bool dfa = g_engine == 1 && !re->tdfa.empty() && (!re->gtags.empty() || t.groups == 0);
+  const bool dfa = g_engine == 1 && narrow_dfa(re) && (!re->gtags.empty() || t.groups == 0);
   std::vector<uint32_t> mem((size_t)csvm::gvm_slots(P.ninst) + 1);
   auto run = [&](int64_t r, auto&& out) {
     const uint8_t* p = c->row(r);

@@ -603,6 +603,41 @@ def test_gpu_long_replacements_on_the_stream_kernel(gpu_engine, oracle_engine, o
     assert int(L.cs_fallback_count()) == before
 
 
+WIDE_PATTERNS = [r"\d{1,3}\.\d{1,3}\.\d{1,3}\.\d{1,3}", r"\w{5}", r"[a-z]{3,8}@", r"[0-9a-f]{8}-[0-9a-f]{4}", r"(a|b|c){6}x", r"\w{5,7} ", r"[ab]{2,6}c|\d{5}"]
+
+
+@pytest.mark.parametrize("pat", WIDE_PATTERNS)
+def test_gpu_patterns_with_five_to_eight_threads(gpu_engine, oracle_engine, orc, pat):
+    """Counted repetitions keep five to eight threads alive: such programs run the tagged DFA with eight start offsets
+    (regex_tdfa.h TdfaWide; cs_regex_engine reports the thread count) in contains_re / match / count_re (tile stream kernel)
+    and replace_re (two-pass), the list simulator elsewhere -- all against the oracle."""
+    import random
+
+    from custrings_amd import nvstrings
+
+    L = gpuutil.lib().lib
+    re = nvstrings._compile(pat)
+    e = int(L.cs_regex_engine(re))
+    L.cs_regex_destroy(re)
+    assert e & 1 and 5 <= ((e >> 8) & 15) <= 8, hex(e)
+    rnd = random.Random(len(pat))
+    s = [_log_like(rnd, 10, 120) for _ in range(3000)] + ["1.2.3.4", "1234.1.2.3", "1.22.333.4444x", "abcdefgh@", "deadbeef-cafe", "aaaaaax", "12345 ", "", None, "é1.2.3.4é"]
+    o, g = oracle_engine, gpu_engine
+    assert g.contains_re(s, pat) == o.contains_re(s, pat)
+    assert g.match(s, pat) == o.match(s, pat)
+    assert g.count_re(s, pat) == o.count_re(s, pat)
+    for repl, n in (("<>", -1), ("", -1), ("#", 2)):
+        assert g.replace_re(s, pat, repl, n) == o.replace_re(s, pat, repl, n), (repl, n)
+    assert g.findall(s, pat) == o.findall(s, pat)
+    # a C3 window through the persistent grid
+    gc, oc = gpuutil.synth(3, 0, 100_000), orc.synth(3, 0, 100_000)
+    blob = np.ascontiguousarray(engines.reference_blob(pat) if engines.reference_blob(pat) is not None else engines.product_blob(pat), dtype=np.int32)
+    want, nwant = orc.contains_re(oc, blob)
+    got, ngot = gpuutil.bools(gc, "cs_contains_re", gpuutil.compile_re(pat))
+    assert np.array_equal(got, want) and ngot == nwant
+    gpuutil.assert_same(gc.replace(pat, "<IP>"), orc.replace_re(oc, blob, "<IP>"), "C3 replace_re")
+
+
 def test_gpu_literal_replace_on_stream_kernel(gpu_engine, oracle_engine, orc):
     """Literal needles without metacharacters and a replacement no longer than the needle take
     the single-pass replace_re kernel; results must equal the literal replace of the oracle."""

@@ -95,6 +95,34 @@ def test_tdfa_vs_oracle_on_generated_patterns(emu_engine, oracle_engine):
     assert converted > 100
 
 
+WIDE_PATTERNS = [r"\d{1,3}\.\d{1,3}\.\d{1,3}\.\d{1,3}", r"\w{5}", r"[a-z]{3,8}@", r"[0-9a-f]{8}-[0-9a-f]{4}", r"(a|b|c){6}x", r"\d{1,3}\.\d{1,3}\.\d{1,3}\.\d{1,3}$",
+                 r"^\w{5,7} ", r"[ab]{2,6}c|\d{5}"]
+
+
+def test_tdfa_with_five_to_eight_threads_vs_oracle(emu_engine, oracle_engine):
+    """Programs that keep five to eight threads alive (counted repetitions) convert to the tagged DFA too and run on the
+    generic executor with eight start offsets (regex_tdfa.h: TdfaWide): contains / match / count / findall / replace
+    spans equal the oracle's and the list simulator's."""
+    s = fuzzdata.log_rows(31, 300) + fuzzdata.rows(5, 300, max_len=70, alphabet=list("abc019..-@ xf\n") + ["é"]) + \
+        ["1.2.3.4", "1234.1.2.3", "1.22.333.4444", "999.999.999.999x1.1.1.1", "abcdefgh@", "ab@", "deadbeef-cafe", "0123456789abcdef-0123",
+         "aaaaaax", "abcabcx", "12345", "1234", "", None]
+    wide = 0
+    for pat in WIDE_PATTERNS:
+        re = emu_engine.e.compile(pat)
+        info = emu_engine.e.tdfa_info(re)
+        emu_engine.e._regex_free(re)
+        wide += info[0] > 0 and 5 <= info[2] <= 8
+        want = (oracle_engine.contains_re(s, pat), oracle_engine.match(s, pat), oracle_engine.count_re(s, pat), oracle_engine.findall(s, pat),
+                oracle_engine.replace_re(s, pat, "<>", -1), oracle_engine.replace_re(s, pat, "#", 2), oracle_engine.replace_re(s, pat, "", -1))
+        for engine in (0, 1):
+            emu_engine.e.set_engine(engine)
+            got = (emu_engine.contains_re(s, pat), emu_engine.match(s, pat), emu_engine.count_re(s, pat), emu_engine.findall(s, pat),
+                   emu_engine.replace_re(s, pat, "<>", -1), emu_engine.replace_re(s, pat, "#", 2), emu_engine.replace_re(s, pat, "", -1))
+            assert got == want, (pat, engine)
+    emu_engine.e.set_engine(1)
+    assert wide >= 5, wide
+
+
 UNIT_PATTERNS = {  # pattern -> (x byte, required) the builder must find (regex_tdfa.cpp, header word 31)
     r"\d+\.\d+\.\d+\.\d+": (".", True), r"\d+": (None, False), r"\d+\.\d+": (".", True), r"\d+(\.\d+)?": (".", False),
     r"[0-9]+-[0-9]+": ("-", True), r"\b\d{1,3}\.\d{1,3}\.\d{1,3}\.\d{1,3}\b": (".", True), r"[a-c]+": (None, False),
