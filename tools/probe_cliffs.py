@@ -54,8 +54,8 @@ c3 = synth(3, 100_000_000)
 b3 = int(L.cs_column_nbytes(c3.m_cptr))
 res = torch.empty(100_000_000, dtype=torch.uint8, device="cuda")
 P = r"\d{1,3}\.\d{1,3}\.\d{1,3}\.\d{1,3}"
-line("C3 contains_re(IPv4 {1,3} without \\\\b: list simulator)", 100_000_000, b3, timed(lambda: c3.contains(P, devptr=res.data_ptr()), reps=1))
-line("C3 replace_re(IPv4 {1,3} without \\\\b: list simulator)", 100_000_000, b3, timed(lambda: c3.replace(P, "<IP>"), reps=1))
+line("C3 contains_re(IPv4 {1,3} without \\\\b: eight-slot DFA)", 100_000_000, b3, timed(lambda: c3.contains(P, devptr=res.data_ptr()), reps=1))
+line("C3 replace_re(IPv4 {1,3} without \\\\b: eight-slot DFA)", 100_000_000, b3, timed(lambda: c3.replace(P, "<IP>"), reps=1))
 line("C3 replace_re(x* -> '-')", 100_000_000, b3, timed(lambda: c3.replace("x*", "-"), reps=1))
 line("C3 split('/')", 100_000_000, b3, timed(lambda: c3.split("/")))
 line("C3 split(' /')  (two-byte delimiter)", 100_000_000, b3, timed(lambda: c3.split(" /")))
