@@ -43,7 +43,8 @@ bool split_fast(const cs_column* col, const unsigned char* delim, int dlen, int 
 namespace {
 
 constexpr int kSub = 64;
-constexpr int kMaxCols = 32;
+constexpr int kMaxCols = 32;      // the second- and third-generation kernels (a register per column in the measure pass)
+constexpr int kMaxColsWide = 64;  // the first generation: lane k holds column k's destination
 
 struct RowWords {  // a row inside an LDS buffer, read through aligned 32-bit words
   const uint8_t* base;  // 4-byte aligned
@@ -310,7 +311,7 @@ struct MeasureArgs {
   int dlen;
   int tokens, cap;
   long long nsub;
-  int32_t* colsum;  // [kMaxCols][nsub]
+  int32_t* colsum;  // [kMaxColsWide][nsub]
   int* max_count;   // [0] most tokens in a row, [1] most bytes one column receives from one sub-tile, [2] longest row,
                     // [3] set when a sub-tile needs the generic kernels (whitespace mode: a row beyond the 96-bit masks)
 };
@@ -335,7 +336,7 @@ __global__ void __launch_bounds__(256) k_split_measure(MeasureArgs a) {
     const bool has = tk.next(lo, hi);
     if (!__any(has)) break;
     count += has;
-    if (k < kMaxCols) {
+    if (k < kMaxColsWide) {
       const int sum = wave_reduce_sum(has ? hi - lo : 0);
       if (lane == 0) a.colsum[(long long)k * a.nsub + sub] = sum;
       widest = max(widest, sum);
@@ -1045,7 +1046,7 @@ bool split_fast(const cs_column* col, const unsigned char* delim, int dlen, int 
   if (rows == 0 || getenv("CS_SPLIT_GENERIC")) return false;
   const int64_t span = max_span64(col, s);
   const int cap_in = (int)((span + 15 + 32 + 127) & ~(int64_t)127);
-  const int cap_out = cap_in + 32 * kMaxCols;
+  const int cap_out = cap_in + 32 * kMaxColsWide;
   if ((size_t)(cap_in + cap_out + 64) * 4 > 150 * 1024) return false;
   const int64_t nsub = (rows + kSub - 1) / kSub;
   const uint32_t dpat = 0x01010101u * (ws ? 0u : (uint32_t)delim[0]);
@@ -1089,8 +1090,8 @@ bool split_fast(const cs_column* col, const unsigned char* delim, int dlen, int 
     CS_HIP(hipMemcpyAsync(hmx, mx->p, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
     CS_HIP(hipStreamSynchronize(s));
     const int ncols = hmx[0], bound = hmx[1], longest_row = hmx[2];
-    if (ncols == 0 || ncols > kMaxCols) return false;  // all-null column / too many columns: generic path
-    const bool emit2_ok = !hmx[3] && longest_row + 3 <= 96;
+    if (ncols == 0 || ncols > kMaxColsWide) return false;  // all-null column / too many columns: generic path
+    const bool emit2_ok = !hmx[3] && longest_row + 3 <= 96 && ncols <= kMaxCols;  // (33 to 64 columns: the first generation)
     const int cap_col = (bound + 64 + 15) & ~15;
     const size_t lds2 = (size_t)(cap_in + 32 + 2 * cap_col + (ws ? 2 : 1) * ncols * 64) * 4;
     if (emit2_ok && lds2 <= 150 * 1024) {
@@ -1171,8 +1172,8 @@ bool split_fast(const cs_column* col, const unsigned char* delim, int dlen, int 
 
   // ---- first generation (one-byte delimiter; rows beyond 93 bytes, wide tiles): one sub-tile per wave
   const unsigned grid = (unsigned)((nsub + 3) / 4);
-  Buf colsum = dev_alloc(sizeof(int32_t) * nsub * kMaxCols, s);
-  CS_HIP(hipMemsetAsync(colsum->p, 0, sizeof(int32_t) * nsub * kMaxCols, s));  // columns a sub-tile never reaches
+  Buf colsum = dev_alloc(sizeof(int32_t) * nsub * kMaxColsWide, s);
+  CS_HIP(hipMemsetAsync(colsum->p, 0, sizeof(int32_t) * nsub * kMaxColsWide, s));  // columns a sub-tile never reaches
   CS_HIP(hipMemsetAsync(mx->p, 0, 4 * sizeof(int), s));
   MeasureArgs ma{view_of(col), dpat, d64, dlen, tokens, cap_in, nsub, ptr<int32_t>(colsum), ptr<int>(mx)};
   {
@@ -1183,7 +1184,7 @@ bool split_fast(const cs_column* col, const unsigned char* delim, int dlen, int 
   CS_HIP(hipMemcpyAsync(hmx, mx->p, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
   CS_HIP(hipStreamSynchronize(s));
   const int ncols = hmx[0];
-  if (ncols == 0 || ncols > kMaxCols) return false;  // all-null column / too many columns: generic path
+  if (ncols == 0 || ncols > kMaxColsWide) return false;  // all-null column / too many columns: generic path
 
   // per column: position of every sub-tile in the column's chars buffer
   Buf base = dev_alloc(sizeof(int64_t) * (nsub + 1) * ncols, s);

@@ -502,6 +502,29 @@ def test_gpu_tile_kernels_row_counts(gpu_engine, oracle_engine, rows):
     assert g.split(s, " ", -1) == o.split(s, " ", -1)
 
 
+@pytest.mark.parametrize("most", [33, 40, 64, 65])
+def test_gpu_split_33_to_64_columns_on_the_tile_kernels(gpu_engine, oracle_engine, most):
+    """Rows of up to 64 tokens (the C5 column splits into 38): the first-generation tile kernels, where lane k holds
+    column k's destination; 65 and more take the generic kernels.  Short rows (second-generation measure pass first)
+    and rows beyond the 96-byte masks."""
+    import random
+    from custrings_amd import _lib
+
+    rnd = random.Random(most)
+    o, g = oracle_engine, gpu_engine
+    for wide in (False, True):
+        s = []
+        for i in range(3000):
+            k = most if i % 50 == 7 else rnd.randint(1, most)
+            s.append(" ".join("".join(rnd.choice("abcde") for _ in range(rnd.randint(0, 5 if wide else 1))) for _ in range(k)))
+        s[5] = None
+        s[6] = ""
+        f0 = int(_lib.lib.cs_fallback_count())
+        assert g.split(s, " ", -1) == o.split(s, " ", -1), (most, wide)
+        assert g.split(s, " ", 40) == o.split(s, " ", 40), (most, wide)
+        assert int(_lib.lib.cs_fallback_count()) == f0
+
+
 @pytest.mark.parametrize("shape", ["fits", "nonascii", "long_rows", "wide_tiles"])
 def test_gpu_tile_kernels_fallback_paths(gpu_engine, oracle_engine, shape):
     """fits: every sub-tile takes the lean scan / emit2; nonascii: some sub-tiles hold a
