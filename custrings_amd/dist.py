@@ -12,7 +12,9 @@ all-gather their (small) sorted key sets, every rank merges them into the
 global key set -- the semantics of NVCategory::create_from_categories
 (NVCategory.cu:430-514) -- and remaps its local codes.  Output: identical keys on
 every rank, values for the rank's own rows, equal to a single-GPU build of the
-whole column.
+whole column.  When the ranks hold millions of keys in all (K close to N) the merge is partitioned by key range
+instead -- splitters from a sample, an all-to-all of every key to its range's owner, an all-gather of the merged
+ranges (`_merge_partitioned`): every rank merges 1/G of the keys instead of all of them.
 
 The local work goes through an `ops` object so the communication logic can be
 exercised on CPU (gloo) by the tests with a stand-in; the default `GpuOps` is the
@@ -105,6 +107,13 @@ class GpuOps:
     def head(self, col, k):
         return col.sublist(0, min(k, col.size()))
 
+    def slice(self, col, start, end, step=1):
+        """rows start, start + step, ... before end (NVStrings::sublist)"""
+        end = min(end, col.size())
+        if start >= end:
+            return col.sublist(0, 0)
+        return col.sublist(start, end, step)
+
     def concat(self, cols):
         cols = [c for c in cols if c.size()]
         if len(cols) == 1:
@@ -175,14 +184,116 @@ def _all_gather_ragged(tensors, group, scalars=()):
     return out, [row[nt:] for row in table]
 
 
+def _all_to_all_ragged(parts, group):
+    """parts[d]: the 1-D tensor this rank sends to rank d (one dtype; any lengths).  Returns the list of the tensors
+    received, by source rank.  One all-to-all of the counts (one host read), one of the data."""
+    world = dist.get_world_size(group)
+    dev = parts[0].device
+    if dev.type == "cuda" and dist.get_backend(group) == "gloo":  # (several ranks on one GPU: gloo moves host memory)
+        return [t.to(dev) for t in _all_to_all_ragged([p.cpu() for p in parts], group)]
+    send = [int(p.numel()) for p in parts]
+    counts = torch.tensor(send, dtype=torch.int64, device=dev)
+    got = torch.empty(world, dtype=torch.int64, device=dev)
+    dist.all_to_all_single(got, counts, group=group)
+    recv = got.tolist()
+    data = torch.cat([p.reshape(-1) for p in parts]) if sum(send) else torch.empty(0, dtype=parts[0].dtype, device=dev)
+    out = torch.empty(sum(recv), dtype=parts[0].dtype, device=dev)
+    dist.all_to_all_single(out, data, recv, send, group=group)
+    return list(torch.split(out, recv))
+
+
+# The key-set all-gather makes every rank merge ALL ranks' key sets: fine for the K = 1K / 1M configurations, G times
+# redundant when the column's keys are mostly distinct (K close to N).  From this many keys (sum of the ranks' local
+# key counts) the merge is PARTITIONED by key range instead (`_merge_partitioned`).
+PARTITION_MIN_KEYS = 1 << 21
+SPLITTER_SAMPLES_PER_RANK = 64  # per destination rank
+
+
+def _merge_partitioned(ops, cat, keys_col, chars, offs, has_null, group):
+    """Global key set by key RANGES: splitters from a sample of every rank's (sorted) keys cut the key space into one
+    range per rank; an all-to-all sends every local key to its range's owner (the local keys are sorted: contiguous
+    slices), the owner merges what it receives -- 1/G of the keys instead of all of them -- and returns to every sender
+    the position of its keys in the merged range; an all-gather of the merged ranges, in rank order, is the global
+    sorted key set on every rank (the same result as NVCategory::create_from_categories on the gathered key sets,
+    NVCategory.cu:430-514), and a local key's global code is its range's base plus the returned position."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    K = keys_col.size()
+    dev = chars.device
+    first = 1 if has_null else 0  # (the null key, key 0 where present, never becomes a splitter: it belongs to range 0)
+    want = SPLITTER_SAMPLES_PER_RANK * world
+    step = max((K - first) // want, 1)
+    sample = ops.slice(keys_col, first, K, step)
+    sc, so, _ = ops.export(sample)
+    (all_sc, all_so), flags = _all_gather_ragged([sc, so], group, scalars=[1 if has_null else 0])
+    null_on = [bool(f[0]) for f in flags]
+    sample_cols = [ops.column(c, o, False) for c, o in zip(all_sc, all_so) if o.numel() > 1]
+    splitters = None
+    if sample_cols:
+        pool, _ = ops.concat_category(sample_cols)  # sorted, unique
+        M = pool.size()
+        stride = max(M // world, 1)
+        splitters = ops.head(ops.slice(pool, stride, M, stride), world - 1)
+        if splitters.size() == 0:
+            splitters = None
+    # the range of every local key: the number of splitters <= key, from the codes of (local keys ++ splitters)
+    if splitters is not None and K:
+        _, codes = ops.concat_category([keys_col, splitters])
+        kc, sp = codes[:K].long(), codes[K:].long()
+        dest = torch.searchsorted(sp.contiguous(), kc.contiguous(), right=True)
+        if has_null:
+            dest[0] = 0
+    else:
+        dest = torch.zeros(K, dtype=torch.int64, device=dev)
+    cut = torch.searchsorted(dest.contiguous(), torch.arange(world + 1, dtype=torch.int64, device=dev)).tolist()
+    lens = (offs[1:] - offs[:-1]).contiguous()
+    byte_at = offs[torch.tensor(cut, dtype=torch.int64, device=dev)].tolist() if K else [0] * (world + 1)
+    got_lens = _all_to_all_ragged([lens[cut[d] : cut[d + 1]] for d in range(world)], group)
+    got_chars = _all_to_all_ragged([chars[byte_at[d] : byte_at[d + 1]] for d in range(world)], group)
+    # this rank's range: merge what the ranks sent (each part sorted and unique)
+    cols, counts = [], []
+    for r in range(world):
+        n = int(got_lens[r].numel())
+        counts.append(n)
+        if n:
+            o = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+            o[1:] = torch.cumsum(got_lens[r], 0)
+            cols.append(ops.column(got_chars[r].contiguous(), o, rank == 0 and null_on[r]))
+    if cols:
+        range_keys, range_codes = ops.concat_category(cols)
+        rk_chars, rk_offs, rk_null = ops.export(range_keys)
+        nrange = range_keys.size()
+    else:
+        range_codes = torch.empty(0, dtype=torch.int32, device=dev)
+        rk_chars, rk_offs, rk_null, nrange = torch.empty(0, dtype=torch.uint8, device=dev), torch.zeros(1, dtype=torch.int64, device=dev), False, 0
+    # positions back to the senders, merged ranges to everybody
+    back = _all_to_all_ragged(list(torch.split(range_codes.to(torch.int32), counts)), group)
+    (all_c, all_o), sizes = _all_gather_ragged([rk_chars, rk_offs], group, scalars=[nrange, 1 if rk_null else 0])
+    nk = [int(z[0]) for z in sizes]
+    base, run, byte_run = [], 0, 0
+    goffs = [torch.zeros(1, dtype=torch.int64, device=dev)]
+    for r in range(world):
+        base.append(run)
+        run += nk[r]
+        if nk[r]:
+            goffs.append(all_o[r][1 : nk[r] + 1] + byte_run)
+            byte_run += int(all_c[r].numel())
+    gchars = torch.cat([c for c, z in zip(all_c, nk) if z]) if run else torch.empty(0, dtype=torch.uint8, device=dev)
+    keys = ops.column(gchars.contiguous(), torch.cat(goffs).contiguous(), bool(sizes[0][1]) and nk[0] > 0)
+    table = torch.cat([back[d].to(torch.int32) + base[d] for d in range(world)]) if K else torch.empty(0, dtype=torch.int32, device=dev)
+    last_category_exchange.update(partitioned=True, range_keys=nrange, keys_sent=K, keys_received=sum(counts), global_keys=run)
+    return keys, ops.remap(cat, table.contiguous())
+
+
 # Reported when the distributed category build stops paying (SURVEY.md section 8e: with K close to N every rank
 # ends up holding, and merging, almost the whole column): the exchanged key bytes against the shard's own bytes.
 last_category_exchange = {}
 
 
-def global_category(local_col, ops=None, group=None):
+def global_category(local_col, ops=None, group=None, partitioned=None):
     """Distributed NVCategory build.  `local_col` holds this rank's row range.
-    Returns (keys column -- identical on all ranks, values i32 tensor for the local rows)."""
+    Returns (keys column -- identical on all ranks, values i32 tensor for the local rows).
+    `partitioned`: merge by key ranges (True), by all-gathered key sets (False), or by the ranks' key counts (None:
+    partitioned from PARTITION_MIN_KEYS keys in all)."""
     ops = ops or GpuOps()
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     cat, (chars, offs, has_null) = ops.category(local_col)
@@ -191,6 +302,14 @@ def global_category(local_col, ops=None, group=None):
             return cat.keys(), ops.values(cat)
         return cat.keys(), ops.remap(cat, torch.arange(cat.keys_size(), dtype=torch.int32, device=chars.device))
     rank = dist.get_rank(group)
+    if partitioned is None:  # (the same answer on every rank: from the sum of the key counts)
+        dev = chars.device if not (chars.device.type == "cuda" and dist.get_backend(group) == "gloo") else torch.device("cpu")
+        total = torch.tensor([cat.keys_size()], dtype=torch.int64, device=dev)
+        dist.all_reduce(total, group=group)
+        partitioned = int(total.item()) >= PARTITION_MIN_KEYS
+    last_category_exchange.clear()
+    if partitioned:
+        return _merge_partitioned(ops, cat, cat.keys(), chars, offs, has_null, group)
     (all_chars, all_offs), flags = _all_gather_ragged([chars, offs], group, scalars=[1 if has_null else 0])
     key_cols = [ops.column(c, o, bool(f[0])) for c, o, f in zip(all_chars, all_offs, flags)]
     gathered = sum(int(c.numel()) + 8 * int(o.numel()) for c, o in zip(all_chars, all_offs))

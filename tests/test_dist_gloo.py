@@ -82,6 +82,9 @@ class OracleOps:
     def head(self, colw, k):
         return _ColWrap(cpulibs.Col.from_list(colw.col.to_bytes_list()[:k]))
 
+    def slice(self, colw, start, end, step=1):
+        return _ColWrap(cpulibs.Col.from_list(colw.col.to_bytes_list()[start:end:step]))
+
     def concat(self, cols):
         items = []
         for c in cols:
@@ -130,6 +133,73 @@ def test_global_category_two_ranks(rows, K):
         assert values == ev[lo:hi].tolist()  # and the codes of its own rows
         assert ncols == 4  # max over ranks of (3 + rank)
     assert got[0][1] == 0 and got[0][2] == got[1][1] and got[1][2] == rows
+
+
+# ---- the merge partitioned by key ranges (K close to N): splitters, all-to-all, all-gather of the merged ranges ----
+def _partition_rows(kind, rows):
+    import random
+
+    rnd = random.Random(len(kind) * 1000 + rows)
+    if kind == "dense":  # nearly every row its own key, a few repeated across the shards
+        items = [("k%06d" % rnd.randrange(rows * 4)).encode() for _ in range(rows)]
+    elif kind == "few":  # fewer keys than ranks * samples, some ranges stay empty
+        items = [rnd.choice([b"a", b"b", b"zz", b""]) for _ in range(rows)]
+    elif kind == "nulls":
+        items = [None if rnd.random() < 0.1 else ("%x" % rnd.randrange(rows)).encode() for _ in range(rows)]
+    elif kind == "skewed":  # the first shard holds one key only, the last all the others (sorted input)
+        items = [b"same"] * (rows // 2) + [("t%05d" % i).encode() for i in range(rows - rows // 2)]
+    elif kind == "prefixes":  # keys that share long prefixes, multi-byte characters
+        items = [("préfixe-commun-" + "x" * rnd.randrange(4) + "%d" % rnd.randrange(rows // 3 + 1)).encode() for _ in range(rows)]
+    else:
+        items = []
+    return items
+
+
+def _worker_part(rank, world, port, kind, rows, q):
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from custrings_amd import dist as csd
+
+    ops = OracleOps()
+    items = _partition_rows(kind, rows)
+    lo, hi = csd.shard_range(rows, rank, world)
+    keys, values = csd.global_category(_ColWrap(cpulibs.Col.from_list(items[lo:hi])), ops=ops, partitioned=True)
+    report = dict(csd.last_category_exchange)
+    # the automatic choice: the ranks agree on it from the sum of their key counts
+    csd.PARTITION_MIN_KEYS = 10 if kind == "dense" else 1 << 40
+    k2, v2 = csd.global_category(_ColWrap(cpulibs.Col.from_list(items[lo:hi])), ops=ops)
+    auto = bool(csd.last_category_exchange.get("partitioned"))
+    q.put((rank, lo, hi, keys.col.to_list(), values.tolist(), report, k2.col.to_list() == keys.col.to_list() and v2.tolist() == values.tolist(), auto))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind,rows,world", [("dense", 6000, 2), ("dense", 5001, 3), ("few", 900, 3), ("nulls", 4000, 2), ("skewed", 3000, 3),
+                                             ("prefixes", 2500, 2), ("empty", 0, 2)])
+def test_global_category_partitioned_by_key_ranges(kind, rows, world):
+    port = 33500 + (os.getpid() % 2000)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_part, args=(r, world, port, kind, rows, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    o = cpulibs.Oracle()
+    ek, ev = o.category(cpulibs.Col.from_list(_partition_rows(kind, rows)))
+    for rank, lo, hi, keys, values, report, same, auto in got:
+        assert keys == ek.to_list(), (kind, rank)  # every rank: the global key set of a single build
+        assert values == ev[lo:hi].tolist(), (kind, rank)
+        assert report.get("partitioned") and report["global_keys"] == ek.rows
+        assert same  # the all-gather form agrees
+        assert auto == (kind == "dense")
+    if kind == "dense":  # every rank merged about its share, not everything
+        assert all(g[5]["range_keys"] < 0.8 * ek.rows for g in got), [g[5] for g in got]
+        assert sum(g[5]["range_keys"] for g in got) == ek.rows
 
 
 def test_shard_range_covers_rows():

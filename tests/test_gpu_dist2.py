@@ -36,9 +36,13 @@ def _worker(rank, world, port, rows, q):
             return nvstrings.nvstrings(out.value)
 
         keys, values = csd.global_category(synth(4, lo, hi - lo, 3000))
+        # the merge partitioned by key ranges (what K close to N takes): mostly distinct keys, a null row on rank 1
+        dense = synth(4, lo, hi - lo, 1 << 30)
+        pk, pv = csd.global_category(dense, partitioned=True)
+        part = (pk.to_host(), pv.cpu().tolist(), dict(csd.last_category_exchange))
         grams = csd.sharded_ngrams(nvtext.tokenize(synth(5, lo, hi - lo)), 2, "_")
         ncols = csd.agree_on_columns(len(synth(3, lo, hi - lo).split(" ")), device="cpu")
-        q.put((rank, "ok", keys.to_host(), values.cpu().tolist(), grams.to_host(), ncols))
+        q.put((rank, "ok", keys.to_host(), values.cpu().tolist(), grams.to_host(), ncols, part))
         dist.barrier()
         dist.destroy_process_group()
     except Exception as e:  # the parent reports it
@@ -79,6 +83,13 @@ def test_gpu_two_rank_exchanges_with_the_gpu_ops(gpu_engine):
     assert got[0][3] + got[1][3] == list(want_values)           # each rank the codes of its own rows
     assert got[0][4] + got[1][4] == want_grams                  # the n-grams across the shard boundary included
     assert got[0][5] == got[1][5] == want_cols
+    dcat = nvcategory.from_strings(synth(4, 1 << 30))
+    dkeys, dvalues = dcat.keys().to_host(), list(dcat.values())
+    assert got[0][6][0] == got[1][6][0] == dkeys
+    assert got[0][6][1] + got[1][6][1] == dvalues
+    r0, r1 = got[0][6][2], got[1][6][2]
+    assert r0["partitioned"] and r0["global_keys"] == len(dkeys) and r0["range_keys"] + r1["range_keys"] == len(dkeys)
+    assert 0.2 * len(dkeys) < r0["range_keys"] < 0.8 * len(dkeys)  # (each rank merged about its half)
 
 
 @pytest.mark.parametrize("config", ["c3", "c5"])
