@@ -475,7 +475,7 @@ __global__ void __launch_bounds__(256, 8) k_split_measure2(Measure2Args a) {  //
 
 struct ColOut {
   uint8_t* chars;
-  int64_t* offsets;
+  void* offsets;  // int64, or int32 when every column stays below 2 GiB (OFF32)
   uint8_t* validity;
   const int64_t* base;  // base[sub] = bytes of this column before sub-tile `sub` (nsub + 1 entries)
 };
@@ -486,7 +486,9 @@ struct EmitArgs {
   long long nsub;
   const ColOut* cols;
 };
+template <bool OFF32>
 __global__ void __launch_bounds__(256) k_split_emit(EmitArgs a) {
+  using Off = typename std::conditional<OFF32, int32_t, int64_t>::type;
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;  // (scalar: what derives from it stays in SGPRs)
   uint8_t* lds_in = reinterpret_cast<uint8_t*>(smem) + (size_t)wv * (a.cap_in + a.cap_out + 64);
@@ -496,14 +498,14 @@ __global__ void __launch_bounds__(256) k_split_emit(EmitArgs a) {
   SubTile t = load_subtile(a.in, sub, lds_in, lane);
   // lane k holds column k's destination for this sub-tile
   uint8_t* my_chars = nullptr;
-  int64_t* my_off = nullptr;
+  Off* my_off = nullptr;
   uint8_t* my_valid = nullptr;
   long long my_base = 0;
   int my_sum = 0, my_lead = 0;
   if (lane < a.ncols) {
     const ColOut c = a.cols[lane];
     my_chars = c.chars;
-    my_off = c.offsets;
+    my_off = static_cast<Off*>(c.offsets);
     my_valid = c.validity;
     my_base = c.base[sub];
     my_sum = (int)(c.base[sub + 1] - my_base);
@@ -523,11 +525,11 @@ __global__ void __launch_bounds__(256) k_split_emit(EmitArgs a) {
     const int incl = wave_inclusive_scan(len);
     const int pre = incl - len;
     const long long cbase = rl64(my_base, k);
-    int64_t* coff = reinterpret_cast<int64_t*>(rl64((long long)(uintptr_t)my_off, k));
+    Off* coff = reinterpret_cast<Off*>(rl64((long long)(uintptr_t)my_off, k));
     uint8_t* cvalid = reinterpret_cast<uint8_t*>(rl64((long long)(uintptr_t)my_valid, k));
     const int cstart = rl(region, k) + rl(my_lead, k);
-    if (lane < t.nrows) coff[t.r0 + lane] = cbase + pre;
-    if (last_tile && lane == t.nrows - 1) coff[a.in.rows] = cbase + incl;
+    if (lane < t.nrows) coff[t.r0 + lane] = (Off)(cbase + pre);
+    if (last_tile && lane == t.nrows - 1) coff[a.in.rows] = (Off)(cbase + incl);
     const unsigned long long vmask = __ballot(has);
     if (lane == 0) *reinterpret_cast<unsigned long long*>(cvalid + sub * 8) = vmask;
     if (has) cstile::lds_copy_short(lds_out, cstart + pre, lds_in, t.lead + t.rbeg + lo, len);
@@ -1191,15 +1193,19 @@ bool split_fast(const cs_column* col, const unsigned char* delim, int dlen, int 
   std::vector<int64_t> totals(ncols);
   offsets_from_lengths_segmented(ptr<int32_t>(colsum), nsub, ncols, ptr<int64_t>(base), totals.data(), s);
 
+  // int32 offsets (as the later generations write them) when every column stays below 2 GiB: half the offset bytes
+  bool off32 = !getenv("CS_SPLIT_OFF64");
+  for (int k = 0; k < ncols; ++k) off32 = off32 && totals[k] < ((int64_t)1 << 31);
   std::vector<ColOut> outs(ncols);
   for (int k = 0; k < ncols; ++k) {
     auto c = std::make_unique<cs_column>();
     c->rows = rows;
     c->nbytes = totals[k];
     c->chars = dev_alloc((size_t)totals[k], s);
-    c->offsets = dev_alloc(sizeof(int64_t) * (rows + 1), s);
+    if (off32) c->offsets32 = dev_alloc(sizeof(int32_t) * (rows + 1), s);
+    else c->offsets = dev_alloc(sizeof(int64_t) * (rows + 1), s);
     c->validity = dev_alloc(validity_bytes(rows), s);
-    outs[k] = ColOut{ptr<uint8_t>(c->chars), ptr<int64_t>(c->offsets), ptr<uint8_t>(c->validity),
+    outs[k] = ColOut{ptr<uint8_t>(c->chars), off32 ? c->offsets32->p : c->offsets->p, ptr<uint8_t>(c->validity),
                      ptr<const int64_t>(base) + (int64_t)k * (nsub + 1)};
     cols.push_back(std::move(c));
   }
@@ -1207,12 +1213,11 @@ bool split_fast(const cs_column* col, const unsigned char* delim, int dlen, int 
   CS_HIP(hipMemcpyAsync(d_outs->p, outs.data(), sizeof(ColOut) * ncols, hipMemcpyHostToDevice, s));
   EmitArgs ea{view_of(col), dpat, tokens, cap_in, cap_out, ncols, nsub, ptr<const ColOut>(d_outs)};
   const size_t lds = (size_t)(cap_in + cap_out + 64) * 4;
-  if (lds > 48 * 1024)
-    CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_split_emit),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  auto kern = off32 ? &k_split_emit<true> : &k_split_emit<false>;
+  if (lds > 48 * 1024) CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   {
     ProfScope ps("k_split_emit", s);
-    hipLaunchKernelGGL(k_split_emit, dim3(grid), dim3(256), lds, s, ea);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, ea);
   }
   CS_HIP(hipGetLastError());
   CS_HIP(hipStreamSynchronize(s));  // `outs` / `base` lifetime
