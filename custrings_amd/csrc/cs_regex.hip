@@ -284,6 +284,108 @@ __global__ void __launch_bounds__(256) k_spans_write_tile(SpanWriteArgs a) {
   }
 }
 
+// The same from PACKED spans (begin << 16 | length, 0xFFFFFFFF = null; written by the scan stream kernels together with
+// every tile's bytes per column), sizing the columns on the way: `tile_base[c][t]` = bytes of column c before tile t
+// (the exclusive scan of the scan kernel's tile totals), so a tile's wave turns its rows' lengths into offsets itself --
+// one wave scan per column -- and writes offsets, validity bits and chars.  The lengths -> offsets passes over every
+// column (k_chunk_sums / k_chunk_offsets: 0.35 ms per column of 100M rows) and the write kernel's reads of the offsets
+// they produced are gone, and the span arrays are half as large.
+struct SpanOut2 {
+  int64_t* off[kMaxGroups];
+  uint8_t* chars[kMaxGroups];
+  uint8_t* valid[kMaxGroups];
+};
+struct SpanWrite2Args {
+  ColView in;
+  int ncols;
+  const uint32_t* spans;     // [column][row]
+  const int64_t* tile_base;  // [column][nsub + 1]
+  SpanOut2 out;
+  long long nsub;
+  int cap;
+};
+__global__ void __launch_bounds__(256) k_spans_write_tile2(SpanWrite2Args a) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+  uint8_t* lds_in = reinterpret_cast<uint8_t*>(smem) + (size_t)wv * (2 * a.cap + 64);
+  uint8_t* region = lds_in + a.cap + 32;
+  const ColView& in = a.in;
+  // a wave walks a run of consecutive tiles with the next tile's chars in flight (register prefetch, tile_utils.h)
+  const long long waves = (long long)gridDim.x * 4;
+  const long long per = (a.nsub + waves - 1) / waves;
+  long long tile = ((long long)blockIdx.x * 4 + wv) * per;
+  const long long tile_end = min(a.nsub, tile + per);
+  if (tile >= tile_end) return;
+  cstile::TileOffs cur = cstile::load_tile_offsets_r(in.offsets, in.rows, tile, 64, lane);
+  cstile::TileOffs nxt = cur;
+  if (tile + 1 < tile_end) nxt = cstile::load_tile_offsets_r(in.offsets, in.rows, tile + 1, 64, lane);
+  cstile::TileChars pf;
+#pragma unroll
+  for (int j = 0; j < cstile::kPfChunks; ++j) pf.v[j] = make_uint4(0, 0, 0, 0);
+  cstile::issue_chars(in.chars, cstile::rl64(cur.o0, 0), cstile::rl64(cur.o1, 63), lane, pf);
+  for (;;) {
+    const long long r0 = tile * 64;
+    const int nrows = (int)min(64ll, in.rows - r0);
+    const long long g0 = cstile::rl64(cur.o0, 0), g1 = cstile::rl64(cur.o1, 63);
+    const int lead = (int)((uintptr_t)(in.chars + g0) & 15);
+    const int want = (int)(g1 - g0) + lead;
+    const int rpos = lead + (int)(cur.o0 - g0);
+    cstile::stage_chars(lds_in, want, lane, pf);
+    // this tile's spans and column positions, the next tile's chars, the offsets of the one after (handed over at the bottom)
+    uint32_t sp[4];
+    long long cb[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      sp[g] = g < a.ncols && lane < nrows ? a.spans[(long long)g * in.rows + r0 + lane] : 0xFFFFFFFFu;
+      cb[g] = g < a.ncols ? a.tile_base[(long long)g * (a.nsub + 1) + tile] : 0;
+    }
+    const bool has_next = tile + 1 < tile_end;
+    const cstile::TileOffs nn = cstile::load_tile_offsets_r(in.offsets, in.rows, tile + 2 < tile_end ? tile + 2 : tile_end - 1, 64, lane);
+    if (has_next) {
+      cur = nxt;
+      cstile::issue_chars(in.chars, cstile::rl64(cur.o0, 0), cstile::rl64(cur.o1, 63), lane, pf);
+    }
+    cstile::wave_lds_fence();
+    for (int g = 0; g < a.ncols; ++g) {
+      uint32_t w;
+      long long base;
+      if (g < 4) {  // (requested above)
+        w = sp[0];
+        base = cb[0];
+#pragma unroll
+        for (int c = 1; c < 4; ++c)
+          if (c == g) {
+            w = sp[c];
+            base = cb[c];
+          }
+      } else {
+        w = lane < nrows ? a.spans[(long long)g * in.rows + r0 + lane] : 0xFFFFFFFFu;
+        base = a.tile_base[(long long)g * (a.nsub + 1) + tile];
+      }
+      const bool valid = w != 0xFFFFFFFFu;
+      const int len = valid ? (int)(w & 0xFFFFu) : 0;
+      const int beg = valid ? (int)(w >> 16) : 0;
+      const int inc = csdev::wave_inclusive_scan(len);
+      const int di = inc - len;
+      const int total = __builtin_amdgcn_readlane(inc, 63);
+      if (lane < nrows) a.out.off[g][r0 + lane] = base + di;
+      if (tile + 1 == a.nsub && lane == nrows - 1) a.out.off[g][in.rows] = base + total;
+      const unsigned long long vbits = __ballot(valid);
+      if (lane == 0) *reinterpret_cast<unsigned long long*>(a.out.valid[g] + tile * 8) = vbits;
+      if (total == 0) continue;
+      for (int k = 0; k < len; k += 16)
+        cstile::lds_put16(region + di + k, *reinterpret_cast<const cstile::lds_u32x4u*>(lds_in + rpos + beg + k), len - k);
+      cstile::wave_lds_fence();
+      cstile::wave_flush_shift(a.out.chars[g] + base, total, region, lane);
+      cstile::wave_lds_fence();  // the next column re-uses the region
+    }
+    cstile::wave_lds_fence();  // the next tile overwrites lds_in
+    if (!has_next) break;
+    ++tile;
+    nxt = nn;
+  }
+}
+
 // ---- tagged-DFA kernels (regex_tdfa.h): tables staged in LDS, no per-thread lists ----
 struct TLaunch {
   const int32_t* tdfa;   // device image
@@ -1667,6 +1769,11 @@ struct ScanStreamArgs {
   int32_t* lens;
   int ncols;
   int* maxp;             // MODE 3 (optional): receives the largest match count of a row
+  // MODE 3, 4 (optional): the spans as ONE word per (column, row) -- begin << 16 | length, 0xFFFFFFFF = null -- instead of
+  // begins / lens (half the span traffic; rows of a tile are far shorter than 64 KiB), and the bytes every 64-row tile
+  // gives to each column, [column][tile] (rows_per_tile == 64 only): k_spans_write_tile2 sizes the columns from those
+  uint32_t* spans;
+  int32_t* tile_tot;
   const int32_t* gtags;  // MODE 4, 5, 6: capture-group tag image
   int gt_off, gt_words;  // when gt_words > 0 the image is staged into LDS at byte offset gt_off (inside tbl_bytes)
   const csvm::BackrefTemplate* tmpl;  // MODE 5, 6 (device memory: indexed per reference, must not live in the kernel arguments)
@@ -1683,13 +1790,15 @@ __global__ void __launch_bounds__(256, ((UNITS && MODE == 3) || MODE == 4) ? 3 :
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;  // (scalar: what derives from it stays in SGPRs)
   const int bm_bytes = (a.cap_in >> 3) + 32;
   // (MODE 4 keeps a lane-private byte per step of a group run behind the bitmap: regex_tdfa.h, group_find_back)
-  const int unit_bytes = UNITS ? bm_bytes + kUnitQueue * 4 + 64 * 4 + 16 : (MODE == 4 ? cstd::Tdfa::kBackSteps * 64 : 0);  // x bitmap, unit queue, per-row results, bail word
+  const int unit_bytes = UNITS ? bm_bytes + kUnitQueue * 4 + 64 * 4 + 16 : (MODE == 4 ? cstd::Tdfa::kBackSteps * 64 + kMaxGroups * 4 : 0);  // x bitmap, unit queue, per-row results, bail word
   uint8_t* lds_in = base + a.tbl_bytes + (size_t)wv * (a.cap_in + 32 + bm_bytes + unit_bytes);
   uint32_t* bitmap = reinterpret_cast<uint32_t*>(lds_in + a.cap_in + 32);
   uint32_t* xbitmap = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(bitmap) + bm_bytes);
   uint32_t* uqueue = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(xbitmap) + bm_bytes);
   uint32_t* rowres = uqueue + kUnitQueue;
   uint32_t* bailw = rowres + 64;
+  uint32_t* gtot = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(xbitmap) + cstd::Tdfa::kBackSteps * 64);  // MODE 4: per group, the tile's bytes
+  if (MODE == 4 && lane < kMaxGroups) gtot[lane] = 0;
   const TCtx c = tsetup<IN_LDS>(a.L, a.flags, smem);
   const cstd::View& D = c.D;
   const csvm::ProgView& P = c.P;
@@ -1843,18 +1952,36 @@ __global__ void __launch_bounds__(256, ((UNITS && MODE == 3) || MODE == 4) ? 3 :
             for (int k = 0; k < cstd::Tdfa::kGroupBatch; ++k)
               if (k < cnt) {
                 const bool ok = found && gb[k] >= 0 && ge[k] > gb[k];
-                a.begins[(long long)(g0 + k) * in.rows + r0 + lane] = ok ? gb[k] : 0;
-                a.lens[(long long)(g0 + k) * in.rows + r0 + lane] = ok ? ge[k] - gb[k] : -1;
+                if (a.spans) {
+                  a.spans[(long long)(g0 + k) * in.rows + r0 + lane] = ok ? (((uint32_t)gb[k] << 16) | (uint32_t)(ge[k] - gb[k])) : 0xFFFFFFFFu;
+                } else {
+                  a.begins[(long long)(g0 + k) * in.rows + r0 + lane] = ok ? gb[k] : 0;
+                  a.lens[(long long)(g0 + k) * in.rows + r0 + lane] = ok ? ge[k] - gb[k] : -1;
+                }
+                if (a.tile_tot && ok) __hip_atomic_fetch_add(gtot + g0 + k, (uint32_t)(ge[k] - gb[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
               }
           }
         } else {
           for (int g = 0; g < a.ncols; ++g) {
             int x = -1, y = -1;
             const bool ok = hit && vm.group_find(mb, a.gtags, g + 1, x, y) && x >= 0 && y > x;
-            a.begins[(long long)g * in.rows + r0 + lane] = ok ? x : 0;
-            a.lens[(long long)g * in.rows + r0 + lane] = ok ? y - x : -1;
+            if (a.tile_tot && ok) __hip_atomic_fetch_add(gtot + g, (uint32_t)(y - x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            if (a.spans) {
+              a.spans[(long long)g * in.rows + r0 + lane] = ok ? (((uint32_t)x << 16) | (uint32_t)(y - x)) : 0xFFFFFFFFu;
+            } else {
+              a.begins[(long long)g * in.rows + r0 + lane] = ok ? x : 0;
+              a.lens[(long long)g * in.rows + r0 + lane] = ok ? y - x : -1;
+            }
           }
         }
+      }
+      if (a.tile_tot) {  // the bytes this tile gives to each group's column (summed in LDS by the row lanes above)
+        cstile::wave_lds_fence();
+        if (lane < a.ncols) {
+          a.tile_tot[(long long)lane * a.nsub + tile] = (int32_t)gtot[lane];
+          gtot[lane] = 0;
+        }
+        cstile::wave_lds_fence();
       }
     } else {
       cstd::Tdfa vm(D, P, lds_in + lead + rbeg, n, (lead + rbeg) & 3);
@@ -1862,10 +1989,18 @@ __global__ void __launch_bounds__(256, ((UNITS && MODE == 3) || MODE == 4) ? 3 :
                         !__any(live && (LONG ? n > cstd::Tdfa::kLongBytes : !vm.masks_fit()));
       bool redo = live && !lean;
       int k = 0;  // MODE 3: matches reported so far
+      int cl[4] = {0, 0, 0, 0};  // (packed spans: the lengths of the row's first four matches, for the tile's column totals)
       auto span = [&](int mb, int me, int) {
         if (k < a.ncols) {
-          a.begins[(long long)k * in.rows + r0 + lane] = mb;
-          a.lens[(long long)k * in.rows + r0 + lane] = me - mb;
+          if (a.spans) {
+            a.spans[(long long)k * in.rows + r0 + lane] = ((uint32_t)mb << 16) | (uint32_t)(me - mb);
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+              if (c == k) cl[c] = me - mb;
+          } else {
+            a.begins[(long long)k * in.rows + r0 + lane] = mb;
+            a.lens[(long long)k * in.rows + r0 + lane] = me - mb;
+          }
         }
         ++k;
       };
@@ -1973,6 +2108,8 @@ __global__ void __launch_bounds__(256, ((UNITS && MODE == 3) || MODE == 4) ? 3 :
         if (redo) {
           if (MODE == 3) {
             k = 0;  // (the spans reported so far are written again, identically)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) cl[c] = 0;
             v = csvm::row_findall(vm, [&](int, int mb, int me) {
               span(mb, me, 1);
               return true;
@@ -1982,8 +2119,21 @@ __global__ void __launch_bounds__(256, ((UNITS && MODE == 3) || MODE == 4) ? 3 :
           }
         }
       }
-      if (MODE == 3 && lane < nrows)
-        for (int j = live ? k : 0; j < a.ncols; ++j) a.lens[(long long)j * in.rows + r0 + lane] = -1;
+      if (MODE == 3 && lane < nrows) {
+        if (a.spans)
+          for (int j = live ? k : 0; j < a.ncols; ++j) a.spans[(long long)j * in.rows + r0 + lane] = 0xFFFFFFFFu;
+        else
+          for (int j = live ? k : 0; j < a.ncols; ++j) a.lens[(long long)j * in.rows + r0 + lane] = -1;
+      }
+      if (MODE == 3 && a.tile_tot) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          if (c < a.ncols) {
+            // (most tiles give the later columns nothing: no reduction then)
+            const int t = __any(live && k > c) ? wave_reduce_sum(live ? cl[c] : 0) : 0;
+            if (lane == 0) a.tile_tot[(long long)c * a.nsub + tile] = t;
+          }
+      }
       if (MODE == 3 && a.maxp) {
         int m = live ? k : 0;
         for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o));
@@ -2622,6 +2772,44 @@ void write_spans(const cs_column* col, int ncols, const int32_t* begins, const i
   }
 }
 
+// The output columns from PACKED spans and the scan kernel's tile totals (k_spans_write_tile2): no pass over the lengths.
+void columns_from_packed_spans(const cs_column* col, int ncols, const uint32_t* spans, const int32_t* tile_tot, int cap, hipStream_t s,
+                               std::vector<std::unique_ptr<cs_column>>& cols) {
+  const int64_t rows = col->rows, nsub = (rows + 63) / 64;
+  Buf base = dev_alloc(sizeof(int64_t) * (nsub + 1) * ncols, s);
+  std::vector<int64_t> totals(ncols);
+  offsets_from_lengths_segmented(tile_tot, nsub, ncols, ptr<int64_t>(base), totals.data(), s);
+  SpanWrite2Args a{};
+  a.in = view_of(col);
+  a.ncols = ncols;
+  a.spans = spans;
+  a.tile_base = ptr<const int64_t>(base);
+  a.nsub = nsub;
+  a.cap = cap;
+  for (int k = 0; k < ncols; ++k) {
+    auto o = std::make_unique<cs_column>();
+    o->rows = rows;
+    o->nbytes = totals[k];
+    o->offsets = dev_alloc(sizeof(int64_t) * (rows + 1), s);
+    o->validity = dev_alloc(validity_bytes(rows), s);
+    o->chars = dev_alloc((size_t)o->nbytes, s);
+    a.out.off[k] = ptr<int64_t>(o->offsets);
+    a.out.valid[k] = ptr<uint8_t>(o->validity);
+    a.out.chars[k] = ptr<uint8_t>(o->chars);
+    cols.push_back(std::move(o));
+  }
+  const size_t lds = (size_t)4 * (2 * cap + 64);
+  if (lds > 48 * 1024)
+    CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spans_write_tile2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const unsigned grid = (unsigned)std::min<long long>((nsub + 3) / 4, 256 * 64);  // (runs of consecutive tiles per wave; short ones share the tail out)
+  {
+    ProfScope ps("k_extract_write", s);
+    hipLaunchKernelGGL(k_spans_write_tile2, dim3(grid), dim3(256), lds, s, a);
+  }
+  CS_HIP(hipGetLastError());
+  CS_HIP(hipStreamSynchronize(s));  // `base` / span buffers
+}
+
 // NVStrings::extract(pattern, results) (NVStrings.h:682; extract.cu:69-151): one column per
 // capture group; a pattern without groups, or an empty column, yields no columns.
 int cs_extract(const cs_column* col, const cs_regex* cre, cs_stream stream, cs_column*** out_cols, int* ncols_out) {
@@ -2652,17 +2840,24 @@ int cs_extract(const cs_column* col, const cs_regex* cre, cs_stream stream, cs_c
       L.arena = ptr<uint32_t>(arena);
     }
     RowSrc src{view_of(col), d_unicode_flags(), col->nbytes + (col->chars && col->chars->capacity ? 64 : 0)};
-    Buf begins = dev_alloc(sizeof(int32_t) * rows * groups, s);
-    Buf lens = dev_alloc(sizeof(int32_t) * rows * groups, s);
+    Buf begins, lens, spans, tile_tot;  // (begins / lens, or packed spans + tile totals from the scan stream kernel on 64-row tiles)
     const bool tdfa = use_tdfa(re);
-    bool streamed = false;
+    bool streamed = false, packed = false;
     if (dfa_groups && !getenv("CS_REGEX_ROWWISE")) {  // rows staged through LDS tiles by the scan stream kernel
       TPlan tp = tplan(re, rows, s);
       const TileChoice tc = choose_tile(col, s);
       const int cap = tc.cap;
       const size_t gt_bytes = re->gtags.size() * 4 <= 16 * 1024 ? ((re->gtags.size() * 4 + 15) & ~size_t(15)) : 0;
-      const size_t lds = tp.lds_bytes + gt_bytes + (size_t)(cap + 32 + (cap >> 3) + 32 + cstd::Tdfa::kBackSteps * 64) * 4;
+      const size_t lds = tp.lds_bytes + gt_bytes + (size_t)(cap + 32 + (cap >> 3) + 32 + cstd::Tdfa::kBackSteps * 64 + kMaxGroups * 4) * 4;
       if (tp.d.in_lds && tc.R && lds <= 150 * 1024) {
+        packed = tc.R == 64 && !getenv("CS_SPANS_UNPACKED");
+        if (packed) {
+          spans = dev_alloc(sizeof(uint32_t) * rows * groups, s);
+          tile_tot = dev_alloc(sizeof(int32_t) * ((rows + 63) / 64) * groups, s);
+        } else {
+          begins = dev_alloc(sizeof(int32_t) * rows * groups, s);
+          lens = dev_alloc(sizeof(int32_t) * rows * groups, s);
+        }
         Buf cnt = dev_alloc(8, s);
         CS_HIP(hipMemsetAsync(cnt->p, 0, 8, s));
         ScanStreamArgs sa{};
@@ -2678,6 +2873,8 @@ int cs_extract(const cs_column* col, const cs_regex* cre, cs_stream stream, cs_c
         sa.gt_words = gt_bytes ? (int)re->gtags.size() : 0;
         sa.begins = ptr<int32_t>(begins);
         sa.lens = ptr<int32_t>(lens);
+        sa.spans = ptr<uint32_t>(spans);
+        sa.tile_tot = ptr<int32_t>(tile_tot);
         sa.ncols = groups;
         sa.gtags = ptr<const int32_t>(re->d_gtags);
         auto kern = tc.lng ? &k_tdfa_scan_stream<4, true, true> : &k_tdfa_scan_stream<4, true, false>;
@@ -2688,6 +2885,10 @@ int cs_extract(const cs_column* col, const cs_regex* cre, cs_stream stream, cs_c
         hipLaunchKernelGGL(kern, dim3(sgrid), dim3(256), lds, s, sa);
         streamed = true;
       }
+    }
+    if (!streamed) {
+      begins = dev_alloc(sizeof(int32_t) * rows * groups, s);
+      lens = dev_alloc(sizeof(int32_t) * rows * groups, s);
     }
     if (streamed) {
     } else if (dfa_groups) {
@@ -2730,6 +2931,15 @@ int cs_extract(const cs_column* col, const cs_regex* cre, cs_stream stream, cs_c
     }
     CS_HIP(hipGetLastError());
     std::vector<std::unique_ptr<cs_column>> cols;
+    if (packed) {
+      columns_from_packed_spans(col, groups, ptr<const uint32_t>(spans), ptr<const int32_t>(tile_tot), choose_tile(col, s).cap, s, cols);
+      cs_column** arr = (cs_column**)malloc(sizeof(cs_column*) * groups);
+      if (!arr) fail(CS_ERR_ALLOC, "host allocation failed");
+      for (int g = 0; g < groups; ++g) arr[g] = cols[g].release();
+      *out_cols = arr;
+      *ncols_out = groups;
+      return;
+    }
     ExtractOut eo{};
     for (int g = 0; g < groups; ++g) {
       auto o = std::make_unique<cs_column>();
@@ -2781,10 +2991,11 @@ int cs_findall(const cs_column* col, const cs_regex* cre, cs_stream stream, cs_c
       return hmax[0];
     };
     RowSrc src{view_of(col), d_unicode_flags(), col->nbytes + (col->chars && col->chars->capacity ? 64 : 0)};
-    Buf begins, lens;
+    Buf begins, lens, spans, tile_tot;
     Plan pl{};
     int ncols = -1;  // unknown
-    bool streamed = false;
+    bool streamed = false, packed = false;
+    int packed_cap = 0;
     // The scan stream kernel reports spans and the largest match count in ONE pass when the rows hold at most
     // kProvisional matches (the span arrays are laid out [k * rows + row], so unused columns cost only memory);
     // a column with busier rows is scanned a second time with the exact column count.
@@ -2816,11 +3027,21 @@ int cs_findall(const cs_column* col, const cs_regex* cre, cs_stream stream, cs_c
         const unsigned grid = resident_grid(reinterpret_cast<const void*>(kern), lds, (sa.nsub + 3) / 4);
         int width = kProvisional;
         for (int pass = 0; pass < 2; ++pass) {
-          begins = dev_alloc(sizeof(int32_t) * rows * width, s);
-          lens = dev_alloc(sizeof(int32_t) * rows * width, s);
+          // (the provisional pass on 64-row tiles leaves packed spans and tile totals: k_spans_write_tile2 needs no pass
+          // over the lengths; a second pass -- rows with more than kProvisional matches -- writes begins / lens)
+          packed = pass == 0 && tc.R == 64 && !getenv("CS_SPANS_UNPACKED");
+          if (packed) {
+            spans = dev_alloc(sizeof(uint32_t) * rows * width, s);
+            tile_tot = dev_alloc(sizeof(int32_t) * ((rows + 63) / 64) * width, s);
+          } else {
+            begins = dev_alloc(sizeof(int32_t) * rows * width, s);
+            lens = dev_alloc(sizeof(int32_t) * rows * width, s);
+          }
           CS_HIP(hipMemsetAsync(dmax->p, 0, 8, s));
-          sa.begins = ptr<int32_t>(begins);
-          sa.lens = ptr<int32_t>(lens);
+          sa.begins = packed ? nullptr : ptr<int32_t>(begins);
+          sa.lens = packed ? nullptr : ptr<int32_t>(lens);
+          sa.spans = packed ? ptr<uint32_t>(spans) : nullptr;
+          sa.tile_tot = packed ? ptr<int32_t>(tile_tot) : nullptr;
           sa.ncols = width;
           {
             ProfScope ps("k_findall_spans", s);
@@ -2832,6 +3053,7 @@ int cs_findall(const cs_column* col, const cs_regex* cre, cs_stream stream, cs_c
           width = ncols;  // busier rows than provisioned for: once more, exactly
         }
         streamed = true;
+        packed_cap = cap;
       }
     }
     if (!streamed) {
@@ -2845,6 +3067,11 @@ int cs_findall(const cs_column* col, const cs_regex* cre, cs_stream stream, cs_c
     }
     if (ncols == 0) {  // findall.cu:149-151
       cols.emplace_back(make_all_null(rows, s));
+      finish(cols);
+      return;
+    }
+    if (streamed && packed) {
+      columns_from_packed_spans(col, ncols, ptr<const uint32_t>(spans), ptr<const int32_t>(tile_tot), packed_cap, s, cols);
       finish(cols);
       return;
     }

@@ -629,6 +629,35 @@ def test_gpu_long_replacements_on_the_stream_kernel(gpu_engine, oracle_engine, o
 WIDE_PATTERNS = [r"\d{1,3}\.\d{1,3}\.\d{1,3}\.\d{1,3}", r"\w{5}", r"[a-z]{3,8}@", r"[0-9a-f]{8}-[0-9a-f]{4}", r"(a|b|c){6}x", r"\w{5,7} ", r"[ab]{2,6}c|\d{5}"]
 
 
+@pytest.mark.parametrize("rows", [1, 64, 65, 4097, 20000])
+def test_gpu_findall_extract_from_packed_spans(gpu_engine, oracle_engine, rows, monkeypatch):
+    """findall / extract on 64-row tiles: the scan stream kernel leaves one packed word per (column, row) and every tile's
+    bytes per column, k_spans_write_tile2 turns lengths into offsets itself (no pass over the lengths).  Nulls, empty
+    rows, rows without a match, more than four matches in a row (the exact-width second pass writes begins / lens),
+    more than four capture groups (columns beyond the write kernel's prefetched four), the last partial tile; the
+    unpacked route must agree."""
+    import random
+
+    rnd = random.Random(rows)
+    s = [_log_like(rnd, 20, 90) for _ in range(rows)]
+    for i in range(0, rows, 53):
+        s[i] = None if i % 2 else ""
+    if rows > 100:
+        s[77] = "1.2.3.4 5.6.7.8 9.9.9.9 10.0.0.1 8.8.8.8 7.7.7.7"  # six matches in one row
+    o, g = oracle_engine, gpu_engine
+    pats_f = [IPV4, r"\d+", r"[a-c]+", r"/\S*"]
+    pats_e = [r"(\d+)\.(\d+)\.\d+\.(\d+) ", r"(\d+)\.(\d+)\.(\d+)\.(\d+)", r"(\w)(\w)(\w)(\w)(\w)(\w)", r"(GET|POST) (/\S*)", r"(a)|(b)"]
+    for pat in pats_f:
+        want = o.findall(s, pat)
+        assert g.findall(s, pat) == want, pat
+    for pat in pats_e:
+        want = o.extract(s, pat)
+        assert g.extract(s, pat) == want, pat
+    monkeypatch.setenv("CS_SPANS_UNPACKED", "1")
+    assert g.findall(s, IPV4) == o.findall(s, IPV4)
+    assert g.extract(s, pats_e[0]) == o.extract(s, pats_e[0])
+
+
 @pytest.mark.parametrize("pat", WIDE_PATTERNS)
 def test_gpu_patterns_with_five_to_eight_threads(gpu_engine, oracle_engine, orc, pat):
     """Counted repetitions keep five to eight threads alive: such programs run the tagged DFA with eight start offsets
