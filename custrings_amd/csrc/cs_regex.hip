@@ -2489,7 +2489,11 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
     // roomier sizing.  A pattern that matches the empty string with a non-empty replacement is
     // unbounded (the zero-length repeat rule) and takes the two-pass kernels.
     const int growth = rb > minlen ? rb - minlen : 0;
-    const bool bounded = growth == 0 || minlen >= 1;
+    // (a pattern that matches the empty string inserts at most one replacement per character and one at the row's end:
+    // short replacements are provisioned for exactly that -- `x*` -> '-' doubles the column -- and stay on the single pass)
+    const bool empties = minlen == 0 && growth > 0;
+    const int minlen_p = std::max(minlen, 1);
+    const bool bounded = growth == 0 || minlen >= 1 || rb <= 8;  // (longer ones: the out tile of 1 + rb times the input does not fit the LDS)
     if (tdfa && bounded && !getenv("CS_REGEX_TWO_PASS")) {
       const int64_t rows = col->rows;
       const int64_t ntiles = (rows + cstile::kTileRows - 1) / cstile::kTileRows;
@@ -2505,10 +2509,14 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
         int cap_out = cap + ((64 * kMaxRec * growth + 127) & ~127);
         int64_t extra = std::min<int64_t>(few, col->nbytes + (1ll << 30));
         if (roomy) {
-          const int64_t worst = ((int64_t)cap * rb + minlen - 1) / minlen;
+          const int64_t worst = ((int64_t)cap * rb + minlen_p - 1) / minlen_p;
           cap_out = std::max(cap_out, (int)((std::min<int64_t>(worst, 3ll * cap) + 127) & ~(int64_t)127));
-          const int64_t worst_extra = (col->nbytes * growth + minlen - 1) / minlen;
+          const int64_t worst_extra = (col->nbytes * growth + minlen_p - 1) / minlen_p;
           extra = std::min(worst_extra, std::max<int64_t>(extra, col->nbytes));
+          if (empties) {  // every character and every row end may take a replacement
+            cap_out = (int)(((int64_t)cap * (1 + rb) + 64 * rb + 127) & ~(int64_t)127);
+            extra = col->nbytes * rb + rows * rb;
+          }
         }
         // the unit scan (k_tdfa_replace_stream<.., UNITS>): patterns whose tagged DFA offers the decomposition, no limit
         // on the number of replacements, rows within the 96-byte masks

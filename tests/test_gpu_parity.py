@@ -629,6 +629,27 @@ def test_gpu_long_replacements_on_the_stream_kernel(gpu_engine, oracle_engine, o
 WIDE_PATTERNS = [r"\d{1,3}\.\d{1,3}\.\d{1,3}\.\d{1,3}", r"\w{5}", r"[a-z]{3,8}@", r"[0-9a-f]{8}-[0-9a-f]{4}", r"(a|b|c){6}x", r"\w{5,7} ", r"[ab]{2,6}c|\d{5}"]
 
 
+@pytest.mark.parametrize("pat,repl", [("x*", "-"), ("a*", "<>"), ("\\d*", "#"), ("[a-c]*", "."), ("b*|c", "_"), ("\\b", "|"), ("$", "!"), ("^", ">"),
+                                      ("x*", "<IP>"), ("\\d*", "<number>")])
+def test_gpu_patterns_that_match_the_empty_string_on_the_stream_kernel(gpu_engine, oracle_engine, pat, repl):
+    """replace_re with a pattern that matches the empty string and a replacement of one or two bytes (replace.cu:91-93,
+    the zero-length repeat rule): bounded growth -- one replacement per character and one at the
+    row's end -- so the single-pass stream kernel takes it (the out tile and the output sized for exactly that; up to
+    eight bytes), with limits too; no fallback."""
+    import random
+    from custrings_amd import _lib
+
+    rnd = random.Random(len(pat) * 31 + len(repl))
+    s = [_log_like(rnd, 0, 93) for _ in range(5000)] + ["", None, "x", "xx", "axxb", "aaa", "abcabc", "é", "xéx", "12", " ", "\n", "a\nb"]
+    o, g = oracle_engine, gpu_engine
+    f0 = int(_lib.lib.cs_fallback_count())
+    for n in (-1, 1, 3):
+        assert g.replace_re(s, pat, repl, n) == o.replace_re(s, pat, repl, n), (pat, repl, n)
+    long_rows = [_log_like(rnd, 100, 260) for _ in range(1500)]
+    assert g.replace_re(long_rows, pat, repl, -1) == o.replace_re(long_rows, pat, repl, -1)
+    assert int(_lib.lib.cs_fallback_count()) == f0
+
+
 @pytest.mark.parametrize("rows", [1, 64, 65, 4097, 20000])
 def test_gpu_findall_extract_from_packed_spans(gpu_engine, oracle_engine, rows, monkeypatch):
     """findall / extract on 64-row tiles: the scan stream kernel leaves one packed word per (column, row) and every tile's
