@@ -66,6 +66,7 @@ CharSet make_set(const char* s, const char* what) {
     cs.c[cs.n++] = c;
     i += w ? (int)w : 1;
   }
+  charset_finish(cs);
   return cs;
 }
 

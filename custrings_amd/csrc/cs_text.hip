@@ -36,6 +36,7 @@ Tokenizer make_tokenizer(const char* delimiter, const char* what) {
       i += w ? (int)w : 1;
     }
   }
+  charset_finish(t.set);
   return t;
 }
 template <class Emit>

@@ -141,8 +141,20 @@ CS_HD void row_replace_write(const uint8_t* p, int n, const uint8_t* needle, int
 struct CharSet {  // up to 64 packed chars
   Char c[64];
   int n;
+  uint32_t ascii[4];  // the set's ASCII members as a bitmap (charset_finish): one bit test instead of a walk over c[]
 };
+// call once the members are in c[0 .. n)
+CS_HD void charset_finish(CharSet& s) {
+  s.ascii[0] = s.ascii[1] = s.ascii[2] = s.ascii[3] = 0;
+  for (int i = 0; i < s.n; ++i)
+    if (s.c[i] < 128u) s.ascii[s.c[i] >> 5] |= 1u << (s.c[i] & 31u);
+}
 CS_HD bool in_set(const CharSet& s, Char ch) {
+  if (s.n > 4 && ch < 128u) {  // (a handful of members: the walk below is cheaper than the word select)
+    const unsigned k = ch >> 5;
+    const uint32_t w = k == 0 ? s.ascii[0] : (k == 1 ? s.ascii[1] : (k == 2 ? s.ascii[2] : s.ascii[3]));
+    return ((w >> (ch & 31u)) & 1u) != 0;
+  }
   for (int i = 0; i < s.n; ++i)
     if (s.c[i] == ch) return true;
   return false;

@@ -64,6 +64,7 @@ static CharSet make_set(const char* s) {
     cs.c[cs.n++] = c;
     i += w ? (int)w : 1;
   }
+  charset_finish(cs);
   return cs;
 }
 
