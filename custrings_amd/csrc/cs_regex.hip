@@ -1060,9 +1060,13 @@ __device__ __forceinline__ uint32_t unit_xbits16(const uint4& q, uint32_t xpat) 
 // template, keeps the group ranges of its first two matches, and assembles text pieces and group substrings straight
 // from the staged row -- where the two-pass form ran the groups twice at two waves per SIMD and wrote its output a
 // byte per lane.
-template <bool IN_LDS, bool REP16, bool INPLACE, bool RESCAN = false, bool LONG = false, bool UNITS = false, int PF = cstile::kPfChunks, bool BREFS = false>
+// WIDE: programs of five to eight live threads (counted repetitions): no lean scan, the rows' generic scan with eight start
+// offsets (regex_tdfa.h: TdfaWide) -- on the staged rows, where the two-pass kernels read them from memory a thread per row.
+template <bool IN_LDS, bool REP16, bool INPLACE, bool RESCAN = false, bool LONG = false, bool UNITS = false, int PF = cstile::kPfChunks, bool BREFS = false,
+          bool WIDE = false>
 __global__ void __launch_bounds__(256, BREFS ? 2 : CS_STREAM_WAVES) k_tdfa_replace_stream(StreamArgs a) {
   static_assert(!UNITS || (!INPLACE && RESCAN && !LONG), "the unit scan builds on the register-record assembly");
+  static_assert(!WIDE || (!UNITS && IN_LDS && !BREFS), "the wide form: generic scan only");
   static_assert(!BREFS || (UNITS && IN_LDS && !REP16), "the backrefs form is a unit-scan variant");
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   uint8_t* base = reinterpret_cast<uint8_t*>(smem);
@@ -1578,7 +1582,10 @@ __global__ void __launch_bounds__(256, BREFS ? 2 : CS_STREAM_WAVES) k_tdfa_repla
       if (__any(redo)) {
         // rows the lean scan handed over continue with the generic scan in the round they stopped in
         // (the matches reported so far are final)
-        if (redo) vm.template scan<cstd::Tdfa::K_REPLACE>(a.maxrepl, rec, resume, nm);
+        if (redo) {
+          if (WIDE) vm.template scan<cstd::Tdfa::K_REPLACE, decltype(rec)&, cstd::kMaxSlotsWide>(a.maxrepl, rec, resume, nm);
+          else vm.template scan<cstd::Tdfa::K_REPLACE>(a.maxrepl, rec, resume, nm);
+        }
       }
       if (INPLACE && live) {
         if (pend >= 0) put_repl_at(pend);
@@ -1719,7 +1726,8 @@ __global__ void __launch_bounds__(256, BREFS ? 2 : CS_STREAM_WAVES) k_tdfa_repla
             copied = me;
           };
           cstd::Tdfa vm2(D, P, lds_in + pi, n, pi & 3);
-          vm2.template scan<cstd::Tdfa::K_REPLACE>(a.maxrepl, piece2, 0, 0);
+          if (WIDE) vm2.template scan<cstd::Tdfa::K_REPLACE, decltype(piece2)&, cstd::kMaxSlotsWide>(a.maxrepl, piece2, 0, 0);
+          else vm2.template scan<cstd::Tdfa::K_REPLACE>(a.maxrepl, piece2, 0, 0);
         }
         cstile::lds_copy(lds_out, oi, lds_in, pi + copied, n - copied);
       }
@@ -2480,7 +2488,7 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
     o->rows = col->rows;
     o->validity = col->validity;
     o->null_count = col->null_count;
-    const int minlen = tdfa ? re->tdfa[13] : 0;
+    const int minlen = (tdfa || wide) ? re->tdfa[13] : 0;
     // Single pass when a match cannot be empty: a match is at least `minlen` bytes, so a row grows
     // by at most (rb - minlen) bytes per match; rb <= minlen means "never grows" and the rows are
     // rewritten in place.  A growing replacement is provisioned for kMaxRec matches per row first
@@ -2494,7 +2502,9 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
     const bool empties = minlen == 0 && growth > 0;
     const int minlen_p = std::max(minlen, 1);
     const bool bounded = growth == 0 || minlen >= 1 || rb <= 8;  // (longer ones: the out tile of 1 + rb times the input does not fit the LDS)
-    if (tdfa && bounded && !getenv("CS_REGEX_TWO_PASS")) {
+    // (programs of five to eight threads: the stream kernel's WIDE forms -- tables in LDS, replacements of up to 16 bytes)
+    const bool wide_stream = wide && tp.d.in_lds && rb <= 16 && !cs::g_backrefs_dev && !getenv("CS_WIDE_TWO_PASS");
+    if ((tdfa || wide_stream) && bounded && !getenv("CS_REGEX_TWO_PASS")) {
       const int64_t rows = col->rows;
       const int64_t ntiles = (rows + cstile::kTileRows - 1) / cstile::kTileRows;
       const int64_t nsub = ntiles * 4;
@@ -2586,7 +2596,16 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
         };
         auto kern = growth == 0 ? pick(std::true_type{}, std::false_type{})
                                 : roomy ? pick(std::false_type{}, std::true_type{}) : pick(std::false_type{}, std::false_type{});
-        if (brefs)
+        if (wide_stream) {
+          constexpr int P6 = cstile::kPfChunks;
+          if (rb <= 8) {
+            if (growth == 0) kern = lng ? &k_tdfa_replace_stream<true, false, true, false, true, false, P6, false, true> : &k_tdfa_replace_stream<true, false, true, false, false, false, P6, false, true>;
+            else kern = lng ? &k_tdfa_replace_stream<true, false, false, true, true, false, P6, false, true> : &k_tdfa_replace_stream<true, false, false, true, false, false, P6, false, true>;
+          } else {
+            if (growth == 0) kern = lng ? &k_tdfa_replace_stream<true, true, true, false, true, false, P6, false, true> : &k_tdfa_replace_stream<true, true, true, false, false, false, P6, false, true>;
+            else kern = lng ? &k_tdfa_replace_stream<true, true, false, true, true, false, P6, false, true> : &k_tdfa_replace_stream<true, true, false, true, false, false, P6, false, true>;
+          }
+        } else if (brefs)
           kern = cap <= 5 * 1024 ? &k_tdfa_replace_stream<true, false, false, true, false, true, 5, true> : &k_tdfa_replace_stream<true, false, false, true, false, true, cstile::kPfChunks, true>;
         else if (units && cap <= 5 * 1024)
           kern = rb > 8 ? (tp.d.in_lds ? &k_tdfa_replace_stream<true, true, false, true, false, true, 5> : &k_tdfa_replace_stream<false, true, false, true, false, true, 5>)
@@ -2647,7 +2666,7 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
       // (... where a match is long enough for the row not to outgrow the out tile: a 19-byte replacement of one-digit matches
       // goes to the two-pass kernels at once instead of failing the single pass twice first)
       if (lds <= 150 * 1024 && (rb <= 16 || (rb <= kMaxStreamRepl && rb <= 4 * minlen)) && tc.R && !getenv("CS_TILE_OLD")) {
-        const bool roomy_first = growth > 0 && (minlen <= 2 || getenv("CS_REPLACE_ROOMY"));
+        const bool roomy_first = growth > 0 && (minlen <= 2 || wide_stream || getenv("CS_REPLACE_ROOMY"));
         int err = stream_attempt(roomy_first);
         if (err == 2 && !roomy_first) err = stream_attempt(true);  // only ran out of room: once more, roomier
         if (err == 0) return;
@@ -2656,7 +2675,7 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
           snprintf(what, sizeof(what), "replace_re (error word %d)", err);
           note_fallback(what);
         }
-      } else if (lds <= 150 * 1024 && growth == 0 && (tc.R == 64 || tc.R == 0) && !cs::g_backrefs_dev) {  // (cap is the 64-row capacity then)
+      } else if (lds <= 150 * 1024 && growth == 0 && (tc.R == 64 || tc.R == 0) && !cs::g_backrefs_dev && !wide) {  // (cap is the 64-row capacity then)
         TileArgs ta{};
         ta.in = view_of(col);
         ta.flags = d_unicode_flags();

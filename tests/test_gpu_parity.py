@@ -683,7 +683,8 @@ def test_gpu_findall_extract_from_packed_spans(gpu_engine, oracle_engine, rows, 
 def test_gpu_patterns_with_five_to_eight_threads(gpu_engine, oracle_engine, orc, pat):
     """Counted repetitions keep five to eight threads alive: such programs run the tagged DFA with eight start offsets
     (regex_tdfa.h TdfaWide; cs_regex_engine reports the thread count) in contains_re / match / count_re (tile stream kernel)
-    and replace_re (two-pass), the list simulator elsewhere -- all against the oracle."""
+    and replace_re (the stream kernel's WIDE forms for replacements of up to 16 bytes, two-pass beyond), the list simulator
+    elsewhere -- all against the oracle."""
     import random
 
     from custrings_amd import nvstrings
@@ -699,8 +700,16 @@ def test_gpu_patterns_with_five_to_eight_threads(gpu_engine, oracle_engine, orc,
     assert g.contains_re(s, pat) == o.contains_re(s, pat)
     assert g.match(s, pat) == o.match(s, pat)
     assert g.count_re(s, pat) == o.count_re(s, pat)
-    for repl, n in (("<>", -1), ("", -1), ("#", 2)):
+    from custrings_amd import _lib
+
+    f0 = int(_lib.lib.cs_fallback_count())
+    for repl, n in (("<>", -1), ("", -1), ("#", 2), ("<longer>", -1), ("[thirteen-b.]", -1), ("[thirteen-b.]", 1), ("a-replacement-of-more-than-16-bytes", -1)):
         assert g.replace_re(s, pat, repl, n) == o.replace_re(s, pat, repl, n), (repl, n)
+    # (rows within the 96-byte masks: the stream kernel's WIDE forms without the sliding window)
+    short = [_log_like(rnd, 10, 90) for _ in range(3000)] + ["1.2.3.4", "", None]
+    for repl in ("<>", "<longer>", "[thirteen-b.]"):
+        assert g.replace_re(short, pat, repl, -1) == o.replace_re(short, pat, repl, -1), repl
+    assert int(_lib.lib.cs_fallback_count()) == f0
     assert g.findall(s, pat) == o.findall(s, pat)
     # a C3 window through the persistent grid
     gc, oc = gpuutil.synth(3, 0, 100_000), orc.synth(3, 0, 100_000)
