@@ -308,6 +308,81 @@ __global__ void k_tie_scatter(const int32_t* __restrict__ titem, const int32_t* 
   int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (j < tied) item[where[j]] = titem[j];
 }
+// ---- the order among tied records: rounds of radix sorts on the keys' next seven bytes --------------------------------
+// The compare network over ALL records that share an 8-byte prefix with a neighbour costs log^2 steps of full key
+// compares through the table: URL-like keys (`https://example.com/...`: every key tied) took 0.76 s at one million keys
+// and 18 s at ten million.  Instead the tied records are refined group by group: a round keys every record by its
+// group (records equal so far) and its next seven key bytes (+ how many there were: a key that ends is smaller than its
+// extensions), sorts by (group, chunk) -- two stable radix sorts, chunk then group -- writes the new order into the
+// groups' positions, and keeps only the records that still tie with a neighbour, in finer groups.  A shared prefix of
+// p bytes costs p / 7 rounds over the tied records, each a few passes of 32 bytes per record.
+__global__ void k_tie_groups0(const uint64_t* __restrict__ tprefix, int64_t tied, int32_t* __restrict__ head) {
+  int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (j < tied) head[j] = (j == 0 || tprefix[j] != tprefix[j - 1]) ? 1 : 0;
+}
+__global__ void k_tie_gid(const int32_t* __restrict__ head, const int64_t* __restrict__ hpos, int64_t tied, int32_t* __restrict__ gid) {
+  int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (j < tied) gid[j] = (int32_t)(hpos[j] + head[j] - 1);  // (number of group heads up to and including j) - 1
+}
+__global__ void k_tie_keys(ColView in, const Entry* __restrict__ table, const int32_t* __restrict__ titem, int64_t tied, int depth,
+                           uint64_t* __restrict__ key, int32_t* __restrict__ perm) {
+  int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (j >= tied) return;
+  const Entry e = table[titem[j]];
+  const int64_t b = entry_off(e);
+  const int n = entry_len(e);
+  const int rem = n - depth;
+  const int cnt = rem < 0 ? (rem < -8 ? -8 : rem) : (rem > 7 ? 7 : rem);  // bytes of the key inside this chunk (negative: it ended before)
+  uint64_t k = 0;
+  for (int i = 0; i < 7; ++i) k = (k << 8) | (i < cnt ? in.chars[b + depth + i] : 0);
+  key[j] = (k << 8) | (uint64_t)(cnt + 8);
+  perm[j] = (int32_t)j;
+}
+__global__ void k_tie_group_keys(const int32_t* __restrict__ gid, const int32_t* __restrict__ perm, int64_t tied, uint64_t* __restrict__ gk,
+                                 int32_t* __restrict__ perm2) {
+  int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (j >= tied) return;
+  gk[j] = (uint64_t)(uint32_t)gid[perm[j]];
+  perm2[j] = (int32_t)j;
+}
+// the records in their new order (group-major, chunk-minor), written into the groups' positions of the full sequence
+__global__ void k_tie_apply(const int32_t* __restrict__ titem, const int32_t* __restrict__ gid, const uint64_t* __restrict__ key1,
+                            const int32_t* __restrict__ perm, const int32_t* __restrict__ perm2, const int32_t* __restrict__ where, int64_t tied,
+                            int32_t* __restrict__ titem2, int32_t* __restrict__ gid2, uint64_t* __restrict__ key2, int32_t* __restrict__ item) {
+  int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (j >= tied) return;
+  const int32_t p2 = perm2[j], src = perm[p2];
+  const int32_t it = titem[src];
+  titem2[j] = it;
+  gid2[j] = gid[src];
+  key2[j] = key1[p2];
+  item[where[j]] = it;
+}
+// which records still tie with a neighbour (same group, same chunk), which of them begin a finer group, and whether any
+// of them has key bytes left (chunk count 7: the key goes on)
+__global__ void k_tie_flags2(const int32_t* __restrict__ gid2, const uint64_t* __restrict__ key2, int64_t tied, int32_t* __restrict__ flags,
+                             int32_t* __restrict__ head, int* __restrict__ more) {
+  int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (j >= tied) return;
+  const int32_t g = gid2[j];
+  const uint64_t k = key2[j];
+  const bool prev = j > 0 && gid2[j - 1] == g && key2[j - 1] == k;
+  const bool next = j + 1 < tied && gid2[j + 1] == g && key2[j + 1] == k;
+  const bool t = prev || next;
+  flags[j] = t ? 1 : 0;
+  head[j] = t && !prev ? 1 : 0;
+  if (t && (k & 255u) == 15u) *more = 1;
+}
+__global__ void k_tie_compact(const int32_t* __restrict__ flags, const int64_t* __restrict__ pos, const int32_t* __restrict__ titem2,
+                              const int32_t* __restrict__ where, const int32_t* __restrict__ head, const int64_t* __restrict__ hpos, int64_t tied,
+                              int32_t* __restrict__ titem, int32_t* __restrict__ where_out, int32_t* __restrict__ gid) {
+  int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (j >= tied || !flags[j]) return;
+  const int64_t d = pos[j];
+  titem[d] = titem2[j];
+  where_out[d] = where[j];
+  gid[d] = (int32_t)(hpos[j] + head[j] - 1);
+}
 __global__ void k_cat_ranks(const int32_t* __restrict__ item, int64_t uniq, int shift,
                             int32_t* __restrict__ rank_of_slot) {
   int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -488,9 +563,47 @@ cs_category* cs::category_build(const cs_column* col, hipStream_t s) {
         hipLaunchKernelGGL(k_tie_gather, dim3(blocks_for(std::max(uniq, tpad))), dim3(kBlock), 0, s, ptr<const uint64_t>(prefix), ptr<const int32_t>(item),
                            ptr<const int32_t>(tflags), ptr<const int64_t>(tpos), uniq, tied, tpad, ptr<uint64_t>(tprefix), ptr<int32_t>(titem),
                            ptr<int32_t>(where));
-        bitonic(ptr<uint64_t>(tprefix), ptr<int32_t>(titem), tpad);
-        hipLaunchKernelGGL(k_tie_scatter, dim3(blocks_for(tied)), dim3(kBlock), 0, s, ptr<const int32_t>(titem), ptr<const int32_t>(where), tied,
-                           ptr<int32_t>(item));
+        if (tied <= kSortChunk || getenv("CS_CAT_TIE_NETWORK")) {
+          // (a handful of ties: one launch of the compare network in LDS)
+          bitonic(ptr<uint64_t>(tprefix), ptr<int32_t>(titem), tpad);
+          hipLaunchKernelGGL(k_tie_scatter, dim3(blocks_for(tied)), dim3(kBlock), 0, s, ptr<const int32_t>(titem), ptr<const int32_t>(where), tied,
+                             ptr<int32_t>(item));
+        } else {
+          // rounds on the next seven key bytes (see above)
+          int64_t nt = tied;
+          Buf gid = dev_alloc(sizeof(int32_t) * nt, s), head = dev_alloc(sizeof(int32_t) * nt, s), hpos = dev_alloc(sizeof(int64_t) * (nt + 1), s);
+          hipLaunchKernelGGL(k_tie_groups0, dim3(blocks_for(nt)), dim3(kBlock), 0, s, ptr<const uint64_t>(tprefix), nt, ptr<int32_t>(head));
+          offsets_from_lengths(ptr<int32_t>(head), nt, ptr<int64_t>(hpos), s);
+          hipLaunchKernelGGL(k_tie_gid, dim3(blocks_for(nt)), dim3(kBlock), 0, s, ptr<const int32_t>(head), ptr<const int64_t>(hpos), nt, ptr<int32_t>(gid));
+          Buf key1 = dev_alloc(sizeof(uint64_t) * nt, s), key2 = dev_alloc(sizeof(uint64_t) * nt, s), gk = dev_alloc(sizeof(uint64_t) * nt, s);
+          Buf perm = dev_alloc(sizeof(int32_t) * nt, s), perm2 = dev_alloc(sizeof(int32_t) * nt, s);
+          Buf titem2 = dev_alloc(sizeof(int32_t) * nt, s), gid2 = dev_alloc(sizeof(int32_t) * nt, s), where2 = dev_alloc(sizeof(int32_t) * nt, s);
+          Buf flags2 = dev_alloc(sizeof(int32_t) * nt, s), fpos = dev_alloc(sizeof(int64_t) * (nt + 1), s), more_d = dev_alloc(sizeof(int), s);
+          int32_t* cur_where = ptr<int32_t>(where);
+          int32_t* alt_where = ptr<int32_t>(where2);
+          for (int depth = 8; nt > 0; depth += 7) {
+            const unsigned g = blocks_for(nt);
+            hipLaunchKernelGGL(k_tie_keys, dim3(g), dim3(kBlock), 0, s, in, ptr<const Entry>(table), ptr<const int32_t>(titem), nt, depth, ptr<uint64_t>(key1),
+                               ptr<int32_t>(perm));
+            radix_sort_pairs64(ptr<uint64_t>(key1), ptr<int32_t>(perm), nt, s);
+            hipLaunchKernelGGL(k_tie_group_keys, dim3(g), dim3(kBlock), 0, s, ptr<const int32_t>(gid), ptr<const int32_t>(perm), nt, ptr<uint64_t>(gk),
+                               ptr<int32_t>(perm2));
+            radix_sort_pairs64(ptr<uint64_t>(gk), ptr<int32_t>(perm2), nt, s);
+            hipLaunchKernelGGL(k_tie_apply, dim3(g), dim3(kBlock), 0, s, ptr<const int32_t>(titem), ptr<const int32_t>(gid), ptr<const uint64_t>(key1),
+                               ptr<const int32_t>(perm), ptr<const int32_t>(perm2), cur_where, nt, ptr<int32_t>(titem2), ptr<int32_t>(gid2), ptr<uint64_t>(key2),
+                               ptr<int32_t>(item));
+            CS_HIP(hipMemsetAsync(more_d->p, 0, sizeof(int), s));
+            hipLaunchKernelGGL(k_tie_flags2, dim3(g), dim3(kBlock), 0, s, ptr<const int32_t>(gid2), ptr<const uint64_t>(key2), nt, ptr<int32_t>(flags2),
+                               ptr<int32_t>(head), ptr<int>(more_d));
+            const int64_t left = offsets_from_lengths(ptr<int32_t>(flags2), nt, ptr<int64_t>(fpos), s);
+            if (left == 0 || !read_back<int>(more_d->p, s)) break;  // (what still ties has no bytes left: equal keys, in input order)
+            offsets_from_lengths(ptr<int32_t>(head), nt, ptr<int64_t>(hpos), s);
+            hipLaunchKernelGGL(k_tie_compact, dim3(g), dim3(kBlock), 0, s, ptr<const int32_t>(flags2), ptr<const int64_t>(fpos), ptr<const int32_t>(titem2),
+                               cur_where, ptr<const int32_t>(head), ptr<const int64_t>(hpos), nt, ptr<int32_t>(titem), alt_where, ptr<int32_t>(gid));
+            std::swap(cur_where, alt_where);
+            nt = left;
+          }
+        }
         CS_HIP(hipStreamSynchronize(s));  // (the tie buffers' lifetime)
       }
     }

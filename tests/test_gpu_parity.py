@@ -629,6 +629,33 @@ def test_gpu_long_replacements_on_the_stream_kernel(gpu_engine, oracle_engine, o
 WIDE_PATTERNS = [r"\d{1,3}\.\d{1,3}\.\d{1,3}\.\d{1,3}", r"\w{5}", r"[a-z]{3,8}@", r"[0-9a-f]{8}-[0-9a-f]{4}", r"(a|b|c){6}x", r"\w{5,7} ", r"[ab]{2,6}c|\d{5}"]
 
 
+@pytest.mark.parametrize("kind", ["url", "nested", "nul", "long", "dups"])
+def test_gpu_category_keys_that_share_long_prefixes(gpu_engine, oracle_engine, kind):
+    """Keys that tie on the sort's 8-byte prefix (URL-like columns: every key): the tied records are ordered by rounds of
+    radix sorts on the next seven key bytes, group by group (cs_category.hip) -- keys that are prefixes of other keys,
+    keys with NUL bytes (zero padding must not tie them with their extensions), prefixes far longer than a round, a
+    column with few ties (the compare network in LDS) -- keys and codes against the oracle; sort / order ride on it."""
+    import random
+
+    rnd = random.Random(len(kind))
+    n = 40000
+    if kind == "url":
+        s = ["https://example.com/%s/%d" % (rnd.choice(["a", "api/v1", "static/img"]), rnd.randrange(30000)) for _ in range(n)]
+    elif kind == "nested":  # every key a prefix of the next ones
+        s = ["prefix-prefix-" + "x" * rnd.randrange(60) for _ in range(n)] + ["prefix-prefix-" + "x" * i + "y" for i in range(40)]
+    elif kind == "nul":
+        alphabet = ["a", "b", "\0", "\0\0", "ab", ""]
+        s = ["".join(rnd.choice(alphabet) for _ in range(rnd.randrange(14))) for _ in range(n)]
+    elif kind == "long":
+        s = ["z" * 200 + "%05d" % rnd.randrange(20000) + "q" * rnd.randrange(3) for _ in range(n)]
+    else:  # few ties
+        s = ["%08x" % rnd.randrange(1 << 30) for _ in range(n)] + ["samesame-%d" % (i % 50) for i in range(500)]
+    s[17] = None
+    s[18] = ""
+    o, g = oracle_engine, gpu_engine
+    assert g.category(s) == o.category(s)
+
+
 @pytest.mark.parametrize("pat,repl", [("x*", "-"), ("a*", "<>"), ("\\d*", "#"), ("[a-c]*", "."), ("b*|c", "_"), ("\\b", "|"), ("$", "!"), ("^", ">"),
                                       ("x*", "<IP>"), ("\\d*", "<number>")])
 def test_gpu_patterns_that_match_the_empty_string_on_the_stream_kernel(gpu_engine, oracle_engine, pat, repl):
