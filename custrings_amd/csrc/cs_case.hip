@@ -87,7 +87,49 @@ __global__ void __launch_bounds__(256) k_case_tile(CaseTileArgs a) {
     const int rbeg = (int)(cur.o0 - g0);
     const int n = live ? (int)(cur.o1 - cur.o0) : 0;
     const int lead = (int)((uintptr_t)(in.chars + g0) & 15);
-    const int want = (int)(g1 - g0) + lead;
+    const long long want64 = g1 - g0 + lead;
+    if (want64 + 16 > a.cap) {
+      // A tile beyond the staging buffer (the host sized it for all but a few tiles: one long row among millions of
+      // short ones): its rows are mapped a thread each, straight from memory, as the row-wise kernels do.
+      // (first the whole span with the wave, sixteen bytes a lane: an ASCII tile -- the usual case, and a long row would
+      // otherwise keep ONE lane busy for milliseconds -- is done after that; only a tile with other bytes goes row by row)
+      bool high = false;
+      {
+        const uint8_t* src = in.chars + (g0 - lead);
+        uint8_t* dst = a.out_chars + (g0 - lead);
+        for (long long i = (long long)lane * 16; i < want64; i += 64 * 16) {
+          const uint4 q = *reinterpret_cast<const uint4*>(src + i);
+          high |= ((q.x | q.y | q.z | q.w) & 0x80808080u) != 0;
+          uint4 o;
+          o.x = flip_ascii(q.x, a.bit);
+          o.y = flip_ascii(q.y, a.bit);
+          o.z = flip_ascii(q.z, a.bit);
+          o.w = flip_ascii(q.w, a.bit);
+          const long long lo = lead - i, hi = want64 - i;  // the span's bytes inside this piece: [lo, hi)
+          if (lo <= 0 && hi >= 16) {
+            *reinterpret_cast<uint4*>(dst + i) = o;
+          } else {
+            const uint32_t w[4] = {o.x, o.y, o.z, o.w};
+            for (int k = (int)(lo > 0 ? lo : 0); k < (int)(hi < 16 ? hi : 16); ++k) dst[i + k] = (uint8_t)(w[k >> 2] >> (8 * (k & 3)));
+          }
+        }
+      }
+      if (__any(high) && n > 0) {
+        const uint8_t* p = in.chars + (g0 + rbeg);
+        if (row_case_size(p, n, a.flags, a.cases, a.bit) != n) atomicOr(a.changed, 1u);
+        else row_case_write(p, n, a.flags, a.cases, a.bit, a.out_chars + (g0 + rbeg));
+      }
+      const bool more = tile + 1 < tile_end;
+      if (more) {
+        cur = nxt;
+        cstile::issue_chars(in.chars, cstile::rl64(cur.o0, 0), cstile::rl64(cur.o1, 63), lane, pf);
+        if (tile + 2 < tile_end) nxt = load_offs(tile + 2);
+      }
+      if (!more) break;
+      ++tile;
+      continue;
+    }
+    const int want = (int)want64;
     // pieces: keep the input in LDS for the row lanes, ASCII-flipped copy in the output tile,
     // one "byte >= 0x80" bit per byte in the bitmap
     uint32_t any_high = 0;
@@ -190,8 +232,13 @@ bool change_case_fast(const cs_column* col, unsigned bit, bool ascii_rule_ok, hi
       break;
     }
   }
+  int64_t span = R ? max_span_rows(col, R, s) : 0;
+  if (!R && few_spans64_over(col, cstile::kPfBytes - 64, s) && !getenv("CS_NO_OUTLIER_TILES")) {
+    // all but a few 64-row tiles fit: the kernel maps the rows of the others a thread each
+    R = 64;
+    span = cstile::kPfBytes - 64;
+  }
   if (!R) return false;
-  const int64_t span = max_span_rows(col, R, s);
   CaseTileArgs a{};
   a.in = view_of(col);
   a.rows_per_tile = R;

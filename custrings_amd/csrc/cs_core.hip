@@ -599,6 +599,38 @@ int64_t max_span_rows(const cs_column* c, int per, hipStream_t s) {
   CS_HIP(hipStreamSynchronize(s));
   return host[0];
 }
+// How many 64-row tiles span more than `limit` bytes: a column whose LARGEST tile does not fit a tile kernel's staging
+// buffer may still have all but a few that do (one long row among millions of short ones) -- the tile kernels then take
+// the column and handle the oversize tiles a thread per row themselves, instead of the whole column going row-wise.
+__global__ void k_count_spans_over(const int64_t* __restrict__ offsets, int64_t rows, int64_t limit, unsigned long long* __restrict__ out) {
+  const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int64_t r0 = t * 64;
+  int v = 0;
+  if (r0 < rows) {
+    const int64_t r1 = r0 + 64 < rows ? r0 + 64 : rows;
+    v = offsets[r1] - offsets[r0] > limit ? 1 : 0;
+  }
+  const long long n = block_reduce_sum(v);
+  if (threadIdx.x == 0 && n) atomicAdd(out, (unsigned long long)n);
+}
+int64_t count_spans64_over(const cs_column* c, int64_t limit, hipStream_t s) {
+  if (c->rows == 0) return 0;
+  if (max_span64(c, s) <= limit) return 0;
+  Buf acc = dev_alloc(8, s);
+  CS_HIP(hipMemsetAsync(acc->p, 0, 8, s));
+  const int64_t nsub = (c->rows + 63) / 64;
+  hipLaunchKernelGGL(k_count_spans_over, dim3(blocks_for(nsub)), dim3(kBlock), 0, s, c->d_offsets(), c->rows, limit, ptr<unsigned long long>(acc));
+  int64_t* host = (int64_t*)pinned_scratch(8);
+  CS_HIP(hipMemcpyAsync(host, acc->p, 8, hipMemcpyDeviceToHost, s));
+  CS_HIP(hipStreamSynchronize(s));
+  return host[0];
+}
+// true when all but a few (at most 8, or one in a thousand) of the 64-row tiles span at most `limit` bytes
+bool few_spans64_over(const cs_column* c, int64_t limit, hipStream_t s) {
+  const int64_t nsub = (c->rows + 63) / 64;
+  const int64_t over = count_spans64_over(c, limit, s);
+  return over <= std::max<int64_t>(8, nsub / 1000);
+}
 int64_t max_row_bytes(const cs_column* c, hipStream_t s) {
   if (c->max_row >= 0) return c->max_row;
   return c->max_row = max_span_rows(c, 1, s);

@@ -156,6 +156,8 @@ int64_t max_row_bytes(const cs_column* c, hipStream_t s);
 bool bytes_plain(const cs_column* c, hipStream_t s);
 // Same for tiles of `per` consecutive rows (per = 64 is the cached one).
 int64_t max_span_rows(const cs_column* c, int per, hipStream_t s);
+int64_t count_spans64_over(const cs_column* c, int64_t limit, hipStream_t s);
+bool few_spans64_over(const cs_column* c, int64_t limit, hipStream_t s);  // all but a few 64-row tiles fit `limit` bytes
 // Workgroups (256 threads, `lds` dynamic bytes) of `kern` resident at once on the device,
 // capped by `wanted`: grid size of the persistent tile kernels.
 unsigned resident_grid(const void* kern, size_t lds, int64_t wanted);

@@ -946,6 +946,7 @@ struct StreamArgs {
   long long nsub;
   int cap_in, cap_out, tbl_bytes;
   int debug;
+  int outliers;  // the buffers are sized for all but a few sub-tiles: an oversize one is handled a thread per row in the kernel
   long long out_cap;  // bytes provisioned at out_chars (growing replacements)
   int rows_per_tile;  // LONG variants: 64, 32 or 16
   unsigned long long* tickets;  // 8 tile counters, 64 bytes apart, zeroed before the launch
@@ -1062,9 +1063,13 @@ __device__ __forceinline__ uint32_t unit_xbits16(const uint4& q, uint32_t xpat) 
 // byte per lane.
 // WIDE: programs of five to eight live threads (counted repetitions): no lean scan, the rows' generic scan with eight start
 // offsets (regex_tdfa.h: TdfaWide) -- on the staged rows, where the two-pass kernels read them from memory a thread per row.
+// OUTL: the buffers are sized for all but a few sub-tiles (one long row among millions of short ones); an oversize
+// sub-tile's rows are sized and written a thread each, straight from memory, inside the prefix chain (separate forms:
+// the code costs the others registers).
 template <bool IN_LDS, bool REP16, bool INPLACE, bool RESCAN = false, bool LONG = false, bool UNITS = false, int PF = cstile::kPfChunks, bool BREFS = false,
-          bool WIDE = false>
+          bool WIDE = false, bool OUTL = false>
 __global__ void __launch_bounds__(256, BREFS ? 2 : CS_STREAM_WAVES) k_tdfa_replace_stream(StreamArgs a) {
+  static_assert(!OUTL || (IN_LDS && !LONG && !UNITS && !BREFS && !WIDE), "oversize sub-tiles: the plain forms only");
   static_assert(!UNITS || (!INPLACE && RESCAN && !LONG), "the unit scan builds on the register-record assembly");
   static_assert(!WIDE || (!UNITS && IN_LDS && !BREFS), "the wide form: generic scan only");
   static_assert(!BREFS || (UNITS && IN_LDS && !REP16), "the backrefs form is a unit-scan variant");
@@ -1208,6 +1213,10 @@ __global__ void __launch_bounds__(256, BREFS ? 2 : CS_STREAM_WAVES) k_tdfa_repla
     const int lead = (int)((uintptr_t)(in.chars + g0) & 15);
     const long long want = g1 - g0 + lead;
     bool bad = want + 16 > a.cap_in || want > PF * 1024;
+    // A sub-tile beyond the staging buffer.  The host sizes the buffers for all but a few sub-tiles when the column's
+    // largest does not fit (one long row among millions of short ones): such a sub-tile's rows are sized and written a
+    // thread each, straight from memory -- inside the prefix chain -- instead of the whole column leaving the single pass.
+    const bool oversize = OUTL && bad && a.outliers;
     if (!bad) cstile::stage_chars(lds_in, (int)want, lane, pf);
     CS_PHASE_MARK(9);   // (wait for the prefetched chars + the LDS writes)
     // bytes that the lean scan does not take (non-ASCII, NUL) anywhere in the staged span, and one
@@ -1275,6 +1284,14 @@ __global__ void __launch_bounds__(256, BREFS ? 2 : CS_STREAM_WAVES) k_tdfa_repla
     bool from_masks = false;
     int mslot = 0;  // BREFS: where the row's matches stand in the match queue / record table
     if (live && !bad) out_len = n;
+    if (oversize && live) {  // the row's output size by the generic scan on the row in memory
+      cstd::Tdfa vg(D, P, in.chars + (g0 + rbeg), n);
+      int len = n;
+      auto add = [&](int mb, int me, int reps) { len += reps * rb - (me - mb); };
+      if (WIDE) vg.template scan<cstd::Tdfa::K_REPLACE, decltype(add)&, cstd::kMaxSlotsWide>(a.maxrepl, add, 0, 0);
+      else vg.template scan<cstd::Tdfa::K_REPLACE>(a.maxrepl, add, 0, 0);
+      out_len = len;
+    }
     if (!bad && !(a.debug & 1)) {
       cstd::Tdfa vm(D, P, lds_in + lead + rbeg, n, (lead + rbeg) & 3);
       const int pi = lead + rbeg;          // byte index of the row in lds_in
@@ -1604,7 +1621,39 @@ __global__ void __launch_bounds__(256, BREFS ? 2 : CS_STREAM_WAVES) k_tdfa_repla
     if (!INPLACE) grew = !bad && (total + 32 > a.cap_out || (!RESCAN && __any(nm > kMaxRec)));
     bad |= total + 32 > a.cap_out;
     if (!INPLACE) bad |= grew;
-    if (bad) {
+    if (oversize) {
+      cstile::lookback_publish(a.status, tile, total, lane);
+      if (p_tile >= 0) finish_pending(p_first);
+      p_tile = -1;
+      // this sub-tile is finished at once: its prefix, the offsets, every row written by its lane
+      long long gb = scanner ? cstile::prefix_wait(a.excl, tile, cstile::status_load(a.excl + tile), a.error, lane)
+                             : cstile::lookback_end(a.status, tile, total, cstile::lookback_poll(a.status, tile, lane), lane);
+      if (gb < 0) {
+        if (lane == 0) atomicOr(a.error, 1u | 8u);
+        gb = 0;
+      }
+      if (lane < nrows) a.out_off[r0 + lane] = gb + lo;
+      if (lane == nrows - 1 && r0 + nrows == in.rows) a.out_off[in.rows] = gb + lo + out_len;
+      if (gb + total > a.out_cap) {
+        if (lane == 0) atomicOr(a.error, 2u);
+        return;
+      }
+      if (live) {
+        const uint8_t* p = in.chars + (g0 + rbeg);
+        uint8_t* o = a.out_chars + gb + lo;
+        int copied = 0;
+        auto piece = [&](int mb, int me, int reps) {
+          for (int i = copied; i < mb; ++i) *o++ = p[i];
+          for (int k = 0; k < reps; ++k)
+            for (int i = 0; i < rb; ++i) *o++ = a.repl[i];
+          copied = me;
+        };
+        cstd::Tdfa vg(D, P, p, n);
+        if (WIDE) vg.template scan<cstd::Tdfa::K_REPLACE, decltype(piece)&, cstd::kMaxSlotsWide>(a.maxrepl, piece, 0, 0);
+        else vg.template scan<cstd::Tdfa::K_REPLACE>(a.maxrepl, piece, 0, 0);
+        for (int i = copied; i < n; ++i) *o++ = p[i];
+      }
+    } else if (bad) {
       // the host discards this launch's output; publish something so successors do not spin
       if (lane == 0) {
         atomicOr(a.error, !INPLACE && grew ? 2u : (1u | 4u));  // (4: a sub-tile beyond the staging capacity)
@@ -2508,7 +2557,15 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
       const int64_t rows = col->rows;
       const int64_t ntiles = (rows + cstile::kTileRows - 1) / cstile::kTileRows;
       const int64_t nsub = ntiles * 4;
-      const TileChoice tc = choose_tile(col, s);
+      TileChoice tc = choose_tile(col, s);
+      // (the column's largest 64-row span does not fit, all but a few do: buffers for those, the kernel handles the rest)
+      bool outliers = false;
+      constexpr int64_t kOutlierSpan = cstile::kPfBytes - 176;  // (its capacity is kPfBytes)
+      if (!tc.R && tdfa && tp.d.in_lds && rb <= 16 && !cs::g_backrefs_dev && !getenv("CS_NO_OUTLIER_TILES") && max_span64(col, s) <= (16 << 20) &&
+          few_spans64_over(col, kOutlierSpan, s)) {
+        tc = TileChoice{64, (int)((kOutlierSpan + 15 + 32 + 127) & ~(int64_t)127), false};
+        outliers = true;
+      }
       const int cap = tc.cap;
       const size_t tbl = tp.d.in_lds ? tp.lds_bytes : 0;
       size_t lds = tbl + (size_t)(cap + cap + 64 + (cap >> 3) + 32) * 4 + 16;
@@ -2538,8 +2595,8 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
         if (brefs && !((re->tdfa[31] & 1) != 0 && !tc.lng && tc.R == 64 && tp.d.in_lds && !re->gtags.empty() && re->prog.num_groups <= cstd::Tdfa::kGroupBatch &&
                        re->gtags.size() * 4 <= 8 * 1024))
           return -1;
-        const bool literal = !brefs && cs::g_replace_plain_only && cs::g_replace_literal_len > 0 && maxrepl < 0 && !tc.lng && tc.R == 64 && !getenv("CS_NO_LITERAL_SCAN");
-        const bool units = literal || brefs || ((re->tdfa[31] & 1) != 0 && maxrepl < 0 && !tc.lng && tc.R == 64 && !cs::g_replace_plain_only && !getenv("CS_NO_UNITS"));
+        const bool literal = !brefs && !outliers && cs::g_replace_plain_only && cs::g_replace_literal_len > 0 && maxrepl < 0 && !tc.lng && tc.R == 64 && !getenv("CS_NO_LITERAL_SCAN");
+        const bool units = literal || brefs || ((re->tdfa[31] & 1) != 0 && maxrepl < 0 && !tc.lng && tc.R == 64 && !outliers && !cs::g_replace_plain_only && !getenv("CS_NO_UNITS"));
         const size_t unit_bytes = units ? (size_t)((cap >> 3) + 32 + kUnitQueue * 4 + 16 + (cs::g_backrefs_dev ? kUnitQueue * 12 + 64 * 4 : 0)) : 0;
         // (backrefs: the group tags and the template text sit behind the DFA table; the template may grow a row by any
         // amount: room for twice the input, a launch that needs more says so and the two-pass form takes over)
@@ -2582,6 +2639,7 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
         sa.gt_off = (int)tbl;
         sa.gt_words = brefs ? (int)re->gtags.size() : 0;
         sa.debug = getenv("CS_TILE_DEBUG") ? atoi(getenv("CS_TILE_DEBUG")) : 0;
+        sa.outliers = outliers ? 1 : 0;
         sa.lit = literal ? cs::g_replace_literal : 0;
         sa.litn = literal ? cs::g_replace_literal_len : 0;
         auto pick2 = [&](auto inplace, auto rescan, auto lng) {
@@ -2596,7 +2654,13 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
         };
         auto kern = growth == 0 ? pick(std::true_type{}, std::false_type{})
                                 : roomy ? pick(std::false_type{}, std::true_type{}) : pick(std::false_type{}, std::false_type{});
-        if (wide_stream) {
+        if (outliers) {  // (the forms that handle oversize sub-tiles: in place, or with the rescan assembly)
+          constexpr int P6 = cstile::kPfChunks;
+          if (growth == 0) kern = rb > 8 ? &k_tdfa_replace_stream<true, true, true, false, false, false, P6, false, false, true>
+                                         : &k_tdfa_replace_stream<true, false, true, false, false, false, P6, false, false, true>;
+          else kern = rb > 8 ? &k_tdfa_replace_stream<true, true, false, true, false, false, P6, false, false, true>
+                             : &k_tdfa_replace_stream<true, false, false, true, false, false, P6, false, false, true>;
+        } else if (wide_stream) {
           constexpr int P6 = cstile::kPfChunks;
           if (rb <= 8) {
             if (growth == 0) kern = lng ? &k_tdfa_replace_stream<true, false, true, false, true, false, P6, false, true> : &k_tdfa_replace_stream<true, false, true, false, false, false, P6, false, true>;
@@ -2666,7 +2730,7 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
       // (... where a match is long enough for the row not to outgrow the out tile: a 19-byte replacement of one-digit matches
       // goes to the two-pass kernels at once instead of failing the single pass twice first)
       if (lds <= 150 * 1024 && (rb <= 16 || (rb <= kMaxStreamRepl && rb <= 4 * minlen)) && tc.R && !getenv("CS_TILE_OLD")) {
-        const bool roomy_first = growth > 0 && (minlen <= 2 || wide_stream || getenv("CS_REPLACE_ROOMY"));
+        const bool roomy_first = growth > 0 && (minlen <= 2 || wide_stream || outliers || getenv("CS_REPLACE_ROOMY"));
         int err = stream_attempt(roomy_first);
         if (err == 2 && !roomy_first) err = stream_attempt(true);  // only ran out of room: once more, roomier
         if (err == 0) return;

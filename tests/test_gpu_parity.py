@@ -629,6 +629,37 @@ def test_gpu_long_replacements_on_the_stream_kernel(gpu_engine, oracle_engine, o
 WIDE_PATTERNS = [r"\d{1,3}\.\d{1,3}\.\d{1,3}\.\d{1,3}", r"\w{5}", r"[a-z]{3,8}@", r"[0-9a-f]{8}-[0-9a-f]{4}", r"(a|b|c){6}x", r"\w{5,7} ", r"[ab]{2,6}c|\d{5}"]
 
 
+def _with_outliers(rnd, rows=6000):
+    """short log-like rows with a few very long ones among them (one ASCII, one with two-byte characters, one at the end)"""
+    s = [_log_like(rnd, 20, 90) for _ in range(rows)]
+    s[rows // 3] = ("GET /Index.HTML 10.1.2.3 Mixed CASE words " * 3000)[:100_000]
+    s[rows // 2] = ("Ünïcödé ÀÉÎ straße 192.168.0.1 " * 400)
+    s[rows // 2 + 1] = None
+    s[-1] = "tail row 8.8.8.8 " * 700
+    return s
+
+
+def test_gpu_one_long_row_among_short_ones_stays_on_the_tile_kernels(gpu_engine, oracle_engine):
+    """A column whose largest 64-row tile does not fit the staging buffer because of a FEW long rows: the tile kernels
+    take it and handle the oversize tiles a thread per row themselves (cs_internal.h: few_spans64_over) -- lower / upper
+    against the oracle."""
+    import random
+
+    from custrings_amd import _lib
+
+    s = _with_outliers(random.Random(5))
+    o, g = oracle_engine, gpu_engine
+    assert g.lower(s) == o.lower(s)
+    assert g.upper(s) == o.upper(s)
+    # replace_re: the stream kernel sizes and writes an oversize sub-tile's rows a thread each, inside the prefix chain
+    f0 = int(_lib.lib.cs_fallback_count())
+    for pat, repl, n in ((IPV4, "<IP>", -1), (IPV4, "", -1), (IPV4, "[a longer replacement]", -1), (r"\d+", "#", 2), (r"[A-Z]+", "x", -1), (r"x*", "-", -1),
+                         (r"\d{1,3}\.\d{1,3}\.\d{1,3}\.\d{1,3}", "<IP>", -1)):
+        assert g.replace_re(s, pat, repl, n) == o.replace_re(s, pat, repl, n), (pat, repl, n)
+    assert g.replace(s, "GET", "PUT") == o.replace(s, "GET", "PUT")
+    assert int(_lib.lib.cs_fallback_count()) == f0
+
+
 @pytest.mark.parametrize("kind", ["url", "nested", "nul", "long", "dups"])
 def test_gpu_category_keys_that_share_long_prefixes(gpu_engine, oracle_engine, kind):
     """Keys that tie on the sort's 8-byte prefix (URL-like columns: every key): the tied records are ordered by rounds of
