@@ -77,7 +77,8 @@ __device__ __forceinline__ uint32_t byte_of(const uint4& q, int b) {
   return (w >> (8 * (b & 3))) & 255u;
 }
 
-template <int PASS>
+// SEGS: some tiles span more than the staging size (the host found no tile size that fits every tile)
+template <int PASS, bool SEGS>
 __global__ void __launch_bounds__(256) k_tok_tile(TokTileArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;  // (scalar: what derives from it stays in SGPRs)
@@ -120,102 +121,126 @@ __global__ void __launch_bounds__(256) k_tok_tile(TokTileArgs a) {
     const int rbeg = (int)(cur.o0 - g0);
     const int n = live ? (int)(cur.o1 - cur.o0) : 0;
     const int lead = (int)((uintptr_t)(in.chars + g0) & 15);
-    const int want = (int)(g1 - g0) + lead;
-    // take this tile's pieces out of the prefetch registers, then refill them
-    cstile::TileChars q = pf;
+    const long long want64 = g1 - g0 + lead;
+    // A tile is taken in SEGMENTS of at most kPfBytes staged bytes: one for the tiles the host sized the kernel for (out of
+    // the prefetch registers); a tile beyond that -- a long row among short ones -- is walked segment by segment straight
+    // from memory, the keep / row-start state and the running totals carried across (all of it is wave-uniform), so a
+    // single long row is still tokenized by the whole wave, sixteen bytes a lane.
+    constexpr int kSeg = cstile::kPfChunks * 1024;
+    const int nseg = SEGS ? (int)((want64 + kSeg - 1) / kSeg) : 1;
+    const cstile::TileChars q0 = pf;
     const bool has_next = tile + 1 < tile_end;
     if (has_next) {
       cur = nxt;
       cstile::issue_chars(in.chars, cstile::rl64(cur.o0, 0), cstile::rl64(cur.o1, 63), lane, pf);
       if (tile + 2 < tile_end) nxt = load_offs(tile + 2);
     }
-    // row-start bitmap: one bit per byte of the staged span, set by the row lanes
-    for (int i = lane * 16; i < kBitmapBytes; i += 64 * 16) *reinterpret_cast<uint4*>(base + i) = make_uint4(0, 0, 0, 0);
-    cstile::wave_lds_fence();
-    if (n > 0) {
-      const int p = lead + rbeg;
-      __hip_atomic_fetch_or(bitmap + (p >> 5), 1u << (p & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-    }
-    cstile::wave_lds_fence();
-
-    int carry_bytes = 0, carry_tokens = 0;  // totals of the pieces before this chunk row (wave-uniform)
-    uint32_t carry_keep = 0;                // was the last byte of the previous chunk row kept?
-    uint32_t carry_expect = 0;              // continuation bytes announced into the next chunk row (set mode check)
+    long long tile_b = 0, tile_t = 0;  // kept bytes / tokens of the segments before this one
+    uint32_t carry_keep = 0;           // was the last byte of the previous chunk row kept?
+    uint32_t carry_expect = 0;         // continuation bytes announced into the next chunk row (set mode check)
+    for (int seg = 0; seg < (nseg > 0 ? nseg : 1); ++seg) {
+      const long long seg_lo = (long long)seg * kSeg;
+      const int want = (int)(want64 - seg_lo < kSeg ? want64 - seg_lo : kSeg);  // staged bytes of this segment
+      const int lead_s = seg == 0 ? lead : 0;
+      cstile::TileChars q = q0;
+      if (SEGS && nseg > 1) {  // (wave-uniform) an oversize tile: this segment's pieces from memory
+        const uint8_t* src = in.chars + (g0 - lead) + seg_lo;
 #pragma unroll
-    for (int j = 0; j < cstile::kPfChunks; ++j) {
-      if (j * 1024 < want) {  // wave-uniform
-        const int i = j * 1024 + lane * 16;
-        const int lo = min(16, max(0, lead - i)), hi = min(16, max(0, want - i));
-        const uint32_t valid = ((1u << hi) - 1u) & ~((1u << lo) - 1u);
-        const uint32_t keep = keep16_of(q.v[j], a) & valid;
-        const uint32_t rs = (bitmap[i >> 5] >> (i & 31)) & 0xFFFFu;
-        // keep bit of the byte before this piece: lane - 1's bit 15 (lane 0: previous chunk row)
-        uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(keep >> 15), 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
-        if (lane == 0) prev = carry_keep;
-        const uint32_t before = ((keep << 1) | prev) & 0xFFFFu;  // bit b = byte b - 1 was kept
-        const uint32_t starts = keep & (rs | ~before) & 0xFFFFu;
-        if (PASS == 0 && a.ndel > 0) {
-          // Delimiter SETS are matched per character by the row-wise routine (row_ops.h), which
-          // swallows the bytes a lead byte announces; that equals this per-byte classification only
-          // on well-formed UTF-8.  Check it: the continuation bytes must sit exactly where the lead
-          // bytes announce them, inside the lead's own row and inside the tile.
-          const uint32_t high = bit16_of(q.v[j], 7) & valid;
-          uint32_t cont = 0, expect = 0;
-          if (__any(high != 0)) {
-            const uint32_t b6 = bit16_of(q.v[j], 6), b5 = bit16_of(q.v[j], 5), b4 = bit16_of(q.v[j], 4);
-            const uint32_t lead2 = high & b6, lead3 = lead2 & b5, lead4 = lead3 & b4;
-            cont = high & ~b6;
-            expect = (lead2 << 1) | (lead3 << 2) | (lead4 << 3);  // bits 16..18 fall into the next piece
-          }
-          uint32_t carry = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(expect >> 16), 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
-          if (lane == 0) carry = carry_expect;
-          const uint32_t announced = (expect & 0xFFFFu) | carry;
-          malformed |= (announced & valid) != cont || (announced & rs) != 0 || (announced & ~valid & 0xFFFFu) != 0;
-          carry_expect = (uint32_t)__builtin_amdgcn_readlane((int)(expect >> 16), 63);
+        for (int j = 0; j < cstile::kPfChunks; ++j) {
+          const int i = j * 1024 + lane * 16;
+          q.v[j] = i < want ? *reinterpret_cast<const uint4*>(src + i) : make_uint4(0, 0, 0, 0);
         }
-        const int nk = __builtin_popcount(keep), nt = __builtin_popcount(starts);
-        const int packed = nk | (nt << 16);
-        const int incl = wave_inclusive_scan(packed);
-        const int tot = __builtin_amdgcn_readlane(incl, 63);
-        if (PASS == 1) {
-          const int excl = incl - packed;
-          const int kbase = carry_bytes + (excl & 0xFFFF);
-          const int tbase = carry_tokens + (excl >> 16);
-          // compaction: kept byte b of the piece lands at kbase + (kept bytes below b)
+      }
+      // row-start bitmap: one bit per byte of the staged segment, set by the row lanes
+      for (int i = lane * 16; i < kBitmapBytes; i += 64 * 16) *reinterpret_cast<uint4*>(base + i) = make_uint4(0, 0, 0, 0);
+      cstile::wave_lds_fence();
+      if (n > 0) {
+        const long long p = (long long)lead + rbeg - seg_lo;
+        if (p >= 0 && p < want) __hip_atomic_fetch_or(bitmap + (p >> 5), 1u << (p & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      }
+      cstile::wave_lds_fence();
+
+      int carry_bytes = 0, carry_tokens = 0;  // totals of the pieces before this chunk row (wave-uniform)
 #pragma unroll
-          for (int b = 0; b < 16; ++b)
-            if ((keep >> b) & 1u) lds_out[kbase + __builtin_popcount(keep & ((1u << b) - 1u))] = (uint8_t)byte_of(q.v[j], b);
-          // token starts: tile-relative position of each, in token order
-          uint32_t s = starts;
-          int t = tbase;
-          while (__any(s != 0)) {
-            if (s != 0) {
-              const int b = __builtin_ctz(s);
-              s &= s - 1;
-              lds_tok[t++] = (uint16_t)(kbase + __builtin_popcount(keep & ((1u << b) - 1u)));
+      for (int j = 0; j < cstile::kPfChunks; ++j) {
+        if (j * 1024 < want) {  // wave-uniform
+          const int i = j * 1024 + lane * 16;
+          const int lo = min(16, max(0, lead_s - i)), hi = min(16, max(0, want - i));
+          const uint32_t valid = ((1u << hi) - 1u) & ~((1u << lo) - 1u);
+          const uint32_t keep = keep16_of(q.v[j], a) & valid;
+          const uint32_t rs = (bitmap[i >> 5] >> (i & 31)) & 0xFFFFu;
+          // keep bit of the byte before this piece: lane - 1's bit 15 (lane 0: previous chunk row)
+          uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(keep >> 15), 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
+          if (lane == 0) prev = carry_keep;
+          const uint32_t before = ((keep << 1) | prev) & 0xFFFFu;  // bit b = byte b - 1 was kept
+          const uint32_t starts = keep & (rs | ~before) & 0xFFFFu;
+          if (PASS == 0 && a.ndel > 0) {
+            // Delimiter SETS are matched per character by the row-wise routine (row_ops.h), which
+            // swallows the bytes a lead byte announces; that equals this per-byte classification only
+            // on well-formed UTF-8.  Check it: the continuation bytes must sit exactly where the lead
+            // bytes announce them, inside the lead's own row and inside the tile.
+            const uint32_t high = bit16_of(q.v[j], 7) & valid;
+            uint32_t cont = 0, expect = 0;
+            if (__any(high != 0)) {
+              const uint32_t b6 = bit16_of(q.v[j], 6), b5 = bit16_of(q.v[j], 5), b4 = bit16_of(q.v[j], 4);
+              const uint32_t lead2 = high & b6, lead3 = lead2 & b5, lead4 = lead3 & b4;
+              cont = high & ~b6;
+              expect = (lead2 << 1) | (lead3 << 2) | (lead4 << 3);  // bits 16..18 fall into the next piece
+            }
+            uint32_t carry = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(expect >> 16), 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
+            if (lane == 0) carry = carry_expect;
+            const uint32_t announced = (expect & 0xFFFFu) | carry;
+            malformed |= (announced & valid) != cont || (announced & rs) != 0 || (announced & ~valid & 0xFFFFu) != 0;
+            carry_expect = (uint32_t)__builtin_amdgcn_readlane((int)(expect >> 16), 63);
+          }
+          const int nk = __builtin_popcount(keep), nt = __builtin_popcount(starts);
+          const int packed = nk | (nt << 16);
+          const int incl = wave_inclusive_scan(packed);
+          const int tot = __builtin_amdgcn_readlane(incl, 63);
+          if (PASS == 1) {
+            const int excl = incl - packed;
+            const int kbase = carry_bytes + (excl & 0xFFFF);
+            const int tbase = carry_tokens + (excl >> 16);
+            // compaction: kept byte b of the piece lands at kbase + (kept bytes below b)
+#pragma unroll
+            for (int b = 0; b < 16; ++b)
+              if ((keep >> b) & 1u) lds_out[kbase + __builtin_popcount(keep & ((1u << b) - 1u))] = (uint8_t)byte_of(q.v[j], b);
+            // token starts: segment-relative position of each, in token order
+            uint32_t st = starts;
+            int t = tbase;
+            while (__any(st != 0)) {
+              if (st != 0) {
+                const int b = __builtin_ctz(st);
+                st &= st - 1;
+                lds_tok[t++] = (uint16_t)(kbase + __builtin_popcount(keep & ((1u << b) - 1u)));
+              }
             }
           }
+          carry_bytes += tot & 0xFFFF;
+          carry_tokens += tot >> 16;
+          carry_keep = (uint32_t)__builtin_amdgcn_readlane((int)(keep >> 15), 63);
         }
-        carry_bytes += tot & 0xFFFF;
-        carry_tokens += tot >> 16;
-        carry_keep = (uint32_t)__builtin_amdgcn_readlane((int)(keep >> 15), 63);
       }
+      if (PASS == 0) {
+        most_bytes = max(most_bytes, carry_bytes);  // (per SEGMENT: what pass 1's LDS regions must hold)
+        most_tokens = max(most_tokens, carry_tokens);
+      } else {
+        cstile::wave_lds_fence();
+        const long long cb = a.byte_base[tile] + tile_b, tb = a.tok_base[tile] + tile_t;
+        cstile::wave_flush_shift(a.out_chars + cb, carry_bytes, lds_out, lane);
+        cstile::gptr<int64_t> oo = cstile::as_global(a.out_off + tb);
+        for (int t = lane; t < carry_tokens; t += 64) oo[t] = cb + lds_tok[t];
+        cstile::wave_lds_fence();  // the next segment / tile reuses the regions
+      }
+      tile_b += carry_bytes;
+      tile_t += carry_tokens;
     }
     if (PASS == 0) {
       malformed |= carry_expect != 0;  // a sequence cut off by the end of the tile's last row
       if (lane == 0) {
-        a.tile_bytes[tile] = carry_bytes;
-        a.tile_tokens[tile] = carry_tokens;
+        a.tile_bytes[tile] = (int32_t)tile_b;
+        a.tile_tokens[tile] = (int32_t)tile_t;
       }
-      most_bytes = max(most_bytes, carry_bytes);
-      most_tokens = max(most_tokens, carry_tokens);
-    } else {
-      cstile::wave_lds_fence();
-      const long long cb = a.byte_base[tile], tb = a.tok_base[tile];
-      cstile::wave_flush_shift(a.out_chars + cb, carry_bytes, lds_out, lane);
-      cstile::gptr<int64_t> oo = cstile::as_global(a.out_off + tb);
-      for (int t = lane; t < carry_tokens; t += 64) oo[t] = cb + lds_tok[t];
-      cstile::wave_lds_fence();  // the next tile reuses the regions
     }
     if (!has_next) break;
     ++tile;
@@ -244,6 +269,12 @@ bool tokenize_fast(const cs_column* col, const unsigned char* delims, int ndel, 
       break;
     }
   }
+  // (no tile size fits every tile: 64-row tiles, the oversize ones taken in segments by the kernel -- byte-parallel still)
+  bool segs = false;
+  if (!R && max_span64(col, s) < ((int64_t)1 << 30) && !getenv("CS_NO_OUTLIER_TILES")) {
+    R = 64;
+    segs = true;
+  }
   if (!R) return false;
   TokTileArgs a{};
   a.in = view_of(col);
@@ -260,9 +291,10 @@ bool tokenize_fast(const cs_column* col, const unsigned char* delims, int ndel, 
   constexpr size_t kBitmapBytes = cstile::kPfBytes / 8 + 32;
   {
     const size_t lds0 = kBitmapBytes * 4;
-    const unsigned g0 = resident_grid(reinterpret_cast<const void*>(&k_tok_tile<0>), lds0, (a.ntiles + 3) / 4);
+    auto k0 = segs ? &k_tok_tile<0, true> : &k_tok_tile<0, false>;
+    const unsigned g0 = resident_grid(reinterpret_cast<const void*>(k0), lds0, (a.ntiles + 3) / 4);
     ProfScope ps("k_tok_count", s);
-    hipLaunchKernelGGL(k_tok_tile<0>, dim3(g0), dim3(256), lds0, s, a);
+    hipLaunchKernelGGL(k0, dim3(g0), dim3(256), lds0, s, a);
   }
   CS_HIP(hipGetLastError());
   // per-tile positions in the output chars and in the token sequence
@@ -294,13 +326,12 @@ bool tokenize_fast(const cs_column* col, const unsigned char* delims, int ndel, 
   a.cap_tok = (hmax[1] + 8 + 7) & ~7;
   const size_t lds1 = (kBitmapBytes + (size_t)a.cap_out + 2 * (size_t)a.cap_tok) * 4;
   if (lds1 > 150 * 1024) return false;
-  if (lds1 > 48 * 1024)
-    CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tok_tile<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)lds1));
+  auto k1 = segs ? &k_tok_tile<1, true> : &k_tok_tile<1, false>;
+  if (lds1 > 48 * 1024) CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
   {
-    const unsigned g1 = resident_grid(reinterpret_cast<const void*>(&k_tok_tile<1>), lds1, (a.ntiles + 3) / 4);
+    const unsigned g1 = resident_grid(reinterpret_cast<const void*>(k1), lds1, (a.ntiles + 3) / 4);
     ProfScope ps("k_tok_write", s);
-    hipLaunchKernelGGL(k_tok_tile<1>, dim3(g1), dim3(256), lds1, s, a);
+    hipLaunchKernelGGL(k1, dim3(g1), dim3(256), lds1, s, a);
   }
   CS_HIP(hipGetLastError());
   // closing offset

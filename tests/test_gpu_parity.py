@@ -658,6 +658,11 @@ def test_gpu_one_long_row_among_short_ones_stays_on_the_tile_kernels(gpu_engine,
         assert g.replace_re(s, pat, repl, n) == o.replace_re(s, pat, repl, n), (pat, repl, n)
     assert g.replace(s, "GET", "PUT") == o.replace(s, "GET", "PUT")
     assert int(_lib.lib.cs_fallback_count()) == f0
+    # tokenize: an oversize tile is walked in segments of the staging size, state carried across (whitespace, a delimiter set)
+    assert g.tokenize(s) == o.tokenize(s)
+    assert g.tokenize(s, " /.") == o.tokenize(s, " /.")
+    long_only = [("word%d " % i) * 3000 for i in range(70)] + [None, "", "x"]  # every tile oversize
+    assert g.tokenize(long_only) == o.tokenize(long_only)
 
 
 @pytest.mark.parametrize("kind", ["url", "nested", "nul", "long", "dups"])
