@@ -68,7 +68,9 @@ __global__ void __launch_bounds__(256) k_strip_tile(StripTileArgs a) {
     const int rbeg = (int)(cur.o0 - g0);
     const int n = live ? (int)(cur.o1 - cur.o0) : 0;
     const int lead = (int)((uintptr_t)(in.chars + g0) & 15);
-    const int want = (int)(g1 - g0) + lead;
+    const long long want64 = g1 - g0 + lead;
+    const bool oversize = want64 + 48 > a.cap;  // (the host sized the buffers for all but a few tiles: a long row among short ones)
+    const int want = oversize ? 0 : (int)want64;
     cstile::stage_chars(lds_in, want, lane, pf);
     // output extents of the tile's rows (the size pass and the scan already ran)
     const long long oo0 = a.out_off[r0 + min(lane, nrows)];
@@ -80,6 +82,25 @@ __global__ void __launch_bounds__(256) k_strip_tile(StripTileArgs a) {
       if (tile + 2 < tile_end) nxt = load_offs(tile + 2);
     }
     cstile::wave_lds_fence();
+    if (oversize) {
+      // straight from memory: a short row by its lane, a long one by the whole wave (a byte a lane)
+      int lo = 0, hi = 0;
+      const uint8_t* p = in.chars + (g0 + rbeg);
+      if (live && n > 0) row_strip(p, n, a.set, a.side, lo, hi);
+      const int len = hi - lo;
+      const unsigned long long big = __ballot(len > 256);
+      if (len > 0 && len <= 256)
+        for (int i = 0; i < len; ++i) a.out_chars[oo0 + i] = p[lo + i];
+      for (unsigned long long m = big; m; m &= m - 1) {
+        const int l = __builtin_ctzll(m);
+        const long long src = cstile::rl64(g0 + rbeg + lo, l), dst = cstile::rl64(oo0, l);
+        const int L = __builtin_amdgcn_readlane(len, l);
+        for (int i = lane; i < L; i += 64) a.out_chars[dst + i] = in.chars[src + i];
+      }
+      if (!has_next) break;
+      ++tile;
+      continue;
+    }
     const long long ob = cstile::rl64(oo0, 0), oe = cstile::rl64(oo1, 63);
     if (live && n > 0) {
       int lo, hi;
@@ -310,13 +331,18 @@ bool strip_write_tiles(const cs_column* in, const CharSet& set, int side, const 
       break;
     }
   }
+  int64_t span = R ? max_span_rows(in, R, s) : 0;
+  if (!R && few_spans64_over(in, cstile::kPfBytes - 64, s) && !getenv("CS_NO_OUTLIER_TILES")) {
+    R = 64;  // all but a few 64-row tiles fit: the kernel copies the rows of the others straight from memory
+    span = cstile::kPfBytes - 64;
+  }
   if (!R) return false;
   StripTileArgs a{};
   a.in = view_of(in);
   a.set = set;
   a.side = side;
   a.rows_per_tile = R;
-  a.cap = (int)((max_span_rows(in, R, s) + 48 + 15) & ~(int64_t)15);
+  a.cap = (int)((span + 48 + 15) & ~(int64_t)15);
   a.ntiles = (in->rows + R - 1) / R;
   a.out_off = out_off;
   a.out_chars = out_chars;

@@ -658,11 +658,22 @@ def test_gpu_one_long_row_among_short_ones_stays_on_the_tile_kernels(gpu_engine,
         assert g.replace_re(s, pat, repl, n) == o.replace_re(s, pat, repl, n), (pat, repl, n)
     assert g.replace(s, "GET", "PUT") == o.replace(s, "GET", "PUT")
     assert int(_lib.lib.cs_fallback_count()) == f0
+    for chars in (None, " GETtailrow8.", "Ü"):
+        assert g.strip(s, chars) == o.strip(s, chars), chars
     # tokenize: an oversize tile is walked in segments of the staging size, state carried across (whitespace, a delimiter set)
     assert g.tokenize(s) == o.tokenize(s)
     assert g.tokenize(s, " /.") == o.tokenize(s, " /.")
     long_only = [("word%d " % i) * 3000 for i in range(70)] + [None, "", "x"]  # every tile oversize
     assert g.tokenize(long_only) == o.tokenize(long_only)
+    # split: such a column takes the thread-per-row kernels (the tile kernels' out tiles cannot hold a long row's tokens)
+    for delim, n in ((" ", 5), (" ", 1), ("#", -1), (".", 3), (None, 4)):
+        assert g.split(s, delim, n) == o.split(s, delim, n), (delim, n)
+    assert g.rsplit(s, " ", 3) == o.rsplit(s, " ", 3)
+    few = list(s)
+    few[len(few) // 3] = "one-token-row" * 1000  # the long rows hold fewer tokens than the short ones
+    few[len(few) // 2] = None
+    few[-1] = ""
+    assert g.split(few, " ", -1) == o.split(few, " ", -1)
 
 
 @pytest.mark.parametrize("kind", ["url", "nested", "nul", "long", "dups"])
