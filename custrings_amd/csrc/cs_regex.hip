@@ -1027,13 +1027,15 @@ __device__ __forceinline__ int unit_discover(const cstd::View& D, const uint32_t
 }
 // Unit lanes: queue entry -> the unit's row (its position and length come from the row's lane) and the row's
 // candidate bits cut to the unit.  Every lane of the wave must call this (shuffles).
+// `clip`: the row handed to the unit's scan ends where the unit ends (see reclassify_high: the byte behind it may be >= 0x80).
 __device__ __forceinline__ void unit_take(uint32_t ent, int rbeg, int n, uint32_t m0, uint32_t m1, uint32_t m2, int& r, int& rbeg_r, int& n_r,
-                                          uint32_t& c0, uint32_t& c1, uint32_t& c2) {
+                                          uint32_t& c0, uint32_t& c1, uint32_t& c2, bool clip = false) {
   using namespace cstd;
   r = (int)(ent & 63u);
   const int us = (int)((ent >> 8) & 255u), uq = (int)((ent >> 16) & 255u);
   rbeg_r = __shfl(rbeg, r, 64);
   n_r = __shfl(n, r, 64);
+  if (clip && uq < n_r) n_r = uq;
   const U128 keep = u128_andn(u128_below(uq), u128_below(us));
   c0 = (uint32_t)__shfl((int)m0, r, 64) & (uint32_t)keep.lo;
   c1 = (uint32_t)__shfl((int)m1, r, 64) & (uint32_t)(keep.lo >> 32);
@@ -1046,6 +1048,32 @@ __device__ __forceinline__ uint32_t unit_xbits16(const uint4& q, uint32_t xpat) 
     return ~(((t & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | t) & 0x80808080u;
   };
   return cstile::gather16_bit7(eq(q.x), eq(q.y), eq(q.z), eq(q.w));
+}
+
+// Sub-tiles that hold bytes >= 0x80 (non-ASCII text).  The lean scan indexes its table with ASCII bytes only, so such a
+// sub-tile used to take the generic per-character scan, three to four times slower.  For a pattern none of whose atoms can
+// match a non-ASCII character and that has no anchors and no \b (header word 31, bit 17) such a character kills every
+// thread, as the end of the row does: the UNIT route can take the sub-tile -- units are runs of candidate / x bytes, ASCII
+// all of them -- provided a unit's scan ends at the unit's end (unit_take: clip) instead of reading the killer behind it.
+// This pass re-derives the candidate bits from the staged bytes with the bytes >= 0x80 taken out (the classification out
+// of the prefetch registers looks at their low seven bits) and says whether the sub-tile holds a NUL byte (then: generic).
+__device__ __forceinline__ bool reclassify_high(const cstd::View& D, bool has_r2, const uint8_t* lds_in, int want, int lane, uint32_t* bitmap) {
+  uint32_t zr = 0;
+  for (int i = lane * 16; i < want; i += 64 * 16) {
+    const uint4 q = *reinterpret_cast<const uint4*>(lds_in + i);
+    zr |= ((q.x - 0x01010101u) & ~q.x) | ((q.y - 0x01010101u) & ~q.y) | ((q.z - 0x01010101u) & ~q.z) | ((q.w - 0x01010101u) & ~q.w);
+    uint32_t bits;
+    if (has_r2)
+      bits = cstile::gather16_bit7(cstd::Tdfa::cand_bits_ascii<true>(D, q.x) & ~q.x, cstd::Tdfa::cand_bits_ascii<true>(D, q.y) & ~q.y,
+                                   cstd::Tdfa::cand_bits_ascii<true>(D, q.z) & ~q.z, cstd::Tdfa::cand_bits_ascii<true>(D, q.w) & ~q.w);
+    else
+      bits = cstile::gather16_bit7(cstd::Tdfa::cand_bits_ascii<false>(D, q.x) & ~q.x, cstd::Tdfa::cand_bits_ascii<false>(D, q.y) & ~q.y,
+                                   cstd::Tdfa::cand_bits_ascii<false>(D, q.z) & ~q.z, cstd::Tdfa::cand_bits_ascii<false>(D, q.w) & ~q.w);
+    cstile::put_bits16(bitmap, i, bits);
+  }
+  cstile::wave_lds_fence();
+  // (a zero byte below a byte >= 0x80 may go unseen by the borrow trick's neighbour term; a byte >= 0x80 never looks like one)
+  return __any((zr & 0x80808080u) != 0);
 }
 
 // UNITS (with !INPLACE, RESCAN, !LONG): the scan runs per UNIT instead of per row (regex_tdfa.cpp, header word 31).
@@ -1337,7 +1365,12 @@ __global__ void __launch_bounds__(256, BREFS ? 2 : CS_STREAM_WAVES) k_tdfa_repla
         ++nm;
       };
       // wave-uniform choice: the lean scan when every row of the sub-tile qualifies
-      const bool lean = D.nskip > 0 && D.img[12] <= 4 && !(a.debug & 32) && !__any((odd & 0x80808080u) != 0) &&
+      const bool has_odd = __any((odd & 0x80808080u) != 0);
+      // (a sub-tile with bytes >= 0x80, a pattern they can only kill: the UNIT route alone -- reclassify_high)
+      bool hi_units = false;
+      if (UNITS && !BREFS && has_odd && a.litn == 0 && ((D.units >> 17) & 1u) && (D.units & 1u) && a.maxrepl < 0 && !(a.debug & 4096))
+        hi_units = !reclassify_high(D, has_r2, lds_in, (int)want, lane, bitmap);
+      const bool lean = D.nskip > 0 && D.img[12] <= 4 && !(a.debug & 32) && (!has_odd || hi_units) &&
                         !__any(live && (LONG ? n > cstd::Tdfa::kLongBytes : !vm.masks_fit()));
       bool redo = live && !lean && a.maxrepl != 0;
       int resume = 0;
@@ -1420,7 +1453,7 @@ __global__ void __launch_bounds__(256, BREFS ? 2 : CS_STREAM_WAVES) k_tdfa_repla
               const bool act = u0 + lane < total_units;
               int r, rbeg_r, n_r;
               uint32_t c0, c1, c2;
-              unit_take(act ? uqueue[u0 + lane] : 0u, rbeg, n, m0, m1, m2, r, rbeg_r, n_r, c0, c1, c2);
+              unit_take(act ? uqueue[u0 + lane] : 0u, rbeg, n, m0, m1, m2, r, rbeg_r, n_r, c0, c1, c2, hi_units);
               if (act) {
                 const int pu = lead + rbeg_r;
                 cstd::Tdfa vu(D, P, lds_in + pu, n_r, pu & 3);
@@ -1538,7 +1571,8 @@ __global__ void __launch_bounds__(256, BREFS ? 2 : CS_STREAM_WAVES) k_tdfa_repla
         if (lane == 0) atomicOr(a.error, 1u | 32u);
         redo = false;
       }
-      if (UNITS && !BREFS && !units_done && lean && a.maxrepl < 0 && D.img[13] >= 1 && !(a.debug & 2048)) {  // (wave-uniform)
+      if (hi_units && !units_done) redo = live;  // (more units than the queue holds: the generic scan, never the lean scan on such bytes)
+      if (UNITS && !BREFS && !units_done && lean && !hi_units && a.maxrepl < 0 && D.img[13] >= 1 && !(a.debug & 2048)) {  // (wave-uniform)
         // A sub-tile the unit route did not take (more units than the queue holds: patterns whose candidate bytes are
         // everywhere, such as alternations of word-bounded literals; or no decomposition at all): every row lane scans its
         // own row, but the matches still go into the two bitmaps -- a start bit and a last-byte bit each, as the unit lanes
@@ -1579,7 +1613,7 @@ __global__ void __launch_bounds__(256, BREFS ? 2 : CS_STREAM_WAVES) k_tdfa_repla
         redo = live && bail;  // (such a row is scanned whole by the generic scan below; nothing of it counts from above)
         units_done = true;
       }
-      if (!BREFS && !units_done && lean && live && a.maxrepl != 0) {
+      if (!BREFS && !units_done && lean && !hi_units && live && a.maxrepl != 0) {
         bool bail = false;
         uint32_t m0, m1, m2;  // candidate bits, bit i = byte i of the row
         if (LONG) {
@@ -2042,7 +2076,11 @@ __global__ void __launch_bounds__(256, ((UNITS && MODE == 3) || MODE == 4) ? 3 :
       }
     } else {
       cstd::Tdfa vm(D, P, lds_in + lead + rbeg, n, (lead + rbeg) & 3);
-      const bool lean = D.nskip > 0 && D.img[12] <= 4 && !__any((odd & 0x80808080u) != 0) &&
+      const bool has_odd = __any((odd & 0x80808080u) != 0);
+      bool hi_units = false;  // (bytes >= 0x80 that can only kill: the unit route alone -- reclassify_high)
+      if (UNITS && (MODE == 2 || MODE == 3) && has_odd && ((D.units >> 17) & 1u) && (D.units & 1u))
+        hi_units = !reclassify_high(D, has_r2, lds_in, want, lane, bitmap);
+      const bool lean = D.nskip > 0 && D.img[12] <= 4 && (!has_odd || hi_units) &&
                         !__any(live && (LONG ? n > cstd::Tdfa::kLongBytes : !vm.masks_fit()));
       bool redo = live && !lean;
       int k = 0;  // MODE 3: matches reported so far
@@ -2080,7 +2118,7 @@ __global__ void __launch_bounds__(256, ((UNITS && MODE == 3) || MODE == 4) ? 3 :
               const bool act = u0 + lane < total_units;
               int r, rbeg_r, n_r;
               uint32_t c0, c1, c2;
-              unit_take(act ? uqueue[u0 + lane] : 0u, rbeg, n, m0, m1, m2, r, rbeg_r, n_r, c0, c1, c2);
+              unit_take(act ? uqueue[u0 + lane] : 0u, rbeg, n, m0, m1, m2, r, rbeg_r, n_r, c0, c1, c2, hi_units);
               if (act) {
                 const int pu = lead + rbeg_r;
                 cstd::Tdfa vu(D, P, lds_in + pu, n_r, pu & 3);
@@ -2126,7 +2164,7 @@ __global__ void __launch_bounds__(256, ((UNITS && MODE == 3) || MODE == 4) ? 3 :
               const bool act = u0 + lane < total_units;
               int r, rbeg_r, n_r;
               uint32_t c0, c1, c2;
-              unit_take(act ? uqueue[u0 + lane] : 0u, rbeg, n, m0, m1, m2, r, rbeg_r, n_r, c0, c1, c2);
+              unit_take(act ? uqueue[u0 + lane] : 0u, rbeg, n, m0, m1, m2, r, rbeg_r, n_r, c0, c1, c2, hi_units);
               if (act) {
                 const int pu = lead + rbeg_r;
                 cstd::Tdfa vu(D, P, lds_in + pu, n_r, pu & 3);
@@ -2143,7 +2181,8 @@ __global__ void __launch_bounds__(256, ((UNITS && MODE == 3) || MODE == 4) ? 3 :
           }
         }
       }
-      if (!units_done && lean && live) {
+      if (hi_units && !units_done) redo = live;  // (never the lean scan over whole rows of such a tile)
+      if (!units_done && lean && !hi_units && live) {
         uint32_t m0, m1, m2;
         constexpr int KIND = MODE == 0 ? cstd::Tdfa::K_CONTAINS : cstd::Tdfa::K_COUNT;
         if (LONG) {

@@ -538,6 +538,12 @@ std::vector<int32_t> build_tdfa(const Program& prog, const std::vector<int32_t>&
           required = !match;
         }
         word = 1 | (x << 8) | (required ? 1 << 16 : 0);
+        // bit 17: a non-ASCII character can only kill -- no atom matches one (every non-ASCII signature is empty), no
+        // anchors, no \b -- exactly as the end of the row does: the unit route may take tiles that hold such bytes,
+        // a unit's scan ending where the unit ends (cs_regex.hip: reclassify_high)
+        bool only_kills = !B.use_word && !B.use_line;
+        for (const auto& kv : B.na_atoms) only_kills = only_kills && kv.first == 0;
+        if (only_kills) word |= 1 << 17;
       }
     }
     img[31] = word;

@@ -1229,13 +1229,28 @@ CS_HD void row_replace_matches(cstd::Tdfa& vm, int maxrepl, Emit&& emit) {
   // checked against the oracle with the same fuzz corpus; matches are buffered because
   // a bail-out must leave no trace
   // the unit decomposition of the replace kernels (regex_tdfa.cpp): every unit scanned on its own, in order
-  if (maxrepl < 0 && (vm.D.units & 1u) && vm.lean_ok()) {
+  // (header word 31 bit 17: rows with bytes >= 0x80 too -- no NUL --, those bytes taken out of the candidate bits and every
+  // unit's scan ending at the unit's end: cs_regex.hip, reclassify_high)
+  bool high = false, nul = false;
+  for (int i = 0; i < vm.n; ++i) {
+    high |= vm.s[i] >= 128;
+    nul |= vm.s[i] == 0;
+  }
+  const bool hi_units = high && !nul && ((vm.D.units >> 17) & 1u) && vm.D.nskip > 0 && vm.masks_fit() && vm.D.img[12] <= 4;
+  if (maxrepl < 0 && (vm.D.units & 1u) && (vm.lean_ok() || hi_units)) {
     int buf[3 * 64];
     int cnt = 0;
     bool bail = false, overflow = false;
     uint32_t c0, c1, c2;
     if (vm.has_range2()) vm.build_masks_lean<true>(c0, c1, c2);
     else vm.build_masks_lean<false>(c0, c1, c2);
+    if (hi_units)
+      for (int i = 0; i < vm.n; ++i)
+        if (vm.s[i] >= 128) {
+          if (i < 32) c0 &= ~(1u << i);
+          else if (i < 64) c1 &= ~(1u << (i - 32));
+          else c2 &= ~(1u << (i - 64));
+        }
     const unsigned x = (vm.D.units >> 8) & 127u;
     const cstd::U128 C = cstd::u128(c0 | ((unsigned long long)c1 << 32), c2);
     cstd::U128 X = cstd::u128(0, 0), N;
@@ -1249,7 +1264,8 @@ CS_HD void row_replace_matches(cstd::Tdfa& vm, int maxrepl, Emit&& emit) {
       const int q = cstd::u128_ctz(W);
       W = cstd::u128_clear_lowest(W);
       const cstd::U128 cm = cstd::u128_and(C, cstd::u128_andn(cstd::u128_below(q), cstd::u128_below(cstd::unit_start(N, q))));
-      vm.scan_lean_dispatch(-1, (uint32_t)cm.lo, (uint32_t)(cm.lo >> 32), (uint32_t)cm.hi, [&](int mb, int me, int reps) {
+      cstd::Tdfa vu(vm.D, vm.P, vm.s, hi_units && q < vm.n ? q : vm.n, vm.sa);
+      vu.scan_lean_dispatch(-1, (uint32_t)cm.lo, (uint32_t)(cm.lo >> 32), (uint32_t)cm.hi, [&](int mb, int me, int reps) {
         if (cnt < 64) {
           buf[3 * cnt] = mb;
           buf[3 * cnt + 1] = me;

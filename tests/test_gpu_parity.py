@@ -629,6 +629,29 @@ def test_gpu_long_replacements_on_the_stream_kernel(gpu_engine, oracle_engine, o
 WIDE_PATTERNS = [r"\d{1,3}\.\d{1,3}\.\d{1,3}\.\d{1,3}", r"\w{5}", r"[a-z]{3,8}@", r"[0-9a-f]{8}-[0-9a-f]{4}", r"(a|b|c){6}x", r"\w{5,7} ", r"[ab]{2,6}c|\d{5}"]
 
 
+def test_gpu_unit_route_on_tiles_with_non_ascii_bytes(gpu_engine, oracle_engine):
+    """Sub-tiles that hold bytes >= 0x80 and a pattern such bytes can only kill (ASCII classes and literals, no anchors, no
+    \\b: regex_tdfa.cpp header word 31 bit 17): the unit route takes them, a unit's scan ending at the unit's end
+    (cs_regex.hip: reclassify_high) -- replace_re / count_re / findall against the oracle, with the characters next to the
+    matches, between units and at the row ends; \\d patterns (non-ASCII digits exist) keep the generic scan and must agree too."""
+    import random
+
+    rnd = random.Random(23)
+    pieces = ["1.2.3.4", "10.20.30.40 ", "é", "ü", "€", "😀", " ", ".", "12", "abc", "a@b", "GET /x ", "7-8", "abc.com ", "@", "-", "b", "0", "٣"]
+    s = []
+    for _ in range(6000):
+        row = "".join(rnd.choice(pieces) for _ in range(rnd.randint(0, 16)))
+        s.append(row if len(row.encode()) <= 90 else row[:28])
+    s += ["é1.2.3.4é", "1.2.3.4é5.6.7.8", "é", "éé1.2.3", "1.2.3.é4", "aaé", "ébé", "😀ab😀", "", None]
+    o, g = oracle_engine, gpu_engine
+    for pat in (r"[0-9]+\.[0-9]+\.[0-9]+\.[0-9]+", r"[0-9]+", r"[a-c]+", r"[a-c]+@[a-c]+", r"[a-z]+\.com", r"\d+\.\d+\.\d+\.\d+", r"\d+"):
+        for repl in ("<IP>", "", "a-longer-one"):
+            assert g.replace_re(s, pat, repl, -1) == o.replace_re(s, pat, repl, -1), (pat, repl)
+        assert g.count_re(s, pat) == o.count_re(s, pat), pat
+        assert g.findall(s, pat) == o.findall(s, pat), pat
+        assert g.contains_re(s, pat) == o.contains_re(s, pat), pat
+
+
 def _with_outliers(rnd, rows=6000):
     """short log-like rows with a few very long ones among them (one ASCII, one with two-byte characters, one at the end)"""
     s = [_log_like(rnd, 20, 90) for _ in range(rows)]

@@ -139,6 +139,44 @@ def test_unit_decomposition_is_offered_where_expected(emu_engine):
         assert not emu_engine.e.units(pat)[0], pat
 
 
+HIGH_OK = [r"[0-9]+\.[0-9]+\.[0-9]+\.[0-9]+", r"[0-9]+", r"[a-c]+", r"[a-c]+@[a-c]+", r"a+b", r"[0-9]+-[0-9]+", r"[a-z]+\.com"]
+# (\d, \w, \s match non-ASCII digits / letters / spaces as the reference's tables say: such patterns keep the generic scan there)
+HIGH_NOT = [r"\d+\.\d+\.\d+\.\d+", r"\d+", r"\b[0-9]{1,3}\.[0-9]{1,3}\b", r"\w+ \w+", r"[^x]+", r"[0-9]+$", r"\s+", r"é+", r"[à-ü]+"]
+
+
+def test_unit_route_on_rows_with_non_ascii_bytes(emu_engine, oracle_engine):
+    """Header word 31 bit 17 (regex_tdfa.cpp): a non-ASCII character can only kill -- the unit route then takes rows that hold
+    bytes >= 0x80, a unit's scan ending at the unit's end (the host build of row_replace_matches mirrors the kernels'
+    reclassify_high route).  The flag where expected; replace_re on rows mixing two-, three- and four-byte characters
+    with the patterns' matches -- adjacent to them, between units, at both row ends -- against the oracle."""
+    import random
+
+    def word(pat):
+        re = emu_engine.e.compile(pat)
+        w = emu_engine.e._regex_units(re)
+        emu_engine.e._regex_free(re)
+        return w
+
+    for pat in HIGH_OK:
+        assert word(pat) & 1 and (word(pat) >> 17) & 1, pat
+    for pat in HIGH_NOT:
+        assert not (word(pat) >> 17) & 1, pat
+    rnd = random.Random(11)
+    pieces = ["1.2.3.4", "10.20.30.40", "é", "ü", "€", "😀", " ", ".", "12", "abc", "a@b", "ab", "aab", "7-8", "x.com", "abc.com", "@", "-", "b", "0"]
+    s = []
+    for _ in range(1500):
+        row = "".join(rnd.choice(pieces) for _ in range(rnd.randint(0, 14)))
+        s.append(row if len(row.encode()) <= 90 else row[:30])
+    s += ["é1.2.3.4é", "1.2.3.4é5.6.7.8", "é", "éé1.2.3", "1.2.3.é4", "aaé", "ébé", "😀ab😀", "", None]
+    emu_engine.e.set_engine(1)
+    try:
+        for pat in HIGH_OK:
+            for repl in ("<IP>", ""):
+                assert emu_engine.replace_re(s, pat, repl, -1) == oracle_engine.replace_re(s, pat, repl, -1), (pat, repl)
+    finally:
+        emu_engine.e.set_engine(0)
+
+
 def test_unit_decomposition_vs_oracle(emu_engine, oracle_engine):
     """replace_re with no limit takes the unit route on ASCII rows (regex_tdfa.h: row_replace_matches, host build):
     every unit scanned on its own must give the whole-row scan's matches -- listed patterns and generated ones."""
