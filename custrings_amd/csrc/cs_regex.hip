@@ -1057,8 +1057,33 @@ __device__ __forceinline__ uint32_t unit_xbits16(const uint4& q, uint32_t xpat) 
 // all of them -- provided a unit's scan ends at the unit's end (unit_take: clip) instead of reading the killer behind it.
 // This pass re-derives the candidate bits from the staged bytes with the bytes >= 0x80 taken out (the classification out
 // of the prefetch registers looks at their low seven bits) and says whether the sub-tile holds a NUL byte (then: generic).
-__device__ __forceinline__ bool reclassify_high(const cstd::View& D, bool has_r2, const uint8_t* lds_in, int want, int lane, uint32_t* bitmap) {
-  uint32_t zr = 0;
+// Header word 31 bit 18 (mask in bits 19-23): the pattern's builtin classes (\w, \s, \d) do match some non-ASCII characters
+// -- those whose unicode flags meet the mask; the row lanes then walk their rows' non-ASCII characters: the sub-tile
+// qualifies when its UTF-8 is well formed inside every row and no character's flags meet the mask.
+__device__ __forceinline__ bool reclassify_high(const cstd::View& D, bool has_r2, const uint8_t* lds_in, int want, int lane, uint32_t* bitmap,
+                                                const uint8_t* flags, const uint8_t* row, int n) {
+  const unsigned fmask = (D.units >> 19) & 31u;
+  bool row_bad = false;
+  if ((D.units >> 18) & 1u) {
+    for (int i = 0; i < n && !row_bad;) {
+      const uint8_t b = row[i];
+      if (b < 0x80) {
+        ++i;
+        continue;
+      }
+      const unsigned w = csrow::lead_width(b);
+      row_bad = w < 2 || i + (int)w > n;
+      for (unsigned k = 1; k < w && !row_bad; ++k) row_bad = !csrow::is_cont(row[i + (int)k]);
+      if (!row_bad) {
+        csrow::Char ch;
+        csrow::decode_at(row, i, n, ch);
+        const unsigned u = csrow::packed_to_cp(ch);
+        row_bad = u <= 0xFFFFu && (flags[u] & fmask) != 0;
+      }
+      i += (int)w;
+    }
+  }
+  uint32_t zr = row_bad ? 0x80u : 0u;
   for (int i = lane * 16; i < want; i += 64 * 16) {
     const uint4 q = *reinterpret_cast<const uint4*>(lds_in + i);
     zr |= ((q.x - 0x01010101u) & ~q.x) | ((q.y - 0x01010101u) & ~q.y) | ((q.z - 0x01010101u) & ~q.z) | ((q.w - 0x01010101u) & ~q.w);
@@ -1368,8 +1393,8 @@ __global__ void __launch_bounds__(256, BREFS ? 2 : CS_STREAM_WAVES) k_tdfa_repla
       const bool has_odd = __any((odd & 0x80808080u) != 0);
       // (a sub-tile with bytes >= 0x80, a pattern they can only kill: the UNIT route alone -- reclassify_high)
       bool hi_units = false;
-      if (UNITS && !BREFS && has_odd && a.litn == 0 && ((D.units >> 17) & 1u) && (D.units & 1u) && a.maxrepl < 0 && !(a.debug & 4096))
-        hi_units = !reclassify_high(D, has_r2, lds_in, (int)want, lane, bitmap);
+      if (UNITS && !BREFS && has_odd && a.litn == 0 && ((D.units >> 17) & 3u) && (D.units & 1u) && a.maxrepl < 0 && !(a.debug & 4096))
+        hi_units = !reclassify_high(D, has_r2, lds_in, (int)want, lane, bitmap, a.flags, lds_in + lead + rbeg, n);
       const bool lean = D.nskip > 0 && D.img[12] <= 4 && !(a.debug & 32) && (!has_odd || hi_units) &&
                         !__any(live && (LONG ? n > cstd::Tdfa::kLongBytes : !vm.masks_fit()));
       bool redo = live && !lean && a.maxrepl != 0;
@@ -2078,8 +2103,8 @@ __global__ void __launch_bounds__(256, ((UNITS && MODE == 3) || MODE == 4) ? 3 :
       cstd::Tdfa vm(D, P, lds_in + lead + rbeg, n, (lead + rbeg) & 3);
       const bool has_odd = __any((odd & 0x80808080u) != 0);
       bool hi_units = false;  // (bytes >= 0x80 that can only kill: the unit route alone -- reclassify_high)
-      if (UNITS && (MODE == 2 || MODE == 3) && has_odd && ((D.units >> 17) & 1u) && (D.units & 1u))
-        hi_units = !reclassify_high(D, has_r2, lds_in, want, lane, bitmap);
+      if (UNITS && (MODE == 2 || MODE == 3) && has_odd && ((D.units >> 17) & 3u) && (D.units & 1u))
+        hi_units = !reclassify_high(D, has_r2, lds_in, want, lane, bitmap, a.flags, lds_in + lead + rbeg, n);
       const bool lean = D.nskip > 0 && D.img[12] <= 4 && (!has_odd || hi_units) &&
                         !__any(live && (LONG ? n > cstd::Tdfa::kLongBytes : !vm.masks_fit()));
       bool redo = live && !lean;

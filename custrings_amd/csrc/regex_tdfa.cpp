@@ -544,6 +544,28 @@ std::vector<int32_t> build_tdfa(const Program& prog, const std::vector<int32_t>&
         bool only_kills = !B.use_word && !B.use_line;
         for (const auto& kv : B.na_atoms) only_kills = only_kills && kv.first == 0;
         if (only_kills) word |= 1 << 17;
+        // bits 18-23: the same for the non-ASCII characters whose unicode flags miss a mask -- a pattern of ASCII literals
+        // and of classes made of ASCII ranges and \w / \s / \d (not negated): a non-ASCII character matches one of its
+        // atoms only through a builtin, i.e. when flags[cp] & mask != 0 (regex_vm.h: class_match; \w: 15, \s: 16, \d: 4).
+        // The kernels then check the characters of a tile against the mask (a column of accented text holds no digit
+        // outside ASCII: `\d+\.\d+\.\d+\.\d+` stays on the unit route there).
+        if (!only_kills && !B.use_word && !B.use_line) {
+          bool ok = true;
+          unsigned fmask = 0;
+          for (size_t i = 0; i < B.pred_type.size() && ok; ++i) {
+            if (B.pred_type[i] == cstd::P_CHAR) {
+              ok = (uint32_t)B.pred_arg[i] < 128u;
+            } else if (B.pred_type[i] == cstd::P_CCLASS) {
+              const CharClass& cc = prog.classes[B.pred_arg[i]];
+              for (uint32_t r : cc.ranges) ok = ok && r < 128u;
+              ok = ok && (cc.builtins & ~7) == 0;
+              fmask |= ((cc.builtins & 1) ? 15u : 0u) | ((cc.builtins & 2) ? 16u : 0u) | ((cc.builtins & 4) ? 4u : 0u);
+            } else {
+              ok = false;  // `.`, a negated class
+            }
+          }
+          if (ok && fmask) word |= (1 << 18) | (int32_t)(fmask << 19);
+        }
       }
     }
     img[31] = word;

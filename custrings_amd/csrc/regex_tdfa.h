@@ -1236,7 +1236,27 @@ CS_HD void row_replace_matches(cstd::Tdfa& vm, int maxrepl, Emit&& emit) {
     high |= vm.s[i] >= 128;
     nul |= vm.s[i] == 0;
   }
-  const bool hi_units = high && !nul && ((vm.D.units >> 17) & 1u) && vm.D.nskip > 0 && vm.masks_fit() && vm.D.img[12] <= 4;
+  bool hi_units = high && !nul && ((vm.D.units >> 17) & 3u) && vm.D.nskip > 0 && vm.masks_fit() && vm.D.img[12] <= 4;
+  if (hi_units && ((vm.D.units >> 18) & 1u)) {  // (bit 18: every non-ASCII character well formed and outside the builtins' flags)
+    const unsigned fmask = (vm.D.units >> 19) & 31u;
+    for (int i = 0; i < vm.n && hi_units;) {
+      const uint8_t b = vm.s[i];
+      if (b < 0x80) {
+        ++i;
+        continue;
+      }
+      const unsigned w = csrow::lead_width(b);
+      hi_units = w >= 2 && i + (int)w <= vm.n;
+      for (unsigned k = 1; k < w && hi_units; ++k) hi_units = csrow::is_cont(vm.s[i + (int)k]);
+      if (hi_units) {
+        csrow::Char ch;
+        csrow::decode_at(vm.s, i, vm.n, ch);
+        const unsigned u = csrow::packed_to_cp(ch);
+        hi_units = !(u <= 0xFFFFu && (vm.P.flags[u] & fmask) != 0);
+      }
+      i += (int)w;
+    }
+  }
   if (maxrepl < 0 && (vm.D.units & 1u) && (vm.lean_ok() || hi_units)) {
     int buf[3 * 64];
     int cnt = 0;

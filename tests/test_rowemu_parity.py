@@ -141,7 +141,9 @@ def test_unit_decomposition_is_offered_where_expected(emu_engine):
 
 HIGH_OK = [r"[0-9]+\.[0-9]+\.[0-9]+\.[0-9]+", r"[0-9]+", r"[a-c]+", r"[a-c]+@[a-c]+", r"a+b", r"[0-9]+-[0-9]+", r"[a-z]+\.com"]
 # (\d, \w, \s match non-ASCII digits / letters / spaces as the reference's tables say: such patterns keep the generic scan there)
-HIGH_NOT = [r"\d+\.\d+\.\d+\.\d+", r"\d+", r"\b[0-9]{1,3}\.[0-9]{1,3}\b", r"\w+ \w+", r"[^x]+", r"[0-9]+$", r"\s+", r"é+", r"[à-ü]+"]
+HIGH_NOT = [r"\b[0-9]{1,3}\.[0-9]{1,3}\b", r"[^x]+", r"[0-9]+$", r"é+", r"[à-ü]+", r"a.c"]
+# builtin classes: non-ASCII characters match them through the unicode flags -- bit 18 with the flags mask (\w 15, \s 16, \d 4)
+HIGH_FLAGS = {r"\d+\.\d+\.\d+\.\d+": 4, r"\d+": 4, r"\w+ \w+": 15 | 0, r"\s+": 16, r"[\da-c]+x": 4}
 
 
 def test_unit_route_on_rows_with_non_ascii_bytes(emu_engine, oracle_engine):
@@ -160,7 +162,10 @@ def test_unit_route_on_rows_with_non_ascii_bytes(emu_engine, oracle_engine):
     for pat in HIGH_OK:
         assert word(pat) & 1 and (word(pat) >> 17) & 1, pat
     for pat in HIGH_NOT:
-        assert not (word(pat) >> 17) & 1, pat
+        assert not (word(pat) >> 17) & 3, pat
+    for pat, mask in HIGH_FLAGS.items():
+        w = word(pat)
+        assert w & 1 and not (w >> 17) & 1 and (w >> 18) & 1 and (w >> 19) & 31 == mask, (pat, hex(w))
     rnd = random.Random(11)
     pieces = ["1.2.3.4", "10.20.30.40", "é", "ü", "€", "😀", " ", ".", "12", "abc", "a@b", "ab", "aab", "7-8", "x.com", "abc.com", "@", "-", "b", "0"]
     s = []
@@ -170,7 +175,10 @@ def test_unit_route_on_rows_with_non_ascii_bytes(emu_engine, oracle_engine):
     s += ["é1.2.3.4é", "1.2.3.4é5.6.7.8", "é", "éé1.2.3", "1.2.3.é4", "aaé", "ébé", "😀ab😀", "", None]
     emu_engine.e.set_engine(1)
     try:
-        for pat in HIGH_OK:
+        pieces += ["٣", "٣.٤", "\u00a0", "Ü1", "é_"]  # a digit, a space outside ASCII: rows that hold one keep the generic scan
+        for _ in range(800):
+            s.append("".join(rnd.choice(pieces) for _ in range(rnd.randint(0, 12)))[:40])
+        for pat in HIGH_OK + list(HIGH_FLAGS):
             for repl in ("<IP>", ""):
                 assert emu_engine.replace_re(s, pat, repl, -1) == oracle_engine.replace_re(s, pat, repl, -1), (pat, repl)
     finally:
