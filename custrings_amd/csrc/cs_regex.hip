@@ -1065,22 +1065,30 @@ __device__ __forceinline__ bool reclassify_high(const cstd::View& D, bool has_r2
   const unsigned fmask = (D.units >> 19) & 31u;
   bool row_bad = false;
   if ((D.units >> 18) & 1u) {
-    for (int i = 0; i < n && !row_bad;) {
-      const uint8_t b = row[i];
-      if (b < 0x80) {
-        ++i;
-        continue;
+    // aligned words of the row, only the bytes >= 0x80 looked at one by one (a lead byte checks its continuation bytes and
+    // covers them; a byte >= 0x80 that no lead covers is a stray one)
+    const int al = (int)((uintptr_t)row & 3);
+    int covered = 0;  // row offsets below this one belong to a character already checked
+    for (int i = -al; i < n && !row_bad; i += 4) {
+      uint32_t h = *reinterpret_cast<const uint32_t*>(row + i) & 0x80808080u;
+      if (i < 0) h &= 0xFFFFFFFFu << (8 * -i);
+      if (i + 4 > n) h &= ~(0xFFFFFFFFu << (8 * (n - i)));
+      while (h && !row_bad) {
+        const int p = i + (__builtin_ctz(h) >> 3);
+        h &= h - 1;
+        if (p < covered) continue;
+        const uint8_t b = row[p];
+        const unsigned w = csrow::lead_width(b);
+        row_bad = w < 2 || p + (int)w > n;
+        for (unsigned k = 1; k < w && !row_bad; ++k) row_bad = !csrow::is_cont(row[p + (int)k]);
+        if (!row_bad) {
+          csrow::Char ch;
+          csrow::decode_at(row, p, n, ch);
+          const unsigned u = csrow::packed_to_cp(ch);
+          row_bad = u <= 0xFFFFu && (flags[u] & fmask) != 0;
+        }
+        covered = p + (int)w;
       }
-      const unsigned w = csrow::lead_width(b);
-      row_bad = w < 2 || i + (int)w > n;
-      for (unsigned k = 1; k < w && !row_bad; ++k) row_bad = !csrow::is_cont(row[i + (int)k]);
-      if (!row_bad) {
-        csrow::Char ch;
-        csrow::decode_at(row, i, n, ch);
-        const unsigned u = csrow::packed_to_cp(ch);
-        row_bad = u <= 0xFFFFu && (flags[u] & fmask) != 0;
-      }
-      i += (int)w;
     }
   }
   uint32_t zr = row_bad ? 0x80u : 0u;
