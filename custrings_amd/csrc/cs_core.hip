@@ -631,6 +631,29 @@ bool few_spans64_over(const cs_column* c, int64_t limit, hipStream_t s) {
   const int64_t over = count_spans64_over(c, limit, s);
   return over <= std::max<int64_t>(8, nsub / 1000);
 }
+// A hint for choosing between kernel forms (never for correctness): does the column look like non-ASCII text?  Three windows
+// of 64 KiB (start, middle, end of the chars), cached on the immutable column.
+__global__ void k_sample_high(const uint8_t* __restrict__ chars, int64_t nbytes, int* __restrict__ out) {
+  const int64_t win = 64 * 1024;
+  const int64_t base = blockIdx.x == 0 ? 0 : (blockIdx.x == 1 ? (nbytes / 2) & ~(int64_t)15 : (nbytes > win ? (nbytes - win) & ~(int64_t)15 : 0));
+  uint32_t any = 0;
+  for (int64_t i = base + (int64_t)threadIdx.x * 16; i + 16 <= nbytes && i < base + win; i += (int64_t)blockDim.x * 16) {
+    const uint4 q = *reinterpret_cast<const uint4*>(chars + i);
+    any |= (q.x | q.y | q.z | q.w) & 0x80808080u;
+  }
+  if (any) *out = 1;
+}
+bool sample_has_high_bytes(const cs_column* c, hipStream_t s) {
+  if (c->high_sample >= 0) return c->high_sample != 0;
+  if (c->nbytes < 16 || !c->chars) return (c->high_sample = 0) != 0;
+  Buf flag = dev_alloc(sizeof(int), s);
+  CS_HIP(hipMemsetAsync(flag->p, 0, sizeof(int), s));
+  hipLaunchKernelGGL(k_sample_high, dim3(3), dim3(256), 0, s, c->d_chars(), c->nbytes, ptr<int>(flag));
+  int* host = (int*)pinned_scratch(sizeof(int));
+  CS_HIP(hipMemcpyAsync(host, flag->p, sizeof(int), hipMemcpyDeviceToHost, s));
+  CS_HIP(hipStreamSynchronize(s));
+  return (c->high_sample = host[0] ? 1 : 0) != 0;
+}
 int64_t max_row_bytes(const cs_column* c, hipStream_t s) {
   if (c->max_row >= 0) return c->max_row;
   return c->max_row = max_span_rows(c, 1, s);

@@ -94,6 +94,7 @@ struct cs_column {
   mutable int64_t max_row = -1;     // longest row in bytes; -1 = unknown
   mutable int drops = -1;           // 1: some row is null or empty (rows create_ngrams drops), 0: none; -1 = unknown
   mutable int plain_bytes = -1;     // 1: no NUL byte and no lead byte announcing over an ASCII byte; -1 = unknown
+  mutable int high_sample = -1;     // 1: a sample of the chars (three 64 KiB windows) holds a byte >= 0x80; -1 = not looked at
   cs::Buf chars, validity;  // validity may be null (all valid)
   // Row extents: int64 offsets (`offsets`) and / or int32 offsets (`offsets32`, columns whose
   // chars stay below 2 GiB -- what split produces: half the bytes written per output row).  A
@@ -156,6 +157,7 @@ int64_t max_row_bytes(const cs_column* c, hipStream_t s);
 bool bytes_plain(const cs_column* c, hipStream_t s);
 // Same for tiles of `per` consecutive rows (per = 64 is the cached one).
 int64_t max_span_rows(const cs_column* c, int per, hipStream_t s);
+bool sample_has_high_bytes(const cs_column* c, hipStream_t s);  // a hint (kernel choice only): non-ASCII text, by three windows of the chars
 int64_t count_spans64_over(const cs_column* c, int64_t limit, hipStream_t s);
 bool few_spans64_over(const cs_column* c, int64_t limit, hipStream_t s);  // all but a few 64-row tiles fit `limit` bytes
 // Workgroups (256 threads, `lds` dynamic bytes) of `kern` resident at once on the device,

@@ -2111,7 +2111,7 @@ __global__ void __launch_bounds__(256, ((UNITS && MODE == 3) || MODE == 4) ? 3 :
       cstd::Tdfa vm(D, P, lds_in + lead + rbeg, n, (lead + rbeg) & 3);
       const bool has_odd = __any((odd & 0x80808080u) != 0);
       bool hi_units = false;  // (bytes >= 0x80 that can only kill: the unit route alone -- reclassify_high)
-      if (UNITS && (MODE == 2 || MODE == 3) && has_odd && ((D.units >> 17) & 3u) && (D.units & 1u))
+      if (UNITS && (MODE == 0 || MODE == 2 || MODE == 3) && has_odd && ((D.units >> 17) & 3u) && (D.units & 1u))
         hi_units = !reclassify_high(D, has_r2, lds_in, want, lane, bitmap, a.flags, lds_in + lead + rbeg, n);
       const bool lean = D.nskip > 0 && D.img[12] <= 4 && (!has_odd || hi_units) &&
                         !__any(live && (LONG ? n > cstd::Tdfa::kLongBytes : !vm.masks_fit()));
@@ -2185,7 +2185,9 @@ __global__ void __launch_bounds__(256, ((UNITS && MODE == 3) || MODE == 4) ? 3 :
           }
         }
       } else if (UNITS) {
-        if (lean && (D.units & 1u)) {  // (wave-uniform)
+        // (contains_re stops at a row's first match: its ASCII tiles keep the row lanes' scan -- scanning every unit cost more
+        // than the balance won --, the unit route serves its tiles with bytes >= 0x80, which the row lanes' scan cannot take)
+        if (lean && (D.units & 1u) && (MODE != 0 || hi_units)) {  // (wave-uniform)
           constexpr int KIND = MODE == 0 ? cstd::Tdfa::K_CONTAINS : cstd::Tdfa::K_COUNT;
           uint32_t m0, m1, m2;
           const int total_units = unit_discover(D, bitmap, xbitmap, lead + rbeg, n, lane, uqueue, m0, m1, m2, [&] {
@@ -2423,7 +2425,11 @@ void scan(const cs_column* col, cs_regex* re, uint8_t* out8, int32_t* out32, int
     // the unit scan (k_tdfa_scan_stream<.., UNITS>): patterns whose tagged DFA offers the decomposition, rows within the masks
     // (count_re only: contains_re stops at a row's first match, and scanning every unit of the row cost more than the
     // balance won -- 3.87 against 2.66 ms on the 100M-row C3 column)
-    const bool units = !wide && MODE == 2 && (re->tdfa[31] & 1) != 0 && !tc.lng && tc.R == 64 && !getenv("CS_NO_UNITS");
+    // (... but the unit form of the kernel is taken for contains_re too when the pattern lets the unit route serve tiles with
+    // bytes >= 0x80 -- header word 31 bits 17 / 18 -- and a sample of the chars holds such bytes: ASCII tiles keep the row
+    // lanes' scan inside it, at a few per cent more than the plain form)
+    const bool units = !wide && (MODE == 2 || (MODE == 0 && ((re->tdfa[31] >> 17) & 3) != 0 && sample_has_high_bytes(col, s))) && (re->tdfa[31] & 1) != 0 &&
+                       !tc.lng && tc.R == 64 && !getenv("CS_NO_UNITS");
     const size_t lds = tp.lds_bytes + (size_t)(cap + 32 + (cap >> 3) + 32 + (units ? (cap >> 3) + 32 + kUnitQueue * 4 + 64 * 4 + 16 : 0)) * 4;
     if (tc.R && lds <= 150 * 1024) {
       ScanStreamArgs sa{};

@@ -12,3 +12,8 @@ for cname, c in (("ascii", plain), ("non-ascii", accent)):
         r = fn(c); del r; torch.cuda.synchronize(); t0 = time.perf_counter(); r = fn(c); torch.cuda.synchronize()
         print("%-10s %-26s %8.2f ms" % (cname, name, (time.perf_counter() - t0) * 1e3), flush=True); del r
 print("fallbacks", int(B.L.cs_fallback_count()))
+res8 = torch.empty(rows, dtype=torch.uint8, device="cuda")
+for cname, c in (("ascii", plain), ("non-ascii", accent)):
+    for name, pat in (("contains_re([0-9] quad)", P), ("contains_re(\\d quad)", B.IPV4)):
+        c.contains(pat, devptr=res8.data_ptr()); torch.cuda.synchronize(); t0 = time.perf_counter(); c.contains(pat, devptr=res8.data_ptr()); torch.cuda.synchronize()
+        print("%-10s %-26s %8.2f ms" % (cname, name, (time.perf_counter() - t0) * 1e3), flush=True)
