@@ -233,8 +233,10 @@ bool change_case_fast(const cs_column* col, unsigned bit, bool ascii_rule_ok, hi
     }
   }
   int64_t span = R ? max_span_rows(col, R, s) : 0;
-  if (!R && few_spans64_over(col, cstile::kPfBytes - 64, s) && !getenv("CS_NO_OUTLIER_TILES")) {
-    // all but a few 64-row tiles fit: the kernel maps the rows of the others a thread each
+  if (!R && !getenv("CS_NO_OUTLIER_TILES")) {
+    // no tile size fits every tile (one long row among short ones, or rows of hundreds of bytes throughout): 64-row tiles,
+    // the kernel maps a tile beyond the staging size with the whole wave, sixteen bytes a lane, straight from memory --
+    // row by row only when the tile holds non-ASCII bytes
     R = 64;
     span = cstile::kPfBytes - 64;
   }

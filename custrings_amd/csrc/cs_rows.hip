@@ -332,8 +332,8 @@ bool strip_write_tiles(const cs_column* in, const CharSet& set, int side, const 
     }
   }
   int64_t span = R ? max_span_rows(in, R, s) : 0;
-  if (!R && few_spans64_over(in, cstile::kPfBytes - 64, s) && !getenv("CS_NO_OUTLIER_TILES")) {
-    R = 64;  // all but a few 64-row tiles fit: the kernel copies the rows of the others straight from memory
+  if (!R && !getenv("CS_NO_OUTLIER_TILES")) {
+    R = 64;  // no tile size fits every tile: the kernel copies the rows of a tile beyond the staging size straight from memory, long rows by the whole wave
     span = cstile::kPfBytes - 64;
   }
   if (!R) return false;

@@ -683,6 +683,11 @@ def test_gpu_one_long_row_among_short_ones_stays_on_the_tile_kernels(gpu_engine,
     assert int(_lib.lib.cs_fallback_count()) == f0
     for chars in (None, " GETtailrow8.", "Ü"):
         assert g.strip(s, chars) == o.strip(s, chars), chars
+    # rows of hundreds of bytes throughout (no tile size fits any tile): the same paths for every tile
+    wide = [_log_like(rnd2, 300, 600, nonascii_every=7, idx=i) for i, rnd2 in ((i, random.Random(i)) for i in range(700))] + [None, "", "Ü" * 300]
+    assert g.lower(wide) == o.lower(wide) and g.upper(wide) == o.upper(wide)
+    assert g.strip(wide, None) == o.strip(wide, None)
+    assert g.tokenize(wide) == o.tokenize(wide)
     # tokenize: an oversize tile is walked in segments of the staging size, state carried across (whitespace, a delimiter set)
     assert g.tokenize(s) == o.tokenize(s)
     assert g.tokenize(s, " /.") == o.tokenize(s, " /.")
