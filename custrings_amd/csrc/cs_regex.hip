@@ -2381,15 +2381,21 @@ struct TileChoice {
   int R, cap;
   bool lng;
 };
-TileChoice choose_tile(const cs_column* col, hipStream_t s) {
+// `small`: also tiles of eight and four rows, also for rows beyond the sliding window (replace_re: its alternative is the
+// two-pass thread-per-row kernels; the scans' row-wise kernels beat such tiles: contains_re 1.9 against 4.6 ms, findall 27
+// against 64 ms on 520-byte rows)
+TileChoice choose_tile(const cs_column* col, hipStream_t s, bool small = false) {
   const int64_t longest = max_row_bytes(col, s);
   auto cap_of = [](int64_t span) { return (int64_t)((span + 15 + 32 + 127) & ~(int64_t)127); };
   const int64_t cap64 = cap_of(max_span64(col, s));
   const bool fits64 = cap64 <= cstile::kPfBytes;
   if (fits64 && longest + 3 <= cstd::Tdfa::kMaskBytes) return {64, (int)cap64, false};
-  if (longest > cstd::Tdfa::kLongBytes) return {fits64 ? 64 : 0, (int)cap64, false};  // (such tiles scan generically)
+  if (longest > cstd::Tdfa::kLongBytes && (fits64 || !small)) return {fits64 ? 64 : 0, (int)cap64, false};  // (such tiles scan generically)
   if (fits64) return {64, (int)cap64, true};
-  for (int r : {32, 16}) {
+  // (eight and four rows a tile: rows of hundreds of bytes -- few lanes of a wave hold a row then, but the rows still arrive
+  // through coalesced tiles and are scanned in LDS; the thread-per-row kernels read them byte by byte from memory)
+  for (int r : {32, 16, 8, 4}) {
+    if (r < 16 && !small) break;
     const int64_t c = cap_of(max_span_rows(col, r, s));
     if (c <= cstile::kPfBytes) return {r, (int)c, true};
   }
@@ -2635,7 +2641,7 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
       const int64_t rows = col->rows;
       const int64_t ntiles = (rows + cstile::kTileRows - 1) / cstile::kTileRows;
       const int64_t nsub = ntiles * 4;
-      TileChoice tc = choose_tile(col, s);
+      TileChoice tc = choose_tile(col, s, !getenv("CS_NO_SMALL_TILES"));
       // (the column's largest 64-row span does not fit, all but a few do: buffers for those, the kernel handles the rest)
       bool outliers = false;
       constexpr int64_t kOutlierSpan = cstile::kPfBytes - 176;  // (its capacity is kPfBytes)

@@ -688,6 +688,13 @@ def test_gpu_one_long_row_among_short_ones_stays_on_the_tile_kernels(gpu_engine,
     assert g.lower(wide) == o.lower(wide) and g.upper(wide) == o.upper(wide)
     assert g.strip(wide, None) == o.strip(wide, None)
     assert g.tokenize(wide) == o.tokenize(wide)
+    # replace_re: tiles of eight / four rows through the stream kernel (rows beyond the sliding window scan generically)
+    f1 = int(_lib.lib.cs_fallback_count())
+    huge = [_log_like(random.Random(1000 + i), 900, 1300) for i in range(300)]
+    for col in (wide, huge):
+        for pat, repl in ((IPV4, "<IP>"), (r"[a-c]+", ""), (r"\d+", "<number>")):
+            assert g.replace_re(col, pat, repl, -1) == o.replace_re(col, pat, repl, -1), (len(col), pat)
+    assert int(_lib.lib.cs_fallback_count()) == f1
     # tokenize: an oversize tile is walked in segments of the staging size, state carried across (whitespace, a delimiter set)
     assert g.tokenize(s) == o.tokenize(s)
     assert g.tokenize(s, " /.") == o.tokenize(s, " /.")
