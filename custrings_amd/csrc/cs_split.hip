@@ -125,10 +125,11 @@ struct SubTile {
   bool live;
 };
 // loads the sub-tile's row extents and stages its chars span into `lds_in`
-__device__ __forceinline__ SubTile load_subtile(const ColView& in, long long sub, uint8_t* lds_in, int lane) {
+// (`R` rows a sub-tile: 64, or fewer for the first-generation kernels on rows of hundreds of bytes)
+__device__ __forceinline__ SubTile load_subtile(const ColView& in, long long sub, uint8_t* lds_in, int lane, int R = kSub) {
   SubTile t;
-  t.r0 = sub * kSub;
-  t.nrows = (int)min((long long)kSub, in.rows - t.r0);
+  t.r0 = sub * R;
+  t.nrows = (int)min((long long)R, in.rows - t.r0);
   const long long o0 = in.offsets[t.r0 + min(lane, t.nrows)];
   const long long o1 = in.offsets[t.r0 + min(lane + 1, t.nrows)];
   t.g0 = rl64(o0, 0);
@@ -311,6 +312,7 @@ struct MeasureArgs {
   int dlen;
   int tokens, cap;
   long long nsub;
+  int rows_per_sub;  // 64, 32, 16 or 8
   int32_t* colsum;  // [kMaxColsWide][nsub]
   int* max_count;   // [0] most tokens in a row, [1] most bytes one column receives from one sub-tile, [2] longest row,
                     // [3] set when a sub-tile needs the generic kernels (whitespace mode: a row beyond the 96-bit masks)
@@ -324,7 +326,7 @@ __global__ void __launch_bounds__(256) k_split_measure(MeasureArgs a) {
   uint8_t* lds_in = reinterpret_cast<uint8_t*>(smem) + (size_t)wv * (a.cap + 32);
   const long long sub = (long long)blockIdx.x * 4 + wv;
   if (sub >= a.nsub) return;
-  SubTile t = load_subtile(a.in, sub, lds_in, lane);
+  SubTile t = load_subtile(a.in, sub, lds_in, lane, a.rows_per_sub);
   TokensT<false, WS, MULTI> tk(lds_in, t.lead + t.rbeg, t.n, t.live, a.dpat, a.tokens, a.d64, a.dlen);
   if ((WS || MULTI) && !tk.masked) {
     if (lane == 0) atomicMax(a.max_count + 3, 1);
@@ -482,6 +484,7 @@ struct ColOut {
 struct EmitArgs {
   ColView in;
   uint32_t dpat;
+  int rows_per_sub;
   int tokens, cap_in, cap_out, ncols;
   long long nsub;
   const ColOut* cols;
@@ -495,7 +498,7 @@ __global__ void __launch_bounds__(256) k_split_emit(EmitArgs a) {
   uint8_t* lds_out = lds_in + a.cap_in + 32;
   const long long sub = (long long)blockIdx.x * 4 + wv;
   if (sub >= a.nsub) return;
-  SubTile t = load_subtile(a.in, sub, lds_in, lane);
+  SubTile t = load_subtile(a.in, sub, lds_in, lane, a.rows_per_sub);
   // lane k holds column k's destination for this sub-tile
   uint8_t* my_chars = nullptr;
   Off* my_off = nullptr;
@@ -531,7 +534,11 @@ __global__ void __launch_bounds__(256) k_split_emit(EmitArgs a) {
     if (lane < t.nrows) coff[t.r0 + lane] = (Off)(cbase + pre);
     if (last_tile && lane == t.nrows - 1) coff[a.in.rows] = (Off)(cbase + incl);
     const unsigned long long vmask = __ballot(has);
-    if (lane == 0) *reinterpret_cast<unsigned long long*>(cvalid + sub * 8) = vmask;
+    if (a.rows_per_sub == kSub) {
+      if (lane == 0) *reinterpret_cast<unsigned long long*>(cvalid + sub * 8) = vmask;
+    } else if (lane < a.rows_per_sub / 8) {  // (32 / 16 / 8 rows: four / two / one validity bytes)
+      cvalid[sub * (a.rows_per_sub / 8) + lane] = (uint8_t)(vmask >> (8 * lane));
+    }
     if (has) cstile::lds_copy_short(lds_out, cstart + pre, lds_in, t.lead + t.rbeg + lo, len);
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1046,9 +1053,24 @@ bool split_fast(const cs_column* col, const unsigned char* delim, int dlen, int 
   for (int i = 0; !ws && i < dlen; ++i) d64 |= (unsigned long long)delim[i] << (8 * i);
   const int64_t rows = col->rows;
   if (rows == 0 || getenv("CS_SPLIT_GENERIC")) return false;
-  const int64_t span = max_span64(col, s);
-  const int cap_in = (int)((span + 15 + 32 + 127) & ~(int64_t)127);
-  const int cap_out = cap_in + 32 * kMaxColsWide;
+  int64_t span = max_span64(col, s);
+  int cap_in = (int)((span + 15 + 32 + 127) & ~(int64_t)127);
+  int cap_out = cap_in + 32 * kMaxColsWide;
+  // (rows of hundreds of bytes: the first-generation kernels on sub-tiles of 32 / 16 / 8 rows -- a one-byte delimiter only)
+  int rows_per_sub = kSub;
+  if ((size_t)(cap_in + cap_out + 64) * 4 > 150 * 1024 && mode == 0 && !reverse && !getenv("CS_NO_SMALL_TILES")) {
+    for (int r : {32, 16, 8}) {
+      const int64_t sp = max_span_rows(col, r, s);
+      const int ci = (int)((sp + 15 + 32 + 127) & ~(int64_t)127);
+      if ((size_t)(ci + ci + 32 * kMaxColsWide + 64) * 4 <= 150 * 1024) {
+        rows_per_sub = r;
+        span = sp;
+        cap_in = ci;
+        cap_out = ci + 32 * kMaxColsWide;
+        break;
+      }
+    }
+  }
   if ((size_t)(cap_in + cap_out + 64) * 4 > 150 * 1024) return false;
   const int64_t nsub = (rows + kSub - 1) / kSub;
   const uint32_t dpat = 0x01010101u * (ws ? 0u : (uint32_t)delim[0]);
@@ -1056,7 +1078,7 @@ bool split_fast(const cs_column* col, const unsigned char* delim, int dlen, int 
   int* hmx = (int*)pinned_scratch(4 * sizeof(int));
 
   // ---- second generation: runs of sub-tiles per wave (rows up to 93 bytes, 64-row spans up to 6 KB)
-  if (cap_in <= cstile::kPfBytes && !getenv("CS_SPLIT_OLD_EMIT")) {
+  if (rows_per_sub == kSub && cap_in <= cstile::kPfBytes && !getenv("CS_SPLIT_OLD_EMIT")) {
     // The run decomposition is a function of the row count alone (not of the emit kernel's
     // residency, which depends on what the measure pass finds): emit needs no co-residency.
     int dev = 0, cus = 0;
@@ -1173,11 +1195,12 @@ bool split_fast(const cs_column* col, const unsigned char* delim, int dlen, int 
   }
 
   // ---- first generation (one-byte delimiter; rows beyond 93 bytes, wide tiles): one sub-tile per wave
-  const unsigned grid = (unsigned)((nsub + 3) / 4);
-  Buf colsum = dev_alloc(sizeof(int32_t) * nsub * kMaxColsWide, s);
-  CS_HIP(hipMemsetAsync(colsum->p, 0, sizeof(int32_t) * nsub * kMaxColsWide, s));  // columns a sub-tile never reaches
+  const int64_t nsub1 = (rows + rows_per_sub - 1) / rows_per_sub;  // (sub-tiles of rows_per_sub rows)
+  const unsigned grid = (unsigned)((nsub1 + 3) / 4);
+  Buf colsum = dev_alloc(sizeof(int32_t) * nsub1 * kMaxColsWide, s);
+  CS_HIP(hipMemsetAsync(colsum->p, 0, sizeof(int32_t) * nsub1 * kMaxColsWide, s));  // columns a sub-tile never reaches
   CS_HIP(hipMemsetAsync(mx->p, 0, 4 * sizeof(int), s));
-  MeasureArgs ma{view_of(col), dpat, d64, dlen, tokens, cap_in, nsub, ptr<int32_t>(colsum), ptr<int>(mx)};
+  MeasureArgs ma{view_of(col), dpat, d64, dlen, tokens, cap_in, nsub1, rows_per_sub, ptr<int32_t>(colsum), ptr<int>(mx)};
   {
     ProfScope ps("k_split_measure", s);
     hipLaunchKernelGGL(k_split_measure<0>, dim3(grid), dim3(256), (size_t)(cap_in + 32) * 4, s, ma);
@@ -1189,9 +1212,9 @@ bool split_fast(const cs_column* col, const unsigned char* delim, int dlen, int 
   if (ncols == 0 || ncols > kMaxColsWide) return false;  // all-null column / too many columns: generic path
 
   // per column: position of every sub-tile in the column's chars buffer
-  Buf base = dev_alloc(sizeof(int64_t) * (nsub + 1) * ncols, s);
+  Buf base = dev_alloc(sizeof(int64_t) * (nsub1 + 1) * ncols, s);
   std::vector<int64_t> totals(ncols);
-  offsets_from_lengths_segmented(ptr<int32_t>(colsum), nsub, ncols, ptr<int64_t>(base), totals.data(), s);
+  offsets_from_lengths_segmented(ptr<int32_t>(colsum), nsub1, ncols, ptr<int64_t>(base), totals.data(), s);
 
   // int32 offsets (as the later generations write them) when every column stays below 2 GiB: half the offset bytes
   bool off32 = !getenv("CS_SPLIT_OFF64");
@@ -1206,12 +1229,12 @@ bool split_fast(const cs_column* col, const unsigned char* delim, int dlen, int 
     else c->offsets = dev_alloc(sizeof(int64_t) * (rows + 1), s);
     c->validity = dev_alloc(validity_bytes(rows), s);
     outs[k] = ColOut{ptr<uint8_t>(c->chars), off32 ? c->offsets32->p : c->offsets->p, ptr<uint8_t>(c->validity),
-                     ptr<const int64_t>(base) + (int64_t)k * (nsub + 1)};
+                     ptr<const int64_t>(base) + (int64_t)k * (nsub1 + 1)};
     cols.push_back(std::move(c));
   }
   Buf d_outs = dev_alloc(sizeof(ColOut) * ncols, s);
   CS_HIP(hipMemcpyAsync(d_outs->p, outs.data(), sizeof(ColOut) * ncols, hipMemcpyHostToDevice, s));
-  EmitArgs ea{view_of(col), dpat, tokens, cap_in, cap_out, ncols, nsub, ptr<const ColOut>(d_outs)};
+  EmitArgs ea{view_of(col), dpat, rows_per_sub, tokens, cap_in, cap_out, ncols, nsub1, ptr<const ColOut>(d_outs)};
   const size_t lds = (size_t)(cap_in + cap_out + 64) * 4;
   auto kern = off32 ? &k_split_emit<true> : &k_split_emit<false>;
   if (lds > 48 * 1024) CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -688,6 +688,10 @@ def test_gpu_one_long_row_among_short_ones_stays_on_the_tile_kernels(gpu_engine,
     assert g.lower(wide) == o.lower(wide) and g.upper(wide) == o.upper(wide)
     assert g.strip(wide, None) == o.strip(wide, None)
     assert g.tokenize(wide) == o.tokenize(wide)
+    # split: the first-generation tile kernels on sub-tiles of 32 / 16 / 8 rows
+    for col in (wide, [_log_like(random.Random(2000 + i), 900, 1300) for i in range(300)] + [None, ""]):
+        for delim, n in ((" ", 8), (" ", 3), (".", -1), ("/", 5)):
+            assert g.split(col, delim, n) == o.split(col, delim, n), (len(col), delim, n)
     # replace_re: tiles of eight / four rows through the stream kernel (rows beyond the sliding window scan generically)
     f1 = int(_lib.lib.cs_fallback_count())
     huge = [_log_like(random.Random(1000 + i), 900, 1300) for i in range(300)]
