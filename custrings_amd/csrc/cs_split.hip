@@ -123,10 +123,13 @@ struct SubTile {
   long long r0, g0;
   int nrows, rbeg, n, lead;
   bool live;
+  bool oversize;  // the span does not fit the staging buffer: nothing staged, the rows are read from memory
 };
 // loads the sub-tile's row extents and stages its chars span into `lds_in`
 // (`R` rows a sub-tile: 64, or fewer for the first-generation kernels on rows of hundreds of bytes)
-__device__ __forceinline__ SubTile load_subtile(const ColView& in, long long sub, uint8_t* lds_in, int lane, int R = kSub) {
+// `cap` > 0: the staging buffer's bytes -- a sub-tile beyond it is not staged (first-generation kernels: the host sized the
+// buffers for all but a few sub-tiles, one long row among millions of short ones)
+__device__ __forceinline__ SubTile load_subtile(const ColView& in, long long sub, uint8_t* lds_in, int lane, int R = kSub, int cap = 0) {
   SubTile t;
   t.r0 = sub * R;
   t.nrows = (int)min((long long)R, in.rows - t.r0);
@@ -139,7 +142,9 @@ __device__ __forceinline__ SubTile load_subtile(const ColView& in, long long sub
   t.n = t.live ? (int)(o1 - o0) : 0;
   t.lead = (int)((uintptr_t)(in.chars + t.g0) & 15);
   const uint8_t* src = in.chars + (t.g0 - t.lead);  // 16-byte aligned
-  const int span = (int)(g1 - t.g0) + t.lead;
+  const long long span64 = g1 - t.g0 + t.lead;
+  t.oversize = cap > 0 && span64 + 32 > cap;
+  const int span = t.oversize ? 0 : (int)span64;
   for (int i = lane * 16; i < span; i += 64 * 16)
     *reinterpret_cast<uint4*>(lds_in + i) = *reinterpret_cast<const uint4*>(src + i);
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -326,8 +331,10 @@ __global__ void __launch_bounds__(256) k_split_measure(MeasureArgs a) {
   uint8_t* lds_in = reinterpret_cast<uint8_t*>(smem) + (size_t)wv * (a.cap + 32);
   const long long sub = (long long)blockIdx.x * 4 + wv;
   if (sub >= a.nsub) return;
-  SubTile t = load_subtile(a.in, sub, lds_in, lane, a.rows_per_sub);
-  TokensT<false, WS, MULTI> tk(lds_in, t.lead + t.rbeg, t.n, t.live, a.dpat, a.tokens, a.d64, a.dlen);
+  SubTile t = load_subtile(a.in, sub, lds_in, lane, a.rows_per_sub, a.cap);
+  // (an oversize sub-tile: the token walk reads the rows from memory through the same aligned words)
+  const uint8_t* rows_at = t.oversize ? a.in.chars + (t.g0 - t.lead) : lds_in;
+  TokensT<false, WS, MULTI> tk(rows_at, t.lead + t.rbeg, t.n, t.live, a.dpat, a.tokens, a.d64, a.dlen);
   if ((WS || MULTI) && !tk.masked) {
     if (lane == 0) atomicMax(a.max_count + 3, 1);
     return;
@@ -498,7 +505,7 @@ __global__ void __launch_bounds__(256) k_split_emit(EmitArgs a) {
   uint8_t* lds_out = lds_in + a.cap_in + 32;
   const long long sub = (long long)blockIdx.x * 4 + wv;
   if (sub >= a.nsub) return;
-  SubTile t = load_subtile(a.in, sub, lds_in, lane, a.rows_per_sub);
+  SubTile t = load_subtile(a.in, sub, lds_in, lane, a.rows_per_sub, a.cap_in);
   // lane k holds column k's destination for this sub-tile
   uint8_t* my_chars = nullptr;
   Off* my_off = nullptr;
@@ -519,7 +526,8 @@ __global__ void __launch_bounds__(256) k_split_emit(EmitArgs a) {
   const int padded = lane < a.ncols ? ((my_lead + my_sum + 15) & ~15) : 0;
   const int region = wave_inclusive_scan(padded) - padded;
 
-  Tokens tk(lds_in, t.lead + t.rbeg, t.n, t.live, a.dpat, a.tokens);
+  const uint8_t* rows_at = t.oversize ? a.in.chars + (t.g0 - t.lead) : lds_in;
+  Tokens tk(rows_at, t.lead + t.rbeg, t.n, t.live, a.dpat, a.tokens);
   const bool last_tile = t.r0 + t.nrows == a.in.rows;
   for (int k = 0; k < a.ncols; ++k) {
     int lo = 0, hi = 0;
@@ -539,8 +547,23 @@ __global__ void __launch_bounds__(256) k_split_emit(EmitArgs a) {
     } else if (lane < a.rows_per_sub / 8) {  // (32 / 16 / 8 rows: four / two / one validity bytes)
       cvalid[sub * (a.rows_per_sub / 8) + lane] = (uint8_t)(vmask >> (8 * lane));
     }
-    if (has) cstile::lds_copy_short(lds_out, cstart + pre, lds_in, t.lead + t.rbeg + lo, len);
+    if (t.oversize) {
+      // straight to the column's chars: a short token by its lane, a long one (the rest of a long row) by the whole wave
+      uint8_t* cchars = reinterpret_cast<uint8_t*>(rl64((long long)(uintptr_t)my_chars, k)) + cbase;
+      const uint8_t* src = a.in.chars + (t.g0 + t.rbeg + lo);
+      if (has && len <= 256)
+        for (int i = 0; i < len; ++i) cchars[pre + i] = src[i];
+      for (unsigned long long m = __ballot(has && len > 256); m; m &= m - 1) {
+        const int l = __builtin_ctzll(m);
+        const long long sp = rl64((long long)(t.g0 + t.rbeg + lo), l);
+        const int dp = rl(pre, l), L = rl(len, l);
+        for (int i = lane; i < L; i += 64) cchars[dp + i] = a.in.chars[sp + i];
+      }
+    } else if (has) {
+      cstile::lds_copy_short(lds_out, cstart + pre, lds_in, t.lead + t.rbeg + lo, len);
+    }
   }
+  if (t.oversize) return;  // (nothing assembled in LDS)
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -1058,6 +1081,7 @@ bool split_fast(const cs_column* col, const unsigned char* delim, int dlen, int 
   int cap_out = cap_in + 32 * kMaxColsWide;
   // (rows of hundreds of bytes: the first-generation kernels on sub-tiles of 32 / 16 / 8 rows -- a one-byte delimiter only)
   int rows_per_sub = kSub;
+  bool outliers = false;
   if ((size_t)(cap_in + cap_out + 64) * 4 > 150 * 1024 && mode == 0 && !reverse && !getenv("CS_NO_SMALL_TILES")) {
     for (int r : {32, 16, 8}) {
       const int64_t sp = max_span_rows(col, r, s);
@@ -1071,6 +1095,17 @@ bool split_fast(const cs_column* col, const unsigned char* delim, int dlen, int 
       }
     }
   }
+  // (no sub-tile size fits the largest sub-tile, all but a few 64-row ones fit: the first-generation kernels with buffers
+  // for those -- they read the rows of an oversize sub-tile from memory and write its tokens straight to the columns)
+  // (also when the largest sub-tile would fit, at one workgroup per CU: a 10 KB row among short ones ran 39 ms that way)
+  if (rows_per_sub == kSub && cap_in > 8 * 1024 && mode == 0 && !reverse && !getenv("CS_NO_OUTLIER_TILES") && max_span64(col, s) < ((int64_t)1 << 30) &&
+      few_spans64_over(col, 8 * 1024 - 64, s)) {
+    rows_per_sub = kSub;
+    span = 8 * 1024 - 64;
+    cap_in = (int)((span + 15 + 32 + 127) & ~(int64_t)127);
+    cap_out = cap_in + 32 * kMaxColsWide;
+    outliers = true;
+  }
   if ((size_t)(cap_in + cap_out + 64) * 4 > 150 * 1024) return false;
   const int64_t nsub = (rows + kSub - 1) / kSub;
   const uint32_t dpat = 0x01010101u * (ws ? 0u : (uint32_t)delim[0]);
@@ -1078,7 +1113,7 @@ bool split_fast(const cs_column* col, const unsigned char* delim, int dlen, int 
   int* hmx = (int*)pinned_scratch(4 * sizeof(int));
 
   // ---- second generation: runs of sub-tiles per wave (rows up to 93 bytes, 64-row spans up to 6 KB)
-  if (rows_per_sub == kSub && cap_in <= cstile::kPfBytes && !getenv("CS_SPLIT_OLD_EMIT")) {
+  if (rows_per_sub == kSub && !outliers && cap_in <= cstile::kPfBytes && !getenv("CS_SPLIT_OLD_EMIT")) {
     // The run decomposition is a function of the row count alone (not of the emit kernel's
     // residency, which depends on what the measure pass finds): emit needs no co-residency.
     int dev = 0, cus = 0;

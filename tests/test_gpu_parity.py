@@ -704,7 +704,7 @@ def test_gpu_one_long_row_among_short_ones_stays_on_the_tile_kernels(gpu_engine,
     assert g.tokenize(s, " /.") == o.tokenize(s, " /.")
     long_only = [("word%d " % i) * 3000 for i in range(70)] + [None, "", "x"]  # every tile oversize
     assert g.tokenize(long_only) == o.tokenize(long_only)
-    # split: such a column takes the thread-per-row kernels (the tile kernels' out tiles cannot hold a long row's tokens)
+    # split: the first-generation tile kernels read an oversize sub-tile.s rows from memory and write its tokens straight to the columns
     for delim, n in ((" ", 5), (" ", 1), ("#", -1), (".", 3), (None, 4)):
         assert g.split(s, delim, n) == o.split(s, delim, n), (delim, n)
     assert g.rsplit(s, " ", 3) == o.rsplit(s, " ", 3)
