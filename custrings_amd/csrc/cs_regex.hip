@@ -1467,7 +1467,25 @@ __global__ void __launch_bounds__(256, BREFS ? 2 : CS_STREAM_WAVES) k_tdfa_repla
           units_done = true;
         }
       } else if (UNITS) {
-        if (lean && a.maxrepl < 0 && (D.units & 1u) && !(a.debug & 1024)) {  // (wave-uniform)
+        if (!BREFS && lean && !has_odd && a.maxrepl < 0 && (D.chain >> 16) && !(a.debug & 8192)) {  // (wave-uniform)
+          // A chain pattern (regex_tdfa.h: chain_match) on a sub-tile of plain ASCII: every row lane derives its row's
+          // matches from the row's candidate and x bits by integer arithmetic -- no unit queue, no table walk, no LDS
+          // traffic beyond the two mask reads.
+          using namespace cstd;
+          uint32_t r0, r1, r2, x0 = 0, x1 = 0, x2 = 0;
+          cstile::row_bits96(bitmap, lead + rbeg, n, r0, r1, r2);
+          if (unit_x != 0) cstile::row_bits96(xbitmap, lead + rbeg, n, x0, x1, x2);
+          p_second = cstile::status_load(a.excl + (p_tile >= 0 ? p_tile : 0));
+          has_second = scanner;
+          if (live) {
+            chain_match(u128(r0 | ((unsigned long long)r1 << 32), r2), u128(x0 | ((unsigned long long)x1 << 32), x2), D.chain, uS, uE);
+            nm = u128_popc(uS);
+            out_len = n - u128_popc(u128_sub(u128_shl1(uE), uS)) + nm * rb;
+            from_masks = true;
+          }
+          redo = false;
+          units_done = true;
+        } else if (lean && a.maxrepl < 0 && (D.units & 1u) && !(a.debug & 1024)) {  // (wave-uniform)
           using namespace cstd;
           // -- row lanes: the row's units from its candidate and x bits
           uint32_t m0, m1, m2;
@@ -2136,7 +2154,25 @@ __global__ void __launch_bounds__(256, ((UNITS && MODE == 3) || MODE == 4) ? 3 :
       if (UNITS && MODE == 3) {
         // findall: the units leave each match's first and last byte in the two bitmaps (as in the replace kernel);
         // the row lanes read their matches back in order
-        if (lean && (D.units & 1u)) {  // (wave-uniform)
+        if (lean && !has_odd && (D.chain >> 16)) {  // (wave-uniform) a chain pattern on plain ASCII: regex_tdfa.h, chain_match
+          using namespace cstd;
+          uint32_t r0, r1, r2, x0 = 0, x1 = 0, x2 = 0;
+          cstile::row_bits96(bitmap, lead + rbeg, n, r0, r1, r2);
+          if (unit_x != 0) cstile::row_bits96(xbitmap, lead + rbeg, n, x0, x1, x2);
+          if (live) {
+            U128 S, E;
+            chain_match(u128(r0 | ((unsigned long long)r1 << 32), r2), u128(x0 | ((unsigned long long)x1 << 32), x2), D.chain, S, E);
+            while (u128_any(S)) {
+              const int mb = u128_ctz(S), me = u128_ctz(E) + 1;
+              S = u128_clear_lowest(S);
+              E = u128_clear_lowest(E);
+              span(mb, me, 0);
+            }
+            v = k;
+          }
+          redo = false;
+          units_done = true;
+        } else if (lean && (D.units & 1u)) {  // (wave-uniform)
           using namespace cstd;
           uint32_t m0, m1, m2;
           const int total_units = unit_discover(D, bitmap, xbitmap, lead + rbeg, n, lane, uqueue, m0, m1, m2, [&] {
@@ -2187,7 +2223,22 @@ __global__ void __launch_bounds__(256, ((UNITS && MODE == 3) || MODE == 4) ? 3 :
       } else if (UNITS) {
         // (contains_re stops at a row's first match: its ASCII tiles keep the row lanes' scan -- scanning every unit cost more
         // than the balance won --, the unit route serves its tiles with bytes >= 0x80, which the row lanes' scan cannot take)
-        if (lean && (D.units & 1u) && (MODE != 0 || hi_units)) {  // (wave-uniform)
+        if (lean && !has_odd && (D.chain >> 16)) {  // (wave-uniform) a chain pattern on plain ASCII: regex_tdfa.h, chain_match
+          using namespace cstd;
+          uint32_t r0, r1, r2, x0 = 0, x1 = 0, x2 = 0;
+          cstile::row_bits96(bitmap, lead + rbeg, n, r0, r1, r2);
+          if (unit_x != 0) cstile::row_bits96(xbitmap, lead + rbeg, n, x0, x1, x2);
+          const U128 R = u128(r0 | ((unsigned long long)r1 << 32), r2), X = u128(x0 | ((unsigned long long)x1 << 32), x2);
+          if (MODE == 0) {
+            v = live && u128_any(chain_ends(R, X, D.chain)) ? 1 : 0;
+          } else {
+            U128 S = u128(0, 0), E;
+            if (live) chain_match(R, X, D.chain, S, E);
+            v = u128_popc(S);
+          }
+          redo = false;
+          units_done = true;
+        } else if (lean && (D.units & 1u) && (MODE != 0 || hi_units)) {  // (wave-uniform)
           constexpr int KIND = MODE == 0 ? cstd::Tdfa::K_CONTAINS : cstd::Tdfa::K_COUNT;
           uint32_t m0, m1, m2;
           const int total_units = unit_discover(D, bitmap, xbitmap, lead + rbeg, n, lane, uqueue, m0, m1, m2, [&] {
@@ -2434,6 +2485,8 @@ void scan(const cs_column* col, cs_regex* re, uint8_t* out8, int32_t* out32, int
     // (... but the unit form of the kernel is taken for contains_re too when the pattern lets the unit route serve tiles with
     // bytes >= 0x80 -- header word 31 bits 17 / 18 -- and a sample of the chars holds such bytes: ASCII tiles keep the row
     // lanes' scan inside it, at a few per cent more than the plain form)
+    // (chain patterns -- header words 29 / 30 -- were tried on the unit form for contains_re as well: 2.18 against 2.10 ms; the
+    // plain form's first-match scan stays)
     const bool units = !wide && (MODE == 2 || (MODE == 0 && ((re->tdfa[31] >> 17) & 3) != 0 && sample_has_high_bytes(col, s))) && (re->tdfa[31] & 1) != 0 &&
                        !tc.lng && tc.R == 64 && !getenv("CS_NO_UNITS");
     const size_t lds = tp.lds_bytes + (size_t)(cap + 32 + (cap >> 3) + 32 + (units ? (cap >> 3) + 32 + kUnitQueue * 4 + 64 * 4 + 16 : 0)) * 4;

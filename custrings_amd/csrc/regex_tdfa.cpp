@@ -3,6 +3,7 @@
 #include "regex_tdfa.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <map>
 #include <vector>
 
@@ -569,6 +570,67 @@ std::vector<int32_t> build_tdfa(const Program& prog, const std::vector<int32_t>&
       }
     }
     img[31] = word;
+    // The CHAIN form (regex_tdfa.h: chain_match), offered beside the unit decomposition: the program is a straight line
+    // of single-character items -- a literal or a class, taken once or in a greedy `+` loop, brackets ignored -- every
+    // item's ASCII members are exactly the candidate ranges (class R) or exactly the byte x, neighbours differ, the first
+    // is R, and the last is repeated when it is R as well.  Then a plain-ASCII row's matches follow from its two
+    // per-byte masks by integer arithmetic alone.
+    if ((word & 1) && !B.use_word && !B.use_line && !getenv("CS_NO_CHAIN")) {
+      const int x = (word >> 8) & 127;
+      uint32_t items = 0;
+      int ni = 0;
+      size_t seen = 0;
+      bool ok = true;
+      int pc = prog.start_inst, prev_cls = -1;
+      while (ok) {
+        if (pc < 0 || (size_t)pc >= prog.insts.size() || seen > prog.insts.size()) {
+          ok = false;
+          break;
+        }
+        const Inst& in = prog.insts[(size_t)pc];
+        ++seen;
+        if (in.type == OP_END) break;
+        if (in.type == OP_LBRA || in.type == OP_RBRA) {
+          pc = in.u2;
+          continue;
+        }
+        if (in.type != OP_CHAR && in.type != OP_CCLASS) {
+          ok = false;
+          break;
+        }
+        // the item's ASCII members against R and against {x}
+        bool is_r = true, is_x = x != 0;
+        for (int c = 1; c < 128; ++c) {
+          const bool m = in.type == OP_CHAR ? (uint32_t)in.u1 == (uint32_t)c : csvm::class_match(B.V, in.u1, (csvm::Char)c);
+          is_r = is_r && m == in_ranges(c);
+          is_x = is_x && m == (c == x);
+        }
+        if (in.type == OP_CHAR && (uint32_t)in.u1 >= 128u) is_r = is_x = false;
+        const int cls = is_r ? 0 : (is_x ? 1 : -1);
+        if (cls < 0 || cls == prev_cls || (ni == 0 && cls != 0) || ni == 8) {
+          ok = false;
+          break;
+        }
+        bool plus = false;
+        int next = in.u2;
+        if (next >= 0 && (size_t)next < prog.insts.size() && prog.insts[(size_t)next].type == OP_OR && prog.insts[(size_t)next].u1 == pc) {
+          plus = true;  // (the preferred branch of the OR goes back to the item: a greedy loop)
+          ++seen;
+          next = prog.insts[(size_t)next].u2;
+        }
+        items |= (uint32_t)(cls | (plus ? 2 : 0)) << (2 * ni);
+        ++ni;
+        prev_cls = cls;
+        pc = next;
+      }
+      // (every instruction on the line: an alternation or an optional part would leave some unvisited)
+      ok = ok && ni > 0 && seen == prog.insts.size();
+      if (ok && (items >> (2 * (ni - 1)) & 1u) == 0 && !((items >> (2 * (ni - 1) + 1)) & 1u)) ok = false;  // R ... R: the tail repeated
+      if (ok) {
+        img[29] |= (int32_t)(items << 16);
+        img[30] |= (int32_t)((uint32_t)ni << 16);
+      }
+    }
   }
   img[15] = (int32_t)img.size();
   if (groups_out && ngroups > 0 && maxslots <= kMaxSlots) {  // (the tag words hold four slots: wider programs track no groups on the DFA)

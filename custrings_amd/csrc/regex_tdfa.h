@@ -27,6 +27,9 @@
 //   [29] [30] two byte ranges (lo | hi << 8) that cover every candidate ASCII byte
 //        (a superset is fine: extra candidates just take the table path)
 //   [31] unit decomposition (regex_tdfa.cpp): bit 0 offered, bits 8..14 the byte x (0 = none), bit 16 = no match without an x
+//   [29] bits 16..31, [30] bits 16..19: the CHAIN form of the pattern (regex_tdfa.cpp; chain_match below): up to eight items,
+//        two bits each (bit 0: the item's class is the byte x instead of the candidate ranges, bit 1: repeated, `+`), and
+//        their number (0 = the pattern is no chain)
 //   INIT   : 3 modes x 8 categories state ids
 //   T1     : nstates x 128 entries (ASCII byte -> transition; byte 0 = embedded NUL)
 //   T2     : nstates x natoms entries (atom 0 = end of row, 1 = embedded NUL,
@@ -120,6 +123,86 @@ CS_HD U128 unit_ends(U128 C, U128 X, bool required, U128& N) {
 // first byte of the run of N that ends just below bit q
 CS_HD int unit_start(U128 N, int q) { return u128_msb(u128_andn(u128_below(q), N)) + 1; }
 
+// ---- chain patterns: every match of a row by bit arithmetic on two per-byte masks, no automaton ----
+// A CHAIN is a sequence of up to eight items, each one byte class taken once or repeated (`+`, greedy), where the class is
+// either R (exactly the ASCII bytes of the two candidate ranges) or the single byte x, neighbours differ, and the last item
+// is repeated when its class is the first one's: `\d+\.\d+\.\d+\.\d+`, `[a-z]+=`, `\d+`.  On a row of plain ASCII such a
+// pattern is deterministic: from a given start there is at most ONE match (a repeated item must take its whole run, the
+// next item's class being disjoint), a match exists from the middle of the first run iff it exists from the run's start, and
+// a later start ends later.  So (Parabix-style marker arithmetic, one marker set for ALL starts of the row at once):
+//   forward   M = run starts of R (every R byte when the first item is single); per item M = (M & C) << 1, and for a
+//             repeated one M = MatchStar(M, C) = (((M & C) + C) ^ C) | M; the ends are what is left (off C for a greedy tail)
+//   backward  the same walk over the bit-reversed masks from the ends: the starts that do reach an end
+//   pairing   the k-th start belongs to the k-th end; a match that begins inside the previous one is dropped (the scan
+//             of regexec.inl:204-442 resumes at the end of a match -- and that position is never inside a first run).
+// R, X: row-relative bits cut at the row length (rows of up to 96 bytes).  S / L receive a bit per match at its first /
+// last byte.  ~300 integer operations a row whatever it holds, against a table walk per candidate byte.
+#if !defined(__HIP_DEVICE_COMPILE__)
+inline int g_chain_host = 1;  // host builds (tests/rowemu): 0 keeps chain patterns on the unit route, so that both are checked
+#endif
+CS_HD U128 u128_xor(U128 a, U128 b) { return u128(a.lo ^ b.lo, a.hi ^ b.hi); }
+CS_HD U128 u128_shr1(U128 a) { return u128((a.lo >> 1) | (a.hi << 63), a.hi >> 1); }
+CS_HD unsigned long long u64_bitrev(unsigned long long v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __brevll(v);
+#else
+  v = ((v >> 1) & 0x5555555555555555ull) | ((v & 0x5555555555555555ull) << 1);
+  v = ((v >> 2) & 0x3333333333333333ull) | ((v & 0x3333333333333333ull) << 2);
+  v = ((v >> 4) & 0x0F0F0F0F0F0F0F0Full) | ((v & 0x0F0F0F0F0F0F0F0Full) << 4);
+  return __builtin_bswap64(v);
+#endif
+}
+// bit p -> bit 126 - p (p <= 126; its own inverse)
+CS_HD U128 u128_rev127(U128 a) { return u128_shr1(u128(u64_bitrev(a.hi), u64_bitrev(a.lo))); }
+CS_HD U128 chain_star(U128 M, U128 C) { return u128_or(u128_xor(u128_add(u128_and(M, C), C), C), M); }
+// the last byte of every match of the row, whatever its start (contains_re needs no more than "any")
+CS_HD U128 chain_ends(U128 R, U128 X, uint32_t chain) {
+  const int ni = (int)((chain >> 16) & 15u);
+  auto is_x = [&](int k) { return ((chain >> (2 * k)) & 1u) != 0; };
+  auto plus = [&](int k) { return ((chain >> (2 * k + 1)) & 1u) != 0; };
+  U128 M = plus(0) ? u128_andn(R, u128_shl1(R)) : R;
+  U128 C = R;
+  for (int k = 0; k < ni; ++k) {
+    C = is_x(k) ? X : R;
+    M = u128_shl1(u128_and(M, C));
+    if (plus(k)) M = chain_star(M, C);
+  }
+  if (plus(ni - 1)) M = u128_andn(M, C);
+  return u128_shr1(M);
+}
+CS_HD void chain_match(U128 R, U128 X, uint32_t chain, U128& S, U128& L) {
+  const int ni = (int)((chain >> 16) & 15u);
+  auto is_x = [&](int k) { return ((chain >> (2 * k)) & 1u) != 0; };
+  auto plus = [&](int k) { return ((chain >> (2 * k + 1)) & 1u) != 0; };
+  U128 Le = chain_ends(R, X, chain);
+  S = u128(0, 0);
+  L = u128(0, 0);
+  if (!u128_any(Le)) return;
+  U128 M, C = R;
+  // backward: the reversed chain over the reversed masks, from the ends
+  const U128 Rr = u128_rev127(R), Xr = u128_rev127(X);
+  M = u128_rev127(Le);
+  for (int k = ni - 1; k >= 0; --k) {
+    C = is_x(k) ? Xr : Rr;
+    M = u128_shl1(u128_and(M, C));
+    if (plus(k)) M = chain_star(M, C);
+  }
+  if (plus(0)) M = u128_andn(M, C);
+  U128 Sv = u128_rev127(u128_shr1(M));  // the starts that reach an end, as many as there are ends
+  int cursor = 0;
+  while (u128_any(Sv) && u128_any(Le)) {
+    const int s = u128_ctz(Sv), l = u128_ctz(Le);
+    const U128 sb = u128_andn(Sv, u128_clear_lowest(Sv)), lb = u128_andn(Le, u128_clear_lowest(Le));
+    Sv = u128_clear_lowest(Sv);
+    Le = u128_clear_lowest(Le);
+    if (s >= cursor) {
+      S = u128_or(S, sb);
+      L = u128_or(L, lb);
+      cursor = l + 1;
+    }
+  }
+}
+
 struct View {
   const int32_t* img;
   const uint32_t* init;
@@ -135,6 +218,7 @@ struct View {
   uint32_t r1lo, r1hi, r2lo, r2hi;  // SWAR constants of the two candidate ranges
   uint32_t skippack, cand0, cand1, cand2, cand3, word0, word1, word2, word3;
   uint32_t units;  // header word 31
+  uint32_t chain;  // bits 0..15 the items, bits 16..19 their number (header words 29 / 30, upper halves)
 };
 CS_HD View make_view(const int32_t* img) {
   View v;
@@ -164,6 +248,7 @@ CS_HD View make_view(const int32_t* img) {
   v.word2 = (uint32_t)img[27];
   v.word3 = (uint32_t)img[28];
   v.units = (uint32_t)img[31];
+  v.chain = (((uint32_t)img[29] >> 16) & 0xFFFFu) | ((((uint32_t)img[30] >> 16) & 15u) << 16);
   {
     const uint32_t lo1 = (uint32_t)img[29] & 255u, hi1 = ((uint32_t)img[29] >> 8) & 255u;
     const uint32_t lo2 = (uint32_t)img[30] & 255u, hi2 = ((uint32_t)img[30] >> 8) & 255u;
@@ -1167,9 +1252,31 @@ struct TdfaWide : Tdfa {
 // Row drivers for the tagged DFA: same contracts as the templates in regex_vm.h
 // (overloads, so call sites are engine-agnostic).
 namespace csvm {
+#if !defined(__HIP_DEVICE_COMPILE__)
+// host builds: a plain-ASCII row's matches by chain_match (the route of the stream kernels), or false
+inline bool row_chain_host(cstd::Tdfa& vm, cstd::U128& S, cstd::U128& L) {
+  if (!(vm.D.chain >> 16) || !cstd::g_chain_host || !vm.lean_ok()) return false;
+  uint32_t c0, c1, c2;
+  if (vm.has_range2()) vm.build_masks_lean<true>(c0, c1, c2);
+  else vm.build_masks_lean<false>(c0, c1, c2);
+  const unsigned x = (vm.D.units >> 8) & 127u;
+  cstd::U128 X = cstd::u128(0, 0);
+  for (int i = 0; x && i < vm.n; ++i)
+    if (vm.s[i] == x) {
+      if (i < 64) X.lo |= 1ull << i;
+      else X.hi |= 1ull << (i - 64);
+    }
+  cstd::chain_match(cstd::u128(c0 | ((unsigned long long)c1 << 32), c2), X, vm.D.chain, S, L);
+  return true;
+}
+#endif
 CS_HD int row_contains_re(cstd::Tdfa& vm, bool anchored) {
   auto none = [](int, int, int) {};
 #if !defined(__HIP_DEVICE_COMPILE__)
+  if (!anchored) {
+    cstd::U128 S, L;
+    if (row_chain_host(vm, S, L)) return cstd::u128_any(S) ? 1 : 0;
+  }
   if (!anchored && vm.lean_ok()) {  // host builds check the lean scan against the oracle (tests/rowemu)
     uint32_t m0, m1, m2;
     if (vm.has_range2()) vm.build_masks_lean<true>(m0, m1, m2);
@@ -1182,6 +1289,10 @@ CS_HD int row_contains_re(cstd::Tdfa& vm, bool anchored) {
 }
 CS_HD int row_count_re(cstd::Tdfa& vm) {
 #if !defined(__HIP_DEVICE_COMPILE__)
+  {
+    cstd::U128 S, L;
+    if (row_chain_host(vm, S, L)) return cstd::u128_popc(S);
+  }
   if (vm.lean_ok()) {
     uint32_t m0, m1, m2;
     if (vm.has_range2()) vm.build_masks_lean<true>(m0, m1, m2);
@@ -1197,6 +1308,18 @@ CS_HD int row_count_re(cstd::Tdfa& vm) {
 template <class Emit>
 CS_HD int row_findall(cstd::Tdfa& vm, Emit&& emit) {
 #if !defined(__HIP_DEVICE_COMPILE__)
+  {
+    cstd::U128 S, L;
+    if (row_chain_host(vm, S, L)) {
+      int k = 0;
+      while (cstd::u128_any(S)) {
+        emit(k++, cstd::u128_ctz(S), cstd::u128_ctz(L) + 1);
+        S = cstd::u128_clear_lowest(S);
+        L = cstd::u128_clear_lowest(L);
+      }
+      return k;
+    }
+  }
   if (vm.lean_ok()) {  // host builds check the lean span scan against the oracle (tests/rowemu)
     uint32_t m0, m1, m2;
     if (vm.has_range2()) vm.build_masks_lean<true>(m0, m1, m2);
@@ -1256,6 +1379,27 @@ CS_HD void row_replace_matches(cstd::Tdfa& vm, int maxrepl, Emit&& emit) {
       }
       i += (int)w;
     }
+  }
+  if (maxrepl < 0 && (vm.D.chain >> 16) && cstd::g_chain_host && vm.lean_ok()) {
+    // chain patterns on plain-ASCII rows: the matches by marker arithmetic (chain_match; the replace stream kernel's route)
+    uint32_t c0, c1, c2;
+    if (vm.has_range2()) vm.build_masks_lean<true>(c0, c1, c2);
+    else vm.build_masks_lean<false>(c0, c1, c2);
+    const unsigned x = (vm.D.units >> 8) & 127u;
+    const cstd::U128 R = cstd::u128(c0 | ((unsigned long long)c1 << 32), c2);
+    cstd::U128 X = cstd::u128(0, 0), S, L;
+    for (int i = 0; x && i < vm.n; ++i)
+      if (vm.s[i] == x) {
+        if (i < 64) X.lo |= 1ull << i;
+        else X.hi |= 1ull << (i - 64);
+      }
+    cstd::chain_match(R, X, vm.D.chain, S, L);
+    while (cstd::u128_any(S)) {
+      emit(cstd::u128_ctz(S), cstd::u128_ctz(L) + 1, 1);
+      S = cstd::u128_clear_lowest(S);
+      L = cstd::u128_clear_lowest(L);
+    }
+    return;
   }
   if (maxrepl < 0 && (vm.D.units & 1u) && (vm.lean_ok() || hi_units)) {
     int buf[3 * 64];

@@ -433,6 +433,8 @@ class RowEmu(CpuLib):
         self._f("set_engine", None, [C.c_int])
         self._f("regex_tdfa_info", None, [vp, C.POINTER(C.c_int)])
         self._f("regex_units", C.c_int, [vp])
+        self._f("regex_chain", C.c_int, [vp])
+        self._f("set_chain", None, [C.c_int])
 
     def set_engine(self, e):
         """0 = list simulator (Pike VM) only, 1 = tagged DFA when the program converts"""
@@ -444,6 +446,18 @@ class RowEmu(CpuLib):
         w = self._regex_units(re)
         self._regex_free(re)
         return bool(w & 1), (chr((w >> 8) & 127) if (w >> 8) & 127 else None), bool((w >> 16) & 1)
+
+    def chain(self, pattern):
+        """The chain form (regex_tdfa.h: chain_match) as a string of items, 'R' / 'x' with '+' when repeated, or None"""
+        re = self.compile(pattern)
+        w = self._regex_chain(re)
+        self._regex_free(re)
+        n = (w >> 16) & 15
+        return "".join(("x" if (w >> (2 * k)) & 1 else "R") + ("+" if (w >> (2 * k + 1)) & 1 else "") for k in range(n)) or None
+
+    def set_chain(self, on):
+        """0: chain patterns keep the unit route in the host emulation of replace_re"""
+        self._set_chain(int(on))
 
     def tdfa_info(self, re):
         out = (C.c_int * 6)()

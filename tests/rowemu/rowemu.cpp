@@ -230,6 +230,10 @@ void emu_regex_tdfa_info(const emu_regex* re, int* out) {
 }
 // header word 31 of the tagged DFA: the unit decomposition offered to the replace kernels (0: none / not convertible)
 int emu_regex_units(const emu_regex* re) { return re->tdfa.empty() ? 0 : re->tdfa[31]; }
+// the chain form (regex_tdfa.h: chain_match): items in bits 0..15, their number in bits 16..19 (0: the pattern is no chain)
+int emu_regex_chain(const emu_regex* re) { return re->tdfa.empty() ? 0 : (int)cstd::make_view(re->tdfa.data()).chain; }
+// 0: chain patterns keep the unit route in replace_re (both routes are checked against the oracle)
+void emu_set_chain(int on) { cstd::g_chain_host = on; }
 // adopt a program blob produced elsewhere (e.g. by the real reference compiler)
 emu_regex* emu_regex_from_blob(const int32_t* words, int n) {
   emu_regex* re = new emu_regex;

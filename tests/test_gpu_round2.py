@@ -242,6 +242,38 @@ def test_gpu_replace_re_unit_scan_edges(gpu_engine, oracle_engine, pat):
     assert _lib.lib.cs_fallback_count() == before  # the single-pass kernel itself produced these results
 
 
+CHAIN_PATS = [r"\d+\.\d+\.\d+\.\d+", r"[0-9]+\.[0-9]+\.[0-9]+\.[0-9]+", r"\d+", r"(\d+)\.(\d+)", r"[a-c]+@[a-c]+", r"\d\.\d+", r"\d+-+\d+", r"[a-cx-z]+_", r"a+b"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pat", CHAIN_PATS)
+def test_gpu_chain_patterns(gpu_engine, oracle_engine, pat):
+    """Chain patterns (regex_tdfa.h: chain_match -- every match of a plain-ASCII row from its candidate / x bit masks by
+    integer arithmetic, in the replace and scan stream kernels): replace_re, count_re, contains_re and findall against
+    the oracle on overlapping candidates (1.2.3.4.5.6.7.8), matches at both row ends, adjacent matches, rows at the
+    96-byte mask limit and beyond it (those sub-tiles keep the automaton), null / empty rows, a non-ASCII row."""
+    rnd = random.Random(len(pat) + 5)
+    ip = lambda: ".".join(str(rnd.randrange(256)) for _ in range(4))
+    junk = lambda k: "".join(rnd.choice("abcxyz@-_. 0123456789") for _ in range(rnd.randrange(0, k)))
+    s = [junk(90) for _ in range(640)]
+    s += ["1.2.3.4.5.6.7.8", "1.2.3.4 5.6.7.8", ".1.2.3.4.", "1..2.3.4", "999.999.999.999x1.1.1.1", "1.2.3.", "12", "", None, "0.0.0.0" * 13,
+          "9" * 93, "1." * 46, ".1" * 46, "a@b@c@@", "ab@cb@ca", "1--2-3", "12.3456", "a_b_cx_", "aab ab b a"] * 3
+    s += [ip() + " " + junk(40) + " " + ip() for _ in range(300)]
+    s += [junk(60) for _ in range(64)] + ["é " + ip()] + [ip() for _ in range(63)]     # a sub-tile with a non-ASCII row
+    s += [ip() + "x" * 120 + ip()] + [ip() for _ in range(63)]                        # a row beyond the masks
+    s += fuzzdata.log_rows(37, 1500)
+    from custrings_amd import _lib
+
+    before = _lib.lib.cs_fallback_count()
+    for repl in ("<IP>", "", "#"):
+        assert gpu_engine.replace_re(s, pat, repl, -1) == oracle_engine.replace_re(s, pat, repl, -1), (pat, repl)
+    assert _lib.lib.cs_fallback_count() == before
+    assert gpu_engine.count_re(s, pat) == oracle_engine.count_re(s, pat)
+    assert gpu_engine.contains_re(s, pat) == oracle_engine.contains_re(s, pat)
+    assert gpu_engine.findall(s, pat) == oracle_engine.findall(s, pat)
+    assert gpu_engine.replace_re(s, pat, "=", 1) == oracle_engine.replace_re(s, pat, "=", 1)
+
+
 @pytest.mark.parametrize("n,sep", [(2, "_"), (3, ""), (5, "--")])
 def test_gpu_sharded_ngrams_pieces(gpu_engine, n, sep):
     """custrings_amd/dist.py sharded_ngrams on the GPU ops (drop_empty / head / export / column / concat / ngrams): the

@@ -211,6 +211,51 @@ def test_unit_decomposition_vs_oracle(emu_engine, oracle_engine):
     assert offered > 60, offered
 
 
+def test_chain_patterns_vs_oracle(emu_engine, oracle_engine):
+    """Chain patterns (regex_tdfa.cpp / regex_tdfa.h: chain_match): which patterns are offered, and replace_re on plain-ASCII
+    rows by marker arithmetic against the oracle -- overlapping candidates, matches at both row ends, rows of 96 bytes,
+    adjacent matches -- with the unit route on the same patterns as a second witness."""
+    import random
+
+    e = emu_engine.e
+    e.set_engine(1)
+    want = {r"\d+\.\d+\.\d+\.\d+": "R+xR+xR+xR+", r"[0-9]+\.[0-9]+\.[0-9]+\.[0-9]+": "R+xR+xR+xR+", r"\d+": "R+", r"(\d+)\.(\d+)": "R+xR+",
+            r"[a-c]+=": "R+x", r"\d\.\d+": "RxR+", r"[a-z]+@[a-z]+": "R+xR+", r"\d+-+\d+": "R+x+R+", r"[a-cx-z]+_": "R+x",
+            r"\w+\.\w+": "R+xR+" if False else None,  # (three ranges and '_': the candidate ranges are a superset)
+            r"\d+\.\d": None, r"\d\d": None, r"\d+\.?\d+": None, r"\d*\.": None, r"\.\d+": None, r"a|b": None, r"\d+?\.": None,
+            r"\b\d+": None, r"[^a]+b": None, r"\d+\.[0-5]+": None, r"é+a": None, r"\d+\.\d+\.\d+\.\d+\.\d+\.": None}
+    for pat, form in want.items():
+        assert e.chain(pat) == form, pat
+    rnd = random.Random(11)
+    s = fuzzdata.log_rows(29, 500) + fuzzdata.rows(31, 500, max_len=96, alphabet=list("0123456789..--ab=@_ ")) + \
+        ["1.2.3.4", "1.2.3.4.5.6.7.8", "1.2.3.4 5.6.7.8", ".1.2.3.4.", "1..2.3.4", "999.999.999.999x1.1.1.1", "1.2.3.", "12", "", None,
+         "1.2.3.4" + "x" * 82 + "5.6.7.8", "9" * 96, "1." * 48, ".1" * 48, "a=b=c==", "ab@cd@ef", "1--2-3", "12.3456", "0.0.0.0" * 13, "1.1.1.1é2.2.2.2"]
+    for pat in [p for p, f in want.items() if f]:
+        for on in (1, 0):
+            e.set_chain(on)
+            try:
+                for repl in ("<IP>", "", "0.0"):
+                    assert emu_engine.replace_re(s, pat, repl, -1) == oracle_engine.replace_re(s, pat, repl, -1), (pat, repl, on)
+                assert emu_engine.replace_re(s, pat, "#", 1) == oracle_engine.replace_re(s, pat, "#", 1), pat
+                assert emu_engine.contains_re(s, pat) == oracle_engine.contains_re(s, pat), pat
+                assert emu_engine.count_re(s, pat) == oracle_engine.count_re(s, pat), pat
+                assert emu_engine.findall(s, pat) == oracle_engine.findall(s, pat), pat
+            finally:
+                e.set_chain(1)
+    # generated chains over digits / '.', and over letters / '-'
+    for _ in range(60):
+        a, x = rnd.choice([("\\d", "\\."), ("[a-c]", "-"), ("[0-9a-b]", "@")])
+        items, prev = [], None
+        for k in range(rnd.randint(1, 8)):
+            cls = a if (k == 0 or prev == x) else x
+            items.append(cls + rnd.choice(["", "+", "+"]))
+            prev = cls
+        pat = "".join(items)
+        if e.chain(pat) is None:
+            continue
+        assert emu_engine.replace_re(s, pat, "<>", -1) == oracle_engine.replace_re(s, pat, "<>", -1), pat
+
+
 GROUP_PATTERNS = [r"(\w+) (\w+)", r"(a|ab)(c|bcd)", r"(a|b)*c", r"((a)|(b))+", r"(\d+)\.(\d+)\.(\d+)\.(\d+)", r"(a*)(b*)", r"(a+?)(a*)",
                   r"(?:x)(y)?z", r"^(\w)(\w*)$", r"(é+)|(a)", r"(\bin\b)|(\ba\b)", r"((\w)\w*) ", r"(a)|(b)|(c)", r"(x?)(y?)(z?)",
                   r"(.)(.)", r"([^ ]+) ([^ ]+) ", r"(GET|POST) (/\S*)", r"(b)?a", r"((a|b)(c|x))+", r"no_groups", r"()a"]
