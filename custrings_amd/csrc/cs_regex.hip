@@ -1485,6 +1485,86 @@ __global__ void __launch_bounds__(256, BREFS ? 2 : CS_STREAM_WAVES) k_tdfa_repla
           }
           redo = false;
           units_done = true;
+        } else if (BREFS && lean && !has_odd && a.maxrepl < 0 && (D.chain >> 16) && (((uint32_t)D.img[30] >> 20) & 1u) && !(a.debug & 8192)) {  // (wave-uniform)
+          // replace_with_backrefs on a chain pattern: the matches by chain_match, and every capture group is a run of
+          // items, so its range follows from the item boundaries of the match -- a walk over the row's two masks per
+          // match where the automaton needed an anchored group run (half the kernel's time).
+          using namespace cstd;
+          const csvm::BackrefTemplate& T = *a.tmpl;
+          const uint32_t gmap = (uint32_t)D.img[D.img[15] - 1];
+          const int ni = (int)((D.chain >> 16) & 15u);
+          uint32_t r0, r1, r2, x0 = 0, x1 = 0, x2 = 0;
+          cstile::row_bits96(bitmap, lead + rbeg, n, r0, r1, r2);
+          if (unit_x != 0) cstile::row_bits96(xbitmap, lead + rbeg, n, x0, x1, x2);
+          const U128 R = u128(r0 | ((unsigned long long)r1 << 32), r2), X = u128(x0 | ((unsigned long long)x1 << 32), x2);
+          p_second = cstile::status_load(a.excl + (p_tile >= 0 ? p_tile : 0));
+          has_second = scanner;
+          if (live) {
+            chain_match(R, X, D.chain, uS, uE);
+            nm = u128_popc(uS);
+            from_masks = true;
+          }
+          const int cnt = from_masks ? nm : 0;
+          const int mincl = csdev::wave_inclusive_scan(cnt);
+          const int total_m = __builtin_amdgcn_readlane(mincl, 63);
+          mslot = mincl - cnt;
+          if (total_m > kUnitQueue) {
+            if (lane == 0) atomicOr(a.error, 1u | 32u);
+          } else {
+            int grow_row = 0, mi = 0;
+            U128 S = uS, E = uE;
+            while (u128_any(S)) {
+              const int mb = u128_ctz(S), me = u128_ctz(E) + 1;
+              S = u128_clear_lowest(S);
+              E = u128_clear_lowest(E);
+              int gb[4] = {-1, -1, -1, -1}, ge[4] = {-1, -1, -1, -1};
+              int p = mb;
+#pragma unroll
+              for (int k = 0; k <= 8; ++k) {
+                if (k <= ni) {  // (wave-uniform) p = the boundary in front of item k
+#pragma unroll
+                  for (int q = 0; q < 4; ++q) {
+                    if ((int)((gmap >> (8 * q)) & 15u) == k) gb[q] = p;
+                    if ((int)((gmap >> (8 * q + 4)) & 15u) == k) ge[q] = p;
+                  }
+                }
+                if (k < ni && k < 8) {
+                  if ((D.chain >> (2 * k + 1)) & 1u) {
+                    const U128 C = ((D.chain >> (2 * k)) & 1u) ? X : R;
+                    p = u128_ctz(u128_andn(u128(~C.lo, ~C.hi), u128_below(p)));  // the first byte at or behind p off the class
+                  } else {
+                    ++p;
+                  }
+                }
+              }
+              int grow = T.bytes - (me - mb);
+              for (int j = 0; j < T.nrefs; ++j) {
+                const int g = T.idx[j];
+                int x = -1, y = -1;
+                if (g == 0) {
+                  x = mb;
+                  y = me;
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                  if (g == q + 1 && g <= T.groups) {
+                    x = gb[q];
+                    y = ge[q];
+                  }
+                if (x >= 0 && y > x) grow += y - x;
+              }
+              grow_row += grow;
+              auto by = [&](int v) { return (uint32_t)(v >= 0 ? v : 255) & 255u; };
+              uint32_t* rec = mrec + (mslot + mi) * 3;
+              rec[0] = by(gb[0]) | (by(ge[0]) << 8) | (by(gb[1]) << 16) | (by(ge[1]) << 24);
+              rec[1] = by(gb[2]) | (by(ge[2]) << 8) | (by(gb[3]) << 16) | (by(ge[3]) << 24);
+              rec[2] = by(me) | (1u << 8);
+              ++mi;
+            }
+            if (from_masks) out_len = n + grow_row;
+          }
+          redo = false;
+          units_done = true;
         } else if (lean && a.maxrepl < 0 && (D.units & 1u) && !(a.debug & 1024)) {  // (wave-uniform)
           using namespace cstd;
           // -- row lanes: the row's units from its candidate and x bits

@@ -582,6 +582,8 @@ std::vector<int32_t> build_tdfa(const Program& prog, const std::vector<int32_t>&
       size_t seen = 0;
       bool ok = true;
       int pc = prog.start_inst, prev_cls = -1;
+      int g_lo[5] = {-1, -1, -1, -1, -1}, g_hi[5] = {-1, -1, -1, -1, -1};  // capture groups 1..4: the items they span
+      bool groups_ok = true;
       while (ok) {
         if (pc < 0 || (size_t)pc >= prog.insts.size() || seen > prog.insts.size()) {
           ok = false;
@@ -591,6 +593,8 @@ std::vector<int32_t> build_tdfa(const Program& prog, const std::vector<int32_t>&
         ++seen;
         if (in.type == OP_END) break;
         if (in.type == OP_LBRA || in.type == OP_RBRA) {
+          if (in.u1 >= 1 && in.u1 <= 4) (in.type == OP_LBRA ? g_lo : g_hi)[in.u1] = ni;
+          else groups_ok = false;
           pc = in.u2;
           continue;
         }
@@ -629,6 +633,20 @@ std::vector<int32_t> build_tdfa(const Program& prog, const std::vector<int32_t>&
       if (ok) {
         img[29] |= (int32_t)(items << 16);
         img[30] |= (int32_t)((uint32_t)ni << 16);
+        // the capture groups of a chain are runs of items: [30] bit 20 = the image's LAST word holds, a byte per group
+        // (1..4), the first item of the group in its low nibble and the item behind its last one in the high nibble (the
+        // backrefs kernel reads a match's group ranges off the item boundaries)
+        uint32_t gmap = 0;
+        for (int g = 1; g <= 4 && groups_ok; ++g) {
+          if (g <= prog.num_groups) {
+            if (g_lo[g] < 0 || g_hi[g] < g_lo[g]) groups_ok = false;
+            else gmap |= (uint32_t)(g_lo[g] | (g_hi[g] << 4)) << (8 * (g - 1));
+          }
+        }
+        if (groups_ok && prog.num_groups >= 1 && prog.num_groups <= 4) {
+          img[30] |= 1 << 20;
+          img.push_back((int32_t)gmap);
+        }
       }
     }
   }
