@@ -1128,8 +1128,12 @@ __device__ __forceinline__ bool reclassify_high(const cstd::View& D, bool has_r2
 // sub-tile's rows are sized and written a thread each, straight from memory, inside the prefix chain (separate forms:
 // the code costs the others registers).
 template <bool IN_LDS, bool REP16, bool INPLACE, bool RESCAN = false, bool LONG = false, bool UNITS = false, int PF = cstile::kPfChunks, bool BREFS = false,
-          bool WIDE = false, bool OUTL = false>
+          bool WIDE = false, bool OUTL = false, bool CHAIN = false>
 __global__ void __launch_bounds__(256, BREFS ? 2 : CS_STREAM_WAVES) k_tdfa_replace_stream(StreamArgs a) {
+  // CHAIN (a UNITS form): the pattern is a chain and a sample of the column holds no byte >= 0x80 -- the unit scan, the
+  // literal scan and the lean scans are compiled out (their registers with them); a sub-tile the chain arithmetic does
+  // not take (a non-ASCII byte after all, a row beyond the masks) goes to the generic scan row by row.
+  static_assert(!CHAIN || (UNITS && IN_LDS && !BREFS), "the chain form is a unit-scan variant");
   static_assert(!OUTL || (IN_LDS && !LONG && !UNITS && !BREFS && !WIDE), "oversize sub-tiles: the plain forms only");
   static_assert(!UNITS || (!INPLACE && RESCAN && !LONG), "the unit scan builds on the register-record assembly");
   static_assert(!WIDE || (!UNITS && IN_LDS && !BREFS), "the wide form: generic scan only");
@@ -1401,7 +1405,7 @@ __global__ void __launch_bounds__(256, BREFS ? 2 : CS_STREAM_WAVES) k_tdfa_repla
       const bool has_odd = __any((odd & 0x80808080u) != 0);
       // (a sub-tile with bytes >= 0x80, a pattern they can only kill: the UNIT route alone -- reclassify_high)
       bool hi_units = false;
-      if (UNITS && !BREFS && has_odd && a.litn == 0 && ((D.units >> 17) & 3u) && (D.units & 1u) && a.maxrepl < 0 && !(a.debug & 4096))
+      if (!CHAIN && UNITS && !BREFS && has_odd && a.litn == 0 && ((D.units >> 17) & 3u) && (D.units & 1u) && a.maxrepl < 0 && !(a.debug & 4096))
         hi_units = !reclassify_high(D, has_r2, lds_in, (int)want, lane, bitmap, a.flags, lds_in + lead + rbeg, n);
       const bool lean = D.nskip > 0 && D.img[12] <= 4 && !(a.debug & 32) && (!has_odd || hi_units) &&
                         !__any(live && (LONG ? n > cstd::Tdfa::kLongBytes : !vm.masks_fit()));
@@ -1409,7 +1413,7 @@ __global__ void __launch_bounds__(256, BREFS ? 2 : CS_STREAM_WAVES) k_tdfa_repla
       int resume = 0;
       bool units_done = false;
       from_masks = false;
-      if (UNITS && a.litn > 0) {
+      if (!CHAIN && UNITS && a.litn > 0) {
         // A literal needle without a border: every match of the sub-tile by byte comparison, sixteen positions per
         // lane and step -- no automaton.  Match starts land in `bitmap`; `xbitmap` holds the row starts, so that a
         // match never spans two rows (or the end of the staged span).  Rows of any bytes qualify (an ASCII needle
@@ -1565,7 +1569,7 @@ __global__ void __launch_bounds__(256, BREFS ? 2 : CS_STREAM_WAVES) k_tdfa_repla
           }
           redo = false;
           units_done = true;
-        } else if (lean && a.maxrepl < 0 && (D.units & 1u) && !(a.debug & 1024)) {  // (wave-uniform)
+        } else if (!CHAIN && lean && a.maxrepl < 0 && (D.units & 1u) && !(a.debug & 1024)) {  // (wave-uniform)
           using namespace cstd;
           // -- row lanes: the row's units from its candidate and x bits
           uint32_t m0, m1, m2;
@@ -1703,7 +1707,8 @@ __global__ void __launch_bounds__(256, BREFS ? 2 : CS_STREAM_WAVES) k_tdfa_repla
         redo = false;
       }
       if (hi_units && !units_done) redo = live;  // (more units than the queue holds: the generic scan, never the lean scan on such bytes)
-      if (UNITS && !BREFS && !units_done && lean && !hi_units && a.maxrepl < 0 && D.img[13] >= 1 && !(a.debug & 2048)) {  // (wave-uniform)
+      if (CHAIN && !units_done) redo = live && a.maxrepl != 0;  // (the generic scan)
+      if (!CHAIN && UNITS && !BREFS && !units_done && lean && !hi_units && a.maxrepl < 0 && D.img[13] >= 1 && !(a.debug & 2048)) {  // (wave-uniform)
         // A sub-tile the unit route did not take (more units than the queue holds: patterns whose candidate bytes are
         // everywhere, such as alternations of word-bounded literals; or no decomposition at all): every row lane scans its
         // own row, but the matches still go into the two bitmaps -- a start bit and a last-byte bit each, as the unit lanes
@@ -1744,7 +1749,7 @@ __global__ void __launch_bounds__(256, BREFS ? 2 : CS_STREAM_WAVES) k_tdfa_repla
         redo = live && bail;  // (such a row is scanned whole by the generic scan below; nothing of it counts from above)
         units_done = true;
       }
-      if (!BREFS && !units_done && lean && !hi_units && live && a.maxrepl != 0) {
+      if (!CHAIN && !BREFS && !units_done && lean && !hi_units && live && a.maxrepl != 0) {
         bool bail = false;
         uint32_t m0, m1, m2;  // candidate bits, bit i = byte i of the row
         if (LONG) {
@@ -2888,6 +2893,10 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
           }
         } else if (brefs)
           kern = cap <= 5 * 1024 ? &k_tdfa_replace_stream<true, false, false, true, false, true, 5, true> : &k_tdfa_replace_stream<true, false, false, true, false, true, cstile::kPfChunks, true>;
+        else if (units && cap <= 5 * 1024 && tp.d.in_lds && !literal && maxrepl < 0 && ((re->tdfa[30] >> 16) & 15) != 0 && !sample_has_high_bytes(col, s) && !getenv("CS_NO_CHAIN_FORM"))
+          // (a chain pattern on a column whose sample is plain ASCII: the form without the unit / lean scans)
+          kern = rb > 8 ? &k_tdfa_replace_stream<true, true, false, true, false, true, 5, false, false, false, true>
+                        : &k_tdfa_replace_stream<true, false, false, true, false, true, 5, false, false, false, true>;
         else if (units && cap <= 5 * 1024)
           kern = rb > 8 ? (tp.d.in_lds ? &k_tdfa_replace_stream<true, true, false, true, false, true, 5> : &k_tdfa_replace_stream<false, true, false, true, false, true, 5>)
                         : (tp.d.in_lds ? &k_tdfa_replace_stream<true, false, false, true, false, true, 5> : &k_tdfa_replace_stream<false, false, false, true, false, true, 5>);

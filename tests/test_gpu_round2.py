@@ -274,6 +274,26 @@ def test_gpu_chain_patterns(gpu_engine, oracle_engine, pat):
     assert gpu_engine.replace_re(s, pat, "=", 1) == oracle_engine.replace_re(s, pat, "=", 1)
 
 
+def test_gpu_chain_form_meets_non_ascii_tiles(gpu_engine, oracle_engine):
+    """The CHAIN form of the replace stream kernel (no unit / lean scans compiled in) is chosen from a SAMPLE of the chars
+    (start, middle, end): a column whose sampled windows are plain ASCII but which holds non-ASCII rows and a NUL byte
+    elsewhere sends those sub-tiles through the form's generic scan -- same bytes as the oracle, no fallback."""
+    rnd = random.Random(77)
+    ip = lambda: ".".join(str(rnd.randrange(256)) for _ in range(4))
+    s = ["%s GET /x/%d %s" % (ip(), i, ip() if i % 3 == 0 else "-") for i in range(40000)]   # about 1.3 MB of chars
+    for at in (9000, 9001, 9100, 29000, 31000):
+        s[at] = "é " + ip() + " ü" + ip()
+    s[12000] = "1.2.3.4\x005.6.7.8"
+    s[30500] = None
+    from custrings_amd import _lib
+
+    before = _lib.lib.cs_fallback_count()
+    for pat in (r"\d+\.\d+\.\d+\.\d+", r"\d+"):
+        for repl in ("<IP>", "<a-longer-replacement>"):
+            assert gpu_engine.replace_re(s, pat, repl, -1) == oracle_engine.replace_re(s, pat, repl, -1), (pat, repl)
+    assert _lib.lib.cs_fallback_count() == before
+
+
 @pytest.mark.parametrize("n,sep", [(2, "_"), (3, ""), (5, "--")])
 def test_gpu_sharded_ngrams_pieces(gpu_engine, n, sep):
     """custrings_amd/dist.py sharded_ngrams on the GPU ops (drop_empty / head / export / column / concat / ngrams): the
