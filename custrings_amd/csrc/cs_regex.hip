@@ -2009,9 +2009,12 @@ struct ScanStreamArgs {
 };
 // UNITS (MODE 0 and 2, !LONG): the unit scan of the replace kernel -- units queued by the row lanes, one unit per lane
 // whatever its row, the per-row result summed (count_re) / OR-ed (contains_re) in LDS.
-template <int MODE, bool IN_LDS, bool LONG = false, bool UNITS = false>
-__global__ void __launch_bounds__(256, ((UNITS && MODE == 3) || MODE == 4) ? 3 : (UNITS || MODE == 3) ? 4 : 1) k_tdfa_scan_stream(ScanStreamArgs a) {
+// CHAIN (a UNITS form, count_re / findall): the pattern is a chain and the column's sample holds no byte >= 0x80 -- the unit
+// and lean scans are compiled out, a sub-tile the chain arithmetic does not take is scanned row by row by the generic executor.
+template <int MODE, bool IN_LDS, bool LONG = false, bool UNITS = false, bool CHAIN = false>
+__global__ void __launch_bounds__(256, CHAIN ? 4 : ((UNITS && MODE == 3) || MODE == 4) ? 3 : (UNITS || MODE == 3) ? 4 : 1) k_tdfa_scan_stream(ScanStreamArgs a) {
   static_assert(!UNITS || ((MODE == 0 || MODE == 2 || MODE == 3) && !LONG), "unit scan: contains_re / count_re / findall on rows within the 96-byte masks");
+  static_assert(!CHAIN || (UNITS && (MODE == 2 || MODE == 3)), "the chain form: count_re / findall");
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   uint8_t* base = reinterpret_cast<uint8_t*>(smem);
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;  // (scalar: what derives from it stays in SGPRs)
@@ -2214,7 +2217,7 @@ __global__ void __launch_bounds__(256, ((UNITS && MODE == 3) || MODE == 4) ? 3 :
       cstd::Tdfa vm(D, P, lds_in + lead + rbeg, n, (lead + rbeg) & 3);
       const bool has_odd = __any((odd & 0x80808080u) != 0);
       bool hi_units = false;  // (bytes >= 0x80 that can only kill: the unit route alone -- reclassify_high)
-      if (UNITS && (MODE == 0 || MODE == 2 || MODE == 3) && has_odd && ((D.units >> 17) & 3u) && (D.units & 1u))
+      if (!CHAIN && UNITS && (MODE == 0 || MODE == 2 || MODE == 3) && has_odd && ((D.units >> 17) & 3u) && (D.units & 1u))
         hi_units = !reclassify_high(D, has_r2, lds_in, want, lane, bitmap, a.flags, lds_in + lead + rbeg, n);
       const bool lean = D.nskip > 0 && D.img[12] <= 4 && (!has_odd || hi_units) &&
                         !__any(live && (LONG ? n > cstd::Tdfa::kLongBytes : !vm.masks_fit()));
@@ -2257,7 +2260,7 @@ __global__ void __launch_bounds__(256, ((UNITS && MODE == 3) || MODE == 4) ? 3 :
           }
           redo = false;
           units_done = true;
-        } else if (lean && (D.units & 1u)) {  // (wave-uniform)
+        } else if (!CHAIN && lean && (D.units & 1u)) {  // (wave-uniform)
           using namespace cstd;
           uint32_t m0, m1, m2;
           const int total_units = unit_discover(D, bitmap, xbitmap, lead + rbeg, n, lane, uqueue, m0, m1, m2, [&] {
@@ -2323,7 +2326,7 @@ __global__ void __launch_bounds__(256, ((UNITS && MODE == 3) || MODE == 4) ? 3 :
           }
           redo = false;
           units_done = true;
-        } else if (lean && (D.units & 1u) && (MODE != 0 || hi_units)) {  // (wave-uniform)
+        } else if (!CHAIN && lean && (D.units & 1u) && (MODE != 0 || hi_units)) {  // (wave-uniform)
           constexpr int KIND = MODE == 0 ? cstd::Tdfa::K_CONTAINS : cstd::Tdfa::K_COUNT;
           uint32_t m0, m1, m2;
           const int total_units = unit_discover(D, bitmap, xbitmap, lead + rbeg, n, lane, uqueue, m0, m1, m2, [&] {
@@ -2353,7 +2356,8 @@ __global__ void __launch_bounds__(256, ((UNITS && MODE == 3) || MODE == 4) ? 3 :
         }
       }
       if (hi_units && !units_done) redo = live;  // (never the lean scan over whole rows of such a tile)
-      if (!units_done && lean && !hi_units && live) {
+      if (CHAIN && !units_done) redo = live;       // (the generic scan)
+      if (!CHAIN && !units_done && lean && !hi_units && live) {
         uint32_t m0, m1, m2;
         constexpr int KIND = MODE == 0 ? cstd::Tdfa::K_CONTAINS : cstd::Tdfa::K_COUNT;
         if (LONG) {
@@ -2589,6 +2593,8 @@ void scan(const cs_column* col, cs_regex* re, uint8_t* out8, int32_t* out32, int
       sa.tbl_bytes = (int)tp.lds_bytes;
       auto kern = tc.lng ? &k_tdfa_scan_stream<MODE, true, true> : &k_tdfa_scan_stream<MODE, true, false>;
       if (units) kern = &k_tdfa_scan_stream<MODE == 2 ? 2 : 0, true, false, true>;
+      if (units && MODE == 2 && ((re->tdfa[30] >> 16) & 15) != 0 && !sample_has_high_bytes(col, s) && !getenv("CS_NO_CHAIN_FORM"))
+        kern = &k_tdfa_scan_stream<2, true, false, true, true>;  // (a chain pattern on a column whose sample is plain ASCII)
       if (wide) kern = tc.lng ? &k_tdfa_scan_stream<MODE + 7, true, true> : &k_tdfa_scan_stream<MODE + 7, true, false>;
       if (lds > 48 * 1024)
         CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -3339,6 +3345,8 @@ int cs_findall(const cs_column* col, const cs_regex* cre, cs_stream stream, cs_c
         sa.maxp = ptr<int>(dmax);
         auto kern = tc.lng ? &k_tdfa_scan_stream<3, true, true> : &k_tdfa_scan_stream<3, true, false>;
         if (units) kern = &k_tdfa_scan_stream<3, true, false, true>;
+        if (units && ((re->tdfa[30] >> 16) & 15) != 0 && !sample_has_high_bytes(col, s) && !getenv("CS_NO_CHAIN_FORM"))
+          kern = &k_tdfa_scan_stream<3, true, false, true, true>;  // (a chain pattern on a column whose sample is plain ASCII)
         if (lds > 48 * 1024)
           CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         const unsigned grid = resident_grid(reinterpret_cast<const void*>(kern), lds, (sa.nsub + 3) / 4);

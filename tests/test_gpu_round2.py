@@ -291,6 +291,9 @@ def test_gpu_chain_form_meets_non_ascii_tiles(gpu_engine, oracle_engine):
     for pat in (r"\d+\.\d+\.\d+\.\d+", r"\d+"):
         for repl in ("<IP>", "<a-longer-replacement>"):
             assert gpu_engine.replace_re(s, pat, repl, -1) == oracle_engine.replace_re(s, pat, repl, -1), (pat, repl)
+        # (the scan stream kernel has the same form for count_re / findall)
+        assert gpu_engine.count_re(s, pat) == oracle_engine.count_re(s, pat), pat
+        assert gpu_engine.findall(s, pat) == oracle_engine.findall(s, pat), pat
     assert _lib.lib.cs_fallback_count() == before
 
 
