@@ -212,8 +212,30 @@ def main():
                     "frac": round(a / 8000.0, 4), "frac_of_achievable_6300": round(a / 6300.0, 4), "traffic": tr,
                     "avg_ms": round(prof[k]["avg_ms"], 3), "alg_bytes_per_row": round(alg_kernel.get(k, 0), 2)}
 
-        roofline = roof(dom) if dom else None
         roofline_kernels = [roof(k) for k in sorted(prof, key=lambda k: -prof[k]["avg_ms"] * prof[k]["launches"])]
+        # ---- op level: an op's algorithmic bytes over the SUMMED device time of every kernel it launched in a step (the
+        # measure pass re-reads what emit reads again: that read is the op's cost, not extra algorithmic bytes).
+        # `roofline` is the slowest op's line; the per-kernel list above keeps each kernel's own bytes.
+        op_kernels = {"split": ["k_split_measure", "k_split_emit", "k_split_write", "k_split_count", "k_split_sizes", "k_write_offsets", "k_scan_lookback"],
+                      "replace_re": ["k_replace_re", "k_replace_re_size", "k_replace_re_write"]}
+        op_alg = {"split": alg_split, "replace_re": alg_replace}
+
+        def roof_op(op):
+            ks = [k for k in op_kernels[op] if k in prof]
+            ms = sum(prof[k]["avg_ms"] * prof[k]["launches"] for k in ks) / args.steps
+            if ms <= 0:
+                return None
+            a = op_alg[op] * rows / (ms * 1e-3) / 1e9
+            tr = None
+            if tj and all(k in tj["kernels"] for k in ks):
+                tr = float(sum(tj["kernels"][k]["hbm_bytes"] * prof[k]["launches"] / args.steps for k in ks))
+            domk = max(ks, key=lambda k: prof[k]["avg_ms"] * prof[k]["launches"])
+            return {"bound": "hbm", "op": op, "kernel": domk, "kernels": {k: round(prof[k]["avg_ms"] * prof[k]["launches"] / args.steps, 3) for k in ks},
+                    "achieved": round(a, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(a / 8000.0, 4), "traffic": tr,
+                    "ms": round(ms, 3), "alg_bytes_per_row": round(op_alg[op], 2)}
+
+        roofline_ops = [r for r in (roof_op(op) for op in op_kernels) if r]
+        roofline = max(roofline_ops, key=lambda r: r["ms"]) if roofline_ops else None
         ms_step = elapsed / args.steps * 1e3
         pipeline = (alg_replace + alg_split) * total_rows / (elapsed / args.steps) / 1e9
         result = {
@@ -234,6 +256,7 @@ def main():
                        "rows_per_gpu": rows, "seed": SEED, "sharding": "row ranges, no data-path collective"},
             "mstrings_per_s": round(total_rows / (elapsed / args.steps) / 1e6, 1),
             "roofline": roofline,
+            "roofline_ops": roofline_ops,
             "roofline_kernels": roofline_kernels,
             "fallbacks_in_timed_region": int(L.cs_fallback_count()) - fallbacks0,
             "roofline_pipeline": {"alg_bytes_per_row": round(alg_replace + alg_split, 1), "achieved": round(pipeline, 1),

@@ -604,6 +604,11 @@ struct Emit2Args {
   int reverse;  // rsplit with a limit (TokensT)
   int debug;  // CS_SPLIT_DEBUG bit mask: 1 no offset stores, 2 no chars stores, 4 no assembly, 8 no column loop (measurement only)
 };
+// v_writelane_b32: the wave-uniform `v` into lane `k` of a vector register (no builtin in this compiler)
+__device__ __forceinline__ int wl(int v, int k, int old) {
+  asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(old) : "s"(v), "s"(k) : "m0");
+  return old;
+}
 __device__ __forceinline__ void lds_or(uint32_t* p, uint32_t v) {
   __hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 }
@@ -844,6 +849,14 @@ constexpr int kEmit3Threads = 128;  // two waves per workgroup: the LDS of a CU 
 // PLAIN: a one-byte delimiter without a split limit on rows of at most 92 bytes -- the token walk then runs on three
 // mask words that also hold a sentinel bit behind the row's last byte (every token ends at a set bit, the walk is over
 // when the mask is empty) instead of the general TokensT::next.
+// (measurement builds, -DCS_EMIT3_EXP: CS_SPLIT_DEBUG bits switch phases of the kernel off -- 1 no offsets stores, 2 no chars
+// stores, 4 no token assembly, 8 no column loop, 16 the token read at an aligned address (wrong bytes: what the unaligned
+// read costs), 32 no pending-region traffic, 64 no wave scan)
+#if defined(CS_EMIT3_EXP)
+#define EXP(bit) (a.debug & (bit))
+#else
+#define EXP(bit) false
+#endif
 template <int MODE, bool OFF32, bool PLAIN>
 __global__ void __launch_bounds__(kEmit3Threads, CS_EMIT3_WAVES) k_split_emit3(Emit3Args args) {
   constexpr bool WS = MODE == 1, MULTI = MODE == 2;
@@ -942,15 +955,16 @@ __global__ void __launch_bounds__(kEmit3Threads, CS_EMIT3_WAVES) k_split_emit3(E
     // (chunks of the pending region: p_nch in all, the first p_nwhole of them whole)
     auto pending_read = [&]() -> cstile::u32x4 {  // lane i < 64 reads chunk i (aligned 16-byte reads)
       cstile::u32x4 v = zero4;
+      if (EXP(32)) return v;
       if (p_k >= 0 && lane < p_nch) v = *reinterpret_cast<const cstile::u32x4*>(lds_out + p_rg + 16 * lane);
       return v;
     };
     auto pending_leave = [&](cstile::u32x4 pv) {
-      if (p_k < 0) return;
+      if (p_k < 0 || EXP(32)) return;
       // chunk i goes to ((chars + pos) & ~15) + 16 i, pos still being the column's position before this sub-tile
       uint8_t* ga = reinterpret_cast<uint8_t*>(((uintptr_t)cstile::rl64((long long)(uintptr_t)my_chars, p_k) + (uintptr_t)cstile::rl64(my_pos, p_k)) & ~(uintptr_t)15);
       const int head = rl(my_head, p_k);
-      if (lane < p_nwhole && !(lane == 0 && head != 0)) *(cstile::gptr<cstile::u32x4>)cstile::as_global(ga + 16 * lane) = pv;
+      if (lane < p_nwhole && !(lane == 0 && head != 0) && !EXP(2)) *(cstile::gptr<cstile::u32x4>)cstile::as_global(ga + 16 * lane) = pv;
       // the bytes behind the last whole chunk become the carry of the column's lane (its own read of that quad: the LDS
       // takes the wave's operations in order, so it comes before the zeroing below; zeros when the region ends on a
       // chunk boundary -- the quad behind it is the next region's, still untouched, or empty)
@@ -979,10 +993,11 @@ __global__ void __launch_bounds__(kEmit3Threads, CS_EMIT3_WAVES) k_split_emit3(E
       }
     };
     bool any_more = true;
-    for (int k = 0; k < a.ncols; ++k) {
+    for (int k = 0; k < (EXP(8) ? 0 : a.ncols); ++k) {
       const long long cbase = cstile::rl64(my_pos, k);
       cstile::gptr<off_t> coff = cstile::as_global(reinterpret_cast<off_t*>(cstile::rl64((long long)(uintptr_t)my_off, k))) + r0;
       if (!any_more) {
+        if (EXP(1)) continue;
         // no row of the sub-tile reaches this column: null rows at the column's running position, the carried
         // bytes stay where they are
         if (lane < nrows) coff[lane] = (off_t)cbase;
@@ -1011,10 +1026,10 @@ __global__ void __launch_bounds__(kEmit3Threads, CS_EMIT3_WAVES) k_split_emit3(E
       any_more = __any(has);
       if (any_more) {
         const int len = has ? hi - lo : 0;
-        const int incl = wave_inclusive_scan_fused(len);
+        const int incl = EXP(64) ? len + lane : wave_inclusive_scan_fused(len);
         const int pre = incl - len;
-        const int csum = rl(incl, 63);  // bytes this sub-tile adds to column k
-        if (lane < nrows) coff[lane] = (off_t)(cbase + pre);
+        const int csum = EXP(64) ? 64 * 7 : rl(incl, 63);  // bytes this sub-tile adds to column k
+        if (lane < nrows && !EXP(1)) coff[lane] = (off_t)(cbase + pre);
         if (last_tile && lane == nrows - 1) coff[nrows] = (off_t)(cbase + incl);
         const unsigned long long vmask = __ballot(has);
         const int cph = rl(my_cph, k);  // carried bytes: they precede the column's position in its 16-byte chunk
@@ -1024,7 +1039,8 @@ __global__ void __launch_bounds__(kEmit3Threads, CS_EMIT3_WAVES) k_split_emit3(E
           // behind them, over the quad's zero tail)
           if (cph) *reinterpret_cast<cstile::u32x4*>(lds_out + rg) = carry;
         }
-        if (has) lds_or16u(lds_out, rg + cph + pre, lds_in, lead + rbeg + lo, min(len, 16), tail);
+        if (has && EXP(16)) lds_or16u(lds_out, rg + cph + pre, lds_in, (lead + rbeg + lo) & ~15, min(len, 16), tail);
+        else if (has && !EXP(4)) lds_or16u(lds_out, rg + cph + pre, lds_in, lead + rbeg + lo, min(len, 16), tail);
         if (__any(len > 16)) {  // (tokens beyond 16 bytes: the same, 16 bytes at a time)
           for (int done = 16; __any(done < len); done += 16)
             if (done < len) lds_or16u(lds_out, rg + cph + pre + done, lds_in, lead + rbeg + lo + done, min(len - done, 16), tail);
@@ -1058,6 +1074,269 @@ __global__ void __launch_bounds__(kEmit3Threads, CS_EMIT3_WAVES) k_split_emit3(E
       cstile::gptr<uint8_t> d = cstile::as_global(reinterpret_cast<uint8_t*>(((uintptr_t)my_chars + (uintptr_t)my_pos) & ~(uintptr_t)15));
       for (int j = my_head; j < have; ++j) d[j] = lds_out[16 * lane + j];
     }
+  }
+}
+
+
+// ---- emit, fourth generation: two columns a round, no per-round flush ------------------------------------
+// Same inputs, outputs and LDS layout as k_split_emit3 (runs of consecutive sub-tiles per wave, column positions from
+// the measure pass, regions side by side in one out tile, partial 16-byte chunks carried in the column's lane).
+// What changed (round 4; measured with the CS_EMIT3_EXP switches: the "pending region" traffic of a round -- chunk
+// reads, address arithmetic through readlanes, carry, zeroing, the head and long-region branches -- cost 1.5 of the
+// kernel's 6.5 ms, the token bytes themselves 0.5): a wave's in-order instruction stream is what bounds the kernel,
+// so the column loop does only what needs the rows' lanes, and everything per COLUMN runs once per sub-tile with the
+// columns in the lanes:
+//   * a round takes TWO columns: two token-walk steps, ONE wave scan over both lengths packed 16 + 16 bits (a
+//     sub-tile adds at most 64 x 96 bytes to a column), offsets stores, the tokens' OR into their regions.  It leaves
+//     the column's byte count and region start in the column's lane (v_writelane) and nothing else;
+//   * after the loop the column lanes -- all at once -- OR their carried bytes in front of their regions, read the
+//     new carry (the partial chunk behind the last whole one), advance position / chunk address / phase and write a
+//     16-byte flush entry per non-empty region into the by then dead in tile, next to a bitmap of region starts;
+//   * one flush pass over the out tile: lane i takes chunks i, i + 64, ...; the region a chunk belongs to is the
+//     number of start bits at or below it (word prefix counts + one popcount), the entry gives the global address;
+//     whole chunks leave with 16-byte stores and are zeroed again, a region's partial last chunk is only zeroed.
+//   * rows beyond the sub-tile's last (the column's last sub-tile only) write the FINAL offset entry: their prefix
+//     is the sub-tile's total, so no store in the loop is predicated on the row count.
+template <int MODE, bool OFF32, bool PLAIN>
+__global__ void __launch_bounds__(kEmit3Threads, CS_EMIT3_WAVES) k_split_emit4(Emit3Args args) {
+  constexpr bool WS = MODE == 1, MULTI = MODE == 2;
+  static_assert(!PLAIN || MODE == 0, "the sentinel walk is the one-byte delimiter's");
+  typedef typename std::conditional<OFF32, int32_t, int64_t>::type off_t;
+  const Emit2Args& a = args.e;
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+  uint8_t* lds_in = reinterpret_cast<uint8_t*>(smem) + 288 + (size_t)wv * (16 + args.cap_in + 32 + args.cap_out) + 16;
+  uint8_t* lds_out = lds_in + args.cap_in + 32;
+  cstile::u32x4* tail = reinterpret_cast<cstile::u32x4*>(smem);
+  if (lane <= 16) {
+    auto first = [](int k) -> uint32_t { return k >= 4 ? 0xFFFFFFFFu : (k <= 0 ? 0u : (1u << (8 * k)) - 1u); };
+    tail[lane] = cstile::u32x4{first(lane), first(lane - 4), first(lane - 8), first(lane - 12)};
+  }
+  const cstile::u32x4 zero4 = {0u, 0u, 0u, 0u};
+  for (int i = lane * 16; i < args.cap_out; i += 64 * 16) *reinterpret_cast<cstile::u32x4*>(lds_out + i) = zero4;
+  // the flush tables live in the in tile once the column loop is over: 32 entries of 16 bytes, 16 words of region-start
+  // bits (a bit per 16-byte chunk of the out tile), 16 words of prefix counts
+  cstile::u32x4* f_entry = reinterpret_cast<cstile::u32x4*>(lds_in);
+  uint32_t* f_bits = reinterpret_cast<uint32_t*>(lds_in + 512);
+  uint32_t* f_pfx = f_bits + 16;
+  const long long per = a.per;
+  const long long run = (long long)blockIdx.x * (kEmit3Threads / 64) + wv;
+  long long tile = run * per;
+  const long long tile_end = min(a.nsub, tile + per);
+  if (tile >= tile_end) return;
+  const ColView& in = a.in;
+  const int ncols = a.ncols;
+  // lane k keeps column k: the 16-byte aligned address of the chunk its chars currently end in, the bytes of that
+  // chunk in front of the end (carried from the previous sub-tile -- or the neighbouring run's, while c_head != 0),
+  // the running position (the offsets' value), the carried bytes
+  unsigned long long c_ga = 0;
+  long long c_pos = 0;
+  int c_cph = 0, c_head = 0;
+  off_t* c_off = nullptr;
+  uint8_t* c_valid = nullptr;
+  cstile::u32x4 carry = zero4;
+  if (lane < ncols) {
+    const ColOut2 c = a.cols[lane];
+    c_off = reinterpret_cast<off_t*>(c.offsets);
+    c_valid = c.validity;
+    c_pos = c.seg_base[run * a.segs_per_run];
+    const uintptr_t at = (uintptr_t)c.chars + (uintptr_t)c_pos;
+    c_ga = at & ~(uintptr_t)15;
+    c_cph = (int)(at & 15);
+    c_head = c_cph;
+  }
+  cstile::TileOffs cur = cstile::load_tile_offsets(in.offsets, in.rows, tile, lane);
+  cstile::TileOffs nxt = cur;
+  if (tile + 1 < tile_end) nxt = cstile::load_tile_offsets(in.offsets, in.rows, tile + 1, lane);
+  cstile::TileChars pf;
+#pragma unroll
+  for (int j = 0; j < cstile::kPfChunks; ++j) pf.v[j] = make_uint4(0, 0, 0, 0);
+  cstile::issue_chars(in.chars, cstile::rl64(cur.o0, 0), cstile::rl64(cur.o1, 63), lane, pf);
+  for (;;) {
+    const long long r0 = tile * 64;
+    const int nrows = (int)min(64ll, in.rows - r0);
+    const long long g0 = cstile::rl64(cur.o0, 0), g1 = cstile::rl64(cur.o1, 63);
+    const bool live = lane < nrows && row_is_valid(in.validity, r0 + lane);
+    const int rbeg = (int)(cur.o0 - g0);
+    const int n = live ? (int)(cur.o1 - cur.o0) : 0;
+    const int lead = (int)((uintptr_t)(in.chars + g0) & 15);
+    const int want = (int)(g1 - g0) + lead;
+    cstile::stage_chars(lds_in, want, lane, pf);
+    const bool has_next = tile + 1 < tile_end;
+    const cstile::TileOffs nn = cstile::load_tile_offsets(in.offsets, in.rows, tile + 2 < tile_end ? tile + 2 : tile_end - 1, lane);
+    if (has_next) {
+      cur = nxt;
+      cstile::issue_chars(in.chars, cstile::rl64(cur.o0, 0), cstile::rl64(cur.o1, 63), lane, pf);
+    }
+    cstile::wave_lds_fence();
+
+    TokensT<true, WS, MULTI> tk(lds_in, lead + rbeg, n, live, a.dpat, a.tokens, a.d64, a.dlen, a.reverse != 0);
+    uint32_t m0 = 0, m1 = 0, m2 = 0;
+    int tcur = 0;
+    if (PLAIN) {
+      m0 = (uint32_t)tk.m_lo;
+      m1 = (uint32_t)(tk.m_lo >> 32);
+      m2 = tk.m_hi;
+      if (live) {
+        const int q = tk.sa + n;
+        const uint32_t bit = 1u << (q & 31);
+        if (q < 32) m0 |= bit;
+        else if (q < 64) m1 |= bit;
+        else m2 |= bit;
+      }
+    }
+    auto step = [&](int& lo, int& hi) -> bool {  // the row's next token
+      if (PLAIN) {
+        const bool has = (m0 | m1 | m2) != 0;
+        const uint32_t q = lowest96(m0, m1, m2);
+        lo = tcur;
+        hi = (int)q - tk.sa;
+        tcur = hi + 1;
+        const unsigned long long l64 = ((unsigned long long)m1 << 32) | m0, d64 = l64 - 1;
+        const uint32_t d2 = m2 - (l64 == 0 ? 1u : 0u);
+        m0 &= (uint32_t)d64;
+        m1 &= (uint32_t)(d64 >> 32);
+        m2 &= d2;
+        return has;
+      }
+      return tk.next(lo, hi);
+    };
+    // a row beyond the sub-tile's last writes the final offset entry (its prefix is the sub-tile's total)
+    const int rowslot = min(lane, nrows);
+    const uint8_t* tok_src = lds_in + lead + rbeg;
+    // what a round leaves in the column's lane: bytes added by this sub-tile (0: the column is not touched below), where
+    // its region begins in the out tile, the validity word
+    int t_sum = 0, t_rg = 0;
+    uint32_t vm_lo = 0, vm_hi = 0;
+    int rg = 0;  // where the next region begins (wave-uniform)
+    int k = 0;
+    auto put_tokens = [&](bool has, int lo, int len, int at) {
+      if (has) lds_or16u(lds_out, at, tok_src, lo, min(len, 16), tail);
+      if (__any(len > 16)) {  // (tokens beyond 16 bytes: the same, 16 bytes at a time)
+        for (int done = 16; __any(done < len); done += 16)
+          if (done < len) lds_or16u(lds_out, at + done, tok_src, lo + done, min(len - done, 16), tail);
+      }
+    };
+    for (; k < ncols; k += 2) {
+      int loA = 0, hiA = 0, loB = 0, hiB = 0;
+      const bool hasA = step(loA, hiA);
+      const unsigned long long vA = __ballot(hasA);
+      if (vA == 0) break;  // no row of the sub-tile reaches column k (nor any behind it)
+      const bool two = k + 1 < ncols;
+      bool hasB = false;
+      if (two) hasB = step(loB, hiB);
+      const unsigned long long vB = __ballot(hasB);
+      const int lenA = hasA ? hiA - loA : 0, lenB = hasB ? hiB - loB : 0;
+      const int incl = wave_inclusive_scan_fused(lenA | (lenB << 16));
+      const int tot2 = rl(incl, 63);
+      const int preA = (incl & 0xffff) - lenA, preB = (int)((unsigned)incl >> 16) - lenB;
+      const int csumA = tot2 & 0xffff, csumB = (int)((unsigned)tot2 >> 16);
+      // ---- column k
+      {
+        cstile::gptr<off_t> coff = cstile::as_global(reinterpret_cast<off_t*>(cstile::rl64((long long)(uintptr_t)c_off, k))) + r0;
+        const off_t base = OFF32 ? (off_t)rl((int)c_pos, k) : (off_t)cstile::rl64(c_pos, k);
+        coff[rowslot] = base + (off_t)preA;
+        const int cph = rl(c_cph, k);
+        vm_lo = (uint32_t)wl((int)(uint32_t)vA, k, (int)vm_lo);
+        vm_hi = (uint32_t)wl((int)(uint32_t)(vA >> 32), k, (int)vm_hi);
+        t_sum = wl(csumA, k, t_sum);
+        t_rg = wl(rg, k, t_rg);
+        put_tokens(hasA, loA, lenA, rg + cph + preA);
+        if (csumA) rg += (cph + csumA + 15) & ~15;
+      }
+      // ---- column k + 1
+      if (two) {
+        cstile::gptr<off_t> coff = cstile::as_global(reinterpret_cast<off_t*>(cstile::rl64((long long)(uintptr_t)c_off, k + 1))) + r0;
+        const off_t base = OFF32 ? (off_t)rl((int)c_pos, k + 1) : (off_t)cstile::rl64(c_pos, k + 1);
+        coff[rowslot] = base + (off_t)preB;
+        const int cph = rl(c_cph, k + 1);
+        vm_lo = (uint32_t)wl((int)(uint32_t)vB, k + 1, (int)vm_lo);
+        vm_hi = (uint32_t)wl((int)(uint32_t)(vB >> 32), k + 1, (int)vm_hi);
+        t_sum = wl(csumB, k + 1, t_sum);
+        t_rg = wl(rg, k + 1, t_rg);
+        if (vB) put_tokens(hasB, loB, lenB, rg + cph + preB);
+        if (csumB) rg += (cph + csumB + 15) & ~15;
+      }
+    }
+    // ---- columns no row of the sub-tile reaches: null rows at the column's running position
+    for (; k < ncols; ++k) {
+      cstile::gptr<off_t> coff = cstile::as_global(reinterpret_cast<off_t*>(cstile::rl64((long long)(uintptr_t)c_off, k))) + r0;
+      const off_t base = OFF32 ? (off_t)rl((int)c_pos, k) : (off_t)cstile::rl64(c_pos, k);
+      coff[rowslot] = base;
+    }
+    // ---- per column, the columns in the lanes
+    const bool act = lane < ncols && t_sum > 0;
+    const int tot = c_cph + t_sum, nwhole = tot >> 4;
+    const unsigned long long actm = __ballot(act);
+    if (lane < 16) f_bits[lane] = 0u;  // (the in tile is dead: every token has been copied)
+    if (act) {
+      // the carried bytes open the region (the tokens were OR-ed in behind them; a run's first chunk keeps zeros in
+      // front: those bytes are the neighbouring run's)
+      if (c_cph) {
+        uint32_t* o = reinterpret_cast<uint32_t*>(lds_out + t_rg);
+        lds_or(o + 0, carry.x);
+        lds_or(o + 1, carry.y);
+        lds_or(o + 2, carry.z);
+        lds_or(o + 3, carry.w);
+      }
+      const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(actm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)actm, 0u));
+      f_entry[rank] = cstile::u32x4{(uint32_t)c_ga, (uint32_t)(c_ga >> 32), (uint32_t)(t_rg >> 4) | ((uint32_t)nwhole << 16), (uint32_t)c_head};
+      lds_or(f_bits + (t_rg >> 9), 1u << ((t_rg >> 4) & 31));
+    }
+    cstile::wave_lds_fence();
+    if (act) {
+      // the bytes behind the last whole chunk are the new carry
+      carry = (tot & 15) ? *reinterpret_cast<const cstile::u32x4*>(lds_out + t_rg + 16 * nwhole) : zero4;
+      c_pos += t_sum;
+      c_ga += (unsigned long long)(16 * nwhole);
+      c_cph = tot & 15;
+    }
+    {
+      const int cnt = lane < 16 ? __builtin_popcount(f_bits[lane]) : 0;
+      const int inc = wave_inclusive_scan_fused(cnt);
+      if (lane < 16) f_pfx[lane] = (uint32_t)(inc - cnt);
+    }
+    cstile::wave_lds_fence();
+    // ---- the flush pass: every 16-byte chunk of the out tile below rg
+    const int nchunks = rg >> 4;
+    for (int c = lane; c < nchunks; c += 64) {
+      const uint32_t word = f_bits[c >> 5];
+      const int rank = (int)f_pfx[c >> 5] + __builtin_popcount(word & (0xFFFFFFFFu >> (31 - (c & 31)))) - 1;
+      const cstile::u32x4 e = f_entry[rank];
+      const cstile::u32x4 v = *reinterpret_cast<const cstile::u32x4*>(lds_out + 16 * c);
+      *reinterpret_cast<cstile::u32x4*>(lds_out + 16 * c) = zero4;
+      const int rel = c - (int)(e.z & 0xffffu);
+      const bool whole = rel < (int)(e.z >> 16);
+      uint8_t* ga = reinterpret_cast<uint8_t*>((((unsigned long long)e.y << 32) | e.x) + (unsigned long long)(16 * rel));
+      const bool head = whole && rel == 0 && e.w != 0;
+      if (whole && !head) *(cstile::gptr<cstile::u32x4>)cstile::as_global(ga) = v;
+      if (__any(head)) {
+        // a run's first whole chunk of a column: its leading bytes belong to the wave in front, bytes head .. 15 go out
+        // one by one (once per run and column)
+        if (head) {
+          const uint32_t d[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+          for (int j = 0; j < 16; ++j)
+            if (j >= (int)e.w) cstile::as_global(ga)[j] = (uint8_t)(d[j >> 2] >> (8 * (j & 3)));
+        }
+      }
+    }
+    if (act && nwhole > 0) c_head = 0;  // (the column's first whole chunk of the run has left)
+    if (lane < ncols) {
+      unsigned long long vm = ((unsigned long long)vm_hi << 32) | vm_lo;
+      *cstile::as_global(reinterpret_cast<unsigned long long*>(c_valid + tile * 8)) = vm;
+      if (r0 + 64 == in.rows) cstile::as_global(c_off)[in.rows] = (off_t)c_pos;  // (a last sub-tile of exactly 64 rows)
+    }
+    if (!has_next) break;
+    tile += 1;
+    nxt = nn;
+    cstile::wave_lds_fence();  // (the tables in the in tile are read; the next sub-tile may be staged over them)
+  }
+  // ---- the run's last bytes of every column: what is still carried goes out bytewise
+  if (lane < ncols && c_cph > c_head) {
+    *reinterpret_cast<cstile::u32x4*>(lds_out + 16 * lane) = carry;
+    cstile::gptr<uint8_t> d = cstile::as_global(reinterpret_cast<uint8_t*>(c_ga));
+    for (int j = c_head; j < c_cph; ++j) d[j] = lds_out[16 * lane + j];
   }
 }
 
@@ -1185,7 +1464,9 @@ bool split_fast(const cs_column* col, const unsigned char* delim, int dlen, int 
       // third generation (all columns side by side in one out tile, one flush per sub-tile) when its tiles fit
       // (regions: every token byte once, up to 15 carried bytes and up to 15 bytes of padding per column, 20 bytes of OR slack)
       const int cap_out3 = (int)((span + 31 * ncols + 48 + 15) & ~(int64_t)15);
-      const int cap_in3 = (int)((span + 15 + 32 + 15) & ~(int64_t)15);
+      // (the fourth generation keeps its flush tables, 640 bytes, in the in tile once the column loop is over)
+      const bool want_emit4 = !getenv("CS_SPLIT_EMIT3") && cap_out3 <= 8192;
+      const int cap_in3 = std::max((int)((span + 15 + 32 + 15) & ~(int64_t)15), want_emit4 ? 640 : 0);
       const size_t lds3 = 288 + (size_t)(16 + cap_in3 + 32 + cap_out3) * (kEmit3Threads / 64);
       unsigned g2 = 0;
       if (want_emit3 && lds3 <= 64 * 1024) {
@@ -1194,7 +1475,10 @@ bool split_fast(const cs_column* col, const unsigned char* delim, int dlen, int 
         const bool plain = plain_walk;
         static const Emit3Kernel kerns3[2][3] = {{k_split_emit3<0, false, false>, k_split_emit3<1, false, false>, k_split_emit3<2, false, false>},
                                                  {k_split_emit3<0, true, false>, k_split_emit3<1, true, false>, k_split_emit3<2, true, false>}};
-        const Emit3Kernel kern3 = plain ? (off32 ? k_split_emit3<0, true, true> : k_split_emit3<0, false, true>) : kerns3[off32 ? 1 : 0][mode];
+        static const Emit3Kernel kerns4[2][3] = {{k_split_emit4<0, false, false>, k_split_emit4<1, false, false>, k_split_emit4<2, false, false>},
+                                                 {k_split_emit4<0, true, false>, k_split_emit4<1, true, false>, k_split_emit4<2, true, false>}};
+        const Emit3Kernel kern3 = want_emit4 ? (plain ? (off32 ? k_split_emit4<0, true, true> : k_split_emit4<0, false, true>) : kerns4[off32 ? 1 : 0][mode])
+                                             : (plain ? (off32 ? k_split_emit3<0, true, true> : k_split_emit3<0, false, true>) : kerns3[off32 ? 1 : 0][mode]);
         if (lds3 > 48 * 1024) CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern3), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
         Emit3Args e3{e2, cap_in3, cap_out3};
         constexpr int wpg = kEmit3Threads / 64;
