@@ -114,6 +114,11 @@ __global__ void __launch_bounds__(256) k_case_tile(CaseTileArgs a) {
           }
         }
       }
+      if (__any(high)) {
+        // the row lanes rewrite bytes the piece lanes have just stored: the first stores must have left the wave before
+        // the second ones are issued (two stores to one address from different lanes are not ordered otherwise)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
       if (__any(high) && n > 0) {
         const uint8_t* p = in.chars + (g0 + rbeg);
         if (row_case_size(p, n, a.flags, a.cases, a.bit) != n) atomicOr(a.changed, 1u);

@@ -1087,16 +1087,78 @@ __global__ void __launch_bounds__(kEmit3Threads, CS_EMIT3_WAVES) k_split_emit3(E
 // so the column loop does only what needs the rows' lanes, and everything per COLUMN runs once per sub-tile with the
 // columns in the lanes:
 //   * a round takes TWO columns: two token-walk steps, ONE wave scan over both lengths packed 16 + 16 bits (a
-//     sub-tile adds at most 64 x 96 bytes to a column), offsets stores, the tokens' OR into their regions.  It leaves
-//     the column's byte count and region start in the column's lane (v_writelane) and nothing else;
+//     sub-tile adds at most 64 x 96 bytes to a column) with the columns' state read out of their lanes in the scan's
+//     wait states, offsets stores (scalar base + lane offset), both tokens read before either is OR-ed into its region
+//     (no predication: a lane without a token ORs nothing at a valid address).  It leaves the column's byte count, region
+//     start and validity word in the column's lane (v_writelane) and nothing else;
 //   * after the loop the column lanes -- all at once -- OR their carried bytes in front of their regions, read the
-//     new carry (the partial chunk behind the last whole one), advance position / chunk address / phase and write a
-//     16-byte flush entry per non-empty region into the by then dead in tile, next to a bitmap of region starts;
+//     new carry (the partial chunk behind the last whole one), advance their position and write a 16-byte flush entry
+//     per non-empty region into the by then dead in tile, next to a bitmap of region starts;
 //   * one flush pass over the out tile: lane i takes chunks i, i + 64, ...; the region a chunk belongs to is the
 //     number of start bits at or below it (word prefix counts + one popcount), the entry gives the global address;
 //     whole chunks leave with 16-byte stores and are zeroed again, a region's partial last chunk is only zeroed.
 //   * rows beyond the sub-tile's last (the column's last sub-tile only) write the FINAL offset entry: their prefix
 //     is the sub-tile's total, so no store in the loop is predicated on the row count.
+// A column's state is its position alone: the chars buffers are 16-byte aligned (checked by the host), so the chunk the
+// column ends in and the bytes in front of the end follow from the position's low four bits.
+
+// the packed scan of a pair round; the six v_readlane that fetch the two columns' offsets pointers and positions stand
+// in the wait states a DPP read of a freshly written register needs (they replace s_nop)
+__device__ __forceinline__ int scan_pair(int v, int k, uint32_t off_lo, uint32_t off_hi, uint32_t pos, uint32_t& a_lo, uint32_t& a_hi, uint32_t& a_pos,
+                                         uint32_t& b_lo, uint32_t& b_hi, uint32_t& b_pos) {
+  const int k1 = k + 1;
+  asm volatile(
+      "v_readlane_b32 %1, %7, %10\n\t"
+      "v_readlane_b32 %2, %8, %10\n\t"
+      "v_add_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_readlane_b32 %3, %9, %10\n\t"
+      "s_nop 0\n\t"
+      "v_add_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_readlane_b32 %4, %7, %11\n\t"
+      "s_nop 0\n\t"
+      "v_add_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_readlane_b32 %5, %8, %11\n\t"
+      "s_nop 0\n\t"
+      "v_add_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_readlane_b32 %6, %9, %11\n\t"
+      "s_nop 0\n\t"
+      "v_add_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_add_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+      "s_nop 1"
+      : "+v"(v), "=&s"(a_lo), "=&s"(a_hi), "=&s"(a_pos), "=&s"(b_lo), "=&s"(b_hi), "=&s"(b_pos)
+      : "v"(off_lo), "v"(off_hi), "v"(pos), "s"(k), "s"(k1));
+  return v;
+}
+// what a round leaves in column k's lane: validity word, byte count | region start << 16
+__device__ __forceinline__ void leave_in_lane(int k, unsigned long long valid, int packed, uint32_t& vm_lo, uint32_t& vm_hi, uint32_t& t_pack) {
+  asm volatile(
+      "s_mov_b32 m0, %3\n\t"
+      "v_writelane_b32 %0, %4, m0\n\t"
+      "v_writelane_b32 %1, %5, m0\n\t"
+      "v_writelane_b32 %2, %6, m0"
+      : "+v"(vm_lo), "+v"(vm_hi), "+v"(t_pack)
+      : "s"(__builtin_amdgcn_readfirstlane(k)), "s"(__builtin_amdgcn_readfirstlane((int)(uint32_t)valid)),
+        "s"(__builtin_amdgcn_readfirstlane((int)(uint32_t)(valid >> 32))), "s"(__builtin_amdgcn_readfirstlane(packed))
+      : "m0");
+}
+// offsets store: wave-uniform base in scalar registers, the lane's byte offset in a vector register.
+// (s_nop 4: a VMEM instruction that reads a scalar register written by a VALU instruction -- the readfirstlane below, when
+// the compiler formed the pointer in vector registers -- needs five wait states, and the compiler's hazard recognizer does
+// not look into inline assembly: the measurement build stored to garbage addresses without it)
+template <class T>
+__device__ __forceinline__ T* scalar_ptr(T* p) {  // (a no-op when the compiler already knows the pointer to be wave-uniform)
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)p);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((uintptr_t)p >> 32));
+  return reinterpret_cast<T*>(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ void store_off(int32_t* base, int voff, int32_t v) {
+  asm volatile("s_nop 4\n\tglobal_store_dword %0, %1, %2" ::"v"(voff), "v"(v), "s"(scalar_ptr(base)) : "memory");
+}
+__device__ __forceinline__ void store_off(int64_t* base, int voff, int64_t v) {
+  asm volatile("s_nop 4\n\tglobal_store_dwordx2 %0, %1, %2" ::"v"(voff), "v"(v), "s"(scalar_ptr(base)) : "memory");
+}
+
 template <int MODE, bool OFF32, bool PLAIN>
 __global__ void __launch_bounds__(kEmit3Threads, CS_EMIT3_WAVES) k_split_emit4(Emit3Args args) {
   constexpr bool WS = MODE == 1, MULTI = MODE == 2;
@@ -1126,24 +1188,21 @@ __global__ void __launch_bounds__(kEmit3Threads, CS_EMIT3_WAVES) k_split_emit4(E
   if (tile >= tile_end) return;
   const ColView& in = a.in;
   const int ncols = a.ncols;
-  // lane k keeps column k: the 16-byte aligned address of the chunk its chars currently end in, the bytes of that
-  // chunk in front of the end (carried from the previous sub-tile -- or the neighbouring run's, while c_head != 0),
-  // the running position (the offsets' value), the carried bytes
-  unsigned long long c_ga = 0;
+  // lane k keeps column k: the running position (the offsets' value; its low four bits = the bytes carried in front of it
+  // in its 16-byte chunk -- the previous sub-tile's, or the neighbouring run's while c_head != 0), the carried bytes
   long long c_pos = 0;
-  int c_cph = 0, c_head = 0;
+  int c_head = 0;
+  uint8_t* c_chars = nullptr;
   off_t* c_off = nullptr;
   uint8_t* c_valid = nullptr;
   cstile::u32x4 carry = zero4;
   if (lane < ncols) {
     const ColOut2 c = a.cols[lane];
+    c_chars = c.chars;
     c_off = reinterpret_cast<off_t*>(c.offsets);
     c_valid = c.validity;
     c_pos = c.seg_base[run * a.segs_per_run];
-    const uintptr_t at = (uintptr_t)c.chars + (uintptr_t)c_pos;
-    c_ga = at & ~(uintptr_t)15;
-    c_cph = (int)(at & 15);
-    c_head = c_cph;
+    c_head = (int)c_pos & 15;
   }
   cstile::TileOffs cur = cstile::load_tile_offsets(in.offsets, in.rows, tile, lane);
   cstile::TileOffs nxt = cur;
@@ -1202,85 +1261,117 @@ __global__ void __launch_bounds__(kEmit3Threads, CS_EMIT3_WAVES) k_split_emit4(E
       return tk.next(lo, hi);
     };
     // a row beyond the sub-tile's last writes the final offset entry (its prefix is the sub-tile's total)
-    const int rowslot = min(lane, nrows);
+    const int rowoff = min(lane, nrows) * (int)sizeof(off_t);
     const uint8_t* tok_src = lds_in + lead + rbeg;
-    // what a round leaves in the column's lane: bytes added by this sub-tile (0: the column is not touched below), where
-    // its region begins in the out tile, the validity word
-    int t_sum = 0, t_rg = 0;
-    uint32_t vm_lo = 0, vm_hi = 0;
+    // what a round leaves in the column's lane: the validity word; bytes added by this sub-tile (0: the column is not
+    // touched below) | where its region begins in the out tile << 16
+    uint32_t t_pack = 0, vm_lo = 0, vm_hi = 0;
     int rg = 0;  // where the next region begins (wave-uniform)
     int k = 0;
-    auto put_tokens = [&](bool has, int lo, int len, int at) {
-      if (has) lds_or16u(lds_out, at, tok_src, lo, min(len, 16), tail);
-      if (__any(len > 16)) {  // (tokens beyond 16 bytes: the same, 16 bytes at a time)
-        for (int done = 16; __any(done < len); done += 16)
-          if (done < len) lds_or16u(lds_out, at + done, tok_src, lo + done, min(len - done, 16), tail);
-      }
+    const uint32_t coff_lo = (uint32_t)(uintptr_t)c_off, coff_hi = (uint32_t)((uintptr_t)c_off >> 32);
+    auto or_token = [&](cstile::u32x4 v, cstile::u32x4 m, int di) {
+      const uint32_t a0 = v.x & m.x, a1 = v.y & m.y, a2 = v.z & m.z, a3 = v.w & m.w;
+      const unsigned up = (0u - (unsigned)di) & 3u;
+      uint32_t* o = reinterpret_cast<uint32_t*>(lds_out + (((di + 3) & ~3) - 4));
+      lds_or(o + 0, __builtin_amdgcn_alignbyte(a0, 0u, up));
+      lds_or(o + 1, __builtin_amdgcn_alignbyte(a1, a0, up));
+      lds_or(o + 2, __builtin_amdgcn_alignbyte(a2, a1, up));
+      lds_or(o + 3, __builtin_amdgcn_alignbyte(a3, a2, up));
+      lds_or(o + 4, __builtin_amdgcn_alignbyte(0u, a3, up));
     };
-    for (; k < ncols; k += 2) {
+    auto long_tokens = [&](int lo, int len, int at) {  // (tokens beyond 16 bytes: the rest, 16 bytes at a time)
+      for (int done = 16; __any(done < len); done += 16)
+        if (done < len) lds_or16u(lds_out, at + done, tok_src, lo + done, min(len - done, 16), tail);
+    };
+    auto off_base = [&](uint32_t lo, uint32_t hi) -> off_t* {
+      return reinterpret_cast<off_t*>((((unsigned long long)hi << 32) | lo) + (unsigned long long)r0 * sizeof(off_t));
+    };
+    // ---- pairs of columns
+    for (; k + 1 < (EXP(8) ? 0 : ncols); k += 2) {
       int loA = 0, hiA = 0, loB = 0, hiB = 0;
       const bool hasA = step(loA, hiA);
       const unsigned long long vA = __ballot(hasA);
       if (vA == 0) break;  // no row of the sub-tile reaches column k (nor any behind it)
-      const bool two = k + 1 < ncols;
-      bool hasB = false;
-      if (two) hasB = step(loB, hiB);
+      const bool hasB = step(loB, hiB);
       const unsigned long long vB = __ballot(hasB);
       const int lenA = hasA ? hiA - loA : 0, lenB = hasB ? hiB - loB : 0;
-      const int incl = wave_inclusive_scan_fused(lenA | (lenB << 16));
+      // both tokens' first sixteen bytes and tail masks (a lane without a token reads its row's start and masks it all)
+      const cstile::lds_u32x4u rA = *reinterpret_cast<const cstile::lds_u32x4u*>(tok_src + (hasA ? loA : 0));
+      const cstile::lds_u32x4u rB = *reinterpret_cast<const cstile::lds_u32x4u*>(tok_src + (hasB ? loB : 0));
+      const cstile::u32x4 mA = tail[min(lenA, 16)], mB = tail[min(lenB, 16)];
+      uint32_t a_lo, a_hi, a_pos, b_lo, b_hi, b_pos;
+      const int incl = scan_pair(lenA | (lenB << 16), k, coff_lo, coff_hi, (uint32_t)c_pos, a_lo, a_hi, a_pos, b_lo, b_hi, b_pos);
       const int tot2 = rl(incl, 63);
       const int preA = (incl & 0xffff) - lenA, preB = (int)((unsigned)incl >> 16) - lenB;
       const int csumA = tot2 & 0xffff, csumB = (int)((unsigned)tot2 >> 16);
-      // ---- column k
-      {
-        cstile::gptr<off_t> coff = cstile::as_global(reinterpret_cast<off_t*>(cstile::rl64((long long)(uintptr_t)c_off, k))) + r0;
-        const off_t base = OFF32 ? (off_t)rl((int)c_pos, k) : (off_t)cstile::rl64(c_pos, k);
-        coff[rowslot] = base + (off_t)preA;
-        const int cph = rl(c_cph, k);
-        vm_lo = (uint32_t)wl((int)(uint32_t)vA, k, (int)vm_lo);
-        vm_hi = (uint32_t)wl((int)(uint32_t)(vA >> 32), k, (int)vm_hi);
-        t_sum = wl(csumA, k, t_sum);
-        t_rg = wl(rg, k, t_rg);
-        put_tokens(hasA, loA, lenA, rg + cph + preA);
-        if (csumA) rg += (cph + csumA + 15) & ~15;
+      const off_t baseA = OFF32 ? (off_t)(int)a_pos : (off_t)cstile::rl64(c_pos, k);
+      const off_t baseB = OFF32 ? (off_t)(int)b_pos : (off_t)cstile::rl64(c_pos, k + 1);
+      if (!EXP(1)) store_off(off_base(a_lo, a_hi), rowoff, baseA + (off_t)preA);
+      if (!EXP(1)) store_off(off_base(b_lo, b_hi), rowoff, baseB + (off_t)preB);
+      const int cphA = (int)a_pos & 15, cphB = (int)b_pos & 15;
+      const int rgB = rg + (csumA ? (cphA + csumA + 15) & ~15 : 0);
+      leave_in_lane(k, vA, csumA | (rg << 16), vm_lo, vm_hi, t_pack);
+      leave_in_lane(k + 1, vB, csumB | (rgB << 16), vm_lo, vm_hi, t_pack);
+      // (a lane without a token ORs zeros: at an address of its own -- the same dword from many lanes would serialise)
+      const int atA = rg + cphA + preA, atB = rgB + cphB + preB;
+      if (!EXP(4)) {
+#if defined(CS_EMIT4_PRED)
+      if (hasA) or_token(cstile::u32x4{rA.x, rA.y, rA.z, rA.w}, mA, atA);
+      if (hasB) or_token(cstile::u32x4{rB.x, rB.y, rB.z, rB.w}, mB, atB);
+#else
+      or_token(cstile::u32x4{rA.x, rA.y, rA.z, rA.w}, mA, hasA ? atA : lane * 20);
+      or_token(cstile::u32x4{rB.x, rB.y, rB.z, rB.w}, mB, hasB ? atB : lane * 20);
+#endif
       }
-      // ---- column k + 1
-      if (two) {
-        cstile::gptr<off_t> coff = cstile::as_global(reinterpret_cast<off_t*>(cstile::rl64((long long)(uintptr_t)c_off, k + 1))) + r0;
-        const off_t base = OFF32 ? (off_t)rl((int)c_pos, k + 1) : (off_t)cstile::rl64(c_pos, k + 1);
-        coff[rowslot] = base + (off_t)preB;
-        const int cph = rl(c_cph, k + 1);
-        vm_lo = (uint32_t)wl((int)(uint32_t)vB, k + 1, (int)vm_lo);
-        vm_hi = (uint32_t)wl((int)(uint32_t)(vB >> 32), k + 1, (int)vm_hi);
-        t_sum = wl(csumB, k + 1, t_sum);
-        t_rg = wl(rg, k + 1, t_rg);
-        if (vB) put_tokens(hasB, loB, lenB, rg + cph + preB);
-        if (csumB) rg += (cph + csumB + 15) & ~15;
+      if (__any(max(lenA, lenB) > 16)) {
+        long_tokens(loA, lenA, atA);
+        long_tokens(loB, lenB, atB);
+      }
+      rg = rgB + (csumB ? (cphB + csumB + 15) & ~15 : 0);
+    }
+    // ---- an odd last column
+    if (k + 1 == ncols) {
+      int lo = 0, hi = 0;
+      const bool has = step(lo, hi);
+      const unsigned long long vA = __ballot(has);
+      if (vA != 0) {
+        const int len = has ? hi - lo : 0;
+        const int incl = wave_inclusive_scan_fused(len);
+        const int csum = rl(incl, 63), pre = incl - len;
+        const off_t base = OFF32 ? (off_t)rl((int)c_pos, k) : (off_t)cstile::rl64(c_pos, k);
+        store_off(off_base((uint32_t)rl((int)coff_lo, k), (uint32_t)rl((int)coff_hi, k)), rowoff, base + (off_t)pre);
+        const int cph = (int)base & 15;
+        leave_in_lane(k, vA, csum | (rg << 16), vm_lo, vm_hi, t_pack);
+        const int at = rg + cph + pre;
+        if (has) lds_or16u(lds_out, at, tok_src, lo, min(len, 16), tail);
+        if (__any(len > 16)) long_tokens(lo, len, at);
+        if (csum) rg += (cph + csum + 15) & ~15;
+        ++k;
       }
     }
     // ---- columns no row of the sub-tile reaches: null rows at the column's running position
-    for (; k < ncols; ++k) {
-      cstile::gptr<off_t> coff = cstile::as_global(reinterpret_cast<off_t*>(cstile::rl64((long long)(uintptr_t)c_off, k))) + r0;
+    for (; k < (EXP(1) ? 0 : ncols); ++k) {
       const off_t base = OFF32 ? (off_t)rl((int)c_pos, k) : (off_t)cstile::rl64(c_pos, k);
-      coff[rowslot] = base;
+      store_off(off_base((uint32_t)rl((int)coff_lo, k), (uint32_t)rl((int)coff_hi, k)), rowoff, base);
     }
     // ---- per column, the columns in the lanes
-    const bool act = lane < ncols && t_sum > 0;
+    const int t_sum = (int)(t_pack & 0xffffu), t_rg = (int)(t_pack >> 16);
+    const bool act = lane < ncols && t_sum > 0 && !EXP(64);
+    const int c_cph = (int)c_pos & 15;
     const int tot = c_cph + t_sum, nwhole = tot >> 4;
     const unsigned long long actm = __ballot(act);
     if (lane < 16) f_bits[lane] = 0u;  // (the in tile is dead: every token has been copied)
     if (act) {
       // the carried bytes open the region (the tokens were OR-ed in behind them; a run's first chunk keeps zeros in
       // front: those bytes are the neighbouring run's)
-      if (c_cph) {
-        uint32_t* o = reinterpret_cast<uint32_t*>(lds_out + t_rg);
-        lds_or(o + 0, carry.x);
-        lds_or(o + 1, carry.y);
-        lds_or(o + 2, carry.z);
-        lds_or(o + 3, carry.w);
-      }
+      uint32_t* o = reinterpret_cast<uint32_t*>(lds_out + t_rg);
+      lds_or(o + 0, carry.x);
+      lds_or(o + 1, carry.y);
+      lds_or(o + 2, carry.z);
+      lds_or(o + 3, carry.w);
       const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(actm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)actm, 0u));
-      f_entry[rank] = cstile::u32x4{(uint32_t)c_ga, (uint32_t)(c_ga >> 32), (uint32_t)(t_rg >> 4) | ((uint32_t)nwhole << 16), (uint32_t)c_head};
+      const unsigned long long ga = (unsigned long long)(uintptr_t)c_chars + (unsigned long long)(c_pos & ~15ll);
+      f_entry[rank] = cstile::u32x4{(uint32_t)ga, (uint32_t)(ga >> 32), (uint32_t)(t_rg >> 4) | ((uint32_t)nwhole << 16), (uint32_t)c_head};
       lds_or(f_bits + (t_rg >> 9), 1u << ((t_rg >> 4) & 31));
     }
     cstile::wave_lds_fence();
@@ -1288,8 +1379,6 @@ __global__ void __launch_bounds__(kEmit3Threads, CS_EMIT3_WAVES) k_split_emit4(E
       // the bytes behind the last whole chunk are the new carry
       carry = (tot & 15) ? *reinterpret_cast<const cstile::u32x4*>(lds_out + t_rg + 16 * nwhole) : zero4;
       c_pos += t_sum;
-      c_ga += (unsigned long long)(16 * nwhole);
-      c_cph = tot & 15;
     }
     {
       const int cnt = lane < 16 ? __builtin_popcount(f_bits[lane]) : 0;
@@ -1298,7 +1387,7 @@ __global__ void __launch_bounds__(kEmit3Threads, CS_EMIT3_WAVES) k_split_emit4(E
     }
     cstile::wave_lds_fence();
     // ---- the flush pass: every 16-byte chunk of the out tile below rg
-    const int nchunks = rg >> 4;
+    const int nchunks = EXP(32) ? 0 : rg >> 4;
     for (int c = lane; c < nchunks; c += 64) {
       const uint32_t word = f_bits[c >> 5];
       const int rank = (int)f_pfx[c >> 5] + __builtin_popcount(word & (0xFFFFFFFFu >> (31 - (c & 31)))) - 1;
@@ -1309,15 +1398,13 @@ __global__ void __launch_bounds__(kEmit3Threads, CS_EMIT3_WAVES) k_split_emit4(E
       const bool whole = rel < (int)(e.z >> 16);
       uint8_t* ga = reinterpret_cast<uint8_t*>((((unsigned long long)e.y << 32) | e.x) + (unsigned long long)(16 * rel));
       const bool head = whole && rel == 0 && e.w != 0;
-      if (whole && !head) *(cstile::gptr<cstile::u32x4>)cstile::as_global(ga) = v;
+      if (whole && !head && !EXP(2)) *(cstile::gptr<cstile::u32x4>)cstile::as_global(ga) = v;
       if (__any(head)) {
         // a run's first whole chunk of a column: its leading bytes belong to the wave in front, bytes head .. 15 go out
         // one by one (once per run and column)
         if (head) {
           const uint32_t d[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-          for (int j = 0; j < 16; ++j)
-            if (j >= (int)e.w) cstile::as_global(ga)[j] = (uint8_t)(d[j >> 2] >> (8 * (j & 3)));
+          for (int j = (int)e.w; j < 16; ++j) cstile::as_global(ga)[j] = (uint8_t)(d[j >> 2] >> (8 * (j & 3)));
         }
       }
     }
@@ -1333,10 +1420,10 @@ __global__ void __launch_bounds__(kEmit3Threads, CS_EMIT3_WAVES) k_split_emit4(E
     cstile::wave_lds_fence();  // (the tables in the in tile are read; the next sub-tile may be staged over them)
   }
   // ---- the run's last bytes of every column: what is still carried goes out bytewise
-  if (lane < ncols && c_cph > c_head) {
+  if (lane < ncols && ((int)c_pos & 15) > c_head) {
     *reinterpret_cast<cstile::u32x4*>(lds_out + 16 * lane) = carry;
-    cstile::gptr<uint8_t> d = cstile::as_global(reinterpret_cast<uint8_t*>(c_ga));
-    for (int j = c_head; j < c_cph; ++j) d[j] = lds_out[16 * lane + j];
+    cstile::gptr<uint8_t> d = cstile::as_global(c_chars + (c_pos & ~15ll));
+    for (int j = c_head; j < ((int)c_pos & 15); ++j) d[j] = lds_out[16 * lane + j];
   }
 }
 
@@ -1465,7 +1552,8 @@ bool split_fast(const cs_column* col, const unsigned char* delim, int dlen, int 
       // (regions: every token byte once, up to 15 carried bytes and up to 15 bytes of padding per column, 20 bytes of OR slack)
       const int cap_out3 = (int)((span + 31 * ncols + 48 + 15) & ~(int64_t)15);
       // (the fourth generation keeps its flush tables, 640 bytes, in the in tile once the column loop is over)
-      const bool want_emit4 = !getenv("CS_SPLIT_EMIT3") && cap_out3 <= 8192;
+      bool want_emit4 = !getenv("CS_SPLIT_EMIT3") && cap_out3 <= 8192;
+      for (int k = 0; k < ncols; ++k) want_emit4 = want_emit4 && ((uintptr_t)outs[k].chars & 15) == 0;  // (a column's state is its position)
       const int cap_in3 = std::max((int)((span + 15 + 32 + 15) & ~(int64_t)15), want_emit4 ? 640 : 0);
       const size_t lds3 = 288 + (size_t)(16 + cap_in3 + 32 + cap_out3) * (kEmit3Threads / 64);
       unsigned g2 = 0;

@@ -112,6 +112,7 @@ __device__ __forceinline__ long long lookback(u64* status, long long stride, lon
     excl += part;
     if (first_inc < 64) break;
     t -= 64;
+    clock.reset();  // (progress: the bound is time WITHOUT progress)
   }
   if (lane == 0) status_store(mine, kFlagInc | ((u64)(excl + aggregate) & kValMask));
   return excl;
@@ -369,6 +370,7 @@ __device__ __forceinline__ long long lookback_end(u64* status, long long tile, l
       break;
     }
     t -= 64;
+    clock.reset();  // (progress: the bound is time WITHOUT progress)
 #if defined(CS_PHASE_PROF)
     ++windows;
 #endif
