@@ -31,6 +31,7 @@
 #include "cs_internal.h"
 #include "device_utils.h"
 #include "tile_utils.h"
+#include "split_parts.h"
 
 using namespace cs;
 using namespace csdev;
@@ -38,277 +39,11 @@ using namespace csdev;
 namespace cs {
 bool split_fast(const cs_column* col, const unsigned char* delim, int dlen, int tokens, hipStream_t s,
                 std::vector<std::unique_ptr<cs_column>>& cols, bool reverse = false);
+int split_single(const cs_column* col, const unsigned char* delim, int dlen, int tokens, hipStream_t s,
+                 std::vector<std::unique_ptr<cs_column>>& cols, bool reverse, int64_t span, bool plain_walk);
 }
 
 namespace {
-
-constexpr int kSub = 64;
-constexpr int kMaxCols = 32;      // the second- and third-generation kernels (a register per column in the measure pass)
-constexpr int kMaxColsWide = 64;  // the first generation: lane k holds column k's destination
-
-struct RowWords {  // a row inside an LDS buffer, read through aligned 32-bit words
-  const uint8_t* base;  // 4-byte aligned
-  int beg;              // byte index of the row's first byte
-  int n;
-  int cwi;
-  uint32_t cw;
-  __device__ __forceinline__ RowWords(const uint8_t* b, int begin, int len) : base(b), beg(begin), n(len), cwi(-1), cw(0) {}
-  __device__ __forceinline__ uint32_t word(int widx) {
-    if (widx != cwi) {
-      cwi = widx;
-      cw = reinterpret_cast<const uint32_t*>(base)[widx];
-    }
-    return cw;
-  }
-  // first position p >= pos (row-relative) holding the delimiter, or n
-  __device__ __forceinline__ int find(int pos, uint32_t dpat) {
-    while (pos < n) {
-      const int j = beg + pos;
-      const uint32_t x = word(j >> 2) ^ dpat;
-      // exact per-byte zero test (no borrow between bytes: a flag below the masked-off
-      // part must not create a false hit above it)
-      const uint32_t m = ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u & (0xFFFFFFFFu << (8 * (j & 3)));
-      if (m) {
-        pos = (j & ~3) - beg + (__builtin_ctz(m) >> 3);
-        return pos < n ? pos : n;
-      }
-      pos = (j & ~3) + 4 - beg;
-    }
-    return n;
-  }
-};
-
-__device__ __forceinline__ int rl(int v, int k) { return __builtin_amdgcn_readlane(v, k); }
-__device__ __forceinline__ long long rl64(long long v, int k) {
-  const int lo = __builtin_amdgcn_readlane((int)(v & 0xffffffffll), k);
-  const int hi = __builtin_amdgcn_readlane((int)(v >> 32), k);
-  return ((long long)hi << 32) | (unsigned int)lo;
-}
-
-// lowest set bit of a 96-bit mask (m2 : m1 : m0), 0xFFFFFFFF when there is none: three v_ffbl_b32 (-1 for zero), the upper
-// two moved up with SATURATING adds so that "none" stays the largest value, one v_min3_u32
-__device__ __forceinline__ uint32_t lowest96(uint32_t m0, uint32_t m1, uint32_t m2) {
-  uint32_t f0, f1, f2, q;
-  asm("v_ffbl_b32 %0, %1" : "=v"(f0) : "v"(m0));
-  asm("v_ffbl_b32 %0, %1" : "=v"(f1) : "v"(m1));
-  asm("v_ffbl_b32 %0, %1" : "=v"(f2) : "v"(m2));
-  asm("v_add_u32_e64 %0, %1, 32 clamp" : "=v"(f1) : "v"(f1));
-  asm("v_add_u32_e64 %0, %1, 64 clamp" : "=v"(f2) : "v"(f2));
-  asm("v_min3_u32 %0, %1, %2, %3" : "=v"(q) : "v"(f0), "v"(f1), "v"(f2));
-  return q;
-}
-
-// The same scan as six fused v_add_u32_dpp (the compiler splits the generic form above into v_mov_b32_dpp + v_add_u32 when
-// the partial sums have other uses: twelve vector instructions).  The s_nop cover the two wait states a DPP read of a
-// freshly written VGPR needs; they cost the wave issue slots, not the SIMD.
-__device__ __forceinline__ int wave_inclusive_scan_fused(int v) {
-  asm volatile(
-      "s_nop 1\n\t"
-      "v_add_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-      "s_nop 1\n\t"
-      "v_add_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-      "s_nop 1\n\t"
-      "v_add_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-      "s_nop 1\n\t"
-      "v_add_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-      "s_nop 1\n\t"
-      "v_add_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
-      "s_nop 1\n\t"
-      "v_add_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
-      "s_nop 1"
-      : "+v"(v));
-  return v;
-}
-struct SubTile {
-  long long r0, g0;
-  int nrows, rbeg, n, lead;
-  bool live;
-  bool oversize;  // the span does not fit the staging buffer: nothing staged, the rows are read from memory
-};
-// loads the sub-tile's row extents and stages its chars span into `lds_in`
-// (`R` rows a sub-tile: 64, or fewer for the first-generation kernels on rows of hundreds of bytes)
-// `cap` > 0: the staging buffer's bytes -- a sub-tile beyond it is not staged (first-generation kernels: the host sized the
-// buffers for all but a few sub-tiles, one long row among millions of short ones)
-__device__ __forceinline__ SubTile load_subtile(const ColView& in, long long sub, uint8_t* lds_in, int lane, int R = kSub, int cap = 0) {
-  SubTile t;
-  t.r0 = sub * R;
-  t.nrows = (int)min((long long)R, in.rows - t.r0);
-  const long long o0 = in.offsets[t.r0 + min(lane, t.nrows)];
-  const long long o1 = in.offsets[t.r0 + min(lane + 1, t.nrows)];
-  t.g0 = rl64(o0, 0);
-  const long long g1 = rl64(o1, 63);
-  t.live = lane < t.nrows && row_is_valid(in.validity, t.r0 + lane);
-  t.rbeg = (int)(o0 - t.g0);
-  t.n = t.live ? (int)(o1 - o0) : 0;
-  t.lead = (int)((uintptr_t)(in.chars + t.g0) & 15);
-  const uint8_t* src = in.chars + (t.g0 - t.lead);  // 16-byte aligned
-  const long long span64 = g1 - t.g0 + t.lead;
-  t.oversize = cap > 0 && span64 + 32 > cap;
-  const int span = t.oversize ? 0 : (int)span64;
-  for (int i = lane * 16; i < span; i += 64 * 16)
-    *reinterpret_cast<uint4*>(lds_in + i) = *reinterpret_cast<const uint4*>(src + i);
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  return t;
-}
-
-// token walker: next() yields [lo, hi) of the row's next token, or false.
-// Rows of up to 96 bytes (from their aligned start) get the positions of all their
-// delimiters as a 96-bit mask held in registers, built in straight-line code from
-// 24 aligned words; the walk is then ctz + clear-lowest-bit per token.  Longer rows
-// search word by word.
-// WS (whitespace splitting, split.cu:863-956): a token is a maximal run of bytes above ' '
-// (every byte <= ' ' separates, no non-ASCII byte does); runs of separators collapse, there are
-// no empty tokens, and the token that exhausts maxsplit takes the rest of the row as it is.
-// The masks then hold token STARTS (m_*) and token ENDS (e_*); only the masked form exists.
-// MULTI (a delimiter of 2..8 ASCII bytes): the mask first holds the positions of the delimiter's
-// first byte; each row lane then keeps those where the whole delimiter stands and that do not
-// overlap the previous occurrence (the search continues after an occurrence, custring_view.inl:
-// 1223-1279), and a token ends where the next kept position begins.  Masked form only.
-template <bool MASKED_ONLY, bool WS = false, bool MULTI = false>
-struct TokensT {
-  RowWords w;
-  uint32_t dpat;
-  int cursor, k, limit;  // limit: token index that swallows the rest (maxsplit), or -1
-  bool more, masked;
-  unsigned long long m_lo;  // delimiter bits 0..63 (bit q = byte at row offset q - sa); WS: token starts
-  uint32_t m_hi;            // bits 64..95
-  unsigned long long e_lo;  // WS: last byte of each token
-  uint32_t e_hi;
-  int sa;
-  int dlen;  // delimiter bytes (1 unless MULTI)
-  // `reverse` (one-byte delimiter, a split limit, masked rows): rsplit -- the LAST `limit` delimiters of the row are the
-  // ones that split (split.cu:1006-1021 finds them from the right), so the first ones are struck from the mask and
-  // the forward walk over what is left yields rsplit's tokens, left-aligned in the columns as the reference has them.
-  __device__ __forceinline__ TokensT(const uint8_t* base, int beg, int n, bool live, uint32_t d, int tokens,
-                                     unsigned long long d64 = 0, int delim_len = 1, bool reverse = false)
-      : w(base, beg, n), dpat(d), cursor(0), k(0), limit(tokens > 0 ? tokens - 1 : -1), more(live), masked(false),
-        m_lo(0), m_hi(0), e_lo(0), e_hi(0), sa(beg & 3), dlen(MULTI ? delim_len : 1) {
-    // (MASKED_ONLY: the caller guarantees that every row fits the 96-bit mask)
-    if (MASKED_ONLY || __all(!live || n + sa <= 96)) {  // wave-uniform choice keeps the unrolled build convergent
-      masked = true;
-      const uint32_t* words = reinterpret_cast<const uint32_t*>(base) + (beg >> 2);
-      uint32_t r[3] = {0, 0, 0};
-      auto flags = [&](int i) -> uint32_t {  // bit 7 of every byte lane that separates
-        if (WS) {
-          const uint32_t x = words[i];  // byte <= 0x20: bit 7 clear and the low seven bits below 0x21
-          return ~(((x & 0x7F7F7F7Fu) + 0x5F5F5F5Fu) | x) & 0x80808080u;
-        }
-        const uint32_t x = words[i] ^ d;
-        return ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u;
-      };
-#pragma unroll
-      for (int i = 0; i < 24; i += 4)  // sixteen bytes -> sixteen bits (byte-wise dot products, tile_utils.h)
-        r[i >> 3] |= cstile::gather16_bit7(flags(i), flags(i + 1), flags(i + 2), flags(i + 3)) << (4 * (i & 7));
-      const int hi = sa + n;  // keep bits sa .. hi - 1
-      uint32_t in0 = 0xFFFFFFFFu << sa;
-      in0 &= hi >= 32 ? 0xFFFFFFFFu : ~(0xFFFFFFFFu << (hi & 31));
-      const uint32_t in1 = hi >= 64 ? 0xFFFFFFFFu : (hi <= 32 ? 0u : ~(0xFFFFFFFFu << (hi & 31)));
-      const uint32_t in2 = hi >= 96 ? 0xFFFFFFFFu : (hi <= 64 ? 0u : ~(0xFFFFFFFFu << (hi & 31)));
-      if (WS) {
-        // token bytes of the row, then starts (byte before is not a token byte) and ends (byte after)
-        const uint32_t t0 = ~r[0] & in0, t1 = ~r[1] & in1, t2 = ~r[2] & in2;
-        const uint32_t up0 = t0 << 1, up1 = (t1 << 1) | (t0 >> 31), up2 = (t2 << 1) | (t1 >> 31);
-        const uint32_t dn0 = (t0 >> 1) | (t1 << 31), dn1 = (t1 >> 1) | (t2 << 31), dn2 = t2 >> 1;
-        m_lo = ((unsigned long long)(t1 & ~up1) << 32) | (t0 & ~up0);
-        m_hi = t2 & ~up2;
-        e_lo = ((unsigned long long)(t1 & ~dn1) << 32) | (t0 & ~dn0);
-        e_hi = t2 & ~dn2;
-        more = live && (m_lo != 0 || m_hi != 0);
-      } else {
-        m_lo = ((unsigned long long)(r[1] & in1) << 32) | (r[0] & in0);
-        m_hi = r[2] & in2;
-        if (!MULTI && reverse && limit >= 0) {
-          int drop = __builtin_popcountll(m_lo) + __builtin_popcount(m_hi) - limit;  // delimiters that do not split
-          while (__any(drop > 0)) {
-            if (drop > 0) {
-              if (m_lo) m_lo &= m_lo - 1;
-              else m_hi &= m_hi - 1;
-              --drop;
-            }
-          }
-        }
-        if (MULTI) {
-          unsigned long long c_lo = m_lo, k_lo = 0;
-          uint32_t c_hi = m_hi, k_hi = 0;
-          int free_from = 0;  // row offset where the next occurrence may begin
-          const uint8_t* row = base + beg;
-          while (c_lo != 0 || c_hi != 0) {
-            int q;
-            if (c_lo) {
-              q = __builtin_ctzll(c_lo);
-              c_lo &= c_lo - 1;
-            } else {
-              q = 64 + __builtin_ctz(c_hi);
-              c_hi &= c_hi - 1;
-            }
-            const int pos = q - sa;
-            if (pos < free_from || pos + dlen > n) continue;
-            int j = 1;
-            while (j < dlen && row[pos + j] == (uint8_t)(d64 >> (8 * j))) ++j;
-            if (j < dlen) continue;
-            if (q < 64) k_lo |= 1ull << q;
-            else k_hi |= 1u << (q - 64);
-            free_from = pos + dlen;
-          }
-          m_lo = k_lo;
-          m_hi = k_hi;
-        }
-      }
-    }
-  }
-  __device__ __forceinline__ int next_delim() {  // masked: position of the next delimiter, or n
-    if (m_lo) {
-      const int q = __builtin_ctzll(m_lo);
-      m_lo &= m_lo - 1;
-      return q - sa;
-    }
-    if (m_hi) {
-      const int q = 64 + __builtin_ctz(m_hi);
-      m_hi &= m_hi - 1;
-      return q - sa;
-    }
-    return w.n;
-  }
-  __device__ __forceinline__ int next_end() {  // WS: position of the last byte of the next token
-    if (e_lo) {
-      const int q = __builtin_ctzll(e_lo);
-      e_lo &= e_lo - 1;
-      return q - sa;
-    }
-    const int q = 64 + __builtin_ctz(e_hi);
-    e_hi &= e_hi - 1;
-    return q - sa;
-  }
-  __device__ __forceinline__ bool next(int& lo, int& hi) {
-    if (!more) return false;
-    if (WS) {
-      lo = next_delim();  // (the next token start)
-      if (k == limit) {
-        hi = w.n;
-        more = false;
-      } else {
-        hi = next_end() + 1;
-        more = m_lo != 0 || m_hi != 0;
-      }
-      ++k;
-      return true;
-    }
-    lo = cursor;
-    if (k == limit) {
-      hi = w.n;
-      more = false;
-    } else {
-      hi = (MASKED_ONLY || masked) ? next_delim() : w.find(cursor, dpat);
-      if (hi >= w.n) more = false;
-      else cursor = hi + dlen;
-    }
-    ++k;
-    return true;
-  }
-};
-using Tokens = TokensT<false>;
 
 struct MeasureArgs {
   ColView in;
@@ -604,14 +339,6 @@ struct Emit2Args {
   int reverse;  // rsplit with a limit (TokensT)
   int debug;  // CS_SPLIT_DEBUG bit mask: 1 no offset stores, 2 no chars stores, 4 no assembly, 8 no column loop (measurement only)
 };
-// v_writelane_b32: the wave-uniform `v` into lane `k` of a vector register (no builtin in this compiler)
-__device__ __forceinline__ int wl(int v, int k, int old) {
-  asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(old) : "s"(v), "s"(k) : "m0");
-  return old;
-}
-__device__ __forceinline__ void lds_or(uint32_t* p, uint32_t v) {
-  __hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-}
 #ifndef CS_EMIT2_WAVES
 #define CS_EMIT2_WAVES 4
 #endif
@@ -774,50 +501,6 @@ __global__ void __launch_bounds__(256, CS_EMIT2_WAVES) k_split_emit2(Emit2Args a
 #endif
 }
 
-
-// ---- byte runs into an LDS tile with ALIGNED accesses only ---------------------------------------------
-// A DS access off its natural alignment is replayed a lane at a time on gfx950: 64 LDS cycles per wave-instruction
-// for every width but one byte (128 for some stores), against 3-5 for an aligned dword (tools/ubench/lds_align.hip).
-// The exact-size stores at any alignment that the second generation assembled its columns with made the LDS pipe
-// the kernel's bound (SQ_LDS_UNALIGNED_STALL: 1.3 k cycles per sub-tile).  Here a run of up to 16 bytes is read as
-// six aligned dwords, moved to the destination's byte phase with v_alignbyte, cut to its bytes with a mask per dword
-// (a 16-entry table in LDS: byte-validity nibble -> byte mask) and OR-ed into the zeroed destination as five aligned
-// dwords.  `src` needs 4 readable bytes in front of index 0 and 24 behind the run; `dst` 20 writable bytes from di & ~3.
-__device__ __forceinline__ void lds_or16(uint8_t* dst, int di, const uint8_t* src, int ti, int len, const uint32_t* lut) {
-  const int delta = (ti & 3) - (di & 3);  // -3 .. 3: source phase minus destination phase
-  const uint32_t* w = reinterpret_cast<const uint32_t*>(src + ((ti & ~3) - (delta < 0 ? 4 : 0)));
-  const unsigned d = (unsigned)delta & 3u;
-  const uint32_t w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3], w4 = w[4], w5 = w[5];
-  const uint32_t valid = ((1u << len) - 1u) << (di & 3);  // one bit per destination byte, from the first dword's byte 0
-  // (every read before the first OR: the compiler keeps a load behind an atomic it may alias and waits for each)
-  const uint32_t m0 = lut[valid & 15u], m1 = lut[(valid >> 4) & 15u], m2 = lut[(valid >> 8) & 15u], m3 = lut[(valid >> 12) & 15u],
-                 m4 = lut[(valid >> 16) & 15u];
-  uint32_t* o = reinterpret_cast<uint32_t*>(dst + (di & ~3));
-  lds_or(o + 0, __builtin_amdgcn_alignbyte(w1, w0, d) & m0);
-  lds_or(o + 1, __builtin_amdgcn_alignbyte(w2, w1, d) & m1);
-  lds_or(o + 2, __builtin_amdgcn_alignbyte(w3, w2, d) & m2);
-  lds_or(o + 3, __builtin_amdgcn_alignbyte(w4, w3, d) & m3);
-  lds_or(o + 4, __builtin_amdgcn_alignbyte(w5, w4, d) & m4);
-}
-
-// The same with ONE read of the run at whatever alignment it has (64 LDS cycles, but the run then stands at byte 0 of
-// four registers): only its tail needs a mask (tailmask: 17 entries of four dwords, entry n = the first n bytes), the
-// shift to the destination's byte phase fills with zeros from below, and the kernel -- bound by its VALU count, with
-// LDS time to spare once the stores are aligned -- gets away with a third of the vector instructions of lds_or16.
-__device__ __forceinline__ void lds_or16u(uint8_t* dst, int di, const uint8_t* src, int ti, int len, const cstile::u32x4* tailmask) {
-  const cstile::lds_u32x4u v = *reinterpret_cast<const cstile::lds_u32x4u*>(src + ti);
-  const cstile::u32x4 m = tailmask[len];
-  const uint32_t a0 = v.x & m.x, a1 = v.y & m.y, a2 = v.z & m.z, a3 = v.w & m.w;
-  // destination dword j receives bytes of {a_j : a_(j-1)} cut at the destination's byte phase pd: alignbyte by (4 - pd) & 3,
-  // which for pd = 0 yields a_(j-1) -- so that case begins one dword earlier (its first OR adds nothing)
-  const unsigned up = (0u - (unsigned)di) & 3u;
-  uint32_t* o = reinterpret_cast<uint32_t*>(dst + (((di + 3) & ~3) - 4));
-  lds_or(o + 0, __builtin_amdgcn_alignbyte(a0, 0u, up));
-  lds_or(o + 1, __builtin_amdgcn_alignbyte(a1, a0, up));
-  lds_or(o + 2, __builtin_amdgcn_alignbyte(a2, a1, up));
-  lds_or(o + 3, __builtin_amdgcn_alignbyte(a3, a2, up));
-  lds_or(o + 4, __builtin_amdgcn_alignbyte(0u, a3, up));
-}
 
 // ---- emit, third generation: all columns assembled side by side, no fence in the column loop ------------
 // Same inputs and outputs as k_split_emit2 (runs of consecutive sub-tiles per wave, column positions from the
@@ -1501,6 +1184,10 @@ bool split_fast(const cs_column* col, const unsigned char* delim, int dlen, int 
     // the sentinel walk (both passes): a one-byte delimiter, no split limit, every row's sentinel bit inside the 96-bit mask
     // (the longest row is column metadata, kept on the immutable column like its largest 64-row span)
     const bool plain_walk = want_emit3 && mode == 0 && tokens <= 0 && !reverse && max_row_bytes(col, s) + 3 <= 95 && !getenv("CS_SPLIT_GENERIC_WALK");
+    // the single pass (cs_split1.hip), on request: measured slower than the two passes below (NOTES.md, round 4:
+    // 8.0 against 6.7 ms on the 100M-row column); they also take over when it gives up
+    if (want_emit3 && getenv("CS_SPLIT_SINGLE") && !getenv("CS_SPLIT_OFF64") && split_single(col, delim, dlen, tokens, s, cols, reverse, span, plain_walk) == 1) return true;
+    cols.clear();
     Measure2Args ma{view_of(col), dpat, d64, dlen, tokens, cap_in, nsub, per, seg, nseg, segs_per_run, reverse ? 1 : 0, ptr<int32_t>(colsum), ptr<int>(mx)};
     {
       ProfScope ps("k_split_measure", s);

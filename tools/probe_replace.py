@@ -32,8 +32,8 @@ t0 = time.perf_counter()
 for _ in range(3): run()
 dt = (time.perf_counter() - t0) / 3
 L.cs_prof_enable(0)
-line = "%s rows=%d debug=%s wall=%.2f ms" % (what, rows, os.environ.get("CS_TILE_DEBUG", "0"), dt * 1e3)
-for k in ["k_replace_re", "k_replace_re_size", "k_replace_re_write", "k_split_count", "k_split_sizes", "k_split_write", "k_split_measure", "k_split_emit", "k_contains_re", "k_write_offsets"]:
+line = "%s rows=%d debug=%s/%s wall=%.2f ms" % (what, rows, os.environ.get("CS_TILE_DEBUG", "0"), os.environ.get("CS_SPLIT_DEBUG", "0"), dt * 1e3)
+for k in ["k_replace_re", "k_replace_re_size", "k_replace_re_write", "k_split_count", "k_split_sizes", "k_split_write", "k_split_sample", "k_split_measure", "k_split_emit", "k_split_fixup", "k_contains_re", "k_write_offsets"]:
     ms, n = C.c_double(), C.c_int64()
     L.cs_prof_get(k.encode(), C.byref(ms), C.byref(n))
     if n.value: line += " | %s %.2f" % (k, ms.value / n.value)
