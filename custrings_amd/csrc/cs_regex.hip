@@ -1179,14 +1179,22 @@ __global__ void __launch_bounds__(256, BREFS ? 2 : CS_STREAM_WAVES) k_tdfa_repla
   // workgroups (blockIdx mod 8, the observed XCD placement -- for speed only): counter k hands out
   // tiles k, k + 8, ...; a single word would saturate at the rate this kernel takes tiles.  The
   // ticket of the tile after next is in flight while the current tile is processed.
-  const long long K = gridDim.x >= 8 ? 8 : 1;
+  const long long K = gridDim.x >= 16 ? 8 : 1;  // (every class needs a workgroup that takes tiles: workgroup 0 may be the scanners')
   const long long key = (long long)blockIdx.x % K;
   const bool fixed = (a.debug & 256) != 0;  // measurement: the static round-robin
-  // Wave 0 of workgroup 0 takes no tiles: it turns the aggregates the other waves publish into each tile's
-  // exclusive prefix, in order (a tile then needs ONE load instead of a walk over its predecessors' words).
-  // (debug 512: the decoupled look-back, for comparison; it also serves tiles too small to lend the scanner its buffer)
-  const bool scanner = !fixed && !(a.debug & 512) && a.cap_in + a.cap_out + 32 >= cstile::kScanBatch * 512;
-  if (scanner && blockIdx.x == 0 && wv == 0) {
+  // Workgroup 0 takes no tiles: its four waves turn the aggregates the other waves publish into each tile's exclusive
+  // prefix, in order (a tile then needs ONE load instead of a walk over its predecessors' words): tile_utils.h,
+  // prefix_scanner_team.  (debug 512: the decoupled look-back, for comparison; debug 1024: the single scanner wave.)
+  const bool team = !fixed && !(a.debug & (512 | 1024)) && gridDim.x > 1;
+  const bool scanner = team || (!fixed && !(a.debug & 512) && a.cap_in + a.cap_out + 32 >= cstile::kScanBatch * 512);
+  if (team && blockIdx.x == 0) {
+    cstile::TeamRing* ring = reinterpret_cast<cstile::TeamRing*>(lds_in - (size_t)wv * (a.cap_in + a.cap_out + 64 + bm_bytes + unit_bytes));
+    if (threadIdx.x < 8) cstile::team_ring_init(ring, threadIdx.x);
+    __syncthreads();
+    if (cstile::prefix_scanner_team(a.status, a.excl, a.nsub, lane, wv, 4, ring, a.error) == 1 && lane == 0) atomicOr(a.error, 1u | 16u);  // (16: the scanners timed out)
+    return;
+  }
+  if (scanner && !team && blockIdx.x == 0 && wv == 0) {
     // (its tile buffers are free: they hold the fetched status words)
     if (!cstile::prefix_scanner(a.status, a.excl, a.nsub, lane, reinterpret_cast<cstile::u64*>(lds_in)) && lane == 0)
       atomicOr(a.error, 1u | 16u);  // (16: the scanner wave timed out)
@@ -1194,11 +1202,20 @@ __global__ void __launch_bounds__(256, BREFS ? 2 : CS_STREAM_WAVES) k_tdfa_repla
   }
   const long long W = (long long)gridDim.x * 4;
   unsigned long long* my_ticket = a.tickets + key * 8;
-  auto take = [&]() -> unsigned long long {
+  // A wave's FIRST three tickets come from a counter per round (words 1..3 of the class's line), the i-th round handing
+  // out the i-th block of `wc` tickets (wc = the class's waves), the running counter everything behind: three tickets
+  // drawn at once from one counter are consecutive, and a wave's second and third tile then lie in front of its
+  // neighbour's first, whose prefix has to wait for them -- a dependency chain through every wave of the class (with a
+  // dozen waves and a lost launch the waiters at its end spun long enough to notice the error word and turn a clean
+  // "once more, roomier" into a fallback; on the full grid it cost the first hundreds of microseconds).  With the
+  // scanners' workgroup out of the count the class's waves are known exactly (the grid is resident).
+  const long long wc = team ? 4 * (((long long)gridDim.x - 1 - key) / K + 1 - (key == 0 ? 1 : 0)) : 0;
+  auto take_from = [&](int which, long long add) -> unsigned long long {
     unsigned long long t = 0;
-    if (lane == 0) t = __hip_atomic_fetch_add(my_ticket, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane == 0) t = __hip_atomic_fetch_add(my_ticket + which, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + (unsigned long long)add;
     return t;
   };
+  auto take = [&]() -> unsigned long long { return take_from(0, 3 * wc); };
   auto tile_of = [&](unsigned long long t) -> long long { return (long long)cstile::rl64((long long)t, 0) * K + key; };
   long long tile, t_nxt, t_nn = 0;
   unsigned long long pending = 0;
@@ -1206,8 +1223,8 @@ __global__ void __launch_bounds__(256, BREFS ? 2 : CS_STREAM_WAVES) k_tdfa_repla
     tile = (long long)blockIdx.x * 4 + wv;
     t_nxt = tile + W;
   } else {
-    const unsigned long long q0 = take(), q1 = take();
-    pending = take();
+    const unsigned long long q0 = team ? take_from(1, 0) : take(), q1 = team ? take_from(2, wc) : take();
+    pending = team ? take_from(3, 2 * wc) : take();
     tile = tile_of(q0);
     t_nxt = tile_of(q1);
   }
@@ -1254,6 +1271,7 @@ __global__ void __launch_bounds__(256, BREFS ? 2 : CS_STREAM_WAVES) k_tdfa_repla
 #endif
     }
     if (gb < 0) {
+      if (lane == 0 && (a.debug & 2048)) printf("no prefix: tile %lld (wave %d of block %d, current tile %lld) error %u\n", p_tile, wv, (int)blockIdx.x, tile, *a.error);
       if (lane == 0) atomicOr(a.error, 1u | 8u);  // (8: no prefix for the tile)
       gb = 0;
     }

@@ -449,6 +449,124 @@ __device__ __forceinline__ bool prefix_scanner(const u64* status, u64* excl, lon
   }
   return true;
 }
+// ---- the same by a TEAM of waves of one workgroup ---------------------------------------------------
+// prefix_scanner above is one wave walking 64 tiles a step: fetch (a device-scope round trip), scan, store, next -- about
+// 140-200 tiles per microsecond, which is what the replace kernel takes tiles at: its waves spent 30 % of their cycles
+// waiting for prefixes (profiles/r04: lookback 7.6 k of 25 k cycles per sub-tile).  Here a lane takes FOUR consecutive
+// tiles (two 16-byte loads, 32 contiguous bytes a lane), a STEP covers 256 tiles with one wave scan, and `team` waves of
+// the workgroup share the steps round-robin: fetching, scanning and storing run in parallel, only the running sum is
+// handed from step to step through an LDS ring, a few hundred cycles a link.  Until a step is complete its wave polls
+// it; every tile up to and including the first unpublished one gets its prefix as soon as the step's base is known
+// (a tile's prefix needs its predecessors only -- small grids hold several tiles of a step in one wave).
+struct TeamRing {            // slot s & 7 holds the sum in front of step s once tag == s + 1
+  unsigned long long val[8];
+  unsigned tag[8];
+};
+__device__ __forceinline__ void team_ring_init(TeamRing* ring, int slot) {  // by eight threads, a barrier behind
+  ring->val[slot] = 0ull;
+  ring->tag[slot] = slot == 0 ? 1u : 0u;  // (nothing in front of step 0)
+}
+__device__ __forceinline__ int wave_scan_fused32(int v) {
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_add_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "s_nop 1\n\t"
+      "v_add_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "s_nop 1\n\t"
+      "v_add_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "s_nop 1\n\t"
+      "v_add_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "s_nop 1\n\t"
+      "v_add_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_add_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+      "s_nop 1"
+      : "+v"(v));
+  return v;
+}
+// wave `h` of `team`: steps h, h + team, ...  Returns 0 when done, 1 on a timeout, 2 when it left because somebody else
+// had raised `error` (the launch is lost anyway; the word is not touched).
+__device__ __forceinline__ int prefix_scanner_team(const u64* status, u64* excl, long long ntiles, int lane, int h, int team, TeamRing* ring,
+                                                    const unsigned* error) {
+  gptr<u64> ex = as_global(excl);
+  for (long long s = h; s * 256 < ntiles; s += team) {
+    const long long t0 = s * 256 + 4 * lane;  // the lane's first tile
+    const u64* at = status + t0;
+    bool in[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) in[i] = t0 + i < ntiles;
+    bool have_base = false;
+    u64 base = 0;
+    int delivered = -1;  // leading tiles of the step that have their prefix
+    SpinClock clock;
+    int idle = 0;
+    for (;;) {
+      u32x4 q0, q1;
+      asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %2, off offset:16 sc1\n\ts_waitcnt vmcnt(0)"
+                   : "=&v"(q0), "=&v"(q1)
+                   : "v"(at)
+                   : "memory");
+      const u64 x[4] = {((u64)q0.y << 32) | q0.x, ((u64)q0.w << 32) | q0.z, ((u64)q1.y << 32) | q1.x, ((u64)q1.w << 32) | q1.z};
+      bool pub[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) pub[i] = !in[i] || (x[i] >> 62) != 0;  // (beyond the last tile: nothing to wait for, nothing to add)
+      const int r = pub[0] ? (pub[1] ? (pub[2] ? (pub[3] ? 4 : 3) : 2) : 1) : 0;  // leading published tiles of the lane
+      const u64 missing = __ballot(r < 4);
+      const int first = missing ? __builtin_ctzll(missing) : 64;  // lanes below are complete
+      const int lead = missing ? 4 * first + __builtin_amdgcn_readlane(r, first) : 256;
+      u64 v[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = in[i] && (lane < first || (lane == first && i < r)) ? (x[i] & kValMask) : 0ull;
+      const u64 p1 = v[0], p2 = p1 + v[1], p3 = p2 + v[2], tot = p3 + v[3];
+      u64 incl = tot;
+      if (lead > delivered) {
+        // (aggregates of 64-row sub-tiles are small: one 32-bit scan; anything bigger takes the 64-bit form)
+        if (__any(tot >> 22)) incl = (u64)csdev::wave_inclusive_scan((long long)tot);
+        else incl = (u64)(unsigned)wave_scan_fused32((int)(unsigned)tot);
+      }
+      // the sum in front of the step: wait for it only when the step is complete (else poll the step again meanwhile)
+      while (!have_base) {
+        if (__hip_atomic_load(&ring->tag[s & 7], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == (unsigned)(s + 1)) {
+          base = __hip_atomic_load(&ring->val[s & 7], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          have_base = true;
+          break;
+        }
+        if (missing) break;
+        if (clock.expired()) return 1;
+        if ((++idle & 1023) == 0 && (__hip_atomic_load(error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 1u) != 0) return 2;
+      }
+      if (have_base && !missing && lane == 0) {  // complete: hand the sum on FIRST (the next step's wave waits for nothing else)
+        const u64 next = base + rl64((long long)incl, 63);
+        __hip_atomic_store(&ring->val[(s + 1) & 7], next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_store(&ring->tag[(s + 1) & 7], (unsigned)(s + 2), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+      if (have_base && lead > delivered) {
+        const u64 e0 = base + incl - tot;  // in front of the lane's first tile
+        const u64 o[4] = {kFlagInc | (e0 & kValMask), kFlagInc | ((e0 + p1) & kValMask), kFlagInc | ((e0 + p2) & kValMask), kFlagInc | ((e0 + p3) & kValMask)};
+        if (lane < first && in[3]) {  // a complete lane: 32 contiguous bytes
+          const u32x4 lo = {(uint32_t)o[0], (uint32_t)(o[0] >> 32), (uint32_t)o[1], (uint32_t)(o[1] >> 32)};
+          const u32x4 hi = {(uint32_t)o[2], (uint32_t)(o[2] >> 32), (uint32_t)o[3], (uint32_t)(o[3] >> 32)};
+          asm volatile("global_store_dwordx4 %0, %1, off sc1\n\tglobal_store_dwordx4 %0, %2, off offset:16 sc1" ::"v"(excl + t0), "v"(lo), "v"(hi) : "memory");
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (in[i] && (lane < first || (lane == first && i <= r))) __hip_atomic_store(ex + (t0 + i), o[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        delivered = lead;
+        clock.reset();
+      }
+      if (have_base && !missing) break;
+      if (clock.expired()) return 1;
+      // (somebody gave up WAITING -- bit 0: the launch is lost.  Other bits, "out of room" for one, are raised by waves that
+      // go on publishing or have published all they hold: the prefixes keep coming, or the waiters would turn a clean
+      // "once more, roomier" into a fallback)
+      if ((++idle & 255) == 0 && (__hip_atomic_load(error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 1u) != 0) return 2;
+      __builtin_amdgcn_s_sleep(1);
+    }
+  }
+  return 0;
+}
+
 // a tile's side: `first` is an early load of excl[tile]; polls until the prefix is there.  -1 = timeout / launch failed.
 __device__ __forceinline__ long long prefix_wait(const u64* excl, long long tile, u64 first, const unsigned* error, int lane) {
   u64 v = first;
@@ -457,7 +575,9 @@ __device__ __forceinline__ long long prefix_wait(const u64* excl, long long tile
   while ((v >> 62) == 0) {
     ++spins;
     if (clock.expired()) return -1;
-    if ((spins & 255) == 0 && __hip_atomic_load(error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return -1;
+    // (bit 0 = somebody gave up waiting or the scanners stopped: no more prefixes.  Other bits -- "out of room" -- leave the
+    // chain intact, and a waiter that gave up on them would turn the host's clean "once more, roomier" into a fallback)
+    if ((spins & 255) == 0 && (__hip_atomic_load(error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 1u) != 0) return -1;
     __builtin_amdgcn_s_sleep(2);
     v = status_load(excl + tile);
   }
