@@ -163,6 +163,14 @@ bool few_spans64_over(const cs_column* c, int64_t limit, hipStream_t s);  // all
 // Workgroups (256 threads, `lds` dynamic bytes) of `kern` resident at once on the device,
 // capped by `wanted`: grid size of the persistent tile kernels.
 unsigned resident_grid(const void* kern, size_t lds, int64_t wanted);
+}  // namespace cs
+namespace csrow {
+struct CharSet;
+}
+namespace cs {
+// cs_ops.hip: the character set of a UTF-8 string of any length (strip, tokenize with a delimiter set, the NVText counters);
+// `more` keeps what does not fit the struct alive for the caller's kernels
+csrow::CharSet make_charset(const char* s, Buf& more, hipStream_t st);
 // Row-wise concatenation of columns into one new column.
 cs_column* concat_columns(const std::vector<const cs_column*>& cols, hipStream_t s);
 

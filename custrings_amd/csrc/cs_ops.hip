@@ -55,20 +55,23 @@ Needle upload(const char* s, hipStream_t st) {
   CS_HIP(hipMemcpyAsync(nd.buf->p, s, (size_t)nd.n + 1, hipMemcpyHostToDevice, st));
   return nd;
 }
-CharSet make_set(const char* s, const char* what) {
-  CharSet cs;
-  cs.n = 0;
-  int n = (int)strlen(s), i = 0;
-  while (i < n) {
-    if (cs.n == 64) fail(CS_ERR_INVALID_ARG, std::string(what) + ": more than 64 characters in the character set");
-    Char c;
-    unsigned w = decode_at((const uint8_t*)s, i, n, c);
-    cs.c[cs.n++] = c;
-    i += w ? (int)w : 1;
+}  // namespace
+namespace cs {
+// the character set of a UTF-8 string of any length; `more` keeps what does not fit the struct alive for the caller's kernels
+CharSet make_charset(const char* s, Buf& more, hipStream_t st) {
+  std::vector<Char> overflow;
+  CharSet cs = charset_from_utf8(reinterpret_cast<const uint8_t*>(s), (int)strlen(s), overflow);
+  if (!overflow.empty()) {
+    more = dev_alloc(sizeof(Char) * overflow.size(), st);
+    CS_HIP(hipMemcpyAsync(more->p, overflow.data(), sizeof(Char) * overflow.size(), hipMemcpyHostToDevice, st));
+    CS_HIP(hipStreamSynchronize(st));  // (`overflow` is pageable and leaves scope)
+    cs.more = ptr<const Char>(more);
+    cs.nmore = (int)overflow.size();
   }
-  charset_finish(cs);
   return cs;
 }
+}  // namespace cs
+namespace {
 
 // ---- generic two-pass driver -------------------------------------------------
 // SizeFn:  int  operator()(const uint8_t* row, int len, int64_t r) const
@@ -426,8 +429,9 @@ int cs_strip(const cs_column* col, const char* to_strip, int side, cs_stream str
   return guard([&] {
     if (!col || !out || side < 0 || side > 2) fail(CS_ERR_INVALID_ARG, "strip: bad arguments");
     require_device();
-    CharSet set = make_set(to_strip ? to_strip : " \n\t", "strip");
     hipStream_t s = S(stream);
+    Buf set_more;
+    CharSet set = make_charset(to_strip ? to_strip : " \n\t", set_more, s);
     // size pass + scan as for every row-wise op; the write pass runs on row tiles (cs_rows.hip)
     if (col->rows > 0 && !getenv("CS_STRIP_ROWWISE")) {
       auto o = std::make_unique<cs_column>();
@@ -709,7 +713,8 @@ int cs_tokenize(const cs_column* col, const char* delimiter, cs_stream stream, c
     }
     TokArgs a;
     a.use_set = delimiter != nullptr;
-    a.set = make_set(delimiter ? delimiter : "", "tokenize");
+    Buf set_more;
+    a.set = make_charset(delimiter ? delimiter : "", set_more, s);
     const unsigned nb = blocks_for(rows);
     Buf counts = dev_alloc(sizeof(int32_t) * rows, s);
     Buf sums = dev_alloc(sizeof(int64_t) * nb, s);

@@ -1256,6 +1256,7 @@ __global__ void __launch_bounds__(256, BREFS ? 2 : CS_STREAM_WAVES) k_tdfa_repla
 #endif
   auto finish_pending = [&](cstile::u64 first) {
     long long gb;
+    if (lane == 0) CS_TILE_TRACE(p_tile, 2);
     if (a.debug & 128) {  // measurement only: one late poll, no chase for an inclusive prefix
       const cstile::u64 v = cstile::lookback_poll(a.status, p_tile, lane);
       const int part = (int)(unsigned)(v & 0xffffffffull);
@@ -1276,6 +1277,7 @@ __global__ void __launch_bounds__(256, BREFS ? 2 : CS_STREAM_WAVES) k_tdfa_repla
       gb = 0;
     }
     CS_PHASE_MARK(6);
+    if (lane == 0) CS_TILE_TRACE(p_tile, 3);
     const long long pr0 = p_tile * R;
     const int pn = (int)min((long long)R, in.rows - pr0);
     if (lane < pn) a.out_off[pr0 + lane] = gb + p_lo;
@@ -1851,6 +1853,7 @@ __global__ void __launch_bounds__(256, BREFS ? 2 : CS_STREAM_WAVES) k_tdfa_repla
       p_tile = -1;
     } else {
       if (!(a.debug & 8)) cstile::lookback_publish(a.status, tile, total, lane);
+      if (lane == 0) CS_TILE_TRACE(tile, 0);
       CS_PHASE_MARK(2);
       if (p_tile >= 0)
         finish_pending((a.debug & 64) ? (scanner ? cstile::status_load(a.excl + p_tile) : cstile::lookback_poll(a.status, p_tile, lane))
@@ -2931,6 +2934,19 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
           CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)lds1));
         const unsigned grid = resident_grid(reinterpret_cast<const void*>(kern), lds1, (nsub1 + 3) / 4);
+#if defined(CS_PHASE_PROF)
+        Buf tracebuf;
+        const long long ntrace = (nsub1 >> 10) + 1;
+        {
+          unsigned long long* tp_ = nullptr;
+          if (getenv("CS_REPLACE_TRACE")) {
+            tracebuf = dev_alloc(sizeof(unsigned long long) * 4 * ntrace, s);
+            CS_HIP(hipMemsetAsync(tracebuf->p, 0, sizeof(unsigned long long) * 4 * ntrace, s));
+            tp_ = ptr<unsigned long long>(tracebuf);
+          }
+          CS_HIP(hipMemcpyToSymbolAsync(HIP_SYMBOL(cstile::g_tile_trace), &tp_, sizeof(tp_), 0, hipMemcpyHostToDevice, s));
+        }
+#endif
         {
           ProfScope ps("k_replace_re", s);
           hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds1, s, sa);
@@ -2944,6 +2960,17 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
         {
           unsigned long long ph[12];
           CS_HIP(hipMemcpy(ph, reinterpret_cast<unsigned long long*>(sa.error) + 1, sizeof(ph), hipMemcpyDeviceToHost));
+          if (tracebuf) {
+            std::vector<unsigned long long> tr(4 * ntrace);
+            CS_HIP(hipMemcpy(tr.data(), tracebuf->p, sizeof(unsigned long long) * 4 * ntrace, hipMemcpyDeviceToHost));
+            unsigned long long t0 = ~0ull;
+            for (long long i = 0; i < ntrace; ++i)
+              if (tr[4 * i]) t0 = std::min(t0, tr[4 * i]);
+            fprintf(stderr, "trace (us since the first publish; every 1024th sub-tile): tile published scanned start-of-finish prefix-seen\n");
+            for (long long i = 0; i < ntrace; i += std::max<long long>(1, ntrace / 40))
+              fprintf(stderr, "trace %8lld %9.1f %9.1f %9.1f %9.1f\n", i << 10, (double)(tr[4 * i] - t0) / 100.0, (double)(tr[4 * i + 1] - t0) / 100.0,
+                      (double)(tr[4 * i + 2] - t0) / 100.0, (double)(tr[4 * i + 3] - t0) / 100.0);
+          }
           unsigned long long lb[4] = {0, 0, 0, 0};
           CS_HIP(hipMemcpyFromSymbol(lb, HIP_SYMBOL(cstile::g_lb_stats), sizeof(lb)));
           fprintf(stderr, "look-back (cumulative): %llu calls, %.2f windows per call, %.2f re-polls per call\n", lb[0], (double)lb[1] / (double)(lb[0] ? lb[0] : 1),

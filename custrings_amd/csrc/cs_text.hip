@@ -21,22 +21,10 @@ struct Tokenizer {
   int has_set;
   CharSet set;
 };
-Tokenizer make_tokenizer(const char* delimiter, const char* what) {
+Tokenizer make_tokenizer(const char* delimiter, Buf& more, hipStream_t st) {
   Tokenizer t;
   t.has_set = delimiter != nullptr && *delimiter != 0;
-  t.set.n = 0;
-  if (t.has_set) {
-    const int n = (int)strlen(delimiter);
-    int i = 0;
-    while (i < n) {
-      if (t.set.n == 64) fail(CS_ERR_INVALID_ARG, std::string(what) + ": more than 64 characters in the delimiter set");
-      Char c;
-      unsigned w = decode_at((const uint8_t*)delimiter, i, n, c);
-      t.set.c[t.set.n++] = c;
-      i += w ? (int)w : 1;
-    }
-  }
-  charset_finish(t.set);
+  t.set = make_charset(t.has_set ? delimiter : "", more, st);
   return t;
 }
 template <class Emit>
@@ -199,7 +187,8 @@ int cs_token_count(const cs_column* col, const char* delimiter, uint32_t* result
     hipStream_t s = S(stream);
     const int64_t rows = col->rows;
     if (rows == 0) return;
-    Tokenizer t = make_tokenizer(delimiter, "token_count");
+    Buf set_more;
+    Tokenizer t = make_tokenizer(delimiter, set_more, s);
     Buf tmp;
     uint32_t* d = results;
     if (!on_device) {
@@ -234,7 +223,8 @@ int cs_tokens_counts(const cs_column* col, const cs_column* tokens, const char* 
     hipStream_t s = S(stream);
     const int64_t rows = col->rows, tc = tokens->rows;
     if (!results || rows == 0 || tc == 0) return;  // tokens.cu:442-443
-    Tokenizer t = make_tokenizer(delimiter, "tokens_counts");
+    Buf set_more;
+    Tokenizer t = make_tokenizer(delimiter, set_more, s);
     Buf tmp;
     uint32_t* d = results;
     if (!on_device) {
@@ -262,7 +252,8 @@ int cs_replace_tokens(const cs_column* col, const cs_column* targets, const cs_c
     if (repls->rows == 0) fail(CS_ERR_INVALID_ARG, "replace-tokens: no replacement given");
     if (repls->rows > 1 && repls->rows != targets->rows)
       fail(CS_ERR_INTERNAL, "replace-tokens tokens and replacements must have the same number of strings");  // (std::runtime_error, tokens.cu:570)
-    Tokenizer t = make_tokenizer(delimiter, "replace_tokens");
+    Buf set_more;
+    Tokenizer t = make_tokenizer(delimiter, set_more, s);
     Buf lens = dev_alloc(sizeof(int32_t) * rows, s);
     hipLaunchKernelGGL(k_replace_tokens<false>, dim3(blocks_for(rows)), dim3(kBlock), 0, s, view_of(col), view_of(targets), view_of(repls), t,
                        ptr<int32_t>(lens), (const int64_t*)nullptr, (uint8_t*)nullptr);
@@ -289,7 +280,8 @@ int cs_normalize_spaces(const cs_column* col, cs_stream stream, cs_column** out)
       *out = new cs_column(*col);
       return;
     }
-    Tokenizer t = make_tokenizer(nullptr, "normalize_spaces");
+    Buf set_more;
+    Tokenizer t = make_tokenizer(nullptr, set_more, s);
     Buf lens = dev_alloc(sizeof(int32_t) * rows, s);
     hipLaunchKernelGGL(k_normalize_spaces<false>, dim3(blocks_for(rows)), dim3(kBlock), 0, s, view_of(col), t, ptr<int32_t>(lens),
                        (const int64_t*)nullptr, (uint8_t*)nullptr);

@@ -138,26 +138,90 @@ CS_HD void row_replace_write(const uint8_t* p, int n, const uint8_t* needle, int
 }
 
 // ---- strip ---------------------------------------------------------------------
-struct CharSet {  // up to 64 packed chars
-  Char c[64];
-  int n;
-  uint32_t ascii[4];  // the set's ASCII members as a bitmap (charset_finish): one bit test instead of a walk over c[]
+struct CharSet {  // a set of characters of any size (custring_view.inl:93-105 walks the caller's string, whatever its length)
+  Char c[64];        // the members -- of a set of more than 64 characters: its first 64 non-ASCII members
+  int n;             // members in c[]
+  uint32_t ascii[4]; // the set's ASCII members as a bitmap (charset_finish): one bit test instead of a walk over c[]
+  int wide;          // more than 64 characters: the ASCII members are in the bitmap ONLY, non-ASCII ones beyond c[] in `more`
+  const Char* more;  // sorted ascending (device memory in kernels, host memory in the host emulation)
+  int nmore;
 };
 // call once the members are in c[0 .. n)
 CS_HD void charset_finish(CharSet& s) {
   s.ascii[0] = s.ascii[1] = s.ascii[2] = s.ascii[3] = 0;
+  s.wide = 0;
+  s.more = nullptr;
+  s.nmore = 0;
   for (int i = 0; i < s.n; ++i)
     if (s.c[i] < 128u) s.ascii[s.c[i] >> 5] |= 1u << (s.c[i] & 31u);
 }
 CS_HD bool in_set(const CharSet& s, Char ch) {
-  if (s.n > 4 && ch < 128u) {  // (a handful of members: the walk below is cheaper than the word select)
+  if ((s.n > 4 || s.wide) && ch < 128u) {  // (a handful of members: the walk below is cheaper than the word select)
     const unsigned k = ch >> 5;
     const uint32_t w = k == 0 ? s.ascii[0] : (k == 1 ? s.ascii[1] : (k == 2 ? s.ascii[2] : s.ascii[3]));
     return ((w >> (ch & 31u)) & 1u) != 0;
   }
   for (int i = 0; i < s.n; ++i)
     if (s.c[i] == ch) return true;
+  int lo = 0, hi = s.nmore;  // (sets beyond 64 non-ASCII characters)
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    const Char m = s.more[mid];
+    if (m == ch) return true;
+    if (m < ch) lo = mid + 1;
+    else hi = mid;
+  }
   return false;
+}
+// Host: the set of the characters of the UTF-8 string `s` (n bytes).  Up to 64 characters: all of them in c[], as ever.
+// Beyond: ASCII members in the bitmap, the first 64 non-ASCII ones in c[], the others sorted into `overflow` -- the caller
+// puts them where the kernels can read them and sets `more` / `nmore`.
+template <class Vec>
+inline CharSet charset_from_utf8(const uint8_t* s, int n, Vec& overflow) {
+  CharSet cs;
+  cs.n = 0;
+  overflow.clear();
+  int count = 0;
+  for (int i = 0; i < n; ++count) {
+    Char c;
+    const unsigned w = decode_at(s, i, n, c);
+    i += w ? (int)w : 1;
+  }
+  if (count <= 64) {
+    for (int i = 0; i < n;) {
+      Char c;
+      const unsigned w = decode_at(s, i, n, c);
+      cs.c[cs.n++] = c;
+      i += w ? (int)w : 1;
+    }
+    charset_finish(cs);
+    return cs;
+  }
+  uint32_t bits[4] = {0, 0, 0, 0};
+  for (int i = 0; i < n;) {
+    Char c;
+    const unsigned w = decode_at(s, i, n, c);
+    i += w ? (int)w : 1;
+    if (c < 128u) {
+      bits[c >> 5] |= 1u << (c & 31u);
+      continue;
+    }
+    bool seen = false;
+    for (int k = 0; k < cs.n && !seen; ++k) seen = cs.c[k] == c;
+    if (seen) continue;
+    if (cs.n < 64) cs.c[cs.n++] = c;
+    else overflow.push_back(c);
+  }
+  charset_finish(cs);
+  for (int k = 0; k < 4; ++k) cs.ascii[k] = bits[k];
+  cs.wide = 1;
+  for (int a = 1; a < (int)overflow.size(); ++a)  // (insertion sort: a few characters)
+    for (int b = a; b > 0 && overflow[b - 1] > overflow[b]; --b) {
+      const Char t = overflow[b - 1];
+      overflow[b - 1] = overflow[b];
+      overflow[b] = t;
+    }
+  return cs;
 }
 // side: 0 both, 1 left, 2 right.  Returns [lo,hi) of the kept bytes.
 CS_HD void row_strip(const uint8_t* p, int n, const CharSet& set, int side, int& lo, int& hi) {

@@ -333,6 +333,16 @@ __device__ __forceinline__ u64 lookback_begin(u64* status, long long tile, long 
 }
 #if defined(CS_PHASE_PROF)
 static __device__ unsigned long long g_lb_stats[4];  // calls, windows walked, re-polls of a window, -
+// time stamps (100 MHz) of every 1024th tile: published, prefix stored by the scanners, start of its finish, prefix seen
+static __device__ unsigned long long* g_tile_trace;
+#define CS_TILE_TRACE(tile, slot)                                                                                       \
+  do {                                                                                                                  \
+    if (cstile::g_tile_trace && ((tile) & 1023) == 0) cstile::g_tile_trace[((tile) >> 10) * 4 + (slot)] = wall_clock64(); \
+  } while (0)
+#else
+#define CS_TILE_TRACE(tile, slot) \
+  do {                            \
+  } while (0)
 #endif
 __device__ __forceinline__ long long lookback_end(u64* status, long long tile, long long aggregate, u64 first, int lane,
                                                   unsigned long long* acc = nullptr) {
@@ -552,6 +562,7 @@ __device__ __forceinline__ int prefix_scanner_team(const u64* status, u64* excl,
           for (int i = 0; i < 4; ++i)
             if (in[i] && (lane < first || (lane == first && i <= r))) __hip_atomic_store(ex + (t0 + i), o[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        if (in[0] && lane <= first) CS_TILE_TRACE(t0, 1);
         delivered = lead;
         clock.reset();
       }

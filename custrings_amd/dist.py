@@ -330,6 +330,51 @@ def global_category(local_col, ops=None, group=None, partitioned=None):
     return merged_keys, ops.remap(cat, table)
 
 
+def global_category_c_abi(local_col, group=None):
+    """The distributed build through the C ABI's own entry point (cs_category_build_distributed_with: local build, key
+    sizes / offsets / bytes all-gathered, merge, remap -- all in the library), with torch.distributed as the transport:
+    the callback below is what ncclAllGather is to cs_category_build_distributed, which a C++ host calls with its
+    ncclComm_t.  Returns an nvcategory whose keys are identical on every rank."""
+    import ctypes as C
+
+    from . import _lib, nvcategory
+
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipStreamSynchronize.argtypes = [C.c_void_p]
+    staged = dist.is_initialized() and dist.get_backend(group) == "gloo"  # (several ranks on one GPU: through host memory)
+
+    @C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+    def allgather(_ctx, send, recv, nbytes, stream):
+        try:
+            if hip.hipStreamSynchronize(stream) != 0:
+                return 1
+            dev = torch.device("cpu") if staged else torch.device("cuda", torch.cuda.current_device())
+            mine = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            if hip.hipMemcpy(mine.data_ptr(), send, nbytes, 2 if staged else 3) != 0:  # (device -> host / device -> device)
+                return 1
+            parts = [torch.empty(nbytes, dtype=torch.uint8, device=dev) for _ in range(world)]
+            if world > 1:
+                dist.all_gather(parts, mine, group=group)
+            else:
+                parts[0].copy_(mine)
+            if not staged:
+                torch.cuda.synchronize()
+            for r, p in enumerate(parts):
+                if hip.hipMemcpy(recv + r * nbytes, p.data_ptr(), nbytes, 1 if staged else 3) != 0:
+                    return 1
+            return 0
+        except Exception:  # (no exception may cross the C frames)
+            return 1
+
+    out = C.c_void_p()
+    ctx = C.c_void_p(1)  # (non-null: run the exchange with one rank too)
+    _lib.check(_lib.lib.cs_category_build_distributed_with(local_col.m_cptr, C.cast(allgather, C.c_void_p), ctx, world, rank, None, C.byref(out)))
+    return nvcategory.nvcategory(out.value)
+
+
 def agree_on_columns(ncols, device="cuda", group=None):
     """split(): every shard must emit max-over-ranks columns (the one scalar exchanged)."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:

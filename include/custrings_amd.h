@@ -30,6 +30,7 @@
 #ifndef CUSTRINGS_AMD_H
 #define CUSTRINGS_AMD_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -346,6 +347,18 @@ int cs_category_merge(const cs_category* const* cats, int ncats, cs_stream strea
  * (NVCategory.cu:430-514); the reference itself is single-GPU. */
 int cs_category_merge_gathered(const cs_category* local, const cs_column* const* keysets, int nranks, int rank, cs_stream stream,
                                cs_column** merged_keys, int32_t* values);
+/* The whole distributed build behind the C ABI (BASELINE.json north_star; what custrings_amd/dist.py does through
+ * torch.distributed): local build (NVCategory.cu:220-304), all-gather of the ranks' sorted key sets, merge
+ * (NVCategory::create_from_categories, NVCategory.cu:430-514), remap.  One process per GPU.  `nccl_comm`: the caller's
+ * ncclComm_t of `nranks` ranks (RCCL is resolved in the process at run time: dlsym, else dlopen of librccl.so);
+ * *out: keys = the same column on every rank, values = this rank's rows' codes.  nranks == 1 is the local build. */
+int cs_category_build_distributed(const cs_column* col, void* nccl_comm, int nranks, int rank, cs_stream stream, cs_category** out);
+/* The same over a caller-supplied all-gather (another transport, a test harness): `allgather(ctx, send, recv, bytes,
+ * stream)` puts every rank's `bytes` bytes at `send` (device memory) behind each other, in rank order, at `recv`
+ * (device memory, nranks * bytes), ordered after the work queued on `stream`; returns 0 on success. */
+typedef int (*cs_allgather_fn)(void* ctx, const void* send, void* recv, size_t bytes, void* stream);
+int cs_category_build_distributed_with(const cs_column* col, cs_allgather_fn allgather, void* ctx, int nranks, int rank, cs_stream stream,
+                                       cs_category** out);
 int cs_category_destroy(cs_category* cat);
 /* NVCategory::create_ipc_transfer / create_from_ipc (NVCategory.h:128,176; ipc_transfer.h:109-200): the key column
  * as above plus the handle of the int32 values. */

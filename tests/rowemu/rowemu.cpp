@@ -54,17 +54,13 @@ static emu_col* two_pass(int64_t rows, Size size, Fill fill) {
   return o;
 }
 
+static std::vector<Char> g_set_overflow;  // (one set alive at a time: every entry point builds its own)
 static CharSet make_set(const char* s) {
-  CharSet cs;
-  cs.n = 0;
-  int n = (int)strlen(s), i = 0;
-  while (i < n && cs.n < 64) {
-    Char c;
-    unsigned w = decode_at((const uint8_t*)s, i, n, c);
-    cs.c[cs.n++] = c;
-    i += w ? (int)w : 1;
+  CharSet cs = charset_from_utf8((const uint8_t*)s, (int)strlen(s), g_set_overflow);
+  if (!g_set_overflow.empty()) {
+    cs.more = g_set_overflow.data();
+    cs.nmore = (int)g_set_overflow.size();
   }
-  charset_finish(cs);
   return cs;
 }
 

@@ -42,7 +42,10 @@ def _worker(rank, world, port, rows, q):
         part = (pk.to_host(), pv.cpu().tolist(), dict(csd.last_category_exchange))
         grams = csd.sharded_ngrams(nvtext.tokenize(synth(5, lo, hi - lo)), 2, "_")
         ncols = csd.agree_on_columns(len(synth(3, lo, hi - lo).split(" ")), device="cpu")
-        q.put((rank, "ok", keys.to_host(), values.cpu().tolist(), grams.to_host(), ncols, part))
+        # the C ABI's own distributed entry point (the exchange inside the library, torch.distributed as its transport)
+        ccat = csd.global_category_c_abi(synth(4, lo, hi - lo, 3000))
+        cabi = (ccat.keys().to_host(), ccat.values())
+        q.put((rank, "ok", keys.to_host(), values.cpu().tolist(), grams.to_host(), ncols, part, cabi))
         dist.barrier()
         dist.destroy_process_group()
     except Exception as e:  # the parent reports it
@@ -90,6 +93,48 @@ def test_gpu_two_rank_exchanges_with_the_gpu_ops(gpu_engine):
     r0, r1 = got[0][6][2], got[1][6][2]
     assert r0["partitioned"] and r0["global_keys"] == len(dkeys) and r0["range_keys"] + r1["range_keys"] == len(dkeys)
     assert 0.2 * len(dkeys) < r0["range_keys"] < 0.8 * len(dkeys)  # (each rank merged about its half)
+    # cs_category_build_distributed_with: the same global key set and codes out of the library's own exchange
+    assert got[0][7][0] == got[1][7][0] == want_keys
+    assert list(got[0][7][1]) + list(got[1][7][1]) == list(want_values)
+
+
+def test_gpu_category_build_distributed_over_rccl():
+    """cs_category_build_distributed with a real ncclComm_t: one rank (RCCL refuses two ranks on the test box's one GPU),
+    so the all-gathers run a rank with itself -- RCCL resolved in the process, the communicator passed through, the
+    padded key sets back through the merge.  Same keys and codes as the local build; a null row and an empty key set too."""
+    import ctypes as C
+
+    from custrings_amd import _lib, nvcategory, nvstrings
+
+    _lib.ensure_init(0)
+    # the RCCL of the HIP runtime this process already uses (PyTorch bundles both: a second runtime next to it crashes)
+    import torch
+
+    bundled = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+    rccl = C.CDLL(bundled if os.path.exists(bundled) else "librccl.so.1", mode=C.RTLD_GLOBAL)
+
+    class UniqueId(C.Structure):
+        _fields_ = [("internal", C.c_char * 128)]
+
+    uid = UniqueId()
+    assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+    comm = C.c_void_p()
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+    assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+    try:
+        for kind, rows, param in ((4, 50_000, 3000), (4, 2_000, 1 << 30), (2, 5_000, 0)):
+            out = C.c_void_p()
+            _lib.check(_lib.lib.cs_synth_column(kind, 0, rows, 20240607, param, None, C.byref(out)))
+            col = nvstrings.nvstrings(out.value)
+            want = nvcategory.from_strings(col)
+            got = C.c_void_p()
+            _lib.check(_lib.lib.cs_category_build_distributed(col.m_cptr, comm, 1, 0, None, C.byref(got)))
+            cat = nvcategory.nvcategory(got.value)
+            assert cat.keys().to_host() == want.keys().to_host()
+            assert list(cat.values()) == list(want.values())
+    finally:
+        rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+        rccl.ncclCommDestroy(comm)
 
 
 @pytest.mark.parametrize("config", ["c3", "c5"])

@@ -146,6 +146,20 @@ def test_gpu_synth_matches_spec(orc, kind, param, first):
     gpuutil.assert_same(gpuutil.synth(kind, first, rows, param), orc.synth(kind, first, rows, param=param), "synth")
 
 
+def test_gpu_character_sets_of_any_size(gpu_engine, oracle_engine):
+    """strip / tokenize / the NVText counters with character sets beyond 64 members (the reference walks a set of any
+    length: custring_view.inl:93-105, text/tokens.cu:45-50)"""
+    from test_rowemu_parity import big_sets
+
+    s = fuzzdata.rows(5, 3000, max_len=40) + ["ΑΒΓ abc ωψχ", "жзи hello ЯЮЭ", "zzz", "", None, "ω", "Я" * 5 + "x" + "α" * 3, "~~~abc~~~"]
+    g, o = gpu_engine, oracle_engine
+    for ts in big_sets():
+        for side in (0, 1, 2):
+            assert g.strip(s, ts, side) == o.strip(s, ts, side), (len(ts), side)
+        assert g.tokenize(s, ts) == o.tokenize(s, ts), len(ts)
+        assert g.token_count(s, ts) == o.token_count(s, ts), len(ts)
+
+
 def test_gpu_c2_lower_strip_split(orc):
     rows = 200_000
     g, o = gpuutil.synth(2, 0, rows), orc.synth(2, 0, rows)

@@ -50,6 +50,25 @@ def test_rowemu_vs_oracle_string_ops(emu_engine, oracle_engine, seed):
         assert e.tokenize(s, d) == o.tokenize(s, d)
 
 
+def big_sets():
+    """character sets beyond the 64 members the set structure keeps inline (custring_view.inl:93-105 walks any length):
+    ASCII only, mixed, and more than 64 non-ASCII members (those go to the sorted overflow list)"""
+    ascii70 = "".join(chr(c) for c in range(33, 103))
+    greek = "".join(chr(c) for c in range(0x391, 0x3CA) if chr(c).isalpha())
+    cyr = "".join(chr(c) for c in range(0x410, 0x450))
+    return [ascii70, ascii70 + "é😀" + greek[:10], greek + cyr, "ab" * 40 + cyr + greek + " "]
+
+
+def test_rowemu_vs_oracle_character_sets_of_any_size(emu_engine, oracle_engine):
+    s = fuzzdata.rows(5, 600, max_len=40)
+    s = s + ["ΑΒΓ abc ωψχ", "жзи hello ЯЮЭ", "zzz", "", None, "ω", "Я" * 5 + "x" + "α" * 3, "~~~abc~~~"]
+    e, o = emu_engine, oracle_engine
+    for ts in big_sets():
+        for side in (0, 1, 2):
+            assert e.strip(s, ts, side) == o.strip(s, ts, side), (len(ts), side)
+        assert e.tokenize(s, ts) == o.tokenize(s, ts), len(ts)
+
+
 @pytest.mark.parametrize("engine", [0, 1], ids=["pike", "tdfa"])
 @pytest.mark.parametrize("pat", PATTERNS)
 def test_rowemu_vs_oracle_regex(emu_engine, oracle_engine, pat, engine):
