@@ -1467,6 +1467,22 @@ int cs_prof_enable(int on) {
   g_prof_on = on != 0;
   return CS_OK;
 }
+__global__ void __launch_bounds__(256) k_debug_spin(unsigned long long ticks) {
+  extern __shared__ uint32_t spin_lds[];
+  if (threadIdx.x == 0) spin_lds[0] = 1;  // (the LDS is what keeps other workgroups off the CU)
+  const unsigned long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+}
+int cs_debug_spin(int blocks, int lds_bytes, int milliseconds, cs_stream stream) {
+  return guard([&] {
+    if (blocks < 1 || lds_bytes < 4 || lds_bytes > 160 * 1024 || milliseconds < 0) fail(CS_ERR_INVALID_ARG, "debug_spin: bad arguments");
+    require_device();
+    if (lds_bytes > 48 * 1024)
+      CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_debug_spin), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    hipLaunchKernelGGL(k_debug_spin, dim3((unsigned)blocks), dim3(256), (size_t)lds_bytes, S(stream), (unsigned long long)milliseconds * 100000ull);  // (100 MHz)
+    CS_HIP(hipGetLastError());
+  });
+}
 int cs_prof_get(const char* kernel, double* total_ms, int64_t* launches) {
   return guard([&] {
     std::lock_guard<std::mutex> lk(g_mu);

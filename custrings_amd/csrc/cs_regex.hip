@@ -1181,11 +1181,12 @@ __global__ void __launch_bounds__(256, BREFS ? 2 : CS_STREAM_WAVES) k_tdfa_repla
   // ticket of the tile after next is in flight while the current tile is processed.
   const long long K = gridDim.x >= 16 ? 8 : 1;  // (every class needs a workgroup that takes tiles: workgroup 0 may be the scanners')
   const long long key = (long long)blockIdx.x % K;
-  const bool fixed = (a.debug & 256) != 0;  // measurement: the static round-robin
+  const bool fixed = (a.debug & (256 | 16384)) != 0;  // measurement: the static round-robin
   // Workgroup 0 takes no tiles: its four waves turn the aggregates the other waves publish into each tile's exclusive
   // prefix, in order (a tile then needs ONE load instead of a walk over its predecessors' words): tile_utils.h,
   // prefix_scanner_team.  (debug 512: the decoupled look-back, for comparison; debug 1024: the single scanner wave.)
-  const bool team = !fixed && !(a.debug & (512 | 1024)) && gridDim.x > 1;
+  const bool fixed_team = (a.debug & 16384) != 0 && gridDim.x > 1;  // measurement: the static round-robin with the scanner team
+  const bool team = (fixed_team || !fixed) && !(a.debug & (512 | 1024)) && gridDim.x > 1;
   const bool scanner = team || (!fixed && !(a.debug & 512) && a.cap_in + a.cap_out + 32 >= cstile::kScanBatch * 512);
   if (team && blockIdx.x == 0) {
     cstile::TeamRing* ring = reinterpret_cast<cstile::TeamRing*>(lds_in - (size_t)wv * (a.cap_in + a.cap_out + 64 + bm_bytes + unit_bytes));
@@ -1215,16 +1216,20 @@ __global__ void __launch_bounds__(256, BREFS ? 2 : CS_STREAM_WAVES) k_tdfa_repla
     if (lane == 0) t = __hip_atomic_fetch_add(my_ticket + which, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + (unsigned long long)add;
     return t;
   };
-  auto take = [&]() -> unsigned long long { return take_from(0, 3 * wc); };
+  auto take = [&]() -> unsigned long long { return take_from(0, (a.debug & 8192) ? 0 : 3 * wc); };
   auto tile_of = [&](unsigned long long t) -> long long { return (long long)cstile::rl64((long long)t, 0) * K + key; };
   long long tile, t_nxt, t_nn = 0;
   unsigned long long pending = 0;
-  if (fixed) {
+  if (fixed_team) {  // (workgroup 0 is the scanners')
+    tile = ((long long)blockIdx.x - 1) * 4 + wv;
+    t_nxt = tile + W - 4;
+  } else if (fixed) {
     tile = (long long)blockIdx.x * 4 + wv;
     t_nxt = tile + W;
   } else {
-    const unsigned long long q0 = team ? take_from(1, 0) : take(), q1 = team ? take_from(2, wc) : take();
-    pending = team ? take_from(3, 2 * wc) : take();
+    const bool rounds = team && !(a.debug & 8192);
+    const unsigned long long q0 = rounds ? take_from(1, 0) : take(), q1 = rounds ? take_from(2, wc) : take();
+    pending = rounds ? take_from(3, 2 * wc) : take();
     tile = tile_of(q0);
     t_nxt = tile_of(q1);
   }
@@ -1352,7 +1357,7 @@ __global__ void __launch_bounds__(256, BREFS ? 2 : CS_STREAM_WAVES) k_tdfa_repla
     }
     // keep the memory pipe busy: next sub-tile's chars, and the offsets of the one after
     const bool has_next = t_nxt < a.nsub;
-    t_nn = fixed ? t_nxt + W : tile_of(pending);
+    t_nn = fixed ? t_nxt + (fixed_team ? W - 4 : W) : tile_of(pending);
     const unsigned long long pending_new = fixed ? 0ull : take();  // (tickets drawn past the end are harmless)
     const cstile::TileOffs nn = cstile::load_tile_offsets_r(in.offsets, in.rows, t_nn < a.nsub ? t_nn : a.nsub - 1, R, lane);
     if (has_next) {

@@ -65,7 +65,8 @@ __device__ __forceinline__ void status_store(u64* p, u64 v) {
 // The bound is TIME, not a poll count (a poll's cost varies with what shares the device: a co-tenant or a CU mask made a
 // count of polls anything from a blink to minutes): kSpinTicks of the constant-rate 100 MHz counter (wall_clock64), looked
 // at every 64 polls.
-constexpr unsigned long long kSpinTicks = 200ull * 1000 * 1000;  // two seconds: far beyond any honest wait
+constexpr unsigned long long kSpinTicks = 25ull * 1000 * 1000;  // a quarter of a second WITHOUT PROGRESS (the clocks are reset whenever
+                                                             // something arrives): far beyond any honest wait
 struct SpinClock {
   unsigned long long t0 = 0;
   int polls = 0;

@@ -452,6 +452,10 @@ int cs_column_digest(const cs_column* col, cs_stream stream, uint64_t* digest);
 int cs_prof_reset(void);
 int cs_prof_enable(int on);
 int cs_prof_get(const char* kernel, double* total_ms, int64_t* launches);
+/* Test aid: `blocks` workgroups of 256 threads and `lds_bytes` of LDS each that do nothing for `milliseconds`, queued on
+ * `stream` -- a co-tenant that keeps part of the GPU occupied while another stream's call runs (the persistent kernels
+ * size their grids for an empty device). */
+int cs_debug_spin(int blocks, int lds_bytes, int milliseconds, cs_stream stream);
 
 #ifdef __cplusplus
 }

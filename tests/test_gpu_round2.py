@@ -508,3 +508,43 @@ def test_gpu_extract_groups_resolved_backwards_edges(gpu_engine, oracle_engine):
     for pat in fuzzdata.GROUP_EDGE_PATTERNS:
         assert gpu_engine.extract(rows, pat) == oracle_engine.extract(rows, pat), pat
 
+
+
+def test_gpu_replace_re_with_a_co_tenant_on_the_gpu():
+    """The persistent replace kernel sizes its grid for an empty device.  With half the CUs held by another stream's
+    kernel the grid is not resident, the waits run into their time bound (a quarter of a second without progress) and
+    the host repeats the call on the two-pass kernels: the result is the oracle's, and the call returns in well under
+    the old two-second bound."""
+    import ctypes as C
+    import time
+
+    import torch
+
+    import cpulibs
+    import gpuutil
+    from custrings_amd import _lib
+
+    orc = cpulibs.Oracle()
+    rows = 2_000_000
+    g, o = gpuutil.synth(3, 0, rows), orc.synth(3, 0, rows)
+    import engines
+
+    pat = r"\d+\.\d+\.\d+\.\d+"
+    blob = engines.reference_blob(pat)
+    blob = np.ascontiguousarray(blob if blob is not None else engines.product_blob(pat), dtype=np.int32)
+    want = orc.replace_re(o, blob, "<IP>")
+    L = _lib.lib
+    side = torch.cuda.Stream()
+    # 128 workgroups with 160 KB of LDS each: 128 of the 256 CUs taken for 1.5 s
+    _lib.check(L.cs_debug_spin(128, 160 * 1024, 1500, C.c_void_p(side.cuda_stream)))
+    time.sleep(0.05)
+    t0 = time.perf_counter()
+    got = g.replace(pat, "<IP>")
+    dt = time.perf_counter() - t0
+    gpuutil.assert_same(got, want, "replace_re next to a co-tenant")
+    assert dt < 1.2, dt
+    torch.cuda.synchronize()
+    # and alone again: the single pass, no fallback
+    before = int(L.cs_fallback_count())
+    gpuutil.assert_same(g.replace(pat, "<IP>"), want, "replace_re alone")
+    assert int(L.cs_fallback_count()) == before
