@@ -1203,20 +1203,11 @@ __global__ void __launch_bounds__(256, BREFS ? 2 : CS_STREAM_WAVES) k_tdfa_repla
   }
   const long long W = (long long)gridDim.x * 4;
   unsigned long long* my_ticket = a.tickets + key * 8;
-  // A wave's FIRST three tickets come from a counter per round (words 1..3 of the class's line), the i-th round handing
-  // out the i-th block of `wc` tickets (wc = the class's waves), the running counter everything behind: three tickets
-  // drawn at once from one counter are consecutive, and a wave's second and third tile then lie in front of its
-  // neighbour's first, whose prefix has to wait for them -- a dependency chain through every wave of the class (with a
-  // dozen waves and a lost launch the waiters at its end spun long enough to notice the error word and turn a clean
-  // "once more, roomier" into a fallback; on the full grid it cost the first hundreds of microseconds).  With the
-  // scanners' workgroup out of the count the class's waves are known exactly (the grid is resident).
-  const long long wc = team ? 4 * (((long long)gridDim.x - 1 - key) / K + 1 - (key == 0 ? 1 : 0)) : 0;
-  auto take_from = [&](int which, long long add) -> unsigned long long {
+  auto take = [&]() -> unsigned long long {
     unsigned long long t = 0;
-    if (lane == 0) t = __hip_atomic_fetch_add(my_ticket + which, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + (unsigned long long)add;
+    if (lane == 0) t = __hip_atomic_fetch_add(my_ticket, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return t;
   };
-  auto take = [&]() -> unsigned long long { return take_from(0, (a.debug & 8192) ? 0 : 3 * wc); };
   auto tile_of = [&](unsigned long long t) -> long long { return (long long)cstile::rl64((long long)t, 0) * K + key; };
   long long tile, t_nxt, t_nn = 0;
   unsigned long long pending = 0;
@@ -1227,11 +1218,15 @@ __global__ void __launch_bounds__(256, BREFS ? 2 : CS_STREAM_WAVES) k_tdfa_repla
     tile = (long long)blockIdx.x * 4 + wv;
     t_nxt = tile + W;
   } else {
-    const bool rounds = team && !(a.debug & 8192);
-    const unsigned long long q0 = rounds ? take_from(1, 0) : take(), q1 = rounds ? take_from(2, wc) : take();
-    pending = rounds ? take_from(3, 2 * wc) : take();
+    // A wave's first three tickets are drawn ONE AT A TIME, each after the one before has arrived (the tile number is
+    // read out of it) and the first tile's loads have been issued: drawn back to back they are consecutive numbers, a wave's
+    // second and third tile then lie in front of its neighbour's first, whose prefix has to wait for them -- a dependency
+    // chain through every wave of the class (the kernel ran 18.6 ms instead of 5.5 once the scanner team stopped hiding
+    // it).  A round trip apart they land among the other waves' tickets of the same round, as in the steady state (one
+    // ticket a wave and iteration).  Nothing here counts waves: workgroups that are not resident draw nothing.
+    const unsigned long long q0 = take();
     tile = tile_of(q0);
-    t_nxt = tile_of(q1);
+    t_nxt = a.nsub;  // (known below)
   }
   if (tile >= a.nsub) return;
   // replacement text in registers (this kernel is only taken for rb <= 8, or <= 16 with REP16)
@@ -1243,12 +1238,17 @@ __global__ void __launch_bounds__(256, BREFS ? 2 : CS_STREAM_WAVES) k_tdfa_repla
   for (int i = 0; i < 4 * kRepRegs; ++i)
     if (i < rb) rep[i >> 2] |= (uint32_t)a.repl[i] << (8 * (i & 3));
   cstile::TileOffs cur = cstile::load_tile_offsets_r(in.offsets, in.rows, tile, R, lane);
-  cstile::TileOffs nxt = cur;
-  if (t_nxt < a.nsub) nxt = cstile::load_tile_offsets_r(in.offsets, in.rows, t_nxt, R, lane);
   cstile::TileCharsT<PF> pf;
 #pragma unroll
   for (int j = 0; j < PF; ++j) pf.v[j] = make_uint4(0, 0, 0, 0);
   cstile::issue_chars(in.chars, cstile::rl64(cur.o0, 0), cstile::rl64(cur.o1, 63), lane, pf);
+  if (!fixed) {
+    const unsigned long long q1 = take();
+    t_nxt = tile_of(q1);
+  }
+  cstile::TileOffs nxt = cur;
+  if (t_nxt < a.nsub) nxt = cstile::load_tile_offsets_r(in.offsets, in.rows, t_nxt, R, lane);
+  if (!fixed) pending = take();
   // The previous sub-tile's output stays assembled in lds_out while this one is scanned;
   // its look-back completes afterwards, when every predecessor's aggregate has long been
   // published, so waves do not wait on each other's scans.
