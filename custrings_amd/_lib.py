@@ -98,6 +98,13 @@ _PROTOS = {
     "cs_strip": (i32, [vp, cp, i32, vp, P(vp)]),
     "cs_find": (i32, [vp, cp, i32, i32, vp, i32, vp, P(i64)]),
     "cs_contains": (i32, [vp, cp, vp, i32, vp, P(i64)]),
+    "cs_rfind": (i32, [vp, cp, i32, i32, vp, i32, vp, P(i64)]),
+    "cs_find_from": (i32, [vp, cp, vp, vp, i32, vp, i32, vp, P(i64)]),
+    "cs_find_multiple": (i32, [vp, vp, vp, i32, vp, P(i64)]),
+    "cs_compare": (i32, [vp, cp, vp, i32, vp, P(i64)]),
+    "cs_match_strings": (i32, [vp, vp, vp, i32, vp, P(i64)]),
+    "cs_startswith": (i32, [vp, cp, vp, i32, vp, P(i64)]),
+    "cs_endswith": (i32, [vp, cp, vp, i32, vp, P(i64)]),
     "cs_replace": (i32, [vp, cp, cp, i32, vp, P(vp)]),
     "cs_split": (i32, [vp, cp, i32, vp, P(P(vp)), P(i32)]),
     "cs_rsplit": (i32, [vp, cp, i32, vp, P(P(vp)), P(i32)]),

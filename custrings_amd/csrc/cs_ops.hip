@@ -495,6 +495,205 @@ int cs_find(const cs_column* col, const char* str, int start, int end, int32_t* 
   });
 }
 
+// ---- rfind, find_from, find_multiple, compare, match_strings, startswith, endswith (find.cu:36-72, 123-236, 276-387) ----
+// One thread a row (these are not on the benchmarked path).  `op`: 0 rfind(start, end), 1 find_from(starts[], ends[]),
+// 2 compare, 3 startswith, 4 endswith; null rows: -2 for the positions, -1 for compare, false for the predicates.
+__global__ void k_find_family(ColView in, int op, const uint8_t* __restrict__ needle, int nb, int start, int end, const int32_t* __restrict__ starts,
+                              const int32_t* __restrict__ ends, int32_t* __restrict__ out32, uint8_t* __restrict__ out8, unsigned long long* __restrict__ count) {
+  const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  int hit = 0;
+  if (r < in.rows) {
+    const bool valid = row_is_valid(in.validity, r);
+    const int64_t b = in.offsets[r];
+    const uint8_t* p = in.chars + b;
+    const int n = valid ? (int)(in.offsets[r + 1] - b) : 0;
+    if (op == 0) {
+      const int v = valid ? row_rfind_count(p, n, needle, nb, (unsigned)start, end - start) : -2;
+      out32[r] = v;
+      hit = v != -1;
+    } else if (op == 1) {
+      int v = -2;
+      if (valid) {
+        const int pos = starts ? starts[r] : 0;
+        v = row_find_count(p, n, needle, nb, (unsigned)pos, ends ? ends[r] - pos : -1);
+      }
+      out32[r] = v;
+      hit = v != -1;
+    } else if (op == 2) {
+      const int v = valid ? row_compare(p, n, needle, nb) : -1;
+      out32[r] = v;
+      hit = v == 0;
+    } else {
+      const bool v = valid && (op == 3 ? row_starts_with(p, n, needle, nb) : row_ends_with(p, n, needle, nb));
+      out8[r] = v ? 1 : 0;
+      hit = v;
+    }
+  }
+  const long long t = block_reduce_sum(hit);
+  if (threadIdx.x == 0 && t) atomicAdd(count, (unsigned long long)t);
+}
+// match_strings: equal rows (two nulls are equal); find_multiple: out[r * tcount + j] = position of target j in row r
+__global__ void k_match_strings(ColView a, ColView b, uint8_t* __restrict__ out, unsigned long long* __restrict__ count) {
+  const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  int hit = 0;
+  if (r < a.rows) {
+    const bool va = row_is_valid(a.validity, r), vb = row_is_valid(b.validity, r);
+    bool same = va == vb;
+    if (va && vb) {
+      const int64_t oa = a.offsets[r], ob = b.offsets[r];
+      same = row_compare(a.chars + oa, (int)(a.offsets[r + 1] - oa), b.chars + ob, (int)(b.offsets[r + 1] - ob)) == 0;
+    }
+    out[r] = same ? 1 : 0;
+    hit = same;
+  }
+  const long long t = block_reduce_sum(hit);
+  if (threadIdx.x == 0 && t) atomicAdd(count, (unsigned long long)t);
+}
+__global__ void k_find_multiple(ColView in, ColView targets, int32_t* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= in.rows * targets.rows) return;
+  const int64_t r = i / targets.rows, j = i - r * targets.rows;
+  int v = -2;
+  if (row_is_valid(in.validity, r) && row_is_valid(targets.validity, j)) {
+    const int64_t b = in.offsets[r], tb = targets.offsets[j];
+    v = row_find_count(in.chars + b, (int)(in.offsets[r + 1] - b), targets.chars + tb, (int)(targets.offsets[j + 1] - tb), 0u, -1);
+  }
+  out[i] = v;
+}
+__global__ void k_count_not_minus_one(const int32_t* __restrict__ v, int64_t n, unsigned long long* __restrict__ count) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const long long t = block_reduce_sum(i < n && v[i] != -1 ? 1 : 0);
+  if (threadIdx.x == 0 && t) atomicAdd(count, (unsigned long long)t);
+}
+// shared driver of the one-needle ops
+static void find_family(const cs_column* col, int op, const char* str, int start, int end, const int32_t* starts, const int32_t* ends, int bounds_on_device,
+                        void* results, int on_device, hipStream_t s, int64_t* found) {
+  const int64_t rows = col->rows;
+  const bool bools = op >= 3;
+  Needle nd = upload(str, s);
+  Buf tmp, cnt = dev_alloc(8, s), sbuf, ebuf;
+  CS_HIP(hipMemsetAsync(cnt->p, 0, 8, s));
+  void* d_out = results;
+  const size_t esz = bools ? 1 : sizeof(int32_t);
+  if (!on_device) {
+    tmp = dev_alloc(esz * rows, s);
+    d_out = tmp->p;
+  }
+  if (starts && !bounds_on_device) {
+    sbuf = dev_alloc(sizeof(int32_t) * rows, s);
+    CS_HIP(hipMemcpyAsync(sbuf->p, starts, sizeof(int32_t) * rows, hipMemcpyHostToDevice, s));
+    starts = ptr<const int32_t>(sbuf);
+  }
+  if (ends && !bounds_on_device) {
+    ebuf = dev_alloc(sizeof(int32_t) * rows, s);
+    CS_HIP(hipMemcpyAsync(ebuf->p, ends, sizeof(int32_t) * rows, hipMemcpyHostToDevice, s));
+    ends = ptr<const int32_t>(ebuf);
+  }
+  {
+    ProfScope ps("k_find_family", s);
+    hipLaunchKernelGGL(k_find_family, dim3(blocks_for(rows)), dim3(kBlock), 0, s, view_of(col), op, nd.d(), nd.n, start, end, starts, ends,
+                       bools ? nullptr : static_cast<int32_t*>(d_out), bools ? static_cast<uint8_t*>(d_out) : nullptr, ptr<unsigned long long>(cnt));
+  }
+  CS_HIP(hipGetLastError());
+  if (!on_device) CS_HIP(hipMemcpyAsync(results, d_out, esz * rows, hipMemcpyDeviceToHost, s));
+  const int64_t n = read_back<int64_t>(cnt, s);  // (synchronises: the staged bounds and the needle may go)
+  if (found) *found = n;
+}
+
+// NVStrings::rfind -- find.cu:163-200
+int cs_rfind(const cs_column* col, const char* str, int start, int end, int32_t* results, int on_device, cs_stream stream, int64_t* found) {
+  return guard([&] {
+    if (found) *found = 0;
+    if (!col || !str || !results || col->rows == 0) return;  // the reference returns 0
+    require_device();
+    find_family(col, 0, str, start < 0 ? 0 : start, end, nullptr, nullptr, 1, results, on_device, S(stream), found);
+  });
+}
+// NVStrings::find_from -- find.cu:123-160 (`starts` / `ends`: one int32 per row, either may be null)
+int cs_find_from(const cs_column* col, const char* str, const int32_t* starts, const int32_t* ends, int bounds_on_device, int32_t* results, int on_device,
+                 cs_stream stream, int64_t* found) {
+  return guard([&] {
+    if (found) *found = 0;
+    if (!col || !str || !results || col->rows == 0) return;
+    require_device();
+    find_family(col, 1, str, 0, 0, starts, ends, bounds_on_device, results, on_device, S(stream), found);
+  });
+}
+// NVStrings::compare -- find.cu:36-72 (an empty `str` leaves the results alone and returns 0)
+int cs_compare(const cs_column* col, const char* str, int32_t* results, int on_device, cs_stream stream, int64_t* matches) {
+  return guard([&] {
+    if (matches) *matches = 0;
+    if (!col || !str || !results || col->rows == 0 || !*str) return;
+    require_device();
+    find_family(col, 2, str, 0, 0, nullptr, nullptr, 1, results, on_device, S(stream), matches);
+  });
+}
+// NVStrings::startswith / endswith -- find.cu:316-387
+int cs_startswith(const cs_column* col, const char* str, uint8_t* results, int on_device, cs_stream stream, int64_t* matches) {
+  return guard([&] {
+    if (matches) *matches = 0;
+    if (!col || !str || !results || col->rows == 0) return;
+    require_device();
+    find_family(col, 3, str, 0, 0, nullptr, nullptr, 1, results, on_device, S(stream), matches);
+  });
+}
+int cs_endswith(const cs_column* col, const char* str, uint8_t* results, int on_device, cs_stream stream, int64_t* matches) {
+  return guard([&] {
+    if (matches) *matches = 0;
+    if (!col || !str || !results || col->rows == 0) return;
+    require_device();
+    find_family(col, 4, str, 0, 0, nullptr, nullptr, 1, results, on_device, S(stream), matches);
+  });
+}
+// NVStrings::match_strings -- find.cu:276-314 (sizes must match: std::invalid_argument there)
+int cs_match_strings(const cs_column* col, const cs_column* other, uint8_t* results, int on_device, cs_stream stream, int64_t* matches) {
+  return guard([&] {
+    if (matches) *matches = -1;
+    if (!col || !other || !results) fail(CS_ERR_INVALID_ARG, "match_strings: null argument");
+    if (matches) *matches = 0;
+    if (col->rows == 0) return;
+    if (col->rows != other->rows) fail(CS_ERR_INVALID_ARG, "sizes must match");
+    require_device();
+    hipStream_t s = S(stream);
+    Buf tmp, cnt = dev_alloc(8, s);
+    CS_HIP(hipMemsetAsync(cnt->p, 0, 8, s));
+    uint8_t* d_out = results;
+    if (!on_device) {
+      tmp = dev_alloc((size_t)col->rows, s);
+      d_out = ptr<uint8_t>(tmp);
+    }
+    hipLaunchKernelGGL(k_match_strings, dim3(blocks_for(col->rows)), dim3(kBlock), 0, s, view_of(col), view_of(other), d_out, ptr<unsigned long long>(cnt));
+    CS_HIP(hipGetLastError());
+    if (!on_device) CS_HIP(hipMemcpyAsync(results, d_out, (size_t)col->rows, hipMemcpyDeviceToHost, s));
+    const int64_t n = read_back<int64_t>(cnt, s);
+    if (matches) *matches = n;
+  });
+}
+// NVStrings::find_multiple -- find.cu:202-234: results[r * targets + j]; the returned count looks at the first rows()
+// entries only, as the reference's does
+int cs_find_multiple(const cs_column* col, const cs_column* targets, int32_t* results, int on_device, cs_stream stream, int64_t* found) {
+  return guard([&] {
+    if (found) *found = 0;
+    if (!col || !targets || !results || col->rows == 0 || targets->rows == 0) return;
+    require_device();
+    hipStream_t s = S(stream);
+    const int64_t total = col->rows * targets->rows;
+    Buf tmp, cnt = dev_alloc(8, s);
+    CS_HIP(hipMemsetAsync(cnt->p, 0, 8, s));
+    int32_t* d_out = results;
+    if (!on_device) {
+      tmp = dev_alloc(sizeof(int32_t) * total, s);
+      d_out = ptr<int32_t>(tmp);
+    }
+    hipLaunchKernelGGL(k_find_multiple, dim3(blocks_for(total)), dim3(kBlock), 0, s, view_of(col), view_of(targets), d_out);
+    hipLaunchKernelGGL(k_count_not_minus_one, dim3(blocks_for(col->rows)), dim3(kBlock), 0, s, d_out, col->rows, ptr<unsigned long long>(cnt));
+    CS_HIP(hipGetLastError());
+    if (!on_device) CS_HIP(hipMemcpyAsync(results, d_out, sizeof(int32_t) * total, hipMemcpyDeviceToHost, s));
+    const int64_t n = read_back<int64_t>(cnt, s);
+    if (found) *found = n;
+  });
+}
+
 // NVStrings::contains -- find.cu:237-272
 int cs_contains(const cs_column* col, const char* str, uint8_t* results, int on_device, cs_stream stream,
                 int64_t* found) {

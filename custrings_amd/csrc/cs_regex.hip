@@ -2939,6 +2939,9 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
           CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)lds1));
         const unsigned grid = resident_grid(reinterpret_cast<const void*>(kern), lds1, (nsub1 + 3) / 4);
+        if (getenv("CS_STREAM_INFO"))
+          fprintf(stderr, "replace stream: grid %u lds %zu (tables %zu, tile %d + %d) rows/tile %d units %d wide %d brefs %d roomy %d growth %d rb %d\n", grid, lds1, tbl + gt_bytes, cap, cap_out,
+                  tc.R, (int)units, (int)wide_stream, (int)brefs, (int)roomy, (int)growth, rb);
 #if defined(CS_PHASE_PROF)
         Buf tracebuf;
         const long long ntrace = (nsub1 >> 10) + 1;

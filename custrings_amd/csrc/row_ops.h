@@ -111,6 +111,62 @@ CS_HD int row_find(const uint8_t* p, int n, const uint8_t* needle, int nb, int s
   return m < 0 ? -1 : count_chars(p, m);
 }
 
+// ---- the rest of the find family (find.cu:36-72, 123-236, 276-387; custring_view.inl:434-442, 481-515, 550-582, 1673-1703) ----
+// byte offset of character position `chpos` as custring_view::offset_for_char_pos has it: 0 for 0, the size from the
+// character count on (the position is UNSIGNED there: a negative argument is past the end)
+CS_HD int offset_for_char_pos(const uint8_t* p, int n, int nchars, unsigned chpos) {
+  if (chpos == 0) return 0;
+  if (chpos >= (unsigned)nchars) return n;
+  return byte_of_char(p, n, (int)chpos);
+}
+// custring_view::find(str, bytes, pos, count): the window is [pos, pos + count) in characters, count < 0 = the rest
+CS_HD int row_find_count(const uint8_t* p, int n, const uint8_t* needle, int nb, unsigned pos, int count) {
+  if (nb == 0) return -1;
+  const int nchars = count_chars(p, n);
+  if (count < 0) count = nchars;
+  int end = (int)pos + count;
+  if (end < 0 || end > nchars) end = nchars;
+  const int spos = offset_for_char_pos(p, n, nchars, pos), epos = offset_for_char_pos(p, n, nchars, (unsigned)end);
+  const int m = find_bytes(p, spos, epos, needle, nb);  // (an empty or inverted window: no start fits)
+  return m < 0 ? -1 : count_chars(p, m);
+}
+// custring_view::rfind(str, bytes, pos, count): the LAST occurrence inside the window; the count is taken as it comes
+// (a negative one moves the window's end in front of its start unless the sum is negative too)
+CS_HD int row_rfind_count(const uint8_t* p, int n, const uint8_t* needle, int nb, unsigned pos, int count) {
+  if (nb == 0) return -1;
+  const int nchars = count_chars(p, n);
+  int end = (int)pos + count;
+  if (end < 0 || end > nchars) end = nchars;
+  const int spos = offset_for_char_pos(p, n, nchars, pos), epos = offset_for_char_pos(p, n, nchars, (unsigned)end);
+  for (int m = epos - nb; m >= spos; --m) {
+    int j = 0;
+    while (j < nb && p[m + j] == needle[j]) ++j;
+    if (j == nb) return count_chars(p, m);
+  }
+  return -1;
+}
+// custr::compare (custring.inl:240-261): the difference of the first bytes that differ, else +1 / -1 for the longer side
+CS_HD int row_compare(const uint8_t* p, int n, const uint8_t* q, int m) {
+  int i = 0;
+  for (; i < n && i < m; ++i)
+    if (p[i] != q[i]) return (int)p[i] - (int)q[i];
+  if (i < n) return 1;
+  if (i < m) return -1;
+  return 0;
+}
+CS_HD bool row_starts_with(const uint8_t* p, int n, const uint8_t* q, int m) {
+  if (m > n) return false;
+  for (int i = 0; i < m; ++i)
+    if (p[i] != q[i]) return false;
+  return true;
+}
+CS_HD bool row_ends_with(const uint8_t* p, int n, const uint8_t* q, int m) {
+  if (m > n) return false;
+  for (int i = 0; i < m; ++i)
+    if (p[n - m + i] != q[i]) return false;
+  return true;
+}
+
 // ---- replace -------------------------------------------------------------------
 // maxrepl < 0: unlimited (the reference's cap, nchars, can never bind)
 CS_HD int row_replace_size(const uint8_t* p, int n, const uint8_t* needle, int nb, int rb,

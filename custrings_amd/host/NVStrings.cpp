@@ -401,6 +401,45 @@ unsigned int NVStrings::find(const char* str, int start, int end, int* results, 
   check(cs_find(m_col, str, start, end, results, devmem ? 1 : 0, nullptr, &n));
   return (unsigned int)n;
 }
+// find.cu:36-72, 123-236, 276-387 (`starts` / `ends` of find_from are device pointers, as the reference's are)
+unsigned int NVStrings::compare(const char* str, int* results, bool devmem) {
+  int64_t n = 0;
+  check(cs_compare(m_col, str, results, devmem ? 1 : 0, nullptr, &n));
+  return (unsigned int)n;
+}
+unsigned int NVStrings::rfind(const char* str, int start, int end, int* results, bool devmem) {
+  int64_t n = 0;
+  check(cs_rfind(m_col, str, start, end, results, devmem ? 1 : 0, nullptr, &n));
+  return (unsigned int)n;
+}
+unsigned int NVStrings::find_from(const char* str, int* starts, int* ends, int* results, bool devmem) {
+  int64_t n = 0;
+  check(cs_find_from(m_col, str, starts, ends, 1, results, devmem ? 1 : 0, nullptr, &n));
+  return (unsigned int)n;
+}
+unsigned int NVStrings::find_multiple(NVStrings& strs, int* results, bool devmem) {
+  int64_t n = 0;
+  check(cs_find_multiple(m_col, strs.handle(), results, devmem ? 1 : 0, nullptr, &n));
+  return (unsigned int)n;
+}
+int NVStrings::match_strings(NVStrings& strs, bool* results, bool devmem) {
+  if (!results) return -1;  // find.cu:278-279
+  if (size() == 0) return 0;
+  if (size() != strs.size()) throw std::invalid_argument("sizes must match");
+  int64_t n = 0;
+  check(cs_match_strings(m_col, strs.handle(), reinterpret_cast<unsigned char*>(results), devmem ? 1 : 0, nullptr, &n));
+  return (int)n;
+}
+unsigned int NVStrings::startswith(const char* str, bool* results, bool devmem) {
+  int64_t n = 0;
+  check(cs_startswith(m_col, str, reinterpret_cast<unsigned char*>(results), devmem ? 1 : 0, nullptr, &n));
+  return (unsigned int)n;
+}
+unsigned int NVStrings::endswith(const char* str, bool* results, bool devmem) {
+  int64_t n = 0;
+  check(cs_endswith(m_col, str, reinterpret_cast<unsigned char*>(results), devmem ? 1 : 0, nullptr, &n));
+  return (unsigned int)n;
+}
 int NVStrings::contains(const char* str, bool* results, bool devmem) {
   if (!str || !results) return -1;  // find.cu:239-240
   int64_t n = 0;

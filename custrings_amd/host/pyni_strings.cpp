@@ -237,6 +237,133 @@ static PyObject* n_find(PyObject*, PyObject* args) {  // (self, str, start, end|
   const int start = (int)int_arg(args, 2, 0), end = (int)int_arg(args, 3, -1);
   return int_results<int>(s, ptr_arg<int>(args, 4), -1, [&](int* out, bool dev) { s->find(str, start, end, out, dev); });
 }
+// the rest of the find family (pystrings.cpp:1005-1044, 2234-2360, 2738-2916)
+static PyObject* n_compare(PyObject*, PyObject* args) {  // (self, str, devptr): None for null rows in the host list
+  NVStrings* s = SELF(args);
+  const char* str = str_arg(args, 1);
+  int* devptr = ptr_arg<int>(args, 2);
+  if (devptr) return int_results<int>(s, devptr, 0, [&](int* out, bool dev) { s->compare(str, out, dev); });
+  const unsigned int count = s->size();
+  if (count == 0) return PyList_New(0);
+  std::vector<int> host(count);
+  std::vector<unsigned char> nulls((count + 7) / 8, 0);
+  unsigned int ncount = 0;
+  if (!guarded([&] {
+        s->compare(str, host.data(), false);
+        ncount = s->set_null_bitarray(nulls.data(), false, false);
+      }))
+    return nullptr;
+  PyObject* ret = PyList_New(count);
+  for (unsigned int i = 0; i < count; ++i) {
+    if (ncount && !((nulls[i / 8] >> (i % 8)) & 1)) {
+      Py_INCREF(Py_None);
+      PyList_SetItem(ret, i, Py_None);
+    } else {
+      PyList_SetItem(ret, i, PyLong_FromLong((long)host[i]));
+    }
+  }
+  return ret;
+}
+static PyObject* n_rfind(PyObject*, PyObject* args) {  // (self, str, start, end|None, devptr)
+  NVStrings* s = SELF(args);
+  const char* str = str_arg(args, 1);
+  const int start = (int)int_arg(args, 2, 0), end = (int)int_arg(args, 3, -1);
+  return int_results<int>(s, ptr_arg<int>(args, 4), -1, [&](int* out, bool dev) { s->rfind(str, start, end, out, dev); });
+}
+static PyObject* n_find_from(PyObject*, PyObject* args) {  // (self, str, starts devptr, ends devptr, devptr)
+  NVStrings* s = SELF(args);
+  const char* str = str_arg(args, 1);
+  int *starts = ptr_arg<int>(args, 2), *ends = ptr_arg<int>(args, 3);
+  return int_results<int>(s, ptr_arg<int>(args, 4), -1, [&](int* out, bool dev) { s->find_from(str, starts, ends, out, dev); });
+}
+static PyObject* n_startswith(PyObject*, PyObject* args) {
+  NVStrings* s = SELF(args);
+  const char* str = str_arg(args, 1);
+  return bool_results(s, ptr_arg<bool>(args, 2), [&](bool* out, bool dev) { return (int)s->startswith(str, out, dev); });
+}
+static PyObject* n_endswith(PyObject*, PyObject* args) {
+  NVStrings* s = SELF(args);
+  const char* str = str_arg(args, 1);
+  return bool_results(s, ptr_arg<bool>(args, 2), [&](bool* out, bool dev) { return (int)s->endswith(str, out, dev); });
+}
+// the other column: an nvstrings object or a list of str / None
+struct OtherStrings {
+  NVStrings* p = nullptr;
+  bool own = false;
+  OtherStrings(PyObject* o, const char* what) {
+    if (o == Py_None) {
+      PyErr_Format(PyExc_ValueError, "nvstrings.%s: parameter required", what);
+    } else if (PyList_Check(o)) {
+      if (PyList_Size(o) == 0) {
+        PyErr_Format(PyExc_ValueError, "nvstrings.%s empty argument list", what);
+        return;
+      }
+      std::vector<const char*> list;
+      list_strings(o, list);
+      guarded([&] { p = NVStrings::create_from_array(list.data(), (unsigned int)list.size()); });
+      own = p != nullptr;
+    } else {
+      p = handle_of<NVStrings>(o);
+      if (!p) PyErr_Format(PyExc_ValueError, "nvstrings.%s: argument must be nvstrings object", what);
+    }
+  }
+  ~OtherStrings() {
+    if (own) guarded([&] { NVStrings::destroy(p); });
+  }
+};
+static PyObject* n_match_strings(PyObject*, PyObject* args) {  // (self, strs, devptr): plain bools (two nulls are equal)
+  NVStrings* s = SELF(args);
+  OtherStrings other(arg(args, 1), "match_strings");
+  if (!other.p) return nullptr;
+  if (other.p->size() != s->size()) {
+    PyErr_SetString(PyExc_ValueError, "nvstrings.match_strings list size must match");
+    return nullptr;
+  }
+  bool* devptr = ptr_arg<bool>(args, 2);
+  if (devptr) {
+    if (!guarded([&] { s->match_strings(*other.p, devptr, true); })) return nullptr;
+    return PyLong_FromVoidPtr(devptr);
+  }
+  const unsigned int count = s->size();
+  if (count == 0) return PyList_New(0);
+  std::vector<unsigned char> host(count);
+  if (!guarded([&] { s->match_strings(*other.p, reinterpret_cast<bool*>(host.data()), false); })) return nullptr;
+  PyObject* ret = PyList_New(count);
+  for (unsigned int i = 0; i < count; ++i) PyList_SetItem(ret, i, PyBool_FromLong(host[i]));
+  return ret;
+}
+static PyObject* n_find_multiple(PyObject*, PyObject* args) {  // (self, strs, devptr): a list of positions per row
+  NVStrings* s = SELF(args);
+  OtherStrings other(arg(args, 1), "find_multiple");
+  if (!other.p) return nullptr;
+  int* devptr = ptr_arg<int>(args, 2);
+  if (devptr) {
+    if (!guarded([&] { s->find_multiple(*other.p, devptr, true); })) return nullptr;
+    return PyLong_FromVoidPtr(devptr);
+  }
+  const unsigned int rows = s->size(), tc = other.p->size();
+  PyObject* ret = PyList_New(rows);
+  if (rows == 0) return ret;
+  std::vector<int> host((size_t)rows * tc);
+  if (!guarded([&] { s->find_multiple(*other.p, host.data(), false); })) {
+    Py_DECREF(ret);
+    return nullptr;
+  }
+  for (unsigned int r = 0; r < rows; ++r) {
+    PyObject* row = PyList_New(tc);
+    for (unsigned int j = 0; j < tc; ++j) {
+      const int v = host[(size_t)r * tc + j];
+      if (v < -1) {
+        Py_INCREF(Py_None);
+        PyList_SetItem(row, j, Py_None);
+      } else {
+        PyList_SetItem(row, j, PyLong_FromLong((long)v));
+      }
+    }
+    PyList_SetItem(ret, r, row);
+  }
+  return ret;
+}
 static PyObject* n_contains(PyObject*, PyObject* args) {  // pystrings.cpp:2588-2666: (self, str, regex, devptr)
   NVStrings* s = SELF(args);
   const char* str = str_arg(args, 1);
@@ -402,7 +529,7 @@ static PyMethodDef s_Methods[] = {
     M(n_createFromHostStrings), M(n_destroyStrings), M(n_createHostStrings), M(n_createFromOffsets), M(n_createFromNVStrings), M(n_create_offsets),
     M(n_size), M(n_len), M(n_byte_count), M(n_null_count), M(n_set_null_bitmask), M(n_copy), M(n_split), M(n_rsplit), M(n_split_record),
     M(n_rsplit_record), M(n_partition), M(n_rpartition), M(n_replace), M(n_replace_multi), M(n_replace_with_backrefs), M(n_lstrip), M(n_strip),
-    M(n_rstrip), M(n_lower), M(n_upper), M(n_find), M(n_contains), M(n_match), M(n_count), M(n_findall), M(n_findall_record), M(n_extract),
+    M(n_rstrip), M(n_lower), M(n_upper), M(n_find), M(n_rfind), M(n_find_from), M(n_find_multiple), M(n_compare), M(n_match_strings), M(n_startswith), M(n_endswith), M(n_contains), M(n_match), M(n_count), M(n_findall), M(n_findall_record), M(n_extract),
     M(n_extract_record), M(n_sort), M(n_order), M(n_gather), M(n_sublist), M(n_scatter), M(n_scalar_scatter), M(n_remove_strings),
     M(n_add_strings), M(n_cat), M(n_join), M(n_device_memory),
 #undef M

@@ -591,6 +591,77 @@ class nvstrings:
         check(lib.cs_find(self.m_cptr, b(sub), int(start), end, res.ctypes.data, 0, None, C.byref(found)))
         return [None if v < -1 else int(v) for v in res[:rows]]
 
+    # ---- the rest of the find family (nvstrings.py:647, 1825-1890, 2005-2095, 2550; find.cu) -----------------------
+    def _positions(self, call, devptr, n=None):
+        rows = self.size() if n is None else n
+        found = C.c_int64()
+        if devptr:
+            check(call(devptr, 1, C.byref(found)))
+            return devptr
+        res = np.zeros(max(rows, 1), dtype=np.int32)
+        check(call(res.ctypes.data, 0, C.byref(found)))
+        return res[:rows]
+
+    def rfind(self, sub, start=0, end=None, devptr=0):
+        """nvstrings.py:1861-1890 -- the LAST occurrence inside characters [start, end); None for null rows."""
+        end = -1 if end is None else int(end)
+        res = self._positions(lambda out, dev, f: lib.cs_rfind(self.m_cptr, b(sub), int(start), end, out, dev, None, f), devptr)
+        return res if devptr else [None if v < -1 else int(v) for v in res]
+
+    def find_from(self, sub, starts=0, ends=0, devptr=0):
+        """nvstrings.py:1825-1859 -- `starts` / `ends`: device pointers to one int32 per row (0 = from the start / to the end)."""
+        res = self._positions(lambda out, dev, f: lib.cs_find_from(self.m_cptr, b(sub), starts or None, ends or None, 1, out, dev, None, f), devptr)
+        return res if devptr else [None if v < -1 else int(v) for v in res]
+
+    def find_multiple(self, strs, devptr=0):
+        """nvstrings.py:2550-2580 -- a row of positions per string, one per target."""
+        if strs is None:
+            raise ValueError("nvstrings.find_multiple: parameter required")
+        targets = strs if isinstance(strs, nvstrings) else to_device(list(strs))
+        tc = targets.size()
+        if tc == 0:
+            raise ValueError("nvstrings.find_multiple empty argument list")
+        rows = self.size()
+        res = self._positions(lambda out, dev, f: lib.cs_find_multiple(self.m_cptr, targets.m_cptr, out, dev, None, f), devptr, rows * tc)
+        if devptr:
+            return res
+        return [[None if v < -1 else int(v) for v in res[r * tc:(r + 1) * tc]] for r in range(rows)]
+
+    def compare(self, str, devptr=0):
+        """nvstrings.py:647-672 -- bytewise difference to `str` (0 = equal); None for null rows in the host list."""
+        rows = self.size()
+        res = self._positions(lambda out, dev, f: lib.cs_compare(self.m_cptr, b(str), out, dev, None, f), devptr)
+        if devptr:
+            return res
+        nulls = self._null_flags()
+        return [None if nulls[i] else int(res[i]) for i in range(rows)]
+
+    def match_strings(self, strs, devptr=0):
+        """nvstrings.py:2005-2047 -- row-wise equality with another instance (or list) of the same size."""
+        if strs is None:
+            raise ValueError("nvstrings.match_strings: parameter required")
+        other = strs if isinstance(strs, nvstrings) else to_device(list(strs))
+        if other.size() != self.size():
+            raise ValueError("nvstrings.match_strings list size must match")
+        rows = self.size()
+        found = C.c_int64()
+        if devptr:
+            check(lib.cs_match_strings(self.m_cptr, other.m_cptr, devptr, 1, None, C.byref(found)))
+            return devptr
+        if rows == 0:
+            return []
+        res = np.zeros(rows, dtype=np.uint8)
+        check(lib.cs_match_strings(self.m_cptr, other.m_cptr, res.ctypes.data, 0, None, C.byref(found)))
+        return [bool(v) for v in res]
+
+    def startswith(self, pat, devptr=0):
+        """nvstrings.py:2049-2071; null rows -> None in the host list."""
+        return self._bools(lambda out, dev, f: lib.cs_startswith(self.m_cptr, b(pat), out, dev, None, f), devptr)
+
+    def endswith(self, pat, devptr=0):
+        """nvstrings.py:2073-2095."""
+        return self._bools(lambda out, dev, f: lib.cs_endswith(self.m_cptr, b(pat), out, dev, None, f), devptr)
+
     def _bools(self, call, devptr):
         rows = self.size()
         found = C.c_int64()

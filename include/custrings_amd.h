@@ -219,6 +219,22 @@ int cs_strip(const cs_column* col, const char* to_strip, int side, cs_stream str
 int cs_find(const cs_column* col, const char* str, int start, int end, int32_t* results,
             int on_device, cs_stream stream, int64_t* found);
 /* NVStrings::contains (NVStrings.h:907; find.cu:237-272): 1 byte per row. */
+/* The rest of NVStrings' find family (NVStrings.h:837-934; find.cu:36-72, 123-236, 276-387).  Positions are character
+ * positions; null rows give -2 (positions), -1 (compare), false (predicates); the count out is what the reference returns. */
+/* NVStrings::rfind: the last occurrence inside characters [start, end) (end < 0: to the end). */
+int cs_rfind(const cs_column* col, const char* str, int start, int end, int32_t* results, int on_device, cs_stream stream, int64_t* found);
+/* NVStrings::find_from: per-row windows; `starts` / `ends` hold one int32 per row (host memory unless bounds_on_device), either may be null. */
+int cs_find_from(const cs_column* col, const char* str, const int32_t* starts, const int32_t* ends, int bounds_on_device, int32_t* results,
+                 int on_device, cs_stream stream, int64_t* found);
+/* NVStrings::find_multiple: results[row * targets + j] = position of targets[j] in the row. */
+int cs_find_multiple(const cs_column* col, const cs_column* targets, int32_t* results, int on_device, cs_stream stream, int64_t* found);
+/* NVStrings::compare: bytewise difference (custring.inl:240-261); *matches = rows equal to `str`. */
+int cs_compare(const cs_column* col, const char* str, int32_t* results, int on_device, cs_stream stream, int64_t* matches);
+/* NVStrings::match_strings: row-wise equality of two columns of the same size (two nulls are equal). */
+int cs_match_strings(const cs_column* col, const cs_column* other, uint8_t* results, int on_device, cs_stream stream, int64_t* matches);
+/* NVStrings::startswith / endswith. */
+int cs_startswith(const cs_column* col, const char* str, uint8_t* results, int on_device, cs_stream stream, int64_t* matches);
+int cs_endswith(const cs_column* col, const char* str, uint8_t* results, int on_device, cs_stream stream, int64_t* matches);
 int cs_contains(const cs_column* col, const char* str, uint8_t* results, int on_device,
                 cs_stream stream, int64_t* found);
 /* NVStrings::replace (NVStrings.h:714; modify.cu:109-192). str NULL/empty ->

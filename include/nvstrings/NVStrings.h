@@ -103,6 +103,14 @@ class NVStrings {
   /* ---- search (NVStrings.h:861-981) ---- */
   unsigned int find(const char* str, int start, int end, int* results, bool devmem = true);
   int contains(const char* str, bool* results, bool devmem = true);
+  // the rest of the find family (reference NVStrings.h:849-934; find.cu)
+  unsigned int compare(const char* str, int* results, bool devmem = true);
+  unsigned int rfind(const char* str, int start, int end, int* results, bool devmem = true);
+  unsigned int find_from(const char* str, int* starts, int* ends, int* results, bool devmem = true);
+  unsigned int find_multiple(NVStrings& strs, int* results, bool devmem = true);
+  int match_strings(NVStrings& strs, bool* results, bool devmem = true);
+  unsigned int startswith(const char* str, bool* results, bool devmem = true);
+  unsigned int endswith(const char* str, bool* results, bool devmem = true);
   int contains_re(const char* pattern, bool* results, bool devmem = true);
   int match(const char* pattern, bool* results, bool devmem = true);
   int count_re(const char* pattern, int* results, bool devmem = true);

@@ -102,6 +102,13 @@ class CpuLib:
         self._f("strip", vp, [vp, C.c_char_p, C.c_int])
         self._f("find", C.c_int64, [vp, C.c_char_p, C.c_int, C.c_int, vp])
         self._f("contains", C.c_int64, [vp, C.c_char_p, vp])
+        self._f("rfind", C.c_int64, [vp, C.c_char_p, C.c_int, C.c_int, vp])
+        self._f("find_from", C.c_int64, [vp, C.c_char_p, vp, vp, vp])
+        self._f("find_multiple", C.c_int64, [vp, vp, vp])
+        self._f("compare", C.c_int64, [vp, C.c_char_p, vp])
+        self._f("match_strings", C.c_int64, [vp, vp, vp])
+        self._f("startswith", C.c_int64, [vp, C.c_char_p, vp])
+        self._f("endswith", C.c_int64, [vp, C.c_char_p, vp])
         self._f("replace", vp, [vp, C.c_char_p, C.c_char_p, C.c_int])
         self._f("split", C.c_int, [vp, C.c_char_p, C.c_int, C.POINTER(C.POINTER(vp))])
         self._f("rsplit", C.c_int, [vp, C.c_char_p, C.c_int, C.POINTER(C.POINTER(vp))])
@@ -179,6 +186,62 @@ class CpuLib:
         h = self.put(col)
         out = np.zeros(col.rows, dtype=np.uint8)
         n = self._contains(h, self._b(s), out.ctypes.data)
+        self._col_free(h)
+        return out, n
+
+    # the rest of the find family (find.cu): results + the count the reference returns
+    def rfind(self, col, s, start=0, end=-1):
+        h = self.put(col)
+        out = np.zeros(col.rows, dtype=np.int32)
+        n = self._rfind(h, self._b(s), start, end, out.ctypes.data)
+        self._col_free(h)
+        return out, n
+
+    def find_from(self, col, s, starts=None, ends=None):
+        h = self.put(col)
+        out = np.zeros(col.rows, dtype=np.int32)
+        st = None if starts is None else np.ascontiguousarray(starts, dtype=np.int32)
+        en = None if ends is None else np.ascontiguousarray(ends, dtype=np.int32)
+        n = self._find_from(h, self._b(s), None if st is None else st.ctypes.data, None if en is None else en.ctypes.data, out.ctypes.data)
+        self._col_free(h)
+        return out, n
+
+    def find_multiple(self, col, targets):
+        h, t = self.put(col), self.put(targets)
+        out = np.zeros(col.rows * targets.rows, dtype=np.int32)
+        n = self._find_multiple(h, t, out.ctypes.data)
+        self._col_free(h)
+        self._col_free(t)
+        return out, n
+
+    def compare(self, col, s):
+        h = self.put(col)
+        out = np.zeros(col.rows, dtype=np.int32)
+        n = self._compare(h, self._b(s), out.ctypes.data)
+        self._col_free(h)
+        return out, n
+
+    def match_strings(self, col, other):
+        h, t = self.put(col), self.put(other)
+        out = np.zeros(col.rows, dtype=np.uint8)
+        n = self._match_strings(h, t, out.ctypes.data)
+        self._col_free(h)
+        self._col_free(t)
+        if n == -2:
+            raise ValueError("sizes must match")
+        return out, n
+
+    def startswith(self, col, s):
+        h = self.put(col)
+        out = np.zeros(col.rows, dtype=np.uint8)
+        n = self._startswith(h, self._b(s), out.ctypes.data)
+        self._col_free(h)
+        return out, n
+
+    def endswith(self, col, s):
+        h = self.put(col)
+        out = np.zeros(col.rows, dtype=np.uint8)
+        n = self._endswith(h, self._b(s), out.ctypes.data)
         self._col_free(h)
         return out, n
 

@@ -81,6 +81,35 @@ class OracleEngine:
         out, n = self.o.find(Col.from_list(s), sub, start, end)
         return out.tolist(), n
 
+    # the rest of the find family: (results, count) as the reference's C++ methods return them
+    def rfind(self, s, sub, start=0, end=-1):
+        out, n = self.o.rfind(Col.from_list(s), sub, start, end)
+        return out.tolist(), n
+
+    def find_from(self, s, sub, starts=None, ends=None):
+        out, n = self.o.find_from(Col.from_list(s), sub, starts, ends)
+        return out.tolist(), n
+
+    def find_multiple(self, s, targets):
+        out, n = self.o.find_multiple(Col.from_list(s), Col.from_list(targets))
+        return out.tolist(), n
+
+    def compare(self, s, sub):
+        out, n = self.o.compare(Col.from_list(s), sub)
+        return out.tolist(), n
+
+    def match_strings(self, s, t):
+        out, n = self.o.match_strings(Col.from_list(s), Col.from_list(t))
+        return [bool(x) for x in out], n
+
+    def startswith(self, s, sub):
+        out, n = self.o.startswith(Col.from_list(s), sub)
+        return [bool(x) for x in out], n
+
+    def endswith(self, s, sub):
+        out, n = self.o.endswith(Col.from_list(s), sub)
+        return [bool(x) for x in out], n
+
     def contains(self, s, pat):
         out, n = self.o.contains(Col.from_list(s), pat)
         return [bool(x) for x in out], n
@@ -309,6 +338,35 @@ class EmuEngine:
         out, n = self.e.find(Col.from_list(s), sub, start, end)
         return out.tolist(), n
 
+    # the rest of the find family: (results, count) as the reference's C++ methods return them
+    def rfind(self, s, sub, start=0, end=-1):
+        out, n = self.e.rfind(Col.from_list(s), sub, start, end)
+        return out.tolist(), n
+
+    def find_from(self, s, sub, starts=None, ends=None):
+        out, n = self.e.find_from(Col.from_list(s), sub, starts, ends)
+        return out.tolist(), n
+
+    def find_multiple(self, s, targets):
+        out, n = self.e.find_multiple(Col.from_list(s), Col.from_list(targets))
+        return out.tolist(), n
+
+    def compare(self, s, sub):
+        out, n = self.e.compare(Col.from_list(s), sub)
+        return out.tolist(), n
+
+    def match_strings(self, s, t):
+        out, n = self.e.match_strings(Col.from_list(s), Col.from_list(t))
+        return [bool(x) for x in out], n
+
+    def startswith(self, s, sub):
+        out, n = self.e.startswith(Col.from_list(s), sub)
+        return [bool(x) for x in out], n
+
+    def endswith(self, s, sub):
+        out, n = self.e.endswith(Col.from_list(s), sub)
+        return [bool(x) for x in out], n
+
     def contains(self, s, pat):
         out, n = self.e.contains(Col.from_list(s), pat)
         return [bool(x) for x in out], n
@@ -419,6 +477,52 @@ class GpuEngine:
         found = C.c_int64()
         self.L.check(self.L.lib.cs_find(c.m_cptr, sub.encode("utf8"), start, end, res.ctypes.data, 0, None, C.byref(found)))
         return res[: len(s)].tolist(), found.value
+
+    # the rest of the find family through the C ABI (host results; (values, count) like the reference's C++ methods)
+    def _i32(self, n, call):
+        res = np.zeros(max(n, 1), dtype=np.int32)
+        found = C.c_int64()
+        self.L.check(call(res.ctypes.data, C.byref(found)))
+        return res[:n].tolist(), found.value
+
+    def _u8(self, n, call):
+        res = np.zeros(max(n, 1), dtype=np.uint8)
+        found = C.c_int64()
+        self.L.check(call(res.ctypes.data, C.byref(found)))
+        return [bool(x) for x in res[:n]], found.value
+
+    def rfind(self, s, sub, start=0, end=-1):
+        c = self.col(s)
+        return self._i32(len(s), lambda out, f: self.L.lib.cs_rfind(c.m_cptr, sub.encode("utf8"), start, end, out, 0, None, f))
+
+    def find_from(self, s, sub, starts=None, ends=None):
+        c = self.col(s)
+        st = None if starts is None else np.ascontiguousarray(starts, dtype=np.int32)
+        en = None if ends is None else np.ascontiguousarray(ends, dtype=np.int32)
+        return self._i32(len(s), lambda out, f: self.L.lib.cs_find_from(c.m_cptr, sub.encode("utf8"), None if st is None else st.ctypes.data,
+                                                                     None if en is None else en.ctypes.data, 0, out, 0, None, f))
+
+    def find_multiple(self, s, targets):
+        c, t = self.col(s), self.col(targets)
+        return self._i32(len(s) * len(targets), lambda out, f: self.L.lib.cs_find_multiple(c.m_cptr, t.m_cptr, out, 0, None, f))
+
+    def compare(self, s, sub):
+        c = self.col(s)
+        return self._i32(len(s), lambda out, f: self.L.lib.cs_compare(c.m_cptr, sub.encode("utf8"), out, 0, None, f))
+
+    def match_strings(self, s, t):
+        c, o = self.col(s), self.col(t)
+        if len(s) != len(t):
+            raise ValueError("sizes must match")
+        return self._u8(len(s), lambda out, f: self.L.lib.cs_match_strings(c.m_cptr, o.m_cptr, out, 0, None, f))
+
+    def startswith(self, s, sub):
+        c = self.col(s)
+        return self._u8(len(s), lambda out, f: self.L.lib.cs_startswith(c.m_cptr, sub.encode("utf8"), out, 0, None, f))
+
+    def endswith(self, s, sub):
+        c = self.col(s)
+        return self._u8(len(s), lambda out, f: self.L.lib.cs_endswith(c.m_cptr, sub.encode("utf8"), out, 0, None, f))
 
     def _bools(self, fn, c, n, *args):
         res = np.zeros(max(n, 1), dtype=np.uint8)
@@ -624,6 +728,20 @@ def run_case(eng, case):
     if op == "find":
         vals, _ = eng.find(s, a["sub"], a["start"], a["end"])
         return [None if (py and v < -1) else v for v in vals]
+    if op in ("rfind", "find_from"):
+        vals, _ = eng.rfind(s, a["sub"], a["start"], a["end"]) if op == "rfind" else eng.find_from(s, a["sub"], a.get("starts"), a.get("ends"))
+        return [None if (py and v < -1) else v for v in vals]
+    if op == "find_multiple":
+        vals, _ = eng.find_multiple(s, a["targets"])
+        tc = len(a["targets"])
+        flat = [None if (py and v < -1) else v for v in vals]
+        return [flat[r * tc:(r + 1) * tc] for r in range(len(s))] if py else flat
+    if op == "compare":
+        return lift(eng.compare(s, a["sub"])[0])
+    if op == "match_strings":
+        return eng.match_strings(s, a["other"])[0]
+    if op in ("startswith", "endswith"):
+        return lift(getattr(eng, op)(s, a["sub"])[0])
     if op == "contains":
         return lift(eng.contains(s, a["pat"])[0])
     if op in ("contains_re", "match", "count_re"):

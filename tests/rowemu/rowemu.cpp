@@ -125,6 +125,74 @@ int64_t emu_find(const emu_col* c, const char* str, int start, int end, int32_t*
   }
   return n;
 }
+int64_t emu_rfind(const emu_col* c, const char* str, int start, int end, int32_t* out) {
+  int nb = (int)strlen(str);
+  if (start < 0) start = 0;
+  int64_t n = 0;
+  for (int64_t r = 0; r < c->rows; ++r) {
+    out[r] = c->ok(r) ? row_rfind_count(c->row(r), c->len(r), (const uint8_t*)str, nb, (unsigned)start, end - start) : -2;
+    n += out[r] != -1;
+  }
+  return n;
+}
+int64_t emu_find_from(const emu_col* c, const char* str, const int32_t* starts, const int32_t* ends, int32_t* out) {
+  int nb = (int)strlen(str);
+  int64_t n = 0;
+  for (int64_t r = 0; r < c->rows; ++r) {
+    int pos = starts ? starts[r] : 0;
+    out[r] = c->ok(r) ? row_find_count(c->row(r), c->len(r), (const uint8_t*)str, nb, (unsigned)pos, ends ? ends[r] - pos : -1) : -2;
+    n += out[r] != -1;
+  }
+  return n;
+}
+int64_t emu_compare(const emu_col* c, const char* str, int32_t* out) {
+  int nb = (int)strlen(str);
+  if (!nb) return 0;
+  int64_t n = 0;
+  for (int64_t r = 0; r < c->rows; ++r) {
+    out[r] = c->ok(r) ? row_compare(c->row(r), c->len(r), (const uint8_t*)str, nb) : -1;
+    n += out[r] == 0;
+  }
+  return n;
+}
+int64_t emu_startswith(const emu_col* c, const char* str, uint8_t* out) {
+  int nb = (int)strlen(str);
+  int64_t n = 0;
+  for (int64_t r = 0; r < c->rows; ++r) {
+    out[r] = c->ok(r) && row_starts_with(c->row(r), c->len(r), (const uint8_t*)str, nb);
+    n += out[r];
+  }
+  return n;
+}
+int64_t emu_endswith(const emu_col* c, const char* str, uint8_t* out) {
+  int nb = (int)strlen(str);
+  int64_t n = 0;
+  for (int64_t r = 0; r < c->rows; ++r) {
+    out[r] = c->ok(r) && row_ends_with(c->row(r), c->len(r), (const uint8_t*)str, nb);
+    n += out[r];
+  }
+  return n;
+}
+int64_t emu_match_strings(const emu_col* a, const emu_col* b, uint8_t* out) {
+  if (a->rows != b->rows) return -2;
+  int64_t n = 0;
+  for (int64_t r = 0; r < a->rows; ++r) {
+    bool same = a->ok(r) == b->ok(r);
+    if (a->ok(r) && b->ok(r)) same = row_compare(a->row(r), a->len(r), b->row(r), b->len(r)) == 0;
+    out[r] = same;
+    n += same;
+  }
+  return n;
+}
+int64_t emu_find_multiple(const emu_col* c, const emu_col* t, int32_t* out) {
+  if (c->rows == 0 || t->rows == 0) return 0;
+  for (int64_t r = 0; r < c->rows; ++r)
+    for (int64_t j = 0; j < t->rows; ++j)
+      out[r * t->rows + j] = c->ok(r) && t->ok(j) ? row_find_count(c->row(r), c->len(r), t->row(j), t->len(j), 0u, -1) : -2;
+  int64_t n = 0;
+  for (int64_t i = 0; i < c->rows; ++i) n += out[i] != -1;
+  return n;
+}
 int64_t emu_contains(const emu_col* c, const char* str, uint8_t* out) {
   int nb = (int)strlen(str);
   int64_t n = 0;

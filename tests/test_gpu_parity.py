@@ -146,6 +146,21 @@ def test_gpu_synth_matches_spec(orc, kind, param, first):
     gpuutil.assert_same(gpuutil.synth(kind, first, rows, param), orc.synth(kind, first, rows, param=param), "synth")
 
 
+def test_gpu_vs_oracle_find_family(gpu_engine, oracle_engine):
+    """rfind, find_from, find_multiple, compare, match_strings, startswith, endswith (find.cu:36-72, 123-236, 276-387)
+    through the C ABI: values and the counts the reference returns; then the Python mirror's host lists."""
+    from test_rowemu_parity import find_family_fuzz
+
+    s = fuzzdata.rows(7, 2000, max_len=30) + ["", None, "a", "aa", "éé", "ab" * 20]
+    find_family_fuzz(gpu_engine, oracle_engine, s)
+    d = gpu_engine.col(["hello", "there", "world", "accéntéd", None, ""])
+    assert d.rfind("d") == [-1, -1, 4, 7, None, -1] and d.find_from("r") == [-1, 3, 2, -1, None, -1]
+    assert d.compare("there") == [-12, 0, 3, -19, None, -1]
+    assert d.find_multiple(["e", "o", "d"]) == [[1, 4, -1], [2, -1, -1], [-1, 1, 4], [-1, -1, 7], [None, None, None], [-1, -1, -1]]
+    assert d.startswith("he") == [True, False, False, False, None, False] and d.endswith("d") == [False, False, True, True, None, False]
+    assert gpu_engine.col(["hello", "here", None, "accéntéd", None, ""]).match_strings(d) == [True, False, False, True, True, True]
+
+
 def test_gpu_character_sets_of_any_size(gpu_engine, oracle_engine):
     """strip / tokenize / the NVText counters with character sets beyond 64 members (the reference walks a set of any
     length: custring_view.inl:93-105, text/tokens.cu:45-50)"""

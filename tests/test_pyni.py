@@ -27,7 +27,7 @@ def _mods():
 COVERED = {
     "nvstrings.py": ("pyniNVStrings", "to_device from_offsets to_host to_offsets size len byte_count null_count set_null_bitmask copy split rsplit "
                      "split_record rsplit_record partition rpartition replace replace_multi replace_with_backrefs lstrip strip rstrip lower upper "
-                     "find contains match count findall findall_record extract extract_record sort order gather sublist scatter scalar_scatter "
+                     "find rfind find_from find_multiple compare match_strings startswith endswith contains match count findall findall_record extract extract_record sort order gather sublist scatter scalar_scatter "
                      "remove_strings add_strings cat join"),
     "nvcategory.py": ("pyniNVCategory", "to_device from_offsets from_strings from_strings_list size keys_size keys indexes_for_key value_for_index value "
                       "values values_cpointer add_strings remove_strings to_strings gather_strings gather gather_and_remap merge_category "
@@ -91,6 +91,21 @@ def test_gpu_pyni_strings_path():
     assert s.n_contains(h, "^a", True, 0) == [False, None, True, False, False]
     assert s.n_find(h, "é", 0, None, 0) == [1, None, -1, 1, -1]
     assert s.n_len(h, 0) == [11, None, 8, 11, 0]
+    # the rest of the find family (python/tests/test_compare.py:10-102)
+    f = s.n_createFromHostStrings(["hello", "there", "world", "accéntéd", None, ""])
+    assert s.n_compare(f, "there", 0) == [-12, 0, 3, -19, None, -1]
+    assert s.n_rfind(f, "d", 0, None, 0) == [-1, -1, 4, 7, None, -1]
+    assert s.n_find_from(f, "r", 0, 0, 0) == [-1, 3, 2, -1, None, -1]
+    assert s.n_find_multiple(f, ["e", "o", "d"], 0) == [[1, 4, -1], [2, -1, -1], [-1, 1, 4], [-1, -1, 7], [None, None, None], [-1, -1, -1]]
+    assert s.n_startswith(f, "he", 0) == [True, False, False, False, None, False]
+    assert s.n_endswith(f, "d", 0) == [False, False, True, True, None, False]
+    import nvstrings as _nvs
+
+    other = _nvs.to_device(["hello", "there", "world", "accéntéd", None, ""])  # (an nvstrings object: the glue reads its m_cptr)
+    assert s.n_match_strings(s.n_createFromHostStrings(["hello", "here", None, "accéntéd", None, ""]), other, 0) == [True, False, False, True, True, True]
+    assert s.n_match_strings(f, ["hello", "there", "world", "accéntéd", None, ""], 0) == [True] * 6
+    with pytest.raises(ValueError):
+        s.n_match_strings(f, ["x"], 0)
     assert s.n_createHostStrings(s.n_upper(h))[0] == "HÉLLO THESÉ"
     assert s.n_createHostStrings(s.n_strip(s.n_createFromHostStrings(["  a  ", None]), None)) == ["a", None]
     assert s.n_createHostStrings(s.n_gather(h, [3, 0], 0)) == ["tést String", "Héllo thesé"]

@@ -8,7 +8,8 @@ import engines
 import fuzzdata
 
 # (ops whose row logic the host harness compiles; the others exist as device kernels only and are covered by the -m gpu tests)
-EMULATED = ("lower", "upper", "strip", "lstrip", "rstrip", "find", "contains", "replace", "split", "rsplit", "tokenize", "contains_re",
+EMULATED = ("lower", "upper", "strip", "lstrip", "rstrip", "find", "contains", "rfind", "find_from", "find_multiple", "compare", "match_strings", "startswith",
+            "endswith", "replace", "split", "rsplit", "tokenize", "contains_re",
             "match", "count_re", "replace_re", "replace_with_backrefs", "extract", "findall")
 REF = [c for c in engines.load_cases("reference_tests.json") if c["op"] in EMULATED]
 APX = [c for c in engines.load_cases("survey_appendix_a.json") if c["op"] in EMULATED]
@@ -48,6 +49,36 @@ def test_rowemu_vs_oracle_string_ops(emu_engine, oracle_engine, seed):
             assert e.split(s, d, n) == o.split(s, d, n), (d, n)
     for d in (None, " ", "_-", "é ", "a\t"):
         assert e.tokenize(s, d) == o.tokenize(s, d)
+
+
+def find_family_fuzz(e, o, s):
+    """rfind / find_from / find_multiple / compare / match_strings / startswith / endswith: values AND counts"""
+    import random
+
+    rnd = random.Random(11)
+    for sub in ("a", "é", "ab", " ", "", "bc", "😀", "x" * 40):
+        for st, en in ((0, -1), (1, 5), (3, 2), (2, 100), (-3, -1), (0, 0), (5, 1)):
+            assert e.rfind(s, sub, st, en) == o.rfind(s, sub, st, en), (sub, st, en)
+        starts = [rnd.randint(-2, 12) for _ in s]
+        ends = [rnd.randint(-2, 30) for _ in s]
+        for a, b in ((None, None), (starts, None), (None, ends), (starts, ends)):
+            assert e.find_from(s, sub, a, b) == o.find_from(s, sub, a, b), (sub, a is None, b is None)
+        assert e.compare(s, sub) == o.compare(s, sub), sub
+        assert e.startswith(s, sub) == o.startswith(s, sub), sub
+        assert e.endswith(s, sub) == o.endswith(s, sub), sub
+    targets = ["a", "é", None, "", "ab", "zz"]
+    assert e.find_multiple(s, targets) == o.find_multiple(s, targets)
+    other = list(s)
+    for i in range(0, len(other), 3):
+        other[i] = None if other[i] is not None and i % 2 else (other[i] or "") + "x"
+    assert e.match_strings(s, other) == o.match_strings(s, other)
+    assert e.match_strings(s, s) == o.match_strings(s, s)
+    with pytest.raises(ValueError):
+        e.match_strings(s, s[:-1])
+
+
+def test_rowemu_vs_oracle_find_family(emu_engine, oracle_engine):
+    find_family_fuzz(emu_engine, oracle_engine, fuzzdata.rows(7, 500, max_len=30) + ["", None, "a", "aa", "éé", "ab" * 20])
 
 
 def big_sets():

@@ -99,6 +99,14 @@ F = ["Héllo", "thesé", None, "ARE THE", "tést strings", ""]
 case("cpp_find", "cpp/tests/test_find.cu:25-36", "find", F, [1, 4, -2, -1, 1, -1], sub="é", start=0, end=-1)
 case("cpp_find_contains", "cpp/tests/test_find.cu:64-76", "contains", F,
      [False, True, False, False, True, False], pat="s")
+case("cpp_compare", "cpp/tests/test_find.cu:9-22", "compare", F, [-44, 0, -1, -51, 91, -1], sub="thesé")
+case("cpp_rfind", "cpp/tests/test_find.cu:37-42", "rfind", F, [3, -1, -2, -1, -1, -1], sub="l", start=0, end=-1)
+case("cpp_match_strings", "cpp/tests/test_find.cu:46-62", "match_strings", F, [False, True, False, False, True, True],
+     other=["héllo", "thesé", "", None, "tést strings", ""])
+case("cpp_find_from", "cpp/tests/test_find.cu:78-91", "find_from", F, [-1, 3, -2, -1, 5, -1], sub="s", starts=[3, 3, 3, 3, 3, 3], ends=None)
+case("cpp_find_multiple", "cpp/tests/test_find.cu:93-110", "find_multiple", F, [1, -1, 4, 2, -2, -2, -1, -1, 1, -1, -1, -1], targets=["é", "e"])
+case("cpp_endswith", "cpp/tests/test_find.cu:112-121", "endswith", F, [False, False, False, True, False, False], sub="E")
+case("cpp_startswith", "cpp/tests/test_find.cu:122-128", "startswith", F, [False, True, False, False, True, False], sub="t")
 
 T = ["the fox jumped over the dog", "the dog chased the cat", "the cat chased the mouse", None, "",
      "the mouse ate the cheese"]
@@ -122,6 +130,15 @@ for f in ("lower", "upper", "strip"):
 Pc = ["hello", "there", "world", "accéntéd", None, ""]
 case("py_find", "python/tests/test_compare.py:27-33", "find", Pc, [4, -1, 1, -1, None, -1], level="py",
      sub="o", start=0, end=-1)
+case("py_compare", "python/tests/test_compare.py:10-16", "compare", Pc, [-12, 0, 3, -19, None, -1], level="py", sub="there")
+case("py_find_from", "python/tests/test_compare.py:36-42", "find_from", Pc, [-1, 3, 2, -1, None, -1], level="py", sub="r", starts=None, ends=None)
+case("py_rfind", "python/tests/test_compare.py:45-51", "rfind", Pc, [-1, -1, 4, 7, None, -1], level="py", sub="d", start=0, end=-1)
+case("py_find_multiple", "python/tests/test_compare.py:54-67", "find_multiple", Pc,
+     [[1, 4, -1], [2, -1, -1], [-1, 1, 4], [-1, -1, 7], [None, None, None], [-1, -1, -1]], level="py", targets=["e", "o", "d"])
+case("py_startswith", "python/tests/test_compare.py:70-76", "startswith", Pc, [True, False, False, False, None, False], level="py", sub="he")
+case("py_endswith", "python/tests/test_compare.py:79-85", "endswith", Pc, [False, False, True, True, None, False], level="py", sub="d")
+case("py_match_strings", "python/tests/test_compare.py:95-102", "match_strings", ["hello", "here", None, "accéntéd", None, ""],
+     [True, False, False, True, True, True], level="py", other=["hello", "there", "world", "accéntéd", None, ""])
 case("py_match", "python/tests/test_compare.py:88-92", "match", ["tempo", "there", "this", "ether", None, ""],
      [False, True, True, False, None, False], level="py", pat="th")
 case("py_contains", "python/tests/test_compare.py:123-129", "contains",
