@@ -894,7 +894,15 @@ __global__ void __launch_bounds__(kEmit3Threads, CS_EMIT3_WAVES) k_split_emit4(E
 #pragma unroll
   for (int j = 0; j < cstile::kPfChunks; ++j) pf.v[j] = make_uint4(0, 0, 0, 0);
   cstile::issue_chars(in.chars, cstile::rl64(cur.o0, 0), cstile::rl64(cur.o1, 63), lane, pf);
+#if defined(CS_PHASE_PROF)
+  unsigned long long phase_acc[6] = {0, 0, 0, 0, 0, 0};
+  unsigned long long phase_t = __builtin_readcyclecounter();
+#endif
   for (;;) {
+#if defined(CS_PHASE_PROF)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (measurement: what the staging below would wait for -- the flush stores)
+    CS_PHASE_MARK(5);
+#endif
     const long long r0 = tile * 64;
     const int nrows = (int)min(64ll, in.rows - r0);
     const long long g0 = cstile::rl64(cur.o0, 0), g1 = cstile::rl64(cur.o1, 63);
@@ -911,6 +919,7 @@ __global__ void __launch_bounds__(kEmit3Threads, CS_EMIT3_WAVES) k_split_emit4(E
       cstile::issue_chars(in.chars, cstile::rl64(cur.o0, 0), cstile::rl64(cur.o1, 63), lane, pf);
     }
     cstile::wave_lds_fence();
+    CS_PHASE_MARK(0);
 
     TokensT<true, WS, MULTI> tk(lds_in, lead + rbeg, n, live, a.dpat, a.tokens, a.d64, a.dlen, a.reverse != 0);
     uint32_t m0 = 0, m1 = 0, m2 = 0;
@@ -969,6 +978,7 @@ __global__ void __launch_bounds__(kEmit3Threads, CS_EMIT3_WAVES) k_split_emit4(E
     auto off_base = [&](uint32_t lo, uint32_t hi) -> off_t* {
       return reinterpret_cast<off_t*>((((unsigned long long)hi << 32) | lo) + (unsigned long long)r0 * sizeof(off_t));
     };
+    CS_PHASE_MARK(1);
     // ---- pairs of columns
     for (; k + 1 < (EXP(8) ? 0 : ncols); k += 2) {
       int loA = 0, hiA = 0, loB = 0, hiB = 0;
@@ -1037,6 +1047,7 @@ __global__ void __launch_bounds__(kEmit3Threads, CS_EMIT3_WAVES) k_split_emit4(E
       const off_t base = OFF32 ? (off_t)rl((int)c_pos, k) : (off_t)cstile::rl64(c_pos, k);
       store_off(off_base((uint32_t)rl((int)coff_lo, k), (uint32_t)rl((int)coff_hi, k)), rowoff, base);
     }
+    CS_PHASE_MARK(2);
     // ---- per column, the columns in the lanes
     const int t_sum = (int)(t_pack & 0xffffu), t_rg = (int)(t_pack >> 16);
     const bool act = lane < ncols && t_sum > 0 && !EXP(64);
@@ -1069,7 +1080,11 @@ __global__ void __launch_bounds__(kEmit3Threads, CS_EMIT3_WAVES) k_split_emit4(E
       if (lane < 16) f_pfx[lane] = (uint32_t)(inc - cnt);
     }
     cstile::wave_lds_fence();
+    CS_PHASE_MARK(3);
     // ---- the flush pass: every 16-byte chunk of the out tile below rg
+    // (moving this pass behind the NEXT sub-tile's staging -- tables out of the in tile, entries in registers -- so that the
+    // staging does not wait for these stores was built and measured: the 2 k cycles a wave waits there moved into the pass
+    // itself, 5.3-5.5 ms either way; profiles/r04)
     const int nchunks = EXP(32) ? 0 : rg >> 4;
     for (int c = lane; c < nchunks; c += 64) {
       const uint32_t word = f_bits[c >> 5];
@@ -1091,6 +1106,7 @@ __global__ void __launch_bounds__(kEmit3Threads, CS_EMIT3_WAVES) k_split_emit4(E
         }
       }
     }
+    CS_PHASE_MARK(4);
     if (act && nwhole > 0) c_head = 0;  // (the column's first whole chunk of the run has left)
     if (lane < ncols) {
       unsigned long long vm = ((unsigned long long)vm_hi << 32) | vm_lo;
@@ -1102,6 +1118,10 @@ __global__ void __launch_bounds__(kEmit3Threads, CS_EMIT3_WAVES) k_split_emit4(E
     nxt = nn;
     cstile::wave_lds_fence();  // (the tables in the in tile are read; the next sub-tile may be staged over them)
   }
+#if defined(CS_PHASE_PROF)
+  if (lane == 0 && a.prof)
+    for (int i = 0; i < 6; ++i) atomicAdd(a.prof + i, phase_acc[i]);
+#endif
   // ---- the run's last bytes of every column: what is still carried goes out bytewise
   if (lane < ncols && ((int)c_pos & 15) > c_head) {
     *reinterpret_cast<cstile::u32x4*>(lds_out + 16 * lane) = carry;
@@ -1277,7 +1297,7 @@ bool split_fast(const cs_column* col, const unsigned char* delim, int dlen, int 
         unsigned long long ph[6];
         CS_HIP(hipMemcpy(ph, e2.prof, sizeof(ph), hipMemcpyDeviceToHost));
         const double it = (double)nsub;
-        fprintf(stderr, "emit2 cycles/wave-iteration: stage %.0f masks %.0f col-walk+scan+offsets %.0f col-assemble %.0f col-flush %.0f tail %.0f | grid %u lds %zu cap_col %d\n",
+        fprintf(stderr, "emit cycles/wave-iteration (emit4: stage, masks, column loop, column lanes, flush, store drain): %.0f %.0f %.0f %.0f %.0f %.0f | grid %u lds %zu cap_col %d\n",
                 ph[0] / it, ph[1] / it, ph[2] / it, ph[3] / it, ph[4] / it, ph[5] / it, g2, lds2, cap_col);
       }
 #endif
