@@ -11,14 +11,14 @@ for what in replace split; do
 done
 cd $REPO
 python - <<'PY'
-import csv, glob, collections
+import csv, glob, collections, re
 for what in ("replace", "split"):
     for f in sorted(glob.glob("gpurun_out/pmc_sq/%s/**/*counter_collection.csv" % what, recursive=True)):
         agg = collections.defaultdict(lambda: [0.0, 0])
         for row in csv.DictReader(open(f)):
             n = row["Kernel_Name"]
-            if "replace_stream" in n or "split_emit2" in n or "split_measure" in n:
-                key = (n.split("(")[0][-28:], row["Counter_Name"])
+            if "replace_stream" in n or "split_emit" in n or "split_measure" in n:
+                key = (re.search(r"k_[a-z0-9_]+", n).group(0), row["Counter_Name"])
                 agg[key][0] += float(row["Counter_Value"]); agg[key][1] += 1
         for (k, c), (v, n) in sorted(agg.items()):
             print("%-30s %-24s %14.0f per launch" % (k, c, v / n))

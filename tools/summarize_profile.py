@@ -10,7 +10,7 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 out, tag = sys.argv[1], sys.argv[2]
-KEYS = {"k_tdfa_replace_stream": "k_replace_re", "k_tdfa_replace_tile": "k_replace_re", "k_split_emit2": "k_split_emit", "k_split_emit3": "k_split_emit",
+KEYS = {"k_tdfa_replace_stream": "k_replace_re", "k_tdfa_replace_tile": "k_replace_re", "k_split_emit2": "k_split_emit", "k_split_emit3": "k_split_emit", "k_split_emit4": "k_split_emit", "k_split_emit5": "k_split_emit",
         "k_split_emit(": "k_split_emit", "k_split_measure": "k_split_measure"}
 
 
