@@ -142,6 +142,7 @@ _PROTOS = {
     "cs_prof_enable": (i32, [i32]),
     "cs_prof_get": (i32, [cp, P(C.c_double), P(i64)]),
     "cs_debug_spin": (i32, [i32, i32, i32, vp]),
+    "cs_stream_forget": (i32, [vp]),
 }
 for _name, (_res, _args) in _PROTOS.items():
     _fn = getattr(lib, _name)

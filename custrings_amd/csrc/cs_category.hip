@@ -123,8 +123,11 @@ constexpr int kProbeLimit = 128;  // longer probe runs mean the table is too sma
 // `dbg` (CS_CAT_DEBUG, measurement only -- wrong results): 1 skips the byte compare, 2 the table.
 __global__ void __launch_bounds__(256) k_cat_insert(ColView in, Entry* table, uint32_t mask,
                                                     int32_t* __restrict__ slot_of_row, int* __restrict__ has_null,
-                                                    int* __restrict__ overflow, int probe_limit, int dbg) {
-  int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+                                                    int* __restrict__ overflow, int probe_limit, int dbg, int64_t stride = 1, int64_t count = -1) {
+  // (`stride` / `count`: the sampling launch takes rows 0, stride, 2 stride, ... -- `count` of them -- and writes no slot ids)
+  const int64_t idx = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (idx >= (count >= 0 ? count : in.rows)) return;
+  const int64_t r = idx * stride;
   if (r >= in.rows) return;
   // a table that turned out too small: the launch is lost, the workgroups that have not begun yet leave at once
   if (__hip_atomic_load(overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 1) return;
@@ -464,7 +467,7 @@ cs_category* cs::category_build(const cs_column* col, hipStream_t s) {
   int first_log2 = 22;
   if (const char* e = getenv("CS_CAT_FIRST_LOG2")) first_log2 = std::max(4, std::min(30, atoi(e)));  // tests: force retries
   int64_t cap = std::min<int64_t>(full, getenv("CS_CAT_FULL_TABLE") && !full_out_of_range ? full : (int64_t)1 << first_log2);
-  constexpr int64_t kSampleRows = 1 << 21;  // (the first rows: they fit the small table whatever they hold)
+  constexpr int64_t kSampleRows = 1 << 21;  // (that many rows fit the small table whatever they hold)
   bool sampled = getenv("CS_CAT_NO_SAMPLE") != nullptr;
   for (;;) {
     table = dev_alloc(sizeof(Entry) * cap, s);
@@ -485,16 +488,17 @@ cs_category* cs::category_build(const cs_column* col, hipStream_t s) {
     if (cap == full || !h[1]) break;  // (room for all-distinct rows: no limit applied, nothing to retry)
     int64_t next_cap = std::min<int64_t>(full, cap * 16);
     if (!sampled && rows > kSampleRows && cap >= 2 * kSampleRows) {
-      // The small table overflowed.  How many distinct keys is this?  The share of distinct keys among the first rows
-      // bounds the column's from above (it only falls as more rows come), so the table is sized from a sample instead of
-      // growing 16-fold per lost pass over all rows (K = 0.5 N: the 64M-slot attempt ran to 90 % before it gave up).
+      // The small table overflowed.  How many distinct keys is this?  A sample of rows taken at a fixed stride across the
+      // WHOLE column (the first rows alone say nothing about a column sorted or clustered by key) gives the share of
+      // distinct keys among that many rows -- for a shuffled column an upper bound of the column's share (it only falls as
+      // more rows come), in general a heuristic: the table is sized from it instead of growing 16-fold per lost pass over
+      // all rows (K = 0.5 N: the 64M-slot attempt ran to 90 % before it gave up), and a table that still turns out too
+      // small grows as before.
       sampled = true;
-      ColView head = in;
-      head.rows = kSampleRows;
       CS_HIP(hipMemsetAsync(table->p, 0xFF, sizeof(Entry) * cap, s));
       CS_HIP(hipMemsetAsync(flags_d->p, 0, 2 * sizeof(int), s));
-      hipLaunchKernelGGL(k_cat_insert, dim3(blocks_for(kSampleRows)), dim3(kBlock), 0, s, head, ptr<Entry>(table), (uint32_t)(cap - 1),
-                         ptr<int32_t>(slot_of_row), ptr<int>(flags_d), ptr<int>(flags_d) + 1, 0x7fffffff, 0);
+      hipLaunchKernelGGL(k_cat_insert, dim3(blocks_for(kSampleRows)), dim3(kBlock), 0, s, in, ptr<Entry>(table), (uint32_t)(cap - 1),
+                         ptr<int32_t>(slot_of_row), ptr<int>(flags_d), ptr<int>(flags_d) + 1, 0x7fffffff, 0, rows / kSampleRows, kSampleRows);
       Buf occ = dev_alloc(sizeof(int32_t) * cap, s);
       hipLaunchKernelGGL(k_cat_flags, dim3(blocks_for(cap)), dim3(kBlock), 0, s, ptr<const Entry>(table), cap, ptr<int32_t>(occ));
       Buf occ_pos = dev_alloc(sizeof(int64_t) * (cap + 1), s);

@@ -149,9 +149,14 @@ Buf dev_alloc(size_t bytes, hipStream_t stream) {
     // a block last used on another stream may still be in flight there: this stream waits for the release event on the
     // device (blocks released before a second stream existed carry none: the host waits for their stream once)
     if (!released.empty()) {
+      struct BackToPool {  // (also when a wait below throws: the events are not lost)
+        std::vector<hipEvent_t>& evs;
+        ~BackToPool() {
+          std::lock_guard<std::mutex> lk(g_mu);
+          for (hipEvent_t e : evs) g_event_pool.push_back(e);
+        }
+      } back{released};
       for (hipEvent_t e : released) CS_HIP(hipStreamWaitEvent(stream, e, 0));
-      std::lock_guard<std::mutex> lk(g_mu);
-      for (hipEvent_t e : released) g_event_pool.push_back(e);
     } else if (prev != stream) {
       CS_HIP(hipStreamSynchronize(prev));
     }
@@ -1466,6 +1471,14 @@ int cs_prof_reset(void) {
 int cs_prof_enable(int on) {
   g_prof_on = on != 0;
   return CS_OK;
+}
+int cs_stream_forget(cs_stream stream) {
+  return guard([&] {
+    if (!stream) return;
+    (void)hipStreamSynchronize(S(stream));  // (what it still runs on cached blocks is done before they can be handed out again)
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_streams.erase(S(stream));
+  });
 }
 __global__ void __launch_bounds__(256) k_debug_spin(unsigned long long ticks) {
   extern __shared__ uint32_t spin_lds[];

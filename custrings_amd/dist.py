@@ -280,7 +280,19 @@ def _merge_partitioned(ops, cat, keys_col, chars, offs, has_null, group):
     gchars = torch.cat([c for c, z in zip(all_c, nk) if z]) if run else torch.empty(0, dtype=torch.uint8, device=dev)
     keys = ops.column(gchars.contiguous(), torch.cat(goffs).contiguous(), bool(sizes[0][1]) and nk[0] > 0)
     table = torch.cat([back[d].to(torch.int32) + base[d] for d in range(world)]) if K else torch.empty(0, dtype=torch.int32, device=dev)
-    last_category_exchange.update(partitioned=True, range_keys=nrange, keys_sent=K, keys_received=sum(counts), global_keys=run)
+    local_rows = cat.size()
+    exchanged = int(chars.numel()) + 4 * K + sum(int(c.numel()) for c in all_c) + 8 * sum(int(o.numel()) for o in all_o)
+    last_category_exchange.update(partitioned=True, range_keys=nrange, keys_sent=K, keys_received=sum(counts), global_keys=run,
+                                  key_bytes_gathered=exchanged, local_keys=K, local_rows=local_rows, keys_per_row=K / max(local_rows, 1),
+                                  range_share=nrange * world / max(run, 1))
+    import warnings
+
+    if run and nrange * world > 2 * run:  # (the splitters come from a fixed-size sample of every rank's keys)
+        warnings.warn("global_category: this rank's key range holds %d of %d keys (%.1f times its share): the sampled splitters "
+                      "do not balance this key distribution" % (nrange, run, nrange * world / run))
+    if local_rows and K > local_rows // 2:
+        warnings.warn("global_category: %d distinct keys in %d local rows -- the exchange of the key sets (%d bytes on this rank) is as "
+                      "large as the data; a hash-partitioned exchange of the rows would move less (SURVEY.md section 8e)" % (K, local_rows, exchanged))
     return keys, ops.remap(cat, table.contiguous())
 
 
@@ -291,6 +303,7 @@ last_category_exchange = {}
 
 def global_category(local_col, ops=None, group=None, partitioned=None):
     """Distributed NVCategory build.  `local_col` holds this rank's row range.
+    (`ops` objects other than GpuOps need `slice` / `head` / `concat_category` as well as the basics: the partitioned merge uses them.)
     Returns (keys column -- identical on all ranks, values i32 tensor for the local rows).
     `partitioned`: merge by key ranges (True), by all-gathered key sets (False), or by the ranks' key counts (None:
     partitioned from PARTITION_MIN_KEYS keys in all)."""

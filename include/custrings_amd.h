@@ -70,6 +70,10 @@ int cs_device_count(void);
  * pool and uploads the unicode tables (reference: lazy get_unicode_flags /
  * get_charcases, NVStringsImpl.cu:69-91). Idempotent. */
 int cs_init(int device);
+/* A stream the caller is about to destroy: the buffer cache stops recording release events on it (blocks released after
+ * a second stream appeared are ordered behind every stream that allocated so far; a destroyed stream is otherwise only
+ * noticed when recording on its stale handle fails, which HIP does not promise).  The null stream cannot be forgotten. */
+int cs_stream_forget(cs_stream stream);
 /* Device the process is bound to (cs_init), or -1.  Compute calls from any host
  * thread run on it (the library re-binds the calling thread when needed). */
 int cs_current_device(void);
