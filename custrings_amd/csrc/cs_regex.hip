@@ -2546,6 +2546,7 @@ Plan plan(cs_regex* re, int64_t rows, hipStream_t s) {
 struct TileChoice {
   int R, cap;
   bool lng;
+  int64_t span;  // the largest span of R consecutive rows (cap = that plus slack, rounded up to 128)
 };
 // `small`: also tiles of eight and four rows, also for rows beyond the sliding window (replace_re: its alternative is the
 // two-pass thread-per-row kernels; the scans' row-wise kernels beat such tiles: contains_re 1.9 against 4.6 ms, findall 27
@@ -2553,19 +2554,21 @@ struct TileChoice {
 TileChoice choose_tile(const cs_column* col, hipStream_t s, bool small = false) {
   const int64_t longest = max_row_bytes(col, s);
   auto cap_of = [](int64_t span) { return (int64_t)((span + 15 + 32 + 127) & ~(int64_t)127); };
-  const int64_t cap64 = cap_of(max_span64(col, s));
+  const int64_t span64 = max_span64(col, s);
+  const int64_t cap64 = cap_of(span64);
   const bool fits64 = cap64 <= cstile::kPfBytes;
-  if (fits64 && longest + 3 <= cstd::Tdfa::kMaskBytes) return {64, (int)cap64, false};
-  if (longest > cstd::Tdfa::kLongBytes && (fits64 || !small)) return {fits64 ? 64 : 0, (int)cap64, false};  // (such tiles scan generically)
-  if (fits64) return {64, (int)cap64, true};
+  if (fits64 && longest + 3 <= cstd::Tdfa::kMaskBytes) return {64, (int)cap64, false, span64};
+  if (longest > cstd::Tdfa::kLongBytes && (fits64 || !small)) return {fits64 ? 64 : 0, (int)cap64, false, span64};  // (such tiles scan generically)
+  if (fits64) return {64, (int)cap64, true, span64};
   // (eight and four rows a tile: rows of hundreds of bytes -- few lanes of a wave hold a row then, but the rows still arrive
   // through coalesced tiles and are scanned in LDS; the thread-per-row kernels read them byte by byte from memory)
   for (int r : {32, 16, 8, 4}) {
     if (r < 16 && !small) break;
-    const int64_t c = cap_of(max_span_rows(col, r, s));
-    if (c <= cstile::kPfBytes) return {r, (int)c, true};
+    const int64_t sp = max_span_rows(col, r, s);
+    const int64_t c = cap_of(sp);
+    if (c <= cstile::kPfBytes) return {r, (int)c, true, sp};
   }
-  return {0, (int)cap64, false};
+  return {0, (int)cap64, false, span64};
 }
 
 template <int MODE>
@@ -2817,7 +2820,7 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
       constexpr int64_t kOutlierSpan = cstile::kPfBytes - 176;  // (its capacity is kPfBytes)
       if (!tc.R && tdfa && tp.d.in_lds && rb <= 16 && !cs::g_backrefs_dev && !getenv("CS_NO_OUTLIER_TILES") && max_span64(col, s) <= (16 << 20) &&
           few_spans64_over(col, kOutlierSpan, s)) {
-        tc = TileChoice{64, (int)((kOutlierSpan + 15 + 32 + 127) & ~(int64_t)127), false};
+        tc = TileChoice{64, (int)((kOutlierSpan + 15 + 32 + 127) & ~(int64_t)127), false, kOutlierSpan};
         outliers = true;
       }
       const int cap = tc.cap;
@@ -2828,6 +2831,9 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
       auto stream_attempt = [&](bool roomy) -> int {
         const int64_t few = (int64_t)rows * kMaxRec * growth;  // extra bytes if no row has more than kMaxRec matches
         int cap_out = cap + ((64 * kMaxRec * growth + 127) & ~127);
+        // (no growth: the out tile holds at most the in tile's span -- rounded up to 16, not to the in tile's 128: a form of
+        // 54 496 bytes of LDS ran two workgroups per CU where 54 240 run three)
+        if (growth == 0 && !outliers) cap_out = (int)std::min<int64_t>(cap, (tc.span + 15 + 32 + 15) & ~(int64_t)15);
         int64_t extra = std::min<int64_t>(few, col->nbytes + (1ll << 30));
         if (roomy) {
           const int64_t worst = ((int64_t)cap * rb + minlen_p - 1) / minlen_p;
