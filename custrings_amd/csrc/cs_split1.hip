@@ -8,19 +8,23 @@
 //     a chars buffer per column of (estimate + 8 sigma): the only thing the numbers are used for.  A column that
 //     outgrows its buffer, a row with more tokens than `ncap` columns, a column beyond 2 GiB or a wait without progress
 //     raise the error word, and the host repeats the call on the two-pass kernels (counted: cs_fallback_count).
-//   * k_split_emit5: persistent waves take sub-tiles (64 rows) round-robin.  A sub-tile's column loop is emit4's --
-//     token walk, one packed wave scan per pair of columns, the tokens OR-ed into the column's region of an LDS out
-//     tile -- but it needs no position: regions begin at 16-byte boundaries of the out tile, the rows' offsets stay
-//     RELATIVE to the sub-tile (two 16-bit values a register, a register per pair of columns).  The sub-tile's bytes
-//     per column are published (two columns a word), one SCANNER wave per pair of columns turns the published
-//     aggregates into exclusive prefixes in tile order (tile_utils.h: the replace kernel's scheme), and the sub-tile
-//     is FINISHED one iteration later, after the next sub-tile has been staged and its delimiter masks built: prefix
-//     + relative offsets -> the offsets stores, the regions -> the columns' chars with 16-byte stores at whatever
-//     alignment the position has (a region's last bytes: 8 / 4 / 2 / 1-byte stores from the column's lane).
+//   * k_split_emit5: persistent waves (CU-sized workgroups) take sub-tiles (64 rows) in a static round-robin sequence.
+//     A sub-tile's walk + scan is emit4's -- token walk, one packed wave scan per pair of columns -- but it needs no
+//     position: the rows' offsets stay RELATIVE to the sub-tile (two 16-bit values a register, a register per pair of
+//     columns), the token starts / lengths stay in registers too, and the sub-tile's bytes per column are PUBLISHED at
+//     once (two columns a word).  Scanner waves (a pair of columns each, four helper waves a pair handing the running
+//     sums on through an LDS ring, on CUs of their own) turn the published words into exclusive prefixes in tile order.
+//     Behind the publish the PREVIOUS sub-tile is finished -- prefix + relative offsets -> the offsets stores, its
+//     regions of the LDS out tile -> the columns' chars with 16-byte stores at whatever alignment the position has (a
+//     region's last bytes: 8 / 4 / 2 / 1-byte stores from the column's lane) -- and then this sub-tile's tokens are
+//     OR-ed into their regions, which begin at 16-byte boundaries of the out tile: a sub-tile has a whole iteration
+//     between its publish and the moment its prefix is needed.
 //   * the column count is a running maximum (one word, atomicMax): a sub-tile writes offsets and validity for the
 //     columns known when it ran and records how many those were; k_split_fixup writes the null rows of columns that
 //     appeared later (only launched when the count grew beyond what the sample saw).
 // Output identical to the two-pass kernels': int32 offsets, validity words, chars (tests/test_gpu_split_single.py).
+// Measured on the 100M-row C3 column: 8.0 ms against 6.7 for the two passes (NOTES.md, profiles/r04/single_pass_split.txt):
+// opt-in (CS_SPLIT_SINGLE=1).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -511,7 +515,7 @@ __global__ void __launch_bounds__(kThreads1) k_split_emit5(Emit5Args a) {
     const int lead = (int)((uintptr_t)(in.chars + g0) & 15);
     const int want = (int)(g1 - g0) + lead;
     cstile::stage_chars(lds_in, want, lane, pf);
-    // Everything fetched here for later -- the prefix poll, the column count, the ticket, the offsets two tiles ahead -- is
+    // Everything fetched here for later -- the prefix poll, the column count, the offsets two tiles ahead -- is
     // assigned unconditionally (clamped addresses) and handed to its loop-carried variable at the bottom of the iteration
     // (cs_regex.hip: a conditional assignment of a value in flight makes the compiler wait for it at the join).
     const u64 p_first = cstile::status_load(my_excl + (p_tile >= 0 ? p_tile : 0));
