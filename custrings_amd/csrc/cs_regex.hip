@@ -790,6 +790,14 @@ __global__ void k_findall_spans(RowSrc src, Launch L, int ncols, int32_t* __rest
 // than the shortest possible match): the output buffer is allocated at the input
 // size, every input byte is read once, the automaton runs once per row, and
 // offsets come from a look-back scan inside the same kernel.
+// CS_TILE_DEBUG (measurement switches of the stream kernels: phases skipped, other tile sequences, the decoupled look-back
+// instead of the scanner team) exists in profiling builds only (make prof): in the product kernels the switches are
+// compile-time zeros -- their cold code moved the hot loops out of the instruction cache (replace_re 5.4 -> 4.9 ms).
+#if defined(CS_PHASE_PROF)
+#define CS_DBG(a) ((a).debug)
+#else
+#define CS_DBG(a) 0
+#endif
 struct TileArgs {
   ColView in;
   const uint8_t* flags;
@@ -851,7 +859,7 @@ __global__ void __launch_bounds__(256) k_tdfa_replace_tile(TileArgs a) {
   const int n = live ? (int)(o1 - o0) : 0;
   bool bad = (g1 - g0) + 16 > a.cap_in;
   int lead = 0;
-  if (!bad && !(a.debug & 16)) {
+  if (!bad && !(CS_DBG(a) & 16)) {
     lead = (int)((uintptr_t)(in.chars + g0) & 15);
     const uint8_t* src = in.chars + (g0 - lead);  // 16-byte aligned
     const int span = (int)(g1 - g0) + lead;
@@ -866,7 +874,7 @@ __global__ void __launch_bounds__(256) k_tdfa_replace_tile(TileArgs a) {
   int nm = 0;
   int out_len = 0;
   if (live && !bad) {
-    if (a.debug & 1) {
+    if (CS_DBG(a) & 1) {
       out_len = n;
     } else {
       cstd::Tdfa vm(D, P, lds_in + lead + rbeg, n, (lead + rbeg) & 3);
@@ -888,7 +896,7 @@ __global__ void __launch_bounds__(256) k_tdfa_replace_tile(TileArgs a) {
   const int lo = incl - out_len;
   const int total = __builtin_amdgcn_readlane(incl, 63);
   bad |= total + 32 > a.cap_out;
-  long long gb = (a.debug & 8) ? sub * 4096 : cstile::lookback(a.status, 1, sub, total);
+  long long gb = (CS_DBG(a) & 8) ? sub * 4096 : cstile::lookback(a.status, 1, sub, total);
   if (gb < 0) {
     bad = true;
     gb = 0;
@@ -901,7 +909,7 @@ __global__ void __launch_bounds__(256) k_tdfa_replace_tile(TileArgs a) {
   if (lane == nrows - 1 && r0 + nrows == in.rows) a.out_off[in.rows] = gb + lo + out_len;
   uint8_t* gdst = a.out_chars + gb;
   const int olead = (int)((uintptr_t)gdst & 15);
-  if (live && !(a.debug & 2)) {
+  if (live && !(CS_DBG(a) & 2)) {
     int oi = olead + lo;         // byte index into lds_out
     const int pi = lead + rbeg;  // byte index of the row in lds_in
     int copied = 0;
@@ -916,7 +924,7 @@ __global__ void __launch_bounds__(256) k_tdfa_replace_tile(TileArgs a) {
       }
     cstile::lds_copy(lds_out, oi, lds_in, pi + copied, n - copied);
   }
-  if (!(a.debug & 4)) {
+  if (!(CS_DBG(a) & 4)) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -1181,13 +1189,13 @@ __global__ void __launch_bounds__(256, BREFS ? 2 : CS_STREAM_WAVES) k_tdfa_repla
   // ticket of the tile after next is in flight while the current tile is processed.
   const long long K = gridDim.x >= 16 ? 8 : 1;  // (every class needs a workgroup that takes tiles: workgroup 0 may be the scanners')
   const long long key = (long long)blockIdx.x % K;
-  const bool fixed = (a.debug & (256 | 16384)) != 0;  // measurement: the static round-robin
+  const bool fixed = (CS_DBG(a) & (256 | 16384)) != 0;  // measurement: the static round-robin
   // Workgroup 0 takes no tiles: its four waves turn the aggregates the other waves publish into each tile's exclusive
   // prefix, in order (a tile then needs ONE load instead of a walk over its predecessors' words): tile_utils.h,
   // prefix_scanner_team.  (debug 512: the decoupled look-back, for comparison; debug 1024: the single scanner wave.)
-  const bool fixed_team = (a.debug & 16384) != 0 && gridDim.x > 1;  // measurement: the static round-robin with the scanner team
-  const bool team = (fixed_team || !fixed) && !(a.debug & (512 | 1024)) && gridDim.x > 1;
-  const bool scanner = team || (!fixed && !(a.debug & 512) && a.cap_in + a.cap_out + 32 >= cstile::kScanBatch * 512);
+  const bool fixed_team = (CS_DBG(a) & 16384) != 0 && gridDim.x > 1;  // measurement: the static round-robin with the scanner team
+  const bool team = (fixed_team || !fixed) && !(CS_DBG(a) & (512 | 1024)) && gridDim.x > 1;
+  const bool scanner = team || (!fixed && !(CS_DBG(a) & 512) && a.cap_in + a.cap_out + 32 >= cstile::kScanBatch * 512);
   if (team && blockIdx.x == 0) {
     cstile::TeamRing* ring = reinterpret_cast<cstile::TeamRing*>(lds_in - (size_t)wv * (a.cap_in + a.cap_out + 64 + bm_bytes + unit_bytes));
     if (threadIdx.x < 8) cstile::team_ring_init(ring, threadIdx.x);
@@ -1221,8 +1229,7 @@ __global__ void __launch_bounds__(256, BREFS ? 2 : CS_STREAM_WAVES) k_tdfa_repla
     // A wave's first three tickets are drawn ONE AT A TIME, each after the one before has arrived (the tile number is
     // read out of it) and the first tile's loads have been issued: drawn back to back they are consecutive numbers, a wave's
     // second and third tile then lie in front of its neighbour's first, whose prefix has to wait for them -- a dependency
-    // chain through every wave of the class (the kernel ran 18.6 ms instead of 5.5 once the scanner team stopped hiding
-    // it).  A round trip apart they land among the other waves' tickets of the same round, as in the steady state (one
+    // chain through every wave of the class.  A round trip apart they land among the other waves' tickets of the same round, as in the steady state (one
     // ticket a wave and iteration).  Nothing here counts waves: workgroups that are not resident draw nothing.
     const unsigned long long q0 = take();
     tile = tile_of(q0);
@@ -1262,22 +1269,24 @@ __global__ void __launch_bounds__(256, BREFS ? 2 : CS_STREAM_WAVES) k_tdfa_repla
   auto finish_pending = [&](cstile::u64 first) {
     long long gb;
     if (lane == 0) CS_TILE_TRACE(p_tile, 2);
-    if (a.debug & 128) {  // measurement only: one late poll, no chase for an inclusive prefix
+    if (CS_DBG(a) & 128) {  // measurement only: one late poll, no chase for an inclusive prefix
       const cstile::u64 v = cstile::lookback_poll(a.status, p_tile, lane);
       const int part = (int)(unsigned)(v & 0xffffffffull);
       gb = p_tile * 4096 + (csdev::wave_reduce_sum(part) & 0) + (long long)(first & 0);
       if (lane == 0) cstile::status_store(a.status + p_tile, cstile::kFlagInc | 1);
-    } else if (scanner) {
-      gb = (a.debug & 8) ? p_tile * 4096 : cstile::prefix_wait(a.excl, p_tile, first, a.error, lane);
+    } else if (__builtin_expect(scanner, 1)) {
+      gb = (CS_DBG(a) & 8) ? p_tile * 4096 : cstile::prefix_wait(a.excl, p_tile, first, a.error, lane);
     } else {
 #if defined(CS_PHASE_PROF)
-      gb = (a.debug & 8) ? p_tile * 4096 : cstile::lookback_end(a.status, p_tile, p_total, first, lane, lb_acc);
+      gb = (CS_DBG(a) & 8) ? p_tile * 4096 : cstile::lookback_end(a.status, p_tile, p_total, first, lane, lb_acc);
 #else
-      gb = (a.debug & 8) ? p_tile * 4096 : cstile::lookback_end(a.status, p_tile, p_total, first, lane);
+      gb = (CS_DBG(a) & 8) ? p_tile * 4096 : cstile::lookback_end(a.status, p_tile, p_total, first, lane);
 #endif
     }
     if (gb < 0) {
-      if (lane == 0 && (a.debug & 2048)) printf("no prefix: tile %lld (wave %d of block %d, current tile %lld) error %u\n", p_tile, wv, (int)blockIdx.x, tile, *a.error);
+#if defined(CS_PHASE_PROF)  // (a device printf costs every variant of this kernel thousands of instructions: profiling builds only)
+      if (lane == 0 && (CS_DBG(a) & 2048)) printf("no prefix: tile %lld (wave %d of block %d, current tile %lld) error %u\n", p_tile, wv, (int)blockIdx.x, tile, *a.error);
+#endif
       if (lane == 0) atomicOr(a.error, 1u | 8u);  // (8: no prefix for the tile)
       gb = 0;
     }
@@ -1291,7 +1300,7 @@ __global__ void __launch_bounds__(256, BREFS ? 2 : CS_STREAM_WAVES) k_tdfa_repla
       if (lane == 0) atomicOr(a.error, 2u);
       return;
     }
-    if (!(a.debug & 4)) cstile::wave_flush_shift(a.out_chars + gb, p_total, lds_out, lane);
+    if (!(CS_DBG(a) & 4)) cstile::wave_flush_shift(a.out_chars + gb, p_total, lds_out, lane);
   };
   for (;;) {
     const long long r0 = tile * R;
@@ -1316,7 +1325,7 @@ __global__ void __launch_bounds__(256, BREFS ? 2 : CS_STREAM_WAVES) k_tdfa_repla
     for (int j = 0; j < PF; ++j)
       if (j * 1024 + lane * 16 < (int)want) {
         uint4 q = pf.v[j];
-        if (tile + 1 == a.nsub && j * 1024 + lane * 16 + 16 > (int)want) {
+        if (__builtin_expect(tile + 1 == a.nsub && j * 1024 + lane * 16 + 16 > (int)want, 0)) {
           // the column's last piece: what lies behind its last byte is allocation slack, not data (zeros there made the
           // last sub-tile look as if it held NUL bytes and sent it to the generic scan)
           const int keep = (int)want - (j * 1024 + lane * 16);  // 1..15 bytes of data
@@ -1353,7 +1362,7 @@ __global__ void __launch_bounds__(256, BREFS ? 2 : CS_STREAM_WAVES) k_tdfa_repla
     bool has_second = false;
     {
       const long long pt = p_tile >= 0 ? p_tile : 0;
-      p_first = scanner ? cstile::status_load(a.excl + pt) : cstile::lookback_poll(a.status, pt, lane);
+      p_first = __builtin_expect(scanner, 1) ? cstile::status_load(a.excl + pt) : cstile::lookback_poll(a.status, pt, lane);
     }
     // keep the memory pipe busy: next sub-tile's chars, and the offsets of the one after
     const bool has_next = t_nxt < a.nsub;
@@ -1382,7 +1391,7 @@ __global__ void __launch_bounds__(256, BREFS ? 2 : CS_STREAM_WAVES) k_tdfa_repla
       else vg.template scan<cstd::Tdfa::K_REPLACE>(a.maxrepl, add, 0, 0);
       out_len = len;
     }
-    if (!bad && !(a.debug & 1)) {
+    if (!bad && !(CS_DBG(a) & 1)) {
       cstd::Tdfa vm(D, P, lds_in + lead + rbeg, n, (lead + rbeg) & 3);
       const int pi = lead + rbeg;          // byte index of the row in lds_in
       int wr = 0, copied = 0, pend = -1;   // INPLACE: write cursor, input consumed, replacement not yet written
@@ -1430,9 +1439,9 @@ __global__ void __launch_bounds__(256, BREFS ? 2 : CS_STREAM_WAVES) k_tdfa_repla
       const bool has_odd = __any((odd & 0x80808080u) != 0);
       // (a sub-tile with bytes >= 0x80, a pattern they can only kill: the UNIT route alone -- reclassify_high)
       bool hi_units = false;
-      if (!CHAIN && UNITS && !BREFS && has_odd && a.litn == 0 && ((D.units >> 17) & 3u) && (D.units & 1u) && a.maxrepl < 0 && !(a.debug & 4096))
+      if (!CHAIN && UNITS && !BREFS && has_odd && a.litn == 0 && ((D.units >> 17) & 3u) && (D.units & 1u) && a.maxrepl < 0 && !(CS_DBG(a) & 4096))
         hi_units = !reclassify_high(D, has_r2, lds_in, (int)want, lane, bitmap, a.flags, lds_in + lead + rbeg, n);
-      const bool lean = D.nskip > 0 && D.img[12] <= 4 && !(a.debug & 32) && (!has_odd || hi_units) &&
+      const bool lean = D.nskip > 0 && D.img[12] <= 4 && !(CS_DBG(a) & 32) && (!has_odd || hi_units) &&
                         !__any(live && (LONG ? n > cstd::Tdfa::kLongBytes : !vm.masks_fit()));
       bool redo = live && !lean && a.maxrepl != 0;
       int resume = 0;
@@ -1496,7 +1505,7 @@ __global__ void __launch_bounds__(256, BREFS ? 2 : CS_STREAM_WAVES) k_tdfa_repla
           units_done = true;
         }
       } else if (UNITS) {
-        if (!BREFS && lean && !has_odd && a.maxrepl < 0 && (D.chain >> 16) && !(a.debug & 8192)) {  // (wave-uniform)
+        if (!BREFS && lean && !has_odd && a.maxrepl < 0 && (D.chain >> 16) && !(CS_DBG(a) & 8192)) {  // (wave-uniform)
           // A chain pattern (regex_tdfa.h: chain_match) on a sub-tile of plain ASCII: every row lane derives its row's
           // matches from the row's candidate and x bits by integer arithmetic -- no unit queue, no table walk, no LDS
           // traffic beyond the two mask reads.
@@ -1514,7 +1523,7 @@ __global__ void __launch_bounds__(256, BREFS ? 2 : CS_STREAM_WAVES) k_tdfa_repla
           }
           redo = false;
           units_done = true;
-        } else if (BREFS && lean && !has_odd && a.maxrepl < 0 && (D.chain >> 16) && (((uint32_t)D.img[30] >> 20) & 1u) && !(a.debug & 8192)) {  // (wave-uniform)
+        } else if (BREFS && lean && !has_odd && a.maxrepl < 0 && (D.chain >> 16) && (((uint32_t)D.img[30] >> 20) & 1u) && !(CS_DBG(a) & 8192)) {  // (wave-uniform)
           // replace_with_backrefs on a chain pattern: the matches by chain_match, and every capture group is a run of
           // items, so its range follows from the item boundaries of the match -- a walk over the row's two masks per
           // match where the automaton needed an anchored group run (half the kernel's time).
@@ -1594,7 +1603,7 @@ __global__ void __launch_bounds__(256, BREFS ? 2 : CS_STREAM_WAVES) k_tdfa_repla
           }
           redo = false;
           units_done = true;
-        } else if (!CHAIN && lean && a.maxrepl < 0 && (D.units & 1u) && !(a.debug & 1024)) {  // (wave-uniform)
+        } else if (!CHAIN && lean && a.maxrepl < 0 && (D.units & 1u) && !(CS_DBG(a) & 1024)) {  // (wave-uniform)
           using namespace cstd;
           // -- row lanes: the row's units from its candidate and x bits
           uint32_t m0, m1, m2;
@@ -1733,7 +1742,7 @@ __global__ void __launch_bounds__(256, BREFS ? 2 : CS_STREAM_WAVES) k_tdfa_repla
       }
       if (hi_units && !units_done) redo = live;  // (more units than the queue holds: the generic scan, never the lean scan on such bytes)
       if (CHAIN && !units_done) redo = live && a.maxrepl != 0;  // (the generic scan)
-      if (!CHAIN && UNITS && !BREFS && !units_done && lean && !hi_units && a.maxrepl < 0 && D.img[13] >= 1 && !(a.debug & 2048)) {  // (wave-uniform)
+      if (!CHAIN && UNITS && !BREFS && !units_done && lean && !hi_units && a.maxrepl < 0 && D.img[13] >= 1 && !(CS_DBG(a) & 2048)) {  // (wave-uniform)
         // A sub-tile the unit route did not take (more units than the queue holds: patterns whose candidate bytes are
         // everywhere, such as alternations of word-bounded literals; or no decomposition at all): every row lane scans its
         // own row, but the matches still go into the two bitmaps -- a start bit and a last-byte bit each, as the unit lanes
@@ -1791,7 +1800,7 @@ __global__ void __launch_bounds__(256, BREFS ? 2 : CS_STREAM_WAVES) k_tdfa_repla
         redo = bail;
         resume = vm.lean_resume_from;
       }
-      if (__any(redo)) {
+      if (__builtin_expect(__any(redo), 0)) {
         // rows the lean scan handed over continue with the generic scan in the round they stopped in
         // (the matches reported so far are final)
         if (redo) {
@@ -1821,7 +1830,7 @@ __global__ void __launch_bounds__(256, BREFS ? 2 : CS_STREAM_WAVES) k_tdfa_repla
       if (p_tile >= 0) finish_pending(p_first);
       p_tile = -1;
       // this sub-tile is finished at once: its prefix, the offsets, every row written by its lane
-      long long gb = scanner ? cstile::prefix_wait(a.excl, tile, cstile::status_load(a.excl + tile), a.error, lane)
+      long long gb = __builtin_expect(scanner, 1) ? cstile::prefix_wait(a.excl, tile, cstile::status_load(a.excl + tile), a.error, lane)
                              : cstile::lookback_end(a.status, tile, total, cstile::lookback_poll(a.status, tile, lane), lane);
       if (gb < 0) {
         if (lane == 0) atomicOr(a.error, 1u | 8u);
@@ -1848,7 +1857,7 @@ __global__ void __launch_bounds__(256, BREFS ? 2 : CS_STREAM_WAVES) k_tdfa_repla
         else vg.template scan<cstd::Tdfa::K_REPLACE>(a.maxrepl, piece, 0, 0);
         for (int i = copied; i < n; ++i) *o++ = p[i];
       }
-    } else if (bad) {
+    } else if (__builtin_expect(bad, 0)) {
       // the host discards this launch's output; publish something so successors do not spin
       if (lane == 0) {
         atomicOr(a.error, !INPLACE && grew ? 2u : (1u | 4u));  // (4: a sub-tile beyond the staging capacity)
@@ -1857,16 +1866,16 @@ __global__ void __launch_bounds__(256, BREFS ? 2 : CS_STREAM_WAVES) k_tdfa_repla
       if (p_tile >= 0) finish_pending(p_first);
       p_tile = -1;
     } else {
-      if (!(a.debug & 8)) cstile::lookback_publish(a.status, tile, total, lane);
+      if (!(CS_DBG(a) & 8)) cstile::lookback_publish(a.status, tile, total, lane);
       if (lane == 0) CS_TILE_TRACE(tile, 0);
       CS_PHASE_MARK(2);
       if (p_tile >= 0)
-        finish_pending((a.debug & 64) ? (scanner ? cstile::status_load(a.excl + p_tile) : cstile::lookback_poll(a.status, p_tile, lane))
+        finish_pending((CS_DBG(a) & 64) ? (__builtin_expect(scanner, 1) ? cstile::status_load(a.excl + p_tile) : cstile::lookback_poll(a.status, p_tile, lane))
                                       : (has_second && (p_first >> 62) == 0 ? p_second : p_first));
       CS_PHASE_MARK(3);
       if (INPLACE) {
-        if (live && !(a.debug & 2)) cstile::lds_copy(lds_out, lo, lds_in, lead + rbeg, out_len);
-      } else if (live && !(a.debug & 2)) {
+        if (live && !(CS_DBG(a) & 2)) cstile::lds_copy_ov(lds_out, lo, lds_in, lead + rbeg, out_len);
+      } else if (live && !(CS_DBG(a) & 2)) {
         int oi = lo;                 // byte index into lds_out
         const int pi = lead + rbeg;  // byte index of the row in lds_in
         int copied = 0;
@@ -1877,7 +1886,7 @@ __global__ void __launch_bounds__(256, BREFS ? 2 : CS_STREAM_WAVES) k_tdfa_repla
             const int mb = cstd::u128_ctz(uS), me = cstd::u128_ctz(uE) + 1;
             uS = cstd::u128_clear_lowest(uS);
             uE = cstd::u128_clear_lowest(uE);
-            cstile::lds_copy(lds_out, oi, lds_in, pi + copied, mb - copied);
+            cstile::lds_copy_ov(lds_out, oi, lds_in, pi + copied, mb - copied);
             oi += mb - copied;
             int gb[cstd::Tdfa::kGroupBatch], ge[cstd::Tdfa::kGroupBatch], mend = me;
             bool ok;
@@ -1892,7 +1901,7 @@ __global__ void __launch_bounds__(256, BREFS ? 2 : CS_STREAM_WAVES) k_tdfa_repla
             }
             int il = 0;
             for (int j = 0; j < T.nrefs; ++j) {
-              cstile::lds_copy(lds_out, oi, ttext, il, T.pos[j] - il);
+              cstile::lds_copy_ov(lds_out, oi, ttext, il, T.pos[j] - il);
               oi += T.pos[j] - il;
               il = T.pos[j];
               const int g = T.idx[j];
@@ -1908,11 +1917,11 @@ __global__ void __launch_bounds__(256, BREFS ? 2 : CS_STREAM_WAVES) k_tdfa_repla
                   y = ge[q];
                 }
               if (ok && x >= 0 && y > x) {
-                cstile::lds_copy(lds_out, oi, lds_in, pi + x, y - x);
+                cstile::lds_copy_ov(lds_out, oi, lds_in, pi + x, y - x);
                 oi += y - x;
               }
             }
-            cstile::lds_copy(lds_out, oi, ttext, il, T.bytes - il);
+            cstile::lds_copy_ov(lds_out, oi, ttext, il, T.bytes - il);
             oi += T.bytes - il;
             copied = me;
             ++mi;
@@ -1922,7 +1931,7 @@ __global__ void __launch_bounds__(256, BREFS ? 2 : CS_STREAM_WAVES) k_tdfa_repla
             const int mb = cstd::u128_ctz(uS), me = cstd::u128_ctz(uE) + 1;
             uS = cstd::u128_clear_lowest(uS);
             uE = cstd::u128_clear_lowest(uE);
-            cstile::lds_copy(lds_out, oi, lds_in, pi + copied, mb - copied);
+            cstile::lds_copy_ov(lds_out, oi, lds_in, pi + copied, mb - copied);
             oi += mb - copied;
             if (REP16) {
               if (rb > 16) {
@@ -1942,7 +1951,7 @@ __global__ void __launch_bounds__(256, BREFS ? 2 : CS_STREAM_WAVES) k_tdfa_repla
 #pragma unroll
           for (int j = 0; j < kMaxRec; ++j)
             if (j < nm) {
-              cstile::lds_copy(lds_out, oi, lds_in, pi + copied, rec_mb[j] - copied);
+              cstile::lds_copy_ov(lds_out, oi, lds_in, pi + copied, rec_mb[j] - copied);
               oi += rec_mb[j] - copied;
               for (int k = 0; k < rec_reps[j]; ++k) {
                 if (REP16) {
@@ -1960,11 +1969,11 @@ __global__ void __launch_bounds__(256, BREFS ? 2 : CS_STREAM_WAVES) k_tdfa_repla
               }
               copied = rec_me[j];
             }
-        } else if (nm > 0) {
+        } else if (__builtin_expect(nm > 0, 0)) {
           // more matches than the registers keep (UNITS: any row measured by the generic scan): the row's size is
           // known from the first scan, so scan it again and assemble as the matches are reported
           auto piece2 = [&](int mb, int me, int reps) {
-            cstile::lds_copy(lds_out, oi, lds_in, pi + copied, mb - copied);
+            cstile::lds_copy_ov(lds_out, oi, lds_in, pi + copied, mb - copied);
             oi += mb - copied;
             for (int k = 0; k < reps; ++k)
               for (int i = 0; i < rb; ++i) lds_out[oi++] = a.repl[i];
@@ -1974,7 +1983,7 @@ __global__ void __launch_bounds__(256, BREFS ? 2 : CS_STREAM_WAVES) k_tdfa_repla
           if (WIDE) vm2.template scan<cstd::Tdfa::K_REPLACE, decltype(piece2)&, cstd::kMaxSlotsWide>(a.maxrepl, piece2, 0, 0);
           else vm2.template scan<cstd::Tdfa::K_REPLACE>(a.maxrepl, piece2, 0, 0);
         }
-        cstile::lds_copy(lds_out, oi, lds_in, pi + copied, n - copied);
+        cstile::lds_copy_ov(lds_out, oi, lds_in, pi + copied, n - copied);
       }
       cstile::wave_lds_fence();
       CS_PHASE_MARK(4);
@@ -1989,7 +1998,7 @@ __global__ void __launch_bounds__(256, BREFS ? 2 : CS_STREAM_WAVES) k_tdfa_repla
     nxt = nn;
     pending = pending_new;
   }
-  if (p_tile >= 0) finish_pending((a.debug & 8) ? 0 : (scanner ? cstile::status_load(a.excl + p_tile) : cstile::lookback_poll(a.status, p_tile, lane)));
+  if (p_tile >= 0) finish_pending((CS_DBG(a) & 8) ? 0 : (__builtin_expect(scanner, 1) ? cstile::status_load(a.excl + p_tile) : cstile::lookback_poll(a.status, p_tile, lane)));
 #if defined(CS_PHASE_PROF)
   CS_PHASE_MARK(5);
   if (lane == 0)

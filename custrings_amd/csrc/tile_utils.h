@@ -229,6 +229,31 @@ __device__ __forceinline__ void lds_put16(uint8_t* dp, lds_u32x4u v, int len) {
   if (len & 1) *dp = (uint8_t)t0;
 }
 
+// lds_copy for the assembly of rows out of short pieces: ONE round trip through LDS for a piece of up to 16 bytes (a
+// 16-byte read at any alignment -- it may run up to 15 bytes past the piece: the caller's source has that slack --, then
+// lds_put16's stores, none waiting for another), longer pieces in 16-byte steps with the next read in flight while
+// the previous one is stored, the last step overlapping the one before instead of a 8 / 4 / 2 / 1 ladder of dependent
+// read-store pairs.  Writes exactly n bytes.
+__device__ __forceinline__ void lds_copy_ov(uint8_t* dbase, int di, const uint8_t* sbase, int si, int n) {
+  if (n <= 0) return;
+  uint8_t* d = dbase + di;
+  const uint8_t* s = sbase + si;
+  lds_u32x4u v = *reinterpret_cast<const lds_u32x4u*>(s);
+  if (n < 16) {
+    lds_put16(d, v, n);
+    return;
+  }
+  int i = 0;
+  while (i + 16 < n) {
+    const int j = min(i + 16, n - 16);
+    const lds_u32x4u w = *reinterpret_cast<const lds_u32x4u*>(s + j);
+    *reinterpret_cast<lds_u32x4u*>(d + i) = v;
+    v = w;
+    i = j;
+  }
+  *reinterpret_cast<lds_u32x4u*>(d + i) = v;
+}
+
 // Copy of a SHORT run (tokens, replacement text): the first 8 bytes go through two
 // funnel-shifted source dwords and straight-line predicated byte stores, longer
 // runs fall back to lds_copy for the rest.
