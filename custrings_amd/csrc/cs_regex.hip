@@ -1516,7 +1516,8 @@ __global__ void __launch_bounds__(256, BREFS ? 2 : CS_STREAM_WAVES) k_tdfa_repla
           p_second = cstile::status_load(a.excl + (p_tile >= 0 ? p_tile : 0));
           has_second = scanner;
           if (live) {
-            chain_match(u128(r0 | ((unsigned long long)r1 << 32), r2), u128(x0 | ((unsigned long long)x1 << 32), x2), D.chain, uS, uE);
+            chain_match(u128(r0 | ((unsigned long long)r1 << 32), r2), u128(x0 | ((unsigned long long)x1 << 32), x2), D.chain, uS, uE, D.sfx, n,
+                        [&](int i) { return lds_in[lead + rbeg + i]; });
             nm = u128_popc(uS);
             out_len = n - u128_popc(u128_sub(u128_shl1(uE), uS)) + nm * rb;
             from_masks = true;
@@ -1530,7 +1531,6 @@ __global__ void __launch_bounds__(256, BREFS ? 2 : CS_STREAM_WAVES) k_tdfa_repla
           using namespace cstd;
           const csvm::BackrefTemplate& T = *a.tmpl;
           const uint32_t gmap = (uint32_t)D.img[D.img[15] - 1];
-          const int ni = (int)((D.chain >> 16) & 15u);
           uint32_t r0, r1, r2, x0 = 0, x1 = 0, x2 = 0;
           cstile::row_bits96(bitmap, lead + rbeg, n, r0, r1, r2);
           if (unit_x != 0) cstile::row_bits96(xbitmap, lead + rbeg, n, x0, x1, x2);
@@ -1538,7 +1538,7 @@ __global__ void __launch_bounds__(256, BREFS ? 2 : CS_STREAM_WAVES) k_tdfa_repla
           p_second = cstile::status_load(a.excl + (p_tile >= 0 ? p_tile : 0));
           has_second = scanner;
           if (live) {
-            chain_match(R, X, D.chain, uS, uE);
+            chain_match(R, X, D.chain, uS, uE, D.sfx, n, [&](int i) { return lds_in[lead + rbeg + i]; });
             nm = u128_popc(uS);
             from_masks = true;
           }
@@ -1555,26 +1555,8 @@ __global__ void __launch_bounds__(256, BREFS ? 2 : CS_STREAM_WAVES) k_tdfa_repla
               const int mb = u128_ctz(S), me = u128_ctz(E) + 1;
               S = u128_clear_lowest(S);
               E = u128_clear_lowest(E);
-              int gb[4] = {-1, -1, -1, -1}, ge[4] = {-1, -1, -1, -1};
-              int p = mb;
-#pragma unroll
-              for (int k = 0; k <= 8; ++k) {
-                if (k <= ni) {  // (wave-uniform) p = the boundary in front of item k
-#pragma unroll
-                  for (int q = 0; q < 4; ++q) {
-                    if ((int)((gmap >> (8 * q)) & 15u) == k) gb[q] = p;
-                    if ((int)((gmap >> (8 * q + 4)) & 15u) == k) ge[q] = p;
-                  }
-                }
-                if (k < ni && k < 8) {
-                  if ((D.chain >> (2 * k + 1)) & 1u) {
-                    const U128 C = ((D.chain >> (2 * k)) & 1u) ? X : R;
-                    p = u128_ctz(u128_andn(u128(~C.lo, ~C.hi), u128_below(p)));  // the first byte at or behind p off the class
-                  } else {
-                    ++p;
-                  }
-                }
-              }
+              int gb[4], ge[4];
+              chain_group_bounds(R, X, D.chain, gmap, mb, gb, ge);
               int grow = T.bytes - (me - mb);
               for (int j = 0; j < T.nrefs; ++j) {
                 const int g = T.idx[j];
@@ -2047,9 +2029,9 @@ struct ScanStreamArgs {
 // CHAIN (a UNITS form, count_re / findall): the pattern is a chain and the column's sample holds no byte >= 0x80 -- the unit
 // and lean scans are compiled out, a sub-tile the chain arithmetic does not take is scanned row by row by the generic executor.
 template <int MODE, bool IN_LDS, bool LONG = false, bool UNITS = false, bool CHAIN = false>
-__global__ void __launch_bounds__(256, CHAIN ? 4 : ((UNITS && MODE == 3) || MODE == 4) ? 3 : (UNITS || MODE == 3) ? 4 : 1) k_tdfa_scan_stream(ScanStreamArgs a) {
-  static_assert(!UNITS || ((MODE == 0 || MODE == 2 || MODE == 3) && !LONG), "unit scan: contains_re / count_re / findall on rows within the 96-byte masks");
-  static_assert(!CHAIN || (UNITS && (MODE == 2 || MODE == 3)), "the chain form: count_re / findall");
+__global__ void __launch_bounds__(256, MODE == 4 ? 3 : CHAIN ? 4 : (UNITS && MODE == 3) ? 3 : (UNITS || MODE == 3) ? 4 : 1) k_tdfa_scan_stream(ScanStreamArgs a) {
+  static_assert(!UNITS || ((MODE == 0 || MODE == 2 || MODE == 3 || (MODE == 4 && CHAIN)) && !LONG), "unit scan: contains_re / count_re / findall on rows within the 96-byte masks");
+  static_assert(!CHAIN || (UNITS && (MODE == 2 || MODE == 3 || MODE == 4)), "the chain form: count_re / findall / extract");
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   uint8_t* base = reinterpret_cast<uint8_t*>(smem);
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;  // (scalar: what derives from it stays in SGPRs)
@@ -2062,7 +2044,8 @@ __global__ void __launch_bounds__(256, CHAIN ? 4 : ((UNITS && MODE == 3) || MODE
   uint32_t* uqueue = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(xbitmap) + bm_bytes);
   uint32_t* rowres = uqueue + kUnitQueue;
   uint32_t* bailw = rowres + 64;
-  uint32_t* gtot = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(xbitmap) + cstd::Tdfa::kBackSteps * 64);  // MODE 4: per group, the tile's bytes
+  // MODE 4: per group, the tile's bytes (the chain form keeps the "equals x" bitmap where the plain form has its history bytes)
+  uint32_t* gtot = UNITS ? rowres : reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(xbitmap) + cstd::Tdfa::kBackSteps * 64);
   if (MODE == 4 && lane < kMaxGroups) gtot[lane] = 0;
   const TCtx c = tsetup<IN_LDS>(a.L, a.flags, smem);
   const cstd::View& D = c.D;
@@ -2189,6 +2172,36 @@ __global__ void __launch_bounds__(256, CHAIN ? 4 : ((UNITS && MODE == 3) || MODE
     } else if (MODE == 4) {
       cstd::Tdfa vm(D, P, lds_in + lead + rbeg, n, (lead + rbeg) & 3);
       int mb = 0, me = 0;
+      bool chain_done = false;
+      if (CHAIN) {
+        // extract on a chain pattern whose groups are runs of items (regex_tdfa.h: chain_match, chain_group_bounds) on a
+        // sub-tile of plain ASCII: the row's first match and its group ranges from the row's two masks, no table walk
+        const bool plain = D.nskip > 0 && D.img[12] <= 4 && !__any((odd & 0x80808080u) != 0) && !__any(live && !vm.masks_fit());
+        if (plain && (D.chain >> 16) && (((uint32_t)D.img[30] >> 20) & 1u) && a.ncols <= 4 && a.spans) {  // (wave-uniform)
+          using namespace cstd;
+          uint32_t r0w, r1w, r2w, x0w = 0, x1w = 0, x2w = 0;
+          cstile::row_bits96(bitmap, lead + rbeg, n, r0w, r1w, r2w);
+          if (unit_x != 0) cstile::row_bits96(xbitmap, lead + rbeg, n, x0w, x1w, x2w);
+          const U128 Rm = u128(r0w | ((unsigned long long)r1w << 32), r2w), Xm = u128(x0w | ((unsigned long long)x1w << 32), x2w);
+          U128 S = u128(0, 0), E = u128(0, 0);
+          if (live) chain_match(Rm, Xm, D.chain, S, E, D.sfx, n, [&](int i) { return lds_in[lead + rbeg + i]; });
+          const bool hit = live && u128_any(S);
+          v = hit;
+          int gb[4], ge[4];
+          chain_group_bounds(Rm, Xm, D.chain, (uint32_t)D.img[D.img[15] - 1], hit ? u128_ctz(S) : 0, gb, ge);
+          if (lane < nrows) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+              if (k < a.ncols) {
+                const bool ok = hit && gb[k] >= 0 && ge[k] > gb[k];
+                a.spans[(long long)k * in.rows + r0 + lane] = ok ? (((uint32_t)gb[k] << 16) | (uint32_t)(ge[k] - gb[k])) : 0xFFFFFFFFu;
+                if (a.tile_tot && ok) __hip_atomic_fetch_add(gtot + k, (uint32_t)(ge[k] - gb[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+              }
+          }
+          chain_done = true;
+        }
+      }
+      if (!chain_done) {
       // leftmost match: the lean scan on ASCII tiles of short rows (as contains_re), else the generic find
       const bool lean = !LONG && D.nskip > 0 && D.img[12] <= 4 && !__any((odd & 0x80808080u) != 0) && !__any(live && !vm.masks_fit());
       int f = -1;
@@ -2210,7 +2223,7 @@ __global__ void __launch_bounds__(256, CHAIN ? 4 : ((UNITS && MODE == 3) || MODE
             const int cnt = min(cstd::Tdfa::kGroupBatch, a.ncols - g0);
             // (backwards from the match where that applies -- short ASCII matches: regex_tdfa.h -- else the forward run)
             int got = -1;
-            if (hit) got = vm.group_find_back(mb, a.gtags, g0 + 1, cnt, gb, ge, mend, cstd::Tdfa::HistBytes{reinterpret_cast<uint8_t*>(xbitmap) + lane, 64});
+            if (!UNITS && hit) got = vm.group_find_back(mb, a.gtags, g0 + 1, cnt, gb, ge, mend, cstd::Tdfa::HistBytes{reinterpret_cast<uint8_t*>(xbitmap) + lane, 64});
             if (hit && got < 0) got = vm.group_find_all(mb, a.gtags, g0 + 1, cnt, gb, ge, mend);
             const bool found = hit && got > 0;
 #pragma unroll
@@ -2240,6 +2253,7 @@ __global__ void __launch_bounds__(256, CHAIN ? 4 : ((UNITS && MODE == 3) || MODE
           }
         }
       }
+      }  // (!chain_done)
       if (a.tile_tot) {  // the bytes this tile gives to each group's column (summed in LDS by the row lanes above)
         cstile::wave_lds_fence();
         if (lane < a.ncols) {
@@ -2284,7 +2298,8 @@ __global__ void __launch_bounds__(256, CHAIN ? 4 : ((UNITS && MODE == 3) || MODE
           if (unit_x != 0) cstile::row_bits96(xbitmap, lead + rbeg, n, x0, x1, x2);
           if (live) {
             U128 S, E;
-            chain_match(u128(r0 | ((unsigned long long)r1 << 32), r2), u128(x0 | ((unsigned long long)x1 << 32), x2), D.chain, S, E);
+            chain_match(u128(r0 | ((unsigned long long)r1 << 32), r2), u128(x0 | ((unsigned long long)x1 << 32), x2), D.chain, S, E, D.sfx, n,
+                        [&](int i) { return lds_in[lead + rbeg + i]; });
             while (u128_any(S)) {
               const int mb = u128_ctz(S), me = u128_ctz(E) + 1;
               S = u128_clear_lowest(S);
@@ -2353,10 +2368,10 @@ __global__ void __launch_bounds__(256, CHAIN ? 4 : ((UNITS && MODE == 3) || MODE
           if (unit_x != 0) cstile::row_bits96(xbitmap, lead + rbeg, n, x0, x1, x2);
           const U128 R = u128(r0 | ((unsigned long long)r1 << 32), r2), X = u128(x0 | ((unsigned long long)x1 << 32), x2);
           if (MODE == 0) {
-            v = live && u128_any(chain_ends(R, X, D.chain)) ? 1 : 0;
+            v = live && u128_any(chain_suffix_filter(chain_ends(R, X, D.chain), D.chain, D.sfx, n, [&](int i) { return lds_in[lead + rbeg + i]; })) ? 1 : 0;
           } else {
             U128 S = u128(0, 0), E;
-            if (live) chain_match(R, X, D.chain, S, E);
+            if (live) chain_match(R, X, D.chain, S, E, D.sfx, n, [&](int i) { return lds_in[lead + rbeg + i]; });
             v = u128_popc(S);
           }
           redo = false;
@@ -2614,7 +2629,10 @@ void scan(const cs_column* col, cs_regex* re, uint8_t* out8, int32_t* out32, int
     // lanes' scan inside it, at a few per cent more than the plain form)
     // (chain patterns -- header words 29 / 30 -- were tried on the unit form for contains_re as well: 2.18 against 2.10 ms; the
     // plain form's first-match scan stays)
-    const bool units = !wide && (MODE == 2 || (MODE == 0 && ((re->tdfa[31] >> 17) & 3) != 0 && sample_has_high_bytes(col, s))) && (re->tdfa[31] & 1) != 0 &&
+    // (a chain pattern without a unit decomposition -- one with a suffix, regex_tdfa.cpp -- takes the same kernels: their unit
+    // routes test header word 31 bit 0 themselves)
+    const bool units = !wide && (MODE == 2 || (MODE == 0 && ((re->tdfa[31] >> 17) & 3) != 0 && sample_has_high_bytes(col, s))) &&
+                       ((re->tdfa[31] & 1) != 0 || (MODE == 2 && ((re->tdfa[30] >> 16) & 15) != 0)) &&
                        !tc.lng && tc.R == 64 && !getenv("CS_NO_UNITS");
     const size_t lds = tp.lds_bytes + (size_t)(cap + 32 + (cap >> 3) + 32 + (units ? (cap >> 3) + 32 + kUnitQueue * 4 + 64 * 4 + 16 : 0)) * 4;
     if (tc.R && lds <= 150 * 1024) {
@@ -2861,11 +2879,12 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
         // replace_with_backrefs on this kernel (cs_replace_with_backrefs left its template in g_backrefs_dev): the unit
         // scan, groups carried by the DFA (four at most), tables in LDS
         const bool brefs = cs::g_backrefs_dev != nullptr;
-        if (brefs && !((re->tdfa[31] & 1) != 0 && !tc.lng && tc.R == 64 && tp.d.in_lds && !re->gtags.empty() && re->prog.num_groups <= cstd::Tdfa::kGroupBatch &&
+        if (brefs && !(((re->tdfa[31] & 1) != 0 || (((re->tdfa[30] >> 16) & 15) != 0 && ((re->tdfa[30] >> 20) & 1) != 0)) && !tc.lng && tc.R == 64 && tp.d.in_lds && !re->gtags.empty() && re->prog.num_groups <= cstd::Tdfa::kGroupBatch &&
                        re->gtags.size() * 4 <= 8 * 1024))
           return -1;
         const bool literal = !brefs && !outliers && cs::g_replace_plain_only && cs::g_replace_literal_len > 0 && maxrepl < 0 && !tc.lng && tc.R == 64 && !getenv("CS_NO_LITERAL_SCAN");
-        const bool units = literal || brefs || ((re->tdfa[31] & 1) != 0 && maxrepl < 0 && !tc.lng && tc.R == 64 && !outliers && !cs::g_replace_plain_only && !getenv("CS_NO_UNITS"));
+        const bool offers = (re->tdfa[31] & 1) != 0 || ((re->tdfa[30] >> 16) & 15) != 0;  // (units, or a chain pattern without them: one with a suffix)
+        const bool units = literal || brefs || (offers && maxrepl < 0 && !tc.lng && tc.R == 64 && !outliers && !cs::g_replace_plain_only && !getenv("CS_NO_UNITS"));
         const size_t unit_bytes = units ? (size_t)((cap >> 3) + 32 + kUnitQueue * 4 + 16 + (cs::g_backrefs_dev ? kUnitQueue * 12 + 64 * 4 : 0)) : 0;
         // (backrefs: the group tags and the template text sit behind the DFA table; the template may grow a row by any
         // amount: room for twice the input, a launch that needs more says so and the two-pass form takes over)
@@ -3239,7 +3258,12 @@ int cs_extract(const cs_column* col, const cs_regex* cre, cs_stream stream, cs_c
       const TileChoice tc = choose_tile(col, s);
       const int cap = tc.cap;
       const size_t gt_bytes = re->gtags.size() * 4 <= 16 * 1024 ? ((re->gtags.size() * 4 + 15) & ~size_t(15)) : 0;
-      const size_t lds = tp.lds_bytes + gt_bytes + (size_t)(cap + 32 + (cap >> 3) + 32 + cstd::Tdfa::kBackSteps * 64 + kMaxGroups * 4) * 4;
+      // (a chain pattern whose groups are runs of items, on a column whose sample is plain ASCII: the chain form -- the match
+      // and the group ranges by mask arithmetic; it keeps the "equals x" bitmap and the unit form's layout)
+      const bool chain_form = tp.d.in_lds && tc.R == 64 && !tc.lng && !getenv("CS_SPANS_UNPACKED") && ((re->tdfa[30] >> 16) & 15) != 0 && ((re->tdfa[30] >> 20) & 1) != 0 &&
+                              groups <= 4 && !getenv("CS_NO_CHAIN_FORM") && !sample_has_high_bytes(col, s);
+      const size_t lds = chain_form ? tp.lds_bytes + gt_bytes + (size_t)(cap + 32 + 2 * ((cap >> 3) + 32) + kUnitQueue * 4 + 64 * 4 + 16) * 4
+                                    : tp.lds_bytes + gt_bytes + (size_t)(cap + 32 + (cap >> 3) + 32 + cstd::Tdfa::kBackSteps * 64 + kMaxGroups * 4) * 4;
       if (tp.d.in_lds && tc.R && lds <= 150 * 1024) {
         packed = tc.R == 64 && !getenv("CS_SPANS_UNPACKED");
         if (packed) {
@@ -3269,6 +3293,7 @@ int cs_extract(const cs_column* col, const cs_regex* cre, cs_stream stream, cs_c
         sa.ncols = groups;
         sa.gtags = ptr<const int32_t>(re->d_gtags);
         auto kern = tc.lng ? &k_tdfa_scan_stream<4, true, true> : &k_tdfa_scan_stream<4, true, false>;
+        if (chain_form) kern = &k_tdfa_scan_stream<4, true, false, true, true>;
         if (lds > 48 * 1024)
           CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         const unsigned sgrid = resident_grid(reinterpret_cast<const void*>(kern), lds, (sa.nsub + 3) / 4);
@@ -3396,7 +3421,7 @@ int cs_findall(const cs_column* col, const cs_regex* cre, cs_stream stream, cs_c
       const TileChoice tc = choose_tile(col, s);
       const int cap = tc.cap;
       // the unit scan where the tagged DFA offers the decomposition (as count_re)
-      const bool units = (re->tdfa[31] & 1) != 0 && !tc.lng && tc.R == 64 && !getenv("CS_NO_UNITS");
+      const bool units = ((re->tdfa[31] & 1) != 0 || ((re->tdfa[30] >> 16) & 15) != 0) && !tc.lng && tc.R == 64 && !getenv("CS_NO_UNITS");
       const size_t lds = tp.lds_bytes + (size_t)(cap + 32 + (cap >> 3) + 32 + (units ? (cap >> 3) + 32 + kUnitQueue * 4 + 64 * 4 + 16 : 0)) * 4;
       if (tp.d.in_lds && tc.R && lds <= 150 * 1024) {
         Buf hits = dev_alloc(8, s);

@@ -575,8 +575,13 @@ std::vector<int32_t> build_tdfa(const Program& prog, const std::vector<int32_t>&
     // item's ASCII members are exactly the candidate ranges (class R) or exactly the byte x, neighbours differ, the first
     // is R, and the last is repeated when it is R as well.  Then a plain-ASCII row's matches follow from its two
     // per-byte masks by integer arithmetic alone.
-    if ((word & 1) && !B.use_word && !B.use_line && !getenv("CS_NO_CHAIN")) {
-      const int x = (word >> 8) & 127;
+    // A chain may end in a SUFFIX of up to four literal ASCII bytes outside R (`\d+\.\d+\.\d+\.\d+ `): the chain part's
+    // ends are then filtered by a byte compare (chain_suffix_filter).  Such a pattern usually has no unit decomposition
+    // (two non-killer bytes outside the ranges); x is then the first literal of the line that is not in R, and header word
+    // 31 carries it WITHOUT bit 0 (the kernels stage the "equals x" bitmap from it; the unit route stays off).
+    if (nskip > 0 && maxslots <= 4 && B.min_match_chars() >= 1 && !B.use_word && !B.use_line && !getenv("CS_NO_CHAIN")) {
+      int x = (word >> 8) & 127;
+      const bool x_free = !(word & 1) && !getenv("CS_NO_CHAIN_SUFFIX");  // (no unit decomposition: the chain picks its own x)
       uint32_t items = 0;
       int ni = 0;
       size_t seen = 0;
@@ -584,6 +589,8 @@ std::vector<int32_t> build_tdfa(const Program& prog, const std::vector<int32_t>&
       int pc = prog.start_inst, prev_cls = -1;
       int g_lo[5] = {-1, -1, -1, -1, -1}, g_hi[5] = {-1, -1, -1, -1, -1};  // capture groups 1..4: the items they span
       bool groups_ok = true;
+      uint32_t sfx = 0;
+      int slen = 0;
       while (ok) {
         if (pc < 0 || (size_t)pc >= prog.insts.size() || seen > prog.insts.size()) {
           ok = false;
@@ -593,7 +600,8 @@ std::vector<int32_t> build_tdfa(const Program& prog, const std::vector<int32_t>&
         ++seen;
         if (in.type == OP_END) break;
         if (in.type == OP_LBRA || in.type == OP_RBRA) {
-          if (in.u1 >= 1 && in.u1 <= 4) (in.type == OP_LBRA ? g_lo : g_hi)[in.u1] = ni;
+          if (slen > 0) groups_ok = false;  // (brackets inside the suffix: no group map)
+          else if (in.u1 >= 1 && in.u1 <= 4) (in.type == OP_LBRA ? g_lo : g_hi)[in.u1] = ni;
           else groups_ok = false;
           pc = in.u2;
           continue;
@@ -602,6 +610,18 @@ std::vector<int32_t> build_tdfa(const Program& prog, const std::vector<int32_t>&
           ok = false;
           break;
         }
+        const bool lit_off_r = in.type == OP_CHAR && (uint32_t)in.u1 >= 1u && (uint32_t)in.u1 < 128u && !in_ranges((int)in.u1);
+        if (slen > 0) {  // inside the suffix: literals outside R only
+          if (!lit_off_r || slen == 4 || getenv("CS_NO_CHAIN_SUFFIX")) {
+            ok = false;
+            break;
+          }
+          sfx |= (uint32_t)in.u1 << (8 * slen);
+          ++slen;
+          pc = in.u2;
+          continue;
+        }
+        if (x == 0 && x_free && lit_off_r && ni > 0) x = (int)in.u1;
         // the item's ASCII members against R and against {x}
         bool is_r = true, is_x = x != 0;
         for (int c = 1; c < 128; ++c) {
@@ -611,6 +631,12 @@ std::vector<int32_t> build_tdfa(const Program& prog, const std::vector<int32_t>&
         }
         if (in.type == OP_CHAR && (uint32_t)in.u1 >= 128u) is_r = is_x = false;
         const int cls = is_r ? 0 : (is_x ? 1 : -1);
+        if (cls < 0 && lit_off_r && ni > 0 && !getenv("CS_NO_CHAIN_SUFFIX")) {  // the suffix begins
+          sfx = (uint32_t)in.u1;
+          slen = 1;
+          pc = in.u2;
+          continue;
+        }
         if (cls < 0 || cls == prev_cls || (ni == 0 && cls != 0) || ni == 8) {
           ok = false;
           break;
@@ -630,9 +656,17 @@ std::vector<int32_t> build_tdfa(const Program& prog, const std::vector<int32_t>&
       // (every instruction on the line: an alternation or an optional part would leave some unvisited)
       ok = ok && ni > 0 && seen == prog.insts.size();
       if (ok && (items >> (2 * (ni - 1)) & 1u) == 0 && !((items >> (2 * (ni - 1) + 1)) & 1u)) ok = false;  // R ... R: the tail repeated
+      // (without a unit decomposition the chain is only worth offering when it brought a suffix or its own x: a plain
+      // chain of a pattern whose decomposition failed for another reason stays where it was)
+      if (ok && !(word & 1) && slen == 0 && ((word >> 8) & 127) == x) ok = false;
       if (ok) {
         img[29] |= (int32_t)(items << 16);
         img[30] |= (int32_t)((uint32_t)ni << 16);
+        if (!(word & 1) && x != ((word >> 8) & 127)) img[31] = word | (x << 8);
+        if (slen > 0) {
+          img[30] |= (int32_t)((uint32_t)slen << 21);
+          img.push_back((int32_t)sfx);
+        }
         // the capture groups of a chain are runs of items: [30] bit 20 = the image's LAST word holds, a byte per group
         // (1..4), the first item of the group in its low nibble and the item behind its last one in the high nibble (the
         // backrefs kernel reads a match's group ranges off the item boundaries)

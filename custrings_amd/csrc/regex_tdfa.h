@@ -29,7 +29,9 @@
 //   [31] unit decomposition (regex_tdfa.cpp): bit 0 offered, bits 8..14 the byte x (0 = none), bit 16 = no match without an x
 //   [29] bits 16..31, [30] bits 16..19: the CHAIN form of the pattern (regex_tdfa.cpp; chain_match below): up to eight items,
 //        two bits each (bit 0: the item's class is the byte x instead of the candidate ranges, bit 1: repeated, `+`), and
-//        their number (0 = the pattern is no chain)
+//        their number (0 = the pattern is no chain); [30] bits 21..23: the chain is followed by that many literal bytes (the
+//        SUFFIX, none of them in the candidate ranges; the word in front of the image's last one -- or the last one when no
+//        group map follows -- holds them, first byte lowest): `(\d+)\.(\d+)\.\d+\.(\d+) `
 //   INIT   : 3 modes x 8 categories state ids
 //   T1     : nstates x 128 entries (ASCII byte -> transition; byte 0 = embedded NUL)
 //   T2     : nstates x natoms entries (atom 0 = end of row, 1 = embedded NUL,
@@ -170,11 +172,30 @@ CS_HD U128 chain_ends(U128 R, U128 X, uint32_t chain) {
   if (plus(ni - 1)) M = u128_andn(M, C);
   return u128_shr1(M);
 }
-CS_HD void chain_match(U128 R, U128 X, uint32_t chain, U128& S, U128& L) {
+// The chain's SUFFIX: literal bytes behind the last item (none in R, so a repeated last item still takes its whole run and
+// a start has one match or none).  Of the ends of the chain part only those stay that the suffix follows; byte_at(i) is
+// byte i of the row (n bytes).
+template <class ByteAt>
+CS_HD U128 chain_suffix_filter(U128 Le, uint32_t chain, uint32_t sfx, int n, ByteAt&& byte_at) {
+  const int sl = (int)((chain >> 20) & 7u);
+  if (!sl) return Le;
+  U128 T = Le;
+  while (u128_any(T)) {
+    const int l = u128_ctz(T);
+    const U128 rest = u128_clear_lowest(T);
+    bool ok = l + 1 + sl <= n;
+    for (int k = 0; k < sl && ok; ++k) ok = (uint32_t)byte_at(l + 1 + k) == ((sfx >> (8 * k)) & 255u);
+    if (!ok) Le = u128_andn(Le, u128_andn(T, rest));
+    T = rest;
+  }
+  return Le;
+}
+template <class ByteAt>
+CS_HD void chain_match(U128 R, U128 X, uint32_t chain, U128& S, U128& L, uint32_t sfx, int n, ByteAt&& byte_at) {
   const int ni = (int)((chain >> 16) & 15u);
   auto is_x = [&](int k) { return ((chain >> (2 * k)) & 1u) != 0; };
   auto plus = [&](int k) { return ((chain >> (2 * k + 1)) & 1u) != 0; };
-  U128 Le = chain_ends(R, X, chain);
+  U128 Le = chain_suffix_filter(chain_ends(R, X, chain), chain, sfx, n, byte_at);
   S = u128(0, 0);
   L = u128(0, 0);
   if (!u128_any(Le)) return;
@@ -189,6 +210,11 @@ CS_HD void chain_match(U128 R, U128 X, uint32_t chain, U128& S, U128& L) {
   }
   if (plus(0)) M = u128_andn(M, C);
   U128 Sv = u128_rev127(u128_shr1(M));  // the starts that reach an end, as many as there are ends
+  {
+    // (the match's last byte is the suffix's: rows end within 96 bytes, the shift loses nothing)
+    const int sl = (int)((chain >> 20) & 7u);
+    if (sl) Le = u128(Le.lo << sl, (Le.hi << sl) | (Le.lo >> (64 - sl)));
+  }
   int cursor = 0;
   while (u128_any(Sv) && u128_any(Le)) {
     const int s = u128_ctz(Sv), l = u128_ctz(Le);
@@ -199,6 +225,41 @@ CS_HD void chain_match(U128 R, U128 X, uint32_t chain, U128& S, U128& L) {
       S = u128_or(S, sb);
       L = u128_or(L, lb);
       cursor = l + 1;
+    }
+  }
+}
+
+// The capture groups of a chain match (header word 30 bit 20; gmap: a byte per group 1..4, low nibble the group's first
+// item, high nibble the item behind its last): every group is a run of items, so its range follows from the item
+// boundaries of the match that starts at mb -- a walk over the row's two masks, no automaton.  gb / ge: -1 for a group
+// the map does not name.
+CS_HD void chain_group_bounds(U128 R, U128 X, uint32_t chain, uint32_t gmap, int mb, int gb[4], int ge[4]) {
+  const int ni = (int)((chain >> 16) & 15u);
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+  for (int q = 0; q < 4; ++q) gb[q] = ge[q] = -1;
+  int p = mb;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+  for (int k = 0; k <= 8; ++k) {
+    if (k <= ni) {  // (uniform) p = the boundary in front of item k
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+      for (int q = 0; q < 4; ++q) {
+        if ((int)((gmap >> (8 * q)) & 15u) == k) gb[q] = p;
+        if ((int)((gmap >> (8 * q + 4)) & 15u) == k) ge[q] = p;
+      }
+    }
+    if (k < ni && k < 8) {
+      if ((chain >> (2 * k + 1)) & 1u) {
+        const U128 C = ((chain >> (2 * k)) & 1u) ? X : R;
+        p = u128_ctz(u128_andn(u128(~C.lo, ~C.hi), u128_below(p)));  // the first byte at or behind p off the class
+      } else {
+        ++p;
+      }
     }
   }
 }
@@ -218,7 +279,8 @@ struct View {
   uint32_t r1lo, r1hi, r2lo, r2hi;  // SWAR constants of the two candidate ranges
   uint32_t skippack, cand0, cand1, cand2, cand3, word0, word1, word2, word3;
   uint32_t units;  // header word 31
-  uint32_t chain;  // bits 0..15 the items, bits 16..19 their number (header words 29 / 30, upper halves)
+  uint32_t chain;  // bits 0..15 the items, bits 16..19 their number (header words 29 / 30, upper halves), bits 20..22 suffix bytes
+  uint32_t sfx;    // the suffix bytes
 };
 CS_HD View make_view(const int32_t* img) {
   View v;
@@ -248,7 +310,8 @@ CS_HD View make_view(const int32_t* img) {
   v.word2 = (uint32_t)img[27];
   v.word3 = (uint32_t)img[28];
   v.units = (uint32_t)img[31];
-  v.chain = (((uint32_t)img[29] >> 16) & 0xFFFFu) | ((((uint32_t)img[30] >> 16) & 15u) << 16);
+  v.chain = (((uint32_t)img[29] >> 16) & 0xFFFFu) | ((((uint32_t)img[30] >> 16) & 15u) << 16) | ((((uint32_t)img[30] >> 21) & 7u) << 20);
+  v.sfx = ((uint32_t)img[30] >> 21) & 7u ? (uint32_t)img[img[15] - 1 - (int)(((uint32_t)img[30] >> 20) & 1u)] : 0u;
   {
     const uint32_t lo1 = (uint32_t)img[29] & 255u, hi1 = ((uint32_t)img[29] >> 8) & 255u;
     const uint32_t lo2 = (uint32_t)img[30] & 255u, hi2 = ((uint32_t)img[30] >> 8) & 255u;
@@ -1266,7 +1329,7 @@ inline bool row_chain_host(cstd::Tdfa& vm, cstd::U128& S, cstd::U128& L) {
       if (i < 64) X.lo |= 1ull << i;
       else X.hi |= 1ull << (i - 64);
     }
-  cstd::chain_match(cstd::u128(c0 | ((unsigned long long)c1 << 32), c2), X, vm.D.chain, S, L);
+  cstd::chain_match(cstd::u128(c0 | ((unsigned long long)c1 << 32), c2), X, vm.D.chain, S, L, vm.D.sfx, vm.n, [&](int i) { return vm.s[i]; });
   return true;
 }
 #endif
@@ -1393,7 +1456,7 @@ CS_HD void row_replace_matches(cstd::Tdfa& vm, int maxrepl, Emit&& emit) {
         if (i < 64) X.lo |= 1ull << i;
         else X.hi |= 1ull << (i - 64);
       }
-    cstd::chain_match(R, X, vm.D.chain, S, L);
+    cstd::chain_match(R, X, vm.D.chain, S, L, vm.D.sfx, vm.n, [&](int i) { return vm.s[i]; });
     while (cstd::u128_any(S)) {
       emit(cstd::u128_ctz(S), cstd::u128_ctz(L) + 1, 1);
       S = cstd::u128_clear_lowest(S);

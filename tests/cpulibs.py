@@ -497,6 +497,7 @@ class RowEmu(CpuLib):
         self._f("regex_tdfa_info", None, [vp, C.POINTER(C.c_int)])
         self._f("regex_units", C.c_int, [vp])
         self._f("regex_chain", C.c_int, [vp])
+        self._f("regex_chain_sfx", C.c_int, [vp])
         self._f("set_chain", None, [C.c_int])
 
     def set_engine(self, e):
@@ -511,12 +512,18 @@ class RowEmu(CpuLib):
         return bool(w & 1), (chr((w >> 8) & 127) if (w >> 8) & 127 else None), bool((w >> 16) & 1)
 
     def chain(self, pattern):
-        """The chain form (regex_tdfa.h: chain_match) as a string of items, 'R' / 'x' with '+' when repeated, or None"""
+        """The chain form (regex_tdfa.h: chain_match) as a string of items, 'R' / 'x' with '+' when repeated, then '|' and the
+        literal suffix when the chain has one -- or None"""
         re = self.compile(pattern)
         w = self._regex_chain(re)
+        sfx = self._regex_chain_sfx(re) & 0xFFFFFFFF
         self._regex_free(re)
         n = (w >> 16) & 15
-        return "".join(("x" if (w >> (2 * k)) & 1 else "R") + ("+" if (w >> (2 * k + 1)) & 1 else "") for k in range(n)) or None
+        items = "".join(("x" if (w >> (2 * k)) & 1 else "R") + ("+" if (w >> (2 * k + 1)) & 1 else "") for k in range(n))
+        sl = (w >> 20) & 7
+        if items and sl:
+            items += "|" + "".join(chr((sfx >> (8 * k)) & 255) for k in range(sl))
+        return items or None
 
     def set_chain(self, on):
         """0: chain patterns keep the unit route in the host emulation of replace_re"""

@@ -296,6 +296,8 @@ void emu_regex_tdfa_info(const emu_regex* re, int* out) {
 int emu_regex_units(const emu_regex* re) { return re->tdfa.empty() ? 0 : re->tdfa[31]; }
 // the chain form (regex_tdfa.h: chain_match): items in bits 0..15, their number in bits 16..19 (0: the pattern is no chain)
 int emu_regex_chain(const emu_regex* re) { return re->tdfa.empty() ? 0 : (int)cstd::make_view(re->tdfa.data()).chain; }
+// the chain's suffix bytes (first byte lowest; their number in bits 20..22 of emu_regex_chain)
+int emu_regex_chain_sfx(const emu_regex* re) { return re->tdfa.empty() ? 0 : (int)cstd::make_view(re->tdfa.data()).sfx; }
 // 0: chain patterns keep the unit route in replace_re (both routes are checked against the oracle)
 void emu_set_chain(int on) { cstd::g_chain_host = on; }
 // adopt a program blob produced elsewhere (e.g. by the real reference compiler)

@@ -242,7 +242,9 @@ def test_gpu_replace_re_unit_scan_edges(gpu_engine, oracle_engine, pat):
     assert _lib.lib.cs_fallback_count() == before  # the single-pass kernel itself produced these results
 
 
-CHAIN_PATS = [r"\d+\.\d+\.\d+\.\d+", r"[0-9]+\.[0-9]+\.[0-9]+\.[0-9]+", r"\d+", r"(\d+)\.(\d+)", r"[a-c]+@[a-c]+", r"\d\.\d+", r"\d+-+\d+", r"[a-cx-z]+_", r"a+b"]
+CHAIN_PATS = [r"\d+\.\d+\.\d+\.\d+", r"[0-9]+\.[0-9]+\.[0-9]+\.[0-9]+", r"\d+", r"(\d+)\.(\d+)", r"[a-c]+@[a-c]+", r"\d\.\d+", r"\d+-+\d+", r"[a-cx-z]+_", r"a+b",
+              # a literal suffix behind the chain (regex_tdfa.cpp: no unit decomposition, the chain brings its own x)
+              r"\d+\.\d+\.\d+\.\d+ ", r"(\d+)\.(\d+)\.\d+\.(\d+) ", r"\d+\.\d+ -", r"[a-c]+@x", r"\d+-\."]
 
 
 @pytest.mark.gpu
@@ -272,6 +274,27 @@ def test_gpu_chain_patterns(gpu_engine, oracle_engine, pat):
     assert gpu_engine.contains_re(s, pat) == oracle_engine.contains_re(s, pat)
     assert gpu_engine.findall(s, pat) == oracle_engine.findall(s, pat)
     assert gpu_engine.replace_re(s, pat, "=", 1) == oracle_engine.replace_re(s, pat, "=", 1)
+    if "(" in pat:  # extract: the chain form of the scan kernel (the first match's group ranges off the item boundaries)
+        assert gpu_engine.extract(s, pat) == oracle_engine.extract(s, pat)
+        refs = "".join("\\%d." % (g + 1) for g in reversed(range(pat.count("("))))
+        assert gpu_engine.replace_with_backrefs(s, pat, refs) == oracle_engine.replace_with_backrefs(s, pat, refs)
+
+
+@pytest.mark.gpu
+def test_gpu_chain_extract_meets_non_ascii_tiles(gpu_engine, oracle_engine):
+    """extract on the chain form of the scan kernel, chosen from a sample of the chars: sub-tiles with non-ASCII rows, a NUL
+    byte or a row beyond the 96-byte masks take the form's automaton route -- same columns as the oracle."""
+    rnd = random.Random(78)
+    ip = lambda: ".".join(str(rnd.randrange(256)) for _ in range(4))
+    s = ["%s GET /x/%d %s " % (ip(), i, ip() if i % 3 == 0 else "-") for i in range(40000)]
+    for at in (9000, 9001, 9100, 29000, 31000):
+        s[at] = "é " + ip() + " ü" + ip() + " "
+    s[12000] = "1.2.3\x004.5.6.7 8.9.10.11 "
+    s[20000] = "x" * 120 + ip() + " "
+    s[30500] = None
+    s[30501] = ""
+    for pat in (r"(\d+)\.(\d+)\.\d+\.(\d+) ", r"(\d+)\.(\d+)", r"((\d+)\.\d+)\.(\d+\.(\d+))", r"(\d+)\.\d+ -"):
+        assert gpu_engine.extract(s, pat) == oracle_engine.extract(s, pat), pat
 
 
 def test_gpu_chain_form_meets_non_ascii_tiles(gpu_engine, oracle_engine):

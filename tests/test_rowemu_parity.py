@@ -273,13 +273,18 @@ def test_chain_patterns_vs_oracle(emu_engine, oracle_engine):
             r"[a-c]+=": "R+x", r"\d\.\d+": "RxR+", r"[a-z]+@[a-z]+": "R+xR+", r"\d+-+\d+": "R+x+R+", r"[a-cx-z]+_": "R+x",
             r"\w+\.\w+": "R+xR+" if False else None,  # (three ranges and '_': the candidate ranges are a superset)
             r"\d+\.\d": None, r"\d\d": None, r"\d+\.?\d+": None, r"\d*\.": None, r"\.\d+": None, r"a|b": None, r"\d+?\.": None,
-            r"\b\d+": None, r"[^a]+b": None, r"\d+\.[0-5]+": None, r"é+a": None, r"\d+\.\d+\.\d+\.\d+\.\d+\.": None}
+            r"\b\d+": None, r"[^a]+b": None, r"\d+\.[0-5]+": None, r"é+a": None, r"\d+\.\d+\.\d+\.\d+\.\d+\.": None,
+            # a literal suffix behind the chain (no unit decomposition: the chain brings its own x)
+            r"\d+\.\d+\.\d+\.\d+ ": "R+xR+xR+xR+| ", r"(\d+)\.(\d+)\.\d+\.(\d+) ": "R+xR+xR+xR+| ", r"\d+\.\d+ -": "R+xR+| -", r"[a-c]+=>": "R+x|>",
+            r"\d+ab": "R+x|b", r"\d+\.\d+:x=\.": "R+xR+|:x=.", r"\d+\.\d+abcde": None, r"\d+\.\d+ 1": None, r"\d+\.\d+ \d": None, r"\d+-\.": "R+x|."}
     for pat, form in want.items():
         assert e.chain(pat) == form, pat
     rnd = random.Random(11)
     s = fuzzdata.log_rows(29, 500) + fuzzdata.rows(31, 500, max_len=96, alphabet=list("0123456789..--ab=@_ ")) + \
         ["1.2.3.4", "1.2.3.4.5.6.7.8", "1.2.3.4 5.6.7.8", ".1.2.3.4.", "1..2.3.4", "999.999.999.999x1.1.1.1", "1.2.3.", "12", "", None,
-         "1.2.3.4" + "x" * 82 + "5.6.7.8", "9" * 96, "1." * 48, ".1" * 48, "a=b=c==", "ab@cd@ef", "1--2-3", "12.3456", "0.0.0.0" * 13, "1.1.1.1é2.2.2.2"]
+         "1.2.3.4" + "x" * 82 + "5.6.7.8", "9" * 96, "1." * 48, ".1" * 48, "a=b=c==", "ab@cd@ef", "1--2-3", "12.3456", "0.0.0.0" * 13, "1.1.1.1é2.2.2.2",
+         "1.2.3.4 ", "1.2.3.4 5.6.7.8 ", "1.2.3.4  5.6.7.8", "1.2 -3.4 - 5.6 -", "7ab8ab9a", "1.2:x=.3.4:x=", "ab=>c=>=>", "1-.2-.-.", "1.2.3.4 " * 12, "x" * 88 + "1.2.3.4 ",
+         "x" * 89 + "1.2.3.4 ", "1.2.3.4" + " " * 89, "5.6 - 7.8 -9.1 -"]
     for pat in [p for p, f in want.items() if f]:
         for on in (1, 0):
             e.set_chain(on)
@@ -293,17 +298,18 @@ def test_chain_patterns_vs_oracle(emu_engine, oracle_engine):
             finally:
                 e.set_chain(1)
     # generated chains over digits / '.', and over letters / '-'
-    for _ in range(60):
+    for _ in range(120):
         a, x = rnd.choice([("\\d", "\\."), ("[a-c]", "-"), ("[0-9a-b]", "@")])
         items, prev = [], None
         for k in range(rnd.randint(1, 8)):
             cls = a if (k == 0 or prev == x) else x
             items.append(cls + rnd.choice(["", "+", "+"]))
             prev = cls
-        pat = "".join(items)
+        pat = "".join(items) + rnd.choice(["", "", " ", "=", "_ ", "@", " -"])
         if e.chain(pat) is None:
             continue
         assert emu_engine.replace_re(s, pat, "<>", -1) == oracle_engine.replace_re(s, pat, "<>", -1), pat
+        assert emu_engine.findall(s, pat) == oracle_engine.findall(s, pat), pat
 
 
 GROUP_PATTERNS = [r"(\w+) (\w+)", r"(a|ab)(c|bcd)", r"(a|b)*c", r"((a)|(b))+", r"(\d+)\.(\d+)\.(\d+)\.(\d+)", r"(a*)(b*)", r"(a+?)(a*)",
