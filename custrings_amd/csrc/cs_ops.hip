@@ -28,6 +28,7 @@ namespace csrow {
 struct CharSet;
 }
 namespace cs {
+bool strip_single(const cs_column* in, const csrow::CharSet& set, int side, hipStream_t s, cs_column* o);
 bool strip_write_tiles(const cs_column* in, const csrow::CharSet& set, int side, const int64_t* out_off, uint8_t* out_chars,
                        hipStream_t s);
 bool find_tiles(const cs_column* in, const unsigned char* needle, int nb, int mode, int start, int end, int32_t* out32,
@@ -438,6 +439,10 @@ int cs_strip(const cs_column* col, const char* to_strip, int side, cs_stream str
       o->rows = col->rows;
       o->validity = col->validity;
       o->null_count = col->null_count;
+      if (strip_single(col, set, side, s, o.get())) {  // one pass (cs_rows.hip: k_strip_stream)
+        *out = o.release();
+        return;
+      }
       const unsigned nb = blocks_for(col->rows);
       Buf lens = dev_alloc(sizeof(int32_t) * col->rows, s);
       Buf sums = dev_alloc(sizeof(int64_t) * nb, s);

@@ -415,6 +415,7 @@ __device__ __forceinline__ long long lookback_end(u64* status, long long tile, l
   }
   excl += (unsigned)csdev::wave_reduce_sum((int)part);
   if (lane == 0) status_store(status + tile, kFlagInc | ((u64)(excl + aggregate) & kValMask));
+  (void)spins;
 #if defined(CS_PHASE_PROF)
   if (acc) {
     acc[0] += 1;
