@@ -957,7 +957,7 @@ struct StreamArgs {
   int outliers;  // the buffers are sized for all but a few sub-tiles: an oversize one is handled a thread per row in the kernel
   long long out_cap;  // bytes provisioned at out_chars (growing replacements)
   int rows_per_tile;  // LONG variants: 64, 32 or 16
-  unsigned long long* tickets;  // 8 tile counters, 64 bytes apart, zeroed before the launch
+  unsigned long long* tickets;  // 16 tile counters, 64 bytes apart, zeroed before the launch
   unsigned long long lit;       // UNITS: a literal needle (first byte lowest), litn bytes; litn == 0: none
   int litn;
   // BREFS (replace_with_backrefs on the unit scan): the template, the capture-group tag image and where both are
@@ -1184,10 +1184,12 @@ __global__ void __launch_bounds__(256, BREFS ? 2 : CS_STREAM_WAVES) k_tdfa_repla
   // Tiles are handed out by tickets, so every tile's predecessors were started before it and a
   // wave that meets a slow tile does not hold back the tiles it would have taken next (with a static
   // round-robin the look-back of everybody else waits for them).  One counter per class of
-  // workgroups (blockIdx mod 8, the observed XCD placement -- for speed only): counter k hands out
-  // tiles k, k + 8, ...; a single word would saturate at the rate this kernel takes tiles.  The
+  // workgroups (blockIdx mod K, K = 16): counter k hands out tiles k, k + K, ...; a single word hands out some 65 tickets a
+  // microsecond (measured with the strip kernel, cs_rows.hip), this kernel takes 320 -- eight counters ran at 40 each and
+  // still cost 0.1 ms against sixteen (4.87 -> 4.75 ms; thirty-two: the same).  The
   // ticket of the tile after next is in flight while the current tile is processed.
-  const long long K = gridDim.x >= 16 ? 8 : 1;  // (every class needs a workgroup that takes tiles: workgroup 0 may be the scanners')
+  // (sixteen for the launches that hold three workgroups a CU; the slower forms -- two a CU -- measured a little better with eight)
+  const long long K = gridDim.x >= 640 ? 16 : (gridDim.x >= 16 ? 8 : 1);  // (every class needs a workgroup that takes tiles: workgroup 0 may be the scanners')
   const long long key = (long long)blockIdx.x % K;
   const bool fixed = (CS_DBG(a) & (256 | 16384)) != 0;  // measurement: the static round-robin
   // Workgroup 0 takes no tiles: its four waves turn the aggregates the other waves publish into each tile's exclusive
@@ -2909,15 +2911,15 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
         sa.out_cap = col->nbytes + extra;
         const int64_t nsub1 = (rows + tc.R - 1) / tc.R;
         sa.rows_per_tile = tc.R;
-        // [aggregates nsub1][error word + phase counters 16][tickets 64][exclusive prefixes nsub1]
+        // [aggregates nsub1][error word + phase counters 16][tickets 128: sixteen counters][exclusive prefixes nsub1]
         // (+ kScanBatch windows of slack: the scanner wave fetches whole batches)
-        const size_t status_bytes = sizeof(cstile::u64) * (2 * (size_t)nsub1 + 16 + 64 + 64 * cstile::kScanBatch);
+        const size_t status_bytes = sizeof(cstile::u64) * (2 * (size_t)nsub1 + 16 + 128 + 64 * cstile::kScanBatch);
         Buf status = dev_alloc(status_bytes, s);
         CS_HIP(hipMemsetAsync(status->p, 0, status_bytes, s));
         sa.status = ptr<cstile::u64>(status);
         sa.error = reinterpret_cast<unsigned*>(ptr<cstile::u64>(status) + nsub1);
         sa.tickets = ptr<cstile::u64>(status) + nsub1 + 16;
-        sa.excl = ptr<cstile::u64>(status) + nsub1 + 16 + 64;
+        sa.excl = ptr<cstile::u64>(status) + nsub1 + 16 + 128;
         sa.nsub = nsub1;
         sa.cap_in = cap;
         sa.cap_out = cap_out;
