@@ -2881,7 +2881,8 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
         // replace_with_backrefs on this kernel (cs_replace_with_backrefs left its template in g_backrefs_dev): the unit
         // scan, groups carried by the DFA (four at most), tables in LDS
         const bool brefs = cs::g_backrefs_dev != nullptr;
-        if (brefs && !(((re->tdfa[31] & 1) != 0 || (((re->tdfa[30] >> 16) & 15) != 0 && ((re->tdfa[30] >> 20) & 1) != 0)) && !tc.lng && tc.R == 64 && tp.d.in_lds && !re->gtags.empty() && re->prog.num_groups <= cstd::Tdfa::kGroupBatch &&
+        // (a chain without a unit decomposition has no route for sub-tiles with bytes >= 0x80 in this form: only on columns whose sample is plain ASCII)
+        if (brefs && !(((re->tdfa[31] & 1) != 0 || (((re->tdfa[30] >> 16) & 15) != 0 && ((re->tdfa[30] >> 20) & 1) != 0 && !sample_has_high_bytes(col, s))) && !tc.lng && tc.R == 64 && tp.d.in_lds && !re->gtags.empty() && re->prog.num_groups <= cstd::Tdfa::kGroupBatch &&
                        re->gtags.size() * 4 <= 8 * 1024))
           return -1;
         const bool literal = !brefs && !outliers && cs::g_replace_plain_only && cs::g_replace_literal_len > 0 && maxrepl < 0 && !tc.lng && tc.R == 64 && !getenv("CS_NO_LITERAL_SCAN");
