@@ -22,4 +22,5 @@ for repl in ("<IP>", r"\0", r"\1", r"\4.\3.\2.\1"):
 t0 = time.perf_counter()
 c3.replace(B.IPV4, "<IP>")
 torch.cuda.synchronize()
-print("replace_re", "%.2f ms" % ((time.perf_counter() - t0) * 1e3), flush=True)
+from custrings_amd import _lib
+print("replace_re", "%.2f ms" % ((time.perf_counter() - t0) * 1e3), "fallbacks so far", int(_lib.lib.cs_fallback_count()), flush=True)
