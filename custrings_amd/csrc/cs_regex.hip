@@ -291,7 +291,7 @@ __global__ void __launch_bounds__(256) k_spans_write_tile(SpanWriteArgs a) {
 // column (k_chunk_sums / k_chunk_offsets: 0.35 ms per column of 100M rows) and the write kernel's reads of the offsets
 // they produced are gone, and the span arrays are half as large.
 struct SpanOut2 {
-  int64_t* off[kMaxGroups];
+  void* off[kMaxGroups];  // int32 offsets when every column stays below 2 GiB (half the offset bytes: as the split kernels write them), else int64
   uint8_t* chars[kMaxGroups];
   uint8_t* valid[kMaxGroups];
 };
@@ -303,6 +303,7 @@ struct SpanWrite2Args {
   SpanOut2 out;
   long long nsub;
   int cap;
+  int off32;
 };
 __global__ void __launch_bounds__(256) k_spans_write_tile2(SpanWrite2Args a) {
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
@@ -368,8 +369,15 @@ __global__ void __launch_bounds__(256) k_spans_write_tile2(SpanWrite2Args a) {
       const int inc = csdev::wave_inclusive_scan(len);
       const int di = inc - len;
       const int total = __builtin_amdgcn_readlane(inc, 63);
-      if (lane < nrows) a.out.off[g][r0 + lane] = base + di;
-      if (tile + 1 == a.nsub && lane == nrows - 1) a.out.off[g][in.rows] = base + total;
+      if (a.off32) {
+        int32_t* o32 = static_cast<int32_t*>(a.out.off[g]);
+        if (lane < nrows) o32[r0 + lane] = (int32_t)(base + di);
+        if (tile + 1 == a.nsub && lane == nrows - 1) o32[in.rows] = (int32_t)(base + total);
+      } else {
+        int64_t* o64 = static_cast<int64_t*>(a.out.off[g]);
+        if (lane < nrows) o64[r0 + lane] = base + di;
+        if (tile + 1 == a.nsub && lane == nrows - 1) o64[in.rows] = base + total;
+      }
       const unsigned long long vbits = __ballot(valid);
       if (lane == 0) *reinterpret_cast<unsigned long long*>(a.out.valid[g] + tile * 8) = vbits;
       if (total == 0) continue;
@@ -3201,14 +3209,18 @@ void columns_from_packed_spans(const cs_column* col, int ncols, const uint32_t* 
   a.tile_base = ptr<const int64_t>(base);
   a.nsub = nsub;
   a.cap = cap;
+  bool off32 = !getenv("CS_SPANS_OFF64");
+  for (int k = 0; k < ncols; ++k) off32 = off32 && totals[k] < ((int64_t)1 << 31);
+  a.off32 = off32 ? 1 : 0;
   for (int k = 0; k < ncols; ++k) {
     auto o = std::make_unique<cs_column>();
     o->rows = rows;
     o->nbytes = totals[k];
-    o->offsets = dev_alloc(sizeof(int64_t) * (rows + 1), s);
+    if (off32) o->offsets32 = dev_alloc(sizeof(int32_t) * (rows + 1), s);
+    else o->offsets = dev_alloc(sizeof(int64_t) * (rows + 1), s);
     o->validity = dev_alloc(validity_bytes(rows), s);
     o->chars = dev_alloc((size_t)o->nbytes, s);
-    a.out.off[k] = ptr<int64_t>(o->offsets);
+    a.out.off[k] = off32 ? o->offsets32->p : o->offsets->p;
     a.out.valid[k] = ptr<uint8_t>(o->validity);
     a.out.chars[k] = ptr<uint8_t>(o->chars);
     cols.push_back(std::move(o));
