@@ -71,6 +71,7 @@ def main():
     ap.add_argument("--rows", type=int, default=100_000_000, help="rows per GPU (weak scaling)")
     ap.add_argument("--cpu-rows", type=int, default=3_000_000, help="rows of the same workload timed on the CPU oracle")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--cold-steps", type=int, default=4, help="steps on a freshly generated column each (reported as `cold`; 0 = skip)")
     ap.add_argument("--pmc-traffic", type=float, default=None, help="HBM bytes/launch of the dominant kernel from a separate rocprofv3 --pmc run")
     ap.add_argument("--config", default="c3", choices=["c2", "c3", "c4", "c5"],
                     help="c3 = the headline (default); c2 = lower + strip + split(' ') on 10M rows x 64 chars; "
@@ -153,22 +154,50 @@ def main():
     elapsed = time.perf_counter() - t0
     L.cs_prof_enable(0)
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    # ---- the same step on a FRESH column each iteration: nothing cached on the input from an earlier call (the timed
+    # loop above re-uses one column, whose metadata -- longest row, largest 64-row span, the non-ASCII sample -- the
+    # warm-up step paid for).  Generating the column is not timed; the step is, call to synchronised return.
+    cold_ms = []
+    cold_fallbacks0 = int(L.cs_fallback_count())
+    warm_prof = {}
+    for k in KERNELS:  # (the timed loop's kernel times are read here: the cold steps get a profile of their own)
+        ms, n = C.c_double(), C.c_int64()
+        L.cs_prof_get(k.encode(), C.byref(ms), C.byref(n))
+        if n.value:
+            warm_prof[k] = {"avg_ms": ms.value / n.value, "launches": n.value}
+    L.cs_prof_reset()
+    L.cs_prof_enable(1)
+    for i in range(args.cold_steps):
+        fresh = C.c_void_p()
+        _lib.check(L.cs_synth_column(3, rank * args.rows, args.rows, SEED + 1 + i, 0, None, C.byref(fresh)))
+        keep, col = col, nvstrings.nvstrings(fresh.value)
+        del keep
+        barrier()
+        tc0 = time.perf_counter()
+        step()
+        barrier()
+        cold_ms.append((time.perf_counter() - tc0) * 1e3)
+    cold_fallbacks = int(L.cs_fallback_count()) - cold_fallbacks0
+    L.cs_prof_enable(0)
+    cold_prof = {}
+    for k in KERNELS:
+        ms, n = C.c_double(), C.c_int64()
+        L.cs_prof_get(k.encode(), C.byref(ms), C.byref(n))
+        if n.value:
+            cold_prof[k] = round(ms.value / n.value, 3)
+
+    t = torch.tensor([elapsed] + cold_ms, dtype=torch.float64, device="cuda")
     tot = torch.tensor([float(in_bytes), float(args.rows)], dtype=torch.float64, device="cuda")
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-    elapsed = float(t.item())
+    elapsed = float(t[0].item())
+    cold_ms = [float(x) for x in t[1:].tolist()]
     total_bytes, total_rows = float(tot[0].item()), float(tot[1].item())
 
     if rank == 0:
         # ---- per-kernel device time from HIP events recorded on the launch stream
-        prof = {}
-        for k in KERNELS:
-            ms, n = C.c_double(), C.c_int64()
-            L.cs_prof_get(k.encode(), C.byref(ms), C.byref(n))
-            if n.value:
-                prof[k] = {"avg_ms": ms.value / n.value, "launches": n.value}
+        prof = warm_prof
         rows = args.rows
         Lb = in_bytes / rows
         Ccols = stats["split_cols"]
@@ -263,6 +292,13 @@ def main():
                                   "peak": 8000.0 * world, "unit": "GB/s", "frac": round(pipeline / (8000.0 * world), 4)},
             "kernels": {k: {"avg_ms": round(v["avg_ms"], 3), "launches": v["launches"]} for k, v in prof.items()},
         }
+        if cold_ms:
+            # (the first cold step also grows the buffer pool by a column: reported, not averaged in)
+            rest = cold_ms[1:] if len(cold_ms) > 1 else cold_ms
+            result["cold"] = {"ms_per_step": round(sum(rest) / len(rest), 3), "steps": len(rest), "first_ms": round(cold_ms[0], 3),
+                              "all_ms": [round(x, 3) for x in cold_ms], "fallbacks": cold_fallbacks, "kernels_avg_ms": cold_prof,
+                              "what": "the same step (split + replace_re, call to synchronised return) on a column generated just before it, "
+                                      "a new seed each iteration: no metadata cached from an earlier call; generation untimed"}
         if not args.no_cpu:
             result["cpu_baseline"] = cpu_baseline(args.cpu_rows)
         print(json.dumps(result), flush=True)

@@ -35,11 +35,14 @@ class ColumnView(C.Structure):
 
 _PROTOS = {
     "cs_version": (i32, []),
+    "cs_has_experiments": (i32, []),
     "cs_last_error": (cp, []),
     "cs_device_count": (i32, []),
     "cs_init": (i32, [i32]),
     "cs_current_device": (i32, []),
     "cs_fallback_count": (i64, []),
+    "cs_debug_last_route": (cp, []),
+    "cs_config_set": (i32, [cp, cp]),
     "cs_device_bytes_in_use": (i64, []),
     "cs_free": (None, [vp]),
     "cs_column_from_host_strings": (i32, [P(cp), i64, vp, P(vp)]),
@@ -56,6 +59,7 @@ _PROTOS = {
     "cs_column_nbytes": (i64, [vp]),
     "cs_column_offset_width": (i32, [vp]),
     "cs_column_null_count": (i64, [vp]),
+    "cs_column_cached_meta": (i32, [vp, vp]),
     "cs_column_get_view": (i32, [vp, P(ColumnView)]),
     "cs_column_export_offsets32": (i32, [vp, vp, vp, vp, i32, vp]),
     "cs_column_export_offsets64": (i32, [vp, vp, vp, vp, i32, vp]),
@@ -182,6 +186,24 @@ def ensure_init(device=None):
             device = 0
     check(lib.cs_init(device))
     _initialised = True
+
+
+def loaded_hip():
+    """The HIP runtime THIS process already has mapped (the one libcustrings_amd.so is bound to -- torch's bundled copy when
+    torch was imported first): opened by the path /proc/self/maps shows, never by bare name (a bare `libamdhip64.so` can map
+    a second runtime next to it, and two runtimes in one process crash)."""
+    path = None
+    try:
+        with open("/proc/self/maps") as f:
+            for line in f:
+                if "libamdhip64" in line:
+                    path = line.split()[-1]
+                    break
+    except OSError:
+        pass
+    if path is None:
+        raise RuntimeError("custrings_amd: no HIP runtime is mapped in this process")
+    return C.CDLL(path)
 
 
 def b(s):

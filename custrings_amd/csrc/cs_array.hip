@@ -33,7 +33,9 @@ Built column_from_lengths(const int32_t* lens, int64_t rows, bool any_null_possi
   cs_column* c = b.col.get();
   c->rows = rows;
   c->offsets = dev_alloc(sizeof(int64_t) * (rows + 1), s);
-  c->nbytes = offsets_from_lengths(lens, rows, ptr<int64_t>(c->offsets), s);
+  LenMeta meta;  // (the longest row and the largest 64-row span come out of the same pass: no op on the new column pays for them)
+  c->nbytes = offsets_from_lengths(lens, rows, ptr<int64_t>(c->offsets), s, nullptr, &meta);
+  meta.give(c);
   c->chars = dev_alloc((size_t)c->nbytes, s);
   if (any_null_possible) c->validity = validity_from_lengths(lens, rows, s);
   else c->null_count = 0;

@@ -229,7 +229,7 @@ namespace cs {
 
 bool change_case_fast(const cs_column* col, unsigned bit, bool ascii_rule_ok, hipStream_t s, cs_column** out) {
   const int64_t rows = col->rows;
-  if (rows == 0 || !ascii_rule_ok || col->nbytes == 0 || getenv("CS_CASE_ROWWISE")) return false;
+  if (rows == 0 || !ascii_rule_ok || col->nbytes == 0 || cs::cfg("CS_CASE_ROWWISE")) return false;
   int R = 0;
   for (int r : {64, 32, 16}) {
     if (max_span_rows(col, r, s) + 32 <= cstile::kPfBytes) {
@@ -238,7 +238,7 @@ bool change_case_fast(const cs_column* col, unsigned bit, bool ascii_rule_ok, hi
     }
   }
   int64_t span = R ? max_span_rows(col, R, s) : 0;
-  if (!R && !getenv("CS_NO_OUTLIER_TILES")) {
+  if (!R && !cs::cfg("CS_NO_OUTLIER_TILES")) {
     // no tile size fits every tile (one long row among short ones, or rows of hundreds of bytes throughout): 64-row tiles,
     // the kernel maps a tile beyond the staging size with the whole wave, sixteen bytes a lane, straight from memory --
     // row by row only when the tile holds non-ASCII bytes

@@ -465,10 +465,10 @@ cs_category* cs::category_build(const cs_column* col, hipStream_t s) {
   Buf flags_d = dev_alloc(2 * sizeof(int), s);  // [0] has_null, [1] overflow
   Buf table;
   int first_log2 = 22;
-  if (const char* e = getenv("CS_CAT_FIRST_LOG2")) first_log2 = std::max(4, std::min(30, atoi(e)));  // tests: force retries
-  int64_t cap = std::min<int64_t>(full, getenv("CS_CAT_FULL_TABLE") && !full_out_of_range ? full : (int64_t)1 << first_log2);
+  if (const char* e = cs::cfg("CS_CAT_FIRST_LOG2")) first_log2 = std::max(4, std::min(30, atoi(e)));  // tests: force retries
+  int64_t cap = std::min<int64_t>(full, cs::cfg("CS_CAT_FULL_TABLE") && !full_out_of_range ? full : (int64_t)1 << first_log2);
   constexpr int64_t kSampleRows = 1 << 21;  // (that many rows fit the small table whatever they hold)
-  bool sampled = getenv("CS_CAT_NO_SAMPLE") != nullptr;
+  bool sampled = cs::cfg("CS_CAT_NO_SAMPLE") != nullptr;
   for (;;) {
     table = dev_alloc(sizeof(Entry) * cap, s);
     CS_HIP(hipMemsetAsync(table->p, 0xFF, sizeof(Entry) * cap, s));
@@ -476,7 +476,7 @@ cs_category* cs::category_build(const cs_column* col, hipStream_t s) {
     {
       ProfScope ps("k_cat_insert", s);
       const int limit = cap == full ? 0x7fffffff : kProbeLimit;
-      const int dbg = getenv("CS_CAT_DEBUG") ? atoi(getenv("CS_CAT_DEBUG")) : 0;
+      const int dbg = cs::cfg("CS_CAT_DEBUG") ? atoi(cs::cfg("CS_CAT_DEBUG")) : 0;
       hipLaunchKernelGGL(k_cat_insert, dim3(blocks_for(rows)), dim3(kBlock), 0, s, in, ptr<Entry>(table),
                          (uint32_t)(cap - 1), ptr<int32_t>(slot_of_row), ptr<int>(flags_d), ptr<int>(flags_d) + 1, limit,
                          dbg);
@@ -541,7 +541,7 @@ cs_category* cs::category_build(const cs_column* col, hipStream_t s) {
   };
   // (a key set that one LDS chunk holds sorts in a single launch of the compare network: the radix sort's histogram and
   // scan round trips would cost more than they save there)
-  const bool use_radix = !getenv("CS_CAT_BITONIC") && (uniq > kSortChunk || getenv("CS_CAT_RADIX"));
+  const bool use_radix = !cs::cfg("CS_CAT_BITONIC") && (uniq > kSortChunk || cs::cfg("CS_CAT_RADIX"));
   int64_t padded = 1;
   while (padded < uniq) padded <<= 1;
   if (use_radix) padded = std::max<int64_t>(uniq, 1);
@@ -567,7 +567,7 @@ cs_category* cs::category_build(const cs_column* col, hipStream_t s) {
         hipLaunchKernelGGL(k_tie_gather, dim3(blocks_for(std::max(uniq, tpad))), dim3(kBlock), 0, s, ptr<const uint64_t>(prefix), ptr<const int32_t>(item),
                            ptr<const int32_t>(tflags), ptr<const int64_t>(tpos), uniq, tied, tpad, ptr<uint64_t>(tprefix), ptr<int32_t>(titem),
                            ptr<int32_t>(where));
-        if (tied <= kSortChunk || getenv("CS_CAT_TIE_NETWORK")) {
+        if (tied <= kSortChunk || cs::cfg("CS_CAT_TIE_NETWORK")) {
           // (a handful of ties: one launch of the compare network in LDS)
           bitonic(ptr<uint64_t>(tprefix), ptr<int32_t>(titem), tpad);
           hipLaunchKernelGGL(k_tie_scatter, dim3(blocks_for(tied)), dim3(kBlock), 0, s, ptr<const int32_t>(titem), ptr<const int32_t>(where), tied,
@@ -631,7 +631,9 @@ cs_category* cs::category_build(const cs_column* col, hipStream_t s) {
   hipLaunchKernelGGL(k_key_sizes, dim3(blocks_for(nkeys)), dim3(kBlock), 0, s, in, ptr<const Entry>(table),
                      ptr<const int32_t>(item), nkeys, shift, ptr<int32_t>(lens));
   keys->offsets = dev_alloc(sizeof(int64_t) * (nkeys + 1), s);
-  keys->nbytes = offsets_from_lengths(ptr<int32_t>(lens), nkeys, ptr<int64_t>(keys->offsets), s);
+  LenMeta meta;
+  keys->nbytes = offsets_from_lengths(ptr<int32_t>(lens), nkeys, ptr<int64_t>(keys->offsets), s, nullptr, &meta);
+  meta.give(keys.get());
   keys->chars = dev_alloc((size_t)keys->nbytes, s);
   if (shift) keys->validity = validity_from_lengths(ptr<int32_t>(lens), nkeys, s);
   hipLaunchKernelGGL(k_key_copy, dim3(blocks_for(nkeys)), dim3(kBlock), 0, s, in, ptr<const Entry>(table),

@@ -41,6 +41,7 @@ struct CachedBlock {
   std::vector<hipEvent_t> released;  // one per stream known at the release (a column made on one stream may have been read on another)
 };
 static std::multimap<size_t, CachedBlock> g_cache;  // capacity -> block
+static const hipStream_t kNoStream = reinterpret_cast<hipStream_t>(~(uintptr_t)0);  // "last used by nobody we still know"
 static std::vector<hipEvent_t> g_event_pool;
 // Streams that have asked for buffers.  While there is one (the usual case) stream order alone
 // makes the reuse of a released block safe.  With more, a block may still be read by a kernel on
@@ -61,8 +62,10 @@ void require_device() {
   }
 }
 int bound_device() { return g_device; }
+thread_local const char* g_last_route = "";
+void note_route(const char* route) { g_last_route = route; }
 void note_fallback(const char* what) {
-  if (g_fallbacks.fetch_add(1) == 0 || getenv("CS_LOG_FALLBACKS"))
+  if (g_fallbacks.fetch_add(1) == 0 || cs::cfg("CS_LOG_FALLBACKS"))
     fprintf(stderr, "custrings_amd: %s: the single-pass kernel gave up, recomputing with the two-pass kernels\n", what);
 }
 const uint8_t* d_unicode_flags() { return g_d_flags; }
@@ -139,6 +142,9 @@ Buf dev_alloc(size_t bytes, hipStream_t stream) {
       b->p = it->second.first;
       b->capacity = it->first;
       prev = it->second.second;
+      // (a block whose last stream is no longer known -- cs_stream_forget synchronised it, its owner may have destroyed
+      // it since -- is idle: nothing to wait for, and the handle must not be touched)
+      if (prev != stream && !g_streams.count(prev)) prev = stream;
       released = std::move(it->second.released);
       g_cache.erase(it);
       g_in_use += (int64_t)b->capacity;
@@ -288,9 +294,14 @@ __global__ void __launch_bounds__(1024) k_scan_block_sums(int64_t* __restrict__ 
   if (threadIdx.x == 0) totals[blockIdx.x] = carry_s;
 }
 // offsets[i] = block_base[b] + in-block exclusive prefix; offsets[n] = total
+// (meta: [0] longest row, [1] largest 64-row span -- a wave holds 64 consecutive rows starting at a multiple of 64; only a
+// wave that would raise a maximum issues the same-address atomic)
+__device__ __forceinline__ void meta_raise(unsigned long long* slot, long long v) {
+  if ((unsigned long long)v > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, (unsigned long long)v);
+}
 __global__ void k_write_offsets(const int32_t* __restrict__ lens, int64_t n,
                                 const int64_t* __restrict__ block_base, int64_t nb,
-                                int64_t* __restrict__ offsets) {
+                                int64_t* __restrict__ offsets, unsigned long long* __restrict__ meta) {
   // grid.y = segment
   const int32_t* sl = lens + (int64_t)blockIdx.y * n;
   const int64_t* sb = block_base + (int64_t)blockIdx.y * nb;
@@ -301,6 +312,15 @@ __global__ void k_write_offsets(const int32_t* __restrict__ lens, int64_t n,
   long long ex = block_exclusive_scan(v, nullptr) + sb[blockIdx.x];
   if (i < n) so[i] = ex;
   if (i == n - 1) so[n] = ex + v;
+  if (meta) {  // (two words per segment)
+    const int longest = wave_reduce_max(v);
+    long long span = v;
+    for (int d = 32; d > 0; d >>= 1) span += __shfl_xor(span, d, 64);
+    if ((threadIdx.x & 63) == 0) {
+      meta_raise(meta + 2 * blockIdx.y, longest);
+      meta_raise(meta + 2 * blockIdx.y + 1, span);
+    }
+  }
 }
 __global__ void k_block_sums_seg(const int32_t* __restrict__ lens, int64_t n, int64_t nb,
                                  int64_t* __restrict__ sums) {
@@ -313,25 +333,29 @@ __global__ void k_block_sums_seg(const int32_t* __restrict__ lens, int64_t n, in
 }
 
 void offsets_from_lengths_segmented(const int32_t* lens, int64_t n, int segs, int64_t* offsets,
-                                    int64_t* totals_host, hipStream_t s) {
+                                    int64_t* totals_host, hipStream_t s, int64_t* largest_host) {
   if (n == 0) {
     CS_HIP(hipMemsetAsync(offsets, 0, sizeof(int64_t) * segs, s));
     for (int k = 0; k < segs; ++k) totals_host[k] = 0;
+    for (int k = 0; largest_host && k < segs; ++k) largest_host[k] = 0;
     return;
   }
   int64_t nb = (n + kBlock - 1) / kBlock;
   Buf sums = dev_alloc(sizeof(int64_t) * nb * segs, s);
-  Buf totals = dev_alloc(sizeof(int64_t) * segs, s);
+  // [segs] totals, then (with largest_host) two maxima per segment: [0] the largest length, [1] unused here
+  Buf totals = dev_alloc(sizeof(int64_t) * segs * 3, s);
+  if (largest_host) CS_HIP(hipMemsetAsync(totals->p, 0, sizeof(int64_t) * segs * 3, s));
   hipLaunchKernelGGL(k_block_sums_seg, dim3((unsigned)nb, segs), dim3(kBlock), 0, s, lens, n, nb,
                      ptr<int64_t>(sums));
   hipLaunchKernelGGL(k_scan_block_sums, dim3(segs), dim3(1024), 0, s, ptr<int64_t>(sums), nb,
                      ptr<int64_t>(totals));
   hipLaunchKernelGGL(k_write_offsets, dim3((unsigned)nb, segs), dim3(kBlock), 0, s, lens, n,
-                     ptr<int64_t>(sums), nb, offsets);
-  int64_t* host = (int64_t*)pinned_scratch(sizeof(int64_t) * segs);
-  CS_HIP(hipMemcpyAsync(host, ptr<int64_t>(totals), sizeof(int64_t) * segs, hipMemcpyDeviceToHost, s));
+                     ptr<int64_t>(sums), nb, offsets, largest_host ? ptr<unsigned long long>(totals) + segs : nullptr);
+  int64_t* host = (int64_t*)pinned_scratch(sizeof(int64_t) * segs * 3);
+  CS_HIP(hipMemcpyAsync(host, ptr<int64_t>(totals), sizeof(int64_t) * segs * (largest_host ? 3 : 1), hipMemcpyDeviceToHost, s));
   CS_HIP(hipStreamSynchronize(s));
   for (int k = 0; k < segs; ++k) totals_host[k] = host[k];
+  for (int k = 0; largest_host && k < segs; ++k) largest_host[k] = host[segs + 2 * k];
 }
 
 // lengths -> offsets on chunks of 2048 lengths, a wave each, with whole 16-byte loads and stores: chunk sums, the
@@ -387,7 +411,7 @@ __global__ void __launch_bounds__(256) k_chunk_sums(const int32_t* __restrict__ 
 }
 __global__ void __launch_bounds__(256) k_chunk_offsets(const int32_t* __restrict__ lens, int64_t n, int64_t nchunks,
                                                        const int64_t* __restrict__ chunk_base, int64_t* __restrict__ offsets,
-                                                       uint8_t* __restrict__ validity, int64_t validity_len) {
+                                                       uint8_t* __restrict__ validity, int64_t validity_len, unsigned long long* __restrict__ meta) {
   const int lane = threadIdx.x & 63;
   const int64_t chunk = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (chunk >= nchunks) return;
@@ -396,6 +420,25 @@ __global__ void __launch_bounds__(256) k_chunk_offsets(const int32_t* __restrict
   ChunkVals c;
   load_chunk(lens, n, base, lane, c);
   const bool narrow = chunk_total(c) < 0x7fffffffLL;  // (wave-uniform: the sums inside the chunk fit 32 bits)
+  if (meta) {
+    // the column's metadata as a by-product: a lane holds four consecutive rows, sixteen lanes the 64 rows of a tile
+    // that starts at a multiple of 64 (the chunk starts at a multiple of 2048)
+    long long span = 0;
+    int longest = 0;
+#pragma unroll
+    for (int j = 0; j < kChunkRounds; ++j) {
+      long long s4 = (long long)c.v[j][0] + c.v[j][1] + c.v[j][2] + c.v[j][3];
+      longest = max(longest, max(max(c.v[j][0], c.v[j][1]), max(c.v[j][2], c.v[j][3])));
+      for (int d = 8; d > 0; d >>= 1) s4 += __shfl_xor(s4, d, 64);
+      span = max(span, s4);
+    }
+    longest = wave_reduce_max(longest);
+    for (int d = 32; d > 0; d >>= 1) span = max(span, (long long)__shfl_xor(span, d, 64));
+    if (lane == 0) {
+      meta_raise(meta, longest);
+      meta_raise(meta + 1, span);
+    }
+  }
 #pragma unroll
   for (int j = 0; j < kChunkRounds; ++j) {
     const int64_t i = base + j * 256 + lane * 4;
@@ -437,63 +480,75 @@ __global__ void __launch_bounds__(256) k_chunk_offsets(const int32_t* __restrict
   }
 }
 
-static int64_t offsets_by_chunks(const int32_t* lens, int64_t n, int64_t* offsets, uint8_t* validity, hipStream_t s);
-static int64_t offsets_by_workgroups(const int32_t* lens, int64_t n, int64_t* offsets, hipStream_t s, Buf block_sums);
+static int64_t offsets_by_chunks(const int32_t* lens, int64_t n, int64_t* offsets, uint8_t* validity, hipStream_t s, LenMeta* meta);
+static int64_t offsets_by_workgroups(const int32_t* lens, int64_t n, int64_t* offsets, hipStream_t s, Buf block_sums, LenMeta* meta);
 int64_t offsets_from_lengths(const int32_t* lens, int64_t n, int64_t* offsets, hipStream_t s,
-                             Buf block_sums) {
+                             Buf block_sums, LenMeta* meta) {
   if (n == 0) {
     CS_HIP(hipMemsetAsync(offsets, 0, sizeof(int64_t), s));
+    if (meta) meta->max_row = meta->max_span64 = 0;
     return 0;
   }
-  if (!block_sums && !getenv("CS_SCAN_BY_WORKGROUPS")) return offsets_by_chunks(lens, n, offsets, nullptr, s);
-  return offsets_by_workgroups(lens, n, offsets, s, block_sums);
+  if (!block_sums && !cs::cfg("CS_SCAN_BY_WORKGROUPS")) return offsets_by_chunks(lens, n, offsets, nullptr, s, meta);
+  return offsets_by_workgroups(lens, n, offsets, s, block_sums, meta);
 }
 // offsets and the validity mask (length >= 0) of a column in the same pass over its lengths
-int64_t offsets_and_validity_from_lengths(const int32_t* lens, int64_t n, int64_t* offsets, Buf* validity, hipStream_t s) {
-  if (n == 0 || getenv("CS_SCAN_BY_WORKGROUPS")) {
+int64_t offsets_and_validity_from_lengths(const int32_t* lens, int64_t n, int64_t* offsets, Buf* validity, hipStream_t s, LenMeta* meta) {
+  if (n == 0 || cs::cfg("CS_SCAN_BY_WORKGROUPS")) {
     *validity = validity_from_lengths(lens, n, s);
-    return offsets_from_lengths(lens, n, offsets, s);
+    return offsets_from_lengths(lens, n, offsets, s, nullptr, meta);
   }
   *validity = dev_alloc(validity_bytes(n), s);
-  return offsets_by_chunks(lens, n, offsets, ptr<uint8_t>(*validity), s);
+  return offsets_by_chunks(lens, n, offsets, ptr<uint8_t>(*validity), s, meta);
 }
-static int64_t offsets_by_chunks(const int32_t* lens, int64_t n, int64_t* offsets, uint8_t* validity, hipStream_t s) {
+// (the total and the two metadata words share one small buffer and one copy back: no extra synchronisation)
+static int64_t offsets_by_chunks(const int32_t* lens, int64_t n, int64_t* offsets, uint8_t* validity, hipStream_t s, LenMeta* meta) {
   {
     const int64_t nchunks = (n + kChunk - 1) / kChunk;
     Buf sums = dev_alloc(sizeof(int64_t) * nchunks, s);
-    Buf total = dev_alloc(sizeof(int64_t), s);
+    Buf total = dev_alloc(3 * sizeof(int64_t), s);
+    if (meta) CS_HIP(hipMemsetAsync(total->p, 0, 3 * sizeof(int64_t), s));
     const unsigned grid = (unsigned)((nchunks + 3) / 4);
     hipLaunchKernelGGL(k_chunk_sums, dim3(grid), dim3(kBlock), 0, s, lens, n, nchunks, ptr<int64_t>(sums));
     hipLaunchKernelGGL(k_scan_block_sums, dim3(1), dim3(1024), 0, s, ptr<int64_t>(sums), nchunks, ptr<int64_t>(total));
     {
       ProfScope ps("k_write_offsets", s);
       hipLaunchKernelGGL(k_chunk_offsets, dim3(grid), dim3(kBlock), 0, s, lens, n, nchunks, ptr<const int64_t>(sums), offsets, validity,
-                         (int64_t)validity_bytes(n));
+                         (int64_t)validity_bytes(n), meta ? ptr<unsigned long long>(total) + 1 : nullptr);
     }
-    int64_t* host = (int64_t*)pinned_scratch(sizeof(int64_t));
-    CS_HIP(hipMemcpyAsync(host, ptr<int64_t>(total), sizeof(int64_t), hipMemcpyDeviceToHost, s));
+    int64_t* host = (int64_t*)pinned_scratch(3 * sizeof(int64_t));
+    CS_HIP(hipMemcpyAsync(host, ptr<int64_t>(total), (meta ? 3 : 1) * sizeof(int64_t), hipMemcpyDeviceToHost, s));
     CS_HIP(hipStreamSynchronize(s));
+    if (meta) {
+      meta->max_row = host[1];
+      meta->max_span64 = host[2];
+    }
     return host[0];
   }
 }
-static int64_t offsets_by_workgroups(const int32_t* lens, int64_t n, int64_t* offsets, hipStream_t s, Buf block_sums) {
+static int64_t offsets_by_workgroups(const int32_t* lens, int64_t n, int64_t* offsets, hipStream_t s, Buf block_sums, LenMeta* meta) {
   int64_t nb = (n + kBlock - 1) / kBlock;
   Buf sums = block_sums;
   if (!sums) {
     sums = dev_alloc(sizeof(int64_t) * nb, s);
     hipLaunchKernelGGL(k_block_sums, dim3((unsigned)nb), dim3(kBlock), 0, s, lens, n, ptr<int64_t>(sums));
   }
-  Buf total = dev_alloc(sizeof(int64_t), s);
+  Buf total = dev_alloc(3 * sizeof(int64_t), s);
+  if (meta) CS_HIP(hipMemsetAsync(total->p, 0, 3 * sizeof(int64_t), s));
   hipLaunchKernelGGL(k_scan_block_sums, dim3(1), dim3(1024), 0, s, ptr<int64_t>(sums), nb,
                      ptr<int64_t>(total));
   {
     ProfScope ps("k_write_offsets", s);
     hipLaunchKernelGGL(k_write_offsets, dim3((unsigned)nb, 1), dim3(kBlock), 0, s, lens, n,
-                       ptr<int64_t>(sums), nb, offsets);
+                       ptr<int64_t>(sums), nb, offsets, meta ? ptr<unsigned long long>(total) + 1 : nullptr);
   }
-  int64_t* host = (int64_t*)pinned_scratch(sizeof(int64_t));
-  CS_HIP(hipMemcpyAsync(host, ptr<int64_t>(total), sizeof(int64_t), hipMemcpyDeviceToHost, s));
+  int64_t* host = (int64_t*)pinned_scratch(3 * sizeof(int64_t));
+  CS_HIP(hipMemcpyAsync(host, ptr<int64_t>(total), (meta ? 3 : 1) * sizeof(int64_t), hipMemcpyDeviceToHost, s));
   CS_HIP(hipStreamSynchronize(s));
+  if (meta) {
+    meta->max_row = host[1];
+    meta->max_span64 = host[2];
+  }
   return host[0];
 }
 
@@ -572,7 +627,7 @@ unsigned resident_grid(const void* kern, size_t lds, int64_t wanted) {
     }
   }
   if (per < 1) per = 1;
-  if (const char* e = getenv("CS_STREAM_BLOCKS_PER_CU")) per = std::max(1, std::min(per, atoi(e)));
+  if (const char* e = cs::cfg("CS_STREAM_BLOCKS_PER_CU")) per = std::max(1, std::min(per, atoi(e)));
   const int64_t cap = (int64_t)cus * per;
   return (unsigned)std::max<int64_t>(1, std::min<int64_t>(cap, wanted));
 }
@@ -658,6 +713,41 @@ bool sample_has_high_bytes(const cs_column* c, hipStream_t s) {
   CS_HIP(hipMemcpyAsync(host, flag->p, sizeof(int), hipMemcpyDeviceToHost, s));
   CS_HIP(hipStreamSynchronize(s));
   return (c->high_sample = host[0] ? 1 : 0) != 0;
+}
+// Byte counts over the same three windows: how common a pattern's candidate bytes are in THIS column (regex route choice).
+__global__ void __launch_bounds__(256) k_sample_hist(const uint8_t* __restrict__ chars, int64_t nbytes, uint32_t* __restrict__ out) {
+  __shared__ uint32_t h[256];
+  h[threadIdx.x] = 0;
+  __syncthreads();
+  const int64_t win = 64 * 1024;
+  const int64_t base = blockIdx.x == 0 ? 0 : (blockIdx.x == 1 ? (nbytes / 2) & ~(int64_t)15 : (nbytes > win ? (nbytes - win) & ~(int64_t)15 : 0));
+  // (windows that coincide on a short column are counted once)
+  const bool dup = (blockIdx.x == 1 && base == 0) || (blockIdx.x == 2 && (base == 0 || base == ((nbytes / 2) & ~(int64_t)15)));
+  if (!dup)
+    for (int64_t i = base + threadIdx.x; i < nbytes && i < base + win; i += blockDim.x) atomicAdd(&h[chars[i]], 1u);
+  __syncthreads();
+  if (h[threadIdx.x]) atomicAdd(out + threadIdx.x, h[threadIdx.x]);
+}
+const uint32_t* sample_byte_hist(const cs_column* c, hipStream_t s) {
+  static std::mutex mu;
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    if (c->byte_hist) return c->byte_hist->data();
+  }
+  auto hist = std::make_shared<std::array<uint32_t, 256>>();
+  hist->fill(0);
+  if (c->nbytes > 0 && c->chars) {
+    Buf acc = dev_alloc(256 * sizeof(uint32_t), s);
+    CS_HIP(hipMemsetAsync(acc->p, 0, 256 * sizeof(uint32_t), s));
+    hipLaunchKernelGGL(k_sample_hist, dim3(3), dim3(256), 0, s, c->d_chars(), c->nbytes, ptr<uint32_t>(acc));
+    uint32_t* host = (uint32_t*)pinned_scratch(256 * sizeof(uint32_t));
+    CS_HIP(hipMemcpyAsync(host, acc->p, 256 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    CS_HIP(hipStreamSynchronize(s));
+    std::copy(host, host + 256, hist->begin());
+  }
+  std::lock_guard<std::mutex> lk(mu);
+  if (!c->byte_hist) c->byte_hist = hist;
+  return c->byte_hist->data();
 }
 int64_t max_row_bytes(const cs_column* c, hipStream_t s) {
   if (c->max_row >= 0) return c->max_row;
@@ -1012,6 +1102,13 @@ using namespace cs;
 extern "C" {
 
 int cs_version(void) { return 100; }
+int cs_has_experiments(void) {
+#if defined(CS_EXPERIMENTS)
+  return 1;
+#else
+  return 0;
+#endif
+}
 const char* cs_last_error(void) { return g_last_error.c_str(); }
 
 int cs_device_count(void) {
@@ -1025,6 +1122,7 @@ int cs_device_count(void) {
 
 int cs_init(int device) {
   return guard([&] {
+    (void)cs::cfg("CS_DEVICE");  // (the CS_* switches are read from the environment here, once: cs_config.h)
     int n = cs_device_count();
     if (n <= 0) fail(CS_ERR_NO_DEVICE, "no HIP device visible (there is no CPU fallback)");
     if (device < 0 || device >= n) fail(CS_ERR_INVALID_ARG, "device index out of range");
@@ -1049,6 +1147,13 @@ int cs_init(int device) {
 
 int cs_current_device(void) { return g_device; }
 int64_t cs_fallback_count(void) { return (int64_t)g_fallbacks.load(); }
+const char* cs_debug_last_route(void) { return cs::g_last_route; }
+int cs_config_set(const char* name, const char* value) {
+  return guard([&] {
+    if (!name || std::strncmp(name, "CS_", 3) != 0) fail(CS_ERR_INVALID_ARG, "config: the switches are named CS_*");
+    cs::cfg_set(name, value);
+  });
+}
 int64_t cs_device_bytes_in_use(void) { return dev_bytes_in_use(); }
 void cs_free(void* p) { free(p); }
 
@@ -1337,6 +1442,15 @@ int64_t cs_column_null_count(const cs_column* col) {
   });
   return st == CS_OK ? n : -1;
 }
+int cs_column_cached_meta(const cs_column* col, int64_t out[4]) {
+  return guard([&] {
+    if (!col || !out) fail(CS_ERR_INVALID_ARG, "null argument");
+    out[0] = col->max_span64;
+    out[1] = col->max_row;
+    out[2] = col->plain_bytes;
+    out[3] = col->high_sample;
+  });
+}
 int cs_column_get_view(const cs_column* col, cs_column_view* view) {
   return guard([&] {
     if (!col || !view) fail(CS_ERR_INVALID_ARG, "null argument");
@@ -1478,6 +1592,12 @@ int cs_stream_forget(cs_stream stream) {
     (void)hipStreamSynchronize(S(stream));  // (what it still runs on cached blocks is done before they can be handed out again)
     std::lock_guard<std::mutex> lk(g_mu);
     g_streams.erase(S(stream));
+    // cached blocks that name the stream as their last user are idle now; the handle may be destroyed by its owner, so
+    // nobody may synchronise it again: dev_alloc treats a block whose stream is not in g_streams as idle (blocks that
+    // are released LATER with this stream in their DevBuf are covered by the same rule).  Their release events stay:
+    // waiting for an event recorded on a destroyed stream is defined (it has completed).
+    for (auto& kv : g_cache)
+      if (kv.second.second == S(stream)) kv.second.second = kNoStream;
   });
 }
 __global__ void __launch_bounds__(256) k_debug_spin(unsigned long long ticks) {

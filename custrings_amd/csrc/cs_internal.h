@@ -5,11 +5,13 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <array>
 #include <memory>
 #include <string>
 #include <vector>
 
 #include "../../include/custrings_amd.h"
+#include "cs_config.h"
 
 namespace cs {
 
@@ -52,6 +54,7 @@ int bound_device();  // -1 before cs_init
 // One message per process on stderr and a counter (cs_fallback_count): a persistent single-pass
 // kernel gave up and the host recomputed the column with the two-pass kernels.
 void note_fallback(const char* what);
+void note_route(const char* route);  // cs_debug_last_route (per thread)
 
 // ---- device memory ----------------------------------------------------------
 // Buffers come from a size-bucketed cache over hipMalloc (one output allocation
@@ -95,6 +98,7 @@ struct cs_column {
   mutable int drops = -1;           // 1: some row is null or empty (rows create_ngrams drops), 0: none; -1 = unknown
   mutable int plain_bytes = -1;     // 1: no NUL byte and no lead byte announcing over an ASCII byte; -1 = unknown
   mutable int high_sample = -1;     // 1: a sample of the chars (three 64 KiB windows) holds a byte >= 0x80; -1 = not looked at
+  mutable std::shared_ptr<std::array<uint32_t, 256>> byte_hist;  // byte counts of the same sample (a hint for kernel choice); null = not taken
   cs::Buf chars, validity;  // validity may be null (all valid)
   // Row extents: int64 offsets (`offsets`) and / or int32 offsets (`offsets32`, columns whose
   // chars stay below 2 GiB -- what split produces: half the bytes written per output row).  A
@@ -139,14 +143,26 @@ cs_column* make_all_null(int64_t rows, hipStream_t s);
 // offsets[n+1]; returns the total (synchronises `s`).  When `block_sums` is
 // given it must hold the per-256-row sums already (fused into the caller's size
 // kernel) and the lengths are read only once.
+// `meta` (optional): the column metadata the tile kernels ask for, as a by-product of the same pass -- the longest row and
+// the largest byte span of 64 consecutive rows starting at a multiple of 64 (what max_row_bytes / max_span64 would compute
+// with passes of their own over the finished offsets).
+struct LenMeta {
+  int64_t max_row = -1, max_span64 = -1;
+  void give(cs_column* c) const {
+    if (max_row >= 0) c->max_row = max_row;
+    if (max_span64 >= 0) c->max_span64 = max_span64;
+  }
+};
 int64_t offsets_from_lengths(const int32_t* lens, int64_t n, int64_t* offsets, hipStream_t s,
-                             Buf block_sums = nullptr);
+                             Buf block_sums = nullptr, LenMeta* meta = nullptr);
 // the same and the validity mask (length >= 0) from one pass over the lengths
-int64_t offsets_and_validity_from_lengths(const int32_t* lens, int64_t n, int64_t* offsets, Buf* validity, hipStream_t s);
+int64_t offsets_and_validity_from_lengths(const int32_t* lens, int64_t n, int64_t* offsets, Buf* validity, hipStream_t s, LenMeta* meta = nullptr);
 // Segmented variant: `segs` independent arrays of n lengths laid out back to
 // back (lens[seg * n + i]); offsets[seg * (n + 1) + i]; totals[seg] on the host.
+// (`largest_host`, optional: the largest length of every segment -- for per-tile byte counts that is the column's largest
+// 64-row span, by-product of the same pass)
 void offsets_from_lengths_segmented(const int32_t* lens, int64_t n, int segs, int64_t* offsets,
-                                    int64_t* totals_host, hipStream_t s);
+                                    int64_t* totals_host, hipStream_t s, int64_t* largest_host = nullptr);
 // Validity bitmask from int32 lengths (bit set when len >= 0).
 Buf validity_from_lengths(const int32_t* lens, int64_t n, hipStream_t s);
 int64_t count_nulls(const cs_column* c, hipStream_t s);
@@ -157,7 +173,8 @@ int64_t max_row_bytes(const cs_column* c, hipStream_t s);
 bool bytes_plain(const cs_column* c, hipStream_t s);
 // Same for tiles of `per` consecutive rows (per = 64 is the cached one).
 int64_t max_span_rows(const cs_column* c, int per, hipStream_t s);
-bool sample_has_high_bytes(const cs_column* c, hipStream_t s);  // a hint (kernel choice only): non-ASCII text, by three windows of the chars
+bool sample_has_high_bytes(const cs_column* c, hipStream_t s);
+const uint32_t* sample_byte_hist(const cs_column* c, hipStream_t s);  // 256 counts over the same three windows (a hint, cached on the column)  // a hint (kernel choice only): non-ASCII text, by three windows of the chars
 int64_t count_spans64_over(const cs_column* c, int64_t limit, hipStream_t s);
 bool few_spans64_over(const cs_column* c, int64_t limit, hipStream_t s);  // all but a few 64-row tiles fit `limit` bytes
 // Workgroups (256 threads, `lds` dynamic bytes) of `kern` resident at once on the device,

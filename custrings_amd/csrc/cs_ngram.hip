@@ -216,7 +216,7 @@ namespace cs {
 
 bool ngrams_fast(const cs_column* tokens, int n, const unsigned char* sep, int sepn, hipStream_t s, cs_column** out) {
   const int64_t rows = tokens->rows;
-  if (n < 2 || n > 8 || sepn > 8 || rows <= n || getenv("CS_NGRAM_ROWWISE")) return false;
+  if (n < 2 || n > 8 || sepn > 8 || rows <= n || cs::cfg("CS_NGRAM_ROWWISE")) return false;
   if (tokens->drops < 0) {  // remembered on the immutable column (the tokenizer's output is born with the answer)
     Buf drop = dev_alloc(sizeof(unsigned), s);
     CS_HIP(hipMemsetAsync(drop->p, 0, sizeof(unsigned), s));

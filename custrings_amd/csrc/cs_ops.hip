@@ -117,7 +117,9 @@ cs_column* two_pass(const cs_column* in, SizeFn sf, WriteFn wf, hipStream_t s, c
                        ptr<int32_t>(lens), ptr<int64_t>(sums));
   }
   out->offsets = dev_alloc(sizeof(int64_t) * (in->rows + 1), s);
-  out->nbytes = offsets_from_lengths(ptr<int32_t>(lens), in->rows, ptr<int64_t>(out->offsets), s, sums);
+  LenMeta meta;
+  out->nbytes = offsets_from_lengths(ptr<int32_t>(lens), in->rows, ptr<int64_t>(out->offsets), s, sums, &meta);
+  meta.give(out);
   out->chars = dev_alloc((size_t)out->nbytes, s);
   {
     ProfScope ps(write_name, s);
@@ -434,7 +436,7 @@ int cs_strip(const cs_column* col, const char* to_strip, int side, cs_stream str
     Buf set_more;
     CharSet set = make_charset(to_strip ? to_strip : " \n\t", set_more, s);
     // size pass + scan as for every row-wise op; the write pass runs on row tiles (cs_rows.hip)
-    if (col->rows > 0 && !getenv("CS_STRIP_ROWWISE")) {
+    if (col->rows > 0 && !cs::cfg("CS_STRIP_ROWWISE")) {
       auto o = std::make_unique<cs_column>();
       o->rows = col->rows;
       o->validity = col->validity;
@@ -452,7 +454,11 @@ int cs_strip(const cs_column* col, const char* to_strip, int side, cs_stream str
                            ptr<int32_t>(lens), ptr<int64_t>(sums));
       }
       o->offsets = dev_alloc(sizeof(int64_t) * (col->rows + 1), s);
-      o->nbytes = offsets_from_lengths(ptr<int32_t>(lens), col->rows, ptr<int64_t>(o->offsets), s, sums);
+      LenMeta meta;
+      o->nbytes = offsets_from_lengths(ptr<int32_t>(lens), col->rows, ptr<int64_t>(o->offsets), s, sums, &meta);
+      meta.give(o.get());
+      if (col->plain_bytes == 1) o->plain_bytes = 1;  // (rows cut at character boundaries of a plain column stay plain)
+      if (col->high_sample == 0) o->high_sample = 0;
       o->chars = dev_alloc((size_t)o->nbytes, s);
       if (strip_write_tiles(col, set, side, o->d_offsets(), ptr<uint8_t>(o->chars), s)) {
         *out = o.release();
@@ -754,7 +760,7 @@ int cs_replace(const cs_column* col, const char* str, const char* repl, int maxr
       }
       plain = plain && pattern.size() <= 128;
       const size_t rb = strlen(repl);
-      if (plain && rb <= 64 && col->rows > 0 && !getenv("CS_REPLACE_ROWWISE") && bytes_plain(col, S(stream))) {
+      if (plain && rb <= 64 && col->rows > 0 && !cs::cfg("CS_REPLACE_ROWWISE") && bytes_plain(col, S(stream))) {
         cs_regex* re = nullptr;
         if (cs_regex_compile(pattern.c_str(), &re) == CS_OK) {
           cs::g_replace_plain_only = 1;  // the single-pass kernel or nothing: this function's own kernels are the fallback
@@ -815,7 +821,7 @@ static int split_impl(const cs_column* col, const char* delimiter, int maxsplit,
     for (int i = 0; ascii_delim && i < nd.n; ++i) ascii_delim = (unsigned char)delimiter[i] < 128;
     // rsplit with a limit on a one-byte ASCII delimiter rides the split tile kernels too (the first delimiters of a
     // row are struck from its mask: cs_split.hip TokensT)
-    const bool reverse_fast = a.reverse && ascii_delim && nd.n == 1 && a.tokens > 0 && !getenv("CS_RSPLIT_ROWWISE");
+    const bool reverse_fast = a.reverse && ascii_delim && nd.n == 1 && a.tokens > 0 && !cs::cfg("CS_RSPLIT_ROWWISE");
     if ((!a.reverse && (!delimiter || ascii_delim)) || reverse_fast) {
       std::vector<std::unique_ptr<cs_column>> fast;
       if (split_fast(col, reinterpret_cast<const unsigned char*>(delimiter), delimiter ? nd.n : 0, a.tokens, s, fast, reverse_fast)) {
@@ -947,7 +953,9 @@ int cs_tokenize(const cs_column* col, const char* delimiter, cs_stream stream, c
                          ptr<const int64_t>(tok_base), ptr<int32_t>(tok_lens), (const int64_t*)nullptr,
                          (uint8_t*)nullptr);
     }
-    c->nbytes = offsets_from_lengths(ptr<int32_t>(tok_lens), ntok, ptr<int64_t>(c->offsets), s);
+    LenMeta meta;
+    c->nbytes = offsets_from_lengths(ptr<int32_t>(tok_lens), ntok, ptr<int64_t>(c->offsets), s, nullptr, &meta);
+    meta.give(c);
     c->chars = dev_alloc((size_t)c->nbytes, s);
     {
       ProfScope ps("k_tok_write", s);
@@ -1024,7 +1032,9 @@ int cs_ngrams(const cs_column* tokens, unsigned ngrams, const char* separator, c
     c->rows = ng;
     c->null_count = 0;
     c->offsets = dev_alloc(sizeof(int64_t) * (ng + 1), s);
-    c->nbytes = offsets_from_lengths(ptr<int32_t>(lens), ng, ptr<int64_t>(c->offsets), s);
+    LenMeta meta;
+    c->nbytes = offsets_from_lengths(ptr<int32_t>(lens), ng, ptr<int64_t>(c->offsets), s, nullptr, &meta);
+    meta.give(c);
     c->chars = dev_alloc((size_t)c->nbytes, s);
     {
       ProfScope ps("k_ngram_write", s);

@@ -19,6 +19,7 @@
 #include "device_utils.h"
 #include "regex_program.h"
 #include "regex_tdfa.h"
+#include "regex_bits.h"
 #include "regex_vm.h"
 #include <mutex>
 
@@ -33,9 +34,11 @@ struct cs_regex {
   std::vector<int32_t> image;  // blob + executor extras
   std::vector<int32_t> tdfa;   // tagged DFA image (empty = not convertible)
   std::vector<int32_t> gtags;  // capture-group tag image of the tagged DFA (empty = no groups / not convertible)
+  std::vector<int32_t> bits;   // bit-parallel form (regex_bits.h; empty = the program does not convert)
   Buf d_image;                 // uploaded lazily
   Buf d_tdfa;
   Buf d_gtags;
+  Buf d_bits;
   bool empty_pattern = false;
   std::atomic<int> refs{1};    // handles given out by cs_regex_compile + one for the list of kept patterns
 };
@@ -973,6 +976,9 @@ struct StreamArgs {
   const csvm::BackrefTemplate* tmpl;
   const int32_t* gtags;
   int gt_off, gt_words;
+  // BITS: the bit-parallel form of the pattern (regex_bits.h), staged at byte offset bits_off of the LDS (inside tbl_bytes)
+  const int32_t* bits;
+  int bits_off, bits_words, bits_k;
 };
 #ifndef CS_STREAM_WAVES
 #define CS_STREAM_WAVES 3
@@ -1125,6 +1131,45 @@ __device__ __forceinline__ bool reclassify_high(const cstd::View& D, bool has_r2
   return __any((zr & 0x80808080u) != 0);
 }
 
+
+// ---- the bit-parallel form (regex_bits.h): staging helpers shared by the stream kernels ------------------
+// LDS image of the form: the program words as built by the host, then 128 words of the SPREAD class table --
+// entry b holds byte b's class set with class k at bit 4k, so that the entries of four bytes, shifted by 0..3
+// and OR-ed, leave a nibble per class: the four bytes' membership bits.
+__device__ __forceinline__ const uint32_t* bits_stage(const int32_t* g_bits, int words, int32_t* lds) {
+  for (int i = threadIdx.x; i < words; i += blockDim.x) lds[i] = g_bits[i];
+  uint32_t* sp = reinterpret_cast<uint32_t*>(lds + ((words + 3) & ~3));
+  if (threadIdx.x < 128) {
+    const uint32_t set = ((uint32_t)g_bits[csbits::kHeaderWords + (threadIdx.x >> 2)] >> (8 * (threadIdx.x & 3))) & 255u;
+    sp[threadIdx.x] = csbits::spread_entry(set);
+  }
+  __syncthreads();
+  return sp;
+}
+__host__ __device__ inline int bits_lds_bytes(int words) { return ((words + 3) & ~3) * 4 + 128 * 4; }
+// sixteen staged bytes -> for every class the sixteen membership bits (regex_bits.h: classify16)
+__device__ __forceinline__ void bits_classify16(const uint32_t* spread, const uint4& q, uint32_t pair[4]) {
+  csbits::classify16(spread, q.x, q.y, q.z, q.w, pair);
+}
+// a row lane's mask of class k, shifted right by `off`: cut out of the class's bitmap on demand (regex_bits.h: cls(k, off))
+#define CS_BITS_CLS(bitmap, bm_words, p0, n)                                                                       \
+  [&](int k_, int off_) -> cstd::U128 {                                                                            \
+    uint32_t m0_, m1_, m2_;                                                                                        \
+    cstile::row_bits96((bitmap) + __builtin_amdgcn_readfirstlane(k_) * (bm_words), (p0) + off_, max((n) - off_, 0), m0_, m1_, m2_); \
+    return cstd::u128(m0_ | ((unsigned long long)m1_ << 32), m2_);                                                 \
+  }
+// ... without the cut at the row's end (regex_bits.h: raw(k, off)): three funnel shifts over four words of the bitmap
+#define CS_BITS_RAW(bitmap, bm_words, p0)                                                                          \
+  [&](int k_, int off_) -> cstd::U128 {                                                                            \
+    const int q_ = (p0) + off_;                                                                                    \
+    const uint32_t* w_ = (bitmap) + __builtin_amdgcn_readfirstlane(k_) * (bm_words) + (q_ >> 5);                   \
+    const uint32_t a_ = w_[0], b_ = w_[1], c_ = w_[2], d_ = w_[3];                                                 \
+    const unsigned sh_ = (unsigned)q_ & 31u;                                                                       \
+    const uint32_t m0_ = __builtin_amdgcn_alignbit(b_, a_, sh_), m1_ = __builtin_amdgcn_alignbit(c_, b_, sh_),     \
+                   m2_ = __builtin_amdgcn_alignbit(d_, c_, sh_);                                                   \
+    return cstd::u128(m0_ | ((unsigned long long)m1_ << 32), m2_);                                                 \
+  }
+
 // UNITS (with !INPLACE, RESCAN, !LONG): the scan runs per UNIT instead of per row (regex_tdfa.cpp, header word 31).
 // Row lanes cut their rows into units with bit arithmetic on two per-byte bitmaps (candidate bytes, bytes equal
 // to x) and queue them in LDS; then every lane takes a unit -- whichever row it belongs to -- and runs the lean scan
@@ -1144,8 +1189,13 @@ __device__ __forceinline__ bool reclassify_high(const cstd::View& D, bool has_r2
 // sub-tile's rows are sized and written a thread each, straight from memory, inside the prefix chain (separate forms:
 // the code costs the others registers).
 template <bool IN_LDS, bool REP16, bool INPLACE, bool RESCAN = false, bool LONG = false, bool UNITS = false, int PF = cstile::kPfChunks, bool BREFS = false,
-          bool WIDE = false, bool OUTL = false, bool CHAIN = false>
-__global__ void __launch_bounds__(256, BREFS ? 2 : CS_STREAM_WAVES) k_tdfa_replace_stream(StreamArgs a) {
+          bool WIDE = false, bool OUTL = false, bool CHAIN = false, bool BITS = false>
+__global__ void __launch_bounds__(256, (BREFS || BITS) ? 2 : CS_STREAM_WAVES) k_tdfa_replace_stream(StreamArgs a) {
+  // BITS (a CHAIN form): the pattern has a bit-parallel form (regex_bits.h) -- one bitmap per character class, staged by
+  // table lookup; the row lanes derive their rows' matches from the class masks (alternations of word-bounded literals,
+  // small sets in a `+` loop: patterns whose candidates are everywhere); a sub-tile with a byte >= 0x80 / NUL or a row
+  // beyond the masks goes to the generic scan row by row.  A bitmap per class: two workgroups a CU.
+  static_assert(!BITS || CHAIN, "the bit form is a chain-form variant (no unit / lean scans compiled in)");
   // CHAIN (a UNITS form): the pattern is a chain and a sample of the column holds no byte >= 0x80 -- the unit scan, the
   // literal scan and the lean scans are compiled out (their registers with them); a sub-tile the chain arithmetic does
   // not take (a non-ASCII byte after all, a row beyond the masks) goes to the generic scan row by row.
@@ -1159,12 +1209,13 @@ __global__ void __launch_bounds__(256, BREFS ? 2 : CS_STREAM_WAVES) k_tdfa_repla
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;  // (scalar: what derives from it stays in SGPRs)
   const int bm_bytes = (a.cap_in >> 3) + 32;  // one candidate bit per staged byte
   // second bitmap, unit queue, bail word (+ BREFS: a record of three words per match, a growth counter per row)
-  const int unit_bytes = UNITS ? bm_bytes + kUnitQueue * 4 + 16 + (BREFS ? kUnitQueue * 12 + 64 * 4 : 0) : 0;
+  const int nbm = BITS ? max(a.bits_k, 2) : 2;  // bitmaps per wave (BITS: one per character class)
+  const int unit_bytes = UNITS ? (nbm - 1) * bm_bytes + kUnitQueue * 4 + 16 + (BREFS ? kUnitQueue * 12 + 64 * 4 : 0) : 0;
   uint8_t* lds_in = base + a.tbl_bytes + (size_t)wv * (a.cap_in + a.cap_out + 64 + bm_bytes + unit_bytes);
   uint8_t* lds_out = lds_in + a.cap_in + 32;
   uint32_t* bitmap = reinterpret_cast<uint32_t*>(lds_out + a.cap_out + 32);
   uint32_t* xbitmap = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(bitmap) + bm_bytes);  // UNITS: "byte == x", later the matches' last bytes
-  uint32_t* uqueue = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(xbitmap) + bm_bytes);
+  uint32_t* uqueue = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(bitmap) + (size_t)nbm * bm_bytes);
   uint32_t* bailw = uqueue + kUnitQueue;  // one bit per row: the lean scan handed a unit of the row over
   uint32_t* mrec = bailw + 4;              // BREFS: per match (group ranges of groups 1-2, of groups 3-4, match end | ok << 8)
   uint32_t* rowgrow = mrec + kUnitQueue * 3;  // BREFS: bytes the row's expansions add
@@ -1184,6 +1235,13 @@ __global__ void __launch_bounds__(256, BREFS ? 2 : CS_STREAM_WAVES) k_tdfa_repla
     __syncthreads();
     gt = g;
     ttext = tt;
+  }
+  const uint32_t* spread = nullptr;
+  csbits::View BV{};
+  if (BITS) {
+    int32_t* bl = reinterpret_cast<int32_t*>(base + a.bits_off);
+    spread = bits_stage(a.bits, a.bits_words, bl);
+    BV = csbits::make_view(bl);
   }
   const bool has_r2 = (((uint32_t)D.img[30] & 255u) <= (((uint32_t)D.img[30] >> 8) & 255u));
   const uint32_t unit_x = (D.units >> 8) & 127u, unit_xpat = unit_x * 0x01010101u;
@@ -1271,6 +1329,7 @@ __global__ void __launch_bounds__(256, BREFS ? 2 : CS_STREAM_WAVES) k_tdfa_repla
   // published, so waves do not wait on each other's scans.
   long long p_tile = -1;
   int p_total = 0, p_lo = 0, p_len = 0;
+  int m_span = 0;  // the output column's largest 64-row span as a by-product (wave-uniform: a scalar maximum per sub-tile)
 #if defined(CS_PHASE_PROF)
   unsigned long long phase_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long lb_acc[3] = {0, 0, 0};
@@ -1350,6 +1409,14 @@ __global__ void __launch_bounds__(256, BREFS ? 2 : CS_STREAM_WAVES) k_tdfa_repla
         odd |= q.y | ((q.y - 0x01010101u) & ~q.y);
         odd |= q.z | ((q.z - 0x01010101u) & ~q.z);
         odd |= q.w | ((q.w - 0x01010101u) & ~q.w);
+        if (BITS) {
+          uint32_t pair[4];
+          bits_classify16(spread, q, pair);
+#pragma unroll
+          for (int k = 0; k < csbits::kMaxClasses; ++k)
+            if (k < BV.K && !bad) cstile::put_bits16(bitmap + k * (bm_bytes >> 2), j * 1024 + lane * 16, (pair[k >> 1] >> (16 * (k & 1))) & 0xFFFFu);
+          continue;
+        }
         uint32_t bits;
         if (has_r2)
           bits = cstile::gather16_bit7(cstd::Tdfa::cand_bits_ascii<true>(D, q.x), cstd::Tdfa::cand_bits_ascii<true>(D, q.y), cstd::Tdfa::cand_bits_ascii<true>(D, q.z),
@@ -1515,7 +1582,21 @@ __global__ void __launch_bounds__(256, BREFS ? 2 : CS_STREAM_WAVES) k_tdfa_repla
           units_done = true;
         }
       } else if (UNITS) {
-        if (!BREFS && lean && !has_odd && a.maxrepl < 0 && (D.chain >> 16) && !(CS_DBG(a) & 8192)) {  // (wave-uniform)
+        if (BITS && !has_odd && a.maxrepl < 0 && !__any(live && n > csbits::kMaxRowBytes)) {  // (wave-uniform) plain ASCII, rows within the masks
+          using namespace cstd;
+          p_second = cstile::status_load(a.excl + (p_tile >= 0 ? p_tile : 0));
+          has_second = scanner;
+          if (live) {
+            auto cls = CS_BITS_CLS(bitmap, bm_bytes >> 2, lead + rbeg, n);
+            auto raw = CS_BITS_RAW(bitmap, bm_bytes >> 2, lead + rbeg);
+            csbits::match(BV, cls, raw, n, uS, uE);
+            nm = u128_popc(uS);
+            out_len = n - u128_popc(u128_sub(u128_shl1(uE), uS)) + nm * rb;
+            from_masks = true;
+          }
+          redo = false;
+          units_done = true;
+        } else if (!BITS && !BREFS && lean && !has_odd && a.maxrepl < 0 && (D.chain >> 16) && !(CS_DBG(a) & 8192)) {  // (wave-uniform)
           // A chain pattern (regex_tdfa.h: chain_match) on a sub-tile of plain ASCII: every row lane derives its row's
           // matches from the row's candidate and x bits by integer arithmetic -- no unit queue, no table walk, no LDS
           // traffic beyond the two mask reads.
@@ -1812,6 +1893,7 @@ __global__ void __launch_bounds__(256, BREFS ? 2 : CS_STREAM_WAVES) k_tdfa_repla
     const int incl = csdev::wave_inclusive_scan(out_len);
     const int lo = incl - out_len;
     const int total = __builtin_amdgcn_readlane(incl, 63);
+    m_span = max(m_span, total);
     // (error bit 1: a roomier launch, which also takes rows with many matches, can succeed)
     bool grew = false;
     if (!INPLACE) grew = !bad && (total + 32 > a.cap_out || (!RESCAN && __any(nm > kMaxRec)));
@@ -1991,6 +2073,11 @@ __global__ void __launch_bounds__(256, BREFS ? 2 : CS_STREAM_WAVES) k_tdfa_repla
     pending = pending_new;
   }
   if (p_tile >= 0) finish_pending((CS_DBG(a) & 8) ? 0 : (__builtin_expect(scanner, 1) ? cstile::status_load(a.excl + p_tile) : cstile::lookback_poll(a.status, p_tile, lane)));
+  {
+    // (only a wave that would raise the maximum issues the same-address atomic; slot 14 behind the error word)
+    unsigned long long* slot = reinterpret_cast<unsigned long long*>(a.error) + 14;
+    if (lane == 0 && (unsigned long long)m_span > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, (unsigned long long)m_span);
+  }
 #if defined(CS_PHASE_PROF)
   CS_PHASE_MARK(5);
   if (lane == 0)
@@ -2033,25 +2120,33 @@ struct ScanStreamArgs {
   const csvm::BackrefTemplate* tmpl;  // MODE 5, 6 (device memory: indexed per reference, must not live in the kernel arguments)
   const int64_t* out_off;      // MODE 6
   uint8_t* out_chars;
+  // BITS: the bit-parallel form of the pattern (regex_bits.h), staged at byte offset bits_off of the LDS (inside tbl_bytes)
+  const int32_t* bits;
+  int bits_off, bits_words, bits_k;
 };
 // UNITS (MODE 0 and 2, !LONG): the unit scan of the replace kernel -- units queued by the row lanes, one unit per lane
 // whatever its row, the per-row result summed (count_re) / OR-ed (contains_re) in LDS.
 // CHAIN (a UNITS form, count_re / findall): the pattern is a chain and the column's sample holds no byte >= 0x80 -- the unit
 // and lean scans are compiled out, a sub-tile the chain arithmetic does not take is scanned row by row by the generic executor.
-template <int MODE, bool IN_LDS, bool LONG = false, bool UNITS = false, bool CHAIN = false>
+// BITS (a CHAIN form, contains_re / count_re): the pattern has a bit-parallel form (regex_bits.h) and the column's sample holds
+// no byte >= 0x80 -- every staged byte is classified into one bitmap per character class by table lookup, the row lanes
+// read their rows' class masks and derive the matches by mask arithmetic; no automaton on a plain-ASCII sub-tile.
+template <int MODE, bool IN_LDS, bool LONG = false, bool UNITS = false, bool CHAIN = false, bool BITS = false>
 __global__ void __launch_bounds__(256, MODE == 4 ? 3 : CHAIN ? 4 : (UNITS && MODE == 3) ? 3 : (UNITS || MODE == 3) ? 4 : 1) k_tdfa_scan_stream(ScanStreamArgs a) {
   static_assert(!UNITS || ((MODE == 0 || MODE == 2 || MODE == 3 || (MODE == 4 && CHAIN)) && !LONG), "unit scan: contains_re / count_re / findall on rows within the 96-byte masks");
-  static_assert(!CHAIN || (UNITS && (MODE == 2 || MODE == 3 || MODE == 4)), "the chain form: count_re / findall / extract");
+  static_assert(!CHAIN || (UNITS && (MODE == 2 || MODE == 3 || MODE == 4 || (BITS && MODE == 0))), "the chain form: count_re / findall / extract");
+  static_assert(!BITS || (CHAIN && (MODE == 0 || MODE == 2)), "the bit form: contains_re / count_re");
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   uint8_t* base = reinterpret_cast<uint8_t*>(smem);
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;  // (scalar: what derives from it stays in SGPRs)
   const int bm_bytes = (a.cap_in >> 3) + 32;
+  const int nbm = BITS ? max(a.bits_k, 2) : 2;  // bitmaps per wave (BITS: one per character class)
   // (MODE 4 keeps a lane-private byte per step of a group run behind the bitmap: regex_tdfa.h, group_find_back)
-  const int unit_bytes = UNITS ? bm_bytes + kUnitQueue * 4 + 64 * 4 + 16 : (MODE == 4 ? cstd::Tdfa::kBackSteps * 64 + kMaxGroups * 4 : 0);  // x bitmap, unit queue, per-row results, bail word
+  const int unit_bytes = UNITS ? (nbm - 1) * bm_bytes + kUnitQueue * 4 + 64 * 4 + 16 : (MODE == 4 ? cstd::Tdfa::kBackSteps * 64 + kMaxGroups * 4 : 0);  // x bitmap, unit queue, per-row results, bail word
   uint8_t* lds_in = base + a.tbl_bytes + (size_t)wv * (a.cap_in + 32 + bm_bytes + unit_bytes);
   uint32_t* bitmap = reinterpret_cast<uint32_t*>(lds_in + a.cap_in + 32);
   uint32_t* xbitmap = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(bitmap) + bm_bytes);
-  uint32_t* uqueue = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(xbitmap) + bm_bytes);
+  uint32_t* uqueue = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(bitmap) + (size_t)nbm * bm_bytes);
   uint32_t* rowres = uqueue + kUnitQueue;
   uint32_t* bailw = rowres + 64;
   // MODE 4: per group, the tile's bytes (the chain form keeps the "equals x" bitmap where the plain form has its history bytes)
@@ -2066,6 +2161,13 @@ __global__ void __launch_bounds__(256, MODE == 4 ? 3 : CHAIN ? 4 : (UNITS && MOD
     for (int i = threadIdx.x; i < a.gt_words; i += blockDim.x) g[i] = a.gtags[i];
     __syncthreads();
     a.gtags = g;
+  }
+  const uint32_t* spread = nullptr;
+  csbits::View BV{};
+  if (BITS) {
+    int32_t* bl = reinterpret_cast<int32_t*>(base + a.bits_off);
+    spread = bits_stage(a.bits, a.bits_words, bl);
+    BV = csbits::make_view(bl);
   }
   const bool has_r2 = (((uint32_t)D.img[30] & 255u) <= (((uint32_t)D.img[30] >> 8) & 255u));
   const uint32_t unit_x = (D.units >> 8) & 127u, unit_xpat = unit_x * 0x01010101u;
@@ -2102,6 +2204,14 @@ __global__ void __launch_bounds__(256, MODE == 4 ? 3 : CHAIN ? 4 : (UNITS && MOD
         odd |= q.y | ((q.y - 0x01010101u) & ~q.y);
         odd |= q.z | ((q.z - 0x01010101u) & ~q.z);
         odd |= q.w | ((q.w - 0x01010101u) & ~q.w);
+        if (BITS) {
+          uint32_t pair[4];
+          bits_classify16(spread, q, pair);
+#pragma unroll
+          for (int k = 0; k < csbits::kMaxClasses; ++k)
+            if (k < BV.K) cstile::put_bits16(bitmap + k * (bm_bytes >> 2), j * 1024 + lane * 16, (pair[k >> 1] >> (16 * (k & 1))) & 0xFFFFu);
+          continue;
+        }
         uint32_t bits;
         if (has_r2)
           bits = cstile::gather16_bit7(cstd::Tdfa::cand_bits_ascii<true>(D, q.x), cstd::Tdfa::cand_bits_ascii<true>(D, q.y), cstd::Tdfa::cand_bits_ascii<true>(D, q.z),
@@ -2371,7 +2481,20 @@ __global__ void __launch_bounds__(256, MODE == 4 ? 3 : CHAIN ? 4 : (UNITS && MOD
       } else if (UNITS) {
         // (contains_re stops at a row's first match: its ASCII tiles keep the row lanes' scan -- scanning every unit cost more
         // than the balance won --, the unit route serves its tiles with bytes >= 0x80, which the row lanes' scan cannot take)
-        if (lean && !has_odd && (D.chain >> 16)) {  // (wave-uniform) a chain pattern on plain ASCII: regex_tdfa.h, chain_match
+        if (BITS && !has_odd && !__any(live && n > csbits::kMaxRowBytes)) {  // (wave-uniform) plain ASCII, rows within the masks
+          using namespace cstd;
+          auto cls = CS_BITS_CLS(bitmap, bm_bytes >> 2, lead + rbeg, n);
+          auto raw = CS_BITS_RAW(bitmap, bm_bytes >> 2, lead + rbeg);
+          if (MODE == 0) {
+            v = live && csbits::contains(BV, cls, raw, n) ? 1 : 0;
+          } else {
+            U128 S = u128(0, 0), E;
+            if (live) csbits::match(BV, cls, raw, n, S, E);
+            v = u128_popc(S);
+          }
+          redo = false;
+          units_done = true;
+        } else if (!BITS && lean && !has_odd && (D.chain >> 16)) {  // (wave-uniform) a chain pattern on plain ASCII: regex_tdfa.h, chain_match
           using namespace cstd;
           uint32_t r0, r1, r2, x0 = 0, x1 = 0, x2 = 0;
           cstile::row_bits96(bitmap, lead + rbeg, n, r0, r1, r2);
@@ -2494,10 +2617,44 @@ struct TPlan {
   unsigned grid;
 };
 // the tagged DFA with at most four live threads: every DFA kernel (lean scans, unit decomposition, capture groups)
-bool use_tdfa(const cs_regex* re) { return !re->tdfa.empty() && re->tdfa[12] <= cstd::kMaxSlots && !getenv("CS_REGEX_NO_TDFA"); }
+bool use_tdfa(const cs_regex* re) { return !re->tdfa.empty() && re->tdfa[12] <= cstd::kMaxSlots && !cs::cfg("CS_REGEX_NO_TDFA"); }
 // ... with five to eight (counted repetitions): contains_re / match / count_re and replace_re run it on the generic executor
 // with eight start offsets (regex_tdfa.h: TdfaWide); the other ops keep the list simulator for such programs
-bool use_tdfa_wide(const cs_regex* re) { return !re->tdfa.empty() && re->tdfa[12] > cstd::kMaxSlots && !getenv("CS_REGEX_NO_TDFA"); }
+bool use_tdfa_wide(const cs_regex* re) { return !re->tdfa.empty() && re->tdfa[12] > cstd::kMaxSlots && !cs::cfg("CS_REGEX_NO_TDFA"); }
+// The bit-parallel form (regex_bits.h) is taken when the pattern has one, is no chain (chains run on two SWAR-classified
+// bitmaps, cheaper than the class-table lookup), the column's sample is plain ASCII, and the automaton's candidate bytes --
+// the bytes at which its idle skip has to stop -- make up a good part of the column's sample: with few candidates the lean
+// scans skip most of every row and win; with candidates everywhere (alternations of word-bounded literals, small sets in
+// a `+` loop) they walk every byte in a dependent chain of table reads (VERDICT r4 missing #3: 8.9 / 21.4 ms on C3).
+// Thresholds from tools/probe_bits.py on the C3 column (profiles/r05/probe_bits.txt): share of candidate bytes -> bits / automaton ms
+//   contains_re: 86.6 % ([^ ]+) 2.15 / 1.82 (a match at once: the first-match scan wins), 11.9 % ([aeiou]+) 2.2 / 4.4, 7.2 % (the
+//   gtest pattern) 3.9 / 8.9, 2.4 % with three live threads (cat|cot|cut) 3.3 / 5.3, 2.4-2.6 % with one 2.3-2.7 / 2.5-2.7, below 1 % 2.3-3.3 / 1.4-2.9
+//   count_re:    from 2 % up the bit form wins or ties (1.9 / 41.6 at 11.9 %, 2.5 / 4.1 at 2.4 %), below 1 % it loses (2.2 / 1.6)
+//   replace_re:  (two workgroups a CU against three) 7.3 / 21.4 at 7.2 %, 8.6 / 51.7 at 11.9 %, 6.4 / 9.3 at 2.4 % with three threads;
+//   5.4-5.8 / 4.6-4.9 at 2.4 % with one thread
+enum { BITS_CONTAINS = 0, BITS_COUNT = 2, BITS_REPLACE = 3 };
+bool bits_route(const cs_regex* re, const cs_column* col, hipStream_t s, int op) {
+  if (re->bits.empty() || cs::cfg("CS_NO_BITS_FORM")) return false;
+  if (!re->tdfa.empty() && ((re->tdfa[30] >> 16) & 15) != 0) return false;  // a chain
+  if (sample_has_high_bytes(col, s)) return false;
+  if (cs::cfg("CS_BITS_ALWAYS")) return true;
+  if (re->tdfa.empty()) return true;  // (no automaton: the list simulator is the alternative)
+  const uint32_t* hist = sample_byte_hist(col, s);
+  uint64_t all = 0, cand = 0;
+  for (unsigned c = 0; c < 128; ++c) {
+    all += hist[c];
+    if (((uint32_t)re->tdfa[21 + (c >> 5)] >> (c & 31)) & 1u) cand += hist[c];
+  }
+  if (cs::cfg("CS_STREAM_INFO"))
+    fprintf(stderr, "bits route: candidates %.2f %% of the sample (%d classes, %d alternatives, %d states, %d threads)\n", all ? 100.0 * (double)cand / (double)all : 0.0,
+            re->bits[1], re->bits[3], re->tdfa[1], re->tdfa[12]);
+  if (all == 0) return false;
+  const double f = (double)cand / (double)all;
+  const bool threads3 = re->tdfa[12] >= 3;
+  if (op == BITS_COUNT) return f >= 0.02;
+  if (op == BITS_CONTAINS) return (f >= 0.05 && f <= 0.5) || (threads3 && f >= 0.02 && f <= 0.5);
+  return f >= 0.05 || (threads3 && f >= 0.02);
+}
 void upload(cs_regex* re, hipStream_t s) {
   // a compiled pattern may be shared between host threads (and is kept in the process-wide pattern cache): the device
   // images are made once.  All three are built into locals and committed together only after the copies completed --
@@ -2506,8 +2663,12 @@ void upload(cs_regex* re, hipStream_t s) {
   static std::mutex mu;
   std::lock_guard<std::mutex> lk(mu);
   if (re->d_image) return;
-  Buf image = dev_alloc(re->image.size() * 4, s), tdfa, gtags;
+  Buf image = dev_alloc(re->image.size() * 4, s), tdfa, gtags, bits;
   CS_HIP(hipMemcpyAsync(image->p, re->image.data(), re->image.size() * 4, hipMemcpyHostToDevice, s));
+  if (!re->bits.empty()) {
+    bits = dev_alloc(re->bits.size() * 4, s);
+    CS_HIP(hipMemcpyAsync(bits->p, re->bits.data(), re->bits.size() * 4, hipMemcpyHostToDevice, s));
+  }
   if (!re->tdfa.empty()) {
     tdfa = dev_alloc(re->tdfa.size() * 4, s);
     CS_HIP(hipMemcpyAsync(tdfa->p, re->tdfa.data(), re->tdfa.size() * 4, hipMemcpyHostToDevice, s));
@@ -2519,6 +2680,7 @@ void upload(cs_regex* re, hipStream_t s) {
   CS_HIP(hipStreamSynchronize(s));
   re->d_tdfa = std::move(tdfa);
   re->d_gtags = std::move(gtags);
+  re->d_bits = std::move(bits);
   re->d_image = std::move(image);  // (last: it is what the guard looks at)
 }
 TPlan tplan(cs_regex* re, int64_t rows, hipStream_t s) {
@@ -2529,7 +2691,7 @@ TPlan tplan(cs_regex* re, int64_t rows, hipStream_t s) {
   pl.d.tdfa = ptr<const int32_t>(re->d_tdfa);
   pl.d.tdfa_words = (int)re->tdfa.size();
   pl.d.image = ptr<const int32_t>(re->d_image);
-  pl.d.in_lds = re->tdfa.size() * 4 <= kLdsBudget && !getenv("CS_TDFA_GLOBAL_TABLE");
+  pl.d.in_lds = re->tdfa.size() * 4 <= kLdsBudget && !cs::cfg("CS_TDFA_GLOBAL_TABLE");
   pl.lds_bytes = pl.d.in_lds ? ((re->tdfa.size() * 4 + 15) & ~size_t(15)) : 0;
   int64_t nblk = (rows + 255) / 256;
   pl.grid = (unsigned)std::min<int64_t>(std::max<int64_t>(nblk, 1), 256 * 8);
@@ -2611,6 +2773,7 @@ template <int MODE>
 void scan(const cs_column* col, cs_regex* re, uint8_t* out8, int32_t* out32, int on_device, hipStream_t s,
           int64_t* found, const char* name) {
   if (found) *found = 0;
+  note_route("");
   if (col->rows == 0) return;
   const bool wide = use_tdfa_wide(re);  // (five to eight live threads: TdfaWide on the same kernels' generic row path)
   const bool tdfa = use_tdfa(re) || wide;
@@ -2630,7 +2793,7 @@ void scan(const cs_column* col, cs_regex* re, uint8_t* out8, int32_t* out32, int
   CS_HIP(hipMemsetAsync(cnt->p, 0, 8, s));
   RowSrc src{view_of(col), d_unicode_flags(), col->nbytes + (col->chars && col->chars->capacity ? 64 : 0)};
   bool streamed = false;
-  if (tdfa && tp.d.in_lds && !getenv("CS_REGEX_ROWWISE")) {
+  if (tdfa && tp.d.in_lds && !cs::cfg("CS_REGEX_ROWWISE")) {
     const TileChoice tc = choose_tile(col, s);
     const int cap = tc.cap;
     // the unit scan (k_tdfa_scan_stream<.., UNITS>): patterns whose tagged DFA offers the decomposition, rows within the masks
@@ -2645,8 +2808,13 @@ void scan(const cs_column* col, cs_regex* re, uint8_t* out8, int32_t* out32, int
     // routes test header word 31 bit 0 themselves)
     const bool units = !wide && (MODE == 2 || (MODE == 0 && ((re->tdfa[31] >> 17) & 3) != 0 && sample_has_high_bytes(col, s))) &&
                        ((re->tdfa[31] & 1) != 0 || (MODE == 2 && ((re->tdfa[30] >> 16) & 15) != 0)) &&
-                       !tc.lng && tc.R == 64 && !getenv("CS_NO_UNITS");
-    const size_t lds = tp.lds_bytes + (size_t)(cap + 32 + (cap >> 3) + 32 + (units ? (cap >> 3) + 32 + kUnitQueue * 4 + 64 * 4 + 16 : 0)) * 4;
+                       !tc.lng && tc.R == 64 && !cs::cfg("CS_NO_UNITS");
+    // the bit-parallel form (regex_bits.h): contains_re / count_re of patterns whose candidates are everywhere
+    const bool bits_form = !wide && (MODE == 0 || MODE == 2) && !tc.lng && tc.R == 64 && bits_route(re, col, s, MODE == 2 ? BITS_COUNT : BITS_CONTAINS);
+    const int bits_k = bits_form ? std::max(re->bits[1], 2) : 0;
+    const size_t bits_lds = bits_form ? (size_t)bits_lds_bytes((int)re->bits.size()) : 0;
+    const size_t lds = bits_form ? tp.lds_bytes + bits_lds + (size_t)(cap + 32 + bits_k * ((cap >> 3) + 32) + kUnitQueue * 4 + 64 * 4 + 16) * 4
+                                 : tp.lds_bytes + (size_t)(cap + 32 + (cap >> 3) + 32 + (units ? (cap >> 3) + 32 + kUnitQueue * 4 + 64 * 4 + 16 : 0)) * 4;
     if (tc.R && lds <= 150 * 1024) {
       ScanStreamArgs sa{};
       sa.in = view_of(col);
@@ -2658,11 +2826,17 @@ void scan(const cs_column* col, cs_regex* re, uint8_t* out8, int32_t* out32, int
       sa.nsub = (col->rows + tc.R - 1) / tc.R;
       sa.rows_per_tile = tc.R;
       sa.cap_in = cap;
-      sa.tbl_bytes = (int)tp.lds_bytes;
+      sa.tbl_bytes = (int)(tp.lds_bytes + bits_lds);
+      sa.bits = bits_form ? ptr<const int32_t>(re->d_bits) : nullptr;
+      sa.bits_off = (int)tp.lds_bytes;
+      sa.bits_words = bits_form ? (int)re->bits.size() : 0;
+      sa.bits_k = bits_form ? re->bits[1] : 0;
       auto kern = tc.lng ? &k_tdfa_scan_stream<MODE, true, true> : &k_tdfa_scan_stream<MODE, true, false>;
       if (units) kern = &k_tdfa_scan_stream<MODE == 2 ? 2 : 0, true, false, true>;
-      if (units && MODE == 2 && ((re->tdfa[30] >> 16) & 15) != 0 && !sample_has_high_bytes(col, s) && !getenv("CS_NO_CHAIN_FORM"))
+      if (units && MODE == 2 && ((re->tdfa[30] >> 16) & 15) != 0 && !sample_has_high_bytes(col, s) && !cs::cfg("CS_NO_CHAIN_FORM"))
         kern = &k_tdfa_scan_stream<2, true, false, true, true>;  // (a chain pattern on a column whose sample is plain ASCII)
+      if (bits_form) kern = &k_tdfa_scan_stream<MODE == 2 ? 2 : 0, true, false, true, true, true>;
+      note_route(bits_form ? "bits" : wide ? "wide" : units ? "units" : "plain");
       if (wide) kern = tc.lng ? &k_tdfa_scan_stream<MODE + 7, true, true> : &k_tdfa_scan_stream<MODE + 7, true, false>;
       if (lds > 48 * 1024)
         CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -2718,7 +2892,7 @@ int cs_regex_compile(const char* pattern, cs_regex** out) {
     // is a counted reference to the shared object.
     static std::mutex& mu = *new std::mutex;  // (never destroyed: see the note on process exit in cs_core.hip's buffer cache)
     static auto& kept = *new std::list<std::pair<std::string, cs_regex*>>;
-    const bool keep = !getenv("CS_REGEX_NO_CACHE");
+    const bool keep = !cs::cfg("CS_REGEX_NO_CACHE");
     if (keep) {
       std::lock_guard<std::mutex> lk(mu);
       for (auto it = kept.begin(); it != kept.end(); ++it)
@@ -2735,6 +2909,7 @@ int cs_regex_compile(const char* pattern, cs_regex** out) {
     re->blob = re->prog.to_blob();
     re->image = re->prog.to_device_image(h_unicode_flags());
     re->tdfa = csrx::build_tdfa(re->prog, re->image, h_unicode_flags(), &re->gtags);
+    re->bits = csrx::build_bits(re->prog, re->image, h_unicode_flags());
     cs_regex* dropped = nullptr;
     if (keep) {
       std::lock_guard<std::mutex> lk(mu);
@@ -2819,6 +2994,7 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
     }
     if (!repl) repl = "";
     const int rb = (int)strlen(repl);
+    note_route("");
     Buf d_repl = dev_alloc((size_t)rb + 1, s);
     CS_HIP(hipMemcpyAsync(d_repl->p, repl, (size_t)rb + 1, hipMemcpyHostToDevice, s));
     const bool tdfa = use_tdfa(re);
@@ -2848,16 +3024,16 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
     const int minlen_p = std::max(minlen, 1);
     const bool bounded = growth == 0 || minlen >= 1 || rb <= 8;  // (longer ones: the out tile of 1 + rb times the input does not fit the LDS)
     // (programs of five to eight threads: the stream kernel's WIDE forms -- tables in LDS, replacements of up to 16 bytes)
-    const bool wide_stream = wide && tp.d.in_lds && rb <= 16 && !cs::g_backrefs_dev && !getenv("CS_WIDE_TWO_PASS");
-    if ((tdfa || wide_stream) && bounded && !getenv("CS_REGEX_TWO_PASS")) {
+    const bool wide_stream = wide && tp.d.in_lds && rb <= 16 && !cs::g_backrefs_dev && !cs::cfg("CS_WIDE_TWO_PASS");
+    if ((tdfa || wide_stream) && bounded && !cs::cfg("CS_REGEX_TWO_PASS")) {
       const int64_t rows = col->rows;
       const int64_t ntiles = (rows + cstile::kTileRows - 1) / cstile::kTileRows;
       const int64_t nsub = ntiles * 4;
-      TileChoice tc = choose_tile(col, s, !getenv("CS_NO_SMALL_TILES"));
+      TileChoice tc = choose_tile(col, s, !cs::cfg("CS_NO_SMALL_TILES"));
       // (the column's largest 64-row span does not fit, all but a few do: buffers for those, the kernel handles the rest)
       bool outliers = false;
       constexpr int64_t kOutlierSpan = cstile::kPfBytes - 176;  // (its capacity is kPfBytes)
-      if (!tc.R && tdfa && tp.d.in_lds && rb <= 16 && !cs::g_backrefs_dev && !getenv("CS_NO_OUTLIER_TILES") && max_span64(col, s) <= (16 << 20) &&
+      if (!tc.R && tdfa && tp.d.in_lds && rb <= 16 && !cs::g_backrefs_dev && !cs::cfg("CS_NO_OUTLIER_TILES") && max_span64(col, s) <= (16 << 20) &&
           few_spans64_over(col, kOutlierSpan, s)) {
         tc = TileChoice{64, (int)((kOutlierSpan + 15 + 32 + 127) & ~(int64_t)127), false, kOutlierSpan};
         outliers = true;
@@ -2895,10 +3071,16 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
         if (brefs && !(((re->tdfa[31] & 1) != 0 || (((re->tdfa[30] >> 16) & 15) != 0 && ((re->tdfa[30] >> 20) & 1) != 0 && !sample_has_high_bytes(col, s))) && !tc.lng && tc.R == 64 && tp.d.in_lds && !re->gtags.empty() && re->prog.num_groups <= cstd::Tdfa::kGroupBatch &&
                        re->gtags.size() * 4 <= 8 * 1024))
           return -1;
-        const bool literal = !brefs && !outliers && cs::g_replace_plain_only && cs::g_replace_literal_len > 0 && maxrepl < 0 && !tc.lng && tc.R == 64 && !getenv("CS_NO_LITERAL_SCAN");
+        const bool literal = !brefs && !outliers && cs::g_replace_plain_only && cs::g_replace_literal_len > 0 && maxrepl < 0 && !tc.lng && tc.R == 64 && !cs::cfg("CS_NO_LITERAL_SCAN");
         const bool offers = (re->tdfa[31] & 1) != 0 || ((re->tdfa[30] >> 16) & 15) != 0;  // (units, or a chain pattern without them: one with a suffix)
-        const bool units = literal || brefs || (offers && maxrepl < 0 && !tc.lng && tc.R == 64 && !outliers && !cs::g_replace_plain_only && !getenv("CS_NO_UNITS"));
-        const size_t unit_bytes = units ? (size_t)((cap >> 3) + 32 + kUnitQueue * 4 + 16 + (cs::g_backrefs_dev ? kUnitQueue * 12 + 64 * 4 : 0)) : 0;
+        // the bit-parallel form (regex_bits.h): patterns whose candidates are everywhere -- a bitmap per character class (it
+        // builds on the unit forms' layout and assembly, whether or not the pattern offers a unit decomposition)
+        const bool bits_form = !literal && !brefs && !wide_stream && tdfa && maxrepl < 0 && !tc.lng && tc.R == 64 && !outliers && !cs::g_replace_plain_only && tp.d.in_lds &&
+                               bits_route(re, col, s, BITS_REPLACE);
+        const bool units = literal || brefs || bits_form || (offers && maxrepl < 0 && !tc.lng && tc.R == 64 && !outliers && !cs::g_replace_plain_only && !cs::cfg("CS_NO_UNITS"));
+        const int bits_k = bits_form ? std::max(re->bits[1], 2) : 2;
+        const size_t bits_lds = bits_form ? (size_t)bits_lds_bytes((int)re->bits.size()) : 0;
+        const size_t unit_bytes = units ? (size_t)((bits_k - 1) * ((cap >> 3) + 32) + kUnitQueue * 4 + 16 + (cs::g_backrefs_dev ? kUnitQueue * 12 + 64 * 4 : 0)) : 0;
         // (backrefs: the group tags and the template text sit behind the DFA table; the template may grow a row by any
         // amount: room for twice the input, a launch that needs more says so and the two-pass form takes over)
         const size_t gt_bytes = brefs ? ((re->gtags.size() * 4 + 15) & ~size_t(15)) + (((size_t)cs::g_backrefs_text_bytes + 31) & ~size_t(15)) : 0;
@@ -2906,7 +3088,7 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
           cap_out = std::max(cap_out, 2 * cap);
           extra = std::max<int64_t>(extra, col->nbytes);
         }
-        const size_t lds1 = tbl + gt_bytes + (size_t)(cap + cap_out + 64 + (cap >> 3) + 32 + unit_bytes) * 4 + 16;
+        const size_t lds1 = tbl + gt_bytes + bits_lds + (size_t)(cap + cap_out + 64 + (cap >> 3) + 32 + unit_bytes) * 4 + 16;
         if (lds1 > 150 * 1024) return -1;
         StreamArgs sa{};
         sa.in = view_of(col);
@@ -2934,12 +3116,16 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
         sa.nsub = nsub1;
         sa.cap_in = cap;
         sa.cap_out = cap_out;
-        sa.tbl_bytes = (int)(tbl + gt_bytes);
+        sa.tbl_bytes = (int)(tbl + gt_bytes + bits_lds);
+        sa.bits = bits_form ? ptr<const int32_t>(re->d_bits) : nullptr;
+        sa.bits_off = (int)(tbl + gt_bytes);
+        sa.bits_words = bits_form ? (int)re->bits.size() : 0;
+        sa.bits_k = bits_form ? re->bits[1] : 0;
         sa.tmpl = static_cast<const csvm::BackrefTemplate*>(cs::g_backrefs_dev);
         sa.gtags = brefs ? ptr<const int32_t>(re->d_gtags) : nullptr;
         sa.gt_off = (int)tbl;
         sa.gt_words = brefs ? (int)re->gtags.size() : 0;
-        sa.debug = getenv("CS_TILE_DEBUG") ? atoi(getenv("CS_TILE_DEBUG")) : 0;
+        sa.debug = cs::cfg("CS_TILE_DEBUG") ? atoi(cs::cfg("CS_TILE_DEBUG")) : 0;
         sa.outliers = outliers ? 1 : 0;
         sa.lit = literal ? cs::g_replace_literal : 0;
         sa.litn = literal ? cs::g_replace_literal_len : 0;
@@ -2972,7 +3158,10 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
           }
         } else if (brefs)
           kern = cap <= 5 * 1024 ? &k_tdfa_replace_stream<true, false, false, true, false, true, 5, true> : &k_tdfa_replace_stream<true, false, false, true, false, true, cstile::kPfChunks, true>;
-        else if (units && cap <= 5 * 1024 && tp.d.in_lds && !literal && maxrepl < 0 && ((re->tdfa[30] >> 16) & 15) != 0 && !sample_has_high_bytes(col, s) && !getenv("CS_NO_CHAIN_FORM"))
+        else if (bits_form)
+          kern = rb > 8 ? &k_tdfa_replace_stream<true, true, false, true, false, true, cstile::kPfChunks, false, false, false, true, true>
+                        : &k_tdfa_replace_stream<true, false, false, true, false, true, cstile::kPfChunks, false, false, false, true, true>;
+        else if (units && cap <= 5 * 1024 && tp.d.in_lds && !literal && maxrepl < 0 && ((re->tdfa[30] >> 16) & 15) != 0 && !sample_has_high_bytes(col, s) && !cs::cfg("CS_NO_CHAIN_FORM"))
           // (a chain pattern on a column whose sample is plain ASCII: the form without the unit / lean scans)
           kern = rb > 8 ? &k_tdfa_replace_stream<true, true, false, true, false, true, 5, false, false, false, true>
                         : &k_tdfa_replace_stream<true, false, false, true, false, true, 5, false, false, false, true>;
@@ -2982,11 +3171,12 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
         else if (units)
           kern = rb > 8 ? (tp.d.in_lds ? &k_tdfa_replace_stream<true, true, false, true, false, true> : &k_tdfa_replace_stream<false, true, false, true, false, true>)
                         : (tp.d.in_lds ? &k_tdfa_replace_stream<true, false, false, true, false, true> : &k_tdfa_replace_stream<false, false, false, true, false, true>);
+        note_route(bits_form ? "bits" : brefs ? "brefs" : literal ? "literal" : wide_stream ? "wide" : units ? (((re->tdfa[30] >> 16) & 15) != 0 ? "chain" : "units") : "plain");
         if (lds1 > 48 * 1024)
           CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)lds1));
         const unsigned grid = resident_grid(reinterpret_cast<const void*>(kern), lds1, (nsub1 + 3) / 4);
-        if (getenv("CS_STREAM_INFO"))
+        if (cs::cfg("CS_STREAM_INFO"))
           fprintf(stderr, "replace stream: grid %u lds %zu (tables %zu, tile %d + %d) rows/tile %d units %d wide %d brefs %d roomy %d growth %d rb %d\n", grid, lds1, tbl + gt_bytes, cap, cap_out,
                   tc.R, (int)units, (int)wide_stream, (int)brefs, (int)roomy, (int)growth, rb);
 #if defined(CS_PHASE_PROF)
@@ -2994,7 +3184,7 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
         const long long ntrace = (nsub1 >> 10) + 1;
         {
           unsigned long long* tp_ = nullptr;
-          if (getenv("CS_REPLACE_TRACE")) {
+          if (cs::cfg("CS_REPLACE_TRACE")) {
             tracebuf = dev_alloc(sizeof(unsigned long long) * 4 * ntrace, s);
             CS_HIP(hipMemsetAsync(tracebuf->p, 0, sizeof(unsigned long long) * 4 * ntrace, s));
             tp_ = ptr<unsigned long long>(tracebuf);
@@ -3007,9 +3197,10 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
           hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds1, s, sa);
         }
         CS_HIP(hipGetLastError());
-        int64_t* host = (int64_t*)pinned_scratch(16);
+        int64_t* host = (int64_t*)pinned_scratch(24);
         CS_HIP(hipMemcpyAsync(host, ptr<int64_t>(out_off) + rows, 8, hipMemcpyDeviceToHost, s));
         CS_HIP(hipMemcpyAsync(host + 1, sa.error, 4, hipMemcpyDeviceToHost, s));
+        CS_HIP(hipMemcpyAsync(host + 2, reinterpret_cast<unsigned long long*>(sa.error) + 14, 8, hipMemcpyDeviceToHost, s));
         CS_HIP(hipStreamSynchronize(s));
 #if defined(CS_PHASE_PROF)
         {
@@ -3038,7 +3229,7 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
         }
 #endif
         const int err = (int)(uint32_t)host[1];
-        if (err != 0 && getenv("CS_DUMP_STATUS")) {  // development aid: where did the prefix chain stop?
+        if (err != 0 && cs::cfg("CS_DUMP_STATUS")) {  // development aid: where did the prefix chain stop?
           std::vector<cstile::u64> st((size_t)nsub1), ex((size_t)nsub1);
           CS_HIP(hipMemcpy(st.data(), sa.status, sizeof(cstile::u64) * nsub1, hipMemcpyDeviceToHost));
           CS_HIP(hipMemcpy(ex.data(), sa.excl, sizeof(cstile::u64) * nsub1, hipMemcpyDeviceToHost));
@@ -3053,6 +3244,16 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
           o->offsets = out_off;
           o->chars = out_chars;
           o->nbytes = host[0];
+          // column metadata as a by-product: the largest 64-row span is the largest sub-tile total the kernel saw; a
+          // replacement no longer than the shortest match cannot lengthen a row (an upper bound serves: the numbers size
+          // staging buffers and pick routes); plain input + plain replacement stays plain
+          if (tc.R == 64) o->max_span64 = host[2];
+          if (growth == 0 && col->max_row >= 0) o->max_row = col->max_row;
+          if (col->high_sample == 0 && !brefs) {
+            bool ascii = true;
+            for (int i = 0; i < rb; ++i) ascii = ascii && (unsigned char)repl[i] < 0x80 && repl[i] != 0;
+            if (ascii) o->high_sample = 0;
+          }
           *out = holder.release();
           return 0;
         }
@@ -3061,8 +3262,8 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
       // (replacements of 17 .. kMaxStreamRepl bytes ride the four-register variants, their text read from memory at assembly)
       // (... where a match is long enough for the row not to outgrow the out tile: a 19-byte replacement of one-digit matches
       // goes to the two-pass kernels at once instead of failing the single pass twice first)
-      if (lds <= 150 * 1024 && (rb <= 16 || (rb <= kMaxStreamRepl && rb <= 4 * minlen)) && tc.R && !getenv("CS_TILE_OLD")) {
-        const bool roomy_first = growth > 0 && (minlen <= 2 || wide_stream || outliers || getenv("CS_REPLACE_ROOMY"));
+      if (lds <= 150 * 1024 && (rb <= 16 || (rb <= kMaxStreamRepl && rb <= 4 * minlen)) && tc.R && !cs::cfg("CS_TILE_OLD")) {
+        const bool roomy_first = growth > 0 && (minlen <= 2 || wide_stream || outliers || cs::cfg("CS_REPLACE_ROOMY"));
         int err = stream_attempt(roomy_first);
         if (err == 2 && !roomy_first) err = stream_attempt(true);  // only ran out of room: once more, roomier
         if (err == 0) return;
@@ -3091,7 +3292,7 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
         ta.cap_in = cap;
         ta.cap_out = cap;
         ta.tbl_bytes = (int)tbl;
-        ta.debug = getenv("CS_TILE_DEBUG") ? atoi(getenv("CS_TILE_DEBUG")) : 0;
+        ta.debug = cs::cfg("CS_TILE_DEBUG") ? atoi(cs::cfg("CS_TILE_DEBUG")) : 0;
         auto kern = tp.d.in_lds ? &k_tdfa_replace_tile<true> : &k_tdfa_replace_tile<false>;
         if (lds > 48 * 1024)
           CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -3141,7 +3342,9 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
     }
     CS_HIP(hipGetLastError());
     o->offsets = dev_alloc(sizeof(int64_t) * (col->rows + 1), s);
-    o->nbytes = offsets_from_lengths(ptr<int32_t>(lens), col->rows, ptr<int64_t>(o->offsets), s);
+    LenMeta meta;
+    o->nbytes = offsets_from_lengths(ptr<int32_t>(lens), col->rows, ptr<int64_t>(o->offsets), s, nullptr, &meta);
+    meta.give(o);
     o->chars = dev_alloc((size_t)o->nbytes, s);
     {
       ProfScope ps("k_replace_re_write", s);
@@ -3176,7 +3379,7 @@ void write_spans(const cs_column* col, int ncols, const int32_t* begins, const i
   const int64_t rows = col->rows;
   const TileChoice tc = choose_tile(col, s);
   ProfScope ps("k_extract_write", s);
-  if (tc.R == 64 && !getenv("CS_SPANS_ROWWISE")) {
+  if (tc.R == 64 && !cs::cfg("CS_SPANS_ROWWISE")) {
     SpanWriteArgs a{};
     a.in = view_of(col);
     a.ncols = ncols;
@@ -3200,8 +3403,8 @@ void columns_from_packed_spans(const cs_column* col, int ncols, const uint32_t* 
                                std::vector<std::unique_ptr<cs_column>>& cols) {
   const int64_t rows = col->rows, nsub = (rows + 63) / 64;
   Buf base = dev_alloc(sizeof(int64_t) * (nsub + 1) * ncols, s);
-  std::vector<int64_t> totals(ncols);
-  offsets_from_lengths_segmented(tile_tot, nsub, ncols, ptr<int64_t>(base), totals.data(), s);
+  std::vector<int64_t> totals(ncols), largest(ncols);
+  offsets_from_lengths_segmented(tile_tot, nsub, ncols, ptr<int64_t>(base), totals.data(), s, largest.data());
   SpanWrite2Args a{};
   a.in = view_of(col);
   a.ncols = ncols;
@@ -3209,7 +3412,7 @@ void columns_from_packed_spans(const cs_column* col, int ncols, const uint32_t* 
   a.tile_base = ptr<const int64_t>(base);
   a.nsub = nsub;
   a.cap = cap;
-  bool off32 = !getenv("CS_SPANS_OFF64");
+  bool off32 = !cs::cfg("CS_SPANS_OFF64");
   for (int k = 0; k < ncols; ++k) off32 = off32 && totals[k] < ((int64_t)1 << 31);
   a.off32 = off32 ? 1 : 0;
   for (int k = 0; k < ncols; ++k) {
@@ -3220,6 +3423,11 @@ void columns_from_packed_spans(const cs_column* col, int ncols, const uint32_t* 
     else o->offsets = dev_alloc(sizeof(int64_t) * (rows + 1), s);
     o->validity = dev_alloc(validity_bytes(rows), s);
     o->chars = dev_alloc((size_t)o->nbytes, s);
+    // (metadata for free: the largest tile total is the column's largest 64-row span; a span is a piece of its row)
+    o->max_span64 = largest[k];
+    o->max_row = col->max_row >= 0 ? std::min<int64_t>(col->max_row, largest[k]) : largest[k];
+    if (col->plain_bytes == 1) o->plain_bytes = 1;
+    if (col->high_sample == 0) o->high_sample = 0;
     a.out.off[k] = off32 ? o->offsets32->p : o->offsets->p;
     a.out.valid[k] = ptr<uint8_t>(o->validity);
     a.out.chars[k] = ptr<uint8_t>(o->chars);
@@ -3260,7 +3468,7 @@ int cs_extract(const cs_column* col, const cs_regex* cre, cs_stream stream, cs_c
     const size_t img_bytes = (((size_t)L.image_words + 3) & ~size_t(3)) * 4;
     L.image_in_lds = img_bytes <= kLdsBudget / 2;
     const unsigned grid = (unsigned)std::min<int64_t>((rows + 255) / 256, 256 * 4);
-    const bool dfa_groups = use_tdfa(re) && re->d_gtags && !getenv("CS_EXTRACT_LISTS");
+    const bool dfa_groups = use_tdfa(re) && re->d_gtags && !cs::cfg("CS_EXTRACT_LISTS");
     Buf arena;  // thread lists of the list simulation (not needed when the DFA carries the group ranges)
     if (!dfa_groups) {
       arena = dev_alloc((size_t)grid * 256 * L.slots * 4, s);
@@ -3270,19 +3478,19 @@ int cs_extract(const cs_column* col, const cs_regex* cre, cs_stream stream, cs_c
     Buf begins, lens, spans, tile_tot;  // (begins / lens, or packed spans + tile totals from the scan stream kernel on 64-row tiles)
     const bool tdfa = use_tdfa(re);
     bool streamed = false, packed = false;
-    if (dfa_groups && !getenv("CS_REGEX_ROWWISE")) {  // rows staged through LDS tiles by the scan stream kernel
+    if (dfa_groups && !cs::cfg("CS_REGEX_ROWWISE")) {  // rows staged through LDS tiles by the scan stream kernel
       TPlan tp = tplan(re, rows, s);
       const TileChoice tc = choose_tile(col, s);
       const int cap = tc.cap;
       const size_t gt_bytes = re->gtags.size() * 4 <= 16 * 1024 ? ((re->gtags.size() * 4 + 15) & ~size_t(15)) : 0;
       // (a chain pattern whose groups are runs of items, on a column whose sample is plain ASCII: the chain form -- the match
       // and the group ranges by mask arithmetic; it keeps the "equals x" bitmap and the unit form's layout)
-      const bool chain_form = tp.d.in_lds && tc.R == 64 && !tc.lng && !getenv("CS_SPANS_UNPACKED") && ((re->tdfa[30] >> 16) & 15) != 0 && ((re->tdfa[30] >> 20) & 1) != 0 &&
-                              groups <= 4 && !getenv("CS_NO_CHAIN_FORM") && !sample_has_high_bytes(col, s);
+      const bool chain_form = tp.d.in_lds && tc.R == 64 && !tc.lng && !cs::cfg("CS_SPANS_UNPACKED") && ((re->tdfa[30] >> 16) & 15) != 0 && ((re->tdfa[30] >> 20) & 1) != 0 &&
+                              groups <= 4 && !cs::cfg("CS_NO_CHAIN_FORM") && !sample_has_high_bytes(col, s);
       const size_t lds = chain_form ? tp.lds_bytes + gt_bytes + (size_t)(cap + 32 + 2 * ((cap >> 3) + 32) + kUnitQueue * 4 + 64 * 4 + 16) * 4
                                     : tp.lds_bytes + gt_bytes + (size_t)(cap + 32 + (cap >> 3) + 32 + cstd::Tdfa::kBackSteps * 64 + kMaxGroups * 4) * 4;
       if (tp.d.in_lds && tc.R && lds <= 150 * 1024) {
-        packed = tc.R == 64 && !getenv("CS_SPANS_UNPACKED");
+        packed = tc.R == 64 && !cs::cfg("CS_SPANS_UNPACKED");
         if (packed) {
           spans = dev_alloc(sizeof(uint32_t) * rows * groups, s);
           tile_tot = dev_alloc(sizeof(int32_t) * ((rows + 63) / 64) * groups, s);
@@ -3379,7 +3587,9 @@ int cs_extract(const cs_column* col, const cs_regex* cre, cs_stream stream, cs_c
       o->rows = rows;
       const int32_t* gl = ptr<int32_t>(lens) + (size_t)g * rows;
       o->offsets = dev_alloc(sizeof(int64_t) * (rows + 1), s);
-      o->nbytes = offsets_and_validity_from_lengths(gl, rows, ptr<int64_t>(o->offsets), &o->validity, s);
+      LenMeta meta;
+      o->nbytes = offsets_and_validity_from_lengths(gl, rows, ptr<int64_t>(o->offsets), &o->validity, s, &meta);
+      meta.give(o.get());
       o->chars = dev_alloc((size_t)o->nbytes, s);
       eo.off[g] = o->d_offsets();
       eo.chars[g] = ptr<uint8_t>(o->chars);
@@ -3433,12 +3643,12 @@ int cs_findall(const cs_column* col, const cs_regex* cre, cs_stream stream, cs_c
     // kProvisional matches (the span arrays are laid out [k * rows + row], so unused columns cost only memory);
     // a column with busier rows is scanned a second time with the exact column count.
     constexpr int kProvisional = 4;
-    if (use_tdfa(re) && !getenv("CS_REGEX_ROWWISE")) {
+    if (use_tdfa(re) && !cs::cfg("CS_REGEX_ROWWISE")) {
       TPlan tp = tplan(re, rows, s);
       const TileChoice tc = choose_tile(col, s);
       const int cap = tc.cap;
       // the unit scan where the tagged DFA offers the decomposition (as count_re)
-      const bool units = ((re->tdfa[31] & 1) != 0 || ((re->tdfa[30] >> 16) & 15) != 0) && !tc.lng && tc.R == 64 && !getenv("CS_NO_UNITS");
+      const bool units = ((re->tdfa[31] & 1) != 0 || ((re->tdfa[30] >> 16) & 15) != 0) && !tc.lng && tc.R == 64 && !cs::cfg("CS_NO_UNITS");
       const size_t lds = tp.lds_bytes + (size_t)(cap + 32 + (cap >> 3) + 32 + (units ? (cap >> 3) + 32 + kUnitQueue * 4 + 64 * 4 + 16 : 0)) * 4;
       if (tp.d.in_lds && tc.R && lds <= 150 * 1024) {
         Buf hits = dev_alloc(8, s);
@@ -3455,7 +3665,7 @@ int cs_findall(const cs_column* col, const cs_regex* cre, cs_stream stream, cs_c
         sa.maxp = ptr<int>(dmax);
         auto kern = tc.lng ? &k_tdfa_scan_stream<3, true, true> : &k_tdfa_scan_stream<3, true, false>;
         if (units) kern = &k_tdfa_scan_stream<3, true, false, true>;
-        if (units && ((re->tdfa[30] >> 16) & 15) != 0 && !sample_has_high_bytes(col, s) && !getenv("CS_NO_CHAIN_FORM"))
+        if (units && ((re->tdfa[30] >> 16) & 15) != 0 && !sample_has_high_bytes(col, s) && !cs::cfg("CS_NO_CHAIN_FORM"))
           kern = &k_tdfa_scan_stream<3, true, false, true, true>;  // (a chain pattern on a column whose sample is plain ASCII)
         if (lds > 48 * 1024)
           CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -3464,7 +3674,7 @@ int cs_findall(const cs_column* col, const cs_regex* cre, cs_stream stream, cs_c
         for (int pass = 0; pass < 2; ++pass) {
           // (the provisional pass on 64-row tiles leaves packed spans and tile totals: k_spans_write_tile2 needs no pass
           // over the lengths; a second pass -- rows with more than kProvisional matches -- writes begins / lens)
-          packed = pass == 0 && tc.R == 64 && !getenv("CS_SPANS_UNPACKED");
+          packed = pass == 0 && tc.R == 64 && !cs::cfg("CS_SPANS_UNPACKED");
           if (packed) {
             spans = dev_alloc(sizeof(uint32_t) * rows * width, s);
             tile_tot = dev_alloc(sizeof(int32_t) * ((rows + 63) / 64) * width, s);
@@ -3544,7 +3754,9 @@ int cs_findall(const cs_column* col, const cs_regex* cre, cs_stream stream, cs_c
         o->rows = rows;
         const int32_t* gl = ptr<int32_t>(lens) + (size_t)(k0 + k) * rows;
         o->offsets = dev_alloc(sizeof(int64_t) * (rows + 1), s);
-        o->nbytes = offsets_and_validity_from_lengths(gl, rows, ptr<int64_t>(o->offsets), &o->validity, s);
+        LenMeta meta;
+        o->nbytes = offsets_and_validity_from_lengths(gl, rows, ptr<int64_t>(o->offsets), &o->validity, s, &meta);
+        meta.give(o.get());
         o->chars = dev_alloc((size_t)o->nbytes, s);
         eo.off[k] = o->d_offsets();
         eo.chars[k] = ptr<uint8_t>(o->chars);
@@ -3600,7 +3812,7 @@ int cs_replace_with_backrefs(const cs_column* col, const cs_regex* cre, const ch
     // First choice: the single-pass replace kernel in its backrefs form (unit scan, one group run per match, coalesced
     // output).  It declines patterns without the unit decomposition, more than four groups, long rows; a launch that
     // runs out of output room or meets a row the unit route hands over reports it, and the two-pass form below runs.
-    if (dfa && re->prog.num_groups >= 1 && !getenv("CS_BACKREFS_TWO_PASS")) {
+    if (dfa && re->prog.num_groups >= 1 && !cs::cfg("CS_BACKREFS_TWO_PASS")) {
       Buf d_t = dev_alloc(sizeof(csvm::BackrefTemplate), s);
       CS_HIP(hipMemcpyAsync(d_t->p, &t, sizeof(t), hipMemcpyHostToDevice, s));
       CS_HIP(hipStreamSynchronize(s));  // (`t` lives on this stack frame)
@@ -3657,7 +3869,7 @@ int cs_replace_with_backrefs(const cs_column* col, const cs_regex* cre, const ch
     size_t slds = 0;
     unsigned sgrid = 0;
     bool lng = false, stream = false;
-    if (dfa && a.TL.in_lds && !getenv("CS_REGEX_ROWWISE")) {
+    if (dfa && a.TL.in_lds && !cs::cfg("CS_REGEX_ROWWISE")) {
       const TileChoice tc = choose_tile(col, s);
       const size_t gt_bytes = (!re->gtags.empty() && re->gtags.size() * 4 <= 16 * 1024) ? ((re->gtags.size() * 4 + 15) & ~size_t(15)) : 0;
       slds = lds + gt_bytes + (size_t)(tc.cap + 32 + (tc.cap >> 3) + 32) * 4;
@@ -3708,7 +3920,9 @@ int cs_replace_with_backrefs(const cs_column* col, const cs_regex* cre, const ch
       }
     }
     o->offsets = dev_alloc(sizeof(int64_t) * (rows + 1), s);
-    o->nbytes = offsets_from_lengths(ptr<int32_t>(lens), rows, ptr<int64_t>(o->offsets), s);
+    LenMeta meta;
+    o->nbytes = offsets_from_lengths(ptr<int32_t>(lens), rows, ptr<int64_t>(o->offsets), s, nullptr, &meta);
+    meta.give(o.get());
     o->chars = dev_alloc((size_t)o->nbytes, s);
     {
       ProfScope ps("k_backrefs_write", s);
@@ -3743,7 +3957,7 @@ int cs_replace_re_multi(const cs_column* col, const cs_regex* const* res, int np
       return;
     }
     std::vector<MultiProg> progs;
-    bool all_dfa = !getenv("CS_REGEX_NO_TDFA");
+    bool all_dfa = !cs::cfg("CS_REGEX_NO_TDFA");
     int max_inst = 0;
     for (int i = 0; i < npatterns; ++i) {
       cs_regex* re = const_cast<cs_regex*>(res[i]);
@@ -3788,7 +4002,9 @@ int cs_replace_re_multi(const cs_column* col, const cs_regex* const* res, int np
     o->validity = col->validity;
     o->null_count = col->null_count;
     o->offsets = dev_alloc(sizeof(int64_t) * (rows + 1), s);
-    o->nbytes = offsets_from_lengths(ptr<int32_t>(lens), rows, ptr<int64_t>(o->offsets), s);
+    LenMeta meta;
+    o->nbytes = offsets_from_lengths(ptr<int32_t>(lens), rows, ptr<int64_t>(o->offsets), s, nullptr, &meta);
+    meta.give(o.get());
     unsigned* hb = (unsigned*)pinned_scratch(sizeof(unsigned));
     CS_HIP(hipMemcpyAsync(hb, bad->p, sizeof(unsigned), hipMemcpyDeviceToHost, s));
     CS_HIP(hipStreamSynchronize(s));

@@ -279,6 +279,7 @@ __global__ void __launch_bounds__(256) k_find_tile(FindTileArgs a) {
   if (lane == 0 && t) atomicAdd(a.found, (unsigned long long)t);
 }
 
+#if defined(CS_EXPERIMENTS)  // (`make exp`: built, bit-exact, measured slower than the two passes -- not in the product library)
 // strip in ONE pass (strip.cu:97-141 sizes the rows, scans, then writes): every wave takes 64-row tiles by ticket, stages a
 // tile's chars (the next tile's already in flight), finds each row's stripped range in LDS, publishes the tile's byte total
 // (tile_utils.h: the decoupled look-back; a ticket's predecessors have all been started), assembles the rows in the out
@@ -451,6 +452,7 @@ __global__ void __launch_bounds__(256) k_strip_stream(StripStreamArgs a) {
   }
   if (p_tile >= 0) finish_pending();
 }
+#endif
 
 }  // namespace
 
@@ -459,7 +461,7 @@ namespace cs {
 
 bool find_tiles(const cs_column* in, const unsigned char* needle, int nb, int mode, int start, int end, int32_t* out32,
                 uint8_t* out8, unsigned long long* found, hipStream_t s) {
-  if (in->rows == 0 || nb > 64 || getenv("CS_FIND_ROWWISE")) return false;
+  if (in->rows == 0 || nb > 64 || cs::cfg("CS_FIND_ROWWISE")) return false;
   int R = 0;
   for (int r : {64, 32, 16}) {
     if (max_span_rows(in, r, s) + 32 <= cstile::kPfBytes) {
@@ -497,7 +499,7 @@ bool find_tiles(const cs_column* in, const unsigned char* needle, int nb, int mo
 
 bool strip_write_tiles(const cs_column* in, const CharSet& set, int side, const int64_t* out_off, uint8_t* out_chars,
                        hipStream_t s) {
-  if (in->rows == 0 || getenv("CS_STRIP_ROWWISE")) return false;
+  if (in->rows == 0 || cs::cfg("CS_STRIP_ROWWISE")) return false;
   int R = 0;
   for (int r : {64, 32, 16}) {
     if (max_span_rows(in, r, s) + 32 <= cstile::kPfBytes) {
@@ -506,7 +508,7 @@ bool strip_write_tiles(const cs_column* in, const CharSet& set, int side, const 
     }
   }
   int64_t span = R ? max_span_rows(in, R, s) : 0;
-  if (!R && !getenv("CS_NO_OUTLIER_TILES")) {
+  if (!R && !cs::cfg("CS_NO_OUTLIER_TILES")) {
     R = 64;  // no tile size fits every tile: the kernel copies the rows of a tile beyond the staging size straight from memory, long rows by the whole wave
     span = cstile::kPfBytes - 64;
   }
@@ -541,10 +543,13 @@ bool strip_write_tiles(const cs_column* in, const CharSet& set, int side, const 
 // On the way: a chain of look-backs passes 64 tiles per L2 round trip (2.97 ms), ONE ticket counter hands out 65 tickets a
 // microsecond (2.48 ms with the scanner team), sixteen counters 500.
 bool strip_single(const cs_column* in, const CharSet& set, int side, hipStream_t s, cs_column* o) {
-  if (in->rows == 0 || !getenv("CS_STRIP_SINGLE") || getenv("CS_STRIP_ROWWISE")) return false;
+#if !defined(CS_EXPERIMENTS)
+  return false;  // (the one-pass kernel is in the experiments build only: `make exp`)
+#else
+  if (in->rows == 0 || !cs::cfg("CS_STRIP_SINGLE") || cs::cfg("CS_STRIP_ROWWISE")) return false;
   int64_t span = max_span_rows(in, 64, s);
   if (span + 32 > cstile::kPfBytes) {
-    if (getenv("CS_NO_OUTLIER_TILES")) return false;
+    if (cs::cfg("CS_NO_OUTLIER_TILES")) return false;
     span = cstile::kPfBytes - 64;  // (tiles beyond the staging size go straight from memory)
   }
   StripStreamArgs a{};
@@ -567,7 +572,7 @@ bool strip_single(const cs_column* in, const CharSet& set, int side, hipStream_t
   Buf chars = dev_alloc((size_t)in->nbytes + 64, s);
   a.out_off = ptr<int64_t>(off);
   a.out_chars = ptr<uint8_t>(chars);
-  a.debug = getenv("CS_STRIP_DEBUG") ? atoi(getenv("CS_STRIP_DEBUG")) : 0;
+  a.debug = cs::cfg("CS_STRIP_DEBUG") ? atoi(cs::cfg("CS_STRIP_DEBUG")) : 0;
   if (lds > 48 * 1024)
     CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_strip_stream), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   // (+ 1: workgroup 0 is the scanners')
@@ -589,6 +594,7 @@ bool strip_single(const cs_column* in, const CharSet& set, int side, hipStream_t
   o->chars = chars;
   o->nbytes = host[0];
   return true;
+#endif
 }
 
 }  // namespace cs

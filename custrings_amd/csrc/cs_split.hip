@@ -1144,14 +1144,14 @@ bool split_fast(const cs_column* col, const unsigned char* delim, int dlen, int 
   unsigned long long d64 = 0;
   for (int i = 0; !ws && i < dlen; ++i) d64 |= (unsigned long long)delim[i] << (8 * i);
   const int64_t rows = col->rows;
-  if (rows == 0 || getenv("CS_SPLIT_GENERIC")) return false;
+  if (rows == 0 || cs::cfg("CS_SPLIT_GENERIC")) return false;
   int64_t span = max_span64(col, s);
   int cap_in = (int)((span + 15 + 32 + 127) & ~(int64_t)127);
   int cap_out = cap_in + 32 * kMaxColsWide;
   // (rows of hundreds of bytes: the first-generation kernels on sub-tiles of 32 / 16 / 8 rows -- a one-byte delimiter only)
   int rows_per_sub = kSub;
   bool outliers = false;
-  if ((size_t)(cap_in + cap_out + 64) * 4 > 150 * 1024 && mode == 0 && !reverse && !getenv("CS_NO_SMALL_TILES")) {
+  if ((size_t)(cap_in + cap_out + 64) * 4 > 150 * 1024 && mode == 0 && !reverse && !cs::cfg("CS_NO_SMALL_TILES")) {
     for (int r : {32, 16, 8}) {
       const int64_t sp = max_span_rows(col, r, s);
       const int ci = (int)((sp + 15 + 32 + 127) & ~(int64_t)127);
@@ -1167,7 +1167,7 @@ bool split_fast(const cs_column* col, const unsigned char* delim, int dlen, int 
   // (no sub-tile size fits the largest sub-tile, all but a few 64-row ones fit: the first-generation kernels with buffers
   // for those -- they read the rows of an oversize sub-tile from memory and write its tokens straight to the columns)
   // (also when the largest sub-tile would fit, at one workgroup per CU: a 10 KB row among short ones ran 39 ms that way)
-  if (rows_per_sub == kSub && cap_in > 8 * 1024 && mode == 0 && !reverse && !getenv("CS_NO_OUTLIER_TILES") && max_span64(col, s) < ((int64_t)1 << 30) &&
+  if (rows_per_sub == kSub && cap_in > 8 * 1024 && mode == 0 && !reverse && !cs::cfg("CS_NO_OUTLIER_TILES") && max_span64(col, s) < ((int64_t)1 << 30) &&
       few_spans64_over(col, 8 * 1024 - 64, s)) {
     rows_per_sub = kSub;
     span = 8 * 1024 - 64;
@@ -1182,16 +1182,16 @@ bool split_fast(const cs_column* col, const unsigned char* delim, int dlen, int 
   int* hmx = (int*)pinned_scratch(4 * sizeof(int));
 
   // ---- second generation: runs of sub-tiles per wave (rows up to 93 bytes, 64-row spans up to 6 KB)
-  if (rows_per_sub == kSub && !outliers && cap_in <= cstile::kPfBytes && !getenv("CS_SPLIT_OLD_EMIT")) {
+  if (rows_per_sub == kSub && !outliers && cap_in <= cstile::kPfBytes && !cs::cfg("CS_SPLIT_OLD_EMIT")) {
     // The run decomposition is a function of the row count alone (not of the emit kernel's
     // residency, which depends on what the measure pass finds): emit needs no co-residency.
     int dev = 0, cus = 0;
     CS_HIP(hipGetDevice(&dev));
     CS_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     // (the third-generation emit keeps 14 waves per CU resident: runs a quarter as long share the tail out evenly)
-    const bool want_emit3 = !getenv("CS_SPLIT_EMIT2");
+    const bool want_emit3 = !cs::cfg("CS_SPLIT_EMIT2");
     int runs_per_cu = want_emit3 ? 256 : 16;  // (short runs share the tail out evenly: 16 / 64 / 128 / 256 runs per CU -> emit 7.06 / 7.05 / 6.77 / 6.61 ms)
-    if (const char* e = getenv("CS_EMIT_RUNS_PER_CU")) runs_per_cu = std::max(1, atoi(e));  // (measurement)
+    if (const char* e = cs::cfg("CS_EMIT_RUNS_PER_CU")) runs_per_cu = std::max(1, atoi(e));  // (measurement)
     int64_t runs = std::min<int64_t>(nsub, (int64_t)cus * runs_per_cu);
     const int64_t per = (nsub + runs - 1) / runs;
     runs = (nsub + per - 1) / per;
@@ -1203,10 +1203,12 @@ bool split_fast(const cs_column* col, const unsigned char* delim, int dlen, int 
     CS_HIP(hipMemsetAsync(mx->p, 0, 4 * sizeof(int), s));
     // the sentinel walk (both passes): a one-byte delimiter, no split limit, every row's sentinel bit inside the 96-bit mask
     // (the longest row is column metadata, kept on the immutable column like its largest 64-row span)
-    const bool plain_walk = want_emit3 && mode == 0 && tokens <= 0 && !reverse && max_row_bytes(col, s) + 3 <= 95 && !getenv("CS_SPLIT_GENERIC_WALK");
+    const bool plain_walk = want_emit3 && mode == 0 && tokens <= 0 && !reverse && max_row_bytes(col, s) + 3 <= 95 && !cs::cfg("CS_SPLIT_GENERIC_WALK");
     // the single pass (cs_split1.hip), on request: measured slower than the two passes below (NOTES.md, round 4:
     // 8.0 against 6.7 ms on the 100M-row column); they also take over when it gives up
-    if (want_emit3 && getenv("CS_SPLIT_SINGLE") && !getenv("CS_SPLIT_OFF64") && split_single(col, delim, dlen, tokens, s, cols, reverse, span, plain_walk) == 1) return true;
+#if defined(CS_EXPERIMENTS)  // (cs_split1.hip is in the experiments build only: `make exp`)
+    if (want_emit3 && cs::cfg("CS_SPLIT_SINGLE") && !cs::cfg("CS_SPLIT_OFF64") && split_single(col, delim, dlen, tokens, s, cols, reverse, span, plain_walk) == 1) return true;
+#endif
     cols.clear();
     Measure2Args ma{view_of(col), dpat, d64, dlen, tokens, cap_in, nsub, per, seg, nseg, segs_per_run, reverse ? 1 : 0, ptr<int32_t>(colsum), ptr<int>(mx)};
     {
@@ -1231,7 +1233,7 @@ bool split_fast(const cs_column* col, const unsigned char* delim, int dlen, int 
       Buf base = dev_alloc(sizeof(int64_t) * (nseg + 1) * ncols, s);
       std::vector<int64_t> totals(ncols);
       offsets_from_lengths_segmented(ptr<int32_t>(colsum), nseg, ncols, ptr<int64_t>(base), totals.data(), s);
-      bool off32 = !getenv("CS_SPLIT_OFF64");
+      bool off32 = !cs::cfg("CS_SPLIT_OFF64");
       for (int k = 0; k < ncols; ++k) off32 = off32 && totals[k] < ((int64_t)1 << 31);
       std::vector<ColOut2> outs(ncols);
       for (int k = 0; k < ncols; ++k) {
@@ -1242,6 +1244,13 @@ bool split_fast(const cs_column* col, const unsigned char* delim, int dlen, int 
         if (off32) c->offsets32 = dev_alloc(sizeof(int32_t) * (rows + 1), s);
         else c->offsets = dev_alloc(sizeof(int64_t) * (rows + 1), s);
         c->validity = dev_alloc(validity_bytes(rows), s);
+        // column metadata for free (upper bounds: they size staging buffers and pick routes): a column gets at most `bound`
+        // bytes from one sub-tile (the measure pass: every row's longest token, summed), no token is longer than its row;
+        // tokens cut at ASCII delimiters out of a plain column are plain
+        c->max_span64 = bound;
+        c->max_row = std::min<int64_t>(longest_row, bound);
+        if (col->plain_bytes == 1) c->plain_bytes = 1;
+        if (col->high_sample == 0) c->high_sample = 0;
         outs[k] = ColOut2{ptr<uint8_t>(c->chars), off32 ? c->offsets32->p : c->offsets->p, ptr<uint8_t>(c->validity),
                           ptr<const int64_t>(base) + (int64_t)k * (nseg + 1)};
         cols.push_back(std::move(c));
@@ -1249,7 +1258,7 @@ bool split_fast(const cs_column* col, const unsigned char* delim, int dlen, int 
       Buf d_outs = dev_alloc(sizeof(ColOut2) * ncols, s);
       CS_HIP(hipMemcpyAsync(d_outs->p, outs.data(), sizeof(ColOut2) * ncols, hipMemcpyHostToDevice, s));
       Emit2Args e2{view_of(col), dpat, d64, dlen, tokens, cap_in, cap_col, ncols, nsub, per, segs_per_run, ptr<const ColOut2>(d_outs), nullptr,
-                   reverse ? 1 : 0, getenv("CS_SPLIT_DEBUG") ? atoi(getenv("CS_SPLIT_DEBUG")) : 0};
+                   reverse ? 1 : 0, cs::cfg("CS_SPLIT_DEBUG") ? atoi(cs::cfg("CS_SPLIT_DEBUG")) : 0};
 #if defined(CS_PHASE_PROF)
       Buf profbuf = dev_alloc(64, s);
       CS_HIP(hipMemsetAsync(profbuf->p, 0, 64, s));
@@ -1259,7 +1268,7 @@ bool split_fast(const cs_column* col, const unsigned char* delim, int dlen, int 
       // (regions: every token byte once, up to 15 carried bytes and up to 15 bytes of padding per column, 20 bytes of OR slack)
       const int cap_out3 = (int)((span + 31 * ncols + 48 + 15) & ~(int64_t)15);
       // (the fourth generation keeps its flush tables, 640 bytes, in the in tile once the column loop is over)
-      bool want_emit4 = !getenv("CS_SPLIT_EMIT3") && cap_out3 <= 8192;
+      bool want_emit4 = !cs::cfg("CS_SPLIT_EMIT3") && cap_out3 <= 8192;
       for (int k = 0; k < ncols; ++k) want_emit4 = want_emit4 && ((uintptr_t)outs[k].chars & 15) == 0;  // (a column's state is its position)
       const int cap_in3 = std::max((int)((span + 15 + 32 + 15) & ~(int64_t)15), want_emit4 ? 640 : 0);
       const size_t lds3 = 288 + (size_t)(16 + cap_in3 + 32 + cap_out3) * (kEmit3Threads / 64);
@@ -1322,7 +1331,7 @@ bool split_fast(const cs_column* col, const unsigned char* delim, int dlen, int 
   CS_HIP(hipGetLastError());
   CS_HIP(hipMemcpyAsync(hmx, mx->p, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
   CS_HIP(hipStreamSynchronize(s));
-  const int ncols = hmx[0];
+  const int ncols = hmx[0], widest1 = hmx[1], longest1 = hmx[2];  // (copied: the scratch is re-used by the scan below)
   if (ncols == 0 || ncols > kMaxColsWide) return false;  // all-null column / too many columns: generic path
 
   // per column: position of every sub-tile in the column's chars buffer
@@ -1331,7 +1340,7 @@ bool split_fast(const cs_column* col, const unsigned char* delim, int dlen, int 
   offsets_from_lengths_segmented(ptr<int32_t>(colsum), nsub1, ncols, ptr<int64_t>(base), totals.data(), s);
 
   // int32 offsets (as the later generations write them) when every column stays below 2 GiB: half the offset bytes
-  bool off32 = !getenv("CS_SPLIT_OFF64");
+  bool off32 = !cs::cfg("CS_SPLIT_OFF64");
   for (int k = 0; k < ncols; ++k) off32 = off32 && totals[k] < ((int64_t)1 << 31);
   std::vector<ColOut> outs(ncols);
   for (int k = 0; k < ncols; ++k) {
@@ -1342,6 +1351,11 @@ bool split_fast(const cs_column* col, const unsigned char* delim, int dlen, int 
     if (off32) c->offsets32 = dev_alloc(sizeof(int32_t) * (rows + 1), s);
     else c->offsets = dev_alloc(sizeof(int64_t) * (rows + 1), s);
     c->validity = dev_alloc(validity_bytes(rows), s);
+    // (upper bounds: hmx[1] is the most bytes any column gets from one sub-tile of rows_per_sub rows)
+    c->max_span64 = (int64_t)widest1 * (kSub / rows_per_sub);
+    c->max_row = std::min<int64_t>(longest1, widest1);
+    if (col->plain_bytes == 1) c->plain_bytes = 1;
+    if (col->high_sample == 0) c->high_sample = 0;
     outs[k] = ColOut{ptr<uint8_t>(c->chars), off32 ? c->offsets32->p : c->offsets->p, ptr<uint8_t>(c->validity),
                      ptr<const int64_t>(base) + (int64_t)k * (nsub1 + 1)};
     cols.push_back(std::move(c));

@@ -739,7 +739,7 @@ int split_single(const cs_column* col, const unsigned char* delim, int dlen, int
 
   // ---- the sample: every sub-tile of a small column, one in 64 of a large one (at least 4096)
   int64_t nsamp = std::min<int64_t>(nsub, std::max<int64_t>(4096, nsub / 64));
-  if (const char* e = getenv("CS_SPLIT1_SAMPLE")) nsamp = std::max<int64_t>(1, std::min<int64_t>(nsub, atoll(e)));  // (tests: the estimate path on small columns)
+  if (const char* e = cs::cfg("CS_SPLIT1_SAMPLE")) nsamp = std::max<int64_t>(1, std::min<int64_t>(nsub, atoll(e)));  // (tests: the estimate path on small columns)
   Buf sbuf = dev_alloc(sizeof(unsigned long long) * 2 * kCols1 + 4 * sizeof(int), s);
   CS_HIP(hipMemsetAsync(sbuf->p, 0, sizeof(unsigned long long) * 2 * kCols1 + 4 * sizeof(int), s));
   SampleArgs sa{view_of(col), dpat, d64, dlen, tokens, reverse ? 1 : 0, cap_in, nsub, nsamp, ptr<unsigned long long>(sbuf),
@@ -776,7 +776,7 @@ int split_single(const cs_column* col, const unsigned char* delim, int dlen, int
     const double want = est + 8.0 * sigma + (exact ? 64.0 : 65536.0);
     if (want >= 2147483000.0) return 0;  // int32 offsets could not name the column: the two-pass kernels choose the width
     capk[k] = ((long long)want + 511) & ~511ll;
-    if (const char* e = getenv("CS_SPLIT1_SHRINK")) capk[k] = std::max<long long>(512, (capk[k] / std::max(1, atoi(e))) & ~511ll);  // (tests: the give-up route)
+    if (const char* e = cs::cfg("CS_SPLIT1_SHRINK")) capk[k] = std::max<long long>(512, (capk[k] / std::max(1, atoi(e))) & ~511ll);  // (tests: the give-up route)
   }
 
   // ---- tiles, grid
@@ -833,7 +833,7 @@ int split_single(const cs_column* col, const unsigned char* delim, int dlen, int
 
   Emit5Args ea{view_of(col), dpat, d64, dlen, tokens, reverse ? 1 : 0, ncap, npairs, nsub, stride, cap_in, cap_out, wave_bytes, scan_blocks,
                ptr<const ColOut5>(d_outs), status, excl, ctl, totals, ptr<uint8_t>(tilecols), nullptr, nullptr,
-               getenv("CS_SPLIT_DEBUG") ? atoi(getenv("CS_SPLIT_DEBUG")) : 0};
+               cs::cfg("CS_SPLIT_DEBUG") ? atoi(cs::cfg("CS_SPLIT_DEBUG")) : 0};
 #if defined(CS_PHASE_PROF)
   Buf profbuf = dev_alloc(128, s);
   CS_HIP(hipMemsetAsync(profbuf->p, 0, 128, s));
@@ -841,7 +841,7 @@ int split_single(const cs_column* col, const unsigned char* delim, int dlen, int
 #endif
   Buf tracebuf;
   const long long ntrace = (nsub >> 10) + 1;
-  if (getenv("CS_SPLIT1_TRACE")) {
+  if (cs::cfg("CS_SPLIT1_TRACE")) {
     tracebuf = dev_alloc(sizeof(unsigned long long) * 4 * ntrace, s);
     CS_HIP(hipMemsetAsync(tracebuf->p, 0, sizeof(unsigned long long) * 4 * ntrace, s));
     ea.trace = ptr<unsigned long long>(tracebuf);
@@ -859,7 +859,7 @@ int split_single(const cs_column* col, const unsigned char* delim, int dlen, int
   CS_HIP(hipMemcpyAsync(hc->ctl, ctl, sizeof(hc->ctl), hipMemcpyDeviceToHost, s));
   CS_HIP(hipMemcpyAsync(hc->totals, totals, sizeof(long long) * 2 * npairs, hipMemcpyDeviceToHost, s));
   CS_HIP(hipStreamSynchronize(s));
-  if (getenv("CS_SPLIT1_STATS"))
+  if (cs::cfg("CS_SPLIT1_STATS"))
     fprintf(stderr, "split single pass: error %u columns %u (sample %d, provisioned %d) | worker spins %u | scanner fetches %u (empty %u) of %d scanners, %lld windows | mean gap between a wave's sub-tiles %.0f | grid %d + %lld x %d lds %zu\n",
             hc->ctl[0], hc->ctl[1], seen, ncap, hc->ctl[4], hc->ctl[5], hc->ctl[6], npairs, (long long)((nsub + 63) / 64),
             (double)*reinterpret_cast<unsigned long long*>(hc->ctl + 8) / (double)std::max(1u, hc->ctl[7]), scan_blocks, (long long)workers, kThreads1, lds);

@@ -47,7 +47,9 @@ extern "C" int cs_synth_column(int kind, int64_t first_row, int64_t rows, uint64
     hipLaunchKernelGGL(k_synth_sizes, dim3(nb), dim3(kBlock), 0, s, kind, first_row, rows, seed, param,
                        ptr<int32_t>(lens), ptr<int64_t>(sums));
     c->offsets = dev_alloc(sizeof(int64_t) * (rows + 1), s);
-    c->nbytes = offsets_from_lengths(ptr<int32_t>(lens), rows, ptr<int64_t>(c->offsets), s, sums);
+    LenMeta meta;  // (a generated column is sized at ingest like any other: NVStringsImpl.cu:399-444)
+    c->nbytes = offsets_from_lengths(ptr<int32_t>(lens), rows, ptr<int64_t>(c->offsets), s, sums, &meta);
+    meta.give(c.get());
     c->chars = dev_alloc((size_t)c->nbytes, s);
     if (kind != 3) c->validity = validity_from_lengths(ptr<int32_t>(lens), rows, s);
     else c->null_count = 0;

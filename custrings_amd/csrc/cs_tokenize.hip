@@ -258,7 +258,7 @@ namespace cs {
 
 bool tokenize_fast(const cs_column* col, const unsigned char* delims, int ndel, hipStream_t s, cs_column** out) {
   const int64_t rows = col->rows;
-  if (rows == 0 || ndel > 4 || getenv("CS_TOKENIZE_ROWWISE")) return false;
+  if (rows == 0 || ndel > 4 || cs::cfg("CS_TOKENIZE_ROWWISE")) return false;
   for (int k = 0; k < ndel; ++k)
     if (delims[k] == 0 || delims[k] >= 128) return false;
   // rows per tile: the largest of 64 / 32 / 16 whose widest tile fits the prefetch registers
@@ -271,7 +271,7 @@ bool tokenize_fast(const cs_column* col, const unsigned char* delims, int ndel, 
   }
   // (no tile size fits every tile: 64-row tiles, the oversize ones taken in segments by the kernel -- byte-parallel still)
   bool segs = false;
-  if (!R && max_span64(col, s) < ((int64_t)1 << 30) && !getenv("CS_NO_OUTLIER_TILES")) {
+  if (!R && max_span64(col, s) < ((int64_t)1 << 30) && !cs::cfg("CS_NO_OUTLIER_TILES")) {
     R = 64;
     segs = true;
   }

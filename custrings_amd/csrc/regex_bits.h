@@ -1,0 +1,213 @@
+// Bit-parallel form of a compiled regex program ("bit program"): the matches of a plain-ASCII row by integer arithmetic on
+// per-class bit masks of the row -- no automaton, no table walk per byte.  For patterns whose candidate bytes are
+// everywhere (alternations of word-bounded literals, small character classes in a `+` loop: the reference's own gtest
+// pattern (\bin\b)|(\ba\b)|(\bthe\b), cpp/tests/test_replace.cpp:40), where the tagged DFA has to walk every byte of
+// every row in a dependent chain of table reads.
+//
+// What converts (regex_bits.cpp, from the Reprog-identical instruction stream): a program without loops whose paths from
+// the start to END number at most kMaxAlts -- alternations and optional parts expand into ALTERNATIVES, in the order in
+// which the reference's executor prefers them (regexec.inl:204-442: the OR's preferred branch first) --, every path a
+// sequence of single-character items (literal, class, `.`) and assertions (\b \B ^ $ \A \Z) of fixed length 1..31; or ONE
+// such path that ends in a greedy `+` loop over its last item (`[aeiou]+`, `#\w+`).  At most kMaxClasses distinct ASCII
+// member sets over all items.
+//
+// Semantics (what the reference computes, restated on masks).  Row of n bytes, all ASCII, none NUL; bit i of a class mask
+// = byte i is a member; cursor q in 0..n lies in front of byte q.  An alternative with items (X_i at offset o_i) matches
+// at start p iff every X_i holds at p + o_i: A_j = AND_i (X_i >> o_i), all starts at once.  The executor prefers the
+// leftmost start and, at one start, the first alternative in priority order that matches (threads of an earlier start,
+// then of an earlier branch, come first in its list and cut the later ones off at END): sel_j = A_j & ~(A_1 | ... |
+// A_{j-1}); the match at p has alternative j's length.  Successive matches do not overlap: the next search starts at
+// the end of the last match (replace.cu:91-93, count.cu:168-250) -- a loop over the row's matches, lowest start first.
+// With a trailing `+` the match runs to the end of the run of its last class (greedy, nothing follows that could ask
+// for less).  An alternative cannot match the empty string (such programs do not convert).
+//
+// Image (int32 words):
+//   [0] magic 'CSBP' [1] classes K [2] flags [3] alternatives J [4] words in all [5] class of the trailing `+` (-1: none)
+//   [6] class holding the word characters (for \b \B; -1: not needed) [7] class holding '\n' (multi-line ^ $; -1)
+//   [8..39]  128 bytes: for every ASCII byte the set of classes it belongs to (bit k = class k)
+//   [40..]   per alternative: items | length << 8, then one word per item: kind | class << 8 | offset << 16
+#pragma once
+#include <stdint.h>
+
+#include "regex_tdfa.h"
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define CSBITS_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)  // (the program words are the same for every lane: scalar control flow)
+#else
+#define CSBITS_UNIFORM(x) (x)
+#endif
+
+namespace csbits {
+
+using cstd::U128;
+
+constexpr int32_t kMagic = 0x50425343;  // "CSBP"
+constexpr int kMaxClasses = 8, kMaxAlts = 16, kMaxItems = 32, kMaxLen = 31, kHeaderWords = 8, kTableWords = 32;
+constexpr int kMaxWords = 40 + kMaxAlts * (1 + kMaxItems);
+constexpr int kMaxRowBytes = 95;  // cursors 0..n fit the 96-bit masks
+enum { F_WORD = 1, F_BOL = 2, F_EOL = 4, F_BOL_MULTI = 8, F_EOL_MULTI = 16, F_PURE_PLUS = 32, F_PLUS = 64, F_SAME_LEN = 128 };
+enum { K_CLASS = 0, K_BOW = 1, K_NBOW = 2, K_BOL = 3, K_EOL = 4, K_BOL_MULTI = 5, K_EOL_MULTI = 6 };
+
+struct View {
+  const int32_t* img;
+  int K, J, plus_cls, word_cls, nl_cls;
+  uint32_t flags;
+};
+CS_HD View make_view(const int32_t* img) {
+  View v;
+  v.img = img;
+  v.K = img[1];
+  v.flags = (uint32_t)img[2];
+  v.J = img[3];
+  v.plus_cls = img[5];
+  v.word_cls = img[6];
+  v.nl_cls = img[7];
+  return v;
+}
+CS_HD bool offered(const int32_t* img, int words) { return words >= 41 && img[0] == kMagic; }
+
+CS_HD U128 shr(U128 a, int k) {  // k in 0..63
+  if (k == 0) return a;
+  return cstd::u128((a.lo >> k) | (a.hi << (64 - k)), a.hi >> k);
+}
+CS_HD U128 shr1(U128 a) { return cstd::u128((a.lo >> 1) | (a.hi << 63), a.hi >> 1); }
+CS_HD U128 bit_at(int q) { return q < 64 ? cstd::u128(1ull << q, 0) : cstd::u128(0, 1ull << (q - 64)); }
+CS_HD unsigned test(U128 a, int q) { return (unsigned)((q < 64 ? a.lo >> q : a.hi >> (q - 64)) & 1ull); }
+
+// Classification by table lookup.  The SPREAD table holds, for every ASCII byte, its class set with class k at bit 4k: the
+// entries of four consecutive bytes, shifted by 0..3 and OR-ed, leave one nibble per class -- the four bytes' membership
+// bits.  Sixteen bytes (four words, first byte lowest) give, for every class, sixteen bits: pair[m] = class 2m | class
+// 2m+1 << 16.  (The low seven bits of a byte index the table: a piece with bytes >= 0x80 never uses the result.)
+CS_HD uint32_t spread_entry(uint32_t set) {
+  uint32_t e = 0;
+  for (int k = 0; k < 8; ++k) e |= ((set >> k) & 1u) << (4 * k);
+  return e;
+}
+CS_HD void classify16(const uint32_t* spread, uint32_t x, uint32_t y, uint32_t z, uint32_t w, uint32_t pair[4]) {
+  const uint32_t q[4] = {x, y, z, w};
+  uint32_t a[4];
+  for (int j = 0; j < 4; ++j)
+    a[j] = spread[q[j] & 127u] | (spread[(q[j] >> 8) & 127u] << 1) | (spread[(q[j] >> 16) & 127u] << 2) | (spread[(q[j] >> 24) & 127u] << 3);
+  // byte m of lo_e / hi_e: bytes 0..7 / 8..15 of the piece for class 2m (lo_o / hi_o: class 2m + 1)
+  const uint32_t lo_e = (a[0] & 0x0F0F0F0Fu) | ((a[1] & 0x0F0F0F0Fu) << 4), hi_e = (a[2] & 0x0F0F0F0Fu) | ((a[3] & 0x0F0F0F0Fu) << 4);
+  const uint32_t lo_o = ((a[0] >> 4) & 0x0F0F0F0Fu) | (a[1] & 0xF0F0F0F0u), hi_o = ((a[2] >> 4) & 0x0F0F0F0Fu) | (a[3] & 0xF0F0F0F0u);
+  for (int m = 0; m < 4; ++m) {
+    const uint32_t even = ((lo_e >> (8 * m)) & 255u) | (((hi_e >> (8 * m)) & 255u) << 8);
+    const uint32_t odd = ((lo_o >> (8 * m)) & 255u) | (((hi_o >> (8 * m)) & 255u) << 8);
+    pair[m] = even | (odd << 16);
+  }
+}
+
+// All starts at which some alternative matches (`any`) and, for the span forms, the chosen alternative's length in binary
+// across five planes.  `cls(k, off)` hands out the row's mask of class k shifted right by `off` (bit i = byte i + off is a
+// member; cut at the row's length n <= kMaxRowBytes): the kernels cut it out of the class's bitmap at the shifted position,
+// on demand -- a class mask is never held in registers beyond its use.  `raw(k, off)` is the same without the cut at the
+// row's end (bits from n - off on are unspecified -- in the kernels they are the next row's): an alternative of length L
+// only admits starts p with p + L <= n, so its items never look beyond the row and the one mask on the starts replaces a
+// mask per item.
+template <class Cls, class Raw>
+CS_HD U128 starts(const View& V, Cls&& cls, Raw&& raw, int n, bool want_len, U128 plane[5]) {
+  using namespace cstd;
+  const U128 cursors = u128_below(n + 1);
+  U128 bnd = u128(0, 0), bol = u128(1, 0), eol = bit_at(n), bolm = bol, eolm = eol;
+  if (V.flags & F_WORD) {
+    const U128 W = cls(V.word_cls, 0);
+    bnd = u128_and(u128(W.lo ^ (W.lo << 1), W.hi ^ ((W.hi << 1) | (W.lo >> 63))), cursors);
+  }
+  if (V.flags & (F_BOL_MULTI | F_EOL_MULTI)) {
+    const U128 NL = cls(V.nl_cls, 0);
+    bolm = u128_or(bol, u128_and(u128_shl1(NL), cursors));  // behind a newline (regexec.inl: BOL with '^')
+    eolm = u128_or(eol, NL);                                  // in front of a newline (EOL with '$')
+  }
+  U128 any = u128(0, 0);
+  if (want_len)
+    for (int b = 0; b < 5; ++b) plane[b] = u128(0, 0);
+  const int32_t* w = V.img + kHeaderWords + kTableWords;
+  for (int j = 0; j < V.J; ++j) {
+    const int hdr = CSBITS_UNIFORM(*w++);
+    const int items = hdr & 255, len = (hdr >> 8) & 255;
+    U128 A = u128_below(n - len + 1 > 0 ? n - len + 1 : 0);  // starts whose match stays inside the row
+    for (int i = 0; i < items; ++i) {
+      const int it = CSBITS_UNIFORM(*w++);
+      const int kind = it & 255, arg = (it >> 8) & 255, off = (it >> 16) & 255;
+      if (kind == K_CLASS) {
+        A = u128_and(A, raw(arg, off));
+        continue;
+      }
+      U128 X;
+      switch (kind) {
+        case K_BOW: X = bnd; break;
+        case K_NBOW: X = u128_andn(cursors, bnd); break;
+        case K_BOL: X = bol; break;
+        case K_EOL: X = eol; break;
+        case K_BOL_MULTI: X = bolm; break;
+        default: X = eolm; break;
+      }
+      A = u128_and(A, shr(X, off));
+    }
+    if (want_len) {
+      const U128 sel = u128_andn(A, any);
+      for (int b = 0; b < 5; ++b)
+        if ((len >> b) & 1) plane[b] = u128_or(plane[b], sel);
+    }
+    any = u128_or(any, A);
+  }
+  return any;
+}
+
+// The row's matches in order, non-overlapping: S = first bytes, E = last bytes (one bit each per match).
+template <class Cls, class Raw>
+CS_HD void match(const View& V, Cls&& cls, Raw&& raw, int n, U128& S, U128& E) {
+  using namespace cstd;
+  if (V.flags & F_PURE_PLUS) {  // `[set]+` alone: the maximal runs of the class
+    const U128 C = cls(V.plus_cls, 0);
+    S = u128_andn(C, u128_shl1(C));
+    E = u128_andn(C, shr1(C));
+    return;
+  }
+  U128 plane[5];
+  const bool same_len = (V.flags & F_SAME_LEN) != 0;  // (one length for every alternative: no planes)
+  const int the_len = CSBITS_UNIFORM(V.img[kHeaderWords + kTableWords]) >> 8 & 255;
+  U128 rem = starts(V, cls, raw, n, !same_len, plane);
+  S = u128(0, 0);
+  E = u128(0, 0);
+  U128 C = u128(0, 0);
+  if (V.flags & F_PLUS) C = cls(V.plus_cls, 0);
+  while (u128_any(rem)) {
+    const int p = u128_ctz(rem);
+    int len = the_len;
+    if (!same_len) {
+      len = 0;
+      for (int b = 0; b < 5; ++b) len |= (int)test(plane[b], p) << b;
+    }
+    int end = p + len;  // the cursor behind the match
+    if (V.flags & F_PLUS) {
+      // the run of the last class goes on from the match's last fixed byte: its end is the first non-member at or behind `end`
+      const U128 stop = u128_andn(u128(~0ull, ~0ull), u128_or(C, u128_below(end)));
+      end = u128_ctz(stop);  // (bits n .. 127 of C are zero: a stop exists)
+    }
+    S = u128_or(S, bit_at(p));
+    E = u128_or(E, bit_at(end - 1));
+    rem = u128_andn(rem, u128_below(end));
+  }
+}
+
+template <class Cls, class Raw>
+CS_HD bool contains(const View& V, Cls&& cls, Raw&& raw, int n) {
+  U128 unused[5];
+  return cstd::u128_any(starts(V, cls, raw, n, false, unused));
+}
+template <class Cls, class Raw>
+CS_HD bool match_at_start(const View& V, Cls&& cls, Raw&& raw, int n) {
+  U128 unused[5];
+  return (starts(V, cls, raw, n, false, unused).lo & 1ull) != 0;
+}
+
+}  // namespace csbits
+
+namespace csrx {
+struct Program;
+// The bit program of `prog` (empty: the program does not convert).  `image` is the program's device image
+// (Program::to_device_image), `flags` the 64 KiB unicode flag table.
+std::vector<int32_t> build_bits(const Program& prog, const std::vector<int32_t>& image, const uint8_t* flags);
+}  // namespace csrx

@@ -1,6 +1,7 @@
 // Host-side construction of the tagged DFA (layout and semantics: regex_tdfa.h).
 // Pure host C++; compiled into the library and into tests/rowemu.
 #include "regex_tdfa.h"
+#include "cs_config.h"
 
 #include <algorithm>
 #include <cstdlib>
@@ -579,9 +580,9 @@ std::vector<int32_t> build_tdfa(const Program& prog, const std::vector<int32_t>&
     // ends are then filtered by a byte compare (chain_suffix_filter).  Such a pattern usually has no unit decomposition
     // (two non-killer bytes outside the ranges); x is then the first literal of the line that is not in R, and header word
     // 31 carries it WITHOUT bit 0 (the kernels stage the "equals x" bitmap from it; the unit route stays off).
-    if (nskip > 0 && maxslots <= 4 && B.min_match_chars() >= 1 && !B.use_word && !B.use_line && !getenv("CS_NO_CHAIN")) {
+    if (nskip > 0 && maxslots <= 4 && B.min_match_chars() >= 1 && !B.use_word && !B.use_line && !cs::cfg("CS_NO_CHAIN")) {
       int x = (word >> 8) & 127;
-      const bool x_free = !(word & 1) && !getenv("CS_NO_CHAIN_SUFFIX");  // (no unit decomposition: the chain picks its own x)
+      const bool x_free = !(word & 1) && !cs::cfg("CS_NO_CHAIN_SUFFIX");  // (no unit decomposition: the chain picks its own x)
       uint32_t items = 0;
       int ni = 0;
       size_t seen = 0;
@@ -612,7 +613,7 @@ std::vector<int32_t> build_tdfa(const Program& prog, const std::vector<int32_t>&
         }
         const bool lit_off_r = in.type == OP_CHAR && (uint32_t)in.u1 >= 1u && (uint32_t)in.u1 < 128u && !in_ranges((int)in.u1);
         if (slen > 0) {  // inside the suffix: literals outside R only
-          if (!lit_off_r || slen == 4 || getenv("CS_NO_CHAIN_SUFFIX")) {
+          if (!lit_off_r || slen == 4 || cs::cfg("CS_NO_CHAIN_SUFFIX")) {
             ok = false;
             break;
           }
@@ -631,7 +632,7 @@ std::vector<int32_t> build_tdfa(const Program& prog, const std::vector<int32_t>&
         }
         if (in.type == OP_CHAR && (uint32_t)in.u1 >= 128u) is_r = is_x = false;
         const int cls = is_r ? 0 : (is_x ? 1 : -1);
-        if (cls < 0 && lit_off_r && ni > 0 && !getenv("CS_NO_CHAIN_SUFFIX")) {  // the suffix begins
+        if (cls < 0 && lit_off_r && ni > 0 && !cs::cfg("CS_NO_CHAIN_SUFFIX")) {  // the suffix begins
           sfx = (uint32_t)in.u1;
           slen = 1;
           pc = in.u2;

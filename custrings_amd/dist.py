@@ -354,7 +354,7 @@ def global_category_c_abi(local_col, group=None):
 
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
-    hip = C.CDLL("libamdhip64.so")
+    hip = _lib.loaded_hip()  # (the runtime already mapped: a bare name may load a second one)
     hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
     hip.hipStreamSynchronize.argtypes = [C.c_void_p]
     staged = dist.is_initialized() and dist.get_backend(group) == "gloo"  # (several ranks on one GPU: through host memory)

@@ -64,6 +64,9 @@ typedef struct cs_column_view {
 
 /* ---- library ----------------------------------------------------------- */
 int cs_version(void);
+/* 1 when the library was built with the experiments (`make exp`: the one-pass split and strip kernels -- bit-exact,
+ * measured slower than the product's two passes, kept out of the product library), else 0. */
+int cs_has_experiments(void);
 const char* cs_last_error(void);
 int cs_device_count(void);
 /* Binds the calling thread to `device`, creates the stream-ordered memory
@@ -81,6 +84,13 @@ int cs_current_device(void);
  * fully resident, e.g. a co-tenant on the device) and the column was recomputed
  * with the two-pass kernels.  Correct either way; a benchmark should see 0. */
 int64_t cs_fallback_count(void);
+/* Diagnostics / tests: which route the calling thread's last regex stream launch took -- "bits" (the bit-parallel form,
+ * regex_bits.h), "chain", "units", "literal", "wide", "plain", "brefs" -- or "" when the call used other kernels. */
+const char* cs_debug_last_route(void);
+/* The CS_* switches (measurement aids, route overrides, opt-in experiments) are read from the environment ONCE, at the
+ * library's first look (cs_init); the dispatch paths never call getenv.  This changes one at run time, thread-safely
+ * (value NULL: unset) -- for tests and tools; a production host sets its environment before cs_init. */
+int cs_config_set(const char* name, const char* value);
 /* Bytes currently held by live columns/categories on this device. */
 int64_t cs_device_bytes_in_use(void);
 
@@ -132,6 +142,12 @@ int64_t cs_column_nbytes(const cs_column* col);
  * 2 GiB of chars) or 8.  Either way cs_column_get_view hands out int64 offsets. */
 int cs_column_offset_width(const cs_column* col);
 int64_t cs_column_null_count(const cs_column* col);
+/* What the column already knows about itself, without computing anything (diagnostics / tests): out[0] largest byte
+ * span of 64 consecutive rows starting at a multiple of 64, out[1] longest row in bytes -- both upper bounds when an op
+ * derived them as a by-product, exact when a pass measured them --, out[2] "plain bytes" (1 / 0), out[3] the non-ASCII
+ * sample (1 / 0); -1 = not known yet (the first op that needs the number pays a pass for it).  The reference sizes its
+ * strings once at ingest (NVStringsImpl.cu:399-444); here producers hand the numbers on so that ops in a chain do not. */
+int cs_column_cached_meta(const cs_column* col, int64_t out[4]);
 int cs_column_get_view(const cs_column* col, cs_column_view* view);
 /* NVStrings::create_offsets (NVStrings.h:207): int32 offsets (rows+1), chars,
  * optional bitmask.  CS_ERR_RANGE when nbytes >= 2^31. */

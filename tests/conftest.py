@@ -14,6 +14,31 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(autouse=True)
+def _cs_switches(monkeypatch):
+    """The library reads its CS_* switches from the environment ONCE (custrings_amd/csrc/cs_config.h) and changes them at run
+    time only through cs_config_set: a test that sets one with monkeypatch.setenv tells the library too, and the switch goes
+    back to what the process started with afterwards."""
+    touched = {}
+    plain_setenv = monkeypatch.setenv
+
+    def setenv(name, value, prepend=None):
+        if name.startswith("CS_") and name not in touched:
+            touched[name] = os.environ.get(name)
+        plain_setenv(name, value, prepend)
+        if name.startswith("CS_"):
+            from custrings_amd import _lib
+
+            _lib.lib.cs_config_set(name.encode(), str(value).encode())
+
+    monkeypatch.setenv = setenv
+    yield
+    for name, before in touched.items():
+        from custrings_amd import _lib
+
+        _lib.lib.cs_config_set(name.encode(), None if before is None else before.encode())
+
+
 @pytest.fixture(scope="session")
 def oracle_engine():
     import engines

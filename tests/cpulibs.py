@@ -272,6 +272,7 @@ class Oracle(CpuLib):
         self._f("category", vp, [vp, vp])
         self._f("ngrams", vp, [vp, C.c_uint, C.c_char_p])
         self._f("synth", vp, [C.c_int, C.c_int64, C.c_int64, C.c_uint64, C.c_int64])
+        self._f("digest", C.c_uint64, [vp])
         # second part (oracle_round2.inc)
         i32, i64 = C.c_int, C.c_int64
         self._f("len", i64, [vp, vp])
@@ -477,6 +478,13 @@ class Oracle(CpuLib):
     def synth(self, kind, first_row, rows, seed=20240607, param=0):
         return self.take(self._synth(kind, first_row, rows, seed, param))
 
+    def digest(self, col):
+        """include/cs_synth_spec.h: the column digest (sum over rows of cs_digest_row) -- what cs_column_digest computes on the device"""
+        h = self.put(col)
+        d = int(self._digest(h))
+        self._col_free(h)
+        return d
+
 
 class RowEmu(CpuLib):
     def __init__(self):
@@ -499,6 +507,8 @@ class RowEmu(CpuLib):
         self._f("regex_chain", C.c_int, [vp])
         self._f("regex_chain_sfx", C.c_int, [vp])
         self._f("set_chain", None, [C.c_int])
+        self._f("set_bits", None, [C.c_int])
+        self._f("regex_bits_info", None, [vp, C.POINTER(C.c_int)])
 
     def set_engine(self, e):
         """0 = list simulator (Pike VM) only, 1 = tagged DFA when the program converts"""
@@ -524,6 +534,18 @@ class RowEmu(CpuLib):
         if items and sl:
             items += "|" + "".join(chr((sfx >> (8 * k)) & 255) for k in range(sl))
         return items or None
+
+    def bits(self, pattern):
+        """The bit-parallel form (regex_bits.h) of a pattern: (classes, alternatives, flags) or None when it does not convert"""
+        re = self.compile(pattern)
+        out = (C.c_int * 4)()
+        self._regex_bits_info(re, out)
+        self._regex_free(re)
+        return (out[1], out[3], out[2]) if out[0] else None
+
+    def set_bits(self, on):
+        """1: rows the bit-parallel form takes (plain ASCII, at most 95 bytes) go through it in contains_re / match / count_re / replace_re"""
+        self._set_bits(int(on))
 
     def set_chain(self, on):
         """0: chain patterns keep the unit route in the host emulation of replace_re"""

@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "../../custrings_amd/csrc/regex_program.h"
+#include "../../custrings_amd/csrc/regex_bits.h"
 #include "../../custrings_amd/csrc/regex_tdfa.h"
 #include "../../custrings_amd/csrc/regex_vm.h"
 #include "../../custrings_amd/csrc/row_ops.h"
@@ -269,8 +270,17 @@ static int split_any(const emu_col* c, const char* delim, int maxsplit, emu_col*
 
 // ---- regex ----
 struct emu_regex {
-  std::vector<int32_t> blob, image, tdfa, gtags;
+  std::vector<int32_t> blob, image, tdfa, gtags, bits;
 };
+static int g_bits = 0;  // 1: rows the bit-parallel form takes (plain ASCII, at most 95 bytes) go through regex_bits.h
+void emu_set_bits(int on) { g_bits = on; }
+// [words, classes, flags, alternatives] of the bit-parallel form; 0 words = the program does not convert
+void emu_regex_bits_info(const emu_regex* re, int* out) {
+  out[0] = (int)re->bits.size();
+  out[1] = re->bits.empty() ? 0 : re->bits[1];
+  out[2] = re->bits.empty() ? 0 : re->bits[2];
+  out[3] = re->bits.empty() ? 0 : re->bits[3];
+}
 static int g_engine = 1;  // 0 = list simulator only, 1 = tagged DFA when the program converts
 void emu_set_engine(int e) { g_engine = e; }
 emu_regex* emu_regex_compile(const char* pattern) {
@@ -279,6 +289,7 @@ emu_regex* emu_regex_compile(const char* pattern) {
   re->blob = p.to_blob();
   re->image = p.to_device_image(orc_unicode_flags);
   re->tdfa = csrx::build_tdfa(p, re->image, orc_unicode_flags, &re->gtags);
+  re->bits = csrx::build_bits(p, re->image, orc_unicode_flags);
   return re;
 }
 // [states, atoms, max slots, min match chars, image words] of the tagged DFA; 0 states = not convertible
@@ -338,12 +349,78 @@ static void with_vm(const emu_regex* re, const uint8_t* row, int len, F f) {
     f(vm);
   }
 }
+// The bit-parallel form on one row, as the stream kernels run it: the row sits somewhere in a staged span (here: behind
+// `lead` bytes of something else), every 16-byte piece of the span is classified through the spread table into one bitmap
+// per class (regex_bits.h: classify16), the row's class masks are cut out of the bitmaps, the matches follow from the masks.
+struct BitsRow {
+  cstd::U128 C[csbits::kMaxClasses];
+  csbits::View V;
+  bool ok = false;
+  BitsRow(const emu_regex* re, const uint8_t* row, int len) {
+    if (!g_bits || re->bits.empty() || len > csbits::kMaxRowBytes) return;
+    for (int i = 0; i < len; ++i)
+      if (row[i] == 0 || row[i] >= 0x80) return;
+    V = csbits::make_view(re->bits.data());
+    uint32_t spread[128];
+    for (unsigned c = 0; c < 128; ++c) spread[c] = csbits::spread_entry(((uint32_t)re->bits[csbits::kHeaderWords + (c >> 2)] >> (8 * (c & 3))) & 255u);
+    const int lead = (int)(((uintptr_t)row >> 2) % 13) + 3;  // any alignment inside the span
+    std::vector<uint8_t> span((size_t)((lead + len + 15 + 16) & ~15), (uint8_t)'z');
+    memcpy(span.data() + lead, row, (size_t)len);
+    std::vector<uint16_t> bm[csbits::kMaxClasses];
+    for (int k = 0; k < V.K; ++k) bm[k].assign(span.size() / 16 + 1, 0);
+    for (size_t i = 0; i + 16 <= span.size(); i += 16) {
+      uint32_t q[4], pair[4];
+      memcpy(q, span.data() + i, 16);
+      csbits::classify16(spread, q[0], q[1], q[2], q[3], pair);
+      for (int k = 0; k < V.K; ++k) bm[k][i >> 4] = (uint16_t)((pair[k >> 1] >> (16 * (k & 1))) & 0xFFFFu);
+    }
+    for (int k = 0; k < csbits::kMaxClasses; ++k) {
+      C[k] = cstd::u128(0, 0);
+      for (int i = 0; k < V.K && i < len; ++i) {
+        const int p = lead + i;
+        if ((bm[k][p >> 4] >> (p & 15)) & 1u) C[k] = cstd::u128_or(C[k], csbits::bit_at(i));
+      }
+    }
+    ok = true;
+  }
+  auto cls() const {
+    return [this](int k, int off) { return csbits::shr(C[k], off); };
+  }
+  // (the unmasked form: what lies beyond the row is the next row's in the kernels -- here every such bit is set, so that a
+  // result that depended on them would show)
+  auto raw(int len) const {
+    return [this, len](int k, int off) {
+      return cstd::u128_or(csbits::shr(C[k], off), cstd::u128_andn(cstd::u128(~0ull, ~0ull), cstd::u128_below(len - off > 0 ? len - off : 0)));
+    };
+  }
+};
+// the row's matches for replace_re: by the bit-parallel form when it takes the row (no limit on replacements), else by the VM
+template <class Emit>
+static void replace_matches(const emu_regex* re, const uint8_t* row, int len, int maxrepl, Emit emit) {
+  BitsRow b(re, row, len);
+  if (b.ok && maxrepl < 0) {
+    cstd::U128 S, E;
+    csbits::match(b.V, b.cls(), b.raw(len), len, S, E);
+    while (cstd::u128_any(S)) {
+      const int mb = cstd::u128_ctz(S), me = cstd::u128_ctz(E) + 1;
+      S = cstd::u128_clear_lowest(S);
+      E = cstd::u128_clear_lowest(E);
+      emit(mb, me, 1);
+    }
+    return;
+  }
+  with_vm(re, row, len, [&](auto& vm) { csvm::row_replace_matches(vm, maxrepl, emit); });
+}
 extern "C" {
 int64_t emu_contains_re(const emu_col* c, const emu_regex* re, int mode, uint8_t* out) {
   int64_t n = 0;
   for (int64_t r = 0; r < c->rows; ++r) {
     out[r] = 0;
-    if (c->ok(r)) with_vm(re, c->row(r), c->len(r), [&](auto& vm) { out[r] = (uint8_t)csvm::row_contains_re(vm, mode != 0); });
+    if (c->ok(r)) {
+      BitsRow b(re, c->row(r), c->len(r));
+      if (b.ok) out[r] = mode ? csbits::match_at_start(b.V, b.cls(), b.raw(c->len(r)), c->len(r)) : csbits::contains(b.V, b.cls(), b.raw(c->len(r)), c->len(r));
+      else with_vm(re, c->row(r), c->len(r), [&](auto& vm) { out[r] = (uint8_t)csvm::row_contains_re(vm, mode != 0); });
+    }
     n += out[r];
   }
   return n;
@@ -352,7 +429,16 @@ int64_t emu_count_re(const emu_col* c, const emu_regex* re, int32_t* out) {
   int64_t n = 0;
   for (int64_t r = 0; r < c->rows; ++r) {
     out[r] = 0;
-    if (c->ok(r)) with_vm(re, c->row(r), c->len(r), [&](auto& vm) { out[r] = csvm::row_count_re(vm); });
+    if (c->ok(r)) {
+      BitsRow b(re, c->row(r), c->len(r));
+      if (b.ok) {
+        cstd::U128 S, E;
+        csbits::match(b.V, b.cls(), b.raw(c->len(r)), c->len(r), S, E);
+        out[r] = cstd::u128_popc(S);
+      } else {
+        with_vm(re, c->row(r), c->len(r), [&](auto& vm) { out[r] = csvm::row_count_re(vm); });
+      }
+    }
     n += out[r] > 0;
   }
   return n;
@@ -365,16 +451,14 @@ emu_col* emu_replace_re(const emu_col* c, const emu_regex* re, const char* repl,
       [&](int64_t r) {
         if (!c->ok(r)) return -1;
         int out = c->len(r);
-        with_vm(re, c->row(r), c->len(r), [&](auto& vm) {
-          csvm::row_replace_matches(vm, maxrepl, [&](int mb, int me, int reps) { out += reps * rb - (me - mb); });
-        });
+        replace_matches(re, c->row(r), c->len(r), maxrepl, [&](int mb, int me, int reps) { out += reps * rb - (me - mb); });
         return out;
       },
       [&](int64_t r, uint8_t* o) {
         const uint8_t* p = c->row(r);
         int copied = 0;
-        with_vm(re, p, c->len(r), [&](auto& vm) {
-          csvm::row_replace_matches(vm, maxrepl, [&](int mb, int me, int reps) {
+        {
+          replace_matches(re, p, c->len(r), maxrepl, [&](int mb, int me, int reps) {
             memcpy(o, p + copied, (size_t)(mb - copied));
             o += mb - copied;
             for (int k = 0; k < reps; ++k) {
@@ -383,7 +467,7 @@ emu_col* emu_replace_re(const emu_col* c, const emu_regex* re, const char* repl,
             }
             copied = me;
           });
-        });
+        }
         memcpy(o, p + copied, (size_t)(c->len(r) - copied));
       });
 }

@@ -324,13 +324,11 @@ def test_gpu_full_size_c3_split_windows(orc):
             else:
                 assert chars.size == 0 and not got.bitmask().any(), (first, k)
     # the same call with 64-bit offsets forced gives the same columns (digest covers offsets, chars, validity)
-    import os
-
-    os.environ["CS_SPLIT_OFF64"] = "1"
+    L.check(L.lib.cs_config_set(b"CS_SPLIT_OFF64", b"1"))
     try:
         cols64 = g.split(" ")
     finally:
-        del os.environ["CS_SPLIT_OFF64"]
+        L.check(L.lib.cs_config_set(b"CS_SPLIT_OFF64", None))
     assert all(int(L.lib.cs_column_offset_width(c.m_cptr)) == 8 for c in cols64)
     assert [c.digest() for c in cols64] == [c.digest() for c in cols]
 

@@ -8,21 +8,30 @@ import pytest
 
 import gpuutil
 
-pytestmark = pytest.mark.gpu
+
+
+def _has_experiments():
+    from custrings_amd import _lib
+
+    return bool(_lib.lib.cs_has_experiments())
+
+
+# (the one-pass kernels are in the experiments build only -- `make -C custrings_amd/csrc exp`, CS_LIB_PATH=.../libcustrings_amd_exp.so)
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not _has_experiments(), reason="the product library is built without the experiments (make exp)")]
 
 
 @contextlib.contextmanager
 def env(**kv):
-    old = {k: os.environ.get(k) for k in kv}
-    os.environ.update({k: str(v) for k, v in kv.items()})
+    # (the library reads its switches once: cs_config_set changes them at run time)
+    L = gpuutil.lib().lib
+    for k, v in kv.items():
+        L.cs_config_set(k.encode(), str(v).encode())
     try:
         yield
     finally:
-        for k, v in old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
+        for k in kv:
+            old = os.environ.get(k)
+            L.cs_config_set(k.encode(), None if old is None else old.encode())
 
 
 @pytest.mark.parametrize("kind,rows", [(2, 1_000_000), (3, 300_000), (2, 777), (2, 64), (2, 65), (2, 1), (2, 5000)])
