@@ -130,6 +130,7 @@ _PROTOS = {
     "cs_category_merge_gathered": (i32, [vp, P(vp), i32, i32, vp, P(vp), vp]),
     "cs_category_build_distributed": (i32, [vp, vp, i32, i32, vp, P(vp)]),
     "cs_category_build_distributed_with": (i32, [vp, vp, vp, i32, i32, vp, P(vp)]),
+    "cs_category_build_distributed_with2": (i32, [vp, vp, vp, vp, i32, i32, vp, P(vp)]),
     "cs_category_destroy": (i32, [vp]),
     "cs_category_size": (i64, [vp]),
     "cs_category_keys_size": (i64, [vp]),

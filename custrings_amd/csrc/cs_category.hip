@@ -120,11 +120,31 @@ __device__ __forceinline__ int compare_keys(const uint8_t* chars, Entry ea, Entr
 }
 
 constexpr int kProbeLimit = 128;  // longer probe runs mean the table is too small: the host retries with a bigger one
+// Slots with the key inside (`sw` == 4: 32-byte slots; tables of up to 2^24 slots).  A probe that meets another row's slot used
+// to make TWO dependent trips -- the slot, then the representative row's bytes somewhere in gigabytes of chars (a cache and TLB
+// miss each: 1.0 of the kernel's 2.6 ms at K = 1M) -- although most keys are short.  Now the row that claims a slot also
+// leaves the key's first 21 bytes in the slot's other three words, seven bytes a word under a tag byte, and a probe compares
+// in registers: one trip.  Each word is written once, by one 8-byte store, from "all ones" to its final value, so a reader
+// sees a word either absent or final -- never torn, whatever the order the stores become visible in; a key whose words are
+// not (yet) all there, or one beyond 21 bytes, is compared through its bytes in chars as before.
+constexpr int kSlotKeyBytes = 21;
+constexpr unsigned long long kSlotTag = 0x01ull << 56;
+__device__ __forceinline__ bool slot_word_there(unsigned long long w) { return (w >> 56) == 0x01ull; }
+// the key's bytes 7 j .. 7 j + 6 (zero beyond its end: row_block32 pads) under the tag
+__device__ __forceinline__ unsigned long long slot_word(const uint32_t w[8], int j) {
+  // bytes [7j, 7j+7) of the little-endian dword array
+  const int b0 = 7 * j, d = b0 >> 2, sh = (b0 & 3) * 8;
+  const unsigned long long lo = (unsigned long long)w[d] | ((unsigned long long)w[d + 1] << 32);
+  unsigned long long v = lo >> sh;
+  if (sh > 8) v |= (unsigned long long)w[d + 2] << (64 - sh);  // (the seven bytes reach into a third dword)
+  return (v & 0x00FFFFFFFFFFFFFFull) | kSlotTag;
+}
 // `dbg` (CS_CAT_DEBUG, measurement only -- wrong results): 1 skips the byte compare, 2 the table.
 __global__ void __launch_bounds__(256) k_cat_insert(ColView in, Entry* table, uint32_t mask,
                                                     int32_t* __restrict__ slot_of_row, int* __restrict__ has_null,
-                                                    int* __restrict__ overflow, int probe_limit, int dbg, int64_t stride = 1, int64_t count = -1) {
-  // (`stride` / `count`: the sampling launch takes rows 0, stride, 2 stride, ... -- `count` of them -- and writes no slot ids)
+                                                    int* __restrict__ overflow, int probe_limit, int dbg, int sw, int64_t stride = 1, int64_t count = -1) {
+  // (`stride` / `count`: the sampling launch takes rows 0, stride, 2 stride, ... -- `count` of them; the slot ids it writes
+  // for those rows are overwritten by the full pass that follows)
   const int64_t idx = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (idx >= (count >= 0 ? count : in.rows)) return;
   const int64_t r = idx * stride;
@@ -161,6 +181,13 @@ __global__ void __launch_bounds__(256) k_cat_insert(ColView in, Entry* table, ui
   }
   uint32_t slot = hash_final(h) & mask;
   const Entry mine = make_entry(b, n);
+  const bool in_slot = sw == 4 && n <= kSlotKeyBytes;
+  unsigned long long k0 = 0, k1 = 0, k2 = 0;
+  if (in_slot) {
+    k0 = slot_word(w, 0);
+    k1 = slot_word(w, 1);
+    k2 = slot_word(w, 2);
+  }
   int probes = 0;
   if (dbg & 2) {  // measurement only: no table
     slot_of_row[r] = (int32_t)slot;
@@ -171,12 +198,44 @@ __global__ void __launch_bounds__(256) k_cat_insert(ColView in, Entry* table, ui
     // value read here is final and the common case (key already present) needs no atomic at
     // all -- with a skewed key distribution the CASes of a hot key would otherwise queue on one
     // address (about 10 ns each: 100 ms for a key that 7 % of 125M rows share).
-    Entry cur = __hip_atomic_load(&table[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (cur == kEmpty) cur = atomicCAS(&table[slot], kEmpty, mine);
-    if (cur == kEmpty || cur == mine) break;  // this row represents the key
+    Entry* sp = table + (size_t)slot * (size_t)sw;
+    Entry cur;
+    unsigned long long s0 = 0, s1 = 0, s2 = 0;
+    if (sw == 4) {
+      // the slot's 32 bytes in two 16-byte loads that go to the L2 (sc1: what a relaxed agent-scope atomic load is on gfx950 --
+      // a slot cached as empty in a CU's L1 would send every later row of a hot key to the CAS); every 8-byte word of the
+      // slot is written once, whole: wider loads see each word absent or final
+      typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+      u32x4_t lo, hi;
+      asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %2, off offset:16 sc1\n\ts_waitcnt vmcnt(0)"
+                   : "=&v"(lo), "=&v"(hi)
+                   : "v"(sp)
+                   : "memory");
+      cur = (Entry)lo.x | ((Entry)lo.y << 32);
+      s0 = (Entry)lo.z | ((Entry)lo.w << 32);
+      s1 = (Entry)hi.x | ((Entry)hi.y << 32);
+      s2 = (Entry)hi.z | ((Entry)hi.w << 32);
+    } else {
+      cur = __hip_atomic_load(sp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (cur == kEmpty) {
+      cur = atomicCAS(sp, kEmpty, mine);
+      if (cur == kEmpty) {  // this row represents the key: leave it in the slot
+        if (in_slot) {
+          __hip_atomic_store(sp + 1, k0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(sp + 2, k1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(sp + 3, k2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        break;
+      }
+      s0 = s1 = s2 = 0;  // (somebody else's slot after all: its key words were read before it was claimed)
+    }
+    if (cur == mine) break;
     if (entry_len(cur) == n) {
       bool same = true;
-      if (n > 0 && !(dbg & 1)) {
+      if (in_slot && slot_word_there(s0) && slot_word_there(s1) && slot_word_there(s2) && !(dbg & 1)) {
+        same = s0 == k0 && s1 == k1 && s2 == k2;
+      } else if (n > 0 && !(dbg & 1)) {
         const uint8_t* q = in.chars + entry_off(cur);
         uint32_t y[8];
         row_block32(q, n, 0, y);
@@ -195,9 +254,13 @@ __global__ void __launch_bounds__(256) k_cat_insert(ColView in, Entry* table, ui
   }
   slot_of_row[r] = (int32_t)slot;
 }
-__global__ void k_cat_flags(const Entry* __restrict__ table, int64_t cap, int32_t* __restrict__ flags) {
+// (slots of `sw` words: the later passes read the slot words from `dense`, one per slot)
+__global__ void k_cat_flags(const Entry* __restrict__ table, int64_t cap, int sw, int32_t* __restrict__ flags, Entry* __restrict__ dense) {
   int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (i < cap) flags[i] = table[i] != kEmpty;
+  if (i >= cap) return;
+  const Entry e = table[(size_t)i * (size_t)sw];
+  flags[i] = e != kEmpty;
+  if (dense) dense[i] = e;
 }
 // sort records: prefix[i] = first 8 key bytes big-endian, item[i] = slot id;
 // padding up to the power of two sorts last
@@ -391,12 +454,26 @@ __global__ void k_cat_ranks(const int32_t* __restrict__ item, int64_t uniq, int 
   int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i < uniq) rank_of_slot[item[i]] = (int32_t)i + shift;
 }
+// (four rows a thread: one 16-byte load, four look-ups in flight, one 16-byte store -- a row a thread left the memory pipe
+// with 4-byte requests and one look-up a lane outstanding: 0.75 ms for 125M rows)
 __global__ void k_cat_values(const int32_t* __restrict__ slot_of_row, const int32_t* __restrict__ rank_of_slot,
                              int64_t rows, int32_t* __restrict__ values) {
-  int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int64_t r = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * 4;
   if (r >= rows) return;
-  int32_t s = slot_of_row[r];
-  values[r] = s < 0 ? 0 : rank_of_slot[s];  // a null row maps to key 0 (the null key)
+  if (r + 4 <= rows) {
+    const int4 s = *reinterpret_cast<const int4*>(slot_of_row + r);
+    int4 v;
+    v.x = s.x < 0 ? 0 : rank_of_slot[s.x];  // a null row maps to key 0 (the null key)
+    v.y = s.y < 0 ? 0 : rank_of_slot[s.y];
+    v.z = s.z < 0 ? 0 : rank_of_slot[s.z];
+    v.w = s.w < 0 ? 0 : rank_of_slot[s.w];
+    *reinterpret_cast<int4*>(values + r) = v;
+    return;
+  }
+  for (int64_t i = r; i < rows; ++i) {
+    const int32_t s = slot_of_row[i];
+    values[i] = s < 0 ? 0 : rank_of_slot[s];
+  }
 }
 __global__ void k_key_sizes(ColView in, const Entry* __restrict__ table, const int32_t* __restrict__ item,
                             int64_t nkeys, int shift, int32_t* __restrict__ lens) {
@@ -469,9 +546,11 @@ cs_category* cs::category_build(const cs_column* col, hipStream_t s) {
   int64_t cap = std::min<int64_t>(full, cs::cfg("CS_CAT_FULL_TABLE") && !full_out_of_range ? full : (int64_t)1 << first_log2);
   constexpr int64_t kSampleRows = 1 << 21;  // (that many rows fit the small table whatever they hold)
   bool sampled = cs::cfg("CS_CAT_NO_SAMPLE") != nullptr;
+  int sw = 1;  // words per slot: 4 = the key's first bytes inside the slot (k_cat_insert)
   for (;;) {
-    table = dev_alloc(sizeof(Entry) * cap, s);
-    CS_HIP(hipMemsetAsync(table->p, 0xFF, sizeof(Entry) * cap, s));
+    sw = cap <= ((int64_t)1 << 24) && !cs::cfg("CS_CAT_PLAIN_SLOTS") ? 4 : 1;
+    table = dev_alloc(sizeof(Entry) * cap * sw, s);
+    CS_HIP(hipMemsetAsync(table->p, 0xFF, sizeof(Entry) * cap * sw, s));
     CS_HIP(hipMemsetAsync(flags_d->p, 0, 2 * sizeof(int), s));
     {
       ProfScope ps("k_cat_insert", s);
@@ -479,7 +558,7 @@ cs_category* cs::category_build(const cs_column* col, hipStream_t s) {
       const int dbg = cs::cfg("CS_CAT_DEBUG") ? atoi(cs::cfg("CS_CAT_DEBUG")) : 0;
       hipLaunchKernelGGL(k_cat_insert, dim3(blocks_for(rows)), dim3(kBlock), 0, s, in, ptr<Entry>(table),
                          (uint32_t)(cap - 1), ptr<int32_t>(slot_of_row), ptr<int>(flags_d), ptr<int>(flags_d) + 1, limit,
-                         dbg);
+                         dbg, sw);
     }
     int* h = (int*)pinned_scratch(2 * sizeof(int));
     CS_HIP(hipMemcpyAsync(h, flags_d->p, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
@@ -495,15 +574,18 @@ cs_category* cs::category_build(const cs_column* col, hipStream_t s) {
       // all rows (K = 0.5 N: the 64M-slot attempt ran to 90 % before it gave up), and a table that still turns out too
       // small grows as before.
       sampled = true;
-      CS_HIP(hipMemsetAsync(table->p, 0xFF, sizeof(Entry) * cap, s));
+      CS_HIP(hipMemsetAsync(table->p, 0xFF, sizeof(Entry) * cap * sw, s));
       CS_HIP(hipMemsetAsync(flags_d->p, 0, 2 * sizeof(int), s));
-      hipLaunchKernelGGL(k_cat_insert, dim3(blocks_for(kSampleRows)), dim3(kBlock), 0, s, in, ptr<Entry>(table), (uint32_t)(cap - 1),
-                         ptr<int32_t>(slot_of_row), ptr<int>(flags_d), ptr<int>(flags_d) + 1, 0x7fffffff, 0, rows / kSampleRows, kSampleRows);
+      // (a stride rounded UP, so that the sample spans the whole column -- rounded down it stopped short of the column's end,
+      // by almost half of it when the column has just under 2 x kSampleRows rows)
+      const int64_t sample_stride = (rows + kSampleRows - 1) / kSampleRows, sample_rows = (rows + sample_stride - 1) / sample_stride;
+      hipLaunchKernelGGL(k_cat_insert, dim3(blocks_for(sample_rows)), dim3(kBlock), 0, s, in, ptr<Entry>(table), (uint32_t)(cap - 1),
+                         ptr<int32_t>(slot_of_row), ptr<int>(flags_d), ptr<int>(flags_d) + 1, 0x7fffffff, 0, sw, sample_stride, sample_rows);
       Buf occ = dev_alloc(sizeof(int32_t) * cap, s);
-      hipLaunchKernelGGL(k_cat_flags, dim3(blocks_for(cap)), dim3(kBlock), 0, s, ptr<const Entry>(table), cap, ptr<int32_t>(occ));
+      hipLaunchKernelGGL(k_cat_flags, dim3(blocks_for(cap)), dim3(kBlock), 0, s, ptr<const Entry>(table), cap, sw, ptr<int32_t>(occ), (Entry*)nullptr);
       Buf occ_pos = dev_alloc(sizeof(int64_t) * (cap + 1), s);
       const int64_t distinct = offsets_from_lengths(ptr<int32_t>(occ), cap, ptr<int64_t>(occ_pos), s);
-      const double share = (double)distinct / (double)kSampleRows;
+      const double share = (double)distinct / (double)sample_rows;
       int64_t want = 256;
       while (want < (int64_t)(2.5 * share * (double)rows)) want <<= 1;
       next_cap = std::min<int64_t>(full, std::max<int64_t>(next_cap, want));
@@ -516,8 +598,13 @@ cs_category* cs::category_build(const cs_column* col, hipStream_t s) {
   Buf has_null_d = flags_d;
   // compact the occupied slots
   Buf flags = dev_alloc(sizeof(int32_t) * cap, s);
-  hipLaunchKernelGGL(k_cat_flags, dim3(blocks_for(cap)), dim3(kBlock), 0, s, ptr<const Entry>(table), cap,
-                     ptr<int32_t>(flags));
+  {
+    // (32-byte slots: the slot words move to a dense array in the same pass -- every later kernel reads that)
+    Buf dense = sw == 1 ? table : dev_alloc(sizeof(Entry) * cap, s);
+    hipLaunchKernelGGL(k_cat_flags, dim3(blocks_for(cap)), dim3(kBlock), 0, s, ptr<const Entry>(table), cap, sw, ptr<int32_t>(flags),
+                       sw == 1 ? (Entry*)nullptr : ptr<Entry>(dense));
+    table = dense;
+  }
   Buf pos = dev_alloc(sizeof(int64_t) * (cap + 1), s);
   const int64_t uniq = offsets_from_lengths(ptr<int32_t>(flags), cap, ptr<int64_t>(pos), s);
   const int shift = read_back<int>(has_null_d->p, s) ? 1 : 0;
@@ -619,7 +706,7 @@ cs_category* cs::category_build(const cs_column* col, hipStream_t s) {
   cat->values = dev_alloc(sizeof(int32_t) * rows, s);
   {
     ProfScope ps("k_cat_values", s);
-    hipLaunchKernelGGL(k_cat_values, dim3(blocks_for(rows)), dim3(kBlock), 0, s, ptr<const int32_t>(slot_of_row),
+    hipLaunchKernelGGL(k_cat_values, dim3(blocks_for((rows + 3) / 4)), dim3(kBlock), 0, s, ptr<const int32_t>(slot_of_row),
                        ptr<const int32_t>(rank_of_slot), rows, ptr<int32_t>(cat->values));
   }
   // keys column

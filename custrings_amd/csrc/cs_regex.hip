@@ -1132,6 +1132,36 @@ __device__ __forceinline__ bool reclassify_high(const cstd::View& D, bool has_r2
 }
 
 
+// The backrefs template in registers (the replace kernel's BREFS form).  The struct lives in device memory; read per match
+// and per reference in the kernel's inner loops -- `T.nrefs`, `T.idx[j]`, `T.pos[j]` -- every read was a scalar load and a
+// wait that also drains the LDS counter.  Up to sixteen references, group numbers up to 15 and positions up to 255 pack into
+// three 64-bit words that stay in scalar registers; the host offers the single pass only to templates that fit.
+struct TemplateRegs {
+  int bytes, nrefs, groups;
+  unsigned long long idx4, pos8lo, pos8hi;
+  __device__ __forceinline__ int idx(int j) const { return (int)((idx4 >> (4 * j)) & 15ull); }
+  __device__ __forceinline__ int pos(int j) const { return (int)(((j < 8 ? pos8lo >> (8 * j) : pos8hi >> (8 * (j - 8)))) & 255ull); }
+};
+__device__ __forceinline__ TemplateRegs template_regs(const csvm::BackrefTemplate* t) {
+  TemplateRegs r;
+  r.bytes = __builtin_amdgcn_readfirstlane(t->bytes);
+  r.nrefs = __builtin_amdgcn_readfirstlane(t->nrefs);
+  r.groups = __builtin_amdgcn_readfirstlane(t->groups);
+  unsigned long long i4 = 0, lo = 0, hi = 0;
+  for (int j = 0; j < csvm::BackrefTemplate::kMaxRefs; ++j) {
+    const unsigned long long g = (unsigned long long)(t->idx[j] & 15), p = (unsigned long long)(t->pos[j] & 255);
+    if (j < r.nrefs) {
+      i4 |= g << (4 * j);
+      if (j < 8) lo |= p << (8 * j);
+      else hi |= p << (8 * (j - 8));
+    }
+  }
+  r.idx4 = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(i4 >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)i4);
+  r.pos8lo = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(lo >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)lo);
+  r.pos8hi = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(hi >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)hi);
+  return r;
+}
+
 // ---- the bit-parallel form (regex_bits.h): staging helpers shared by the stream kernels ------------------
 // LDS image of the form: the program words as built by the host, then 128 words of the SPREAD class table --
 // entry b holds byte b's class set with class k at bit 4k, so that the entries of four bytes, shifted by 0..3
@@ -1236,6 +1266,8 @@ __global__ void __launch_bounds__(256, (BREFS || BITS) ? 2 : CS_STREAM_WAVES) k_
     gt = g;
     ttext = tt;
   }
+  TemplateRegs T{};
+  if (BREFS) T = template_regs(a.tmpl);
   const uint32_t* spread = nullptr;
   csbits::View BV{};
   if (BITS) {
@@ -1620,7 +1652,6 @@ __global__ void __launch_bounds__(256, (BREFS || BITS) ? 2 : CS_STREAM_WAVES) k_
           // items, so its range follows from the item boundaries of the match -- a walk over the row's two masks per
           // match where the automaton needed an anchored group run (half the kernel's time).
           using namespace cstd;
-          const csvm::BackrefTemplate& T = *a.tmpl;
           const uint32_t gmap = (uint32_t)D.img[D.img[15] - 1];
           uint32_t r0, r1, r2, x0 = 0, x1 = 0, x2 = 0;
           cstile::row_bits96(bitmap, lead + rbeg, n, r0, r1, r2);
@@ -1646,11 +1677,11 @@ __global__ void __launch_bounds__(256, (BREFS || BITS) ? 2 : CS_STREAM_WAVES) k_
               const int mb = u128_ctz(S), me = u128_ctz(E) + 1;
               S = u128_clear_lowest(S);
               E = u128_clear_lowest(E);
-              int gb[4], ge[4];
-              chain_group_bounds(R, X, D.chain, gmap, mb, gb, ge);
+              int gb[4] = {-1, -1, -1, -1}, ge[4] = {-1, -1, -1, -1};
+              if (T.nrefs > 0) chain_group_bounds(R, X, D.chain, gmap, mb, gb, ge);  // (a template without references needs no groups)
               int grow = T.bytes - (me - mb);
               for (int j = 0; j < T.nrefs; ++j) {
-                const int g = T.idx[j];
+                const int g = T.idx(j);
                 int x = -1, y = -1;
                 if (g == 0) {
                   x = mb;
@@ -1738,7 +1769,6 @@ __global__ void __launch_bounds__(256, (BREFS || BITS) ? 2 : CS_STREAM_WAVES) k_
               {
                 // the matches of the sub-tile go through the queue once more, one per lane whatever its row (as the units
                 // did): ONE anchored group run per match sizes its expansion and leaves its group ranges in LDS
-                const csvm::BackrefTemplate& T = *a.tmpl;
                 const int cnt = from_masks ? nm : 0;
                 const int mincl = csdev::wave_inclusive_scan(cnt);
                 const int total_m = __builtin_amdgcn_readlane(mincl, 63);
@@ -1778,7 +1808,7 @@ __global__ void __launch_bounds__(256, (BREFS || BITS) ? 2 : CS_STREAM_WAVES) k_
                       const bool ok = got > 0;
                       int grow = T.bytes - (me - mb);
                       for (int j = 0; j < T.nrefs; ++j) {
-                        const int g = T.idx[j];
+                        const int g = T.idx(j);
                         int x = -1, y = -1;
                         if (g == 0) {
                           x = mb;
@@ -1954,7 +1984,6 @@ __global__ void __launch_bounds__(256, (BREFS || BITS) ? 2 : CS_STREAM_WAVES) k_
         const int pi = lead + rbeg;  // byte index of the row in lds_in
         int copied = 0;
         if (BREFS && from_masks) {
-          const csvm::BackrefTemplate& T = *a.tmpl;
           int mi = 0;
           while (cstd::u128_any(uS)) {
             const int mb = cstd::u128_ctz(uS), me = cstd::u128_ctz(uE) + 1;
@@ -1975,10 +2004,10 @@ __global__ void __launch_bounds__(256, (BREFS || BITS) ? 2 : CS_STREAM_WAVES) k_
             }
             int il = 0;
             for (int j = 0; j < T.nrefs; ++j) {
-              cstile::lds_copy_ov(lds_out, oi, ttext, il, T.pos[j] - il);
-              oi += T.pos[j] - il;
-              il = T.pos[j];
-              const int g = T.idx[j];
+              cstile::lds_copy_ov(lds_out, oi, ttext, il, T.pos(j) - il);
+              oi += T.pos(j) - il;
+              il = T.pos(j);
+              const int g = T.idx(j);
               int x = -1, y = -1;
               if (g == 0) {
                 x = mb;
@@ -3812,7 +3841,9 @@ int cs_replace_with_backrefs(const cs_column* col, const cs_regex* cre, const ch
     // First choice: the single-pass replace kernel in its backrefs form (unit scan, one group run per match, coalesced
     // output).  It declines patterns without the unit decomposition, more than four groups, long rows; a launch that
     // runs out of output room or meets a row the unit route hands over reports it, and the two-pass form below runs.
-    if (dfa && re->prog.num_groups >= 1 && !cs::cfg("CS_BACKREFS_TWO_PASS")) {
+    bool packs = t.bytes <= 255;  // (the kernel keeps the references' group numbers and positions packed in registers)
+    for (int j = 0; j < t.nrefs; ++j) packs = packs && t.idx[j] <= 15 && t.pos[j] <= 255;
+    if (dfa && packs && re->prog.num_groups >= 1 && !cs::cfg("CS_BACKREFS_TWO_PASS")) {
       Buf d_t = dev_alloc(sizeof(csvm::BackrefTemplate), s);
       CS_HIP(hipMemcpyAsync(d_t->p, &t, sizeof(t), hipMemcpyHostToDevice, s));
       CS_HIP(hipStreamSynchronize(s));  // (`t` lives on this stack frame)

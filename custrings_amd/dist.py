@@ -382,10 +382,55 @@ def global_category_c_abi(local_col, group=None):
         except Exception:  # (no exception may cross the C frames)
             return 1
 
+    @C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t),
+                 C.c_int, C.c_void_p)
+    def alltoallv(_ctx, send, send_bytes, send_off, recv, recv_bytes, recv_off, n, stream):
+        # (what grouped ncclSend / ncclRecv are to cs_category_build_distributed: the key-range partitioned merge's transport)
+        try:
+            if hip.hipStreamSynchronize(stream) != 0:
+                return 1
+            dev = torch.device("cpu") if staged else torch.device("cuda", torch.cuda.current_device())
+            outs, ins = [], []
+            for d in range(n):
+                t = torch.empty(send_bytes[d], dtype=torch.uint8, device=dev)
+                if send_bytes[d] and hip.hipMemcpy(t.data_ptr(), (send or 0) + send_off[d], send_bytes[d], 2 if staged else 3) != 0:
+                    return 1
+                outs.append(t)
+                ins.append(torch.empty(recv_bytes[d], dtype=torch.uint8, device=dev))
+            if world > 1:
+                dist.all_to_all(ins, outs, group=group) if not staged else _all_to_all_by_gather(ins, outs, group)
+            else:
+                ins[0].copy_(outs[0])
+            if not staged:
+                torch.cuda.synchronize()
+            for d in range(n):
+                if recv_bytes[d] and hip.hipMemcpy((recv or 0) + recv_off[d], ins[d].data_ptr(), recv_bytes[d], 1 if staged else 3) != 0:
+                    return 1
+            return 0
+        except Exception:  # (no exception may cross the C frames)
+            return 1
+
     out = C.c_void_p()
     ctx = C.c_void_p(1)  # (non-null: run the exchange with one rank too)
-    _lib.check(_lib.lib.cs_category_build_distributed_with(local_col.m_cptr, C.cast(allgather, C.c_void_p), ctx, world, rank, None, C.byref(out)))
+    _lib.check(_lib.lib.cs_category_build_distributed_with2(local_col.m_cptr, C.cast(allgather, C.c_void_p), C.cast(alltoallv, C.c_void_p), ctx, world, rank,
+                                                            None, C.byref(out)))
     return nvcategory.nvcategory(out.value)
+
+
+def _all_to_all_by_gather(ins, outs, group):
+    """all_to_all for the gloo backend (which has none for tensors of unequal sizes on every build): every rank gathers
+    every rank's pieces for it -- test transport only."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    for src in range(world):
+        # rank `src` scatters its pieces: piece d goes to rank d
+        sizes = torch.tensor([int(t.numel()) for t in outs], dtype=torch.int64) if rank == src else torch.zeros(world, dtype=torch.int64)
+        dist.broadcast(sizes, src=src, group=group)
+        total = int(sizes.sum())
+        flat = torch.cat(outs) if rank == src else torch.empty(total, dtype=torch.uint8)
+        if total:
+            dist.broadcast(flat, src=src, group=group)
+        lo = int(sizes[:rank].sum())
+        ins[src].copy_(flat[lo : lo + int(sizes[rank])])
 
 
 def agree_on_columns(ncols, device="cuda", group=None):

@@ -395,6 +395,18 @@ int cs_category_build_distributed(const cs_column* col, void* nccl_comm, int nra
 typedef int (*cs_allgather_fn)(void* ctx, const void* send, void* recv, size_t bytes, void* stream);
 int cs_category_build_distributed_with(const cs_column* col, cs_allgather_fn allgather, void* ctx, int nranks, int rank, cs_stream stream,
                                        cs_category** out);
+/* ... and a caller-supplied all-to-all of variable pieces, which opens the second route: from 2^21 keys in all (K close to
+ * N) the merge is partitioned by key RANGE -- splitters from a sample of every rank's keys, every key to its range's
+ * owner, the merged ranges all-gathered: every rank merges 1/nranks of the keys instead of all of them.
+ * `alltoallv(ctx, send, send_bytes, send_off, recv, recv_bytes, recv_off, nranks, stream)`: this rank's piece for rank d
+ * is send_bytes[d] bytes at send + send_off[d] (device memory); what rank d sent to this rank arrives at recv + recv_off[d]
+ * (recv_bytes[d] bytes: the library exchanged the sizes beforehand); ordered after the work queued on `stream`; 0 on
+ * success.  cs_category_build_distributed passes grouped ncclSend / ncclRecv.  NULL: the all-gather route only.
+ * A rank whose local build fails still takes part in the first exchange and every rank returns an error together. */
+typedef int (*cs_alltoallv_fn)(void* ctx, const void* send, const size_t* send_bytes, const size_t* send_off, void* recv, const size_t* recv_bytes,
+                               const size_t* recv_off, int nranks, void* stream);
+int cs_category_build_distributed_with2(const cs_column* col, cs_allgather_fn allgather, cs_alltoallv_fn alltoallv, void* ctx, int nranks, int rank,
+                                        cs_stream stream, cs_category** out);
 int cs_category_destroy(cs_category* cat);
 /* NVCategory::create_ipc_transfer / create_from_ipc (NVCategory.h:128,176; ipc_transfer.h:109-200): the key column
  * as above plus the handle of the int32 values. */

@@ -45,6 +45,14 @@ def _worker(rank, world, port, rows, q):
         # the C ABI's own distributed entry point (the exchange inside the library, torch.distributed as its transport)
         ccat = csd.global_category_c_abi(synth(4, lo, hi - lo, 3000))
         cabi = (ccat.keys().to_host(), ccat.values())
+        # ... and its key-range partitioned merge (forced: the test's key sets are far below 2^21 keys), on the mostly
+        # distinct keys and on a skewed split of the small key set (rank 0 gets a tenth of the rows)
+        _lib.check(_lib.lib.cs_config_set(b"CS_DIST_PARTITIONED", b"1"))
+        pcat = csd.global_category_c_abi(dense)
+        slo, shi = (0, rows // 10) if rank == 0 else (rows // 10 + (rank - 1) * ((rows - rows // 10) // (world - 1)), rows // 10 + rank * ((rows - rows // 10) // (world - 1)) if rank < world - 1 else rows)
+        scat = csd.global_category_c_abi(synth(4, slo, shi - slo, 3000))
+        _lib.check(_lib.lib.cs_config_set(b"CS_DIST_PARTITIONED", None))
+        cabi = cabi + (pcat.keys().to_host(), pcat.values(), scat.keys().to_host(), scat.values())
         q.put((rank, "ok", keys.to_host(), values.cpu().tolist(), grams.to_host(), ncols, part, cabi))
         dist.barrier()
         dist.destroy_process_group()
@@ -54,14 +62,15 @@ def _worker(rank, world, port, rows, q):
         q.put((rank, "error", traceback.format_exc() + repr(e)))
 
 
-def test_gpu_two_rank_exchanges_with_the_gpu_ops(gpu_engine):
+@pytest.mark.parametrize("world", [2, 3])
+def test_gpu_two_rank_exchanges_with_the_gpu_ops(gpu_engine, world):
     import ctypes as C
 
     import torch.multiprocessing as mp
 
     from custrings_amd import _lib, nvcategory, nvstrings, nvtext
 
-    rows, world = 40_000, 2
+    rows = 40_000
     port = 33500 + (os.getpid() % 2000)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -82,20 +91,82 @@ def test_gpu_two_rank_exchanges_with_the_gpu_ops(gpu_engine):
     want_keys, want_values = cat.keys().to_host(), cat.values()
     want_grams = nvtext.ngrams(nvtext.tokenize(synth(5)), 2, "_").to_host()
     want_cols = len(synth(3).split(" "))
-    assert got[0][2] == got[1][2] == want_keys                  # the same, global key set on both ranks
-    assert got[0][3] + got[1][3] == list(want_values)           # each rank the codes of its own rows
-    assert got[0][4] + got[1][4] == want_grams                  # the n-grams across the shard boundary included
-    assert got[0][5] == got[1][5] == want_cols
+    assert all(g[2] == want_keys for g in got)                              # the same, global key set on every rank
+    assert sum((g[3] for g in got), []) == list(want_values)                # each rank the codes of its own rows
+    assert sum((g[4] for g in got), []) == want_grams                       # the n-grams across the shard boundaries included
+    assert all(g[5] == want_cols for g in got)
     dcat = nvcategory.from_strings(synth(4, 1 << 30))
     dkeys, dvalues = dcat.keys().to_host(), list(dcat.values())
-    assert got[0][6][0] == got[1][6][0] == dkeys
-    assert got[0][6][1] + got[1][6][1] == dvalues
-    r0, r1 = got[0][6][2], got[1][6][2]
-    assert r0["partitioned"] and r0["global_keys"] == len(dkeys) and r0["range_keys"] + r1["range_keys"] == len(dkeys)
-    assert 0.2 * len(dkeys) < r0["range_keys"] < 0.8 * len(dkeys)  # (each rank merged about its half)
-    # cs_category_build_distributed_with: the same global key set and codes out of the library's own exchange
-    assert got[0][7][0] == got[1][7][0] == want_keys
-    assert list(got[0][7][1]) + list(got[1][7][1]) == list(want_values)
+    assert all(g[6][0] == dkeys for g in got)
+    assert sum((g[6][1] for g in got), []) == dvalues
+    infos = [g[6][2] for g in got]
+    assert infos[0]["partitioned"] and infos[0]["global_keys"] == len(dkeys) and sum(i["range_keys"] for i in infos) == len(dkeys)
+    assert all(0.4 / world * len(dkeys) < i["range_keys"] < 1.6 / world * len(dkeys) for i in infos)  # (each rank merged about its share)
+    # cs_category_build_distributed_with2: the same global key set and codes out of the library's own exchange
+    assert all(g[7][0] == want_keys for g in got)
+    assert sum((list(g[7][1]) for g in got), []) == list(want_values)
+    # ... by key ranges (mostly distinct keys), and with a skewed split of the rows
+    assert all(g[7][2] == dkeys for g in got)
+    assert sum((list(g[7][3]) for g in got), []) == dvalues
+    assert all(g[7][4] == want_keys for g in got)
+    assert sum((list(g[7][5]) for g in got), []) == list(want_values)
+
+
+def _failing_worker(rank, world, port, rows, q):
+    sys.path.insert(0, os.path.dirname(HERE))
+    sys.path.insert(0, HERE)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    try:
+        import ctypes as C
+
+        import torch
+        import torch.distributed as dist
+
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from custrings_amd import _lib, nvstrings
+        from custrings_amd import dist as csd
+
+        _lib.ensure_init(0)
+        lo, hi = csd.shard_range(rows, rank, world)
+        out = C.c_void_p()
+        _lib.check(_lib.lib.cs_synth_column(4, lo, hi - lo, 20240607, 3000, None, C.byref(out)))
+        col = nvstrings.nvstrings(out.value)
+        _lib.check(_lib.lib.cs_config_set(b"CS_DIST_TEST_FAIL", b"1"))  # rank 1's local build "fails"
+        try:
+            csd.global_category_c_abi(col)
+            res = "no error"
+        except RuntimeError as e:
+            res = str(e)
+        _lib.check(_lib.lib.cs_config_set(b"CS_DIST_TEST_FAIL", None))
+        ok = csd.global_category_c_abi(col).keys_size()  # the ranks are still in step: the next build works
+        q.put((rank, "ok", res, ok))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as e:
+        import traceback
+
+        q.put((rank, "error", traceback.format_exc() + repr(e)))
+
+
+def test_gpu_distributed_build_fails_on_every_rank_together():
+    """a rank whose local build throws must not leave the others waiting in a collective.  It takes part in the
+    first exchange with a status word; every rank returns an error (naming the rank), none hangs, and the next build works."""
+    import torch.multiprocessing as mp
+
+    rows, world = 20_000, 2
+    port = 35500 + (os.getpid() % 2000)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_failing_worker, args=(r, world, port, rows, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+    assert all(g[1] == "ok" for g in got), [g[2] for g in got if g[1] != "ok"]
+    assert all("rank 1 failed before the exchange" in g[2] for g in got), [g[2] for g in got]
+    assert got[0][3] == got[1][3] > 0
 
 
 def test_gpu_category_build_distributed_over_rccl():

@@ -336,3 +336,34 @@ def test_gpu_full_size_headline_vs_oracle_10m_rows():
             checked += win
     assert checked == nwin * win
     print("oracle cross-check: %d rows of the 100M-row column in %d windows on %d cores" % (checked, nwin, cores))
+
+
+# ---- category: the key inside the slot (cs_category.hip: 32-byte slots) ------------------------------
+@pytest.mark.parametrize("plain_slots", [False, True])
+def test_gpu_category_keys_inside_the_slots(plain_slots, monkeypatch):
+    """Keys of 0..40 bytes around the 21 bytes a slot holds -- equal up to byte 21 and different behind it, prefixes of each
+    other, empty, null, multi-byte characters, a NUL byte inside -- against the oracle's sorted unique keys and codes; the
+    same with the slots without key words (CS_CAT_PLAIN_SLOTS: the comparison through the chars, as large tables do)."""
+    import random
+
+    from custrings_amd import nvcategory
+
+    if plain_slots:
+        monkeypatch.setenv("CS_CAT_PLAIN_SLOTS", "1")
+    rnd = random.Random(17)
+    stems = ["", "a", "ab", "x" * 20, "x" * 21, "x" * 22, "y" * 21 + "1", "y" * 21 + "2", "y" * 21, "é" * 10, "é" * 11, "k\x00ey", "k\x00ez",
+             "0123456789abcdefghij", "0123456789abcdefghijk", "0123456789abcdefghijkl", "0123456789abcdefghijkm", "z" * 40, "z" * 39 + "y"]
+    pool = stems + [rnd.choice(stems)[: rnd.randint(0, 25)] + rnd.choice(["", "q", "qq", "7"]) for _ in range(400)]
+    rows = [rnd.choice(pool) if rnd.random() > 0.01 else None for _ in range(200_000)]
+    o = cpulibs.Col.from_list(rows)
+    orc = cpulibs.Oracle()
+    ok, ov = orc.category(o)
+    cat = nvcategory.from_strings(gpuutil.from_col(o))
+    gpuutil.assert_same(cat.keys(), ok, "keys")
+    assert cat.values() == ov.tolist()
+    # C4 rows (16 bytes exactly: the whole key in the slot) with a few thousand keys
+    g, o4 = gpuutil.synth(4, 0, 300_000, param=5000), orc.synth(4, 0, 300_000, param=5000)
+    ok, ov = orc.category(o4)
+    cat = nvcategory.from_strings(g)
+    gpuutil.assert_same(cat.keys(), ok, "C4 keys")
+    assert cat.values() == ov.tolist()
