@@ -634,7 +634,9 @@ int cs_find_from(const cs_column* col, const char* str, const int32_t* starts, c
 int cs_compare(const cs_column* col, const char* str, int32_t* results, int on_device, cs_stream stream, int64_t* matches) {
   return guard([&] {
     if (matches) *matches = 0;
-    if (!col || !str || !results || col->rows == 0 || !*str) return;
+    // (an empty `str`: the reference returns without writing -- find.cu -- and its callers read an uninitialised buffer; here
+    // the comparison with the empty string is computed like any other: 1 for a non-empty row, 0 for an empty one)
+    if (!col || !str || !results || col->rows == 0) return;
     require_device();
     find_family(col, 2, str, 0, 0, nullptr, nullptr, 1, results, on_device, S(stream), matches);
   });

@@ -44,6 +44,7 @@ struct cs_regex {
 };
 
 namespace cs {
+bool replace_class_runs(const cs_column* col, const int32_t* d_bits, const std::vector<int32_t>& bits, const char* repl, int rb, hipStream_t s, cs_column** out);
 thread_local int g_replace_plain_only = 0;  // set by cs_replace around its call of cs_replace_re: single-pass kernel or nothing
 // cs_replace also leaves the needle itself here when it has at most eight bytes and no border (no proper prefix that is
 // also a suffix: occurrences cannot overlap): the stream kernel then finds the matches by byte comparison, all bytes of
@@ -2662,6 +2663,17 @@ bool use_tdfa_wide(const cs_regex* re) { return !re->tdfa.empty() && re->tdfa[12
 //   replace_re:  (two workgroups a CU against three) 7.3 / 21.4 at 7.2 %, 8.6 / 51.7 at 11.9 %, 6.4 / 9.3 at 2.4 % with three threads;
 //   5.4-5.8 / 4.6-4.9 at 2.4 % with one thread
 enum { BITS_CONTAINS = 0, BITS_COUNT = 2, BITS_REPLACE = 3 };
+// the share of the column's sampled bytes at which the automaton's idle skip has to stop
+double candidate_share(const cs_regex* re, const cs_column* col, hipStream_t s) {
+  if (re->tdfa.empty()) return 1.0;
+  const uint32_t* hist = sample_byte_hist(col, s);
+  uint64_t all = 0, cand = 0;
+  for (unsigned c = 0; c < 256; ++c) {
+    all += hist[c];
+    if (c < 128 && (((uint32_t)re->tdfa[21 + (c >> 5)] >> (c & 31)) & 1u)) cand += hist[c];
+  }
+  return all ? (double)cand / (double)all : 0.0;
+}
 bool bits_route(const cs_regex* re, const cs_column* col, hipStream_t s, int op) {
   if (re->bits.empty() || cs::cfg("CS_NO_BITS_FORM")) return false;
   if (!re->tdfa.empty() && ((re->tdfa[30] >> 16) & 15) != 0) return false;  // a chain
@@ -3032,6 +3044,21 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
     TPlan tp{};
     if (tdfa || wide) tp = tplan(re, col->rows, s);
     else pl = plan(re, col->rows, s);
+    // One character class, once or in a `+` loop, on a column the 96-bit-mask forms do not take -- rows beyond 93 bytes,
+    // tiles of fewer than 64 rows, non-ASCII text -- and whose candidates are everywhere: byte-parallel stream compaction
+    // (cs_runs.hip; BASELINE.json C5: replace_re([aeiou]+) on 40-150-byte rows, 82.8 ms on the long-row automaton forms).
+    if (!cs::g_backrefs_dev && !cs::g_replace_plain_only && maxrepl < 0 && col->rows > 0 && !re->bits.empty() && (re->bits[2] & csbits::F_BYTE_CLASS) &&
+        re->d_bits) {
+      const TileChoice tc0 = choose_tile(col, s, true);
+      const bool masks_form = tc0.R == 64 && !tc0.lng && !sample_has_high_bytes(col, s);
+      const bool wanted = cs::cfg("CS_CLASS_RUNS_ALWAYS") || (!masks_form && candidate_share(re, col, s) >= 0.05);
+      cs_column* r = nullptr;
+      if (wanted && replace_class_runs(col, ptr<const int32_t>(re->d_bits), re->bits, repl, rb, s, &r)) {
+        note_route("runs");
+        *out = r;
+        return;
+      }
+    }
     RowSrc src{view_of(col), d_unicode_flags(), col->nbytes + (col->chars && col->chars->capacity ? 64 : 0)};
     auto* o = new cs_column;
     std::unique_ptr<cs_column> holder(o);

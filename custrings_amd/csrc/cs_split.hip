@@ -790,27 +790,33 @@ __global__ void __launch_bounds__(kEmit3Threads, CS_EMIT3_WAVES) k_split_emit3(E
 __device__ __forceinline__ int scan_pair(int v, int k, uint32_t off_lo, uint32_t off_hi, uint32_t pos, uint32_t& a_lo, uint32_t& a_hi, uint32_t& a_pos,
                                          uint32_t& b_lo, uint32_t& b_hi, uint32_t& b_pos) {
   const int k1 = k + 1;
+  // (the lane selects go through m0, written by s_mov: a v_readlane whose lane-select SGPR was written by a VALU instruction
+  // -- should a compiler ever materialise k through v_readfirstlane -- needs four wait states that the hazard recogniser,
+  // which does not look into inline assembly, would not insert; m0 <- SALU has no such hazard.  The second s_mov takes the
+  // slot of an s_nop.)
   asm volatile(
-      "v_readlane_b32 %1, %7, %10\n\t"
-      "v_readlane_b32 %2, %8, %10\n\t"
+      "s_mov_b32 m0, %10\n\t"
+      "v_readlane_b32 %1, %7, m0\n\t"
+      "v_readlane_b32 %2, %8, m0\n\t"
       "v_add_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-      "v_readlane_b32 %3, %9, %10\n\t"
-      "s_nop 0\n\t"
+      "v_readlane_b32 %3, %9, m0\n\t"
+      "s_mov_b32 m0, %11\n\t"
       "v_add_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-      "v_readlane_b32 %4, %7, %11\n\t"
+      "v_readlane_b32 %4, %7, m0\n\t"
       "s_nop 0\n\t"
       "v_add_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-      "v_readlane_b32 %5, %8, %11\n\t"
+      "v_readlane_b32 %5, %8, m0\n\t"
       "s_nop 0\n\t"
       "v_add_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-      "v_readlane_b32 %6, %9, %11\n\t"
+      "v_readlane_b32 %6, %9, m0\n\t"
       "s_nop 0\n\t"
       "v_add_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
       "s_nop 1\n\t"
       "v_add_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
       "s_nop 1"
       : "+v"(v), "=&s"(a_lo), "=&s"(a_hi), "=&s"(a_pos), "=&s"(b_lo), "=&s"(b_hi), "=&s"(b_pos)
-      : "v"(off_lo), "v"(off_hi), "v"(pos), "s"(k), "s"(k1));
+      : "v"(off_lo), "v"(off_hi), "v"(pos), "s"(k), "s"(k1)
+      : "m0");
   return v;
 }
 // what a round leaves in column k's lane: validity word, byte count | region start << 16

@@ -22,6 +22,7 @@ namespace {
 
 struct Item {
   int kind, arg, off;
+  int inst = -1;  // (class items: the instruction they come from)
 };
 struct Alt {
   std::vector<Item> items;
@@ -121,7 +122,7 @@ struct Walker {
         return;
       }
       const int cls = class_of(members(in));
-      cur.items.push_back({csbits::K_CLASS, cls, cur.len});
+      cur.items.push_back({csbits::K_CLASS, cls, cur.len, pc});
       ++cur.len;
       // the trailing greedy `+`: item; OR(preferred -> the item, other -> brackets -> END)
       const int nx = skip_brackets(in.u2);
@@ -196,6 +197,21 @@ std::vector<int32_t> build_bits(const Program& prog, const std::vector<int32_t>&
   bool same = true;
   for (const Alt& a : w.alts) same = same && a.len == first.len;
   if (same) fl |= csbits::F_SAME_LEN;
+  if (w.alts.size() == 1 && first.items.size() == 1 && first.items[0].kind == csbits::K_CLASS) {
+    const Inst& in = prog.insts[(size_t)first.items[0].inst];
+    bool bytewise = false, high = false;
+    if (in.type == OP_CHAR) {
+      bytewise = (uint32_t)in.u1 >= 1u && (uint32_t)in.u1 < 128u;
+    } else if (in.type == OP_ANY || in.type == OP_ANYNL) {
+      bytewise = high = true;
+    } else if ((in.type == OP_CCLASS || in.type == OP_NCCLASS) && in.u1 >= 0 && (size_t)in.u1 < prog.classes.size()) {
+      const CharClass& cc = prog.classes[(size_t)in.u1];
+      bytewise = cc.builtins == 0;
+      for (uint32_t r : cc.ranges) bytewise = bytewise && r < 128u;
+      high = in.type == OP_NCCLASS;
+    }
+    if (bytewise) fl |= csbits::F_BYTE_CLASS | (high ? csbits::F_HIGH_MEMBER : 0u);
+  }
 
   std::vector<int32_t> img(csbits::kHeaderWords + csbits::kTableWords, 0);
   img[0] = csbits::kMagic;

@@ -45,7 +45,11 @@ constexpr int32_t kMagic = 0x50425343;  // "CSBP"
 constexpr int kMaxClasses = 8, kMaxAlts = 16, kMaxItems = 32, kMaxLen = 31, kHeaderWords = 8, kTableWords = 32;
 constexpr int kMaxWords = 40 + kMaxAlts * (1 + kMaxItems);
 constexpr int kMaxRowBytes = 95;  // cursors 0..n fit the 96-bit masks
-enum { F_WORD = 1, F_BOL = 2, F_EOL = 4, F_BOL_MULTI = 8, F_EOL_MULTI = 16, F_PURE_PLUS = 32, F_PLUS = 64, F_SAME_LEN = 128 };
+enum { F_WORD = 1, F_BOL = 2, F_EOL = 4, F_BOL_MULTI = 8, F_EOL_MULTI = 16, F_PURE_PLUS = 32, F_PLUS = 64, F_SAME_LEN = 128,
+       // the program is ONE class, once or in a `+` loop, whose membership is decided byte by byte on ANY text: a literal ASCII
+       // byte, a set of ASCII bytes and ranges (no builtin classes: \w \s \d reach into the non-ASCII characters), its negation
+       // or `.` -- F_HIGH_MEMBER: every non-ASCII character, i.e. every byte >= 0x80, is a member (cs_runs.hip)
+       F_BYTE_CLASS = 256, F_HIGH_MEMBER = 512 };
 enum { K_CLASS = 0, K_BOW = 1, K_NBOW = 2, K_BOL = 3, K_EOL = 4, K_BOL_MULTI = 5, K_EOL_MULTI = 6 };
 
 struct View {

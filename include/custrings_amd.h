@@ -248,7 +248,9 @@ int cs_find_from(const cs_column* col, const char* str, const int32_t* starts, c
                  int on_device, cs_stream stream, int64_t* found);
 /* NVStrings::find_multiple: results[row * targets + j] = position of targets[j] in the row. */
 int cs_find_multiple(const cs_column* col, const cs_column* targets, int32_t* results, int on_device, cs_stream stream, int64_t* found);
-/* NVStrings::compare: bytewise difference (custring.inl:240-261); *matches = rows equal to `str`. */
+/* NVStrings::compare: bytewise difference (custring.inl:240-261); *matches = rows equal to `str`.  An empty `str` is
+ * compared like any other (1 for a non-empty row, 0 for an empty one) -- the reference returns without writing its
+ * results (find.cu) and its callers hand back an uninitialised buffer. */
 int cs_compare(const cs_column* col, const char* str, int32_t* results, int on_device, cs_stream stream, int64_t* matches);
 /* NVStrings::match_strings: row-wise equality of two columns of the same size (two nulls are equal). */
 int cs_match_strings(const cs_column* col, const cs_column* other, uint8_t* results, int on_device, cs_stream stream, int64_t* matches);

@@ -535,9 +535,10 @@ def test_gpu_extract_groups_resolved_backwards_edges(gpu_engine, oracle_engine):
 
 def test_gpu_replace_re_with_a_co_tenant_on_the_gpu():
     """The persistent replace kernel sizes its grid for an empty device.  With half the CUs held by another stream's
-    kernel the grid is not resident, the waits run into their time bound (a quarter of a second without progress) and
-    the host repeats the call on the two-pass kernels: the result is the oracle's, and the call returns in well under
-    the old two-second bound."""
+    kernel only half of its workgroups are resident at first -- and that is all it needs: tiles are
+    drawn by ticket, so the resident workgroups take every tile; the others start when CUs come free, find the tickets
+    drawn and leave.  No wait runs into its time bound (a quarter of a second without progress), nothing falls back to the
+    two-pass kernels, and the call returns in a small multiple of its time alone -- long before the co-tenant (1.5 s) ends."""
     import ctypes as C
     import time
 
@@ -557,17 +558,25 @@ def test_gpu_replace_re_with_a_co_tenant_on_the_gpu():
     blob = np.ascontiguousarray(blob if blob is not None else engines.product_blob(pat), dtype=np.int32)
     want = orc.replace_re(o, blob, "<IP>")
     L = _lib.lib
+    gpuutil.assert_same(g.replace(pat, "<IP>"), want, "replace_re alone (warm-up: kernel load, buffer pool)")
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    alone = g.replace(pat, "<IP>")
+    dt_alone = time.perf_counter() - t0
+    del alone
     side = torch.cuda.Stream()
+    before = int(L.cs_fallback_count())
     # 128 workgroups with 160 KB of LDS each: 128 of the 256 CUs taken for 1.5 s
     _lib.check(L.cs_debug_spin(128, 160 * 1024, 1500, C.c_void_p(side.cuda_stream)))
     time.sleep(0.05)
     t0 = time.perf_counter()
     got = g.replace(pat, "<IP>")
     dt = time.perf_counter() - t0
+    assert int(L.cs_fallback_count()) == before, "the single pass gave up next to a co-tenant"
+    assert gpuutil.lib().lib.cs_debug_last_route() == b"chain"
     gpuutil.assert_same(got, want, "replace_re next to a co-tenant")
-    assert dt < 1.2, dt
+    assert dt < 0.1 and dt < 0.02 + 20 * dt_alone, (dt, dt_alone)  # (far below the quarter-second no-progress bound)
     torch.cuda.synchronize()
     # and alone again: the single pass, no fallback
-    before = int(L.cs_fallback_count())
     gpuutil.assert_same(g.replace(pat, "<IP>"), want, "replace_re alone")
     assert int(L.cs_fallback_count()) == before

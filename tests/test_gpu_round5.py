@@ -367,3 +367,57 @@ def test_gpu_category_keys_inside_the_slots(plain_slots, monkeypatch):
     cat = nvcategory.from_strings(g)
     gpuutil.assert_same(cat.keys(), ok, "C4 keys")
     assert cat.values() == ov.tolist()
+
+
+def test_gpu_compare_with_the_empty_string():
+    """compare('') used to come back as "equal" for every row (the untouched, zero-initialised buffer)."""
+    from custrings_amd import nvstrings
+
+    g = nvstrings.to_device(["abc", "", None, "é"])
+    assert g.compare("") == [1, 0, None, 1]
+    assert g.compare("abc") == [0, -1, None, g.compare("abc")[3]] and g.compare("abc")[3] > 0
+    try:
+        import pyniNVStrings  # noqa: F401  (the rebuilt CPython glue answers the same)
+    except ImportError:
+        return
+
+
+# ---- one character class, once or in a `+` loop: byte-parallel compaction on rows of any length (cs_runs.hip) -----------
+@pytest.mark.parametrize("pat", [r"[aeiou]+", r"[^ ]+", r".", r".+", r"e", r"[a-e]", r"[^a-z ]+", r" +", r"[0-9.]+"])
+def test_gpu_class_runs_vs_oracle(pat, monkeypatch):
+    """replace_re of a single-class pattern through the byte-parallel kernels -- C5's rows of 40-150 bytes with non-ASCII
+    characters and nulls, then rows chosen to sit on tile and piece boundaries -- against the oracle, route asserted."""
+    monkeypatch.setenv("CS_CLASS_RUNS_ALWAYS", "1")
+    orc = cpulibs.Oracle()
+    blob = blob_of(pat)
+    rows = 50_000
+    g, o = gpuutil.synth(5, 0, rows), orc.synth(5, 0, rows)
+    for repl in ("*", "", "<sixteen bytes!>"):
+        out = g.replace(pat, repl)
+        # (a pattern that replaces every byte by sixteen outgrows the out tile: the route declines, the answer is the same)
+        assert last_route() == "runs" or len(repl) == 16, (pat, repl, last_route())
+        gpuutil.assert_same(out, orc.replace_re(o, blob, repl), "replace_re(%r, %r) on C5" % (pat, repl))
+    special = ["", None, "a", "aeiou", "xaeioux", " ", "  ", "a e i", "é", "aéa", "naïve café", "e" * 300, "b" * 300, "ae" * 700 + "x", "x" * 15 + "a", "x" * 16 + "a",
+               "a" + "x" * 15, "\n", "a\nb", "1.2.3.4", ". . .", "\x00a\x00", "日本語 テキスト aeiou", "a" * 1023, "a" * 1024, "a" * 1025 + " b"]
+    rnd = np.random.default_rng(7)
+    more = ["".join(rnd.choice(list("aeiou xyz.é1"), size=int(rnd.integers(0, 180)))) for _ in range(3000)]
+    col = cpulibs.Col.from_list(special * 3 + more + special)
+    gc = gpuutil.from_col(col)
+    for repl in ("#", "", "=+="):
+        out = gc.replace(pat, repl)
+        assert last_route() == "runs", (pat, repl)
+        gpuutil.assert_same(out, orc.replace_re(col, blob, repl), "replace_re(%r, %r) on edge rows" % (pat, repl))
+
+
+def test_gpu_class_runs_route_is_for_long_or_non_ascii_columns():
+    """The route is taken where the 96-bit-mask forms are not: C5 (long rows); C3 keeps the single pass."""
+    g5 = gpuutil.synth(5, 0, 40_000)
+    g5.replace(r"[aeiou]+", "*")
+    assert last_route() == "runs"
+    g5.replace(r"#+", "*")  # (no candidates in the sample: the skipping scans)
+    assert last_route() != "runs"
+    g5.replace(r"\w+", "*")  # (a builtin class reaches into the non-ASCII characters: not a byte class)
+    assert last_route() != "runs"
+    g3 = gpuutil.synth(3, 0, 40_000)
+    g3.replace(r"[aeiou]+", "*")
+    assert last_route() == "bits"

@@ -63,7 +63,13 @@ def find_family_fuzz(e, o, s):
         ends = [rnd.randint(-2, 30) for _ in s]
         for a, b in ((None, None), (starts, None), (None, ends), (starts, ends)):
             assert e.find_from(s, sub, a, b) == o.find_from(s, sub, a, b), (sub, a is None, b is None)
-        assert e.compare(s, sub) == o.compare(s, sub), sub
+        if sub == "" and type(e).__name__ == "GpuEngine":
+            # (the reference returns from compare("") without writing its results -- find.cu -- and the oracle follows it; the
+            # C ABI compares with the empty string like with any other: 1 for a non-empty row, 0 for an empty one, -1 null)
+            want = [-1 if x is None else (1 if len(x.encode("utf8")) else 0) for x in s]
+            assert e.compare(s, sub) == (want, sum(1 for w in want if w == 0)), sub
+        else:
+            assert e.compare(s, sub) == o.compare(s, sub), sub
         assert e.startswith(s, sub) == o.startswith(s, sub), sub
         assert e.endswith(s, sub) == o.endswith(s, sub), sub
     targets = ["a", "é", None, "", "ab", "zz"]
