@@ -145,9 +145,17 @@ def run_c3(a, ov):
         report("C3", "contains_re(%s) [%d instructions; %s]" % (name, ninst, how), rows, b, b + ov * rows + rows,
                timed(lambda: c3.contains(pat, devptr=resb.data_ptr())))
         report("C3", "match(%s)" % name, rows, b, b + ov * rows + rows, timed(lambda: c3.match(pat, devptr=resb.data_ptr())))
+        cnt32 = torch.zeros(rows, dtype=torch.int32, device="cuda")
+        report("C3", "count_re(%s)" % name, rows, b, b + ov * rows + 4 * rows, timed(lambda: c3.count(pat, devptr=cnt32.data_ptr())))
+        del cnt32
         rep = c3.replace(pat, repl)
-        report("C3", "replace_re(%s,'%s')" % (name, repl), rows, b, b + nbytes(rep) + 2 * ov * rows, timed(lambda: c3.replace(pat, repl), reps=2))
+        route = L.cs_debug_last_route().decode()
+        report("C3", "replace_re(%s,'%s') [route: %s]" % (name, repl, route), rows, b, b + nbytes(rep) + 2 * ov * rows, timed(lambda: c3.replace(pat, repl), reps=2))
         del rep
+    # a small set in a `+` loop: candidates in a good share of the bytes (the bit-parallel form, regex_bits.h)
+    rep = c3.replace(r"[aeiou]+", "*")
+    report("C3", "replace_re([aeiou]+,'*') [route: %s]" % L.cs_debug_last_route().decode(), rows, b, b + nbytes(rep) + 2 * ov * rows, timed(lambda: c3.replace(r"[aeiou]+", "*"), reps=2))
+    del rep
     report("C3", "match(IPv4)", rows, b, b + ov * rows + rows, timed(lambda: c3.match(IPV4, devptr=resb.data_ptr())))
     rc = c3.rsplit(" ")
     report("C3", "rsplit(' ') (no limit: the split kernels)", rows, b, b + ov * rows + sum(nbytes(c) for c in rc) + sum(col_ov(c) for c in rc) * rows,
@@ -213,7 +221,12 @@ def run_c5(a, ov):
     tok = nvtext.tokenize(c5)
     t = tok.size()
     report("C5", "tokenize", rows, b, b + ov * rows + nbytes(tok) + ov * t, timed(lambda: nvtext.tokenize(c5), reps=2))
+    # a single class in a `+` loop on rows of 40-150 bytes (beyond the 96-bit masks): byte-parallel compaction (cs_runs.hip)
+    rp = c5.replace(r"[aeiou]+", "*")
+    report("C5", "replace_re([aeiou]+,'*') [route: %s]" % L.cs_debug_last_route().decode(), rows, b, b + nbytes(rp) + 2 * ov * rows, timed(lambda: c5.replace(r"[aeiou]+", "*"), reps=2))
+    del rp
     del c5
+    rep = c5.replace(r"[aeiou]+", "*") if False else None
     ng = nvtext.ngrams(tok, 2, "_")
     report("C5", "ngrams(2)", t, nbytes(tok), nbytes(tok) + ov * t + nbytes(ng) + ov * ng.size(), timed(lambda: nvtext.ngrams(tok, 2, "_"), reps=2))
 
