@@ -1184,21 +1184,21 @@ __device__ __forceinline__ void bits_classify16(const uint32_t* spread, const ui
 }
 // a row lane's mask of class k, shifted right by `off`: cut out of the class's bitmap on demand (regex_bits.h: cls(k, off))
 #define CS_BITS_CLS(bitmap, bm_words, p0, n)                                                                       \
-  [&](int k_, int off_) -> cstd::U128 {                                                                            \
+  [&](int k_, int off_) -> csbits::M96 {                                                                           \
     uint32_t m0_, m1_, m2_;                                                                                        \
     cstile::row_bits96((bitmap) + __builtin_amdgcn_readfirstlane(k_) * (bm_words), (p0) + off_, max((n) - off_, 0), m0_, m1_, m2_); \
-    return cstd::u128(m0_ | ((unsigned long long)m1_ << 32), m2_);                                                 \
+    return csbits::m96(m0_, m1_, m2_);                                                                             \
   }
 // ... without the cut at the row's end (regex_bits.h: raw(k, off)): three funnel shifts over four words of the bitmap
 #define CS_BITS_RAW(bitmap, bm_words, p0)                                                                          \
-  [&](int k_, int off_) -> cstd::U128 {                                                                            \
+  [&](int k_, int off_) -> csbits::M96 {                                                                           \
     const int q_ = (p0) + off_;                                                                                    \
     const uint32_t* w_ = (bitmap) + __builtin_amdgcn_readfirstlane(k_) * (bm_words) + (q_ >> 5);                   \
     const uint32_t a_ = w_[0], b_ = w_[1], c_ = w_[2], d_ = w_[3];                                                 \
     const unsigned sh_ = (unsigned)q_ & 31u;                                                                       \
     const uint32_t m0_ = __builtin_amdgcn_alignbit(b_, a_, sh_), m1_ = __builtin_amdgcn_alignbit(c_, b_, sh_),     \
                    m2_ = __builtin_amdgcn_alignbit(d_, c_, sh_);                                                   \
-    return cstd::u128(m0_ | ((unsigned long long)m1_ << 32), m2_);                                                 \
+    return csbits::m96(m0_, m1_, m2_);                                                                             \
   }
 
 // UNITS (with !INPLACE, RESCAN, !LONG): the scan runs per UNIT instead of per row (regex_tdfa.cpp, header word 31).

@@ -95,12 +95,65 @@ CS_HD void classify16(const uint32_t* spread, uint32_t x, uint32_t y, uint32_t z
   // byte m of lo_e / hi_e: bytes 0..7 / 8..15 of the piece for class 2m (lo_o / hi_o: class 2m + 1)
   const uint32_t lo_e = (a[0] & 0x0F0F0F0Fu) | ((a[1] & 0x0F0F0F0Fu) << 4), hi_e = (a[2] & 0x0F0F0F0Fu) | ((a[3] & 0x0F0F0F0Fu) << 4);
   const uint32_t lo_o = ((a[0] >> 4) & 0x0F0F0F0Fu) | (a[1] & 0xF0F0F0F0u), hi_o = ((a[2] >> 4) & 0x0F0F0F0Fu) | (a[3] & 0xF0F0F0F0u);
+#if defined(__HIP_DEVICE_COMPILE__)
+  // one byte permute per pair of classes: [lo_e.m, hi_e.m, lo_o.m, hi_o.m] out of the eight bytes of (hi, lo)
+  const uint32_t e01 = __builtin_amdgcn_perm(hi_e, lo_e, 0x05010400u), e23 = __builtin_amdgcn_perm(hi_e, lo_e, 0x07030602u);
+  const uint32_t o01 = __builtin_amdgcn_perm(hi_o, lo_o, 0x05010400u), o23 = __builtin_amdgcn_perm(hi_o, lo_o, 0x07030602u);
+  // e01 = class 0 (16 bits) | class 2 << 16; o01 = class 1 | class 3 << 16; e23 = class 4 | class 6 << 16; o23 = class 5 | class 7 << 16
+  pair[0] = __builtin_amdgcn_perm(o01, e01, 0x05040100u);  // class 0 | class 1 << 16
+  pair[1] = __builtin_amdgcn_perm(o01, e01, 0x07060302u);  // class 2 | class 3 << 16
+  pair[2] = __builtin_amdgcn_perm(o23, e23, 0x05040100u);
+  pair[3] = __builtin_amdgcn_perm(o23, e23, 0x07060302u);
+#else
   for (int m = 0; m < 4; ++m) {
     const uint32_t even = ((lo_e >> (8 * m)) & 255u) | (((hi_e >> (8 * m)) & 255u) << 8);
     const uint32_t odd = ((lo_o >> (8 * m)) & 255u) | (((hi_o >> (8 * m)) & 255u) << 8);
     pair[m] = even | (odd << 16);
   }
+#endif
 }
+
+// A row's mask: 96 bits in three words (bit i of w[i / 32]: byte / cursor i).  The evaluation below runs on these -- the
+// 2 x 64-bit form the kernels keep their match bits in costs four register operations where three do, and its shifts are
+// 64-bit ones.
+struct M96 {
+  uint32_t a, b, c;
+};
+CS_HD M96 m96(uint32_t a, uint32_t b, uint32_t c) {
+  M96 r;
+  r.a = a;
+  r.b = b;
+  r.c = c;
+  return r;
+}
+CS_HD M96 m_and(M96 x, M96 y) { return m96(x.a & y.a, x.b & y.b, x.c & y.c); }
+CS_HD M96 m_or(M96 x, M96 y) { return m96(x.a | y.a, x.b | y.b, x.c | y.c); }
+CS_HD M96 m_andn(M96 x, M96 y) { return m96(x.a & ~y.a, x.b & ~y.b, x.c & ~y.c); }  // x & ~y
+CS_HD bool m_any(M96 x) { return (x.a | x.b | x.c) != 0; }
+CS_HD uint32_t funnel_r(uint32_t hi, uint32_t lo, unsigned k) {  // low word of (hi:lo) >> k, k in 0..31
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_alignbit(hi, lo, k);
+#else
+  return k ? (lo >> k) | (hi << (32 - k)) : lo;
+#endif
+}
+CS_HD M96 m_shr(M96 x, int k) {  // k in 0..31
+  return m96(funnel_r(x.b, x.a, (unsigned)k), funnel_r(x.c, x.b, (unsigned)k), x.c >> k);
+}
+CS_HD M96 m_shl1(M96 x) { return m96(x.a << 1, (x.b << 1) | (x.a >> 31), (x.c << 1) | (x.b >> 31)); }
+CS_HD M96 m_shr1(M96 x) { return m96((x.a >> 1) | (x.b << 31), (x.b >> 1) | (x.c << 31), x.c >> 1); }
+CS_HD uint32_t word_below(int q) { return q >= 32 ? 0xFFFFFFFFu : (q <= 0 ? 0u : ~(0xFFFFFFFFu << q)); }
+CS_HD M96 m_below(int q) { return m96(word_below(q), word_below(q - 32), word_below(q - 64)); }  // bits 0 .. q-1, q in 0..96
+CS_HD M96 m_bit(int q) {
+  const uint32_t bit = 1u << (q & 31);
+  return m96(q < 32 ? bit : 0u, (q >= 32 && q < 64) ? bit : 0u, q >= 64 ? bit : 0u);
+}
+CS_HD unsigned m_test(M96 x, int q) { return ((q < 32 ? x.a : (q < 64 ? x.b : x.c)) >> (q & 31)) & 1u; }
+CS_HD int m_ctz(M96 x) {  // x != 0
+  return x.a ? __builtin_ctz(x.a) : (x.b ? 32 + __builtin_ctz(x.b) : 64 + __builtin_ctz(x.c));
+}
+CS_HD M96 m_from(U128 x) { return m96((uint32_t)x.lo, (uint32_t)(x.lo >> 32), (uint32_t)x.hi); }
+CS_HD U128 m_to128(M96 x) { return cstd::u128(x.a | ((unsigned long long)x.b << 32), x.c); }
 
 // All starts at which some alternative matches (`any`) and, for the span forms, the chosen alternative's length in binary
 // across five planes.  `cls(k, off)` hands out the row's mask of class k shifted right by `off` (bit i = byte i + off is a
@@ -110,101 +163,101 @@ CS_HD void classify16(const uint32_t* spread, uint32_t x, uint32_t y, uint32_t z
 // only admits starts p with p + L <= n, so its items never look beyond the row and the one mask on the starts replaces a
 // mask per item.
 template <class Cls, class Raw>
-CS_HD U128 starts(const View& V, Cls&& cls, Raw&& raw, int n, bool want_len, U128 plane[5]) {
-  using namespace cstd;
-  const U128 cursors = u128_below(n + 1);
-  U128 bnd = u128(0, 0), bol = u128(1, 0), eol = bit_at(n), bolm = bol, eolm = eol;
+CS_HD M96 starts(const View& V, Cls&& cls, Raw&& raw, int n, bool want_len, M96 plane[5]) {
+  const M96 cursors = m_below(n + 1);
+  M96 bnd = m96(0, 0, 0), bol = m96(1, 0, 0), eol = m_bit(n), bolm = bol, eolm = eol;
   if (V.flags & F_WORD) {
-    const U128 W = cls(V.word_cls, 0);
-    bnd = u128_and(u128(W.lo ^ (W.lo << 1), W.hi ^ ((W.hi << 1) | (W.lo >> 63))), cursors);
+    const M96 W = cls(V.word_cls, 0);
+    const M96 L = m_shl1(W);
+    bnd = m_and(m96(W.a ^ L.a, W.b ^ L.b, W.c ^ L.c), cursors);
   }
   if (V.flags & (F_BOL_MULTI | F_EOL_MULTI)) {
-    const U128 NL = cls(V.nl_cls, 0);
-    bolm = u128_or(bol, u128_and(u128_shl1(NL), cursors));  // behind a newline (regexec.inl: BOL with '^')
-    eolm = u128_or(eol, NL);                                  // in front of a newline (EOL with '$')
+    const M96 NL = cls(V.nl_cls, 0);
+    bolm = m_or(bol, m_and(m_shl1(NL), cursors));  // behind a newline (regexec.inl: BOL with '^')
+    eolm = m_or(eol, NL);                           // in front of a newline (EOL with '$')
   }
-  U128 any = u128(0, 0);
+  M96 any = m96(0, 0, 0);
   if (want_len)
-    for (int b = 0; b < 5; ++b) plane[b] = u128(0, 0);
+    for (int b = 0; b < 5; ++b) plane[b] = m96(0, 0, 0);
   const int32_t* w = V.img + kHeaderWords + kTableWords;
   for (int j = 0; j < V.J; ++j) {
     const int hdr = CSBITS_UNIFORM(*w++);
     const int items = hdr & 255, len = (hdr >> 8) & 255;
-    U128 A = u128_below(n - len + 1 > 0 ? n - len + 1 : 0);  // starts whose match stays inside the row
+    M96 A = m_below(n - len + 1);  // starts whose match stays inside the row
     for (int i = 0; i < items; ++i) {
       const int it = CSBITS_UNIFORM(*w++);
       const int kind = it & 255, arg = (it >> 8) & 255, off = (it >> 16) & 255;
       if (kind == K_CLASS) {
-        A = u128_and(A, raw(arg, off));
+        A = m_and(A, raw(arg, off));
         continue;
       }
-      U128 X;
+      M96 X;
       switch (kind) {
         case K_BOW: X = bnd; break;
-        case K_NBOW: X = u128_andn(cursors, bnd); break;
+        case K_NBOW: X = m_andn(cursors, bnd); break;
         case K_BOL: X = bol; break;
         case K_EOL: X = eol; break;
         case K_BOL_MULTI: X = bolm; break;
         default: X = eolm; break;
       }
-      A = u128_and(A, shr(X, off));
+      A = m_and(A, m_shr(X, off));
     }
     if (want_len) {
-      const U128 sel = u128_andn(A, any);
+      const M96 sel = m_andn(A, any);
       for (int b = 0; b < 5; ++b)
-        if ((len >> b) & 1) plane[b] = u128_or(plane[b], sel);
+        if ((len >> b) & 1) plane[b] = m_or(plane[b], sel);
     }
-    any = u128_or(any, A);
+    any = m_or(any, A);
   }
   return any;
 }
 
 // The row's matches in order, non-overlapping: S = first bytes, E = last bytes (one bit each per match).
 template <class Cls, class Raw>
-CS_HD void match(const View& V, Cls&& cls, Raw&& raw, int n, U128& S, U128& E) {
-  using namespace cstd;
+CS_HD void match(const View& V, Cls&& cls, Raw&& raw, int n, U128& S128, U128& E128) {
   if (V.flags & F_PURE_PLUS) {  // `[set]+` alone: the maximal runs of the class
-    const U128 C = cls(V.plus_cls, 0);
-    S = u128_andn(C, u128_shl1(C));
-    E = u128_andn(C, shr1(C));
+    const M96 C = cls(V.plus_cls, 0);
+    S128 = m_to128(m_andn(C, m_shl1(C)));
+    E128 = m_to128(m_andn(C, m_shr1(C)));
     return;
   }
-  U128 plane[5];
+  M96 plane[5];
   const bool same_len = (V.flags & F_SAME_LEN) != 0;  // (one length for every alternative: no planes)
   const int the_len = CSBITS_UNIFORM(V.img[kHeaderWords + kTableWords]) >> 8 & 255;
-  U128 rem = starts(V, cls, raw, n, !same_len, plane);
-  S = u128(0, 0);
-  E = u128(0, 0);
-  U128 C = u128(0, 0);
+  M96 rem = starts(V, cls, raw, n, !same_len, plane);
+  M96 S = m96(0, 0, 0), E = m96(0, 0, 0), C = m96(0, 0, 0);
   if (V.flags & F_PLUS) C = cls(V.plus_cls, 0);
-  while (u128_any(rem)) {
-    const int p = u128_ctz(rem);
+  while (m_any(rem)) {
+    const int p = m_ctz(rem);
     int len = the_len;
     if (!same_len) {
       len = 0;
-      for (int b = 0; b < 5; ++b) len |= (int)test(plane[b], p) << b;
+      for (int b = 0; b < 5; ++b) len |= (int)m_test(plane[b], p) << b;
     }
     int end = p + len;  // the cursor behind the match
     if (V.flags & F_PLUS) {
-      // the run of the last class goes on from the match's last fixed byte: its end is the first non-member at or behind `end`
-      const U128 stop = u128_andn(u128(~0ull, ~0ull), u128_or(C, u128_below(end)));
-      end = u128_ctz(stop);  // (bits n .. 127 of C are zero: a stop exists)
+      // the run of the last class goes on from the match's last fixed byte: its end is the first non-member at or behind
+      // `end` (the row's end at the latest: C is cut there, and n <= 95 leaves bit 95 clear)
+      const M96 stop = m_andn(m96(~0u, ~0u, ~0u), m_or(C, m_below(end)));
+      end = m_ctz(stop);
     }
-    S = u128_or(S, bit_at(p));
-    E = u128_or(E, bit_at(end - 1));
-    rem = u128_andn(rem, u128_below(end));
+    S = m_or(S, m_bit(p));
+    E = m_or(E, m_bit(end - 1));
+    rem = m_andn(rem, m_below(end));
   }
+  S128 = m_to128(S);
+  E128 = m_to128(E);
 }
 
 template <class Cls, class Raw>
 CS_HD bool contains(const View& V, Cls&& cls, Raw&& raw, int n) {
-  U128 unused[5];
-  return cstd::u128_any(starts(V, cls, raw, n, false, unused));
+  M96 unused[5];
+  return m_any(starts(V, cls, raw, n, false, unused));
 }
 template <class Cls, class Raw>
 CS_HD bool match_at_start(const View& V, Cls&& cls, Raw&& raw, int n) {
-  U128 unused[5];
-  return (starts(V, cls, raw, n, false, unused).lo & 1ull) != 0;
+  M96 unused[5];
+  return (starts(V, cls, raw, n, false, unused).a & 1u) != 0;
 }
 
 }  // namespace csbits

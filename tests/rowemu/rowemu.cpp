@@ -384,13 +384,13 @@ struct BitsRow {
     ok = true;
   }
   auto cls() const {
-    return [this](int k, int off) { return csbits::shr(C[k], off); };
+    return [this](int k, int off) { return csbits::m_from(csbits::shr(C[k], off)); };
   }
   // (the unmasked form: what lies beyond the row is the next row's in the kernels -- here every such bit is set, so that a
   // result that depended on them would show)
   auto raw(int len) const {
     return [this, len](int k, int off) {
-      return cstd::u128_or(csbits::shr(C[k], off), cstd::u128_andn(cstd::u128(~0ull, ~0ull), cstd::u128_below(len - off > 0 ? len - off : 0)));
+      return csbits::m_from(cstd::u128_or(csbits::shr(C[k], off), cstd::u128_andn(cstd::u128(~0ull, ~0ull), cstd::u128_below(len - off > 0 ? len - off : 0))));
     };
   }
 };
