@@ -3324,8 +3324,14 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
         if (err == 2 && !roomy_first) err = stream_attempt(true);  // only ran out of room: once more, roomier
         if (err == 0) return;
         if (err > 0) {  // (counted: cs_fallback_count)
-          char what[64];
-          snprintf(what, sizeof(what), "replace_re (error word %d)", err);
+          // what gave up, in words: the error word's bits and the column's shape (profiles/r04/soak.txt showed "error word 33"
+          // without saying that it is the backrefs form meeting a sub-tile with more than 128 matches)
+          char what[256];
+          snprintf(what, sizeof(what), "%s (error word %d:%s%s%s%s%s%s; %lld rows, longest %lld bytes, largest 64-row span %lld)",
+                   cs::g_backrefs_dev ? "replace_with_backrefs" : "replace_re", err, (err & 1) ? " launch abandoned" : "", (err & 2) ? " out of output room" : "",
+                   (err & 4) ? " a sub-tile beyond the staging buffer" : "", (err & 8) ? " no prefix for a tile" : "", (err & 16) ? " the scanners timed out" : "",
+                   (err & 32) ? " a sub-tile with more than 128 matches or a row handed over by the unit route (the template needs the unit route's masks)" : "",
+                   (long long)col->rows, (long long)col->max_row, (long long)col->max_span64);
           note_fallback(what);
         }
       } else if (lds <= 150 * 1024 && growth == 0 && (tc.R == 64 || tc.R == 0) && !cs::g_backrefs_dev && !wide) {  // (cap is the 64-row capacity then)

@@ -13,13 +13,17 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import cpulibs  # noqa: E402
 import gpuutil  # noqa: E402
-from custrings_amd import nvtext, nvcategory  # noqa: E402
+from custrings_amd import nvtext, nvcategory, _lib  # noqa: E402
+
+LIB = _lib.lib
 
 TOGGLES = ("CS_REGEX_TWO_PASS", "CS_REGEX_ROWWISE", "CS_SPLIT_GENERIC", "CS_TOKENIZE_ROWWISE", "CS_STRIP_ROWWISE",
            "CS_FIND_ROWWISE", "CS_REPLACE_ROWWISE", "CS_CASE_ROWWISE", "CS_NGRAM_ROWWISE")
 PATS = [(r"\d+\.\d+\.\d+\.\d+", "<IP>"), (r"\d", "#"), (r"[a-c]+", "xyz__"), (r"\s+", " "), (r"\w+", "<w>"), (r"b|ab", ""),
         (r"\bx", "YY"), (r"[0-9]+", "<number-here>"), (r"a", "aa"), (r"(a|b)c", "-"),
-        (r"\d+\.\d+ ", "<n>"), (r"[a-c]+=>", ""), (r"\d+ab", "#")]  # (chains with a literal suffix)
+        (r"\d+\.\d+ ", "<n>"), (r"[a-c]+=>", ""), (r"\d+ab", "#"),  # (chains with a literal suffix)
+        # the bit-parallel form (regex_bits.h) and the single-class byte-parallel route (cs_runs.hip)
+        (r"(\bab\b)|(\bc\b)|(\bxyz\b)", "="), (r"[abc1]+", "*"), (r"ab|a1|bc", "#"), (r"[^ ]+", "_"), (r".", "?"), (r"x?y?z", "Q")]
 
 
 def make_column(seed):
@@ -210,12 +214,12 @@ def main():
     while time.time() - t0 < budget:
         col, flavour = make_column(seed)
         g = gpuutil.from_col(col)
-        for v in TOGGLES:
-            os.environ.pop(v, None)
+        for v in TOGGLES:  # (the library reads its switches once: cs_config_set changes them at run time)
+            LIB.cs_config_set(v.encode(), None)
         fast = snapshot(g, col.rows, seed)
         cat_f = nvcategory.from_strings(g)
         for v in TOGGLES:
-            os.environ[v] = "1"
+            LIB.cs_config_set(v.encode(), b"1")
         slow = snapshot(g, col.rows, seed)
         for k in fast:
             if not same(fast[k], slow[k]):
