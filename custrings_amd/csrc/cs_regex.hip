@@ -1230,7 +1230,7 @@ __global__ void __launch_bounds__(256, (BREFS || BITS) ? 2 : CS_STREAM_WAVES) k_
   // CHAIN (a UNITS form): the pattern is a chain and a sample of the column holds no byte >= 0x80 -- the unit scan, the
   // literal scan and the lean scans are compiled out (their registers with them); a sub-tile the chain arithmetic does
   // not take (a non-ASCII byte after all, a row beyond the masks) goes to the generic scan row by row.
-  static_assert(!CHAIN || (UNITS && IN_LDS && !BREFS), "the chain form is a unit-scan variant");
+  static_assert(!CHAIN || (UNITS && !BREFS), "the chain form is a unit-scan variant");
   static_assert(!OUTL || (IN_LDS && !LONG && !UNITS && !BREFS && !WIDE), "oversize sub-tiles: the plain forms only");
   static_assert(!UNITS || (!INPLACE && RESCAN && !LONG), "the unit scan builds on the register-record assembly");
   static_assert(!WIDE || (!UNITS && IN_LDS && !BREFS), "the wide form: generic scan only");
@@ -1640,7 +1640,7 @@ __global__ void __launch_bounds__(256, (BREFS || BITS) ? 2 : CS_STREAM_WAVES) k_
           p_second = cstile::status_load(a.excl + (p_tile >= 0 ? p_tile : 0));
           has_second = scanner;
           if (live) {
-            chain_match(u128(r0 | ((unsigned long long)r1 << 32), r2), u128(x0 | ((unsigned long long)x1 << 32), x2), D.chain, uS, uE, D.sfx, n,
+            chain_match(u128(r0 | ((unsigned long long)r1 << 32), r2), u128(x0 | ((unsigned long long)x1 << 32), x2), D.chain, D.crep, uS, uE, D.sfx, n,
                         [&](int i) { return lds_in[lead + rbeg + i]; });
             nm = u128_popc(uS);
             out_len = n - u128_popc(u128_sub(u128_shl1(uE), uS)) + nm * rb;
@@ -1661,7 +1661,7 @@ __global__ void __launch_bounds__(256, (BREFS || BITS) ? 2 : CS_STREAM_WAVES) k_
           p_second = cstile::status_load(a.excl + (p_tile >= 0 ? p_tile : 0));
           has_second = scanner;
           if (live) {
-            chain_match(R, X, D.chain, uS, uE, D.sfx, n, [&](int i) { return lds_in[lead + rbeg + i]; });
+            chain_match(R, X, D.chain, D.crep, uS, uE, D.sfx, n, [&](int i) { return lds_in[lead + rbeg + i]; });
             nm = u128_popc(uS);
             from_masks = true;
           }
@@ -1679,7 +1679,7 @@ __global__ void __launch_bounds__(256, (BREFS || BITS) ? 2 : CS_STREAM_WAVES) k_
               S = u128_clear_lowest(S);
               E = u128_clear_lowest(E);
               int gb[4] = {-1, -1, -1, -1}, ge[4] = {-1, -1, -1, -1};
-              if (T.nrefs > 0) chain_group_bounds(R, X, D.chain, gmap, mb, gb, ge);  // (a template without references needs no groups)
+              if (T.nrefs > 0) chain_group_bounds(R, X, D.chain, D.crep, gmap, mb, gb, ge);  // (a template without references needs no groups)
               int grow = T.bytes - (me - mb);
               for (int j = 0; j < T.nrefs; ++j) {
                 const int g = T.idx(j);
@@ -2334,11 +2334,11 @@ __global__ void __launch_bounds__(256, MODE == 4 ? 3 : CHAIN ? 4 : (UNITS && MOD
           if (unit_x != 0) cstile::row_bits96(xbitmap, lead + rbeg, n, x0w, x1w, x2w);
           const U128 Rm = u128(r0w | ((unsigned long long)r1w << 32), r2w), Xm = u128(x0w | ((unsigned long long)x1w << 32), x2w);
           U128 S = u128(0, 0), E = u128(0, 0);
-          if (live) chain_match(Rm, Xm, D.chain, S, E, D.sfx, n, [&](int i) { return lds_in[lead + rbeg + i]; });
+          if (live) chain_match(Rm, Xm, D.chain, D.crep, S, E, D.sfx, n, [&](int i) { return lds_in[lead + rbeg + i]; });
           const bool hit = live && u128_any(S);
           v = hit;
           int gb[4], ge[4];
-          chain_group_bounds(Rm, Xm, D.chain, (uint32_t)D.img[D.img[15] - 1], hit ? u128_ctz(S) : 0, gb, ge);
+          chain_group_bounds(Rm, Xm, D.chain, D.crep, (uint32_t)D.img[D.img[15] - 1], hit ? u128_ctz(S) : 0, gb, ge);
           if (lane < nrows) {
 #pragma unroll
             for (int k = 0; k < 4; ++k)
@@ -2448,7 +2448,7 @@ __global__ void __launch_bounds__(256, MODE == 4 ? 3 : CHAIN ? 4 : (UNITS && MOD
           if (unit_x != 0) cstile::row_bits96(xbitmap, lead + rbeg, n, x0, x1, x2);
           if (live) {
             U128 S, E;
-            chain_match(u128(r0 | ((unsigned long long)r1 << 32), r2), u128(x0 | ((unsigned long long)x1 << 32), x2), D.chain, S, E, D.sfx, n,
+            chain_match(u128(r0 | ((unsigned long long)r1 << 32), r2), u128(x0 | ((unsigned long long)x1 << 32), x2), D.chain, D.crep, S, E, D.sfx, n,
                         [&](int i) { return lds_in[lead + rbeg + i]; });
             while (u128_any(S)) {
               const int mb = u128_ctz(S), me = u128_ctz(E) + 1;
@@ -2530,11 +2530,15 @@ __global__ void __launch_bounds__(256, MODE == 4 ? 3 : CHAIN ? 4 : (UNITS && MOD
           cstile::row_bits96(bitmap, lead + rbeg, n, r0, r1, r2);
           if (unit_x != 0) cstile::row_bits96(xbitmap, lead + rbeg, n, x0, x1, x2);
           const U128 R = u128(r0 | ((unsigned long long)r1 << 32), r2), X = u128(x0 | ((unsigned long long)x1 << 32), x2);
-          if (MODE == 0) {
-            v = live && u128_any(chain_suffix_filter(chain_ends(R, X, D.chain), D.chain, D.sfx, n, [&](int i) { return lds_in[lead + rbeg + i]; })) ? 1 : 0;
+          if (MODE == 0 && !(D.chain & kChainLeadB)) {  // (a `\b` in front of the chain is checked per match: chain_match)
+            v = live && u128_any(chain_suffix_filter(chain_ends(R, X, D.chain, D.crep), D.chain, D.sfx, n, [&](int i) { return lds_in[lead + rbeg + i]; })) ? 1 : 0;
+          } else if (MODE == 0) {
+            U128 S = u128(0, 0), E;
+            if (live) chain_match(R, X, D.chain, D.crep, S, E, D.sfx, n, [&](int i) { return lds_in[lead + rbeg + i]; });
+            v = u128_any(S) ? 1 : 0;
           } else {
             U128 S = u128(0, 0), E;
-            if (live) chain_match(R, X, D.chain, S, E, D.sfx, n, [&](int i) { return lds_in[lead + rbeg + i]; });
+            if (live) chain_match(R, X, D.chain, D.crep, S, E, D.sfx, n, [&](int i) { return lds_in[lead + rbeg + i]; });
             v = u128_popc(S);
           }
           redo = false;
@@ -3144,12 +3148,23 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
           cap_out = std::max(cap_out, 2 * cap);
           extra = std::max<int64_t>(extra, col->nbytes);
         }
-        const size_t lds1 = tbl + gt_bytes + bits_lds + (size_t)(cap + cap_out + 64 + (cap >> 3) + 32 + unit_bytes) * 4 + 16;
+        // (a chain pattern on a column whose sample is plain ASCII: the form without the unit / lean scans)
+        const bool chain_form = !bits_form && !brefs && !wide_stream && !outliers && units && cap <= 5 * 1024 && tp.d.in_lds && !literal && maxrepl < 0 &&
+                                ((re->tdfa[30] >> 16) & 15) != 0 && !sample_has_high_bytes(col, s) && !cs::cfg("CS_NO_CHAIN_FORM");
+        // The chain arithmetic reads no table: when the tables are what keeps a third workgroup off the CU (the 26-instruction
+        // dotted quad with `\b` and {1,3}: 36 states, 19 KB), they stay in memory -- only a sub-tile the arithmetic does not take
+        // (bytes >= 0x80, a row beyond the masks) walks them there, and the sample says those are rare.
+        const size_t tile_lds = gt_bytes + bits_lds + (size_t)(cap + cap_out + 64 + (cap >> 3) + 32 + unit_bytes) * 4 + 16;
+        constexpr size_t kThird = 160 * 1024 / 3;
+        const bool chain_global = chain_form && tbl + tile_lds > kThird && tile_lds <= kThird && !cs::cfg("CS_CHAIN_TABLES_IN_LDS");
+        const size_t tbl_lds = chain_global ? 0 : tbl;
+        const size_t lds1 = tbl_lds + tile_lds;
         if (lds1 > 150 * 1024) return -1;
         StreamArgs sa{};
         sa.in = view_of(col);
         sa.flags = d_unicode_flags();
         sa.L = tp.d;
+        if (chain_global) sa.L.in_lds = 0;
         sa.repl = ptr<const uint8_t>(d_repl);
         sa.rb = rb;
         sa.maxrepl = maxrepl;
@@ -3172,7 +3187,7 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
         sa.nsub = nsub1;
         sa.cap_in = cap;
         sa.cap_out = cap_out;
-        sa.tbl_bytes = (int)(tbl + gt_bytes + bits_lds);
+        sa.tbl_bytes = (int)(tbl_lds + gt_bytes + bits_lds);
         sa.bits = bits_form ? ptr<const int32_t>(re->d_bits) : nullptr;
         sa.bits_off = (int)(tbl + gt_bytes);
         sa.bits_words = bits_form ? (int)re->bits.size() : 0;
@@ -3217,8 +3232,10 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
         else if (bits_form)
           kern = rb > 8 ? &k_tdfa_replace_stream<true, true, false, true, false, true, cstile::kPfChunks, false, false, false, true, true>
                         : &k_tdfa_replace_stream<true, false, false, true, false, true, cstile::kPfChunks, false, false, false, true, true>;
-        else if (units && cap <= 5 * 1024 && tp.d.in_lds && !literal && maxrepl < 0 && ((re->tdfa[30] >> 16) & 15) != 0 && !sample_has_high_bytes(col, s) && !cs::cfg("CS_NO_CHAIN_FORM"))
-          // (a chain pattern on a column whose sample is plain ASCII: the form without the unit / lean scans)
+        else if (chain_form && chain_global)
+          kern = rb > 8 ? &k_tdfa_replace_stream<false, true, false, true, false, true, 5, false, false, false, true>
+                        : &k_tdfa_replace_stream<false, false, false, true, false, true, 5, false, false, false, true>;
+        else if (chain_form)
           kern = rb > 8 ? &k_tdfa_replace_stream<true, true, false, true, false, true, 5, false, false, false, true>
                         : &k_tdfa_replace_stream<true, false, false, true, false, true, 5, false, false, false, true>;
         else if (units && cap <= 5 * 1024)
@@ -3233,8 +3250,8 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
                                      (int)lds1));
         const unsigned grid = resident_grid(reinterpret_cast<const void*>(kern), lds1, (nsub1 + 3) / 4);
         if (cs::cfg("CS_STREAM_INFO"))
-          fprintf(stderr, "replace stream: grid %u lds %zu (tables %zu, tile %d + %d) rows/tile %d units %d wide %d brefs %d roomy %d growth %d rb %d\n", grid, lds1, tbl + gt_bytes, cap, cap_out,
-                  tc.R, (int)units, (int)wide_stream, (int)brefs, (int)roomy, (int)growth, rb);
+          fprintf(stderr, "replace stream: grid %u lds %zu (tables %zu, tile %d + %d) rows/tile %d units %d chain %d wide %d brefs %d roomy %d growth %d rb %d\n", grid, lds1, tbl_lds + gt_bytes, cap, cap_out,
+                  tc.R, (int)units, chain_form ? (chain_global ? 2 : 1) : 0, (int)wide_stream, (int)brefs, (int)roomy, (int)growth, rb);
 #if defined(CS_PHASE_PROF)
         Buf tracebuf;
         const long long ntrace = (nsub1 >> 10) + 1;

@@ -572,26 +572,36 @@ std::vector<int32_t> build_tdfa(const Program& prog, const std::vector<int32_t>&
     }
     img[31] = word;
     // The CHAIN form (regex_tdfa.h: chain_match), offered beside the unit decomposition: the program is a straight line
-    // of single-character items -- a literal or a class, taken once or in a greedy `+` loop, brackets ignored -- every
-    // item's ASCII members are exactly the candidate ranges (class R) or exactly the byte x, neighbours differ, the first
-    // is R, and the last is repeated when it is R as well.  Then a plain-ASCII row's matches follow from its two
-    // per-byte masks by integer arithmetic alone.
+    // of single-character items -- a literal or a class, taken once, in a greedy `+` loop or a counted number of times
+    // (`{m,n}`: the compiler's m copies and n - m nested optional ones, regex_compile.cpp: expand_counted), brackets
+    // ignored -- every item's ASCII members are exactly the candidate ranges (class R) or exactly the byte x, neighbours
+    // differ, the first is R, and the last is repeated when it is R as well.  Then a plain-ASCII row's matches follow from
+    // its two per-byte masks by integer arithmetic alone.
     // A chain may end in a SUFFIX of up to four literal ASCII bytes outside R (`\d+\.\d+\.\d+\.\d+ `): the chain part's
     // ends are then filtered by a byte compare (chain_suffix_filter).  Such a pattern usually has no unit decomposition
     // (two non-killer bytes outside the ranges); x is then the first literal of the line that is not in R, and header word
     // 31 carries it WITHOUT bit 0 (the kernels stage the "equals x" bitmap from it; the unit route stays off).
-    if (nskip > 0 && maxslots <= 4 && B.min_match_chars() >= 1 && !B.use_word && !B.use_line && !cs::cfg("CS_NO_CHAIN")) {
+    // A `\b` may open the line and close it ([30] bits 24 / 25) when the class beside it holds letters and digits only: the
+    // boundary is then "the byte on the other side is no word character", a byte test per match (chain_match).
+    if (nskip > 0 && maxslots <= 4 && B.min_match_chars() >= 1 && !B.use_line && !cs::cfg("CS_NO_CHAIN")) {
       int x = (word >> 8) & 127;
       const bool x_free = !(word & 1) && !cs::cfg("CS_NO_CHAIN_SUFFIX");  // (no unit decomposition: the chain picks its own x)
+      const bool counted_ok = !cs::cfg("CS_NO_CHAIN_COUNTED");  // (off: `{m,n}` items and `\b` keep the pattern off the chain form)
       uint32_t items = 0;
+      unsigned long long crep = 0;
       int ni = 0;
       size_t seen = 0;
-      bool ok = true;
+      bool ok = true, lead_b = false, trail_b = false;
       int pc = prog.start_inst, prev_cls = -1;
       int g_lo[5] = {-1, -1, -1, -1, -1}, g_hi[5] = {-1, -1, -1, -1, -1};  // capture groups 1..4: the items they span
       bool groups_ok = true;
       uint32_t sfx = 0;
       int slen = 0;
+      auto inst_at = [&](int at) -> const Inst* { return at >= 0 && (size_t)at < prog.insts.size() ? &prog.insts[(size_t)at] : nullptr; };
+      auto same_atom = [](const Inst& a, const Inst& b) { return a.type == b.type && a.u1 == b.u1 && (a.type == OP_CHAR || a.type == OP_CCLASS); };
+      auto word_byte = [](int c) { return (c >= '0' && c <= '9') || (c >= 'a' && c <= 'z') || (c >= 'A' && c <= 'Z'); };
+      bool r_is_word = true;  // every byte of R a letter or a digit?
+      for (int c = 1; c < 128; ++c) r_is_word = r_is_word && (!in_ranges(c) || word_byte(c));
       while (ok) {
         if (pc < 0 || (size_t)pc >= prog.insts.size() || seen > prog.insts.size()) {
           ok = false;
@@ -607,7 +617,12 @@ std::vector<int32_t> build_tdfa(const Program& prog, const std::vector<int32_t>&
           pc = in.u2;
           continue;
         }
-        if (in.type != OP_CHAR && in.type != OP_CCLASS) {
+        if (in.type == OP_BOW && counted_ok && !trail_b && slen == 0 && (ni > 0 || !lead_b)) {
+          (ni == 0 ? lead_b : trail_b) = true;
+          pc = in.u2;
+          continue;
+        }
+        if ((in.type != OP_CHAR && in.type != OP_CCLASS) || trail_b) {  // (behind the closing `\b`: brackets and the end only)
           ok = false;
           break;
         }
@@ -642,28 +657,72 @@ std::vector<int32_t> build_tdfa(const Program& prog, const std::vector<int32_t>&
           ok = false;
           break;
         }
-        bool plus = false;
-        int next = in.u2;
-        if (next >= 0 && (size_t)next < prog.insts.size() && prog.insts[(size_t)next].type == OP_OR && prog.insts[(size_t)next].u1 == pc) {
-          plus = true;  // (the preferred branch of the OR goes back to the item: a greedy loop)
+        // how often: copies of the item in a row, then a loop back to the last one (`+`, `{m,}`) or nested optional copies
+        int least = 1, most = 1, last = pc, next = in.u2;
+        while (counted_ok) {
+          const Inst* nx = inst_at(next);
+          if (!nx || !same_atom(*nx, in) || least == 15) break;
+          ++least;
           ++seen;
-          next = prog.insts[(size_t)next].u2;
+          last = next;
+          next = nx->u2;
         }
-        items |= (uint32_t)(cls | (plus ? 2 : 0)) << (2 * ni);
+        most = least;
+        if (const Inst* o = inst_at(next); o && o->type == OP_OR && o->u1 == last) {
+          most = 0;  // (the preferred branch of the OR goes back to the item: a greedy loop)
+          ++seen;
+          next = o->u2;
+        } else if (o && o->type == OP_OR && counted_ok && inst_at(o->u1) && same_atom(*inst_at(o->u1), in)) {
+          // OR(copy -> OR(copy -> ... -> exit, exit), exit): every copy optional, each only behind the one before
+          const int exit = o->u2;
+          const Inst* cur = o;
+          while (ok) {
+            const Inst* copy = inst_at(cur->u1);
+            if (!copy || !same_atom(*copy, in) || cur->u2 != exit || most == 15) {
+              ok = false;
+              break;
+            }
+            ++most;
+            seen += 2;
+            if (copy->u2 == exit) break;
+            cur = inst_at(copy->u2);
+            if (!cur || cur->type != OP_OR) ok = false;
+          }
+          if (!ok) break;
+          next = exit;
+        }
+        items |= (uint32_t)(cls | (most == 0 ? 2 : 0)) << (2 * ni);
+        crep |= (unsigned long long)(uint32_t)(least | (most << 4)) << (8 * ni);
         ++ni;
         prev_cls = cls;
         pc = next;
       }
       // (every instruction on the line: an alternation or an optional part would leave some unvisited)
       ok = ok && ni > 0 && seen == prog.insts.size();
-      if (ok && (items >> (2 * (ni - 1)) & 1u) == 0 && !((items >> (2 * (ni - 1) + 1)) & 1u)) ok = false;  // R ... R: the tail repeated
+      if (ok) {
+        const uint32_t first = (uint32_t)(crep & 255u), tail = (uint32_t)(crep >> (8 * (ni - 1))) & 255u;
+        const bool tail_r = ((items >> (2 * (ni - 1))) & 1u) == 0;
+        // R ... R: the tail takes its whole run (the scan resumes behind a match, and never inside a first run)
+        if (tail_r && (tail >> 4) == 1 && !trail_b) ok = false;
+        // a bounded run in front can be entered in its middle unless a `\b` pins the start; one at the end must be followed
+        // by something its class does not hold
+        if ((first >> 4) > 1 && !lead_b) ok = false;
+        if ((tail >> 4) > 1 && !trail_b && slen == 0) ok = false;
+        // `\b` beside a class of word characters only (and the closing one not behind a suffix)
+        if (lead_b && !r_is_word) ok = false;
+        if (trail_b && (slen > 0 || !(tail_r ? r_is_word : word_byte(x)))) ok = false;
+      }
       // (without a unit decomposition the chain is only worth offering when it brought a suffix or its own x: a plain
       // chain of a pattern whose decomposition failed for another reason stays where it was)
       if (ok && !(word & 1) && slen == 0 && ((word >> 8) & 127) == x) ok = false;
       if (ok) {
         img[29] |= (int32_t)(items << 16);
-        img[30] |= (int32_t)((uint32_t)ni << 16);
+        img[30] |= (int32_t)((uint32_t)ni << 16) | (lead_b ? 1 << 24 : 0) | (trail_b ? 1 << 25 : 0);
         if (!(word & 1) && x != ((word >> 8) & 127)) img[31] = word | (x << 8);
+        // the image's tail: the repetition counts (two words), then the suffix, then the group map (make_view reads them back
+        // from the end)
+        img.push_back((int32_t)(uint32_t)crep);
+        img.push_back((int32_t)(uint32_t)(crep >> 32));
         if (slen > 0) {
           img[30] |= (int32_t)((uint32_t)slen << 21);
           img.push_back((int32_t)sfx);

@@ -31,7 +31,9 @@
 //        two bits each (bit 0: the item's class is the byte x instead of the candidate ranges, bit 1: repeated, `+`), and
 //        their number (0 = the pattern is no chain); [30] bits 21..23: the chain is followed by that many literal bytes (the
 //        SUFFIX, none of them in the candidate ranges; the word in front of the image's last one -- or the last one when no
-//        group map follows -- holds them, first byte lowest): `(\d+)\.(\d+)\.\d+\.(\d+) `
+//        group map follows -- holds them, first byte lowest): `(\d+)\.(\d+)\.\d+\.(\d+) `; [30] bits 24 / 25: a `\b` in front of
+//        the chain / behind it.  Two words in front of those tail words: how often each item is taken, a byte per item (low
+//        nibble the least, high nibble the most repetitions, 0 = unbounded): `\b\d{1,3}\.\d{1,3}\.\d{1,3}\.\d{1,3}\b`
 //   INIT   : 3 modes x 8 categories state ids
 //   T1     : nstates x 128 entries (ASCII byte -> transition; byte 0 = embedded NUL)
 //   T2     : nstates x natoms entries (atom 0 = end of row, 1 = embedded NUL,
@@ -126,17 +128,25 @@ CS_HD U128 unit_ends(U128 C, U128 X, bool required, U128& N) {
 CS_HD int unit_start(U128 N, int q) { return u128_msb(u128_andn(u128_below(q), N)) + 1; }
 
 // ---- chain patterns: every match of a row by bit arithmetic on two per-byte masks, no automaton ----
-// A CHAIN is a sequence of up to eight items, each one byte class taken once or repeated (`+`, greedy), where the class is
-// either R (exactly the ASCII bytes of the two candidate ranges) or the single byte x, neighbours differ, and the last item
-// is repeated when its class is the first one's: `\d+\.\d+\.\d+\.\d+`, `[a-z]+=`, `\d+`.  On a row of plain ASCII such a
+// A CHAIN is a sequence of up to eight items, each one byte class taken a counted number of times -- once, `+` (greedy), or
+// `{m,n}` / `{m,}` / `{m}` with n <= 15 (crep: a byte per item, low nibble the least and high nibble the most repetitions, 0 =
+// unbounded) -- where the class is either R (exactly the ASCII bytes of the two candidate ranges) or the single byte x,
+// neighbours differ, and the last item is repeated when its class is the first one's: `\d+\.\d+\.\d+\.\d+`, `[a-z]+=`,
+// `\d+`.  A `\b` may stand in front of the chain and behind it when the class next to it holds letters and digits only
+// (chain bits 24 / 25): `\b\d{1,3}\.\d{1,3}\.\d{1,3}\.\d{1,3}\b`.  On a row of plain ASCII such a
 // pattern is deterministic: from a given start there is at most ONE match (a repeated item must take its whole run, the
-// next item's class being disjoint), a match exists from the middle of the first run iff it exists from the run's start, and
-// a later start ends later.  So (Parabix-style marker arithmetic, one marker set for ALL starts of the row at once):
-//   forward   M = run starts of R (every R byte when the first item is single); per item M = (M & C) << 1, and for a
-//             repeated one M = MatchStar(M, C) = (((M & C) + C) ^ C) | M; the ends are what is left (off C for a greedy tail)
+// next item's class being disjoint -- which is also why a bounded item is a run of at most n bytes and nothing subtler; a
+// bounded FIRST item needs the `\b` in front of it, or the match could begin inside the run, and a bounded last one a `\b`
+// or a suffix behind it: regex_tdfa.cpp checks both), a match exists from the middle of the first run only if it exists from
+// the run's start, and a later start ends later.  So (Parabix-style marker arithmetic, one marker set for ALL starts of the
+// row at once):
+//   forward   M = run starts of R (every R byte when the first item is single); per item M = (M & C) << 1 for each
+//             repetition it must have, then for an unbounded one M = MatchStar(M, C) = (((M & C) + C) ^ C) | M, for a bounded
+//             one M |= (M & C) << 1 per optional repetition; the ends are what is left (off C for a repeated tail)
 //   backward  the same walk over the bit-reversed masks from the ends: the starts that do reach an end
 //   pairing   the k-th start belongs to the k-th end; a match that begins inside the previous one is dropped (the scan
-//             of regexec.inl:204-442 resumes at the end of a match -- and that position is never inside a first run).
+//             of regexec.inl:204-442 resumes at the end of a match -- and that position is never inside a first run), and
+//             so is one whose start is no word boundary when the pattern asks for one.
 // R, X: row-relative bits cut at the row length (rows of up to 96 bytes).  S / L receive a bit per match at its first /
 // last byte.  ~300 integer operations a row whatever it holds, against a table walk per candidate byte.
 #if !defined(__HIP_DEVICE_COMPILE__)
@@ -157,45 +167,62 @@ CS_HD unsigned long long u64_bitrev(unsigned long long v) {
 // bit p -> bit 126 - p (p <= 126; its own inverse)
 CS_HD U128 u128_rev127(U128 a) { return u128_shr1(u128(u64_bitrev(a.hi), u64_bitrev(a.lo))); }
 CS_HD U128 chain_star(U128 M, U128 C) { return u128_or(u128_xor(u128_add(u128_and(M, C), C), C), M); }
-// the last byte of every match of the row, whatever its start (contains_re needs no more than "any")
-CS_HD U128 chain_ends(U128 R, U128 X, uint32_t chain) {
+constexpr uint32_t kChainLeadB = 1u << 24, kChainTrailB = 1u << 25;  // `\b` in front of the chain / behind it
+// the bytes `\b` counts as word characters on a plain-ASCII row (regexec.inl:290-299: alphanumeric; '_' is none)
+CS_HD bool chain_word_byte(uint32_t c) { return c - 48u < 10u || (c | 32u) - 97u < 26u; }
+CS_HD uint32_t chain_rep(unsigned long long crep, int k) { return (uint32_t)(crep >> (8 * k)) & 255u; }
+// is item k a run (it takes every byte of its class that is there), as against a single byte?
+CS_HD bool chain_runs(unsigned long long crep, int k) { return (chain_rep(crep, k) >> 4) != 1u; }
+// the markers behind one item: M in front of it, C its class
+CS_HD U128 chain_item(U128 M, U128 C, uint32_t rep) {
+  const int least = (int)(rep & 15u), most = (int)(rep >> 4);
+  for (int i = 0; i < least; ++i) M = u128_shl1(u128_and(M, C));
+  if (most == 0) return chain_star(M, C);
+  U128 T = M;
+  for (int i = least; i < most; ++i) {
+    T = u128_shl1(u128_and(T, C));
+    M = u128_or(M, T);
+  }
+  return M;
+}
+// the last byte of every match of the row, whatever its start (a `\b` in front of the chain is NOT looked at: chain_match)
+CS_HD U128 chain_ends(U128 R, U128 X, uint32_t chain, unsigned long long crep) {
   const int ni = (int)((chain >> 16) & 15u);
   auto is_x = [&](int k) { return ((chain >> (2 * k)) & 1u) != 0; };
-  auto plus = [&](int k) { return ((chain >> (2 * k + 1)) & 1u) != 0; };
-  U128 M = plus(0) ? u128_andn(R, u128_shl1(R)) : R;
+  U128 M = chain_runs(crep, 0) ? u128_andn(R, u128_shl1(R)) : R;
   U128 C = R;
   for (int k = 0; k < ni; ++k) {
     C = is_x(k) ? X : R;
-    M = u128_shl1(u128_and(M, C));
-    if (plus(k)) M = chain_star(M, C);
+    M = chain_item(M, C, chain_rep(crep, k));
   }
-  if (plus(ni - 1)) M = u128_andn(M, C);
+  if (chain_runs(crep, ni - 1)) M = u128_andn(M, C);
   return u128_shr1(M);
 }
 // The chain's SUFFIX: literal bytes behind the last item (none in R, so a repeated last item still takes its whole run and
-// a start has one match or none).  Of the ends of the chain part only those stay that the suffix follows; byte_at(i) is
-// byte i of the row (n bytes).
+// a start has one match or none), or a `\b` there.  Of the ends of the chain part only those stay that the suffix follows;
+// byte_at(i) is byte i of the row (n bytes).
 template <class ByteAt>
 CS_HD U128 chain_suffix_filter(U128 Le, uint32_t chain, uint32_t sfx, int n, ByteAt&& byte_at) {
   const int sl = (int)((chain >> 20) & 7u);
-  if (!sl) return Le;
+  const bool wb = (chain & kChainTrailB) != 0;
+  if (!sl && !wb) return Le;
   U128 T = Le;
   while (u128_any(T)) {
     const int l = u128_ctz(T);
     const U128 rest = u128_clear_lowest(T);
     bool ok = l + 1 + sl <= n;
     for (int k = 0; k < sl && ok; ++k) ok = (uint32_t)byte_at(l + 1 + k) == ((sfx >> (8 * k)) & 255u);
+    if (wb && l + 1 < n) ok = !chain_word_byte((uint32_t)byte_at(l + 1));  // (the last byte is a word character: regex_tdfa.cpp)
     if (!ok) Le = u128_andn(Le, u128_andn(T, rest));
     T = rest;
   }
   return Le;
 }
 template <class ByteAt>
-CS_HD void chain_match(U128 R, U128 X, uint32_t chain, U128& S, U128& L, uint32_t sfx, int n, ByteAt&& byte_at) {
+CS_HD void chain_match(U128 R, U128 X, uint32_t chain, unsigned long long crep, U128& S, U128& L, uint32_t sfx, int n, ByteAt&& byte_at) {
   const int ni = (int)((chain >> 16) & 15u);
   auto is_x = [&](int k) { return ((chain >> (2 * k)) & 1u) != 0; };
-  auto plus = [&](int k) { return ((chain >> (2 * k + 1)) & 1u) != 0; };
-  U128 Le = chain_suffix_filter(chain_ends(R, X, chain), chain, sfx, n, byte_at);
+  U128 Le = chain_suffix_filter(chain_ends(R, X, chain, crep), chain, sfx, n, byte_at);
   S = u128(0, 0);
   L = u128(0, 0);
   if (!u128_any(Le)) return;
@@ -205,23 +232,24 @@ CS_HD void chain_match(U128 R, U128 X, uint32_t chain, U128& S, U128& L, uint32_
   M = u128_rev127(Le);
   for (int k = ni - 1; k >= 0; --k) {
     C = is_x(k) ? Xr : Rr;
-    M = u128_shl1(u128_and(M, C));
-    if (plus(k)) M = chain_star(M, C);
+    M = chain_item(M, C, chain_rep(crep, k));
   }
-  if (plus(0)) M = u128_andn(M, C);
+  if (chain_runs(crep, 0)) M = u128_andn(M, C);
   U128 Sv = u128_rev127(u128_shr1(M));  // the starts that reach an end, as many as there are ends
   {
     // (the match's last byte is the suffix's: rows end within 96 bytes, the shift loses nothing)
     const int sl = (int)((chain >> 20) & 7u);
     if (sl) Le = u128(Le.lo << sl, (Le.hi << sl) | (Le.lo >> (64 - sl)));
   }
+  const bool wb = (chain & kChainLeadB) != 0;
   int cursor = 0;
   while (u128_any(Sv) && u128_any(Le)) {
     const int s = u128_ctz(Sv), l = u128_ctz(Le);
     const U128 sb = u128_andn(Sv, u128_clear_lowest(Sv)), lb = u128_andn(Le, u128_clear_lowest(Le));
     Sv = u128_clear_lowest(Sv);
     Le = u128_clear_lowest(Le);
-    if (s >= cursor) {
+    // (`\b` in front: the first byte is a word character, so the one before it must be none)
+    if (s >= cursor && !(wb && s > 0 && chain_word_byte((uint32_t)byte_at(s - 1)))) {
       S = u128_or(S, sb);
       L = u128_or(L, lb);
       cursor = l + 1;
@@ -233,7 +261,7 @@ CS_HD void chain_match(U128 R, U128 X, uint32_t chain, U128& S, U128& L, uint32_
 // item, high nibble the item behind its last): every group is a run of items, so its range follows from the item
 // boundaries of the match that starts at mb -- a walk over the row's two masks, no automaton.  gb / ge: -1 for a group
 // the map does not name.
-CS_HD void chain_group_bounds(U128 R, U128 X, uint32_t chain, uint32_t gmap, int mb, int gb[4], int ge[4]) {
+CS_HD void chain_group_bounds(U128 R, U128 X, uint32_t chain, unsigned long long crep, uint32_t gmap, int mb, int gb[4], int ge[4]) {
   const int ni = (int)((chain >> 16) & 15u);
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
@@ -254,7 +282,7 @@ CS_HD void chain_group_bounds(U128 R, U128 X, uint32_t chain, uint32_t gmap, int
       }
     }
     if (k < ni && k < 8) {
-      if ((chain >> (2 * k + 1)) & 1u) {
+      if (chain_runs(crep, k)) {
         const U128 C = ((chain >> (2 * k)) & 1u) ? X : R;
         p = u128_ctz(u128_andn(u128(~C.lo, ~C.hi), u128_below(p)));  // the first byte at or behind p off the class
       } else {
@@ -279,7 +307,8 @@ struct View {
   uint32_t r1lo, r1hi, r2lo, r2hi;  // SWAR constants of the two candidate ranges
   uint32_t skippack, cand0, cand1, cand2, cand3, word0, word1, word2, word3;
   uint32_t units;  // header word 31
-  uint32_t chain;  // bits 0..15 the items, bits 16..19 their number (header words 29 / 30, upper halves), bits 20..22 suffix bytes
+  uint32_t chain;  // bits 0..15 the items, bits 16..19 their number (header words 29 / 30, upper halves), bits 20..22 suffix bytes, 24 / 25 `\\b` in front / behind
+  unsigned long long crep;  // the items' repetition counts (chain_item), a byte each
   uint32_t sfx;    // the suffix bytes
 };
 CS_HD View make_view(const int32_t* img) {
@@ -311,7 +340,13 @@ CS_HD View make_view(const int32_t* img) {
   v.word3 = (uint32_t)img[28];
   v.units = (uint32_t)img[31];
   v.chain = (((uint32_t)img[29] >> 16) & 0xFFFFu) | ((((uint32_t)img[30] >> 16) & 15u) << 16) | ((((uint32_t)img[30] >> 21) & 7u) << 20);
+  v.chain |= (((uint32_t)img[30] >> 24) & 3u) << 24;
   v.sfx = ((uint32_t)img[30] >> 21) & 7u ? (uint32_t)img[img[15] - 1 - (int)(((uint32_t)img[30] >> 20) & 1u)] : 0u;
+  v.crep = 0;
+  if (v.chain >> 16) {  // the two words in front of the suffix / group-map words at the image's end
+    const int at = img[15] - 2 - (int)(((uint32_t)img[30] >> 20) & 1u) - ((((uint32_t)img[30] >> 21) & 7u) ? 1 : 0);
+    v.crep = (unsigned long long)(uint32_t)img[at] | ((unsigned long long)(uint32_t)img[at + 1] << 32);
+  }
   {
     const uint32_t lo1 = (uint32_t)img[29] & 255u, hi1 = ((uint32_t)img[29] >> 8) & 255u;
     const uint32_t lo2 = (uint32_t)img[30] & 255u, hi2 = ((uint32_t)img[30] >> 8) & 255u;
@@ -1329,7 +1364,7 @@ inline bool row_chain_host(cstd::Tdfa& vm, cstd::U128& S, cstd::U128& L) {
       if (i < 64) X.lo |= 1ull << i;
       else X.hi |= 1ull << (i - 64);
     }
-  cstd::chain_match(cstd::u128(c0 | ((unsigned long long)c1 << 32), c2), X, vm.D.chain, S, L, vm.D.sfx, vm.n, [&](int i) { return vm.s[i]; });
+  cstd::chain_match(cstd::u128(c0 | ((unsigned long long)c1 << 32), c2), X, vm.D.chain, vm.D.crep, S, L, vm.D.sfx, vm.n, [&](int i) { return vm.s[i]; });
   return true;
 }
 #endif
@@ -1456,7 +1491,7 @@ CS_HD void row_replace_matches(cstd::Tdfa& vm, int maxrepl, Emit&& emit) {
         if (i < 64) X.lo |= 1ull << i;
         else X.hi |= 1ull << (i - 64);
       }
-    cstd::chain_match(R, X, vm.D.chain, S, L, vm.D.sfx, vm.n, [&](int i) { return vm.s[i]; });
+    cstd::chain_match(R, X, vm.D.chain, vm.D.crep, S, L, vm.D.sfx, vm.n, [&](int i) { return vm.s[i]; });
     while (cstd::u128_any(S)) {
       emit(cstd::u128_ctz(S), cstd::u128_ctz(L) + 1, 1);
       S = cstd::u128_clear_lowest(S);

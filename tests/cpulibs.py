@@ -506,6 +506,7 @@ class RowEmu(CpuLib):
         self._f("regex_units", C.c_int, [vp])
         self._f("regex_chain", C.c_int, [vp])
         self._f("regex_chain_sfx", C.c_int, [vp])
+        self._f("regex_chain_rep", C.c_uint64, [vp])
         self._f("set_chain", None, [C.c_int])
         self._f("set_bits", None, [C.c_int])
         self._f("regex_bits_info", None, [vp, C.POINTER(C.c_int)])
@@ -522,18 +523,31 @@ class RowEmu(CpuLib):
         return bool(w & 1), (chr((w >> 8) & 127) if (w >> 8) & 127 else None), bool((w >> 16) & 1)
 
     def chain(self, pattern):
-        """The chain form (regex_tdfa.h: chain_match) as a string of items, 'R' / 'x' with '+' when repeated, then '|' and the
-        literal suffix when the chain has one -- or None"""
+        """The chain form (regex_tdfa.h: chain_match) as a string of items, 'R' / 'x' with '+' when repeated or '{m,n}' when
+        counted, '\\b' in front / behind when the chain has one, then '|' and the literal suffix when the chain has one -- or None"""
         re = self.compile(pattern)
         w = self._regex_chain(re)
         sfx = self._regex_chain_sfx(re) & 0xFFFFFFFF
+        rep = self._regex_chain_rep(re)
         self._regex_free(re)
         n = (w >> 16) & 15
-        items = "".join(("x" if (w >> (2 * k)) & 1 else "R") + ("+" if (w >> (2 * k + 1)) & 1 else "") for k in range(n))
+        if not n:
+            return None
+
+        def count(k):
+            least, most = (rep >> (8 * k)) & 15, (rep >> (8 * k + 4)) & 15
+            if (least, most) == (1, 1):
+                return ""
+            if (least, most) == (1, 0):
+                return "+"
+            return "{%d,%s}" % (least, most or "") if least != most else "{%d}" % least
+
+        items = "".join(("x" if (w >> (2 * k)) & 1 else "R") + count(k) for k in range(n))
+        items = ("\\b" if (w >> 24) & 1 else "") + items + ("\\b" if (w >> 25) & 1 else "")
         sl = (w >> 20) & 7
-        if items and sl:
+        if sl:
             items += "|" + "".join(chr((sfx >> (8 * k)) & 255) for k in range(sl))
-        return items or None
+        return items
 
     def bits(self, pattern):
         """The bit-parallel form (regex_bits.h) of a pattern: (classes, alternatives, flags) or None when it does not convert"""

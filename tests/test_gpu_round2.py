@@ -244,7 +244,10 @@ def test_gpu_replace_re_unit_scan_edges(gpu_engine, oracle_engine, pat):
 
 CHAIN_PATS = [r"\d+\.\d+\.\d+\.\d+", r"[0-9]+\.[0-9]+\.[0-9]+\.[0-9]+", r"\d+", r"(\d+)\.(\d+)", r"[a-c]+@[a-c]+", r"\d\.\d+", r"\d+-+\d+", r"[a-cx-z]+_", r"a+b",
               # a literal suffix behind the chain (regex_tdfa.cpp: no unit decomposition, the chain brings its own x)
-              r"\d+\.\d+\.\d+\.\d+ ", r"(\d+)\.(\d+)\.\d+\.(\d+) ", r"\d+\.\d+ -", r"[a-c]+@x", r"\d+-\."]
+              r"\d+\.\d+\.\d+\.\d+ ", r"(\d+)\.(\d+)\.\d+\.(\d+) ", r"\d+\.\d+ -", r"[a-c]+@x", r"\d+-\.",
+              # counted items, a `\b` at either end (round 5: the 26-instruction dotted quad of the ops table)
+              r"\b\d{1,3}\.\d{1,3}\.\d{1,3}\.\d{1,3}\b", r"\b(\d{1,3})\.(\d{1,3})\b", r"\b(\d+)\.(\d+)\b", r"\d\d+\.\d+", r"(\d+)\.(\d{2})\.(\d+)", r"\d+\.\d\b",
+              r"\d+\.{1,2}\d+", r"\b[a-c]{2,3}@", r"\d+\.(\d{1,2})x", r"\b\d{2}-\d{2}\b"]
 
 
 @pytest.mark.gpu
@@ -259,7 +262,9 @@ def test_gpu_chain_patterns(gpu_engine, oracle_engine, pat):
     junk = lambda k: "".join(rnd.choice("abcxyz@-_. 0123456789") for _ in range(rnd.randrange(0, k)))
     s = [junk(90) for _ in range(640)]
     s += ["1.2.3.4.5.6.7.8", "1.2.3.4 5.6.7.8", ".1.2.3.4.", "1..2.3.4", "999.999.999.999x1.1.1.1", "1.2.3.", "12", "", None, "0.0.0.0" * 13,
-          "9" * 93, "1." * 46, ".1" * 46, "a@b@c@@", "ab@cb@ca", "1--2-3", "12.3456", "a_b_cx_", "aab ab b a"] * 3
+          "9" * 93, "1." * 46, ".1" * 46, "a@b@c@@", "ab@cb@ca", "1--2-3", "12.3456", "a_b_cx_", "aab ab b a",
+          "a1.2.3.4", "1.2.3.4a", "a1.2.3.4.5", "1.2.3.4.5a", "1234.5.6.7", "1.2345.6.7", "1.2.3.4567", "123.123.123.123", "1.2.3.4_5.6.7.8", "_1.2.3.4_",
+          "12-34-56", "12-34 123-45 12-345 x12-34", "1..2 1...234 1.2x 1.23x 1.234x", "ab@ abc@ abcd@ xab@ a@", "1.2" + "9" * 90, "1.2.3.4b 1.2.3.4"] * 3
     s += [ip() + " " + junk(40) + " " + ip() for _ in range(300)]
     s += [junk(60) for _ in range(64)] + ["é " + ip()] + [ip() for _ in range(63)]     # a sub-tile with a non-ASCII row
     s += [ip() + "x" * 120 + ip()] + [ip() for _ in range(63)]                        # a row beyond the masks

@@ -279,7 +279,14 @@ def test_chain_patterns_vs_oracle(emu_engine, oracle_engine):
             r"[a-c]+=": "R+x", r"\d\.\d+": "RxR+", r"[a-z]+@[a-z]+": "R+xR+", r"\d+-+\d+": "R+x+R+", r"[a-cx-z]+_": "R+x",
             r"\w+\.\w+": "R+xR+" if False else None,  # (three ranges and '_': the candidate ranges are a superset)
             r"\d+\.\d": None, r"\d\d": None, r"\d+\.?\d+": None, r"\d*\.": None, r"\.\d+": None, r"a|b": None, r"\d+?\.": None,
-            r"\b\d+": None, r"[^a]+b": None, r"\d+\.[0-5]+": None, r"é+a": None, r"\d+\.\d+\.\d+\.\d+\.\d+\.": None,
+            r"[^a]+b": None,
+            # counted items and a `\b` at either end (a bounded first item needs the `\b`, a bounded last one a `\b` or a suffix)
+            r"\b\d+": "\\bR+", r"\b\d{1,3}\.\d{1,3}\.\d{1,3}\.\d{1,3}\b": "\\bR{1,3}xR{1,3}xR{1,3}xR{1,3}\\b", r"\b\d+\.\d+\b": "\\bR+xR+\\b",
+            r"\b(\d{1,3})\.(\d{1,3})\b": "\\bR{1,3}xR{1,3}\\b", r"\d\d+\.\d+": "R{2,}xR+", r"\d+\.\d{2}\.\d+": "R+xR{2}xR+", r"\d+\.\d\b": "R+xR\\b",
+            r"\d+\.\d{2,}": "R+xR{2,}", r"\b\d{2}-\d{2}-\d{2}\b": "\\bR{2}xR{2}xR{2}\\b", r"\b\d{4}-\d{2}\b": "\\bR{4}xR{2}\\b", r"\d+\.{1,2}\d+": "R+x{1,2}R+",
+            r"\d+\.\d{1,2}x": "R+xR{1,2}|x", r"\b[a-c]{2,3}=": "\\bR{2,3}x", r"\d+\.{2,}\d{3,}\b": "R+x{2,}R{3,}\\b", r"\b\d\.\d\b": "\\bRxR\\b",
+            r"\d{1,3}\.\d{1,3}": None, r"\d{2,3}x": None, r"\d+\.\d{1,2}": None, r"\d+\B": None, r"\d+\b\.\d+": None, r"\b\.\d+": None, r"\d+\.\b": None,
+            r"\d{0,2}\.\d+": None, r"\d{4}-\d{2}": None, r"\d+ \b": None, r"\d+\.[0-5]+": None, r"é+a": None, r"\d+\.\d+\.\d+\.\d+\.\d+\.": None,
             # a literal suffix behind the chain (no unit decomposition: the chain brings its own x)
             r"\d+\.\d+\.\d+\.\d+ ": "R+xR+xR+xR+| ", r"(\d+)\.(\d+)\.\d+\.(\d+) ": "R+xR+xR+xR+| ", r"\d+\.\d+ -": "R+xR+| -", r"[a-c]+=>": "R+x|>",
             r"\d+ab": "R+x|b", r"\d+\.\d+:x=\.": "R+xR+|:x=.", r"\d+\.\d+abcde": None, r"\d+\.\d+ 1": None, r"\d+\.\d+ \d": None, r"\d+-\.": "R+x|."}
@@ -290,7 +297,11 @@ def test_chain_patterns_vs_oracle(emu_engine, oracle_engine):
         ["1.2.3.4", "1.2.3.4.5.6.7.8", "1.2.3.4 5.6.7.8", ".1.2.3.4.", "1..2.3.4", "999.999.999.999x1.1.1.1", "1.2.3.", "12", "", None,
          "1.2.3.4" + "x" * 82 + "5.6.7.8", "9" * 96, "1." * 48, ".1" * 48, "a=b=c==", "ab@cd@ef", "1--2-3", "12.3456", "0.0.0.0" * 13, "1.1.1.1é2.2.2.2",
          "1.2.3.4 ", "1.2.3.4 5.6.7.8 ", "1.2.3.4  5.6.7.8", "1.2 -3.4 - 5.6 -", "7ab8ab9a", "1.2:x=.3.4:x=", "ab=>c=>=>", "1-.2-.-.", "1.2.3.4 " * 12, "x" * 88 + "1.2.3.4 ",
-         "x" * 89 + "1.2.3.4 ", "1.2.3.4" + " " * 89, "5.6 - 7.8 -9.1 -"]
+         "x" * 89 + "1.2.3.4 ", "1.2.3.4" + " " * 89, "5.6 - 7.8 -9.1 -",
+         # word boundaries and run-length bounds: a letter either side, four digits in any octet, candidates that overlap
+         "a1.2.3.4", "1.2.3.4a", "a1.2.3.4.5", "1.2.3.4.5a", "1234.5.6.7", "1.2345.6.7", "1.2.3.4567", "123.123.123.123", "1.2.3.4_5.6.7.8", "_1.2.3.4_",
+         "1.2.3.4.5.6.7.8.9.10.11.12", "12-34-56", "12-34-567", "012-34-56", "12-34-56-78-90-12", "1999-12 1999-123 x1999-12", "1..2 1...234 1.2x 1.23x 1.234x",
+         "ab= abc= abcd= xab= a=", "1.2 3.4", "1.2" + "9" * 93, "9" * 92 + ".1.2", "7.7.7.7" + "." * 89, "1.2.3.4b 1.2.3.4", "0.0.0.0.0.0.0.0a"]
     for pat in [p for p, f in want.items() if f]:
         for on in (1, 0):
             e.set_chain(on)
@@ -304,18 +315,22 @@ def test_chain_patterns_vs_oracle(emu_engine, oracle_engine):
             finally:
                 e.set_chain(1)
     # generated chains over digits / '.', and over letters / '-'
-    for _ in range(120):
+    generated = 0
+    for _ in range(400):
         a, x = rnd.choice([("\\d", "\\."), ("[a-c]", "-"), ("[0-9a-b]", "@")])
         items, prev = [], None
         for k in range(rnd.randint(1, 8)):
             cls = a if (k == 0 or prev == x) else x
-            items.append(cls + rnd.choice(["", "+", "+"]))
+            items.append(cls + rnd.choice(["", "+", "+", "{1,3}", "{2}", "{2,}", "{1,2}"]))
             prev = cls
-        pat = "".join(items) + rnd.choice(["", "", " ", "=", "_ ", "@", " -"])
+        pat = rnd.choice(["", "\\b"]) + "".join(items) + rnd.choice(["", "", " ", "=", "_ ", "@", " -", "\\b", "\\b"])
         if e.chain(pat) is None:
             continue
+        generated += 1
         assert emu_engine.replace_re(s, pat, "<>", -1) == oracle_engine.replace_re(s, pat, "<>", -1), pat
         assert emu_engine.findall(s, pat) == oracle_engine.findall(s, pat), pat
+        assert emu_engine.contains_re(s, pat) == oracle_engine.contains_re(s, pat), pat
+    assert generated > 100, generated
 
 
 GROUP_PATTERNS = [r"(\w+) (\w+)", r"(a|ab)(c|bcd)", r"(a|b)*c", r"((a)|(b))+", r"(\d+)\.(\d+)\.(\d+)\.(\d+)", r"(a*)(b*)", r"(a+?)(a*)",
