@@ -55,6 +55,7 @@ thread_local int g_replace_literal_len = 0;
 // nullptr: plain replace_re
 thread_local const void* g_backrefs_dev = nullptr;
 thread_local int g_backrefs_text_bytes = 0;
+thread_local const void* g_backrefs_host = nullptr;  // the same template, host copy (sizing: how much a match can grow)
 }
 
 namespace {
@@ -1221,7 +1222,7 @@ __device__ __forceinline__ void bits_classify16(const uint32_t* spread, const ui
 // the code costs the others registers).
 template <bool IN_LDS, bool REP16, bool INPLACE, bool RESCAN = false, bool LONG = false, bool UNITS = false, int PF = cstile::kPfChunks, bool BREFS = false,
           bool WIDE = false, bool OUTL = false, bool CHAIN = false, bool BITS = false>
-__global__ void __launch_bounds__(256, (BREFS || BITS) ? 2 : CS_STREAM_WAVES) k_tdfa_replace_stream(StreamArgs a) {
+__global__ void __launch_bounds__(256, ((BREFS && !CHAIN) || BITS) ? 2 : CS_STREAM_WAVES) k_tdfa_replace_stream(StreamArgs a) {
   // BITS (a CHAIN form): the pattern has a bit-parallel form (regex_bits.h) -- one bitmap per character class, staged by
   // table lookup; the row lanes derive their rows' matches from the class masks (alternations of word-bounded literals,
   // small sets in a `+` loop: patterns whose candidates are everywhere); a sub-tile with a byte >= 0x80 / NUL or a row
@@ -1230,24 +1231,31 @@ __global__ void __launch_bounds__(256, (BREFS || BITS) ? 2 : CS_STREAM_WAVES) k_
   // CHAIN (a UNITS form): the pattern is a chain and a sample of the column holds no byte >= 0x80 -- the unit scan, the
   // literal scan and the lean scans are compiled out (their registers with them); a sub-tile the chain arithmetic does
   // not take (a non-ASCII byte after all, a row beyond the masks) goes to the generic scan row by row.
-  static_assert(!CHAIN || (UNITS && !BREFS), "the chain form is a unit-scan variant");
+  static_assert(!CHAIN || UNITS, "the chain form is a unit-scan variant");
+  // BREFS + CHAIN: replace_with_backrefs on a chain pattern whose groups are runs of items, a sample of the column plain ASCII
+  // -- matches and group ranges by marker arithmetic alone, so no table, no group tags, no unit queue in LDS and none of the
+  // unit / lean / group-run code in the kernel: three workgroups a CU where the backrefs form proper holds two.  A sub-tile
+  // the arithmetic does not take gives the launch up exactly as it does there (error 32: the two-pass form).
+  static_assert(!(BREFS && CHAIN) || (!IN_LDS && !BITS), "the backrefs chain form reads no table");
   static_assert(!OUTL || (IN_LDS && !LONG && !UNITS && !BREFS && !WIDE), "oversize sub-tiles: the plain forms only");
   static_assert(!UNITS || (!INPLACE && RESCAN && !LONG), "the unit scan builds on the register-record assembly");
   static_assert(!WIDE || (!UNITS && IN_LDS && !BREFS), "the wide form: generic scan only");
-  static_assert(!BREFS || (UNITS && IN_LDS && !REP16), "the backrefs form is a unit-scan variant");
+  static_assert(!BREFS || (UNITS && (IN_LDS || CHAIN) && !REP16), "the backrefs form is a unit-scan variant");
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   uint8_t* base = reinterpret_cast<uint8_t*>(smem);
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;  // (scalar: what derives from it stays in SGPRs)
   const int bm_bytes = (a.cap_in >> 3) + 32;  // one candidate bit per staged byte
   // second bitmap, unit queue, bail word (+ BREFS: a record of three words per match, a growth counter per row)
   const int nbm = BITS ? max(a.bits_k, 2) : 2;  // bitmaps per wave (BITS: one per character class)
-  const int unit_bytes = UNITS ? (nbm - 1) * bm_bytes + kUnitQueue * 4 + 16 + (BREFS ? kUnitQueue * 12 + 64 * 4 : 0) : 0;
+  // (BREFS + CHAIN: the second bitmap, the bail word's slot and the match records -- no unit queue, no growth counters)
+  const int unit_bytes = (BREFS && CHAIN) ? bm_bytes + 16 + kUnitQueue * 12
+                                          : UNITS ? (nbm - 1) * bm_bytes + kUnitQueue * 4 + 16 + (BREFS ? kUnitQueue * 12 + 64 * 4 : 0) : 0;
   uint8_t* lds_in = base + a.tbl_bytes + (size_t)wv * (a.cap_in + a.cap_out + 64 + bm_bytes + unit_bytes);
   uint8_t* lds_out = lds_in + a.cap_in + 32;
   uint32_t* bitmap = reinterpret_cast<uint32_t*>(lds_out + a.cap_out + 32);
   uint32_t* xbitmap = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(bitmap) + bm_bytes);  // UNITS: "byte == x", later the matches' last bytes
   uint32_t* uqueue = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(bitmap) + (size_t)nbm * bm_bytes);
-  uint32_t* bailw = uqueue + kUnitQueue;  // one bit per row: the lean scan handed a unit of the row over
+  uint32_t* bailw = uqueue + ((BREFS && CHAIN) ? 0 : kUnitQueue);  // one bit per row: the lean scan handed a unit of the row over
   uint32_t* mrec = bailw + 4;              // BREFS: per match (group ranges of groups 1-2, of groups 3-4, match end | ok << 8)
   uint32_t* rowgrow = mrec + kUnitQueue * 3;  // BREFS: bytes the row's expansions add
   const TCtx c = tsetup<IN_LDS>(a.L, a.flags, smem);  // (block barrier inside when staging)
@@ -1845,7 +1853,7 @@ __global__ void __launch_bounds__(256, (BREFS || BITS) ? 2 : CS_STREAM_WAVES) k_
         redo = false;
       }
       if (hi_units && !units_done) redo = live;  // (more units than the queue holds: the generic scan, never the lean scan on such bytes)
-      if (CHAIN && !units_done) redo = live && a.maxrepl != 0;  // (the generic scan)
+      if (CHAIN && !BREFS && !units_done) redo = live && a.maxrepl != 0;  // (the generic scan)
       if (!CHAIN && UNITS && !BREFS && !units_done && lean && !hi_units && a.maxrepl < 0 && D.img[13] >= 1 && !(CS_DBG(a) & 2048)) {  // (wave-uniform)
         // A sub-tile the unit route did not take (more units than the queue holds: patterns whose candidate bytes are
         // everywhere, such as alternations of word-bounded literals; or no decomposition at all): every row lane scans its
@@ -1904,7 +1912,7 @@ __global__ void __launch_bounds__(256, (BREFS || BITS) ? 2 : CS_STREAM_WAVES) k_
         redo = bail;
         resume = vm.lean_resume_from;
       }
-      if (__builtin_expect(__any(redo), 0)) {
+      if (!(BREFS && CHAIN) && __builtin_expect(__any(redo), 0)) {
         // rows the lean scan handed over continue with the generic scan in the round they stopped in
         // (the matches reported so far are final)
         if (redo) {
@@ -2073,7 +2081,7 @@ __global__ void __launch_bounds__(256, (BREFS || BITS) ? 2 : CS_STREAM_WAVES) k_
               }
               copied = rec_me[j];
             }
-        } else if (__builtin_expect(nm > 0, 0)) {
+        } else if (!(BREFS && CHAIN) && __builtin_expect(nm > 0, 0)) {
           // more matches than the registers keep (UNITS: any row measured by the generic scan): the row's size is
           // known from the first scan, so scan it again and assemble as the matches are reported
           auto piece2 = [&](int mb, int me, int reps) {
@@ -3137,14 +3145,55 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
         // builds on the unit forms' layout and assembly, whether or not the pattern offers a unit decomposition)
         const bool bits_form = !literal && !brefs && !wide_stream && tdfa && maxrepl < 0 && !tc.lng && tc.R == 64 && !outliers && !cs::g_replace_plain_only && tp.d.in_lds &&
                                bits_route(re, col, s, BITS_REPLACE);
+        // replace_with_backrefs on a chain whose groups are runs of items, the sample plain ASCII: the form that keeps neither
+        // tables nor group tags in LDS (k_tdfa_replace_stream<.., BREFS, .., CHAIN>).  Its out tile is sized from the
+        // template: an expansion is the template's literal bytes plus the groups it names, so a match grows by at most
+        //   G = literal bytes + sum over items of (times the item is named - 1) * its length
+        // -- with every item named at most once, G = literal bytes - the least length of the items NOT named, often <= 0
+        // (`\4.\3.\2.\1` on four dotted groups: 3 - 3).  An item named twice and unbounded leaves the old "twice the input".
+        bool bchain = false;
+        int64_t brefs_grow = -1;  // per match; -1: unknown
+        if (brefs && ((re->tdfa[30] >> 16) & 15) != 0 && ((re->tdfa[30] >> 20) & 1) != 0 && cap <= 5 * 1024 && !tc.lng && tc.R == 64 && maxrepl < 0 &&
+            cs::g_backrefs_host && !cs::cfg("CS_NO_BREFS_CHAIN") && !sample_has_high_bytes(col, s)) {
+          const auto* ht = static_cast<const csvm::BackrefTemplate*>(cs::g_backrefs_host);
+          const cstd::View hv = cstd::make_view(re->tdfa.data());
+          const int ni = (int)((hv.chain >> 16) & 15u);
+          const uint32_t gmap = (uint32_t)re->tdfa[re->tdfa[15] - 1];
+          int named[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+          for (int j = 0; j < ht->nrefs; ++j) {
+            const int g = ht->idx[j];
+            int lo = 0, hi = 0;
+            if (g == 0) hi = ni;
+            else if (g <= 4 && g <= ht->groups) lo = (int)((gmap >> (8 * (g - 1))) & 15u), hi = (int)((gmap >> (8 * (g - 1) + 4)) & 15u);
+            for (int k = lo; k < hi && k < 8; ++k) ++named[k];
+          }
+          int64_t G = ht->bytes;
+          bool bounded_g = true;
+          for (int k = 0; k < ni && k < 8; ++k) {
+            const int least = (int)(cstd::chain_rep(hv.crep, k) & 15u), most = (int)(cstd::chain_rep(hv.crep, k) >> 4);
+            if (named[k] == 0) G -= least;
+            else if (named[k] > 1) {
+              if (most == 0) bounded_g = false;
+              else G += (int64_t)(named[k] - 1) * most;
+            }
+          }
+          bchain = true;
+          if (bounded_g) brefs_grow = std::max<int64_t>(G, 0);
+        }
         const bool units = literal || brefs || bits_form || (offers && maxrepl < 0 && !tc.lng && tc.R == 64 && !outliers && !cs::g_replace_plain_only && !cs::cfg("CS_NO_UNITS"));
         const int bits_k = bits_form ? std::max(re->bits[1], 2) : 2;
         const size_t bits_lds = bits_form ? (size_t)bits_lds_bytes((int)re->bits.size()) : 0;
-        const size_t unit_bytes = units ? (size_t)((bits_k - 1) * ((cap >> 3) + 32) + kUnitQueue * 4 + 16 + (cs::g_backrefs_dev ? kUnitQueue * 12 + 64 * 4 : 0)) : 0;
+        const size_t unit_bytes = bchain ? (size_t)((cap >> 3) + 32 + 16 + kUnitQueue * 12)
+                                  : units ? (size_t)((bits_k - 1) * ((cap >> 3) + 32) + kUnitQueue * 4 + 16 + (cs::g_backrefs_dev ? kUnitQueue * 12 + 64 * 4 : 0)) : 0;
         // (backrefs: the group tags and the template text sit behind the DFA table; the template may grow a row by any
         // amount: room for twice the input, a launch that needs more says so and the two-pass form takes over)
-        const size_t gt_bytes = brefs ? ((re->gtags.size() * 4 + 15) & ~size_t(15)) + (((size_t)cs::g_backrefs_text_bytes + 31) & ~size_t(15)) : 0;
-        if (brefs) {
+        const size_t gt_bytes = brefs ? (bchain ? 0 : ((re->gtags.size() * 4 + 15) & ~size_t(15))) + (((size_t)cs::g_backrefs_text_bytes + 31) & ~size_t(15)) : 0;
+        if (brefs && brefs_grow >= 0) {
+          // (at most span / minlen matches in a sub-tile, each growing by at most brefs_grow bytes)
+          const int64_t span_room = std::min<int64_t>(cap, (tc.span + 15 + 32 + 15) & ~(int64_t)15);
+          cap_out = (int)((span_room + (tc.span / minlen_p + 1) * brefs_grow + (brefs_grow ? 127 : 0)) & ~(int64_t)(brefs_grow ? 127 : 15));
+          extra = (col->nbytes / minlen_p + 1) * brefs_grow;
+        } else if (brefs) {
           cap_out = std::max(cap_out, 2 * cap);
           extra = std::max<int64_t>(extra, col->nbytes);
         }
@@ -3157,14 +3206,14 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
         const size_t tile_lds = gt_bytes + bits_lds + (size_t)(cap + cap_out + 64 + (cap >> 3) + 32 + unit_bytes) * 4 + 16;
         constexpr size_t kThird = 160 * 1024 / 3;
         const bool chain_global = chain_form && tbl + tile_lds > kThird && tile_lds <= kThird && !cs::cfg("CS_CHAIN_TABLES_IN_LDS");
-        const size_t tbl_lds = chain_global ? 0 : tbl;
+        const size_t tbl_lds = (chain_global || bchain) ? 0 : tbl;
         const size_t lds1 = tbl_lds + tile_lds;
         if (lds1 > 150 * 1024) return -1;
         StreamArgs sa{};
         sa.in = view_of(col);
         sa.flags = d_unicode_flags();
         sa.L = tp.d;
-        if (chain_global) sa.L.in_lds = 0;
+        if (chain_global || bchain) sa.L.in_lds = 0;
         sa.repl = ptr<const uint8_t>(d_repl);
         sa.rb = rb;
         sa.maxrepl = maxrepl;
@@ -3189,13 +3238,13 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
         sa.cap_out = cap_out;
         sa.tbl_bytes = (int)(tbl_lds + gt_bytes + bits_lds);
         sa.bits = bits_form ? ptr<const int32_t>(re->d_bits) : nullptr;
-        sa.bits_off = (int)(tbl + gt_bytes);
+        sa.bits_off = (int)(tbl_lds + gt_bytes);
         sa.bits_words = bits_form ? (int)re->bits.size() : 0;
         sa.bits_k = bits_form ? re->bits[1] : 0;
         sa.tmpl = static_cast<const csvm::BackrefTemplate*>(cs::g_backrefs_dev);
         sa.gtags = brefs ? ptr<const int32_t>(re->d_gtags) : nullptr;
-        sa.gt_off = (int)tbl;
-        sa.gt_words = brefs ? (int)re->gtags.size() : 0;
+        sa.gt_off = (int)tbl_lds;
+        sa.gt_words = brefs && !bchain ? (int)re->gtags.size() : 0;
         sa.debug = cs::cfg("CS_TILE_DEBUG") ? atoi(cs::cfg("CS_TILE_DEBUG")) : 0;
         sa.outliers = outliers ? 1 : 0;
         sa.lit = literal ? cs::g_replace_literal : 0;
@@ -3227,7 +3276,9 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
             if (growth == 0) kern = lng ? &k_tdfa_replace_stream<true, true, true, false, true, false, P6, false, true> : &k_tdfa_replace_stream<true, true, true, false, false, false, P6, false, true>;
             else kern = lng ? &k_tdfa_replace_stream<true, true, false, true, true, false, P6, false, true> : &k_tdfa_replace_stream<true, true, false, true, false, false, P6, false, true>;
           }
-        } else if (brefs)
+        } else if (bchain)
+          kern = &k_tdfa_replace_stream<false, false, false, true, false, true, 5, true, false, false, true>;
+        else if (brefs)
           kern = cap <= 5 * 1024 ? &k_tdfa_replace_stream<true, false, false, true, false, true, 5, true> : &k_tdfa_replace_stream<true, false, false, true, false, true, cstile::kPfChunks, true>;
         else if (bits_form)
           kern = rb > 8 ? &k_tdfa_replace_stream<true, true, false, true, false, true, cstile::kPfChunks, false, false, false, true, true>
@@ -3244,14 +3295,14 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
         else if (units)
           kern = rb > 8 ? (tp.d.in_lds ? &k_tdfa_replace_stream<true, true, false, true, false, true> : &k_tdfa_replace_stream<false, true, false, true, false, true>)
                         : (tp.d.in_lds ? &k_tdfa_replace_stream<true, false, false, true, false, true> : &k_tdfa_replace_stream<false, false, false, true, false, true>);
-        note_route(bits_form ? "bits" : brefs ? "brefs" : literal ? "literal" : wide_stream ? "wide" : units ? (((re->tdfa[30] >> 16) & 15) != 0 ? "chain" : "units") : "plain");
+        note_route(bits_form ? "bits" : bchain ? "brefs-chain" : brefs ? "brefs" : literal ? "literal" : wide_stream ? "wide" : units ? (((re->tdfa[30] >> 16) & 15) != 0 ? "chain" : "units") : "plain");
         if (lds1 > 48 * 1024)
           CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)lds1));
         const unsigned grid = resident_grid(reinterpret_cast<const void*>(kern), lds1, (nsub1 + 3) / 4);
         if (cs::cfg("CS_STREAM_INFO"))
           fprintf(stderr, "replace stream: grid %u lds %zu (tables %zu, tile %d + %d) rows/tile %d units %d chain %d wide %d brefs %d roomy %d growth %d rb %d\n", grid, lds1, tbl_lds + gt_bytes, cap, cap_out,
-                  tc.R, (int)units, chain_form ? (chain_global ? 2 : 1) : 0, (int)wide_stream, (int)brefs, (int)roomy, (int)growth, rb);
+                  tc.R, (int)units, bchain ? 3 : chain_form ? (chain_global ? 2 : 1) : 0, (int)wide_stream, (int)brefs, (int)roomy, (int)growth, rb);
 #if defined(CS_PHASE_PROF)
         Buf tracebuf;
         const long long ntrace = (nsub1 >> 10) + 1;
@@ -3899,11 +3950,13 @@ int cs_replace_with_backrefs(const cs_column* col, const cs_regex* cre, const ch
       CS_HIP(hipStreamSynchronize(s));  // (`t` lives on this stack frame)
       cs::g_backrefs_dev = d_t->p;
       cs::g_backrefs_text_bytes = t.bytes;
+      cs::g_backrefs_host = &t;
       cs::g_replace_plain_only = 1;  // (single-pass kernel or nothing)
       cs_column* fast = nullptr;
       const int rc = cs_replace_re(col, re, "", -1, stream, &fast);
       cs::g_backrefs_dev = nullptr;
       cs::g_backrefs_text_bytes = 0;
+      cs::g_backrefs_host = nullptr;
       cs::g_replace_plain_only = 0;
       if (rc == CS_OK) {
         *out = fast;

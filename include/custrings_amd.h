@@ -85,7 +85,7 @@ int cs_current_device(void);
  * with the two-pass kernels.  Correct either way; a benchmark should see 0. */
 int64_t cs_fallback_count(void);
 /* Diagnostics / tests: which route the calling thread's last regex stream launch took -- "bits" (the bit-parallel form,
- * regex_bits.h), "chain", "units", "literal", "wide", "plain", "brefs" -- or "" when the call used other kernels. */
+ * regex_bits.h), "chain", "units", "literal", "wide", "plain", "brefs", "brefs-chain" -- or "" when the call used other kernels. */
 const char* cs_debug_last_route(void);
 /* The CS_* switches (measurement aids, route overrides, opt-in experiments) are read from the environment ONCE, at the
  * library's first look (cs_init); the dispatch paths never call getenv.  This changes one at run time, thread-safely

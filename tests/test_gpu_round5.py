@@ -290,6 +290,45 @@ def test_gpu_counted_chain_with_its_tables_in_memory():
         check_regex_ops(gpuutil.from_col(sub), sub, IPV4B, orc, repls=("#",))
 
 
+BREFS_CHAIN_CASES = [(r"(\d+)\.(\d+)\.(\d+)\.(\d+)", r"\4.\3.\2.\1"), (r"(\d+)\.(\d+)\.(\d+)\.(\d+)", r"<\1>"), (r"(\d+)\.(\d+)\.(\d+)\.(\d+)", r"[\0|\2\2]--a-longer-literal-part--"),
+                     (r"(\d+)\.(\d+)", r"\2"), (r"(\d+)\.(\d+)", r""), (r"(\d+)\.(\d+)", r"\9x\3"), (r"((\d+)\.(\d+))\.\d+", r"\1=\3=\2"),
+                     (IPV4B.replace(r"\d{1,3}", r"(\d{1,3})"), r"\4.\3.\2.\1"), (r"\b(\d{1,3})\.(\d{1,3})\b", r"\2\2\2\1"), (r"(\d+)\.(\d+)\.\d+\.(\d+) ", r"\3-\1 "),
+                     (r"([a-z]+)=", r"=\1\1")]
+
+
+@pytest.mark.parametrize("pat,repl", BREFS_CHAIN_CASES, ids=["%s->%s" % (p[:18], r[:10]) for p, r in BREFS_CHAIN_CASES])
+def test_gpu_backrefs_chain_form(pat, repl):
+    """replace_with_backrefs on a chain whose groups are runs of items (k_tdfa_replace_stream<.., BREFS, .., CHAIN>: no table,
+    no group tags in LDS; the out tile sized from the template -- cs_regex.hip: brefs_grow): templates that shrink, keep and
+    grow a match, a group named twice (bounded and not), group 0, groups the pattern does not have, nested groups, counted
+    items with `\\b`, a literal suffix -- against the oracle, on the form itself (no fallback)."""
+    orc = cpulibs.Oracle()
+    L = gpuutil.lib()
+    rows = 60_000
+    g, o = gpuutil.synth(3, 1_000_000, rows), orc.synth(3, 1_000_000, rows)
+    f0 = L.lib.cs_fallback_count()
+    got = g.replace_with_backrefs(pat, repl)
+    assert last_route() == "brefs-chain", (pat, repl, last_route())
+    assert L.lib.cs_fallback_count() == f0, (pat, repl)
+    gpuutil.assert_same(got, orc.replace_with_backrefs(o, blob_of(pat), repl), "replace_with_backrefs(%r, %r)" % (pat, repl))
+
+
+def test_gpu_backrefs_chain_form_gives_up_like_the_backrefs_form():
+    """A sub-tile the marker arithmetic does not take (a byte >= 0x80 or a NUL outside the sampled windows), a sub-tile with
+    more than 128 matches: the launch is given up and the two-pass form answers -- the same rows as the oracle's."""
+    orc = cpulibs.Oracle()
+    base = orc.synth(3, 0, 30_000)
+    rows = base.to_list()
+    pat, repl = r"(\d+)\.(\d+)\.(\d+)\.(\d+)", r"\4.\3.\2.\1"
+    for special in ("é 10.2.3.4 1.2.3.4", "1.2.3.4\x005.6.7.8", "1.2.3.4 " * 11):
+        r2 = list(rows)
+        for k in range(64 if special.startswith("1.2.3.4 1") else 1):
+            r2[11_003 + k] = special
+        o = cpulibs.Col.from_list(r2)
+        g = gpuutil.from_col(o)
+        gpuutil.assert_same(g.replace_with_backrefs(pat, repl), orc.replace_with_backrefs(o, blob_of(pat), repl), repr(special[:12]))
+
+
 # ---- full-size parity of the headline ops (VERDICT r4 weak #9) ----------------------------------------------------------
 def test_gpu_full_size_headline_routes_agree():
     """split(' ') and replace_re(IPv4, '<IP>') on the FULL 100M-row C3 column by two independent implementations each -- the
