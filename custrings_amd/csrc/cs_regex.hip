@@ -2866,30 +2866,37 @@ void scan(const cs_column* col, cs_regex* re, uint8_t* out8, int32_t* out32, int
     const bool bits_form = !wide && (MODE == 0 || MODE == 2) && !tc.lng && tc.R == 64 && bits_route(re, col, s, MODE == 2 ? BITS_COUNT : BITS_CONTAINS);
     const int bits_k = bits_form ? std::max(re->bits[1], 2) : 0;
     const size_t bits_lds = bits_form ? (size_t)bits_lds_bytes((int)re->bits.size()) : 0;
-    const size_t lds = bits_form ? tp.lds_bytes + bits_lds + (size_t)(cap + 32 + bits_k * ((cap >> 3) + 32) + kUnitQueue * 4 + 64 * 4 + 16) * 4
+    size_t lds = bits_form ? tp.lds_bytes + bits_lds + (size_t)(cap + 32 + bits_k * ((cap >> 3) + 32) + kUnitQueue * 4 + 64 * 4 + 16) * 4
                                  : tp.lds_bytes + (size_t)(cap + 32 + (cap >> 3) + 32 + (units ? (cap >> 3) + 32 + kUnitQueue * 4 + 64 * 4 + 16 : 0)) * 4;
+    // (a chain's arithmetic reads no table: where the tables cost the launch a workgroup per CU -- four fit in 40 KB each --
+    // they stay in memory, as in cs_replace_re)
+    const bool chain_scan = units && MODE == 2 && !bits_form && ((re->tdfa[30] >> 16) & 15) != 0 && !sample_has_high_bytes(col, s) && !cs::cfg("CS_NO_CHAIN_FORM");
+    // (the bit form is such a form too: its sub-tiles of plain ASCII never touch the automaton)
+    const bool chain_global = (chain_scan || bits_form) && lds > 40 * 1024 && lds - tp.lds_bytes <= 40 * 1024 && !cs::cfg("CS_CHAIN_TABLES_IN_LDS");
+    if (chain_global) lds -= tp.lds_bytes;
     if (tc.R && lds <= 150 * 1024) {
       ScanStreamArgs sa{};
       sa.in = view_of(col);
       sa.flags = d_unicode_flags();
       sa.L = tp.d;
+      if (chain_global) sa.L.in_lds = 0;
       sa.out8 = out8;
       sa.out32 = out32;
       sa.found = ptr<unsigned long long>(cnt);
       sa.nsub = (col->rows + tc.R - 1) / tc.R;
       sa.rows_per_tile = tc.R;
       sa.cap_in = cap;
-      sa.tbl_bytes = (int)(tp.lds_bytes + bits_lds);
+      sa.tbl_bytes = (int)((chain_global ? 0 : tp.lds_bytes) + bits_lds);
       sa.bits = bits_form ? ptr<const int32_t>(re->d_bits) : nullptr;
-      sa.bits_off = (int)tp.lds_bytes;
+      sa.bits_off = chain_global ? 0 : (int)tp.lds_bytes;
       sa.bits_words = bits_form ? (int)re->bits.size() : 0;
       sa.bits_k = bits_form ? re->bits[1] : 0;
       auto kern = tc.lng ? &k_tdfa_scan_stream<MODE, true, true> : &k_tdfa_scan_stream<MODE, true, false>;
       if (units) kern = &k_tdfa_scan_stream<MODE == 2 ? 2 : 0, true, false, true>;
-      if (units && MODE == 2 && ((re->tdfa[30] >> 16) & 15) != 0 && !sample_has_high_bytes(col, s) && !cs::cfg("CS_NO_CHAIN_FORM"))
-        kern = &k_tdfa_scan_stream<2, true, false, true, true>;  // (a chain pattern on a column whose sample is plain ASCII)
-      if (bits_form) kern = &k_tdfa_scan_stream<MODE == 2 ? 2 : 0, true, false, true, true, true>;
-      note_route(bits_form ? "bits" : wide ? "wide" : units ? "units" : "plain");
+      if (chain_scan) kern = &k_tdfa_scan_stream<2, true, false, true, true>;  // (a chain pattern on a column whose sample is plain ASCII)
+      if (chain_global) kern = &k_tdfa_scan_stream<2, false, false, true, true>;
+      if (bits_form) kern = chain_global ? &k_tdfa_scan_stream<MODE == 2 ? 2 : 0, false, false, true, true, true> : &k_tdfa_scan_stream<MODE == 2 ? 2 : 0, true, false, true, true, true>;
+      note_route(bits_form ? "bits" : wide ? "wide" : chain_scan ? "chain" : units ? "units" : "plain");
       if (wide) kern = tc.lng ? &k_tdfa_scan_stream<MODE + 7, true, true> : &k_tdfa_scan_stream<MODE + 7, true, false>;
       if (lds > 48 * 1024)
         CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -3779,7 +3786,10 @@ int cs_findall(const cs_column* col, const cs_regex* cre, cs_stream stream, cs_c
       const int cap = tc.cap;
       // the unit scan where the tagged DFA offers the decomposition (as count_re)
       const bool units = ((re->tdfa[31] & 1) != 0 || ((re->tdfa[30] >> 16) & 15) != 0) && !tc.lng && tc.R == 64 && !cs::cfg("CS_NO_UNITS");
-      const size_t lds = tp.lds_bytes + (size_t)(cap + 32 + (cap >> 3) + 32 + (units ? (cap >> 3) + 32 + kUnitQueue * 4 + 64 * 4 + 16 : 0)) * 4;
+      size_t lds = tp.lds_bytes + (size_t)(cap + 32 + (cap >> 3) + 32 + (units ? (cap >> 3) + 32 + kUnitQueue * 4 + 64 * 4 + 16 : 0)) * 4;
+      const bool chain_scan = units && ((re->tdfa[30] >> 16) & 15) != 0 && !sample_has_high_bytes(col, s) && !cs::cfg("CS_NO_CHAIN_FORM");
+      const bool chain_global = chain_scan && tp.d.in_lds && lds > 40 * 1024 && lds - tp.lds_bytes <= 40 * 1024 && !cs::cfg("CS_CHAIN_TABLES_IN_LDS");  // (as in count_re)
+      if (chain_global) lds -= tp.lds_bytes;
       if (tp.d.in_lds && tc.R && lds <= 150 * 1024) {
         Buf hits = dev_alloc(8, s);
         CS_HIP(hipMemsetAsync(hits->p, 0, 8, s));
@@ -3791,12 +3801,13 @@ int cs_findall(const cs_column* col, const cs_regex* cre, cs_stream stream, cs_c
         sa.nsub = (rows + tc.R - 1) / tc.R;
         sa.rows_per_tile = tc.R;
         sa.cap_in = cap;
-        sa.tbl_bytes = (int)tp.lds_bytes;
+        sa.tbl_bytes = chain_global ? 0 : (int)tp.lds_bytes;
+        if (chain_global) sa.L.in_lds = 0;
         sa.maxp = ptr<int>(dmax);
         auto kern = tc.lng ? &k_tdfa_scan_stream<3, true, true> : &k_tdfa_scan_stream<3, true, false>;
         if (units) kern = &k_tdfa_scan_stream<3, true, false, true>;
-        if (units && ((re->tdfa[30] >> 16) & 15) != 0 && !sample_has_high_bytes(col, s) && !cs::cfg("CS_NO_CHAIN_FORM"))
-          kern = &k_tdfa_scan_stream<3, true, false, true, true>;  // (a chain pattern on a column whose sample is plain ASCII)
+        if (chain_scan) kern = &k_tdfa_scan_stream<3, true, false, true, true>;  // (a chain pattern on a column whose sample is plain ASCII)
+        if (chain_global) kern = &k_tdfa_scan_stream<3, false, false, true, true>;
         if (lds > 48 * 1024)
           CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         const unsigned grid = resident_grid(reinterpret_cast<const void*>(kern), lds, (sa.nsub + 3) / 4);
