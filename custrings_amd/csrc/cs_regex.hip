@@ -1648,7 +1648,7 @@ __global__ void __launch_bounds__(256, ((BREFS && !CHAIN) || BITS) ? 2 : CS_STRE
           p_second = cstile::status_load(a.excl + (p_tile >= 0 ? p_tile : 0));
           has_second = scanner;
           if (live) {
-            chain_match(u128(r0 | ((unsigned long long)r1 << 32), r2), u128(x0 | ((unsigned long long)x1 << 32), x2), D.chain, D.crep, uS, uE, D.sfx, n,
+            chain_match(u128(r0 | ((unsigned long long)r1 << 32), r2), u128(x0 | ((unsigned long long)x1 << 32), x2), D.chain, D.img, uS, uE, D.sfx, n,
                         [&](int i) { return lds_in[lead + rbeg + i]; });
             nm = u128_popc(uS);
             out_len = n - u128_popc(u128_sub(u128_shl1(uE), uS)) + nm * rb;
@@ -1669,7 +1669,7 @@ __global__ void __launch_bounds__(256, ((BREFS && !CHAIN) || BITS) ? 2 : CS_STRE
           p_second = cstile::status_load(a.excl + (p_tile >= 0 ? p_tile : 0));
           has_second = scanner;
           if (live) {
-            chain_match(R, X, D.chain, D.crep, uS, uE, D.sfx, n, [&](int i) { return lds_in[lead + rbeg + i]; });
+            chain_match(R, X, D.chain, D.img, uS, uE, D.sfx, n, [&](int i) { return lds_in[lead + rbeg + i]; });
             nm = u128_popc(uS);
             from_masks = true;
           }
@@ -1687,7 +1687,7 @@ __global__ void __launch_bounds__(256, ((BREFS && !CHAIN) || BITS) ? 2 : CS_STRE
               S = u128_clear_lowest(S);
               E = u128_clear_lowest(E);
               int gb[4] = {-1, -1, -1, -1}, ge[4] = {-1, -1, -1, -1};
-              if (T.nrefs > 0) chain_group_bounds(R, X, D.chain, D.crep, gmap, mb, gb, ge);  // (a template without references needs no groups)
+              if (T.nrefs > 0) chain_group_bounds(R, X, D.chain, D.img, gmap, mb, gb, ge);  // (a template without references needs no groups)
               int grow = T.bytes - (me - mb);
               for (int j = 0; j < T.nrefs; ++j) {
                 const int g = T.idx(j);
@@ -2342,11 +2342,11 @@ __global__ void __launch_bounds__(256, MODE == 4 ? 3 : CHAIN ? 4 : (UNITS && MOD
           if (unit_x != 0) cstile::row_bits96(xbitmap, lead + rbeg, n, x0w, x1w, x2w);
           const U128 Rm = u128(r0w | ((unsigned long long)r1w << 32), r2w), Xm = u128(x0w | ((unsigned long long)x1w << 32), x2w);
           U128 S = u128(0, 0), E = u128(0, 0);
-          if (live) chain_match(Rm, Xm, D.chain, D.crep, S, E, D.sfx, n, [&](int i) { return lds_in[lead + rbeg + i]; });
+          if (live) chain_match(Rm, Xm, D.chain, D.img, S, E, D.sfx, n, [&](int i) { return lds_in[lead + rbeg + i]; });
           const bool hit = live && u128_any(S);
           v = hit;
           int gb[4], ge[4];
-          chain_group_bounds(Rm, Xm, D.chain, D.crep, (uint32_t)D.img[D.img[15] - 1], hit ? u128_ctz(S) : 0, gb, ge);
+          chain_group_bounds(Rm, Xm, D.chain, D.img, (uint32_t)D.img[D.img[15] - 1], hit ? u128_ctz(S) : 0, gb, ge);
           if (lane < nrows) {
 #pragma unroll
             for (int k = 0; k < 4; ++k)
@@ -2456,7 +2456,7 @@ __global__ void __launch_bounds__(256, MODE == 4 ? 3 : CHAIN ? 4 : (UNITS && MOD
           if (unit_x != 0) cstile::row_bits96(xbitmap, lead + rbeg, n, x0, x1, x2);
           if (live) {
             U128 S, E;
-            chain_match(u128(r0 | ((unsigned long long)r1 << 32), r2), u128(x0 | ((unsigned long long)x1 << 32), x2), D.chain, D.crep, S, E, D.sfx, n,
+            chain_match(u128(r0 | ((unsigned long long)r1 << 32), r2), u128(x0 | ((unsigned long long)x1 << 32), x2), D.chain, D.img, S, E, D.sfx, n,
                         [&](int i) { return lds_in[lead + rbeg + i]; });
             while (u128_any(S)) {
               const int mb = u128_ctz(S), me = u128_ctz(E) + 1;
@@ -2539,14 +2539,14 @@ __global__ void __launch_bounds__(256, MODE == 4 ? 3 : CHAIN ? 4 : (UNITS && MOD
           if (unit_x != 0) cstile::row_bits96(xbitmap, lead + rbeg, n, x0, x1, x2);
           const U128 R = u128(r0 | ((unsigned long long)r1 << 32), r2), X = u128(x0 | ((unsigned long long)x1 << 32), x2);
           if (MODE == 0 && !(D.chain & kChainLeadB)) {  // (a `\b` in front of the chain is checked per match: chain_match)
-            v = live && u128_any(chain_suffix_filter(chain_ends(R, X, D.chain, D.crep), D.chain, D.sfx, n, [&](int i) { return lds_in[lead + rbeg + i]; })) ? 1 : 0;
+            v = live && u128_any(chain_suffix_filter(chain_ends(R, X, D.chain, D.img), D.chain, D.sfx, n, [&](int i) { return lds_in[lead + rbeg + i]; })) ? 1 : 0;
           } else if (MODE == 0) {
             U128 S = u128(0, 0), E;
-            if (live) chain_match(R, X, D.chain, D.crep, S, E, D.sfx, n, [&](int i) { return lds_in[lead + rbeg + i]; });
+            if (live) chain_match(R, X, D.chain, D.img, S, E, D.sfx, n, [&](int i) { return lds_in[lead + rbeg + i]; });
             v = u128_any(S) ? 1 : 0;
           } else {
             U128 S = u128(0, 0), E;
-            if (live) chain_match(R, X, D.chain, D.crep, S, E, D.sfx, n, [&](int i) { return lds_in[lead + rbeg + i]; });
+            if (live) chain_match(R, X, D.chain, D.img, S, E, D.sfx, n, [&](int i) { return lds_in[lead + rbeg + i]; });
             v = u128_popc(S);
           }
           redo = false;
@@ -3165,6 +3165,7 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
           const auto* ht = static_cast<const csvm::BackrefTemplate*>(cs::g_backrefs_host);
           const cstd::View hv = cstd::make_view(re->tdfa.data());
           const int ni = (int)((hv.chain >> 16) & 15u);
+          const unsigned long long hcrep = cstd::chain_crep(re->tdfa.data());
           const uint32_t gmap = (uint32_t)re->tdfa[re->tdfa[15] - 1];
           int named[8] = {0, 0, 0, 0, 0, 0, 0, 0};
           for (int j = 0; j < ht->nrefs; ++j) {
@@ -3177,7 +3178,7 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
           int64_t G = ht->bytes;
           bool bounded_g = true;
           for (int k = 0; k < ni && k < 8; ++k) {
-            const int least = (int)(cstd::chain_rep(hv.crep, k) & 15u), most = (int)(cstd::chain_rep(hv.crep, k) >> 4);
+            const int least = (int)(cstd::chain_rep(hcrep, k) & 15u), most = (int)(cstd::chain_rep(hcrep, k) >> 4);
             if (named[k] == 0) G -= least;
             else if (named[k] > 1) {
               if (most == 0) bounded_g = false;

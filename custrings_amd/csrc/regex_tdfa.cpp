@@ -718,6 +718,10 @@ std::vector<int32_t> build_tdfa(const Program& prog, const std::vector<int32_t>&
       if (ok) {
         img[29] |= (int32_t)(items << 16);
         img[30] |= (int32_t)((uint32_t)ni << 16) | (lead_b ? 1 << 24 : 0) | (trail_b ? 1 << 25 : 0);
+        // bit 26: the general (counted) form of the arithmetic -- some item is neither single nor `+`, or a `\b` stands at an end
+        bool general = lead_b || trail_b;
+        for (int k = 0; k < ni; ++k) general = general || (((crep >> (8 * k)) & 255u) != 0x11u && ((crep >> (8 * k)) & 255u) != 0x01u);
+        if (general) img[30] |= 1 << 26;
         if (!(word & 1) && x != ((word >> 8) & 127)) img[31] = word | (x << 8);
         // the image's tail: the repetition counts (two words), then the suffix, then the group map (make_view reads them back
         // from the end)

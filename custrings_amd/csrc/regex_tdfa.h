@@ -32,7 +32,7 @@
 //        their number (0 = the pattern is no chain); [30] bits 21..23: the chain is followed by that many literal bytes (the
 //        SUFFIX, none of them in the candidate ranges; the word in front of the image's last one -- or the last one when no
 //        group map follows -- holds them, first byte lowest): `(\d+)\.(\d+)\.\d+\.(\d+) `; [30] bits 24 / 25: a `\b` in front of
-//        the chain / behind it.  Two words in front of those tail words: how often each item is taken, a byte per item (low
+//        the chain / behind it, bit 26: the general form of the arithmetic (a counted item or a `\\b`: chain_match_counted).  Two words in front of those tail words: how often each item is taken, a byte per item (low
 //        nibble the least, high nibble the most repetitions, 0 = unbounded): `\b\d{1,3}\.\d{1,3}\.\d{1,3}\.\d{1,3}\b`
 //   INIT   : 3 modes x 8 categories state ids
 //   T1     : nstates x 128 entries (ASCII byte -> transition; byte 0 = embedded NUL)
@@ -167,6 +167,21 @@ CS_HD unsigned long long u64_bitrev(unsigned long long v) {
 // bit p -> bit 126 - p (p <= 126; its own inverse)
 CS_HD U128 u128_rev127(U128 a) { return u128_shr1(u128(u64_bitrev(a.hi), u64_bitrev(a.lo))); }
 CS_HD U128 chain_star(U128 M, U128 C) { return u128_or(u128_xor(u128_add(u128_and(M, C), C), C), M); }
+// The chain's description is the same in every lane, but it comes out of the image in LDS, i.e. in vector registers: taken
+// into scalar registers once per call, the item loops below branch and shift on the scalar unit (without this the counted
+// form cost the headline's replace_re kernel 0.55 ms of 4.7: vector compares and exec-masked loops per item).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define CS_CHAIN_UNIFORM(chain, crep)                                                                                      \
+  do {                                                                                                                     \
+    chain = (uint32_t)__builtin_amdgcn_readfirstlane((int)(chain));                                                        \
+    crep = (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(crep)) |                            \
+           ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((crep) >> 32)) << 32);            \
+  } while (0)
+#else
+#define CS_CHAIN_UNIFORM(chain, crep) \
+  do {                                \
+  } while (0)
+#endif
 constexpr uint32_t kChainLeadB = 1u << 24, kChainTrailB = 1u << 25;  // `\b` in front of the chain / behind it
 // the bytes `\b` counts as word characters on a plain-ASCII row (regexec.inl:290-299: alphanumeric; '_' is none)
 CS_HD bool chain_word_byte(uint32_t c) { return c - 48u < 10u || (c | 32u) - 97u < 26u; }
@@ -175,8 +190,13 @@ CS_HD uint32_t chain_rep(unsigned long long crep, int k) { return (uint32_t)(cre
 CS_HD bool chain_runs(unsigned long long crep, int k) { return (chain_rep(crep, k) >> 4) != 1u; }
 // the markers behind one item: M in front of it, C its class
 CS_HD U128 chain_item(U128 M, U128 C, uint32_t rep) {
+  M = u128_shl1(u128_and(M, C));  // (every item is taken once at least)
+  // (the two common items first, a uniform branch each: the counting loops below cost the dotted quad of the headline a
+  // tenth of its replace_re kernel when every item went through them)
+  if (rep == 0x11u) return M;
+  if (rep == 0x01u) return chain_star(M, C);
   const int least = (int)(rep & 15u), most = (int)(rep >> 4);
-  for (int i = 0; i < least; ++i) M = u128_shl1(u128_and(M, C));
+  for (int i = 1; i < least; ++i) M = u128_shl1(u128_and(M, C));
   if (most == 0) return chain_star(M, C);
   U128 T = M;
   for (int i = least; i < most; ++i) {
@@ -186,7 +206,8 @@ CS_HD U128 chain_item(U128 M, U128 C, uint32_t rep) {
   return M;
 }
 // the last byte of every match of the row, whatever its start (a `\b` in front of the chain is NOT looked at: chain_match)
-CS_HD U128 chain_ends(U128 R, U128 X, uint32_t chain, unsigned long long crep) {
+CS_HD U128 chain_ends_counted(U128 R, U128 X, uint32_t chain, unsigned long long crep) {
+  CS_CHAIN_UNIFORM(chain, crep);
   const int ni = (int)((chain >> 16) & 15u);
   auto is_x = [&](int k) { return ((chain >> (2 * k)) & 1u) != 0; };
   U128 M = chain_runs(crep, 0) ? u128_andn(R, u128_shl1(R)) : R;
@@ -203,6 +224,10 @@ CS_HD U128 chain_ends(U128 R, U128 X, uint32_t chain, unsigned long long crep) {
 // byte_at(i) is byte i of the row (n bytes).
 template <class ByteAt>
 CS_HD U128 chain_suffix_filter(U128 Le, uint32_t chain, uint32_t sfx, int n, ByteAt&& byte_at) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  chain = (uint32_t)__builtin_amdgcn_readfirstlane((int)chain);
+  sfx = (uint32_t)__builtin_amdgcn_readfirstlane((int)sfx);
+#endif
   const int sl = (int)((chain >> 20) & 7u);
   const bool wb = (chain & kChainTrailB) != 0;
   if (!sl && !wb) return Le;
@@ -219,10 +244,11 @@ CS_HD U128 chain_suffix_filter(U128 Le, uint32_t chain, uint32_t sfx, int n, Byt
   return Le;
 }
 template <class ByteAt>
-CS_HD void chain_match(U128 R, U128 X, uint32_t chain, unsigned long long crep, U128& S, U128& L, uint32_t sfx, int n, ByteAt&& byte_at) {
+CS_HD void chain_match_counted(U128 R, U128 X, uint32_t chain, unsigned long long crep, U128& S, U128& L, uint32_t sfx, int n, ByteAt&& byte_at) {
+  CS_CHAIN_UNIFORM(chain, crep);
   const int ni = (int)((chain >> 16) & 15u);
   auto is_x = [&](int k) { return ((chain >> (2 * k)) & 1u) != 0; };
-  U128 Le = chain_suffix_filter(chain_ends(R, X, chain, crep), chain, sfx, n, byte_at);
+  U128 Le = chain_suffix_filter(chain_ends_counted(R, X, chain, crep), chain, sfx, n, byte_at);
   S = u128(0, 0);
   L = u128(0, 0);
   if (!u128_any(Le)) return;
@@ -261,7 +287,11 @@ CS_HD void chain_match(U128 R, U128 X, uint32_t chain, unsigned long long crep, 
 // item, high nibble the item behind its last): every group is a run of items, so its range follows from the item
 // boundaries of the match that starts at mb -- a walk over the row's two masks, no automaton.  gb / ge: -1 for a group
 // the map does not name.
-CS_HD void chain_group_bounds(U128 R, U128 X, uint32_t chain, unsigned long long crep, uint32_t gmap, int mb, int gb[4], int ge[4]) {
+CS_HD void chain_group_bounds_counted(U128 R, U128 X, uint32_t chain, unsigned long long crep, uint32_t gmap, int mb, int gb[4], int ge[4]) {
+  CS_CHAIN_UNIFORM(chain, crep);
+#if defined(__HIP_DEVICE_COMPILE__)
+  gmap = (uint32_t)__builtin_amdgcn_readfirstlane((int)gmap);
+#endif
   const int ni = (int)((chain >> 16) & 15u);
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
@@ -292,6 +322,137 @@ CS_HD void chain_group_bounds(U128 R, U128 X, uint32_t chain, unsigned long long
   }
 }
 
+// ---- the same for chains of single and `+` items alone, as they were before the counted form: the headline's dotted quad runs
+// ---- these (the general form above cost its replace_re kernel 0.6 of 4.7 ms even with the fast paths in chain_item)
+// the last byte of every match of the row, whatever its start (contains_re needs no more than "any")
+CS_HD U128 chain_ends_plain(U128 R, U128 X, uint32_t chain) {
+  const int ni = (int)((chain >> 16) & 15u);
+  auto is_x = [&](int k) { return ((chain >> (2 * k)) & 1u) != 0; };
+  auto plus = [&](int k) { return ((chain >> (2 * k + 1)) & 1u) != 0; };
+  U128 M = plus(0) ? u128_andn(R, u128_shl1(R)) : R;
+  U128 C = R;
+  for (int k = 0; k < ni; ++k) {
+    C = is_x(k) ? X : R;
+    M = u128_shl1(u128_and(M, C));
+    if (plus(k)) M = chain_star(M, C);
+  }
+  if (plus(ni - 1)) M = u128_andn(M, C);
+  return u128_shr1(M);
+}
+// The chain's SUFFIX: literal bytes behind the last item (none in R, so a repeated last item still takes its whole run and
+// a start has one match or none).  Of the ends of the chain part only those stay that the suffix follows; byte_at(i) is
+// byte i of the row (n bytes).
+template <class ByteAt>
+CS_HD U128 chain_suffix_filter_plain(U128 Le, uint32_t chain, uint32_t sfx, int n, ByteAt&& byte_at) {
+  const int sl = (int)((chain >> 20) & 7u);
+  if (!sl) return Le;
+  U128 T = Le;
+  while (u128_any(T)) {
+    const int l = u128_ctz(T);
+    const U128 rest = u128_clear_lowest(T);
+    bool ok = l + 1 + sl <= n;
+    for (int k = 0; k < sl && ok; ++k) ok = (uint32_t)byte_at(l + 1 + k) == ((sfx >> (8 * k)) & 255u);
+    if (!ok) Le = u128_andn(Le, u128_andn(T, rest));
+    T = rest;
+  }
+  return Le;
+}
+template <class ByteAt>
+CS_HD void chain_match_plain(U128 R, U128 X, uint32_t chain, U128& S, U128& L, uint32_t sfx, int n, ByteAt&& byte_at) {
+  const int ni = (int)((chain >> 16) & 15u);
+  auto is_x = [&](int k) { return ((chain >> (2 * k)) & 1u) != 0; };
+  auto plus = [&](int k) { return ((chain >> (2 * k + 1)) & 1u) != 0; };
+  U128 Le = chain_suffix_filter_plain(chain_ends_plain(R, X, chain), chain, sfx, n, byte_at);
+  S = u128(0, 0);
+  L = u128(0, 0);
+  if (!u128_any(Le)) return;
+  U128 M, C = R;
+  // backward: the reversed chain over the reversed masks, from the ends
+  const U128 Rr = u128_rev127(R), Xr = u128_rev127(X);
+  M = u128_rev127(Le);
+  for (int k = ni - 1; k >= 0; --k) {
+    C = is_x(k) ? Xr : Rr;
+    M = u128_shl1(u128_and(M, C));
+    if (plus(k)) M = chain_star(M, C);
+  }
+  if (plus(0)) M = u128_andn(M, C);
+  U128 Sv = u128_rev127(u128_shr1(M));  // the starts that reach an end, as many as there are ends
+  {
+    // (the match's last byte is the suffix's: rows end within 96 bytes, the shift loses nothing)
+    const int sl = (int)((chain >> 20) & 7u);
+    if (sl) Le = u128(Le.lo << sl, (Le.hi << sl) | (Le.lo >> (64 - sl)));
+  }
+  int cursor = 0;
+  while (u128_any(Sv) && u128_any(Le)) {
+    const int s = u128_ctz(Sv), l = u128_ctz(Le);
+    const U128 sb = u128_andn(Sv, u128_clear_lowest(Sv)), lb = u128_andn(Le, u128_clear_lowest(Le));
+    Sv = u128_clear_lowest(Sv);
+    Le = u128_clear_lowest(Le);
+    if (s >= cursor) {
+      S = u128_or(S, sb);
+      L = u128_or(L, lb);
+      cursor = l + 1;
+    }
+  }
+}
+
+// The capture groups of a chain match (header word 30 bit 20; gmap: a byte per group 1..4, low nibble the group's first
+// item, high nibble the item behind its last): every group is a run of items, so its range follows from the item
+// boundaries of the match that starts at mb -- a walk over the row's two masks, no automaton.  gb / ge: -1 for a group
+// the map does not name.
+CS_HD void chain_group_bounds_plain(U128 R, U128 X, uint32_t chain, uint32_t gmap, int mb, int gb[4], int ge[4]) {
+  const int ni = (int)((chain >> 16) & 15u);
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+  for (int q = 0; q < 4; ++q) gb[q] = ge[q] = -1;
+  int p = mb;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+  for (int k = 0; k <= 8; ++k) {
+    if (k <= ni) {  // (uniform) p = the boundary in front of item k
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+      for (int q = 0; q < 4; ++q) {
+        if ((int)((gmap >> (8 * q)) & 15u) == k) gb[q] = p;
+        if ((int)((gmap >> (8 * q + 4)) & 15u) == k) ge[q] = p;
+      }
+    }
+    if (k < ni && k < 8) {
+      if ((chain >> (2 * k + 1)) & 1u) {
+        const U128 C = ((chain >> (2 * k)) & 1u) ? X : R;
+        p = u128_ctz(u128_andn(u128(~C.lo, ~C.hi), u128_below(p)));  // the first byte at or behind p off the class
+      } else {
+        ++p;
+      }
+    }
+  }
+}
+
+
+constexpr uint32_t kChainCounted = 1u << 23;  // some item is counted, or a `\\b` stands at an end: the general form
+// the items' repetition counts (chain_item), a byte each: the two words in front of the suffix / group-map words at the image's
+// end (read where the general form runs, not kept in the view: the plain form's kernels do not pay registers for them)
+CS_HD unsigned long long chain_crep(const int32_t* img) {
+  const int at = img[15] - 2 - (int)(((uint32_t)img[30] >> 20) & 1u) - ((((uint32_t)img[30] >> 21) & 7u) ? 1 : 0);
+  return (unsigned long long)(uint32_t)img[at] | ((unsigned long long)(uint32_t)img[at + 1] << 32);
+}
+CS_HD U128 chain_ends(U128 R, U128 X, uint32_t chain, const int32_t* img) {
+  if (chain & kChainCounted) return chain_ends_counted(R, X, chain, chain_crep(img));
+  return chain_ends_plain(R, X, chain);
+}
+template <class ByteAt>
+CS_HD void chain_match(U128 R, U128 X, uint32_t chain, const int32_t* img, U128& S, U128& L, uint32_t sfx, int n, ByteAt&& byte_at) {
+  if (chain & kChainCounted) chain_match_counted(R, X, chain, chain_crep(img), S, L, sfx, n, byte_at);
+  else chain_match_plain(R, X, chain, S, L, sfx, n, byte_at);
+}
+CS_HD void chain_group_bounds(U128 R, U128 X, uint32_t chain, const int32_t* img, uint32_t gmap, int mb, int gb[4], int ge[4]) {
+  if (chain & kChainCounted) chain_group_bounds_counted(R, X, chain, chain_crep(img), gmap, mb, gb, ge);
+  else chain_group_bounds_plain(R, X, chain, gmap, mb, gb, ge);
+}
+
 struct View {
   const int32_t* img;
   const uint32_t* init;
@@ -308,7 +469,6 @@ struct View {
   uint32_t skippack, cand0, cand1, cand2, cand3, word0, word1, word2, word3;
   uint32_t units;  // header word 31
   uint32_t chain;  // bits 0..15 the items, bits 16..19 their number (header words 29 / 30, upper halves), bits 20..22 suffix bytes, 24 / 25 `\\b` in front / behind
-  unsigned long long crep;  // the items' repetition counts (chain_item), a byte each
   uint32_t sfx;    // the suffix bytes
 };
 CS_HD View make_view(const int32_t* img) {
@@ -340,13 +500,8 @@ CS_HD View make_view(const int32_t* img) {
   v.word3 = (uint32_t)img[28];
   v.units = (uint32_t)img[31];
   v.chain = (((uint32_t)img[29] >> 16) & 0xFFFFu) | ((((uint32_t)img[30] >> 16) & 15u) << 16) | ((((uint32_t)img[30] >> 21) & 7u) << 20);
-  v.chain |= (((uint32_t)img[30] >> 24) & 3u) << 24;
+  v.chain |= ((((uint32_t)img[30] >> 24) & 3u) << 24) | ((((uint32_t)img[30] >> 26) & 1u) << 23);
   v.sfx = ((uint32_t)img[30] >> 21) & 7u ? (uint32_t)img[img[15] - 1 - (int)(((uint32_t)img[30] >> 20) & 1u)] : 0u;
-  v.crep = 0;
-  if (v.chain >> 16) {  // the two words in front of the suffix / group-map words at the image's end
-    const int at = img[15] - 2 - (int)(((uint32_t)img[30] >> 20) & 1u) - ((((uint32_t)img[30] >> 21) & 7u) ? 1 : 0);
-    v.crep = (unsigned long long)(uint32_t)img[at] | ((unsigned long long)(uint32_t)img[at + 1] << 32);
-  }
   {
     const uint32_t lo1 = (uint32_t)img[29] & 255u, hi1 = ((uint32_t)img[29] >> 8) & 255u;
     const uint32_t lo2 = (uint32_t)img[30] & 255u, hi2 = ((uint32_t)img[30] >> 8) & 255u;
@@ -1364,7 +1519,7 @@ inline bool row_chain_host(cstd::Tdfa& vm, cstd::U128& S, cstd::U128& L) {
       if (i < 64) X.lo |= 1ull << i;
       else X.hi |= 1ull << (i - 64);
     }
-  cstd::chain_match(cstd::u128(c0 | ((unsigned long long)c1 << 32), c2), X, vm.D.chain, vm.D.crep, S, L, vm.D.sfx, vm.n, [&](int i) { return vm.s[i]; });
+  cstd::chain_match(cstd::u128(c0 | ((unsigned long long)c1 << 32), c2), X, vm.D.chain, vm.D.img, S, L, vm.D.sfx, vm.n, [&](int i) { return vm.s[i]; });
   return true;
 }
 #endif
@@ -1491,7 +1646,7 @@ CS_HD void row_replace_matches(cstd::Tdfa& vm, int maxrepl, Emit&& emit) {
         if (i < 64) X.lo |= 1ull << i;
         else X.hi |= 1ull << (i - 64);
       }
-    cstd::chain_match(R, X, vm.D.chain, vm.D.crep, S, L, vm.D.sfx, vm.n, [&](int i) { return vm.s[i]; });
+    cstd::chain_match(R, X, vm.D.chain, vm.D.img, S, L, vm.D.sfx, vm.n, [&](int i) { return vm.s[i]; });
     while (cstd::u128_any(S)) {
       emit(cstd::u128_ctz(S), cstd::u128_ctz(L) + 1, 1);
       S = cstd::u128_clear_lowest(S);

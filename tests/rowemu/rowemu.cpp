@@ -309,7 +309,7 @@ int emu_regex_units(const emu_regex* re) { return re->tdfa.empty() ? 0 : re->tdf
 int emu_regex_chain(const emu_regex* re) { return re->tdfa.empty() ? 0 : (int)cstd::make_view(re->tdfa.data()).chain; }
 // the chain's suffix bytes (first byte lowest; their number in bits 20..22 of emu_regex_chain)
 // the chain's repetition counts (regex_tdfa.h: chain_item), a byte per item
-unsigned long long emu_regex_chain_rep(const emu_regex* re) { return re->tdfa.empty() ? 0 : cstd::make_view(re->tdfa.data()).crep; }
+unsigned long long emu_regex_chain_rep(const emu_regex* re) { return re->tdfa.empty() || !(cstd::make_view(re->tdfa.data()).chain >> 16) ? 0 : cstd::chain_crep(re->tdfa.data()); }
 int emu_regex_chain_sfx(const emu_regex* re) { return re->tdfa.empty() ? 0 : (int)cstd::make_view(re->tdfa.data()).sfx; }
 // 0: chain patterns keep the unit route in replace_re (both routes are checked against the oracle)
 void emu_set_chain(int on) { cstd::g_chain_host = on; }
