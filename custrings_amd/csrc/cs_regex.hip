@@ -417,6 +417,15 @@ __device__ __forceinline__ TCtx tsetup(const TLaunch& L, const uint8_t* flags, u
     for (int i = threadIdx.x; i < L.tdfa_words; i += blockDim.x) smem[i] = (uint32_t)L.tdfa[i];
     __syncthreads();
     c.D = cstd::make_view((const int32_t*)smem);
+  } else if (L.in_lds == 2) {
+    // the tables stay in memory, the header and the image's last words (suffix, repetition counts, group map) come into LDS:
+    // what the hot loops read of the image -- as scalar loads from memory each read also waited for every LDS access in flight
+    // (replace_re of the dotted quad on this form: 5.1 against 4.7 ms)
+    if (threadIdx.x < cstd::kHeadTailWords)
+      smem[threadIdx.x] = threadIdx.x == 15 ? (uint32_t)cstd::kHeadTailWords
+                                            : (uint32_t)L.tdfa[threadIdx.x < 32 ? (int)threadIdx.x : L.tdfa_words - cstd::kHeadTailWords + (int)threadIdx.x];
+    __syncthreads();
+    c.D = cstd::make_view((const int32_t*)smem, L.tdfa);
   } else {
     c.D = cstd::make_view(L.tdfa);
   }
@@ -2872,23 +2881,24 @@ void scan(const cs_column* col, cs_regex* re, uint8_t* out8, int32_t* out32, int
     // they stay in memory, as in cs_replace_re)
     const bool chain_scan = units && MODE == 2 && !bits_form && ((re->tdfa[30] >> 16) & 15) != 0 && !sample_has_high_bytes(col, s) && !cs::cfg("CS_NO_CHAIN_FORM");
     // (the bit form is such a form too: its sub-tiles of plain ASCII never touch the automaton)
-    const bool chain_global = (chain_scan || bits_form) && lds > 40 * 1024 && lds - tp.lds_bytes <= 40 * 1024 && !cs::cfg("CS_CHAIN_TABLES_IN_LDS");
-    if (chain_global) lds -= tp.lds_bytes;
+    const bool chain_global = (chain_scan || bits_form) && lds > 40 * 1024 && lds - tp.lds_bytes + cstd::kHeadTailWords * 4 <= 40 * 1024 && !cs::cfg("CS_CHAIN_TABLES_IN_LDS");
+    const size_t scan_tbl = chain_global ? (size_t)cstd::kHeadTailWords * 4 : tp.lds_bytes;  // (header + tail words: tsetup)
+    if (chain_global) lds -= tp.lds_bytes - scan_tbl;
     if (tc.R && lds <= 150 * 1024) {
       ScanStreamArgs sa{};
       sa.in = view_of(col);
       sa.flags = d_unicode_flags();
       sa.L = tp.d;
-      if (chain_global) sa.L.in_lds = 0;
+      if (chain_global) sa.L.in_lds = 2;
       sa.out8 = out8;
       sa.out32 = out32;
       sa.found = ptr<unsigned long long>(cnt);
       sa.nsub = (col->rows + tc.R - 1) / tc.R;
       sa.rows_per_tile = tc.R;
       sa.cap_in = cap;
-      sa.tbl_bytes = (int)((chain_global ? 0 : tp.lds_bytes) + bits_lds);
+      sa.tbl_bytes = (int)(scan_tbl + bits_lds);
       sa.bits = bits_form ? ptr<const int32_t>(re->d_bits) : nullptr;
-      sa.bits_off = chain_global ? 0 : (int)tp.lds_bytes;
+      sa.bits_off = (int)scan_tbl;
       sa.bits_words = bits_form ? (int)re->bits.size() : 0;
       sa.bits_k = bits_form ? re->bits[1] : 0;
       auto kern = tc.lng ? &k_tdfa_scan_stream<MODE, true, true> : &k_tdfa_scan_stream<MODE, true, false>;
@@ -3213,15 +3223,15 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
         // (bytes >= 0x80, a row beyond the masks) walks them there, and the sample says those are rare.
         const size_t tile_lds = gt_bytes + bits_lds + (size_t)(cap + cap_out + 64 + (cap >> 3) + 32 + unit_bytes) * 4 + 16;
         constexpr size_t kThird = 160 * 1024 / 3;
-        const bool chain_global = chain_form && tbl + tile_lds > kThird && tile_lds <= kThird && !cs::cfg("CS_CHAIN_TABLES_IN_LDS");
-        const size_t tbl_lds = (chain_global || bchain) ? 0 : tbl;
+        const bool chain_global = chain_form && ((tbl + tile_lds > kThird && tile_lds + cstd::kHeadTailWords * 4 <= kThird) || cs::cfg("CS_CHAIN_TABLES_IN_MEMORY")) && !cs::cfg("CS_CHAIN_TABLES_IN_LDS");
+        const size_t tbl_lds = (chain_global || bchain) ? (size_t)cstd::kHeadTailWords * 4 : tbl;  // (header + tail words: tsetup)
         const size_t lds1 = tbl_lds + tile_lds;
         if (lds1 > 150 * 1024) return -1;
         StreamArgs sa{};
         sa.in = view_of(col);
         sa.flags = d_unicode_flags();
         sa.L = tp.d;
-        if (chain_global || bchain) sa.L.in_lds = 0;
+        if (chain_global || bchain) sa.L.in_lds = 2;
         sa.repl = ptr<const uint8_t>(d_repl);
         sa.rb = rb;
         sa.maxrepl = maxrepl;
@@ -3789,8 +3799,9 @@ int cs_findall(const cs_column* col, const cs_regex* cre, cs_stream stream, cs_c
       const bool units = ((re->tdfa[31] & 1) != 0 || ((re->tdfa[30] >> 16) & 15) != 0) && !tc.lng && tc.R == 64 && !cs::cfg("CS_NO_UNITS");
       size_t lds = tp.lds_bytes + (size_t)(cap + 32 + (cap >> 3) + 32 + (units ? (cap >> 3) + 32 + kUnitQueue * 4 + 64 * 4 + 16 : 0)) * 4;
       const bool chain_scan = units && ((re->tdfa[30] >> 16) & 15) != 0 && !sample_has_high_bytes(col, s) && !cs::cfg("CS_NO_CHAIN_FORM");
-      const bool chain_global = chain_scan && tp.d.in_lds && lds > 40 * 1024 && lds - tp.lds_bytes <= 40 * 1024 && !cs::cfg("CS_CHAIN_TABLES_IN_LDS");  // (as in count_re)
-      if (chain_global) lds -= tp.lds_bytes;
+      const bool chain_global = chain_scan && tp.d.in_lds && lds > 40 * 1024 && lds - tp.lds_bytes + cstd::kHeadTailWords * 4 <= 40 * 1024 && !cs::cfg("CS_CHAIN_TABLES_IN_LDS");  // (as in count_re)
+      const size_t scan_tbl = chain_global ? (size_t)cstd::kHeadTailWords * 4 : tp.lds_bytes;
+      if (chain_global) lds -= tp.lds_bytes - scan_tbl;
       if (tp.d.in_lds && tc.R && lds <= 150 * 1024) {
         Buf hits = dev_alloc(8, s);
         CS_HIP(hipMemsetAsync(hits->p, 0, 8, s));
@@ -3802,8 +3813,8 @@ int cs_findall(const cs_column* col, const cs_regex* cre, cs_stream stream, cs_c
         sa.nsub = (rows + tc.R - 1) / tc.R;
         sa.rows_per_tile = tc.R;
         sa.cap_in = cap;
-        sa.tbl_bytes = chain_global ? 0 : (int)tp.lds_bytes;
-        if (chain_global) sa.L.in_lds = 0;
+        sa.tbl_bytes = (int)scan_tbl;
+        if (chain_global) sa.L.in_lds = 2;
         sa.maxp = ptr<int>(dmax);
         auto kern = tc.lng ? &k_tdfa_scan_stream<3, true, true> : &k_tdfa_scan_stream<3, true, false>;
         if (units) kern = &k_tdfa_scan_stream<3, true, false, true>;

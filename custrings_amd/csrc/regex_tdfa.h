@@ -471,21 +471,25 @@ struct View {
   uint32_t chain;  // bits 0..15 the items, bits 16..19 their number (header words 29 / 30, upper halves), bits 20..22 suffix bytes, 24 / 25 `\\b` in front / behind
   uint32_t sfx;    // the suffix bytes
 };
-CS_HD View make_view(const int32_t* img) {
+// (`tables`: where the tables lie when `img` is only a copy of the header and of the image's last words -- cs_regex.hip,
+// tsetup: the forms that leave the tables in memory keep those 40 words in LDS, kHeadTailWords)
+constexpr int kHeadTailWords = 40;  // the 32 header words and the last 8 of the image (word 15 of the copy says 40)
+CS_HD View make_view(const int32_t* img, const int32_t* tables = nullptr) {
   View v;
   v.img = img;
+  if (!tables) tables = img;
   v.nstates = img[1];
   v.natoms = img[2];
   v.npreds = img[3];
   v.nna = img[4];
   v.uses = img[5];
-  v.init = (const uint32_t*)(img + img[6]);
-  v.t1 = (const uint32_t*)(img + img[7]);
-  v.t2 = (const uint32_t*)(img + img[8]);
-  v.preds = img + img[9];
-  v.atomsig = (const uint32_t*)(img + img[10]);
-  v.act = (const uint32_t*)(img + img[11]);
-  v.cat = (const uint32_t*)(img + img[14]);
+  v.init = (const uint32_t*)(tables + img[6]);
+  v.t1 = (const uint32_t*)(tables + img[7]);
+  v.t2 = (const uint32_t*)(tables + img[8]);
+  v.preds = tables + img[9];
+  v.atomsig = (const uint32_t*)(tables + img[10]);
+  v.act = (const uint32_t*)(tables + img[11]);
+  v.cat = (const uint32_t*)(tables + img[14]);
   v.nskip = (uint32_t)img[16];
   // idle state per category, 8 bits each (idle states have ids < 8)
   v.skippack = ((uint32_t)img[17] & 255u) | (((uint32_t)img[18] & 255u) << 8) | (((uint32_t)img[19] & 255u) << 16) |
