@@ -1657,8 +1657,7 @@ __global__ void __launch_bounds__(256, ((BREFS && !CHAIN) || BITS) ? 2 : CS_STRE
           p_second = cstile::status_load(a.excl + (p_tile >= 0 ? p_tile : 0));
           has_second = scanner;
           if (live) {
-            chain_match(u128(r0 | ((unsigned long long)r1 << 32), r2), u128(x0 | ((unsigned long long)x1 << 32), x2), D.chain, D.img, uS, uE, D.sfx, n,
-                        [&](int i) { return lds_in[lead + rbeg + i]; });
+            chain_match96(r0, r1, r2, x0, x1, x2, D.chain, D.img, uS, uE, D.sfx, n, [&](int i) { return lds_in[lead + rbeg + i]; });
             nm = u128_popc(uS);
             out_len = n - u128_popc(u128_sub(u128_shl1(uE), uS)) + nm * rb;
             from_masks = true;
@@ -1678,7 +1677,7 @@ __global__ void __launch_bounds__(256, ((BREFS && !CHAIN) || BITS) ? 2 : CS_STRE
           p_second = cstile::status_load(a.excl + (p_tile >= 0 ? p_tile : 0));
           has_second = scanner;
           if (live) {
-            chain_match(R, X, D.chain, D.img, uS, uE, D.sfx, n, [&](int i) { return lds_in[lead + rbeg + i]; });
+            chain_match96(r0, r1, r2, x0, x1, x2, D.chain, D.img, uS, uE, D.sfx, n, [&](int i) { return lds_in[lead + rbeg + i]; });
             nm = u128_popc(uS);
             from_masks = true;
           }
@@ -2351,7 +2350,7 @@ __global__ void __launch_bounds__(256, MODE == 4 ? 3 : CHAIN ? 4 : (UNITS && MOD
           if (unit_x != 0) cstile::row_bits96(xbitmap, lead + rbeg, n, x0w, x1w, x2w);
           const U128 Rm = u128(r0w | ((unsigned long long)r1w << 32), r2w), Xm = u128(x0w | ((unsigned long long)x1w << 32), x2w);
           U128 S = u128(0, 0), E = u128(0, 0);
-          if (live) chain_match(Rm, Xm, D.chain, D.img, S, E, D.sfx, n, [&](int i) { return lds_in[lead + rbeg + i]; });
+          if (live) chain_match96(r0w, r1w, r2w, x0w, x1w, x2w, D.chain, D.img, S, E, D.sfx, n, [&](int i) { return lds_in[lead + rbeg + i]; });
           const bool hit = live && u128_any(S);
           v = hit;
           int gb[4], ge[4];
@@ -2465,8 +2464,7 @@ __global__ void __launch_bounds__(256, MODE == 4 ? 3 : CHAIN ? 4 : (UNITS && MOD
           if (unit_x != 0) cstile::row_bits96(xbitmap, lead + rbeg, n, x0, x1, x2);
           if (live) {
             U128 S, E;
-            chain_match(u128(r0 | ((unsigned long long)r1 << 32), r2), u128(x0 | ((unsigned long long)x1 << 32), x2), D.chain, D.img, S, E, D.sfx, n,
-                        [&](int i) { return lds_in[lead + rbeg + i]; });
+            chain_match96(r0, r1, r2, x0, x1, x2, D.chain, D.img, S, E, D.sfx, n, [&](int i) { return lds_in[lead + rbeg + i]; });
             while (u128_any(S)) {
               const int mb = u128_ctz(S), me = u128_ctz(E) + 1;
               S = u128_clear_lowest(S);
@@ -2551,11 +2549,11 @@ __global__ void __launch_bounds__(256, MODE == 4 ? 3 : CHAIN ? 4 : (UNITS && MOD
             v = live && u128_any(chain_suffix_filter(chain_ends(R, X, D.chain, D.img), D.chain, D.sfx, n, [&](int i) { return lds_in[lead + rbeg + i]; })) ? 1 : 0;
           } else if (MODE == 0) {
             U128 S = u128(0, 0), E;
-            if (live) chain_match(R, X, D.chain, D.img, S, E, D.sfx, n, [&](int i) { return lds_in[lead + rbeg + i]; });
+            if (live) chain_match96(r0, r1, r2, x0, x1, x2, D.chain, D.img, S, E, D.sfx, n, [&](int i) { return lds_in[lead + rbeg + i]; });
             v = u128_any(S) ? 1 : 0;
           } else {
             U128 S = u128(0, 0), E;
-            if (live) chain_match(R, X, D.chain, D.img, S, E, D.sfx, n, [&](int i) { return lds_in[lead + rbeg + i]; });
+            if (live) chain_match96(r0, r1, r2, x0, x1, x2, D.chain, D.img, S, E, D.sfx, n, [&](int i) { return lds_in[lead + rbeg + i]; });
             v = u128_popc(S);
           }
           redo = false;

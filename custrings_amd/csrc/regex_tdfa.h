@@ -150,7 +150,7 @@ CS_HD int unit_start(U128 N, int q) { return u128_msb(u128_andn(u128_below(q), N
 // R, X: row-relative bits cut at the row length (rows of up to 96 bytes).  S / L receive a bit per match at its first /
 // last byte.  ~300 integer operations a row whatever it holds, against a table walk per candidate byte.
 #if !defined(__HIP_DEVICE_COMPILE__)
-inline int g_chain_host = 1;  // host builds (tests/rowemu): 0 keeps chain patterns on the unit route, so that both are checked
+inline int g_chain_host = 1;  // host builds (tests/rowemu): 0 keeps chain patterns on the unit route, 2 runs the two-half form of the arithmetic, so that all are checked
 #endif
 CS_HD U128 u128_xor(U128 a, U128 b) { return u128(a.lo ^ b.lo, a.hi ^ b.hi); }
 CS_HD U128 u128_shr1(U128 a) { return u128((a.lo >> 1) | (a.hi << 63), a.hi >> 1); }
@@ -432,6 +432,184 @@ CS_HD void chain_group_bounds_plain(U128 R, U128 X, uint32_t chain, uint32_t gma
 }
 
 
+// ---- the plain form on THREE 32-bit words (rows of at most 95 bytes: the kernels take these forms up to 93): a quarter fewer
+// ---- integer operations than on two 64-bit halves -- every 64-bit operation is two 32-bit ones on this machine, the fourth word
+// ---- was always zero.  Positions reverse as p -> 94 - p (the backward walk ends one beyond the start: bit 95 for a start at 0).
+struct W96 {
+  uint32_t a, b, c;
+};
+CS_HD W96 w96(uint32_t a, uint32_t b, uint32_t c) {
+  W96 r;
+  r.a = a;
+  r.b = b;
+  r.c = c;
+  return r;
+}
+CS_HD W96 w_and(W96 x, W96 y) { return w96(x.a & y.a, x.b & y.b, x.c & y.c); }
+CS_HD W96 w_or(W96 x, W96 y) { return w96(x.a | y.a, x.b | y.b, x.c | y.c); }
+CS_HD W96 w_xor(W96 x, W96 y) { return w96(x.a ^ y.a, x.b ^ y.b, x.c ^ y.c); }
+CS_HD W96 w_andn(W96 x, W96 y) { return w96(x.a & ~y.a, x.b & ~y.b, x.c & ~y.c); }  // x & ~y
+CS_HD bool w_any(W96 x) { return (x.a | x.b | x.c) != 0; }
+CS_HD W96 w_shl1(W96 x) { return w96(x.a << 1, (x.b << 1) | (x.a >> 31), (x.c << 1) | (x.b >> 31)); }
+CS_HD W96 w_shr1(W96 x) { return w96((x.a >> 1) | (x.b << 31), (x.b >> 1) | (x.c << 31), x.c >> 1); }
+CS_HD W96 w_add(W96 x, W96 y) {
+  unsigned long long t = (unsigned long long)x.a + y.a;
+  const uint32_t a = (uint32_t)t;
+  t = (unsigned long long)x.b + y.b + (t >> 32);
+  return w96(a, (uint32_t)t, x.c + y.c + (uint32_t)(t >> 32));
+}
+CS_HD uint32_t u32_bitrev(uint32_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __brev(v);
+#else
+  v = ((v >> 1) & 0x55555555u) | ((v & 0x55555555u) << 1);
+  v = ((v >> 2) & 0x33333333u) | ((v & 0x33333333u) << 2);
+  v = ((v >> 4) & 0x0F0F0F0Fu) | ((v & 0x0F0F0F0Fu) << 4);
+  return __builtin_bswap32(v);
+#endif
+}
+CS_HD W96 w_rev94(W96 x) { return w_shr1(w96(u32_bitrev(x.c), u32_bitrev(x.b), u32_bitrev(x.a))); }  // bit p -> bit 94 - p (its own inverse)
+CS_HD int w_ctz(W96 x) { return x.a ? __builtin_ctz(x.a) : (x.b ? 32 + __builtin_ctz(x.b) : 64 + __builtin_ctz(x.c)); }  // x != 0
+CS_HD W96 w_clear_lowest(W96 x) {
+  // x & (x - 1)
+  const uint32_t a = x.a - 1u, b = x.b - (x.a == 0u ? 1u : 0u), c = x.c - ((x.a | x.b) == 0u ? 1u : 0u);
+  return w96(x.a & a, x.b & b, x.c & c);
+}
+CS_HD W96 w_star(W96 M, W96 C) { return w_or(w_xor(w_add(w_and(M, C), C), C), M); }
+CS_HD U128 w_to128(W96 x) { return u128(x.a | ((unsigned long long)x.b << 32), x.c); }
+// chain_match_plain on 96-bit words: the same walks, the same pairing (rows of at most 95 bytes)
+template <class ByteAt>
+CS_HD void chain_match_plain96(W96 R, W96 X, uint32_t chain, U128& S128, U128& L128, uint32_t sfx, int n, ByteAt&& byte_at) {
+  const int ni = (int)((chain >> 16) & 15u);
+  auto is_x = [&](int k) { return ((chain >> (2 * k)) & 1u) != 0; };
+  auto plus = [&](int k) { return ((chain >> (2 * k + 1)) & 1u) != 0; };
+  W96 M = plus(0) ? w_andn(R, w_shl1(R)) : R, C = R;
+  for (int k = 0; k < ni; ++k) {
+    C = is_x(k) ? X : R;
+    M = w_shl1(w_and(M, C));
+    if (plus(k)) M = w_star(M, C);
+  }
+  if (plus(ni - 1)) M = w_andn(M, C);
+  W96 Le = w_shr1(M);
+  const int sl = (int)((chain >> 20) & 7u);
+  if (sl) {  // the suffix: of the ends only those it follows
+    W96 T = Le;
+    while (w_any(T)) {
+      const int l = w_ctz(T);
+      const W96 rest = w_clear_lowest(T);
+      bool ok = l + 1 + sl <= n;
+      for (int k = 0; k < sl && ok; ++k) ok = (uint32_t)byte_at(l + 1 + k) == ((sfx >> (8 * k)) & 255u);
+      if (!ok) Le = w_andn(Le, w_andn(T, rest));
+      T = rest;
+    }
+  }
+  W96 S = w96(0, 0, 0), L = w96(0, 0, 0);
+  if (w_any(Le)) {
+    const W96 Rr = w_rev94(R), Xr = w_rev94(X);
+    M = w_rev94(Le);
+    for (int k = ni - 1; k >= 0; --k) {
+      C = is_x(k) ? Xr : Rr;
+      M = w_shl1(w_and(M, C));
+      if (plus(k)) M = w_star(M, C);
+    }
+    if (plus(0)) M = w_andn(M, C);
+    W96 Sv = w_rev94(w_shr1(M));
+    if (sl) {  // (the match's last byte is the suffix's; rows end within 95 bytes, the shift loses nothing)
+      const unsigned long long lo = (unsigned long long)Le.a | ((unsigned long long)Le.b << 32);
+      Le = w96((uint32_t)(lo << sl), (uint32_t)((lo << sl) >> 32), (Le.c << sl) | (uint32_t)(lo >> (64 - sl)));
+    }
+    int cursor = 0;
+    while (w_any(Sv) && w_any(Le)) {
+      const int s = w_ctz(Sv), l = w_ctz(Le);
+      const W96 sr = w_clear_lowest(Sv), lr = w_clear_lowest(Le);
+      if (s >= cursor) {
+        S = w_or(S, w_andn(Sv, sr));
+        L = w_or(L, w_andn(Le, lr));
+        cursor = l + 1;
+      }
+      Sv = sr;
+      Le = lr;
+    }
+  }
+  S128 = w_to128(S);
+  L128 = w_to128(L);
+}
+// ... and the general form (counted items, `\\b`) on the same words
+CS_HD W96 chain_item96(W96 M, W96 C, uint32_t rep) {
+  M = w_shl1(w_and(M, C));
+  if (rep == 0x11u) return M;
+  if (rep == 0x01u) return w_star(M, C);
+  const int least = (int)(rep & 15u), most = (int)(rep >> 4);
+  for (int i = 1; i < least; ++i) M = w_shl1(w_and(M, C));
+  if (most == 0) return w_star(M, C);
+  W96 T = M;
+  for (int i = least; i < most; ++i) {
+    T = w_shl1(w_and(T, C));
+    M = w_or(M, T);
+  }
+  return M;
+}
+template <class ByteAt>
+CS_HD void chain_match_counted96(W96 R, W96 X, uint32_t chain, unsigned long long crep, U128& S128, U128& L128, uint32_t sfx, int n, ByteAt&& byte_at) {
+  CS_CHAIN_UNIFORM(chain, crep);
+  const int ni = (int)((chain >> 16) & 15u);
+  auto is_x = [&](int k) { return ((chain >> (2 * k)) & 1u) != 0; };
+  W96 M = chain_runs(crep, 0) ? w_andn(R, w_shl1(R)) : R, C = R;
+  for (int k = 0; k < ni; ++k) {
+    C = is_x(k) ? X : R;
+    M = chain_item96(M, C, chain_rep(crep, k));
+  }
+  if (chain_runs(crep, ni - 1)) M = w_andn(M, C);
+  W96 Le = w_shr1(M);
+  const int sl = (int)((chain >> 20) & 7u);
+  const bool tb = (chain & kChainTrailB) != 0, lb = (chain & kChainLeadB) != 0;
+  if (sl || tb) {  // the suffix / the closing `\\b`: of the ends only those it follows
+    W96 T = Le;
+    while (w_any(T)) {
+      const int l = w_ctz(T);
+      const W96 rest = w_clear_lowest(T);
+      bool ok = l + 1 + sl <= n;
+      for (int k = 0; k < sl && ok; ++k) ok = (uint32_t)byte_at(l + 1 + k) == ((sfx >> (8 * k)) & 255u);
+      if (tb && l + 1 < n) ok = !chain_word_byte((uint32_t)byte_at(l + 1));
+      if (!ok) Le = w_andn(Le, w_andn(T, rest));
+      T = rest;
+    }
+  }
+  W96 S = w96(0, 0, 0), L = w96(0, 0, 0);
+  if (w_any(Le)) {
+    const W96 Rr = w_rev94(R), Xr = w_rev94(X);
+    M = w_rev94(Le);
+    for (int k = ni - 1; k >= 0; --k) {
+      C = is_x(k) ? Xr : Rr;
+      M = chain_item96(M, C, chain_rep(crep, k));
+    }
+    if (chain_runs(crep, 0)) M = w_andn(M, C);
+    W96 Sv = w_rev94(w_shr1(M));
+    if (sl) {
+      const unsigned long long lo = (unsigned long long)Le.a | ((unsigned long long)Le.b << 32);
+      Le = w96((uint32_t)(lo << sl), (uint32_t)((lo << sl) >> 32), (Le.c << sl) | (uint32_t)(lo >> (64 - sl)));
+    }
+    int cursor = 0;
+    while (w_any(Sv) && w_any(Le)) {
+      const int s = w_ctz(Sv), l = w_ctz(Le);
+      const W96 sr = w_clear_lowest(Sv), lr = w_clear_lowest(Le);
+      if (s >= cursor && !(lb && s > 0 && chain_word_byte((uint32_t)byte_at(s - 1)))) {
+        S = w_or(S, w_andn(Sv, sr));
+        L = w_or(L, w_andn(Le, lr));
+        cursor = l + 1;
+      }
+      Sv = sr;
+      Le = lr;
+    }
+  }
+  S128 = w_to128(S);
+  L128 = w_to128(L);
+}
+// the row's masks as they come out of the bitmaps (three words each)
+template <class ByteAt>
+CS_HD void chain_match96(uint32_t r0, uint32_t r1, uint32_t r2, uint32_t x0, uint32_t x1, uint32_t x2, uint32_t chain, const int32_t* img, U128& S, U128& L,
+                         uint32_t sfx, int n, ByteAt&& byte_at);
+
 constexpr uint32_t kChainCounted = 1u << 23;  // some item is counted, or a `\\b` stands at an end: the general form
 // the items' repetition counts (chain_item), a byte each: the two words in front of the suffix / group-map words at the image's
 // end (read where the general form runs, not kept in the view: the plain form's kernels do not pay registers for them)
@@ -447,6 +625,12 @@ template <class ByteAt>
 CS_HD void chain_match(U128 R, U128 X, uint32_t chain, const int32_t* img, U128& S, U128& L, uint32_t sfx, int n, ByteAt&& byte_at) {
   if (chain & kChainCounted) chain_match_counted(R, X, chain, chain_crep(img), S, L, sfx, n, byte_at);
   else chain_match_plain(R, X, chain, S, L, sfx, n, byte_at);
+}
+template <class ByteAt>
+CS_HD void chain_match96(uint32_t r0, uint32_t r1, uint32_t r2, uint32_t x0, uint32_t x1, uint32_t x2, uint32_t chain, const int32_t* img, U128& S, U128& L,
+                         uint32_t sfx, int n, ByteAt&& byte_at) {
+  if (chain & kChainCounted) chain_match_counted96(w96(r0, r1, r2), w96(x0, x1, x2), chain, chain_crep(img), S, L, sfx, n, byte_at);
+  else chain_match_plain96(w96(r0, r1, r2), w96(x0, x1, x2), chain, S, L, sfx, n, byte_at);
 }
 CS_HD void chain_group_bounds(U128 R, U128 X, uint32_t chain, const int32_t* img, uint32_t gmap, int mb, int gb[4], int ge[4]) {
   if (chain & kChainCounted) chain_group_bounds_counted(R, X, chain, chain_crep(img), gmap, mb, gb, ge);
@@ -1523,7 +1707,10 @@ inline bool row_chain_host(cstd::Tdfa& vm, cstd::U128& S, cstd::U128& L) {
       if (i < 64) X.lo |= 1ull << i;
       else X.hi |= 1ull << (i - 64);
     }
-  cstd::chain_match(cstd::u128(c0 | ((unsigned long long)c1 << 32), c2), X, vm.D.chain, vm.D.img, S, L, vm.D.sfx, vm.n, [&](int i) { return vm.s[i]; });
+  if (vm.n <= 95 && cstd::g_chain_host == 1)  // (the three-word form of the replace kernel; g_chain_host 2: the two-half form on every row)
+    cstd::chain_match96(c0, c1, c2, (uint32_t)X.lo, (uint32_t)(X.lo >> 32), (uint32_t)X.hi, vm.D.chain, vm.D.img, S, L, vm.D.sfx, vm.n, [&](int i) { return vm.s[i]; });
+  else
+    cstd::chain_match(cstd::u128(c0 | ((unsigned long long)c1 << 32), c2), X, vm.D.chain, vm.D.img, S, L, vm.D.sfx, vm.n, [&](int i) { return vm.s[i]; });
   return true;
 }
 #endif
@@ -1650,7 +1837,9 @@ CS_HD void row_replace_matches(cstd::Tdfa& vm, int maxrepl, Emit&& emit) {
         if (i < 64) X.lo |= 1ull << i;
         else X.hi |= 1ull << (i - 64);
       }
-    cstd::chain_match(R, X, vm.D.chain, vm.D.img, S, L, vm.D.sfx, vm.n, [&](int i) { return vm.s[i]; });
+    if (vm.n <= 95 && cstd::g_chain_host == 1)  // (the three-word form, as the replace stream kernel runs it)
+      cstd::chain_match96(c0, c1, c2, (uint32_t)X.lo, (uint32_t)(X.lo >> 32), (uint32_t)X.hi, vm.D.chain, vm.D.img, S, L, vm.D.sfx, vm.n, [&](int i) { return vm.s[i]; });
+    else cstd::chain_match(R, X, vm.D.chain, vm.D.img, S, L, vm.D.sfx, vm.n, [&](int i) { return vm.s[i]; });
     while (cstd::u128_any(S)) {
       emit(cstd::u128_ctz(S), cstd::u128_ctz(L) + 1, 1);
       S = cstd::u128_clear_lowest(S);

@@ -310,7 +310,7 @@ def test_chain_patterns_vs_oracle(emu_engine, oracle_engine):
          "1.2.3.4.5.6.7.8.9.10.11.12", "12-34-56", "12-34-567", "012-34-56", "12-34-56-78-90-12", "1999-12 1999-123 x1999-12", "1..2 1...234 1.2x 1.23x 1.234x",
          "ab= abc= abcd= xab= a=", "1.2 3.4", "1.2" + "9" * 93, "9" * 92 + ".1.2", "7.7.7.7" + "." * 89, "1.2.3.4b 1.2.3.4", "0.0.0.0.0.0.0.0a"]
     for pat in [p for p, f in want.items() if f]:
-        for on in (1, 0):
+        for on in (1, 2, 0):  # the three-word arithmetic, the two-half one, the unit route
             e.set_chain(on)
             try:
                 for repl in ("<IP>", "", "0.0"):
