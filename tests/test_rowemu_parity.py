@@ -305,6 +305,9 @@ def test_chain_patterns_vs_oracle(emu_engine, oracle_engine):
          "1.2.3.4" + "x" * 82 + "5.6.7.8", "9" * 96, "1." * 48, ".1" * 48, "a=b=c==", "ab@cd@ef", "1--2-3", "12.3456", "0.0.0.0" * 13, "1.1.1.1é2.2.2.2",
          "1.2.3.4 ", "1.2.3.4 5.6.7.8 ", "1.2.3.4  5.6.7.8", "1.2 -3.4 - 5.6 -", "7ab8ab9a", "1.2:x=.3.4:x=", "ab=>c=>=>", "1-.2-.-.", "1.2.3.4 " * 12, "x" * 88 + "1.2.3.4 ",
          "x" * 89 + "1.2.3.4 ", "1.2.3.4" + " " * 89, "5.6 - 7.8 -9.1 -",
+         # rows of 94 and 95 bytes: the last the three-word arithmetic takes (regex_tdfa.h: chain_match96)
+         "x" * 87 + "1.2.3.4 ", "x" * 88 + "1.2.3.4", "1.2.3.4" + "x" * 81 + "5.6.7.8", "9" * 95, "9" * 94, "1." * 47, ".1" * 47 + "1", "1" + ".1" * 47, "1.2.3.4 " * 11 + "1.2.3.4",
+         "0.0.0.0" * 13 + "0.0.", "a=" * 47 + "a", "1.2.3.4" + " " * 88, " " * 88 + "1.2.3.4", "1.2:x=.3.4:x=." + "7" * 81,
          # word boundaries and run-length bounds: a letter either side, four digits in any octet, candidates that overlap
          "a1.2.3.4", "1.2.3.4a", "a1.2.3.4.5", "1.2.3.4.5a", "1234.5.6.7", "1.2345.6.7", "1.2.3.4567", "123.123.123.123", "1.2.3.4_5.6.7.8", "_1.2.3.4_",
          "1.2.3.4.5.6.7.8.9.10.11.12", "12-34-56", "12-34-567", "012-34-56", "12-34-56-78-90-12", "1999-12 1999-123 x1999-12", "1..2 1...234 1.2x 1.23x 1.234x",
