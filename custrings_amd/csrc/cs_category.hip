@@ -140,7 +140,10 @@ __device__ __forceinline__ unsigned long long slot_word(const uint32_t w[8], int
   return (v & 0x00FFFFFFFFFFFFFFull) | kSlotTag;
 }
 // `dbg` (CS_CAT_DEBUG, measurement only -- wrong results): 1 skips the byte compare, 2 the table.
-__global__ void __launch_bounds__(256) k_cat_insert(ColView in, Entry* table, uint32_t mask,
+// (eight waves a SIMD: the kernel is three dependent trips a row -- offsets, key bytes, slot -- and what bounds it is how many of
+// those chains the resident threads keep in flight: 2.56 -> 2.31 ms at K = 1M against six waves, eleven registers spilled; two
+// rows a thread, phase by phase, at six waves: 2.90 -- the registers of the second row cost more than its trips overlap)
+__global__ void __launch_bounds__(256, 8) k_cat_insert(ColView in, Entry* table, uint32_t mask,
                                                     int32_t* __restrict__ slot_of_row, int* __restrict__ has_null,
                                                     int* __restrict__ overflow, int probe_limit, int dbg, int sw, int64_t stride = 1, int64_t count = -1) {
   // (`stride` / `count`: the sampling launch takes rows 0, stride, 2 stride, ... -- `count` of them; the slot ids it writes
