@@ -270,7 +270,9 @@ def test_gpu_counted_chain_with_its_tables_in_memory():
     o = cpulibs.Col.from_list(rows)
     g = gpuutil.from_col(o)
     f0 = L.lib.cs_fallback_count()
-    for pat in (IPV4B, r"\b\d+\.\d+\b", r"\b(\d{1,3})\.(\d{1,3})\b", r"\d+\.\d{2}\.\d+"):
+    # (the third: counted items, a literal suffix and the tables in memory -- the suffix and the counts come from the image's
+    # last words, staged in LDS beside the header: cs_regex.hip, tsetup)
+    for pat in (IPV4B, r"\b\d+\.\d+\b", r"\b\d{1,3}\.\d{1,3}\.\d{1,3}\.\d{1,3} -", r"\b(\d{1,3})\.(\d{1,3})\b", r"\d+\.\d{2}\.\d+"):
         check_regex_ops(g, o, pat, orc, repls=("<IP>", "", "<a-much-longer-one>"))
         g.replace(pat, "#")
         assert last_route() == "chain", (pat, last_route())
