@@ -22,6 +22,9 @@ TOGGLES = ("CS_REGEX_TWO_PASS", "CS_REGEX_ROWWISE", "CS_SPLIT_GENERIC", "CS_TOKE
 PATS = [(r"\d+\.\d+\.\d+\.\d+", "<IP>"), (r"\d", "#"), (r"[a-c]+", "xyz__"), (r"\s+", " "), (r"\w+", "<w>"), (r"b|ab", ""),
         (r"\bx", "YY"), (r"[0-9]+", "<number-here>"), (r"a", "aa"), (r"(a|b)c", "-"),
         (r"\d+\.\d+ ", "<n>"), (r"[a-c]+=>", ""), (r"\d+ab", "#"),  # (chains with a literal suffix)
+        # chains with counted items and `\b` (regex_tdfa.h: chain_match_counted96)
+        (r"\b\d{1,3}\.\d{1,3}\.\d{1,3}\.\d{1,3}\b", "<IP>"), (r"\b\d+\.\d+\b", ""), (r"\d+\.\d{2}\.\d+", "#"), (r"\b[a-c]{2,3}=", "<a-longer-replacement>"),
+        (r"\d\d+\.\d+", "."), (r"\d+\.{1,2}\d+", "x"),
         # the bit-parallel form (regex_bits.h) and the single-class byte-parallel route (cs_runs.hip)
         (r"(\bab\b)|(\bc\b)|(\bxyz\b)", "="), (r"[abc1]+", "*"), (r"ab|a1|bc", "#"), (r"[^ ]+", "_"), (r".", "?"), (r"x?y?z", "Q")]
 
@@ -91,11 +94,12 @@ def snapshot(g, rows, rng_seed):
         out["split %r %d" % (d, n)] = [gpuutil.to_col(c) for c in g.split(d, n)]
     for d, n in ((" ", 2), (None, 1), ("ab", -1), ("aa", -1)):
         out["rsplit %r %d" % (d, n)] = [gpuutil.to_col(c) for c in g.rsplit(d, n)]
-    for pat in (r"(\d+)\.(\d+)", r"(a|b)(c)?", r"(\w+) (\w+)"):
+    for pat in (r"(\d+)\.(\d+)", r"(a|b)(c)?", r"(\w+) (\w+)", r"\b(\d{1,3})\.(\d{1,3})\b"):
         out["extract %r" % pat] = [gpuutil.to_col(c) for c in g.extract(pat)]
-    for pat in (r"\d+", r"[a-c]+"):
+    for pat in (r"\d+", r"[a-c]+", r"\b\d+\.\d+\b"):
         out["findall %r" % pat] = [gpuutil.to_col(c) for c in g.findall(pat)]
-    for pat, repl in ((r"(\d+)\.(\d+)", r"\2.\1"), (r"(a|b)(c)?", r"<\2\1\0>")):
+    for pat, repl in ((r"(\d+)\.(\d+)", r"\2.\1"), (r"(a|b)(c)?", r"<\2\1\0>"), (r"\b(\d{1,3})\.(\d{1,3})\b", r"\2\2-\1"), (r"(\d+)\.(\d+)", r"[\0|\1]"),
+                      (r"([a-c]+)=", r"=\1\1")):
         out["backrefs %r %r" % (pat, repl)] = gpuutil.to_col(g.replace_with_backrefs(pat, repl))
     tok = nvtext.tokenize(g)
     out["tokenize"] = gpuutil.to_col(tok)
