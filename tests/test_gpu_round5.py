@@ -359,6 +359,52 @@ def test_gpu_full_size_headline_routes_agree():
     assert fast_rep == slow_rep
 
 
+def test_gpu_full_size_round5_forms_agree_with_the_two_pass_kernels():
+    """The forms added late in round 5, on the FULL 100M-row C3 column, each against an independent implementation by digest:
+    replace_re of the counted dotted quad with `\\b` (the counted chain arithmetic on three words, tables in memory) and
+    replace_with_backrefs (the backrefs chain form, out tile sized from the template) against the two-pass size / write kernels on
+    the tagged DFA; contains_re / count_re of the gtest pattern (bit form, tables in memory) against the row-wise scan."""
+    L = gpuutil.lib()
+    g = gpuutil.synth(3, 0, 100_000_000)
+    quad, tmpl = r"(\d+)\.(\d+)\.(\d+)\.(\d+)", r"\4.\3.\2.\1"
+    f0 = L.lib.cs_fallback_count()
+    fast = g.replace(IPV4B, "<IP>")
+    assert last_route() == "chain"
+    fast = fast.digest()
+    fastb = g.replace_with_backrefs(quad, tmpl)
+    assert last_route() == "brefs-chain"
+    fastb = fastb.digest()
+    res = np.zeros(g.size(), dtype=np.uint8)
+    cnt = np.zeros(g.size(), dtype=np.int32)
+    found = C.c_int64()
+    re = gpuutil.compile_re(GTEST)
+    try:
+        L.check(L.lib.cs_contains_re(g.m_cptr, re, res.ctypes.data, 0, None, C.byref(found)))
+        assert last_route() == "bits"
+        fast_found = found.value
+        L.check(L.lib.cs_count_re(g.m_cptr, re, cnt.ctypes.data, 0, None, C.byref(found)))
+        assert last_route() == "bits"
+        fast_hits, fast_sum, fast_res = found.value, int(cnt.sum(dtype=np.int64)), res.copy()
+        assert L.lib.cs_fallback_count() == f0
+        for name in ("CS_REGEX_TWO_PASS", "CS_BACKREFS_TWO_PASS", "CS_REGEX_ROWWISE"):
+            L.check(L.lib.cs_config_set(name.encode(), b"1"))
+        try:
+            slow = g.replace(IPV4B, "<IP>")
+            assert last_route() == ""
+            slow = slow.digest()
+            slowb = g.replace_with_backrefs(quad, tmpl).digest()
+            L.check(L.lib.cs_contains_re(g.m_cptr, re, res.ctypes.data, 0, None, C.byref(found)))
+            assert last_route() == "" and found.value == fast_found and np.array_equal(res, fast_res)
+            L.check(L.lib.cs_count_re(g.m_cptr, re, cnt.ctypes.data, 0, None, C.byref(found)))
+            assert found.value == fast_hits and int(cnt.sum(dtype=np.int64)) == fast_sum
+        finally:
+            for name in ("CS_REGEX_TWO_PASS", "CS_BACKREFS_TWO_PASS", "CS_REGEX_ROWWISE"):
+                L.check(L.lib.cs_config_set(name.encode(), None))
+    finally:
+        L.lib.cs_regex_destroy(re)
+    assert fast == slow and fastb == slowb
+
+
 def _mix64(z):
     z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
     z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
