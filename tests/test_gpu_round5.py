@@ -441,10 +441,19 @@ def test_gpu_full_size_headline_vs_oracle_10m_rows():
     g = gpuutil.synth(3, 0, total)
     cols = g.split(" ")
     rep = g.replace(IPV4, "<IP>")
-    prog = os.path.join(tempfile.mkdtemp(prefix="cs_digest_"), "ipv4.npy")
+    tmpd = tempfile.mkdtemp(prefix="cs_digest_")
+    prog = os.path.join(tmpd, "ipv4.npy")
     np.save(prog, blob_of(IPV4))
+    # (the forms added late in round 5 ride along: the counted dotted quad with `\\b`, replace_with_backrefs on the chain form)
+    quad, tmpl = r"(\d+)\.(\d+)\.(\d+)\.(\d+)", r"\4.\3.\2.\1"
+    more = {"replace_b": g.replace(IPV4B, "<IP>"), "backrefs": g.replace_with_backrefs(quad, tmpl)}
+    assert last_route() == "brefs-chain"
+    np.save(os.path.join(tmpd, "ipv4b.npy"), blob_of(IPV4B))
+    np.save(os.path.join(tmpd, "quad.npy"), blob_of(quad))
+    with open(os.path.join(tmpd, "extra.json"), "w") as f:
+        json.dump([["replace_b", "replace", os.path.join(tmpd, "ipv4b.npy"), "<IP>"], ["backrefs", "backrefs", os.path.join(tmpd, "quad.npy"), tmpl]], f)
     worker = os.path.join(cpulibs.ROOT, "tests", "cpu_digest_worker.py")
-    env = dict(os.environ, CS_CPULIBS_PREBUILT="1", OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1")
+    env = dict(os.environ, CS_CPULIBS_PREBUILT="1", OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", CS_DIGEST_EXTRA=os.path.join(tmpd, "extra.json"))
     procs = [subprocess.Popen([sys.executable, worker, prog, str(win)] + [str(f) for f in firsts[i::cores]], stdout=subprocess.PIPE, text=True, env=env)
              for i in range(cores) if firsts[i::cores]]
     null_digest = _all_null_digest(win)
@@ -460,6 +469,8 @@ def test_gpu_full_size_headline_vs_oracle_10m_rows():
                 want = w["split"][k] if k < len(w["split"]) else null_digest
                 assert c.sublist(first, first + win).digest() == want, ("split column", k, "rows from", first)
             assert rep.sublist(first, first + win).digest() == w["replace"], ("replace_re, rows from", first)
+            for name, col in more.items():
+                assert col.sublist(first, first + win).digest() == w[name], (name, "rows from", first)
             checked += win
     assert checked == nwin * win
     print("oracle cross-check: %d rows of the 100M-row column in %d windows on %d cores" % (checked, nwin, cores))
