@@ -1231,7 +1231,7 @@ __device__ __forceinline__ void bits_classify16(const uint32_t* spread, const ui
 // the code costs the others registers).
 template <bool IN_LDS, bool REP16, bool INPLACE, bool RESCAN = false, bool LONG = false, bool UNITS = false, int PF = cstile::kPfChunks, bool BREFS = false,
           bool WIDE = false, bool OUTL = false, bool CHAIN = false, bool BITS = false>
-__global__ void __launch_bounds__(256, ((BREFS && !CHAIN) || BITS) ? 2 : CS_STREAM_WAVES) k_tdfa_replace_stream(StreamArgs a) {
+__global__ void __launch_bounds__(256, ((BREFS && !CHAIN) || (BITS && IN_LDS)) ? 2 : CS_STREAM_WAVES) k_tdfa_replace_stream(StreamArgs a) {
   // BITS (a CHAIN form): the pattern has a bit-parallel form (regex_bits.h) -- one bitmap per character class, staged by
   // table lookup; the row lanes derive their rows' matches from the class masks (alternations of word-bounded literals,
   // small sets in a `+` loop: patterns whose candidates are everywhere); a sub-tile with a byte >= 0x80 / NUL or a row
@@ -3221,7 +3221,11 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
         // (bytes >= 0x80, a row beyond the masks) walks them there, and the sample says those are rare.
         const size_t tile_lds = gt_bytes + bits_lds + (size_t)(cap + cap_out + 64 + (cap >> 3) + 32 + unit_bytes) * 4 + 16;
         constexpr size_t kThird = 160 * 1024 / 3;
-        const bool chain_global = chain_form && ((tbl + tile_lds > kThird && tile_lds + cstd::kHeadTailWords * 4 <= kThird) || cs::cfg("CS_CHAIN_TABLES_IN_MEMORY")) && !cs::cfg("CS_CHAIN_TABLES_IN_LDS");
+        // (the bit form likewise: its kernel with the tables in memory is built for three workgroups a CU -- 168 registers)
+        // (... whenever its tile leaves room for three, whatever the tables' size: the form with the tables in LDS is the 189-register one)
+        const bool chain_global = ((chain_form && tbl + tile_lds > kThird && tile_lds + cstd::kHeadTailWords * 4 <= kThird) ||
+                                   (bits_form && tile_lds + cstd::kHeadTailWords * 4 <= kThird) || ((chain_form || bits_form) && cs::cfg("CS_CHAIN_TABLES_IN_MEMORY"))) &&
+                                  !cs::cfg("CS_CHAIN_TABLES_IN_LDS");
         const size_t tbl_lds = (chain_global || bchain) ? (size_t)cstd::kHeadTailWords * 4 : tbl;  // (header + tail words: tsetup)
         const size_t lds1 = tbl_lds + tile_lds;
         if (lds1 > 150 * 1024) return -1;
@@ -3296,6 +3300,9 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
           kern = &k_tdfa_replace_stream<false, false, false, true, false, true, 5, true, false, false, true>;
         else if (brefs)
           kern = cap <= 5 * 1024 ? &k_tdfa_replace_stream<true, false, false, true, false, true, 5, true> : &k_tdfa_replace_stream<true, false, false, true, false, true, cstile::kPfChunks, true>;
+        else if (bits_form && chain_global)
+          kern = rb > 8 ? &k_tdfa_replace_stream<false, true, false, true, false, true, cstile::kPfChunks, false, false, false, true, true>
+                        : &k_tdfa_replace_stream<false, false, false, true, false, true, cstile::kPfChunks, false, false, false, true, true>;
         else if (bits_form)
           kern = rb > 8 ? &k_tdfa_replace_stream<true, true, false, true, false, true, cstile::kPfChunks, false, false, false, true, true>
                         : &k_tdfa_replace_stream<true, false, false, true, false, true, cstile::kPfChunks, false, false, false, true, true>;
