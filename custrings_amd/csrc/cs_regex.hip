@@ -1253,18 +1253,24 @@ __global__ void __launch_bounds__(256, ((BREFS && !CHAIN) || (BITS && IN_LDS)) ?
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   uint8_t* base = reinterpret_cast<uint8_t*>(smem);
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;  // (scalar: what derives from it stays in SGPRs)
-  const int bm_bytes = (a.cap_in >> 3) + 32;  // one candidate bit per staged byte
+  // one candidate bit per staged byte (BITS: sixteen bytes of slack instead of thirty-two -- a class bitmap is written up to
+  // cap / 8 and read a few words beyond that into the next one, whose bits do not count: the seven bitmaps of the gtest
+  // pattern then leave room for a third workgroup)
+  const int bm_bytes = (a.cap_in >> 3) + (BITS ? 16 : 32);
   // second bitmap, unit queue, bail word (+ BREFS: a record of three words per match, a growth counter per row)
   const int nbm = BITS ? max(a.bits_k, 2) : 2;  // bitmaps per wave (BITS: one per character class)
   // (BREFS + CHAIN: the second bitmap, the bail word's slot and the match records -- no unit queue, no growth counters)
+  // (CHAIN, BITS: no unit queue either)
   const int unit_bytes = (BREFS && CHAIN) ? bm_bytes + 16 + kUnitQueue * 12
-                                          : UNITS ? (nbm - 1) * bm_bytes + kUnitQueue * 4 + 16 + (BREFS ? kUnitQueue * 12 + 64 * 4 : 0) : 0;
+                         : CHAIN          ? (nbm - 1) * bm_bytes + 16
+                         : UNITS          ? (nbm - 1) * bm_bytes + kUnitQueue * 4 + 16 + (BREFS ? kUnitQueue * 12 + 64 * 4 : 0)
+                                          : 0;
   uint8_t* lds_in = base + a.tbl_bytes + (size_t)wv * (a.cap_in + a.cap_out + 64 + bm_bytes + unit_bytes);
   uint8_t* lds_out = lds_in + a.cap_in + 32;
   uint32_t* bitmap = reinterpret_cast<uint32_t*>(lds_out + a.cap_out + 32);
   uint32_t* xbitmap = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(bitmap) + bm_bytes);  // UNITS: "byte == x", later the matches' last bytes
   uint32_t* uqueue = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(bitmap) + (size_t)nbm * bm_bytes);
-  uint32_t* bailw = uqueue + ((BREFS && CHAIN) ? 0 : kUnitQueue);  // one bit per row: the lean scan handed a unit of the row over
+  uint32_t* bailw = uqueue + (CHAIN ? 0 : kUnitQueue);  // one bit per row: the lean scan handed a unit of the row over
   uint32_t* mrec = bailw + 4;              // BREFS: per match (group ranges of groups 1-2, of groups 3-4, match end | ok << 8)
   uint32_t* rowgrow = mrec + kUnitQueue * 3;  // BREFS: bytes the row's expansions add
   const TCtx c = tsetup<IN_LDS>(a.L, a.flags, smem);  // (block barrier inside when staging)
@@ -3201,8 +3207,15 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
         const bool units = literal || brefs || bits_form || (offers && maxrepl < 0 && !tc.lng && tc.R == 64 && !outliers && !cs::g_replace_plain_only && !cs::cfg("CS_NO_UNITS"));
         const int bits_k = bits_form ? std::max(re->bits[1], 2) : 2;
         const size_t bits_lds = bits_form ? (size_t)bits_lds_bytes((int)re->bits.size()) : 0;
-        const size_t unit_bytes = bchain ? (size_t)((cap >> 3) + 32 + 16 + kUnitQueue * 12)
-                                  : units ? (size_t)((bits_k - 1) * ((cap >> 3) + 32) + kUnitQueue * 4 + 16 + (cs::g_backrefs_dev ? kUnitQueue * 12 + 64 * 4 : 0)) : 0;
+        // (a chain pattern on a column whose sample is plain ASCII: the form without the unit / lean scans)
+        const bool chain_form = !bits_form && !brefs && !wide_stream && !outliers && units && cap <= 5 * 1024 && tp.d.in_lds && !literal && maxrepl < 0 &&
+                                ((re->tdfa[30] >> 16) & 15) != 0 && !sample_has_high_bytes(col, s) && !cs::cfg("CS_NO_CHAIN_FORM");
+        // (the kernel's layout, k_tdfa_replace_stream: a bitmap's bytes, what stands behind the first one)
+        const size_t bm = (size_t)(cap >> 3) + (bits_form ? 16 : 32);
+        const size_t unit_bytes = bchain                      ? bm + 16 + kUnitQueue * 12
+                                  : (chain_form || bits_form) ? (size_t)(bits_k - 1) * bm + 16
+                                  : units                     ? (size_t)(bits_k - 1) * bm + kUnitQueue * 4 + 16 + (cs::g_backrefs_dev ? kUnitQueue * 12 + 64 * 4 : 0)
+                                                              : 0;
         // (backrefs: the group tags and the template text sit behind the DFA table; the template may grow a row by any
         // amount: room for twice the input, a launch that needs more says so and the two-pass form takes over)
         const size_t gt_bytes = brefs ? (bchain ? 0 : ((re->gtags.size() * 4 + 15) & ~size_t(15))) + (((size_t)cs::g_backrefs_text_bytes + 31) & ~size_t(15)) : 0;
@@ -3215,18 +3228,17 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
           cap_out = std::max(cap_out, 2 * cap);
           extra = std::max<int64_t>(extra, col->nbytes);
         }
-        // (a chain pattern on a column whose sample is plain ASCII: the form without the unit / lean scans)
-        const bool chain_form = !bits_form && !brefs && !wide_stream && !outliers && units && cap <= 5 * 1024 && tp.d.in_lds && !literal && maxrepl < 0 &&
-                                ((re->tdfa[30] >> 16) & 15) != 0 && !sample_has_high_bytes(col, s) && !cs::cfg("CS_NO_CHAIN_FORM");
         // The chain arithmetic reads no table: when the tables are what keeps a third workgroup off the CU (the 26-instruction
         // dotted quad with `\b` and {1,3}: 36 states, 19 KB), they stay in memory -- only a sub-tile the arithmetic does not take
         // (bytes >= 0x80, a row beyond the masks) walks them there, and the sample says those are rare.
-        const size_t tile_lds = gt_bytes + bits_lds + (size_t)(cap + cap_out + 64 + (cap >> 3) + 32 + unit_bytes) * 4 + 16;
+        const size_t tile_lds = gt_bytes + bits_lds + (size_t)(cap + cap_out + 64 + bm + unit_bytes) * 4 + 16;
         constexpr size_t kThird = 160 * 1024 / 3;
         // (the bit form likewise: its kernel with the tables in memory is built for three workgroups a CU -- 168 registers)
-        // (... whenever its tile leaves room for three, whatever the tables' size: the form with the tables in LDS is the 189-register one)
+        // (... whenever its tile leaves room for three, whatever the tables' size: the form with the tables in LDS is the 189-register
+        // one -- for patterns of up to five classes: the gtest pattern's seven fit a third workgroup too once the layout was trimmed,
+        // but its evaluation then spills where it hurts: 8.4 against 7.1 ms)
         const bool chain_global = ((chain_form && tbl + tile_lds > kThird && tile_lds + cstd::kHeadTailWords * 4 <= kThird) ||
-                                   (bits_form && tile_lds + cstd::kHeadTailWords * 4 <= kThird) || ((chain_form || bits_form) && cs::cfg("CS_CHAIN_TABLES_IN_MEMORY"))) &&
+                                   (bits_form && re->bits[1] <= 5 && tile_lds + cstd::kHeadTailWords * 4 <= kThird) || ((chain_form || bits_form) && cs::cfg("CS_CHAIN_TABLES_IN_MEMORY"))) &&
                                   !cs::cfg("CS_CHAIN_TABLES_IN_LDS");
         const size_t tbl_lds = (chain_global || bchain) ? (size_t)cstd::kHeadTailWords * 4 : tbl;  // (header + tail words: tsetup)
         const size_t lds1 = tbl_lds + tile_lds;
