@@ -2184,7 +2184,7 @@ struct ScanStreamArgs {
 // no byte >= 0x80 -- every staged byte is classified into one bitmap per character class by table lookup, the row lanes
 // read their rows' class masks and derive the matches by mask arithmetic; no automaton on a plain-ASCII sub-tile.
 template <int MODE, bool IN_LDS, bool LONG = false, bool UNITS = false, bool CHAIN = false, bool BITS = false>
-__global__ void __launch_bounds__(256, MODE == 4 ? 3 : CHAIN ? 4 : (UNITS && MODE == 3) ? 3 : (UNITS || MODE == 3) ? 4 : 1) k_tdfa_scan_stream(ScanStreamArgs a) {
+__global__ void __launch_bounds__(256, MODE == 4 ? ((CHAIN && !IN_LDS) ? 4 : 3) : CHAIN ? 4 : (UNITS && MODE == 3) ? 3 : (UNITS || MODE == 3) ? 4 : (MODE <= 1 && !LONG) ? 5 : 1) k_tdfa_scan_stream(ScanStreamArgs a) {
   static_assert(!UNITS || ((MODE == 0 || MODE == 2 || MODE == 3 || (MODE == 4 && CHAIN)) && !LONG), "unit scan: contains_re / count_re / findall on rows within the 96-byte masks");
   static_assert(!CHAIN || (UNITS && (MODE == 2 || MODE == 3 || MODE == 4 || (BITS && MODE == 0))), "the chain form: count_re / findall / extract");
   static_assert(!BITS || (CHAIN && (MODE == 0 || MODE == 2)), "the bit form: contains_re / count_re");
@@ -3654,7 +3654,10 @@ int cs_extract(const cs_column* col, const cs_regex* cre, cs_stream stream, cs_c
       // and the group ranges by mask arithmetic; it keeps the "equals x" bitmap and the unit form's layout)
       const bool chain_form = tp.d.in_lds && tc.R == 64 && !tc.lng && !cs::cfg("CS_SPANS_UNPACKED") && ((re->tdfa[30] >> 16) & 15) != 0 && ((re->tdfa[30] >> 20) & 1) != 0 &&
                               groups <= 4 && !cs::cfg("CS_NO_CHAIN_FORM") && !sample_has_high_bytes(col, s);
-      const size_t lds = chain_form ? tp.lds_bytes + gt_bytes + (size_t)(cap + 32 + 2 * ((cap >> 3) + 32) + kUnitQueue * 4 + 64 * 4 + 16) * 4
+      // (the chain form with the tables in memory: a fourth workgroup per CU -- the kernel is built for 128 registers then)
+      const bool chain_mem = chain_form && !cs::cfg("CS_CHAIN_TABLES_IN_LDS");
+      const size_t tbl_x = chain_mem ? (size_t)cstd::kHeadTailWords * 4 : tp.lds_bytes;
+      const size_t lds = chain_form ? tbl_x + gt_bytes + (size_t)(cap + 32 + 2 * ((cap >> 3) + 32) + kUnitQueue * 4 + 64 * 4 + 16) * 4
                                     : tp.lds_bytes + gt_bytes + (size_t)(cap + 32 + (cap >> 3) + 32 + cstd::Tdfa::kBackSteps * 64 + kMaxGroups * 4) * 4;
       if (tp.d.in_lds && tc.R && lds <= 150 * 1024) {
         packed = tc.R == 64 && !cs::cfg("CS_SPANS_UNPACKED");
@@ -3675,8 +3678,9 @@ int cs_extract(const cs_column* col, const cs_regex* cre, cs_stream stream, cs_c
         sa.nsub = (rows + tc.R - 1) / tc.R;
         sa.rows_per_tile = tc.R;
         sa.cap_in = cap;
-        sa.tbl_bytes = (int)(tp.lds_bytes + gt_bytes);
-        sa.gt_off = (int)tp.lds_bytes;
+        sa.tbl_bytes = (int)(tbl_x + gt_bytes);
+        sa.gt_off = (int)tbl_x;
+        if (chain_mem) sa.L.in_lds = 2;
         sa.gt_words = gt_bytes ? (int)re->gtags.size() : 0;
         sa.begins = ptr<int32_t>(begins);
         sa.lens = ptr<int32_t>(lens);
@@ -3685,7 +3689,7 @@ int cs_extract(const cs_column* col, const cs_regex* cre, cs_stream stream, cs_c
         sa.ncols = groups;
         sa.gtags = ptr<const int32_t>(re->d_gtags);
         auto kern = tc.lng ? &k_tdfa_scan_stream<4, true, true> : &k_tdfa_scan_stream<4, true, false>;
-        if (chain_form) kern = &k_tdfa_scan_stream<4, true, false, true, true>;
+        if (chain_form) kern = chain_mem ? &k_tdfa_scan_stream<4, false, false, true, true> : &k_tdfa_scan_stream<4, true, false, true, true>;
         if (lds > 48 * 1024)
           CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         const unsigned sgrid = resident_grid(reinterpret_cast<const void*>(kern), lds, (sa.nsub + 3) / 4);
