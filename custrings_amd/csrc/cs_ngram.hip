@@ -233,7 +233,9 @@ bool ngrams_fast(const cs_column* tokens, int n, const unsigned char* sep, int s
   int M = 0;
   int64_t span_in = 0, span_out = 0;
   Buf maxima = dev_alloc(16, s);
+  const int m_first = cs::cfg("CS_NGRAM_M") ? atoi(cs::cfg("CS_NGRAM_M")) : 8;  // (measurement: n-grams per lane and tile)
   for (int m : {8, 4, 2, 1}) {
+    if (m > m_first) continue;
     const int NG = 64 * m;
     const int64_t nt = (ng + NG - 1) / NG;
     CS_HIP(hipMemsetAsync(maxima->p, 0, 16, s));
@@ -243,10 +245,16 @@ bool ngrams_fast(const cs_column* tokens, int n, const unsigned char* sep, int s
     CS_HIP(hipMemcpyAsync(h, maxima->p, 16, hipMemcpyDeviceToHost, s));
     CS_HIP(hipStreamSynchronize(s));
     if (h[0] + 32 <= cstile::kPfBytes && h[1] + 64 <= 12 * 1024) {
-      M = m;
-      span_in = h[0];
-      span_out = h[1];
-      break;
+      // (... preferring, down to four n-grams a lane, one whose LDS leaves room for four workgroups a CU -- the kernel's registers
+      // allow four waves a SIMD: C5 bigrams at M = 8 / 4 / 2 / 1: 10.4 / 9.4 / 11.7 / 16.2 ms, the first at three workgroups of 47 KB)
+      const size_t wave_lds = (((size_t)(NG + n + 1) * 4 + 15) & ~(size_t)15) + (size_t)((h[0] + 32 + 15) & ~(int64_t)15) + (size_t)((h[1] + 64 + 15) & ~(int64_t)15);
+      const bool roomy = wave_lds * 4 <= 40 * 1024;
+      if (!M || roomy) {
+        M = m;
+        span_in = h[0];
+        span_out = h[1];
+      }
+      if (roomy || m <= 4) break;
     }
   }
   if (!M) return false;
