@@ -41,15 +41,11 @@ __device__ __forceinline__ void lds_or(uint32_t* p, uint32_t v) {
 }
 // ORs `len` bytes (the low bytes of t0..t3, garbage above `len` allowed) into the zeroed
 // buffer at byte index di; len <= 16
-__device__ __forceinline__ void or_bytes(uint8_t* region, int di, uint32_t t0, uint32_t t1, uint32_t t2, uint32_t t3, int len) {
-  unsigned long long tlo = ((unsigned long long)t1 << 32) | t0, thi = ((unsigned long long)t3 << 32) | t2;
-  if (len < 8) {
-    tlo &= ~(~0ull << (8 * len));
-    thi = 0;
-  } else if (len < 16) {
-    thi &= ~(~0ull << (8 * (len - 8)));
-  }
-  t0 = (uint32_t)tlo, t1 = (uint32_t)(tlo >> 32), t2 = (uint32_t)thi, t3 = (uint32_t)(thi >> 32);
+// (`tail`: seventeen masks of four dwords in LDS, entry n = the first n bytes -- one aligned 16-byte read and four ANDs where the
+// mask was built with 64-bit shifts, the slowest integer instructions of the machine)
+__device__ __forceinline__ void or_bytes(uint8_t* region, int di, uint32_t t0, uint32_t t1, uint32_t t2, uint32_t t3, int len, const cstile::u32x4* tail) {
+  const cstile::u32x4 m = tail[len];
+  t0 &= m.x, t1 &= m.y, t2 &= m.z, t3 &= m.w;
   const unsigned sd = (unsigned)(di & 3);
   uint32_t* dp = reinterpret_cast<uint32_t*>(region) + (di >> 2);
   uint32_t d0 = t0, d1 = t1, d2 = t2, d3 = t3, d4 = 0;
@@ -76,7 +72,14 @@ __global__ void __launch_bounds__(256) k_ngram_tile(NgramArgs a) {
   const int NG = 64 * a.M;
   const int nrel = NG + a.n + 1;                       // relative offsets kept per tile
   const int rel_bytes = (nrel * 4 + 15) & ~15;
-  uint8_t* base = reinterpret_cast<uint8_t*>(smem) + (size_t)wv * (rel_bytes + a.cap_in + a.cap_out);
+  cstile::u32x4* tail = reinterpret_cast<cstile::u32x4*>(smem);  // tail[n], n = 0..16 (or_bytes); 288 bytes in front of the waves' regions
+  if (threadIdx.x <= 16) {
+    auto first = [](int k) -> uint32_t { return k >= 4 ? 0xFFFFFFFFu : (k <= 0 ? 0u : (1u << (8 * k)) - 1u); };
+    const int t = (int)threadIdx.x;
+    tail[t] = cstile::u32x4{first(t), first(t - 4), first(t - 8), first(t - 12)};
+  }
+  __syncthreads();
+  uint8_t* base = reinterpret_cast<uint8_t*>(smem) + 288 + (size_t)wv * (rel_bytes + a.cap_in + a.cap_out);
   int32_t* relo = reinterpret_cast<int32_t*>(base);     // relo[t] = off[G0 + t] - off[G0]
   uint8_t* lds_in = base + rel_bytes;
   uint8_t* lds_out = lds_in + a.cap_in;
@@ -159,11 +162,11 @@ __global__ void __launch_bounds__(256) k_ngram_tile(NgramArgs a) {
           const int first = len < 16 ? len : 16;
           if (on)
             or_bytes(lds_out, di, __builtin_amdgcn_alignbyte(w1, w0, sh), __builtin_amdgcn_alignbyte(w2, w1, sh),
-                     __builtin_amdgcn_alignbyte(w3, w2, sh), __builtin_amdgcn_alignbyte(w4, w3, sh), first);
+                     __builtin_amdgcn_alignbyte(w3, w2, sh), __builtin_amdgcn_alignbyte(w4, w3, sh), first, tail);
           if (on && len > 16) cstile::lds_copy(lds_out, di + 16, lds_in, si + 16, len - 16);
           di += len;
           if (k + 1 < a.n && a.sepn) {
-            if (on) or_bytes(lds_out, di, a.sep0, a.sep1, 0, 0, a.sepn);
+            if (on) or_bytes(lds_out, di, a.sep0, a.sep1, 0, 0, a.sepn, tail);
             di += a.sepn;
           }
         }
@@ -294,7 +297,7 @@ bool ngrams_fast(const cs_column* tokens, int n, const unsigned char* sep, int s
   CS_HIP(hipMemsetAsync(err->p, 0, sizeof(unsigned), s));
   a.error = ptr<unsigned>(err);
   const size_t rel_bytes = ((size_t)(64 * M + n + 1) * 4 + 15) & ~(size_t)15;
-  const size_t lds = (rel_bytes + (size_t)a.cap_in + (size_t)a.cap_out) * 4;
+  const size_t lds = 288 + (rel_bytes + (size_t)a.cap_in + (size_t)a.cap_out) * 4;
   if (lds > 150 * 1024) return false;
   if (lds > 48 * 1024)
     CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ngram_tile), hipFuncAttributeMaxDynamicSharedMemorySize,
