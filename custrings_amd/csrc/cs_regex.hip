@@ -1515,6 +1515,7 @@ __global__ void __launch_bounds__(256, ((BREFS && !CHAIN) || (BITS && IN_LDS)) ?
     cstd::U128 uS = cstd::u128(0, 0), uE = cstd::u128(0, 0);  // UNITS: the row's match starts / last bytes
     bool from_masks = false;
     int mslot = 0;  // BREFS: where the row's matches stand in the match queue / record table
+    bool dense_tile = false;  // BREFS + CHAIN: more matches than the record table holds -- the assembly derives the groups again
     if (live && !bad) out_len = n;
     if (oversize && live) {  // the row's output size by the generic scan on the row in memory
       cstd::Tdfa vg(D, P, in.chars + (g0 + rbeg), n);
@@ -1691,7 +1692,11 @@ __global__ void __launch_bounds__(256, ((BREFS && !CHAIN) || (BITS && IN_LDS)) ?
           const int mincl = csdev::wave_inclusive_scan(cnt);
           const int total_m = __builtin_amdgcn_readlane(mincl, 63);
           mslot = mincl - cnt;
-          if (total_m > kUnitQueue) {
+          // (the chain form proper keeps going when the sub-tile holds more matches than the record table: the sizes now, the
+          // group ranges once more at the assembly -- replace_with_backrefs((\d+), <\1>) on the C3 column, 5 numbers a row, gave
+          // every launch up and took 174 ms on the two-pass form)
+          dense_tile = CHAIN && total_m > kUnitQueue;
+          if (!CHAIN && total_m > kUnitQueue) {
             if (lane == 0) atomicOr(a.error, 1u | 32u);
           } else {
             int grow_row = 0, mi = 0;
@@ -1720,10 +1725,12 @@ __global__ void __launch_bounds__(256, ((BREFS && !CHAIN) || (BITS && IN_LDS)) ?
               }
               grow_row += grow;
               auto by = [&](int v) { return (uint32_t)(v >= 0 ? v : 255) & 255u; };
-              uint32_t* rec = mrec + (mslot + mi) * 3;
-              rec[0] = by(gb[0]) | (by(ge[0]) << 8) | (by(gb[1]) << 16) | (by(ge[1]) << 24);
-              rec[1] = by(gb[2]) | (by(ge[2]) << 8) | (by(gb[3]) << 16) | (by(ge[3]) << 24);
-              rec[2] = by(me) | (1u << 8);
+              if (!dense_tile) {
+                uint32_t* rec = mrec + (mslot + mi) * 3;
+                rec[0] = by(gb[0]) | (by(ge[0]) << 8) | (by(gb[1]) << 16) | (by(ge[1]) << 24);
+                rec[1] = by(gb[2]) | (by(ge[2]) << 8) | (by(gb[3]) << 16) | (by(ge[3]) << 24);
+                rec[2] = by(me) | (1u << 8);
+              }
               ++mi;
             }
             if (from_masks) out_len = n + grow_row;
@@ -2016,7 +2023,17 @@ __global__ void __launch_bounds__(256, ((BREFS && !CHAIN) || (BITS && IN_LDS)) ?
             oi += mb - copied;
             int gb[cstd::Tdfa::kGroupBatch], ge[cstd::Tdfa::kGroupBatch], mend = me;
             bool ok;
-            {
+            if (CHAIN && dense_tile) {  // (wave-uniform) no record of this match: its groups off the row's masks again
+              uint32_t r0, r1, r2, x0 = 0, x1 = 0, x2 = 0;
+              cstile::row_bits96(bitmap, pi, n, r0, r1, r2);
+              if (unit_x != 0) cstile::row_bits96(xbitmap, pi, n, x0, x1, x2);
+              int g4b[4], g4e[4];
+              cstd::chain_group_bounds(cstd::u128(r0 | ((unsigned long long)r1 << 32), r2), cstd::u128(x0 | ((unsigned long long)x1 << 32), x2), D.chain, D.img,
+                                       (uint32_t)D.img[D.img[15] - 1], mb, g4b, g4e);
+#pragma unroll
+              for (int q = 0; q < cstd::Tdfa::kGroupBatch; ++q) gb[q] = q < 4 ? g4b[q] : -1, ge[q] = q < 4 ? g4e[q] : -1;
+              ok = true;
+            } else {
               const uint32_t* rec = mrec + (mslot + mi) * 3;
               const uint32_t lo4 = rec[0], hi4 = rec[1], e4 = rec[2];
               auto un = [](uint32_t v) { return v == 255u ? -1 : (int)v; };
@@ -3176,7 +3193,7 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
         // (`\4.\3.\2.\1` on four dotted groups: 3 - 3).  An item named twice and unbounded leaves the old "twice the input".
         bool bchain = false;
         int64_t brefs_grow = -1;  // per match; -1: unknown
-        if (brefs && ((re->tdfa[30] >> 16) & 15) != 0 && ((re->tdfa[30] >> 20) & 1) != 0 && cap <= 5 * 1024 && !tc.lng && tc.R == 64 && maxrepl < 0 &&
+        if (brefs && ((re->tdfa[30] >> 16) & 15) != 0 && ((re->tdfa[30] >> 20) & 1) != 0 && !tc.lng && tc.R == 64 && maxrepl < 0 &&
             cs::g_backrefs_host && !cs::cfg("CS_NO_BREFS_CHAIN") && !sample_has_high_bytes(col, s)) {
           const auto* ht = static_cast<const csvm::BackrefTemplate*>(cs::g_backrefs_host);
           const cstd::View hv = cstd::make_view(re->tdfa.data());
@@ -3220,10 +3237,18 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
         // amount: room for twice the input, a launch that needs more says so and the two-pass form takes over)
         const size_t gt_bytes = brefs ? (bchain ? 0 : ((re->gtags.size() * 4 + 15) & ~size_t(15))) + (((size_t)cs::g_backrefs_text_bytes + 31) & ~size_t(15)) : 0;
         if (brefs && brefs_grow >= 0) {
-          // (at most span / minlen matches in a sub-tile, each growing by at most brefs_grow bytes)
+          // (at most span / minlen matches in a sub-tile, each growing by at most brefs_grow bytes -- the roomy sizing; the first
+          // attempt provisions a quarter of the input instead when that is less: `(\d+)` -> `<\1>` may triple a row of digits
+          // and spaces, and adds a sixth to a log line -- at the worst case's 84 KB of LDS one workgroup fits a CU, 48.8 ms on the
+          // C3 column; a launch that runs out of room says so and the roomy one follows)
           const int64_t span_room = std::min<int64_t>(cap, (tc.span + 15 + 32 + 15) & ~(int64_t)15);
-          cap_out = (int)((span_room + (tc.span / minlen_p + 1) * brefs_grow + (brefs_grow ? 127 : 0)) & ~(int64_t)(brefs_grow ? 127 : 15));
-          extra = (col->nbytes / minlen_p + 1) * brefs_grow;
+          int64_t tile_grow = (tc.span / minlen_p + 1) * brefs_grow, col_grow = (col->nbytes / minlen_p + 1) * brefs_grow;
+          if (!roomy) {
+            tile_grow = std::min<int64_t>(tile_grow, std::max<int64_t>(tc.span / 4, 256));
+            col_grow = std::min<int64_t>(col_grow, col->nbytes / 4 + (1 << 20));
+          }
+          cap_out = (int)((span_room + tile_grow + (tile_grow ? 127 : 0)) & ~(int64_t)(tile_grow ? 127 : 15));
+          extra = col_grow;
         } else if (brefs) {
           cap_out = std::max(cap_out, 2 * cap);
           extra = std::max<int64_t>(extra, col->nbytes);
@@ -3311,7 +3336,8 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
             else kern = lng ? &k_tdfa_replace_stream<true, true, false, true, true, false, P6, false, true> : &k_tdfa_replace_stream<true, true, false, true, false, false, P6, false, true>;
           }
         } else if (bchain)
-          kern = &k_tdfa_replace_stream<false, false, false, true, false, true, 5, true, false, false, true>;
+          kern = cap <= 5 * 1024 ? &k_tdfa_replace_stream<false, false, false, true, false, true, 5, true, false, false, true>
+                                 : &k_tdfa_replace_stream<false, false, false, true, false, true, cstile::kPfChunks, true, false, false, true>;
         else if (brefs)
           kern = cap <= 5 * 1024 ? &k_tdfa_replace_stream<true, false, false, true, false, true, 5, true> : &k_tdfa_replace_stream<true, false, false, true, false, true, cstile::kPfChunks, true>;
         else if (bits_form && chain_global)

@@ -2,6 +2,7 @@
 pool after cs_stream_forget, the bit-parallel regex route, full-size cross-checks of the headline ops between the
 tile route and the independent row-wise route."""
 import ctypes as C
+import random
 
 import numpy as np
 import pytest
@@ -313,6 +314,29 @@ def test_gpu_backrefs_chain_form(pat, repl):
     assert last_route() == "brefs-chain", (pat, repl, last_route())
     assert L.lib.cs_fallback_count() == f0, (pat, repl)
     gpuutil.assert_same(got, orc.replace_with_backrefs(o, blob_of(pat), repl), "replace_with_backrefs(%r, %r)" % (pat, repl))
+
+
+def test_gpu_backrefs_chain_form_on_dense_matches():
+    """Sub-tiles with more matches than the record table holds (128) stay on the chain form -- the group ranges are derived once
+    more at the assembly -- and a template that outgrows the first attempt's room (a quarter of the input) is repeated with the
+    worst-case sizing inside the same call: rows of short numbers, `(\\d+)` -> `<\\1>` triples them.  No fallback, the oracle's rows."""
+    orc = cpulibs.Oracle()
+    L = gpuutil.lib()
+    rnd = random.Random(77)
+    rows = [" ".join(str(rnd.randrange(1000)) for _ in range(rnd.randrange(1, 16))) for _ in range(20_000)]      # ~8 matches a row
+    rows += ["1 2 3 4 5 6 7 8 9 0 1 2 3 4 5 6 7 8 9 0 1 2 3 4 5 6 7 8 9 0 1 2 3 4 5 6 7 8 9 0"] * 300                  # 40 matches a row: 2 560 a sub-tile
+    rows += orc.synth(3, 0, 20_000).to_list()                                                                  # log lines among them
+    rows += ["", None, "x", "7", "no digits here"] * 10
+    o = cpulibs.Col.from_list(rows)
+    g = gpuutil.from_col(o)
+    for pat, repl in ((r"(\d+)", r"<\1>"), (r"(\d+)", r"\1\1"), (r"(\d+)", r""), (r"(\d+) (\d+)", r"\2 \1")):
+        f0 = L.lib.cs_fallback_count()
+        got = g.replace_with_backrefs(pat, repl)
+        assert last_route() == "brefs-chain", (pat, repl, last_route())
+        assert L.lib.cs_fallback_count() == f0, (pat, repl)
+        gpuutil.assert_same(got, orc.replace_with_backrefs(o, blob_of(pat), repl), "replace_with_backrefs(%r, %r)" % (pat, repl))
+    # (no chain -- a single digit is not a run: the backrefs form proper gives such sub-tiles up and the two-pass form answers)
+    gpuutil.assert_same(g.replace_with_backrefs(r"(\d)", r"[\1]"), orc.replace_with_backrefs(o, blob_of(r"(\d)"), r"[\1]"), "replace_with_backrefs((\\d))")
 
 
 def test_gpu_backrefs_chain_form_gives_up_like_the_backrefs_form():
