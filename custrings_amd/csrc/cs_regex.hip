@@ -3449,7 +3449,12 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
       // (replacements of 17 .. kMaxStreamRepl bytes ride the four-register variants, their text read from memory at assembly)
       // (... where a match is long enough for the row not to outgrow the out tile: a 19-byte replacement of one-digit matches
       // goes to the two-pass kernels at once instead of failing the single pass twice first)
-      if (lds <= 150 * 1024 && (rb <= 16 || (rb <= kMaxStreamRepl && rb <= 4 * minlen)) && tc.R && !cs::cfg("CS_TILE_OLD")) {
+      // (... or where the sample says matches are few: at most about three candidate bytes a row -- the first attempt is
+      // provisioned for kMaxRec matches a row; `-` -> 35 bytes on the log lines, two or three dashes each: 58 ms on the two-pass
+      // kernels.  A column that has more after all loses one launch before them)
+      const bool few_matches = rb <= kMaxStreamRepl && minlen >= 1 && col->rows > 0 &&
+                               candidate_share(re, col, s) * ((double)col->nbytes / (double)col->rows) <= (double)(kMaxRec - 1);
+      if (lds <= 150 * 1024 && (rb <= 16 || (rb <= kMaxStreamRepl && rb <= 4 * minlen) || few_matches) && tc.R && !cs::cfg("CS_TILE_OLD")) {
         const bool roomy_first = growth > 0 && (minlen <= 2 || wide_stream || outliers || cs::cfg("CS_REPLACE_ROOMY"));
         int err = stream_attempt(roomy_first);
         if (err == 2 && !roomy_first) err = stream_attempt(true);  // only ran out of room: once more, roomier

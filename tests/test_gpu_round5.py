@@ -339,6 +339,27 @@ def test_gpu_backrefs_chain_form_on_dense_matches():
     gpuutil.assert_same(g.replace_with_backrefs(r"(\d)", r"[\1]"), orc.replace_with_backrefs(o, blob_of(r"(\d)"), r"[\1]"), "replace_with_backrefs((\\d))")
 
 
+def test_gpu_long_replacement_of_short_matches():
+    """A replacement longer than four times the shortest match rides the stream kernel when the sample says matches are few
+    (cs_regex.hip: few_matches) -- `-` -> 35 bytes on log lines -- and a column that holds many after all (rows of dashes outside
+    the sampled windows) is answered by the kernels behind it: the oracle's rows either way."""
+    orc = cpulibs.Oracle()
+    L = gpuutil.lib()
+    repl = "<a-replacement-of-thirty-five-bytes>"
+    base = orc.synth(3, 0, 40_000)
+    g = gpuutil.from_col(base)
+    f0 = L.lib.cs_fallback_count()
+    for pat in (r"-", r"\[", r"GET"):
+        gpuutil.assert_same(g.replace(pat, repl), orc.replace_re(base, blob_of(pat), repl), "replace_re(%r, 35 bytes)" % pat)
+        assert last_route() != "", pat  # (a stream launch)
+    assert L.lib.cs_fallback_count() == f0
+    rows = base.to_list()
+    for k in range(64):
+        rows[17_000 + k] = "-" * 60 + " - - -"
+    o = cpulibs.Col.from_list(rows)
+    gpuutil.assert_same(gpuutil.from_col(o).replace(r"-", repl), orc.replace_re(o, blob_of(r"-"), repl), "replace_re('-', 35 bytes), a sub-tile of dashes")
+
+
 def test_gpu_backrefs_chain_form_gives_up_like_the_backrefs_form():
     """A sub-tile the marker arithmetic does not take (a byte >= 0x80 or a NUL outside the sampled windows), a sub-tile with
     more than 128 matches: the launch is given up and the two-pass form answers -- the same rows as the oracle's."""
