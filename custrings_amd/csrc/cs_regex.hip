@@ -3099,11 +3099,16 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
     // One character class, once or in a `+` loop, on a column the 96-bit-mask forms do not take -- rows beyond 93 bytes,
     // tiles of fewer than 64 rows, non-ASCII text -- and whose candidates are everywhere: byte-parallel stream compaction
     // (cs_runs.hip; BASELINE.json C5: replace_re([aeiou]+) on 40-150-byte rows, 82.8 ms on the long-row automaton forms).
-    if (!cs::g_backrefs_dev && !cs::g_replace_plain_only && maxrepl < 0 && col->rows > 0 && !re->bits.empty() && (re->bits[2] & csbits::F_BYTE_CLASS) &&
+    if (!cs::g_backrefs_dev && !cs::g_replace_plain_only && maxrepl < 0 && col->rows > 0 && !re->bits.empty() && (re->bits[2] & (csbits::F_BYTE_CLASS | csbits::F_FLAG_CLASS)) &&
         re->d_bits) {
       const TileChoice tc0 = choose_tile(col, s, true);
       const bool masks_form = tc0.R == 64 && !tc0.lng && !sample_has_high_bytes(col, s);
-      const bool wanted = cs::cfg("CS_CLASS_RUNS_ALWAYS") || (!masks_form && candidate_share(re, col, s) >= 0.05);
+      // (a class with builtins -- `\w+` -- sends every tile with a byte >= 0x80 row by row: worth it against the automaton's
+      // long-row and dense forms -- `\w+` on the C5 column 97.7 -> 11.2 ms, on C2 16.2 -> 5.1 --, not against the chain
+      // arithmetic where that runs: `\s+` on C2 4.4 there, 6.7 here)
+      const bool chain_there = !re->tdfa.empty() && ((re->tdfa[30] >> 16) & 15) != 0 && tc0.R == 64 && !tc0.lng;
+      const bool flag_class = (re->bits[2] & csbits::F_BYTE_CLASS) == 0;
+      const bool wanted = cs::cfg("CS_CLASS_RUNS_ALWAYS") || (!masks_form && !(flag_class && chain_there) && candidate_share(re, col, s) >= 0.05);
       cs_column* r = nullptr;
       if (wanted && replace_class_runs(col, ptr<const int32_t>(re->d_bits), re->bits, repl, rb, s, &r)) {
         note_route("runs");

@@ -42,6 +42,8 @@ struct RunsArgs {
   long long ntiles;
   const int32_t* bits;  // the pattern's bit image (class table: regex_bits.h)
   int high_member;      // bytes >= 0x80 belong to the class (a negated class, `.`)
+  int flag_class;       // 0, or 1 | builtins << 8 | negated << 16: a non-ASCII character belongs through the unicode flags (regex_bits.h: F_FLAG_CLASS)
+  const uint8_t* flags; // the unicode flags table (64 K entries)
   int plus;             // runs (class+) or single members
   int rb;
   uint32_t rep[4];
@@ -149,6 +151,7 @@ __global__ void __launch_bounds__(256) k_runs_tile(RunsArgs a) {
           auto z = [](uint32_t w) { return (w - 0x01010101u) & ~w & 0x80808080u; };  // (exact for the lowest zero byte: enough for "any")
           const uint32_t zero = high16_of(make_uint4(z(q.v[j].x), z(q.v[j].y), z(q.v[j].z), z(q.v[j].w)));
           nul_seen |= zero & valid;
+          if (a.flag_class) nul_seen |= high & valid;  // (such a tile goes row by row too: its non-ASCII characters are decoded there)
         }
         const uint32_t mem = (a.high_member ? ((pair[0] & 0xFFFFu) | high) : ((pair[0] & 0xFFFFu) & ~high)) & valid;
         const uint32_t rs = (bitmap[i >> 5] >> (i & 31)) & 0xFFFFu;
@@ -183,6 +186,37 @@ __global__ void __launch_bounds__(256) k_runs_tile(RunsArgs a) {
         for (int i = 0; i < n; ++i) {
           const uint32_t b = p[i];
           dead = dead || b == 0;
+          if (a.flag_class && b >= 128u && !dead) {
+            // a non-ASCII character of a class with builtins: decoded as the executor decodes it (regex_vm.h: char_at -- the width
+            // from the lead byte, a stray continuation byte a character of its own, a sequence cut at the row's end), a member
+            // through the unicode flags (class_match), all its bytes together
+            csrow::Char ch;
+            unsigned w = csrow::decode_at(p, i, n, ch);
+            if (w == 0) w = 1;
+            if (i + (int)w > n) w = (unsigned)(n - i);
+            const unsigned cp = csrow::packed_to_cp(ch);
+            bool cm = false;
+            if (cp <= 0xFFFFu) {
+              const unsigned f = a.flags[cp], bi = (unsigned)(a.flag_class >> 8) & 63u;
+              const bool alnum = (f & 15u) != 0;
+              cm = ((bi & 1u) && alnum) || ((bi & 2u) && (f & 16u)) || ((bi & 4u) && (f & 4u)) || ((bi & 8u) && !alnum) || ((bi & 16u) && !(f & 16u)) || ((bi & 32u) && !(f & 4u));
+            }
+            const bool m = ((a.flag_class >> 16) & 1) ? !cm : cm;
+            if (m) {
+              if (!a.plus || !in_run) {
+                if (PASS)
+                  for (int k = 0; k < rb; ++k) o[len + k] = (uint8_t)(a.rep[k >> 2] >> (8 * (k & 3)));
+                len += rb;
+              }
+            } else {
+              if (PASS)
+                for (unsigned k = 0; k < w; ++k) o[len + (int)k] = p[i + (int)k];
+              len += (int)w;
+            }
+            in_run = m;
+            i += (int)w - 1;
+            continue;
+          }
           const bool m = !dead && (b < 128u ? (spread[b] & 1u) != 0 : a.high_member != 0);
           if (m) {
             if (a.plus ? !in_run : (b & 0xC0u) != 0x80u) {
@@ -268,6 +302,8 @@ bool replace_class_runs(const cs_column* col, const int32_t* d_bits, const std::
   a.ntiles = (rows + R - 1) / R;
   a.bits = d_bits;
   a.high_member = (bits[2] & csbits::F_HIGH_MEMBER) ? 1 : 0;
+  a.flag_class = (bits[2] & csbits::F_FLAG_CLASS) ? (1 | (((bits[2] >> 16) & 63) << 8) | (((bits[2] >> 22) & 1) << 16)) : 0;
+  a.flags = d_unicode_flags();
   a.plus = (bits[2] & csbits::F_PLUS) ? 1 : 0;
   a.rb = rb;
   for (int k = 0; k < rb; ++k) a.rep[k >> 2] |= (uint32_t)(unsigned char)repl[k] << (8 * (k & 3));

@@ -211,6 +211,12 @@ std::vector<int32_t> build_bits(const Program& prog, const std::vector<int32_t>&
       high = in.type == OP_NCCLASS;
     }
     if (bytewise) fl |= csbits::F_BYTE_CLASS | (high ? csbits::F_HIGH_MEMBER : 0u);
+    if (!bytewise && (in.type == OP_CCLASS || in.type == OP_NCCLASS) && in.u1 >= 0 && (size_t)in.u1 < prog.classes.size()) {
+      const CharClass& cc = prog.classes[(size_t)in.u1];
+      bool ascii_ranges = cc.builtins != 0 && (cc.builtins & ~63) == 0;
+      for (uint32_t r : cc.ranges) ascii_ranges = ascii_ranges && r < 128u;
+      if (ascii_ranges && !cs::cfg("CS_NO_FLAG_CLASS")) fl |= csbits::F_FLAG_CLASS | ((uint32_t)cc.builtins << 16) | (in.type == OP_NCCLASS ? 1u << 22 : 0u);
+    }
   }
 
   std::vector<int32_t> img(csbits::kHeaderWords + csbits::kTableWords, 0);

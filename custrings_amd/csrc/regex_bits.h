@@ -49,7 +49,11 @@ enum { F_WORD = 1, F_BOL = 2, F_EOL = 4, F_BOL_MULTI = 8, F_EOL_MULTI = 16, F_PU
        // the program is ONE class, once or in a `+` loop, whose membership is decided byte by byte on ANY text: a literal ASCII
        // byte, a set of ASCII bytes and ranges (no builtin classes: \w \s \d reach into the non-ASCII characters), its negation
        // or `.` -- F_HIGH_MEMBER: every non-ASCII character, i.e. every byte >= 0x80, is a member (cs_runs.hip)
-       F_BYTE_CLASS = 256, F_HIGH_MEMBER = 512 };
+       F_BYTE_CLASS = 256, F_HIGH_MEMBER = 512,
+       // ... or ONE class of ASCII ranges and builtin classes (`\w+`, `[\w.]`, `\S+`, `[^\d]`): byte by byte on text WITHOUT bytes >= 0x80;
+       // a non-ASCII character is a member through the unicode flags alone -- bits 16..21 the class's builtins (regex_vm.h:
+       // class_match), bit 22 the class is negated: cs_runs.hip takes tiles with such bytes row by row, decoding as the reference does
+       F_FLAG_CLASS = 1024 };
 enum { K_CLASS = 0, K_BOW = 1, K_NBOW = 2, K_BOL = 3, K_EOL = 4, K_BOL_MULTI = 5, K_EOL_MULTI = 6 };
 
 struct View {

@@ -566,7 +566,9 @@ def test_gpu_compare_with_the_empty_string():
 
 
 # ---- one character class, once or in a `+` loop: byte-parallel compaction on rows of any length (cs_runs.hip) -----------
-@pytest.mark.parametrize("pat", [r"[aeiou]+", r"[^ ]+", r".", r".+", r"e", r"[a-e]", r"[^a-z ]+", r" +", r"[0-9.]+"])
+@pytest.mark.parametrize("pat", [r"[aeiou]+", r"[^ ]+", r".", r".+", r"e", r"[a-e]", r"[^a-z ]+", r" +", r"[0-9.]+",
+                                 # classes with builtins: a non-ASCII character is a member through the unicode flags (tiles with such bytes row by row)
+                                 r"\w+", r"\W+", r"\S+", r"[\w.]+", r"[^\w]", r"\d", r"[^\d ]+", r"\s", r"[\W\d]+", r"\w"])
 def test_gpu_class_runs_vs_oracle(pat, monkeypatch):
     """replace_re of a single-class pattern through the byte-parallel kernels -- C5's rows of 40-150 bytes with non-ASCII
     characters and nulls, then rows chosen to sit on tile and piece boundaries -- against the oracle, route asserted."""
@@ -581,9 +583,12 @@ def test_gpu_class_runs_vs_oracle(pat, monkeypatch):
         assert last_route() == "runs" or len(repl) == 16, (pat, repl, last_route())
         gpuutil.assert_same(out, orc.replace_re(o, blob, repl), "replace_re(%r, %r) on C5" % (pat, repl))
     special = ["", None, "a", "aeiou", "xaeioux", " ", "  ", "a e i", "é", "aéa", "naïve café", "e" * 300, "b" * 300, "ae" * 700 + "x", "x" * 15 + "a", "x" * 16 + "a",
-               "a" + "x" * 15, "\n", "a\nb", "1.2.3.4", ". . .", "\x00a\x00", "日本語 テキスト aeiou", "a" * 1023, "a" * 1024, "a" * 1025 + " b"]
+               "a" + "x" * 15, "\n", "a\nb", "1.2.3.4", ". . .", "\x00a\x00", "日本語 テキスト aeiou", "a" * 1023, "a" * 1024, "a" * 1025 + " b",
+               # what the unicode flags decide: accented letters, digits of other scripts, spaces of other kinds, an emoji (beyond the
+               # flags table), '_' and the newline
+               "señor_1 ½ ٣٤ ３ 　x\u00a0y\u2003z", "x😀y 😀😀 _a_", "é" * 40 + " " + "ü" * 40, "a_b\nc_d", "Ωμέγα-3", "\u0660\u0661 ۲۳", "x" * 15 + "é" + "y" * 15 + "日"]
     rnd = np.random.default_rng(7)
-    more = ["".join(rnd.choice(list("aeiou xyz.é1"), size=int(rnd.integers(0, 180)))) for _ in range(3000)]
+    more = ["".join(rnd.choice(list("aeiou xyz.é1_") + ["日", "😀", "\u00a0", "٣"], size=int(rnd.integers(0, 180)))) for _ in range(3000)]
     col = cpulibs.Col.from_list(special * 3 + more + special)
     gc = gpuutil.from_col(col)
     for repl in ("#", "", "=+="):
@@ -599,8 +604,8 @@ def test_gpu_class_runs_route_is_for_long_or_non_ascii_columns():
     assert last_route() == "runs"
     g5.replace(r"#+", "*")  # (no candidates in the sample: the skipping scans)
     assert last_route() != "runs"
-    g5.replace(r"\w+", "*")  # (a builtin class reaches into the non-ASCII characters: not a byte class)
-    assert last_route() != "runs"
+    g5.replace(r"\w+", "*")  # (a builtin class: byte-parallel on the tiles without bytes >= 0x80, row by row on the others)
+    assert last_route() == "runs"
     g3 = gpuutil.synth(3, 0, 40_000)
     g3.replace(r"[aeiou]+", "*")
     assert last_route() == "bits"

@@ -26,6 +26,7 @@ PATS = [(r"\d+\.\d+\.\d+\.\d+", "<IP>"), (r"\d", "#"), (r"[a-c]+", "xyz__"), (r"
         (r"\b\d{1,3}\.\d{1,3}\.\d{1,3}\.\d{1,3}\b", "<IP>"), (r"\b\d+\.\d+\b", ""), (r"\d+\.\d{2}\.\d+", "#"), (r"\b[a-c]{2,3}=", "<a-longer-replacement>"),
         (r"\d\d+\.\d+", "."), (r"\d+\.{1,2}\d+", "x"),
         # the bit-parallel form (regex_bits.h) and the single-class byte-parallel route (cs_runs.hip)
+        (r"\w+", "<w>"), (r"\S+", "s"), (r"[^\w]", "_"), (r"[\w.]+", ""), (r"\W+", " "), (r"\d", "9"),  # (classes with builtins: cs_runs.hip, F_FLAG_CLASS)
         (r"(\bab\b)|(\bc\b)|(\bxyz\b)", "="), (r"[abc1]+", "*"), (r"ab|a1|bc", "#"), (r"[^ ]+", "_"), (r".", "?"), (r"x?y?z", "Q")]
 
 
