@@ -45,6 +45,7 @@ struct cs_regex {
 
 namespace cs {
 bool replace_class_runs(const cs_column* col, const int32_t* d_bits, const std::vector<int32_t>& bits, const char* repl, int rb, hipStream_t s, cs_column** out);
+bool count_class_runs(const cs_column* col, const int32_t* d_bits, const std::vector<int32_t>& bits, hipStream_t s, int32_t* results, int64_t* hits);
 thread_local int g_replace_plain_only = 0;  // set by cs_replace around its call of cs_replace_re: single-pass kernel or nothing
 // cs_replace also leaves the needle itself here when it has at most eight bytes and no border (no proper prefix that is
 // also a suffix: occurrences cannot overlap): the stream kernel then finds the matches by byte comparison, all bytes of
@@ -2873,6 +2874,27 @@ void scan(const cs_column* col, cs_regex* re, uint8_t* out8, int32_t* out32, int
     tmp = dev_alloc(esz * col->rows, s);
     if (MODE == 2) out32 = ptr<int32_t>(tmp);
     else out8 = ptr<uint8_t>(tmp);
+  }
+  // count_re of ONE class, once or in a `+` loop, on a column the 96-bit-mask forms do not take (long rows, non-ASCII text) and
+  // whose candidates are everywhere: the byte-parallel size pass of cs_runs.hip counting matches -- count_re(\w+), the words of
+  // a row, on the C5 column: 15.8 ms on the long-row automaton form
+  if (MODE == 2 && !re->bits.empty() && (re->bits[2] & (csbits::F_BYTE_CLASS | csbits::F_FLAG_CLASS))) {
+    upload(re, s);
+    const TileChoice tc0 = choose_tile(col, s, true);
+    const bool masks_form = tc0.R == 64 && !tc0.lng && !sample_has_high_bytes(col, s);
+    const bool chain_there = !re->tdfa.empty() && ((re->tdfa[30] >> 16) & 15) != 0 && tc0.R == 64 && !tc0.lng;
+    const bool flag_class = (re->bits[2] & csbits::F_BYTE_CLASS) == 0;
+    int64_t hits = 0;
+    if (re->d_bits && (cs::cfg("CS_CLASS_RUNS_ALWAYS") || (!masks_form && !(flag_class && chain_there) && candidate_share(re, col, s) >= 0.05)) &&
+        count_class_runs(col, ptr<const int32_t>(re->d_bits), re->bits, s, out32, &hits)) {
+      note_route("runs");
+      if (!on_device) {
+        CS_HIP(hipMemcpyAsync(host_out, tmp->p, esz * col->rows, hipMemcpyDeviceToHost, s));
+        CS_HIP(hipStreamSynchronize(s));
+      }
+      if (found) *found = hits;
+      return;
+    }
   }
   Buf cnt = dev_alloc(8, s);
   CS_HIP(hipMemsetAsync(cnt->p, 0, 8, s));

@@ -30,6 +30,7 @@ using namespace csdev;
 
 namespace cs {
 bool replace_class_runs(const cs_column* col, const int32_t* d_bits, const std::vector<int32_t>& bits, const char* repl, int rb, hipStream_t s, cs_column** out);
+bool count_class_runs(const cs_column* col, const int32_t* d_bits, const std::vector<int32_t>& bits, hipStream_t s, int32_t* results, int64_t* hits);
 }
 
 namespace {
@@ -46,6 +47,7 @@ struct RunsArgs {
   const uint8_t* flags; // the unicode flags table (64 K entries)
   int plus;             // runs (class+) or single members
   int rb;
+  int count_only;       // pass 0 as count_re: a row's matches instead of its output bytes (rb = 1, kept bytes count nothing, a null row 0)
   uint32_t rep[4];
   // pass 0
   int32_t* lens;  // [rows]: output bytes, -1 for a null row
@@ -106,7 +108,7 @@ __global__ void __launch_bounds__(256) k_runs_tile(RunsArgs a) {
 #pragma unroll
   for (int j = 0; j < cstile::kPfChunks; ++j) pf.v[j] = make_uint4(0, 0, 0, 0);
   cstile::issue_chars(in.chars, cstile::rl64(cur.o0, 0), cstile::rl64(cur.o1, 63), lane, pf);
-  int most = 0;
+  int most = 0, hit_rows = 0;
   for (;;) {
     const long long r0 = tile * R;
     const int nrows = (int)min((long long)R, in.rows - r0);
@@ -163,14 +165,14 @@ __global__ void __launch_bounds__(256) k_runs_tile(RunsArgs a) {
         const uint32_t cont = high & ~high16_of(make_uint4(q.v[j].x << 1, q.v[j].y << 1, q.v[j].z << 1, q.v[j].w << 1));
         const uint32_t starts = a.plus ? (mem & (rs | ~before) & 0xFFFFu) : (mem & ~cont);
         const uint32_t keep = ~mem & valid;
-        const int nout = __builtin_popcount(keep) + rb * __builtin_popcount(starts);
+        const int nout = (a.count_only ? 0 : __builtin_popcount(keep)) + rb * __builtin_popcount(starts);
         const int incl = wave_inclusive_scan(nout);
         const int excl = carry + incl - nout;
         keep_j[j] = keep;
         start_j[j] = starts;
         base_j[j] = excl;
         pexcl[i >> 4] = (uint32_t)excl;
-        pmask[i >> 4] = keep | (starts << 16);
+        pmask[i >> 4] = (a.count_only ? 0u : keep) | (starts << 16);
         carry += __builtin_amdgcn_readlane(incl, 63);
         carry_mem = (uint32_t)__builtin_amdgcn_readlane((int)(mem >> 15), 63);
       }
@@ -211,7 +213,7 @@ __global__ void __launch_bounds__(256) k_runs_tile(RunsArgs a) {
             } else {
               if (PASS)
                 for (unsigned k = 0; k < w; ++k) o[len + (int)k] = p[i + (int)k];
-              len += (int)w;
+              if (!a.count_only) len += (int)w;
             }
             in_run = m;
             i += (int)w - 1;
@@ -226,10 +228,15 @@ __global__ void __launch_bounds__(256) k_runs_tile(RunsArgs a) {
             }
           } else {
             if (PASS) o[len] = (uint8_t)b;
-            ++len;
+            if (!a.count_only) ++len;
           }
           in_run = m;
         }
+      }
+      if (PASS == 0 && a.count_only) {
+        if (len < 0) len = 0;
+        const unsigned long long hits = __ballot(len > 0);
+        hit_rows += __builtin_popcountll(hits);  // (added to the column's count once, when the wave is through: a same-address atomic a tile cost more than the tile)
       }
       if (PASS == 0 && lane < nrows) a.lens[r0 + lane] = len;
       cstile::wave_lds_fence();
@@ -249,8 +256,12 @@ __global__ void __launch_bounds__(256) k_runs_tile(RunsArgs a) {
       return (int)pexcl[x >> 4] + __builtin_popcount(m & below) + rb * __builtin_popcount((m >> 16) & below);
     };
     if (PASS == 0) {
-      int len = -1;
+      int len = a.count_only ? 0 : -1;
       if (live) len = n > 0 ? pos_of(lead + rbeg + n) - pos_of(lead + rbeg) : 0;
+      if (a.count_only) {
+        const unsigned long long hits = __ballot(len > 0);
+        hit_rows += __builtin_popcountll(hits);  // (added to the column's count once, when the wave is through: a same-address atomic a tile cost more than the tile)
+      }
       if (lane < nrows) a.lens[r0 + lane] = len;
       most = max(most, total);
     } else {
@@ -278,11 +289,54 @@ __global__ void __launch_bounds__(256) k_runs_tile(RunsArgs a) {
     ++tile;
   }
   if (PASS == 0 && lane == 0 && most > __hip_atomic_load(a.maxima, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(a.maxima, most);
+  if (PASS == 0 && lane == 0 && hit_rows) atomicAdd(a.maxima + 1, hit_rows);
 }
 
 }  // namespace
 
 namespace cs {
+
+// count_re of such a pattern: the size pass counting matches (results: device, int32 per row; *hits = rows with a match)
+bool count_class_runs(const cs_column* col, const int32_t* d_bits, const std::vector<int32_t>& bits, hipStream_t s, int32_t* results, int64_t* hits) {
+  const int64_t rows = col->rows;
+  if (rows == 0 || cs::cfg("CS_NO_CLASS_RUNS")) return false;
+  int R = 0;
+  for (int r : {64, 32, 16}) {
+    if (max_span_rows(col, r, s) + 16 <= cstile::kPfBytes) {
+      R = r;
+      break;
+    }
+  }
+  if (!R) return false;
+  RunsArgs a{};
+  a.in = view_of(col);
+  a.rows_per_tile = R;
+  a.ntiles = (rows + R - 1) / R;
+  a.bits = d_bits;
+  a.high_member = (bits[2] & csbits::F_HIGH_MEMBER) ? 1 : 0;
+  a.flag_class = (bits[2] & csbits::F_FLAG_CLASS) ? (1 | (((bits[2] >> 16) & 63) << 8) | (((bits[2] >> 22) & 1) << 16)) : 0;
+  a.flags = d_unicode_flags();
+  a.plus = (bits[2] & csbits::F_PLUS) ? 1 : 0;
+  a.rb = 1;
+  a.count_only = 1;
+  Buf maxima = dev_alloc(2 * sizeof(int), s);
+  CS_HIP(hipMemsetAsync(maxima->p, 0, 2 * sizeof(int), s));
+  a.lens = results;
+  a.maxima = ptr<int>(maxima);
+  constexpr size_t kBitmapBytes = cstile::kPfBytes / 8 + 32, kPieces = cstile::kPfChunks * 64;
+  const size_t lds0 = 512 + (kBitmapBytes + (kPieces + 1) * 8) * 4;
+  {
+    const unsigned g0 = resident_grid(reinterpret_cast<const void*>(&k_runs_tile<0>), lds0, (a.ntiles + 3) / 4);
+    ProfScope ps("k_runs_count", s);
+    hipLaunchKernelGGL(k_runs_tile<0>, dim3(g0), dim3(256), lds0, s, a);
+  }
+  CS_HIP(hipGetLastError());
+  int* host = (int*)pinned_scratch(2 * sizeof(int));
+  CS_HIP(hipMemcpyAsync(host, maxima->p, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
+  CS_HIP(hipStreamSynchronize(s));
+  if (hits) *hits = host[1];
+  return true;
+}
 
 // false: the column does not take the route (the caller goes on with the automaton kernels)
 bool replace_class_runs(const cs_column* col, const int32_t* d_bits, const std::vector<int32_t>& bits, const char* repl, int rb, hipStream_t s, cs_column** out) {
@@ -308,8 +362,8 @@ bool replace_class_runs(const cs_column* col, const int32_t* d_bits, const std::
   a.rb = rb;
   for (int k = 0; k < rb; ++k) a.rep[k >> 2] |= (uint32_t)(unsigned char)repl[k] << (8 * (k & 3));
   Buf lens = dev_alloc(sizeof(int32_t) * (size_t)rows, s);
-  Buf maxima = dev_alloc(sizeof(int), s);
-  CS_HIP(hipMemsetAsync(maxima->p, 0, sizeof(int), s));
+  Buf maxima = dev_alloc(2 * sizeof(int), s);
+  CS_HIP(hipMemsetAsync(maxima->p, 0, 2 * sizeof(int), s));
   a.lens = ptr<int32_t>(lens);
   a.maxima = ptr<int>(maxima);
   constexpr size_t kBitmapBytes = cstile::kPfBytes / 8 + 32, kPieces = cstile::kPfChunks * 64;

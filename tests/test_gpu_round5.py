@@ -595,6 +595,19 @@ def test_gpu_class_runs_vs_oracle(pat, monkeypatch):
         out = gc.replace(pat, repl)
         assert last_route() == "runs", (pat, repl)
         gpuutil.assert_same(out, orc.replace_re(col, blob, repl), "replace_re(%r, %r) on edge rows" % (pat, repl))
+    # count_re: the same size pass counting matches
+    L = gpuutil.lib()
+    re = gpuutil.compile_re(pat)
+    try:
+        for gg, oo, what in ((g, o, "C5"), (gc, col, "edge rows")):
+            cnt = np.zeros(max(gg.size(), 1), dtype=np.int32)
+            found = C.c_int64()
+            L.check(L.lib.cs_count_re(gg.m_cptr, re, cnt.ctypes.data, 0, None, C.byref(found)))
+            assert last_route() == "runs", (pat, what)
+            exp, en = orc.count_re(oo, blob)
+            assert np.array_equal(cnt[: gg.size()], exp) and found.value == en, (pat, "count_re", what)
+    finally:
+        L.lib.cs_regex_destroy(re)
 
 
 def test_gpu_class_runs_route_is_for_long_or_non_ascii_columns():
