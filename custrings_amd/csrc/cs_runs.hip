@@ -135,6 +135,7 @@ __global__ void __launch_bounds__(256) k_runs_tile(RunsArgs a) {
     cstile::wave_lds_fence();
     int carry = 0;            // output bytes of the pieces before this chunk row (wave-uniform)
     uint32_t carry_mem = 0;   // was the last byte of the previous chunk row a member?
+    uint32_t carry_ann = 0;   // continuation bytes the previous chunk row's last leads announce for this one
     uint32_t nul_seen = 0;
     uint32_t keep_j[cstile::kPfChunks], start_j[cstile::kPfChunks];
     int base_j[cstile::kPfChunks];
@@ -163,6 +164,25 @@ __global__ void __launch_bounds__(256) k_runs_tile(RunsArgs a) {
         // (without the `+` every member CHARACTER is a match: a multi-byte character -- a member only when bytes >= 0x80
         // are -- counts at its lead byte, its continuation bytes 10xxxxxx just go)
         const uint32_t cont = high & ~high16_of(make_uint4(q.v[j].x << 1, q.v[j].y << 1, q.v[j].z << 1, q.v[j].w << 1));
+        {
+          // Byte by byte is the executor's answer only where the bytes >= 0x80 form whole characters: it takes a character's width
+          // from its lead byte and swallows what follows, whatever that is (regex_vm.h: char_at) -- an ASCII member behind a
+          // lead without its continuation bytes is no match, a stray continuation byte is a character of its own.  The positions
+          // the leads ANNOUNCE as continuation bytes (one / two / three behind a lead >= 0xC0 / 0xE0 / 0xF0, carried into the
+          // next piece) must be exactly the continuation bytes, and none may open a row: anything else sends the tile row by row.
+          // (a chunk row without a byte >= 0x80 and nothing announced into it has nothing to check: most of plain text)
+          if (__any((high & valid) != 0) || carry_ann != 0) {
+          const uint32_t b5 = high16_of(make_uint4(q.v[j].x << 2, q.v[j].y << 2, q.v[j].z << 2, q.v[j].w << 2));
+          const uint32_t b4 = high16_of(make_uint4(q.v[j].x << 3, q.v[j].y << 3, q.v[j].z << 3, q.v[j].w << 3));
+          const uint32_t l2 = high & ~cont & valid, l3 = l2 & b5, l4 = l3 & b4;
+          const uint32_t ann = (l2 << 1) | (l3 << 2) | (l4 << 3);  // bits 1..18
+          uint32_t from_prev = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(ann >> 16), 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
+          if (lane == 0) from_prev = carry_ann;
+          const uint32_t expect = (ann & 0xFFFFu) | from_prev;
+          nul_seen |= ((expect ^ cont) | (cont & rs)) & valid;
+          carry_ann = (uint32_t)__builtin_amdgcn_readlane((int)(ann >> 16), 63);
+          }
+        }
         const uint32_t starts = a.plus ? (mem & (rs | ~before) & 0xFFFFu) : (mem & ~cont);
         const uint32_t keep = ~mem & valid;
         const int nout = (a.count_only ? 0 : __builtin_popcount(keep)) + rb * __builtin_popcount(starts);
@@ -188,22 +208,25 @@ __global__ void __launch_bounds__(256) k_runs_tile(RunsArgs a) {
         for (int i = 0; i < n; ++i) {
           const uint32_t b = p[i];
           dead = dead || b == 0;
-          if (a.flag_class && b >= 128u && !dead) {
-            // a non-ASCII character of a class with builtins: decoded as the executor decodes it (regex_vm.h: char_at -- the width
-            // from the lead byte, a stray continuation byte a character of its own, a sequence cut at the row's end), a member
-            // through the unicode flags (class_match), all its bytes together
+          if (b >= 128u && !dead) {
+            // a non-ASCII character, decoded as the executor decodes it (regex_vm.h: char_at -- the width from the lead byte, a stray
+            // continuation byte a character of its own, a sequence cut at the row's end), all its bytes together: a member by the
+            // class's flag (a byte class: every such character or none) or through the unicode flags (class_match)
             csrow::Char ch;
             unsigned w = csrow::decode_at(p, i, n, ch);
             if (w == 0) w = 1;
             if (i + (int)w > n) w = (unsigned)(n - i);
-            const unsigned cp = csrow::packed_to_cp(ch);
-            bool cm = false;
-            if (cp <= 0xFFFFu) {
-              const unsigned f = a.flags[cp], bi = (unsigned)(a.flag_class >> 8) & 63u;
-              const bool alnum = (f & 15u) != 0;
-              cm = ((bi & 1u) && alnum) || ((bi & 2u) && (f & 16u)) || ((bi & 4u) && (f & 4u)) || ((bi & 8u) && !alnum) || ((bi & 16u) && !(f & 16u)) || ((bi & 32u) && !(f & 4u));
+            bool m = a.high_member != 0;
+            if (a.flag_class) {
+              const unsigned cp = csrow::packed_to_cp(ch);
+              bool cm = false;
+              if (cp <= 0xFFFFu) {
+                const unsigned f = a.flags[cp], bi = (unsigned)(a.flag_class >> 8) & 63u;
+                const bool alnum = (f & 15u) != 0;
+                cm = ((bi & 1u) && alnum) || ((bi & 2u) && (f & 16u)) || ((bi & 4u) && (f & 4u)) || ((bi & 8u) && !alnum) || ((bi & 16u) && !(f & 16u)) || ((bi & 32u) && !(f & 4u));
+              }
+              m = ((a.flag_class >> 16) & 1) ? !cm : cm;
             }
-            const bool m = ((a.flag_class >> 16) & 1) ? !cm : cm;
             if (m) {
               if (!a.plus || !in_run) {
                 if (PASS)

@@ -610,6 +610,53 @@ def test_gpu_class_runs_vs_oracle(pat, monkeypatch):
         L.lib.cs_regex_destroy(re)
 
 
+@pytest.mark.parametrize("pat", [r"[a-c]+", r".", r"[^ ]+", r"\w+", r"[^\w]", r"b"])
+def test_gpu_class_runs_on_arbitrary_bytes(pat, monkeypatch):
+    """Malformed UTF-8: the executor takes a character's width from its lead byte and swallows what follows -- an ASCII member
+    behind a lead without its continuation bytes is no match, a stray continuation byte is a character of its own.  The
+    byte-parallel route answers byte by byte only on tiles whose bytes >= 0x80 form whole characters (cs_runs.hip: the
+    announced continuation bytes) and decodes the others row by row: replace_re and count_re on rows of random bytes against
+    the automaton kernels (the route off).  (Found by the soak: count_re([a-c]+) on `x\\xa9\\xe2b\\xf0BAb6`.)"""
+    monkeypatch.setenv("CS_CLASS_RUNS_ALWAYS", "1")
+    orc = cpulibs.Oracle()
+    L = gpuutil.lib()
+    rng = np.random.default_rng(20108)
+    pool = np.array(list(b"ab1.2 3.4.5.6 x9_\t\nABc") + [0, 0xC3, 0xA9, 0xE2, 0x82, 0xAC, 0xFF, 0x80, 0x1F, 0xF0, 0x9F], dtype=np.uint8)
+    lens = np.concatenate([rng.integers(0, 250, 6000), (rng.pareto(1.5, 300) * 20).astype(np.int64) % 3000, [0, 1, 2, 15, 16, 17, 1023, 1024, 1025]])
+    offs = np.zeros(len(lens) + 1, dtype=np.int64)
+    np.cumsum(lens, out=offs[1:])
+    col = cpulibs.Col(pool[rng.integers(0, len(pool), int(offs[-1]))], offs, None)
+    rows = [b"x\xa9\xe2b\xf0BAb6..\x00\xac.6x", b"\xe2.b\x0031.4\x82", b"\xe2ab", b"ab\xe2", b"ab\xf0\x9f", b"\x80a\x80b", b"\xc3\xa9a\xc3", b"a\xffb\xffc", b"\xf0abcd", b"\xf0\x9f\x98\x80ab"]
+    extra = cpulibs.Col(np.frombuffer(b"".join(rows), dtype=np.uint8).copy(), np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.int64), None)
+    blob = blob_of(pat)
+    re = gpuutil.compile_re(pat)
+    try:
+        for c in (extra, col):
+            g = gpuutil.from_col(c)
+            got = g.replace(pat, "#")
+            assert last_route() == "runs", pat
+            cnt = np.zeros(c.rows, dtype=np.int32)
+            found = C.c_int64()
+            L.check(L.lib.cs_count_re(g.m_cptr, re, cnt.ctypes.data, 0, None, C.byref(found)))
+            assert last_route() == "runs", pat
+            L.check(L.lib.cs_config_set(b"CS_CLASS_RUNS_ALWAYS", None))
+            L.check(L.lib.cs_config_set(b"CS_NO_CLASS_RUNS", b"1"))
+            try:
+                want = g.replace(pat, "#")
+                assert last_route() != "runs"
+                cnt2 = np.zeros(c.rows, dtype=np.int32)
+                L.check(L.lib.cs_count_re(g.m_cptr, re, cnt2.ctypes.data, 0, None, C.byref(found)))
+            finally:
+                L.check(L.lib.cs_config_set(b"CS_NO_CLASS_RUNS", None))
+                L.check(L.lib.cs_config_set(b"CS_CLASS_RUNS_ALWAYS", b"1"))
+            # (against the product's automaton kernels, as every test on malformed input: the reference's contract is valid UTF-8,
+            # where the oracle is the witness -- test_gpu_class_runs_vs_oracle)
+            gpuutil.assert_same(got, gpuutil.to_col(want), "replace_re(%r) on arbitrary bytes: runs against the automaton" % pat)
+            assert np.array_equal(cnt, cnt2), (pat, "count_re: runs against the automaton", np.flatnonzero(cnt != cnt2)[:5])
+    finally:
+        L.lib.cs_regex_destroy(re)
+
+
 def test_gpu_class_runs_route_is_for_long_or_non_ascii_columns():
     """The route is taken where the 96-bit-mask forms are not: C5 (long rows); C3 keeps the single pass."""
     g5 = gpuutil.synth(5, 0, 40_000)

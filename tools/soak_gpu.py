@@ -18,7 +18,8 @@ from custrings_amd import nvtext, nvcategory, _lib  # noqa: E402
 LIB = _lib.lib
 
 TOGGLES = ("CS_REGEX_TWO_PASS", "CS_REGEX_ROWWISE", "CS_SPLIT_GENERIC", "CS_TOKENIZE_ROWWISE", "CS_STRIP_ROWWISE",
-           "CS_FIND_ROWWISE", "CS_REPLACE_ROWWISE", "CS_CASE_ROWWISE", "CS_NGRAM_ROWWISE")
+           "CS_FIND_ROWWISE", "CS_REPLACE_ROWWISE", "CS_CASE_ROWWISE", "CS_NGRAM_ROWWISE",
+           "CS_NO_CLASS_RUNS")  # (the byte-parallel class route is a fast path too: off in the witness -- it sat on both sides until round 5's last soak)
 PATS = [(r"\d+\.\d+\.\d+\.\d+", "<IP>"), (r"\d", "#"), (r"[a-c]+", "xyz__"), (r"\s+", " "), (r"\w+", "<w>"), (r"b|ab", ""),
         (r"\bx", "YY"), (r"[0-9]+", "<number-here>"), (r"a", "aa"), (r"(a|b)c", "-"),
         (r"\d+\.\d+ ", "<n>"), (r"[a-c]+=>", ""), (r"\d+ab", "#"),  # (chains with a literal suffix)
