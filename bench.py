@@ -26,6 +26,7 @@ import torch.distributed as dist  # noqa: E402
 IPV4 = r"\d+\.\d+\.\d+\.\d+"
 REPL = "<IP>"
 SEED = 20240607
+RANKS_INFO = {"n_gpus": 1, "backend": None, "rccl_ranks": 0}
 KERNELS = ["k_split_measure", "k_split_emit", "k_split_write", "k_replace_re", "k_replace_re_size", "k_replace_re_write",
            "k_split_count", "k_split_sizes", "k_write_offsets", "k_scan_lookback"]
 
@@ -79,11 +80,30 @@ def main():
                          "c5 = tokenize + n-grams(2) with the shard-boundary exchange inside the timed region")
     ap.add_argument("--keys", type=int, default=1_000_000, help="c4: distinct tokens K")
     ap.add_argument("--backend", default="nccl", help="process-group backend (nccl = RCCL; gloo lets several ranks share one GPU for a plumbing check)")
+    ap.add_argument("--no-box", action="store_true", help="skip the box's streaming-rate calibration (`box` block)")
+    ap.add_argument("--concurrent-steps", type=int, default=10, help="steps with split and replace_re issued on two streams (reported as `concurrent`; 0 = skip)")
     args = ap.parse_args()
+
+    # ---- one process per GPU.  The driver launches N > 1 under torch.distributed.run (WORLD_SIZE in the environment);
+    # a plain `python bench.py --gpus N` re-executes itself that way, so that it cannot silently measure one rank.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        have = torch.cuda.device_count()
+        if args.backend == "nccl" and have < args.gpus:
+            sys.exit("bench.py: --gpus %d asked for, %d GPU(s) visible: refusing to measure fewer ranks than asked" % (args.gpus, have))
+        import socket
+
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        os.execv(sys.executable, cmd)
 
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but the process group has %d rank(s) (WORLD_SIZE): launch with --nproc-per-node equal to --gpus" % (args.gpus, world))
     local = local % max(torch.cuda.device_count(), 1)  # (more ranks than GPUs only with --backend gloo)
     torch.cuda.set_device(local)
     if world > 1:
@@ -91,6 +111,10 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(args.backend)
+        assert dist.get_world_size() == args.gpus, "process group size differs from --gpus"
+    global RANKS_INFO
+    RANKS_INFO = {"n_gpus": dist.get_world_size() if world > 1 else 1, "backend": (args.backend if world > 1 else None),
+                  "rccl_ranks": (dist.get_world_size() if world > 1 and args.backend == "nccl" else 0)}
 
     from custrings_amd import _lib, nvstrings
 
@@ -115,6 +139,19 @@ def main():
             dist.destroy_process_group()
         return
 
+    # ---- what this box's memory delivers to hand-written streaming kernels (custrings_amd/csrc/box_rates.h), same process
+    box = None
+    if not args.no_box and rank == 0:
+        rates = (C.c_double * 5)()
+        _lib.check(L.cs_box_rates(2048, 3, None, rates))
+        box = {"copy_TBps": round(rates[0], 2), "read_TBps": round(rates[1], 2), "write_TBps": round(rates[2], 2),
+               "scatter21_TBps": round(rates[3], 2), "scatter21_nt_TBps": round(rates[4], 2),
+               "what": "own streaming kernels, 2 GiB buffers, median of 3 launches, bytes read + written over the launch time: a 16 B/lane "
+                       "copy, a read-only and a write-only stream, and the split emit kernel's shape (one read stream into 20 x (256 + 192 + 8) B "
+                       "pieces per 64-row sub-tile, runs of 24 sub-tiles a wave) with plain / non-temporal stores"}
+        L.cs_pool_trim(0)  # (the calibration's buffers go back to the driver: the pool is empty again, as at the process's start)
+    barrier()
+
     # ---- this rank's shard: rows [rank*rows, (rank+1)*rows) of the C3 column
     out = C.c_void_p()
     _lib.check(L.cs_synth_column(3, rank * args.rows, args.rows, SEED, 0, None, C.byref(out)))
@@ -123,10 +160,10 @@ def main():
     re = nvstrings._compile(IPV4)
     stats = {}
 
-    def step(record=False):
+    def do_split(stream=None, record=False):
         arr = C.POINTER(C.c_void_p)()
         ncols = C.c_int()
-        _lib.check(L.cs_split(col.m_cptr, b" ", -1, None, C.byref(arr), C.byref(ncols)))
+        _lib.check(L.cs_split(col.m_cptr, b" ", -1, stream, C.byref(arr), C.byref(ncols)))
         if record:
             stats["split_cols"] = ncols.value
             stats["split_out_bytes"] = sum(int(L.cs_column_nbytes(arr[i])) for i in range(ncols.value))
@@ -134,11 +171,17 @@ def main():
         for i in range(ncols.value):
             L.cs_column_destroy(arr[i])
         L.cs_free(arr)
+
+    def do_replace(stream=None, record=False):
         o = C.c_void_p()
-        _lib.check(L.cs_replace_re(col.m_cptr, re, REPL.encode(), -1, None, C.byref(o)))
+        _lib.check(L.cs_replace_re(col.m_cptr, re, REPL.encode(), -1, stream, C.byref(o)))
         if record:
             stats["replace_out_bytes"] = int(L.cs_column_nbytes(o))
         L.cs_column_destroy(o)
+
+    def step(record=False):
+        do_split(None, record)
+        do_replace(None, record)
 
     step(record=True)
     for _ in range(max(args.warmup - 1, 0)):
@@ -157,7 +200,9 @@ def main():
     # ---- the same step on a FRESH column each iteration: nothing cached on the input from an earlier call (the timed
     # loop above re-uses one column, whose metadata -- longest row, largest 64-row span, the non-ASCII sample -- the
     # warm-up step paid for).  Generating the column is not timed; the step is, call to synchronised return.
+    barrier()
     cold_ms = []
+    mallocs0 = int(L.cs_debug_malloc_count())
     cold_fallbacks0 = int(L.cs_fallback_count())
     warm_prof = {}
     for k in KERNELS:  # (the timed loop's kernel times are read here: the cold steps get a profile of their own)
@@ -170,10 +215,9 @@ def main():
     for i in range(args.cold_steps):
         fresh = C.c_void_p()
         col = None  # (the old column's buffers go back to the pool first: the new one takes them)
-        # (the same seed: a column of another seed differs in size by a few KB, finds no block of its size in the buffer pool
-        # and pays a hipMalloc of gigabytes -- 120 ms, the allocator's cost, not the column's; the new column shares nothing
-        # with the old one but its content: fresh buffers, nothing cached on it)
-        _lib.check(L.cs_synth_column(3, rank * args.rows, args.rows, SEED, 0, None, C.byref(fresh)))
+        # (ANOTHER seed every step: the column and all 21 outputs differ in size by a few KB from the last ones; the pool's
+        # size classes -- cs_core.hip: size_class -- still find blocks for them, `cold.mallocs` counts the hipMalloc calls)
+        _lib.check(L.cs_synth_column(3, rank * args.rows, args.rows, SEED + 1 + i, 0, None, C.byref(fresh)))
         col = nvstrings.nvstrings(fresh.value)
         barrier()
         tc0 = time.perf_counter()
@@ -181,6 +225,7 @@ def main():
         barrier()
         cold_ms.append((time.perf_counter() - tc0) * 1e3)
     cold_fallbacks = int(L.cs_fallback_count()) - cold_fallbacks0
+    cold_mallocs = int(L.cs_debug_malloc_count()) - mallocs0
     L.cs_prof_enable(0)
     cold_prof = {}
     for k in KERNELS:
@@ -189,13 +234,54 @@ def main():
         if n.value:
             cold_prof[k] = round(ms.value / n.value, 3)
 
-    t = torch.tensor([elapsed] + cold_ms, dtype=torch.float64, device="cuda")
+    # ---- the same step with the two ops issued on two streams by two host threads (split's emit kernel is bound by its
+    # store drain and its LDS round trips, replace_re by its instruction stream: they overlap).  A SEPARATE entry: `value`
+    # and `ms_per_step` above are the ops one after the other on one stream.
+    conc_elapsed = 0.0
+    if args.concurrent_steps > 0:
+        import threading
+
+        sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+        pa, pb = C.c_void_p(sa.cuda_stream), C.c_void_p(sb.cuda_stream)
+        errs = []
+
+        def guarded(fn, st):
+            try:
+                fn(st)
+            except Exception as e:  # noqa: BLE001
+                errs.append(e)
+
+        def step_concurrent():
+            ta = threading.Thread(target=guarded, args=(do_split, pa))
+            tb = threading.Thread(target=guarded, args=(do_replace, pb))
+            ta.start()
+            tb.start()
+            ta.join()
+            tb.join()
+            if errs:
+                raise errs[0]
+
+        for _ in range(2):
+            step_concurrent()
+        conc_fallbacks0 = int(L.cs_fallback_count())
+        barrier()
+        tq = time.perf_counter()
+        for _ in range(args.concurrent_steps):
+            step_concurrent()
+        barrier()
+        conc_elapsed = time.perf_counter() - tq
+        conc_fallbacks = int(L.cs_fallback_count()) - conc_fallbacks0
+        L.cs_stream_forget(pa)
+        L.cs_stream_forget(pb)
+
+    t = torch.tensor([elapsed, conc_elapsed] + cold_ms, dtype=torch.float64, device="cuda")
     tot = torch.tensor([float(in_bytes), float(args.rows)], dtype=torch.float64, device="cuda")
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
     elapsed = float(t[0].item())
-    cold_ms = [float(x) for x in t[1:].tolist()]
+    conc_elapsed = float(t[1].item())
+    cold_ms = [float(x) for x in t[2:].tolist()]
     total_bytes, total_rows = float(tot[0].item()), float(tot[1].item())
 
     if rank == 0:
@@ -274,7 +360,8 @@ def main():
             "metric": "GB/s input chars, split(' ') + replace_re(IPv4) on 100M log-line rows per GPU",
             "value": round(total_bytes / (elapsed / args.steps) / 1e9, 2),
             "unit": "GB/s",
-            "n_gpus": world,
+            "n_gpus": RANKS_INFO["n_gpus"],
+            "rccl_ranks": RANKS_INFO["rccl_ranks"],
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(ms_step, 3),
@@ -300,8 +387,19 @@ def main():
             rest = cold_ms[1:] if len(cold_ms) > 1 else cold_ms
             result["cold"] = {"ms_per_step": round(sum(rest) / len(rest), 3), "steps": len(rest), "first_ms": round(cold_ms[0], 3),
                               "all_ms": [round(x, 3) for x in cold_ms], "fallbacks": cold_fallbacks, "kernels_avg_ms": cold_prof,
-                              "what": "the same step (split + replace_re, call to synchronised return) on a column generated just before it "
-                                      "(new buffers, nothing cached on it from an earlier call); generation untimed"}
+                              "mallocs": cold_mallocs,
+                              "what": "the same step (split + replace_re, call to synchronised return) on a column of ANOTHER SEED generated just "
+                                      "before it (other sizes, nothing cached on it from an earlier call); generation untimed; `mallocs` = hipMalloc "
+                                      "calls during all cold steps incl. the generation (the pool's size classes serve the rest)"}
+        if box:
+            result["box"] = box
+        if args.concurrent_steps > 0:
+            cms = conc_elapsed / args.concurrent_steps * 1e3
+            result["concurrent"] = {"ms_per_step": round(cms, 3), "steps": args.concurrent_steps, "fallbacks": conc_fallbacks,
+                                    "value": round(total_bytes / (cms * 1e-3) / 1e9, 2), "unit": "GB/s",
+                                    "what": "the same two ops on the same column issued on TWO streams by two host threads (cs_split on one, "
+                                            "cs_replace_re on the other), K steps between barriers; not the headline: `ms_per_step` above is "
+                                            "the ops one after the other"}
         if not args.no_cpu:
             result["cpu_baseline"] = cpu_baseline(args.cpu_rows)
         print(json.dumps(result), flush=True)
@@ -373,7 +471,7 @@ def run_c2(args, rank, world, barrier):
     total_alg = sum(alg.values())
     result = {
         "metric": "GB/s input chars, lower() + strip() + split(' ') on 10M rows x 64 chars per GPU (C2)",
-        "value": round(float(tot[0].item()) / per / 1e9, 2), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "value": round(float(tot[0].item()) / per / 1e9, 2), "unit": "GB/s", "n_gpus": RANKS_INFO["n_gpus"], "rccl_ranks": RANKS_INFO["rccl_ranks"], "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(per * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
         "config": {"workload": "C2: %d rows x 64 chars per GPU (5 %% rows with two-byte characters, 1 %% null, 0.5 %% empty), lower() -> strip() -> split(' ') into %d columns"
                                % (rows, info["cols"]), "rows_per_gpu": rows, "seed": SEED, "sharding": "row ranges, no data-path collective"},
@@ -442,7 +540,7 @@ def run_other_config(args, rank, world, barrier):
                    "GB/s input chars, tokenize + ngrams(2) incl. the shard-boundary exchange (C5)"),
         "value": round((float(tot[1].item()) / per / 1e6) if c4 else (float(tot[0].item()) / per / 1e9), 2),
         "unit": "Mstrings/s" if c4 else "GB/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(per * 1e3, 3), "higher_is_better": True,
+        "n_gpus": RANKS_INFO["n_gpus"], "rccl_ranks": RANKS_INFO["rccl_ranks"], "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(per * 1e3, 3), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
         "config": {"workload": ("C4: %d rows x 16-char tokens per GPU, Zipf(1.1) over K = %d, category build + key-set all-gather + merge + remap" % (rows, args.keys))
                    if c4 else ("C5: %d tweet-like rows per GPU, tokenize() + ngrams(2, '_') with the first-token exchange" % rows),

@@ -43,6 +43,10 @@ _PROTOS = {
     "cs_fallback_count": (i64, []),
     "cs_debug_last_route": (cp, []),
     "cs_config_set": (i32, [cp, cp]),
+    "cs_debug_malloc_count": (i64, []),
+    "cs_box_rates": (i32, [i64, i32, vp, P(C.c_double)]),
+    "cs_pool_cached_bytes": (i64, []),
+    "cs_pool_trim": (i32, [i64]),
     "cs_device_bytes_in_use": (i64, []),
     "cs_free": (None, [vp]),
     "cs_column_from_host_strings": (i32, [P(cp), i64, vp, P(vp)]),

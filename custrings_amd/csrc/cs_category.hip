@@ -558,7 +558,7 @@ cs_category* cs::category_build(const cs_column* col, hipStream_t s) {
     {
       ProfScope ps("k_cat_insert", s);
       const int limit = cap == full ? 0x7fffffff : kProbeLimit;
-      const int dbg = cs::cfg("CS_CAT_DEBUG") ? atoi(cs::cfg("CS_CAT_DEBUG")) : 0;
+      const int dbg = cs::cfg_int("CS_CAT_DEBUG", 0);
       hipLaunchKernelGGL(k_cat_insert, dim3(blocks_for(rows)), dim3(kBlock), 0, s, in, ptr<Entry>(table),
                          (uint32_t)(cap - 1), ptr<int32_t>(slot_of_row), ptr<int>(flags_d), ptr<int>(flags_d) + 1, limit,
                          dbg, sw);

@@ -1,6 +1,8 @@
 // cs_config.h: the CS_* switches, read from the environment once.
 #include "cs_config.h"
 
+#include <cstdlib>
+
 #include <cstring>
 #include <deque>
 #include <map>
@@ -48,6 +50,11 @@ const char* cfg(const char* name) {
   if (!st.loaded) load_locked(st);
   auto it = st.vals.find(std::string_view(name));
   return it == st.vals.end() ? nullptr : it->second;
+}
+
+int cfg_int(const char* name, int fallback) {
+  const char* e = cfg(name);
+  return e ? atoi(e) : fallback;
 }
 
 void cfg_set(const char* name, const char* value) {

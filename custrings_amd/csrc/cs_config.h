@@ -7,4 +7,6 @@ namespace cs {
 // the switch's value, or nullptr when it is not set (the pointer stays valid for the life of the process)
 const char* cfg(const char* name);
 void cfg_set(const char* name, const char* value);  // value == nullptr: unset
+// the switch as an integer, `fallback` when it is not set -- ONE look-up (a switch may be unset from another thread between two)
+int cfg_int(const char* name, int fallback);
 }  // namespace cs

@@ -41,6 +41,9 @@ struct CachedBlock {
   std::vector<hipEvent_t> released;  // one per stream known at the release (a column made on one stream may have been read on another)
 };
 static std::multimap<size_t, CachedBlock> g_cache;  // capacity -> block
+static int64_t g_cached_bytes = 0;                  // sum of the capacities in g_cache
+static int64_t g_cache_limit = 0;                   // 0 = not sized yet (half the device's memory, CS_POOL_MAX_MB overrides)
+static std::atomic<long long> g_mallocs{0};         // hipMalloc calls made by dev_alloc (cs_debug_malloc_count)
 static const hipStream_t kNoStream = reinterpret_cast<hipStream_t>(~(uintptr_t)0);  // "last used by nobody we still know"
 static std::vector<hipEvent_t> g_event_pool;
 // Streams that have asked for buffers.  While there is one (the usual case) stream order alone
@@ -80,6 +83,43 @@ static void release_cache_locked() {
     for (hipEvent_t e : kv.second.released) g_event_pool.push_back(e);
   }
   g_cache.clear();
+  g_cached_bytes = 0;
+}
+
+// Capacity a new block gets for a request of `want` bytes (reference: the RMM pool behind every device_alloc,
+// cpp/src/util.inl:90-106, python/tests/utils.py:25-34 -- a column a few KB larger than the last one must not cost a
+// hipMalloc of gigabytes, 120-134 ms on this machine).  From 1 MiB on: 1/32 of headroom, then the next of eight
+// geometric steps per octave, so the block also serves every later request up to 3 % larger (and, by the reuse rule in
+// dev_alloc, down to 20 % smaller); at most 16 % over the request.  Below that the sizes of a pipeline's buffers vary
+// more from column to column (a split column that few rows reach: +-10 %) and their bytes do not matter: 1/8 of headroom
+// and four steps per octave from 4 KiB on, whole 4 KiB pages below.
+static size_t size_class(size_t want) {
+  if (want <= 4096) return 4096;
+  const bool small = want < ((size_t)1 << 20);
+  const size_t w = want + want / (small ? 8 : 32);
+  const int e = 63 - __builtin_clzll((unsigned long long)w);
+  const size_t step = (size_t)1 << (e - (small ? 2 : 3));
+  return (w + step - 1) / step * step;
+}
+// the largest idle block a request may take: 25 % over it, or 256 KiB (the small blocks' classes are coarse)
+static size_t reuse_limit(size_t want) { return want + std::max<size_t>(want / 4 + 4096, (size_t)256 << 10); }
+
+// The cache is bounded: beyond the limit the largest idle blocks go back to the driver (hipFree waits for the device:
+// rare by construction -- the limit is half the device's memory unless CS_POOL_MAX_MB says otherwise).
+static void trim_cache_locked() {
+  if (g_cache_limit == 0) {
+    size_t free_b = 0, total_b = 0;
+    if (const char* e = cs::cfg("CS_POOL_MAX_MB")) g_cache_limit = std::max<int64_t>(1, atoll(e)) << 20;
+    else if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b) g_cache_limit = (int64_t)(total_b / 2);
+    else g_cache_limit = (int64_t)64 << 30;
+  }
+  while (g_cached_bytes > g_cache_limit && !g_cache.empty()) {
+    auto it = std::prev(g_cache.end());
+    (void)hipFree(it->second.first);
+    for (hipEvent_t e : it->second.released) g_event_pool.push_back(e);
+    g_cached_bytes -= (int64_t)it->first;
+    g_cache.erase(it);
+  }
 }
 
 DevBuf::~DevBuf() {
@@ -123,6 +163,8 @@ DevBuf::~DevBuf() {
   std::lock_guard<std::mutex> lk(g_mu);
   g_in_use -= (int64_t)capacity;
   g_cache.emplace(capacity, CachedBlock{p, stream, std::move(evs)});
+  g_cached_bytes += (int64_t)capacity;
+  trim_cache_locked();
 }
 
 Buf dev_alloc(size_t bytes, hipStream_t stream) {
@@ -138,7 +180,7 @@ Buf dev_alloc(size_t bytes, hipStream_t stream) {
     std::lock_guard<std::mutex> lk(g_mu);
     if (g_streams.insert(stream).second && g_streams.size() > 1) g_multi_stream.store(true);
     auto it = g_cache.lower_bound(want);
-    if (it != g_cache.end() && it->first <= want + want / 4 + 4096) {
+    if (it != g_cache.end() && it->first <= reuse_limit(want)) {
       b->p = it->second.first;
       b->capacity = it->first;
       prev = it->second.second;
@@ -147,6 +189,7 @@ Buf dev_alloc(size_t bytes, hipStream_t stream) {
       if (prev != stream && !g_streams.count(prev)) prev = stream;
       released = std::move(it->second.released);
       g_cache.erase(it);
+      g_cached_bytes -= (int64_t)b->capacity;
       g_in_use += (int64_t)b->capacity;
       reused = true;
     }
@@ -169,6 +212,15 @@ Buf dev_alloc(size_t bytes, hipStream_t stream) {
     return b;
   }
   void* p = nullptr;
+  const size_t asked = want;
+  want = size_class(want);
+  g_mallocs.fetch_add(1, std::memory_order_relaxed);
+  if (cs::cfg("CS_POOL_TRACE")) {  // (tests / tools: which requests miss the pool)
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = g_cache.lower_bound(asked);
+    fprintf(stderr, "custrings_amd pool: hipMalloc %zu bytes for a request of %zu (%zu idle blocks, %lld bytes; the next larger idle block: %zu)\n", want, asked, g_cache.size(),
+            (long long)g_cached_bytes, it == g_cache.end() ? (size_t)0 : it->first);
+  }
   hipError_t e = hipMalloc(&p, want);
   if (e != hipSuccess) {
     (void)hipGetLastError();
@@ -1155,6 +1207,22 @@ int cs_config_set(const char* name, const char* value) {
   });
 }
 int64_t cs_device_bytes_in_use(void) { return dev_bytes_in_use(); }
+int64_t cs_debug_malloc_count(void) { return (int64_t)g_mallocs.load(); }
+int64_t cs_pool_cached_bytes(void) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  return g_cached_bytes;
+}
+int cs_pool_trim(int64_t keep_bytes) {
+  return guard([&] {
+    require_device();
+    CS_HIP(hipDeviceSynchronize());
+    std::lock_guard<std::mutex> lk(g_mu);
+    const int64_t limit = g_cache_limit;
+    g_cache_limit = std::max<int64_t>(keep_bytes, 1);
+    trim_cache_locked();
+    g_cache_limit = limit;
+  });
+}
 void cs_free(void* p) { free(p); }
 
 int cs_column_from_host_strings(const char* const* strs, int64_t rows, cs_stream stream, cs_column** out) {

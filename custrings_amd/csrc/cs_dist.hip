@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdio>
 #include <cstring>
 #include <mutex>
 #include <vector>
@@ -73,11 +74,23 @@ int rccl_alltoallv(void* comm, const void* send, const size_t* send_bytes, const
                    int nranks, void* stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);
   rccl_check(g_group_start(), "ncclGroupStart");
-  for (int d = 0; d < nranks; ++d) {
-    if (send_bytes[d]) rccl_check(g_send(const_cast<uint8_t*>(static_cast<const uint8_t*>(send)) + send_off[d], send_bytes[d], 1, d, comm, s), "ncclSend");
-    if (recv_bytes[d]) rccl_check(g_recv(static_cast<uint8_t*>(recv) + recv_off[d], recv_bytes[d], 1, d, comm, s), "ncclRecv");
+  // (an error inside the group is remembered, the group is CLOSED whatever happened -- an open group would stay on the
+  // caller's communicator -- and only then reported)
+  int first = 0;
+  const char* where = "";
+  for (int d = 0; d < nranks && first == 0; ++d) {
+    if (send_bytes[d]) {
+      first = g_send(const_cast<uint8_t*>(static_cast<const uint8_t*>(send)) + send_off[d], send_bytes[d], 1, d, comm, s);
+      where = "ncclSend";
+    }
+    if (first == 0 && recv_bytes[d]) {
+      first = g_recv(static_cast<uint8_t*>(recv) + recv_off[d], recv_bytes[d], 1, d, comm, s);
+      where = "ncclRecv";
+    }
   }
-  rccl_check(g_group_end(), "ncclGroupEnd");
+  const int end = g_group_end();
+  rccl_check(first, where);
+  rccl_check(end, "ncclGroupEnd");
   return 0;
 }
 
@@ -118,10 +131,33 @@ std::vector<KeyHeader> gather_headers(const Exchange& x, const cs_column* mine, 
   for (int r = 0; r < n; ++r)
     if (all[r].status != 0)
       fail(all[r].status == CS_ERR_ALLOC ? CS_ERR_ALLOC : CS_ERR_INTERNAL, "category_build_distributed: rank " + std::to_string(r) + " failed before the exchange (status " +
-                                                                               std::to_string(all[r].status) + "); every rank stops");
+                                                                               std::to_string(all[r].status) + ", " + what + "); every rank stops");
   if (all[x.rank].keys != me.keys || all[x.rank].bytes != me.bytes) fail(CS_ERR_INTERNAL, "category_build_distributed: the exchange returned another rank's record at this rank's place");
   return all;
 }
+// An agreement point of the partitioned merge: every rank contributes its status word, and when any rank has failed
+// since the last exchange ALL ranks stop here together -- the one that failed with its own error, the others naming it --
+// instead of one rank throwing while its peers wait in the next collective for ever.
+void agree(const Exchange& x, int status, const std::string& why, const char* stage) {
+  hipStream_t s = x.s;
+  const int n = x.nranks;
+  int64_t me = status;
+  Buf w = dev_alloc(sizeof(int64_t) * (n + 1), s);
+  int64_t* d = ptr<int64_t>(w);
+  CS_HIP(hipMemcpyAsync(d + n, &me, sizeof(me), hipMemcpyHostToDevice, s));
+  CS_HIP(hipStreamSynchronize(s));
+  if (x.allgather(x.ctx, d + n, d, sizeof(int64_t), s) != 0)
+    fail(CS_ERR_INTERNAL, std::string("category_build_distributed: the status exchange failed (") + stage + ")");
+  std::vector<int64_t> all(n);
+  CS_HIP(hipMemcpyAsync(all.data(), d, sizeof(int64_t) * n, hipMemcpyDeviceToHost, s));
+  CS_HIP(hipStreamSynchronize(s));
+  if (status) fail(status, why + " (" + stage + "; every rank stops)");
+  for (int r = 0; r < n; ++r)
+    if (all[r] != 0)
+      fail(all[r] == CS_ERR_ALLOC ? CS_ERR_ALLOC : CS_ERR_INTERNAL, "category_build_distributed: rank " + std::to_string(r) + " failed (status " + std::to_string(all[r]) +
+                                                                        ", " + stage + "); every rank stops");
+}
+
 // Every rank's column on every rank: offsets and chars padded to the largest (an all-gather moves equal pieces); the
 // columns are views into the two gathered buffers.
 struct Gathered {
@@ -148,8 +184,18 @@ Gathered gather_columns(const Exchange& x, const cs_column* mine, std::vector<Ke
   }
   const KeyHeader& me = g.hdr[x.rank];
   const size_t off_piece = sizeof(int64_t) * (size_t)(max_keys + 1), chr_piece = (size_t)((max_bytes + 15) & ~(int64_t)15);
-  g.offs = dev_alloc(off_piece * (n + 1), s);
-  g.chrs = dev_alloc(chr_piece * (n + 1) + 16, s);
+  {  // (the gathered buffers hold every rank's piece: a rank that cannot have them says so before anybody enters the all-gather)
+    int st = 0;
+    std::string why;
+    try {
+      g.offs = dev_alloc(off_piece * (n + 1), s);
+      g.chrs = dev_alloc(chr_piece * (n + 1) + 16, s);
+    } catch (const Error& e) {
+      st = e.code ? e.code : CS_ERR_INTERNAL;
+      why = e.msg;
+    }
+    agree(x, st, why, what);
+  }
   uint8_t* my_off = ptr<uint8_t>(g.offs) + off_piece * n;
   uint8_t* my_chr = ptr<uint8_t>(g.chrs) + chr_piece * n;
   CS_HIP(hipMemsetAsync(my_off, 0, off_piece, s));
@@ -190,7 +236,7 @@ constexpr int kSplitterSamplesPerRank = 64;  // per destination rank
 // cut[j + 1] = index of the first local key (from `first` on: a null key stays in range 0) that is not below splitter j
 // (custring.inl:240-261: unsigned bytewise, shorter is less)
 __global__ void k_range_cuts(ColView keys, int64_t first, ColView split, int nsplit, int64_t* __restrict__ cut) {
-  const int j = threadIdx.x;
+  const int j = (int)(blockIdx.x * blockDim.x + threadIdx.x);
   if (j >= nsplit) return;
   const uint8_t* sp = split.chars + split.offsets[j];
   const int64_t sn = split.offsets[j + 1] - split.offsets[j];
@@ -234,75 +280,130 @@ std::unique_ptr<cs_column> rows_at(const cs_column* col, const std::vector<int32
   return std::unique_ptr<cs_column>(gather_rows(col, ptr<const int32_t>(d), (int64_t)pos.size(), s));
 }
 
+// Failure agreement: between the collectives below sit multi-GB allocations and consistency checks that may
+// throw on ONE rank (the owner of a skewed range running out of memory, say).  Every stretch of local work runs under
+// `attempt`, which turns a throw into a status; the next exchange -- a header gather, the size exchange (one more slot per
+// row) or an `agree` in front of an all-to-all whose sizes are already fixed -- carries the status, and all ranks stop
+// there together.  CS_DIST_TEST_FAIL_AT=<rank>:<stage> simulates a failure in stage 1..4 (tests).
 cs_category* merge_partitioned(const Exchange& x, const cs_category* local, const std::vector<KeyHeader>& heads) {
   hipStream_t s = x.s;
   const int n = x.nranks;
   const cs_column* keys = local->keys.get();
   const int64_t K = keys->rows, first = heads[x.rank].null_first ? 1 : 0;
-  // ---- splitters: a strided sample of every rank's keys, pooled, sorted, cut into n ranges
-  std::vector<int32_t> pos;
-  {
+  int status = 0;
+  std::string why;
+  int fail_stage = 0;
+  if (const char* f = cs::cfg("CS_DIST_TEST_FAIL_AT")) {
+    int r = -1, st = 0;
+    if (sscanf(f, "%d:%d", &r, &st) == 2 && r == x.rank) fail_stage = st;
+  }
+  int stage = 0;
+  auto attempt = [&](auto&& work) {
+    ++stage;
+    if (status) return;
+    try {
+      if (stage == fail_stage) fail(CS_ERR_ALLOC, "simulated failure in stage " + std::to_string(stage) + " of the partitioned merge (CS_DIST_TEST_FAIL_AT)");
+      work();
+    } catch (const Error& e) {
+      status = e.code ? e.code : CS_ERR_INTERNAL;
+      why = e.msg;
+    } catch (const std::exception& e) {
+      status = CS_ERR_INTERNAL;
+      why = e.what();
+    }
+  };
+  // ---- stage 1: splitters -- a strided sample of every rank's keys, pooled, sorted, cut into n ranges
+  std::unique_ptr<cs_column> sample;
+  attempt([&] {
+    std::vector<int32_t> pos;
     const int64_t want = (int64_t)kSplitterSamplesPerRank * n, step = std::max<int64_t>((K - first) / want, 1);
     for (int64_t i = first; i < K; i += step) pos.push_back((int32_t)i);
+    sample = rows_at(keys, pos, s);
+  });
+  Gathered gs;
+  {
+    std::vector<KeyHeader> sh;
+    try {
+      sh = gather_headers(x, status ? nullptr : sample.get(), status, "splitter samples");
+    } catch (const Error& e) {
+      if (status) fail(status, why + " (" + e.msg + ")");
+      throw;
+    }
+    gs = gather_columns(x, sample.get(), std::move(sh), "splitter samples");
   }
-  std::unique_ptr<cs_column> sample = rows_at(keys, pos, s);
-  Gathered gs = gather_columns(x, sample.get(), gather_headers(x, sample.get(), 0, "splitter samples"), "splitter samples");
-  std::unique_ptr<cs_column> splitters;
-  int nsplit = 0;
-  if (gs.total_keys > 0) {
-    std::unique_ptr<cs_column> pooled(concat_columns(gs.ptrs(), s));
-    std::unique_ptr<cs_category> pool(category_build(pooled.get(), s));  // sorted, unique: the same on every rank
-    const int64_t M = pool->keys->rows, stride = std::max<int64_t>(M / n, 1);
-    std::vector<int32_t> sp;
-    for (int64_t i = stride; i < M && (int)sp.size() < n - 1; i += stride) sp.push_back((int32_t)i);
-    nsplit = (int)sp.size();
-    if (nsplit) splitters = rows_at(pool->keys.get(), sp, s);
-  }
-  // ---- this rank's keys by range: keys cut[d] .. cut[d + 1] go to rank d
-  std::vector<int64_t> cut(n + 1, K);
+  // ---- stage 2: this rank's keys by range: keys cut[d] .. cut[d + 1] go to rank d
+  std::vector<int64_t> cut(n + 1, K), byte_at(n + 1, 0);
   cut[0] = 0;
-  Buf d_cut = upload_i64(cut, s);
-  if (nsplit && K > 0) {
-    hipLaunchKernelGGL(k_range_cuts, dim3(1), dim3(256), 0, s, view_of(keys), first, view_of(splitters.get()), nsplit, ptr<int64_t>(d_cut));
-    CS_HIP(hipGetLastError());
-    CS_HIP(hipMemcpyAsync(cut.data(), d_cut->p, sizeof(int64_t) * (n + 1), hipMemcpyDeviceToHost, s));
-    CS_HIP(hipStreamSynchronize(s));
-    for (int d = nsplit + 1; d <= n; ++d) cut[d] = K;
-    for (int d = 1; d <= n; ++d) cut[d] = std::max(cut[d], cut[d - 1]);
-    CS_HIP(hipMemcpyAsync(d_cut->p, cut.data(), sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice, s));
-    CS_HIP(hipStreamSynchronize(s));
-  }
-  std::vector<int64_t> byte_at(n + 1, 0);
-  if (K > 0) {
-    for (int d = 0; d <= n; ++d) CS_HIP(hipMemcpyAsync(&byte_at[d], keys->d_offsets() + cut[d], sizeof(int64_t), hipMemcpyDeviceToHost, s));
-    CS_HIP(hipStreamSynchronize(s));
-  }
-  // ---- who sends how much to whom: every rank's (keys, bytes) per destination, all-gathered
-  std::vector<int64_t> mine(2 * n);
-  for (int d = 0; d < n; ++d) {
+  Buf d_cut;
+  attempt([&] {
+    std::unique_ptr<cs_column> splitters;
+    int nsplit = 0;
+    if (gs.total_keys > 0) {
+      std::unique_ptr<cs_column> pooled(concat_columns(gs.ptrs(), s));
+      std::unique_ptr<cs_category> pool(category_build(pooled.get(), s));  // sorted, unique: the same on every rank
+      const int64_t M = pool->keys->rows, stride = std::max<int64_t>(M / n, 1);
+      std::vector<int32_t> sp;
+      for (int64_t i = stride; i < M && (int)sp.size() < n - 1; i += stride) sp.push_back((int32_t)i);
+      nsplit = (int)sp.size();
+      if (nsplit) splitters = rows_at(pool->keys.get(), sp, s);
+    }
+    d_cut = upload_i64(cut, s);
+    if (nsplit && K > 0) {
+      hipLaunchKernelGGL(k_range_cuts, dim3((unsigned)((nsplit + 255) / 256)), dim3(256), 0, s, view_of(keys), first, view_of(splitters.get()), nsplit, ptr<int64_t>(d_cut));
+      CS_HIP(hipGetLastError());
+      CS_HIP(hipMemcpyAsync(cut.data(), d_cut->p, sizeof(int64_t) * (n + 1), hipMemcpyDeviceToHost, s));
+      CS_HIP(hipStreamSynchronize(s));
+      for (int d = nsplit + 1; d <= n; ++d) cut[d] = K;
+      for (int d = 1; d <= n; ++d) cut[d] = std::max(cut[d], cut[d - 1]);
+      CS_HIP(hipMemcpyAsync(d_cut->p, cut.data(), sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice, s));
+      CS_HIP(hipStreamSynchronize(s));
+    }
+    if (K > 0) {
+      for (int d = 0; d <= n; ++d) CS_HIP(hipMemcpyAsync(&byte_at[d], keys->d_offsets() + cut[d], sizeof(int64_t), hipMemcpyDeviceToHost, s));
+      CS_HIP(hipStreamSynchronize(s));
+    }
+  });
+  // ---- who sends how much to whom: every rank's (keys, bytes) per destination and its status, all-gathered
+  const size_t slots = 2 * (size_t)n + 1, row = sizeof(int64_t) * slots;
+  std::vector<int64_t> mine(slots, 0);
+  for (int d = 0; d < n && !status; ++d) {
     mine[2 * d] = cut[d + 1] - cut[d];
     mine[2 * d + 1] = byte_at[d + 1] - byte_at[d];
   }
-  const size_t row = sizeof(int64_t) * 2 * (size_t)n;
-  Buf d_counts = dev_alloc(row * (n + 1), s);
-  CS_HIP(hipMemcpyAsync(ptr<uint8_t>(d_counts) + row * n, mine.data(), row, hipMemcpyHostToDevice, s));
-  CS_HIP(hipStreamSynchronize(s));
-  if (x.allgather(x.ctx, ptr<uint8_t>(d_counts) + row * n, d_counts->p, row, s) != 0) fail(CS_ERR_INTERNAL, "category_build_distributed: the exchange of the range sizes failed");
-  std::vector<int64_t> counts((size_t)2 * n * n);
-  CS_HIP(hipMemcpyAsync(counts.data(), d_counts->p, row * n, hipMemcpyDeviceToHost, s));
-  CS_HIP(hipStreamSynchronize(s));
+  mine[2 * n] = status;
+  std::vector<int64_t> counts(slots * n);
+  {
+    Buf d_counts = dev_alloc(row * (n + 1), s);  // (small: a failure here is the exchange's own)
+    CS_HIP(hipMemcpyAsync(ptr<uint8_t>(d_counts) + row * n, mine.data(), row, hipMemcpyHostToDevice, s));
+    CS_HIP(hipStreamSynchronize(s));
+    if (x.allgather(x.ctx, ptr<uint8_t>(d_counts) + row * n, d_counts->p, row, s) != 0) fail(CS_ERR_INTERNAL, "category_build_distributed: the exchange of the range sizes failed");
+    CS_HIP(hipMemcpyAsync(counts.data(), d_counts->p, row * n, hipMemcpyDeviceToHost, s));
+    CS_HIP(hipStreamSynchronize(s));
+  }
+  if (status) fail(status, why + " (before the exchange of the range sizes; every rank stops)");
+  for (int r = 0; r < n; ++r)
+    if (counts[slots * r + 2 * n] != 0)
+      fail(counts[slots * r + 2 * n] == CS_ERR_ALLOC ? CS_ERR_ALLOC : CS_ERR_INTERNAL, "category_build_distributed: rank " + std::to_string(r) + " failed (status " +
+                                                                                          std::to_string(counts[slots * r + 2 * n]) + ", range sizes); every rank stops");
   std::vector<int64_t> got_keys(n), got_bytes(n);
   int64_t in_keys = 0, in_bytes = 0;
   for (int r = 0; r < n; ++r) {
-    got_keys[r] = counts[(size_t)2 * n * r + 2 * x.rank];
-    got_bytes[r] = counts[(size_t)2 * n * r + 2 * x.rank + 1];
+    got_keys[r] = counts[slots * r + 2 * x.rank];
+    got_bytes[r] = counts[slots * r + 2 * x.rank + 1];
     in_keys += got_keys[r];
     in_bytes += got_bytes[r];
   }
+  // ---- stage 3: room for what arrives (the owner of a skewed range may not have it: agreed on BEFORE anything is sent)
+  Buf lens, in_lens, in_chars, back;
+  attempt([&] {
+    lens = dev_alloc(sizeof(int32_t) * (size_t)std::max<int64_t>(K, 1), s);
+    if (K) hipLaunchKernelGGL(k_key_lens, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, s, keys->d_offsets(), K, ptr<int32_t>(lens));
+    in_lens = dev_alloc(sizeof(int32_t) * (size_t)std::max<int64_t>(in_keys, 1), s);
+    in_chars = dev_alloc((size_t)in_bytes + 16, s);
+    back = dev_alloc(sizeof(int32_t) * (size_t)std::max<int64_t>(K, 1), s);
+  });
+  agree(x, status, why, "receive buffers of the key ranges");
   // ---- the keys travel: lengths, then bytes
-  Buf lens = dev_alloc(sizeof(int32_t) * (size_t)std::max<int64_t>(K, 1), s);
-  if (K) hipLaunchKernelGGL(k_key_lens, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, s, keys->d_offsets(), K, ptr<int32_t>(lens));
-  Buf in_lens = dev_alloc(sizeof(int32_t) * (size_t)std::max<int64_t>(in_keys, 1), s), in_chars = dev_alloc((size_t)in_bytes + 16, s);
   std::vector<size_t> sb(n), so(n), rb(n), lro(n), cro(n);
   size_t acc = 0;
   for (int d = 0; d < n; ++d) {
@@ -325,46 +426,48 @@ cs_category* merge_partitioned(const Exchange& x, const cs_category* local, cons
   const uint8_t* my_chars = keys->nbytes > 0 ? keys->d_chars() + byte_at[0] : ptr<const uint8_t>(in_chars);  // (a valid address when nothing is sent)
   if (x.alltoallv(x.ctx, my_chars, sb.data(), so.data(), in_chars->p, rb.data(), cro.data(), n, s) != 0)
     fail(CS_ERR_INTERNAL, "category_build_distributed: the all-to-all of the key bytes failed");
-  // ---- this rank's range: the parts that arrived (each sorted and unique), merged
+  // ---- stage 4: this rank's range -- the parts that arrived (each sorted and unique), merged
   std::vector<std::unique_ptr<cs_column>> parts;
-  std::vector<const cs_column*> part_ptrs;
   std::vector<int64_t> part_at(n, 0);  // where sender r's keys stand in the concatenation
-  int64_t at = 0;
-  for (int r = 0; r < n; ++r) {
-    part_at[r] = at;
-    if (got_keys[r] == 0) continue;
-    auto c = std::make_unique<cs_column>();
-    c->rows = got_keys[r];
-    c->nbytes = got_bytes[r];
-    c->offsets = dev_alloc(sizeof(int64_t) * (size_t)(got_keys[r] + 1), s);
-    const int64_t total = offsets_from_lengths(ptr<const int32_t>(in_lens) + at, got_keys[r], ptr<int64_t>(c->offsets), s);
-    if (total != got_bytes[r]) fail(CS_ERR_INTERNAL, "category_build_distributed: a received part's lengths do not add up to its bytes");
-    c->chars = dev_wrap(ptr<uint8_t>(in_chars) + cro[r], (size_t)got_bytes[r]);
-    // (a null key travels as a key of no bytes at the head of its sender's slice for range 0 -- the sizes exchange said
-    // which ranks have one)
-    if (x.rank == 0 && heads[r].null_first) {
-      c->validity = dev_alloc(validity_bytes(got_keys[r]), s);
-      CS_HIP(hipMemsetAsync(c->validity->p, 0xFF, validity_bytes(got_keys[r]), s));
-      CS_HIP(hipMemsetAsync(c->validity->p, 0xFE, 1, s));
-      c->null_count = 1;
-    } else {
-      c->null_count = 0;
-    }
-    at += got_keys[r];
-    part_ptrs.push_back(c.get());
-    parts.push_back(std::move(c));
-  }
   std::unique_ptr<cs_category> range;
   std::unique_ptr<cs_column> range_keys;
-  if (!part_ptrs.empty()) {
-    std::unique_ptr<cs_column> all(concat_columns(part_ptrs, s));
-    range.reset(category_build(all.get(), s));
-    range_keys = std::move(range->keys);
-  } else {
-    range_keys.reset(make_all_null(0, s));
-  }
+  attempt([&] {
+    std::vector<const cs_column*> part_ptrs;
+    int64_t at = 0;
+    for (int r = 0; r < n; ++r) {
+      part_at[r] = at;
+      if (got_keys[r] == 0) continue;
+      auto c = std::make_unique<cs_column>();
+      c->rows = got_keys[r];
+      c->nbytes = got_bytes[r];
+      c->offsets = dev_alloc(sizeof(int64_t) * (size_t)(got_keys[r] + 1), s);
+      const int64_t total = offsets_from_lengths(ptr<const int32_t>(in_lens) + at, got_keys[r], ptr<int64_t>(c->offsets), s);
+      if (total != got_bytes[r]) fail(CS_ERR_INTERNAL, "category_build_distributed: a received part's lengths do not add up to its bytes");
+      c->chars = dev_wrap(ptr<uint8_t>(in_chars) + cro[r], (size_t)got_bytes[r]);
+      // (a null key travels as a key of no bytes at the head of its sender's slice for range 0 -- the sizes exchange said
+      // which ranks have one)
+      if (x.rank == 0 && heads[r].null_first) {
+        c->validity = dev_alloc(validity_bytes(got_keys[r]), s);
+        CS_HIP(hipMemsetAsync(c->validity->p, 0xFF, validity_bytes(got_keys[r]), s));
+        CS_HIP(hipMemsetAsync(c->validity->p, 0xFE, 1, s));
+        c->null_count = 1;
+      } else {
+        c->null_count = 0;
+      }
+      at += got_keys[r];
+      part_ptrs.push_back(c.get());
+      parts.push_back(std::move(c));
+    }
+    if (!part_ptrs.empty()) {
+      std::unique_ptr<cs_column> all(concat_columns(part_ptrs, s));
+      range.reset(category_build(all.get(), s));
+      range_keys = std::move(range->keys);
+    } else {
+      range_keys.reset(make_all_null(0, s));
+    }
+  });
+  agree(x, status, why, "merge of the received key range");
   // ---- positions back to the senders (in the senders' key order: slice d lands at this rank's keys cut[d] ..)
-  Buf back = dev_alloc(sizeof(int32_t) * (size_t)std::max<int64_t>(K, 1), s);
   for (int d = 0; d < n; ++d) {
     sb[d] = sizeof(int32_t) * (size_t)got_keys[d];
     so[d] = sizeof(int32_t) * (size_t)part_at[d];
@@ -384,6 +487,7 @@ cs_category* merge_partitioned(const Exchange& x, const cs_category* local, cons
     run += gr.hdr[r].keys;
     if (gr.hdr[r].keys > 0) nonempty.push_back(gr.cols[r].get());
   }
+  // (the same sum on every rank: all of them stop here together)
   if (run >= ((int64_t)1 << 31)) fail(CS_ERR_RANGE, "category_build_distributed: more than 2^31 keys in all");
   auto merged = std::make_unique<cs_category>();
   merged->rows = local->rows;
@@ -397,7 +501,7 @@ cs_category* merge_partitioned(const Exchange& x, const cs_category* local, cons
     const int rc = cs_remap_codes(ptr<const int32_t>(local->values), local->rows, ptr<const int32_t>(table), ptr<int32_t>(merged->values), x.s);
     if (rc != 0) fail(rc, cs_last_error());
   }
-  CS_HIP(hipStreamSynchronize(s));  // (the gathered buffers leave scope)
+  CS_HIP(hipStreamSynchronize(s));  // (the gathered buffers leave scope; what follows the last collective fails locally, nobody waits)
   return merged.release();
 }
 

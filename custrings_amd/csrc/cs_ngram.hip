@@ -236,7 +236,7 @@ bool ngrams_fast(const cs_column* tokens, int n, const unsigned char* sep, int s
   int M = 0;
   int64_t span_in = 0, span_out = 0;
   Buf maxima = dev_alloc(16, s);
-  const int m_first = cs::cfg("CS_NGRAM_M") ? atoi(cs::cfg("CS_NGRAM_M")) : 8;  // (measurement: n-grams per lane and tile)
+  const int m_first = cs::cfg_int("CS_NGRAM_M", 8);  // (measurement: n-grams per lane and tile)
   for (int m : {8, 4, 2, 1}) {
     if (m > m_first) continue;
     const int NG = 64 * m;

@@ -835,6 +835,7 @@ static int split_impl(const cs_column* col, const char* delimiter, int maxsplit,
         return;
       }
     }
+    note_route("split-rowwise");
     int ncols = 0;
     Buf counts;
     const unsigned nb = blocks_for(rows);

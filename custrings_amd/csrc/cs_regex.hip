@@ -1422,7 +1422,11 @@ __global__ void __launch_bounds__(256, ((BREFS && !CHAIN) || (BITS && IN_LDS)) ?
     if (lane == 0) CS_TILE_TRACE(p_tile, 3);
     const long long pr0 = p_tile * R;
     const int pn = (int)min((long long)R, in.rows - pr0);
+#if defined(CS_NT_STORES)
+    if (lane < pn) __builtin_nontemporal_store(gb + p_lo, a.out_off + pr0 + lane);
+#else
     if (lane < pn) a.out_off[pr0 + lane] = gb + p_lo;
+#endif
     if (lane == pn - 1 && pr0 + pn == in.rows) a.out_off[in.rows] = gb + p_lo + p_len;
     if (!INPLACE && gb + p_total > a.out_cap) {  // more growth than the host provisioned for
       if (lane == 0) atomicOr(a.error, 2u);
@@ -3333,7 +3337,7 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
         sa.gtags = brefs ? ptr<const int32_t>(re->d_gtags) : nullptr;
         sa.gt_off = (int)tbl_lds;
         sa.gt_words = brefs && !bchain ? (int)re->gtags.size() : 0;
-        sa.debug = cs::cfg("CS_TILE_DEBUG") ? atoi(cs::cfg("CS_TILE_DEBUG")) : 0;
+        sa.debug = cs::cfg_int("CS_TILE_DEBUG", 0);
         sa.outliers = outliers ? 1 : 0;
         sa.lit = literal ? cs::g_replace_literal : 0;
         sa.litn = literal ? cs::g_replace_literal_len : 0;
@@ -3519,7 +3523,7 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
         ta.cap_in = cap;
         ta.cap_out = cap;
         ta.tbl_bytes = (int)tbl;
-        ta.debug = cs::cfg("CS_TILE_DEBUG") ? atoi(cs::cfg("CS_TILE_DEBUG")) : 0;
+        ta.debug = cs::cfg_int("CS_TILE_DEBUG", 0);
         auto kern = tp.d.in_lds ? &k_tdfa_replace_tile<true> : &k_tdfa_replace_tile<false>;
         if (lds > 48 * 1024)
           CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -572,7 +572,7 @@ bool strip_single(const cs_column* in, const CharSet& set, int side, hipStream_t
   Buf chars = dev_alloc((size_t)in->nbytes + 64, s);
   a.out_off = ptr<int64_t>(off);
   a.out_chars = ptr<uint8_t>(chars);
-  a.debug = cs::cfg("CS_STRIP_DEBUG") ? atoi(cs::cfg("CS_STRIP_DEBUG")) : 0;
+  a.debug = cs::cfg_int("CS_STRIP_DEBUG", 0);
   if (lds > 48 * 1024)
     CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_strip_stream), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   // (+ 1: workgroup 0 is the scanners')

@@ -319,10 +319,9 @@ __global__ void __launch_bounds__(256) k_runs_tile(RunsArgs a) {
 
 namespace cs {
 
-// count_re of such a pattern: the size pass counting matches (results: device, int32 per row; *hits = rows with a match)
-bool count_class_runs(const cs_column* col, const int32_t* d_bits, const std::vector<int32_t>& bits, hipStream_t s, int32_t* results, int64_t* hits) {
+// what both entry points share: the tile size the column's spans allow, the class description out of the bit program
+static bool runs_setup(const cs_column* col, const int32_t* d_bits, const std::vector<int32_t>& bits, hipStream_t s, RunsArgs& a) {
   const int64_t rows = col->rows;
-  if (rows == 0 || cs::cfg("CS_NO_CLASS_RUNS")) return false;
   int R = 0;
   for (int r : {64, 32, 16}) {
     if (max_span_rows(col, r, s) + 16 <= cstile::kPfBytes) {
@@ -331,7 +330,6 @@ bool count_class_runs(const cs_column* col, const int32_t* d_bits, const std::ve
     }
   }
   if (!R) return false;
-  RunsArgs a{};
   a.in = view_of(col);
   a.rows_per_tile = R;
   a.ntiles = (rows + R - 1) / R;
@@ -340,14 +338,24 @@ bool count_class_runs(const cs_column* col, const int32_t* d_bits, const std::ve
   a.flag_class = (bits[2] & csbits::F_FLAG_CLASS) ? (1 | (((bits[2] >> 16) & 63) << 8) | (((bits[2] >> 22) & 1) << 16)) : 0;
   a.flags = d_unicode_flags();
   a.plus = (bits[2] & csbits::F_PLUS) ? 1 : 0;
+  return true;
+}
+constexpr size_t kRunsBitmapBytes = cstile::kPfBytes / 8 + 32, kRunsPieces = cstile::kPfChunks * 64;
+constexpr size_t kRunsWave0 = kRunsBitmapBytes + (kRunsPieces + 1) * 8;  // LDS of a wave in the size pass
+
+// count_re of such a pattern: the size pass counting matches (results: device, int32 per row; *hits = rows with a match)
+bool count_class_runs(const cs_column* col, const int32_t* d_bits, const std::vector<int32_t>& bits, hipStream_t s, int32_t* results, int64_t* hits) {
+  const int64_t rows = col->rows;
+  if (rows == 0 || cs::cfg("CS_NO_CLASS_RUNS")) return false;
+  RunsArgs a{};
+  if (!runs_setup(col, d_bits, bits, s, a)) return false;
   a.rb = 1;
   a.count_only = 1;
   Buf maxima = dev_alloc(2 * sizeof(int), s);
   CS_HIP(hipMemsetAsync(maxima->p, 0, 2 * sizeof(int), s));
   a.lens = results;
   a.maxima = ptr<int>(maxima);
-  constexpr size_t kBitmapBytes = cstile::kPfBytes / 8 + 32, kPieces = cstile::kPfChunks * 64;
-  const size_t lds0 = 512 + (kBitmapBytes + (kPieces + 1) * 8) * 4;
+  const size_t lds0 = 512 + kRunsWave0 * 4;
   {
     const unsigned g0 = resident_grid(reinterpret_cast<const void*>(&k_runs_tile<0>), lds0, (a.ntiles + 3) / 4);
     ProfScope ps("k_runs_count", s);
@@ -365,23 +373,8 @@ bool count_class_runs(const cs_column* col, const int32_t* d_bits, const std::ve
 bool replace_class_runs(const cs_column* col, const int32_t* d_bits, const std::vector<int32_t>& bits, const char* repl, int rb, hipStream_t s, cs_column** out) {
   const int64_t rows = col->rows;
   if (rows == 0 || rb > kMaxRunRepl || cs::cfg("CS_NO_CLASS_RUNS")) return false;
-  int R = 0;
-  for (int r : {64, 32, 16}) {
-    if (max_span_rows(col, r, s) + 16 <= cstile::kPfBytes) {
-      R = r;
-      break;
-    }
-  }
-  if (!R) return false;
   RunsArgs a{};
-  a.in = view_of(col);
-  a.rows_per_tile = R;
-  a.ntiles = (rows + R - 1) / R;
-  a.bits = d_bits;
-  a.high_member = (bits[2] & csbits::F_HIGH_MEMBER) ? 1 : 0;
-  a.flag_class = (bits[2] & csbits::F_FLAG_CLASS) ? (1 | (((bits[2] >> 16) & 63) << 8) | (((bits[2] >> 22) & 1) << 16)) : 0;
-  a.flags = d_unicode_flags();
-  a.plus = (bits[2] & csbits::F_PLUS) ? 1 : 0;
+  if (!runs_setup(col, d_bits, bits, s, a)) return false;
   a.rb = rb;
   for (int k = 0; k < rb; ++k) a.rep[k >> 2] |= (uint32_t)(unsigned char)repl[k] << (8 * (k & 3));
   Buf lens = dev_alloc(sizeof(int32_t) * (size_t)rows, s);
@@ -389,15 +382,26 @@ bool replace_class_runs(const cs_column* col, const int32_t* d_bits, const std::
   CS_HIP(hipMemsetAsync(maxima->p, 0, 2 * sizeof(int), s));
   a.lens = ptr<int32_t>(lens);
   a.maxima = ptr<int>(maxima);
-  constexpr size_t kBitmapBytes = cstile::kPfBytes / 8 + 32, kPieces = cstile::kPfChunks * 64;
-  const size_t wave0 = kBitmapBytes + (kPieces + 1) * 8;
   {
-    const size_t lds0 = 512 + wave0 * 4;
+    const size_t lds0 = 512 + kRunsWave0 * 4;
     const unsigned g0 = resident_grid(reinterpret_cast<const void*>(&k_runs_tile<0>), lds0, (a.ntiles + 3) / 4);
     ProfScope ps("k_runs_size", s);
     hipLaunchKernelGGL(k_runs_tile<0>, dim3(g0), dim3(256), lds0, s, a);
   }
   CS_HIP(hipGetLastError());
+  // the largest output tile decides whether the write pass fits the LDS -- known right after the size pass: a column that
+  // does not fit (a 16-byte replacement for `.` on dense rows) leaves HERE, before the offsets scan and before its
+  // output is allocated (it used to find out after both)
+  int most = 0;
+  {
+    int* host = (int*)pinned_scratch(sizeof(int));
+    CS_HIP(hipMemcpyAsync(host, maxima->p, sizeof(int), hipMemcpyDeviceToHost, s));
+    CS_HIP(hipStreamSynchronize(s));
+    most = host[0];
+  }
+  a.cap_out = (most + 32 + 15) & ~15;
+  const size_t lds1 = 512 + (kRunsWave0 + (size_t)a.cap_out) * 4;
+  if (lds1 > 150 * 1024) return false;
   auto o = std::make_unique<cs_column>();
   o->rows = rows;
   o->validity = col->validity;  // null rows stay null; columns are immutable, so share
@@ -406,19 +410,9 @@ bool replace_class_runs(const cs_column* col, const int32_t* d_bits, const std::
   LenMeta meta;
   o->nbytes = offsets_from_lengths(ptr<int32_t>(lens), rows, ptr<int64_t>(o->offsets), s, nullptr, &meta);
   meta.give(o.get());
-  int most = 0;
-  {
-    int* host = (int*)pinned_scratch(sizeof(int));
-    CS_HIP(hipMemcpyAsync(host, maxima->p, sizeof(int), hipMemcpyDeviceToHost, s));
-    CS_HIP(hipStreamSynchronize(s));
-    most = host[0];
-  }
   o->chars = dev_alloc((size_t)o->nbytes, s);
   a.out_off = o->d_offsets();
   a.out_chars = ptr<uint8_t>(o->chars);
-  a.cap_out = (most + 32 + 15) & ~15;
-  const size_t lds1 = 512 + (wave0 + (size_t)a.cap_out) * 4;
-  if (lds1 > 150 * 1024) return false;
   if (lds1 > 48 * 1024) CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_runs_tile<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
   {
     const unsigned g1 = resident_grid(reinterpret_cast<const void*>(&k_runs_tile<1>), lds1, (a.ntiles + 3) / 4);

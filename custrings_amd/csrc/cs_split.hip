@@ -10,7 +10,7 @@
 //           keeps its own sum per column; one reduction per column per segment).
 //           A small scan over the segments gives every emit wave the position of
 //           its run of sub-tiles in every column's chars.
-//   pass 2  k_split_emit2: walks the tokens again; each wave owns a contiguous run
+//   pass 2  k_split_emit4: walks the tokens again; each wave owns a contiguous run
 //           of sub-tiles and carries its position in every column along; column
 //           k's tokens of the 64 rows are contiguous in column k's chars buffer,
 //           so they are assembled in LDS and flushed with 16-byte stores; offsets
@@ -19,7 +19,10 @@
 //           (one ballot per column) are written coalesced.  All columns come out
 //           of this single pass.
 //   (k_split_measure / k_split_emit: the first tile generation, one sub-tile per
-//   wave with per-sub-tile column sums; kept for rows beyond 93 bytes.)
+//   wave with per-sub-tile column sums; kept for rows beyond 188 bytes, 64-row spans
+//   beyond 8 KB and sub-tiles of fewer rows.  The second and third emit generations
+//   -- k_split_emit2 / _emit3, reachable only through measurement switches since the
+//   fourth -- left the library in round 6.)
 // Rows with more than kMaxCols tokens, multi-byte delimiters and whitespace
 // splitting use the generic kernels in cs_ops.hip.
 #include <hip/hip_runtime.h>
@@ -115,11 +118,12 @@ struct Measure2Args {
   int* max_count;   // [0] most tokens in a row, [1] bound on the bytes one column receives from one sub-tile
                     // (sum over its rows of the row's longest token), [2] longest row, [3] a sub-tile needs the generic kernels
 };
-// PLAIN (a one-byte delimiter, no split limit, rows of at most 92 bytes): the sentinel walk of k_split_emit3 -- three mask
-// words with a bit behind the row's last byte, lowest96 + a 96-bit clear per token.
-template <int MODE, bool PLAIN = false>
-__global__ void __launch_bounds__(256, 8) k_split_measure2(Measure2Args a) {  // (8 waves per SIMD: 2.05 -> 1.94 ms)
+// PLAIN (a one-byte delimiter, no split limit): the sentinel walk of k_split_emit4 on W mask words (split_parts.h: RowBits --
+// W = 3: rows of at most 92 bytes, a register per column for 32 columns; W = 6: rows up to 188 bytes, 64 columns).
+template <int MODE, bool PLAIN = false, int W = 3>
+__global__ void __launch_bounds__(256, (PLAIN && W > 3) ? 4 : 8) k_split_measure2(Measure2Args a) {  // (8 waves per SIMD: 2.05 -> 1.94 ms)
   constexpr bool WS = MODE == 1, MULTI = MODE == 2;
+  constexpr int MAXC = (PLAIN && W > 3) ? kMaxColsLong : kMaxCols;
   static_assert(!PLAIN || MODE == 0, "the sentinel walk is the one-byte delimiter's");
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;  // (scalar: what derives from it stays in SGPRs)
@@ -129,52 +133,40 @@ __global__ void __launch_bounds__(256, 8) k_split_measure2(Measure2Args a) {  //
   const long long run = sid / a.segs_per_run;
   const long long t0 = run * a.per + (sid - run * a.segs_per_run) * a.seg;
   const long long t1 = min(min(t0 + a.seg, (run + 1) * a.per), a.nsub);
-  int acc[kMaxCols];
+  int acc[MAXC];
 #pragma unroll
-  for (int k = 0; k < kMaxCols; ++k) acc[k] = 0;
+  for (int k = 0; k < MAXC; ++k) acc[k] = 0;
   int most = 0, widest = 0, longest = 0;
   bool generic = false;
   for (long long sub = t0; sub < t1; ++sub) {
     SubTile t = load_subtile(a.in, sub, lds_in, lane);
-    TokensT<false, WS, MULTI> tk(lds_in, t.lead + t.rbeg, t.n, t.live, a.dpat, a.tokens, a.d64, a.dlen, a.reverse != 0);
-    if ((WS || MULTI || a.reverse) && !tk.masked) {  // (wave-uniform)
-      generic = true;
-      break;
-    }
     int count = 0, rowmax = 0;
     bool any_more = true;
-    if (PLAIN) {
-      uint32_t m0 = (uint32_t)tk.m_lo, m1 = (uint32_t)(tk.m_lo >> 32), m2 = tk.m_hi;
-      if (t.live) {  // the sentinel: bit sa + n (<= 95)
-        const int q = tk.sa + t.n;
-        const uint32_t bit = 1u << (q & 31);
-        if (q < 32) m0 |= bit;
-        else if (q < 64) m1 |= bit;
-        else m2 |= bit;
-      }
-      count = __builtin_popcount(m0) + __builtin_popcount(m1) + __builtin_popcount(m2);
-      int prev = tk.sa - 1;  // mask position of the delimiter in front of the current token
+    if constexpr (PLAIN) {
+      RowBits<W> rb(lds_in, t.lead + t.rbeg, t.n, t.live, a.dpat);
+      count = rb.count();
+      int prev = rb.sa - 1;  // mask position of the delimiter in front of the current token
 #pragma unroll
-      for (int k = 0; k < kMaxCols; ++k) {
+      for (int k = 0; k < MAXC; ++k) {
         if (any_more) {
-          const bool has = (m0 | m1 | m2) != 0;
+          const bool has = rb.any();
           any_more = __any(has);
-          const int q = (int)lowest96(m0, m1, m2);
+          const int q = rb.take_lowest();
           const int len = has ? q - prev - 1 : 0;
           prev = q;
-          const unsigned long long l64 = ((unsigned long long)m1 << 32) | m0, d64 = l64 - 1;
-          const uint32_t d2 = m2 - (l64 == 0 ? 1u : 0u);
-          m0 &= (uint32_t)d64;
-          m1 &= (uint32_t)(d64 >> 32);
-          m2 &= d2;
           acc[k] += len;
           rowmax = max(rowmax, len);
         }
       }
-      any_more = false;  // (rows with more than kMaxCols tokens: `count` says so, the host takes the generic path)
+      // (rows with more than MAXC tokens: `count` says so, the host takes the generic path)
     } else {
+      TokensT<false, WS, MULTI> tk(lds_in, t.lead + t.rbeg, t.n, t.live, a.dpat, a.tokens, a.d64, a.dlen, a.reverse != 0);
+      if ((WS || MULTI || a.reverse) && !tk.masked) {  // (wave-uniform)
+        generic = true;
+        break;
+      }
 #pragma unroll
-      for (int k = 0; k < kMaxCols; ++k) {
+      for (int k = 0; k < MAXC; ++k) {
         if (any_more) {
           int lo = 0, hi = 0;
           const bool has = tk.next(lo, hi);
@@ -185,12 +177,12 @@ __global__ void __launch_bounds__(256, 8) k_split_measure2(Measure2Args a) {  //
           rowmax = max(rowmax, len);
         }
       }
-    }
-    while (any_more) {  // rows with more than kMaxCols tokens: the host takes the generic path
-      int lo = 0, hi = 0;
-      const bool has = tk.next(lo, hi);
-      any_more = __any(has);
-      count += has;
+      while (any_more) {  // rows with more than kMaxCols tokens: the host takes the generic path
+        int lo = 0, hi = 0;
+        const bool has = tk.next(lo, hi);
+        any_more = __any(has);
+        count += has;
+      }
     }
     most = max(most, count);
     longest = max(longest, t.n);
@@ -203,7 +195,7 @@ __global__ void __launch_bounds__(256, 8) k_split_measure2(Measure2Args a) {  //
   }
   const int m = wave_reduce_max(most);
 #pragma unroll
-  for (int k = 0; k < kMaxCols; ++k) {
+  for (int k = 0; k < MAXC; ++k) {
     if (k < m) {
       const int sum = wave_reduce_sum(acc[k]);
       if (lane == 0) a.colsum[(long long)k * a.nseg + sid] = sum;
@@ -339,169 +331,6 @@ struct Emit2Args {
   int reverse;  // rsplit with a limit (TokensT)
   int debug;  // CS_SPLIT_DEBUG bit mask: 1 no offset stores, 2 no chars stores, 4 no assembly, 8 no column loop (measurement only)
 };
-#ifndef CS_EMIT2_WAVES
-#define CS_EMIT2_WAVES 4
-#endif
-template <int MODE, bool OFF32>
-__global__ void __launch_bounds__(256, CS_EMIT2_WAVES) k_split_emit2(Emit2Args a) {
-  constexpr bool WS = MODE == 1, MULTI = MODE == 2;
-  typedef typename std::conditional<OFF32, int32_t, int64_t>::type off_t;
-  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;  // (scalar: what derives from it stays in SGPRs)
-  uint8_t* lds_in = reinterpret_cast<uint8_t*>(smem) + (size_t)wv * (a.cap_in + 32 + 2 * a.cap_col + (WS ? 2 : 1) * a.ncols * 64);
-  uint8_t* region0 = lds_in + a.cap_in + 32;
-  uint8_t* dpos = region0 + 2 * a.cap_col;  // dpos[j * 64 + lane] = row offset of the lane's j-th delimiter (WS: j-th token start)
-  uint8_t* epos = dpos + a.ncols * 64;      // WS: last byte of the lane's j-th token
-  // each wave owns a contiguous run of sub-tiles: its pieces of every output column are
-  // contiguous too, so the cache lines that two neighbouring sub-tiles share are completed in
-  // one L2 instead of being written half-filled from two XCDs
-  const long long per = a.per;
-  constexpr long long W = 1;
-  const long long run = (long long)blockIdx.x * 4 + wv;
-  long long tile = run * per;
-  const long long tile_end = min(a.nsub, tile + per);
-  if (tile >= tile_end) return;
-  const ColView& in = a.in;
-  // lane k keeps column k's destination and the wave's running position in column k's chars
-  uint8_t* my_chars = nullptr;
-  off_t* my_off = nullptr;
-  uint8_t* my_valid = nullptr;
-  long long my_pos = 0;
-  if (lane < a.ncols) {
-    const ColOut2 c = a.cols[lane];
-    my_chars = c.chars;
-    my_off = reinterpret_cast<off_t*>(c.offsets);
-    my_valid = c.validity;
-    my_pos = c.seg_base[run * a.segs_per_run];
-  }
-  cstile::TileOffs cur = cstile::load_tile_offsets(in.offsets, in.rows, tile, lane);
-  cstile::TileOffs nxt = cur;
-  if (tile + W < tile_end) nxt = cstile::load_tile_offsets(in.offsets, in.rows, tile + W, lane);
-  cstile::TileChars pf;
-#pragma unroll
-  for (int j = 0; j < cstile::kPfChunks; ++j) pf.v[j] = make_uint4(0, 0, 0, 0);
-  cstile::issue_chars(in.chars, cstile::rl64(cur.o0, 0), cstile::rl64(cur.o1, 63), lane, pf);
-#if defined(CS_PHASE_PROF)
-  unsigned long long phase_acc[6] = {0, 0, 0, 0, 0, 0};
-  unsigned long long phase_t = __builtin_readcyclecounter();
-#endif
-  for (;;) {
-    const long long r0 = tile * 64;
-    const int nrows = (int)min(64ll, in.rows - r0);
-    const long long g0 = cstile::rl64(cur.o0, 0), g1 = cstile::rl64(cur.o1, 63);
-    const bool live = lane < nrows && row_is_valid(in.validity, r0 + lane);
-    const int rbeg = (int)(cur.o0 - g0);
-    const int n = live ? (int)(cur.o1 - cur.o0) : 0;
-    const int lead = (int)((uintptr_t)(in.chars + g0) & 15);
-    const int want = (int)(g1 - g0) + lead;
-    cstile::stage_chars(lds_in, want, lane, pf);
-    const long long my_base = my_pos;
-    const int my_lead = (int)((uintptr_t)(my_chars + my_base) & 15);
-    const bool has_next = tile + W < tile_end;
-    // The offsets two sub-tiles ahead are fetched unconditionally (clamped index) and become `nxt` only at the bottom
-    // of the iteration: assigned under a condition, a value still in flight is copied at the join of the branch, and
-    // the compiler waited for it there -- s_waitcnt vmcnt(0) right behind the issue of the whole prefetch, every
-    // iteration (the prefetch never overlapped the work it was meant to hide behind).
-    const cstile::TileOffs nn = cstile::load_tile_offsets(in.offsets, in.rows, tile + 2 * W < tile_end ? tile + 2 * W : tile_end - 1, lane);
-    if (has_next) {
-      cur = nxt;
-      cstile::issue_chars(in.chars, cstile::rl64(cur.o0, 0), cstile::rl64(cur.o1, 63), lane, pf);
-    }
-    cstile::wave_lds_fence();
-    CS_PHASE_MARK(0);
-
-    TokensT<true, WS, MULTI> tk(lds_in, lead + rbeg, n, live, a.dpat, a.tokens, a.d64, a.dlen, a.reverse != 0);
-    // every row's delimiter positions go to LDS once, in a loop that does nothing else; the
-    // column loop then needs one byte load per token instead of the bit-mask walk
-    const int nd = __builtin_popcountll(tk.m_lo) + __builtin_popcount(tk.m_hi);
-    auto fill = [&](unsigned long long lo64, uint32_t hi32, uint8_t* table, int entries) {
-      // word by word, lowest set bit first: ffbl, clear, one byte store per position
-      uint32_t w[3] = {(uint32_t)lo64, (uint32_t)(lo64 >> 32), hi32};
-      uint8_t* slot = table + lane;  // advances one table row (64 bytes) per position found
-      const uint8_t* last = table + entries * 64;
-#pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        uint32_t v = w[i];
-        while (__any(v != 0)) {
-          if (v != 0) {
-            const int q = 32 * i + __builtin_ctz(v) - tk.sa;
-            v &= v - 1;
-            if (slot < last) *slot = (uint8_t)q;
-            slot += 64;
-          }
-        }
-      }
-    };
-    if (WS) {
-      fill(tk.m_lo, tk.m_hi, dpos, a.ncols);
-      fill(tk.e_lo, tk.e_hi, epos, a.ncols);
-    } else {
-      fill(tk.m_lo, tk.m_hi, dpos, a.ncols - 1);
-    }
-    const int ntok = !live ? 0 : WS ? min(nd, a.tokens > 0 ? a.tokens : 1 << 20) : min(nd, a.tokens > 0 ? a.tokens - 1 : 1 << 20) + 1;
-    cstile::wave_lds_fence();
-    CS_PHASE_MARK(1);
-    const bool last_tile = r0 + nrows == in.rows;
-    unsigned long long my_vmask = 0;
-    int cursor = 0;
-    for (int k = 0; k < ((a.debug & 8) ? 0 : a.ncols); ++k) {
-      uint8_t* region = region0 + (k & 1) * a.cap_col;
-      const int dk = dpos[k * 64 + lane];
-      const bool has = k < ntok;
-      int lo, hi;
-      if (WS) {  // the token that exhausts maxsplit keeps the rest of the row
-        lo = dk;
-        hi = (a.tokens > 0 && k == a.tokens - 1) ? n : epos[k * 64 + lane] + 1;
-      } else {
-        lo = cursor;
-        hi = k == ntok - 1 ? n : dk;
-        cursor = hi + (MULTI ? a.dlen : 1);
-      }
-      const int len = has ? hi - lo : 0;
-      const int incl = wave_inclusive_scan(len);
-      const int pre = incl - len;
-      const long long cbase = cstile::rl64(my_base, k);
-      cstile::gptr<off_t> coff = cstile::as_global(reinterpret_cast<off_t*>(cstile::rl64((long long)(uintptr_t)my_off, k)));
-      const int clead = rl(my_lead, k);
-      const int csum = rl(incl, 63);  // bytes this sub-tile adds to column k
-      if (lane < nrows && !(a.debug & 1)) coff[r0 + lane] = (off_t)(cbase + pre);
-      if (last_tile && lane == nrows - 1) coff[in.rows] = (off_t)(cbase + incl);
-      const unsigned long long vmask = __ballot(has);
-      if (lane == k) {
-        my_vmask = vmask;
-        my_pos += csum;
-      }
-      CS_PHASE_MARK(2);
-      if (csum == 0 || (a.debug & 4)) continue;  // no row of this sub-tile reaches column k (or all its tokens are empty): offsets only
-      if (has) {
-        // the token goes to its place in the column's region with at most five stores of 16 / 8 / 4 / 2 / 1 bytes at
-        // whatever alignment the position has (gfx950 takes DS accesses at any alignment): one 16-byte read of the
-        // staged row, no zeroing of the region, no funnel shifts, no OR-assembly (round 1 composed the token from five
-        // aligned dwords, shifted it to the destination's byte phase and OR-ed it into a zeroed region)
-        const int ti = lead + rbeg + lo;
-        const int di = clead + pre;
-        cstile::lds_put16(region + di, *reinterpret_cast<const cstile::lds_u32x4u*>(lds_in + ti), len);
-        if (len > 16) cstile::lds_copy(region, di + 16, lds_in, ti + 16, len - 16);
-      }
-      cstile::wave_lds_fence();
-      CS_PHASE_MARK(3);
-      uint8_t* dst = reinterpret_cast<uint8_t*>(cstile::rl64((long long)(uintptr_t)my_chars, k)) + cbase;
-      if (!(a.debug & 2)) cstile::wave_flush(dst, csum, region, clead, lane);
-      CS_PHASE_MARK(4);
-    }
-    if (lane < a.ncols) *cstile::as_global(reinterpret_cast<unsigned long long*>(my_valid + tile * 8)) = my_vmask;
-    if (!has_next) break;
-    tile += W;
-    nxt = nn;
-  }
-#if defined(CS_PHASE_PROF)
-  CS_PHASE_MARK(5);
-  if (lane == 0 && a.prof)
-    for (int k = 0; k < 6; ++k) atomicAdd(a.prof + k, phase_acc[k]);
-#endif
-}
-
-
 // ---- emit, third generation: all columns assembled side by side, no fence in the column loop ------------
 // Same inputs and outputs as k_split_emit2 (runs of consecutive sub-tiles per wave, column positions from the
 // measure pass).  What changed is the shape of the column loop, whose twenty rounds of "walk, scan, assemble,
@@ -529,6 +358,8 @@ struct Emit3Args {
 #define CS_EMIT3_WAVES 4
 #endif
 constexpr int kEmit3Threads = 128;  // two waves per workgroup: the LDS of a CU is shared out in finer grains
+constexpr int kEmit4TableBytes = 1024 + 128 + 128;  // the flush tables of k_split_emit4 (in the in tile once the column loop is over)
+constexpr int kEmit4MaxOut = 16 * 1024;             // bytes of its out tile (32 words of chunk bits)
 // PLAIN: a one-byte delimiter without a split limit on rows of at most 92 bytes -- the token walk then runs on three
 // mask words that also hold a sentinel bit behind the row's last byte (every token ends at a set bit, the walk is over
 // when the mask is empty) instead of the general TokensT::next.
@@ -540,226 +371,6 @@ constexpr int kEmit3Threads = 128;  // two waves per workgroup: the LDS of a CU 
 #else
 #define EXP(bit) false
 #endif
-template <int MODE, bool OFF32, bool PLAIN>
-__global__ void __launch_bounds__(kEmit3Threads, CS_EMIT3_WAVES) k_split_emit3(Emit3Args args) {
-  constexpr bool WS = MODE == 1, MULTI = MODE == 2;
-  static_assert(!PLAIN || MODE == 0, "the sentinel walk is the one-byte delimiter's");
-  typedef typename std::conditional<OFF32, int32_t, int64_t>::type off_t;
-  const Emit2Args& a = args.e;
-  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-  // (the wave index through readfirstlane: everything derived from it -- tile, first row, addresses -- is then
-  // wave-uniform to the compiler too and lives in scalar registers)
-  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
-  // the workgroup's mask table first (17 entries, both waves write the same values); then per wave 16 bytes of slack
-  // (a run's dwords may begin 4 bytes in front of a tile), the in tile, the out tile
-  uint8_t* lds_in = reinterpret_cast<uint8_t*>(smem) + 288 + (size_t)wv * (16 + args.cap_in + 32 + args.cap_out) + 16;
-  uint8_t* lds_out = lds_in + args.cap_in + 32;
-  // tail[n], n = 0..16: a mask of the first n bytes of sixteen (lds_or16u)
-  cstile::u32x4* tail = reinterpret_cast<cstile::u32x4*>(smem);
-  if (lane <= 16) {
-    auto first = [](int k) -> uint32_t { return k >= 4 ? 0xFFFFFFFFu : (k <= 0 ? 0u : (1u << (8 * k)) - 1u); };
-    tail[lane] = cstile::u32x4{first(lane), first(lane - 4), first(lane - 8), first(lane - 12)};
-  }
-  // the out tile is zero whenever a sub-tile begins (tokens are OR-ed in; what is flushed or carried is zeroed again)
-  const cstile::u32x4 zero4 = {0u, 0u, 0u, 0u};
-  for (int i = lane * 16; i < args.cap_out; i += 64 * 16) *reinterpret_cast<cstile::u32x4*>(lds_out + i) = zero4;
-  const long long per = a.per;
-  const long long run = (long long)blockIdx.x * (kEmit3Threads / 64) + wv;
-  long long tile = run * per;
-  const long long tile_end = min(a.nsub, tile + per);
-  if (tile >= tile_end) return;
-  const ColView& in = a.in;
-  // lane k keeps column k: destination, the wave's running position in the column's chars, the bytes carried
-  // over from the previous sub-tile (they precede `my_pos` in the same 16-byte chunk) and how many leading bytes
-  // of the next chunk to go out belong to the wave in front (non-zero until the run's first whole chunk left)
-  uint8_t* my_chars = nullptr;
-  off_t* my_off = nullptr;
-  uint8_t* my_valid = nullptr;
-  long long my_pos = 0;
-  int my_head = 0;
-  cstile::u32x4 carry = zero4;
-  if (lane < a.ncols) {
-    const ColOut2 c = a.cols[lane];
-    my_chars = c.chars;
-    my_off = reinterpret_cast<off_t*>(c.offsets);
-    my_valid = c.validity;
-    my_pos = c.seg_base[run * a.segs_per_run];
-    my_head = (int)((uintptr_t)(my_chars + my_pos) & 15);
-  }
-  cstile::TileOffs cur = cstile::load_tile_offsets(in.offsets, in.rows, tile, lane);
-  cstile::TileOffs nxt = cur;
-  if (tile + 1 < tile_end) nxt = cstile::load_tile_offsets(in.offsets, in.rows, tile + 1, lane);
-  cstile::TileChars pf;
-#pragma unroll
-  for (int j = 0; j < cstile::kPfChunks; ++j) pf.v[j] = make_uint4(0, 0, 0, 0);
-  cstile::issue_chars(in.chars, cstile::rl64(cur.o0, 0), cstile::rl64(cur.o1, 63), lane, pf);
-  for (;;) {
-    const long long r0 = tile * 64;
-    const int nrows = (int)min(64ll, in.rows - r0);
-    const long long g0 = cstile::rl64(cur.o0, 0), g1 = cstile::rl64(cur.o1, 63);
-    const bool live = lane < nrows && row_is_valid(in.validity, r0 + lane);
-    const int rbeg = (int)(cur.o0 - g0);
-    const int n = live ? (int)(cur.o1 - cur.o0) : 0;
-    const int lead = (int)((uintptr_t)(in.chars + g0) & 15);
-    const int want = (int)(g1 - g0) + lead;
-    cstile::stage_chars(lds_in, want, lane, pf);
-    const bool has_next = tile + 1 < tile_end;
-    // (fetched unconditionally, handed to `nxt` at the bottom: see k_split_emit2)
-    const cstile::TileOffs nn = cstile::load_tile_offsets(in.offsets, in.rows, tile + 2 < tile_end ? tile + 2 : tile_end - 1, lane);
-    if (has_next) {
-      cur = nxt;
-      cstile::issue_chars(in.chars, cstile::rl64(cur.o0, 0), cstile::rl64(cur.o1, 63), lane, pf);
-    }
-    cstile::wave_lds_fence();
-
-    TokensT<true, WS, MULTI> tk(lds_in, lead + rbeg, n, live, a.dpat, a.tokens, a.d64, a.dlen, a.reverse != 0);
-    // PLAIN: the delimiter bits and the sentinel behind the row (bit sa + n <= 95), the start of the next token
-    uint32_t m0 = 0, m1 = 0, m2 = 0;
-    int tcur = 0;
-    if (PLAIN) {
-      m0 = (uint32_t)tk.m_lo;
-      m1 = (uint32_t)(tk.m_lo >> 32);
-      m2 = tk.m_hi;
-      if (live) {
-        const int q = tk.sa + n;
-        const uint32_t bit = 1u << (q & 31);
-        if (q < 32) m0 |= bit;
-        else if (q < 64) m1 |= bit;
-        else m2 |= bit;
-      }
-    }
-    const bool last_tile = r0 + nrows == in.rows;
-    unsigned long long my_vmask = 0;
-    const int my_cph = (int)(((uintptr_t)my_chars + (uintptr_t)my_pos) & 15);  // bytes carried into this sub-tile
-    int rg = 0;  // where the next column's region begins in the out tile (wave-uniform)
-    // The region of the column before is flushed while this column's round runs (its chunks are read at the top of the
-    // round and stored at the bottom): p_k < 0 = nothing pending.  All wave-uniform.
-    int p_k = -1, p_rg = 0, p_nwhole = 0, p_nch = 0, p_tot = 0, p_cph = 0;
-    // (chunks of the pending region: p_nch in all, the first p_nwhole of them whole)
-    auto pending_read = [&]() -> cstile::u32x4 {  // lane i < 64 reads chunk i (aligned 16-byte reads)
-      cstile::u32x4 v = zero4;
-      if (EXP(32)) return v;
-      if (p_k >= 0 && lane < p_nch) v = *reinterpret_cast<const cstile::u32x4*>(lds_out + p_rg + 16 * lane);
-      return v;
-    };
-    auto pending_leave = [&](cstile::u32x4 pv) {
-      if (p_k < 0 || EXP(32)) return;
-      // chunk i goes to ((chars + pos) & ~15) + 16 i, pos still being the column's position before this sub-tile
-      uint8_t* ga = reinterpret_cast<uint8_t*>(((uintptr_t)cstile::rl64((long long)(uintptr_t)my_chars, p_k) + (uintptr_t)cstile::rl64(my_pos, p_k)) & ~(uintptr_t)15);
-      const int head = rl(my_head, p_k);
-      if (lane < p_nwhole && !(lane == 0 && head != 0) && !EXP(2)) *(cstile::gptr<cstile::u32x4>)cstile::as_global(ga + 16 * lane) = pv;
-      // the bytes behind the last whole chunk become the carry of the column's lane (its own read of that quad: the LDS
-      // takes the wave's operations in order, so it comes before the zeroing below; zeros when the region ends on a
-      // chunk boundary -- the quad behind it is the next region's, still untouched, or empty)
-      if (lane == p_k) {
-        carry = *reinterpret_cast<const cstile::u32x4*>(lds_out + p_rg + 16 * p_nwhole);
-        if (p_nwhole == p_nch) carry = zero4;
-        my_pos += p_tot - p_cph;
-      }
-      if (lane < p_nch) *reinterpret_cast<cstile::u32x4*>(lds_out + p_rg + 16 * lane) = zero4;  // (zero again for the next sub-tile)
-      if (head != 0 && p_nwhole > 0) {
-        // a run's first whole chunk of a column: its leading bytes belong to the wave in front, bytes head .. 15 go out
-        // one per lane from lane 0's quad (once per run and column)
-        const int w = lane >> 2;
-        const uint32_t d0 = (uint32_t)__builtin_amdgcn_readlane((int)pv.x, 0), d1 = (uint32_t)__builtin_amdgcn_readlane((int)pv.y, 0),
-                       d2 = (uint32_t)__builtin_amdgcn_readlane((int)pv.z, 0), d3 = (uint32_t)__builtin_amdgcn_readlane((int)pv.w, 0);
-        const uint32_t dw = w == 0 ? d0 : (w == 1 ? d1 : (w == 2 ? d2 : d3));
-        if (lane >= head && lane < 16) cstile::as_global(ga)[lane] = (uint8_t)(dw >> (8 * (lane & 3)));
-        if (lane == p_k) my_head = 0;
-      }
-      if (p_nch > 64) {  // (a column that receives a KB or more from one sub-tile: the rest of its chunks)
-        for (int i = 64 + lane; i < p_nch; i += 64) {
-          const cstile::u32x4 w = *reinterpret_cast<const cstile::u32x4*>(lds_out + p_rg + 16 * i);
-          *reinterpret_cast<cstile::u32x4*>(lds_out + p_rg + 16 * i) = zero4;
-          if (i < p_nwhole) *(cstile::gptr<cstile::u32x4>)cstile::as_global(ga + 16 * i) = w;
-        }
-      }
-    };
-    bool any_more = true;
-    for (int k = 0; k < (EXP(8) ? 0 : a.ncols); ++k) {
-      const long long cbase = cstile::rl64(my_pos, k);
-      cstile::gptr<off_t> coff = cstile::as_global(reinterpret_cast<off_t*>(cstile::rl64((long long)(uintptr_t)my_off, k))) + r0;
-      if (!any_more) {
-        if (EXP(1)) continue;
-        // no row of the sub-tile reaches this column: null rows at the column's running position, the carried
-        // bytes stay where they are
-        if (lane < nrows) coff[lane] = (off_t)cbase;
-        if (last_tile && lane == nrows - 1) coff[nrows] = (off_t)cbase;
-        continue;
-      }
-      // ---- the region of the column before: its chunks are read here and leave at the bottom of the round
-      const cstile::u32x4 pv = pending_read();
-      // ---- this column's tokens
-      int lo = 0, hi = 0;
-      bool has;
-      if (PLAIN) {
-        has = (m0 | m1 | m2) != 0;
-        const uint32_t q = lowest96(m0, m1, m2);
-        lo = tcur;
-        hi = (int)q - tk.sa;
-        tcur = hi + 1;
-        const unsigned long long l64 = ((unsigned long long)m1 << 32) | m0, d64 = l64 - 1;
-        const uint32_t d2 = m2 - (l64 == 0 ? 1u : 0u);
-        m0 &= (uint32_t)d64;
-        m1 &= (uint32_t)(d64 >> 32);
-        m2 &= d2;
-      } else {
-        has = tk.next(lo, hi);
-      }
-      any_more = __any(has);
-      if (any_more) {
-        const int len = has ? hi - lo : 0;
-        const int incl = EXP(64) ? len + lane : wave_inclusive_scan_fused(len);
-        const int pre = incl - len;
-        const int csum = EXP(64) ? 64 * 7 : rl(incl, 63);  // bytes this sub-tile adds to column k
-        if (lane < nrows && !EXP(1)) coff[lane] = (off_t)(cbase + pre);
-        if (last_tile && lane == nrows - 1) coff[nrows] = (off_t)(cbase + incl);
-        const unsigned long long vmask = __ballot(has);
-        const int cph = rl(my_cph, k);  // carried bytes: they precede the column's position in its 16-byte chunk
-        if (lane == k) {
-          my_vmask = vmask;
-          // the carried bytes open the region (the LDS takes a wave's operations in order: the tokens below land
-          // behind them, over the quad's zero tail)
-          if (cph) *reinterpret_cast<cstile::u32x4*>(lds_out + rg) = carry;
-        }
-        if (has && EXP(16)) lds_or16u(lds_out, rg + cph + pre, lds_in, (lead + rbeg + lo) & ~15, min(len, 16), tail);
-        else if (has && !EXP(4)) lds_or16u(lds_out, rg + cph + pre, lds_in, lead + rbeg + lo, min(len, 16), tail);
-        if (__any(len > 16)) {  // (tokens beyond 16 bytes: the same, 16 bytes at a time)
-          for (int done = 16; __any(done < len); done += 16)
-            if (done < len) lds_or16u(lds_out, rg + cph + pre + done, lds_in, lead + rbeg + lo + done, min(len - done, 16), tail);
-        }
-        // ---- the column before leaves: whole chunks to its chars, the bytes behind them into its lane's carry quad
-        pending_leave(pv);
-        p_k = k;
-        p_rg = rg;
-        p_cph = cph;
-        p_tot = cph + csum;
-        p_nwhole = p_tot >> 4;
-        p_nch = (p_tot + 15) >> 4;
-        rg += p_nch << 4;
-      } else {
-        --k;  // (this column again, on the short path above)
-      }
-    }
-    // ---- the last column with tokens leaves (the same steps, nothing to overlap them with)
-    pending_leave(pending_read());
-    if (lane < a.ncols) *cstile::as_global(reinterpret_cast<unsigned long long*>(my_valid + tile * 8)) = my_vmask;
-    if (!has_next) break;
-    tile += 1;
-    nxt = nn;
-  }
-  // ---- the run's last bytes of every column: what is still carried goes out bytewise
-  if (lane < a.ncols) {
-    const int have = (int)((uintptr_t)(my_chars + my_pos) & 15);
-    if (have > my_head) {
-      // (the quad's bytes through the out tile: a lane's own 16 bytes, nobody else's)
-      *reinterpret_cast<cstile::u32x4*>(lds_out + 16 * lane) = carry;
-      cstile::gptr<uint8_t> d = cstile::as_global(reinterpret_cast<uint8_t*>(((uintptr_t)my_chars + (uintptr_t)my_pos) & ~(uintptr_t)15));
-      for (int j = my_head; j < have; ++j) d[j] = lds_out[16 * lane + j];
-    }
-  }
-}
-
 
 // ---- emit, fourth generation: two columns a round, no per-round flush ------------------------------------
 // Same inputs, outputs and LDS layout as k_split_emit3 (runs of consecutive sub-tiles per wave, column positions from
@@ -835,6 +446,11 @@ __device__ __forceinline__ void leave_in_lane(int k, unsigned long long valid, i
 // (s_nop 4: a VMEM instruction that reads a scalar register written by a VALU instruction -- the readfirstlane below, when
 // the compiler formed the pointer in vector registers -- needs five wait states, and the compiler's hazard recognizer does
 // not look into inline assembly: the measurement build stored to garbage addresses without it)
+#if defined(CS_NT_STORES)
+#define CS_NT_ASM " nt"
+#else
+#define CS_NT_ASM ""
+#endif
 template <class T>
 __device__ __forceinline__ T* scalar_ptr(T* p) {  // (a no-op when the compiler already knows the pointer to be wave-uniform)
   const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)p);
@@ -842,14 +458,17 @@ __device__ __forceinline__ T* scalar_ptr(T* p) {  // (a no-op when the compiler 
   return reinterpret_cast<T*>(((unsigned long long)hi << 32) | lo);
 }
 __device__ __forceinline__ void store_off(int32_t* base, int voff, int32_t v) {
-  asm volatile("s_nop 4\n\tglobal_store_dword %0, %1, %2" ::"v"(voff), "v"(v), "s"(scalar_ptr(base)) : "memory");
+  asm volatile("s_nop 4\n\tglobal_store_dword %0, %1, %2" CS_NT_ASM ::"v"(voff), "v"(v), "s"(scalar_ptr(base)) : "memory");
 }
 __device__ __forceinline__ void store_off(int64_t* base, int voff, int64_t v) {
-  asm volatile("s_nop 4\n\tglobal_store_dwordx2 %0, %1, %2" ::"v"(voff), "v"(v), "s"(scalar_ptr(base)) : "memory");
+  asm volatile("s_nop 4\n\tglobal_store_dwordx2 %0, %1, %2" CS_NT_ASM ::"v"(voff), "v"(v), "s"(scalar_ptr(base)) : "memory");
 }
 
-template <int MODE, bool OFF32, bool PLAIN>
-__global__ void __launch_bounds__(kEmit3Threads, CS_EMIT3_WAVES) k_split_emit4(Emit3Args args) {
+// W: mask words of the sentinel walk (PLAIN only: 3 = rows up to 92 bytes, 6 = up to 188); PF: 16-byte prefetch chunks a lane
+// (6 = sub-tiles up to 6 KB, 8 = up to 8 KB: 64 rows of 95 bytes on average).  Up to 64 columns (a lane a column).
+// (the long-row form's tiles leave room for two or three waves a SIMD anyway: it may keep its registers)
+template <int MODE, bool OFF32, bool PLAIN, int W = 3, int PF = cstile::kPfChunks>
+__global__ void __launch_bounds__(kEmit3Threads, W > 3 ? 3 : CS_EMIT3_WAVES) k_split_emit4(Emit3Args args) {
   constexpr bool WS = MODE == 1, MULTI = MODE == 2;
   static_assert(!PLAIN || MODE == 0, "the sentinel walk is the one-byte delimiter's");
   typedef typename std::conditional<OFF32, int32_t, int64_t>::type off_t;
@@ -865,11 +484,11 @@ __global__ void __launch_bounds__(kEmit3Threads, CS_EMIT3_WAVES) k_split_emit4(E
   }
   const cstile::u32x4 zero4 = {0u, 0u, 0u, 0u};
   for (int i = lane * 16; i < args.cap_out; i += 64 * 16) *reinterpret_cast<cstile::u32x4*>(lds_out + i) = zero4;
-  // the flush tables live in the in tile once the column loop is over: 32 entries of 16 bytes, 16 words of region-start
-  // bits (a bit per 16-byte chunk of the out tile), 16 words of prefix counts
+  // the flush tables live in the in tile once the column loop is over: 64 entries of 16 bytes, 32 words of region-start
+  // bits (a bit per 16-byte chunk of the out tile: up to 16 KB), 32 words of prefix counts -- kEmit4TableBytes in all
   cstile::u32x4* f_entry = reinterpret_cast<cstile::u32x4*>(lds_in);
-  uint32_t* f_bits = reinterpret_cast<uint32_t*>(lds_in + 512);
-  uint32_t* f_pfx = f_bits + 16;
+  uint32_t* f_bits = reinterpret_cast<uint32_t*>(lds_in + 1024);
+  uint32_t* f_pfx = f_bits + 32;
   const long long per = a.per;
   const long long run = (long long)blockIdx.x * (kEmit3Threads / 64) + wv;
   long long tile = run * per;
@@ -896,9 +515,9 @@ __global__ void __launch_bounds__(kEmit3Threads, CS_EMIT3_WAVES) k_split_emit4(E
   cstile::TileOffs cur = cstile::load_tile_offsets(in.offsets, in.rows, tile, lane);
   cstile::TileOffs nxt = cur;
   if (tile + 1 < tile_end) nxt = cstile::load_tile_offsets(in.offsets, in.rows, tile + 1, lane);
-  cstile::TileChars pf;
+  cstile::TileCharsT<PF> pf;
 #pragma unroll
-  for (int j = 0; j < cstile::kPfChunks; ++j) pf.v[j] = make_uint4(0, 0, 0, 0);
+  for (int j = 0; j < PF; ++j) pf.v[j] = make_uint4(0, 0, 0, 0);
   cstile::issue_chars(in.chars, cstile::rl64(cur.o0, 0), cstile::rl64(cur.o1, 63), lane, pf);
 #if defined(CS_PHASE_PROF)
   unsigned long long phase_acc[6] = {0, 0, 0, 0, 0, 0};
@@ -927,36 +546,24 @@ __global__ void __launch_bounds__(kEmit3Threads, CS_EMIT3_WAVES) k_split_emit4(E
     cstile::wave_lds_fence();
     CS_PHASE_MARK(0);
 
-    TokensT<true, WS, MULTI> tk(lds_in, lead + rbeg, n, live, a.dpat, a.tokens, a.d64, a.dlen, a.reverse != 0);
-    uint32_t m0 = 0, m1 = 0, m2 = 0;
+    // the walker: PLAIN -- delimiter bits and a sentinel behind the row on W words (RowBits); else the general token walker
+    auto make_walker = [&]() {
+      if constexpr (PLAIN) return RowBits<W>(lds_in, lead + rbeg, n, live, a.dpat);
+      else return TokensT<true, WS, MULTI>(lds_in, lead + rbeg, n, live, a.dpat, a.tokens, a.d64, a.dlen, a.reverse != 0);
+    };
+    auto tk = make_walker();
     int tcur = 0;
-    if (PLAIN) {
-      m0 = (uint32_t)tk.m_lo;
-      m1 = (uint32_t)(tk.m_lo >> 32);
-      m2 = tk.m_hi;
-      if (live) {
-        const int q = tk.sa + n;
-        const uint32_t bit = 1u << (q & 31);
-        if (q < 32) m0 |= bit;
-        else if (q < 64) m1 |= bit;
-        else m2 |= bit;
-      }
-    }
     auto step = [&](int& lo, int& hi) -> bool {  // the row's next token
-      if (PLAIN) {
-        const bool has = (m0 | m1 | m2) != 0;
-        const uint32_t q = lowest96(m0, m1, m2);
+      if constexpr (PLAIN) {
+        const bool has = tk.any();
+        const int q = tk.take_lowest();
         lo = tcur;
-        hi = (int)q - tk.sa;
+        hi = q - tk.sa;
         tcur = hi + 1;
-        const unsigned long long l64 = ((unsigned long long)m1 << 32) | m0, d64 = l64 - 1;
-        const uint32_t d2 = m2 - (l64 == 0 ? 1u : 0u);
-        m0 &= (uint32_t)d64;
-        m1 &= (uint32_t)(d64 >> 32);
-        m2 &= d2;
         return has;
+      } else {
+        return tk.next(lo, hi);
       }
-      return tk.next(lo, hi);
     };
     // a row beyond the sub-tile's last writes the final offset entry (its prefix is the sub-tile's total)
     const int rowoff = min(lane, nrows) * (int)sizeof(off_t);
@@ -1060,7 +667,7 @@ __global__ void __launch_bounds__(kEmit3Threads, CS_EMIT3_WAVES) k_split_emit4(E
     const int c_cph = (int)c_pos & 15;
     const int tot = c_cph + t_sum, nwhole = tot >> 4;
     const unsigned long long actm = __ballot(act);
-    if (lane < 16) f_bits[lane] = 0u;  // (the in tile is dead: every token has been copied)
+    if (lane < 32) f_bits[lane] = 0u;  // (the in tile is dead: every token has been copied)
     if (act) {
       // the carried bytes open the region (the tokens were OR-ed in behind them; a run's first chunk keeps zeros in
       // front: those bytes are the neighbouring run's)
@@ -1081,9 +688,9 @@ __global__ void __launch_bounds__(kEmit3Threads, CS_EMIT3_WAVES) k_split_emit4(E
       c_pos += t_sum;
     }
     {
-      const int cnt = lane < 16 ? __builtin_popcount(f_bits[lane]) : 0;
+      const int cnt = lane < 32 ? __builtin_popcount(f_bits[lane]) : 0;
       const int inc = wave_inclusive_scan_fused(cnt);
-      if (lane < 16) f_pfx[lane] = (uint32_t)(inc - cnt);
+      if (lane < 32) f_pfx[lane] = (uint32_t)(inc - cnt);
     }
     cstile::wave_lds_fence();
     CS_PHASE_MARK(3);
@@ -1102,7 +709,7 @@ __global__ void __launch_bounds__(kEmit3Threads, CS_EMIT3_WAVES) k_split_emit4(E
       const bool whole = rel < (int)(e.z >> 16);
       uint8_t* ga = reinterpret_cast<uint8_t*>((((unsigned long long)e.y << 32) | e.x) + (unsigned long long)(16 * rel));
       const bool head = whole && rel == 0 && e.w != 0;
-      if (whole && !head && !EXP(2)) *(cstile::gptr<cstile::u32x4>)cstile::as_global(ga) = v;
+      if (whole && !head && !EXP(2)) cstile::gstore16((cstile::gptr<cstile::u32x4>)cstile::as_global(ga), v);
       if (__any(head)) {
         // a run's first whole chunk of a column: its leading bytes belong to the wave in front, bytes head .. 15 go out
         // one by one (once per run and column)
@@ -1187,33 +794,37 @@ bool split_fast(const cs_column* col, const unsigned char* delim, int dlen, int 
   Buf mx = dev_alloc(4 * sizeof(int), s);
   int* hmx = (int*)pinned_scratch(4 * sizeof(int));
 
-  // ---- second generation: runs of sub-tiles per wave (rows up to 93 bytes, 64-row spans up to 6 KB)
-  if (rows_per_sub == kSub && !outliers && cap_in <= cstile::kPfBytes && !cs::cfg("CS_SPLIT_OLD_EMIT")) {
+  // ---- the tile kernels proper (k_split_measure2 + k_split_emit4): runs of sub-tiles per wave.  Rows up to 92-93 bytes on
+  // 96-bit masks and 64-row spans up to 6 KB; a plain split (one-byte delimiter, no limit) also rows up to 188 bytes on six
+  // mask words, spans up to 8 KB and 64 columns -- BASELINE's C5 column, which left these kernels until round 6
+  const bool plain_mode = mode == 0 && tokens <= 0 && !reverse && !cs::cfg("CS_SPLIT_GENERIC_WALK");
+  const int64_t longest_known = plain_mode ? max_row_bytes(col, s) : 0;  // (column metadata, kept on the immutable column like its largest 64-row span)
+  // mask words of the sentinel walk (both passes): every row's sentinel bit inside the mask; 0 = the general token walker
+  const int walk_words = !plain_mode ? 0 : (longest_known + 3 <= 95 ? 3 : (longest_known + 3 <= 191 && !cs::cfg("CS_SPLIT_NO_LONG_WALK") ? 6 : 0));
+  const bool tiles_ok = cap_in <= cstile::kPfBytes || (walk_words == 6 && cap_in <= 8 * 1024);
+  if (rows_per_sub == kSub && !outliers && tiles_ok && !cs::cfg("CS_SPLIT_OLD_EMIT")) {
     // The run decomposition is a function of the row count alone (not of the emit kernel's
     // residency, which depends on what the measure pass finds): emit needs no co-residency.
     int dev = 0, cus = 0;
     CS_HIP(hipGetDevice(&dev));
     CS_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    // (the third-generation emit keeps 14 waves per CU resident: runs a quarter as long share the tail out evenly)
-    const bool want_emit3 = !cs::cfg("CS_SPLIT_EMIT2");
-    int runs_per_cu = want_emit3 ? 256 : 16;  // (short runs share the tail out evenly: 16 / 64 / 128 / 256 runs per CU -> emit 7.06 / 7.05 / 6.77 / 6.61 ms)
-    if (const char* e = cs::cfg("CS_EMIT_RUNS_PER_CU")) runs_per_cu = std::max(1, atoi(e));  // (measurement)
+    int runs_per_cu = 256;  // (short runs share the tail out evenly: 16 / 64 / 128 / 256 runs per CU -> emit 7.06 / 7.05 / 6.77 / 6.61 ms)
+    runs_per_cu = std::max(1, cs::cfg_int("CS_EMIT_RUNS_PER_CU", runs_per_cu));  // (measurement)
     int64_t runs = std::min<int64_t>(nsub, (int64_t)cus * runs_per_cu);
     const int64_t per = (nsub + runs - 1) / runs;
     runs = (nsub + per - 1) / per;
-    const int segs_per_run = (int)std::min<int64_t>(want_emit3 ? 2 : 4, per);
+    const int segs_per_run = (int)std::min<int64_t>(2, per);
     const int64_t seg = (per + segs_per_run - 1) / segs_per_run;
     const int64_t nseg = runs * segs_per_run;
-    Buf colsum = dev_alloc(sizeof(int32_t) * nseg * kMaxCols, s);
-    CS_HIP(hipMemsetAsync(colsum->p, 0, sizeof(int32_t) * nseg * kMaxCols, s));
+    const int maxc = walk_words == 6 ? kMaxColsLong : kMaxCols;
+    Buf colsum = dev_alloc(sizeof(int32_t) * nseg * maxc, s);
+    CS_HIP(hipMemsetAsync(colsum->p, 0, sizeof(int32_t) * nseg * maxc, s));
     CS_HIP(hipMemsetAsync(mx->p, 0, 4 * sizeof(int), s));
-    // the sentinel walk (both passes): a one-byte delimiter, no split limit, every row's sentinel bit inside the 96-bit mask
-    // (the longest row is column metadata, kept on the immutable column like its largest 64-row span)
-    const bool plain_walk = want_emit3 && mode == 0 && tokens <= 0 && !reverse && max_row_bytes(col, s) + 3 <= 95 && !cs::cfg("CS_SPLIT_GENERIC_WALK");
+    const bool plain_walk = walk_words != 0;
     // the single pass (cs_split1.hip), on request: measured slower than the two passes below (NOTES.md, round 4:
     // 8.0 against 6.7 ms on the 100M-row column); they also take over when it gives up
 #if defined(CS_EXPERIMENTS)  // (cs_split1.hip is in the experiments build only: `make exp`)
-    if (want_emit3 && cs::cfg("CS_SPLIT_SINGLE") && !cs::cfg("CS_SPLIT_OFF64") && split_single(col, delim, dlen, tokens, s, cols, reverse, span, plain_walk) == 1) return true;
+    if (walk_words != 6 && cs::cfg("CS_SPLIT_SINGLE") && !cs::cfg("CS_SPLIT_OFF64") && split_single(col, delim, dlen, tokens, s, cols, reverse, span, walk_words == 3) == 1) return true;
 #endif
     cols.clear();
     Measure2Args ma{view_of(col), dpat, d64, dlen, tokens, cap_in, nsub, per, seg, nseg, segs_per_run, reverse ? 1 : 0, ptr<int32_t>(colsum), ptr<int>(mx)};
@@ -1223,7 +834,8 @@ bool split_fast(const cs_column* col, const unsigned char* delim, int dlen, int 
       const size_t lds = (size_t)(cap_in + 32) * 4;
       if (mode == 1) hipLaunchKernelGGL(k_split_measure2<1>, dim3(g), dim3(256), lds, s, ma);
       else if (mode == 2) hipLaunchKernelGGL(k_split_measure2<2>, dim3(g), dim3(256), lds, s, ma);
-      else if (plain_walk) hipLaunchKernelGGL((k_split_measure2<0, true>), dim3(g), dim3(256), lds, s, ma);
+      else if (walk_words == 6) hipLaunchKernelGGL((k_split_measure2<0, true, 6>), dim3(g), dim3(256), lds, s, ma);
+      else if (walk_words == 3) hipLaunchKernelGGL((k_split_measure2<0, true, 3>), dim3(g), dim3(256), lds, s, ma);
       else hipLaunchKernelGGL(k_split_measure2<0>, dim3(g), dim3(256), lds, s, ma);
     }
     CS_HIP(hipGetLastError());
@@ -1231,10 +843,13 @@ bool split_fast(const cs_column* col, const unsigned char* delim, int dlen, int 
     CS_HIP(hipStreamSynchronize(s));
     const int ncols = hmx[0], bound = hmx[1], longest_row = hmx[2];
     if (ncols == 0 || ncols > kMaxColsWide) return false;  // all-null column / too many columns: generic path
-    const bool emit2_ok = !hmx[3] && longest_row + 3 <= 96 && ncols <= kMaxCols;  // (33 to 64 columns: the first generation)
-    const int cap_col = (bound + 64 + 15) & ~15;
-    const size_t lds2 = (size_t)(cap_in + 32 + 2 * cap_col + (ws ? 2 : 1) * ncols * 64) * 4;
-    if (emit2_ok && lds2 <= 150 * 1024) {
+    // regions of the out tile: every token byte once, up to 15 carried bytes and up to 15 bytes of padding per column, 20 bytes of OR slack
+    const int cap_out3 = (int)((span + 31 * ncols + 48 + 15) & ~(int64_t)15);
+    // (the in tile also holds the flush tables once the column loop is over)
+    const int cap_in3 = std::max((int)((span + 15 + 32 + 15) & ~(int64_t)15), kEmit4TableBytes);
+    const size_t lds3 = 288 + (size_t)(16 + cap_in3 + 32 + cap_out3) * (kEmit3Threads / 64);
+    const bool emit4_ok = !hmx[3] && ncols <= maxc && longest_row + 3 <= (plain_walk ? 32 * walk_words - 1 : 96) && cap_out3 <= kEmit4MaxOut && lds3 <= 64 * 1024;
+    if (emit4_ok) {
       // per column: position of every segment in the column's chars buffer
       Buf base = dev_alloc(sizeof(int64_t) * (nseg + 1) * ncols, s);
       std::vector<int64_t> totals(ncols);
@@ -1257,54 +872,35 @@ bool split_fast(const cs_column* col, const unsigned char* delim, int dlen, int 
         c->max_row = std::min<int64_t>(longest_row, bound);
         if (col->plain_bytes == 1) c->plain_bytes = 1;
         if (col->high_sample == 0) c->high_sample = 0;
+        if (((uintptr_t)ptr<uint8_t>(c->chars) & 15) != 0) fail(CS_ERR_INTERNAL, "split: a column's chars buffer is not 16-byte aligned");  // (a column's state is its position)
         outs[k] = ColOut2{ptr<uint8_t>(c->chars), off32 ? c->offsets32->p : c->offsets->p, ptr<uint8_t>(c->validity),
                           ptr<const int64_t>(base) + (int64_t)k * (nseg + 1)};
         cols.push_back(std::move(c));
       }
       Buf d_outs = dev_alloc(sizeof(ColOut2) * ncols, s);
       CS_HIP(hipMemcpyAsync(d_outs->p, outs.data(), sizeof(ColOut2) * ncols, hipMemcpyHostToDevice, s));
-      Emit2Args e2{view_of(col), dpat, d64, dlen, tokens, cap_in, cap_col, ncols, nsub, per, segs_per_run, ptr<const ColOut2>(d_outs), nullptr,
-                   reverse ? 1 : 0, cs::cfg("CS_SPLIT_DEBUG") ? atoi(cs::cfg("CS_SPLIT_DEBUG")) : 0};
+      Emit2Args e2{view_of(col), dpat, d64, dlen, tokens, cap_in, 0, ncols, nsub, per, segs_per_run, ptr<const ColOut2>(d_outs), nullptr,
+                   reverse ? 1 : 0, cs::cfg_int("CS_SPLIT_DEBUG", 0)};
 #if defined(CS_PHASE_PROF)
       Buf profbuf = dev_alloc(64, s);
       CS_HIP(hipMemsetAsync(profbuf->p, 0, 64, s));
       e2.prof = ptr<unsigned long long>(profbuf);
 #endif
-      // third generation (all columns side by side in one out tile, one flush per sub-tile) when its tiles fit
-      // (regions: every token byte once, up to 15 carried bytes and up to 15 bytes of padding per column, 20 bytes of OR slack)
-      const int cap_out3 = (int)((span + 31 * ncols + 48 + 15) & ~(int64_t)15);
-      // (the fourth generation keeps its flush tables, 640 bytes, in the in tile once the column loop is over)
-      bool want_emit4 = !cs::cfg("CS_SPLIT_EMIT3") && cap_out3 <= 8192;
-      for (int k = 0; k < ncols; ++k) want_emit4 = want_emit4 && ((uintptr_t)outs[k].chars & 15) == 0;  // (a column's state is its position)
-      const int cap_in3 = std::max((int)((span + 15 + 32 + 15) & ~(int64_t)15), want_emit4 ? 640 : 0);
-      const size_t lds3 = 288 + (size_t)(16 + cap_in3 + 32 + cap_out3) * (kEmit3Threads / 64);
-      unsigned g2 = 0;
-      if (want_emit3 && lds3 <= 64 * 1024) {
-        typedef void (*Emit3Kernel)(Emit3Args);
-        // the sentinel walk: a one-byte delimiter, no split limit, rows whose sentinel bit fits the 96-bit mask
-        const bool plain = plain_walk;
-        static const Emit3Kernel kerns3[2][3] = {{k_split_emit3<0, false, false>, k_split_emit3<1, false, false>, k_split_emit3<2, false, false>},
-                                                 {k_split_emit3<0, true, false>, k_split_emit3<1, true, false>, k_split_emit3<2, true, false>}};
-        static const Emit3Kernel kerns4[2][3] = {{k_split_emit4<0, false, false>, k_split_emit4<1, false, false>, k_split_emit4<2, false, false>},
-                                                 {k_split_emit4<0, true, false>, k_split_emit4<1, true, false>, k_split_emit4<2, true, false>}};
-        const Emit3Kernel kern3 = want_emit4 ? (plain ? (off32 ? k_split_emit4<0, true, true> : k_split_emit4<0, false, true>) : kerns4[off32 ? 1 : 0][mode])
-                                             : (plain ? (off32 ? k_split_emit3<0, true, true> : k_split_emit3<0, false, true>) : kerns3[off32 ? 1 : 0][mode]);
-        if (lds3 > 48 * 1024) CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern3), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
-        Emit3Args e3{e2, cap_in3, cap_out3};
-        constexpr int wpg = kEmit3Threads / 64;
-        g2 = (unsigned)((runs + wpg - 1) / wpg);
+      typedef void (*Emit3Kernel)(Emit3Args);
+      static const Emit3Kernel kerns4[2][3] = {{k_split_emit4<0, false, false>, k_split_emit4<1, false, false>, k_split_emit4<2, false, false>},
+                                               {k_split_emit4<0, true, false>, k_split_emit4<1, true, false>, k_split_emit4<2, true, false>}};
+      const Emit3Kernel kern3 = walk_words == 6   ? (off32 ? k_split_emit4<0, true, true, 6, 8> : k_split_emit4<0, false, true, 6, 8>)
+                                : walk_words == 3 ? (off32 ? k_split_emit4<0, true, true> : k_split_emit4<0, false, true>)
+                                                  : kerns4[off32 ? 1 : 0][mode];
+      if (lds3 > 48 * 1024) CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern3), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
+      Emit3Args e3{e2, cap_in3, cap_out3};
+      constexpr int wpg = kEmit3Threads / 64;
+      const unsigned g2 = (unsigned)((runs + wpg - 1) / wpg);
+      {
         ProfScope ps("k_split_emit", s);
         hipLaunchKernelGGL(kern3, dim3(g2), dim3(kEmit3Threads), lds3, s, e3);
-      } else {
-        typedef void (*EmitKernel)(Emit2Args);
-        static const EmitKernel kerns[2][3] = {{k_split_emit2<0, false>, k_split_emit2<1, false>, k_split_emit2<2, false>},
-                                               {k_split_emit2<0, true>, k_split_emit2<1, true>, k_split_emit2<2, true>}};
-        const EmitKernel kern = kerns[off32 ? 1 : 0][mode];
-        if (lds2 > 48 * 1024) CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
-        g2 = (unsigned)((runs + 3) / 4);
-        ProfScope ps("k_split_emit", s);
-        hipLaunchKernelGGL(kern, dim3(g2), dim3(256), lds2, s, e2);
       }
+      note_route(walk_words == 6 ? "split-tiles-188" : (walk_words == 3 ? "split-tiles-92" : "split-tiles"));
       CS_HIP(hipGetLastError());
       CS_HIP(hipStreamSynchronize(s));  // `outs` / `base` lifetime
 #if defined(CS_PHASE_PROF)
@@ -1312,8 +908,8 @@ bool split_fast(const cs_column* col, const unsigned char* delim, int dlen, int 
         unsigned long long ph[6];
         CS_HIP(hipMemcpy(ph, e2.prof, sizeof(ph), hipMemcpyDeviceToHost));
         const double it = (double)nsub;
-        fprintf(stderr, "emit cycles/wave-iteration (emit4: stage, masks, column loop, column lanes, flush, store drain): %.0f %.0f %.0f %.0f %.0f %.0f | grid %u lds %zu cap_col %d\n",
-                ph[0] / it, ph[1] / it, ph[2] / it, ph[3] / it, ph[4] / it, ph[5] / it, g2, lds2, cap_col);
+        fprintf(stderr, "emit cycles/wave-iteration (emit4: stage, masks, column loop, column lanes, flush, store drain): %.0f %.0f %.0f %.0f %.0f %.0f | grid %u lds %zu\n",
+                ph[0] / it, ph[1] / it, ph[2] / it, ph[3] / it, ph[4] / it, ph[5] / it, g2, lds3);
       }
 #endif
       return true;
@@ -1323,7 +919,7 @@ bool split_fast(const cs_column* col, const unsigned char* delim, int dlen, int 
     return false;
   }
 
-  // ---- first generation (one-byte delimiter; rows beyond 93 bytes, wide tiles): one sub-tile per wave
+  // ---- first generation (one-byte delimiter; rows beyond 188 bytes, wide tiles, more than 32 / 64 columns): one sub-tile per wave
   const int64_t nsub1 = (rows + rows_per_sub - 1) / rows_per_sub;  // (sub-tiles of rows_per_sub rows)
   const unsigned grid = (unsigned)((nsub1 + 3) / 4);
   Buf colsum = dev_alloc(sizeof(int32_t) * nsub1 * kMaxColsWide, s);
@@ -1378,6 +974,7 @@ bool split_fast(const cs_column* col, const unsigned char* delim, int dlen, int 
   }
   CS_HIP(hipGetLastError());
   CS_HIP(hipStreamSynchronize(s));  // `outs` / `base` lifetime
+  note_route("split-first-generation");
   return true;
 }
 

@@ -833,7 +833,7 @@ int split_single(const cs_column* col, const unsigned char* delim, int dlen, int
 
   Emit5Args ea{view_of(col), dpat, d64, dlen, tokens, reverse ? 1 : 0, ncap, npairs, nsub, stride, cap_in, cap_out, wave_bytes, scan_blocks,
                ptr<const ColOut5>(d_outs), status, excl, ctl, totals, ptr<uint8_t>(tilecols), nullptr, nullptr,
-               cs::cfg("CS_SPLIT_DEBUG") ? atoi(cs::cfg("CS_SPLIT_DEBUG")) : 0};
+               cs::cfg_int("CS_SPLIT_DEBUG", 0)};
 #if defined(CS_PHASE_PROF)
   Buf profbuf = dev_alloc(128, s);
   CS_HIP(hipMemsetAsync(profbuf->p, 0, 128, s));

@@ -42,6 +42,29 @@ template <class T>
 __device__ __forceinline__ gptr<T> as_global(T* p) {
   return (gptr<T>)p;
 }
+// 16-byte global accesses of the streaming kernels: NON-TEMPORAL -- every byte of these streams is touched once (the
+// headline step 11.38-11.41 -> 11.14 ms with both, 11.28-11.29 with the stores alone, A / B on one box: profiles/r06/nt_ab.txt;
+// the box's own streaming rates: read-only 6.5 -> 7.1 TB/s with nt loads, emit's store shape 5.0 -> 5.3 with nt stores:
+// profiles/r06/stream_rate.txt).  -DCS_PLAIN_STREAM restores the default cache policy (measurement).
+#if !defined(CS_PLAIN_STREAM)
+#define CS_NT_STORES 1
+#define CS_NT_LOADS 1
+#endif
+__device__ __forceinline__ void gstore16(gptr<u32x4> p, u32x4 v) {
+#if defined(CS_NT_STORES)
+  __builtin_nontemporal_store(v, p);
+#else
+  *p = v;
+#endif
+}
+__device__ __forceinline__ uint4 gload16_stream(const uint4* p) {
+#if defined(CS_NT_LOADS)
+  const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+  return make_uint4(v.x, v.y, v.z, v.w);
+#else
+  return *p;
+#endif
+}
 
 constexpr int kTileRows = 256;
 constexpr unsigned long long kFlagAgg = 1ull << 62, kFlagInc = 2ull << 62, kValMask = (1ull << 62) - 1;
@@ -167,7 +190,7 @@ __device__ __forceinline__ void wave_flush(uint8_t* dst, int total, const uint8_
     return;
   }
   for (int i = first_full + lane * 16; i < last_full; i += 64 * 16)
-    *(gptr<u32x4>)(a0 + i) = *reinterpret_cast<const u32x4*>(lds + i);
+    gstore16((gptr<u32x4>)(a0 + i), *reinterpret_cast<const u32x4*>(lds + i));
   // head bytes on lanes 0..15, tail bytes on lanes 16..31: one predicated byte store for both
   const int j = lane < 16 ? lead + lane : last_full + lane - 16;
   const bool ok = lane < 16 ? j < first_full : (lane < 32 && j < end);
@@ -325,7 +348,7 @@ __device__ __forceinline__ void issue_chars(const uint8_t* chars, long long g0, 
 #pragma unroll
   for (int j = 0; j < N; ++j) {
     const int i = j * 1024 + lane * 16;
-    if (i < span) c.v[j] = *reinterpret_cast<const uint4*>(src + i);
+    if (i < span) c.v[j] = gload16_stream(reinterpret_cast<const uint4*>(src + i));
   }
 }
 template <int N>
@@ -680,7 +703,7 @@ __device__ __forceinline__ void wave_flush_shift(uint8_t* dst, int total, const 
   for (int i = first_full + lane * 16; i < last_full; i += 64 * 16) {
     const lds_u32x4u v = *reinterpret_cast<const lds_u32x4u*>(lds + head + (i - first_full));
     u32x4 o = {v.x, v.y, v.z, v.w};
-    *(gptr<u32x4>)(a0 + i) = o;
+    gstore16((gptr<u32x4>)(a0 + i), o);
   }
   const int tail0 = last_full - olead;               // output index of the first tail byte
   if (tail0 + lane < total) gdst[tail0 + lane] = lds[tail0 + lane];

@@ -93,6 +93,20 @@ const char* cs_debug_last_route(void);
 int cs_config_set(const char* name, const char* value);
 /* Bytes currently held by live columns/categories on this device. */
 int64_t cs_device_bytes_in_use(void);
+/* The buffer pool (reference: the RMM pool behind device_alloc, cpp/src/util.inl:90-106): released blocks are kept and
+ * re-used; a new block's capacity is rounded up to a geometric size class (eight per octave, 3 % of headroom) so that a
+ * column a little larger than the last one finds a block.  cs_debug_malloc_count: hipMalloc calls so far (tests: a
+ * pipeline on columns of slightly different sizes allocates once); cs_pool_cached_bytes: bytes idle in the pool (bounded
+ * by half the device's memory, CS_POOL_MAX_MB); cs_pool_trim: give idle blocks back down to `keep_bytes`. */
+int64_t cs_debug_malloc_count(void);
+/* What this box's memory delivers to hand-written streaming kernels (custrings_amd/csrc/box_rates.h), in TB/s (bytes read
+ * + bytes written over the median of `reps` launches): tbps[0] a 16-byte-a-lane copy, [1] a read-only stream, [2] a
+ * write-only stream, [3] the split emit kernel's shape -- one read stream into 20 x (256 + 192 + 8)-byte pieces per
+ * 64-row sub-tile -- with plain stores, [4] the same with non-temporal stores.  `mbytes`: buffer size.  bench.py prints
+ * them as the `box` block of its line (the headline's kernels follow the box's mixed read / write rate). */
+int cs_box_rates(int64_t mbytes, int reps, cs_stream stream, double* tbps);
+int64_t cs_pool_cached_bytes(void);
+int cs_pool_trim(int64_t keep_bytes);
 
 /* ---- column construction / export -------------------------------------- */
 /* NVStrings::create_from_array (NVStrings.h:86): NULL entry = null row. */

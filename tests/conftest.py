@@ -20,23 +20,36 @@ def _cs_switches(monkeypatch):
     time only through cs_config_set: a test that sets one with monkeypatch.setenv tells the library too, and the switch goes
     back to what the process started with afterwards."""
     touched = {}
-    plain_setenv = monkeypatch.setenv
+    plain_setenv, plain_delenv = monkeypatch.setenv, monkeypatch.delenv
+
+    def tell(name, value):
+        # (a CPU-only test -- rowemu, oracle -- may touch a CS_ name on a box without the GPU runtime: the library is then
+        # simply not there to be told)
+        try:
+            from custrings_amd import _lib
+        except (ImportError, OSError):
+            return
+        _lib.lib.cs_config_set(name.encode(), None if value is None else str(value).encode())
 
     def setenv(name, value, prepend=None):
         if name.startswith("CS_") and name not in touched:
             touched[name] = os.environ.get(name)
         plain_setenv(name, value, prepend)
         if name.startswith("CS_"):
-            from custrings_amd import _lib
+            tell(name, value)
 
-            _lib.lib.cs_config_set(name.encode(), str(value).encode())
+    def delenv(name, raising=True):
+        if name.startswith("CS_") and name not in touched:
+            touched[name] = os.environ.get(name)
+        plain_delenv(name, raising)
+        if name.startswith("CS_"):
+            tell(name, None)
 
     monkeypatch.setenv = setenv
+    monkeypatch.delenv = delenv
     yield
     for name, before in touched.items():
-        from custrings_amd import _lib
-
-        _lib.lib.cs_config_set(name.encode(), None if before is None else before.encode())
+        tell(name, before)
 
 
 @pytest.fixture(scope="session")

@@ -112,7 +112,7 @@ def test_gpu_two_rank_exchanges_with_the_gpu_ops(gpu_engine, world):
     assert sum((list(g[7][5]) for g in got), []) == list(want_values)
 
 
-def _failing_worker(rank, world, port, rows, q):
+def _failing_worker(rank, world, port, rows, q, fail_at=None):
     sys.path.insert(0, os.path.dirname(HERE))
     sys.path.insert(0, HERE)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
@@ -132,13 +132,18 @@ def _failing_worker(rank, world, port, rows, q):
         out = C.c_void_p()
         _lib.check(_lib.lib.cs_synth_column(4, lo, hi - lo, 20240607, 3000, None, C.byref(out)))
         col = nvstrings.nvstrings(out.value)
-        _lib.check(_lib.lib.cs_config_set(b"CS_DIST_TEST_FAIL", b"1"))  # rank 1's local build "fails"
+        if fail_at is None:
+            _lib.check(_lib.lib.cs_config_set(b"CS_DIST_TEST_FAIL", b"1"))  # rank 1's local build "fails"
+        else:  # a failure INSIDE the partitioned merge: "<rank>:<stage>" (cs_dist.hip: merge_partitioned)
+            _lib.check(_lib.lib.cs_config_set(b"CS_DIST_PARTITIONED", b"1"))
+            _lib.check(_lib.lib.cs_config_set(b"CS_DIST_TEST_FAIL_AT", fail_at.encode()))
         try:
             csd.global_category_c_abi(col)
             res = "no error"
         except RuntimeError as e:
             res = str(e)
         _lib.check(_lib.lib.cs_config_set(b"CS_DIST_TEST_FAIL", None))
+        _lib.check(_lib.lib.cs_config_set(b"CS_DIST_TEST_FAIL_AT", None))
         ok = csd.global_category_c_abi(col).keys_size()  # the ranks are still in step: the next build works
         q.put((rank, "ok", res, ok))
         dist.barrier()
@@ -166,6 +171,30 @@ def test_gpu_distributed_build_fails_on_every_rank_together():
         p.join(timeout=60)
     assert all(g[1] == "ok" for g in got), [g[2] for g in got if g[1] != "ok"]
     assert all("rank 1 failed before the exchange" in g[2] for g in got), [g[2] for g in got]
+    assert got[0][3] == got[1][3] > 0
+
+
+@pytest.mark.parametrize("fail_at", ["1:1", "1:2", "0:3", "1:4"])
+def test_gpu_partitioned_merge_fails_on_every_rank_together(fail_at):
+    """the key-range partitioned merge runs about ten collectives with multi-GB allocations and consistency checks
+    between them.  A rank that fails in any stage (sample, range cuts, receive buffers, merge of its range) reports it at the
+    next agreement point and EVERY rank returns an error there -- none is left waiting in RCCL -- and the next build works."""
+    import torch.multiprocessing as mp
+
+    rows, world = 20_000, 2
+    port = 37500 + (os.getpid() % 2000)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_failing_worker, args=(r, world, port, rows, q, fail_at)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+    assert all(g[1] == "ok" for g in got), [g[2] for g in got if g[1] != "ok"]
+    bad_rank, stage = fail_at.split(":")
+    assert "simulated failure in stage %s" % stage in got[int(bad_rank)][2], got[int(bad_rank)][2]
+    assert ("rank %s failed" % bad_rank) in got[1 - int(bad_rank)][2], got[1 - int(bad_rank)][2]
     assert got[0][3] == got[1][3] > 0
 
 

@@ -1,0 +1,290 @@
+"""Round 6: the buffer pool's size classes (no hipMalloc for a column a little larger than the last one), regression
+tests for the two malformed-UTF-8 parity bugs the round-5 soak found, a fixed-seed slice of tools/soak_gpu.py inside
+the suite -- once per forced regex route, the ORACLE as the witness on valid UTF-8 / ASCII columns and the row-wise
+kernels on arbitrary bytes --, rows beyond 93 bytes on the fast split / regex forms."""
+import ctypes as C
+import importlib.util
+import os
+
+import numpy as np
+import pytest
+
+import cpulibs
+import engines
+import gpuutil
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+IPV4 = r"\d+\.\d+\.\d+\.\d+"
+
+
+def last_route():
+    return gpuutil.lib().lib.cs_debug_last_route().decode()
+
+
+def blob_of(pat):
+    b = engines.reference_blob(pat)
+    return np.ascontiguousarray(b if b is not None else engines.product_blob(pat), dtype=np.int32)
+
+
+def col_of(rows):
+    chars = np.frombuffer(b"".join(rows), dtype=np.uint8).copy()
+    offs = np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.int64)
+    return cpulibs.Col(chars, offs, None)
+
+
+_soak = None
+
+
+def soak():
+    """tools/soak_gpu.py as a module (its column generator, op snapshot and oracle leg are the suite's too)."""
+    global _soak
+    if _soak is None:
+        spec = importlib.util.spec_from_file_location("soak_gpu", os.path.join(ROOT, "tools", "soak_gpu.py"))
+        _soak = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(_soak)
+    return _soak
+
+
+# ---- the buffer pool (reference: the RMM pool behind device_alloc, cpp/src/util.inl:90-106) ----------------------------
+
+def test_gpu_pool_serves_columns_of_slightly_different_sizes():
+    """The headline step on five columns whose sizes differ by up to +-1 % (other seeds, other row counts): after the first
+    column every buffer -- the column's own and all 21 outputs -- comes out of the pool (cs_core.hip: size_class: 3 % of
+    headroom, eight classes an octave).  Until round 5 a column a few KB larger than the last one paid a hipMalloc per
+    buffer (120-134 ms at 100M rows: VERDICT r05 missing 4)."""
+    L = gpuutil.lib()
+    from custrings_amd import nvstrings
+
+    re = gpuutil.compile_re(IPV4)
+
+    def step(rows, seed):
+        g = gpuutil.synth(3, 0, rows, seed=seed)
+        cols = g.split(" ")
+        o = C.c_void_p()
+        L.check(L.lib.cs_replace_re(g.m_cptr, re, b"<IP>", -1, None, C.byref(o)))
+        out = nvstrings.nvstrings(o.value)
+        n = (len(cols), out.size())
+        del cols, out, g
+        return n
+
+    base = 3_000_000
+    try:
+        step(int(base * 1.01), 11)  # (the largest first: what the pool holds afterwards serves every smaller request within 20 %)
+        m0 = int(L.lib.cs_debug_malloc_count())
+        L.check(L.lib.cs_config_set(b"CS_POOL_TRACE", b"1"))  # (a miss says which request it was, on stderr)
+        for i, f in enumerate((0.99, 1.0, 0.995, 1.008, 1.01)):
+            step(int(base * f), 12 + i)
+        assert int(L.lib.cs_debug_malloc_count()) == m0, "a column within 1 %% of the last one allocated %d new block(s)" % (int(L.lib.cs_debug_malloc_count()) - m0)
+        # growing by 2 % a step: the headroom of a class (3 %) absorbs a step, a new class is entered at most every second step
+        m0 = int(L.lib.cs_debug_malloc_count())
+        rows = base
+        for i in range(6):
+            rows = int(rows * 1.02)
+            step(rows, 30 + i)
+        grown = int(L.lib.cs_debug_malloc_count()) - m0
+        assert grown <= 3 * 70, "growing columns: %d allocations" % grown  # (about 66 buffers a step; at most every second step allocates)
+    finally:
+        L.lib.cs_regex_destroy(re)
+        L.check(L.lib.cs_config_set(b"CS_POOL_TRACE", None))
+    assert int(L.lib.cs_pool_cached_bytes()) > 0
+    L.check(L.lib.cs_pool_trim(0))
+    assert int(L.lib.cs_pool_cached_bytes()) == 0
+
+
+# ---- malformed UTF-8: what the round-5 soak found ------------------------------------------------------------------------
+
+LEAD_ROWS = [b"4\xc3b", b"ab b", b"\xc3b", b"b\xc3", b"a\xe2bb", b"\xf0abcb", b"\xc3\xa9b", b"b\x80b", b"\xe2\x82b ab", b"4\xc3b" * 9, b"", b"b"]
+# what the reference's executor sees (regexec.inl:204-442 walks custring_view::iterator, whose operator++ advances by the
+# LEAD byte's width -- custring_view.inl:48-57,361-366 -- so the bytes behind a lead are swallowed whatever they are; a stray
+# continuation byte has width 0 there, the product treats it as a character of its own): matches of b|ab per row
+LEAD_COUNTS = [0, 2, 0, 1, 0, 1, 1, 2, 1, 0, 0, 1]
+
+
+def test_gpu_unit_route_lead_byte_swallows_the_ascii_byte_behind_it():
+    """count_re / contains_re / replace_re of `b|ab` (a unit-route program) on rows where a lead byte >= 0xC0 stands without its
+    continuation bytes: the byte behind it belongs to the 'character' and is no match.  Round 5's last soak (seed 70058) found
+    the unit route counting the `b` of `4\\xc3b`: its whole-character check ran only for patterns that look flags up
+    (cs_regex.hip: reclassify_high; fix 35b5107, which landed without a test)."""
+    L = gpuutil.lib()
+    pat = r"b|ab"
+    re = gpuutil.compile_re(pat)
+    rng = np.random.default_rng(70058)
+    filler = [bytes(rng.choice(list(b"ab4 .x"), int(rng.integers(0, 60))).astype(np.uint8)) for _ in range(4000)]
+    # the malformed rows in the middle of plain ones (the tile's other rows stay on the fast form) and in tiles of their own
+    rows = filler[:1000] + LEAD_ROWS + filler[1000:2000] + LEAD_ROWS * 20 + filler[2000:]
+    col = col_of(rows)
+    g = gpuutil.from_col(col)
+    try:
+        cnt = np.zeros(col.rows, dtype=np.int32)
+        found = C.c_int64()
+        L.check(L.lib.cs_count_re(g.m_cptr, re, cnt.ctypes.data, 0, None, C.byref(found)))
+        assert last_route() in ("units", "bits", "chain", "plain"), last_route()
+        got_rep = gpuutil.to_col(g.replace(pat, "_"))
+        got_has, _ = gpuutil.bools(g, "cs_contains_re", re)
+        # witness 1: the hand-derived counts of the explicit rows
+        assert cnt[1000:1000 + len(LEAD_ROWS)].tolist() == LEAD_COUNTS
+        assert (got_has[1000:1000 + len(LEAD_ROWS)] != 0).tolist() == [c > 0 for c in LEAD_COUNTS]
+        # witness 2: the row-wise kernels on the whole column
+        for v in ("CS_REGEX_ROWWISE", "CS_REGEX_TWO_PASS"):
+            L.check(L.lib.cs_config_set(v.encode(), b"1"))
+        try:
+            cnt2 = np.zeros(col.rows, dtype=np.int32)
+            L.check(L.lib.cs_count_re(g.m_cptr, re, cnt2.ctypes.data, 0, None, C.byref(found)))
+            want_rep = gpuutil.to_col(g.replace(pat, "_"))
+            want_has, _ = gpuutil.bools(g, "cs_contains_re", re)
+        finally:
+            for v in ("CS_REGEX_ROWWISE", "CS_REGEX_TWO_PASS"):
+                L.check(L.lib.cs_config_set(v.encode(), None))
+        assert np.array_equal(cnt, cnt2), np.flatnonzero(cnt != cnt2)[:8]
+        assert np.array_equal(got_has, want_has)
+        assert got_rep.same_as(want_rep)
+        # witness 3: the oracle on the rows that ARE valid UTF-8 (the reference's contract)
+        valid = [i for i, r in enumerate(rows) if _is_utf8(r)]
+        ocnt, _ = cpulibs.Oracle().count_re(col, blob_of(pat))
+        assert np.array_equal(cnt[valid], ocnt[valid])
+    finally:
+        L.lib.cs_regex_destroy(re)
+
+
+def _is_utf8(b):
+    try:
+        b.decode("utf-8")
+        return True
+    except UnicodeDecodeError:
+        return False
+
+
+def test_gpu_soak_seed_70058_and_its_neighbours():
+    """The soak column that exposed the unit-route bug, and the class-runs one (findall([a-c]+) on random bytes), replayed."""
+    s = soak()
+    bad = 0
+    for seed in (70058, 70056):
+        bad += s.check_column(seed, pats=[(r"b|ab", ""), (r"[a-c]+", "xyz__"), (r"(a|b)c", "-"), (r"\w+", "<w>")], regex_only=True, category=False)
+    assert bad == 0
+
+
+# ---- a slice of the soak inside the suite, once per forced route -----------------------------------------------------------
+
+ROUTE_SLICES = {
+    # forced switches, (pattern, replacement) pairs the route converts, seeds: [valid UTF-8 (oracle), ASCII (oracle), arbitrary bytes (row-wise)]
+    "default": ((), None, (21 + 28 * 3, 9 + 28 * 5, 3 + 28 * 7)),
+    "bits": (("CS_BITS_ALWAYS",), [(r"(\bab\b)|(\bc\b)|(\bxyz\b)", "="), (r"[abc1]+", "*"), (r"ab|a1|bc", "#"), (r"x?y?z", "Q"), (r"b|ab", ""), (r"\d\.|\.\d", "~")],
+             (22 + 28 * 2, 7 + 28 * 4, 0 + 28 * 6)),
+    "class-runs": (("CS_CLASS_RUNS_ALWAYS",), [(r"[a-c]+", "xyz__"), (r"\w+", "<w>"), (r"\S+", "s"), (r"[^\w]", "_"), (r".", "?"), (r"\d", "9"), (r"[^ ]+", "_")],
+                   (27 + 28 * 1, 10 + 28 * 2, 34 + 28 * 3)),
+    "chain-tables-in-memory": (("CS_CHAIN_TABLES_IN_MEMORY",), [(IPV4, "<IP>"), (r"\b\d{1,3}\.\d{1,3}\.\d{1,3}\.\d{1,3}\b", "<IP>"), (r"[a-c]+=>", ""), (r"\d+\.\d+ ", "<n>"),
+                                                                (r"\b\d+\.\d+\b", ""), (r"\d+\.\d{2}\.\d+", "#")],
+                               (23 + 28 * 9, 8 + 28 * 3, 5 + 28 * 2)),
+}
+
+
+@pytest.mark.parametrize("route", sorted(ROUTE_SLICES))
+def test_gpu_soak_slice(route):
+    """tools/soak_gpu.py, fixed seeds, inside the suite: the fast kernels with one regex route forced
+    against the CPU oracle on the columns of valid UTF-8 / ASCII text and against the row-wise kernels on every column
+    (the only witness on arbitrary bytes: the reference is undefined there).  The default slice runs every op of the path."""
+    s = soak()
+    assert s.ORC is not None, "the oracle library is the witness of this test"
+    forced, pats, seeds = ROUTE_SLICES[route]
+    bad = 0
+    lines = []
+    for seed in seeds:
+        bad += s.check_column(seed, pats=pats, regex_only=pats is not None, max_rows=6000, forced=forced, category=pats is None, log=lines.append)
+    assert bad == 0, lines[:10]
+
+
+# ---- rows beyond 93 bytes on the fast split kernels (split.cu:751-816, custring_view.cuh:36-42: any row length) ---------------
+
+def _random_rows(rng, n, lo, hi, tokens_hi=40, alphabet=b"abcdefghijklmnop0123456789.-_/", wide=("é", "€", "😀", "ß")):
+    """rows of lo..hi BYTES: words of 1..12 characters joined by single spaces (now and then two, or a leading / trailing one)."""
+    wide_b = [w.encode() for w in wide]
+    out = []
+    for _ in range(n):
+        target = int(rng.integers(lo, hi + 1))
+        parts, size, toks = [], 0, 0
+        while size < target and toks < tokens_hi:
+            k = int(rng.integers(1, 13))
+            if rng.random() < 0.08:
+                w = b"".join(wide_b[int(i)] for i in rng.integers(0, len(wide_b), max(1, k // 3)))
+            else:
+                w = bytes(rng.choice(list(alphabet), k).astype(np.uint8))
+            sep = b"  " if rng.random() < 0.05 else b" "
+            parts.append(w + sep)
+            size += len(w) + len(sep)
+            toks += 1
+        row = b"".join(parts)[:target]
+        if rng.random() < 0.05:
+            row = b" " + row[:-1] if row else row
+        out.append(row)
+    return out
+
+
+def _with_nulls(rows, rng, share=0.02):
+    col = col_of(rows)
+    keep = rng.random(len(rows)) >= share
+    keep[-8:] = True  # (the rows a test appends by hand stay)
+    lens = np.array([len(r) if k else 0 for r, k in zip(rows, keep)], dtype=np.int64)
+    chars = np.frombuffer(b"".join(r for r, k in zip(rows, keep) if k), dtype=np.uint8).copy()
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    return cpulibs.Col(chars, offs, np.packbits(keep, bitorder="little"))
+
+
+@pytest.mark.parametrize("lo,hi,longest,route", [(40, 150, 150, "split-tiles-188"), (0, 170, 188, "split-tiles-188"), (94, 128, 188, "split-tiles-188"),
+                                                 (0, 92, 92, "split-tiles-92"), (0, 92, 93, "split-tiles-188"), (60, 120, 189, "split-first-generation")])
+def test_gpu_split_rows_beyond_93_bytes_vs_oracle(lo, hi, longest, route):
+    """split(' ') on rows of up to 188 bytes -- BASELINE's C5 lengths and the edges of the six-word masks -- through
+    k_split_measure2<0, true, 6> + k_split_emit4<.., 6, 8>, against the oracle: every column bit for bit, non-ASCII rows and
+    null rows included.  A column whose longest row has 189 bytes keeps the first-generation kernels."""
+    rng = np.random.default_rng(9300 + lo + hi + longest)
+    rows = _random_rows(rng, 20_000, lo, hi)
+    # the longest row, delimiters only (as many tokens as the walk's columns allow), three-byte tokens, an empty row
+    rows += [b"x" * longest, b" " * (28 if route == "split-tiles-92" else 60), b"a b" * (min(longest, 186) // 3), b"", b"z" * (longest - 1) + b" "]
+    col = _with_nulls(rows, rng)
+    g = gpuutil.from_col(col)
+    got = g.split(" ")
+    assert last_route() == route, last_route()
+    want = cpulibs.Oracle().split(col, " ")
+    assert len(got) == len(want)
+    for k, (a, b) in enumerate(zip(got, want)):
+        gpuutil.assert_same(a, b, "split(' ') column %d of %d, rows %d..%d bytes" % (k, len(want), lo, hi))
+
+
+def test_gpu_split_long_rows_many_columns_and_the_fallbacks():
+    """More than 64 tokens in a row (the six-word walk holds 64 columns) or a 64-row span beyond 8 KB: the column leaves the
+    tile kernels for the first-generation / row-wise ones -- same columns as the oracle either way."""
+    rng = np.random.default_rng(9377)
+    orc = cpulibs.Oracle()
+    base = _random_rows(rng, 5000, 40, 150)
+    for extra, route in (([b"a " * 70], ("split-first-generation", "split-rowwise")),          # 71 tokens in one row
+                         ([b"y" * 188] * 64, ("split-first-generation", "split-rowwise", "split-tiles-188")),  # a sub-tile of 12 KB
+                         ([b"q " * 32], ("split-tiles-188",))):                                  # 33 columns: beyond the 96-bit kernels' 32
+        col = col_of(base[:2000] + extra + base[2000:])
+        g = gpuutil.from_col(col)
+        got = g.split(" ")
+        assert last_route() in route, (last_route(), route)
+        want = orc.split(col, " ")
+        assert len(got) == len(want)
+        for a, b in zip(got, want):
+            gpuutil.assert_same(a, b, "split(' ') with %r..." % extra[0][:8])
+
+
+def test_gpu_split_c5_column_on_the_long_row_kernels():
+    """BASELINE's C5 column (tweet-like rows of 40-150 bytes): split(' ') takes the six-word tile kernels and equals the oracle;
+    split with a limit and whitespace splitting (96-bit token walker only) still answer through the older kernels."""
+    rows = 200_000
+    g = gpuutil.synth(5, 0, rows)
+    o = cpulibs.Oracle().synth(5, 0, rows)
+    got = g.split(" ")
+    assert last_route() == "split-tiles-188", last_route()
+    want = cpulibs.Oracle().split(o, " ")
+    assert len(got) == len(want)
+    for k, (a, b) in enumerate(zip(got, want)):
+        gpuutil.assert_same(a, b, "C5 split(' ') column %d" % k)
+    for d, n in ((" ", 3), (None, -1)):
+        got = g.split(d, n)
+        want = cpulibs.Oracle().split(o, d, n)
+        assert len(got) == len(want)
+        for a, b in zip(got, want):
+            gpuutil.assert_same(a, b, "C5 split(%r, %d)" % (d, n))

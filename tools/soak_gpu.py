@@ -31,10 +31,10 @@ PATS = [(r"\d+\.\d+\.\d+\.\d+", "<IP>"), (r"\d", "#"), (r"[a-c]+", "xyz__"), (r"
         (r"(\bab\b)|(\bc\b)|(\bxyz\b)", "="), (r"[abc1]+", "*"), (r"ab|a1|bc", "#"), (r"[^ ]+", "_"), (r".", "?"), (r"x?y?z", "Q")]
 
 
-def make_column(seed):
+def make_column(seed, max_rows=40_000):
     rng = np.random.default_rng(seed)
     kind = seed % 7
-    rows = int(rng.integers(1, 40_000))
+    rows = int(rng.integers(1, max_rows))
     if kind == 0:
         lens = rng.integers(0, 95, rows)
     elif kind == 1:
@@ -76,12 +76,13 @@ def make_column(seed):
     return cpulibs.Col(chars, offs, valid), flavour
 
 
-def snapshot(g, rows, rng_seed):
+def snapshot(g, rows, rng_seed, pats=None, regex_only=False):
+    """Every op of the path on one device column -> {name: result}.  `pats`: the (pattern, replacement) pairs of the
+    replace_re / contains_re / count_re leg (default: four of PATS drawn from the seed); `regex_only`: that leg and findall only."""
     L = gpuutil.lib()
     rng = np.random.default_rng(rng_seed)
     out = {}
-    for i in rng.choice(len(PATS), 4, replace=False):
-        pat, repl = PATS[i]
+    for pat, repl in (pats if pats is not None else [PATS[i] for i in rng.choice(len(PATS), 4, replace=False)]):
         n = int(rng.choice([-1, -1, 1, 3]))
         out["replace_re %r %r %d" % (pat, repl, n)] = gpuutil.to_col(g.replace(pat, repl, n))
         re = gpuutil.compile_re(pat)
@@ -89,7 +90,12 @@ def snapshot(g, rows, rng_seed):
         cnt = np.zeros(max(rows, 1), dtype=np.int32)
         found = C.c_int64()
         L.check(L.lib.cs_count_re(g.m_cptr, re, cnt.ctypes.data, 0, None, C.byref(found)))
-        out["count_re %r" % pat] = (cnt, found.value)
+        out["count_re %r" % pat] = (cnt[:rows], found.value)
+        L.lib.cs_regex_destroy(re)
+        if regex_only:
+            out["findall %r" % pat] = [gpuutil.to_col(c) for c in g.findall(pat)]
+    if regex_only:
+        return out
     for pat, repl in (("a", "b"), ("ab", "x"), (" ", "  "), ("1", "one")):
         out["replace %r %r" % (pat, repl)] = gpuutil.to_col(g.replace(pat, repl, regex=False))
     for d, n in ((" ", -1), (".", 2), (None, -1), (None, 2), ("ab", -1)):
@@ -138,6 +144,12 @@ def oracle_leg(col, fast, seed):
             if op == "replace_re":
                 pat, repl, n = _parse3(rest)
                 want[k] = ORC.replace_re(col, np.ascontiguousarray(engines.reference_blob(pat)), repl, n)
+            elif op == "contains_re":
+                import ast
+                want[k] = ORC.contains_re(col, np.ascontiguousarray(engines.reference_blob(ast.literal_eval(rest))))
+            elif op == "count_re":
+                import ast
+                want[k] = ORC.count_re(col, np.ascontiguousarray(engines.reference_blob(ast.literal_eval(rest))))
             elif op == "replace":
                 pat, repl = _split_reprs(rest)
                 want[k] = ORC.replace(col, pat, repl)
@@ -208,8 +220,61 @@ def same(a, b):
     if isinstance(a, list):
         return len(a) == len(b) and all(x.same_as(y) for x, y in zip(a, b))
     if isinstance(a, tuple):
-        return np.array_equal(a[0], b[0]) and a[1] == b[1]
+        return np.array_equal(np.asarray(a[0]).astype(np.int64), np.asarray(b[0]).astype(np.int64)) and int(a[1]) == int(b[1])
     return a.same_as(b)
+
+
+def check_column(seed, pats=None, regex_only=False, max_rows=40_000, forced=(), category=True, log=print):
+    """One column of the soak: the fast paths (plus the switches in `forced`, e.g. ("CS_BITS_ALWAYS",)) against (a) the
+    row-wise / two-pass kernels -- the witness on arbitrary bytes, where the reference is undefined (its iterator steps by the
+    lead byte's width, custring_view.inl:361-366, past the row's end) -- and (b) the CPU ORACLE on valid UTF-8 / ASCII columns
+    (flavours 1 and 3: the reference's contract).  Returns the number of mismatches."""
+    bad = 0
+    col, flavour = make_column(seed, max_rows)
+    g = gpuutil.from_col(col)
+    for v in TOGGLES:  # (the library reads its switches once: cs_config_set changes them at run time)
+        LIB.cs_config_set(v.encode(), None)
+    for v in forced:
+        LIB.cs_config_set(v.encode(), b"1")
+    try:
+        fast = snapshot(g, col.rows, seed, pats, regex_only)
+        cat_f = nvcategory.from_strings(g) if category else None
+    finally:
+        for v in forced:
+            LIB.cs_config_set(v.encode(), None)
+    for v in TOGGLES:
+        LIB.cs_config_set(v.encode(), b"1")
+    try:
+        slow = snapshot(g, col.rows, seed, pats, regex_only)
+    finally:
+        for v in TOGGLES:
+            LIB.cs_config_set(v.encode(), None)
+    for k in fast:
+        if not same(fast[k], slow[k]):
+            bad += 1
+            log("MISMATCH seed=%d rows=%d op=%s" % (seed, col.rows, k))
+    if flavour in (1, 3) and ORC is not None:
+        bad += oracle_leg(col, fast, seed)
+    if not category:
+        return bad
+    # category against numpy's view of the same bytes
+    keys = gpuutil.to_col(cat_f.keys())
+    vals = np.zeros(max(col.rows, 1), dtype=np.int32)
+    cat_f.values(vals)
+    rows_b = col.to_bytes_list()
+    uniq = sorted({x for x in rows_b if x is not None})
+    want_keys = ([None] if any(x is None for x in rows_b) else []) + uniq
+    got_keys = keys.to_bytes_list()
+    if got_keys != want_keys:
+        bad += 1
+        log("MISMATCH seed=%d category keys" % seed)
+    else:
+        idx = {k: i for i, k in enumerate(want_keys)}
+        want_vals = np.array([idx[x] for x in rows_b], dtype=np.int32)
+        if not np.array_equal(vals[:col.rows], want_vals):
+            bad += 1
+            log("MISMATCH seed=%d category values" % seed)
+    return bad
 
 
 def main():
@@ -218,38 +283,7 @@ def main():
     t0 = time.time()
     bad = done = 0
     while time.time() - t0 < budget:
-        col, flavour = make_column(seed)
-        g = gpuutil.from_col(col)
-        for v in TOGGLES:  # (the library reads its switches once: cs_config_set changes them at run time)
-            LIB.cs_config_set(v.encode(), None)
-        fast = snapshot(g, col.rows, seed)
-        cat_f = nvcategory.from_strings(g)
-        for v in TOGGLES:
-            LIB.cs_config_set(v.encode(), b"1")
-        slow = snapshot(g, col.rows, seed)
-        for k in fast:
-            if not same(fast[k], slow[k]):
-                bad += 1
-                print("MISMATCH seed=%d rows=%d op=%s" % (seed, col.rows, k), flush=True)
-        if flavour in (1, 3) and ORC is not None:
-            bad += oracle_leg(col, fast, seed)
-        # category against numpy's view of the same bytes
-        keys = gpuutil.to_col(cat_f.keys())
-        vals = np.zeros(max(col.rows, 1), dtype=np.int32)
-        cat_f.values(vals)
-        rows_b = col.to_bytes_list()
-        uniq = sorted({x for x in rows_b if x is not None})
-        want_keys = ([None] if any(x is None for x in rows_b) else []) + uniq
-        got_keys = keys.to_bytes_list()
-        if got_keys != want_keys:
-            bad += 1
-            print("MISMATCH seed=%d category keys" % seed, flush=True)
-        else:
-            idx = {k: i for i, k in enumerate(want_keys)}
-            want_vals = np.array([idx[x] for x in rows_b], dtype=np.int32)
-            if not np.array_equal(vals[:col.rows], want_vals):
-                bad += 1
-                print("MISMATCH seed=%d category values" % seed, flush=True)
+        bad += check_column(seed, log=lambda m: print(m, flush=True))
         done += 1
         seed += 1
     print("soak: %d columns, %d mismatches, %.0f s" % (done, bad, time.time() - t0))
