@@ -142,13 +142,14 @@ def main():
     # ---- what this box's memory delivers to hand-written streaming kernels (custrings_amd/csrc/box_rates.h), same process
     box = None
     if not args.no_box and rank == 0:
-        rates = (C.c_double * 5)()
+        rates = (C.c_double * 6)()
         _lib.check(L.cs_box_rates(2048, 3, None, rates))
         box = {"copy_TBps": round(rates[0], 2), "read_TBps": round(rates[1], 2), "write_TBps": round(rates[2], 2),
-               "scatter21_TBps": round(rates[3], 2), "scatter21_nt_TBps": round(rates[4], 2),
+               "scatter21_TBps": round(rates[3], 2), "scatter21_nt_TBps": round(rates[4], 2), "shader_GHz_under_load": round(rates[5], 3),
                "what": "own streaming kernels, 2 GiB buffers, median of 3 launches, bytes read + written over the launch time: a 16 B/lane "
                        "copy, a read-only and a write-only stream, and the split emit kernel's shape (one read stream into 20 x (256 + 192 + 8) B "
-                       "pieces per 64-row sub-tile, runs of 24 sub-tiles a wave) with plain / non-temporal stores"}
+                       "pieces per 64-row sub-tile, runs of 24 sub-tiles a wave) with plain / non-temporal stores; the shader clock (s_memtime over "
+                       "s_memrealtime) one wave saw while every CU ran integer + LDS work"}
         L.cs_pool_trim(0)  # (the calibration's buffers go back to the driver: the pool is empty again, as at the process's start)
     barrier()
 

@@ -127,4 +127,30 @@ __global__ void __launch_bounds__(WAVES * 64) k_scatter(ScatterArgs a) {
   }
 }
 
+// The shader clock under load: every CU runs dependent integer adds and LDS round trips for a fixed number of iterations;
+// wave 0 of workgroup 0 reads the shader-clock counter (s_memtime) and the constant 100 MHz counter (s_memrealtime) around
+// its loop.  out[0] = shader cycles, out[1] = 100 MHz ticks.  (The row-lane kernels -- emit above all -- follow the clock the
+// box sustains, the streaming rates above do not: a box can be "slow" in one and not in the other.)
+__global__ void __launch_bounds__(256) k_clock_probe(int iters, unsigned long long* __restrict__ out, uint32_t* __restrict__ sink) {
+  __shared__ uint32_t buf[256];
+  buf[threadIdx.x] = threadIdx.x;
+  __syncthreads();
+  uint32_t a = threadIdx.x, b = blockIdx.x;
+  const unsigned long long c0 = __builtin_readcyclecounter(), r0 = __builtin_amdgcn_s_memrealtime();
+  for (int i = 0; i < iters; ++i) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      a = a * 3u + b;
+      b = b ^ (a >> 3);
+    }
+    a += buf[(a + threadIdx.x) & 255];
+  }
+  const unsigned long long c1 = __builtin_readcyclecounter(), r1 = __builtin_amdgcn_s_memrealtime();
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    out[0] = c1 - c0;
+    out[1] = r1 - r0;
+  }
+  if (a == 0x12345u && b == 0x54321u) sink[0] = a;  // (never: keeps the loop)
+}
+
 }  // namespace csbox

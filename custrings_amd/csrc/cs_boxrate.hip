@@ -37,6 +37,7 @@ double median_ms(const std::function<void()>& launch, hipStream_t s, int reps) {
 }
 }  // namespace
 
+// tbps[5] = the shader clock in GHz that wave 0 saw while every CU ran k_clock_probe (about a millisecond of integer and LDS work).
 // tbps[0..4] = TB/s (bytes read + bytes written over the median launch time) of: a 16-byte-a-lane copy, a read-only
 // stream, a write-only stream, emit's shape (one read stream -> 20 x (256 + 192 + 8)-byte pieces a sub-tile, runs of 24
 // sub-tiles a wave) with plain and with non-temporal stores.  `mbytes`: size of the copy buffers (the scatter reads as much).
@@ -80,5 +81,20 @@ extern "C" int cs_box_rates(int64_t mbytes, int reps, cs_stream stream, double* 
     tbps[3] = moved / ms / 1e9;
     ms = median_ms([&] { hipLaunchKernelGGL((k_scatter<2, true, false>), dim3(g), dim3(128), 0, s, a); }, s, reps);
     tbps[4] = moved / ms / 1e9;
+    {
+      int dev = 0, cus = 0;
+      CS_HIP(hipGetDevice(&dev));
+      CS_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+      Buf counters = dev_alloc(64, s);
+      unsigned long long* host = (unsigned long long*)pinned_scratch(16);
+      double ghz = 0;
+      for (int r = 0; r < 3; ++r) {  // (the last of three launches: the clock has settled under the load)
+        hipLaunchKernelGGL(k_clock_probe, dim3((unsigned)(cus * 8)), dim3(256), 0, s, 20000, (unsigned long long*)counters->p, (uint32_t*)counters->p + 8);
+        CS_HIP(hipMemcpyAsync(host, counters->p, 16, hipMemcpyDeviceToHost, s));
+        CS_HIP(hipStreamSynchronize(s));
+        ghz = host[1] ? (double)host[0] / (double)host[1] * 0.1 : 0.0;
+      }
+      tbps[5] = ghz;
+    }
   });
 }

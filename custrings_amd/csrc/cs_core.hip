@@ -101,8 +101,11 @@ static size_t size_class(size_t want) {
   const size_t step = (size_t)1 << (e - (small ? 2 : 3));
   return (w + step - 1) / step * step;
 }
-// the largest idle block a request may take: 25 % over it, or 256 KiB (the small blocks' classes are coarse)
-static size_t reuse_limit(size_t want) { return want + std::max<size_t>(want / 4 + 4096, (size_t)256 << 10); }
+// the largest idle block a request may take: half as much again (one class up from the block a request 3 % larger was
+// given: with 25 % a request for 15.06 MB missed an idle 18.87 MB block by 50 KB -- tools/pool_replay.py replays a trace of
+// the pool's requests through this policy), or 256 KiB (the small blocks' classes are coarse)
+static size_t reuse_limit(size_t want) { return want + std::max<size_t>(want / 2 + 4096, (size_t)256 << 10); }
+constexpr int kPageBlocksAtFirstTouch = 64;  // page-sized blocks allocated together the first time one is needed (below)
 
 // The cache is bounded: beyond the limit the largest idle blocks go back to the driver (hipFree waits for the device:
 // rare by construction -- the limit is half the device's memory unless CS_POOL_MAX_MB says otherwise).
@@ -162,6 +165,7 @@ DevBuf::~DevBuf() {
   }
   std::lock_guard<std::mutex> lk(g_mu);
   g_in_use -= (int64_t)capacity;
+  if (cs::cfg_int("CS_POOL_TRACE", 0) >= 2) fprintf(stderr, "pool- %zu %zu\n", bytes, capacity);
   g_cache.emplace(capacity, CachedBlock{p, stream, std::move(evs)});
   g_cached_bytes += (int64_t)capacity;
   trim_cache_locked();
@@ -194,6 +198,7 @@ Buf dev_alloc(size_t bytes, hipStream_t stream) {
       reused = true;
     }
   }
+  if (cs::cfg_int("CS_POOL_TRACE", 0) >= 2) fprintf(stderr, "pool+ %zu %zu %s\n", bytes, reused ? b->capacity : (size_t)0, reused ? "hit" : "miss");
   if (reused) {
     // a block last used on another stream may still be in flight there: this stream waits for the release event on the
     // device (blocks released before a second stream existed carry none: the host waits for their stream once)
@@ -239,6 +244,23 @@ Buf dev_alloc(size_t bytes, hipStream_t stream) {
   b->capacity = want;
   std::lock_guard<std::mutex> lk(g_mu);
   g_in_use += (int64_t)want;
+  // Page-sized blocks (scalars, flags, the chars of a column that few rows reach): how many of them are live at once
+  // varies from column to column as sizes cross the page -- the first one brings its siblings along (each its own
+  // allocation: any of them may later be exported over HIP IPC), so that a later op does not stop for a 4 KB hipMalloc.
+  static bool page_blocks_made = false;
+  if (want == 4096 && !page_blocks_made) {
+    page_blocks_made = true;
+    for (int i = 0; i < kPageBlocksAtFirstTouch; ++i) {
+      void* q = nullptr;
+      if (hipMalloc(&q, 4096) != hipSuccess) {
+        (void)hipGetLastError();
+        break;
+      }
+      g_mallocs.fetch_add(1, std::memory_order_relaxed);
+      g_cache.emplace((size_t)4096, CachedBlock{q, kNoStream, {}});
+      g_cached_bytes += 4096;
+    }
+  }
   return b;
 }
 

@@ -821,20 +821,6 @@ __global__ void k_findall_spans(RowSrc src, Launch L, int ncols, int32_t* __rest
 #else
 #define CS_DBG(a) 0
 #endif
-struct TileArgs {
-  ColView in;
-  const uint8_t* flags;
-  TLaunch L;
-  const uint8_t* repl;
-  int rb, maxrepl;
-  int64_t* out_off;
-  uint8_t* out_chars;
-  cstile::u64* status;
-  unsigned* error;  // set non-zero when the single pass could not complete
-  long long ntiles;
-  int cap_in, cap_out, tbl_bytes;
-  int debug;  // CS_TILE_DEBUG bit mask: skip phases (measurement only, results are wrong)
-};
 constexpr int kMaxRec = 4;  // matches per row kept in registers between the size and write phases
 
 template <class VM, class Rec>
@@ -847,117 +833,11 @@ __device__ __forceinline__ int tile_row_size(VM& vm, int n, int rb, int maxrepl,
   return len;
 }
 
-// One wave = one sub-tile of 64 consecutive rows (workgroup = 4 sub-tiles, tile id =
-// blockIdx: nothing persistent, the hardware scheduler overlaps as many workgroups
-// as LDS allows).  Each wave stages its rows' contiguous span of the chars buffer
-// into its private LDS region with coalesced 16-byte loads, runs the automaton per
-// lane, turns the output sizes into offsets with a wave scan + decoupled look-back
-// (sub-tile granularity), assembles the output rows in LDS and flushes them with
-// coalesced 16-byte stores.  The transition tables are read through the vector
-// cache (they are consulted only on the few bytes that leave the idle state).
-// A sub-tile that does not fit the staging buffers, or a look-back that times out,
-// raises *a.error: the host then recomputes the column with the two-pass kernels.
-template <bool IN_LDS>
-__global__ void __launch_bounds__(256) k_tdfa_replace_tile(TileArgs a) {
-  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-  uint8_t* base = reinterpret_cast<uint8_t*>(smem);
-  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;  // (scalar: what derives from it stays in SGPRs)
-  uint8_t* lds_in = base + a.tbl_bytes + (size_t)wv * (a.cap_in + a.cap_out + 64);
-  uint8_t* lds_out = lds_in + a.cap_in + 32;
-  const TCtx c = tsetup<IN_LDS>(a.L, a.flags, smem);  // (block barrier inside when staging)
-  const cstd::View& D = c.D;
-  const csvm::ProgView& P = c.P;
-  const ColView& in = a.in;
-  const int rb = a.rb;
-  constexpr int kSub = 64;
-  const long long sub = (long long)blockIdx.x * 4 + wv;
-  const long long r0 = sub * kSub;
-  if (r0 >= in.rows) return;
-  const int nrows = (int)min((long long)kSub, in.rows - r0);
-  const long long o0 = in.offsets[r0 + min(lane, nrows)];
-  const long long o1 = in.offsets[r0 + min(lane + 1, nrows)];
-  const long long g0 = __shfl(o0, 0, 64), g1 = __shfl(o1, 63, 64);
-  const bool live = lane < nrows && row_is_valid(in.validity, r0 + lane);
-  const int rbeg = (int)(o0 - g0);
-  const int n = live ? (int)(o1 - o0) : 0;
-  bool bad = (g1 - g0) + 16 > a.cap_in;
-  int lead = 0;
-  if (!bad && !(CS_DBG(a) & 16)) {
-    lead = (int)((uintptr_t)(in.chars + g0) & 15);
-    const uint8_t* src = in.chars + (g0 - lead);  // 16-byte aligned
-    const int span = (int)(g1 - g0) + lead;
-    for (int i = lane * 16; i < span; i += 64 * 16)
-      *reinterpret_cast<uint4*>(lds_in + i) = *reinterpret_cast<const uint4*>(src + i);
-  }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-
-  int rec_mb[kMaxRec], rec_me[kMaxRec], rec_reps[kMaxRec];
-  int nm = 0;
-  int out_len = 0;
-  if (live && !bad) {
-    if (CS_DBG(a) & 1) {
-      out_len = n;
-    } else {
-      cstd::Tdfa vm(D, P, lds_in + lead + rbeg, n, (lead + rbeg) & 3);
-      out_len = tile_row_size(vm, n, rb, a.maxrepl, [&](int mb, int me, int reps) {
-#pragma unroll
-        for (int j = 0; j < kMaxRec; ++j)
-          if (nm == j) {
-            rec_mb[j] = mb;
-            rec_me[j] = me;
-            rec_reps[j] = reps;
-          }
-        ++nm;
-      });
-    }
-  }
-  bad |= __any(nm > kMaxRec);
-  // sub-tile scan (wave-wide) and look-back
-  const int incl = csdev::wave_inclusive_scan(out_len);
-  const int lo = incl - out_len;
-  const int total = __builtin_amdgcn_readlane(incl, 63);
-  bad |= total + 32 > a.cap_out;
-  long long gb = (CS_DBG(a) & 8) ? sub * 4096 : cstile::lookback(a.status, 1, sub, total);
-  if (gb < 0) {
-    bad = true;
-    gb = 0;
-  }
-  if (bad) {
-    if (lane == 0) atomicOr(a.error, 1u);
-    return;
-  }
-  if (lane < nrows) a.out_off[r0 + lane] = gb + lo;
-  if (lane == nrows - 1 && r0 + nrows == in.rows) a.out_off[in.rows] = gb + lo + out_len;
-  uint8_t* gdst = a.out_chars + gb;
-  const int olead = (int)((uintptr_t)gdst & 15);
-  if (live && !(CS_DBG(a) & 2)) {
-    int oi = olead + lo;         // byte index into lds_out
-    const int pi = lead + rbeg;  // byte index of the row in lds_in
-    int copied = 0;
-#pragma unroll
-    for (int j = 0; j < kMaxRec; ++j)
-      if (j < nm) {
-        cstile::lds_copy(lds_out, oi, lds_in, pi + copied, rec_mb[j] - copied);
-        oi += rec_mb[j] - copied;
-        for (int k = 0; k < rec_reps[j]; ++k)
-          for (int i = 0; i < rb; ++i) lds_out[oi++] = a.repl[i];
-        copied = rec_me[j];
-      }
-    cstile::lds_copy(lds_out, oi, lds_in, pi + copied, n - copied);
-  }
-  if (!(CS_DBG(a) & 4)) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    cstile::wave_flush(gdst, total, lds_out, olead, lane);
-  }
-}
-
 
 // ---- persistent single-pass replace_re (tile_utils.h: sub-tile stream) ----------------
-// Same contract as k_tdfa_replace_tile, restructured for latency: the grid is sized to
+// (its non-persistent predecessor, k_tdfa_replace_tile -- one sub-tile a wave, plain look-back, reached only for replacements
+// beyond 16 bytes that do not grow a row -- left the library in round 6: no test reached it, the two-pass kernels answer.)
+// The grid is sized to
 // the device's residency, wave `wid` of W walks sub-tiles wid, wid + W, ...; the chars of
 // the next sub-tile are prefetched into registers while the current one is scanned, the
 // look-back poll is issued before the output rows are assembled and consumed after, and
@@ -1234,7 +1114,7 @@ __device__ __forceinline__ void bits_classify16(const uint32_t* spread, const ui
 // the code costs the others registers).
 template <bool IN_LDS, bool REP16, bool INPLACE, bool RESCAN = false, bool LONG = false, bool UNITS = false, int PF = cstile::kPfChunks, bool BREFS = false,
           bool WIDE = false, bool OUTL = false, bool CHAIN = false, bool BITS = false>
-__global__ void __launch_bounds__(256, ((BREFS && !CHAIN) || (BITS && IN_LDS)) ? 2 : CS_STREAM_WAVES) k_tdfa_replace_stream(StreamArgs a) {
+__global__ void __launch_bounds__(256, ((BREFS && !CHAIN) || (BITS && IN_LDS) || (LONG && PF > cstile::kPfChunks)) ? 2 : CS_STREAM_WAVES) k_tdfa_replace_stream(StreamArgs a) {
   // BITS (a CHAIN form): the pattern has a bit-parallel form (regex_bits.h) -- one bitmap per character class, staged by
   // table lookup; the row lanes derive their rows' matches from the class masks (alternations of word-bounded literals,
   // small sets in a `+` loop: patterns whose candidates are everywhere); a sub-tile with a byte >= 0x80 / NUL or a row
@@ -2837,11 +2717,16 @@ struct TileChoice {
   int R, cap;
   bool lng;
   int64_t span;  // the largest span of R consecutive rows (cap = that plus slack, rounded up to 128)
+  int pf = cstile::kPfChunks;  // 16-byte prefetch chunks a lane the tile needs (8: a long-row tile of 64 rows up to 8 KB)
 };
 // `small`: also tiles of eight and four rows, also for rows beyond the sliding window (replace_re: its alternative is the
 // two-pass thread-per-row kernels; the scans' row-wise kernels beat such tiles: contains_re 1.9 against 4.6 ms, findall 27
 // against 64 ms on 520-byte rows)
-TileChoice choose_tile(const cs_column* col, hipStream_t s, bool small = false) {
+// `wide8k` (replace_re): long rows keep 64-row tiles while those fit 8 KB (eight prefetch chunks a lane: BASELINE's C5 column,
+// 64 rows of 95 bytes on average).  Halving the rows instead halves the work a wave has between publishing a tile's size
+// and needing its prefix -- the prefix then arrives late: 23 k of 38 k cycles per tile spent waiting on the C5 column
+// (profiles/r06/c5_phases.txt).
+TileChoice choose_tile(const cs_column* col, hipStream_t s, bool small = false, bool wide8k = false) {
   const int64_t longest = max_row_bytes(col, s);
   auto cap_of = [](int64_t span) { return (int64_t)((span + 15 + 32 + 127) & ~(int64_t)127); };
   const int64_t span64 = max_span64(col, s);
@@ -2850,6 +2735,7 @@ TileChoice choose_tile(const cs_column* col, hipStream_t s, bool small = false) 
   if (fits64 && longest + 3 <= cstd::Tdfa::kMaskBytes) return {64, (int)cap64, false, span64};
   if (longest > cstd::Tdfa::kLongBytes && (fits64 || !small)) return {fits64 ? 64 : 0, (int)cap64, false, span64};  // (such tiles scan generically)
   if (fits64) return {64, (int)cap64, true, span64};
+  if (wide8k && cap64 <= 8 * 1024 && !cs::cfg("CS_NO_WIDE_TILES")) return {64, (int)cap64, true, span64, 8};
   // (eight and four rows a tile: rows of hundreds of bytes -- few lanes of a wave hold a row then, but the rows still arrive
   // through coalesced tiles and are scanned in LDS; the thread-per-row kernels read them byte by byte from memory)
   for (int r : {32, 16, 8, 4}) {
@@ -3170,7 +3056,7 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
       const int64_t rows = col->rows;
       const int64_t ntiles = (rows + cstile::kTileRows - 1) / cstile::kTileRows;
       const int64_t nsub = ntiles * 4;
-      TileChoice tc = choose_tile(col, s, !cs::cfg("CS_NO_SMALL_TILES"));
+      TileChoice tc = choose_tile(col, s, !cs::cfg("CS_NO_SMALL_TILES"), tp.d.in_lds && !wide_stream && !cs::g_backrefs_dev);
       // (the column's largest 64-row span does not fit, all but a few do: buffers for those, the kernel handles the rest)
       bool outliers = false;
       constexpr int64_t kOutlierSpan = cstile::kPfBytes - 176;  // (its capacity is kPfBytes)
@@ -3185,6 +3071,8 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
       // persistent stream kernel (grid = what is resident at once); returns its error word, or -1
       // when the sizing does not fit
       auto stream_attempt = [&](bool roomy) -> int {
+        // (a DFA whose tables do not fit the LDS budget: the two-pass kernels read them from memory)
+        if (!tp.d.in_lds) return -1;
         const int64_t few = (int64_t)rows * kMaxRec * growth;  // extra bytes if no row has more than kMaxRec matches
         int cap_out = cap + ((64 * kMaxRec * growth + 127) & ~127);
         // (no growth: the out tile holds at most the in tile's span -- rounded up to 16, not to the in tile's 128: a form of
@@ -3341,10 +3229,11 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
         sa.outliers = outliers ? 1 : 0;
         sa.lit = literal ? cs::g_replace_literal : 0;
         sa.litn = literal ? cs::g_replace_literal_len : 0;
+        // (tables in LDS: a DFA beyond the LDS budget left this function above -- the forms with the tables in memory that are
+        // not chain forms were never reached by a test and spilled 20-60 registers: out since round 6, kernel_coverage.txt)
         auto pick2 = [&](auto inplace, auto rescan, auto lng) {
           constexpr bool IP = decltype(inplace)::value, RS = decltype(rescan)::value, LG = decltype(lng)::value;
-          return rb > 8 ? (tp.d.in_lds ? &k_tdfa_replace_stream<true, true, IP, RS, LG> : &k_tdfa_replace_stream<false, true, IP, RS, LG>)
-                        : (tp.d.in_lds ? &k_tdfa_replace_stream<true, false, IP, RS, LG> : &k_tdfa_replace_stream<false, false, IP, RS, LG>);
+          return rb > 8 ? &k_tdfa_replace_stream<true, true, IP, RS, LG> : &k_tdfa_replace_stream<true, false, IP, RS, LG>;
         };
         // rows beyond the 96-byte candidate masks (and up to 255 bytes) take the sliding-window form
         const bool lng = tc.lng;
@@ -3353,6 +3242,11 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
         };
         auto kern = growth == 0 ? pick(std::true_type{}, std::false_type{})
                                 : roomy ? pick(std::false_type{}, std::true_type{}) : pick(std::false_type{}, std::false_type{});
+        if (tc.pf == 8) {  // (long rows, 64-row tiles of up to 8 KB: tables in LDS only -- choose_tile was told)
+          if (growth == 0) kern = rb > 8 ? &k_tdfa_replace_stream<true, true, true, false, true, false, 8> : &k_tdfa_replace_stream<true, false, true, false, true, false, 8>;
+          else if (roomy) kern = rb > 8 ? &k_tdfa_replace_stream<true, true, false, true, true, false, 8> : &k_tdfa_replace_stream<true, false, false, true, true, false, 8>;
+          else kern = rb > 8 ? &k_tdfa_replace_stream<true, true, false, false, true, false, 8> : &k_tdfa_replace_stream<true, false, false, false, true, false, 8>;
+        }
         if (outliers) {  // (the forms that handle oversize sub-tiles: in place, or with the rescan assembly)
           constexpr int P6 = cstile::kPfChunks;
           if (growth == 0) kern = rb > 8 ? &k_tdfa_replace_stream<true, true, true, false, false, false, P6, false, false, true>
@@ -3386,11 +3280,9 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
           kern = rb > 8 ? &k_tdfa_replace_stream<true, true, false, true, false, true, 5, false, false, false, true>
                         : &k_tdfa_replace_stream<true, false, false, true, false, true, 5, false, false, false, true>;
         else if (units && cap <= 5 * 1024)
-          kern = rb > 8 ? (tp.d.in_lds ? &k_tdfa_replace_stream<true, true, false, true, false, true, 5> : &k_tdfa_replace_stream<false, true, false, true, false, true, 5>)
-                        : (tp.d.in_lds ? &k_tdfa_replace_stream<true, false, false, true, false, true, 5> : &k_tdfa_replace_stream<false, false, false, true, false, true, 5>);
+          kern = rb > 8 ? &k_tdfa_replace_stream<true, true, false, true, false, true, 5> : &k_tdfa_replace_stream<true, false, false, true, false, true, 5>;
         else if (units)
-          kern = rb > 8 ? (tp.d.in_lds ? &k_tdfa_replace_stream<true, true, false, true, false, true> : &k_tdfa_replace_stream<false, true, false, true, false, true>)
-                        : (tp.d.in_lds ? &k_tdfa_replace_stream<true, false, false, true, false, true> : &k_tdfa_replace_stream<false, false, false, true, false, true>);
+          kern = rb > 8 ? &k_tdfa_replace_stream<true, true, false, true, false, true> : &k_tdfa_replace_stream<true, false, false, true, false, true>;
         note_route(bits_form ? "bits" : bchain ? "brefs-chain" : brefs ? "brefs" : literal ? "literal" : wide_stream ? "wide" : units ? (((re->tdfa[30] >> 16) & 15) != 0 ? "chain" : "units") : "plain");
         if (lds1 > 48 * 1024)
           CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -3487,7 +3379,7 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
       // kernels.  A column that has more after all loses one launch before them)
       const bool few_matches = rb <= kMaxStreamRepl && minlen >= 1 && col->rows > 0 &&
                                candidate_share(re, col, s) * ((double)col->nbytes / (double)col->rows) <= (double)(kMaxRec - 1);
-      if (lds <= 150 * 1024 && (rb <= 16 || (rb <= kMaxStreamRepl && rb <= 4 * minlen) || few_matches) && tc.R && !cs::cfg("CS_TILE_OLD")) {
+      if (lds <= 150 * 1024 && (rb <= 16 || (rb <= kMaxStreamRepl && rb <= 4 * minlen) || few_matches) && tc.R) {
         const bool roomy_first = growth > 0 && (minlen <= 2 || wide_stream || outliers || cs::cfg("CS_REPLACE_ROOMY"));
         int err = stream_attempt(roomy_first);
         if (err == 2 && !roomy_first) err = stream_attempt(true);  // only ran out of room: once more, roomier
@@ -3503,48 +3395,6 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
                    (long long)col->rows, (long long)col->max_row, (long long)col->max_span64);
           note_fallback(what);
         }
-      } else if (lds <= 150 * 1024 && growth == 0 && (tc.R == 64 || tc.R == 0) && !cs::g_backrefs_dev && !wide) {  // (cap is the 64-row capacity then)
-        TileArgs ta{};
-        ta.in = view_of(col);
-        ta.flags = d_unicode_flags();
-        ta.L = tp.d;
-        ta.repl = ptr<const uint8_t>(d_repl);
-        ta.rb = rb;
-        ta.maxrepl = maxrepl;
-        Buf out_off = dev_alloc(sizeof(int64_t) * (rows + 1), s);
-        Buf out_chars = dev_alloc((size_t)col->nbytes + 64, s);
-        ta.out_off = ptr<int64_t>(out_off);
-        ta.out_chars = ptr<uint8_t>(out_chars);
-        Buf status = dev_alloc(sizeof(cstile::u64) * nsub + 16, s);
-        CS_HIP(hipMemsetAsync(status->p, 0, sizeof(cstile::u64) * nsub + 16, s));
-        ta.status = ptr<cstile::u64>(status);
-        ta.error = reinterpret_cast<unsigned*>(ptr<cstile::u64>(status) + nsub);
-        ta.ntiles = ntiles;
-        ta.cap_in = cap;
-        ta.cap_out = cap;
-        ta.tbl_bytes = (int)tbl;
-        ta.debug = cs::cfg_int("CS_TILE_DEBUG", 0);
-        auto kern = tp.d.in_lds ? &k_tdfa_replace_tile<true> : &k_tdfa_replace_tile<false>;
-        if (lds > 48 * 1024)
-          CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)lds));
-        {
-          ProfScope ps("k_replace_re", s);
-          hipLaunchKernelGGL(kern, dim3((unsigned)ntiles), dim3(256), lds, s, ta);
-        }
-        CS_HIP(hipGetLastError());
-        int64_t* host = (int64_t*)pinned_scratch(16);
-        CS_HIP(hipMemcpyAsync(host, ptr<int64_t>(out_off) + rows, 8, hipMemcpyDeviceToHost, s));
-        CS_HIP(hipMemcpyAsync(host + 1, ta.error, 4, hipMemcpyDeviceToHost, s));
-        CS_HIP(hipStreamSynchronize(s));
-        if ((uint32_t)host[1] == 0) {
-          o->offsets = out_off;
-          o->chars = out_chars;
-          o->nbytes = host[0];
-          *out = holder.release();
-          return;
-        }
-        note_fallback("replace_re (tile kernel)");
       }
       // an oversize sub-tile or a look-back timeout: fall through to the two-pass kernels
     }

@@ -102,8 +102,9 @@ int64_t cs_debug_malloc_count(void);
 /* What this box's memory delivers to hand-written streaming kernels (custrings_amd/csrc/box_rates.h), in TB/s (bytes read
  * + bytes written over the median of `reps` launches): tbps[0] a 16-byte-a-lane copy, [1] a read-only stream, [2] a
  * write-only stream, [3] the split emit kernel's shape -- one read stream into 20 x (256 + 192 + 8)-byte pieces per
- * 64-row sub-tile -- with plain stores, [4] the same with non-temporal stores.  `mbytes`: buffer size.  bench.py prints
- * them as the `box` block of its line (the headline's kernels follow the box's mixed read / write rate). */
+ * 64-row sub-tile -- with plain stores, [4] the same with non-temporal stores; tbps[5]: the shader clock in GHz under an
+ * all-CU integer + LDS load (six doubles in all).  `mbytes`: buffer size.  bench.py prints them as the `box` block of
+ * its line (the headline's kernels follow the box's mixed read / write rate and its clock). */
 int cs_box_rates(int64_t mbytes, int reps, cs_stream stream, double* tbps);
 int64_t cs_pool_cached_bytes(void);
 int cs_pool_trim(int64_t keep_bytes);

@@ -288,3 +288,82 @@ def test_gpu_split_c5_column_on_the_long_row_kernels():
         assert len(got) == len(want)
         for a, b in zip(got, want):
             gpuutil.assert_same(a, b, "C5 split(%r, %d)" % (d, n))
+
+
+
+# ---- forms the suite did not reach until round 6 (profiles/r06/kernel_coverage.txt) ----------------------------------------------
+
+def test_gpu_split_with_int64_offsets(monkeypatch):
+    """The split tile kernels' int64-offsets forms (a column of 2 GiB or more; CS_SPLIT_OFF64 forces them on a small one):
+    k_split_emit4<.., OFF32 = false, ..> in its three walks, against the oracle."""
+    monkeypatch.setenv("CS_SPLIT_OFF64", "1")
+    orc = cpulibs.Oracle()
+    rng = np.random.default_rng(6464)
+    for rows_b, delim, n, route in ((_random_rows(rng, 9000, 0, 92), " ", -1, "split-tiles-92"), (_random_rows(rng, 9000, 40, 150), " ", -1, "split-tiles-188"),
+                                    (_random_rows(rng, 9000, 0, 92), None, -1, "split-tiles"), (_random_rows(rng, 9000, 0, 92), "  ", -1, "split-tiles"),
+                                    (_random_rows(rng, 9000, 0, 92), " ", 3, "split-tiles")):
+        col = _with_nulls(rows_b, rng)
+        g = gpuutil.from_col(col)
+        got = g.split(delim, n)
+        assert last_route() == route, (last_route(), route)
+        assert all(int(gpuutil.lib().lib.cs_column_offset_width(c.m_cptr)) == 8 for c in got)
+        want = orc.split(col, delim, n)
+        assert len(got) == len(want)
+        for a, b in zip(got, want):
+            gpuutil.assert_same(a, b, "split(%r, %d) with int64 offsets" % (delim, n))
+
+
+@pytest.mark.parametrize("pat,repl", [(IPV4, "<IP>"), (r"(\bab\b)|(\bc\b)", "="), (r"\w+@\w+", "<m>"), (r"#\w+", "<a-longer-tag>")])
+def test_gpu_regex_with_the_dfa_tables_in_memory(pat, repl, monkeypatch):
+    """A DFA beyond the LDS budget keeps its tables in memory (CS_TDFA_GLOBAL_TABLE forces that for any pattern): replace_re
+    then takes the two-pass kernels (the stream forms with the tables in memory left the library in round 6), the scans
+    their table-in-memory forms -- all against the oracle."""
+    monkeypatch.setenv("CS_TDFA_GLOBAL_TABLE", "1")
+    L = gpuutil.lib()
+    orc = cpulibs.Oracle()
+    blob = blob_of(pat)
+    for kind, rows in ((3, 30_011), (5, 20_000)):
+        g, o = gpuutil.synth(kind, 0, rows), orc.synth(kind, 0, rows)
+        gpuutil.assert_same(g.replace(pat, repl), orc.replace_re(o, blob, repl), "replace_re(%r), tables in memory" % pat)
+        re = gpuutil.compile_re(pat)
+        try:
+            has, n = gpuutil.bools(g, "cs_contains_re", re)
+            want_has, want_n = orc.contains_re(o, blob)
+            assert np.array_equal(has, want_has) and n == want_n
+            cnt = np.zeros(rows, dtype=np.int32)
+            found = C.c_int64()
+            L.check(L.lib.cs_count_re(g.m_cptr, re, cnt.ctypes.data, 0, None, C.byref(found)))
+            want_cnt, _ = orc.count_re(o, blob)
+            assert np.array_equal(cnt, want_cnt)
+        finally:
+            L.lib.cs_regex_destroy(re)
+        got = g.findall(pat)
+        want = orc.findall(o, blob)
+        assert len(got) == len(want)
+        for a, b in zip(got, want):
+            gpuutil.assert_same(a, b, "findall(%r), tables in memory" % pat)
+
+
+@pytest.mark.parametrize("pat,repl", [(IPV4, "<IP>"), (r"#\w+", "<tag>"), (r"\w+@\w+", "<m>"), (r"(\bin\b)|(\ba\b)|(\bthe\b)", "="), (r"\d", "##"), (r"[a-z]+ing\b", "")])
+def test_gpu_replace_re_long_rows_on_64_row_tiles(pat, repl, monkeypatch):
+    """replace_re on rows of 94-188 bytes: the long-row form of the stream kernel on 64-row tiles of up to 8 KB (eight prefetch
+    chunks a lane) -- until round 6 such a column took 32-row tiles, whose waves wait for their tile's prefix most of the time
+    (profiles/r06/c5_phases.txt).  Against the oracle, and the 32-row tiles (CS_NO_WIDE_TILES) give the same."""
+    L = gpuutil.lib()
+    orc = cpulibs.Oracle()
+    blob = blob_of(pat)
+    rng = np.random.default_rng(8800)
+    rows_b = _random_rows(rng, 30_000, 40, 150, alphabet=b"abcdefghijklmnop0123456789.-_/#@ing the a in") + [b"1.2.3.4 " * 20, b"x" * 188, b"#tag@mail.com " * 13]
+    cases = [(gpuutil.synth(5, 0, 150_000), orc.synth(5, 0, 150_000), "C5"), (None, _with_nulls(rows_b, rng), "random long rows")]
+    for g, o, what in cases:
+        if g is None:
+            g = gpuutil.from_col(o)
+        want = orc.replace_re(o, blob, repl)
+        f0 = int(L.lib.cs_fallback_count())
+        gpuutil.assert_same(g.replace(pat, repl), want, "replace_re(%r) on %s" % (pat, what))
+        L.check(L.lib.cs_config_set(b"CS_NO_WIDE_TILES", b"1"))
+        try:
+            gpuutil.assert_same(g.replace(pat, repl), want, "replace_re(%r) on %s, 32-row tiles" % (pat, what))
+        finally:
+            L.check(L.lib.cs_config_set(b"CS_NO_WIDE_TILES", None))
+        assert int(L.lib.cs_fallback_count()) == f0, "a single-pass kernel gave up"
