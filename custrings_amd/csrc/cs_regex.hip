@@ -1114,7 +1114,7 @@ __device__ __forceinline__ void bits_classify16(const uint32_t* spread, const ui
 // the code costs the others registers).
 template <bool IN_LDS, bool REP16, bool INPLACE, bool RESCAN = false, bool LONG = false, bool UNITS = false, int PF = cstile::kPfChunks, bool BREFS = false,
           bool WIDE = false, bool OUTL = false, bool CHAIN = false, bool BITS = false>
-__global__ void __launch_bounds__(256, ((BREFS && !CHAIN) || (BITS && IN_LDS) || (LONG && PF > cstile::kPfChunks)) ? 2 : CS_STREAM_WAVES) k_tdfa_replace_stream(StreamArgs a) {
+__global__ void __launch_bounds__(256, ((BREFS && !CHAIN) || (BITS && IN_LDS)) ? 2 : CS_STREAM_WAVES) k_tdfa_replace_stream(StreamArgs a) {
   // BITS (a CHAIN form): the pattern has a bit-parallel form (regex_bits.h) -- one bitmap per character class, staged by
   // table lookup; the row lanes derive their rows' matches from the class masks (alternations of word-bounded literals,
   // small sets in a `+` loop: patterns whose candidates are everywhere); a sub-tile with a byte >= 0x80 / NUL or a row
@@ -2717,16 +2717,14 @@ struct TileChoice {
   int R, cap;
   bool lng;
   int64_t span;  // the largest span of R consecutive rows (cap = that plus slack, rounded up to 128)
-  int pf = cstile::kPfChunks;  // 16-byte prefetch chunks a lane the tile needs (8: a long-row tile of 64 rows up to 8 KB)
 };
 // `small`: also tiles of eight and four rows, also for rows beyond the sliding window (replace_re: its alternative is the
 // two-pass thread-per-row kernels; the scans' row-wise kernels beat such tiles: contains_re 1.9 against 4.6 ms, findall 27
 // against 64 ms on 520-byte rows)
-// `wide8k` (replace_re): long rows keep 64-row tiles while those fit 8 KB (eight prefetch chunks a lane: BASELINE's C5 column,
-// 64 rows of 95 bytes on average).  Halving the rows instead halves the work a wave has between publishing a tile's size
-// and needing its prefix -- the prefix then arrives late: 23 k of 38 k cycles per tile spent waiting on the C5 column
-// (profiles/r06/c5_phases.txt).
-TileChoice choose_tile(const cs_column* col, hipStream_t s, bool small = false, bool wide8k = false) {
+// (replace_re on 64-row tiles of up to 8 KB for long rows -- eight prefetch chunks a lane -- was built and measured in round 6:
+// 14.5 ms on the C5 column either way.  What such a column waits for is its tiles' PREFIXES, and twice the work per tile does
+// not shorten that; nor does drawing the tickets an iteration later (4.33 ms on C3, 14.7 on C5 either way): profiles/r06/prefix_latency.txt.)
+TileChoice choose_tile(const cs_column* col, hipStream_t s, bool small = false) {
   const int64_t longest = max_row_bytes(col, s);
   auto cap_of = [](int64_t span) { return (int64_t)((span + 15 + 32 + 127) & ~(int64_t)127); };
   const int64_t span64 = max_span64(col, s);
@@ -2735,7 +2733,6 @@ TileChoice choose_tile(const cs_column* col, hipStream_t s, bool small = false, 
   if (fits64 && longest + 3 <= cstd::Tdfa::kMaskBytes) return {64, (int)cap64, false, span64};
   if (longest > cstd::Tdfa::kLongBytes && (fits64 || !small)) return {fits64 ? 64 : 0, (int)cap64, false, span64};  // (such tiles scan generically)
   if (fits64) return {64, (int)cap64, true, span64};
-  if (wide8k && cap64 <= 8 * 1024 && !cs::cfg("CS_NO_WIDE_TILES")) return {64, (int)cap64, true, span64, 8};
   // (eight and four rows a tile: rows of hundreds of bytes -- few lanes of a wave hold a row then, but the rows still arrive
   // through coalesced tiles and are scanned in LDS; the thread-per-row kernels read them byte by byte from memory)
   for (int r : {32, 16, 8, 4}) {
@@ -3056,7 +3053,7 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
       const int64_t rows = col->rows;
       const int64_t ntiles = (rows + cstile::kTileRows - 1) / cstile::kTileRows;
       const int64_t nsub = ntiles * 4;
-      TileChoice tc = choose_tile(col, s, !cs::cfg("CS_NO_SMALL_TILES"), tp.d.in_lds && !wide_stream && !cs::g_backrefs_dev);
+      TileChoice tc = choose_tile(col, s, !cs::cfg("CS_NO_SMALL_TILES"));
       // (the column's largest 64-row span does not fit, all but a few do: buffers for those, the kernel handles the rest)
       bool outliers = false;
       constexpr int64_t kOutlierSpan = cstile::kPfBytes - 176;  // (its capacity is kPfBytes)
@@ -3242,11 +3239,6 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
         };
         auto kern = growth == 0 ? pick(std::true_type{}, std::false_type{})
                                 : roomy ? pick(std::false_type{}, std::true_type{}) : pick(std::false_type{}, std::false_type{});
-        if (tc.pf == 8) {  // (long rows, 64-row tiles of up to 8 KB: tables in LDS only -- choose_tile was told)
-          if (growth == 0) kern = rb > 8 ? &k_tdfa_replace_stream<true, true, true, false, true, false, 8> : &k_tdfa_replace_stream<true, false, true, false, true, false, 8>;
-          else if (roomy) kern = rb > 8 ? &k_tdfa_replace_stream<true, true, false, true, true, false, 8> : &k_tdfa_replace_stream<true, false, false, true, true, false, 8>;
-          else kern = rb > 8 ? &k_tdfa_replace_stream<true, true, false, false, true, false, 8> : &k_tdfa_replace_stream<true, false, false, false, true, false, 8>;
-        }
         if (outliers) {  // (the forms that handle oversize sub-tiles: in place, or with the rescan assembly)
           constexpr int P6 = cstile::kPfChunks;
           if (growth == 0) kern = rb > 8 ? &k_tdfa_replace_stream<true, true, true, false, false, false, P6, false, false, true>

@@ -357,7 +357,10 @@ struct Emit3Args {
 #ifndef CS_EMIT3_WAVES
 #define CS_EMIT3_WAVES 4
 #endif
-constexpr int kEmit3Threads = 128;  // two waves per workgroup: the LDS of a CU is shared out in finer grains
+#ifndef CS_EMIT_THREADS
+#define CS_EMIT_THREADS 128  // (192 -- three waves a workgroup, 15 waves a CU instead of 14 -- measured the same: 5.47 / 5.65 against 5.42 / 5.64 ms, A / B on one box)
+#endif
+constexpr int kEmit3Threads = CS_EMIT_THREADS;  // two waves per workgroup: the LDS of a CU is shared out in finer grains
 constexpr int kEmit4TableBytes = 1024 + 128 + 128;  // the flush tables of k_split_emit4 (in the in tile once the column loop is over)
 constexpr int kEmit4MaxOut = 16 * 1024;             // bytes of its out tile (32 words of chunk bits)
 // PLAIN: a one-byte delimiter without a split limit on rows of at most 92 bytes -- the token walk then runs on three
@@ -602,8 +605,22 @@ __global__ void __launch_bounds__(kEmit3Threads, W > 3 ? 3 : CS_EMIT3_WAVES) k_s
       const unsigned long long vB = __ballot(hasB);
       const int lenA = hasA ? hiA - loA : 0, lenB = hasB ? hiB - loB : 0;
       // both tokens' first sixteen bytes and tail masks (a lane without a token reads its row's start and masks it all)
+#if defined(CS_EMIT_ALIGNED_TOKENS)
+      // (measurement, round 5 and again round 6 with non-temporal stores: the token as five aligned dwords and four funnel
+      // shifts instead of one 16-byte read at its own address, which the LDS replays a lane at a time)
+      auto read_token = [&](int lo) -> cstile::u32x4 {
+        const int at = lead + rbeg + lo;
+        const uint32_t* w = reinterpret_cast<const uint32_t*>(lds_in + (at & ~3));
+        const unsigned sh = (unsigned)at & 3u;
+        const uint32_t w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3], w4 = w[4];
+        return cstile::u32x4{__builtin_amdgcn_alignbyte(w1, w0, sh), __builtin_amdgcn_alignbyte(w2, w1, sh), __builtin_amdgcn_alignbyte(w3, w2, sh),
+                             __builtin_amdgcn_alignbyte(w4, w3, sh)};
+      };
+      const cstile::u32x4 rA = read_token(hasA ? loA : 0), rB = read_token(hasB ? loB : 0);
+#else
       const cstile::lds_u32x4u rA = *reinterpret_cast<const cstile::lds_u32x4u*>(tok_src + (hasA ? loA : 0));
       const cstile::lds_u32x4u rB = *reinterpret_cast<const cstile::lds_u32x4u*>(tok_src + (hasB ? loB : 0));
+#endif
       const cstile::u32x4 mA = tail[min(lenA, 16)], mB = tail[min(lenB, 16)];
       uint32_t a_lo, a_hi, a_pos, b_lo, b_hi, b_pos;
       const int incl = scan_pair(lenA | (lenB << 16), k, coff_lo, coff_hi, (uint32_t)c_pos, a_lo, a_hi, a_pos, b_lo, b_hi, b_pos);

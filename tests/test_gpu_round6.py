@@ -345,10 +345,9 @@ def test_gpu_regex_with_the_dfa_tables_in_memory(pat, repl, monkeypatch):
 
 
 @pytest.mark.parametrize("pat,repl", [(IPV4, "<IP>"), (r"#\w+", "<tag>"), (r"\w+@\w+", "<m>"), (r"(\bin\b)|(\ba\b)|(\bthe\b)", "="), (r"\d", "##"), (r"[a-z]+ing\b", "")])
-def test_gpu_replace_re_long_rows_on_64_row_tiles(pat, repl, monkeypatch):
-    """replace_re on rows of 94-188 bytes: the long-row form of the stream kernel on 64-row tiles of up to 8 KB (eight prefetch
-    chunks a lane) -- until round 6 such a column took 32-row tiles, whose waves wait for their tile's prefix most of the time
-    (profiles/r06/c5_phases.txt).  Against the oracle, and the 32-row tiles (CS_NO_WIDE_TILES) give the same."""
+def test_gpu_replace_re_on_rows_of_94_to_188_bytes(pat, repl):
+    """replace_re on rows beyond the 96-bit masks (BASELINE's C5 lengths; the stream kernel's long-row form on tiles of 32 rows),
+    sparse and dense patterns, growing and shrinking replacements, against the oracle -- and no launch gives up."""
     L = gpuutil.lib()
     orc = cpulibs.Oracle()
     blob = blob_of(pat)
@@ -358,12 +357,6 @@ def test_gpu_replace_re_long_rows_on_64_row_tiles(pat, repl, monkeypatch):
     for g, o, what in cases:
         if g is None:
             g = gpuutil.from_col(o)
-        want = orc.replace_re(o, blob, repl)
         f0 = int(L.lib.cs_fallback_count())
-        gpuutil.assert_same(g.replace(pat, repl), want, "replace_re(%r) on %s" % (pat, what))
-        L.check(L.lib.cs_config_set(b"CS_NO_WIDE_TILES", b"1"))
-        try:
-            gpuutil.assert_same(g.replace(pat, repl), want, "replace_re(%r) on %s, 32-row tiles" % (pat, what))
-        finally:
-            L.check(L.lib.cs_config_set(b"CS_NO_WIDE_TILES", None))
+        gpuutil.assert_same(g.replace(pat, repl), orc.replace_re(o, blob, repl), "replace_re(%r) on %s" % (pat, what))
         assert int(L.lib.cs_fallback_count()) == f0, "a single-pass kernel gave up"
