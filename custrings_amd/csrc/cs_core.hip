@@ -67,6 +67,17 @@ void require_device() {
 int bound_device() { return g_device; }
 thread_local const char* g_last_route = "";
 void note_route(const char* route) { g_last_route = route; }
+// the op ran on the column's pieces (cs_virtual.hip): the inner launch's route under a "pieces:" prefix
+void note_route_pieces() {
+  static const char* const names[][2] = {{"bits", "pieces:bits"}, {"chain", "pieces:chain"}, {"units", "pieces:units"}, {"plain", "pieces:plain"},
+                                         {"literal", "pieces:literal"}, {"wide", "pieces:wide"}, {"runs", "pieces:runs"}, {"", "pieces:"}};
+  for (const auto& n : names)
+    if (std::strcmp(g_last_route, n[0]) == 0) {
+      g_last_route = n[1];
+      return;
+    }
+  g_last_route = "pieces:other";
+}
 void note_fallback(const char* what) {
   if (g_fallbacks.fetch_add(1) == 0 || cs::cfg("CS_LOG_FALLBACKS"))
     fprintf(stderr, "custrings_amd: %s: the single-pass kernel gave up, recomputing with the two-pass kernels\n", what);

@@ -55,6 +55,7 @@ int bound_device();  // -1 before cs_init
 // kernel gave up and the host recomputed the column with the two-pass kernels.
 void note_fallback(const char* what);
 void note_route(const char* route);  // cs_debug_last_route (per thread)
+void note_route_pieces();             // ... of an op that ran on the column's pieces (cs_virtual.hip)
 
 // ---- device memory ----------------------------------------------------------
 // Buffers come from a size-bucketed cache over hipMalloc (one output allocation
@@ -88,6 +89,9 @@ const uint16_t* h_charcases();
 
 }  // namespace cs
 
+namespace cs {
+struct VirtualRows;  // cs_virtual.hip: the column's rows cut into pieces of at most 92 bytes (a second column over the same chars)
+}
 // ---- the column ---------------------------------------------------------------
 struct cs_column {
   int64_t rows = 0;
@@ -99,6 +103,8 @@ struct cs_column {
   mutable int plain_bytes = -1;     // 1: no NUL byte and no lead byte announcing over an ASCII byte; -1 = unknown
   mutable int high_sample = -1;     // 1: a sample of the chars (three 64 KiB windows) holds a byte >= 0x80; -1 = not looked at
   mutable std::shared_ptr<std::array<uint32_t, 256>> byte_hist;  // byte counts of the same sample (a hint for kernel choice); null = not taken
+  mutable std::shared_ptr<cs::VirtualRows> virt;  // the view of a long-row column as pieces (built on first use; cs_virtual.hip)
+  mutable int virt_state = 0;                     // 0: not looked at, 1: `virt` holds it, -1: the column has none
   cs::Buf chars, validity;  // validity may be null (all valid)
   // Row extents: int64 offsets (`offsets`) and / or int32 offsets (`offsets32`, columns whose
   // chars stay below 2 GiB -- what split produces: half the bytes written per output row).  A
@@ -191,6 +197,16 @@ csrow::CharSet make_charset(const char* s, Buf& more, hipStream_t st);
 // Row-wise concatenation of columns into one new column.
 cs_column* concat_columns(const std::vector<const cs_column*>& cols, hipStream_t s);
 
+// cs_virtual.hip: a long-row column as a column of pieces that fit the 96-bit masks
+struct VirtualRows {
+  std::unique_ptr<cs_column> col;  // the pieces: the same chars buffer, offsets of their own
+  Buf first;                       // int64[rows + 1]: row r's pieces are first[r] .. first[r + 1] - 1
+};
+const VirtualRows* virtual_rows(const cs_column* col, hipStream_t s);
+int virtual_piece_bytes();
+int64_t virtual_reduce_u8(const VirtualRows* vr, const uint8_t* piece_res, int64_t rows, uint8_t* out, hipStream_t s);
+int64_t virtual_reduce_i32(const VirtualRows* vr, const int32_t* piece_res, int64_t rows, int32_t* out, hipStream_t s);
+cs_column* virtual_rows_to_rows(const cs_column* col, const VirtualRows* vr, std::unique_ptr<cs_column> pieces_out, hipStream_t s);
 // cs_radix.hip: stable LSD radix sort of n (64-bit key, 32-bit item) pairs by key, ascending, in place (synchronises `s`)
 void radix_sort_pairs64(uint64_t* keys, int32_t* items, int64_t n, hipStream_t s);
 // cs_category.hip: keys = sorted unique rows (null first), values[r] = index of row r's key

@@ -2744,12 +2744,55 @@ TileChoice choose_tile(const cs_column* col, hipStream_t s, bool small = false) 
   return {0, (int)cap64, false, span64};
 }
 
+// A column with rows beyond the 96-bit masks, a program for which white space is a safe cut (regex_tdfa.cpp, header word 31
+// bit 25): the op runs on the column's PIECES (cs_virtual.hip) -- chain arithmetic, bit form, unit scan as on short rows --
+// and the rows' results follow from the pieces'.
+// Not for a single class, once or in a `+` loop (cs_runs.hip takes rows of any length byte-parallel: count_re([aeiou]+) on the
+// C5 column 3.0 ms there, 5.6 on the pieces), and not -- `replacing` -- for a program that would take the unit scan on a column
+// whose sample holds bytes >= 0x80: the unit route hands every sub-tile with such a byte to the row-by-row scan, and more,
+// shorter rows make that worse (replace_re of the gtest pattern on C5: 40 ms on the pieces, 30 on the long-row form).
+const VirtualRows* pieces_for(const cs_column* col, const cs_regex* re, hipStream_t s, bool replacing) {
+  if (cs::cfg("CS_NO_VIRTUAL_ROWS") || col->virt_state < 0 || !use_tdfa(re) || !((re->tdfa[31] >> 25) & 1)) return nullptr;
+  if (max_row_bytes(col, s) + 3 <= cstd::Tdfa::kMaskBytes) return nullptr;  // (the masks hold the rows as they are)
+  if (!re->bits.empty() && (re->bits[2] & (csbits::F_BYTE_CLASS | csbits::F_FLAG_CLASS)) && !cs::cfg("CS_NO_CLASS_RUNS")) return nullptr;
+  const bool chain = ((re->tdfa[30] >> 16) & 15) != 0;
+  if (replacing && (re->tdfa[31] & 1) && !chain && sample_has_high_bytes(col, s)) return nullptr;
+  // The executor ends a row's scan at a NUL byte and takes a character's width from its lead byte (an ASCII byte behind a
+  // lead without its continuation bytes is swallowed -- a cut byte too): a piece behind such a byte would be scanned where
+  // the row is not.  Columns of well-formed text only (`plain_bytes`: column metadata, one pass when nobody has looked yet).
+  if (!bytes_plain(col, s)) return nullptr;
+  return virtual_rows(col, s);
+}
+
 template <int MODE>
 void scan(const cs_column* col, cs_regex* re, uint8_t* out8, int32_t* out32, int on_device, hipStream_t s,
           int64_t* found, const char* name) {
   if (found) *found = 0;
   note_route("");
   if (col->rows == 0) return;
+  if (MODE == 0 || MODE == 2) {
+    if (const VirtualRows* vr = pieces_for(col, re, s, false)) {
+      const cs_column* pc = vr->col.get();
+      const size_t esz1 = MODE == 2 ? 4 : 1;
+      Buf piece_res = dev_alloc(esz1 * (size_t)pc->rows, s);
+      scan<MODE>(pc, re, MODE == 0 ? ptr<uint8_t>(piece_res) : nullptr, MODE == 2 ? ptr<int32_t>(piece_res) : nullptr, 1, s, nullptr, name);
+      note_route_pieces();
+      Buf row_res;
+      void* dst = MODE == 2 ? (void*)out32 : (void*)out8;
+      if (!on_device) {
+        row_res = dev_alloc(esz1 * (size_t)col->rows, s);
+        dst = row_res->p;
+      }
+      const int64_t hits = MODE == 2 ? virtual_reduce_i32(vr, ptr<const int32_t>(piece_res), col->rows, static_cast<int32_t*>(dst), s)
+                                     : virtual_reduce_u8(vr, ptr<const uint8_t>(piece_res), col->rows, static_cast<uint8_t*>(dst), s);
+      if (!on_device) {
+        CS_HIP(hipMemcpyAsync(MODE == 2 ? (void*)out32 : (void*)out8, row_res->p, esz1 * (size_t)col->rows, hipMemcpyDeviceToHost, s));
+        CS_HIP(hipStreamSynchronize(s));
+      }
+      if (found) *found = hits;
+      return;
+    }
+  }
   const bool wide = use_tdfa_wide(re);  // (five to eight live threads: TdfaWide on the same kernels' generic row path)
   const bool tdfa = use_tdfa(re) || wide;
   Plan pl{};
@@ -3007,6 +3050,17 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
     TPlan tp{};
     if (tdfa || wide) tp = tplan(re, col->rows, s);
     else pl = plan(re, col->rows, s);
+    // rows beyond the 96-bit masks, white space a safe cut for this program: the pieces' replace_re is the rows' (cs_virtual.hip)
+    if (!cs::g_backrefs_dev && !cs::g_replace_plain_only && maxrepl < 0 && tdfa && !cs::cfg("CS_CLASS_RUNS_ALWAYS")) {
+      if (const VirtualRows* vr = pieces_for(col, re, s, true)) {
+        cs_column* po = nullptr;
+        const int rc = cs_replace_re(vr->col.get(), cre, repl, maxrepl, stream, &po);
+        if (rc != 0) fail(rc, cs_last_error());
+        note_route_pieces();
+        *out = virtual_rows_to_rows(col, vr, std::unique_ptr<cs_column>(po), s);
+        return;
+      }
+    }
     // One character class, once or in a `+` loop, on a column the 96-bit-mask forms do not take -- rows beyond 93 bytes,
     // tiles of fewer than 64 rows, non-ASCII text -- and whose candidates are everywhere: byte-parallel stream compaction
     // (cs_runs.hip; BASELINE.json C5: replace_re([aeiou]+) on 40-150-byte rows, 82.8 ms on the long-row automaton forms).

@@ -570,6 +570,37 @@ std::vector<int32_t> build_tdfa(const Program& prog, const std::vector<int32_t>&
         }
       }
     }
+    // bit 25: the bytes a column's VIRTUAL ROWS are cut behind -- space, tab, LF, CR (cs_virtual.hip: a long row cut into
+    // pieces of at most 92 bytes so that the kernels on 96-bit masks take it) -- are SAFE CUTS for this program: whatever
+    // state consumes one, nothing is kept, the automaton does not stop, and the idle state it lands in behaves exactly as
+    // the start of a row does (the same row of byte transitions and of end-of-text / assertion atoms: a program with `^`
+    // or a `\b` that tells a row's start from "behind a space" fails here).  A match can then neither span a cut nor tell
+    // the piece from the row, so an op on the pieces is the op on the rows.
+    if (nskip > 0 && maxslots <= 4 && B.min_match_chars() >= 1) {
+      const uint32_t a0 = init[cstd::MODE_RESTART * 8 + 4];  // the start of a row
+      auto same_rows = [&](uint32_t u, uint32_t v) {
+        if (u == v) return true;
+        for (int c = 0; c < 128; ++c)
+          if (T1[(size_t)u * 128 + c] != T1[(size_t)v * 128 + c]) return false;
+        for (int k = 0; k < natoms; ++k)
+          if (T2[(size_t)u * natoms + k] != T2[(size_t)v * natoms + k]) return false;
+        return true;
+      };
+      bool safe = a0 < nskip;
+      for (int c : {9, 10, 13, 32}) {
+        // (1) a killer: whichever state consumes it, nothing is kept; the scan stops (the seeded / no-restart states: a later
+        // seed starts from an init state again) or lands in an idle state that behaves as the start of a row does
+        for (int st = 0; st < nstates && safe; ++st) {
+          const uint32_t e = T1[(size_t)st * 128 + c];
+          safe = !(e & cstd::E_COMPLEX) && cstd::e_keep(e) == 15u && ((e & cstd::E_STOP) || ((e & cstd::E_STATE) < nskip && same_rows(e & cstd::E_STATE, a0)));
+        }
+        // (2) a scan seeded right behind it starts as one seeded at a row's first byte does (regex_tdfa.h: prev_cat -- category
+        // 4 is the row's start, a space's is 0, a line feed's 2), in every mode
+        const int k = c == 10 ? 2 : 0;
+        for (int m = 0; m < 3 && safe; ++m) safe = same_rows(init[m * 8 + k], init[m * 8 + 4]);
+      }
+      if (safe) word |= 1 << 25;
+    }
     img[31] = word;
     // The CHAIN form (regex_tdfa.h: chain_match), offered beside the unit decomposition: the program is a straight line
     // of single-character items -- a literal or a class, taken once, in a greedy `+` loop or a counted number of times

@@ -360,3 +360,80 @@ def test_gpu_replace_re_on_rows_of_94_to_188_bytes(pat, repl):
         f0 = int(L.lib.cs_fallback_count())
         gpuutil.assert_same(g.replace(pat, repl), orc.replace_re(o, blob, repl), "replace_re(%r) on %s" % (pat, what))
         assert int(L.lib.cs_fallback_count()) == f0, "a single-pass kernel gave up"
+
+
+# ---- rows beyond the masks as PIECES (cs_virtual.hip) -----------------------------------------------------------------------------
+
+# (pattern, replacement, does replace_re take the pieces too?  None: not asserted -- a program that would take the unit scan stays
+# on the long-row form when the column's sample holds bytes >= 0x80: cs_regex.hip, pieces_for)
+PIECE_PATTERNS = [(IPV4, "<IP>", True), (r"(\bin\b)|(\ba\b)|(\bthe\b)", "=", None), (r"\w+@\w+", "<m>", None), (r"#\w+", "<a-longer-tag>", True),
+                  (r"\b\d{1,3}\.\d{1,3}\.\d{1,3}\.\d{1,3}\b", "", True), (r"\d+$", "N", None), (r"[a-z]+ing\b", "ING", None), (r"GET|POST|the", "V", True)]
+
+
+@pytest.mark.parametrize("pat,repl,replace_on_pieces", PIECE_PATTERNS)
+def test_gpu_regex_on_long_rows_as_pieces(pat, repl, replace_on_pieces):
+    """A column with rows beyond 93 bytes, a program for which white space is a safe cut (regex_tdfa.cpp: header word 31 bit 25):
+    contains_re / count_re / replace_re run on the column's PIECES -- every long row cut behind a space / tab / LF / CR into
+    pieces of at most 92 bytes, a second column over the same chars -- on the kernels of short rows, and the rows' results
+    follow from the pieces'.  Against the oracle on the ROWS: BASELINE's C5 column, random long rows with nulls and non-ASCII
+    words, rows of tabs and line feeds, a row whose only cut byte sits at the 92nd position."""
+    L = gpuutil.lib()
+    orc = cpulibs.Oracle()
+    blob = blob_of(pat)
+    rng = np.random.default_rng(9200)
+    # (well-formed text: a row cut inside a character would leave a lead byte in front of the next row's first byte, and such a
+    # column -- like one with NUL bytes -- keeps the long-row kernels: test_gpu_regex_on_long_rows_not_as_pieces)
+    rows_b = [r.decode("utf-8", "ignore").encode() for r in _random_rows(rng, 20_000, 40, 220, alphabet=b"abcdefghijklmnop0123456789.-_/#@ing the a in")]
+    rows_b += [b"1.2.3.4 " * 30, b"x" * 91 + b" " + b"y" * 92, b"a\tb\nc\rd " * 25, b" " * 200, b"the in a " * 40, b"#tag@mail.com\n" * 20, b"", b"short"]
+    cases = [(gpuutil.synth(5, 0, 120_000), orc.synth(5, 0, 120_000), "C5"), (None, _with_nulls(rows_b, rng), "random long rows")]
+    for g, o, what in cases:
+        if g is None:
+            g = gpuutil.from_col(o)
+        f0 = int(L.lib.cs_fallback_count())
+        got = g.replace(pat, repl)
+        if replace_on_pieces:
+            assert last_route().startswith("pieces:"), (what, last_route())
+        gpuutil.assert_same(got, orc.replace_re(o, blob, repl), "replace_re(%r) on %s" % (pat, what))
+        re = gpuutil.compile_re(pat)
+        try:
+            has, n = gpuutil.bools(g, "cs_contains_re", re)
+            assert last_route().startswith("pieces:"), (what, last_route())
+            want_has, want_n = orc.contains_re(o, blob)
+            assert np.array_equal(has, want_has) and n == want_n, what
+            cnt = np.zeros(o.rows, dtype=np.int32)
+            found = C.c_int64()
+            L.check(L.lib.cs_count_re(g.m_cptr, re, cnt.ctypes.data, 0, None, C.byref(found)))
+            want_cnt, want_found = orc.count_re(o, blob)
+            assert np.array_equal(cnt, want_cnt), (what, np.flatnonzero(cnt != want_cnt)[:5])
+            assert found.value == want_found
+        finally:
+            L.lib.cs_regex_destroy(re)
+        assert int(L.lib.cs_fallback_count()) == f0
+
+
+@pytest.mark.parametrize("pat,repl", [(r"^\d+", "N"), (r"\s+", " "), (r"(\d+) (\d+)", "x"), (r"[^a]+", "-"), (r"\w+\s\w+", "2")])
+def test_gpu_regex_on_long_rows_not_as_pieces(pat, repl):
+    """Programs that can tell a piece from a row -- `^`, white space inside a match, a class that holds it -- and a column with a
+    92-byte stretch without white space keep the long-row kernels; same answers as the oracle."""
+    orc = cpulibs.Oracle()
+    blob = blob_of(pat)
+    g, o = gpuutil.synth(5, 0, 60_000), orc.synth(5, 0, 60_000)
+    gpuutil.assert_same(g.replace(pat, repl), orc.replace_re(o, blob, repl), "replace_re(%r)" % pat)
+    assert not last_route().startswith("pieces:"), last_route()
+    rng = np.random.default_rng(9201)
+    plain = [r.decode("utf-8", "ignore").encode() for r in _random_rows(rng, 5000, 40, 150)]
+    for extra, why in (([b"z" * 150], "a stretch of 92 bytes without white space"), ([b"a b\x00c d " * 12], "a NUL byte: the executor ends the row's scan there"),
+                       ([b"word \xc3 word " * 10], "a lead byte in front of a space: the executor swallows the space")):
+        col = col_of(plain + extra)
+        g2 = gpuutil.from_col(col)
+        got = g2.replace(IPV4, "<IP>")
+        assert not last_route().startswith("pieces:"), (why, last_route())
+        L = gpuutil.lib()
+        for v in ("CS_REGEX_ROWWISE", "CS_REGEX_TWO_PASS"):
+            L.check(L.lib.cs_config_set(v.encode(), b"1"))
+        try:
+            want = gpuutil.to_col(g2.replace(IPV4, "<IP>"))
+        finally:
+            for v in ("CS_REGEX_ROWWISE", "CS_REGEX_TWO_PASS"):
+                L.check(L.lib.cs_config_set(v.encode(), None))
+        gpuutil.assert_same(got, want, "a column without a view (%s): against the row-wise kernels" % why)

@@ -22,13 +22,16 @@ def t(name, fn, n=2):
     r = fn()
     del r
     torch.cuda.synchronize()
+    m0 = int(_lib.lib.cs_debug_malloc_count())
     t0 = time.perf_counter()
     for _ in range(n):
         r = fn()
         del r
     torch.cuda.synchronize()
-    print("%-58s %8.2f ms  route %-12s fallbacks %d" % (name, (time.perf_counter() - t0) / n * 1e3, _lib.lib.cs_debug_last_route().decode() or "-",
-                                                       int(_lib.lib.cs_fallback_count()) - f0), flush=True)
+    # (mallocs: hipMalloc calls inside the timed calls -- the pool missed; idle: GB the pool holds afterwards)
+    print("%-58s %8.2f ms  route %-16s fallbacks %d  mallocs %d  idle %.0f GB" % (name, (time.perf_counter() - t0) / n * 1e3, _lib.lib.cs_debug_last_route().decode() or "-",
+                                                       int(_lib.lib.cs_fallback_count()) - f0, int(_lib.lib.cs_debug_malloc_count()) - m0,
+                                                       int(_lib.lib.cs_pool_cached_bytes()) / 1e9), flush=True)
 
 
 for pat, repl in ((r"\d+", "#"), (r"\d+", "<number>"), (r"\d", "##"), (r"[a-z]+", "w"), (r"\s+", " "), (r" ", "  "), (r"GET|POST", "VERB"), (r"HTTP/1\.[01]", "H"),

@@ -37,6 +37,35 @@ def main():
     for name, kind, rows in (("c5", 5, c5_rows), ("c3", 3, c3_rows)):
         col = B.synth(kind, rows)
         nb = B.nbytes(col)
+        if kind == 5:  # the FIRST regex op on a fresh long-row column also builds the column's pieces (cs_virtual.hip), once
+            re0 = nvstrings._compile(IPV4)
+            tmp = torch.empty(rows, dtype=torch.uint8, device="cuda")
+            f = C.c_int64()
+            for attempt, what in ((0, "cold pool"), (1, "warm pool: a second fresh column")):
+                if attempt:
+                    col = None
+                    out2 = C.c_void_p()
+                    _lib.check(L.cs_synth_column(kind, 0, rows, B.SEED + 7, 0, None, C.byref(out2)))
+                    col = nvstrings.nvstrings(out2.value)
+                L.cs_prof_reset()
+                L.cs_prof_enable(1)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                _lib.check(L.cs_contains_re(col.m_cptr, re0, C.c_void_p(tmp.data_ptr()), 1, None, C.byref(f)))
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+                L.cs_prof_enable(0)
+                ks = {}
+                for k in ("k_virt_count", "k_virt_write", "k_contains_re"):
+                    ms, n = C.c_double(), C.c_int64()
+                    L.cs_prof_get(k.encode(), C.byref(ms), C.byref(n))
+                    if n.value:
+                        ks[k] = round(ms.value / n.value, 3)
+                print(json.dumps({"config": name, "op": "contains_re, FIRST regex op on a fresh column (builds its pieces), " + what, "pattern": "ipv4", "rows": rows,
+                                  "ms": round(dt * 1e3, 3), "kernels_ms": ks, "route": L.cs_debug_last_route().decode()}), flush=True)
+            L.cs_regex_destroy(re0)
+            del tmp
+            nb = B.nbytes(col)
         import numpy as np
 
         res = torch.empty(rows, dtype=torch.uint8, device="cuda")
