@@ -2713,6 +2713,26 @@ Plan plan(cs_regex* re, int64_t rows, hipStream_t s) {
 // Rows per tile and staging capacity for the stream kernels: 64 rows when their widest span fits
 // the prefetch registers and no row outgrows the 96-byte candidate masks; otherwise the long-row
 // variants (rows up to 255 bytes) with 64, 32 or 16 rows per tile.  R == 0: no stream kernel.
+// matches per tile of R rows out of count_re's per-row counts: the column's total and the busiest tile's (replace_re with a
+// growing replacement sizes its out tile and its output from them instead of provisioning for the worst case)
+__global__ void __launch_bounds__(256) k_match_stats(const int32_t* __restrict__ counts, int64_t rows, int R, unsigned long long* __restrict__ total, unsigned* __restrict__ tilemax) {
+  const int lane = threadIdx.x & 63;
+  const int64_t ntiles = (rows + R - 1) / R;
+  unsigned long long sum = 0;
+  unsigned most = 0;
+  for (int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); t < ntiles; t += (int64_t)gridDim.x * 4) {
+    const int64_t r = t * R + lane;
+    const int c = lane < R && r < rows ? max(counts[r], 0) : 0;
+    const int ts = wave_reduce_sum(c);
+    sum += (unsigned)ts;
+    most = max(most, (unsigned)ts);
+  }
+  if (lane == 0) {
+    if (sum) atomicAdd(total, sum);
+    if (most > __hip_atomic_load(tilemax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(tilemax, most);
+  }
+}
+
 struct TileChoice {
   int R, cap;
   bool lng;
@@ -3121,6 +3141,7 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
       size_t lds = tbl + (size_t)(cap + cap + 64 + (cap >> 3) + 32) * 4 + 16;
       // persistent stream kernel (grid = what is resident at once); returns its error word, or -1
       // when the sizing does not fit
+      int64_t sized_total = -1, sized_tilemax = 0;  // matches in the column / in its busiest tile, when they were counted first
       auto stream_attempt = [&](bool roomy) -> int {
         // (a DFA whose tables do not fit the LDS budget: the two-pass kernels read them from memory)
         if (!tp.d.in_lds) return -1;
@@ -3130,7 +3151,12 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
         // 54 496 bytes of LDS ran two workgroups per CU where 54 240 run three)
         if (growth == 0 && !outliers) cap_out = (int)std::min<int64_t>(cap, (tc.span + 15 + 32 + 15) & ~(int64_t)15);
         int64_t extra = std::min<int64_t>(few, col->nbytes + (1ll << 30));
-        if (roomy) {
+        if (roomy && sized_total >= 0) {
+          // (the matches were counted first: the busiest tile's growth and the column's, exactly)
+          const int64_t span_room = std::min<int64_t>(cap, (tc.span + 15 + 32 + 15) & ~(int64_t)15);
+          cap_out = (int)((span_room + sized_tilemax * growth + 127) & ~(int64_t)127);
+          extra = sized_total * growth + 64;
+        } else if (roomy) {
           const int64_t worst = ((int64_t)cap * rb + minlen_p - 1) / minlen_p;
           cap_out = std::max(cap_out, (int)((std::min<int64_t>(worst, 3ll * cap) + 127) & ~(int64_t)127));
           const int64_t worst_extra = (col->nbytes * growth + minlen_p - 1) / minlen_p;
@@ -3427,6 +3453,25 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
                                candidate_share(re, col, s) * ((double)col->nbytes / (double)col->rows) <= (double)(kMaxRec - 1);
       if (lds <= 150 * 1024 && (rb <= 16 || (rb <= kMaxStreamRepl && rb <= 4 * minlen) || few_matches) && tc.R) {
         const bool roomy_first = growth > 0 && (minlen <= 2 || wide_stream || outliers || cs::cfg("CS_REPLACE_ROOMY"));
+        // A growing replacement for a pattern of one or two bytes (`\d+` -> '<number>', `\d` -> '##'): provisioned for the worst
+        // case the out tile is three times the in tile -- two workgroups a CU -- and the output twice the column (18 ms on the
+        // C3 column where `\d+` -> '#' takes 5.9).  count_re first (2.4 ms) says how many matches the column and its busiest
+        // tile hold: the out tile and the output are sized exactly: 17.9 -> 12.1 ms.
+        // (where the worst case is within three times the in tile anyway -- `\d` -> '##' -- the count only costs: 15.6 -> 17.9 ms)
+        if (roomy_first && rb >= 3 * minlen_p && tdfa && !wide_stream && !outliers && !cs::g_backrefs_dev && !cs::g_replace_plain_only && maxrepl < 0 && !empties && tp.d.in_lds &&
+            !cs::cfg("CS_NO_COUNT_SIZING")) {
+          Buf counts = dev_alloc(sizeof(int32_t) * (size_t)rows, s), stats = dev_alloc(16, s);
+          scan<2>(col, re, nullptr, ptr<int32_t>(counts), 1, s, nullptr, "k_count_re");
+          CS_HIP(hipMemsetAsync(stats->p, 0, 16, s));
+          hipLaunchKernelGGL(k_match_stats, dim3(1024), dim3(256), 0, s, ptr<const int32_t>(counts), rows, tc.R, ptr<unsigned long long>(stats), reinterpret_cast<unsigned*>(ptr<unsigned long long>(stats) + 1));
+          CS_HIP(hipGetLastError());
+          unsigned long long* h = (unsigned long long*)pinned_scratch(16);
+          CS_HIP(hipMemcpyAsync(h, stats->p, 16, hipMemcpyDeviceToHost, s));
+          CS_HIP(hipStreamSynchronize(s));
+          sized_total = (int64_t)h[0];
+          sized_tilemax = (int64_t)(unsigned)h[1];
+          note_route("");
+        }
         int err = stream_attempt(roomy_first);
         if (err == 2 && !roomy_first) err = stream_attempt(true);  // only ran out of room: once more, roomier
         if (err == 0) return;

@@ -437,3 +437,23 @@ def test_gpu_regex_on_long_rows_not_as_pieces(pat, repl):
             for v in ("CS_REGEX_ROWWISE", "CS_REGEX_TWO_PASS"):
                 L.check(L.lib.cs_config_set(v.encode(), None))
         gpuutil.assert_same(got, want, "a column without a view (%s): against the row-wise kernels" % why)
+
+
+@pytest.mark.parametrize("pat,repl", [(r"\d+", "<number>"), (r"\d", "##"), (r" ", "  "), (r"[a-z]", "<x>"), (r"\.", "[dot]")])
+def test_gpu_growing_replacement_sized_from_count_re(pat, repl, monkeypatch):
+    """A replacement longer than a one- or two-byte match: count_re runs first and the stream kernel's out tile and output are
+    sized from the matches the column and its busiest tile hold (cs_regex.hip: k_match_stats) instead of the worst case
+    (three times the in tile, twice the column).  Same column as the oracle's, no launch given up; the worst-case sizing
+    (CS_NO_COUNT_SIZING) gives the same."""
+    L = gpuutil.lib()
+    orc = cpulibs.Oracle()
+    blob = blob_of(pat)
+    for kind, rows in ((3, 200_003), (2, 100_000)):
+        g, o = gpuutil.synth(kind, 0, rows), orc.synth(kind, 0, rows)
+        want = orc.replace_re(o, blob, repl)
+        f0 = int(L.lib.cs_fallback_count())
+        gpuutil.assert_same(g.replace(pat, repl), want, "replace_re(%r -> %r), sized from the count" % (pat, repl))
+        assert int(L.lib.cs_fallback_count()) == f0
+        monkeypatch.setenv("CS_NO_COUNT_SIZING", "1")
+        gpuutil.assert_same(g.replace(pat, repl), want, "replace_re(%r -> %r), worst-case sizing" % (pat, repl))
+        monkeypatch.delenv("CS_NO_COUNT_SIZING")
