@@ -457,3 +457,31 @@ def test_gpu_growing_replacement_sized_from_count_re(pat, repl, monkeypatch):
         monkeypatch.setenv("CS_NO_COUNT_SIZING", "1")
         gpuutil.assert_same(g.replace(pat, repl), want, "replace_re(%r -> %r), worst-case sizing" % (pat, repl))
         monkeypatch.delenv("CS_NO_COUNT_SIZING")
+
+
+@pytest.mark.parametrize("pat", [r"\w+@\w+", r"[a-z]+\.[a-z]+", r"\w+-\w+"])
+def test_gpu_contains_re_of_a_dense_unit_program_by_its_counts(pat, monkeypatch):
+    """contains_re of a program with a unit decomposition whose candidate bytes are most of the column runs count_re's unit scan
+    and turns the counts into flags (cs_regex.hip: scan<0>): flags and the number of rows that hold a match against the oracle,
+    null rows included, and the row lanes' scan (CS_NO_CONTAINS_BY_COUNT) says the same."""
+    orc = cpulibs.Oracle()
+    blob = blob_of(pat)
+    rng = np.random.default_rng(77)
+    rows_b = [bytes(rng.choice(list(b"abcdefghij  ..@-"), int(n)).astype(np.uint8)) for n in rng.integers(0, 91, 30_000)]
+    # (every fourth row with two-byte characters: the unit scan's tiles that hold bytes >= 0x80)
+    glyphs = list("abcdefgh  .@-") + ["\u00e9", "\u00fc", "\u0416"]
+    for i in range(0, len(rows_b), 4):
+        rows_b[i] = "".join(rng.choice(glyphs, int(rng.integers(0, 40)))).encode()
+    col = _with_nulls(rows_b, rng)
+    g = gpuutil.from_col(col)
+    re = gpuutil.compile_re(pat)
+    try:
+        has, n = gpuutil.bools(g, "cs_contains_re", re)
+        assert last_route() in (("units",) if "@" in pat else ("units", "bits", "plain")), last_route()
+        want, want_n = orc.contains_re(col, blob)
+        assert np.array_equal(has, want) and n == want_n
+        monkeypatch.setenv("CS_NO_CONTAINS_BY_COUNT", "1")
+        has2, n2 = gpuutil.bools(g, "cs_contains_re", re)
+        assert np.array_equal(has2, want) and n2 == want_n
+    finally:
+        gpuutil.lib().lib.cs_regex_destroy(re)
