@@ -68,15 +68,19 @@ int bound_device() { return g_device; }
 thread_local const char* g_last_route = "";
 void note_route(const char* route) { g_last_route = route; }
 // the op ran on the column's pieces (cs_virtual.hip): the inner launch's route under a "pieces:" prefix
+thread_local char g_route_text[64];
 void note_route_pieces() {
-  static const char* const names[][2] = {{"bits", "pieces:bits"}, {"chain", "pieces:chain"}, {"units", "pieces:units"}, {"plain", "pieces:plain"},
-                                         {"literal", "pieces:literal"}, {"wide", "pieces:wide"}, {"runs", "pieces:runs"}, {"", "pieces:"}};
-  for (const auto& n : names)
-    if (std::strcmp(g_last_route, n[0]) == 0) {
-      g_last_route = n[1];
-      return;
-    }
-  g_last_route = "pieces:other";
+  char inner[48];
+  snprintf(inner, sizeof inner, "%s", g_last_route);
+  snprintf(g_route_text, sizeof g_route_text, "pieces:%s", inner);
+  g_last_route = g_route_text;
+}
+// the scan put the rows with bytes >= 0x80 off to a second launch (cs_regex.hip: ScanStreamArgs::deferred)
+void note_route_put_off() {
+  char inner[48];
+  snprintf(inner, sizeof inner, "%s", g_last_route);
+  snprintf(g_route_text, sizeof g_route_text, "%s+later", inner);
+  g_last_route = g_route_text;
 }
 void note_fallback(const char* what) {
   if (g_fallbacks.fetch_add(1) == 0 || cs::cfg("CS_LOG_FALLBACKS"))

@@ -55,6 +55,7 @@ int bound_device();  // -1 before cs_init
 // kernel gave up and the host recomputed the column with the two-pass kernels.
 void note_fallback(const char* what);
 void note_route(const char* route);  // cs_debug_last_route (per thread)
+void note_route_put_off();            // ... of a scan that left its rows with bytes >= 0x80 to a second launch
 void note_route_pieces();             // ... of an op that ran on the column's pieces (cs_virtual.hip)
 
 // ---- device memory ----------------------------------------------------------

@@ -511,9 +511,8 @@ int cs_find(const cs_column* col, const char* str, int start, int end, int32_t* 
 // 2 compare, 3 startswith, 4 endswith; null rows: -2 for the positions, -1 for compare, false for the predicates.
 __global__ void k_find_family(ColView in, int op, const uint8_t* __restrict__ needle, int nb, int start, int end, const int32_t* __restrict__ starts,
                               const int32_t* __restrict__ ends, int32_t* __restrict__ out32, uint8_t* __restrict__ out8, unsigned long long* __restrict__ count) {
-  const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  int hit = 0;
-  if (r < in.rows) {
+  int hit = 0;  // (a capped grid, rows a grid apart: one addition to `count` per workgroup -- see k_find)
+  for (int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x; r < in.rows; r += (int64_t)gridDim.x * kBlock) {
     const bool valid = row_is_valid(in.validity, r);
     const int64_t b = in.offsets[r];
     const uint8_t* p = in.chars + b;
@@ -521,7 +520,7 @@ __global__ void k_find_family(ColView in, int op, const uint8_t* __restrict__ ne
     if (op == 0) {
       const int v = valid ? row_rfind_count(p, n, needle, nb, (unsigned)start, end - start) : -2;
       out32[r] = v;
-      hit = v != -1;
+      hit += v != -1;
     } else if (op == 1) {
       int v = -2;
       if (valid) {
@@ -529,15 +528,15 @@ __global__ void k_find_family(ColView in, int op, const uint8_t* __restrict__ ne
         v = row_find_count(p, n, needle, nb, (unsigned)pos, ends ? ends[r] - pos : -1);
       }
       out32[r] = v;
-      hit = v != -1;
+      hit += v != -1;
     } else if (op == 2) {
       const int v = valid ? row_compare(p, n, needle, nb) : -1;
       out32[r] = v;
-      hit = v == 0;
+      hit += v == 0;
     } else {
       const bool v = valid && (op == 3 ? row_starts_with(p, n, needle, nb) : row_ends_with(p, n, needle, nb));
       out8[r] = v ? 1 : 0;
-      hit = v;
+      hit += v;
     }
   }
   const long long t = block_reduce_sum(hit);
@@ -545,9 +544,8 @@ __global__ void k_find_family(ColView in, int op, const uint8_t* __restrict__ ne
 }
 // match_strings: equal rows (two nulls are equal); find_multiple: out[r * tcount + j] = position of target j in row r
 __global__ void k_match_strings(ColView a, ColView b, uint8_t* __restrict__ out, unsigned long long* __restrict__ count) {
-  const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   int hit = 0;
-  if (r < a.rows) {
+  for (int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x; r < a.rows; r += (int64_t)gridDim.x * kBlock) {
     const bool va = row_is_valid(a.validity, r), vb = row_is_valid(b.validity, r);
     bool same = va == vb;
     if (va && vb) {
@@ -555,7 +553,7 @@ __global__ void k_match_strings(ColView a, ColView b, uint8_t* __restrict__ out,
       same = row_compare(a.chars + oa, (int)(a.offsets[r + 1] - oa), b.chars + ob, (int)(b.offsets[r + 1] - ob)) == 0;
     }
     out[r] = same ? 1 : 0;
-    hit = same;
+    hit += same;
   }
   const long long t = block_reduce_sum(hit);
   if (threadIdx.x == 0 && t) atomicAdd(count, (unsigned long long)t);
@@ -572,8 +570,9 @@ __global__ void k_find_multiple(ColView in, ColView targets, int32_t* __restrict
   out[i] = v;
 }
 __global__ void k_count_not_minus_one(const int32_t* __restrict__ v, int64_t n, unsigned long long* __restrict__ count) {
-  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  const long long t = block_reduce_sum(i < n && v[i] != -1 ? 1 : 0);
+  int hit = 0;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) hit += v[i] != -1;
+  const long long t = block_reduce_sum(hit);
   if (threadIdx.x == 0 && t) atomicAdd(count, (unsigned long long)t);
 }
 // shared driver of the one-needle ops
@@ -602,7 +601,7 @@ static void find_family(const cs_column* col, int op, const char* str, int start
   }
   {
     ProfScope ps("k_find_family", s);
-    hipLaunchKernelGGL(k_find_family, dim3(blocks_for(rows)), dim3(kBlock), 0, s, view_of(col), op, nd.d(), nd.n, start, end, starts, ends,
+    hipLaunchKernelGGL(k_find_family, dim3(std::min(blocks_for(rows), 8192u)), dim3(kBlock), 0, s, view_of(col), op, nd.d(), nd.n, start, end, starts, ends,
                        bools ? nullptr : static_cast<int32_t*>(d_out), bools ? static_cast<uint8_t*>(d_out) : nullptr, ptr<unsigned long long>(cnt));
   }
   CS_HIP(hipGetLastError());
@@ -675,7 +674,7 @@ int cs_match_strings(const cs_column* col, const cs_column* other, uint8_t* resu
       tmp = dev_alloc((size_t)col->rows, s);
       d_out = ptr<uint8_t>(tmp);
     }
-    hipLaunchKernelGGL(k_match_strings, dim3(blocks_for(col->rows)), dim3(kBlock), 0, s, view_of(col), view_of(other), d_out, ptr<unsigned long long>(cnt));
+    hipLaunchKernelGGL(k_match_strings, dim3(std::min(blocks_for(col->rows), 8192u)), dim3(kBlock), 0, s, view_of(col), view_of(other), d_out, ptr<unsigned long long>(cnt));
     CS_HIP(hipGetLastError());
     if (!on_device) CS_HIP(hipMemcpyAsync(results, d_out, (size_t)col->rows, hipMemcpyDeviceToHost, s));
     const int64_t n = read_back<int64_t>(cnt, s);
@@ -699,7 +698,7 @@ int cs_find_multiple(const cs_column* col, const cs_column* targets, int32_t* re
       d_out = ptr<int32_t>(tmp);
     }
     hipLaunchKernelGGL(k_find_multiple, dim3(blocks_for(total)), dim3(kBlock), 0, s, view_of(col), view_of(targets), d_out);
-    hipLaunchKernelGGL(k_count_not_minus_one, dim3(blocks_for(col->rows)), dim3(kBlock), 0, s, d_out, col->rows, ptr<unsigned long long>(cnt));
+    hipLaunchKernelGGL(k_count_not_minus_one, dim3(std::min(blocks_for(col->rows), 8192u)), dim3(kBlock), 0, s, d_out, col->rows, ptr<unsigned long long>(cnt));
     CS_HIP(hipGetLastError());
     if (!on_device) CS_HIP(hipMemcpyAsync(results, d_out, sizeof(int32_t) * total, hipMemcpyDeviceToHost, s));
     const int64_t n = read_back<int64_t>(cnt, s);

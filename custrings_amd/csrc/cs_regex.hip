@@ -460,6 +460,29 @@ __global__ void __launch_bounds__(256) k_tdfa_scan(RowSrc src, TLaunch L, uint8_
   long long t = block_reduce_sum(hits);
   if (threadIdx.x == 0 && t) atomicAdd(found, (unsigned long long)t);
 }
+// the rows a stream launch put off (ScanStreamArgs::deferred): a thread a row, the generic executor on the row's bytes in memory
+template <int MODE>
+__global__ void __launch_bounds__(256) k_tdfa_scan_list(RowSrc src, TLaunch L, const int32_t* __restrict__ list, const unsigned* __restrict__ nlist, unsigned cap,
+                                                        uint8_t* __restrict__ out8, int32_t* __restrict__ out32, unsigned long long* __restrict__ found) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  const unsigned total = min(*nlist, cap);
+  if ((unsigned)blockIdx.x * 256u >= total) return;  // (nothing for this workgroup: not even the tables)
+  TCtx c = tsetup<true>(L, src.flags, smem);
+  const ColView& in = src.in;
+  int hits = 0;
+  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+    const int64_t r = list[i];
+    const int64_t b = in.offsets[r];
+    cstd::Tdfa vm(c.D, c.P, in.chars + b, (int)(in.offsets[r + 1] - b));
+    vm.wide_ok = (b & ~(int64_t)3) + cstd::Tdfa::kMaskBytes <= src.safe_end;
+    const int v = MODE == 2 ? csvm::row_count_re(vm) : csvm::row_contains_re(vm, false);
+    if (MODE == 2) out32[r] = v;
+    else out8[r] = (uint8_t)v;
+    hits += v > 0;
+  }
+  const long long t = block_reduce_sum(hits);
+  if (threadIdx.x == 0 && t) atomicAdd(found, (unsigned long long)t);
+}
 template <bool IN_LDS, bool WIDE = false>
 __global__ void __launch_bounds__(256) k_tdfa_replace_size(RowSrc src, TLaunch L, int rb, int maxrepl,
                                                            int32_t* __restrict__ lens) {
@@ -2079,6 +2102,12 @@ struct ScanStreamArgs {
   // BITS: the bit-parallel form of the pattern (regex_bits.h), staged at byte offset bits_off of the LDS (inside tbl_bytes)
   const int32_t* bits;
   int bits_off, bits_words, bits_k;
+  // MODE 0 / 2, 64-row tiles (optional): rows that hold a byte >= 0x80 or a NUL are not scanned here -- their indices go to
+  // this list (k_tdfa_scan_list scans them afterwards, a thread a row), and the tile's other rows keep the form the launch was
+  // chosen for (bit form, chain arithmetic, unit scan, lean scan) instead of the whole sub-tile going to the row-by-row scan
+  int32_t* deferred;
+  unsigned* ndeferred;
+  unsigned deferred_cap;
 };
 // UNITS (MODE 0 and 2, !LONG): the unit scan of the replace kernel -- units queued by the row lanes, one unit per lane
 // whatever its row, the per-row result summed (count_re) / OR-ed (contains_re) in LDS.
@@ -2099,12 +2128,28 @@ __global__ void __launch_bounds__(256, MODE == 4 ? ((CHAIN && !IN_LDS) ? 4 : 3) 
   const int nbm = BITS ? max(a.bits_k, 2) : 2;  // bitmaps per wave (BITS: one per character class)
   // (MODE 4 keeps a lane-private byte per step of a group run behind the bitmap: regex_tdfa.h, group_find_back)
   const int unit_bytes = UNITS ? (nbm - 1) * bm_bytes + kUnitQueue * 4 + 64 * 4 + 16 : (MODE == 4 ? cstd::Tdfa::kBackSteps * 64 + kMaxGroups * 4 : 0);  // x bitmap, unit queue, per-row results, bail word
-  uint8_t* lds_in = base + a.tbl_bytes + (size_t)wv * (a.cap_in + 32 + bm_bytes + unit_bytes);
+  uint8_t* lds_in = base + a.tbl_bytes + (size_t)wv * (a.cap_in + 32 + bm_bytes + unit_bytes + (((MODE == 0 || MODE == 2) && !LONG && a.deferred) ? bm_bytes + 64 * 4 : 0));
   uint32_t* bitmap = reinterpret_cast<uint32_t*>(lds_in + a.cap_in + 32);
   uint32_t* xbitmap = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(bitmap) + bm_bytes);
   uint32_t* uqueue = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(bitmap) + (size_t)nbm * bm_bytes);
   uint32_t* rowres = uqueue + kUnitQueue;
   uint32_t* bailw = rowres + 64;
+  constexpr bool kDefer = (MODE == 0 || MODE == 2) && !LONG;
+  const bool deferring = kDefer && a.deferred != nullptr;  // (wave-uniform)
+  uint32_t* oddmap = reinterpret_cast<uint32_t*>(lds_in + a.cap_in + 32 + bm_bytes + unit_bytes);  // (behind everything else of the wave)
+  // the wave's rows put off and not yet in the list: one atomic on the list's counter per 64 of them at most (one per sub-tile
+  // with such a row was 600K on one address for the C5 column's pieces -- 2 ms of a 4 ms kernel)
+  int32_t* pend = reinterpret_cast<int32_t*>(reinterpret_cast<uint8_t*>(oddmap) + bm_bytes);
+  int npend = 0;  // (wave-uniform)
+  auto flush_pend = [&] {
+    cstile::wave_lds_fence();
+    unsigned at = 0;
+    if (lane == 0) at = atomicAdd(a.ndeferred, (unsigned)npend);
+    at = (unsigned)__builtin_amdgcn_readfirstlane((int)at);
+    if (lane < npend && at + (unsigned)lane < a.deferred_cap) a.deferred[at + lane] = pend[lane];
+    cstile::wave_lds_fence();
+    npend = 0;
+  };
   // MODE 4: per group, the tile's bytes (the chain form keeps the "equals x" bitmap where the plain form has its history bytes)
   uint32_t* gtot = UNITS ? rowres : reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(xbitmap) + cstd::Tdfa::kBackSteps * 64);
   if (MODE == 4 && lane < kMaxGroups) gtot[lane] = 0;
@@ -2145,9 +2190,9 @@ __global__ void __launch_bounds__(256, MODE == 4 ? ((CHAIN && !IN_LDS) ? 4 : 3) 
     const long long r0 = tile * R;
     const int nrows = (int)min((long long)R, in.rows - r0);
     const long long g0 = cstile::rl64(cur.o0, 0), g1 = cstile::rl64(cur.o1, 63);
-    const bool live = lane < nrows && row_is_valid(in.validity, r0 + lane);
+    const bool live0 = lane < nrows && row_is_valid(in.validity, r0 + lane);
     const int rbeg = (int)(cur.o0 - g0);
-    const int n = live ? (int)(cur.o1 - cur.o0) : 0;
+    const int n0 = live0 ? (int)(cur.o1 - cur.o0) : 0;
     const int lead = (int)((uintptr_t)(in.chars + g0) & 15);
     const int want = (int)(g1 - g0) + lead;
     cstile::stage_chars(lds_in, want, lane, pf);
@@ -2156,10 +2201,10 @@ __global__ void __launch_bounds__(256, MODE == 4 ? ((CHAIN && !IN_LDS) ? 4 : 3) 
     for (int j = 0; j < cstile::kPfChunks; ++j)
       if (j * 1024 + lane * 16 < want) {
         const uint4 q = pf.v[j];
-        odd |= q.x | ((q.x - 0x01010101u) & ~q.x);
-        odd |= q.y | ((q.y - 0x01010101u) & ~q.y);
-        odd |= q.z | ((q.z - 0x01010101u) & ~q.z);
-        odd |= q.w | ((q.w - 0x01010101u) & ~q.w);
+        const uint32_t ox = q.x | ((q.x - 0x01010101u) & ~q.x), oy = q.y | ((q.y - 0x01010101u) & ~q.y);
+        const uint32_t oz = q.z | ((q.z - 0x01010101u) & ~q.z), ow = q.w | ((q.w - 0x01010101u) & ~q.w);
+        odd |= ox | oy | oz | ow;
+        if (deferring) cstile::put_bits16(oddmap, j * 1024 + lane * 16, cstile::gather16_bit7(ox & 0x80808080u, oy & 0x80808080u, oz & 0x80808080u, ow & 0x80808080u));
         if (BITS) {
           uint32_t pair[4];
           bits_classify16(spread, q, pair);
@@ -2187,6 +2232,28 @@ __global__ void __launch_bounds__(256, MODE == 4 ? ((CHAIN && !IN_LDS) ? 4 : 3) 
       cstile::issue_chars(in.chars, cstile::rl64(cur.o0, 0), cstile::rl64(cur.o1, 63), lane, pf);
     }
     cstile::wave_lds_fence();
+    bool has_odd = __any((odd & 0x80808080u) != 0);
+    bool live = live0;
+    if (deferring && has_odd) {  // (wave-uniform)
+      uint32_t d0, d1, d2;
+      cstile::row_bits96(oddmap, lead + rbeg, n0 < 96 ? n0 : 96, d0, d1, d2);
+      // (a row beyond the masks is not looked at: the tile is scanned row by row as before)
+      const bool fits = !__any(live0 && n0 + ((lead + rbeg) & 3) > cstd::Tdfa::kMaskBytes);
+      const bool put_off = fits && live0 && (d0 | d1 | d2) != 0;
+      const unsigned long long who = __ballot(put_off);
+      if (who) {
+        const int k = __builtin_popcountll(who);
+        if (npend + k > 64) flush_pend();
+        if (put_off) pend[npend + __builtin_popcountll(who & ((1ull << lane) - 1ull))] = (int32_t)(r0 + lane);
+        npend += k;
+      }
+      if (fits) {
+        live = live0 && !put_off;
+        has_odd = false;  // (what is left of the tile is plain)
+        odd = 0;
+      }
+    }
+    const int n = live ? n0 : 0;
     int v = 0;
     if (MODE == 5 || MODE == 6) {
       const uint8_t* p = lds_in + lead + rbeg;
@@ -2340,7 +2407,6 @@ __global__ void __launch_bounds__(256, MODE == 4 ? ((CHAIN && !IN_LDS) ? 4 : 3) 
       }
     } else {
       cstd::Tdfa vm(D, P, lds_in + lead + rbeg, n, (lead + rbeg) & 3);
-      const bool has_odd = __any((odd & 0x80808080u) != 0);
       bool hi_units = false;  // (bytes >= 0x80 that can only kill: the unit route alone -- reclassify_high)
       if (!CHAIN && UNITS && (MODE == 0 || MODE == 2 || MODE == 3) && has_odd && ((D.units >> 17) & 3u) && (D.units & 1u))
         hi_units = !reclassify_high(D, has_r2, lds_in, want, lane, bitmap, a.flags, lds_in + lead + rbeg, n);
@@ -2566,6 +2632,7 @@ __global__ void __launch_bounds__(256, MODE == 4 ? ((CHAIN && !IN_LDS) ? 4 : 3) 
     ++tile;
     nxt = nn;
   }
+  if (kDefer && npend > 0) flush_pend();
   const int t = wave_reduce_sum(hits);
   if (lane == 0 && t) atomicAdd(a.found, (unsigned long long)t);
 }
@@ -2603,10 +2670,23 @@ double candidate_share(const cs_regex* re, const cs_column* col, hipStream_t s) 
   }
   return all ? (double)cand / (double)all : 0.0;
 }
-bool bits_route(const cs_regex* re, const cs_column* col, hipStream_t s, int op) {
+// Rows with a byte >= 0x80 or a NUL, by the column's sample: are they few enough (at most one row in twenty -- an upper bound: every
+// such byte counted as a row of its own) for a scan to put them off (ScanStreamArgs::deferred) and run as on plain ASCII?
+bool odd_rows_few(const cs_column* col, hipStream_t s) {
+  if (cs::cfg("CS_NO_DEFERRED_ROWS") || col->rows == 0) return false;
+  const uint32_t* hist = sample_byte_hist(col, s);
+  uint64_t all = 0, oddb = hist[0];
+  for (unsigned c = 0; c < 256; ++c) {
+    all += hist[c];
+    if (c >= 128) oddb += hist[c];
+  }
+  if (all == 0) return false;
+  return (double)oddb / (double)all * ((double)col->nbytes / (double)col->rows) <= 0.05;
+}
+bool bits_route(const cs_regex* re, const cs_column* col, hipStream_t s, int op, bool high_ok = false) {
   if (re->bits.empty() || cs::cfg("CS_NO_BITS_FORM")) return false;
   if (!re->tdfa.empty() && ((re->tdfa[30] >> 16) & 15) != 0) return false;  // a chain
-  if (sample_has_high_bytes(col, s)) return false;
+  if (sample_has_high_bytes(col, s) && !high_ok) return false;
   if (cs::cfg("CS_BITS_ALWAYS")) return true;
   if (re->tdfa.empty()) return true;  // (no automaton: the list simulator is the alternative)
   const uint32_t* hist = sample_byte_hist(col, s);
@@ -2622,7 +2702,8 @@ bool bits_route(const cs_regex* re, const cs_column* col, hipStream_t s, int op)
   const double f = (double)cand / (double)all;
   const bool threads3 = re->tdfa[12] >= 3;
   if (op == BITS_COUNT) return f >= 0.02;
-  if (op == BITS_CONTAINS) return (f >= 0.05 && f <= 0.5) || (threads3 && f >= 0.02 && f <= 0.5);
+  // (the C5 column's pieces, the gtest pattern, 4.8 %: 4.0 / 7.1 -- the line between the 2.4 % tie and 7.2 % moved from 5 % to 3.5 %)
+  if (op == BITS_CONTAINS) return (f >= 0.035 && f <= 0.5) || (threads3 && f >= 0.02 && f <= 0.5);
   // (a pattern whose shortest match is one byte matches at most of its candidates: the automaton's routes then pay per match --
   // replace_re('e') on the C3 column, 4 % candidates: units 7.65, the bit form 6.45 ms)
   return f >= 0.05 || ((threads3 || re->tdfa[13] == 1) && f >= 0.02);
@@ -2822,7 +2903,8 @@ void scan(const cs_column* col, cs_regex* re, uint8_t* out8, int32_t* out32, int
   // the row lanes' scan restarts at every candidate -- 9.0 ms on the C3 column where count_re, on the unit scan, takes 1.9.
   // "Holds a match" is "counts at least one": the unit scan's counts, turned into flags.
   if (MODE == 0 && use_tdfa(re) && (re->tdfa[31] & 1) && ((re->tdfa[30] >> 16) & 15) == 0 && !cs::cfg("CS_NO_CONTAINS_BY_COUNT") && !cs::cfg("CS_REGEX_ROWWISE") &&
-      !cs::cfg("CS_NO_UNITS") && (((re->tdfa[31] >> 17) & 3) != 0 || !sample_has_high_bytes(col, s)) && max_row_bytes(col, s) + 3 <= cstd::Tdfa::kMaskBytes && !bits_route(re, col, s, BITS_CONTAINS) &&
+      !cs::cfg("CS_NO_UNITS") && (((re->tdfa[31] >> 17) & 3) != 0 || !sample_has_high_bytes(col, s) || odd_rows_few(col, s)) && max_row_bytes(col, s) + 3 <= cstd::Tdfa::kMaskBytes &&
+      !bits_route(re, col, s, BITS_CONTAINS, odd_rows_few(col, s)) &&
       candidate_share(re, col, s) >= 0.5) {
     Buf counts = dev_alloc(sizeof(int32_t) * (size_t)col->rows, s);
     int64_t hits = 0;
@@ -2860,7 +2942,7 @@ void scan(const cs_column* col, cs_regex* re, uint8_t* out8, int32_t* out32, int
   if (MODE == 2 && !re->bits.empty() && (re->bits[2] & (csbits::F_BYTE_CLASS | csbits::F_FLAG_CLASS))) {
     upload(re, s);
     const TileChoice tc0 = choose_tile(col, s, true);
-    const bool masks_form = tc0.R == 64 && !tc0.lng && !sample_has_high_bytes(col, s);
+    const bool masks_form = tc0.R == 64 && !tc0.lng && (!sample_has_high_bytes(col, s) || odd_rows_few(col, s));
     const bool chain_there = !re->tdfa.empty() && ((re->tdfa[30] >> 16) & 15) != 0 && tc0.R == 64 && !tc0.lng;
     const bool flag_class = (re->bits[2] & csbits::F_BYTE_CLASS) == 0;
     int64_t hits = 0;
@@ -2892,18 +2974,24 @@ void scan(const cs_column* col, cs_regex* re, uint8_t* out8, int32_t* out32, int
     // plain form's first-match scan stays)
     // (a chain pattern without a unit decomposition -- one with a suffix, regex_tdfa.cpp -- takes the same kernels: their unit
     // routes test header word 31 bit 0 themselves)
-    const bool units = !wide && (MODE == 2 || (MODE == 0 && ((re->tdfa[31] >> 17) & 3) != 0 && sample_has_high_bytes(col, s))) &&
+    // (a column whose sample holds a few bytes >= 0x80: the rows that hold them are put off -- ScanStreamArgs::deferred,
+    // k_tdfa_scan_list -- and the forms are chosen as on plain ASCII; the C5 column, one row in 170: contains_re of the gtest
+    // pattern 9.9 ms when every sub-tile with such a row went to the row-by-row scan)
+    const bool put_off = (MODE == 0 || MODE == 2) && !wide && !tc.lng && tc.R == 64 && sample_has_high_bytes(col, s) && odd_rows_few(col, s);
+    const bool high_sample = sample_has_high_bytes(col, s) && !put_off;
+    const bool units = !wide && (MODE == 2 || (MODE == 0 && ((re->tdfa[31] >> 17) & 3) != 0 && high_sample)) &&
                        ((re->tdfa[31] & 1) != 0 || (MODE == 2 && ((re->tdfa[30] >> 16) & 15) != 0)) &&
                        !tc.lng && tc.R == 64 && !cs::cfg("CS_NO_UNITS");
     // the bit-parallel form (regex_bits.h): contains_re / count_re of patterns whose candidates are everywhere
-    const bool bits_form = !wide && (MODE == 0 || MODE == 2) && !tc.lng && tc.R == 64 && bits_route(re, col, s, MODE == 2 ? BITS_COUNT : BITS_CONTAINS);
+    const bool bits_form = !wide && (MODE == 0 || MODE == 2) && !tc.lng && tc.R == 64 && bits_route(re, col, s, MODE == 2 ? BITS_COUNT : BITS_CONTAINS, put_off);
     const int bits_k = bits_form ? std::max(re->bits[1], 2) : 0;
     const size_t bits_lds = bits_form ? (size_t)bits_lds_bytes((int)re->bits.size()) : 0;
     size_t lds = bits_form ? tp.lds_bytes + bits_lds + (size_t)(cap + 32 + bits_k * ((cap >> 3) + 32) + kUnitQueue * 4 + 64 * 4 + 16) * 4
                                  : tp.lds_bytes + (size_t)(cap + 32 + (cap >> 3) + 32 + (units ? (cap >> 3) + 32 + kUnitQueue * 4 + 64 * 4 + 16 : 0)) * 4;
+    if (put_off) lds += (size_t)((cap >> 3) + 32 + 64 * 4) * 4;  // (the bitmap of such bytes and the rows waiting for the list, a wave)
     // (a chain's arithmetic reads no table: where the tables cost the launch a workgroup per CU -- four fit in 40 KB each --
     // they stay in memory, as in cs_replace_re)
-    const bool chain_scan = units && MODE == 2 && !bits_form && ((re->tdfa[30] >> 16) & 15) != 0 && !sample_has_high_bytes(col, s) && !cs::cfg("CS_NO_CHAIN_FORM");
+    const bool chain_scan = units && MODE == 2 && !bits_form && ((re->tdfa[30] >> 16) & 15) != 0 && !high_sample && !cs::cfg("CS_NO_CHAIN_FORM");
     // (the bit form is such a form too: its sub-tiles of plain ASCII never touch the automaton)
     const bool chain_global = (chain_scan || bits_form) && lds > 40 * 1024 && lds - tp.lds_bytes + cstd::kHeadTailWords * 4 <= 40 * 1024 && !cs::cfg("CS_CHAIN_TABLES_IN_LDS");
     const size_t scan_tbl = chain_global ? (size_t)cstd::kHeadTailWords * 4 : tp.lds_bytes;  // (header + tail words: tsetup)
@@ -2935,9 +3023,38 @@ void scan(const cs_column* col, cs_regex* re, uint8_t* out8, int32_t* out32, int
       if (lds > 48 * 1024)
         CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       const unsigned grid = resident_grid(reinterpret_cast<const void*>(kern), lds, (sa.nsub + 3) / 4);
-      ProfScope ps(name, s);
-      hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, sa);
+      Buf later, nlater;
+      if (put_off) {
+        sa.deferred_cap = (unsigned)std::min<int64_t>(col->rows, col->rows / 8 + 4096);
+        later = dev_alloc(sizeof(int32_t) * (size_t)sa.deferred_cap, s);
+        nlater = dev_alloc(sizeof(unsigned), s);
+        CS_HIP(hipMemsetAsync(nlater->p, 0, sizeof(unsigned), s));
+        sa.deferred = ptr<int32_t>(later);
+        sa.ndeferred = ptr<unsigned>(nlater);
+      }
+      {
+        ProfScope ps(name, s);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, sa);
+      }
       streamed = true;
+      if (put_off) {
+        note_route_put_off();
+        const unsigned lgrid = (unsigned)std::min<int64_t>(((int64_t)sa.deferred_cap + 255) / 256, 2048);
+        if (tp.lds_bytes > 48 * 1024)
+          CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tdfa_scan_list<MODE == 2 ? 2 : 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tp.lds_bytes));
+        ProfScope ps("k_tdfa_scan_list", s);
+        hipLaunchKernelGGL((k_tdfa_scan_list<MODE == 2 ? 2 : 0>), dim3(lgrid), dim3(256), tp.lds_bytes, s, src, tp.d, ptr<const int32_t>(later), ptr<const unsigned>(nlater),
+                           sa.deferred_cap, out8, out32, ptr<unsigned long long>(cnt));
+        // (more such rows than the sample promised and the list holds: the column is scanned again with nothing put off)
+        unsigned* hn = (unsigned*)pinned_scratch(sizeof(unsigned));
+        CS_HIP(hipMemcpyAsync(hn, nlater->p, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+        CS_HIP(hipStreamSynchronize(s));
+        if (*hn > sa.deferred_cap) {
+          note_fallback("regex-deferred-rows-overflow");
+          streamed = false;
+          CS_HIP(hipMemsetAsync(cnt->p, 0, 8, s));
+        }
+      }
     }
   }
   if (!streamed) {

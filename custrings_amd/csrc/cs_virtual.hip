@@ -113,16 +113,17 @@ __global__ void k_virt_write(ColView in, long long nbytes, const int64_t* __rest
 // a row's result out of its pieces': OR (bytes) or sum (int32); rows with a result > 0 are counted
 template <class T>
 __global__ void k_virt_reduce(const int64_t* __restrict__ first, const T* __restrict__ piece_res, int64_t rows, T* __restrict__ out, unsigned long long* __restrict__ hits) {
-  const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  // (a bounded grid, the threads taking rows a grid apart: with a workgroup per 256 rows the hit counter took 244K additions on
+  // one address when most rows hold a match -- 2.95 ms for 62.5M rows where the kernel's traffic is worth 0.3)
   int hit = 0;
-  if (r < rows) {
+  for (int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x; r < rows; r += (int64_t)gridDim.x * kBlock) {
     const int64_t a = first[r], b = first[r + 1];
     T v = piece_res[a];  // (a null row has one piece: its value passes through)
     for (int64_t k = a + 1; k < b; ++k) v = sizeof(T) == 1 ? (T)(v | piece_res[k]) : (T)(v + piece_res[k]);
     out[r] = v;
-    hit = v > 0;
+    hit += v > 0;
   }
-  const int t = csdev::block_reduce_sum(hit);
+  const long long t = csdev::block_reduce_sum(hit);
   if (threadIdx.x == 0 && t) atomicAdd(hits, (unsigned long long)t);
 }
 // a row's output offset = its first piece's
@@ -194,7 +195,7 @@ const VirtualRows* virtual_rows(const cs_column* col, hipStream_t s) {
 int64_t virtual_reduce_u8(const VirtualRows* vr, const uint8_t* piece_res, int64_t rows, uint8_t* out, hipStream_t s) {
   Buf hits = dev_alloc(sizeof(unsigned long long), s);
   CS_HIP(hipMemsetAsync(hits->p, 0, sizeof(unsigned long long), s));
-  hipLaunchKernelGGL(k_virt_reduce<uint8_t>, dim3(blocks_for(rows)), dim3(kBlock), 0, s, ptr<const int64_t>(vr->first), piece_res, rows, out, ptr<unsigned long long>(hits));
+  hipLaunchKernelGGL(k_virt_reduce<uint8_t>, dim3(std::min(blocks_for(rows), 4096u)), dim3(kBlock), 0, s, ptr<const int64_t>(vr->first), piece_res, rows, out, ptr<unsigned long long>(hits));
   CS_HIP(hipGetLastError());
   unsigned long long* h = (unsigned long long*)pinned_scratch(sizeof(unsigned long long));
   CS_HIP(hipMemcpyAsync(h, hits->p, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
@@ -204,7 +205,7 @@ int64_t virtual_reduce_u8(const VirtualRows* vr, const uint8_t* piece_res, int64
 int64_t virtual_reduce_i32(const VirtualRows* vr, const int32_t* piece_res, int64_t rows, int32_t* out, hipStream_t s) {
   Buf hits = dev_alloc(sizeof(unsigned long long), s);
   CS_HIP(hipMemsetAsync(hits->p, 0, sizeof(unsigned long long), s));
-  hipLaunchKernelGGL(k_virt_reduce<int32_t>, dim3(blocks_for(rows)), dim3(kBlock), 0, s, ptr<const int64_t>(vr->first), piece_res, rows, out, ptr<unsigned long long>(hits));
+  hipLaunchKernelGGL(k_virt_reduce<int32_t>, dim3(std::min(blocks_for(rows), 4096u)), dim3(kBlock), 0, s, ptr<const int64_t>(vr->first), piece_res, rows, out, ptr<unsigned long long>(hits));
   CS_HIP(hipGetLastError());
   unsigned long long* h = (unsigned long long*)pinned_scratch(sizeof(unsigned long long));
   CS_HIP(hipMemcpyAsync(h, hits->p, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));

@@ -88,6 +88,18 @@ __device__ __forceinline__ long long block_reduce_sum(int v) {
   block_exclusive_scan(v, &t);
   return t;
 }
+// (64-bit addends: what a thread gathered over the rows of a grid-stride loop)
+__device__ __forceinline__ long long block_reduce_sum_ll(long long v) {
+  __shared__ long long wave_sum[kMaxWaves];
+  const int nwaves = (blockDim.x + kWave - 1) / kWave;
+  for (int d = kWave / 2; d > 0; d >>= 1) v += __shfl_xor(v, d, kWave);
+  __syncthreads();
+  if ((threadIdx.x & (kWave - 1)) == 0) wave_sum[threadIdx.x / kWave] = v;
+  __syncthreads();
+  long long t = 0;
+  for (int k = 0; k < nwaves; ++k) t += wave_sum[k];
+  return t;
+}
 __device__ __forceinline__ int block_reduce_max(int v) {
   __shared__ int wave_max[kMaxWaves];
   const int nwaves = (blockDim.x + kWave - 1) / kWave;

@@ -485,3 +485,85 @@ def test_gpu_contains_re_of_a_dense_unit_program_by_its_counts(pat, monkeypatch)
         assert np.array_equal(has2, want) and n2 == want_n
     finally:
         gpuutil.lib().lib.cs_regex_destroy(re)
+
+
+# ---- rows with bytes >= 0x80 put off to a second launch (cs_regex.hip: ScanStreamArgs::deferred, k_tdfa_scan_list) ----
+LATER_PATTERNS = [r"\w+@\w+", r"(\bin\b)|(\ba\b)|(\bthe\b)", r"[aeiou]+", r"\d+\.\d+\.\d+\.\d+", r"[a-z]+ing\b", r"\d+", r"#\w+"]
+
+
+def _mostly_ascii_rows(rng, count, odd_share, lo=0, hi=90):
+    glyphs = list("abcdefghing the in a 0123456789.@#-")
+    rows = []
+    for i in range(count):
+        n = int(rng.integers(lo, hi + 1))
+        row = "".join(rng.choice(glyphs, n))
+        if rng.random() < odd_share and n >= 4:
+            k = int(rng.integers(0, n - 2))
+            row = row[:k] + str(rng.choice(["é", "Ж", "€", "\x00"])) + row[k + 2:]
+        rows.append(row.encode()[:hi])
+    # (a row cut inside a character by the [:hi] above is made whole again)
+    return [r.decode("utf-8", "ignore").encode() for r in rows]
+
+
+@pytest.mark.parametrize("pat", LATER_PATTERNS)
+def test_gpu_scan_puts_rows_with_high_bytes_off(pat, monkeypatch):
+    """contains_re / count_re on a column whose sample holds a FEW bytes >= 0x80: the rows that hold them (and rows with a NUL)
+    go to a list and are scanned by k_tdfa_scan_list, the other rows of their sub-tiles keep the bit form / the chain arithmetic /
+    the unit scan -- flags, counts and the number of rows with a match against the oracle, nulls and empty rows included; the
+    same with nothing put off (CS_NO_DEFERRED_ROWS)."""
+    L = gpuutil.lib()
+    orc = cpulibs.Oracle()
+    blob = blob_of(pat)
+    rng = np.random.default_rng(4100)
+    rows_b = _mostly_ascii_rows(rng, 40_000, 0.01)
+    rows_b[0] = "é first window".encode()  # (the sample's first window sees such a byte whatever the draw)
+    col = _with_nulls(rows_b, rng)
+    g = gpuutil.from_col(col)
+    re = gpuutil.compile_re(pat)
+    try:
+        want_has, want_n = orc.contains_re(col, blob)
+        want_cnt = orc.count_re(col, blob)
+        for env in (None, "1"):
+            if env:
+                monkeypatch.setenv("CS_NO_DEFERRED_ROWS", env)
+            f0 = int(L.lib.cs_fallback_count())
+            has, n = gpuutil.bools(g, "cs_contains_re", re)
+            r1 = last_route()
+            cnt = np.zeros(col.rows, dtype=np.int32)
+            found = C.c_int64()
+            L.check(L.lib.cs_count_re(g.m_cptr, re, cnt.ctypes.data, 0, None, C.byref(found)))
+            r2 = last_route()
+            assert np.array_equal(has, want_has) and n == want_n, (pat, env, r1)
+            assert np.array_equal(cnt, want_cnt[0] if isinstance(want_cnt, tuple) else want_cnt), (pat, env, r2)
+            assert int(L.lib.cs_fallback_count()) == f0
+            if env is None:
+                assert r1.endswith("+later") and r2.endswith("+later"), (r1, r2)
+            else:
+                assert "+later" not in r1 + r2
+    finally:
+        L.lib.cs_regex_destroy(re)
+
+
+def test_gpu_scan_with_more_such_rows_than_the_list_holds():
+    """The sample's three windows see one byte >= 0x80, the column between them is full of such rows: the list overflows, the op
+    says so (a counted fallback) and scans the column again with nothing put off -- the result is the oracle's."""
+    L = gpuutil.lib()
+    orc = cpulibs.Oracle()
+    pat = r"\w+@\w+"
+    blob = blob_of(pat)
+    rng = np.random.default_rng(4101)
+    rows_b = _mostly_ascii_rows(rng, 60_000, 0.0, lo=30, hi=80)
+    rows_b[0] = "é first window".encode()
+    for i in range(6_000, 24_000):  # (the windows are 64 KiB at the start, the middle and the end of ~3.3 MB of chars)
+        rows_b[i] = ("é" + rows_b[i].decode()[2:]).encode()
+    col = _with_nulls(rows_b, rng)
+    g = gpuutil.from_col(col)
+    re = gpuutil.compile_re(pat)
+    try:
+        f0 = int(L.lib.cs_fallback_count())
+        has, n = gpuutil.bools(g, "cs_contains_re", re)
+        want_has, want_n = orc.contains_re(col, blob)
+        assert np.array_equal(has, want_has) and n == want_n
+        assert int(L.lib.cs_fallback_count()) == f0 + 1
+    finally:
+        L.lib.cs_regex_destroy(re)

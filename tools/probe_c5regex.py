@@ -83,8 +83,25 @@ def main():
             for op, fn in (("contains_re", contains), ("count_re", count), ("replace_re", lambda: col.replace(pat, repl))):
                 f0 = int(L.cs_fallback_count())
                 dt = timed(fn)
-                print(json.dumps({"config": name, "op": op, "pattern": pname, "rows": rows, "ms": round(dt * 1e3, 3), "input_GBps": round(nb / dt / 1e9, 1),
-                                  "ps_per_byte": round(dt / nb * 1e12, 3), "route": L.cs_debug_last_route().decode(), "fallbacks": int(L.cs_fallback_count()) - f0}), flush=True)
+                route = L.cs_debug_last_route().decode()
+                ks = {}
+                if os.environ.get("PROBE_KERNELS"):  # (one more call under the library's kernel timers)
+                    L.cs_prof_reset()
+                    L.cs_prof_enable(1)
+                    r = fn()
+                    del r
+                    torch.cuda.synchronize()
+                    L.cs_prof_enable(0)
+                    for k in ("k_contains_re", "k_count_re", "k_tdfa_scan_list", "k_virt_reduce", "k_replace_re"):
+                        ms, n = C.c_double(), C.c_int64()
+                        L.cs_prof_get(k.encode(), C.byref(ms), C.byref(n))
+                        if n.value:
+                            ks[k] = round(ms.value / n.value, 3)
+                line = {"config": name, "op": op, "pattern": pname, "rows": rows, "ms": round(dt * 1e3, 3), "input_GBps": round(nb / dt / 1e9, 1),
+                        "ps_per_byte": round(dt / nb * 1e12, 3), "route": route, "fallbacks": int(L.cs_fallback_count()) - f0}
+                if ks:
+                    line["kernels_ms"] = ks
+                print(json.dumps(line), flush=True)
             L.cs_regex_destroy(re)
         dt = timed(lambda: col.split(" "))
         print(json.dumps({"config": name, "op": "split(' ')", "rows": rows, "ms": round(dt * 1e3, 3), "input_GBps": round(nb / dt / 1e9, 1), "ps_per_byte": round(dt / nb * 1e12, 3),
