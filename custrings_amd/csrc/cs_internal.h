@@ -91,6 +91,7 @@ const uint16_t* h_charcases();
 }  // namespace cs
 
 namespace cs {
+struct OddRows;      // cs_virtual.hip: the rows that hold a byte >= 0x80 or a NUL, as a list and as a mask per 64-row tile
 struct VirtualRows;  // cs_virtual.hip: the column's rows cut into pieces of at most 92 bytes (a second column over the same chars)
 }
 // ---- the column ---------------------------------------------------------------
@@ -106,6 +107,7 @@ struct cs_column {
   mutable std::shared_ptr<std::array<uint32_t, 256>> byte_hist;  // byte counts of the same sample (a hint for kernel choice); null = not taken
   mutable std::shared_ptr<cs::VirtualRows> virt;  // the view of a long-row column as pieces (built on first use; cs_virtual.hip)
   mutable int virt_state = 0;                     // 0: not looked at, 1: `virt` holds it, -1: the column has none
+  mutable std::shared_ptr<cs::OddRows> odd;       // the rows with a byte >= 0x80 or a NUL (built on first use; cs_virtual.hip)
   cs::Buf chars, validity;  // validity may be null (all valid)
   // Row extents: int64 offsets (`offsets`) and / or int32 offsets (`offsets32`, columns whose
   // chars stay below 2 GiB -- what split produces: half the bytes written per output row).  A
@@ -204,6 +206,15 @@ struct VirtualRows {
   Buf first;                       // int64[rows + 1]: row r's pieces are first[r] .. first[r + 1] - 1
 };
 const VirtualRows* virtual_rows(const cs_column* col, hipStream_t s);
+// the rows that hold a byte >= 0x80 or a NUL byte -- the rows the 96-bit-mask forms of the regex kernels do not take: replace_re
+// leaves them holes in its single pass and fills them from a thread a row (cs_regex.hip); column metadata, one pass over the chars
+struct OddRows {
+  int64_t count = 0;
+  Buf list;   // int32[count]: their indices, ascending
+  Buf mask;   // uint64[tiles]: bit j of word t = row 64 t + j is such a row
+  Buf first;  // int64[tiles + 1]: list[first[t]] is tile t's first
+};
+const OddRows* odd_rows(const cs_column* col, hipStream_t s);
 int virtual_piece_bytes();
 int64_t virtual_reduce_u8(const VirtualRows* vr, const uint8_t* piece_res, int64_t rows, uint8_t* out, hipStream_t s);
 int64_t virtual_reduce_i32(const VirtualRows* vr, const int32_t* piece_res, int64_t rows, int32_t* out, hipStream_t s);

@@ -533,6 +533,39 @@ __global__ void __launch_bounds__(256) k_tdfa_replace_write(RowSrc src, TLaunch 
   }
 }
 
+// replace_re of the rows in `list` (StreamArgs::hole_*): their output sizes (lens[i] for list[i]), or -- WRITE -- their bytes at
+// the offsets the stream launch left them
+template <bool WRITE>
+__global__ void __launch_bounds__(256) k_tdfa_replace_list(RowSrc src, TLaunch L, const int32_t* __restrict__ list, int64_t count, const uint8_t* __restrict__ repl, int rb,
+                                                           int32_t* __restrict__ lens, const int64_t* __restrict__ out_off, uint8_t* __restrict__ out_chars) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  TCtx c = tsetup<true>(L, src.flags, smem);
+  const ColView& in = src.in;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = list[i];
+    const int64_t b = in.offsets[r];
+    const int n = (int)(in.offsets[r + 1] - b);
+    const uint8_t* p = in.chars + b;
+    cstd::Tdfa vm(c.D, c.P, p, n);
+    vm.wide_ok = (b & ~(int64_t)3) + cstd::Tdfa::kMaskBytes <= src.safe_end;
+    if (!WRITE) {
+      int len = n;
+      csvm::row_replace_matches(vm, -1, [&](int mb, int me, int reps) { len += reps * rb - (me - mb); });
+      lens[i] = len;
+    } else {
+      uint8_t* o = out_chars + out_off[r];
+      int copied = 0;
+      csvm::row_replace_matches(vm, -1, [&](int mb, int me, int reps) {
+        for (int k = copied; k < mb; ++k) *o++ = p[k];
+        for (int k = 0; k < reps; ++k)
+          for (int q = 0; q < rb; ++q) *o++ = repl[q];
+        copied = me;
+      });
+      for (int k = copied; k < n; ++k) *o++ = p[k];
+    }
+  }
+}
+
 // extract with the leftmost match found by the tagged DFA (table in LDS); only rows that hold a
 // match run the list simulation, and only from the match start
 template <bool IN_LDS, bool SMALL>
@@ -894,6 +927,14 @@ struct StreamArgs {
   // BITS: the bit-parallel form of the pattern (regex_bits.h), staged at byte offset bits_off of the LDS (inside tbl_bytes)
   const int32_t* bits;
   int bits_off, bits_words, bits_k;
+  // HOLES (every form of 64-row tiles without a template; optional): the column's rows that hold a byte >= 0x80 or a NUL
+  // (cs_virtual.hip: OddRows) are not scanned here.  Their output sizes were taken beforehand, a thread a row
+  // (k_tdfa_replace_list<false>); a row lane of such a row leaves a hole of that size in the tile's output, which
+  // k_tdfa_replace_list<true> fills after the launch -- and the other rows of its sub-tile keep the bit form / the chain
+  // arithmetic / the unit scan, where one such row used to send all 64 to the row-by-row scan.
+  const unsigned long long* hole_mask;  // [tile]
+  const int64_t* hole_first;            // [tile]: index of the tile's first such row in hole_len
+  const int32_t* hole_len;
 };
 #ifndef CS_STREAM_WAVES
 #define CS_STREAM_WAVES 3
@@ -1292,6 +1333,18 @@ __global__ void __launch_bounds__(256, ((BREFS && !CHAIN) || (BITS && IN_LDS)) ?
   long long p_tile = -1;
   int p_total = 0, p_lo = 0, p_len = 0;
   int m_span = 0;  // the output column's largest 64-row span as a by-product (wave-uniform: a scalar maximum per sub-tile)
+  // HOLES: the tile's mask of rows that are sized and written elsewhere, and where their sizes begin -- fetched a tile ahead,
+  // like the offsets (unconditionally, from a harmless address when the launch has none: see the note at the first poll)
+  constexpr bool kHoles = !BREFS && !LONG && !OUTL && !WIDE;
+  const bool holes = kHoles && a.hole_mask != nullptr;
+  const unsigned long long* hole_mask_p = holes ? a.hole_mask : reinterpret_cast<const unsigned long long*>(a.tickets);
+  const int64_t* hole_first_p = holes ? a.hole_first : reinterpret_cast<const int64_t*>(a.tickets);
+  unsigned long long c_hm = 0;
+  long long c_hf = 0;
+  if (kHoles) {
+    c_hm = hole_mask_p[holes ? tile : 0];
+    c_hf = hole_first_p[holes ? tile : 0];
+  }
 #if defined(CS_PHASE_PROF)
   unsigned long long phase_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long lb_acc[3] = {0, 0, 0};
@@ -1341,9 +1394,9 @@ __global__ void __launch_bounds__(256, ((BREFS && !CHAIN) || (BITS && IN_LDS)) ?
     const long long r0 = tile * R;
     const int nrows = (int)min((long long)R, in.rows - r0);
     const long long g0 = cstile::rl64(cur.o0, 0), g1 = cstile::rl64(cur.o1, 63);
-    const bool live = lane < nrows && row_is_valid(in.validity, r0 + lane);
+    const bool live0 = lane < nrows && row_is_valid(in.validity, r0 + lane);
     const int rbeg = (int)(cur.o0 - g0);
-    const int n = live ? (int)(cur.o1 - cur.o0) : 0;
+    const int n0 = live0 ? (int)(cur.o1 - cur.o0) : 0;
     const int lead = (int)((uintptr_t)(in.chars + g0) & 15);
     const long long want = g1 - g0 + lead;
     bool bad = want + 16 > a.cap_in || want > PF * 1024;
@@ -1412,12 +1465,33 @@ __global__ void __launch_bounds__(256, ((BREFS && !CHAIN) || (BITS && IN_LDS)) ?
     t_nn = fixed ? t_nxt + (fixed_team ? W - 4 : W) : tile_of(pending);
     const unsigned long long pending_new = fixed ? 0ull : take();  // (tickets drawn past the end are harmless)
     const cstile::TileOffs nn = cstile::load_tile_offsets_r(in.offsets, in.rows, t_nn < a.nsub ? t_nn : a.nsub - 1, R, lane);
+    unsigned long long n_hm = 0;
+    long long n_hf = 0;
+    if (kHoles) {
+      const long long tq = holes ? (has_next ? t_nxt : tile) : 0;
+      n_hm = hole_mask_p[tq];
+      n_hf = hole_first_p[tq];
+    }
     if (has_next) {
       cur = nxt;
       cstile::issue_chars(in.chars, cstile::rl64(cur.o0, 0), cstile::rl64(cur.o1, 63), lane, pf);
     }
     cstile::wave_lds_fence();
     CS_PHASE_MARK(0);
+    // HOLES: the rows of this sub-tile that hold a byte >= 0x80 or a NUL take no part below -- and the others are plain
+    bool hole = false, tile_plain = false;
+    int hole_bytes = 0;
+    if (kHoles && holes && !bad) {
+      const unsigned long long hm = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(c_hm >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)c_hm);
+      // (a row beyond the masks: the sub-tile goes row by row as before -- its rows of the list are then written twice, the same bytes)
+      tile_plain = !__any(live0 && n0 + ((lead + rbeg) & 3) > cstd::Tdfa::kMaskBytes);
+      if (tile_plain && hm) {
+        hole = live0 && ((hm >> lane) & 1ull) != 0;
+        if (hole) hole_bytes = a.hole_len[cstile::rl64(c_hf, 0) + __builtin_popcountll(hm & ((1ull << lane) - 1ull))];
+      }
+    }
+    const bool live = live0 && !hole;
+    const int n = live ? n0 : 0;
 
     int rec_mb[kMaxRec], rec_me[kMaxRec], rec_reps[kMaxRec];
     int nm = 0;
@@ -1480,7 +1554,7 @@ __global__ void __launch_bounds__(256, ((BREFS && !CHAIN) || (BITS && IN_LDS)) ?
         ++nm;
       };
       // wave-uniform choice: the lean scan when every row of the sub-tile qualifies
-      const bool has_odd = __any((odd & 0x80808080u) != 0);
+      const bool has_odd = !tile_plain && __any((odd & 0x80808080u) != 0);
       // (a sub-tile with bytes >= 0x80, a pattern they can only kill: the UNIT route alone -- reclassify_high)
       bool hi_units = false;
       if (!CHAIN && UNITS && !BREFS && has_odd && a.litn == 0 && ((D.units >> 17) & 3u) && (D.units & 1u) && a.maxrepl < 0 && !(CS_DBG(a) & 4096))
@@ -1860,6 +1934,7 @@ __global__ void __launch_bounds__(256, ((BREFS && !CHAIN) || (BITS && IN_LDS)) ?
       }
     }
     CS_PHASE_MARK(1);
+    if (kHoles && hole) out_len = hole_bytes;
     const int incl = csdev::wave_inclusive_scan(out_len);
     const int lo = incl - out_len;
     const int total = __builtin_amdgcn_readlane(incl, 63);
@@ -2050,6 +2125,8 @@ __global__ void __launch_bounds__(256, ((BREFS && !CHAIN) || (BITS && IN_LDS)) ?
     t_nxt = t_nn;
     nxt = nn;
     pending = pending_new;
+    c_hm = n_hm;
+    c_hf = n_hf;
   }
   if (p_tile >= 0) finish_pending((CS_DBG(a) & 8) ? 0 : (__builtin_expect(scanner, 1) ? cstile::status_load(a.excl + p_tile) : cstile::lookback_poll(a.status, p_tile, lane)));
   {
@@ -2862,7 +2939,8 @@ const VirtualRows* pieces_for(const cs_column* col, const cs_regex* re, hipStrea
   if (max_row_bytes(col, s) + 3 <= cstd::Tdfa::kMaskBytes) return nullptr;  // (the masks hold the rows as they are)
   if (!re->bits.empty() && (re->bits[2] & (csbits::F_BYTE_CLASS | csbits::F_FLAG_CLASS)) && !cs::cfg("CS_NO_CLASS_RUNS")) return nullptr;
   const bool chain = ((re->tdfa[30] >> 16) & 15) != 0;
-  if (replacing && (re->tdfa[31] & 1) && !chain && sample_has_high_bytes(col, s)) return nullptr;
+  // (... unless such bytes are rare: the single pass then leaves the rows that hold them holes -- StreamArgs::hole_mask)
+  if (replacing && (re->tdfa[31] & 1) && !chain && sample_has_high_bytes(col, s) && !odd_rows_few(col, s)) return nullptr;
   // The executor ends a row's scan at a NUL byte and takes a character's width from its lead byte (an ASCII byte behind a
   // lead without its continuation bytes is swallowed -- a cut byte too): a piece behind such a byte would be scanned where
   // the row is not.  Columns of well-formed text only (`plain_bytes`: column metadata, one pass when nobody has looked yet).
@@ -2904,7 +2982,7 @@ void scan(const cs_column* col, cs_regex* re, uint8_t* out8, int32_t* out32, int
   // "Holds a match" is "counts at least one": the unit scan's counts, turned into flags.
   if (MODE == 0 && use_tdfa(re) && (re->tdfa[31] & 1) && ((re->tdfa[30] >> 16) & 15) == 0 && !cs::cfg("CS_NO_CONTAINS_BY_COUNT") && !cs::cfg("CS_REGEX_ROWWISE") &&
       !cs::cfg("CS_NO_UNITS") && (((re->tdfa[31] >> 17) & 3) != 0 || !sample_has_high_bytes(col, s) || odd_rows_few(col, s)) && max_row_bytes(col, s) + 3 <= cstd::Tdfa::kMaskBytes &&
-      !bits_route(re, col, s, BITS_CONTAINS, odd_rows_few(col, s)) &&
+      !bits_route(re, col, s, BITS_CONTAINS, odd_rows_few(col, s)) && !bits_route(re, col, s, BITS_COUNT, odd_rows_few(col, s)) &&
       candidate_share(re, col, s) >= 0.5) {
     Buf counts = dev_alloc(sizeof(int32_t) * (size_t)col->rows, s);
     int64_t hits = 0;
@@ -3286,6 +3364,12 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
       // persistent stream kernel (grid = what is resident at once); returns its error word, or -1
       // when the sizing does not fit
       int64_t sized_total = -1, sized_tilemax = 0;  // matches in the column / in its busiest tile, when they were counted first
+      // a column whose sample holds a few bytes >= 0x80: the unit forms run as on plain ASCII, the rows that hold such bytes are
+      // sized beforehand and written afterwards, a thread a row (StreamArgs::hole_mask) -- replace_re of the gtest pattern on the C5
+      // column's pieces: 34 ms when a third of the sub-tiles went to the row-by-row scan for the sake of one row each
+      const bool holes_ok = tdfa && tp.d.in_lds && maxrepl < 0 && !cs::g_backrefs_dev && !cs::g_replace_plain_only && !wide_stream && !outliers && tc.R == 64 && !tc.lng &&
+                            sample_has_high_bytes(col, s) && odd_rows_few(col, s);
+      Buf hole_lens;  // (taken once: a second, roomier attempt uses them again)
       auto stream_attempt = [&](bool roomy) -> int {
         // (a DFA whose tables do not fit the LDS budget: the two-pass kernels read them from memory)
         if (!tp.d.in_lds) return -1;
@@ -3326,7 +3410,7 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
         // the bit-parallel form (regex_bits.h): patterns whose candidates are everywhere -- a bitmap per character class (it
         // builds on the unit forms' layout and assembly, whether or not the pattern offers a unit decomposition)
         const bool bits_form = !literal && !brefs && !wide_stream && tdfa && maxrepl < 0 && !tc.lng && tc.R == 64 && !outliers && !cs::g_replace_plain_only && tp.d.in_lds &&
-                               bits_route(re, col, s, BITS_REPLACE);
+                               bits_route(re, col, s, BITS_REPLACE, holes_ok);
         // replace_with_backrefs on a chain whose groups are runs of items, the sample plain ASCII: the form that keeps neither
         // tables nor group tags in LDS (k_tdfa_replace_stream<.., BREFS, .., CHAIN>).  Its out tile is sized from the
         // template: an expansion is the template's literal bytes plus the groups it names, so a match grows by at most
@@ -3368,7 +3452,7 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
         const size_t bits_lds = bits_form ? (size_t)bits_lds_bytes((int)re->bits.size()) : 0;
         // (a chain pattern on a column whose sample is plain ASCII: the form without the unit / lean scans)
         const bool chain_form = !bits_form && !brefs && !wide_stream && !outliers && units && cap <= 5 * 1024 && tp.d.in_lds && !literal && maxrepl < 0 &&
-                                ((re->tdfa[30] >> 16) & 15) != 0 && !sample_has_high_bytes(col, s) && !cs::cfg("CS_NO_CHAIN_FORM");
+                                ((re->tdfa[30] >> 16) & 15) != 0 && (!sample_has_high_bytes(col, s) || holes_ok) && !cs::cfg("CS_NO_CHAIN_FORM");
         // (the kernel's layout, k_tdfa_replace_stream: a bitmap's bytes, what stands behind the first one)
         const size_t bm = (size_t)(cap >> 3) + (bits_form ? 16 : 32);
         const size_t unit_bytes = bchain                      ? bm + 16 + kUnitQueue * 12
@@ -3450,6 +3534,25 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
         sa.outliers = outliers ? 1 : 0;
         sa.lit = literal ? cs::g_replace_literal : 0;
         sa.litn = literal ? cs::g_replace_literal_len : 0;
+        const OddRows* od = holes_ok && !literal && !brefs ? odd_rows(col, s) : nullptr;
+        const bool with_holes = od && od->count > 0;
+        const unsigned hole_grid = with_holes ? (unsigned)std::min<int64_t>((od->count + 255) / 256, 2048) : 0;
+        if (with_holes) {
+          if (tp.lds_bytes > 48 * 1024) {
+            CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tdfa_replace_list<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tp.lds_bytes));
+            CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tdfa_replace_list<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tp.lds_bytes));
+          }
+          if (!hole_lens) {
+            hole_lens = dev_alloc(sizeof(int32_t) * (size_t)od->count, s);
+            ProfScope ps("k_tdfa_replace_list", s);
+            hipLaunchKernelGGL(k_tdfa_replace_list<false>, dim3(hole_grid), dim3(256), tp.lds_bytes, s, src, tp.d, ptr<const int32_t>(od->list), od->count, ptr<const uint8_t>(d_repl), rb,
+                               ptr<int32_t>(hole_lens), (const int64_t*)nullptr, (uint8_t*)nullptr);
+            CS_HIP(hipGetLastError());
+          }
+          sa.hole_mask = ptr<const unsigned long long>(od->mask);
+          sa.hole_first = ptr<const int64_t>(od->first);
+          sa.hole_len = ptr<const int32_t>(hole_lens);
+        }
         // (tables in LDS: a DFA beyond the LDS budget left this function above -- the forms with the tables in memory that are
         // not chain forms were never reached by a test and spilled 20-60 registers: out since round 6, kernel_coverage.txt)
         auto pick2 = [&](auto inplace, auto rescan, auto lng) {
@@ -3500,6 +3603,7 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
         else if (units)
           kern = rb > 8 ? &k_tdfa_replace_stream<true, true, false, true, false, true> : &k_tdfa_replace_stream<true, false, false, true, false, true>;
         note_route(bits_form ? "bits" : bchain ? "brefs-chain" : brefs ? "brefs" : literal ? "literal" : wide_stream ? "wide" : units ? (((re->tdfa[30] >> 16) & 15) != 0 ? "chain" : "units") : "plain");
+        if (with_holes) note_route_put_off();
         if (lds1 > 48 * 1024)
           CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                      (int)lds1));
@@ -3567,6 +3671,13 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
           for (int64_t t = 0; t < nsub1 && t < 64; ++t)
             fprintf(stderr, "  tile %lld: agg flag %u val %llu | excl flag %u val %llu\n", (long long)t, (unsigned)(st[t] >> 62), (unsigned long long)(st[t] & cstile::kValMask),
                     (unsigned)(ex[t] >> 62), (unsigned long long)(ex[t] & cstile::kValMask));
+        }
+        if (err == 0 && with_holes) {  // the holes' bytes
+          ProfScope ps("k_tdfa_replace_list", s);
+          hipLaunchKernelGGL(k_tdfa_replace_list<true>, dim3(hole_grid), dim3(256), tp.lds_bytes, s, src, tp.d, ptr<const int32_t>(od->list), od->count, ptr<const uint8_t>(d_repl), rb,
+                             (int32_t*)nullptr, ptr<const int64_t>(out_off), ptr<uint8_t>(out_chars));
+          CS_HIP(hipGetLastError());
+          CS_HIP(hipStreamSynchronize(s));
         }
         if (err == 0) {  // (a launch whose error word is set never yields a column, measurement switches or not)
           o->offsets = out_off;

@@ -132,12 +132,87 @@ __global__ void k_virt_offsets(const int64_t* __restrict__ first, const int64_t*
   if (r <= rows) out[r] = piece_off[first[r]];
 }
 
+// ---- the rows with a byte >= 0x80 or a NUL (OddRows) ----
+// a lane a row: the row's bytes as the aligned 16-byte pieces that cover them, what lies outside the row blanked
+__global__ void __launch_bounds__(256) k_odd_masks(ColView in, int64_t tiles, unsigned long long* __restrict__ mask, int32_t* __restrict__ cnt) {
+  const int lane = threadIdx.x & 63;
+  const int64_t waves = (int64_t)gridDim.x * 4;
+  for (int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); t < tiles; t += waves) {
+    const int64_t r = t * 64 + lane;
+    bool odd = false;
+    if (r < in.rows && row_is_valid(in.validity, r)) {
+      const int64_t b = in.offsets[r], e = in.offsets[r + 1];
+      for (int64_t q = b & ~(int64_t)15; q < e && !odd; q += 16) {
+        const uint4 v = *reinterpret_cast<const uint4*>(in.chars + q);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int64_t p = q + 4 * k;  // bytes p .. p + 3
+          uint32_t keep = 0xFFFFFFFFu;
+          if (p < b) keep &= b - p >= 4 ? 0u : 0xFFFFFFFFu << (8 * (int)(b - p));
+          if (p + 4 > e) keep &= e <= p ? 0u : 0xFFFFFFFFu >> (8 * (int)(p + 4 - e));
+          const uint32_t x = (w[k] & keep) | (0x20202020u & ~keep);
+          odd = odd || (((x | ((x - 0x01010101u) & ~x)) & 0x80808080u) != 0);
+        }
+      }
+    }
+    const unsigned long long m = __ballot(odd);
+    if (lane == 0) {
+      mask[t] = m;
+      cnt[t] = __builtin_popcountll(m);
+    }
+  }
+}
+__global__ void __launch_bounds__(256) k_odd_list(const unsigned long long* __restrict__ mask, const int64_t* __restrict__ first, int64_t tiles, int32_t* __restrict__ list) {
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;  // a lane a row again
+  const int64_t t = i >> 6;
+  if (t >= tiles) return;
+  const unsigned long long m = mask[t];
+  const int j = (int)(i & 63);
+  if ((m >> j) & 1ull) list[first[t] + __builtin_popcountll(m & ((1ull << j) - 1ull))] = (int32_t)i;
+}
+
 std::mutex g_virt_mu;
 }  // namespace
 
 namespace cs {
 
 int virtual_piece_bytes() { return kPiece; }
+
+const OddRows* odd_rows(const cs_column* col, hipStream_t s) {
+  std::lock_guard<std::mutex> lk(g_virt_mu);
+  if (col->odd) return col->odd.get();
+  auto od = std::make_shared<OddRows>();
+  const int64_t tiles = (col->rows + 63) / 64;
+  // (the chars are read as aligned 16-byte pieces: a buffer's first and last piece lie inside its allocation -- dev_alloc
+  // rounds up -- unless a caller's buffer was wrapped at an odd address, which has no list: count -1)
+  if (tiles == 0 || col->nbytes == 0) {
+    col->odd = od;
+    return col->odd.get();
+  }
+  if (((uintptr_t)col->d_chars() & 15) || !col->chars || col->chars->capacity < (((size_t)col->nbytes + 15) & ~(size_t)15)) {
+    od->count = -1;
+    col->odd = od;
+    return col->odd.get();
+  }
+  od->mask = dev_alloc(sizeof(unsigned long long) * (size_t)tiles, s);
+  od->first = dev_alloc(sizeof(int64_t) * (size_t)(tiles + 1), s);
+  Buf cnt = dev_alloc(sizeof(int32_t) * (size_t)tiles, s);
+  {
+    ProfScope ps("k_odd_masks", s);
+    hipLaunchKernelGGL(k_odd_masks, dim3((unsigned)std::min<int64_t>((tiles + 3) / 4, 256 * 32)), dim3(256), 0, s, view_of(col), tiles, ptr<unsigned long long>(od->mask), ptr<int32_t>(cnt));
+  }
+  CS_HIP(hipGetLastError());
+  od->count = offsets_from_lengths(ptr<int32_t>(cnt), tiles, ptr<int64_t>(od->first), s);
+  od->list = dev_alloc(sizeof(int32_t) * (size_t)std::max<int64_t>(od->count, 1), s);
+  if (od->count > 0) {
+    hipLaunchKernelGGL(k_odd_list, dim3(blocks_for(tiles * 64)), dim3(kBlock), 0, s, ptr<const unsigned long long>(od->mask), ptr<const int64_t>(od->first), tiles, ptr<int32_t>(od->list));
+    CS_HIP(hipGetLastError());
+  }
+  CS_HIP(hipStreamSynchronize(s));
+  col->odd = od;
+  return col->odd.get();
+}
 
 // the column's view, or nullptr when it has none (built on first use, kept on the column)
 const VirtualRows* virtual_rows(const cs_column* col, hipStream_t s) {

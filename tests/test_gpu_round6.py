@@ -567,3 +567,49 @@ def test_gpu_scan_with_more_such_rows_than_the_list_holds():
         assert int(L.lib.cs_fallback_count()) == f0 + 1
     finally:
         L.lib.cs_regex_destroy(re)
+
+
+@pytest.mark.parametrize("pat,repl", [(r"\w+@\w+", "<m>"), (r"(\bin\b)|(\ba\b)|(\bthe\b)", "="), (r"\d+\.\d+\.\d+\.\d+", "<IP>"), (r"[a-z]+ing\b", ""),
+                                      (r"#\w+", "<a longer tag>"), (r"\d+", "<number>"), (r"\bthe\b", "THE")])
+def test_gpu_replace_re_leaves_rows_with_high_bytes_holes(pat, repl, monkeypatch):
+    """replace_re on a column whose sample holds a FEW bytes >= 0x80 (cs_regex.hip: StreamArgs::hole_mask): the rows that hold
+    them (cs_virtual.hip: OddRows -- rows with a NUL too) are sized beforehand and written afterwards, a thread a row; the
+    single pass leaves them holes and runs its unit forms on the others.  Against the oracle: shrinking, equal and growing
+    replacements, such rows first and last in their 64-row tile, next to nulls and empty rows; and with the holes off."""
+    L = gpuutil.lib()
+    orc = cpulibs.Oracle()
+    blob = blob_of(pat)
+    rng = np.random.default_rng(4200)
+    rows_b = _mostly_ascii_rows(rng, 50_000, 0.01)
+    rows_b[0] = "é in the first window a@b 1.2.3.4 #tag".encode()
+    for r in (63, 64, 127, 128, 4095, 4096, 49_999):
+        rows_b[r] = ("the ünïcode a@b in " + str(r) + " 10.0.0.1 #x testing").encode()
+    rows_b[200] = b"nul \x00 in the middle a@b 1.2.3.4"
+    rows_b[201] = b""
+    col = _with_nulls(rows_b, rng)
+    g = gpuutil.from_col(col)
+    want = orc.replace_re(col, blob, repl)
+    for env in (None, "1"):
+        if env:
+            monkeypatch.setenv("CS_NO_DEFERRED_ROWS", env)
+        f0 = int(L.lib.cs_fallback_count())
+        got = g.replace(pat, repl)
+        route = last_route()
+        gpuutil.assert_same(got, want, "replace_re(%r) route %s" % (pat, route))
+        assert int(L.lib.cs_fallback_count()) == f0
+        if env:
+            assert "+later" not in route
+
+
+def test_gpu_replace_re_with_holes_on_the_pieces_of_long_rows():
+    """BASELINE's C5 column (rows of 40-150 bytes, one in 170 with an accent): replace_re runs on the column's pieces, and the
+    pieces with a byte >= 0x80 are the single pass's holes -- against the oracle on the rows."""
+    L = gpuutil.lib()
+    orc = cpulibs.Oracle()
+    g, o = gpuutil.synth(5, 0, 150_000), orc.synth(5, 0, 150_000)
+    for pat, repl in ((r"(\bin\b)|(\ba\b)|(\bthe\b)", "="), (r"\w+@\w+", "<m>"), (r"#\w+", "<tag>"), (r"#\w+", "#"), (r"[a-z]+ing\b", "")):
+        f0 = int(L.lib.cs_fallback_count())
+        got = g.replace(pat, repl)
+        assert last_route().startswith("pieces:") and last_route().endswith("+later"), last_route()
+        gpuutil.assert_same(got, orc.replace_re(o, blob_of(pat), repl), "replace_re(%r) on C5 (%s)" % (pat, last_route()))
+        assert int(L.lib.cs_fallback_count()) == f0
