@@ -581,6 +581,23 @@ int64_t offsets_from_lengths(const int32_t* lens, int64_t n, int64_t* offsets, h
   if (!block_sums && !cs::cfg("CS_SCAN_BY_WORKGROUPS")) return offsets_by_chunks(lens, n, offsets, nullptr, s, meta);
   return offsets_by_workgroups(lens, n, offsets, s, block_sums, meta);
 }
+// the same scan, nothing read back: the total is offsets[n] in device memory, the stream is not waited for (the radix sort's
+// eight passes each scan their tile counts -- a round trip to the host per pass was most of its time on a million keys)
+void offsets_from_lengths_async(const int32_t* lens, int64_t n, int64_t* offsets, hipStream_t s) {
+  if (n == 0) {
+    CS_HIP(hipMemsetAsync(offsets, 0, sizeof(int64_t), s));
+    return;
+  }
+  const int64_t nchunks = (n + kChunk - 1) / kChunk;
+  Buf sums = dev_alloc(sizeof(int64_t) * nchunks, s);
+  Buf total = dev_alloc(3 * sizeof(int64_t), s);
+  const unsigned grid = (unsigned)((nchunks + 3) / 4);
+  hipLaunchKernelGGL(k_chunk_sums, dim3(grid), dim3(kBlock), 0, s, lens, n, nchunks, ptr<int64_t>(sums));
+  hipLaunchKernelGGL(k_scan_block_sums, dim3(1), dim3(1024), 0, s, ptr<int64_t>(sums), nchunks, ptr<int64_t>(total));
+  hipLaunchKernelGGL(k_chunk_offsets, dim3(grid), dim3(kBlock), 0, s, lens, n, nchunks, ptr<const int64_t>(sums), offsets, (uint8_t*)nullptr, (int64_t)validity_bytes(n),
+                     (unsigned long long*)nullptr);
+  CS_HIP(hipGetLastError());
+}
 // offsets and the validity mask (length >= 0) of a column in the same pass over its lengths
 int64_t offsets_and_validity_from_lengths(const int32_t* lens, int64_t n, int64_t* offsets, Buf* validity, hipStream_t s, LenMeta* meta) {
   if (n == 0 || cs::cfg("CS_SCAN_BY_WORKGROUPS")) {

@@ -164,6 +164,7 @@ struct LenMeta {
 };
 int64_t offsets_from_lengths(const int32_t* lens, int64_t n, int64_t* offsets, hipStream_t s,
                              Buf block_sums = nullptr, LenMeta* meta = nullptr);
+void offsets_from_lengths_async(const int32_t* lens, int64_t n, int64_t* offsets, hipStream_t s);  // nothing read back, no wait: the total is offsets[n] on the device
 // the same and the validity mask (length >= 0) from one pass over the lengths
 int64_t offsets_and_validity_from_lengths(const int32_t* lens, int64_t n, int64_t* offsets, Buf* validity, hipStream_t s, LenMeta* meta = nullptr);
 // Segmented variant: `segs` independent arrays of n lengths laid out back to

@@ -149,7 +149,7 @@ void radix_sort_pairs64(uint64_t* keys, int32_t* items, int64_t n, hipStream_t s
     if (trivial) continue;  // every key holds the same digit here: the pass would be the identity
     const int shift = 8 * pass;
     hipLaunchKernelGGL(k_radix_count, dim3((unsigned)ntiles), dim3(kRadixThreads), 0, s, kin, n, shift, ntiles, ptr<int32_t>(counts));
-    offsets_from_lengths(ptr<int32_t>(counts), 256 * ntiles, ptr<int64_t>(bases), s);
+    offsets_from_lengths_async(ptr<int32_t>(counts), 256 * ntiles, ptr<int64_t>(bases), s);  // (no round trip to the host inside the passes)
     hipLaunchKernelGGL(k_radix_scatter, dim3((unsigned)ntiles), dim3(kRadixThreads), 0, s, kin, iin, n, shift, ntiles, ptr<const int64_t>(bases), kout,
                        iout);
     std::swap(kin, kout);

@@ -72,6 +72,18 @@ def make_column(seed, max_rows=40_000):
         toks = [bytes([c]) for c in b"abcab 12.3 XY"] + ["é".encode(), "É".encode(), "€".encode(), "😀".encode(), "İ".encode(), "ß".encode()]
         data = b"".join(toks[i] for i in rng.integers(0, len(toks), int(offs[-1]) + 4))
         chars = np.frombuffer(data[:int(offs[-1])], dtype=np.uint8).copy()
+    if flavour == 1 and (seed // 28) % 2 == 1 and int(offs[-1]) >= 2:
+        # ASCII text with a FEW rows that hold a two-byte character or a NUL -- and such a byte where the sample's first
+        # window sees it: the rows the scans put off and the single-pass replace leaves holes (cs_regex.hip: deferred / hole_mask)
+        for r in np.flatnonzero((rng.random(rows) < 0.01) & (lens >= 2)):
+            k = int(offs[r]) + int(rng.integers(0, int(lens[r]) - 1))
+            if rng.random() < 0.8:
+                chars[k], chars[k + 1] = 0xC3, 0xA9
+            else:
+                chars[k] = 0
+        r0 = int(np.argmax(lens >= 2))
+        if lens[r0] >= 2:
+            chars[int(offs[r0])], chars[int(offs[r0]) + 1] = 0xC3, 0xA9
     valid = np.packbits(rng.random(rows) > 0.03, bitorder="little") if seed % 4 else None
     return cpulibs.Col(chars, offs, valid), flavour
 
