@@ -148,10 +148,8 @@ __global__ void __launch_bounds__(256, 8) k_cat_insert(ColView in, Entry* table,
                                                     int* __restrict__ overflow, int probe_limit, int dbg, int sw, int64_t stride = 1, int64_t count = -1) {
   // (`stride` / `count`: the sampling launch takes rows 0, stride, 2 stride, ... -- `count` of them; the slot ids it writes
   // for those rows are overwritten by the full pass that follows)
-  // (a grid of a few workgroups per resident slot, every thread taking rows a grid apart: one row a thread was 488K workgroups
-  // for 125M rows, and at K = 1000 -- the table in the L2 -- the kernel ran at the rate the workgroups were dispatched at)
-  const int64_t todo = count >= 0 ? count : in.rows;
-  for (int64_t idx = (int64_t)blockIdx.x * kBlock + threadIdx.x; idx < todo; idx += (int64_t)gridDim.x * kBlock) [&] {
+  const int64_t idx = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (idx >= (count >= 0 ? count : in.rows)) return;
   const int64_t r = idx * stride;
   if (r >= in.rows) return;
   // a table that turned out too small: the launch is lost, the workgroups that have not begun yet leave at once
@@ -258,7 +256,6 @@ __global__ void __launch_bounds__(256, 8) k_cat_insert(ColView in, Entry* table,
     }
   }
   slot_of_row[r] = (int32_t)slot;
-  }();
 }
 // (slots of `sw` words: the later passes read the slot words from `dense`, one per slot)
 __global__ void k_cat_flags(const Entry* __restrict__ table, int64_t cap, int sw, int32_t* __restrict__ flags, Entry* __restrict__ dense) {
@@ -464,23 +461,21 @@ __global__ void k_cat_ranks(const int32_t* __restrict__ item, int64_t uniq, int 
 // with 4-byte requests and one look-up a lane outstanding: 0.75 ms for 125M rows)
 __global__ void k_cat_values(const int32_t* __restrict__ slot_of_row, const int32_t* __restrict__ rank_of_slot,
                              int64_t rows, int32_t* __restrict__ values) {
-  // (the slot ids are read once and the values written once: both pass the caches by, which the rank table keeps)
-  typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
-  for (int64_t r = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * 4; r < rows; r += (int64_t)gridDim.x * kBlock * 4) {
-    if (r + 4 <= rows) {
-      const i32x4 s = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(slot_of_row + r));
-      i32x4 v;
-      v.x = s.x < 0 ? 0 : rank_of_slot[s.x];  // a null row maps to key 0 (the null key)
-      v.y = s.y < 0 ? 0 : rank_of_slot[s.y];
-      v.z = s.z < 0 ? 0 : rank_of_slot[s.z];
-      v.w = s.w < 0 ? 0 : rank_of_slot[s.w];
-      __builtin_nontemporal_store(v, reinterpret_cast<i32x4*>(values + r));
-      continue;
-    }
-    for (int64_t i = r; i < rows; ++i) {
-      const int32_t s = slot_of_row[i];
-      values[i] = s < 0 ? 0 : rank_of_slot[s];
-    }
+  const int64_t r = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * 4;
+  if (r >= rows) return;
+  if (r + 4 <= rows) {
+    const int4 s = *reinterpret_cast<const int4*>(slot_of_row + r);
+    int4 v;
+    v.x = s.x < 0 ? 0 : rank_of_slot[s.x];  // a null row maps to key 0 (the null key)
+    v.y = s.y < 0 ? 0 : rank_of_slot[s.y];
+    v.z = s.z < 0 ? 0 : rank_of_slot[s.z];
+    v.w = s.w < 0 ? 0 : rank_of_slot[s.w];
+    *reinterpret_cast<int4*>(values + r) = v;
+    return;
+  }
+  for (int64_t i = r; i < rows; ++i) {
+    const int32_t s = slot_of_row[i];
+    values[i] = s < 0 ? 0 : rank_of_slot[s];
   }
 }
 __global__ void k_key_sizes(ColView in, const Entry* __restrict__ table, const int32_t* __restrict__ item,
@@ -510,13 +505,6 @@ __global__ void k_remap(const int32_t* __restrict__ codes, int64_t n, const int3
   if (i >= n) return;
   int32_t v = codes[i];
   out[i] = v < 0 ? v : table[v];
-}
-
-// workgroups for a kernel whose threads take rows a grid apart: CS_CAT_GRID_X (4) times what is resident at once
-unsigned row_grid(const void* kern, unsigned wanted) {
-  const int64_t x = std::max(1, cs::cfg_int("CS_CAT_GRID_X", 4));
-  if (x >= 1000) return wanted;  // (measurement: a row a thread, as before)
-  return (unsigned)std::min<int64_t>(wanted, (int64_t)resident_grid(kern, 0, (int64_t)1 << 40) * x);
 }
 
 template <class T>
@@ -571,7 +559,7 @@ cs_category* cs::category_build(const cs_column* col, hipStream_t s) {
       ProfScope ps("k_cat_insert", s);
       const int limit = cap == full ? 0x7fffffff : kProbeLimit;
       const int dbg = cs::cfg_int("CS_CAT_DEBUG", 0);
-      hipLaunchKernelGGL(k_cat_insert, dim3(row_grid(reinterpret_cast<const void*>(&k_cat_insert), blocks_for(rows))), dim3(kBlock), 0, s, in, ptr<Entry>(table),
+      hipLaunchKernelGGL(k_cat_insert, dim3(blocks_for(rows)), dim3(kBlock), 0, s, in, ptr<Entry>(table),
                          (uint32_t)(cap - 1), ptr<int32_t>(slot_of_row), ptr<int>(flags_d), ptr<int>(flags_d) + 1, limit,
                          dbg, sw);
     }
@@ -594,7 +582,7 @@ cs_category* cs::category_build(const cs_column* col, hipStream_t s) {
       // (a stride rounded UP, so that the sample spans the whole column -- rounded down it stopped short of the column's end,
       // by almost half of it when the column has just under 2 x kSampleRows rows)
       const int64_t sample_stride = (rows + kSampleRows - 1) / kSampleRows, sample_rows = (rows + sample_stride - 1) / sample_stride;
-      hipLaunchKernelGGL(k_cat_insert, dim3(row_grid(reinterpret_cast<const void*>(&k_cat_insert), blocks_for(sample_rows))), dim3(kBlock), 0, s, in, ptr<Entry>(table), (uint32_t)(cap - 1),
+      hipLaunchKernelGGL(k_cat_insert, dim3(blocks_for(sample_rows)), dim3(kBlock), 0, s, in, ptr<Entry>(table), (uint32_t)(cap - 1),
                          ptr<int32_t>(slot_of_row), ptr<int>(flags_d), ptr<int>(flags_d) + 1, 0x7fffffff, 0, sw, sample_stride, sample_rows);
       Buf occ = dev_alloc(sizeof(int32_t) * cap, s);
       hipLaunchKernelGGL(k_cat_flags, dim3(blocks_for(cap)), dim3(kBlock), 0, s, ptr<const Entry>(table), cap, sw, ptr<int32_t>(occ), (Entry*)nullptr);
@@ -721,7 +709,7 @@ cs_category* cs::category_build(const cs_column* col, hipStream_t s) {
   cat->values = dev_alloc(sizeof(int32_t) * rows, s);
   {
     ProfScope ps("k_cat_values", s);
-    hipLaunchKernelGGL(k_cat_values, dim3(row_grid(reinterpret_cast<const void*>(&k_cat_values), blocks_for((rows + 3) / 4))), dim3(kBlock), 0, s, ptr<const int32_t>(slot_of_row),
+    hipLaunchKernelGGL(k_cat_values, dim3(blocks_for((rows + 3) / 4)), dim3(kBlock), 0, s, ptr<const int32_t>(slot_of_row),
                        ptr<const int32_t>(rank_of_slot), rows, ptr<int32_t>(cat->values));
   }
   // keys column
