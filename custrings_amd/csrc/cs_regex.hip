@@ -543,6 +543,7 @@ __global__ void __launch_bounds__(256) k_tdfa_replace_list(RowSrc src, TLaunch L
   const ColView& in = src.in;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256) {
     const int64_t r = list[i];
+    if (!row_is_valid(in.validity, r)) continue;  // (a null row over bytes of the chars: no hole was left for it)
     const int64_t b = in.offsets[r];
     const int n = (int)(in.offsets[r + 1] - b);
     const uint8_t* p = in.chars + b;
@@ -1337,8 +1338,9 @@ __global__ void __launch_bounds__(256, ((BREFS && !CHAIN) || (BITS && IN_LDS)) ?
   // like the offsets (unconditionally, from a harmless address when the launch has none: see the note at the first poll)
   constexpr bool kHoles = !BREFS && !LONG && !OUTL && !WIDE;
   const bool holes = kHoles && a.hole_mask != nullptr;
-  const unsigned long long* hole_mask_p = holes ? a.hole_mask : reinterpret_cast<const unsigned long long*>(a.tickets);
-  const int64_t* hole_first_p = holes ? a.hole_first : reinterpret_cast<const int64_t*>(a.tickets);
+  // (the column's first offsets: read-only, sixteen bytes at least -- not the ticket words, which every wave's atomics hammer)
+  const unsigned long long* hole_mask_p = holes ? a.hole_mask : reinterpret_cast<const unsigned long long*>(in.offsets);
+  const int64_t* hole_first_p = holes ? a.hole_first : in.offsets;
   unsigned long long c_hm = 0;
   long long c_hf = 0;
   if (kHoles) {

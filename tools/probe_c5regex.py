@@ -65,6 +65,28 @@ def main():
                                   "ms": round(dt * 1e3, 3), "kernels_ms": ks, "route": L.cs_debug_last_route().decode()}), flush=True)
             L.cs_regex_destroy(re0)
             del tmp
+            # ... and the first replace_re on a fresh column also lists the column's rows with bytes >= 0x80 (cs_virtual.hip: OddRows)
+            col = None
+            out3 = C.c_void_p()
+            _lib.check(L.cs_synth_column(kind, 0, rows, B.SEED + 8, 0, None, C.byref(out3)))
+            col = nvstrings.nvstrings(out3.value)
+            L.cs_prof_reset()
+            L.cs_prof_enable(1)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            r = col.replace(IPV4, "<IP>")
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            L.cs_prof_enable(0)
+            del r
+            ks = {}
+            for k in ("k_virt_count", "k_virt_write", "k_odd_masks", "k_tdfa_replace_list", "k_replace_re"):
+                ms, n = C.c_double(), C.c_int64()
+                L.cs_prof_get(k.encode(), C.byref(ms), C.byref(n))
+                if n.value:
+                    ks[k] = round(ms.value / n.value, 3)
+            print(json.dumps({"config": name, "op": "replace_re, FIRST regex op on a fresh column (builds its pieces and the list of their rows with bytes >= 0x80), warm pool",
+                              "pattern": "ipv4", "rows": rows, "ms": round(dt * 1e3, 3), "kernels_ms": ks, "route": L.cs_debug_last_route().decode()}), flush=True)
             nb = B.nbytes(col)
         import numpy as np
 
