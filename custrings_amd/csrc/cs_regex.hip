@@ -1177,8 +1177,11 @@ __device__ __forceinline__ void bits_classify16(const uint32_t* spread, const ui
 // OUTL: the buffers are sized for all but a few sub-tiles (one long row among millions of short ones); an oversize
 // sub-tile's rows are sized and written a thread each, straight from memory, inside the prefix chain (separate forms:
 // the code costs the others registers).
+// HOLES: the hole words of StreamArgs are compiled in.  On by default -- the chain, bit and plain forms measured the same with
+// and without them -- but the unit form proper (UNITS, no CHAIN), which literal needles ride too, lost 15 % to the eight registers
+// (replace('a','xx') on C2: 0.73 -> 0.83 ms): it exists in both variants, and the host takes the one with holes only when it has some.
 template <bool IN_LDS, bool REP16, bool INPLACE, bool RESCAN = false, bool LONG = false, bool UNITS = false, int PF = cstile::kPfChunks, bool BREFS = false,
-          bool WIDE = false, bool OUTL = false, bool CHAIN = false, bool BITS = false>
+          bool WIDE = false, bool OUTL = false, bool CHAIN = false, bool BITS = false, bool HOLES = true>
 __global__ void __launch_bounds__(256, ((BREFS && !CHAIN) || (BITS && IN_LDS)) ? 2 : CS_STREAM_WAVES) k_tdfa_replace_stream(StreamArgs a) {
   // BITS (a CHAIN form): the pattern has a bit-parallel form (regex_bits.h) -- one bitmap per character class, staged by
   // table lookup; the row lanes derive their rows' matches from the class masks (alternations of word-bounded literals,
@@ -1336,7 +1339,11 @@ __global__ void __launch_bounds__(256, ((BREFS && !CHAIN) || (BITS && IN_LDS)) ?
   int m_span = 0;  // the output column's largest 64-row span as a by-product (wave-uniform: a scalar maximum per sub-tile)
   // HOLES: the tile's mask of rows that are sized and written elsewhere, and where their sizes begin -- fetched a tile ahead,
   // like the offsets (unconditionally, from a harmless address when the launch has none: see the note at the first poll)
-  constexpr bool kHoles = !BREFS && !LONG && !OUTL && !WIDE;
+#if defined(CS_NO_HOLE_FORMS)  // (measurement: the kernels without the hole words)
+  constexpr bool kHoles = false;
+#else
+  constexpr bool kHoles = HOLES && !BREFS && !LONG && !OUTL && !WIDE;
+#endif
   const bool holes = kHoles && a.hole_mask != nullptr;
   // (the column's first offsets: read-only, sixteen bytes at least -- not the ticket words, which every wave's atomics hammer)
   const unsigned long long* hole_mask_p = holes ? a.hole_mask : reinterpret_cast<const unsigned long long*>(in.offsets);
@@ -3600,10 +3607,16 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
         else if (chain_form)
           kern = rb > 8 ? &k_tdfa_replace_stream<true, true, false, true, false, true, 5, false, false, false, true>
                         : &k_tdfa_replace_stream<true, false, false, true, false, true, 5, false, false, false, true>;
-        else if (units && cap <= 5 * 1024)
+        else if (units && cap <= 5 * 1024 && with_holes)
           kern = rb > 8 ? &k_tdfa_replace_stream<true, true, false, true, false, true, 5> : &k_tdfa_replace_stream<true, false, false, true, false, true, 5>;
-        else if (units)
+        else if (units && with_holes)
           kern = rb > 8 ? &k_tdfa_replace_stream<true, true, false, true, false, true> : &k_tdfa_replace_stream<true, false, false, true, false, true>;
+        else if (units && cap <= 5 * 1024)
+          kern = rb > 8 ? &k_tdfa_replace_stream<true, true, false, true, false, true, 5, false, false, false, false, false, false>
+                        : &k_tdfa_replace_stream<true, false, false, true, false, true, 5, false, false, false, false, false, false>;
+        else if (units)
+          kern = rb > 8 ? &k_tdfa_replace_stream<true, true, false, true, false, true, cstile::kPfChunks, false, false, false, false, false, false>
+                        : &k_tdfa_replace_stream<true, false, false, true, false, true, cstile::kPfChunks, false, false, false, false, false, false>;
         note_route(bits_form ? "bits" : bchain ? "brefs-chain" : brefs ? "brefs" : literal ? "literal" : wide_stream ? "wide" : units ? (((re->tdfa[30] >> 16) & 15) != 0 ? "chain" : "units") : "plain");
         if (with_holes) note_route_put_off();
         if (lds1 > 48 * 1024)
