@@ -2756,18 +2756,21 @@ double candidate_share(const cs_regex* re, const cs_column* col, hipStream_t s) 
   }
   return all ? (double)cand / (double)all : 0.0;
 }
-// Rows with a byte >= 0x80 or a NUL, by the column's sample: are they few enough (at most one row in twenty -- an upper bound: every
-// such byte counted as a row of its own) for a scan to put them off (ScanStreamArgs::deferred) and run as on plain ASCII?
+// Rows with a byte >= 0x80 or a NUL, by the column's sample: are they few enough (at most about one row in thirty -- an upper
+// bound: every lead byte and every NUL counted as a row of its own) for a scan to put them off (ScanStreamArgs::deferred) and run
+// as on plain ASCII?  (Measured on the C2 column, one row in twenty: the bit form's ops gain -- gtest contains_re 1.08 -> 0.57 ms,
+// replace_re 2.31 -> 1.56 --, but a pattern whose generic scan is slow pays more for its rows on the list, a thread each, than the
+// sub-tiles cost row by row: `[a-z]+ing\b` replace_re 3.9 -> 5.6, `\d+` 0.72 -> 1.35.  At one row in 170 -- C5 -- everything gains.)
 bool odd_rows_few(const cs_column* col, hipStream_t s) {
   if (cs::cfg("CS_NO_DEFERRED_ROWS") || col->rows == 0) return false;
   const uint32_t* hist = sample_byte_hist(col, s);
   uint64_t all = 0, oddb = hist[0];
   for (unsigned c = 0; c < 256; ++c) {
     all += hist[c];
-    if (c >= 128) oddb += hist[c];
+    if (c >= 0xC0) oddb += hist[c];  // (one lead byte a character; a stray continuation byte has no lead in front of it -- rare enough not to matter for a hint)
   }
   if (all == 0) return false;
-  return (double)oddb / (double)all * ((double)col->nbytes / (double)col->rows) <= 0.05;
+  return (double)oddb / (double)all * ((double)col->nbytes / (double)col->rows) <= cs::cfg_int("CS_ODD_ROWS_PERMILLE", 30) / 1000.0;
 }
 bool bits_route(const cs_regex* re, const cs_column* col, hipStream_t s, int op, bool high_ok = false) {
   if (re->bits.empty() || cs::cfg("CS_NO_BITS_FORM")) return false;
@@ -2789,7 +2792,10 @@ bool bits_route(const cs_regex* re, const cs_column* col, hipStream_t s, int op,
   const bool threads3 = re->tdfa[12] >= 3;
   if (op == BITS_COUNT) return f >= 0.02;
   // (the C5 column's pieces, the gtest pattern, 4.8 %: 4.0 / 7.1 -- the line between the 2.4 % tie and 7.2 % moved from 5 % to 3.5 %)
-  if (op == BITS_CONTAINS) return (f >= 0.035 && f <= 0.5) || (threads3 && f >= 0.02 && f <= 0.5);
+  // (candidates everywhere and assertions behind the `+` loop -- `[^ ]+$` --: the first-match scan does not "find a match at once",
+  // it fails at every start: 8.4 ms on the C3 column against the bit form's 2.3)
+  const bool tail = (re->bits[2] & csbits::F_TAIL) != 0;
+  if (op == BITS_CONTAINS) return (f >= 0.035 && (f <= 0.5 || tail)) || (threads3 && f >= 0.02 && f <= 0.5);
   // (a pattern whose shortest match is one byte matches at most of its candidates: the automaton's routes then pay per match --
   // replace_re('e') on the C3 column, 4 % candidates: units 7.65, the bit form 6.45 ms)
   return f >= 0.05 || ((threads3 || re->tdfa[13] == 1) && f >= 0.02);

@@ -28,6 +28,7 @@ struct Alt {
   std::vector<Item> items;
   int len = 0;
   bool plus = false;
+  std::vector<int> tail;  // assertions behind the trailing `+` loop (kinds)
 };
 using Members = std::array<uint32_t, 4>;  // ASCII member set of a consuming instruction
 
@@ -129,9 +130,22 @@ struct Walker {
       if (nx >= 0 && (size_t)nx < prog.insts.size() && prog.insts[(size_t)nx].type == OP_OR) {
         const Inst& orr = prog.insts[(size_t)nx];
         if (skip_brackets(orr.u1) == pc) {
-          const int out = skip_brackets(orr.u2);
+          int out = skip_brackets(orr.u2);
           // (brackets between the item and the OR would close and re-open a group inside the loop: only whole matches are
           // reported, so they do not matter)
+          // behind the loop: END, or up to three assertions and END (the tail: `[^ ]+$`, `\w+\b`)
+          while (out >= 0 && (size_t)out < prog.insts.size() && cur.tail.size() < 3) {
+            const Inst& t = prog.insts[(size_t)out];
+            int kind = -1;
+            if (t.type == OP_BOW) kind = csbits::K_BOW;
+            else if (t.type == OP_NBOW) kind = csbits::K_NBOW;
+            else if (t.type == OP_BOL) kind = (uint32_t)t.u1 == (uint32_t)'^' ? csbits::K_BOL_MULTI : csbits::K_BOL;
+            else if (t.type == OP_EOL) kind = (uint32_t)t.u1 == (uint32_t)'$' ? csbits::K_EOL_MULTI : csbits::K_EOL;
+            if (kind < 0) break;
+            cur.tail.push_back(kind);
+            out = skip_brackets(t.u2);
+          }
+          if (cs::cfg("CS_NO_BITS_TAIL") && !cur.tail.empty()) out = -1;
           if (out < 0 || (size_t)out >= prog.insts.size() || prog.insts[(size_t)out].type != OP_END || !alts.empty()) {
             ok = false;
             return;
@@ -174,6 +188,12 @@ std::vector<int32_t> build_bits(const Program& prog, const std::vector<int32_t>&
       if (it.kind == csbits::K_BOL_MULTI) fl |= csbits::F_BOL_MULTI;
       if (it.kind == csbits::K_EOL_MULTI) fl |= csbits::F_EOL_MULTI;
     }
+  for (const Alt& a : w.alts)
+    for (int kind : a.tail) {  // (the tail's masks are built where they are used, but the classes they read must exist)
+      if (kind == csbits::K_BOW || kind == csbits::K_NBOW) fl |= csbits::F_WORD;
+      if (kind == csbits::K_BOL_MULTI) fl |= csbits::F_BOL_MULTI;
+      if (kind == csbits::K_EOL_MULTI) fl |= csbits::F_EOL_MULTI;
+    }
   int word_cls = -1, nl_cls = -1;
   if (fl & csbits::F_WORD) {
     Members m{0, 0, 0, 0};
@@ -192,12 +212,14 @@ std::vector<int32_t> build_bits(const Program& prog, const std::vector<int32_t>&
   if (first.plus) {
     plus_cls = first.items.back().arg;
     fl |= csbits::F_PLUS;
-    if (first.items.size() == 1) fl |= csbits::F_PURE_PLUS;
+    if (first.items.size() == 1 && first.tail.empty()) fl |= csbits::F_PURE_PLUS;
+    if (!first.tail.empty()) fl |= csbits::F_TAIL;
+    if (!first.tail.empty() && first.items.size() == 1 && !cs::cfg("CS_NO_BITS_PURE_TAIL")) fl |= csbits::F_PURE_TAIL;
   }
   bool same = true;
   for (const Alt& a : w.alts) same = same && a.len == first.len;
   if (same) fl |= csbits::F_SAME_LEN;
-  if (w.alts.size() == 1 && first.items.size() == 1 && first.items[0].kind == csbits::K_CLASS) {
+  if (w.alts.size() == 1 && first.items.size() == 1 && first.items[0].kind == csbits::K_CLASS && first.tail.empty()) {
     const Inst& in = prog.insts[(size_t)first.items[0].inst];
     bool bytewise = false, high = false;
     if (in.type == OP_CHAR) {
@@ -236,6 +258,11 @@ std::vector<int32_t> build_bits(const Program& prog, const std::vector<int32_t>&
   for (const Alt& a : w.alts) {
     img.push_back((int32_t)(a.items.size() | ((size_t)a.len << 8)));
     for (const Item& it : a.items) img.push_back(it.kind | (it.arg << 8) | (it.off << 16));
+  }
+  if (!first.tail.empty()) {
+    uint32_t tw = (uint32_t)first.tail.size();
+    for (size_t i = 0; i < first.tail.size(); ++i) tw |= (uint32_t)first.tail[i] << (8 * (i + 1));
+    img.push_back((int32_t)tw);
   }
   img[4] = (int32_t)img.size();
   return img;

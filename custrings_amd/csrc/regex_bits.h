@@ -8,8 +8,8 @@
 // the start to END number at most kMaxAlts -- alternations and optional parts expand into ALTERNATIVES, in the order in
 // which the reference's executor prefers them (regexec.inl:204-442: the OR's preferred branch first) --, every path a
 // sequence of single-character items (literal, class, `.`) and assertions (\b \B ^ $ \A \Z) of fixed length 1..31; or ONE
-// such path that ends in a greedy `+` loop over its last item (`[aeiou]+`, `#\w+`).  At most kMaxClasses distinct ASCII
-// member sets over all items.
+// such path that ends in a greedy `+` loop over its last item (`[aeiou]+`, `#\w+`), with assertions behind the loop at most
+// (`[^ ]+$`, `\w+\b`: the TAIL).  At most kMaxClasses distinct ASCII member sets over all items.
 //
 // Semantics (what the reference computes, restated on masks).  Row of n bytes, all ASCII, none NUL; bit i of a class mask
 // = byte i is a member; cursor q in 0..n lies in front of byte q.  An alternative with items (X_i at offset o_i) matches
@@ -19,13 +19,17 @@
 // A_{j-1}); the match at p has alternative j's length.  Successive matches do not overlap: the next search starts at
 // the end of the last match (replace.cu:91-93, count.cu:168-250) -- a loop over the row's matches, lowest start first.
 // With a trailing `+` the match runs to the end of the run of its last class (greedy, nothing follows that could ask
-// for less).  An alternative cannot match the empty string (such programs do not convert).
+// for less).  With a tail the loop's exits are tried longest first (the executor prefers the thread that stays in the loop):
+// the match ends at the LAST cursor of the run at which every assertion of the tail holds, and a start whose run has no such
+// cursor matches nothing (`[^ ]+$`: only the run that reaches the row's end -- the automaton's scan tried every start of every
+// run to its end: 35 ms on the C3 column).  An alternative cannot match the empty string (such programs do not convert).
 //
 // Image (int32 words):
 //   [0] magic 'CSBP' [1] classes K [2] flags [3] alternatives J [4] words in all [5] class of the trailing `+` (-1: none)
 //   [6] class holding the word characters (for \b \B; -1: not needed) [7] class holding '\n' (multi-line ^ $; -1)
 //   [8..39]  128 bytes: for every ASCII byte the set of classes it belongs to (bit k = class k)
 //   [40..]   per alternative: items | length << 8, then one word per item: kind | class << 8 | offset << 16
+//   (F_TAIL) the image's last word: assertions behind the `+` loop, count | kind << 8 | kind << 16 | kind << 24
 #pragma once
 #include <stdint.h>
 
@@ -53,7 +57,9 @@ enum { F_WORD = 1, F_BOL = 2, F_EOL = 4, F_BOL_MULTI = 8, F_EOL_MULTI = 16, F_PU
        // ... or ONE class of ASCII ranges and builtin classes (`\w+`, `[\w.]`, `\S+`, `[^\d]`): byte by byte on text WITHOUT bytes >= 0x80;
        // a non-ASCII character is a member through the unicode flags alone -- bits 16..21 the class's builtins (regex_vm.h:
        // class_match), bit 22 the class is negated: cs_runs.hip takes tiles with such bytes row by row, decoding as the reference does
-       F_FLAG_CLASS = 1024 };
+       F_FLAG_CLASS = 1024,
+       F_TAIL = 2048,        // assertions behind the trailing `+` loop (the image's last word)
+       F_PURE_TAIL = 4096 };  // ... behind `[set]+` alone (`[^ ]+$`): the matches from the tail's cursors, a step per MATCH
 enum { K_CLASS = 0, K_BOW = 1, K_NBOW = 2, K_BOL = 3, K_EOL = 4, K_BOL_MULTI = 5, K_EOL_MULTI = 6 };
 
 struct View {
@@ -156,6 +162,9 @@ CS_HD unsigned m_test(M96 x, int q) { return ((q < 32 ? x.a : (q < 64 ? x.b : x.
 CS_HD int m_ctz(M96 x) {  // x != 0
   return x.a ? __builtin_ctz(x.a) : (x.b ? 32 + __builtin_ctz(x.b) : 64 + __builtin_ctz(x.c));
 }
+CS_HD int m_top(M96 x) {  // x != 0: its highest set bit
+  return x.c ? 95 - __builtin_clz(x.c) : (x.b ? 63 - __builtin_clz(x.b) : 31 - __builtin_clz(x.a));
+}
 CS_HD M96 m_from(U128 x) { return m96((uint32_t)x.lo, (uint32_t)(x.lo >> 32), (uint32_t)x.hi); }
 CS_HD U128 m_to128(M96 x) { return cstd::u128(x.a | ((unsigned long long)x.b << 32), x.c); }
 
@@ -216,6 +225,48 @@ CS_HD M96 starts(const View& V, Cls&& cls, Raw&& raw, int n, bool want_len, M96 
   return any;
 }
 
+// F_TAIL: the cursors at which every assertion behind the `+` loop holds
+template <class Cls>
+CS_HD M96 tail_cursors(const View& V, Cls&& cls, int n) {
+  const M96 cursors = m_below(n + 1);
+  M96 X = cursors;
+  const uint32_t tw = (uint32_t)CSBITS_UNIFORM(V.img[CSBITS_UNIFORM(V.img[4]) - 1]);
+  const int cnt = (int)(tw & 255u);
+  for (int i = 0; i < cnt && i < 3; ++i) {
+    const int kind = (int)((tw >> (8 * (i + 1))) & 255u);
+    M96 A;
+    if (kind == K_BOW || kind == K_NBOW) {
+      const M96 W = cls(V.word_cls, 0);
+      const M96 L = m_shl1(W);
+      const M96 bnd = m_and(m96(W.a ^ L.a, W.b ^ L.b, W.c ^ L.c), cursors);
+      A = kind == K_BOW ? bnd : m_andn(cursors, bnd);
+    } else if (kind == K_BOL) {
+      A = m96(1, 0, 0);
+    } else if (kind == K_EOL) {
+      A = m_bit(n);
+    } else {
+      const M96 NL = cls(V.nl_cls, 0);
+      A = kind == K_BOL_MULTI ? m_or(m96(1, 0, 0), m_and(m_shl1(NL), cursors)) : m_or(m_bit(n), NL);
+    }
+    X = m_and(X, A);
+  }
+  return X;
+}
+// the cursor behind the match that starts with its fixed part ending at cursor `end` (F_PLUS): the end of the run of the last
+// class -- with a tail the last cursor of the run at which the tail holds, -1 when there is none
+// (`run_end`: where the run ends either way.  A start that fails takes with it every later start whose fixed part still ends
+// inside the same run -- its exits are a subset: the callers drop the starts up to run_end - length at once, so a row costs a
+// step per RUN, not per byte: `[^ ]+$` walked 55 failing starts a log line one by one, 44 ms on the C3 column)
+CS_HD int plus_end(const View& V, M96 C, M96 X, int end, int& run_end) {
+  // the run goes on from the match's last fixed byte: its end is the first non-member at or behind `end` (the row's end at
+  // the latest: C is cut there, and n <= 95 leaves bit 95 clear)
+  const M96 stop = m_andn(m96(~0u, ~0u, ~0u), m_or(C, m_below(end)));
+  run_end = m_ctz(stop);
+  if (!(V.flags & F_TAIL)) return run_end;
+  const M96 cand = m_andn(m_and(X, m_below(run_end + 1)), m_below(end));
+  return m_any(cand) ? m_top(cand) : -1;
+}
+
 // The row's matches in order, non-overlapping: S = first bytes, E = last bytes (one bit each per match).
 template <class Cls, class Raw>
 CS_HD void match(const View& V, Cls&& cls, Raw&& raw, int n, U128& S128, U128& E128) {
@@ -225,12 +276,32 @@ CS_HD void match(const View& V, Cls&& cls, Raw&& raw, int n, U128& S128, U128& E
     E128 = m_to128(m_andn(C, m_shr1(C)));
     return;
   }
+  if (V.flags & F_PURE_TAIL) {
+    // `[set]+` and a tail: a run of the class holds at most one match -- from the run's first byte to the LAST cursor inside
+    // the run at which the tail holds (what is left of the run behind it has no exit).  From the top: every tail cursor with a
+    // member in front of it ends a match unless a higher one of its run did.
+    const M96 C = cls(V.plus_cls, 0);
+    M96 K = m_and(tail_cursors(V, cls, n), m_shl1(C));
+    M96 S = m96(0, 0, 0), E = m96(0, 0, 0);
+    while (m_any(K)) {
+      const int q = m_top(K);
+      const M96 out = m_andn(m_below(q), C);  // the non-members in front of q
+      const int s0 = m_any(out) ? m_top(out) + 1 : 0;
+      S = m_or(S, m_bit(s0));
+      E = m_or(E, m_bit(q - 1));
+      K = m_and(K, m_below(s0 + 1));
+    }
+    S128 = m_to128(S);
+    E128 = m_to128(E);
+    return;
+  }
   M96 plane[5];
   const bool same_len = (V.flags & F_SAME_LEN) != 0;  // (one length for every alternative: no planes)
   const int the_len = CSBITS_UNIFORM(V.img[kHeaderWords + kTableWords]) >> 8 & 255;
   M96 rem = starts(V, cls, raw, n, !same_len, plane);
-  M96 S = m96(0, 0, 0), E = m96(0, 0, 0), C = m96(0, 0, 0);
+  M96 S = m96(0, 0, 0), E = m96(0, 0, 0), C = m96(0, 0, 0), X = m96(0, 0, 0);
   if (V.flags & F_PLUS) C = cls(V.plus_cls, 0);
+  if (V.flags & F_TAIL) X = tail_cursors(V, cls, n);
   while (m_any(rem)) {
     const int p = m_ctz(rem);
     int len = the_len;
@@ -240,10 +311,13 @@ CS_HD void match(const View& V, Cls&& cls, Raw&& raw, int n, U128& S128, U128& E
     }
     int end = p + len;  // the cursor behind the match
     if (V.flags & F_PLUS) {
-      // the run of the last class goes on from the match's last fixed byte: its end is the first non-member at or behind
-      // `end` (the row's end at the latest: C is cut there, and n <= 95 leaves bit 95 clear)
-      const M96 stop = m_andn(m96(~0u, ~0u, ~0u), m_or(C, m_below(end)));
-      end = m_ctz(stop);
+      int run_end;
+      end = plus_end(V, C, X, end, run_end);
+      if (end < 0) {  // (no exit of the loop passes the tail: nothing matches at this start, nor at the starts that share its run)
+        const int upto = run_end - len + 1;
+        rem = m_andn(rem, m_below(upto > p + 1 ? upto : p + 1));
+        continue;
+      }
     }
     S = m_or(S, m_bit(p));
     E = m_or(E, m_bit(end - 1));
@@ -256,12 +330,32 @@ CS_HD void match(const View& V, Cls&& cls, Raw&& raw, int n, U128& S128, U128& E
 template <class Cls, class Raw>
 CS_HD bool contains(const View& V, Cls&& cls, Raw&& raw, int n) {
   M96 unused[5];
+  if (V.flags & F_PURE_TAIL) return m_any(m_and(tail_cursors(V, cls, n), m_shl1(cls(V.plus_cls, 0))));  // (a tail cursor with a member in front of it)
+  if (V.flags & F_TAIL) {  // (a start counts only with an exit of its loop that passes the tail: one alternative, one length)
+    M96 rem = starts(V, cls, raw, n, false, unused);
+    const int len = CSBITS_UNIFORM(V.img[kHeaderWords + kTableWords]) >> 8 & 255;
+    const M96 C = cls(V.plus_cls, 0), X = tail_cursors(V, cls, n);
+    while (m_any(rem)) {
+      const int p = m_ctz(rem);
+      int run_end;
+      if (plus_end(V, C, X, p + len, run_end) >= 0) return true;
+      const int upto = run_end - len + 1;
+      rem = m_andn(rem, m_below(upto > p + 1 ? upto : p + 1));
+    }
+    return false;
+  }
   return m_any(starts(V, cls, raw, n, false, unused));
 }
 template <class Cls, class Raw>
 CS_HD bool match_at_start(const View& V, Cls&& cls, Raw&& raw, int n) {
   M96 unused[5];
-  return (starts(V, cls, raw, n, false, unused).a & 1u) != 0;
+  const M96 st = starts(V, cls, raw, n, false, unused);
+  if ((st.a & 1u) && (V.flags & F_TAIL)) {
+    const int len = CSBITS_UNIFORM(V.img[kHeaderWords + kTableWords]) >> 8 & 255;
+    int run_end;
+    return plus_end(V, cls(V.plus_cls, 0), tail_cursors(V, cls, n), len, run_end) >= 0;
+  }
+  return (st.a & 1u) != 0;
 }
 
 }  // namespace csbits

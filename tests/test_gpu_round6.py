@@ -613,3 +613,38 @@ def test_gpu_replace_re_with_holes_on_the_pieces_of_long_rows():
         assert last_route().startswith("pieces:") and last_route().endswith("+later"), last_route()
         gpuutil.assert_same(got, orc.replace_re(o, blob_of(pat), repl), "replace_re(%r) on C5 (%s)" % (pat, last_route()))
         assert int(L.lib.cs_fallback_count()) == f0
+
+
+@pytest.mark.parametrize("pat,repl", [(r"[^ ]+$", "LAST"), (r"\w+\b", "w"), (r"[a-z]+\b", ""), (r"#\w+$", "<tag>"), (r"\d+$", "N"), (r"[a-e]+\B", "=")])
+def test_gpu_bit_form_with_assertions_behind_the_plus_loop(pat, repl, monkeypatch):
+    """A path that ends in a greedy `+` loop with assertions behind it (regex_bits.h: the TAIL -- the loop's exits are tried
+    longest first, a start whose run has no exit that passes matches nothing): contains_re / count_re / replace_re on the bit
+    form (forced: CS_BITS_ALWAYS) against the oracle -- log lines, rows that end in a space, a newline, a digit, nulls."""
+    monkeypatch.setenv("CS_BITS_ALWAYS", "1")
+    L = gpuutil.lib()
+    orc = cpulibs.Oracle()
+    blob = blob_of(pat)
+    rng = np.random.default_rng(4300)
+    base = orc.synth(3, 0, 30_000).to_list()
+    extra = ["the last word", "ends in space ", "ends in newline\n", "two\nlines here", "abc1", "abc_", "a_b c-d", "#tag", "x #tag", "#tag x", "", "42", "x 42", "42 x", "abcde", "abcdef x"]
+    for k, e in enumerate(extra):
+        base[1000 + 37 * k] = e
+    col = _with_nulls([r.encode() if r is not None else b"" for r in base], rng)
+    g = gpuutil.from_col(col)
+    re = gpuutil.compile_re(pat)
+    try:
+        f0 = int(L.lib.cs_fallback_count())
+        has, n = gpuutil.bools(g, "cs_contains_re", re)
+        want_has, want_n = orc.contains_re(col, blob)
+        assert np.array_equal(has, want_has) and n == want_n, (pat, last_route())
+        cnt = np.zeros(col.rows, dtype=np.int32)
+        found = C.c_int64()
+        L.check(L.lib.cs_count_re(g.m_cptr, re, cnt.ctypes.data, 0, None, C.byref(found)))
+        assert last_route() in ("bits", "chain"), last_route()  # (a chain -- `[a-z]+\b` -- keeps the chain arithmetic)
+        assert np.array_equal(cnt, orc.count_re(col, blob)[0]), pat
+        got = g.replace(pat, repl)
+        assert last_route() in ("bits", "chain"), last_route()
+        gpuutil.assert_same(got, orc.replace_re(col, blob, repl), "replace_re(%r)" % pat)
+        assert int(L.lib.cs_fallback_count()) == f0
+    finally:
+        L.lib.cs_regex_destroy(re)

@@ -31,6 +31,10 @@ FORMS = {
     r"(a|b)(c|d)": (4, 4),
     r"a*": None, r"(ab)+": None, r"a+b": None, r"\d+\.\d+": None, r"a+?": None, r"": None, r"\b": None, r"a{2,3}x": (2, 2),
     r"(a|b)*c": None, r"[a-c]+[x-z]": None, r"é": None if False else (1, 1),
+    # assertions behind the trailing `+` loop (the TAIL: the loop's exits are tried longest first)
+    # (`$` reads the newline's class, `\b` the word characters': `_` is a `\w` and not one of them)
+    r"[^ ]+$": (2, 1), r"\w+\b": (2, 1), r"[a-z]+\b": (2, 1), r"#\w+$": (3, 1), r"[a-e]+\B": (2, 1), r"\bth[a-z]+\b$": (5, 1), r"x[0-9]+\Z": (2, 1),
+    r"[^ ]+$x": None,
 }
 
 
@@ -96,8 +100,8 @@ def test_generated_alternations_vs_oracle(emu_engine, oracle_engine):
             body = "".join(rnd.choice(atoms) + rnd.choice(["", "", "", "?"]) for _ in range(rnd.randint(1, 4)))
             alts.append(rnd.choice(pre) + body + rnd.choice(post))
         pat = "|".join(alts) if rnd.random() < 0.7 else "(" + ")|(".join(alts) + ")"
-        if rnd.random() < 0.15:
-            pat = rnd.choice(pre) + rnd.choice(atoms) + rnd.choice(atoms) + "+"
+        if rnd.random() < 0.25:
+            pat = rnd.choice(pre) + rnd.choice(atoms) + rnd.choice(atoms) + "+" + rnd.choice(post) + rnd.choice(["", "", r"\b", "$"])
         if e.bits(pat) is None:
             continue
         done += 1
