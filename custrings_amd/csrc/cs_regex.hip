@@ -2949,11 +2949,18 @@ TileChoice choose_tile(const cs_column* col, hipStream_t s, bool small = false) 
 // C5 column 3.0 ms there, 5.6 on the pieces), and not -- `replacing` -- for a program that would take the unit scan on a column
 // whose sample holds bytes >= 0x80: the unit route hands every sub-tile with such a byte to the row-by-row scan, and more,
 // shorter rows make that worse (replace_re of the gtest pattern on C5: 40 ms on the pieces, 30 on the long-row form).
-const VirtualRows* pieces_for(const cs_column* col, const cs_regex* re, hipStream_t s, bool replacing) {
+const VirtualRows* pieces_for(const cs_column* col, const cs_regex* re, hipStream_t s, bool replacing, bool containing = false) {
   if (cs::cfg("CS_NO_VIRTUAL_ROWS") || col->virt_state < 0 || !use_tdfa(re) || !((re->tdfa[31] >> 25) & 1)) return nullptr;
   if (max_row_bytes(col, s) + 3 <= cstd::Tdfa::kMaskBytes) return nullptr;  // (the masks hold the rows as they are)
-  if (!re->bits.empty() && (re->bits[2] & (csbits::F_BYTE_CLASS | csbits::F_FLAG_CLASS)) && !cs::cfg("CS_NO_CLASS_RUNS")) return nullptr;
   const bool chain = ((re->tdfa[30] >> 16) & 15) != 0;
+  // One class, once or in a `+` loop: cs_runs.hip counts and replaces such a pattern byte-parallel on rows of any length -- and
+  // keeps the patterns that would take the chain arithmetic here (`[a-z]+` -> '_' on the C5 column: 11.2 ms there, 13.1 on the
+  // pieces) and the columns where bytes >= 0x80 are common (it takes them as they come; the mask forms do not).  The others go to
+  // the pieces' bit form once such rows are put off / left holes: `\w+` 27.7 -> 7.9 ms (cs_runs.hip sends every tile with such a
+  // byte row by row for a class with builtins), `[aeiou]+` 11.1 -> 8.0, count_re 2.9 -> 2.5; contains_re has no form there at all.
+  if (!containing && !re->bits.empty() && (re->bits[2] & (csbits::F_BYTE_CLASS | csbits::F_FLAG_CLASS)) && !cs::cfg("CS_NO_CLASS_RUNS") &&
+      (chain || (sample_has_high_bytes(col, s) && !odd_rows_few(col, s)) || cs::cfg("CS_CLASS_RUNS_ALWAYS")))
+    return nullptr;
   // (... unless such bytes are rare: the single pass then leaves the rows that hold them holes -- StreamArgs::hole_mask)
   if (replacing && (re->tdfa[31] & 1) && !chain && sample_has_high_bytes(col, s) && !odd_rows_few(col, s)) return nullptr;
   // The executor ends a row's scan at a NUL byte and takes a character's width from its lead byte (an ASCII byte behind a
@@ -2970,7 +2977,7 @@ void scan(const cs_column* col, cs_regex* re, uint8_t* out8, int32_t* out32, int
   note_route("");
   if (col->rows == 0) return;
   if (MODE == 0 || MODE == 2) {
-    if (const VirtualRows* vr = pieces_for(col, re, s, false)) {
+    if (const VirtualRows* vr = pieces_for(col, re, s, false, MODE == 0)) {
       const cs_column* pc = vr->col.get();
       const size_t esz1 = MODE == 2 ? 4 : 1;
       Buf piece_res = dev_alloc(esz1 * (size_t)pc->rows, s);
@@ -3324,7 +3331,7 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
     if (!cs::g_backrefs_dev && !cs::g_replace_plain_only && maxrepl < 0 && col->rows > 0 && !re->bits.empty() && (re->bits[2] & (csbits::F_BYTE_CLASS | csbits::F_FLAG_CLASS)) &&
         re->d_bits) {
       const TileChoice tc0 = choose_tile(col, s, true);
-      const bool masks_form = tc0.R == 64 && !tc0.lng && !sample_has_high_bytes(col, s);
+      const bool masks_form = tc0.R == 64 && !tc0.lng && (!sample_has_high_bytes(col, s) || odd_rows_few(col, s));  // (few rows with such bytes: holes)
       // (a class with builtins -- `\w+` -- sends every tile with a byte >= 0x80 row by row: worth it against the automaton's
       // long-row and dense forms -- `\w+` on the C5 column 97.7 -> 11.2 ms, on C2 16.2 -> 5.1 --, not against the chain
       // arithmetic where that runs: `\s+` on C2 4.4 there, 6.7 here)
