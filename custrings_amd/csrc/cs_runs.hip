@@ -46,6 +46,7 @@ struct RunsArgs {
   int flag_class;       // 0, or 1 | builtins << 8 | negated << 16: a non-ASCII character belongs through the unicode flags (regex_bits.h: F_FLAG_CLASS)
   const uint8_t* flags; // the unicode flags table (64 K entries)
   int plus;             // runs (class+) or single members
+  int nul_blind;        // the pattern is a literal character (`a`, `a+`): a NUL byte ends nothing (regex_bits.h: F_CHAR_FIRST)
   int rb;
   int count_only;       // pass 0 as count_re: a row's matches instead of its output bytes (rb = 1, kept bytes count nothing, a null row 0)
   uint32_t rep[4];
@@ -207,7 +208,7 @@ __global__ void __launch_bounds__(256) k_runs_tile(RunsArgs a) {
         bool in_run = false, dead = false;
         for (int i = 0; i < n; ++i) {
           const uint32_t b = p[i];
-          dead = dead || b == 0;
+          dead = dead || (b == 0 && !a.nul_blind);
           if (b >= 128u && !dead) {
             // a non-ASCII character, decoded as the executor decodes it (regex_vm.h: char_at -- the width from the lead byte, a stray
             // continuation byte a character of its own, a sequence cut at the row's end), all its bytes together: a member by the
@@ -338,6 +339,7 @@ static bool runs_setup(const cs_column* col, const int32_t* d_bits, const std::v
   a.flag_class = (bits[2] & csbits::F_FLAG_CLASS) ? (1 | (((bits[2] >> 16) & 63) << 8) | (((bits[2] >> 22) & 1) << 16)) : 0;
   a.flags = d_unicode_flags();
   a.plus = (bits[2] & csbits::F_PLUS) ? 1 : 0;
+  a.nul_blind = (bits[2] & csbits::F_CHAR_FIRST) ? 1 : 0;
   return true;
 }
 constexpr size_t kRunsBitmapBytes = cstile::kPfBytes / 8 + 32, kRunsPieces = cstile::kPfChunks * 64;

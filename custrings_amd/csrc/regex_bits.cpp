@@ -233,6 +233,7 @@ std::vector<int32_t> build_bits(const Program& prog, const std::vector<int32_t>&
       high = in.type == OP_NCCLASS;
     }
     if (bytewise) fl |= csbits::F_BYTE_CLASS | (high ? csbits::F_HIGH_MEMBER : 0u);
+    if (in.type == OP_CHAR && prog.start_inst == first.items[0].inst) fl |= csbits::F_CHAR_FIRST;
     if (!bytewise && (in.type == OP_CCLASS || in.type == OP_NCCLASS) && in.u1 >= 0 && (size_t)in.u1 < prog.classes.size()) {
       const CharClass& cc = prog.classes[(size_t)in.u1];
       bool ascii_ranges = cc.builtins != 0 && (cc.builtins & ~63) == 0;

@@ -59,7 +59,10 @@ enum { F_WORD = 1, F_BOL = 2, F_EOL = 4, F_BOL_MULTI = 8, F_EOL_MULTI = 16, F_PU
        // class_match), bit 22 the class is negated: cs_runs.hip takes tiles with such bytes row by row, decoding as the reference does
        F_FLAG_CLASS = 1024,
        F_TAIL = 2048,        // assertions behind the trailing `+` loop (the image's last word)
-       F_PURE_TAIL = 4096 };  // ... behind `[set]+` alone (`[^ ]+$`): the matches from the tail's cursors, a step per MATCH
+       F_PURE_TAIL = 4096,  // ... behind `[set]+` alone (`[^ ]+$`): the matches from the tail's cursors, a step per MATCH
+       // the program's first instruction is a literal character: the reference's search for the next start jumps to it by length
+       // (regexec.inl:220-232), over NUL bytes -- a NUL ends nothing for `a` or `a+` (cs_runs.hip)
+       F_CHAR_FIRST = 8192 };
 enum { K_CLASS = 0, K_BOW = 1, K_NBOW = 2, K_BOL = 3, K_EOL = 4, K_BOL_MULTI = 5, K_EOL_MULTI = 6 };
 
 struct View {

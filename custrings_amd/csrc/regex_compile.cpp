@@ -698,6 +698,9 @@ bool class_accepts(const CharClass& c, uint32_t ch, const uint8_t* flags) {
 
 std::vector<int32_t> Program::to_device_image(const uint8_t* flags) const {
   std::vector<int32_t> img = to_blob();
+  // (the reference's starttype CHAR, regexec.inl:220-232: the search for the next start jumps to the program's first
+  // character by length -- over NUL bytes; extras word 0 bit 1 tells the executors' skip to do the same)
+  const bool char_first = start_inst >= 0 && (size_t)start_inst < insts.size() && insts[(size_t)start_inst].type == OP_CHAR;
   const size_t extra = img.size();
   img[7] = (int32_t)extra;
   img.resize(extra + 10 + 4 * classes.size(), 0);
@@ -766,7 +769,7 @@ std::vector<int32_t> Program::to_device_image(const uint8_t* flags) const {
         break;
     }
   }
-  ex[0] = usable ? 1u : 0u;
+  ex[0] = (usable ? 1u : 0u) | (usable && char_first ? 2u : 0u);
   for (int k = 0; k < 4; ++k) ex[1 + k] = first[k];
   ex[5] = nonascii ? 1u : 0u;
   return img;

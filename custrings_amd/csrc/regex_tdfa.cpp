@@ -283,6 +283,19 @@ struct Builder {
       out.tag_e.push_back(q.te);
     }
     out.stop = a.eot || (nk.empty() && out.next.mode == cstd::MODE_NORESTART);
+    // The reference's search for the next start (regexec.inl:220-258): with no thread alive and a program whose FIRST
+    // instruction is a literal character it jumps to that character's next occurrence with custring_view::find -- by length,
+    // over anything in between, NUL bytes too; the loop's `while (c && ...)` never sees them.  A NUL byte met with no thread
+    // alive therefore ends nothing for such a program (count_re('a') of "a\0a" is 2); met by a live thread it ends the call as before.
+    if (a.nul && S.kernel.empty() && S.mode == cstd::MODE_RESTART && out.match < 0 && P.start_inst >= 0 && (size_t)P.start_inst < P.insts.size() &&
+        P.insts[(size_t)P.start_inst].type == OP_CHAR) {
+      out.stop = false;
+      out.next.kernel.clear();
+      out.origins.clear();
+      out.tag_b.clear();
+      out.tag_e.clear();
+      out.next.mode = cstd::MODE_RESTART;
+    }
     return true;
   }
 

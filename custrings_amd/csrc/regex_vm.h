@@ -219,7 +219,7 @@ struct Vm {
           int q = pos;
           while (q < win_end && q < n) {
             uint8_t b = s[q];
-            if (b == 0) break;
+            if (b == 0 && !(P.extra[0] & 2u)) break;  // (bit 1: the first instruction is a literal -- the reference's jump to it passes NUL bytes)
             if (b < 128 ? bm_test(P.extra + 1, b) : (P.extra[5] != 0 && !csrow::is_cont(b))) break;
             ++q;
           }

@@ -648,3 +648,45 @@ def test_gpu_bit_form_with_assertions_behind_the_plus_loop(pat, repl, monkeypatc
         assert int(L.lib.cs_fallback_count()) == f0
     finally:
         L.lib.cs_regex_destroy(re)
+
+
+@pytest.mark.parametrize("switch", [None, "CS_REGEX_ROWWISE", "CS_CLASS_RUNS_ALWAYS", "CS_REGEX_NO_TDFA", "CS_NO_DEFERRED_ROWS"])
+def test_gpu_regex_on_rows_with_nul_bytes(switch, monkeypatch):
+    """Embedded NUL bytes (tests/test_nul_bytes.py: the reference ends a call at a NUL met by a live thread, but its search for the
+    next start of a program whose first instruction is a literal jumps over them): contains_re / count_re / replace_re against
+    the oracle on a column where one row in fifty holds a NUL -- short rows (the mask forms put such rows off / leave them holes)
+    and rows beyond the masks; every executor (the stream kernels' generic scan, the row-wise kernels, cs_runs.hip, the list
+    simulator)."""
+    if switch:
+        monkeypatch.setenv(switch, "1")
+    L = gpuutil.lib()
+    orc = cpulibs.Oracle()
+    rng = np.random.default_rng(4400)
+    for lo, hi in ((0, 60), (20, 200)):
+        rows_b = []
+        for i in range(12_000):
+            n = int(rng.integers(lo, hi + 1))
+            r = bytes(rng.choice(list(b"ab1 a.b  xa"), n).astype(np.uint8))
+            if rng.random() < 0.02 and n >= 3:
+                k = int(rng.integers(0, n))
+                r = r[:k] + b"\x00" + r[k + 1:]
+            rows_b.append(r)
+        rows_b[0] = b"\x00a first window"
+        rows_b[77] = b"a\x00a"
+        rows_b[78] = b"\x00\x00a\x00"
+        col = _with_nulls(rows_b, rng)
+        g = gpuutil.from_col(col)
+        for pat, repl in (("a", "aa"), ("a+", "-"), ("ab", ""), (r"a\d", "<>"), ("[ab]+", "="), (r"\d", "##"), (r"a\b", "A"), ("b a", "_")):
+            blob = blob_of(pat)
+            re = gpuutil.compile_re(pat)
+            try:
+                has, n = gpuutil.bools(g, "cs_contains_re", re)
+                want_has, want_n = orc.contains_re(col, blob)
+                assert np.array_equal(has, want_has) and n == want_n, (pat, switch, last_route())
+                cnt = np.zeros(col.rows, dtype=np.int32)
+                found = C.c_int64()
+                L.check(L.lib.cs_count_re(g.m_cptr, re, cnt.ctypes.data, 0, None, C.byref(found)))
+                assert np.array_equal(cnt, orc.count_re(col, blob)[0]), (pat, switch, last_route())
+            finally:
+                L.lib.cs_regex_destroy(re)
+            gpuutil.assert_same(g.replace(pat, repl), orc.replace_re(col, blob, repl), "replace_re(%r) %s %s" % (pat, switch, last_route()))
