@@ -701,6 +701,8 @@ std::vector<int32_t> Program::to_device_image(const uint8_t* flags) const {
   // (the reference's starttype CHAR, regexec.inl:220-232: the search for the next start jumps to the program's first
   // character by length -- over NUL bytes; extras word 0 bit 1 tells the executors' skip to do the same)
   const bool char_first = start_inst >= 0 && (size_t)start_inst < insts.size() && insts[(size_t)start_inst].type == OP_CHAR;
+  // (starttype BOL with `^`: the jump to the byte behind the next line feed, regexec.inl:233-246 -- extras word 0 bit 2)
+  const bool bol_first = start_inst >= 0 && (size_t)start_inst < insts.size() && insts[(size_t)start_inst].type == OP_BOL && (uint32_t)insts[(size_t)start_inst].u1 == (uint32_t)'^';
   const size_t extra = img.size();
   img[7] = (int32_t)extra;
   img.resize(extra + 10 + 4 * classes.size(), 0);
@@ -769,7 +771,7 @@ std::vector<int32_t> Program::to_device_image(const uint8_t* flags) const {
         break;
     }
   }
-  ex[0] = (usable ? 1u : 0u) | (usable && char_first ? 2u : 0u);
+  ex[0] = (usable ? 1u : 0u) | (usable && char_first ? 2u : 0u) | (bol_first ? 4u : 0u);
   for (int k = 0; k < 4; ++k) ex[1 + k] = first[k];
   ex[5] = nonascii ? 1u : 0u;
   return img;

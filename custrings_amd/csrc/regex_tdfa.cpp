@@ -287,8 +287,14 @@ struct Builder {
     // instruction is a literal character it jumps to that character's next occurrence with custring_view::find -- by length,
     // over anything in between, NUL bytes too; the loop's `while (c && ...)` never sees them.  A NUL byte met with no thread
     // alive therefore ends nothing for such a program (count_re('a') of "a\0a" is 2); met by a live thread it ends the call as before.
-    if (a.nul && S.kernel.empty() && S.mode == cstd::MODE_RESTART && out.match < 0 && P.start_inst >= 0 && (size_t)P.start_inst < P.insts.size() &&
-        P.insts[(size_t)P.start_inst].type == OP_CHAR) {
+    // (a first instruction `^`, multi-line: the jump goes to the byte behind the next line feed at or after the PREVIOUS byte --
+    // unless the call stands at byte 0, where nothing jumps; behind a line feed it lands on the NUL itself, which then ends the call)
+    bool jumps = false;
+    if (P.start_inst >= 0 && (size_t)P.start_inst < P.insts.size()) {
+      const Inst& first = P.insts[(size_t)P.start_inst];
+      jumps = first.type == OP_CHAR || (first.type == OP_BOL && (Char)first.u1 == '^' && !at0 && !pc_nl);
+    }
+    if (a.nul && S.kernel.empty() && S.mode == cstd::MODE_RESTART && out.match < 0 && jumps) {
       out.stop = false;
       out.next.kernel.clear();
       out.origins.clear();

@@ -207,11 +207,26 @@ struct Vm {
     Char pc = char_before(pos);
     Char c = char_at(pos, w);
     Char cn = c ? char_at(pos + (int)w, wn) : 0;
-    const bool prefilter = P.extra[0] != 0;
+    const bool prefilter = (P.extra[0] & 1u) != 0;
+    const bool bol_jump = (P.extra[0] & 4u) != 0;  // (the first instruction is a multi-line `^`)
     int cur = 0;
     begin_list(cur);  // threads that advanced into `pos` (none yet)
     for (;;) {
       if (match == 0 && pos < win_end) {
+        if (cnt == 0 && bol_jump && pos != 0) {
+          // the reference's search for the next start (regexec.inl:233-246): the byte behind the next line feed at or after the
+          // previous byte -- found by length, NUL bytes or not
+          int q = pos - 1;
+          while (q < n && s[q] != '\n') ++q;
+          if (q >= n) break;
+          if (q + 1 != pos) {
+            pos = q + 1;
+            pc = char_before(pos);
+            c = char_at(pos, w);
+            cn = c ? char_at(pos + (int)w, wn) : 0;
+            begin_list(cur);
+          }
+        }
         if (cnt == 0 && prefilter) {
           // no live thread: a start thread can only survive on a character that
           // can begin a match, so skip ahead to the next such character (this

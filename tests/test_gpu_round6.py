@@ -674,9 +674,11 @@ def test_gpu_regex_on_rows_with_nul_bytes(switch, monkeypatch):
         rows_b[0] = b"\x00a first window"
         rows_b[77] = b"a\x00a"
         rows_b[78] = b"\x00\x00a\x00"
+        for k, r in enumerate((b"x\x00\na", b"\x00\na", b"a\x00\na", b"x\n\x00a", b"xa\x00\nab\nab", b"\n\x00\na", b"ab\nab", b"x\nab\n\nab x\x00y\nab")):
+            rows_b[100 + 3 * k] = r
         col = _with_nulls(rows_b, rng)
         g = gpuutil.from_col(col)
-        for pat, repl in (("a", "aa"), ("a+", "-"), ("ab", ""), (r"a\d", "<>"), ("[ab]+", "="), (r"\d", "##"), (r"a\b", "A"), ("b a", "_")):
+        for pat, repl in (("a", "aa"), ("a+", "-"), ("ab", ""), (r"a\d", "<>"), ("[ab]+", "="), (r"\d", "##"), (r"a\b", "A"), ("b a", "_"), ("^a", "<"), (r"^\w", "W"), ("^ab", "")):
             blob = blob_of(pat)
             re = gpuutil.compile_re(pat)
             try:

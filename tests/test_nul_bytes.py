@@ -6,8 +6,11 @@ against the oracle (round 6)."""
 import pytest
 
 ROWS = ["xa\x00a", "a\x00", "\x00a", "b\x00b a", "aéa", "é", "ab\x00", "\x00", "aa\x00aa\x00", "\x00\x00a\x00", "ab\x00ab", "a\x00b ab", "", None,
-        "ab\x00" * 20, "x" * 70 + "\x00" + "ab" * 10, "\x00" * 5 + "a1 a2 a3"]
-PATTERNS = ["a", "a+", "ab", r"a\d", "ab?", "a|b", "(a)b", "[ab]", r"\da", "a$", "^a", r"a\b", "[a]+", r"\w+", "b a", r"a\d a"]
+        "ab\x00" * 20, "x" * 70 + "\x00" + "ab" * 10, "\x00" * 5 + "a1 a2 a3",
+        # (a first instruction `^`, multi-line: the jump to the byte behind the next line feed passes NUL bytes too -- regexec.inl:233-246)
+        "x\x00\na", "\x00\na", "a\x00\na", "x\n\x00a", "xa\x00\nab\nab", "\n\x00\na", "ab\nab", "x\nab\n\nab x\x00y\nab", "\n"]
+PATTERNS = ["a", "a+", "ab", r"a\d", "ab?", "a|b", "(a)b", "[ab]", r"\da", "a$", "^a", r"a\b", "[a]+", r"\w+", "b a", r"a\d a",
+            "^ab", "^a|^b", r"^\w", r"^\w+$", r"^a\b", "^x|^a", r"\Aa"]
 
 
 @pytest.mark.parametrize("engine", [0, 1])
