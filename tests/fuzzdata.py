@@ -1,7 +1,7 @@
 """Seeded random string columns for differential tests (python lists)."""
 import random
 
-ALPHA = list("abcABC xyz_-,.019 \t\n") + ["é", "É", "ß", "İ", "٣", " ", "Σ", "😀", "ａ", "ǅ"]
+ALPHA = list("abcABC xyz_-,.019 \t\n\x00") + ["é", "É", "ß", "İ", "٣", " ", "Σ", "😀", "ａ", "ǅ"]
 
 
 def rows(seed, n, max_len=24, null_p=0.08, empty_p=0.08, alphabet=None):
