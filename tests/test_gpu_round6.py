@@ -570,7 +570,9 @@ def test_gpu_scan_with_more_such_rows_than_the_list_holds():
 
 
 @pytest.mark.parametrize("pat,repl", [(r"\w+@\w+", "<m>"), (r"(\bin\b)|(\ba\b)|(\bthe\b)", "="), (r"\d+\.\d+\.\d+\.\d+", "<IP>"), (r"[a-z]+ing\b", ""),
-                                      (r"#\w+", "<a longer tag>"), (r"\d+", "<number>"), (r"\bthe\b", "THE")])
+                                      (r"#\w+", "<a longer tag>"), (r"\d+", "<number>"), (r"\bthe\b", "THE"),
+                                      # (replacements of 9-16 bytes: the four-register variants of every form)
+                                      (r"\w+@\w+", "<mail-address>"), (r"(\bin\b)|(\ba\b)|(\bthe\b)", "<stop-word>"), (r"\d+\.\d+\.\d+\.\d+", "<ip-address>")])
 def test_gpu_replace_re_leaves_rows_with_high_bytes_holes(pat, repl, monkeypatch):
     """replace_re on a column whose sample holds a FEW bytes >= 0x80 (cs_regex.hip: StreamArgs::hole_mask): the rows that hold
     them (cs_virtual.hip: OddRows -- rows with a NUL too) are sized beforehand and written afterwards, a thread a row; the
