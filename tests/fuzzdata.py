@@ -1,11 +1,15 @@
 """Seeded random string columns for differential tests (python lists)."""
 import random
 
-ALPHA = list("abcABC xyz_-,.019 \t\n\x00") + ["é", "É", "ß", "İ", "٣", " ", "Σ", "😀", "ａ", "ǅ"]
+ALPHA = list("abcABC xyz_-,.019 \t\n") + ["é", "É", "ß", "İ", "٣", " ", "Σ", "😀", "ａ", "ǅ"]
 
 
-def rows(seed, n, max_len=24, null_p=0.08, empty_p=0.08, alphabet=None):
+def rows(seed, n, max_len=24, null_p=0.08, empty_p=0.08, alphabet=None, nul_p=0.1):
+    """(`nul_p`: the share of rows in which one character is a NUL byte -- the reference's strings are counted, not terminated,
+    and its regex executor treats the byte in two ways: tests/test_nul_bytes.py.  Drawn from a generator of its own, so that the
+    rows without one are the rows of earlier rounds.)"""
     rnd = random.Random(seed)
+    rnd0 = random.Random(seed * 7919 + 13)
     alphabet = alphabet or ALPHA
     out = []
     for _ in range(n):
@@ -15,7 +19,10 @@ def rows(seed, n, max_len=24, null_p=0.08, empty_p=0.08, alphabet=None):
         elif u < null_p + empty_p:
             out.append("")
         else:
-            out.append("".join(rnd.choice(alphabet) for _ in range(rnd.randint(1, max_len))))
+            r = [rnd.choice(alphabet) for _ in range(rnd.randint(1, max_len))]
+            if rnd0.random() < nul_p:
+                r[rnd0.randrange(len(r))] = "\x00"
+            out.append("".join(r))
     return out
 
 

@@ -60,7 +60,7 @@ def rows_for_fuzz(seed):
         if rnd.random() < 0.3:
             s = s.strip()
         out.append(s[: rnd.choice([95, 95, 96, 120, 40])])
-    out += fuzzdata.rows(seed + 1, 300, max_len=97, alphabet=list("aeinth  .,\n_xyGETPU#01c"))
+    out += fuzzdata.rows(seed + 1, 300, max_len=97, alphabet=list("aeinth  .,\n_xyGETPU#01c\x00"))
     out += fuzzdata.log_rows(seed + 2, 200)
     out += ["", None, "a", "in", "the", " a ", "a a a a", "in the a", "thea", "a" * 95, "a " * 47 + "a", "a " * 48, "x" * 94 + "a", "x" * 93 + " a", "the" * 31 + "xx",
             "naïve a in", "in\x00a", "é a", "aeiou" * 19, "b" * 95, "ua" * 47, "colourcolorcolouur", "ing\ning", "GET x\nPUT y", "PUTGET", "#a#b ##c", "x123 x1 x12"]
@@ -105,7 +105,7 @@ def test_generated_alternations_vs_oracle(emu_engine, oracle_engine):
         if e.bits(pat) is None:
             continue
         done += 1
-        s = fuzzdata.rows(done, 120, max_len=96, alphabet=list("aabbc  1_\n.")) + ["", "a", "ab", "abc", "a b c", "a" * 95, "ab " * 31]
+        s = fuzzdata.rows(done, 120, max_len=96, alphabet=list("aabbc  1_\n.\x00")) + ["", "a", "ab", "abc", "a b c", "a" * 95, "ab " * 31]
         e.set_bits(1)
         try:
             assert emu_engine.contains_re(s, pat) == oracle_engine.contains_re(s, pat), pat
