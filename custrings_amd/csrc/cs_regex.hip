@@ -2700,6 +2700,18 @@ __global__ void __launch_bounds__(256, MODE == 4 ? ((CHAIN && !IN_LDS) ? 4 : 3) 
             const int t = __any(live && k > c) ? wave_reduce_sum(live ? cl[c] : 0) : 0;
             if (lane == 0) a.tile_tot[(long long)c * a.nsub + tile] = t;
           }
+        // (columns beyond the fourth -- rows with many matches, `[a-z]+` on log lines: eighteen --: no registers kept their lengths;
+        // every lane reads its own spans back, just written, and the wave adds them up.  The exact-width pass then leaves packed
+        // spans and tile totals like the provisional one, where it used to write begins / lens for a scan over the lengths of
+        // every column: findall([a-z]+) on the C3 column 31.8 ms)
+        for (int c = 4; c < a.ncols; ++c) {
+          int t = 0;
+          if (__any(live && k > c)) {  // (wave-uniform)
+            const uint32_t w = (live && k > c) ? a.spans[(long long)c * in.rows + r0 + lane] : 0u;
+            t = wave_reduce_sum((int)(w & 0xFFFFu));
+          }
+          if (lane == 0) a.tile_tot[(long long)c * a.nsub + tile] = t;
+        }
       }
       if (MODE == 3 && a.maxp) {
         int m = live ? k : 0;
@@ -4138,7 +4150,7 @@ int cs_findall(const cs_column* col, const cs_regex* cre, cs_stream stream, cs_c
         for (int pass = 0; pass < 2; ++pass) {
           // (the provisional pass on 64-row tiles leaves packed spans and tile totals: k_spans_write_tile2 needs no pass
           // over the lengths; a second pass -- rows with more than kProvisional matches -- writes begins / lens)
-          packed = pass == 0 && tc.R == 64 && !cs::cfg("CS_SPANS_UNPACKED");
+          packed = tc.R == 64 && width <= kMaxGroups && (pass == 0 || !cs::cfg("CS_SPANS_EXACT_UNPACKED")) && !cs::cfg("CS_SPANS_UNPACKED");
           if (packed) {
             spans = dev_alloc(sizeof(uint32_t) * rows * width, s);
             tile_tot = dev_alloc(sizeof(int32_t) * ((rows + 63) / 64) * width, s);
