@@ -694,3 +694,29 @@ def test_gpu_regex_on_rows_with_nul_bytes(switch, monkeypatch):
             finally:
                 L.lib.cs_regex_destroy(re)
             gpuutil.assert_same(g.replace(pat, repl), orc.replace_re(col, blob, repl), "replace_re(%r) %s %s" % (pat, switch, last_route()))
+
+
+def test_gpu_put_off_rows_on_a_column_with_int32_offsets():
+    """A split's output column (int32 offsets, nulls where a row had fewer tokens) with a few tokens that hold a two-byte character:
+    contains_re / count_re put those rows off, replace_re leaves them holes -- against the oracle on the oracle's own split."""
+    L = gpuutil.lib()
+    orc = cpulibs.Oracle()
+    rng = np.random.default_rng(4500)
+    rows_b = _mostly_ascii_rows(rng, 60_000, 0.03, lo=10, hi=90)
+    rows_b[0] = "é in the first window".encode()
+    col = _with_nulls(rows_b, rng)
+    g = gpuutil.from_col(col)
+    gcols = g.split(" ", 3)
+    ocols = orc.split(col, " ", 3)
+    assert len(gcols) == len(ocols)
+    for gc, oc in zip(gcols, ocols):
+        for pat, repl in ((r"[a-z]+ing\b", "-"), (r"\d+", "<n>"), (r"(\bin\b)|(\ba\b)|(\bthe\b)", "=")):
+            blob = blob_of(pat)
+            re = gpuutil.compile_re(pat)
+            try:
+                has, n = gpuutil.bools(gc, "cs_contains_re", re)
+                want_has, want_n = orc.contains_re(oc, blob)
+                assert np.array_equal(has, want_has) and n == want_n, (pat, last_route())
+            finally:
+                L.lib.cs_regex_destroy(re)
+            gpuutil.assert_same(gc.replace(pat, repl), orc.replace_re(oc, blob, repl), "replace_re(%r) %s" % (pat, last_route()))
