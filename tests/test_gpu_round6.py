@@ -720,3 +720,15 @@ def test_gpu_put_off_rows_on_a_column_with_int32_offsets():
             finally:
                 L.lib.cs_regex_destroy(re)
             gpuutil.assert_same(gc.replace(pat, repl), orc.replace_re(oc, blob, repl), "replace_re(%r) %s" % (pat, last_route()))
+
+
+def test_gpu_generated_patterns_against_the_oracle():
+    """A slice of tools/fuzz_patterns_gpu.py: sixty generated patterns (alternations, classes, counted items, assertions, `+` tails)
+    on columns of ASCII text with a few rows of two-byte characters and NUL bytes -- contains_re, count_re, replace_re against the
+    oracle (1359 patterns, 0 mismatches in the round's long run)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("fuzz_patterns_gpu", os.path.join(ROOT, "tools", "fuzz_patterns_gpu.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    done, bad = mod.run(120.0, 606, max_patterns=60)
+    assert done == 60 and bad == 0
