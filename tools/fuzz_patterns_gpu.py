@@ -92,6 +92,28 @@ def run(budget, seed, max_patterns=1 << 30):
                 if not np.array_equal(cnt, orc.count_re(c, blob)[0]):
                     bad += 1
                     print("MISMATCH count_re %r column %d route %s" % (pat, ci, r2), flush=True)
+                try:  # the span ops: findall always, extract / replace_with_backrefs where the pattern has groups
+                    got_cols = [gpuutil.to_col(x) for x in g.findall(pat)]
+                    want_cols = orc.findall(c, blob)
+                    if len(got_cols) != len(want_cols) or not all(a.same_as(b) for a, b in zip(got_cols, want_cols)):
+                        bad += 1
+                        print("MISMATCH findall %r column %d route %s (%d / %d columns)" % (pat, ci, L.lib.cs_debug_last_route().decode(), len(got_cols), len(want_cols)), flush=True)
+                    if "(" in pat:
+                        got_cols = [gpuutil.to_col(x) for x in g.extract(pat)]
+                        want_cols = orc.extract(c, blob)
+                        if len(got_cols) != len(want_cols) or not all(a.same_as(b) for a, b in zip(got_cols, want_cols)):
+                            bad += 1
+                            print("MISMATCH extract %r column %d route %s" % (pat, ci, L.lib.cs_debug_last_route().decode()), flush=True)
+                        try:
+                            got = gpuutil.to_col(g.replace_with_backrefs(pat, r"<\1|\0>"))
+                        except Exception:
+                            got = None  # (refused: a pattern that matches the empty string)
+                        if got is not None and not got.same_as(orc.replace_with_backrefs(c, blob, r"<\1|\0>")):
+                            bad += 1
+                            print("MISMATCH backrefs %r column %d route %s" % (pat, ci, L.lib.cs_debug_last_route().decode()), flush=True)
+                except Exception as e:
+                    print("EXCEPTION span ops %r: %s" % (pat, e), flush=True)
+                    bad += 1
                 for repl in ("<>", ""):
                     try:
                         got = g.replace(pat, repl)
