@@ -460,7 +460,19 @@ __global__ void __launch_bounds__(256) k_tdfa_scan(RowSrc src, TLaunch L, uint8_
   long long t = block_reduce_sum(hits);
   if (threadIdx.x == 0 && t) atomicAdd(found, (unsigned long long)t);
 }
-// the rows a stream launch put off (ScanStreamArgs::deferred): a thread a row, the generic executor on the row's bytes in memory
+// A row of the list kernels in LDS: the aligned 16-byte pieces that cover it (rows within the masks: seven at most), copied by
+// the row's own thread -- the generic executor then walks LDS bytes instead of a chain of dependent loads from memory
+// (k_tdfa_replace_list on the C5 pieces: 0.38 ms a launch from memory).  Returns the row's first byte; a longer row stays in memory.
+constexpr int kListRowBytes = 112;
+// (the pieces must lie inside the chars buffer -- [lo, hi): a caller's memory wrapped at an odd address has no slack around it)
+__device__ __forceinline__ const uint8_t* list_row_to_lds(const uint8_t* src, int n, uint8_t* buf, const uint8_t* lo, const uint8_t* hi) {
+  const int sh = (int)((uintptr_t)src & 15);
+  if (sh + n > kListRowBytes || src - sh < lo || src - sh + ((sh + n + 15) & ~15) > hi) return src;
+  const uint4* a = reinterpret_cast<const uint4*>(src - sh);
+  for (int k = 0; k * 16 < sh + n; ++k) *reinterpret_cast<uint4*>(buf + 16 * k) = a[k];
+  return buf + sh;
+}
+// the rows a stream launch put off (ScanStreamArgs::deferred): a thread a row, the generic executor on the row's bytes (staged in LDS)
 template <int MODE>
 __global__ void __launch_bounds__(256) k_tdfa_scan_list(RowSrc src, TLaunch L, const int32_t* __restrict__ list, const unsigned* __restrict__ nlist, unsigned cap,
                                                         uint8_t* __restrict__ out8, int32_t* __restrict__ out32, unsigned long long* __restrict__ found) {
@@ -473,8 +485,11 @@ __global__ void __launch_bounds__(256) k_tdfa_scan_list(RowSrc src, TLaunch L, c
   for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
     const int64_t r = list[i];
     const int64_t b = in.offsets[r];
-    cstd::Tdfa vm(c.D, c.P, in.chars + b, (int)(in.offsets[r + 1] - b));
-    vm.wide_ok = (b & ~(int64_t)3) + cstd::Tdfa::kMaskBytes <= src.safe_end;
+    const int n = (int)(in.offsets[r + 1] - b);
+    uint8_t* buf = reinterpret_cast<uint8_t*>(smem) + (((size_t)L.tdfa_words * 4 + 15) & ~(size_t)15) + (size_t)threadIdx.x * kListRowBytes;
+    const uint8_t* p = list_row_to_lds(in.chars + b, n, buf, in.chars, in.chars + src.safe_end);
+    cstd::Tdfa vm(c.D, c.P, p, n);
+    vm.wide_ok = p != in.chars + b || (b & ~(int64_t)3) + cstd::Tdfa::kMaskBytes <= src.safe_end;
     const int v = MODE == 2 ? csvm::row_count_re(vm) : csvm::row_contains_re(vm, false);
     if (MODE == 2) out32[r] = v;
     else out8[r] = (uint8_t)v;
@@ -546,9 +561,10 @@ __global__ void __launch_bounds__(256) k_tdfa_replace_list(RowSrc src, TLaunch L
     if (!row_is_valid(in.validity, r)) continue;  // (a null row over bytes of the chars: no hole was left for it)
     const int64_t b = in.offsets[r];
     const int n = (int)(in.offsets[r + 1] - b);
-    const uint8_t* p = in.chars + b;
+    uint8_t* buf = reinterpret_cast<uint8_t*>(smem) + (((size_t)L.tdfa_words * 4 + 15) & ~(size_t)15) + (size_t)threadIdx.x * kListRowBytes;
+    const uint8_t* p = list_row_to_lds(in.chars + b, n, buf, in.chars, in.chars + src.safe_end);
     cstd::Tdfa vm(c.D, c.P, p, n);
-    vm.wide_ok = (b & ~(int64_t)3) + cstd::Tdfa::kMaskBytes <= src.safe_end;
+    vm.wide_ok = p != in.chars + b || (b & ~(int64_t)3) + cstd::Tdfa::kMaskBytes <= src.safe_end;
     if (!WRITE) {
       int len = n;
       csvm::row_replace_matches(vm, -1, [&](int mb, int me, int reps) { len += reps * rb - (me - mb); });
@@ -3152,10 +3168,11 @@ void scan(const cs_column* col, cs_regex* re, uint8_t* out8, int32_t* out32, int
       if (put_off) {
         note_route_put_off();
         const unsigned lgrid = (unsigned)std::min<int64_t>(((int64_t)sa.deferred_cap + 255) / 256, 2048);
-        if (tp.lds_bytes > 48 * 1024)
-          CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tdfa_scan_list<MODE == 2 ? 2 : 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tp.lds_bytes));
+        const size_t list_lds = tp.lds_bytes + (size_t)256 * kListRowBytes;  // (the tables and a row a thread)
+        if (list_lds > 48 * 1024)
+          CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tdfa_scan_list<MODE == 2 ? 2 : 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)list_lds));
         ProfScope ps("k_tdfa_scan_list", s);
-        hipLaunchKernelGGL((k_tdfa_scan_list<MODE == 2 ? 2 : 0>), dim3(lgrid), dim3(256), tp.lds_bytes, s, src, tp.d, ptr<const int32_t>(later), ptr<const unsigned>(nlater),
+        hipLaunchKernelGGL((k_tdfa_scan_list<MODE == 2 ? 2 : 0>), dim3(lgrid), dim3(256), list_lds, s, src, tp.d, ptr<const int32_t>(later), ptr<const unsigned>(nlater),
                            sa.deferred_cap, out8, out32, ptr<unsigned long long>(cnt));
         // (more such rows than the sample promised and the list holds: the column is scanned again with nothing put off)
         unsigned* hn = (unsigned*)pinned_scratch(sizeof(unsigned));
@@ -3571,15 +3588,16 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
         const OddRows* od = holes_ok && !literal && !brefs ? odd_rows(col, s) : nullptr;
         const bool with_holes = od && od->count > 0;
         const unsigned hole_grid = with_holes ? (unsigned)std::min<int64_t>((od->count + 255) / 256, 2048) : 0;
+        const size_t list_lds = tp.lds_bytes + (size_t)256 * kListRowBytes;  // (the tables and a row a thread)
         if (with_holes) {
-          if (tp.lds_bytes > 48 * 1024) {
-            CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tdfa_replace_list<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tp.lds_bytes));
-            CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tdfa_replace_list<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)tp.lds_bytes));
+          if (list_lds > 48 * 1024) {
+            CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tdfa_replace_list<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)list_lds));
+            CS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tdfa_replace_list<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)list_lds));
           }
           if (!hole_lens) {
             hole_lens = dev_alloc(sizeof(int32_t) * (size_t)od->count, s);
             ProfScope ps("k_tdfa_replace_list", s);
-            hipLaunchKernelGGL(k_tdfa_replace_list<false>, dim3(hole_grid), dim3(256), tp.lds_bytes, s, src, tp.d, ptr<const int32_t>(od->list), od->count, ptr<const uint8_t>(d_repl), rb,
+            hipLaunchKernelGGL(k_tdfa_replace_list<false>, dim3(hole_grid), dim3(256), list_lds, s, src, tp.d, ptr<const int32_t>(od->list), od->count, ptr<const uint8_t>(d_repl), rb,
                                ptr<int32_t>(hole_lens), (const int64_t*)nullptr, (uint8_t*)nullptr);
             CS_HIP(hipGetLastError());
           }
@@ -3714,7 +3732,7 @@ int cs_replace_re(const cs_column* col, const cs_regex* cre, const char* repl, i
         }
         if (err == 0 && with_holes) {  // the holes' bytes
           ProfScope ps("k_tdfa_replace_list", s);
-          hipLaunchKernelGGL(k_tdfa_replace_list<true>, dim3(hole_grid), dim3(256), tp.lds_bytes, s, src, tp.d, ptr<const int32_t>(od->list), od->count, ptr<const uint8_t>(d_repl), rb,
+          hipLaunchKernelGGL(k_tdfa_replace_list<true>, dim3(hole_grid), dim3(256), list_lds, s, src, tp.d, ptr<const int32_t>(od->list), od->count, ptr<const uint8_t>(d_repl), rb,
                              (int32_t*)nullptr, ptr<const int64_t>(out_off), ptr<uint8_t>(out_chars));
           CS_HIP(hipGetLastError());
           CS_HIP(hipStreamSynchronize(s));
