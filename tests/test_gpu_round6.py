@@ -732,3 +732,17 @@ def test_gpu_generated_patterns_against_the_oracle():
     spec.loader.exec_module(mod)
     done, bad = mod.run(120.0, 606, max_patterns=60)
     assert done == 60 and bad == 0
+
+
+def test_gpu_random_arguments_of_the_other_ops_against_the_oracle():
+    """A slice of tools/fuzz_ops_gpu.py: random delimiters and limits for split / rsplit, character sets for strip, needles and
+    replacements for the literal replace, delimiter sets for tokenize -- on columns with a few two-byte characters and NUL bytes,
+    against the oracle (10 328 rounds, 0 mismatches in the round's long run)."""
+    import importlib.util
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    spec = importlib.util.spec_from_file_location("fuzz_ops_gpu", os.path.join(ROOT, "tools", "fuzz_ops_gpu.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    done, bad = mod.run(120.0, 707, max_rounds=150)
+    assert done == 150 and bad == 0
